@@ -1,0 +1,288 @@
+"""
+oracle/demux_oracle.py -- TEST INFRASTRUCTURE ONLY.
+
+CPU restatement (numpy) of the reference's Demultiplexer EM hot path.  Only
+`tests/`, `__graft_entry__.smoke()` and the `cpu_baseline` leg of `bench.py`
+may import this module; nothing under `demuxalot_amd/` does.
+
+Every function names the reference lines (relative to /root/reference) whose
+arithmetic it restates.  The dtype ladder (float32 element-wise work, float64
+bincount accumulation, one float32 rounding) is kept operation for operation so
+that, on the numpy build the fixtures were captured with, logits are
+bit-identical to the reference's.  Pinned by tests/test_oracle_golden.py against
+the fixtures under tests/golden/ (captured from the imported reference by
+tests/golden/make_fixtures.py).
+
+Plain-array conventions used here (and in the fixtures):
+  calls:      list of per-chromosome dicts, in the reference dict's iteration
+              order, each {'chrom': str, 'mol_cb': i32[m], 'call_mol': i32[c],
+              'call_pos': i32[c], 'call_base': u8[c], 'call_p': f32[c]}
+  genotypes:  'var_chrom' (list[str]), 'var_pos' (int array), 'var_base'
+              (u8 array, A/C/G/T/N = 0..4), listed in var2varid insertion order,
+              'var_row' (the variant index each key maps to), 'betas' f32[V,G],
+              'default_prior' float
+"""
+import ctypes
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_npsimd = None
+
+
+def load_npsimd():
+    """ctypes handle on oracle/libnpsimd.so (built by oracle/Makefile)."""
+    global _npsimd
+    if _npsimd is None:
+        lib = ctypes.CDLL(os.path.join(_HERE, 'libnpsimd.so'))
+        lib.npsimd_logf.restype = ctypes.c_float
+        lib.npsimd_logf.argtypes = [ctypes.c_float]
+        lib.npsimd_expf.restype = ctypes.c_float
+        lib.npsimd_expf.argtypes = [ctypes.c_float]
+        lib.npsimd_sum_f32.restype = ctypes.c_float
+        lib.npsimd_sum_f32.argtypes = [ctypes.c_void_p, ctypes.c_long]
+        for name in ('npsimd_log_array', 'npsimd_exp_array'):
+            getattr(lib, name).restype = None
+            getattr(lib, name).argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_long]
+        for name in ('npsimd_rowsum_f32', 'npsimd_softmax_rows'):
+            getattr(lib, name).restype = None
+            getattr(lib, name).argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_long, ctypes.c_long]
+        _npsimd = lib
+    return _npsimd
+
+
+def _c_unary(name, x):
+    x = np.ascontiguousarray(x, dtype=np.float32)
+    out = np.empty_like(x)
+    getattr(load_npsimd(), name)(x.ctypes.data, out.ctypes.data, x.size)
+    return out
+
+
+def log_f32(x, impl='numpy'):
+    """float32 natural log: numpy's own kernel or its C restatement (oracle/npsimd.c)."""
+    if impl == 'numpy':
+        return np.log(x)
+    return _c_unary('npsimd_log_array', x)
+
+
+def softmax_rows(logits, impl='numpy'):
+    """scipy.special.softmax(x, axis=-1) on float32 (reference demux.py:101,152):
+    max, exp(x - max), sum over the row, divide -- all float32."""
+    logits = np.ascontiguousarray(logits, dtype=np.float32)
+    if impl == 'numpy':
+        top = np.amax(logits, axis=-1, keepdims=True)
+        shifted = np.exp(logits - top)
+        return shifted / np.sum(shifted, axis=-1, keepdims=True)
+    out = np.empty_like(logits)
+    load_npsimd().npsimd_softmax_rows(logits.ctypes.data, out.ctypes.data, logits.shape[0], logits.shape[1])
+    return out
+
+
+# --------------------------------------------------------------------------- #
+# options and penalties
+# --------------------------------------------------------------------------- #
+
+def doublet_penalties(n_genotypes, doublet_prior):
+    """reference demux.py:158-173: zero for singlets, a constant log-odds bonus for
+    every pair so that the prior doublet mass does not depend on G."""
+    assert 0 <= doublet_prior < 1
+    if doublet_prior == 0:
+        return np.zeros(n_genotypes, dtype='float32')
+    n_pairs_norm = n_genotypes * max(n_genotypes - 1, 1) / 2
+    bonus = np.log(n_genotypes * doublet_prior) - np.log(n_pairs_norm * (1 - doublet_prior))
+    pen = np.zeros(n_genotypes * (n_genotypes + 1) // 2, dtype='float32')
+    pen[n_genotypes:] = bonus
+    return pen
+
+
+def option_pairs(n_genotypes, doublet_prior):
+    """reference demux.py:175-191: singlets (g, g) first, then pairs g1 < g2 row-major."""
+    first = list(range(n_genotypes))
+    second = list(range(n_genotypes))
+    if doublet_prior != 0:
+        for g1 in range(n_genotypes):
+            for g2 in range(g1 + 1, n_genotypes):
+                first.append(g1)
+                second.append(g2)
+    return np.asarray(first, dtype=np.int32), np.asarray(second, dtype=np.int32)
+
+
+def option_names(genotype_names, doublet_prior):
+    """column names, reference demux.py:180,190."""
+    g1, g2 = option_pairs(len(genotype_names), doublet_prior)
+    return [genotype_names[a] if a == b else f'{genotype_names[a]}+{genotype_names[b]}' for a, b in zip(g1, g2)]
+
+
+# --------------------------------------------------------------------------- #
+# pack: molecule calls -> unique (variant, barcode) calls + regularised betas
+# --------------------------------------------------------------------------- #
+
+def snp_ids_for_variants(var_chrom, var_pos, var_row):
+    """reference genotypes.py:56-66: SNP ids in first-seen order of the var2varid keys."""
+    seen = {}
+    out = np.full(len(var_row), -1, dtype='int32')
+    for chrom, pos, row in zip(var_chrom, var_pos, var_row):
+        out[row] = seen.setdefault((chrom, int(pos)), len(seen))
+    assert (out >= 0).all()
+    return out
+
+
+def match_calls_to_variants(calls, var_chrom, var_pos, var_base, var_row):
+    """reference demux.py:332-363: per chromosome, exact (position, base) lookup of each
+    molecule call among that chromosome's variants; unmatched calls are dropped.
+    Returns variant_id, compressed_cb, p_base_wrong of the surviving molecule calls,
+    in the reference's order (chromosome order of the dict, then call order)."""
+    var_chrom = np.asarray(var_chrom, dtype=object)
+    var_pos = np.asarray(var_pos, dtype=np.int64)
+    var_base = np.asarray(var_base, dtype=np.int64)
+    var_row = np.asarray(var_row, dtype=np.int32)
+    out_v, out_cb, out_p = [], [], []
+    n_expected = sum(len(c['call_pos']) for c in calls)
+    n_seen = 0
+    for c in calls:
+        sel = np.nonzero(var_chrom == c['chrom'])[0]
+        if len(sel) == 0:
+            # reference demux.py:339-341 skips without advancing -> assert at :359 fires
+            continue
+        key = var_pos[sel] * 8 + var_base[sel]
+        order = np.argsort(key, kind='stable')
+        key_sorted = key[order]
+        rows_sorted = var_row[sel][order]
+        q = c['call_pos'].astype(np.int64) * 8 + c['call_base'].astype(np.int64)
+        at = np.searchsorted(key_sorted, q).clip(0, len(key_sorted) - 1)
+        vid = np.where(key_sorted[at] == q, rows_sorted[at], -1).astype(np.int32)
+        out_v.append(vid)
+        out_cb.append(c['mol_cb'][c['call_mol']].astype(np.int32))
+        out_p.append(c['call_p'].astype(np.float32))
+        n_seen += len(q)
+    assert n_seen == n_expected  # reference demux.py:359
+    if not out_v:
+        z = np.zeros(0, dtype=np.int32)
+        return z, z.copy(), np.zeros(0, dtype=np.float32)
+    vid = np.concatenate(out_v)
+    keep = vid != -1
+    return vid[keep], np.concatenate(out_cb)[keep], np.concatenate(out_p)[keep]
+
+
+def dedupe_calls(mol_variant, mol_cb, mol_p):
+    """reference demux.py:276-300: unique (variant, barcode) pairs sorted by variant
+    then barcode; p_base_wrong of a pair = float32 product of its members taken in
+    molecule-call order (np.multiply.at semantics: sequential, starting from 1)."""
+    key = mol_variant.astype(np.int64) * (1 << 32) + mol_cb.astype(np.int64)
+    order = np.argsort(key, kind='stable')
+    ks = key[order]
+    if len(ks) == 0:
+        z = np.zeros(0, dtype=np.int32)
+        return z, z.copy(), np.zeros(0, dtype=np.float32), np.zeros(0, dtype=np.int64)
+    starts = np.flatnonzero(np.concatenate([[True], ks[1:] != ks[:-1]]))
+    p = np.ones(len(starts), dtype=np.float32)
+    inverse = np.empty(len(ks), dtype=np.int64)
+    inverse[order] = np.repeat(np.arange(len(starts)), np.diff(np.concatenate([starts, [len(ks)]])))
+    np.multiply.at(p, inverse, mol_p)
+    counts = np.diff(np.concatenate([starts, [len(ks)]]))
+    return (mol_variant[order][starts].astype(np.int32), mol_cb[order][starts].astype(np.int32),
+            p, counts.astype(np.int64))
+
+
+def prior_betas(betas, v2snp, mol_variant, default_prior, add_data_prior):
+    """reference demux.py:367-388: beta' = beta + f32((1 + [data] n_mol/(sum_snp n_mol + 100)
+    + betasum/(sum_snp betasum + 100)) * default_prior)[:, None]."""
+    assert np.all(betas >= 0), 'bad genotypes provided, negative betas appeared'
+
+    def over_snp(per_variant, reg):
+        per_snp = np.bincount(v2snp, weights=per_variant)[v2snp]
+        return per_variant / (per_snp + reg)
+
+    scale = 1.
+    if add_data_prior:
+        n_mol = np.bincount(mol_variant, minlength=len(v2snp))
+        scale = scale + over_snp(n_mol, 100.)
+    scale = scale + over_snp(betas.sum(axis=1), 100.)
+    add = scale[:, np.newaxis] * default_prior
+    out = betas + add.astype(betas.dtype)
+    out.flags.writeable = False
+    return out
+
+
+def pack(calls, geno, add_data_prior):
+    """reference demux.py:303-392 on plain arrays. Returns a dict with v2snp, prior betas and
+    the de-duplicated calls (variant-major COO: variant_id, compressed_cb, p_base_wrong)."""
+    v2snp = snp_ids_for_variants(geno['var_chrom'], geno['var_pos'], geno['var_row'])
+    mv, mcb, mp = match_calls_to_variants(calls, geno['var_chrom'], geno['var_pos'], geno['var_base'], geno['var_row'])
+    v, cb, p, counts = dedupe_calls(mv, mcb, mp)
+    betas = prior_betas(np.asarray(geno['betas'], dtype=np.float32), v2snp, mv, geno['default_prior'], add_data_prior)
+    return dict(v2snp=v2snp, betas=betas, variant_id=v, compressed_cb=cb, p_base_wrong=p,
+                barcode_variant_count=counts, mol_variant=mv, mol_cb=mcb, mol_p=mp)
+
+
+# --------------------------------------------------------------------------- #
+# P / E / M steps
+# --------------------------------------------------------------------------- #
+
+def probs_from_betas(v2snp, betas, p_clip):
+    """reference demux.py:267-274: per genotype, beta / max(sum of beta over the SNP's
+    variants, 1e-7) in float64, stored float32, clipped to [p, 1-p]."""
+    out = np.zeros(betas.shape, dtype='float32')
+    for g in range(betas.shape[1]):
+        col = betas[:, g]
+        den = np.bincount(v2snp, weights=col)[v2snp]
+        out[:, g] = col / den.clip(1e-7)
+    return out.clip(p_clip, 1 - p_clip)
+
+
+def barcode_logits(variant_id, compressed_cb, p_base_wrong, prob, n_barcodes, doublet_prior, log_impl='numpy'):
+    """reference demux.py:246-265 (+ :35-36 of utils.py for the float64 bincount):
+    logit[b,k] = f32(pen[k] + sum_c f64(log(p_k[v_c]*(1-e_c) + max(e_c,1e-4))))."""
+    n_genotypes = prob.shape[1]
+    pen = doublet_penalties(n_genotypes, doublet_prior)
+    g1, g2 = option_pairs(n_genotypes, doublet_prior)
+    logits = np.zeros([n_barcodes, 1], dtype='float32') + pen
+    keep = 1 - p_base_wrong
+    floor = p_base_wrong.clip(1e-4)
+    for k, (a, b) in enumerate(zip(g1, g2)):
+        col = prob[:, a] if a == b else (prob[:, a] + prob[:, b]) * 0.5
+        terms = log_f32(col[variant_id] * keep + floor, impl=log_impl)
+        logits[:, k] = logits[:, k] + np.bincount(compressed_cb, weights=terms, minlength=n_barcodes)
+    return logits
+
+
+def beta_addition(variant_id, compressed_cb, p_base_wrong, post, n_variants, n_genotypes, power=2.):
+    """reference demux.py:113-118: add[v,g] = f32(sum_c f64((post[cb_c,g]*(1-e_c))**power)),
+    singlet columns only."""
+    add = np.zeros([n_variants, n_genotypes], dtype='float32')
+    keep = 1 - p_base_wrong
+    for g in range(n_genotypes):
+        w = post[compressed_cb, g] * keep
+        w **= power
+        add[:, g] = add[:, g] + np.bincount(variant_id, weights=w, minlength=n_variants)
+    return add
+
+
+def em(packed, n_barcodes, n_iterations, p_clip, doublet_prior, prior_logits=None, power=2., impl='numpy'):
+    """reference demux.py:86-118: EM loop. Returns per-iteration records
+    (logits, probs, addition used in that iteration's E-step)."""
+    v, cb, e = packed['variant_id'], packed['compressed_cb'], packed['p_base_wrong']
+    betas, v2snp = packed['betas'], packed['v2snp']
+    n_variants, n_genotypes = betas.shape
+    addition = np.zeros_like(betas)
+    history = []
+    for it in range(n_iterations):
+        prob = probs_from_betas(v2snp, betas + addition, p_clip)
+        logits = barcode_logits(v, cb, e, prob, n_barcodes, doublet_prior, log_impl=impl)
+        if it == 0 and prior_logits is not None:
+            assert prior_logits.shape == logits.shape, 'mismatching priors passed'
+            logits += prior_logits
+        post = softmax_rows(logits, impl=impl)
+        history.append(dict(logits=logits, probs=post, addition=addition, prob_table=prob))
+        addition = beta_addition(v, cb, e, post, n_variants, n_genotypes, power=power)
+    return history
+
+
+def predict(packed, n_barcodes, p_clip, doublet_prior, impl='numpy'):
+    """reference demux.py:120-156 without the DataFrame wrapping."""
+    prob = probs_from_betas(packed['v2snp'], packed['betas'], p_clip)
+    assert np.isfinite(prob).all()
+    logits = barcode_logits(packed['variant_id'], packed['compressed_cb'], packed['p_base_wrong'], prob,
+                            n_barcodes, doublet_prior, log_impl=impl)
+    return logits, softmax_rows(logits, impl=impl), prob

@@ -1,0 +1,22 @@
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+
+def pytest_configure(config):
+    config.addinivalue_line('markers', 'gpu: needs a real MI355X (run with -m gpu on the GPU box)')
+
+
+@pytest.fixture(scope='session')
+def oracle():
+    """The CPU oracle (test infrastructure). Builds oracle/libnpsimd.so on first use."""
+    import subprocess
+    subprocess.check_call(['make', '-s', '-C', os.path.join(ROOT, 'oracle')])
+    from oracle import demux_oracle
+    demux_oracle.load_npsimd()
+    return demux_oracle

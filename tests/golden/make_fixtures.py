@@ -1,0 +1,414 @@
+"""
+tests/golden/make_fixtures.py -- regenerates the golden vectors under tests/golden/.
+
+Runs ONLY in the build container, where the reference lives at /root/reference:
+it imports the reference's own `demuxalot` package (pure Python) and captures the
+inputs and outputs of `Demultiplexer.pack_calls`, `predict_posteriors` and
+`staged_genotype_learning` / `learn_genotypes` as plain arrays.  Nothing of the
+reference's source travels: the fixtures are data (inputs + expected outputs).
+
+`pysam` (htslib bindings) is not installed here and is only needed by the
+reference's BAM front-end, so an in-memory stand-in module is registered before
+the import.  It implements just the surface the reference's synthetic test
+(tests/test_synthetic.py:106-145) and `count_snps` touch, so that the F1/F2
+inputs are produced by the reference's own generator and BAM scanner.
+
+    python tests/golden/make_fixtures.py            # writes tests/golden/*.npz
+"""
+import importlib.util
+import os
+import sys
+import types
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+REFERENCE = '/root/reference'
+
+
+# --------------------------------------------------------------------------- #
+# in-memory pysam stand-in
+# --------------------------------------------------------------------------- #
+
+def _install_pysam_standin():
+    mod = types.ModuleType('pysam')
+    store = {}  # filename -> {'header': dict, 'reads': list}
+
+    class AlignedSegment:
+        def __init__(self):
+            self.query_name = None
+            self.query_sequence = None
+            self.flag = 0
+            self.reference_id = -1
+            self.reference_start = 0
+            self.mapping_quality = 0
+            self.cigar = ()
+            self.template_length = 0
+            self.query_qualities = None
+            self.tags = ()
+
+        @property
+        def seq(self):
+            return self.query_sequence
+
+        @property
+        def pos(self):
+            return self.reference_start
+
+        @property
+        def mapq(self):
+            return self.mapping_quality
+
+        @property
+        def cigartuples(self):
+            return list(self.cigar)
+
+        @property
+        def reference_end(self):
+            return self.reference_start + sum(n for op, n in self.cigar if op in (0, 2, 3, 7, 8))
+
+        def has_tag(self, name):
+            return any(t[0] == name for t in self.tags)
+
+        def get_tag(self, name):
+            for t in self.tags:
+                if t[0] == name:
+                    return t[1]
+            raise KeyError(name)
+
+    class _Stat:
+        def __init__(self, contig, mapped):
+            self.contig, self.mapped = contig, mapped
+
+    class AlignmentFile:
+        def __init__(self, filename, mode='rb', header=None):
+            self.filename = str(filename)
+            self.mode = mode
+            if 'w' in mode:
+                store[self.filename] = {'header': header, 'reads': []}
+            self._data = store[self.filename]
+
+        def __enter__(self):
+            return self
+
+        def __exit__(self, *a):
+            return False
+
+        def close(self):
+            pass
+
+        def write(self, read):
+            self._data['reads'].append(read)
+
+        def _names(self):
+            return [sq['SN'] for sq in self._data['header']['SQ']]
+
+        def get_reference_length(self, chrom):
+            return {sq['SN']: sq['LN'] for sq in self._data['header']['SQ']}[chrom]
+
+        def get_index_statistics(self):
+            names = self._names()
+            counts = {n: 0 for n in names}
+            for r in self._data['reads']:
+                counts[names[r.reference_id]] += 1
+            return [_Stat(n, counts[n]) for n in names]
+
+        def fetch(self, contig=None, start=None, stop=None):
+            rid = self._names().index(contig)
+            for r in self._data['reads']:
+                if r.reference_id != rid:
+                    continue
+                if start is not None and r.reference_end <= start:
+                    continue
+                if stop is not None and r.reference_start >= stop:
+                    continue
+                yield r
+
+    def sort(*args):
+        assert args[0] == '-o'
+        out, src = args[1], args[2]
+        reads = sorted(store[src]['reads'], key=lambda r: (r.reference_id, r.reference_start))  # stable
+        store[out] = {'header': store[src]['header'], 'reads': reads}
+
+    def index(filename):
+        return None
+
+    def qualitystring_to_array(s):
+        return np.frombuffer(s.encode(), dtype=np.uint8).astype(np.int64) - 33
+
+    mod.AlignedSegment = AlignedSegment
+    mod.AlignedRead = AlignedSegment
+    mod.AlignmentFile = AlignmentFile
+    mod.VariantFile = type('VariantFile', (), {})
+    mod.sort = sort
+    mod.index = index
+    mod.qualitystring_to_array = qualitystring_to_array
+    sys.modules['pysam'] = mod
+    return mod
+
+
+def import_reference():
+    """Imports the reference package and its synthetic-test module (container only)."""
+    if 'pysam' not in sys.modules:
+        _install_pysam_standin()
+    if REFERENCE not in sys.path:
+        sys.path.insert(0, REFERENCE)
+    import demuxalot  # noqa: the reference
+    assert demuxalot.__file__.startswith(REFERENCE), demuxalot.__file__
+    spec = importlib.util.spec_from_file_location('ref_test_synthetic', f'{REFERENCE}/tests/test_synthetic.py')
+    ref_tests = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(ref_tests)
+    return demuxalot, ref_tests
+
+
+# --------------------------------------------------------------------------- #
+# plain-array views of the reference's objects
+# --------------------------------------------------------------------------- #
+BASES = {'A': 0, 'C': 1, 'G': 2, 'T': 3, 'N': 4}
+
+
+def inputs_as_arrays(calls, genotypes, barcode_handler):
+    out = {}
+    chroms = list(calls)
+    out['chroms'] = np.asarray(chroms, dtype=str)
+    for i, chrom in enumerate(chroms):
+        c = calls[chrom]
+        mol = c.molecules[:c.n_molecules]
+        sc = c.snp_calls[:c.n_snp_calls]
+        out[f'c{i}_mol_cb'] = mol['compressed_cb'].copy()
+        out[f'c{i}_mol_ub'] = mol['compressed_ub'].copy()
+        out[f'c{i}_mol_pmis'] = mol['p_group_misaligned'].copy()
+        out[f'c{i}_call_mol'] = sc['molecule_index'].copy()
+        out[f'c{i}_call_pos'] = sc['snp_position'].copy()
+        out[f'c{i}_call_base'] = sc['base_index'].copy()
+        out[f'c{i}_call_p'] = sc['p_base_wrong'].copy()
+    keys = list(genotypes.var2varid.items())
+    out['var_chrom'] = np.asarray([k[0] for k, _ in keys], dtype=str)
+    out['var_pos'] = np.asarray([k[1] for k, _ in keys], dtype=np.int64)
+    out['var_base'] = np.asarray([BASES[k[2]] for k, _ in keys], dtype=np.uint8)
+    out['var_row'] = np.asarray([row for _, row in keys], dtype=np.int32)
+    out['betas'] = np.array(genotypes.variant_betas[:genotypes.n_variants], dtype=np.float32)
+    out['genotype_names'] = np.asarray(genotypes.genotype_names, dtype=str)
+    out['default_prior'] = np.float64(genotypes.default_prior)
+    out['barcodes'] = np.asarray(barcode_handler.ordered_barcodes, dtype=str)
+    return out
+
+
+def capture(ref, calls, genotypes, barcode_handler, predict_dps=(0., 0.35), em_runs=()):
+    """Runs the reference and records everything the parity tests compare."""
+    D = ref.Demultiplexer
+    out = inputs_as_arrays(calls, genotypes, barcode_handler)
+    for flag in (False, True):
+        v2snp, betas, mol_calls, bc = D.pack_calls(calls, genotypes, add_data_prior=flag)
+        tag = f'pack{int(flag)}'
+        out[f'{tag}_betas'] = np.array(betas)
+        if not flag:
+            out['pack_v2snp'] = v2snp
+            out['pack_n_molecule_calls'] = np.int64(len(mol_calls))
+            out['pack_bc_variant_id'] = np.array(bc['variant_id'])
+            out['pack_bc_snp_id'] = np.array(bc['snp_id'])
+            out['pack_bc_cb'] = np.array(bc['compressed_cb'])
+            out['pack_bc_p'] = np.array(bc['p_base_wrong'])
+            out['pack_bc_variant_count'] = np.array(bc['barcode_variant_count'])
+            out['pack_bc_snp_count'] = np.array(bc['barcode_snp_count'])
+    for i, spec in enumerate(predict_dps):
+        dp, clip = spec if isinstance(spec, tuple) else (spec, 0.01)
+        logits, probs = D.predict_posteriors(calls, genotypes, barcode_handler,
+                                             p_genotype_clip=clip, doublet_prior=dp)
+        assert logits.index.name == 'BARCODE' and list(logits.index) == list(barcode_handler.ordered_barcodes)
+        out[f'predict{i}_dp'] = np.float64(dp)
+        out[f'predict{i}_clip'] = np.float64(clip)
+        out[f'predict{i}_logits'] = logits.values
+        out[f'predict{i}_probs'] = probs.values
+        out[f'predict{i}_columns'] = np.asarray(list(logits.columns), dtype=str)
+    out['n_predict'] = np.int64(len(predict_dps))
+    for i, run in enumerate(em_runs):
+        kwargs = dict(n_iterations=run.get('n_iterations', 5), p_genotype_clip=run.get('clip', 0.01),
+                      doublet_prior=run.get('dp', 0.))
+        prior = run.get('prior_logits')
+        stages = list(D.staged_genotype_learning(calls, genotypes, barcode_handler,
+                                                 barcode_prior_logits=None if prior is None else prior.copy(),
+                                                 **kwargs))
+        for it, (probs_df, dbg) in enumerate(stages):
+            out[f'em{i}_it{it}_logits'] = np.array(dbg['barcode_logits'])
+            out[f'em{i}_it{it}_probs'] = probs_df.values.copy()
+            out[f'em{i}_it{it}_addition'] = np.array(dbg['genotype_addition'])
+        learnt, last_probs = D.learn_genotypes(calls, genotypes, barcode_handler,
+                                               barcode_prior_logits=None if prior is None else prior.copy(),
+                                               **kwargs)
+        assert last_probs.index.name is None
+        assert np.array_equal(last_probs.values, stages[-1][0].values)
+        out[f'em{i}_learnt_betas'] = np.array(learnt.variant_betas)
+        out[f'em{i}_columns'] = np.asarray(list(last_probs.columns), dtype=str)
+        out[f'em{i}_n_iterations'] = np.int64(kwargs['n_iterations'])
+        out[f'em{i}_clip'] = np.float64(kwargs['p_genotype_clip'])
+        out[f'em{i}_dp'] = np.float64(kwargs['doublet_prior'])
+        if prior is not None:
+            out[f'em{i}_prior_logits'] = prior
+    out['n_em'] = np.int64(len(em_runs))
+    return out
+
+
+def save(name, arrays):
+    path = os.path.join(HERE, name)
+    np.savez_compressed(path, **arrays)
+    print(f'{name}: {os.path.getsize(path) / 1e6:.2f} MB, {len(arrays)} arrays')
+
+
+# --------------------------------------------------------------------------- #
+# fixture families
+# --------------------------------------------------------------------------- #
+
+def synthetic_bam_case(ref, ref_tests, **gen_kwargs):
+    """The reference's own test inputs: generate_bam_file (tests/test_synthetic.py:106-145,
+    seed 42 as in :160) scanned by the reference's count_snps (single process)."""
+    np.random.seed(42)
+    filename, genotypes, _ids, bc2names = ref_tests.generate_bam_file(filename='/tmp/golden_fixture.bam', **gen_kwargs)
+    handler = ref.BarcodeHandler(list(bc2names))
+    calls = ref.count_snps(filename, chromosome2positions=genotypes.get_chromosome2positions(),
+                           barcode_handler=handler, joblib_n_jobs=1, joblib_verbosity=0)
+    return calls, genotypes, handler, bc2names
+
+
+def build_calls(ref, per_chrom):
+    """per_chrom: {chrom: (mol_cb list, [(mol_index, pos, base_index, p), ...])}"""
+    from demuxalot.snp_counter import CompressedSNPCalls
+    calls = {}
+    for chrom, (mol_cb, rows) in per_chrom.items():
+        cc = CompressedSNPCalls()
+        cc.molecules = np.zeros(len(mol_cb), dtype=cc.molecules.dtype)
+        cc.molecules['compressed_cb'] = mol_cb
+        cc.molecules['compressed_ub'] = np.arange(len(mol_cb))
+        cc.molecules['p_group_misaligned'] = 0.01
+        cc.snp_calls = np.zeros(len(rows), dtype=cc.snp_calls.dtype)
+        for j, (m, pos, base, p) in enumerate(rows):
+            cc.snp_calls[j] = (m, pos, base, p)
+        cc.n_molecules, cc.n_snp_calls = len(mol_cb), len(rows)
+        calls[chrom] = cc
+    return calls
+
+
+def random_small_case(ref, rng, n_genotypes, n_barcodes, n_snps, n_molecules, calls_per_mol=3,
+                      zero_beta_genotype=False, multiallelic=True, unmatched=True):
+    """Hand-sized random problem exercising the edge cases listed in SURVEY 8c/F3: duplicated
+    (variant, barcode) molecules, a tri-allelic SNP, unmatched calls (wrong base / unknown
+    position), a barcode without calls, tiny p_base_wrong products, an all-zero genotype column."""
+    names = [f'D{i:02d}' for i in range(n_genotypes)]
+    g = ref.ProbabilisticGenotypes(names)
+    chroms = ['chrA', 'chrB']
+    var2varid = {}
+    snps = []
+    for s in range(n_snps):
+        chrom = chroms[s % 2]
+        pos = 10 + 7 * s
+        n_alleles = 3 if (multiallelic and s % 5 == 0) else 2
+        bases = list(rng.choice(4, size=n_alleles, replace=False))
+        snps.append((chrom, pos, bases))
+    order = rng.permutation(sum(len(b) for _, _, b in snps))  # scrambled variant rows
+    flat = [(chrom, pos, b) for chrom, pos, bases in snps for b in bases]
+    for slot in order:
+        chrom, pos, b = flat[slot]
+        var2varid[(chrom, pos, 'ACGT'[b])] = len(var2varid)
+    g.var2varid = var2varid
+    betas = rng.choice([0.5, 50., 100.], size=(len(var2varid), n_genotypes)).astype('float32')
+    betas *= rng.uniform(0.5, 1.5, size=betas.shape).astype('float32')
+    if zero_beta_genotype:
+        betas[:, -1] = 0
+    g.variant_betas = betas
+    barcodes = [f'BC{i:04d}-1' for i in range(n_barcodes)]
+    handler = ref.BarcodeHandler(barcodes)
+    per_chrom = {}
+    for chrom in chroms:
+        chrom_snps = [s for s in snps if s[0] == chrom]
+        mol_cb = rng.integers(0, n_barcodes - 1, size=n_molecules)  # last barcode never observed
+        rows = []
+        for m in range(n_molecules):
+            for _ in range(calls_per_mol):
+                _c, pos, bases = chrom_snps[rng.integers(len(chrom_snps))]
+                roll = rng.random()
+                if unmatched and roll < 0.05:
+                    base = [b for b in range(4) if b not in bases][0]  # base not among the variants
+                elif unmatched and roll < 0.08:
+                    pos, base = pos + 1, 0  # position that is not a SNP
+                else:
+                    base = bases[rng.integers(len(bases))]
+                q = rng.integers(5, 41)
+                p = np.float32(0.1 ** (0.1 * q))
+                if rng.random() < 0.1:
+                    p = np.float32(p * 1e-30)  # products that run towards FLT_MIN
+                rows.append((m, pos, base, p))
+        # molecules of one barcode hitting the same variant repeatedly
+        for rep in range(6):
+            _c, pos, bases = chrom_snps[0]
+            rows.append((0, pos, bases[0], np.float32(0.05 + 0.01 * rep)))
+        per_chrom[chrom] = (mol_cb, rows)
+    return build_calls(ref, per_chrom), g, handler
+
+
+def main():
+    ref, ref_tests = import_reference()
+    rng = np.random.default_rng(20240607)
+
+    # F4: doublet penalties (reference demux.py:158-173; pinned by tests/test_utils.py:34-40)
+    f4 = {}
+    for G in (2, 3, 10, 20, 64, 128):
+        for dp in (0., 0.25, 0.35, 0.5):
+            f4[f'G{G}_dp{dp}'] = ref.Demultiplexer._doublet_penalties(G, dp)
+    save('f4_doublet_penalties.npz', f4)
+
+    # F3: hand-sized edge cases
+    cases = [
+        dict(n_genotypes=2, n_barcodes=6, n_snps=5, n_molecules=12),
+        dict(n_genotypes=3, n_barcodes=17, n_snps=11, n_molecules=40, zero_beta_genotype=True),
+        dict(n_genotypes=5, n_barcodes=40, n_snps=23, n_molecules=150),
+        dict(n_genotypes=9, n_barcodes=33, n_snps=30, n_molecules=200, calls_per_mol=5),
+        dict(n_genotypes=70, n_barcodes=24, n_snps=40, n_molecules=300, calls_per_mol=4),
+    ]
+    for i, kw in enumerate(cases):
+        calls, g, handler = random_small_case(ref, rng, **kw)
+        G, B = g.n_genotypes, handler.n_barcodes
+        K2 = G * (G + 1) // 2
+        prior_s = (rng.normal(size=(B, G)) * 3).astype('float32')
+        prior_d = (rng.normal(size=(B, K2)) * 3).astype('float32')
+        arrays = capture(
+            ref, calls, g, handler,
+            predict_dps=(0., 0.35, (0.2, 0.05), (0., 0.)),
+            em_runs=(dict(n_iterations=4, dp=0.), dict(n_iterations=3, dp=0.25, clip=0.02),
+                     dict(n_iterations=3, dp=0., prior_logits=prior_s),
+                     dict(n_iterations=2, dp=0.4, prior_logits=prior_d)),
+        )
+        save(f'f3_small_{i}.npz', arrays)
+
+    # F2: reduced reference synthetic test (closest to BASELINE.json configs[0] wording)
+    calls, g, handler, _ = synthetic_bam_case(ref, ref_tests, n_genotypes=4, n_barcodes=200, mutation_prob=0.12)
+    arrays = capture(ref, calls, g, handler, predict_dps=(0., 0.35),
+                     em_runs=(dict(n_iterations=5, dp=0.), dict(n_iterations=3, dp=0.25)))
+    print('F2: G', g.n_genotypes, 'V', g.n_variants, 'B', handler.n_barcodes,
+          'M', int(arrays['pack_n_molecule_calls']), 'N', len(arrays['pack_bc_cb']))
+    save('f2_synthetic_g4.npz', arrays)
+
+    # F1: the reference's test_synthetic defaults (tests/test_synthetic.py:106-115,160)
+    calls, g, handler, bc2names = synthetic_bam_case(ref, ref_tests)
+    B, G = handler.n_barcodes, g.n_genotypes
+    # the labelled-barcodes scenario of tests/test_synthetic.py:200-239 (+100 on known singlets)
+    prior = np.zeros((B, G), dtype='float32')
+    label_p = rng.random(B)
+    for (bc, donors), p in zip(bc2names.items(), label_p):
+        if len(donors) == 1 and p < 0.2:
+            prior[handler.barcode2index[bc], g.genotype_names.index(donors[0])] += 100.
+    empty = g.clone()
+    empty.variant_betas[:] = 0
+    arrays = capture(ref, calls, g, handler, predict_dps=(0., 0.25, 0.35),
+                     em_runs=(dict(n_iterations=5, dp=0.), dict(n_iterations=2, dp=0.25)))
+    print('F1: G', G, 'V', g.n_variants, 'S', int(arrays['pack_v2snp'].max()) + 1, 'B', B,
+          'M', int(arrays['pack_n_molecule_calls']), 'N', len(arrays['pack_bc_cb']))
+    save('f1_synthetic_default.npz', arrays)
+    # same calls, empty genotypes + prior logits: only outputs are stored (inputs = F1's)
+    arr2 = capture(ref, calls, empty, handler, predict_dps=(),
+                   em_runs=(dict(n_iterations=5, dp=0., prior_logits=prior),))
+    keep = {k: v for k, v in arr2.items() if k.startswith(('em', 'n_em', 'pack1', 'pack0'))}
+    save('f1_from_assignment.npz', keep)
+
+
+if __name__ == '__main__':
+    main()
