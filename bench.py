@@ -1,0 +1,198 @@
+#!/usr/bin/env python
+"""bench.py -- EM-iteration throughput of the Demultiplexer hot path on MI355X.
+
+    python bench.py --gpus 1 --steps 10 --warmup 2
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+           --master-port P bench.py --gpus N --steps K --warmup W
+
+One "step" = one EM iteration of learn_genotypes on device-resident inputs: P-step (beta ->
+probability), E-step + softmax, M-step (+ RCCL all-reduce of the beta addition when N > 1).
+Workload (BASELINE.json metric): 200k barcodes x 100k SNPs x 64 genotypes per GPU, synthetic
+(demuxalot_amd/synth.py).  With N GPUs every rank owns its own 200k-barcode shard
+of an N x 200k-barcode experiment (weak scaling); the genotype tables are replicated and the
+per-rank beta additions are all-reduced every iteration.
+
+Prints ONE JSON line on rank 0 (contract in the task statement) with `roofline` (E-step kernel,
+HIP-event timed on the stream it runs on) and `cpu_baseline` (the numpy oracle, one core, on a
+bounded barcode sub-sample; rank 0, N = 1 only).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+WORKLOADS = {
+    # name: (barcodes per GPU, SNPs, genotypes, doublet_prior, generator seed)
+    'em_200k_100k_64': (200_000, 100_000, 64, 0.0, 1237),   # BASELINE.json metric / configs[3] shape
+    'em_200k_100k_32': (200_000, 100_000, 32, 0.0, 1236),   # configs[2]
+    'predict_20k_20k_8': (20_000, 20_000, 8, 0.35, 1235),   # configs[1]
+    'em_20k_10k_64': (20_000, 10_000, 64, 0.0, 77),         # quick check
+}
+
+
+def algorithmic_bytes(B, V, G, K, N):
+    """compulsory HBM bytes, every input read once and every output written once."""
+    e = 8 * N + 8 * (B + 1) + 4 * V * G + 8 * B * K      # calls (variant, p_wrong), row_ptr (int64), prob table, logits + posteriors
+    m = 8 * N + 8 * (V + 1) + 4 * B * G + 4 * V * G      # calls (cb, p_wrong), col_ptr, singlet posteriors, addition
+    p = 12 * V * G + 4 * V                               # prior + addition in, prob out, v2snp
+    return dict(estep=e, mstep=m, pstep=p, iteration=e + m + p)
+
+
+def cpu_baseline(problem, betas, doublet_prior, target_seconds=20.0):
+    """The numpy oracle (same passes as the reference: K column passes + bincount; G passes for the
+    M-step) on one core, on the first barcodes of the workload; size picked for ~10-30 s."""
+    from oracle import demux_oracle
+    G = problem.n_genotypes
+    K = G if doublet_prior == 0 else G * (G + 1) // 2
+    per_call_option = 22e-9  # SURVEY.md section 6 probe: 18-29 ns per call x option, E and M each
+    calls_budget = target_seconds / (per_call_option * (K + G))
+    mean_row = problem.n_calls / problem.n_barcodes
+    n_sample = int(max(200, min(problem.n_barcodes, calls_budget / mean_row)))
+    v, cb, e = problem.subset_barcodes(0, n_sample)
+    t0 = time.perf_counter()
+    prob = demux_oracle.probs_from_betas(problem.v2snp, betas, 0.01)
+    logits = demux_oracle.barcode_logits(v, cb, e, prob, n_sample, doublet_prior)
+    post = demux_oracle.softmax_rows(logits)
+    demux_oracle.beta_addition(v, cb, e, post, problem.n_variants, G)
+    dt = time.perf_counter() - t0
+    return dict(value=n_sample / dt, unit='barcodes/s', cores=1, kind='port',
+                sample=f'first {n_sample} barcodes ({len(v)} calls) of the workload, full V and G, '
+                       f'one EM iteration in {dt:.1f} s, numpy single-threaded like the reference',
+                host_cores=os.cpu_count()), logits, post, n_sample
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=10)
+    ap.add_argument('--warmup', type=int, default=2)
+    ap.add_argument('--workload', default='em_200k_100k_64', choices=sorted(WORKLOADS))
+    ap.add_argument('--reduce-dtype', default='f64', choices=['f64', 'f32'])
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    args = ap.parse_args()
+
+    rank = int(os.environ.get('RANK', '0'))
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    assert world == args.gpus, f'--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run'
+
+    dist = None
+    if world > 1:
+        # control plane only (rendezvous, barrier, max-reduce of the wall time) over gloo;
+        # the data-plane collective is RCCL inside libdemux_hip.so
+        import torch.distributed as dist
+        dist.init_process_group('gloo', rank=rank, world_size=world)
+
+    from demuxalot_amd import Demultiplexer, synth
+    from demuxalot_amd.device import DeviceContext
+
+    B, S, G, dp, seed = WORKLOADS[args.workload]
+    t_gen = time.perf_counter()
+    problem = synth.generate(B, S, G, doublets=dp > 0, seed=seed, seed_calls=seed * 1000 + rank)
+    betas = problem.prior_betas(add_data_prior=False)  # identical on every rank
+    t_gen = time.perf_counter() - t_gen
+    V, N = problem.n_variants, problem.n_calls
+    pen = Demultiplexer._doublet_penalties(G, dp)
+    K = len(pen)
+
+    ctx = DeviceContext(local_rank)
+    t_up = time.perf_counter()
+    ctx.set_problem(B, V, G, problem.variant_id, problem.compressed_cb, problem.p_base_wrong, problem.v2snp)
+    ctx.set_betas(betas)
+    t_up = time.perf_counter() - t_up
+    if world > 1:
+        ids = [DeviceContext.new_unique_id() if rank == 0 else None]
+        dist.broadcast_object_list(ids, src=0)
+        ctx.comm_init(rank, world, ids[0], reduce_dtype=args.reduce_dtype)
+
+    # first pass fixes the options and gives the outputs used for the sanity check below
+    ctx.set_addition(None)
+    ctx.probs_from_betas(0.01, fetch=False)
+    logits0, probs0 = ctx.estep(pen, with_doublets=dp > 0)
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+
+    ctx.run_iterations(args.warmup, 0.01)
+    ctx.synchronize()
+    ctx.reset_timings()
+    barrier()
+    ctx.synchronize()
+    t0 = time.perf_counter()
+    ctx.run_iterations(args.steps, 0.01)
+    ctx.synchronize()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        import torch
+        t = torch.tensor([elapsed], dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t[0])
+    timers = ctx.timings()
+
+    # predict_posteriors throughput on the same resident problem (P + E only), rank-local
+    ctx.synchronize()
+    t1 = time.perf_counter()
+    n_pred = max(3, args.steps // 2)
+    for _ in range(n_pred):
+        ctx.probs_from_betas(0.01, fetch=False)
+        ctx.estep(pen, with_doublets=dp > 0, fetch_logits=False, fetch_probs=False)
+    predict_s = (time.perf_counter() - t1) / n_pred
+
+    if rank == 0:
+        ab = algorithmic_bytes(B, V, G, K, N)
+        e_ms = timers['estep']['ms'] / max(1, timers['estep']['launches'])
+        m_ms = timers['mstep']['ms'] / max(1, timers['mstep']['launches'])
+        achieved = ab['estep'] / (e_ms * 1e-3) / 1e9
+        out = {
+            'metric': 'barcodes/s through one EM iteration (P-step + E-step + softmax + M-step) of learn_genotypes, '
+                      f'{B // 1000}k barcodes x {S // 1000}k SNPs x {G} genotypes per GPU',
+            'value': world * B * args.steps / elapsed,
+            'unit': 'barcodes/s',
+            'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
+            'ms_per_step': 1e3 * elapsed / args.steps,
+            'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
+            'dtype': 'f32 terms, f64 accumulate', 'data': 'synthetic',
+            'config': {'workload': args.workload, 'barcodes_per_gpu': B, 'snps': S, 'variants': V, 'genotypes': G,
+                       'options': K, 'calls_per_gpu': N, 'doublet_prior': dp,
+                       'parallelism': f'barcode shards x{world}' + (f', RCCL all-reduce {args.reduce_dtype}' if world > 1 else '')},
+            'em_iterations_per_s': args.steps / elapsed,
+            'predict_barcodes_per_s': world * B / predict_s,
+            'kernel_ms': {k: (v['ms'] / max(1, v['launches'])) for k, v in timers.items()},
+            'roofline': {'bound': 'hbm', 'kernel': 'k_estep_direct', 'achieved': achieved, 'peak': 8000.0, 'unit': 'GB/s',
+                         'frac': achieved / 8000.0, 'traffic': None,
+                         'algorithmic_bytes_per_launch': ab['estep'],
+                         'iteration_bytes': ab['iteration'],
+                         'iteration_frac': ab['iteration'] / (1e-3 * (e_ms + m_ms + timers['pstep']['ms'] / max(1, timers['pstep']['launches']) + timers['mcombine']['ms'] / max(1, timers['mcombine']['launches']))) / 1e9 / 8000.0,
+                         'log_terms_per_s': N * K / (e_ms * 1e-3),
+                         'note': 'E-step is VALU-bound (N*K float32 log terms evaluated with numpy-exact rounding), see DESIGN.md'},
+            'setup_s': {'generate': t_gen, 'upload': t_up},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            base, ref_logits, ref_post, n_s = cpu_baseline(problem, betas, dp)
+            out['cpu_baseline'] = base
+            out['cpu_baseline']['speedup_vs_gpu_value'] = out['value'] / base['value']
+            # sanity: the GPU rows of the sampled barcodes equal the oracle's
+            out['parity_on_sample'] = {
+                'argmax_identical': bool(np.array_equal(ref_post.argmax(1), probs0[:n_s].argmax(1))),
+                'max_abs_posterior_diff': float(np.abs(ref_post - probs0[:n_s]).max()),
+                'logits_bitwise_equal': bool(np.array_equal(ref_logits.view(np.uint32), logits0[:n_s].view(np.uint32))),
+            }
+        else:
+            out['cpu_baseline'] = None
+        print(json.dumps(out))
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

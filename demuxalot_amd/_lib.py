@@ -1,0 +1,99 @@
+"""ctypes binding of libdemux_hip.so (C ABI: include/demux_hip.h).
+
+There is no CPU fallback: if the shared library is missing, or no MI355X is visible when a
+device context is requested, the calls raise.  Host-only entry points (dmx_pack_calls_host)
+work without a GPU.
+"""
+import ctypes
+import os
+from ctypes import POINTER, c_char_p, c_double, c_float, c_int, c_int32, c_int64, c_void_p
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, 'libdemux_hip.so')
+
+DMX_F32, DMX_F64 = 0, 1
+T_PSTEP, T_ESTEP, T_MSTEP, T_MCOMBINE, T_ALLREDUCE, T_COUNT = 0, 1, 2, 3, 4, 5
+TIMER_NAMES = ('pstep', 'estep', 'mstep', 'mcombine', 'allreduce')
+UNIQUE_ID_BYTES = 128
+
+# every symbol include/demux_hip.h declares: (restype, argtypes)
+_P = c_void_p
+SIGNATURES = {
+    'dmx_last_error': (c_char_p, []),
+    'dmx_version': (c_char_p, []),
+    'dmx_device_count': (c_int, [POINTER(c_int)]),
+    'dmx_create': (c_int, [c_int, POINTER(_P)]),
+    'dmx_destroy': (c_int, [_P]),
+    'dmx_synchronize': (c_int, [_P]),
+    'dmx_pack_calls_host': (c_int, [c_int64, _P, _P, _P, c_int64, _P, _P, _P, _P, _P, _P,
+                                    POINTER(c_int64), POINTER(c_int64), _P, _P, _P, _P, _P]),
+    'dmx_set_problem': (c_int, [_P, c_int64, c_int64, c_int32, c_int64, _P, _P, _P, _P]),
+    'dmx_set_betas': (c_int, [_P, _P]),
+    'dmx_set_addition': (c_int, [_P, _P]),
+    'dmx_probs_from_betas': (c_int, [_P, c_float, c_float, _P]),
+    'dmx_set_probs': (c_int, [_P, _P]),
+    'dmx_estep': (c_int, [_P, c_int, _P, _P, c_int, _P, _P]),
+    'dmx_mstep': (c_int, [_P, c_float, _P]),
+    'dmx_em': (c_int, [_P, c_int, c_float, c_float, c_int, _P, _P, c_int, c_float, _P, _P, _P]),
+    'dmx_run_iterations': (c_int, [_P, c_int, c_float, c_float, c_float]),
+    'dmx_get_logits': (c_int, [_P, _P]),
+    'dmx_get_probs': (c_int, [_P, _P]),
+    'dmx_get_addition': (c_int, [_P, _P]),
+    'dmx_get_assignments': (c_int, [_P, _P, _P]),
+    'dmx_comm_unique_id': (c_int, [_P]),
+    'dmx_comm_init': (c_int, [_P, c_int, c_int, _P, c_int]),
+    'dmx_get_timings': (c_int, [_P, POINTER(c_double), POINTER(c_int64)]),
+    'dmx_reset_timings': (c_int, [_P]),
+    'dmx_device_bytes': (c_int, [_P, POINTER(c_int64)]),
+    'dmx_test_logf': (c_int, [_P, _P, _P, c_int64]),
+    'dmx_test_expf': (c_int, [_P, _P, _P, c_int64]),
+    'dmx_test_softmax': (c_int, [_P, _P, _P, c_int64, c_int64]),
+}
+
+_lib = None
+
+
+class DemuxHipError(RuntimeError):
+    pass
+
+
+def load():
+    """Loads libdemux_hip.so; raises (loudly) when it has not been built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise DemuxHipError(
+                f'{LIB_PATH} is missing: build it with `python -c "import __graft_entry__ as g; g.build()"` '
+                f'or `make -C demuxalot_amd/csrc`. demuxalot_amd has no CPU fallback.')
+        lib = ctypes.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(lib, name)
+            fn.restype = res
+            fn.argtypes = args
+        _lib = lib
+    return _lib
+
+
+def check(status):
+    if status != 0:
+        raise DemuxHipError(f'libdemux_hip: {load().dmx_last_error().decode()} (status {status})')
+
+
+def ptr(a):
+    """void* of a C-contiguous numpy array (None -> NULL)."""
+    if a is None:
+        return None
+    assert a.flags.c_contiguous
+    return a.ctypes.data
+
+
+def as_c(a, dtype):
+    return np.ascontiguousarray(a, dtype=dtype)
+
+
+def device_count():
+    n = c_int(0)
+    status = load().dmx_device_count(ctypes.byref(n))
+    return n.value if status == 0 else 0

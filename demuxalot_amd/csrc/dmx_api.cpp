@@ -1,0 +1,817 @@
+// dmx_api.cpp -- C ABI of libdemux_hip.so (include/demux_hip.h): context, device memory,
+// problem upload (CSR/CSC derivation), step drivers, RCCL all-reduce, timing.
+#include <dlfcn.h>
+#include <hip/hip_runtime.h>
+#include <rccl/rccl.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "dmx_internal.h"
+#include "kernels.h"
+
+// ------------------------------------------------------------------------------------
+// error handling
+// ------------------------------------------------------------------------------------
+namespace dmx {
+static thread_local std::string g_last_error;
+
+int fail(int code, const char *fmt, ...)
+{
+    char buf[1024];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    g_last_error = buf;
+    return code;
+}
+}  // namespace dmx
+
+using dmx::fail;
+
+#define HIP_TRY(expr)                                                                                   \
+    do {                                                                                                \
+        hipError_t _e = (expr);                                                                         \
+        if (_e != hipSuccess) return fail(DMX_ERR_HIP, "%s failed: %s", #expr, hipGetErrorString(_e)); \
+    } while (0)
+
+#define DMX_TRY(expr)         \
+    do {                      \
+        int _s = (expr);      \
+        if (_s != 0) return _s; \
+    } while (0)
+
+// ------------------------------------------------------------------------------------
+// RCCL, loaded on demand so that single-GPU use has no dependency on it
+// ------------------------------------------------------------------------------------
+namespace {
+struct RcclApi {
+    void *handle = nullptr;
+    ncclResult_t (*GetUniqueId)(ncclUniqueId *) = nullptr;
+    ncclResult_t (*CommInitRank)(ncclComm_t *, int, ncclUniqueId, int) = nullptr;
+    ncclResult_t (*AllReduce)(const void *, void *, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+    const char *(*GetErrorString)(ncclResult_t) = nullptr;
+};
+RcclApi g_rccl;
+
+int load_rccl()
+{
+    if (g_rccl.handle) return 0;
+    const char *names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+    void *h = nullptr;
+    for (const char *n : names) {
+        h = dlopen(n, RTLD_NOW | RTLD_GLOBAL);
+        if (h) break;
+    }
+    if (!h) return fail(DMX_ERR_RCCL, "cannot load librccl: %s", dlerror());
+    g_rccl.GetUniqueId = (decltype(g_rccl.GetUniqueId))dlsym(h, "ncclGetUniqueId");
+    g_rccl.CommInitRank = (decltype(g_rccl.CommInitRank))dlsym(h, "ncclCommInitRank");
+    g_rccl.AllReduce = (decltype(g_rccl.AllReduce))dlsym(h, "ncclAllReduce");
+    g_rccl.CommDestroy = (decltype(g_rccl.CommDestroy))dlsym(h, "ncclCommDestroy");
+    g_rccl.GetErrorString = (decltype(g_rccl.GetErrorString))dlsym(h, "ncclGetErrorString");
+    if (!g_rccl.GetUniqueId || !g_rccl.CommInitRank || !g_rccl.AllReduce || !g_rccl.CommDestroy)
+        return fail(DMX_ERR_RCCL, "librccl lacks a required symbol");
+    g_rccl.handle = h;
+    return 0;
+}
+}  // namespace
+
+// ------------------------------------------------------------------------------------
+// context
+// ------------------------------------------------------------------------------------
+struct TimerSlot {
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> pending;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> free_list;
+    double ms = 0.0;
+    int64_t launches = 0;
+};
+
+struct dmx_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    long long B = 0, V = 0, N = 0, S = 0;
+    int G = 0, K = 0;
+    bool have_problem = false, have_betas = false, have_probs = false, have_post = false;
+
+    long long *d_row_ptr = nullptr;
+    uint2 *d_csr = nullptr;
+    uint2 *d_csc = nullptr;
+    long long *d_item_start = nullptr;
+    int *d_item_len = nullptr;
+    long long *d_item_ptr = nullptr;
+    long long n_items = 0;
+    int *d_v2snp = nullptr, *d_snp_ptr = nullptr, *d_snp_vars = nullptr;
+    float *d_prior = nullptr, *d_add = nullptr, *d_prob = nullptr;
+    double *d_add64 = nullptr, *d_partial = nullptr;
+    float *d_logits = nullptr, *d_post = nullptr;
+    long long cap_bk = 0;
+    float *d_pen = nullptr;
+    unsigned *d_pairs = nullptr;
+    int cap_k = 0;
+    void *d_prior_logits = nullptr;
+    size_t cap_prior = 0;
+    int *d_best = nullptr;
+    float *d_bestp = nullptr;
+    void *d_scratch = nullptr;  // self tests
+    size_t cap_scratch = 0;
+
+    ncclComm_t comm = nullptr;
+    int rank = 0, nranks = 1, reduce_dtype = DMX_F64;
+
+    int64_t bytes = 0;
+    TimerSlot timers[DMX_T_COUNT];
+};
+
+namespace {
+
+template <typename T>
+int dev_alloc(dmx_ctx *c, T **p, size_t count)
+{
+    *p = nullptr;
+    if (count == 0) count = 1;
+    hipError_t e = hipMalloc((void **)p, count * sizeof(T));
+    if (e != hipSuccess)
+        return fail(DMX_ERR_HIP, "hipMalloc of %zu bytes failed: %s", count * sizeof(T), hipGetErrorString(e));
+    c->bytes += (int64_t)(count * sizeof(T));
+    return 0;
+}
+
+template <typename T>
+void dev_free(dmx_ctx *c, T **p, size_t count)
+{
+    if (*p) {
+        (void)hipFree(*p);
+        c->bytes -= (int64_t)((count ? count : 1) * sizeof(T));
+        *p = nullptr;
+    }
+}
+
+int bind(dmx_ctx *c)
+{
+    if (!c) return fail(DMX_ERR_INVALID, "null ctx");
+    HIP_TRY(hipSetDevice(c->device));
+    return 0;
+}
+
+void timer_begin(dmx_ctx *c, int slot, std::pair<hipEvent_t, hipEvent_t> *ev)
+{
+    TimerSlot &t = c->timers[slot];
+    if (!t.free_list.empty()) {
+        *ev = t.free_list.back();
+        t.free_list.pop_back();
+    } else {
+        (void)hipEventCreate(&ev->first);
+        (void)hipEventCreate(&ev->second);
+    }
+    (void)hipEventRecord(ev->first, c->stream);
+}
+
+void timer_flush(dmx_ctx *c, int slot)
+{
+    TimerSlot &t = c->timers[slot];
+    for (auto &ev : t.pending) {
+        (void)hipEventSynchronize(ev.second);
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, ev.first, ev.second) == hipSuccess) t.ms += ms;
+        t.free_list.push_back(ev);
+    }
+    t.pending.clear();
+}
+
+void timer_end(dmx_ctx *c, int slot, const std::pair<hipEvent_t, hipEvent_t> &ev)
+{
+    TimerSlot &t = c->timers[slot];
+    (void)hipEventRecord(ev.second, c->stream);
+    t.pending.push_back(ev);
+    t.launches++;
+    if (t.pending.size() >= 4096) timer_flush(c, slot);
+}
+
+void release_problem(dmx_ctx *c)
+{
+    dev_free(c, &c->d_row_ptr, (size_t)c->B + 1);
+    dev_free(c, &c->d_csr, (size_t)c->N);
+    dev_free(c, &c->d_csc, (size_t)c->N);
+    dev_free(c, &c->d_item_start, (size_t)c->n_items);
+    dev_free(c, &c->d_item_len, (size_t)c->n_items);
+    dev_free(c, &c->d_item_ptr, (size_t)c->V + 1);
+    dev_free(c, &c->d_v2snp, (size_t)c->V);
+    dev_free(c, &c->d_snp_ptr, (size_t)c->S + 1);
+    dev_free(c, &c->d_snp_vars, (size_t)c->V);
+    const size_t vg = (size_t)c->V * c->G;
+    dev_free(c, &c->d_prior, vg);
+    dev_free(c, &c->d_add, vg);
+    dev_free(c, &c->d_prob, vg);
+    dev_free(c, &c->d_add64, vg);
+    dev_free(c, &c->d_partial, (size_t)c->n_items * c->G);
+    dev_free(c, &c->d_logits, (size_t)c->cap_bk);
+    dev_free(c, &c->d_post, (size_t)c->cap_bk);
+    c->cap_bk = 0;
+    dev_free(c, &c->d_pen, (size_t)c->cap_k);
+    dev_free(c, &c->d_pairs, (size_t)c->cap_k);
+    c->cap_k = 0;
+    if (c->d_prior_logits) {
+        (void)hipFree(c->d_prior_logits);
+        c->bytes -= (int64_t)c->cap_prior;
+        c->d_prior_logits = nullptr;
+        c->cap_prior = 0;
+    }
+    dev_free(c, &c->d_best, (size_t)c->B);
+    dev_free(c, &c->d_bestp, (size_t)c->B);
+    c->have_problem = c->have_betas = c->have_probs = c->have_post = false;
+    c->B = c->V = c->N = c->S = 0;
+    c->G = c->K = 0;
+    c->n_items = 0;
+}
+
+int ensure_options(dmx_ctx *c, int with_doublets, const float *penalties)
+{
+    const int G = c->G;
+    const long long K = with_doublets ? (long long)G * (G + 1) / 2 : G;
+    if (K > (1 << 24)) return fail(DMX_ERR_UNSUPPORTED, "too many options (%lld)", K);
+    if (!with_doublets && G > 256)
+        return fail(DMX_ERR_UNSUPPORTED, "more than 256 genotypes are not supported without doublets yet (G=%d)", G);
+    if (with_doublets && (K + 255) / 256 > 65)
+        return fail(DMX_ERR_UNSUPPORTED, "doublets with G=%d (K=%lld options) exceed the per-workgroup accumulator budget", G, K);
+    if (K > c->cap_k) {
+        dev_free(c, &c->d_pen, (size_t)c->cap_k);
+        dev_free(c, &c->d_pairs, (size_t)c->cap_k);
+        c->cap_k = 0;
+        DMX_TRY(dev_alloc(c, &c->d_pen, (size_t)K));
+        DMX_TRY(dev_alloc(c, &c->d_pairs, (size_t)K));
+        c->cap_k = (int)K;
+    }
+    if (c->B * K > c->cap_bk) {
+        dev_free(c, &c->d_logits, (size_t)c->cap_bk);
+        dev_free(c, &c->d_post, (size_t)c->cap_bk);
+        c->cap_bk = 0;
+        DMX_TRY(dev_alloc(c, &c->d_logits, (size_t)(c->B * K)));
+        DMX_TRY(dev_alloc(c, &c->d_post, (size_t)(c->B * K)));
+        c->cap_bk = c->B * K;
+    }
+    // option k -> (g1, g2): singlets (g, g) first, then g1 < g2 row-major (demux.py:175-191)
+    std::vector<unsigned> pairs((size_t)K);
+    for (int g = 0; g < G; g++) pairs[g] = (unsigned)g | ((unsigned)g << 16);
+    if (with_doublets) {
+        size_t k = G;
+        for (int g1 = 0; g1 < G; g1++)
+            for (int g2 = g1 + 1; g2 < G; g2++) pairs[k++] = (unsigned)g1 | ((unsigned)g2 << 16);
+    }
+    HIP_TRY(hipMemcpyAsync(c->d_pairs, pairs.data(), sizeof(unsigned) * K, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipMemcpyAsync(c->d_pen, penalties, sizeof(float) * K, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));  // `pairs` is a local
+    c->K = (int)K;
+    return 0;
+}
+
+int upload_prior_logits(dmx_ctx *c, const void *prior, int dtype)
+{
+    if (!prior) return 0;
+    if (dtype != DMX_F32 && dtype != DMX_F64) return fail(DMX_ERR_INVALID, "prior_dtype must be DMX_F32 or DMX_F64");
+    const size_t bytes = (size_t)c->B * c->K * (dtype == DMX_F64 ? 8 : 4);
+    if (bytes > c->cap_prior) {
+        if (c->d_prior_logits) {
+            (void)hipFree(c->d_prior_logits);
+            c->bytes -= (int64_t)c->cap_prior;
+            c->d_prior_logits = nullptr;
+            c->cap_prior = 0;
+        }
+        hipError_t e = hipMalloc(&c->d_prior_logits, bytes ? bytes : 1);
+        if (e != hipSuccess) return fail(DMX_ERR_HIP, "hipMalloc(prior logits, %zu bytes): %s", bytes, hipGetErrorString(e));
+        c->cap_prior = bytes;
+        c->bytes += (int64_t)bytes;
+    }
+    HIP_TRY(hipMemcpyAsync(c->d_prior_logits, prior, bytes, hipMemcpyHostToDevice, c->stream));
+    return 0;
+}
+
+int run_pstep(dmx_ctx *c, float lo, float hi, bool with_addition)
+{
+    std::pair<hipEvent_t, hipEvent_t> ev;
+    timer_begin(c, DMX_T_PSTEP, &ev);
+    HIP_TRY(dmx::launch_probs_from_betas(c->stream, c->d_prior, with_addition ? c->d_add : nullptr, c->d_v2snp,
+                                         c->d_snp_ptr, c->d_snp_vars, c->V, c->G, lo, hi, c->d_prob));
+    timer_end(c, DMX_T_PSTEP, ev);
+    c->have_probs = true;
+    return 0;
+}
+
+int run_estep(dmx_ctx *c, int with_doublets, bool with_prior, int prior_dtype)
+{
+    dmx::EstepArgs a;
+    a.row_ptr = c->d_row_ptr;
+    a.calls = c->d_csr;
+    a.prob = c->d_prob;
+    a.opt_pairs = c->d_pairs;
+    a.pen = c->d_pen;
+    a.prior = with_prior ? c->d_prior_logits : nullptr;
+    a.prior_dtype = prior_dtype;
+    a.logits = c->d_logits;
+    a.post = c->d_post;
+    a.B = c->B;
+    a.G = c->G;
+    a.K = c->K;
+    std::pair<hipEvent_t, hipEvent_t> ev;
+    timer_begin(c, DMX_T_ESTEP, &ev);
+    HIP_TRY(dmx::launch_estep(c->stream, a, with_doublets != 0));
+    timer_end(c, DMX_T_ESTEP, ev);
+    c->have_post = true;
+    return 0;
+}
+
+int run_mstep(dmx_ctx *c, float power)
+{
+    dmx::MstepArgs a;
+    a.item_start = c->d_item_start;
+    a.item_len = c->d_item_len;
+    a.calls = c->d_csc;
+    a.post = c->d_post;
+    a.partial = c->d_partial;
+    a.n_items = c->n_items;
+    a.K = c->K;
+    a.G = c->G;
+    a.square = (power == 2.0f);
+    a.power = power;
+    std::pair<hipEvent_t, hipEvent_t> ev;
+    timer_begin(c, DMX_T_MSTEP, &ev);
+    HIP_TRY(dmx::launch_mstep(c->stream, a));
+    timer_end(c, DMX_T_MSTEP, ev);
+
+    const long long vg = c->V * c->G;
+    const bool dist = c->comm != nullptr && c->nranks > 1;
+    timer_begin(c, DMX_T_MCOMBINE, &ev);
+    if (!dist) {
+        HIP_TRY(dmx::launch_mcombine(c->stream, c->d_partial, c->d_item_ptr, c->V, c->G, c->d_add, nullptr));
+    } else if (c->reduce_dtype == DMX_F64) {
+        HIP_TRY(dmx::launch_mcombine(c->stream, c->d_partial, c->d_item_ptr, c->V, c->G, nullptr, c->d_add64));
+    } else {
+        HIP_TRY(dmx::launch_mcombine(c->stream, c->d_partial, c->d_item_ptr, c->V, c->G, c->d_add, nullptr));
+    }
+    timer_end(c, DMX_T_MCOMBINE, ev);
+    if (dist) {
+        timer_begin(c, DMX_T_ALLREDUCE, &ev);
+        ncclResult_t r;
+        if (c->reduce_dtype == DMX_F64) {
+            r = g_rccl.AllReduce(c->d_add64, c->d_add64, (size_t)vg, ncclDouble, ncclSum, c->comm, c->stream);
+            if (r == ncclSuccess) HIP_TRY(dmx::launch_f64_to_f32(c->stream, c->d_add64, c->d_add, vg));
+        } else {
+            r = g_rccl.AllReduce(c->d_add, c->d_add, (size_t)vg, ncclFloat, ncclSum, c->comm, c->stream);
+        }
+        timer_end(c, DMX_T_ALLREDUCE, ev);
+        if (r != ncclSuccess)
+            return fail(DMX_ERR_RCCL, "ncclAllReduce failed: %s", g_rccl.GetErrorString ? g_rccl.GetErrorString(r) : "?");
+    }
+    return 0;
+}
+
+int copy_out(dmx_ctx *c, float *dst, const float *src, size_t count)
+{
+    if (!dst) return 0;
+    HIP_TRY(hipMemcpyAsync(dst, src, count * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+    return 0;
+}
+
+int need(dmx_ctx *c, bool cond, const char *what)
+{
+    (void)c;
+    if (!cond) return fail(DMX_ERR_INVALID, "call order: %s", what);
+    return 0;
+}
+
+}  // namespace
+
+// ------------------------------------------------------------------------------------
+// ABI
+// ------------------------------------------------------------------------------------
+extern "C" {
+
+const char *dmx_last_error(void) { return dmx::g_last_error.c_str(); }
+
+const char *dmx_version(void) { return "demux_hip 0.1 (gfx950)"; }
+
+int dmx_device_count(int *count)
+{
+    if (!count) return fail(DMX_ERR_INVALID, "null count");
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess) {
+        *count = 0;
+        return fail(DMX_ERR_NO_DEVICE, "hipGetDeviceCount: %s", hipGetErrorString(e));
+    }
+    *count = n;
+    return 0;
+}
+
+int dmx_create(int device, dmx_ctx **out)
+{
+    if (!out) return fail(DMX_ERR_INVALID, "null out pointer");
+    *out = nullptr;
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0)
+        return fail(DMX_ERR_NO_DEVICE, "no HIP device visible: the demuxalot_amd hot path needs an MI355X (there is no CPU fallback)");
+    if (device < 0 || device >= n) return fail(DMX_ERR_INVALID, "device %d out of range (%d visible)", device, n);
+    HIP_TRY(hipSetDevice(device));
+    dmx_ctx *c = new dmx_ctx();
+    c->device = device;
+    hipError_t e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
+    if (e != hipSuccess) {
+        delete c;
+        return fail(DMX_ERR_HIP, "hipStreamCreate: %s", hipGetErrorString(e));
+    }
+    *out = c;
+    return 0;
+}
+
+int dmx_destroy(dmx_ctx *c)
+{
+    if (!c) return 0;
+    (void)hipSetDevice(c->device);
+    (void)hipStreamSynchronize(c->stream);
+    if (c->comm && g_rccl.CommDestroy) g_rccl.CommDestroy(c->comm);
+    release_problem(c);
+    if (c->d_scratch) (void)hipFree(c->d_scratch);
+    for (auto &t : c->timers) {
+        for (auto &ev : t.pending) {
+            (void)hipEventDestroy(ev.first);
+            (void)hipEventDestroy(ev.second);
+        }
+        for (auto &ev : t.free_list) {
+            (void)hipEventDestroy(ev.first);
+            (void)hipEventDestroy(ev.second);
+        }
+    }
+    (void)hipStreamDestroy(c->stream);
+    delete c;
+    return 0;
+}
+
+int dmx_synchronize(dmx_ctx *c)
+{
+    DMX_TRY(bind(c));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return 0;
+}
+
+int dmx_set_problem(dmx_ctx *c, int64_t B, int64_t V, int32_t G, int64_t N, const int32_t *variant_id,
+                    const int32_t *cb, const float *p_wrong, const int32_t *v2snp)
+{
+    DMX_TRY(bind(c));
+    if (B < 0 || V < 0 || G <= 0 || N < 0) return fail(DMX_ERR_INVALID, "bad problem sizes B=%lld V=%lld G=%d N=%lld", (long long)B, (long long)V, G, (long long)N);
+    if (G > 65535) return fail(DMX_ERR_UNSUPPORTED, "G=%d genotypes exceed the 16-bit option encoding", G);
+    if (B >= (int64_t(1) << 31) || V >= (int64_t(1) << 31)) return fail(DMX_ERR_UNSUPPORTED, "B and V must fit int32");
+    if (N > 0 && (!variant_id || !cb || !p_wrong)) return fail(DMX_ERR_INVALID, "null call arrays");
+    if (V > 0 && !v2snp) return fail(DMX_ERR_INVALID, "null v2snp");
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    release_problem(c);
+
+    // ---- host side: CSR by barcode and CSC by variant, both stable in the input order ----
+    std::vector<long long> row_ptr((size_t)B + 1, 0), col_ptr((size_t)V + 1, 0);
+    for (int64_t i = 0; i < N; i++) {
+        const int32_t b = cb[i], v = variant_id[i];
+        if (b < 0 || b >= B) return fail(DMX_ERR_INVALID, "compressed_cb[%lld]=%d outside [0,%lld)", (long long)i, b, (long long)B);
+        if (v < 0 || v >= V) return fail(DMX_ERR_INVALID, "variant_id[%lld]=%d outside [0,%lld)", (long long)i, v, (long long)V);
+        row_ptr[(size_t)b + 1]++;
+        col_ptr[(size_t)v + 1]++;
+    }
+    for (int64_t b = 0; b < B; b++) row_ptr[b + 1] += row_ptr[b];
+    for (int64_t v = 0; v < V; v++) col_ptr[v + 1] += col_ptr[v];
+    std::vector<uint2> csr((size_t)N), csc((size_t)N);
+    {
+        std::vector<long long> rcur(row_ptr.begin(), row_ptr.end() - 1), ccur(col_ptr.begin(), col_ptr.end() - 1);
+        for (int64_t i = 0; i < N; i++) {
+            uint32_t ebits;
+            std::memcpy(&ebits, &p_wrong[i], 4);
+            csr[(size_t)rcur[cb[i]]++] = make_uint2((uint32_t)variant_id[i], ebits);
+            csc[(size_t)ccur[variant_id[i]]++] = make_uint2((uint32_t)cb[i], ebits);
+        }
+    }
+    // M-step work items: runs of <= ITEM_CALLS calls of one variant
+    std::vector<long long> item_start, item_ptr((size_t)V + 1, 0);
+    std::vector<int> item_len;
+    for (int64_t v = 0; v < V; v++) {
+        item_ptr[v] = (long long)item_start.size();
+        for (long long s = col_ptr[v]; s < col_ptr[v + 1]; s += dmx::ITEM_CALLS) {
+            item_start.push_back(s);
+            item_len.push_back((int)std::min<long long>(dmx::ITEM_CALLS, col_ptr[v + 1] - s));
+        }
+    }
+    item_ptr[V] = (long long)item_start.size();
+    // SNP groups: variants of each SNP in increasing variant index (np.bincount order)
+    long long S = 0;
+    for (int64_t v = 0; v < V; v++) {
+        if (v2snp[v] < 0) return fail(DMX_ERR_INVALID, "v2snp[%lld] negative", (long long)v);
+        S = std::max<long long>(S, (long long)v2snp[v] + 1);
+    }
+    std::vector<int> snp_ptr((size_t)S + 1, 0), snp_vars((size_t)V);
+    for (int64_t v = 0; v < V; v++) snp_ptr[(size_t)v2snp[v] + 1]++;
+    for (long long s = 0; s < S; s++) snp_ptr[s + 1] += snp_ptr[s];
+    {
+        std::vector<int> cur(snp_ptr.begin(), snp_ptr.end() - 1);
+        for (int64_t v = 0; v < V; v++) snp_vars[(size_t)cur[v2snp[v]]++] = (int)v;
+    }
+
+    // ---- device ----
+    c->B = B;
+    c->V = V;
+    c->G = G;
+    c->N = N;
+    c->S = S;
+    c->n_items = (long long)item_start.size();
+    const size_t vg = (size_t)V * G;
+    DMX_TRY(dev_alloc(c, &c->d_row_ptr, (size_t)B + 1));
+    DMX_TRY(dev_alloc(c, &c->d_csr, (size_t)N));
+    DMX_TRY(dev_alloc(c, &c->d_csc, (size_t)N));
+    DMX_TRY(dev_alloc(c, &c->d_item_start, (size_t)c->n_items));
+    DMX_TRY(dev_alloc(c, &c->d_item_len, (size_t)c->n_items));
+    DMX_TRY(dev_alloc(c, &c->d_item_ptr, (size_t)V + 1));
+    DMX_TRY(dev_alloc(c, &c->d_v2snp, (size_t)V));
+    DMX_TRY(dev_alloc(c, &c->d_snp_ptr, (size_t)S + 1));
+    DMX_TRY(dev_alloc(c, &c->d_snp_vars, (size_t)V));
+    DMX_TRY(dev_alloc(c, &c->d_prior, vg));
+    DMX_TRY(dev_alloc(c, &c->d_add, vg));
+    DMX_TRY(dev_alloc(c, &c->d_prob, vg));
+    DMX_TRY(dev_alloc(c, &c->d_add64, vg));
+    DMX_TRY(dev_alloc(c, &c->d_partial, (size_t)c->n_items * G));
+    DMX_TRY(dev_alloc(c, &c->d_best, (size_t)B));
+    DMX_TRY(dev_alloc(c, &c->d_bestp, (size_t)B));
+    hipStream_t st = c->stream;
+    HIP_TRY(hipMemcpyAsync(c->d_row_ptr, row_ptr.data(), sizeof(long long) * (B + 1), hipMemcpyHostToDevice, st));
+    if (N) {
+        HIP_TRY(hipMemcpyAsync(c->d_csr, csr.data(), sizeof(uint2) * N, hipMemcpyHostToDevice, st));
+        HIP_TRY(hipMemcpyAsync(c->d_csc, csc.data(), sizeof(uint2) * N, hipMemcpyHostToDevice, st));
+    }
+    if (c->n_items) {
+        HIP_TRY(hipMemcpyAsync(c->d_item_start, item_start.data(), sizeof(long long) * c->n_items, hipMemcpyHostToDevice, st));
+        HIP_TRY(hipMemcpyAsync(c->d_item_len, item_len.data(), sizeof(int) * c->n_items, hipMemcpyHostToDevice, st));
+    }
+    HIP_TRY(hipMemcpyAsync(c->d_item_ptr, item_ptr.data(), sizeof(long long) * (V + 1), hipMemcpyHostToDevice, st));
+    if (V) {
+        HIP_TRY(hipMemcpyAsync(c->d_v2snp, v2snp, sizeof(int) * V, hipMemcpyHostToDevice, st));
+        HIP_TRY(hipMemcpyAsync(c->d_snp_vars, snp_vars.data(), sizeof(int) * V, hipMemcpyHostToDevice, st));
+    }
+    HIP_TRY(hipMemcpyAsync(c->d_snp_ptr, snp_ptr.data(), sizeof(int) * (S + 1), hipMemcpyHostToDevice, st));
+    HIP_TRY(hipMemsetAsync(c->d_add, 0, sizeof(float) * (vg ? vg : 1), st));
+    HIP_TRY(hipStreamSynchronize(st));  // host staging vectors die here
+    c->have_problem = true;
+    return 0;
+}
+
+int dmx_set_betas(dmx_ctx *c, const float *prior)
+{
+    DMX_TRY(bind(c));
+    DMX_TRY(need(c, c->have_problem, "dmx_set_problem before dmx_set_betas"));
+    if (!prior && c->V > 0) return fail(DMX_ERR_INVALID, "null betas");
+    HIP_TRY(hipMemcpyAsync(c->d_prior, prior, sizeof(float) * c->V * c->G, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    c->have_betas = true;
+    return 0;
+}
+
+int dmx_set_addition(dmx_ctx *c, const float *addition)
+{
+    DMX_TRY(bind(c));
+    DMX_TRY(need(c, c->have_problem, "dmx_set_problem before dmx_set_addition"));
+    const size_t vg = (size_t)c->V * c->G;
+    if (addition) {
+        HIP_TRY(hipMemcpyAsync(c->d_add, addition, sizeof(float) * vg, hipMemcpyHostToDevice, c->stream));
+        HIP_TRY(hipStreamSynchronize(c->stream));
+    } else {
+        HIP_TRY(hipMemsetAsync(c->d_add, 0, sizeof(float) * (vg ? vg : 1), c->stream));
+    }
+    return 0;
+}
+
+int dmx_probs_from_betas(dmx_ctx *c, float lo, float hi, float *prob_out)
+{
+    DMX_TRY(bind(c));
+    DMX_TRY(need(c, c->have_problem && c->have_betas, "dmx_set_problem + dmx_set_betas before dmx_probs_from_betas"));
+    DMX_TRY(run_pstep(c, lo, hi, true));
+    DMX_TRY(copy_out(c, prob_out, c->d_prob, (size_t)c->V * c->G));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return 0;
+}
+
+int dmx_set_probs(dmx_ctx *c, const float *prob)
+{
+    DMX_TRY(bind(c));
+    DMX_TRY(need(c, c->have_problem, "dmx_set_problem before dmx_set_probs"));
+    if (!prob && c->V > 0) return fail(DMX_ERR_INVALID, "null prob table");
+    HIP_TRY(hipMemcpyAsync(c->d_prob, prob, sizeof(float) * c->V * c->G, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    c->have_probs = true;
+    return 0;
+}
+
+int dmx_estep(dmx_ctx *c, int with_doublets, const float *penalties, const void *prior_logits, int prior_dtype,
+              float *logits_out, float *probs_out)
+{
+    DMX_TRY(bind(c));
+    DMX_TRY(need(c, c->have_problem && c->have_probs, "genotype probabilities (dmx_probs_from_betas / dmx_set_probs) before dmx_estep"));
+    if (!penalties) return fail(DMX_ERR_INVALID, "null penalties");
+    DMX_TRY(ensure_options(c, with_doublets, penalties));
+    DMX_TRY(upload_prior_logits(c, prior_logits, prior_dtype));
+    DMX_TRY(run_estep(c, with_doublets, prior_logits != nullptr, prior_dtype));
+    const size_t bk = (size_t)c->B * c->K;
+    DMX_TRY(copy_out(c, logits_out, c->d_logits, bk));
+    DMX_TRY(copy_out(c, probs_out, c->d_post, bk));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return 0;
+}
+
+int dmx_mstep(dmx_ctx *c, float power, float *addition_out)
+{
+    DMX_TRY(bind(c));
+    DMX_TRY(need(c, c->have_problem && c->have_post, "dmx_estep before dmx_mstep"));
+    DMX_TRY(run_mstep(c, power));
+    DMX_TRY(copy_out(c, addition_out, c->d_add, (size_t)c->V * c->G));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return 0;
+}
+
+int dmx_em(dmx_ctx *c, int n_iterations, float lo, float hi, int with_doublets, const float *penalties,
+           const void *prior_logits, int prior_dtype, float power, float *logits_out, float *probs_out,
+           float *addition_out)
+{
+    DMX_TRY(bind(c));
+    DMX_TRY(need(c, c->have_problem && c->have_betas, "dmx_set_problem + dmx_set_betas before dmx_em"));
+    if (n_iterations < 1) return fail(DMX_ERR_INVALID, "n_iterations must be >= 1");
+    if (!penalties) return fail(DMX_ERR_INVALID, "null penalties");
+    DMX_TRY(ensure_options(c, with_doublets, penalties));
+    DMX_TRY(upload_prior_logits(c, prior_logits, prior_dtype));
+    const size_t vg = (size_t)c->V * c->G;
+    HIP_TRY(hipMemsetAsync(c->d_add, 0, sizeof(float) * (vg ? vg : 1), c->stream));  // demux.py:86
+    for (int it = 0; it < n_iterations; it++) {
+        DMX_TRY(run_pstep(c, lo, hi, true));
+        DMX_TRY(run_estep(c, with_doublets, it == 0 && prior_logits != nullptr, prior_dtype));
+        if (it + 1 < n_iterations) DMX_TRY(run_mstep(c, power));  // the M-step after the last yield is dead
+    }
+    const size_t bk = (size_t)c->B * c->K;
+    DMX_TRY(copy_out(c, logits_out, c->d_logits, bk));
+    DMX_TRY(copy_out(c, probs_out, c->d_post, bk));
+    DMX_TRY(copy_out(c, addition_out, c->d_add, vg));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return 0;
+}
+
+int dmx_run_iterations(dmx_ctx *c, int n_iterations, float lo, float hi, float power)
+{
+    DMX_TRY(bind(c));
+    DMX_TRY(need(c, c->have_problem && c->have_betas && c->have_post && c->K > 0,
+                 "dmx_estep or dmx_em (to fix the options) before dmx_run_iterations"));
+    if (n_iterations < 0) return fail(DMX_ERR_INVALID, "negative n_iterations");
+    const int with_doublets = c->K != c->G;
+    for (int it = 0; it < n_iterations; it++) {
+        DMX_TRY(run_pstep(c, lo, hi, true));
+        DMX_TRY(run_estep(c, with_doublets, false, DMX_F32));
+        DMX_TRY(run_mstep(c, power));
+    }
+    return 0;
+}
+
+int dmx_get_logits(dmx_ctx *c, float *out)
+{
+    DMX_TRY(bind(c));
+    DMX_TRY(need(c, c->have_post, "dmx_estep before dmx_get_logits"));
+    DMX_TRY(copy_out(c, out, c->d_logits, (size_t)c->B * c->K));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return 0;
+}
+
+int dmx_get_probs(dmx_ctx *c, float *out)
+{
+    DMX_TRY(bind(c));
+    DMX_TRY(need(c, c->have_post, "dmx_estep before dmx_get_probs"));
+    DMX_TRY(copy_out(c, out, c->d_post, (size_t)c->B * c->K));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return 0;
+}
+
+int dmx_get_addition(dmx_ctx *c, float *out)
+{
+    DMX_TRY(bind(c));
+    DMX_TRY(need(c, c->have_problem, "dmx_set_problem before dmx_get_addition"));
+    DMX_TRY(copy_out(c, out, c->d_add, (size_t)c->V * c->G));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return 0;
+}
+
+int dmx_get_assignments(dmx_ctx *c, int32_t *best, float *best_p)
+{
+    DMX_TRY(bind(c));
+    DMX_TRY(need(c, c->have_post, "dmx_estep before dmx_get_assignments"));
+    HIP_TRY(dmx::launch_assign(c->stream, c->d_post, c->B, c->K, c->d_best, c->d_bestp));
+    if (best) HIP_TRY(hipMemcpyAsync(best, c->d_best, sizeof(int) * c->B, hipMemcpyDeviceToHost, c->stream));
+    if (best_p) HIP_TRY(hipMemcpyAsync(best_p, c->d_bestp, sizeof(float) * c->B, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return 0;
+}
+
+int dmx_comm_unique_id(void *id_out)
+{
+    if (!id_out) return fail(DMX_ERR_INVALID, "null id buffer");
+    DMX_TRY(load_rccl());
+    static_assert(sizeof(ncclUniqueId) == DMX_UNIQUE_ID_BYTES, "unique id size");
+    ncclUniqueId id;
+    ncclResult_t r = g_rccl.GetUniqueId(&id);
+    if (r != ncclSuccess) return fail(DMX_ERR_RCCL, "ncclGetUniqueId failed (%d)", (int)r);
+    std::memcpy(id_out, &id, sizeof id);
+    return 0;
+}
+
+int dmx_comm_init(dmx_ctx *c, int rank, int nranks, const void *unique_id, int reduce_dtype)
+{
+    DMX_TRY(bind(c));
+    if (nranks < 1 || rank < 0 || rank >= nranks || !unique_id) return fail(DMX_ERR_INVALID, "bad communicator arguments");
+    if (reduce_dtype != DMX_F32 && reduce_dtype != DMX_F64) return fail(DMX_ERR_INVALID, "reduce_dtype must be DMX_F32 or DMX_F64");
+    DMX_TRY(load_rccl());
+    if (c->comm) {
+        g_rccl.CommDestroy(c->comm);
+        c->comm = nullptr;
+    }
+    ncclUniqueId id;
+    std::memcpy(&id, unique_id, sizeof id);
+    ncclResult_t r = g_rccl.CommInitRank(&c->comm, nranks, id, rank);
+    if (r != ncclSuccess) {
+        c->comm = nullptr;
+        return fail(DMX_ERR_RCCL, "ncclCommInitRank failed: %s", g_rccl.GetErrorString ? g_rccl.GetErrorString(r) : "?");
+    }
+    c->rank = rank;
+    c->nranks = nranks;
+    c->reduce_dtype = reduce_dtype;
+    return 0;
+}
+
+int dmx_get_timings(dmx_ctx *c, double *ms, int64_t *launches)
+{
+    DMX_TRY(bind(c));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    for (int s = 0; s < DMX_T_COUNT; s++) {
+        timer_flush(c, s);
+        if (ms) ms[s] = c->timers[s].ms;
+        if (launches) launches[s] = c->timers[s].launches;
+    }
+    return 0;
+}
+
+int dmx_reset_timings(dmx_ctx *c)
+{
+    DMX_TRY(bind(c));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    for (int s = 0; s < DMX_T_COUNT; s++) {
+        timer_flush(c, s);
+        c->timers[s].ms = 0.0;
+        c->timers[s].launches = 0;
+    }
+    return 0;
+}
+
+int dmx_device_bytes(dmx_ctx *c, int64_t *bytes)
+{
+    if (!c || !bytes) return fail(DMX_ERR_INVALID, "null argument");
+    *bytes = c->bytes;
+    return 0;
+}
+
+// ---- self tests -------------------------------------------------------------------
+static int scratch(dmx_ctx *c, size_t bytes)
+{
+    if (bytes <= c->cap_scratch) return 0;
+    if (c->d_scratch) (void)hipFree(c->d_scratch);
+    c->d_scratch = nullptr;
+    c->cap_scratch = 0;
+    hipError_t e = hipMalloc(&c->d_scratch, bytes);
+    if (e != hipSuccess) return fail(DMX_ERR_HIP, "hipMalloc(scratch %zu): %s", bytes, hipGetErrorString(e));
+    c->cap_scratch = bytes;
+    return 0;
+}
+
+static int unary_test(dmx_ctx *c, const float *in, float *out, int64_t n, int which, int64_t rows, int64_t cols)
+{
+    DMX_TRY(bind(c));
+    if (n < 0 || (n > 0 && (!in || !out))) return fail(DMX_ERR_INVALID, "bad test buffers");
+    if (n == 0) return 0;
+    DMX_TRY(scratch(c, (size_t)n * 8));
+    float *d_in = (float *)c->d_scratch, *d_out = d_in + n;
+    HIP_TRY(hipMemcpyAsync(d_in, in, (size_t)n * 4, hipMemcpyHostToDevice, c->stream));
+    if (which == 0) HIP_TRY(dmx::launch_test_log(c->stream, d_in, d_out, n));
+    if (which == 1) HIP_TRY(dmx::launch_test_exp(c->stream, d_in, d_out, n));
+    if (which == 2) HIP_TRY(dmx::launch_test_softmax(c->stream, d_in, d_out, rows, (int)cols));
+    HIP_TRY(hipMemcpyAsync(out, d_out, (size_t)n * 4, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return 0;
+}
+
+int dmx_test_logf(dmx_ctx *c, const float *in, float *out, int64_t n) { return unary_test(c, in, out, n, 0, 0, 0); }
+int dmx_test_expf(dmx_ctx *c, const float *in, float *out, int64_t n) { return unary_test(c, in, out, n, 1, 0, 0); }
+int dmx_test_softmax(dmx_ctx *c, const float *in, float *out, int64_t rows, int64_t cols)
+{
+    if (rows < 0 || cols <= 0 || cols > (1 << 24)) return fail(DMX_ERR_INVALID, "bad softmax test shape");
+    return unary_test(c, in, out, rows * cols, 2, rows, cols);
+}
+
+}  // extern "C"

@@ -1,0 +1,53 @@
+// kernels.h -- argument blocks and launchers of kernels.hip
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "demux_hip.h"
+
+namespace dmx {
+
+struct EstepArgs {
+    const long long *row_ptr;   // [B+1] CSR offsets (barcode-major)
+    const uint2 *calls;         // [N] (variant_id, bits of p_base_wrong), sorted by (barcode, input order)
+    const float *prob;          // [V, G] genotype_prob, row-major
+    const unsigned *opt_pairs;  // [K] g1 | g2 << 16 (doublet runs only)
+    const float *pen;           // [K] doublet penalties
+    const void *prior;          // nullable [B, K] prior logits (device)
+    int prior_dtype;            // DMX_F32 / DMX_F64
+    float *logits;              // [B, K]
+    float *post;                // [B, K]
+    long long B;
+    int G;
+    int K;
+};
+
+struct MstepArgs {
+    const long long *item_start;  // [n_items] first CSC call of the item
+    const int *item_len;          // [n_items] number of calls (<= ITEM_CALLS)
+    const uint2 *calls;           // [N] (compressed_cb, bits of p_base_wrong), variant-major
+    const float *post;            // [B, K] posteriors (singlet columns 0..G-1 are read)
+    double *partial;              // [n_items, G]
+    long long n_items;
+    long long K;
+    int G;
+    int square;   // contribution_power == 2
+    float power;  // otherwise
+};
+
+constexpr int ITEM_CALLS = 1024;  // longest run of one variant's calls handled by one wavefront
+
+hipError_t launch_probs_from_betas(hipStream_t st, const float *prior, const float *addition, const int *v2snp,
+                                   const int *snp_ptr, const int *snp_vars, long long V, int G, float lo, float hi,
+                                   float *prob);
+hipError_t launch_estep(hipStream_t st, const EstepArgs &a, bool pairs);
+hipError_t launch_mstep(hipStream_t st, const MstepArgs &a);
+hipError_t launch_mcombine(hipStream_t st, const double *partial, const long long *item_ptr, long long V, int G,
+                           float *add32, double *add64);
+hipError_t launch_f64_to_f32(hipStream_t st, const double *in, float *out, long long n);
+hipError_t launch_f32_to_f64(hipStream_t st, const float *in, double *out, long long n);
+hipError_t launch_assign(hipStream_t st, const float *post, long long B, int K, int *best, float *best_p);
+hipError_t launch_test_log(hipStream_t st, const float *in, float *out, long long n);
+hipError_t launch_test_exp(hipStream_t st, const float *in, float *out, long long n);
+hipError_t launch_test_softmax(hipStream_t st, const float *in, float *out, long long rows, int cols);
+
+}  // namespace dmx

@@ -1,0 +1,647 @@
+// kernels.hip -- gfx950 kernels of the Demultiplexer EM hot path.
+//
+//   k_probs_from_betas   P-step   demuxalot/demux.py:267-274
+//   k_estep_direct       E-step + softmax, one wavefront per barcode, options on lanes
+//                        (K <= 256)                         demux.py:246-265, :101/:152
+//   k_estep_block        E-step + softmax, one 256-thread workgroup per barcode, genotype
+//                        rows staged in LDS (K > 256: doublets of many genotypes)
+//   k_mstep / k_mcombine M-step (variant-major, no atomics)  demux.py:113-118
+//   k_assign             per-barcode argmax of the posterior
+//
+// Numerics: float32 element-wise work in the reference's operation order, float64
+// accumulation (np.bincount), one float32 rounding; log/exp/sum as numpy evaluates them
+// (np_math.h).  Built with -ffp-contract=off.
+#include <hip/hip_runtime.h>
+
+#include "kernels.h"
+#include "np_math.h"
+
+namespace dmx {
+
+static __device__ __forceinline__ double shfl_xor_f64(double v, int mask)
+{
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __shfl_xor(lo, mask);
+    hi = __shfl_xor(hi, mask);
+    return __hiloint2double(hi, lo);
+}
+
+// ------------------------------------------------------------------------------------
+// P-step.  One thread per (variant, genotype).  The per-SNP denominator is the float64 sum
+// of beta over the SNP's variants in increasing variant index (np.bincount order).
+// ------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_probs_from_betas(const float *__restrict__ prior,
+                                                          const float *__restrict__ addition,
+                                                          const int *__restrict__ v2snp,
+                                                          const int *__restrict__ snp_ptr,
+                                                          const int *__restrict__ snp_vars, long long V, int G,
+                                                          float clip_lo, float clip_hi, float *__restrict__ prob)
+{
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= V * G) return;
+    const long long v = i / G;
+    const int g = (int)(i - v * G);
+    const int snp = v2snp[v];
+    double den = 0.0;
+    for (int j = snp_ptr[snp]; j < snp_ptr[snp + 1]; j++) {
+        const long long o = (long long)snp_vars[j] * G + g;
+        const float b = addition ? prior[o] + addition[o] : prior[o];  // float32 add, demux.py:90
+        den += (double)b;
+    }
+    const float beta = addition ? prior[i] + addition[i] : prior[i];
+    const double q = (double)beta / fmax(den, 1e-7);
+    float p = (float)q;
+    p = fminf(fmaxf(p, clip_lo), clip_hi);  // ndarray.clip(lo, hi) = minimum(maximum(x, lo), hi)
+    prob[i] = p;
+}
+
+// ------------------------------------------------------------------------------------
+// helpers for the in-register softmax of the direct kernel: option k lives in lane (k & 63),
+// register slot (k >> 6).
+// ------------------------------------------------------------------------------------
+template <int A>
+static __device__ __forceinline__ float reg_elem(const float (&x)[A], int i)
+{
+    float v = 0.0f;
+#pragma unroll
+    for (int a = 0; a < A; a++) {
+        const float t = __shfl(x[a], i & 63);
+        v = ((i >> 6) == a) ? t : v;
+    }
+    return v;
+}
+
+// numpy pairwise block (n <= 128) over elements [start, start+n) held in registers
+template <int A>
+static __device__ __forceinline__ float reg_block_sum(const float (&x)[A], int start, int n, int lane)
+{
+    if (n < 8) {
+        float res = 0.0f;
+        for (int i = 0; i < n; i++) res += reg_elem<A>(x, start + i);
+        return res;
+    }
+    const int j = lane & 7;
+    const int nfull = n - (n & 7);
+    float r = reg_elem<A>(x, start + j);
+    for (int i = 8; i < nfull; i += 8) r += reg_elem<A>(x, start + i + j);
+    r = r + __shfl_xor(r, 1);
+    r = r + __shfl_xor(r, 2);
+    r = r + __shfl_xor(r, 4);
+    for (int i = nfull; i < n; i++) r += reg_elem<A>(x, start + i);
+    return r;
+}
+
+static __device__ __forceinline__ int pw_half(int n)
+{
+    int h = n / 2;
+    return h - (h % 8);
+}
+
+// np.sum of K <= 256 register-resident elements
+template <int A>
+static __device__ __forceinline__ float reg_row_sum(const float (&x)[A], int K, int lane)
+{
+    if (K <= 128) return reg_block_sum<A>(x, 0, K, lane);
+    const int h = pw_half(K);
+    const float left = reg_block_sum<A>(x, 0, h, lane);
+    const int rn = K - h;
+    float right;
+    if (rn <= 128) {
+        right = reg_block_sum<A>(x, h, rn, lane);
+    } else {
+        const int h2 = pw_half(rn);
+        right = reg_block_sum<A>(x, h, h2, lane) + reg_block_sum<A>(x, h + h2, rn - h2, lane);
+    }
+    return left + right;
+}
+
+// ------------------------------------------------------------------------------------
+// E-step, direct form.  One wavefront per barcode; the 64 lanes are split into 64/L groups
+// of L lanes; a group handles one call per step, lane (l % L) + 64*a handles option k.
+// Per call: one 8-byte descriptor (variant, p_base_wrong) and G*4 bytes of the prob row.
+// ------------------------------------------------------------------------------------
+template <int L, int A, bool PAIRS, int U>
+__global__ __launch_bounds__(256) void k_estep_direct(EstepArgs a)
+{
+    static_assert(A == 1 || L == 64, "several accumulators per lane only with 64 lanes per call");
+    constexpr int CPW = 64 / L;
+    const int lane = threadIdx.x & 63;
+    const long long b = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (b >= a.B) return;
+    const int sub = lane / L;
+    const int o0 = lane % L;
+    const int K = a.K, G = a.G;
+
+    int g1[A], g2[A];
+    bool valid[A];
+    int kk[A];
+#pragma unroll
+    for (int s = 0; s < A; s++) {
+        const int k = o0 + 64 * s;
+        valid[s] = k < K;
+        kk[s] = valid[s] ? k : K - 1;
+        if (PAIRS) {
+            const unsigned pr = a.opt_pairs[kk[s]];
+            g1[s] = pr & 0xFFFF;
+            g2[s] = pr >> 16;
+        } else {
+            g1[s] = kk[s];
+            g2[s] = kk[s];
+        }
+    }
+
+    double acc[A];
+#pragma unroll
+    for (int s = 0; s < A; s++) acc[s] = 0.0;
+
+    const long long beg = a.row_ptr[b], end = a.row_ptr[b + 1];
+    for (long long pos = beg; pos < end; pos += CPW * U) {
+        uint2 d[U];
+        bool ok[U];
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            const long long idx = pos + u * CPW + sub;
+            ok[u] = idx < end;
+            d[u] = a.calls[ok[u] ? idx : beg];
+        }
+        float p1[U][A], p2[U][A];
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            const float *row = a.prob + (size_t)d[u].x * G;
+#pragma unroll
+            for (int s = 0; s < A; s++) {
+                p1[u][s] = row[g1[s]];
+                if (PAIRS) p2[u][s] = row[g2[s]];
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            const float e = __uint_as_float(d[u].y);
+            const float keep = 1.0f - e;
+            const float flo = fmaxf(e, 1e-4f);
+#pragma unroll
+            for (int s = 0; s < A; s++) {
+                const float p = PAIRS ? (p1[u][s] + p2[u][s]) * 0.5f : p1[u][s];
+                float t = p * keep;
+                t = t + flo;
+                const float lp = npm::log_f32<false>(t);
+                acc[s] += ok[u] ? (double)lp : 0.0;
+            }
+        }
+    }
+    // groups -> lanes 0..L-1
+#pragma unroll
+    for (int off = L; off < 64; off <<= 1) {
+#pragma unroll
+        for (int s = 0; s < A; s++) acc[s] += shfl_xor_f64(acc[s], off);
+    }
+
+    // epilogue: penalties, optional prior, softmax as scipy evaluates it
+    float lg[A], x[A];
+    float mx = -__builtin_inff();
+#pragma unroll
+    for (int s = 0; s < A; s++) {
+        const double t = (double)a.pen[kk[s]] + acc[s];
+        float l = (float)t;
+        if (a.prior) {
+            const size_t o = (size_t)b * K + kk[s];
+            if (a.prior_dtype == DMX_F32)
+                l = l + ((const float *)a.prior)[o];
+            else
+                l = (float)((double)l + ((const double *)a.prior)[o]);
+        }
+        lg[s] = l;
+        mx = (valid[s] && sub == 0) ? fmaxf(mx, l) : mx;
+    }
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) mx = fmaxf(mx, __shfl_xor(mx, off));
+#pragma unroll
+    for (int s = 0; s < A; s++) x[s] = npm::exp_f32(lg[s] - mx);
+    const float tot = reg_row_sum<A>(x, K, lane);
+#pragma unroll
+    for (int s = 0; s < A; s++) {
+        if (valid[s] && sub == 0) {
+            const size_t o = (size_t)b * K + kk[s];
+            a.logits[o] = lg[s];
+            a.post[o] = x[s] / tot;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------
+// E-step, block form (K > 256).  One 256-thread workgroup per barcode, option k = s*256 + tid.
+// A chunk of C calls is staged in LDS (descriptor scalars + the G-vector of each call's
+// variant), then every thread walks its options reading two LDS words per term.  Consecutive
+// lanes hold consecutive pairs (g1, g2): g1 is (nearly) wave-uniform -> broadcast, g2 is
+// consecutive -> conflict-free.
+// ------------------------------------------------------------------------------------
+template <int A>
+__global__ __launch_bounds__(256) void k_estep_block(EstepArgs a, int C)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const long long b = blockIdx.x;
+    const int K = a.K, G = a.G;
+    // LDS carve: rows [C*G] f32 | keep [C] | floor [C] | vid [C] | red [8]; the softmax reuses
+    // the front of the buffer for K floats (launcher sizes smem for the larger of the two).
+    float *sh_rows = (float *)smem;
+    float *sh_keep = sh_rows + (size_t)C * G;
+    float *sh_floor = sh_keep + C;
+    int *sh_vid = (int *)(sh_floor + C);
+
+    unsigned pr[A];
+#pragma unroll
+    for (int s = 0; s < A; s++) {
+        const int k = s * 256 + tid;
+        pr[s] = a.opt_pairs[k < K ? k : K - 1];
+    }
+    double acc[A];
+#pragma unroll
+    for (int s = 0; s < A; s++) acc[s] = 0.0;
+
+    const long long beg = a.row_ptr[b], end = a.row_ptr[b + 1];
+    for (long long pos = beg; pos < end; pos += C) {
+        const int n = (int)((end - pos) < C ? (end - pos) : C);
+        __syncthreads();
+        if (tid < n) {
+            const uint2 d = a.calls[pos + tid];
+            const float e = __uint_as_float(d.y);
+            sh_vid[tid] = (int)d.x;
+            sh_keep[tid] = 1.0f - e;
+            sh_floor[tid] = fmaxf(e, 1e-4f);
+        }
+        __syncthreads();
+        for (int i = tid; i < n * G; i += 256) {
+            const int c = i / G, g = i - c * G;
+            sh_rows[i] = a.prob[(size_t)sh_vid[c] * G + g];
+        }
+        __syncthreads();
+        for (int c = 0; c < n; c++) {
+            const float keep = sh_keep[c], flo = sh_floor[c];
+            const float *row = sh_rows + c * G;
+#pragma unroll
+            for (int s = 0; s < A; s++) {
+                const float p = (row[pr[s] & 0xFFFF] + row[pr[s] >> 16]) * 0.5f;
+                float t = p * keep;
+                t = t + flo;
+                acc[s] += (double)npm::log_f32<false>(t);
+            }
+        }
+    }
+    __syncthreads();
+
+    // logits -> LDS, block max, exp, numpy-ordered sum by wave 0, divide
+    float *sh_x = (float *)smem;  // K floats
+    float *sh_red = sh_x + K;     // 8 floats
+    float mx = -__builtin_inff();
+    float lg[A];
+#pragma unroll
+    for (int s = 0; s < A; s++) {
+        const int k = s * 256 + tid;
+        if (k < K) {
+            const double t = (double)a.pen[k] + acc[s];
+            float l = (float)t;
+            if (a.prior) {
+                const size_t o = (size_t)b * K + k;
+                if (a.prior_dtype == DMX_F32)
+                    l = l + ((const float *)a.prior)[o];
+                else
+                    l = (float)((double)l + ((const double *)a.prior)[o]);
+            }
+            lg[s] = l;
+            mx = fmaxf(mx, l);
+        } else {
+            lg[s] = -__builtin_inff();
+        }
+    }
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) mx = fmaxf(mx, __shfl_xor(mx, off));
+    if (lane == 0) sh_red[wave] = mx;
+    __syncthreads();
+    mx = fmaxf(fmaxf(sh_red[0], sh_red[1]), fmaxf(sh_red[2], sh_red[3]));
+    float x[A];
+#pragma unroll
+    for (int s = 0; s < A; s++) {
+        const int k = s * 256 + tid;
+        x[s] = npm::exp_f32(lg[s] - mx);
+        if (k < K) sh_x[k] = x[s];
+    }
+    __syncthreads();
+    if (wave == 0) {
+        const float tot = npm::row_sum_wave(sh_x, K, lane);
+        if (lane == 0) sh_red[4] = tot;
+    }
+    __syncthreads();
+    const float tot = sh_red[4];
+#pragma unroll
+    for (int s = 0; s < A; s++) {
+        const int k = s * 256 + tid;
+        if (k < K) {
+            const size_t o = (size_t)b * K + k;
+            a.logits[o] = lg[s];
+            a.post[o] = x[s] / tot;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------
+// M-step.  One wavefront per work item (a run of <= ITEM_CALLS consecutive CSC calls of one
+// variant); lanes = genotypes; gathers the singlet columns of the posterior row of each call's
+// barcode; float64 accumulation in CSC (= reference bincount) order; float64 partial per item.
+// ------------------------------------------------------------------------------------
+template <int L, int A, int U, bool SQUARE>
+__global__ __launch_bounds__(256) void k_mstep(MstepArgs a)
+{
+    static_assert(A == 1 || L == 64, "several accumulators per lane only with 64 lanes per call");
+    constexpr int CPW = 64 / L;
+    const int lane = threadIdx.x & 63;
+    const long long item = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (item >= a.n_items) return;
+    const int sub = lane / L;
+    const int g0 = lane % L;
+    const int G = a.G;
+    int gg[A];
+#pragma unroll
+    for (int s = 0; s < A; s++) {
+        const int g = g0 + 64 * s;
+        gg[s] = g < G ? g : G - 1;
+    }
+    double acc[A];
+#pragma unroll
+    for (int s = 0; s < A; s++) acc[s] = 0.0;
+
+    const long long beg = a.item_start[item], end = beg + a.item_len[item];
+    for (long long pos = beg; pos < end; pos += CPW * U) {
+        uint2 d[U];
+        bool ok[U];
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            const long long idx = pos + u * CPW + sub;
+            ok[u] = idx < end;
+            d[u] = a.calls[ok[u] ? idx : beg];
+        }
+        float p[U][A];
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            const float *row = a.post + (size_t)d[u].x * a.K;
+#pragma unroll
+            for (int s = 0; s < A; s++) p[u][s] = row[gg[s]];
+        }
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            const float keep = 1.0f - __uint_as_float(d[u].y);
+#pragma unroll
+            for (int s = 0; s < A; s++) {
+                float c = p[u][s] * keep;
+                c = SQUARE ? c * c : powf(c, a.power);
+                acc[s] += ok[u] ? (double)c : 0.0;
+            }
+        }
+    }
+#pragma unroll
+    for (int off = L; off < 64; off <<= 1) {
+#pragma unroll
+        for (int s = 0; s < A; s++) acc[s] += shfl_xor_f64(acc[s], off);
+    }
+#pragma unroll
+    for (int s = 0; s < A; s++) {
+        const int g = g0 + 64 * s;
+        if (sub == 0 && g < G) a.partial[(size_t)item * G + g] = acc[s];
+    }
+}
+
+// sums the item partials of each variant in item order; writes float32 (single GPU) or the
+// float64 total that goes into the all-reduce
+__global__ __launch_bounds__(256) void k_mcombine(const double *__restrict__ partial,
+                                                  const long long *__restrict__ item_ptr, long long V, int G,
+                                                  float *__restrict__ add32, double *__restrict__ add64)
+{
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= V * G) return;
+    const long long v = i / G;
+    const int g = (int)(i - v * G);
+    double s = 0.0;
+    for (long long it = item_ptr[v]; it < item_ptr[v + 1]; it++) s += partial[(size_t)it * G + g];
+    if (add64) add64[i] = s;
+    if (add32) add32[i] = (float)s;
+}
+
+__global__ __launch_bounds__(256) void k_f64_to_f32(const double *__restrict__ in, float *__restrict__ out, long long n)
+{
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = (float)in[i];
+}
+
+__global__ __launch_bounds__(256) void k_f32_to_f64(const float *__restrict__ in, double *__restrict__ out, long long n)
+{
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = (double)in[i];
+}
+
+// per-barcode argmax of the posterior (first maximum, like DataFrame.idxmax / np.argmax)
+__global__ __launch_bounds__(256) void k_assign(const float *__restrict__ post, long long B, int K,
+                                                int *__restrict__ best, float *__restrict__ best_p)
+{
+    const int lane = threadIdx.x & 63;
+    const long long b = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (b >= B) return;
+    const float *row = post + (size_t)b * K;
+    float bv = -__builtin_inff();
+    int bi = 0x7FFFFFFF;
+    for (int k = lane; k < K; k += 64) {
+        const float v = row[k];
+        if (v > bv) {
+            bv = v;
+            bi = k;
+        }
+    }
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const float ov = __shfl_xor(bv, off);
+        const int oi = __shfl_xor(bi, off);
+        if (ov > bv || (ov == bv && oi < bi)) {
+            bv = ov;
+            bi = oi;
+        }
+    }
+    if (lane == 0) {
+        best[b] = bi;
+        best_p[b] = bv;
+    }
+}
+
+// ------------------------------------------------------------------------------------
+// self-test kernels for the numpy-exact float32 building blocks
+// ------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_test_log(const float *in, float *out, long long n)
+{
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = npm::log_f32<true>(in[i]);
+}
+
+__global__ __launch_bounds__(256) void k_test_exp(const float *in, float *out, long long n)
+{
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = npm::exp_f32(in[i]);
+}
+
+// one wave per row, row staged through global memory (in -> out in place semantics)
+__global__ __launch_bounds__(64) void k_test_softmax(const float *in, float *out, long long rows, int cols)
+{
+    const long long r = blockIdx.x;
+    const int lane = threadIdx.x;
+    const float *x = in + (size_t)r * cols;
+    float *y = out + (size_t)r * cols;
+    float mx = -__builtin_inff();
+    for (int c = lane; c < cols; c += 64) mx = fmaxf(mx, x[c]);
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) mx = fmaxf(mx, __shfl_xor(mx, off));
+    for (int c = lane; c < cols; c += 64) y[c] = npm::exp_f32(x[c] - mx);
+    __threadfence_block();
+    __syncthreads();
+    const float tot = npm::row_sum_wave(y, cols, lane);
+    __syncthreads();
+    for (int c = lane; c < cols; c += 64) y[c] = y[c] / tot;
+}
+
+// ------------------------------------------------------------------------------------
+// launchers
+// ------------------------------------------------------------------------------------
+static inline unsigned blocks_for(long long n, int per_block) { return (unsigned)((n + per_block - 1) / per_block); }
+
+hipError_t launch_probs_from_betas(hipStream_t st, const float *prior, const float *addition, const int *v2snp,
+                                   const int *snp_ptr, const int *snp_vars, long long V, int G, float lo, float hi,
+                                   float *prob)
+{
+    if (V * G == 0) return hipSuccess;
+    hipLaunchKernelGGL(k_probs_from_betas, dim3(blocks_for(V * G, 256)), dim3(256), 0, st, prior, addition, v2snp,
+                       snp_ptr, snp_vars, V, G, lo, hi, prob);
+    return hipGetLastError();
+}
+
+template <int L, int A, int U>
+static void launch_direct(hipStream_t st, const EstepArgs &a, bool pairs)
+{
+    const dim3 grid(blocks_for(a.B, 4)), block(256);
+    if (pairs)
+        hipLaunchKernelGGL((k_estep_direct<L, A, true, U>), grid, block, 0, st, a);
+    else
+        hipLaunchKernelGGL((k_estep_direct<L, A, false, U>), grid, block, 0, st, a);
+}
+
+template <int A>
+static hipError_t launch_block(hipStream_t st, const EstepArgs &a)
+{
+    int C = 16384 / (4 * a.G);
+    C = C < 8 ? 8 : (C > 128 ? 128 : C);
+    size_t stage = (size_t)C * a.G * 4 + (size_t)C * 12;
+    size_t soft = (size_t)a.K * 4 + 64;
+    size_t bytes = stage > soft ? stage : soft;
+    bytes = (bytes + 15) & ~size_t(15);
+    hipError_t e = hipFuncSetAttribute((const void *)k_estep_block<A>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                       (int)bytes);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL((k_estep_block<A>), dim3((unsigned)a.B), dim3(256), bytes, st, a, C);
+    return hipGetLastError();
+}
+
+hipError_t launch_estep(hipStream_t st, const EstepArgs &a, bool pairs)
+{
+    if (a.B == 0) return hipSuccess;
+    const int K = a.K;
+    if (K <= 256) {
+        if (K <= 4) launch_direct<4, 1, 8>(st, a, pairs);
+        else if (K <= 8) launch_direct<8, 1, 8>(st, a, pairs);
+        else if (K <= 16) launch_direct<16, 1, 8>(st, a, pairs);
+        else if (K <= 32) launch_direct<32, 1, 8>(st, a, pairs);
+        else if (K <= 64) launch_direct<64, 1, 8>(st, a, pairs);
+        else if (K <= 128) launch_direct<64, 2, 4>(st, a, pairs);
+        else launch_direct<64, 4, 2>(st, a, pairs);
+        return hipGetLastError();
+    }
+    if (!pairs) return hipErrorInvalidValue;  // K = G > 256 singlets: not supported (checked by the caller)
+    const int need = (K + 255) / 256;
+    if (need <= 2) return launch_block<2>(st, a);
+    if (need <= 4) return launch_block<4>(st, a);
+    if (need <= 8) return launch_block<8>(st, a);
+    if (need <= 16) return launch_block<16>(st, a);
+    if (need <= 33) return launch_block<33>(st, a);
+    if (need <= 65) return launch_block<65>(st, a);
+    return hipErrorInvalidValue;
+}
+
+template <int L, int A, int U>
+static void launch_m(hipStream_t st, const MstepArgs &a)
+{
+    if (a.square)
+        hipLaunchKernelGGL((k_mstep<L, A, U, true>), dim3(blocks_for(a.n_items, 4)), dim3(256), 0, st, a);
+    else
+        hipLaunchKernelGGL((k_mstep<L, A, U, false>), dim3(blocks_for(a.n_items, 4)), dim3(256), 0, st, a);
+}
+
+hipError_t launch_mstep(hipStream_t st, const MstepArgs &a)
+{
+    if (a.n_items == 0) return hipSuccess;
+    const int G = a.G;
+    if (G <= 4) launch_m<4, 1, 8>(st, a);
+    else if (G <= 8) launch_m<8, 1, 8>(st, a);
+    else if (G <= 16) launch_m<16, 1, 8>(st, a);
+    else if (G <= 32) launch_m<32, 1, 8>(st, a);
+    else if (G <= 64) launch_m<64, 1, 8>(st, a);
+    else if (G <= 128) launch_m<64, 2, 4>(st, a);
+    else if (G <= 256) launch_m<64, 4, 2>(st, a);
+    else return hipErrorInvalidValue;
+    return hipGetLastError();
+}
+
+hipError_t launch_mcombine(hipStream_t st, const double *partial, const long long *item_ptr, long long V, int G,
+                           float *add32, double *add64)
+{
+    if (V * G == 0) return hipSuccess;
+    hipLaunchKernelGGL(k_mcombine, dim3(blocks_for(V * G, 256)), dim3(256), 0, st, partial, item_ptr, V, G, add32, add64);
+    return hipGetLastError();
+}
+
+hipError_t launch_f64_to_f32(hipStream_t st, const double *in, float *out, long long n)
+{
+    if (n == 0) return hipSuccess;
+    hipLaunchKernelGGL(k_f64_to_f32, dim3(blocks_for(n, 256)), dim3(256), 0, st, in, out, n);
+    return hipGetLastError();
+}
+
+hipError_t launch_f32_to_f64(hipStream_t st, const float *in, double *out, long long n)
+{
+    if (n == 0) return hipSuccess;
+    hipLaunchKernelGGL(k_f32_to_f64, dim3(blocks_for(n, 256)), dim3(256), 0, st, in, out, n);
+    return hipGetLastError();
+}
+
+hipError_t launch_assign(hipStream_t st, const float *post, long long B, int K, int *best, float *best_p)
+{
+    if (B == 0) return hipSuccess;
+    hipLaunchKernelGGL(k_assign, dim3(blocks_for(B, 4)), dim3(256), 0, st, post, B, K, best, best_p);
+    return hipGetLastError();
+}
+
+hipError_t launch_test_log(hipStream_t st, const float *in, float *out, long long n)
+{
+    if (n == 0) return hipSuccess;
+    hipLaunchKernelGGL(k_test_log, dim3(blocks_for(n, 256)), dim3(256), 0, st, in, out, n);
+    return hipGetLastError();
+}
+
+hipError_t launch_test_exp(hipStream_t st, const float *in, float *out, long long n)
+{
+    if (n == 0) return hipSuccess;
+    hipLaunchKernelGGL(k_test_exp, dim3(blocks_for(n, 256)), dim3(256), 0, st, in, out, n);
+    return hipGetLastError();
+}
+
+hipError_t launch_test_softmax(hipStream_t st, const float *in, float *out, long long rows, int cols)
+{
+    if (rows == 0) return hipSuccess;
+    hipLaunchKernelGGL(k_test_softmax, dim3((unsigned)rows), dim3(64), 0, st, in, out, rows, cols);
+    return hipGetLastError();
+}
+
+}  // namespace dmx

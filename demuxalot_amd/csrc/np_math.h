@@ -1,0 +1,180 @@
+// np_math.h -- device-side float32 building blocks with numpy's exact roundings.
+//
+// The reference evaluates log / exp / row sums with numpy on float32 arrays
+// (demuxalot/demux.py:261 np.log; :101,:152 scipy softmax = np.exp + np.sum).  numpy's
+// x86 float32 kernels are rational minimax approximations evaluated with fused
+// multiply-adds (published in numpy's loops_exponent_log.dispatch.c.src); they are not
+// correctly rounded (up to 3.83 ulp for log), so matching the reference bit for bit
+// means repeating the same operation sequence.  gfx950 has everything needed in
+// hardware: v_frexp_mant/exp, v_fma_f32, IEEE float32 division, v_ldexp_f32.
+//
+// Compile with -ffp-contract=off: every fused step below is an explicit fmaf and the
+// compiler must not add or remove fusions.
+#pragma once
+#include <hip/hip_runtime.h>
+
+namespace npm {
+
+// SPECIALS = false is the hot-path form: its argument is finite and >= 1e-4 by construction of
+// the E-step term (a NaN input still comes out NaN through the arithmetic).
+template <bool SPECIALS = true>
+__device__ __forceinline__ float log_f32(float v)
+{
+    const float P0 = 0.000000000000000000000e+00f, P1 = 9.999999999999998702752e-01f,
+                P2 = 2.112677543073053063722e+00f, P3 = 1.480000633576506585156e+00f,
+                P4 = 3.808837741388407920751e-01f, P5 = 2.589979117907922693523e-02f;
+    const float Q0 = 1.000000000000000000000e+00f, Q1 = 2.612677543073109236779e+00f,
+                Q2 = 2.453006071784736363091e+00f, Q3 = 9.864942958519418960339e-01f,
+                Q4 = 1.546476374983906719538e-01f, Q5 = 5.875095403124574342950e-03f;
+    const float LN2 = 0.693147180559945309417232121458176568f;
+    const float RSQRT2 = 0.707106781186547524400844362104849039f;
+
+    float m = __builtin_amdgcn_frexp_mantf(v);  // [0.5, 1)
+    float kf = (float)__builtin_amdgcn_frexp_expf(v);
+    const bool low = m <= RSQRT2;
+    m = low ? m + m : m;
+    kf = low ? kf - 1.0f : kf;
+    const float r = m - 1.0f;
+    float num = __builtin_fmaf(P5, r, P4);
+    num = __builtin_fmaf(num, r, P3);
+    num = __builtin_fmaf(num, r, P2);
+    num = __builtin_fmaf(num, r, P1);
+    num = __builtin_fmaf(num, r, P0);
+    float den = __builtin_fmaf(Q5, r, Q4);
+    den = __builtin_fmaf(den, r, Q3);
+    den = __builtin_fmaf(den, r, Q2);
+    den = __builtin_fmaf(den, r, Q1);
+    den = __builtin_fmaf(den, r, Q0);
+    const float q = num / den;  // IEEE-754 division (-fhip-fp32-correctly-rounded-divide-sqrt)
+    float res = __builtin_fmaf(kf, LN2, q);
+    if (SPECIALS) {  // special values, as numpy returns them
+        res = (v == 0.0f) ? -__builtin_inff() : res;
+        res = (v < 0.0f) ? -__builtin_nanf("") : res;
+        res = (v != v || v == __builtin_inff()) ? v : res;
+    }
+    return res;
+}
+
+__device__ __forceinline__ float exp_f32(float v)
+{
+    const float P0 = 9.999999999980870924916e-01f, P1 = 7.257664613233124478488e-01f,
+                P2 = 2.473615434895520810817e-01f, P3 = 5.114512081637298353406e-02f,
+                P4 = 6.757896990527504603057e-03f, P5 = 5.082762527590693718096e-04f;
+    const float Q0 = 1.000000000000000000000e+00f, Q1 = -2.742335390411667452936e-01f,
+                Q2 = 2.159509375685829852307e-02f;
+    const float CW_HI = -6.93145752e-1f, CW_LO = -1.42860677e-6f;
+    const float LOG2E = 1.442695040888963407359924681001892137f;
+    const float MAGIC = 0x1.800000p+23f;
+    const float XMAX = 88.72283935546875f, XMIN = -103.97208404541015625f;
+
+    const bool too_big = v >= XMAX, too_small = v <= XMIN, is_nan = v != v;
+    const float x = (too_big || too_small || is_nan) ? 0.0f : v;
+    float k = x * LOG2E;
+    k = k + MAGIC;  // round to nearest integer through the 1.5*2^23 constant
+    k = k - MAGIC;
+    float r = __builtin_fmaf(k, CW_HI, x);
+    r = __builtin_fmaf(k, CW_LO, r);
+    float num = __builtin_fmaf(P5, r, P4);
+    num = __builtin_fmaf(num, r, P3);
+    num = __builtin_fmaf(num, r, P2);
+    num = __builtin_fmaf(num, r, P1);
+    num = __builtin_fmaf(num, r, P0);
+    float den = __builtin_fmaf(Q2, r, Q1);
+    den = __builtin_fmaf(den, r, Q0);
+    const float q = num / den;
+    float res = __builtin_amdgcn_ldexpf(q, (int)k);  // v_ldexp_f32: one rounding, subnormals kept
+    res = too_small ? 0.0f : res;
+    res = too_big ? __builtin_inff() : res;
+    res = is_nan ? v : res;
+    return res;
+}
+
+// ---------------------------------------------------------------------------------------
+// np.sum over a contiguous float32 row, numpy's association:
+//   chunks of 8192 elements added left to right; a chunk is summed pairwise: blocks of
+//   <= 128 elements use 8 interleaved partial sums r[j] (j = i mod 8) combined as
+//   ((r0+r1)+(r2+r3))+((r4+r5)+(r6+r7)) followed by the <8 leftover elements in order;
+//   longer blocks split at n/2 rounded down to a multiple of 8.
+// ---------------------------------------------------------------------------------------
+
+// Leaf (8 <= n <= 128) summed by lanes 0..7 of the calling wave in parallel; a[] may be LDS
+// or global.  All 64 lanes must call; the result is valid in lanes 0..7.
+__device__ __forceinline__ float leaf_sum_wave8(const float *a, int n, int lane)
+{
+    const int j = lane & 7;
+    const int nfull = n - (n & 7);
+    float r = a[j];
+    for (int i = 8 + j; i < nfull; i += 8) r += a[i];
+    // IEEE addition is commutative, so xor-butterflies give exactly the bracketed tree
+    r = r + __shfl_xor(r, 1);
+    r = r + __shfl_xor(r, 2);
+    r = r + __shfl_xor(r, 4);
+    for (int i = nfull; i < n; i++) r += a[i];
+    return r;
+}
+
+// Serial version for tiny rows (n < 8): starts from +0 like numpy.
+__device__ __forceinline__ float short_sum(const float *a, int n)
+{
+    float res = 0.0f;
+    for (int i = 0; i < n; i++) res += a[i];
+    return res;
+}
+
+// Pairwise sum of a[0..n) for n <= 8192 executed by one whole wave (uniform control flow).
+// Explicit stack instead of recursion: depth <= 7 for n <= 8192.
+__device__ __forceinline__ float chunk_sum_wave(const float *a, int n, int lane)
+{
+    if (n < 8) return short_sum(a, n);
+    if (n <= 128) return leaf_sum_wave8(a, n, lane);
+    // post-order traversal of the split tree
+    int st_start[16], st_len[16];
+    unsigned char st_state[16];
+    float st_left[16];
+    int sp = 0;
+    st_start[0] = 0;
+    st_len[0] = n;
+    st_state[0] = 0;
+    float ret = 0.0f;
+    while (sp >= 0) {
+        const int s = st_start[sp], len = st_len[sp];
+        if (len <= 128) {
+            ret = (len < 8) ? short_sum(a + s, len) : leaf_sum_wave8(a + s, len, lane);
+            sp--;
+            continue;
+        }
+        int half = len / 2;
+        half -= half % 8;
+        if (st_state[sp] == 0) {
+            st_state[sp] = 1;
+            sp++;
+            st_start[sp] = s;
+            st_len[sp] = half;
+            st_state[sp] = 0;
+        } else if (st_state[sp] == 1) {
+            st_left[sp] = ret;
+            st_state[sp] = 2;
+            sp++;
+            st_start[sp] = s + half;
+            st_len[sp] = len - half;
+            st_state[sp] = 0;
+        } else {
+            ret = st_left[sp] + ret;
+            sp--;
+        }
+    }
+    return ret;
+}
+
+// Full np.sum(row) by one wave.
+__device__ __forceinline__ float row_sum_wave(const float *a, int n, int lane)
+{
+    float res = 0.0f;
+    for (int s = 0; s < n; s += 8192) {
+        const int m = (n - s) < 8192 ? (n - s) : 8192;
+        res = res + chunk_sum_wave(a + s, m, lane);
+    }
+    return res;
+}
+
+}  // namespace npm

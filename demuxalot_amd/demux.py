@@ -1,0 +1,385 @@
+"""Demultiplexer: the reference's EM front-end (demuxalot/demux.py) over the MI355X kernels.
+
+Same static-method surface, argument meaning, output conventions and assertion behaviour as the
+reference class, so `from demuxalot_amd import Demultiplexer` can replace
+`from demuxalot import Demultiplexer` behind an unchanged front-end (BAM scanning, genotype
+import).  Inputs are duck-typed: the reference's own CompressedSNPCalls / ProbabilisticGenotypes /
+BarcodeHandler objects work as well as this package's mirrors.
+
+What runs where
+  host, C++  (libdemux_hip.so, dmx_pack_calls_host): variant matching, de-duplication with float32
+             products, CSR/CSC derivation                      -> demux.py:276-300, 332-365
+  host, numpy: regularised prior betas (O(V*G), one-off)       -> demux.py:367-388
+  GPU (HIP):  beta -> probability normalisation                -> demux.py:267-274
+              per-barcode log-likelihood accumulation + softmax -> demux.py:246-265, :101, :152
+              squared-posterior beta update (+ RCCL all-reduce) -> demux.py:113-118
+There is no CPU fallback for the GPU steps.
+"""
+from typing import Dict, Tuple
+
+import numpy as np
+import pandas as pd
+
+from . import _lib
+from .device import get_context
+
+_MOLECULE_CALL_DTYPE = [('variant_id', 'int32'), ('snp_id', 'int32'), ('compressed_cb', 'int32'),
+                        ('molecule_id', 'int32'), ('p_base_wrong', 'float32'), ('p_molecule_aligned_wrong', 'float32')]
+_BASES = {'A': 0, 'C': 1, 'G': 2, 'T': 3, 'N': 4}
+
+
+class _Packed:
+    """Result of the host-side repack: what the device needs plus what pack_calls returns."""
+    __slots__ = ('v2snp', 'betas', 'variant_id', 'compressed_cb', 'p_base_wrong', 'variant_count',
+                 'molecule_calls', 'n_molecule_calls')
+
+
+def _flatten_inputs(chromosome2compressed_snp_calls, genotypes, want_molecule_table):
+    """var2varid -> per-row key arrays; per-chromosome call containers -> flat call arrays."""
+    n_variants = genotypes.n_variants
+    chrom_index = {}
+    var_chrom = np.zeros(n_variants, dtype=np.int32)
+    var_pos = np.zeros(n_variants, dtype=np.int32)
+    var_base = np.zeros(n_variants, dtype=np.uint8)
+    seen = np.zeros(n_variants, dtype=bool)
+    for (chrom, pos, base), row in genotypes.var2varid.items():
+        assert 0 <= row < n_variants and not seen[row], 'var2varid rows must enumerate 0..n_variants-1'
+        seen[row] = True
+        var_chrom[row] = chrom_index.setdefault(chrom, len(chrom_index))
+        var_pos[row] = pos
+        var_base[row] = _BASES[base]
+    assert seen.all(), 'var2varid rows must enumerate 0..n_variants-1'  # demux.py:317
+
+    parts = []
+    n_expected = n_taken = 0
+    for chrom, container in chromosome2compressed_snp_calls.items():
+        n = container.n_snp_calls
+        n_expected += n
+        if chrom not in chrom_index:
+            continue  # demux.py:339-341: no SNPs on this chromosome (the cursor is not advanced)
+        calls = container.snp_calls[:n]
+        molecules = container.molecules[:container.n_molecules]
+        mol = calls['molecule_index']
+        part = dict(chrom=np.full(n, chrom_index[chrom], dtype=np.int32), pos=calls['snp_position'],
+                    base=calls['base_index'], cb=molecules['compressed_cb'][mol], p=calls['p_base_wrong'])
+        if want_molecule_table:
+            part['mol'] = mol
+            part['pmis'] = molecules['p_group_misaligned'][mol]
+        parts.append(part)
+        n_taken += n
+    assert n_taken == n_expected  # demux.py:359 (fires when a chromosome with calls has no variants)
+
+    def cat(name, dtype):
+        if not parts:
+            return np.zeros(0, dtype=dtype)
+        return np.ascontiguousarray(np.concatenate([p[name] for p in parts]), dtype=dtype)
+
+    flat = dict(chrom=cat('chrom', np.int32), pos=cat('pos', np.int32), base=cat('base', np.uint8),
+                cb=cat('cb', np.int32), p=cat('p', np.float32))
+    if want_molecule_table:
+        flat['mol'] = cat('mol', np.int32)
+        flat['pmis'] = cat('pmis', np.float32)
+    return (var_chrom, var_pos, var_base), flat
+
+
+def _prior_betas(genotypes, v2snp, mol_per_variant, add_data_prior):
+    """demux.py:367-388. beta' = beta + f32((1 + [data] n_mol/(n_mol_snp + 100)
+    + betasum/(betasum_snp + 100)) * default_prior)[:, None]; float64 per-SNP sums."""
+    betas = genotypes.get_betas()
+    assert np.all(betas >= 0), 'bad genotypes provided, negative betas appeared'
+
+    def share_within_snp(per_variant, regularization):
+        assert len(per_variant) == len(v2snp)
+        per_snp = np.bincount(v2snp, weights=per_variant)[v2snp] if len(v2snp) else np.zeros(0)
+        return per_variant / (per_snp + regularization)
+
+    scale = 1.
+    if add_data_prior:
+        scale = scale + share_within_snp(mol_per_variant, 100.)
+    scale = scale + share_within_snp(betas.sum(axis=1), 100.)
+    addition = scale[:, np.newaxis] * genotypes.default_prior
+    out = betas + addition.astype(betas.dtype)
+    out.flags.writeable = False
+    return out
+
+
+def _pack(chromosome2compressed_snp_calls, genotypes, add_data_prior, want_molecule_table=False) -> _Packed:
+    lib = _lib.load()
+    (var_chrom, var_pos, var_base), flat = _flatten_inputs(
+        chromosome2compressed_snp_calls, genotypes, want_molecule_table)
+    v2snp = genotypes.get_snp_ids_for_variants()
+    assert np.all(v2snp >= 0)
+    n_variants, n_calls = len(var_pos), len(flat['pos'])
+
+    call_variant = np.empty(n_calls, dtype=np.int32) if want_molecule_table else None
+    out_variant = np.empty(n_calls, dtype=np.int32)
+    out_cb = np.empty(n_calls, dtype=np.int32)
+    out_p = np.empty(n_calls, dtype=np.float32)
+    out_count = np.empty(n_calls, dtype=np.int64)
+    mol_per_variant = np.zeros(n_variants, dtype=np.int64)
+    import ctypes
+    n_matched, n_unique = ctypes.c_int64(0), ctypes.c_int64(0)
+    _lib.check(lib.dmx_pack_calls_host(
+        n_variants, _lib.ptr(var_chrom), _lib.ptr(var_pos), _lib.ptr(var_base),
+        n_calls, _lib.ptr(flat['chrom']), _lib.ptr(flat['pos']), _lib.ptr(flat['base']), _lib.ptr(flat['cb']),
+        _lib.ptr(flat['p']), _lib.ptr(call_variant), ctypes.byref(n_matched), ctypes.byref(n_unique),
+        _lib.ptr(out_variant), _lib.ptr(out_cb), _lib.ptr(out_p), _lib.ptr(out_count), _lib.ptr(mol_per_variant)))
+    n = n_unique.value
+
+    packed = _Packed()
+    packed.v2snp = v2snp
+    packed.variant_id = out_variant[:n].copy()
+    packed.compressed_cb = out_cb[:n].copy()
+    packed.p_base_wrong = out_p[:n].copy()
+    packed.variant_count = out_count[:n].copy()
+    packed.n_molecule_calls = n_matched.value
+    packed.betas = _prior_betas(genotypes, v2snp, mol_per_variant, add_data_prior)
+    packed.molecule_calls = None
+    if want_molecule_table:
+        keep = call_variant != -1
+        table = np.zeros(int(keep.sum()), dtype=_MOLECULE_CALL_DTYPE)
+        table['variant_id'] = call_variant[keep]
+        table['snp_id'] = v2snp[call_variant[keep]]
+        table['compressed_cb'] = flat['cb'][keep]
+        table['molecule_id'] = flat['mol'][keep]
+        table['p_base_wrong'] = flat['p'][keep]
+        table['p_molecule_aligned_wrong'] = flat['pmis'][keep]
+        packed.molecule_calls = table
+    return packed
+
+
+def _option_names(genotype_names, doublet_prior):
+    """Column names: singlets, then 'A+B' for A before B (demux.py:175-191)."""
+    names = list(genotype_names)
+    if doublet_prior != 0:
+        assert doublet_prior > 0
+        names = names + [f'{a}+{b}' for i, a in enumerate(genotype_names) for b in genotype_names[i + 1:]]
+    return names
+
+
+class Demultiplexer:
+    """
+    Demultiplexer that can infer (learn) additional information about genotypes to achieve better quality.
+    GPU-backed; see the module docstring for what runs where.
+    """
+    # same knobs as the reference class (demux.py:30-32)
+    contribution_power = 2.
+    aggregate_on_snps = False
+    compensation_during_computing_barcode_logits = 0.5
+
+    # ------------------------------------------------------------------------------------
+    @staticmethod
+    def learn_genotypes(chromosome2compressed_snp_calls,
+                        genotypes,
+                        barcode_handler,
+                        n_iterations=5,
+                        p_genotype_clip=0.01,
+                        doublet_prior=0.,
+                        barcode_prior_logits: np.ndarray = None,
+                        ) -> Tuple[object, pd.DataFrame]:
+        """
+        Learn genotypes starting from an initial guess (demux.py:35-66).
+        :return: learnt genotypes (a copy of `genotypes` with betas = raw betas + the addition used by the
+            last E-step) and the barcode-to-donor posteriors of the last iteration.
+        The whole loop runs on the GPU (dmx_em); only the last iteration's results come back.
+        """
+        Demultiplexer._check_not_aggregating()
+        assert 0 <= doublet_prior < 1
+        n_genotypes = genotypes.n_genotypes
+        penalties = Demultiplexer._doublet_penalties(n_genotypes, doublet_prior)
+        if barcode_prior_logits is not None:
+            assert barcode_prior_logits.shape == (barcode_handler.n_barcodes, len(penalties)), 'wrong shape of priors'
+        assert n_iterations >= 1, 'n_iterations should be positive'  # the reference fails to unpack an empty run
+
+        packed = _pack(chromosome2compressed_snp_calls, genotypes, add_data_prior=True)
+        ctx = Demultiplexer._upload(packed, barcode_handler.n_barcodes, n_genotypes)
+        _logits, probs, addition = ctx.em(
+            n_iterations, p_genotype_clip, penalties, with_doublets=doublet_prior != 0,
+            prior_logits=barcode_prior_logits, contribution_power=Demultiplexer.contribution_power,
+            fetch_logits=False)
+        probs_df = pd.DataFrame(data=probs, index=barcode_handler.ordered_barcodes,
+                                columns=_option_names(genotypes.genotype_names, doublet_prior))
+        learnt_genotypes = genotypes._with_betas(genotypes.get_betas() + addition)
+        return learnt_genotypes, probs_df
+
+    @staticmethod
+    def staged_genotype_learning(chromosome2compressed_snp_calls,
+                                 genotypes,
+                                 barcode_handler,
+                                 n_iterations=5,
+                                 p_genotype_clip=0.01,
+                                 doublet_prior=0.,
+                                 barcode_prior_logits: np.ndarray = None):
+        """Generator over EM iterations (demux.py:69-118): yields (posterior DataFrame, debug dict with
+        'barcode_logits', 'genotype_prior', 'genotype_addition'), aligned as in the reference: the yielded
+        addition is the one the iteration's E-step used."""
+        Demultiplexer._check_not_aggregating()
+        assert 0 <= doublet_prior < 1
+        n_genotypes = genotypes.n_genotypes
+        penalties = Demultiplexer._doublet_penalties(n_genotypes, doublet_prior)
+        if barcode_prior_logits is not None:
+            assert barcode_prior_logits.shape == (barcode_handler.n_barcodes, len(penalties)), 'wrong shape of priors'
+
+        packed = _pack(chromosome2compressed_snp_calls, genotypes, add_data_prior=True)
+        ctx = Demultiplexer._upload(packed, barcode_handler.n_barcodes, n_genotypes)
+        column_names = _option_names(genotypes.genotype_names, doublet_prior)
+        genotype_addition = np.zeros_like(packed.betas)
+        ctx.set_addition(None)
+
+        for iteration in range(n_iterations):
+            ctx.probs_from_betas(p_genotype_clip, fetch=False)
+            prior = barcode_prior_logits if iteration == 0 else None
+            logits, probs = ctx.estep(penalties, with_doublets=doublet_prior != 0, prior_logits=prior)
+            probs_df = pd.DataFrame(data=probs, index=barcode_handler.ordered_barcodes, columns=column_names)
+            yield probs_df, {
+                'barcode_logits': logits,
+                'genotype_prior': packed.betas,
+                'genotype_addition': genotype_addition,
+            }
+            genotype_addition = ctx.mstep(Demultiplexer.contribution_power)
+
+    @staticmethod
+    def predict_posteriors(chromosome2compressed_snp_calls,
+                           genotypes,
+                           barcode_handler,
+                           p_genotype_clip=0.01,
+                           doublet_prior=0.35):
+        """One P + E pass (demux.py:120-156). Returns (logits_df, probs_df), rows in
+        barcode_handler.ordered_barcodes order, index named 'BARCODE'."""
+        Demultiplexer._check_not_aggregating()
+        penalties = Demultiplexer._doublet_penalties(genotypes.n_genotypes, doublet_prior)
+        packed = _pack(chromosome2compressed_snp_calls, genotypes, add_data_prior=False)
+        ctx = Demultiplexer._upload(packed, barcode_handler.n_barcodes, genotypes.n_genotypes)
+        ctx.set_addition(None)
+        genotype_prob = ctx.probs_from_betas(p_genotype_clip)
+        assert np.isfinite(genotype_prob).all()
+        logits, probs = ctx.estep(penalties, with_doublets=doublet_prior != 0)
+
+        column_names = _option_names(genotypes.genotype_names, doublet_prior)
+        logits_df = pd.DataFrame(data=logits, index=list(barcode_handler.ordered_barcodes), columns=column_names)
+        logits_df.index.name = 'BARCODE'
+        probs_df = pd.DataFrame(data=probs, index=list(barcode_handler.ordered_barcodes), columns=column_names)
+        probs_df.index.name = 'BARCODE'
+        return logits_df, probs_df
+
+    # ------------------------------------------------------------------------------------
+    @staticmethod
+    def _doublet_penalties(n_genotypes: int, doublet_prior: float) -> np.ndarray:
+        """Logit offsets of the K options (demux.py:158-173): zero for singlets; for pairs the log-odds
+        that makes the prior doublet mass equal `doublet_prior` whatever the number of genotypes."""
+        assert 0 <= doublet_prior < 1
+        if doublet_prior == 0:
+            return np.zeros(n_genotypes, dtype='float32')
+        n_pair_slots = n_genotypes * max(n_genotypes - 1, 1) / 2
+        bonus = np.log(n_genotypes * doublet_prior) - np.log(n_pair_slots * (1 - doublet_prior))
+        penalties = np.zeros(n_genotypes * (n_genotypes + 1) // 2, dtype='float32')
+        penalties[n_genotypes:] = bonus
+        return penalties
+
+    @staticmethod
+    def compute_barcode_logits(genotype_names, barcode_calls, molecule_calls, doublet_prior: float,
+                               genotype_prob: np.ndarray, n_barcodes: int, n_genotypes: int):
+        """Dispatcher of demux.py:193-202."""
+        Demultiplexer._check_not_aggregating()
+        return Demultiplexer.compute_barcode_logits_using_barcode_calls(
+            genotype_names, barcode_calls=barcode_calls, doublet_prior=doublet_prior,
+            genotype_prob=genotype_prob, n_barcodes=n_barcodes, n_genotypes=n_genotypes)
+
+    @staticmethod
+    def compute_barcode_logits_using_barcode_calls(genotype_names, barcode_calls, doublet_prior,
+                                                   genotype_prob: np.ndarray, n_barcodes: int, n_genotypes: int):
+        """E-step on caller-supplied tables (demux.py:246-265): barcode_calls carries the columns
+        'variant_id', 'compressed_cb', 'p_base_wrong'; genotype_prob is float32[V, G]."""
+        genotype_prob = np.asarray(genotype_prob)
+        assert genotype_prob.shape[1] == n_genotypes == len(genotype_names)
+        ctx = get_context()
+        ctx.set_problem(n_barcodes, genotype_prob.shape[0], n_genotypes, barcode_calls['variant_id'],
+                        barcode_calls['compressed_cb'], barcode_calls['p_base_wrong'],
+                        np.zeros(genotype_prob.shape[0], dtype=np.int32))
+        ctx.set_probs(genotype_prob)
+        penalties = Demultiplexer._doublet_penalties(n_genotypes, doublet_prior=doublet_prior)
+        logits, _ = ctx.estep(penalties, with_doublets=doublet_prior != 0, fetch_probs=False)
+        return logits, _option_names(genotype_names, doublet_prior)
+
+    @staticmethod
+    def _compute_probs_from_betas(variant_index2snp_index, variant_index2betas, p_genotype_clip):
+        """P-step on caller-supplied tables (demux.py:267-274)."""
+        betas = np.asarray(variant_index2betas, dtype=np.float32)
+        ctx = get_context()
+        empty_i = np.zeros(0, dtype=np.int32)
+        ctx.set_problem(0, betas.shape[0], betas.shape[1], empty_i, empty_i, np.zeros(0, dtype=np.float32),
+                        variant_index2snp_index)
+        ctx.set_betas(betas)
+        ctx.set_addition(None)
+        return ctx.probs_from_betas(p_genotype_clip)
+
+    @staticmethod
+    def molecule_calls2barcode_calls(molecule_calls, _prepacked=None):
+        """Unique (variant, barcode) calls from matched molecule calls (demux.py:276-300), as the
+        reference's record array (variant-major order)."""
+        variant_id = np.ascontiguousarray(molecule_calls['variant_id'], dtype=np.int32)
+        snp_id = np.ascontiguousarray(molecule_calls['snp_id'], dtype=np.int32)
+        cb = np.ascontiguousarray(molecule_calls['compressed_cb'], dtype=np.int32)
+        p = np.ascontiguousarray(molecule_calls['p_base_wrong'], dtype=np.float32)
+        if _prepacked is None:
+            # route the already-matched calls through the same host packer: key = variant row
+            import ctypes
+            lib = _lib.load()
+            n = len(variant_id)
+            n_variants = int(variant_id.max()) + 1 if n else 0
+            rows = np.arange(n_variants, dtype=np.int32)
+            zeros_v = np.zeros(n_variants, dtype=np.int32)
+            zeros_b = np.zeros(n_variants, dtype=np.uint8)
+            out_v, out_cb = np.empty(n, dtype=np.int32), np.empty(n, dtype=np.int32)
+            out_p, out_count = np.empty(n, dtype=np.float32), np.empty(n, dtype=np.int64)
+            n_matched, n_unique = ctypes.c_int64(0), ctypes.c_int64(0)
+            _lib.check(lib.dmx_pack_calls_host(
+                n_variants, _lib.ptr(zeros_v), _lib.ptr(rows), _lib.ptr(zeros_b),
+                n, _lib.ptr(np.zeros(n, dtype=np.int32)), _lib.ptr(variant_id), _lib.ptr(np.zeros(n, dtype=np.uint8)),
+                _lib.ptr(cb), _lib.ptr(p), None, ctypes.byref(n_matched), ctypes.byref(n_unique),
+                _lib.ptr(out_v), _lib.ptr(out_cb), _lib.ptr(out_p), _lib.ptr(out_count), None))
+            k = n_unique.value
+            u_variant, u_cb, u_p, u_count = out_v[:k].copy(), out_cb[:k].copy(), out_p[:k].copy(), out_count[:k].copy()
+        else:
+            u_variant, u_cb, u_p, u_count = _prepacked
+        # snp id of a unique call: snp_id is a function of variant_id
+        variant2snp = np.zeros(int(variant_id.max()) + 1 if len(variant_id) else 0, dtype=np.int32)
+        variant2snp[variant_id] = snp_id
+        u_snp = variant2snp[u_variant] if len(u_variant) else np.zeros(0, dtype=np.int32)
+        # how many molecules of the barcode hit the SNP (any variant of it); nothing downstream reads it
+        if len(u_variant):
+            key = u_snp.astype(np.int64) * (int(u_cb.max()) + 1) + u_cb
+            _, inverse = np.unique(key, return_inverse=True)
+            snp_count = np.bincount(inverse, u_count)[inverse]
+        else:
+            snp_count = np.zeros(0, dtype=np.float64)
+        return np.rec.fromarrays(
+            [u_variant, u_snp, u_cb, u_p, u_count, snp_count],
+            names=['variant_id', 'snp_id', 'compressed_cb', 'p_base_wrong', 'barcode_variant_count',
+                   'barcode_snp_count'])
+
+    @staticmethod
+    def pack_calls(chromosome2compressed_snp_calls, genotypes, add_data_prior: bool):
+        """demux.py:303-392: returns (variant_index2snp_index, regularised betas (read-only),
+        matched molecule calls, unique barcode calls)."""
+        packed = _pack(chromosome2compressed_snp_calls, genotypes, add_data_prior, want_molecule_table=True)
+        barcode_calls = Demultiplexer.molecule_calls2barcode_calls(
+            packed.molecule_calls,
+            _prepacked=(packed.variant_id, packed.compressed_cb, packed.p_base_wrong, packed.variant_count))
+        return packed.v2snp, packed.betas, packed.molecule_calls, barcode_calls
+
+    # ------------------------------------------------------------------------------------
+    @staticmethod
+    def _check_not_aggregating():
+        if Demultiplexer.aggregate_on_snps:
+            raise NotImplementedError(
+                'aggregate_on_snps=True (demux.py:204-244, off by default and slated for removal in the '
+                'reference) is not part of the MI355X hot path')
+
+    @staticmethod
+    def _upload(packed: _Packed, n_barcodes, n_genotypes):
+        ctx = get_context()
+        ctx.set_problem(n_barcodes, len(packed.v2snp), n_genotypes, packed.variant_id, packed.compressed_cb,
+                        packed.p_base_wrong, packed.v2snp)
+        ctx.set_betas(packed.betas)
+        return ctx

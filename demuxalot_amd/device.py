@@ -1,0 +1,211 @@
+"""Thin object wrapper over the dmx_ctx of libdemux_hip.so: one context = one GPU + one HIP
+stream + one resident problem (calls CSR/CSC, beta tables, logits/posteriors)."""
+import ctypes
+import os
+
+import numpy as np
+
+from . import _lib
+from ._lib import DMX_F32, DMX_F64, as_c, check, ptr
+
+
+class DeviceContext:
+    def __init__(self, device=0):
+        self._lib = _lib.load()
+        handle = ctypes.c_void_p()
+        check(self._lib.dmx_create(int(device), ctypes.byref(handle)))
+        self._h = handle
+        self.device = int(device)
+        self.B = self.V = self.G = self.N = 0
+        self.K = 0
+
+    def close(self):
+        if getattr(self, '_h', None):
+            self._lib.dmx_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ---- problem ----------------------------------------------------------------------
+    def set_problem(self, n_barcodes, n_variants, n_genotypes, variant_id, compressed_cb, p_base_wrong, v2snp):
+        variant_id = as_c(variant_id, np.int32)
+        compressed_cb = as_c(compressed_cb, np.int32)
+        p_base_wrong = as_c(p_base_wrong, np.float32)
+        v2snp = as_c(v2snp, np.int32)
+        assert len(variant_id) == len(compressed_cb) == len(p_base_wrong)
+        assert len(v2snp) == n_variants
+        check(self._lib.dmx_set_problem(self._h, n_barcodes, n_variants, n_genotypes, len(variant_id),
+                                        ptr(variant_id), ptr(compressed_cb), ptr(p_base_wrong), ptr(v2snp)))
+        self.B, self.V, self.G, self.N = int(n_barcodes), int(n_variants), int(n_genotypes), len(variant_id)
+
+    def set_betas(self, betas):
+        betas = as_c(betas, np.float32)
+        assert betas.shape == (self.V, self.G)
+        check(self._lib.dmx_set_betas(self._h, ptr(betas)))
+
+    def set_addition(self, addition=None):
+        if addition is not None:
+            addition = as_c(addition, np.float32)
+            assert addition.shape == (self.V, self.G)
+        check(self._lib.dmx_set_addition(self._h, ptr(addition)))
+
+    def set_probs(self, prob):
+        prob = as_c(prob, np.float32)
+        assert prob.shape == (self.V, self.G)
+        check(self._lib.dmx_set_probs(self._h, ptr(prob)))
+
+    # ---- steps ------------------------------------------------------------------------
+    @staticmethod
+    def clip_bounds(p_genotype_clip):
+        # ndarray.clip(p, 1 - p) on a float32 array: both Python floats become float32 scalars
+        return float(np.float32(p_genotype_clip)), float(np.float32(1 - p_genotype_clip))
+
+    def probs_from_betas(self, p_genotype_clip, fetch=True):
+        lo, hi = self.clip_bounds(p_genotype_clip)
+        out = np.empty((self.V, self.G), dtype=np.float32) if fetch else None
+        check(self._lib.dmx_probs_from_betas(self._h, lo, hi, ptr(out)))
+        return out
+
+    def _n_options(self, with_doublets):
+        return self.G * (self.G + 1) // 2 if with_doublets else self.G
+
+    @staticmethod
+    def _prior_arg(prior_logits, shape):
+        if prior_logits is None:
+            return None, DMX_F32
+        prior_logits = np.asarray(prior_logits)
+        assert prior_logits.shape == shape, 'mismatching priors passed'
+        if prior_logits.dtype == np.float32:
+            return as_c(prior_logits, np.float32), DMX_F32
+        # any other dtype takes numpy's float64 path of `logits += prior`
+        return as_c(prior_logits, np.float64), DMX_F64
+
+    def estep(self, penalties, with_doublets, prior_logits=None, fetch_logits=True, fetch_probs=True):
+        K = self._n_options(with_doublets)
+        penalties = as_c(penalties, np.float32)
+        assert penalties.shape == (K,)
+        prior, prior_dtype = self._prior_arg(prior_logits, (self.B, K))
+        logits = np.empty((self.B, K), dtype=np.float32) if fetch_logits else None
+        probs = np.empty((self.B, K), dtype=np.float32) if fetch_probs else None
+        check(self._lib.dmx_estep(self._h, int(with_doublets), ptr(penalties), ptr(prior), prior_dtype,
+                                  ptr(logits), ptr(probs)))
+        self.K = K
+        return logits, probs
+
+    def mstep(self, contribution_power=2., fetch=True):
+        out = np.empty((self.V, self.G), dtype=np.float32) if fetch else None
+        check(self._lib.dmx_mstep(self._h, float(contribution_power), ptr(out)))
+        return out
+
+    def em(self, n_iterations, p_genotype_clip, penalties, with_doublets, prior_logits=None,
+           contribution_power=2., fetch_logits=True, fetch_probs=True, fetch_addition=True):
+        K = self._n_options(with_doublets)
+        lo, hi = self.clip_bounds(p_genotype_clip)
+        penalties = as_c(penalties, np.float32)
+        assert penalties.shape == (K,)
+        prior, prior_dtype = self._prior_arg(prior_logits, (self.B, K))
+        logits = np.empty((self.B, K), dtype=np.float32) if fetch_logits else None
+        probs = np.empty((self.B, K), dtype=np.float32) if fetch_probs else None
+        addition = np.empty((self.V, self.G), dtype=np.float32) if fetch_addition else None
+        check(self._lib.dmx_em(self._h, int(n_iterations), lo, hi, int(with_doublets), ptr(penalties), ptr(prior),
+                               prior_dtype, float(contribution_power), ptr(logits), ptr(probs), ptr(addition)))
+        self.K = K
+        return logits, probs, addition
+
+    def run_iterations(self, n_iterations, p_genotype_clip, contribution_power=2.):
+        """Enqueue n full EM iterations (P, E, M) without synchronising; see dmx_run_iterations."""
+        lo, hi = self.clip_bounds(p_genotype_clip)
+        check(self._lib.dmx_run_iterations(self._h, int(n_iterations), lo, hi, float(contribution_power)))
+
+    def get_logits(self):
+        out = np.empty((self.B, self.K), dtype=np.float32)
+        check(self._lib.dmx_get_logits(self._h, ptr(out)))
+        return out
+
+    def get_probs(self):
+        out = np.empty((self.B, self.K), dtype=np.float32)
+        check(self._lib.dmx_get_probs(self._h, ptr(out)))
+        return out
+
+    def get_addition(self):
+        out = np.empty((self.V, self.G), dtype=np.float32)
+        check(self._lib.dmx_get_addition(self._h, ptr(out)))
+        return out
+
+    def get_assignments(self):
+        best = np.empty(self.B, dtype=np.int32)
+        prob = np.empty(self.B, dtype=np.float32)
+        check(self._lib.dmx_get_assignments(self._h, ptr(best), ptr(prob)))
+        return best, prob
+
+    def synchronize(self):
+        check(self._lib.dmx_synchronize(self._h))
+
+    # ---- multi-GPU ----------------------------------------------------------------------
+    @staticmethod
+    def new_unique_id() -> bytes:
+        buf = ctypes.create_string_buffer(_lib.UNIQUE_ID_BYTES)
+        check(_lib.load().dmx_comm_unique_id(buf))
+        return buf.raw
+
+    def comm_init(self, rank, nranks, unique_id: bytes, reduce_dtype='f64'):
+        assert len(unique_id) == _lib.UNIQUE_ID_BYTES
+        buf = ctypes.create_string_buffer(unique_id, _lib.UNIQUE_ID_BYTES)
+        check(self._lib.dmx_comm_init(self._h, int(rank), int(nranks), buf, DMX_F64 if reduce_dtype == 'f64' else DMX_F32))
+
+    # ---- instrumentation ----------------------------------------------------------------
+    def timings(self):
+        ms = (ctypes.c_double * _lib.T_COUNT)()
+        n = (ctypes.c_int64 * _lib.T_COUNT)()
+        check(self._lib.dmx_get_timings(self._h, ms, n))
+        return {name: dict(ms=ms[i], launches=int(n[i])) for i, name in enumerate(_lib.TIMER_NAMES)}
+
+    def reset_timings(self):
+        check(self._lib.dmx_reset_timings(self._h))
+
+    def device_bytes(self):
+        n = ctypes.c_int64(0)
+        check(self._lib.dmx_device_bytes(self._h, ctypes.byref(n)))
+        return n.value
+
+    # ---- device self-tests (numpy-exact float32 building blocks) -------------------------
+    def test_log(self, x):
+        x = as_c(x, np.float32)
+        out = np.empty_like(x)
+        check(self._lib.dmx_test_logf(self._h, ptr(x), ptr(out), x.size))
+        return out
+
+    def test_exp(self, x):
+        x = as_c(x, np.float32)
+        out = np.empty_like(x)
+        check(self._lib.dmx_test_expf(self._h, ptr(x), ptr(out), x.size))
+        return out
+
+    def test_softmax(self, x):
+        x = as_c(x, np.float32)
+        out = np.empty_like(x)
+        check(self._lib.dmx_test_softmax(self._h, ptr(x), ptr(out), x.shape[0], x.shape[1]))
+        return out
+
+
+_contexts = {}
+
+
+def default_device():
+    """GPU used by the Demultiplexer front-end: DEMUXALOT_AMD_DEVICE, else LOCAL_RANK, else 0."""
+    for var in ('DEMUXALOT_AMD_DEVICE', 'LOCAL_RANK'):
+        if os.environ.get(var, '') != '':
+            return int(os.environ[var])
+    return 0
+
+
+def get_context(device=None) -> DeviceContext:
+    """Process-wide cached context per device. Raises when no GPU is visible (no CPU fallback)."""
+    device = default_device() if device is None else int(device)
+    if device not in _contexts:
+        _contexts[device] = DeviceContext(device)
+    return _contexts[device]

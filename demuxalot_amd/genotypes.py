@@ -1,0 +1,117 @@
+"""ProbabilisticGenotypes: the Dirichlet-beta store the EM reads and returns (mirror of the core
+of demuxalot/genotypes.py:18-78, 301-361).  No math lives here; the table is float32[capacity, G]
+with a dict (chrom, pos, base) -> row.  `var2varid`, `variant_betas`, `genotype_names` and
+`default_prior` stay plain writable attributes because callers (and the reference's tests,
+tests/test_synthetic.py:101-102, 182, 213) assign them directly.
+
+VCF / bead-array importers of the reference (genotypes.py:112-265) need pysam/htslib and are out
+of scope; the parquet round-trip (save_betas / add_prior_betas, genotypes.py:267-299, 336-358) is
+kept because it is the checkpoint format of learnt genotypes."""
+from collections import defaultdict
+from copy import deepcopy
+from typing import Dict, List, Tuple
+from warnings import warn
+
+import numpy as np
+
+
+class ProbabilisticGenotypes:
+    def __init__(self, genotype_names: List[str], default_prior=1.):
+        self.var2varid: Dict[Tuple, int] = {}
+        self.genotype_names: List[str] = list(genotype_names)
+        assert (np.sort(self.genotype_names) == self.genotype_names).all(), 'please order genotype names'
+        assert len(set(genotype_names)) == len(genotype_names), f'Duplicates in genotypes: {genotype_names}'
+        self.variant_betas: np.ndarray = np.zeros([32768, self.n_genotypes], 'float32')
+        self.default_prior: float = default_prior
+
+    def __repr__(self):
+        contigs = {chrom for chrom, _, _ in self.var2varid}
+        return (f'<Genotypes with {self.n_variants} variants on {len(contigs)} contigs ("chromosomes") '
+                f'and {self.n_genotypes} genotypes: \n{self.genotype_names}')
+
+    @property
+    def n_genotypes(self):
+        return len(self.genotype_names)
+
+    @property
+    def n_variants(self) -> int:
+        return len(self.var2varid)
+
+    def get_betas(self) -> np.ndarray:
+        view = self.variant_betas[:self.n_variants]
+        view.flags.writeable = False
+        return view
+
+    def get_snp_ids_for_variants(self) -> np.ndarray:
+        """SNP id of every variant row; ids are handed out in first-seen order of var2varid."""
+        ids = {}
+        out = np.full(self.n_variants, -1, dtype='int32')
+        for (chrom, pos, _base), row in self.var2varid.items():
+            out[row] = ids.setdefault((chrom, pos), len(ids))
+        assert np.all(out >= 0)
+        assert np.all(out < self.n_variants)
+        return out
+
+    def get_variant_id(self, chrom, pos, base):
+        key = chrom, pos, base
+        if key not in self.var2varid:
+            self.var2varid[key] = self.n_variants
+            self.extend_variants(1)
+        return self.var2varid[key]
+
+    def extend_variants(self, n_samples=1):
+        while n_samples + self.n_variants > len(self.variant_betas):
+            self.variant_betas = np.concatenate([self.variant_betas, np.zeros_like(self.variant_betas)], axis=0)
+
+    def get_chromosome2positions(self):
+        by_chrom = defaultdict(list)
+        for chrom, pos, _base in self.var2varid:
+            by_chrom[chrom].append(pos)
+        if len(by_chrom) == 0:
+            warn('Genotypes are empty. Did you forget to add vcf/betas?')
+        return {chrom: np.unique(np.asarray(p, dtype=int)) for chrom, p in by_chrom.items()}
+
+    def get_snp_positions_set(self) -> set:
+        return {(chrom, pos) for chrom, pos, _base in self.var2varid}
+
+    def _with_betas(self, external_betas: np.ndarray) -> 'ProbabilisticGenotypes':
+        """Copy of the genotypes carrying new beta weights."""
+        assert external_betas.shape == (self.n_variants, self.n_genotypes)
+        assert external_betas.dtype == self.variant_betas.dtype
+        assert np.min(external_betas) >= 0
+        out = self.clone()
+        out.variant_betas = external_betas.copy()
+        return out
+
+    def clone(self):
+        return deepcopy(self)
+
+    # ---- checkpoint format of learnt genotypes (parquet) ---------------------------------
+    def as_pandas_dataframe(self):
+        import pandas as pd
+        keys = sorted(self.var2varid.items())
+        rows = np.asarray([row for _key, row in keys], dtype=np.int64)
+        index = pd.MultiIndex.from_frame(pd.DataFrame({
+            'CHROM': [k[0] for k, _ in keys], 'POS': [k[1] for k, _ in keys], 'BASE': [k[2] for k, _ in keys]}))
+        return pd.DataFrame(data=self.variant_betas[:self.n_variants][rows], index=index, columns=self.genotype_names)
+
+    def save_betas(self, path_or_buf):
+        self.as_pandas_dataframe().to_parquet(path_or_buf)
+
+    def add_prior_betas(self, prior_filename, *, prior_strength: float = 1.):
+        import pandas as pd
+        prior = pd.read_parquet(prior_filename) * prior_strength
+        print('Provided prior information about genotypes:', [*prior.columns])
+        missing = [g for g in self.genotype_names if g not in prior.columns]
+        if missing:
+            print(f'No information for genotypes: {missing}')
+        frame = prior.index.to_frame()
+        rows = []
+        for key in zip(frame['CHROM'], frame['POS'], frame['BASE']):
+            if key not in self.var2varid:
+                self.extend_variants(1)
+                self.var2varid[key] = self.n_variants
+            rows.append(self.var2varid[key])
+        for g, name in enumerate(self.genotype_names):
+            if name in prior.columns:
+                np.add.at(self.variant_betas[:, g], rows, prior[name])

@@ -1,0 +1,180 @@
+/*
+ * demux_hip.h -- C ABI of libdemux_hip.so, the MI355X (gfx950) implementation of
+ * demuxalot's Demultiplexer EM hot path.
+ *
+ * The reference (arogozhnikov/demuxalot, pure Python/numpy) has no FFI boundary of
+ * its own: its boundary is the Python call surface of demuxalot/demux.py.  The
+ * Python host layer in demuxalot_amd/ keeps that surface verbatim and binds the
+ * entry points below with ctypes (see INTEGRATION.md for the stub a maintainer of
+ * the reference would add).  Each entry point cites the reference code it replaces
+ * (paths relative to the reference checkout).
+ *
+ * Conventions
+ *   - plain pointers and sizes only; all host arrays are C-contiguous, caller-owned;
+ *     the library owns every device allocation.
+ *   - every function returns 0 on success and a negative dmx_status otherwise;
+ *     dmx_last_error() gives the message of the last failure on the calling thread.
+ *   - a dmx_ctx is bound to one GPU and one HIP stream; calls on one ctx must not
+ *     overlap in time (the reference's caller is single-threaded too); different
+ *     ctxs are independent.
+ *   - "options" are the K posterior columns: K = G without doublets, G(G+1)/2 with
+ *     (singlets first, then pairs g1<g2 row-major: demuxalot/demux.py:175-191).
+ */
+#ifndef DEMUX_HIP_H
+#define DEMUX_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct dmx_ctx dmx_ctx;
+
+typedef enum {
+    DMX_OK = 0,
+    DMX_ERR_INVALID = -1,   /* bad argument / call order            */
+    DMX_ERR_HIP = -2,       /* a HIP runtime call failed            */
+    DMX_ERR_NO_DEVICE = -3, /* no usable GPU                        */
+    DMX_ERR_RCCL = -4,      /* RCCL missing or a collective failed  */
+    DMX_ERR_UNSUPPORTED = -5
+} dmx_status;
+
+/* dtype tags for optional float inputs */
+#define DMX_F32 0
+#define DMX_F64 1
+
+/* timing slots of dmx_get_timings */
+enum { DMX_T_PSTEP = 0, DMX_T_ESTEP = 1, DMX_T_MSTEP = 2, DMX_T_MCOMBINE = 3, DMX_T_ALLREDUCE = 4, DMX_T_COUNT = 5 };
+
+const char *dmx_last_error(void);
+const char *dmx_version(void);
+
+/* Number of visible GPUs (does not initialise a device). */
+int dmx_device_count(int *count);
+
+int dmx_create(int device, dmx_ctx **out);
+int dmx_destroy(dmx_ctx *ctx);
+int dmx_synchronize(dmx_ctx *ctx);
+
+/* ------------------------------------------------------------------------- *
+ * Host-side repack (no GPU involved).
+ * Replaces Demultiplexer.pack_calls' variant matching + molecule_calls2barcode_calls
+ * (demuxalot/demux.py:276-300, 332-365): every molecule call is matched to the variant
+ * with the same (chromosome, position, base); unmatched calls are dropped; the rest are
+ * reduced to unique (variant, barcode) pairs sorted by variant then barcode, whose
+ * p_base_wrong is the float32 product of the members in input order.
+ *
+ *   var_*        [n_variants]   key of variant row i (chromosome as a caller-side index)
+ *   call_*       [n_calls]      molecule calls in the reference's order
+ *   call_variant [n_calls]      nullable; matched variant row of every input call, -1 if none
+ *   out_*        caller-allocated, capacity n_calls; *n_unique entries are written
+ *   mol_per_variant [n_variants] number of matched molecule calls per variant
+ *                (np.bincount(molecule_calls['variant_id']) of demux.py:381)
+ * ------------------------------------------------------------------------- */
+int dmx_pack_calls_host(int64_t n_variants, const int32_t *var_chrom, const int32_t *var_pos,
+                        const uint8_t *var_base, int64_t n_calls, const int32_t *call_chrom,
+                        const int32_t *call_pos, const uint8_t *call_base, const int32_t *call_cb,
+                        const float *call_p, int32_t *call_variant, int64_t *n_matched,
+                        int64_t *n_unique, int32_t *out_variant, int32_t *out_cb, float *out_p, int64_t *out_count,
+                        int64_t *mol_per_variant);
+
+/* ------------------------------------------------------------------------- *
+ * Problem upload.  The calls come as the reference's `barcode_calls` columns
+ * (variant_id, compressed_cb, p_base_wrong; demux.py:290-300), in any order; the
+ * library derives a barcode-major CSR (E-step) and a variant-major CSC (M-step),
+ * both stable with respect to the given order so that float64 sums run in the
+ * reference's bincount order.  v2snp is genotypes.get_snp_ids_for_variants()
+ * (demuxalot/genotypes.py:56-66).
+ * ------------------------------------------------------------------------- */
+int dmx_set_problem(dmx_ctx *ctx, int64_t n_barcodes, int64_t n_variants, int32_t n_genotypes,
+                    int64_t n_calls, const int32_t *variant_id, const int32_t *compressed_cb,
+                    const float *p_base_wrong, const int32_t *v2snp);
+
+/* Regularised prior betas float32[V*G] (output of pack_calls, demux.py:372-388). */
+int dmx_set_betas(dmx_ctx *ctx, const float *prior_betas);
+
+/* genotype_addition float32[V*G]; NULL resets it to zero (demux.py:86). */
+int dmx_set_addition(dmx_ctx *ctx, const float *addition);
+
+/* P-step: Demultiplexer._compute_probs_from_betas (demux.py:267-274) applied to
+ * prior_betas + addition (float32 add, demux.py:90).  clip_lo / clip_hi are
+ * float32(p_genotype_clip) and float32(1 - p_genotype_clip).  prob_out (float32[V*G],
+ * nullable) receives a copy of the table. */
+int dmx_probs_from_betas(dmx_ctx *ctx, float clip_lo, float clip_hi, float *prob_out);
+
+/* Direct upload of a genotype_prob table float32[V*G] (for callers of
+ * compute_barcode_logits_using_barcode_calls that bring their own table). */
+int dmx_set_probs(dmx_ctx *ctx, const float *prob);
+
+/* E-step + posterior: Demultiplexer.compute_barcode_logits_using_barcode_calls
+ * (demux.py:246-265) followed by scipy softmax (demux.py:101,152).
+ *   with_doublets  0: K = G;  1: K = G(G+1)/2
+ *   penalties      float32[K] = Demultiplexer._doublet_penalties (demux.py:158-173)
+ *   prior_logits   nullable [B*K] added to the logits before the softmax
+ *                  (demux.py:97-99); prior_dtype says float32 or float64
+ *   logits_out / probs_out  nullable float32[B*K]; NULL keeps the result on the GPU */
+int dmx_estep(dmx_ctx *ctx, int with_doublets, const float *penalties, const void *prior_logits,
+              int prior_dtype, float *logits_out, float *probs_out);
+
+/* M-step: genotype_addition of demux.py:113-118 from the posteriors of the last
+ * dmx_estep (singlet columns only); contribution_power as Demultiplexer.contribution_power.
+ * With a communicator attached the per-rank partial sums are all-reduced over RCCL.
+ * addition_out nullable float32[V*G]. */
+int dmx_mstep(dmx_ctx *ctx, float contribution_power, float *addition_out);
+
+/* Fused EM driver: the loop of staged_genotype_learning (demux.py:86-118) without the
+ * dead M-step after the last iteration.  Outputs (all nullable) are those of the last
+ * iteration: logits, posteriors and the addition that iteration's E-step used. */
+int dmx_em(dmx_ctx *ctx, int n_iterations, float clip_lo, float clip_hi, int with_doublets,
+           const float *penalties, const void *prior_logits, int prior_dtype,
+           float contribution_power, float *logits_out, float *probs_out, float *addition_out);
+
+/* Enqueues n_iterations x (P-step, E-step + softmax, M-step [+ all-reduce]) on the ctx stream
+ * and returns WITHOUT synchronising (pair with dmx_synchronize).  Unlike dmx_em every iteration
+ * includes its M-step, the addition is not reset, and no prior logits are applied: this is the
+ * steady-state EM iteration the benchmark times.  Options/penalties are those of the last
+ * dmx_estep / dmx_em call. */
+int dmx_run_iterations(dmx_ctx *ctx, int n_iterations, float clip_lo, float clip_hi, float contribution_power);
+
+/* Copy the device-resident results of the last E-step / M-step. */
+int dmx_get_logits(dmx_ctx *ctx, float *logits_out);
+int dmx_get_probs(dmx_ctx *ctx, float *probs_out);
+int dmx_get_addition(dmx_ctx *ctx, float *addition_out);
+
+/* Per-barcode reduction of the posterior on the GPU: argmax option and its
+ * probability (what users take from the DataFrame: probs.idxmax(axis=1)). */
+int dmx_get_assignments(dmx_ctx *ctx, int32_t *best_option, float *best_prob);
+
+/* ------------------------------------------------------------------------- *
+ * Multi-GPU: one ctx per rank, barcodes sharded by the caller; the only exchange
+ * is the all-reduce of the beta addition inside dmx_mstep / dmx_em.
+ * dmx_comm_unique_id fills 128 bytes on rank 0 (ncclGetUniqueId); the caller
+ * broadcasts them and every rank calls dmx_comm_init.
+ * reduce_dtype: DMX_F64 all-reduces the float64 partial sums and rounds once
+ * (rank-count independent up to float64 re-association); DMX_F32 halves the bytes.
+ * ------------------------------------------------------------------------- */
+#define DMX_UNIQUE_ID_BYTES 128
+int dmx_comm_unique_id(void *id_out);
+int dmx_comm_init(dmx_ctx *ctx, int rank, int nranks, const void *unique_id, int reduce_dtype);
+
+/* Accumulated kernel time per slot (ms, from HIP events on the ctx stream) and launch
+ * counts since the last dmx_reset_timings. Arrays of DMX_T_COUNT entries. */
+int dmx_get_timings(dmx_ctx *ctx, double *ms, int64_t *launches);
+int dmx_reset_timings(dmx_ctx *ctx);
+
+/* Device memory currently held by the ctx, bytes. */
+int dmx_device_bytes(dmx_ctx *ctx, int64_t *bytes);
+
+/* ------------------------------------------------------------------------- *
+ * Device self-tests of the float32 building blocks (used by tests/ on the GPU box):
+ * the device restatements of numpy's float32 log / exp and of scipy's row softmax.
+ * ------------------------------------------------------------------------- */
+int dmx_test_logf(dmx_ctx *ctx, const float *in, float *out, int64_t n);
+int dmx_test_expf(dmx_ctx *ctx, const float *in, float *out, int64_t n);
+int dmx_test_softmax(dmx_ctx *ctx, const float *in, float *out, int64_t rows, int64_t cols);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DEMUX_HIP_H */

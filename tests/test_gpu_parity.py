@@ -1,0 +1,256 @@
+"""GPU parity tests (run with -m gpu on an MI355X). Everything goes through the C ABI of
+libdemux_hip.so via the Python front-end; the oracle and the golden fixtures are the checkers.
+
+Acceptance from BASELINE.json: barcode->donor assignments bit-identical, posteriors within 1e-5.
+The kernels repeat numpy's float32 operation order, so the tests first demand the stronger
+property -- bitwise equality of logits, posteriors and beta additions with the reference's own
+outputs -- and only report the tolerance numbers alongside."""
+import numpy as np
+import pytest
+
+from tests import fixture_io as fio
+
+pytestmark = pytest.mark.gpu
+
+TOL_POSTERIOR = 1e-5  # BASELINE.json north_star
+
+
+@pytest.fixture(scope='module')
+def ctx():
+    from demuxalot_amd.device import get_context
+    return get_context()
+
+
+def check_posteriors(got_logits, got_probs, ref_logits, ref_probs, what):
+    # the contractual gate
+    assert np.array_equal(got_probs.argmax(axis=1), ref_probs.argmax(axis=1)), f'{what}: assignments differ'
+    assert np.abs(got_probs - ref_probs).max() <= TOL_POSTERIOR, f'{what}: posterior tolerance'
+    # the stronger property this implementation is built for
+    fio.assert_bitwise(got_logits, ref_logits, f'{what} logits')
+    fio.assert_bitwise(got_probs, ref_probs, f'{what} probs')
+
+
+# ---- numpy-exact float32 building blocks on the device ------------------------------------
+def test_device_log_matches_numpy_kernel(ctx, oracle):
+    lo, hi = np.float32(1e-5).view(np.int32), np.float32(4.0).view(np.int32)
+    bits = np.arange(int(lo), int(hi), 7, dtype=np.int32)
+    x = bits.view(np.float32)
+    fio.assert_bitwise(ctx.test_log(x), oracle.log_f32(x, impl='npsimd'), 'log')
+    special = np.array([0.0, -1.0, np.inf, np.nan, 1e-45, 1e-38, 3e38], dtype=np.float32)
+    with np.errstate(all='ignore'):
+        want = oracle.log_f32(special, impl='npsimd')
+    got = ctx.test_log(special)
+    assert np.array_equal(np.isnan(got), np.isnan(want))
+    assert np.array_equal(got[~np.isnan(want)], want[~np.isnan(want)])
+
+
+def test_device_exp_and_softmax_match_numpy_kernel(ctx, oracle):
+    lo, hi = np.float32(-0.0).view(np.uint32), np.float32(-104.5).view(np.uint32)
+    bits = np.arange(int(lo), int(hi), 41, dtype=np.uint32)
+    x = bits.view(np.float32)
+    fio.assert_bitwise(ctx.test_exp(x), oracle._c_unary('npsimd_exp_array', x), 'exp')
+    rng = np.random.default_rng(3)
+    for K in (1, 2, 7, 8, 9, 20, 36, 64, 127, 128, 129, 135, 210, 255, 256, 257, 528, 2080, 8191, 8192, 8193, 8256):
+        logits = (rng.normal(size=(5, K)) * rng.choice([1., 30., 200.])).astype(np.float32)
+        fio.assert_bitwise(ctx.test_softmax(logits), oracle.softmax_rows(logits, impl='npsimd'), f'softmax K={K}')
+
+
+# ---- golden fixtures: the reference's own outputs -----------------------------------------
+@pytest.mark.parametrize('name', fio.SMALL + fio.SYNTH)
+def test_predict_posteriors_matches_reference(name):
+    from demuxalot_amd import Demultiplexer
+    fx = fio.load(name)
+    calls, genotypes, handler = fio.product_inputs(fx)
+    for i in range(int(fx['n_predict'])):
+        dp, clip = float(fx[f'predict{i}_dp']), float(fx[f'predict{i}_clip'])
+        logits_df, probs_df = Demultiplexer.predict_posteriors(
+            calls, genotypes, handler, p_genotype_clip=clip, doublet_prior=dp)
+        assert logits_df.index.name == 'BARCODE' and probs_df.index.name == 'BARCODE'
+        assert list(logits_df.index) == [str(b) for b in fx['barcodes']]
+        assert list(probs_df.columns) == [str(c) for c in fx[f'predict{i}_columns']]
+        assert logits_df.values.dtype == np.float32 and probs_df.values.dtype == np.float32
+        check_posteriors(logits_df.values, probs_df.values, fx[f'predict{i}_logits'], fx[f'predict{i}_probs'],
+                         f'{name} predict dp={dp} clip={clip}')
+
+
+@pytest.mark.parametrize('name', fio.SMALL + fio.SYNTH)
+def test_staged_learning_matches_reference(name):
+    from demuxalot_amd import Demultiplexer
+    fx = fio.load(name)
+    calls, genotypes, handler = fio.product_inputs(fx)
+    for i in range(int(fx['n_em'])):
+        kwargs = dict(n_iterations=int(fx[f'em{i}_n_iterations']), p_genotype_clip=float(fx[f'em{i}_clip']),
+                      doublet_prior=float(fx[f'em{i}_dp']))
+        prior = fx.get(f'em{i}_prior_logits')
+        stages = list(Demultiplexer.staged_genotype_learning(
+            calls, genotypes, handler, barcode_prior_logits=None if prior is None else prior.copy(), **kwargs))
+        assert len(stages) == kwargs['n_iterations']
+        for it, (probs_df, dbg) in enumerate(stages):
+            what = f'{name} run {i} it {it}'
+            assert probs_df.index.name is None and list(probs_df.columns) == [str(c) for c in fx[f'em{i}_columns']]
+            check_posteriors(dbg['barcode_logits'], probs_df.values, fx[f'em{i}_it{it}_logits'],
+                             fx[f'em{i}_it{it}_probs'], what)
+            fio.assert_bitwise(dbg['genotype_addition'], fx[f'em{i}_it{it}_addition'], what + ' addition')
+            fio.assert_bitwise(dbg['genotype_prior'], fx['pack1_betas'], what + ' prior')
+        learnt, last_probs = Demultiplexer.learn_genotypes(
+            calls, genotypes, handler, barcode_prior_logits=None if prior is None else prior.copy(), **kwargs)
+        assert learnt is not genotypes and type(learnt) is type(genotypes)
+        fio.assert_bitwise(learnt.variant_betas, fx[f'em{i}_learnt_betas'], f'{name} run {i} learnt betas')
+        fio.assert_bitwise(last_probs.values, fx[f'em{i}_it{kwargs["n_iterations"] - 1}_probs'], 'last probs')
+        assert last_probs.index.name is None
+
+
+def test_learning_from_assignment_matches_reference():
+    """The reference's test_demultiplex_start_from_assignment scenario (tests/test_synthetic.py:200-239)."""
+    from demuxalot_amd import Demultiplexer
+    fx, out = fio.load('f1_synthetic_default.npz'), fio.load('f1_from_assignment.npz')
+    calls, genotypes, handler = fio.product_inputs(fx, betas=np.zeros_like(fx['betas']))
+    prior = out['em0_prior_logits']
+    learnt, probs = Demultiplexer.learn_genotypes(calls, genotypes, handler, barcode_prior_logits=prior)
+    n_it = int(out['em0_n_iterations'])
+    fio.assert_bitwise(probs.values, out[f'em0_it{n_it - 1}_probs'], 'probs')
+    fio.assert_bitwise(learnt.variant_betas, out['em0_learnt_betas'], 'learnt betas')
+    # float64 prior logits take numpy's float64 in-place add path: same values here, must still agree
+    learnt64, probs64 = Demultiplexer.learn_genotypes(calls, genotypes, handler,
+                                                      barcode_prior_logits=prior.astype(np.float64))
+    assert np.abs(probs64.values - probs.values).max() <= TOL_POSTERIOR
+
+
+def test_front_end_asserts_like_reference():
+    from demuxalot_amd import Demultiplexer
+    fx = fio.load('f3_small_0.npz')
+    calls, genotypes, handler = fio.product_inputs(fx)
+    with pytest.raises(AssertionError):
+        Demultiplexer.predict_posteriors(calls, genotypes, handler, doublet_prior=1.0)
+    with pytest.raises(AssertionError, match='wrong shape of priors'):
+        Demultiplexer.learn_genotypes(calls, genotypes, handler, barcode_prior_logits=np.zeros((3, 3), dtype='float32'))
+    Demultiplexer.aggregate_on_snps = True
+    try:
+        with pytest.raises(NotImplementedError):
+            Demultiplexer.predict_posteriors(calls, genotypes, handler)
+    finally:
+        Demultiplexer.aggregate_on_snps = False
+
+
+# ---- unit entry points on caller-supplied tables vs the oracle -------------------------------
+@pytest.mark.parametrize('G,dp', [(2, 0.), (3, 0.3), (8, 0.35), (16, 0.), (20, 0.25), (22, 0.5), (23, 0.2), (32, 0.),
+                                  (33, 0.), (64, 0.), (64, 0.1), (100, 0.), (128, 0.), (130, 0.05), (200, 0.)])
+def test_unit_steps_match_oracle(oracle, G, dp):
+    from demuxalot_amd import Demultiplexer, synth
+    rng = np.random.default_rng(G * 1000 + int(dp * 100))
+    prob_size = synth.generate(n_barcodes=150, n_snps=300, n_genotypes=G, calls_per_barcode=60, doublets=dp > 0, seed=G)
+    betas = prob_size.prior_betas(add_data_prior=True)
+    betas = (betas * rng.uniform(0.3, 2.0, size=betas.shape)).astype(np.float32)
+    names = [f'g{i:03d}' for i in range(G)]
+    # P-step
+    for clip in (0.01, 0.0, 0.2):
+        want = oracle.probs_from_betas(prob_size.v2snp, betas, clip)
+        got = Demultiplexer._compute_probs_from_betas(prob_size.v2snp, betas, clip)
+        fio.assert_bitwise(got, want, f'probs_from_betas clip={clip}')
+    prob = oracle.probs_from_betas(prob_size.v2snp, betas, 0.01)
+    # E-step on a shuffled COO (bincount order = given order; float64 re-association only)
+    order = rng.permutation(prob_size.n_calls)
+    bc = dict(variant_id=prob_size.variant_id[order], compressed_cb=prob_size.compressed_cb[order],
+              p_base_wrong=prob_size.p_base_wrong[order])
+    want = oracle.barcode_logits(bc['variant_id'], bc['compressed_cb'], bc['p_base_wrong'], prob, 150, dp, log_impl='npsimd')
+    got, columns = Demultiplexer.compute_barcode_logits_using_barcode_calls(
+        names, bc, doublet_prior=dp, genotype_prob=prob, n_barcodes=150, n_genotypes=G)
+    assert columns == oracle.option_names(names, dp)
+    fio.assert_bitwise(got, want, f'logits G={G} dp={dp}')
+
+
+def test_contribution_power_is_honoured(ctx, oracle):
+    from demuxalot_amd import Demultiplexer
+    fx = fio.load('f3_small_2.npz')
+    calls, genotypes, handler = fio.product_inputs(fx)
+    packed = oracle.pack(fio.oracle_calls(fx), fio.oracle_geno(fx), add_data_prior=True)
+    Demultiplexer.contribution_power = 1.5
+    try:
+        stages = list(Demultiplexer.staged_genotype_learning(calls, genotypes, handler, n_iterations=2))
+    finally:
+        Demultiplexer.contribution_power = 2.
+    hist = oracle.em(packed, handler.n_barcodes, 2, 0.01, 0., power=1.5)
+    assert np.allclose(stages[1][1]['genotype_addition'], hist[1]['addition'], rtol=2e-6, atol=1e-7)
+
+
+# ---- mid/large sizes ------------------------------------------------------------------------------
+def test_midsize_em_matches_oracle(oracle):
+    """20k barcodes x 10k SNPs x 64 genotypes (N ~ 3.6M): three EM iterations against the numpy oracle."""
+    from demuxalot_amd import synth
+    from demuxalot_amd.device import get_context
+    p = synth.generate(20000, 10000, 64, calls_per_barcode=200, seed=77)
+    betas = p.prior_betas()
+    ctx = get_context()
+    ctx.set_problem(p.n_barcodes, p.n_variants, 64, p.variant_id, p.compressed_cb, p.p_base_wrong, p.v2snp)
+    ctx.set_betas(betas)
+    pen = np.zeros(64, dtype=np.float32)
+    logits, probs, addition = ctx.em(3, 0.01, pen, with_doublets=False)
+    packed = dict(variant_id=p.variant_id, compressed_cb=p.compressed_cb, p_base_wrong=p.p_base_wrong,
+                  betas=betas, v2snp=p.v2snp)
+    hist = oracle.em(packed, p.n_barcodes, 3, 0.01, 0., impl='npsimd')
+    check_posteriors(logits, probs, hist[-1]['logits'], hist[-1]['probs'], 'midsize EM')
+    fio.assert_bitwise(addition, hist[-1]['addition'], 'midsize addition')
+    best, best_p = ctx.get_assignments()
+    assert np.array_equal(best, probs.argmax(axis=1)) and np.array_equal(best_p, probs.max(axis=1))
+
+
+def test_doublets_block_kernel_matches_oracle(oracle):
+    """K > 256 options (block kernel): 40 genotypes with doublets (K = 820), and 128 (K = 8256 > 8192)."""
+    from demuxalot_amd import synth
+    from demuxalot_amd.device import get_context
+    from demuxalot_amd import Demultiplexer
+    for G, B in ((40, 300), (128, 24)):
+        p = synth.generate(B, 500, G, calls_per_barcode=80, doublets=True, seed=G)
+        betas = p.prior_betas()
+        ctx = get_context()
+        ctx.set_problem(B, p.n_variants, G, p.variant_id, p.compressed_cb, p.p_base_wrong, p.v2snp)
+        ctx.set_betas(betas)
+        pen = Demultiplexer._doublet_penalties(G, 0.3)
+        logits, probs, addition = ctx.em(2, 0.01, pen, with_doublets=True)
+        packed = dict(variant_id=p.variant_id, compressed_cb=p.compressed_cb, p_base_wrong=p.p_base_wrong,
+                      betas=betas, v2snp=p.v2snp)
+        hist = oracle.em(packed, B, 2, 0.01, 0.3, impl='npsimd')
+        check_posteriors(logits, probs, hist[-1]['logits'], hist[-1]['probs'], f'doublets G={G}')
+        fio.assert_bitwise(addition, hist[-1]['addition'], f'doublets G={G} addition')
+
+
+def test_full_size_properties():
+    """BASELINE.json size (200k barcodes x 100k SNPs x 64 genotypes, N ~ 78M): size-independent
+    properties instead of an oracle run -- posteriors are distributions; a barcode shard computed
+    alone gives the same rows (E-step rows are independent); the beta addition is additive over
+    barcode shards (what the multi-GPU all-reduce relies on); results are reproducible run to run."""
+    from demuxalot_amd import synth
+    from demuxalot_amd.device import get_context
+    p = synth.generate(200_000, 100_000, 64, seed=1237)
+    betas = p.prior_betas()
+    ctx = get_context()
+    pen = np.zeros(64, dtype=np.float32)
+    ctx.set_problem(p.n_barcodes, p.n_variants, 64, p.variant_id, p.compressed_cb, p.p_base_wrong, p.v2snp)
+    ctx.set_betas(betas)
+    ctx.set_addition(None)
+    ctx.probs_from_betas(0.01, fetch=False)
+    logits, probs = ctx.estep(pen, with_doublets=False)
+    addition = ctx.mstep(2.)
+    assert np.isfinite(logits).all() and np.abs(probs.sum(axis=1) - 1).max() < 1e-5
+    assert (probs >= 0).all() and (addition >= 0).all()
+    truth_hit = (probs.argmax(axis=1) == p.truth[:, 0]).mean()
+    assert truth_hit > 0.95, truth_hit
+    # run-to-run determinism (no atomics anywhere)
+    logits2, probs2 = ctx.estep(pen, with_doublets=False)
+    addition2 = ctx.mstep(2.)
+    fio.assert_bitwise(logits2, logits, 'E determinism')
+    fio.assert_bitwise(addition2, addition, 'M determinism')
+    # shard independence / additivity on two halves of the barcodes
+    cut = 100_000
+    total = np.zeros_like(addition, dtype=np.float64)
+    for lo, hi in ((0, cut), (cut, p.n_barcodes)):
+        v, cb, e = p.subset_barcodes(lo, hi)
+        ctx.set_problem(hi - lo, p.n_variants, 64, v, cb, e, p.v2snp)
+        ctx.set_betas(betas)
+        ctx.set_addition(None)
+        ctx.probs_from_betas(0.01, fetch=False)
+        l_s, p_s = ctx.estep(pen, with_doublets=False)
+        fio.assert_bitwise(l_s, logits[lo:hi], f'shard [{lo},{hi}) logits')
+        fio.assert_bitwise(p_s, probs[lo:hi], f'shard [{lo},{hi}) probs')
+        total += ctx.mstep(2.)
+    assert np.allclose(total, addition, rtol=3e-7, atol=1e-6)

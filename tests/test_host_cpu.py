@@ -1,0 +1,137 @@
+"""CPU-side checks of the product: the C-ABI library loads and exports every declared symbol,
+the host repack (C++ dmx_pack_calls_host + numpy prior betas) reproduces the reference's
+pack_calls bit for bit on the golden fixtures, and the mirrored containers behave like the
+reference's. No GPU compute is attempted here."""
+import os
+import re
+
+import numpy as np
+import pytest
+
+from tests import fixture_io as fio
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_exports_every_declared_symbol():
+    from demuxalot_amd import _lib
+    header = open(os.path.join(ROOT, 'include', 'demux_hip.h')).read()
+    declared = set(re.findall(r'\b(dmx_[a-z0-9_]+)\s*\(', header))
+    declared -= {'dmx_ctx', 'dmx_status'}
+    assert len(declared) >= 25
+    lib = _lib.load()
+    for name in sorted(declared):
+        assert hasattr(lib, name), f'{name} is declared in include/demux_hip.h but not exported'
+    assert declared == set(_lib.SIGNATURES), declared ^ set(_lib.SIGNATURES)
+    assert lib.dmx_version().decode().startswith('demux_hip')
+
+
+def test_no_gpu_means_loud_failure():
+    from demuxalot_amd import _lib
+    from demuxalot_amd.device import DeviceContext
+    if _lib.device_count() > 0:
+        pytest.skip('a GPU is visible')
+    with pytest.raises(_lib.DemuxHipError, match='no HIP device'):
+        DeviceContext(0)
+
+
+def test_product_does_not_import_oracle():
+    """The oracle is test infrastructure: nothing under demuxalot_amd/ may reference it."""
+    pkg = os.path.join(ROOT, 'demuxalot_amd')
+    for dirpath, _dirs, files in os.walk(pkg):
+        for f in files:
+            if f.endswith(('.py', '.cpp', '.hip', '.h')):
+                text = open(os.path.join(dirpath, f)).read()
+                assert 'import oracle' not in text and 'from oracle' not in text and 'demux_oracle' not in text, f
+
+
+@pytest.mark.parametrize('name', fio.SMALL + fio.SYNTH)
+def test_pack_calls_matches_reference(name):
+    from demuxalot_amd import Demultiplexer
+    fx = fio.load(name)
+    calls, genotypes, _handler = fio.product_inputs(fx)
+    for flag in (False, True):
+        v2snp, betas, molecule_calls, bc = Demultiplexer.pack_calls(calls, genotypes, add_data_prior=flag)
+        assert v2snp.dtype == np.int32 and np.array_equal(v2snp, fx['pack_v2snp'])
+        fio.assert_bitwise(betas, fx[f'pack{int(flag)}_betas'], 'prior betas')
+        assert not betas.flags.writeable
+        assert len(molecule_calls) == int(fx['pack_n_molecule_calls'])
+        assert molecule_calls.dtype.names == ('variant_id', 'snp_id', 'compressed_cb', 'molecule_id',
+                                              'p_base_wrong', 'p_molecule_aligned_wrong')
+        assert np.array_equal(bc['variant_id'], fx['pack_bc_variant_id'])
+        assert np.array_equal(bc['snp_id'], fx['pack_bc_snp_id'])
+        assert np.array_equal(bc['compressed_cb'], fx['pack_bc_cb'])
+        fio.assert_bitwise(bc['p_base_wrong'], fx['pack_bc_p'], 'p_base_wrong')
+        assert np.array_equal(bc['barcode_variant_count'], fx['pack_bc_variant_count'])
+        assert np.array_equal(bc['barcode_snp_count'], fx['pack_bc_snp_count'])
+        assert bc['barcode_snp_count'].dtype == np.float64 and bc['barcode_variant_count'].dtype == np.int64
+
+
+def test_pack_asserts_like_reference():
+    from demuxalot_amd import CompressedSNPCalls, Demultiplexer, ProbabilisticGenotypes
+    g = ProbabilisticGenotypes(['A', 'B'])
+    g.var2varid = {('chr1', 5, 'A'): 0, ('chr1', 5, 'C'): 1}
+    g.variant_betas = np.ones((2, 2), dtype=np.float32)
+    ok = CompressedSNPCalls.from_arrays([0], [0], [5], [0], [0.01])
+    stray = CompressedSNPCalls.from_arrays([0], [0], [7], [1], [0.01])
+    # a chromosome that carries calls but has no variant in the genotypes trips the reference's assert (demux.py:359)
+    with pytest.raises(AssertionError):
+        Demultiplexer.pack_calls({'chr1': ok, 'chrX': stray}, g, add_data_prior=False)
+    # ... an empty container on such a chromosome does not
+    Demultiplexer.pack_calls({'chr1': ok, 'chrX': CompressedSNPCalls.from_arrays([], [], [], [], [])}, g, False)
+    g.variant_betas = -np.ones((2, 2), dtype=np.float32)
+    with pytest.raises(AssertionError, match='negative betas'):
+        Demultiplexer.pack_calls({'chr1': ok}, g, add_data_prior=False)
+
+
+def test_doublet_penalties_identity_and_golden():
+    """tests/test_utils.py:34-40 of the reference + the captured table."""
+    from scipy.special import softmax
+    from demuxalot_amd import Demultiplexer
+    for n_genotypes in [2, 3, 10]:
+        for doublet_prob in [0., 0.25, 0.5]:
+            pen = Demultiplexer._doublet_penalties(n_genotypes=n_genotypes, doublet_prior=doublet_prob)
+            assert np.allclose(softmax(pen)[:n_genotypes].sum(), 1 - doublet_prob)
+    for key, ref in fio.load('f4_doublet_penalties.npz').items():
+        G, dp = key.split('_dp')
+        fio.assert_bitwise(Demultiplexer._doublet_penalties(int(G[1:]), float(dp)), ref, key)
+    with pytest.raises(AssertionError):
+        Demultiplexer._doublet_penalties(4, 1.0)
+
+
+def test_genotypes_store_and_roundtrip(tmp_path):
+    """tests/test_synthetic.py:241-260 of the reference (save_betas -> add_prior_betas)."""
+    from demuxalot_amd import ProbabilisticGenotypes
+    fx = fio.load('f2_synthetic_g4.npz')
+    _calls, genotypes, _h = fio.product_inputs(fx)
+    assert genotypes.n_variants == len(fx['var_row']) and genotypes.n_genotypes == 4
+    assert not genotypes.get_betas().flags.writeable
+    path = tmp_path / 'genotypes.parquet'
+    genotypes.save_betas(path)
+    again = ProbabilisticGenotypes(genotype_names=genotypes.genotype_names, default_prior=genotypes.default_prior)
+    again.add_prior_betas(path)
+    assert set(again.var2varid) == set(genotypes.var2varid)
+    for variant, row in genotypes.var2varid.items():
+        assert np.allclose(genotypes.variant_betas[row], again.variant_betas[again.var2varid[variant]])
+    learnt = genotypes._with_betas(genotypes.get_betas() + np.float32(1))
+    assert learnt is not genotypes and learnt.variant_betas.shape == (genotypes.n_variants, 4)
+    with pytest.raises(AssertionError):
+        ProbabilisticGenotypes(['b', 'a'])
+    with pytest.raises(AssertionError):
+        genotypes._with_betas(np.zeros((3, 4), dtype=np.float32))
+
+
+def test_barcode_handler_and_container():
+    from demuxalot_amd import BarcodeHandler, CompressedSNPCalls
+    h = BarcodeHandler(['T-1', 'A-1', 'G-1'])
+    assert h.ordered_barcodes == ['A-1', 'G-1', 'T-1'] and h.n_barcodes == 3 and h.barcode2index['G-1'] == 1
+    with pytest.raises(AssertionError):
+        BarcodeHandler(['A', 'A'])
+    c = CompressedSNPCalls(start_snps_size=2, start_molecule_size=1)
+    c.add_calls_from_read_group(3, 77, 0.01, [(10, 'A', 0.1), (11, 'T', 0.2), (15, 'G', 0.3)])
+    c.add_calls_from_read_group(1, 78, 0.02, [(10, 'C', 0.1)])
+    assert (c.n_molecules, c.n_snp_calls) == (2, 4)
+    assert list(c.snp_calls[:4]['base_index']) == [0, 3, 2, 1] and list(c.snp_calls[:4]['molecule_index']) == [0, 0, 0, 1]
+    c.minimize_memory_footprint()
+    joined = CompressedSNPCalls.concatenate([c, c])
+    assert joined.n_molecules == 4 and list(joined.snp_calls['molecule_index']) == [0, 0, 0, 1, 2, 2, 2, 3]
