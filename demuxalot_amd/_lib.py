@@ -48,6 +48,7 @@ SIGNATURES = {
     'dmx_reset_timings': (c_int, [_P]),
     'dmx_device_bytes': (c_int, [_P, POINTER(c_int64)]),
     'dmx_test_logf': (c_int, [_P, _P, _P, c_int64]),
+    'dmx_test_logf_hot': (c_int, [_P, _P, _P, c_int64]),
     'dmx_test_expf': (c_int, [_P, _P, _P, c_int64]),
     'dmx_test_softmax': (c_int, [_P, _P, _P, c_int64, c_int64]),
 }

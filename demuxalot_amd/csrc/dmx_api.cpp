@@ -104,6 +104,7 @@ struct dmx_ctx {
     long long *d_item_start = nullptr;
     int *d_item_len = nullptr;
     long long *d_item_ptr = nullptr;
+    int *d_bc_order = nullptr, *d_item_order = nullptr;
     long long n_items = 0;
     int *d_v2snp = nullptr, *d_snp_ptr = nullptr, *d_snp_vars = nullptr;
     float *d_prior = nullptr, *d_add = nullptr, *d_prob = nullptr;
@@ -200,6 +201,8 @@ void release_problem(dmx_ctx *c)
     dev_free(c, &c->d_item_start, (size_t)c->n_items);
     dev_free(c, &c->d_item_len, (size_t)c->n_items);
     dev_free(c, &c->d_item_ptr, (size_t)c->V + 1);
+    dev_free(c, &c->d_bc_order, (size_t)c->B);
+    dev_free(c, &c->d_item_order, (size_t)c->n_items);
     dev_free(c, &c->d_v2snp, (size_t)c->V);
     dev_free(c, &c->d_snp_ptr, (size_t)c->S + 1);
     dev_free(c, &c->d_snp_vars, (size_t)c->V);
@@ -305,6 +308,7 @@ int run_estep(dmx_ctx *c, int with_doublets, bool with_prior, int prior_dtype)
 {
     dmx::EstepArgs a;
     a.row_ptr = c->d_row_ptr;
+    a.order = c->d_bc_order;
     a.calls = c->d_csr;
     a.prob = c->d_prob;
     a.opt_pairs = c->d_pairs;
@@ -327,6 +331,7 @@ int run_estep(dmx_ctx *c, int with_doublets, bool with_prior, int prior_dtype)
 int run_mstep(dmx_ctx *c, float power)
 {
     dmx::MstepArgs a;
+    a.order = c->d_item_order;
     a.item_start = c->d_item_start;
     a.item_len = c->d_item_len;
     a.calls = c->d_csc;
@@ -464,6 +469,9 @@ int dmx_set_problem(dmx_ctx *c, int64_t B, int64_t V, int32_t G, int64_t N, cons
     if (B < 0 || V < 0 || G <= 0 || N < 0) return fail(DMX_ERR_INVALID, "bad problem sizes B=%lld V=%lld G=%d N=%lld", (long long)B, (long long)V, G, (long long)N);
     if (G > 65535) return fail(DMX_ERR_UNSUPPORTED, "G=%d genotypes exceed the 16-bit option encoding", G);
     if (B >= (int64_t(1) << 31) || V >= (int64_t(1) << 31)) return fail(DMX_ERR_UNSUPPORTED, "B and V must fit int32");
+    if ((long long)V * G * 4 >= (1LL << 32))
+        return fail(DMX_ERR_UNSUPPORTED, "genotype table of %lld x %d floats exceeds the 4 GiB reachable by 32-bit row offsets",
+                    (long long)V, G);
     if (N > 0 && (!variant_id || !cb || !p_wrong)) return fail(DMX_ERR_INVALID, "null call arrays");
     if (V > 0 && !v2snp) return fail(DMX_ERR_INVALID, "null v2snp");
     HIP_TRY(hipStreamSynchronize(c->stream));
@@ -486,7 +494,8 @@ int dmx_set_problem(dmx_ctx *c, int64_t B, int64_t V, int32_t G, int64_t N, cons
         for (int64_t i = 0; i < N; i++) {
             uint32_t ebits;
             std::memcpy(&ebits, &p_wrong[i], 4);
-            csr[(size_t)rcur[cb[i]]++] = make_uint2((uint32_t)variant_id[i], ebits);
+            // E-step descriptor: byte offset of the variant's row in the [V, G] float32 prob table
+            csr[(size_t)rcur[cb[i]]++] = make_uint2((uint32_t)variant_id[i] * (uint32_t)G * 4u, ebits);
             csc[(size_t)ccur[variant_id[i]]++] = make_uint2((uint32_t)cb[i], ebits);
         }
     }
@@ -501,6 +510,20 @@ int dmx_set_problem(dmx_ctx *c, int64_t B, int64_t V, int32_t G, int64_t N, cons
         }
     }
     item_ptr[V] = (long long)item_start.size();
+    if (item_start.size() >= (size_t(1) << 31)) return fail(DMX_ERR_UNSUPPORTED, "too many M-step work items");
+    // work distribution: longest rows / items first, neighbours of similar length (counting sort by length)
+    auto by_decreasing_length = [](size_t count, auto length_of) {
+        long long max_len = 0;
+        for (size_t i = 0; i < count; i++) max_len = std::max<long long>(max_len, length_of(i));
+        std::vector<long long> start((size_t)max_len + 2, 0);
+        for (size_t i = 0; i < count; i++) start[(size_t)(max_len - length_of(i)) + 1]++;
+        for (size_t l = 0; l + 1 < start.size(); l++) start[l + 1] += start[l];
+        std::vector<int> order(count);
+        for (size_t i = 0; i < count; i++) order[(size_t)start[(size_t)(max_len - length_of(i))]++] = (int)i;
+        return order;
+    };
+    std::vector<int> bc_order = by_decreasing_length((size_t)B, [&](size_t b) { return row_ptr[b + 1] - row_ptr[b]; });
+    std::vector<int> item_order = by_decreasing_length(item_len.size(), [&](size_t i) { return (long long)item_len[i]; });
     // SNP groups: variants of each SNP in increasing variant index (np.bincount order)
     long long S = 0;
     for (int64_t v = 0; v < V; v++) {
@@ -529,6 +552,8 @@ int dmx_set_problem(dmx_ctx *c, int64_t B, int64_t V, int32_t G, int64_t N, cons
     DMX_TRY(dev_alloc(c, &c->d_item_start, (size_t)c->n_items));
     DMX_TRY(dev_alloc(c, &c->d_item_len, (size_t)c->n_items));
     DMX_TRY(dev_alloc(c, &c->d_item_ptr, (size_t)V + 1));
+    DMX_TRY(dev_alloc(c, &c->d_bc_order, (size_t)B));
+    DMX_TRY(dev_alloc(c, &c->d_item_order, (size_t)c->n_items));
     DMX_TRY(dev_alloc(c, &c->d_v2snp, (size_t)V));
     DMX_TRY(dev_alloc(c, &c->d_snp_ptr, (size_t)S + 1));
     DMX_TRY(dev_alloc(c, &c->d_snp_vars, (size_t)V));
@@ -550,6 +575,9 @@ int dmx_set_problem(dmx_ctx *c, int64_t B, int64_t V, int32_t G, int64_t N, cons
         HIP_TRY(hipMemcpyAsync(c->d_item_len, item_len.data(), sizeof(int) * c->n_items, hipMemcpyHostToDevice, st));
     }
     HIP_TRY(hipMemcpyAsync(c->d_item_ptr, item_ptr.data(), sizeof(long long) * (V + 1), hipMemcpyHostToDevice, st));
+    if (B) HIP_TRY(hipMemcpyAsync(c->d_bc_order, bc_order.data(), sizeof(int) * B, hipMemcpyHostToDevice, st));
+    if (c->n_items)
+        HIP_TRY(hipMemcpyAsync(c->d_item_order, item_order.data(), sizeof(int) * c->n_items, hipMemcpyHostToDevice, st));
     if (V) {
         HIP_TRY(hipMemcpyAsync(c->d_v2snp, v2snp, sizeof(int) * V, hipMemcpyHostToDevice, st));
         HIP_TRY(hipMemcpyAsync(c->d_snp_vars, snp_vars.data(), sizeof(int) * V, hipMemcpyHostToDevice, st));
@@ -800,6 +828,7 @@ static int unary_test(dmx_ctx *c, const float *in, float *out, int64_t n, int wh
     HIP_TRY(hipMemcpyAsync(d_in, in, (size_t)n * 4, hipMemcpyHostToDevice, c->stream));
     if (which == 0) HIP_TRY(dmx::launch_test_log(c->stream, d_in, d_out, n));
     if (which == 1) HIP_TRY(dmx::launch_test_exp(c->stream, d_in, d_out, n));
+    if (which == 3) HIP_TRY(dmx::launch_test_log_hot(c->stream, d_in, d_out, n));
     if (which == 2) HIP_TRY(dmx::launch_test_softmax(c->stream, d_in, d_out, rows, (int)cols));
     HIP_TRY(hipMemcpyAsync(out, d_out, (size_t)n * 4, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
@@ -807,6 +836,7 @@ static int unary_test(dmx_ctx *c, const float *in, float *out, int64_t n, int wh
 }
 
 int dmx_test_logf(dmx_ctx *c, const float *in, float *out, int64_t n) { return unary_test(c, in, out, n, 0, 0, 0); }
+int dmx_test_logf_hot(dmx_ctx *c, const float *in, float *out, int64_t n) { return unary_test(c, in, out, n, 3, 0, 0); }
 int dmx_test_expf(dmx_ctx *c, const float *in, float *out, int64_t n) { return unary_test(c, in, out, n, 1, 0, 0); }
 int dmx_test_softmax(dmx_ctx *c, const float *in, float *out, int64_t rows, int64_t cols)
 {

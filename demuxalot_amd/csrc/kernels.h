@@ -8,7 +8,9 @@ namespace dmx {
 
 struct EstepArgs {
     const long long *row_ptr;   // [B+1] CSR offsets (barcode-major)
-    const uint2 *calls;         // [N] (variant_id, bits of p_base_wrong), sorted by (barcode, input order)
+    const int *order;           // [B] barcodes by decreasing row length (work distribution)
+    const uint2 *calls;         // [N] (variant_id * G * 4 = byte offset of the prob row, bits of p_base_wrong),
+                                //     sorted by (barcode, input order)
     const float *prob;          // [V, G] genotype_prob, row-major
     const unsigned *opt_pairs;  // [K] g1 | g2 << 16 (doublet runs only)
     const float *pen;           // [K] doublet penalties
@@ -22,6 +24,7 @@ struct EstepArgs {
 };
 
 struct MstepArgs {
+    const int *order;             // [n_items] items by decreasing length (work distribution)
     const long long *item_start;  // [n_items] first CSC call of the item
     const int *item_len;          // [n_items] number of calls (<= ITEM_CALLS)
     const uint2 *calls;           // [N] (compressed_cb, bits of p_base_wrong), variant-major
@@ -47,6 +50,7 @@ hipError_t launch_f64_to_f32(hipStream_t st, const double *in, float *out, long 
 hipError_t launch_f32_to_f64(hipStream_t st, const float *in, double *out, long long n);
 hipError_t launch_assign(hipStream_t st, const float *post, long long B, int K, int *best, float *best_p);
 hipError_t launch_test_log(hipStream_t st, const float *in, float *out, long long n);
+hipError_t launch_test_log_hot(hipStream_t st, const float *in, float *out, long long n);
 hipError_t launch_test_exp(hipStream_t st, const float *in, float *out, long long n);
 hipError_t launch_test_softmax(hipStream_t st, const float *in, float *out, long long rows, int cols);
 

@@ -56,38 +56,40 @@ __global__ __launch_bounds__(256) void k_probs_from_betas(const float *__restric
 }
 
 // ------------------------------------------------------------------------------------
-// helpers for the in-register softmax of the direct kernel: option k lives in lane (k & 63),
-// register slot (k >> 6).
+// helpers for the in-register softmax of the direct kernel: option k of a lane group lives in
+// lane (group base + (k & 63)), register slot (k >> 6).
 // ------------------------------------------------------------------------------------
 template <int A>
-static __device__ __forceinline__ float reg_elem(const float (&x)[A], int i)
+static __device__ __forceinline__ float reg_elem(const float (&x)[A], int i, int gbase)
 {
     float v = 0.0f;
 #pragma unroll
     for (int a = 0; a < A; a++) {
-        const float t = __shfl(x[a], i & 63);
+        const float t = __shfl(x[a], gbase + (i & 63));
         v = ((i >> 6) == a) ? t : v;
     }
     return v;
 }
 
-// numpy pairwise block (n <= 128) over elements [start, start+n) held in registers
+// numpy pairwise block (n <= 128) over elements [start, start+n) held in registers.
+// Lane groups are 8-aligned whenever n >= 8 can occur, so (lane & 7) indexes the 8 partial sums
+// and the xor butterflies stay inside the group.
 template <int A>
-static __device__ __forceinline__ float reg_block_sum(const float (&x)[A], int start, int n, int lane)
+static __device__ __forceinline__ float reg_block_sum(const float (&x)[A], int start, int n, int lane, int gbase)
 {
     if (n < 8) {
         float res = 0.0f;
-        for (int i = 0; i < n; i++) res += reg_elem<A>(x, start + i);
+        for (int i = 0; i < n; i++) res += reg_elem<A>(x, start + i, gbase);
         return res;
     }
     const int j = lane & 7;
     const int nfull = n - (n & 7);
-    float r = reg_elem<A>(x, start + j);
-    for (int i = 8; i < nfull; i += 8) r += reg_elem<A>(x, start + i + j);
+    float r = reg_elem<A>(x, start + j, gbase);
+    for (int i = 8; i < nfull; i += 8) r += reg_elem<A>(x, start + i + j, gbase);
     r = r + __shfl_xor(r, 1);
     r = r + __shfl_xor(r, 2);
     r = r + __shfl_xor(r, 4);
-    for (int i = nfull; i < n; i++) r += reg_elem<A>(x, start + i);
+    for (int i = nfull; i < n; i++) r += reg_elem<A>(x, start + i, gbase);
     return r;
 }
 
@@ -99,101 +101,126 @@ static __device__ __forceinline__ int pw_half(int n)
 
 // np.sum of K <= 256 register-resident elements
 template <int A>
-static __device__ __forceinline__ float reg_row_sum(const float (&x)[A], int K, int lane)
+static __device__ __forceinline__ float reg_row_sum(const float (&x)[A], int K, int lane, int gbase)
 {
-    if (K <= 128) return reg_block_sum<A>(x, 0, K, lane);
+    if (K <= 128) return reg_block_sum<A>(x, 0, K, lane, gbase);
     const int h = pw_half(K);
-    const float left = reg_block_sum<A>(x, 0, h, lane);
+    const float left = reg_block_sum<A>(x, 0, h, lane, gbase);
     const int rn = K - h;
     float right;
     if (rn <= 128) {
-        right = reg_block_sum<A>(x, h, rn, lane);
+        right = reg_block_sum<A>(x, h, rn, lane, gbase);
     } else {
         const int h2 = pw_half(rn);
-        right = reg_block_sum<A>(x, h, h2, lane) + reg_block_sum<A>(x, h + h2, rn - h2, lane);
+        right = reg_block_sum<A>(x, h, h2, lane, gbase) + reg_block_sum<A>(x, h + h2, rn - h2, lane, gbase);
     }
     return left + right;
 }
 
+// value of lane (group base + i) for every lane of the group; i is wave-uniform
+template <int L, typename T>
+static __device__ __forceinline__ T group_bcast(T v, int i, int gbase)
+{
+    static_assert(sizeof(T) == 4, "32-bit payloads");
+    if (L == 64) {
+        const int r = __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), i);  // -> SGPR
+        return __builtin_bit_cast(T, r);
+    }
+    return __shfl(v, gbase + i);
+}
+
+template <int L>
+static __device__ __forceinline__ int group_max_over_wave(int v)
+{
+#pragma unroll
+    for (int off = L; off < 64; off <<= 1) v = max(v, __shfl_xor(v, off));
+    return v;
+}
+
 // ------------------------------------------------------------------------------------
-// E-step, direct form.  One wavefront per barcode; the 64 lanes are split into 64/L groups
-// of L lanes; a group handles one call per step, lane (l % L) + 64*a handles option k.
-// Per call: one 8-byte descriptor (variant, p_base_wrong) and G*4 bytes of the prob row.
+// E-step, direct form (K <= 256).  A wavefront is cut into 64/L lane groups; every group owns
+// one barcode and walks its calls IN ORDER (so the float64 sum has the reference's bincount
+// association), lane l of the group accumulates option l (+64*s).  Barcodes are handed out from
+// a row-length-sorted list, so the groups of a wave (and neighbouring waves) finish together.
+// Per L calls a group loads L 8-byte descriptors coalesced (prob-row byte offset, p_base_wrong),
+// derives 1-e and max(e,1e-4) once per call, and broadcasts them call by call; per call the
+// group reads G*4 contiguous bytes of the prob table.
 // ------------------------------------------------------------------------------------
 template <int L, int A, bool PAIRS, int U>
 __global__ __launch_bounds__(256) void k_estep_direct(EstepArgs a)
 {
     static_assert(A == 1 || L == 64, "several accumulators per lane only with 64 lanes per call");
+    static_assert(L % U == 0, "descriptor chunk must be a multiple of the unroll");
     constexpr int CPW = 64 / L;
     const int lane = threadIdx.x & 63;
-    const long long b = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (b >= a.B) return;
-    const int sub = lane / L;
-    const int o0 = lane % L;
-    const int K = a.K, G = a.G;
+    const int li = lane % L;
+    const int gbase = lane - li;
+    const long long slot = ((long long)blockIdx.x * 4 + (threadIdx.x >> 6)) * CPW + lane / L;
+    const bool live = slot < a.B;
+    const long long b = a.order[live ? slot : a.B - 1];
+    const long long beg = a.row_ptr[b];
+    const int n = live ? (int)(a.row_ptr[b + 1] - beg) : 0;
+    const uint2 *__restrict__ calls = a.calls + beg;
+    const int nmax = group_max_over_wave<L>(n);
+    const int K = a.K;
 
-    int g1[A], g2[A];
+    int o1[A], o2[A], kk[A];
     bool valid[A];
-    int kk[A];
 #pragma unroll
     for (int s = 0; s < A; s++) {
-        const int k = o0 + 64 * s;
+        const int k = li + 64 * s;
         valid[s] = k < K;
         kk[s] = valid[s] ? k : K - 1;
         if (PAIRS) {
             const unsigned pr = a.opt_pairs[kk[s]];
-            g1[s] = pr & 0xFFFF;
-            g2[s] = pr >> 16;
+            o1[s] = (pr & 0xFFFF) * 4;
+            o2[s] = (pr >> 16) * 4;
         } else {
-            g1[s] = kk[s];
-            g2[s] = kk[s];
+            o1[s] = kk[s] * 4;
+            o2[s] = o1[s];
         }
     }
-
     double acc[A];
 #pragma unroll
     for (int s = 0; s < A; s++) acc[s] = 0.0;
 
-    const long long beg = a.row_ptr[b], end = a.row_ptr[b + 1];
-    for (long long pos = beg; pos < end; pos += CPW * U) {
-        uint2 d[U];
-        bool ok[U];
+    const char *__restrict__ prob = (const char *)a.prob;
+    for (int c0 = 0; c0 < nmax; c0 += L) {
+        // descriptor of call c0 + li of this group's row (clamped: finished groups reload their last one)
+        int ci = c0 + li;
+        ci = ci < n ? ci : n - 1;
+        uint2 d = make_uint2(0u, 0u);
+        if (n > 0) d = calls[ci];
+        const float e = __uint_as_float(d.y);
+        const bool pad = (c0 + li) >= n;  // past the end of this group's row
+        // padding calls get keep = 0, floor = 1: p*0 + 1 = 1 and log(1) = +0 exactly, so they add nothing
+        const float keep_v = pad ? 0.0f : 1.0f - e;
+        const float floor_v = pad ? 1.0f : (e > 1e-4f ? e : 1e-4f);  // e.clip(1e-4)
+        const int cnt = (nmax - c0) < L ? (nmax - c0) : L;
+        for (int i0 = 0; i0 < cnt; i0 += U) {
+            float p1[U][A], p2[U][A], keep[U], flo[U];
 #pragma unroll
-        for (int u = 0; u < U; u++) {
-            const long long idx = pos + u * CPW + sub;
-            ok[u] = idx < end;
-            d[u] = a.calls[ok[u] ? idx : beg];
-        }
-        float p1[U][A], p2[U][A];
+            for (int u = 0; u < U; u++) {
+                const unsigned ro = group_bcast<L>(d.x, i0 + u, gbase);
+                keep[u] = group_bcast<L>(keep_v, i0 + u, gbase);
+                flo[u] = group_bcast<L>(floor_v, i0 + u, gbase);
 #pragma unroll
-        for (int u = 0; u < U; u++) {
-            const float *row = a.prob + (size_t)d[u].x * G;
+                for (int s = 0; s < A; s++) {
+                    p1[u][s] = *(const float *)(prob + (ro + (unsigned)o1[s]));
+                    if (PAIRS) p2[u][s] = *(const float *)(prob + (ro + (unsigned)o2[s]));
+                }
+            }
 #pragma unroll
-            for (int s = 0; s < A; s++) {
-                p1[u][s] = row[g1[s]];
-                if (PAIRS) p2[u][s] = row[g2[s]];
+            for (int u = 0; u < U; u++) {
+#pragma unroll
+                for (int s = 0; s < A; s++) {
+                    const float p = PAIRS ? (p1[u][s] + p2[u][s]) * 0.5f : p1[u][s];
+                    float t = p * keep[u];
+                    t = t + flo[u];
+                    acc[s] += (double)npm::log_f32<false, true>(t);
+                }
             }
         }
-#pragma unroll
-        for (int u = 0; u < U; u++) {
-            const float e = __uint_as_float(d[u].y);
-            const float keep = 1.0f - e;
-            const float flo = fmaxf(e, 1e-4f);
-#pragma unroll
-            for (int s = 0; s < A; s++) {
-                const float p = PAIRS ? (p1[u][s] + p2[u][s]) * 0.5f : p1[u][s];
-                float t = p * keep;
-                t = t + flo;
-                const float lp = npm::log_f32<false>(t);
-                acc[s] += ok[u] ? (double)lp : 0.0;
-            }
-        }
-    }
-    // groups -> lanes 0..L-1
-#pragma unroll
-    for (int off = L; off < 64; off <<= 1) {
-#pragma unroll
-        for (int s = 0; s < A; s++) acc[s] += shfl_xor_f64(acc[s], off);
     }
 
     // epilogue: penalties, optional prior, softmax as scipy evaluates it
@@ -211,16 +238,16 @@ __global__ __launch_bounds__(256) void k_estep_direct(EstepArgs a)
                 l = (float)((double)l + ((const double *)a.prior)[o]);
         }
         lg[s] = l;
-        mx = (valid[s] && sub == 0) ? fmaxf(mx, l) : mx;
+        mx = valid[s] ? fmaxf(mx, l) : mx;
     }
 #pragma unroll
-    for (int off = 1; off < 64; off <<= 1) mx = fmaxf(mx, __shfl_xor(mx, off));
+    for (int off = 1; off < L; off <<= 1) mx = fmaxf(mx, __shfl_xor(mx, off));
 #pragma unroll
     for (int s = 0; s < A; s++) x[s] = npm::exp_f32(lg[s] - mx);
-    const float tot = reg_row_sum<A>(x, K, lane);
+    const float tot = reg_row_sum<A>(x, K, lane, gbase);
 #pragma unroll
     for (int s = 0; s < A; s++) {
-        if (valid[s] && sub == 0) {
+        if (live && valid[s]) {
             const size_t o = (size_t)b * K + kk[s];
             a.logits[o] = lg[s];
             a.post[o] = x[s] / tot;
@@ -240,7 +267,7 @@ __global__ __launch_bounds__(256) void k_estep_block(EstepArgs a, int C)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const long long b = blockIdx.x;
+    const long long b = a.order[blockIdx.x];
     const int K = a.K, G = a.G;
     // LDS carve: rows [C*G] f32 | keep [C] | floor [C] | vid [C] | red [8]; the softmax reuses
     // the front of the buffer for K floats (launcher sizes smem for the larger of the two).
@@ -273,7 +300,7 @@ __global__ __launch_bounds__(256) void k_estep_block(EstepArgs a, int C)
         __syncthreads();
         for (int i = tid; i < n * G; i += 256) {
             const int c = i / G, g = i - c * G;
-            sh_rows[i] = a.prob[(size_t)sh_vid[c] * G + g];
+            sh_rows[i] = *(const float *)((const char *)a.prob + ((unsigned)sh_vid[c] + (unsigned)g * 4u));
         }
         __syncthreads();
         for (int c = 0; c < n; c++) {
@@ -284,7 +311,7 @@ __global__ __launch_bounds__(256) void k_estep_block(EstepArgs a, int C)
                 const float p = (row[pr[s] & 0xFFFF] + row[pr[s] >> 16]) * 0.5f;
                 float t = p * keep;
                 t = t + flo;
-                acc[s] += (double)npm::log_f32<false>(t);
+                acc[s] += (double)npm::log_f32<false, true>(t);
             }
         }
     }
@@ -345,68 +372,71 @@ __global__ __launch_bounds__(256) void k_estep_block(EstepArgs a, int C)
 }
 
 // ------------------------------------------------------------------------------------
-// M-step.  One wavefront per work item (a run of <= ITEM_CALLS consecutive CSC calls of one
-// variant); lanes = genotypes; gathers the singlet columns of the posterior row of each call's
-// barcode; float64 accumulation in CSC (= reference bincount) order; float64 partial per item.
+// M-step.  Work item = a run of <= ITEM_CALLS consecutive CSC calls of one variant.  As in the
+// E-step a wavefront is cut into 64/L lane groups; a group owns one item and walks it in CSC
+// (= reference bincount) order, lane = genotype; it gathers the singlet columns of the
+// posterior row of each call's barcode; float64 accumulation; one float64 partial per item.
+// Items are handed out from a length-sorted list.
 // ------------------------------------------------------------------------------------
 template <int L, int A, int U, bool SQUARE>
 __global__ __launch_bounds__(256) void k_mstep(MstepArgs a)
 {
     static_assert(A == 1 || L == 64, "several accumulators per lane only with 64 lanes per call");
+    static_assert(L % U == 0, "descriptor chunk must be a multiple of the unroll");
     constexpr int CPW = 64 / L;
     const int lane = threadIdx.x & 63;
-    const long long item = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (item >= a.n_items) return;
-    const int sub = lane / L;
-    const int g0 = lane % L;
+    const int li = lane % L;
+    const int gbase = lane - li;
+    const long long slot = ((long long)blockIdx.x * 4 + (threadIdx.x >> 6)) * CPW + lane / L;
+    const bool live = slot < a.n_items;
+    const long long item = a.order[live ? slot : a.n_items - 1];
+    const int n = live ? a.item_len[item] : 0;
+    const uint2 *__restrict__ calls = a.calls + a.item_start[item];
+    const int nmax = group_max_over_wave<L>(n);
     const int G = a.G;
-    int gg[A];
+    int go[A];
 #pragma unroll
     for (int s = 0; s < A; s++) {
-        const int g = g0 + 64 * s;
-        gg[s] = g < G ? g : G - 1;
+        const int g = li + 64 * s;
+        go[s] = g < G ? g : G - 1;
     }
     double acc[A];
 #pragma unroll
     for (int s = 0; s < A; s++) acc[s] = 0.0;
 
-    const long long beg = a.item_start[item], end = beg + a.item_len[item];
-    for (long long pos = beg; pos < end; pos += CPW * U) {
-        uint2 d[U];
-        bool ok[U];
+    for (int c0 = 0; c0 < nmax; c0 += L) {
+        int ci = c0 + li;
+        ci = ci < n ? ci : n - 1;
+        uint2 d = make_uint2(0u, 0u);
+        if (n > 0) d = calls[ci];
+        // padding calls get keep = 0: (p*0)^power = +0 adds nothing
+        const float keep_v = (c0 + li) >= n ? 0.0f : 1.0f - __uint_as_float(d.y);
+        const int cnt = (nmax - c0) < L ? (nmax - c0) : L;
+        for (int i0 = 0; i0 < cnt; i0 += U) {
+            float p[U][A], keep[U];
 #pragma unroll
-        for (int u = 0; u < U; u++) {
-            const long long idx = pos + u * CPW + sub;
-            ok[u] = idx < end;
-            d[u] = a.calls[ok[u] ? idx : beg];
-        }
-        float p[U][A];
+            for (int u = 0; u < U; u++) {
+                const unsigned cb = group_bcast<L>(d.x, i0 + u, gbase);
+                keep[u] = group_bcast<L>(keep_v, i0 + u, gbase);
+                const float *row = a.post + (size_t)cb * a.K;
 #pragma unroll
-        for (int u = 0; u < U; u++) {
-            const float *row = a.post + (size_t)d[u].x * a.K;
+                for (int s = 0; s < A; s++) p[u][s] = row[go[s]];
+            }
 #pragma unroll
-            for (int s = 0; s < A; s++) p[u][s] = row[gg[s]];
-        }
+            for (int u = 0; u < U; u++) {
 #pragma unroll
-        for (int u = 0; u < U; u++) {
-            const float keep = 1.0f - __uint_as_float(d[u].y);
-#pragma unroll
-            for (int s = 0; s < A; s++) {
-                float c = p[u][s] * keep;
-                c = SQUARE ? c * c : powf(c, a.power);
-                acc[s] += ok[u] ? (double)c : 0.0;
+                for (int s = 0; s < A; s++) {
+                    float c = p[u][s] * keep[u];
+                    c = SQUARE ? c * c : powf(c, a.power);
+                    acc[s] += (double)c;
+                }
             }
         }
     }
 #pragma unroll
-    for (int off = L; off < 64; off <<= 1) {
-#pragma unroll
-        for (int s = 0; s < A; s++) acc[s] += shfl_xor_f64(acc[s], off);
-    }
-#pragma unroll
     for (int s = 0; s < A; s++) {
-        const int g = g0 + 64 * s;
-        if (sub == 0 && g < G) a.partial[(size_t)item * G + g] = acc[s];
+        const int g = li + 64 * s;
+        if (live && g < G) a.partial[(size_t)item * G + g] = acc[s];
     }
 }
 
@@ -479,6 +509,12 @@ __global__ __launch_bounds__(256) void k_test_log(const float *in, float *out, l
     if (i < n) out[i] = npm::log_f32<true>(in[i]);
 }
 
+__global__ __launch_bounds__(256) void k_test_log_hot(const float *in, float *out, long long n)
+{
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = npm::log_f32<false, true>(in[i]);  // the form the E-step kernels use
+}
+
 __global__ __launch_bounds__(256) void k_test_exp(const float *in, float *out, long long n)
 {
     const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -522,7 +558,7 @@ hipError_t launch_probs_from_betas(hipStream_t st, const float *prior, const flo
 template <int L, int A, int U>
 static void launch_direct(hipStream_t st, const EstepArgs &a, bool pairs)
 {
-    const dim3 grid(blocks_for(a.B, 4)), block(256);
+    const dim3 grid(blocks_for(a.B, 4 * (64 / L))), block(256);
     if (pairs)
         hipLaunchKernelGGL((k_estep_direct<L, A, true, U>), grid, block, 0, st, a);
     else
@@ -550,7 +586,7 @@ hipError_t launch_estep(hipStream_t st, const EstepArgs &a, bool pairs)
     if (a.B == 0) return hipSuccess;
     const int K = a.K;
     if (K <= 256) {
-        if (K <= 4) launch_direct<4, 1, 8>(st, a, pairs);
+        if (K <= 4) launch_direct<4, 1, 4>(st, a, pairs);
         else if (K <= 8) launch_direct<8, 1, 8>(st, a, pairs);
         else if (K <= 16) launch_direct<16, 1, 8>(st, a, pairs);
         else if (K <= 32) launch_direct<32, 1, 8>(st, a, pairs);
@@ -573,17 +609,18 @@ hipError_t launch_estep(hipStream_t st, const EstepArgs &a, bool pairs)
 template <int L, int A, int U>
 static void launch_m(hipStream_t st, const MstepArgs &a)
 {
+    const dim3 grid(blocks_for(a.n_items, 4 * (64 / L)));
     if (a.square)
-        hipLaunchKernelGGL((k_mstep<L, A, U, true>), dim3(blocks_for(a.n_items, 4)), dim3(256), 0, st, a);
+        hipLaunchKernelGGL((k_mstep<L, A, U, true>), grid, dim3(256), 0, st, a);
     else
-        hipLaunchKernelGGL((k_mstep<L, A, U, false>), dim3(blocks_for(a.n_items, 4)), dim3(256), 0, st, a);
+        hipLaunchKernelGGL((k_mstep<L, A, U, false>), grid, dim3(256), 0, st, a);
 }
 
 hipError_t launch_mstep(hipStream_t st, const MstepArgs &a)
 {
     if (a.n_items == 0) return hipSuccess;
     const int G = a.G;
-    if (G <= 4) launch_m<4, 1, 8>(st, a);
+    if (G <= 4) launch_m<4, 1, 4>(st, a);
     else if (G <= 8) launch_m<8, 1, 8>(st, a);
     else if (G <= 16) launch_m<16, 1, 8>(st, a);
     else if (G <= 32) launch_m<32, 1, 8>(st, a);
@@ -627,6 +664,13 @@ hipError_t launch_test_log(hipStream_t st, const float *in, float *out, long lon
 {
     if (n == 0) return hipSuccess;
     hipLaunchKernelGGL(k_test_log, dim3(blocks_for(n, 256)), dim3(256), 0, st, in, out, n);
+    return hipGetLastError();
+}
+
+hipError_t launch_test_log_hot(hipStream_t st, const float *in, float *out, long long n)
+{
+    if (n == 0) return hipSuccess;
+    hipLaunchKernelGGL(k_test_log_hot, dim3(blocks_for(n, 256)), dim3(256), 0, st, in, out, n);
     return hipGetLastError();
 }
 

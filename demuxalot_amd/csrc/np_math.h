@@ -15,9 +15,25 @@
 
 namespace npm {
 
+// Correctly rounded num / den for the operands that occur inside log_f32: den = Q(r) lies in
+// [0.4, 2.7] and |num| < 1, so no range scaling / fix-up is needed: reciprocal estimate, one
+// Newton step, quotient, exact remainder, one correction (Markstein's sequence).  Because num
+// and den are functions of the 2^24 possible reduced arguments only, the equality with IEEE
+// division is checked EXHAUSTIVELY on the device (tests/test_gpu_parity.py::test_device_log_*).
+__device__ __forceinline__ float div_small_range(float num, float den)
+{
+    float rc = __builtin_amdgcn_rcpf(den);
+    const float e0 = __builtin_fmaf(-den, rc, 1.0f);
+    rc = __builtin_fmaf(e0, rc, rc);
+    const float q0 = num * rc;
+    const float rem = __builtin_fmaf(-den, q0, num);
+    return __builtin_fmaf(rem, rc, q0);
+}
+
 // SPECIALS = false is the hot-path form: its argument is finite and >= 1e-4 by construction of
-// the E-step term (a NaN input still comes out NaN through the arithmetic).
-template <bool SPECIALS = true>
+// the E-step term (a NaN input still comes out NaN through the arithmetic); FASTDIV selects
+// div_small_range instead of the compiler's generic IEEE division sequence.
+template <bool SPECIALS = true, bool FASTDIV = false>
 __device__ __forceinline__ float log_f32(float v)
 {
     const float P0 = 0.000000000000000000000e+00f, P1 = 9.999999999999998702752e-01f,
@@ -45,7 +61,8 @@ __device__ __forceinline__ float log_f32(float v)
     den = __builtin_fmaf(den, r, Q2);
     den = __builtin_fmaf(den, r, Q1);
     den = __builtin_fmaf(den, r, Q0);
-    const float q = num / den;  // IEEE-754 division (-fhip-fp32-correctly-rounded-divide-sqrt)
+    // IEEE-754 division (-fhip-fp32-correctly-rounded-divide-sqrt) or its range-restricted equal
+    const float q = FASTDIV ? div_small_range(num, den) : num / den;
     float res = __builtin_fmaf(kf, LN2, q);
     if (SPECIALS) {  // special values, as numpy returns them
         res = (v == 0.0f) ? -__builtin_inff() : res;

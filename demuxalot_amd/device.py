@@ -179,6 +179,12 @@ class DeviceContext:
         check(self._lib.dmx_test_logf(self._h, ptr(x), ptr(out), x.size))
         return out
 
+    def test_log_hot(self, x):
+        x = as_c(x, np.float32)
+        out = np.empty_like(x)
+        check(self._lib.dmx_test_logf_hot(self._h, ptr(x), ptr(out), x.size))
+        return out
+
     def test_exp(self, x):
         x = as_c(x, np.float32)
         out = np.empty_like(x)

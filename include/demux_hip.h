@@ -171,6 +171,8 @@ int dmx_device_bytes(dmx_ctx *ctx, int64_t *bytes);
  * the device restatements of numpy's float32 log / exp and of scipy's row softmax.
  * ------------------------------------------------------------------------- */
 int dmx_test_logf(dmx_ctx *ctx, const float *in, float *out, int64_t n);
+/* the form the E-step kernels inline: positive finite arguments only, range-restricted division */
+int dmx_test_logf_hot(dmx_ctx *ctx, const float *in, float *out, int64_t n);
 int dmx_test_expf(dmx_ctx *ctx, const float *in, float *out, int64_t n);
 int dmx_test_softmax(dmx_ctx *ctx, const float *in, float *out, int64_t rows, int64_t cols);
 

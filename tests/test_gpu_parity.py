@@ -44,6 +44,20 @@ def test_device_log_matches_numpy_kernel(ctx, oracle):
     assert np.array_equal(got[~np.isnan(want)], want[~np.isnan(want)])
 
 
+def test_device_log_hot_path_exhaustive(ctx, oracle):
+    """The E-step inlines log with a range-restricted division instead of the generic IEEE sequence.
+    Numerator and denominator depend only on the reduced argument, so every float32 in [0.5, 2)
+    (all 2^24 mantissa/branch combinations) proves the equality for every positive normal input;
+    a strided sweep over [1e-5, 4) adds the exponent handling."""
+    bits = np.arange(np.float32(0.5).view(np.int32), np.float32(2.0).view(np.int32), dtype=np.int32)
+    x = bits.view(np.float32)
+    assert len(x) == 2 ** 24
+    fio.assert_bitwise(ctx.test_log_hot(x), oracle.log_f32(x, impl='npsimd'), 'hot log, all mantissas')
+    lo, hi = np.float32(1e-5).view(np.int32), np.float32(4.0).view(np.int32)
+    x = np.arange(int(lo), int(hi), 11, dtype=np.int32).view(np.float32)
+    fio.assert_bitwise(ctx.test_log_hot(x), oracle.log_f32(x, impl='npsimd'), 'hot log, sweep')
+
+
 def test_device_exp_and_softmax_match_numpy_kernel(ctx, oracle):
     lo, hi = np.float32(-0.0).view(np.uint32), np.float32(-104.5).view(np.uint32)
     bits = np.arange(int(lo), int(hi), 41, dtype=np.uint32)
