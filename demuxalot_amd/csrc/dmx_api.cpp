@@ -98,8 +98,9 @@ struct dmx_ctx {
     int G = 0, K = 0;
     bool have_problem = false, have_betas = false, have_probs = false, have_post = false;
 
-    long long *d_row_ptr = nullptr;
-    uint2 *d_csr = nullptr;
+    long long *d_pair_ptr = nullptr;
+    dmx::CallPair *d_call_pairs = nullptr;
+    long long n_pairs = 0;
     uint2 *d_csc = nullptr;
     long long *d_item_start = nullptr;
     int *d_item_len = nullptr;
@@ -195,8 +196,9 @@ void timer_end(dmx_ctx *c, int slot, const std::pair<hipEvent_t, hipEvent_t> &ev
 
 void release_problem(dmx_ctx *c)
 {
-    dev_free(c, &c->d_row_ptr, (size_t)c->B + 1);
-    dev_free(c, &c->d_csr, (size_t)c->N);
+    dev_free(c, &c->d_pair_ptr, (size_t)c->B + 1);
+    dev_free(c, &c->d_call_pairs, (size_t)c->n_pairs);
+    c->n_pairs = 0;
     dev_free(c, &c->d_csc, (size_t)c->N);
     dev_free(c, &c->d_item_start, (size_t)c->n_items);
     dev_free(c, &c->d_item_len, (size_t)c->n_items);
@@ -307,9 +309,9 @@ int run_pstep(dmx_ctx *c, float lo, float hi, bool with_addition)
 int run_estep(dmx_ctx *c, int with_doublets, bool with_prior, int prior_dtype)
 {
     dmx::EstepArgs a;
-    a.row_ptr = c->d_row_ptr;
+    a.pair_ptr = c->d_pair_ptr;
     a.order = c->d_bc_order;
-    a.calls = c->d_csr;
+    a.pairs = c->d_call_pairs;
     a.prob = c->d_prob;
     a.opt_pairs = c->d_pairs;
     a.pen = c->d_pen;
@@ -318,6 +320,7 @@ int run_estep(dmx_ctx *c, int with_doublets, bool with_prior, int prior_dtype)
     a.logits = c->d_logits;
     a.post = c->d_post;
     a.B = c->B;
+    a.prob_bytes = (unsigned)((unsigned long long)c->V * c->G * 4ull);
     a.G = c->G;
     a.K = c->K;
     std::pair<hipEvent_t, hipEvent_t> ev;
@@ -488,14 +491,30 @@ int dmx_set_problem(dmx_ctx *c, int64_t B, int64_t V, int32_t G, int64_t N, cons
     }
     for (int64_t b = 0; b < B; b++) row_ptr[b + 1] += row_ptr[b];
     for (int64_t v = 0; v < V; v++) col_ptr[v + 1] += col_ptr[v];
-    std::vector<uint2> csr((size_t)N), csc((size_t)N);
+    // E-step records: rows padded to 8 calls with neutral calls, two calls per CallPair
+    std::vector<long long> pair_ptr((size_t)B + 1, 0);
+    for (int64_t b = 0; b < B; b++) pair_ptr[b + 1] = pair_ptr[b] + ((row_ptr[b + 1] - row_ptr[b] + 7) / 8) * 4;
+    const long long n_pairs = pair_ptr[B];
+    std::vector<dmx::CallPair> pairs((size_t)n_pairs);
+    for (auto &pr : pairs) {
+        pr.row_off[0] = pr.row_off[1] = 0u;
+        pr.keep[0] = pr.keep[1] = 0.0f;
+        pr.floor[0] = pr.floor[1] = 1.0f;
+        pr.reserved[0] = pr.reserved[1] = 0u;
+    }
+    std::vector<uint2> csc((size_t)N);
     {
-        std::vector<long long> rcur(row_ptr.begin(), row_ptr.end() - 1), ccur(col_ptr.begin(), col_ptr.end() - 1);
+        std::vector<long long> rcur((size_t)B, 0), ccur(col_ptr.begin(), col_ptr.end() - 1);
         for (int64_t i = 0; i < N; i++) {
+            const float e = p_wrong[i];
             uint32_t ebits;
-            std::memcpy(&ebits, &p_wrong[i], 4);
-            // E-step descriptor: byte offset of the variant's row in the [V, G] float32 prob table
-            csr[(size_t)rcur[cb[i]]++] = make_uint2((uint32_t)variant_id[i] * (uint32_t)G * 4u, ebits);
+            std::memcpy(&ebits, &e, 4);
+            const long long j = rcur[cb[i]]++;  // position inside the barcode's row (input order)
+            dmx::CallPair &pr = pairs[(size_t)(pair_ptr[cb[i]] + (j >> 1))];
+            // byte offset of the variant's row in the [V, G] float32 prob table
+            pr.row_off[j & 1] = (uint32_t)variant_id[i] * (uint32_t)G * 4u;
+            pr.keep[j & 1] = 1.0f - e;                    // float32, numpy's `1 - e`
+            pr.floor[j & 1] = e > 1e-4f ? e : 1e-4f;      // numpy's `e.clip(1e-4)`
             csc[(size_t)ccur[variant_id[i]]++] = make_uint2((uint32_t)cb[i], ebits);
         }
     }
@@ -546,8 +565,9 @@ int dmx_set_problem(dmx_ctx *c, int64_t B, int64_t V, int32_t G, int64_t N, cons
     c->S = S;
     c->n_items = (long long)item_start.size();
     const size_t vg = (size_t)V * G;
-    DMX_TRY(dev_alloc(c, &c->d_row_ptr, (size_t)B + 1));
-    DMX_TRY(dev_alloc(c, &c->d_csr, (size_t)N));
+    c->n_pairs = n_pairs;
+    DMX_TRY(dev_alloc(c, &c->d_pair_ptr, (size_t)B + 1));
+    DMX_TRY(dev_alloc(c, &c->d_call_pairs, (size_t)n_pairs));
     DMX_TRY(dev_alloc(c, &c->d_csc, (size_t)N));
     DMX_TRY(dev_alloc(c, &c->d_item_start, (size_t)c->n_items));
     DMX_TRY(dev_alloc(c, &c->d_item_len, (size_t)c->n_items));
@@ -565,11 +585,10 @@ int dmx_set_problem(dmx_ctx *c, int64_t B, int64_t V, int32_t G, int64_t N, cons
     DMX_TRY(dev_alloc(c, &c->d_best, (size_t)B));
     DMX_TRY(dev_alloc(c, &c->d_bestp, (size_t)B));
     hipStream_t st = c->stream;
-    HIP_TRY(hipMemcpyAsync(c->d_row_ptr, row_ptr.data(), sizeof(long long) * (B + 1), hipMemcpyHostToDevice, st));
-    if (N) {
-        HIP_TRY(hipMemcpyAsync(c->d_csr, csr.data(), sizeof(uint2) * N, hipMemcpyHostToDevice, st));
-        HIP_TRY(hipMemcpyAsync(c->d_csc, csc.data(), sizeof(uint2) * N, hipMemcpyHostToDevice, st));
-    }
+    HIP_TRY(hipMemcpyAsync(c->d_pair_ptr, pair_ptr.data(), sizeof(long long) * (B + 1), hipMemcpyHostToDevice, st));
+    if (n_pairs)
+        HIP_TRY(hipMemcpyAsync(c->d_call_pairs, pairs.data(), sizeof(dmx::CallPair) * n_pairs, hipMemcpyHostToDevice, st));
+    if (N) HIP_TRY(hipMemcpyAsync(c->d_csc, csc.data(), sizeof(uint2) * N, hipMemcpyHostToDevice, st));
     if (c->n_items) {
         HIP_TRY(hipMemcpyAsync(c->d_item_start, item_start.data(), sizeof(long long) * c->n_items, hipMemcpyHostToDevice, st));
         HIP_TRY(hipMemcpyAsync(c->d_item_len, item_len.data(), sizeof(int) * c->n_items, hipMemcpyHostToDevice, st));

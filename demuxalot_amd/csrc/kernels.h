@@ -6,11 +6,25 @@
 
 namespace dmx {
 
+// E-step call records.  A barcode's calls are stored in input order, padded to a multiple of 8
+// with neutral calls (keep 0, floor 1 -> log(p*0 + 1) = +0), two calls per 32-byte record so that
+// a wavefront can fetch them with scalar loads and feed the packed float32 instructions straight
+// from SGPR pairs:
+//   row_off  byte offset of the call's variant row in the [V, G] float32 prob table
+//   keep     1 - p_base_wrong                    (float32, as numpy evaluates `1 - e`)
+//   floor    max(p_base_wrong, 1e-4)             (`e.clip(1e-4)`)
+struct alignas(32) CallPair {
+    unsigned row_off[2];
+    float keep[2];
+    float floor[2];
+    unsigned reserved[2];
+};
+static_assert(sizeof(CallPair) == 32, "CallPair layout");
+
 struct EstepArgs {
-    const long long *row_ptr;   // [B+1] CSR offsets (barcode-major)
+    const long long *pair_ptr;  // [B+1] offsets into `pairs` (barcode-major, rows padded to 4 pairs)
     const int *order;           // [B] barcodes by decreasing row length (work distribution)
-    const uint2 *calls;         // [N] (variant_id * G * 4 = byte offset of the prob row, bits of p_base_wrong),
-                                //     sorted by (barcode, input order)
+    const CallPair *pairs;      // call records, see above
     const float *prob;          // [V, G] genotype_prob, row-major
     const unsigned *opt_pairs;  // [K] g1 | g2 << 16 (doublet runs only)
     const float *pen;           // [K] doublet penalties
@@ -19,6 +33,7 @@ struct EstepArgs {
     float *logits;              // [B, K]
     float *post;                // [B, K]
     long long B;
+    unsigned prob_bytes;        // V * G * 4 (< 4 GiB): extent of the prob table for buffer addressing
     int G;
     int K;
 };

@@ -142,29 +142,52 @@ static __device__ __forceinline__ int group_max_over_wave(int v)
 // one barcode and walks its calls IN ORDER (so the float64 sum has the reference's bincount
 // association), lane l of the group accumulates option l (+64*s).  Barcodes are handed out from
 // a row-length-sorted list, so the groups of a wave (and neighbouring waves) finish together.
-// Per L calls a group loads L 8-byte descriptors coalesced (prob-row byte offset, p_base_wrong),
-// derives 1-e and max(e,1e-4) once per call, and broadcasts them call by call; per call the
-// group reads G*4 contiguous bytes of the prob table.
+//   L == 64: the whole wave works on one barcode, so the call records are wave-uniform: they are
+//            fetched with scalar loads (s_load_dwordx8 per pair of calls) and keep/floor reach
+//            the packed multiplies/adds as SGPR pairs - no per-call VALU work besides the terms.
+//   L <  64: lane i of a group fetches the fields of call c0+i, the group broadcasts them call by
+//            call through ds_bpermute.
+// Per call the group reads G*4 contiguous bytes of the prob table (global_load_dword, SGPR base).
 // ------------------------------------------------------------------------------------
+template <int A, bool PAIRS, int U>
+static __device__ __forceinline__ void estep_terms(const float (&p1)[U][A], const float (&p2)[U][A],
+                                                   const float (&keep)[U], const float (&flo)[U], double (&acc)[A])
+{
+    // two terms per packed instruction: calls u and u+1 of the same option
+    static_assert(U % 2 == 0, "calls are processed in pairs");
+#pragma unroll
+    for (int u = 0; u < U; u += 2) {
+        const npm::f32x2 keep2 = {keep[u], keep[u + 1]};
+        const npm::f32x2 flo2 = {flo[u], flo[u + 1]};
+#pragma unroll
+        for (int s = 0; s < A; s++) {
+            npm::f32x2 p = {p1[u][s], p1[u + 1][s]};
+            if (PAIRS) {
+                const npm::f32x2 q = {p2[u][s], p2[u + 1][s]};
+                p = (p + q) * 0.5f;
+            }
+            npm::f32x2 t = p * keep2;
+            t = t + flo2;
+            const npm::f32x2 lp = npm::log_f32_hot2(t);
+            acc[s] += (double)lp.x;  // call order preserved: u before u+1
+            acc[s] += (double)lp.y;
+        }
+    }
+}
+
 template <int L, int A, bool PAIRS, int U>
 __global__ __launch_bounds__(256) void k_estep_direct(EstepArgs a)
 {
     static_assert(A == 1 || L == 64, "several accumulators per lane only with 64 lanes per call");
-    static_assert(L % U == 0, "descriptor chunk must be a multiple of the unroll");
+    static_assert(L % U == 0 && U % 2 == 0 && U <= 8, "rows are padded to 8 calls; chunks must tile them");
     constexpr int CPW = 64 / L;
     const int lane = threadIdx.x & 63;
     const int li = lane % L;
     const int gbase = lane - li;
-    const long long slot = ((long long)blockIdx.x * 4 + (threadIdx.x >> 6)) * CPW + lane / L;
-    const bool live = slot < a.B;
-    const long long b = a.order[live ? slot : a.B - 1];
-    const long long beg = a.row_ptr[b];
-    const int n = live ? (int)(a.row_ptr[b + 1] - beg) : 0;
-    const uint2 *__restrict__ calls = a.calls + beg;
-    const int nmax = group_max_over_wave<L>(n);
     const int K = a.K;
 
-    int o1[A], o2[A], kk[A];
+    unsigned o1[A], o2[A];  // byte offsets of this lane's genotype(s) inside a prob row
+    int kk[A];
     bool valid[A];
 #pragma unroll
     for (int s = 0; s < A; s++) {
@@ -173,52 +196,90 @@ __global__ __launch_bounds__(256) void k_estep_direct(EstepArgs a)
         kk[s] = valid[s] ? k : K - 1;
         if (PAIRS) {
             const unsigned pr = a.opt_pairs[kk[s]];
-            o1[s] = (pr & 0xFFFF) * 4;
-            o2[s] = (pr >> 16) * 4;
+            o1[s] = (pr & 0xFFFFu) * 4u;
+            o2[s] = (pr >> 16) * 4u;
         } else {
-            o1[s] = kk[s] * 4;
+            o1[s] = (unsigned)kk[s] * 4u;
             o2[s] = o1[s];
         }
     }
     double acc[A];
 #pragma unroll
     for (int s = 0; s < A; s++) acc[s] = 0.0;
-
     const char *__restrict__ prob = (const char *)a.prob;
-    for (int c0 = 0; c0 < nmax; c0 += L) {
-        // descriptor of call c0 + li of this group's row (clamped: finished groups reload their last one)
-        int ci = c0 + li;
-        ci = ci < n ? ci : n - 1;
-        uint2 d = make_uint2(0u, 0u);
-        if (n > 0) d = calls[ci];
-        const float e = __uint_as_float(d.y);
-        const bool pad = (c0 + li) >= n;  // past the end of this group's row
-        // padding calls get keep = 0, floor = 1: p*0 + 1 = 1 and log(1) = +0 exactly, so they add nothing
-        const float keep_v = pad ? 0.0f : 1.0f - e;
-        const float floor_v = pad ? 1.0f : (e > 1e-4f ? e : 1e-4f);  // e.clip(1e-4)
-        const int cnt = (nmax - c0) < L ? (nmax - c0) : L;
-        for (int i0 = 0; i0 < cnt; i0 += U) {
+
+    long long b;
+    bool live;
+    if constexpr (L == 64) {
+        // ---- wave-uniform path: everything about the row lives in SGPRs ----
+        const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+        const long long slot = (long long)blockIdx.x * 4 + wave;
+        if (slot >= a.B) return;
+        live = true;
+        b = a.order[slot];
+        const long long pbeg = a.pair_ptr[b];
+        const int npairs = (int)(a.pair_ptr[b + 1] - pbeg);
+        const CallPair *__restrict__ recs = a.pairs + pbeg;
+        // buffer addressing: descriptor base = prob table, voffset = this lane's genotype (VGPR, fixed),
+        // soffset = the call's row offset straight from the scalar load -> no VALU work per load
+        const __amdgpu_buffer_rsrc_t rsrc =
+            __builtin_amdgcn_make_buffer_rsrc((void *)a.prob, 0, (int)a.prob_bytes, 0x00020000);
+        for (int j0 = 0; j0 < npairs; j0 += U / 2) {
             float p1[U][A], p2[U][A], keep[U], flo[U];
 #pragma unroll
-            for (int u = 0; u < U; u++) {
-                const unsigned ro = group_bcast<L>(d.x, i0 + u, gbase);
-                keep[u] = group_bcast<L>(keep_v, i0 + u, gbase);
-                flo[u] = group_bcast<L>(floor_v, i0 + u, gbase);
+            for (int q = 0; q < U / 2; q++) {
+                const CallPair r = recs[j0 + q];
 #pragma unroll
-                for (int s = 0; s < A; s++) {
-                    p1[u][s] = *(const float *)(prob + (ro + (unsigned)o1[s]));
-                    if (PAIRS) p2[u][s] = *(const float *)(prob + (ro + (unsigned)o2[s]));
+                for (int h = 0; h < 2; h++) {
+                    keep[2 * q + h] = r.keep[h];
+                    flo[2 * q + h] = r.floor[h];
+#pragma unroll
+                    for (int s = 0; s < A; s++) {
+                        p1[2 * q + h][s] = __builtin_bit_cast(
+                            float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, (int)o1[s], (int)r.row_off[h], 0));
+                        if (PAIRS)
+                            p2[2 * q + h][s] = __builtin_bit_cast(
+                                float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, (int)o2[s], (int)r.row_off[h], 0));
+                    }
                 }
             }
+            estep_terms<A, PAIRS, U>(p1, p2, keep, flo, acc);
+        }
+    } else {
+        const long long slot = ((long long)blockIdx.x * 4 + (threadIdx.x >> 6)) * CPW + lane / L;
+        live = slot < a.B;
+        b = a.order[live ? slot : a.B - 1];
+        const long long pbeg = a.pair_ptr[b];
+        const int n = live ? 2 * (int)(a.pair_ptr[b + 1] - pbeg) : 0;  // calls incl. padding, multiple of 8
+        const unsigned *__restrict__ words = (const unsigned *)(a.pairs + pbeg);
+        const int nmax = group_max_over_wave<L>(n);
+        for (int c0 = 0; c0 < nmax; c0 += L) {
+            // fields of call c0 + li of this group's row; groups that are done feed neutral calls
+            const int ci = c0 + li;
+            const bool mine = ci < n;
+            const int w = mine ? (ci >> 1) * 8 + (ci & 1) : 0;
+            unsigned ro_v = 0u;
+            float keep_v = 0.0f, floor_v = 1.0f;
+            if (mine) {
+                ro_v = words[w];
+                keep_v = __uint_as_float(words[w + 2]);
+                floor_v = __uint_as_float(words[w + 4]);
+            }
+            const int cnt = (nmax - c0) < L ? (nmax - c0) : L;
+            for (int i0 = 0; i0 < cnt; i0 += U) {
+                float p1[U][A], p2[U][A], keep[U], flo[U];
 #pragma unroll
-            for (int u = 0; u < U; u++) {
+                for (int u = 0; u < U; u++) {
+                    const unsigned ro = group_bcast<L>(ro_v, i0 + u, gbase);
+                    keep[u] = group_bcast<L>(keep_v, i0 + u, gbase);
+                    flo[u] = group_bcast<L>(floor_v, i0 + u, gbase);
 #pragma unroll
-                for (int s = 0; s < A; s++) {
-                    const float p = PAIRS ? (p1[u][s] + p2[u][s]) * 0.5f : p1[u][s];
-                    float t = p * keep[u];
-                    t = t + flo[u];
-                    acc[s] += (double)npm::log_f32<false, true>(t);
+                    for (int s = 0; s < A; s++) {
+                        p1[u][s] = *(const float *)(prob + (ro + o1[s]));
+                        if (PAIRS) p2[u][s] = *(const float *)(prob + (ro + o2[s]));
+                    }
                 }
+                estep_terms<A, PAIRS, U>(p1, p2, keep, flo, acc);
             }
         }
     }
@@ -286,16 +347,17 @@ __global__ __launch_bounds__(256) void k_estep_block(EstepArgs a, int C)
 #pragma unroll
     for (int s = 0; s < A; s++) acc[s] = 0.0;
 
-    const long long beg = a.row_ptr[b], end = a.row_ptr[b + 1];
-    for (long long pos = beg; pos < end; pos += C) {
-        const int n = (int)((end - pos) < C ? (end - pos) : C);
+    const unsigned *__restrict__ words = (const unsigned *)(a.pairs + a.pair_ptr[b]);
+    const int n_calls = 2 * (int)(a.pair_ptr[b + 1] - a.pair_ptr[b]);  // incl. neutral padding calls
+    for (int pos = 0; pos < n_calls; pos += C) {
+        const int n = (n_calls - pos) < C ? (n_calls - pos) : C;
         __syncthreads();
         if (tid < n) {
-            const uint2 d = a.calls[pos + tid];
-            const float e = __uint_as_float(d.y);
-            sh_vid[tid] = (int)d.x;
-            sh_keep[tid] = 1.0f - e;
-            sh_floor[tid] = fmaxf(e, 1e-4f);
+            const int ci = pos + tid;
+            const int w = (ci >> 1) * 8 + (ci & 1);
+            sh_vid[tid] = (int)words[w];  // byte offset of the prob row
+            sh_keep[tid] = __uint_as_float(words[w + 2]);
+            sh_floor[tid] = __uint_as_float(words[w + 4]);
         }
         __syncthreads();
         for (int i = tid; i < n * G; i += 256) {
@@ -303,15 +365,24 @@ __global__ __launch_bounds__(256) void k_estep_block(EstepArgs a, int C)
             sh_rows[i] = *(const float *)((const char *)a.prob + ((unsigned)sh_vid[c] + (unsigned)g * 4u));
         }
         __syncthreads();
-        for (int c = 0; c < n; c++) {
-            const float keep = sh_keep[c], flo = sh_floor[c];
-            const float *row = sh_rows + c * G;
+        // calls in pairs (c, c+1) through the packed log; an odd tail call is paired with a padding
+        // call (keep 0, floor 1 -> log(1) = +0)
+        for (int c = 0; c < n; c += 2) {
+            const bool tail = c + 1 >= n;
+            const npm::f32x2 keep2 = {sh_keep[c], tail ? 0.0f : sh_keep[c + 1]};
+            const npm::f32x2 flo2 = {sh_floor[c], tail ? 1.0f : sh_floor[c + 1]};
+            const float *row0 = sh_rows + c * G;
+            const float *row1 = tail ? row0 : row0 + G;
 #pragma unroll
             for (int s = 0; s < A; s++) {
-                const float p = (row[pr[s] & 0xFFFF] + row[pr[s] >> 16]) * 0.5f;
-                float t = p * keep;
-                t = t + flo;
-                acc[s] += (double)npm::log_f32<false, true>(t);
+                const int g1 = pr[s] & 0xFFFF, g2 = pr[s] >> 16;
+                const npm::f32x2 pa = {row0[g1], row1[g1]};
+                const npm::f32x2 pb = {row0[g2], row1[g2]};
+                npm::f32x2 t = ((pa + pb) * 0.5f) * keep2;
+                t = t + flo2;
+                const npm::f32x2 lp = npm::log_f32_hot2(t);
+                acc[s] += (double)lp.x;
+                acc[s] += (double)lp.y;
             }
         }
     }
@@ -511,8 +582,14 @@ __global__ __launch_bounds__(256) void k_test_log(const float *in, float *out, l
 
 __global__ __launch_bounds__(256) void k_test_log_hot(const float *in, float *out, long long n)
 {
-    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) out[i] = npm::log_f32<false, true>(in[i]);  // the form the E-step kernels use
+    // the packed two-argument form the E-step kernels use; element pairs (2i, 2i+1)
+    const long long i = ((long long)blockIdx.x * blockDim.x + threadIdx.x) * 2;
+    if (i >= n) return;
+    const bool has2 = i + 1 < n;
+    const npm::f32x2 v = {in[i], has2 ? in[i + 1] : 1.0f};
+    const npm::f32x2 r = npm::log_f32_hot2(v);
+    out[i] = r.x;
+    if (has2) out[i + 1] = r.y;
 }
 
 __global__ __launch_bounds__(256) void k_test_exp(const float *in, float *out, long long n)
@@ -670,7 +747,7 @@ hipError_t launch_test_log(hipStream_t st, const float *in, float *out, long lon
 hipError_t launch_test_log_hot(hipStream_t st, const float *in, float *out, long long n)
 {
     if (n == 0) return hipSuccess;
-    hipLaunchKernelGGL(k_test_log_hot, dim3(blocks_for(n, 256)), dim3(256), 0, st, in, out, n);
+    hipLaunchKernelGGL(k_test_log_hot, dim3(blocks_for(n, 512)), dim3(256), 0, st, in, out, n);
     return hipGetLastError();
 }
 

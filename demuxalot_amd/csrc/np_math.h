@@ -72,6 +72,62 @@ __device__ __forceinline__ float log_f32(float v)
     return res;
 }
 
+// ---------------------------------------------------------------------------------------
+// Hot-path form of log_f32 for the E-step: TWO independent positive finite arguments per lane,
+// evaluated with packed float32 instructions (v_pk_fma_f32 / v_pk_mul_f32 / v_pk_add_f32 issue
+// two lanes' worth of work per instruction slot; the E-step is VALU-issue bound).
+// Same roundings as log_f32, operation by operation:
+//   * range reduction on the bit pattern: subtracting the bits of nextafter(1/sqrt(2)) splits
+//     x = m' * 2^k with m' in (1/sqrt2, sqrt2] in 5 integer ops; m' and k are exactly the values
+//     log_f32 derives from frexp + compare + select (both are exact operations, so equality of
+//     the results is a matter of integer arithmetic; checked exhaustively on the device);
+//   * P5(r), Q5(r): the two Horner chains of both arguments as packed FMAs;
+//   * division: div_small_range, packed.
+// ---------------------------------------------------------------------------------------
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+static __device__ __forceinline__ f32x2 pk_fma(f32x2 a, f32x2 b, f32x2 c) { return __builtin_elementwise_fma(a, b, c); }
+
+__device__ __forceinline__ f32x2 log_f32_hot2(f32x2 v)
+{
+    const float P0 = 0.000000000000000000000e+00f, P1 = 9.999999999999998702752e-01f,
+                P2 = 2.112677543073053063722e+00f, P3 = 1.480000633576506585156e+00f,
+                P4 = 3.808837741388407920751e-01f, P5 = 2.589979117907922693523e-02f;
+    const float Q0 = 1.000000000000000000000e+00f, Q1 = 2.612677543073109236779e+00f,
+                Q2 = 2.453006071784736363091e+00f, Q3 = 9.864942958519418960339e-01f,
+                Q4 = 1.546476374983906719538e-01f, Q5 = 5.875095403124574342950e-03f;
+    const float LN2 = 0.693147180559945309417232121458176568f;
+    const int SPLIT = 0x3f3504f4;  // bits of the float32 just above 1/sqrt(2) (0x3f3504f3)
+
+    const int ia = __float_as_int(v.x) - SPLIT, ib = __float_as_int(v.y) - SPLIT;
+    f32x2 k, m;
+    k.x = (float)(ia >> 23);
+    k.y = (float)(ib >> 23);
+    m.x = __int_as_float((ia & 0x007fffff) + SPLIT);
+    m.y = __int_as_float((ib & 0x007fffff) + SPLIT);
+    const f32x2 r = m - 1.0f;
+    f32x2 num = pk_fma((f32x2)(P5), r, (f32x2)(P4));
+    f32x2 den = pk_fma((f32x2)(Q5), r, (f32x2)(Q4));
+    num = pk_fma(num, r, (f32x2)(P3));
+    den = pk_fma(den, r, (f32x2)(Q3));
+    num = pk_fma(num, r, (f32x2)(P2));
+    den = pk_fma(den, r, (f32x2)(Q2));
+    num = pk_fma(num, r, (f32x2)(P1));
+    den = pk_fma(den, r, (f32x2)(Q1));
+    num = pk_fma(num, r, (f32x2)(P0));
+    den = pk_fma(den, r, (f32x2)(Q0));
+    f32x2 rc;
+    rc.x = __builtin_amdgcn_rcpf(den.x);
+    rc.y = __builtin_amdgcn_rcpf(den.y);
+    const f32x2 nden = -den;
+    const f32x2 e0 = pk_fma(nden, rc, (f32x2)(1.0f));
+    rc = pk_fma(e0, rc, rc);
+    const f32x2 q0 = num * rc;
+    const f32x2 rem = pk_fma(nden, q0, num);
+    const f32x2 q = pk_fma(rem, rc, q0);
+    return pk_fma(k, (f32x2)(LN2), q);
+}
+
 __device__ __forceinline__ float exp_f32(float v)
 {
     const float P0 = 9.999999999980870924916e-01f, P1 = 7.257664613233124478488e-01f,
