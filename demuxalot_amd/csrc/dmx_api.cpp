@@ -111,6 +111,7 @@ struct dmx_ctx {
     float *d_prior = nullptr, *d_add = nullptr, *d_prob = nullptr;
     double *d_add64 = nullptr, *d_partial = nullptr;
     float *d_logits = nullptr, *d_post = nullptr;
+    unsigned long long *d_nz = nullptr;
     long long cap_bk = 0;
     float *d_pen = nullptr;
     unsigned *d_pairs = nullptr;
@@ -217,6 +218,7 @@ void release_problem(dmx_ctx *c)
     dev_free(c, &c->d_logits, (size_t)c->cap_bk);
     dev_free(c, &c->d_post, (size_t)c->cap_bk);
     c->cap_bk = 0;
+    dev_free(c, &c->d_nz, (size_t)c->B * ((c->G + 63) / 64));
     dev_free(c, &c->d_pen, (size_t)c->cap_k);
     dev_free(c, &c->d_pairs, (size_t)c->cap_k);
     c->cap_k = 0;
@@ -319,6 +321,7 @@ int run_estep(dmx_ctx *c, int with_doublets, bool with_prior, int prior_dtype)
     a.prior_dtype = prior_dtype;
     a.logits = c->d_logits;
     a.post = c->d_post;
+    a.nz = c->d_nz;
     a.B = c->B;
     a.prob_bytes = (unsigned)((unsigned long long)c->V * c->G * 4ull);
     a.G = c->G;
@@ -339,6 +342,8 @@ int run_mstep(dmx_ctx *c, float power)
     a.item_len = c->d_item_len;
     a.calls = c->d_csc;
     a.post = c->d_post;
+    a.nz = c->d_nz;
+    a.post_bytes = (unsigned long long)c->B * (unsigned long long)c->K * 4ull;
     a.partial = c->d_partial;
     a.n_items = c->n_items;
     a.K = c->K;
@@ -515,6 +520,8 @@ int dmx_set_problem(dmx_ctx *c, int64_t B, int64_t V, int32_t G, int64_t N, cons
             pr.row_off[j & 1] = (uint32_t)variant_id[i] * (uint32_t)G * 4u;
             pr.keep[j & 1] = 1.0f - e;                    // float32, numpy's `1 - e`
             pr.floor[j & 1] = e > 1e-4f ? e : 1e-4f;      // numpy's `e.clip(1e-4)`
+            const float keep = 1.0f - e;  // the M-step only ever needs 1 - e
+            std::memcpy(&ebits, &keep, 4);
             csc[(size_t)ccur[variant_id[i]]++] = make_uint2((uint32_t)cb[i], ebits);
         }
     }
@@ -582,6 +589,7 @@ int dmx_set_problem(dmx_ctx *c, int64_t B, int64_t V, int32_t G, int64_t N, cons
     DMX_TRY(dev_alloc(c, &c->d_prob, vg));
     DMX_TRY(dev_alloc(c, &c->d_add64, vg));
     DMX_TRY(dev_alloc(c, &c->d_partial, (size_t)c->n_items * G));
+    DMX_TRY(dev_alloc(c, &c->d_nz, (size_t)B * ((G + 63) / 64)));
     DMX_TRY(dev_alloc(c, &c->d_best, (size_t)B));
     DMX_TRY(dev_alloc(c, &c->d_bestp, (size_t)B));
     hipStream_t st = c->stream;

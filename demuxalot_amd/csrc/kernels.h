@@ -32,6 +32,7 @@ struct EstepArgs {
     int prior_dtype;            // DMX_F32 / DMX_F64
     float *logits;              // [B, K]
     float *post;                // [B, K]
+    unsigned long long *nz;     // [B, ceil(G/64)] bit g set <=> post[b, g] != 0 (singlet columns; read by the M-step)
     long long B;
     unsigned prob_bytes;        // V * G * 4 (< 4 GiB): extent of the prob table for buffer addressing
     int G;
@@ -39,14 +40,16 @@ struct EstepArgs {
 };
 
 struct MstepArgs {
-    const int *order;             // [n_items] items by decreasing length (work distribution)
-    const long long *item_start;  // [n_items] first CSC call of the item
-    const int *item_len;          // [n_items] number of calls (<= ITEM_CALLS)
-    const uint2 *calls;           // [N] (compressed_cb, bits of p_base_wrong), variant-major
-    const float *post;            // [B, K] posteriors (singlet columns 0..G-1 are read)
-    double *partial;              // [n_items, G]
+    const int *order;               // [n_items] items by decreasing length (work distribution)
+    const long long *item_start;    // [n_items] first CSC call of the item
+    const int *item_len;            // [n_items] number of calls (<= ITEM_CALLS)
+    const uint2 *calls;             // [N] (compressed_cb, bits of 1 - p_base_wrong), variant-major
+    const float *post;              // [B, K] posteriors (singlet columns 0..G-1 are read)
+    const unsigned long long *nz;   // [B, ceil(G/64)] non-zero bitmap of the singlet posteriors
+    double *partial;                // [n_items, G]
     long long n_items;
     long long K;
+    unsigned long long post_bytes;  // B * K * 4
     int G;
     int square;   // contribution_power == 2
     float power;  // otherwise

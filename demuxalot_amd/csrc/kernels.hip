@@ -306,12 +306,21 @@ __global__ __launch_bounds__(256) void k_estep_direct(EstepArgs a)
 #pragma unroll
     for (int s = 0; s < A; s++) x[s] = npm::exp_f32(lg[s] - mx);
     const float tot = reg_row_sum<A>(x, K, lane, gbase);
+    const int W = (a.G + 63) >> 6;
 #pragma unroll
     for (int s = 0; s < A; s++) {
+        const float post = x[s] / tot;
         if (live && valid[s]) {
             const size_t o = (size_t)b * K + kk[s];
             a.logits[o] = lg[s];
-            a.post[o] = x[s] / tot;
+            a.post[o] = post;
+        }
+        // non-zero bitmap of the singlet columns (the M-step skips exact zeros: (0*keep)^2 = +0)
+        const unsigned long long bal = __ballot(live && valid[s] && (li + 64 * s) < a.G && post != 0.0f);
+        if (L == 64) {
+            if (lane == 0 && s < W) a.nz[(size_t)b * W + s] = bal;
+        } else {
+            if (live && li == 0) a.nz[(size_t)b] = (bal >> gbase) & ((1ull << L) - 1ull);
         }
     }
 }
@@ -431,13 +440,19 @@ __global__ __launch_bounds__(256) void k_estep_block(EstepArgs a, int C)
     }
     __syncthreads();
     const float tot = sh_red[4];
+    const int W = (G + 63) >> 6;
 #pragma unroll
     for (int s = 0; s < A; s++) {
         const int k = s * 256 + tid;
+        const float post = x[s] / tot;
         if (k < K) {
             const size_t o = (size_t)b * K + k;
             a.logits[o] = lg[s];
-            a.post[o] = x[s] / tot;
+            a.post[o] = post;
+        }
+        if (s == 0) {  // singlet columns k < G <= 256 all live in slot 0: one bitmap word per wave
+            const unsigned long long bal = __ballot(k < G && post != 0.0f);
+            if (lane == 0 && wave < W) a.nz[(size_t)b * W + wave] = bal;
         }
     }
 }
@@ -445,11 +460,31 @@ __global__ __launch_bounds__(256) void k_estep_block(EstepArgs a, int C)
 // ------------------------------------------------------------------------------------
 // M-step.  Work item = a run of <= ITEM_CALLS consecutive CSC calls of one variant.  As in the
 // E-step a wavefront is cut into 64/L lane groups; a group owns one item and walks it in CSC
-// (= reference bincount) order, lane = genotype; it gathers the singlet columns of the
-// posterior row of each call's barcode; float64 accumulation; one float64 partial per item.
-// Items are handed out from a length-sorted list.
+// (= reference bincount) order, lane = genotype, float64 accumulation, one float64 partial per
+// item.  Items are handed out from a length-sorted list.
+// Posterior rows are mostly EXACT zeros once genotypes are informative (exp underflows below
+// -103.97), and (0 * keep)^2 = +0 leaves a float64 sum unchanged, so a lane only loads its
+// posterior when the barcode's non-zero bitmap (written by the E-step) has its bit set:
+//   L == 64: call records and bitmap words come through scalar loads, the bitmap becomes the EXEC
+//            mask of the gather (inverse ballot), the row address is an SGPR soffset of a buffer load;
+//   L <  64: per-lane predicate.
 // ------------------------------------------------------------------------------------
-template <int L, int A, int U, bool SQUARE>
+template <int A, int U, bool SQUARE>
+static __device__ __forceinline__ void mstep_terms(const float (&p)[U][A], const float (&keep)[U], float power,
+                                                   double (&acc)[A])
+{
+#pragma unroll
+    for (int u = 0; u < U; u++) {
+#pragma unroll
+        for (int s = 0; s < A; s++) {
+            float c = p[u][s] * keep[u];
+            c = SQUARE ? c * c : powf(c, power);
+            acc[s] += (double)c;
+        }
+    }
+}
+
+template <int L, int A, int U, bool SQUARE, bool SMALL>
 __global__ __launch_bounds__(256) void k_mstep(MstepArgs a)
 {
     static_assert(A == 1 || L == 64, "several accumulators per lane only with 64 lanes per call");
@@ -458,49 +493,116 @@ __global__ __launch_bounds__(256) void k_mstep(MstepArgs a)
     const int lane = threadIdx.x & 63;
     const int li = lane % L;
     const int gbase = lane - li;
-    const long long slot = ((long long)blockIdx.x * 4 + (threadIdx.x >> 6)) * CPW + lane / L;
-    const bool live = slot < a.n_items;
-    const long long item = a.order[live ? slot : a.n_items - 1];
-    const int n = live ? a.item_len[item] : 0;
-    const uint2 *__restrict__ calls = a.calls + a.item_start[item];
-    const int nmax = group_max_over_wave<L>(n);
     const int G = a.G;
-    int go[A];
-#pragma unroll
-    for (int s = 0; s < A; s++) {
-        const int g = li + 64 * s;
-        go[s] = g < G ? g : G - 1;
-    }
+    const int W = (G + 63) >> 6;
     double acc[A];
 #pragma unroll
     for (int s = 0; s < A; s++) acc[s] = 0.0;
+    long long item;
+    bool live;
 
-    for (int c0 = 0; c0 < nmax; c0 += L) {
-        int ci = c0 + li;
-        ci = ci < n ? ci : n - 1;
-        uint2 d = make_uint2(0u, 0u);
-        if (n > 0) d = calls[ci];
-        // padding calls get keep = 0: (p*0)^power = +0 adds nothing
-        const float keep_v = (c0 + li) >= n ? 0.0f : 1.0f - __uint_as_float(d.y);
-        const int cnt = (nmax - c0) < L ? (nmax - c0) : L;
-        for (int i0 = 0; i0 < cnt; i0 += U) {
-            float p[U][A], keep[U];
+    if constexpr (L == 64) {
+        const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+        const long long slot = (long long)blockIdx.x * 4 + wave;
+        if (slot >= a.n_items) return;
+        live = true;
+        item = a.order[slot];
+        const int n = a.item_len[item];
+        const uint2 *__restrict__ calls = a.calls + a.item_start[item];
+        // row offsets fit the 32-bit soffset of a buffer load when the posterior table is < 4 GiB
+        const __amdgpu_buffer_rsrc_t rsrc =
+            __builtin_amdgcn_make_buffer_rsrc((void *)a.post, 0, SMALL ? (int)a.post_bytes : 0, 0x00020000);
+        unsigned voff[A];
 #pragma unroll
-            for (int u = 0; u < U; u++) {
-                const unsigned cb = group_bcast<L>(d.x, i0 + u, gbase);
-                keep[u] = group_bcast<L>(keep_v, i0 + u, gbase);
-                const float *row = a.post + (size_t)cb * a.K;
+        for (int s = 0; s < A; s++) voff[s] = (unsigned)(lane + 64 * s) * 4u;
+
+        // 64 calls per chunk, lane i <-> call c0+i: one coalesced load of the records, one gather of the
+        // barcodes' bitmap words, then call by call: readlane -> SGPRs -> EXEC-masked row gather.
+        // Software pipeline: records two chunks ahead, bitmaps one chunk ahead.
+        auto load_records = [&](int c0) {
+            const int ci = c0 + lane;
+            uint2 d = make_uint2(0u, 0u);  // keep bits 0 -> keep = +0: padding adds (p*0)^power = +0
+            if (ci < n) d = calls[ci];
+            return d;
+        };
+        auto load_bitmap = [&](int c0, uint2 d, int s) {
+            unsigned long long m = 0ull;
+            if (c0 + lane < n && (A == 1 || s < W)) m = a.nz[(size_t)d.x * W + s];
+            return m;
+        };
+        uint2 d_cur = load_records(0);
+        uint2 d_nxt = load_records(64);
+        unsigned long long m_cur[A], m_nxt[A];
 #pragma unroll
-                for (int s = 0; s < A; s++) p[u][s] = row[go[s]];
-            }
+        for (int s = 0; s < A; s++) m_cur[s] = load_bitmap(0, d_cur, s);
+        for (int c0 = 0; c0 < n; c0 += 64) {
+            const uint2 d_nn = load_records(c0 + 128);
 #pragma unroll
-            for (int u = 0; u < U; u++) {
+            for (int s = 0; s < A; s++) m_nxt[s] = load_bitmap(c0 + 64, d_nxt, s);
+            const float keep_v = __uint_as_float(d_cur.y);
+            const int cnt = (n - c0) < 64 ? (n - c0) : 64;
+            for (int i0 = 0; i0 < cnt; i0 += U) {
+                float p[U][A], keep[U];
 #pragma unroll
-                for (int s = 0; s < A; s++) {
-                    float c = p[u][s] * keep[u];
-                    c = SQUARE ? c * c : powf(c, a.power);
-                    acc[s] += (double)c;
+                for (int u = 0; u < U; u++) {
+                    const unsigned cb = (unsigned)__builtin_amdgcn_readlane((int)d_cur.x, i0 + u);
+                    keep[u] = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, keep_v), i0 + u));
+                    const unsigned long long row = (unsigned long long)cb * (unsigned long long)a.K * 4ull;
+#pragma unroll
+                    for (int s = 0; s < A; s++) {
+                        const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)m_cur[s], i0 + u);
+                        const unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(m_cur[s] >> 32), i0 + u);
+                        const unsigned long long m = ((unsigned long long)hi << 32) | lo;
+                        float v = 0.0f;
+                        if (__builtin_amdgcn_inverse_ballot_w64(m)) {  // EXEC := bitmap
+                            if (SMALL)
+                                v = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(
+                                                                  rsrc, (int)voff[s], (int)(unsigned)row, 0));
+                            else
+                                v = *(const float *)((const char *)a.post + row + voff[s]);
+                        }
+                        p[u][s] = v;
+                    }
                 }
+                mstep_terms<A, U, SQUARE>(p, keep, a.power, acc);
+            }
+            d_cur = d_nxt;
+            d_nxt = d_nn;
+#pragma unroll
+            for (int s = 0; s < A; s++) m_cur[s] = m_nxt[s];
+        }
+    } else {
+        const long long slot = ((long long)blockIdx.x * 4 + (threadIdx.x >> 6)) * CPW + lane / L;
+        live = slot < a.n_items;
+        item = a.order[live ? slot : a.n_items - 1];
+        const int n = live ? a.item_len[item] : 0;
+        const uint2 *__restrict__ calls = a.calls + a.item_start[item];
+        const int nmax = group_max_over_wave<L>(n);
+        for (int c0 = 0; c0 < nmax; c0 += L) {
+            int ci = c0 + li;
+            const bool mine = ci < n;
+            ci = mine ? ci : 0;
+            uint2 d = make_uint2(0u, 0u);
+            unsigned long long bits_v = 0ull;
+            if (mine) {
+                d = calls[ci];
+                bits_v = a.nz[(size_t)d.x];  // W == 1 here (G <= 32)
+            }
+            const float keep_v = mine ? __uint_as_float(d.y) : 0.0f;
+            const unsigned lo_v = (unsigned)bits_v;
+            const int cnt = (nmax - c0) < L ? (nmax - c0) : L;
+            for (int i0 = 0; i0 < cnt; i0 += U) {
+                float p[U][A], keep[U];
+#pragma unroll
+                for (int u = 0; u < U; u++) {
+                    const unsigned cb = group_bcast<L>(d.x, i0 + u, gbase);
+                    keep[u] = group_bcast<L>(keep_v, i0 + u, gbase);
+                    const unsigned bits = group_bcast<L>(lo_v, i0 + u, gbase);
+                    float v = 0.0f;
+                    if ((bits >> li) & 1u) v = a.post[(size_t)cb * a.K + li];
+                    p[u][0] = v;
+                }
+                mstep_terms<A, U, SQUARE>(p, keep, a.power, acc);
             }
         }
     }
@@ -687,10 +789,15 @@ template <int L, int A, int U>
 static void launch_m(hipStream_t st, const MstepArgs &a)
 {
     const dim3 grid(blocks_for(a.n_items, 4 * (64 / L)));
-    if (a.square)
-        hipLaunchKernelGGL((k_mstep<L, A, U, true>), grid, dim3(256), 0, st, a);
+    const bool small = a.post_bytes < (1ull << 32);
+    if (a.square && small)
+        hipLaunchKernelGGL((k_mstep<L, A, U, true, true>), grid, dim3(256), 0, st, a);
+    else if (a.square)
+        hipLaunchKernelGGL((k_mstep<L, A, U, true, false>), grid, dim3(256), 0, st, a);
+    else if (small)
+        hipLaunchKernelGGL((k_mstep<L, A, U, false, true>), grid, dim3(256), 0, st, a);
     else
-        hipLaunchKernelGGL((k_mstep<L, A, U, false>), grid, dim3(256), 0, st, a);
+        hipLaunchKernelGGL((k_mstep<L, A, U, false, false>), grid, dim3(256), 0, st, a);
 }
 
 hipError_t launch_mstep(hipStream_t st, const MstepArgs &a)
