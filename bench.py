@@ -45,27 +45,48 @@ def algorithmic_bytes(B, V, G, K, N):
     return dict(estep=e, mstep=m, pstep=p, iteration=e + m + p)
 
 
-def cpu_baseline(problem, betas, doublet_prior, target_seconds=20.0):
-    """The numpy oracle (same passes as the reference: K column passes + bincount; G passes for the
-    M-step) on one core, on the first barcodes of the workload; size picked for ~10-30 s."""
-    from oracle import demux_oracle
+def _oracle_iteration(demux_oracle, problem, betas, doublet_prior, n_sample):
     G = problem.n_genotypes
-    K = G if doublet_prior == 0 else G * (G + 1) // 2
-    per_call_option = 22e-9  # SURVEY.md section 6 probe: 18-29 ns per call x option, E and M each
-    calls_budget = target_seconds / (per_call_option * (K + G))
-    mean_row = problem.n_calls / problem.n_barcodes
-    n_sample = int(max(200, min(problem.n_barcodes, calls_budget / mean_row)))
     v, cb, e = problem.subset_barcodes(0, n_sample)
     t0 = time.perf_counter()
     prob = demux_oracle.probs_from_betas(problem.v2snp, betas, 0.01)
     logits = demux_oracle.barcode_logits(v, cb, e, prob, n_sample, doublet_prior)
     post = demux_oracle.softmax_rows(logits)
     demux_oracle.beta_addition(v, cb, e, post, problem.n_variants, G)
-    dt = time.perf_counter() - t0
+    return time.perf_counter() - t0, len(v), logits, post
+
+
+def cpu_baseline(problem, betas, doublet_prior, target_seconds=15.0):
+    """The numpy oracle (same passes as the reference: K column passes + bincount; G passes for the
+    M-step) on ONE core -- the reference path is single-threaded -- on the first barcodes of the
+    workload. A small probe calibrates the sample so that the timed run takes ~10-30 s."""
+    from oracle import demux_oracle
+    n_probe = min(problem.n_barcodes, 1000)
+    t_probe, calls_probe, _, _ = _oracle_iteration(demux_oracle, problem, betas, doublet_prior, n_probe)
+    # the probe pays the fixed O(V*G) P-step too; scale only the per-call part
+    t_fixed = 0.0
+    if problem.n_barcodes > n_probe:
+        t0 = time.perf_counter()
+        demux_oracle.probs_from_betas(problem.v2snp, betas, 0.01)
+        t_fixed = time.perf_counter() - t0
+    per_barcode = max(1e-7, (t_probe - t_fixed) / n_probe)
+    n_sample = int(max(n_probe, min(problem.n_barcodes, (target_seconds - t_fixed) / per_barcode)))
+    dt, n_calls, logits, post = _oracle_iteration(demux_oracle, problem, betas, doublet_prior, n_sample)
     return dict(value=n_sample / dt, unit='barcodes/s', cores=1, kind='port',
-                sample=f'first {n_sample} barcodes ({len(v)} calls) of the workload, full V and G, '
+                sample=f'first {n_sample} barcodes ({n_calls} calls) of the workload, full V and G, '
                        f'one EM iteration in {dt:.1f} s, numpy single-threaded like the reference',
                 host_cores=os.cpu_count()), logits, post, n_sample
+
+
+def measured_traffic(workload, kernel):
+    """HBM-side bytes per launch from the rocprofv3 PMC passes committed under profiles/ (FETCH_SIZE +
+    WRITE_SIZE, see profiles/README.md); None when no profile of this workload/kernel is recorded."""
+    path = os.path.join(ROOT, 'profiles', 'pmc_traffic.json')
+    try:
+        table = json.load(open(path))
+        return table[workload][kernel]['bytes_per_launch']
+    except (OSError, KeyError, ValueError):
+        return None
 
 
 def main():
@@ -168,12 +189,14 @@ def main():
             'predict_barcodes_per_s': world * B / predict_s,
             'kernel_ms': {k: (v['ms'] / max(1, v['launches'])) for k, v in timers.items()},
             'roofline': {'bound': 'hbm', 'kernel': 'k_estep_direct', 'achieved': achieved, 'peak': 8000.0, 'unit': 'GB/s',
-                         'frac': achieved / 8000.0, 'traffic': None,
+                         'frac': achieved / 8000.0, 'traffic': measured_traffic(args.workload, 'k_estep_direct'),
                          'algorithmic_bytes_per_launch': ab['estep'],
                          'iteration_bytes': ab['iteration'],
                          'iteration_frac': ab['iteration'] / (1e-3 * (e_ms + m_ms + timers['pstep']['ms'] / max(1, timers['pstep']['launches']) + timers['mcombine']['ms'] / max(1, timers['mcombine']['launches']))) / 1e9 / 8000.0,
                          'log_terms_per_s': N * K / (e_ms * 1e-3),
-                         'note': 'E-step is VALU-bound (N*K float32 log terms evaluated with numpy-exact rounding), see DESIGN.md'},
+                         'delivered_gather_GBps': (N * 4 * G) / (e_ms * 1e-3) / 1e9,
+                         'note': 'the E-step is bound by VALU issue of N*K numpy-exact float32 log terms and by the '
+                                 'indexed row gather from L2/Infinity Cache (N*4G delivered bytes), not by HBM: see DESIGN.md 4'},
             'setup_s': {'generate': t_gen, 'upload': t_up},
         }
         if world == 1 and not args.no_cpu_baseline:

@@ -187,6 +187,40 @@ def test_contribution_power_is_honoured(ctx, oracle):
     assert np.allclose(stages[1][1]['genotype_addition'], hist[1]['addition'], rtol=2e-6, atol=1e-7)
 
 
+# ---- multi-GPU plumbing on one GPU -----------------------------------------------------------------
+@pytest.mark.parametrize('reduce_dtype', ['f64', 'f32'])
+def test_rccl_communicator_single_rank(reduce_dtype):
+    """A one-rank RCCL communicator exercises the whole collective path of dmx_mstep (dlopen of
+    librccl, ncclGetUniqueId / ncclCommInitRank, float64 combine -> ncclAllReduce -> float32) on the one
+    GPU a test box has; with one rank the all-reduce is the identity, so results stay bit-exact."""
+    from demuxalot_amd.device import DeviceContext
+    from demuxalot_amd.distributed import ShardedEM
+    from demuxalot_amd import Demultiplexer
+    fx = fio.load('f3_small_3.npz')
+    calls, genotypes, handler = fio.product_inputs(fx)
+    v2snp, betas, _mol, bc = Demultiplexer.pack_calls(calls, genotypes, add_data_prior=True)
+    ctx = DeviceContext(0)
+    try:
+        ctx.set_problem(handler.n_barcodes, len(v2snp), genotypes.n_genotypes, bc['variant_id'], bc['compressed_cb'],
+                        bc['p_base_wrong'], v2snp)
+        ctx.set_betas(betas)
+        ctx.comm_init(0, 1, DeviceContext.new_unique_id(), reduce_dtype=reduce_dtype)
+        n_it = int(fx['em0_n_iterations'])
+        logits, probs, addition = ctx.em(n_it, float(fx['em0_clip']), np.zeros(genotypes.n_genotypes, dtype=np.float32),
+                                         with_doublets=False)
+        fio.assert_bitwise(probs, fx[f'em0_it{n_it - 1}_probs'], 'probs through the RCCL path')
+        fio.assert_bitwise(addition, fx[f'em0_it{n_it - 1}_addition'], 'addition through the RCCL path')
+        assert ctx.timings()['allreduce']['launches'] == n_it - 1
+    finally:
+        ctx.close()
+    # the sharded front-end with world size 1 (no communicator) gives the same rows
+    em = ShardedEM(0, 1, handler.n_barcodes, v2snp, betas, bc['variant_id'], bc['compressed_cb'], bc['p_base_wrong'], device=0)
+    probs1, addition1 = em.learn(n_it, float(fx['em0_clip']), np.zeros(genotypes.n_genotypes, dtype=np.float32), False)
+    em.ctx.close()
+    fio.assert_bitwise(probs1, probs, 'ShardedEM world=1')
+    fio.assert_bitwise(addition1, addition, 'ShardedEM world=1 addition')
+
+
 # ---- mid/large sizes ------------------------------------------------------------------------------
 def test_midsize_em_matches_oracle(oracle):
     """20k barcodes x 10k SNPs x 64 genotypes (N ~ 3.6M): three EM iterations against the numpy oracle."""
