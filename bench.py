@@ -97,6 +97,8 @@ def main():
     ap.add_argument('--workload', default='em_200k_100k_64', choices=sorted(WORKLOADS))
     ap.add_argument('--reduce-dtype', default='f64', choices=['f64', 'f32'])
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--force-dist', action='store_true',
+                    help='testing aid: run the multi-rank control/collective path even with one rank')
     args = ap.parse_args()
 
     rank = int(os.environ.get('RANK', '0'))
@@ -105,10 +107,13 @@ def main():
     assert world == args.gpus, f'--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run'
 
     dist = None
-    if world > 1:
+    use_dist = world > 1 or args.force_dist
+    if use_dist:
         # control plane only (rendezvous, barrier, max-reduce of the wall time) over gloo;
         # the data-plane collective is RCCL inside libdemux_hip.so
         import torch.distributed as dist
+        if 'MASTER_ADDR' not in os.environ:  # --force-dist without a launcher
+            os.environ['MASTER_ADDR'], os.environ['MASTER_PORT'] = '127.0.0.1', '29533'
         dist.init_process_group('gloo', rank=rank, world_size=world)
 
     from demuxalot_amd import Demultiplexer, synth
@@ -128,7 +133,7 @@ def main():
     ctx.set_problem(B, V, G, problem.variant_id, problem.compressed_cb, problem.p_base_wrong, problem.v2snp)
     ctx.set_betas(betas)
     t_up = time.perf_counter() - t_up
-    if world > 1:
+    if use_dist:
         ids = [DeviceContext.new_unique_id() if rank == 0 else None]
         dist.broadcast_object_list(ids, src=0)
         ctx.comm_init(rank, world, ids[0], reduce_dtype=args.reduce_dtype)
@@ -184,7 +189,7 @@ def main():
             'dtype': 'f32 terms, f64 accumulate', 'data': 'synthetic',
             'config': {'workload': args.workload, 'barcodes_per_gpu': B, 'snps': S, 'variants': V, 'genotypes': G,
                        'options': K, 'calls_per_gpu': N, 'doublet_prior': dp,
-                       'parallelism': f'barcode shards x{world}' + (f', RCCL all-reduce {args.reduce_dtype}' if world > 1 else '')},
+                       'parallelism': f'barcode shards x{world}' + (f', RCCL all-reduce {args.reduce_dtype}' if use_dist else '')},
             'em_iterations_per_s': args.steps / elapsed,
             'predict_barcodes_per_s': world * B / predict_s,
             'kernel_ms': {k: (v['ms'] / max(1, v['launches'])) for k, v in timers.items()},

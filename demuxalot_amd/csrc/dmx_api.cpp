@@ -62,11 +62,18 @@ RcclApi g_rccl;
 int load_rccl()
 {
     if (g_rccl.handle) return 0;
+    // Prefer a copy of RCCL that is already mapped into the process (e.g. by a launcher that imported
+    // torch.distributed for its control plane) so that only one RCCL runtime is ever active; otherwise
+    // load the ROCm one.  RTLD_LOCAL: the symbols are taken from the handle, nothing is interposed.
     const char *names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
     void *h = nullptr;
     for (const char *n : names) {
-        h = dlopen(n, RTLD_NOW | RTLD_GLOBAL);
+        h = dlopen(n, RTLD_NOW | RTLD_LOCAL | RTLD_NOLOAD);
         if (h) break;
+    }
+    for (const char *n : names) {
+        if (h) break;
+        h = dlopen(n, RTLD_NOW | RTLD_LOCAL);
     }
     if (!h) return fail(DMX_ERR_RCCL, "cannot load librccl: %s", dlerror());
     g_rccl.GetUniqueId = (decltype(g_rccl.GetUniqueId))dlsym(h, "ncclGetUniqueId");

@@ -277,6 +277,23 @@ class Demultiplexer:
         return penalties
 
     @staticmethod
+    def _iterate_genotypes_options(genotype_names, genotype_prob: np.ndarray, doublet_prior: float):
+        """Enumerates the K options as the reference does (demux.py:175-191): (index, column name,
+        per-variant probability vector), singlets first, then pairs g1 < g2 row-major with
+        (p1 + p2) * 0.5.  Kept for callers that inspect the options; the GPU kernels enumerate the same
+        order internally and never call this."""
+        k = 0
+        for g, name in enumerate(genotype_names):
+            yield k, name, genotype_prob[:, g]
+            k += 1
+        if doublet_prior != 0:
+            assert doublet_prior > 0
+            for g1, name1 in enumerate(genotype_names):
+                for g2 in range(g1 + 1, len(genotype_names)):
+                    yield k, f'{name1}+{genotype_names[g2]}', (genotype_prob[:, g1] + genotype_prob[:, g2]) * 0.5
+                    k += 1
+
+    @staticmethod
     def compute_barcode_logits(genotype_names, barcode_calls, molecule_calls, doublet_prior: float,
                                genotype_prob: np.ndarray, n_barcodes: int, n_genotypes: int):
         """Dispatcher of demux.py:193-202."""

@@ -187,6 +187,59 @@ def test_contribution_power_is_honoured(ctx, oracle):
     assert np.allclose(stages[1][1]['genotype_addition'], hist[1]['addition'], rtol=2e-6, atol=1e-7)
 
 
+# ---- edge cases --------------------------------------------------------------------------------------
+def test_empty_and_degenerate_inputs(ctx, oracle):
+    """No calls at all, a single genotype, barcodes without calls, variants without calls."""
+    from demuxalot_amd import BarcodeHandler, CompressedSNPCalls, Demultiplexer, ProbabilisticGenotypes
+    from scipy.special import softmax
+    g = ProbabilisticGenotypes(['A', 'B', 'C'])
+    g.var2varid = {('chr1', 5, 'A'): 0, ('chr1', 5, 'C'): 1, ('chr1', 9, 'G'): 2, ('chr1', 9, 'T'): 3}
+    g.variant_betas = np.array([[5, 1, 1], [1, 5, 5], [9, 0, 2], [0, 9, 7]], dtype=np.float32)
+    handler = BarcodeHandler(['b0', 'b1', 'b2', 'b3'])
+    empty = {'chr1': CompressedSNPCalls.from_arrays([], [], [], [], [])}
+    for dp in (0., 0.35):
+        logits, probs = Demultiplexer.predict_posteriors(empty, g, handler, doublet_prior=dp)
+        pen = Demultiplexer._doublet_penalties(3, dp)
+        assert np.array_equal(logits.values, np.tile(pen, (4, 1)))
+        fio.assert_bitwise(probs.values, softmax(np.tile(pen, (4, 1)), axis=1), 'softmax of the penalties')
+    learnt, probs = Demultiplexer.learn_genotypes(empty, g, handler, n_iterations=3)
+    assert np.array_equal(learnt.variant_betas, g.variant_betas) and np.allclose(probs.values, 1 / 3)
+    # one call only, on barcode b2; G = 1
+    one = {'chr1': CompressedSNPCalls.from_arrays([2], [0], [9], [3], [0.05])}
+    g1 = ProbabilisticGenotypes(['only'])
+    g1.var2varid = dict(g.var2varid)
+    g1.variant_betas = g.variant_betas[:, :1].copy()
+    logits, probs = Demultiplexer.predict_posteriors(one, g1, handler, doublet_prior=0.)
+    assert np.array_equal(probs.values, np.ones((4, 1), dtype=np.float32)) and logits.values[2, 0] < 0
+    assert (logits.values[[0, 1, 3], 0] == 0).all()
+    learnt, _ = Demultiplexer.learn_genotypes(one, g1, handler, n_iterations=2)
+    keep = np.float32(1) - np.float32(0.05)
+    expect = g1.variant_betas.copy()
+    expect[3, 0] += np.float32(keep * keep)
+    fio.assert_bitwise(learnt.variant_betas, expect, 'single-call addition')
+
+
+def test_c_abi_rejects_bad_calls():
+    from demuxalot_amd import _lib
+    from demuxalot_amd.device import DeviceContext
+    ctx = DeviceContext(0)
+    try:
+        with pytest.raises(_lib.DemuxHipError, match='call order'):
+            ctx.estep(np.zeros(3, dtype=np.float32), with_doublets=False)
+        with pytest.raises(_lib.DemuxHipError, match='outside'):
+            ctx.set_problem(2, 3, 2, np.array([0, 5]), np.array([0, 1]), np.array([.1, .1], dtype='f4'), np.zeros(3, dtype='i4'))
+        with pytest.raises(_lib.DemuxHipError, match='outside'):
+            ctx.set_problem(2, 3, 2, np.array([0, 1]), np.array([0, 2]), np.array([.1, .1], dtype='f4'), np.zeros(3, dtype='i4'))
+        ctx.set_problem(2, 3, 2, np.array([0, 1]), np.array([0, 1]), np.array([.1, .1], dtype='f4'), np.zeros(3, dtype='i4'))
+        with pytest.raises(_lib.DemuxHipError, match='call order'):
+            ctx.mstep()
+        with pytest.raises(_lib.DemuxHipError, match='call order'):
+            ctx.probs_from_betas(0.01)
+        assert ctx.device_bytes() > 0
+    finally:
+        ctx.close()
+
+
 # ---- multi-GPU plumbing on one GPU -----------------------------------------------------------------
 @pytest.mark.parametrize('reduce_dtype', ['f64', 'f32'])
 def test_rccl_communicator_single_rank(reduce_dtype):
