@@ -34,6 +34,8 @@ WORKLOADS = {
     'em_200k_100k_32': (200_000, 100_000, 32, 0.0, 1236),   # configs[2]
     'predict_20k_20k_8': (20_000, 20_000, 8, 0.35, 1235),   # configs[1]
     'em_20k_10k_64': (20_000, 10_000, 64, 0.0, 77),         # quick check
+    'predict_20k_20k_32_doublets': (20_000, 20_000, 32, 0.25, 1240),   # K = 528: workgroup-per-barcode kernel
+    'predict_5k_20k_128_doublets': (5_000, 20_000, 128, 0.25, 1241),   # K = 8256 (configs[4] option count)
 }
 
 
@@ -193,7 +195,7 @@ def main():
             'em_iterations_per_s': args.steps / elapsed,
             'predict_barcodes_per_s': world * B / predict_s,
             'kernel_ms': {k: (v['ms'] / max(1, v['launches'])) for k, v in timers.items()},
-            'roofline': {'bound': 'hbm', 'kernel': 'k_estep_direct', 'achieved': achieved, 'peak': 8000.0, 'unit': 'GB/s',
+            'roofline': {'bound': 'hbm', 'kernel': 'k_estep_direct' if K <= 256 else 'k_estep_block', 'achieved': achieved, 'peak': 8000.0, 'unit': 'GB/s',
                          'frac': achieved / 8000.0, 'traffic': measured_traffic(args.workload, 'k_estep_direct'),
                          'algorithmic_bytes_per_launch': ab['estep'],
                          'iteration_bytes': ab['iteration'],

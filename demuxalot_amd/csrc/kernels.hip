@@ -327,10 +327,12 @@ __global__ __launch_bounds__(256) void k_estep_direct(EstepArgs a)
 
 // ------------------------------------------------------------------------------------
 // E-step, block form (K > 256).  One 256-thread workgroup per barcode, option k = s*256 + tid.
-// A chunk of C calls is staged in LDS (descriptor scalars + the G-vector of each call's
-// variant), then every thread walks its options reading two LDS words per term.  Consecutive
-// lanes hold consecutive pairs (g1, g2): g1 is (nearly) wave-uniform -> broadcast, g2 is
-// consecutive -> conflict-free.
+// A chunk of C calls (C a multiple of 8 = the row padding) is staged in LDS TRANSPOSED:
+// sh_t[g][c], row stride C+2 dwords, so that the probabilities of genotype g for the call pair
+// (c, c+1) are one aligned 8-byte word = exactly the packed operand of the two-term log.  Every
+// thread then walks its options with two ds_read_b64 per term pair.  Consecutive lanes hold
+// consecutive pairs (g1, g2): g1 is (nearly) wave-uniform -> LDS broadcast; g2 is consecutive ->
+// lane stride (C+2) dwords, conflict-free inside each 32-lane service group of ds_read_b64.
 // ------------------------------------------------------------------------------------
 template <int A>
 __global__ __launch_bounds__(256) void k_estep_block(EstepArgs a, int C)
@@ -339,54 +341,53 @@ __global__ __launch_bounds__(256) void k_estep_block(EstepArgs a, int C)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const long long b = a.order[blockIdx.x];
     const int K = a.K, G = a.G;
-    // LDS carve: rows [C*G] f32 | keep [C] | floor [C] | vid [C] | red [8]; the softmax reuses
-    // the front of the buffer for K floats (launcher sizes smem for the larger of the two).
-    float *sh_rows = (float *)smem;
-    float *sh_keep = sh_rows + (size_t)C * G;
+    const int CS = C + 2;
+    // LDS carve: sh_t [G*CS] f32 | keep [C] | floor [C] | row offsets [C]; the softmax reuses the
+    // front of the buffer for K floats + 8 (launcher sizes smem for the larger of the two).
+    float *sh_t = (float *)smem;
+    float *sh_keep = sh_t + (size_t)G * CS;
     float *sh_floor = sh_keep + C;
-    int *sh_vid = (int *)(sh_floor + C);
+    unsigned *sh_off = (unsigned *)(sh_floor + C);
 
-    unsigned pr[A];
+    unsigned a1[A], a2[A];  // LDS dword index of the (g1, .) and (g2, .) rows of this thread's options
 #pragma unroll
     for (int s = 0; s < A; s++) {
         const int k = s * 256 + tid;
-        pr[s] = a.opt_pairs[k < K ? k : K - 1];
+        const unsigned pr = a.opt_pairs[k < K ? k : K - 1];
+        a1[s] = (pr & 0xFFFFu) * (unsigned)CS;
+        a2[s] = (pr >> 16) * (unsigned)CS;
     }
     double acc[A];
 #pragma unroll
     for (int s = 0; s < A; s++) acc[s] = 0.0;
 
     const unsigned *__restrict__ words = (const unsigned *)(a.pairs + a.pair_ptr[b]);
-    const int n_calls = 2 * (int)(a.pair_ptr[b + 1] - a.pair_ptr[b]);  // incl. neutral padding calls
+    const int n_calls = 2 * (int)(a.pair_ptr[b + 1] - a.pair_ptr[b]);  // incl. neutral padding, multiple of 8
     for (int pos = 0; pos < n_calls; pos += C) {
-        const int n = (n_calls - pos) < C ? (n_calls - pos) : C;
+        const int n = (n_calls - pos) < C ? (n_calls - pos) : C;  // multiple of 8
         __syncthreads();
         if (tid < n) {
             const int ci = pos + tid;
             const int w = (ci >> 1) * 8 + (ci & 1);
-            sh_vid[tid] = (int)words[w];  // byte offset of the prob row
+            sh_off[tid] = words[w];  // byte offset of the prob row
             sh_keep[tid] = __uint_as_float(words[w + 2]);
             sh_floor[tid] = __uint_as_float(words[w + 4]);
         }
         __syncthreads();
-        for (int i = tid; i < n * G; i += 256) {
-            const int c = i / G, g = i - c * G;
-            sh_rows[i] = *(const float *)((const char *)a.prob + ((unsigned)sh_vid[c] + (unsigned)g * 4u));
+        // wave w stages calls w, w+4, ...: coalesced row read, transposed LDS write
+        for (int c = wave; c < n; c += 4) {
+            const char *row = (const char *)a.prob + sh_off[c];
+            for (int g = lane; g < G; g += 64) sh_t[g * CS + c] = *(const float *)(row + (unsigned)g * 4u);
         }
         __syncthreads();
-        // calls in pairs (c, c+1) through the packed log; an odd tail call is paired with a padding
-        // call (keep 0, floor 1 -> log(1) = +0)
         for (int c = 0; c < n; c += 2) {
-            const bool tail = c + 1 >= n;
-            const npm::f32x2 keep2 = {sh_keep[c], tail ? 0.0f : sh_keep[c + 1]};
-            const npm::f32x2 flo2 = {sh_floor[c], tail ? 1.0f : sh_floor[c + 1]};
-            const float *row0 = sh_rows + c * G;
-            const float *row1 = tail ? row0 : row0 + G;
+            const npm::f32x2 keep2 = *(const npm::f32x2 *)(sh_keep + c);
+            const npm::f32x2 flo2 = *(const npm::f32x2 *)(sh_floor + c);
 #pragma unroll
             for (int s = 0; s < A; s++) {
-                const int g1 = pr[s] & 0xFFFF, g2 = pr[s] >> 16;
-                const npm::f32x2 pa = {row0[g1], row1[g1]};
-                const npm::f32x2 pb = {row0[g2], row1[g2]};
+                if (s * 256 + wave * 64 >= K) continue;  // wave-uniform: this wave's slot lies past the last option
+                const npm::f32x2 pa = *(const npm::f32x2 *)(sh_t + a1[s] + c);
+                const npm::f32x2 pb = *(const npm::f32x2 *)(sh_t + a2[s] + c);
                 npm::f32x2 t = ((pa + pb) * 0.5f) * keep2;
                 t = t + flo2;
                 const npm::f32x2 lp = npm::log_f32_hot2(t);
@@ -747,9 +748,9 @@ static void launch_direct(hipStream_t st, const EstepArgs &a, bool pairs)
 template <int A>
 static hipError_t launch_block(hipStream_t st, const EstepArgs &a)
 {
-    int C = 16384 / (4 * a.G);
+    int C = (16384 / (4 * a.G)) & ~7;  // calls staged per chunk: multiple of the 8-call row padding
     C = C < 8 ? 8 : (C > 128 ? 128 : C);
-    size_t stage = (size_t)C * a.G * 4 + (size_t)C * 12;
+    size_t stage = (size_t)(C + 2) * a.G * 4 + (size_t)C * 12;
     size_t soft = (size_t)a.K * 4 + 64;
     size_t bytes = stage > soft ? stage : soft;
     bytes = (bytes + 15) & ~size_t(15);
@@ -777,10 +778,15 @@ hipError_t launch_estep(hipStream_t st, const EstepArgs &a, bool pairs)
     if (!pairs) return hipErrorInvalidValue;  // K = G > 256 singlets: not supported (checked by the caller)
     const int need = (K + 255) / 256;
     if (need <= 2) return launch_block<2>(st, a);
+    if (need <= 3) return launch_block<3>(st, a);
     if (need <= 4) return launch_block<4>(st, a);
+    if (need <= 6) return launch_block<6>(st, a);
     if (need <= 8) return launch_block<8>(st, a);
+    if (need <= 12) return launch_block<12>(st, a);
     if (need <= 16) return launch_block<16>(st, a);
+    if (need <= 24) return launch_block<24>(st, a);
     if (need <= 33) return launch_block<33>(st, a);
+    if (need <= 48) return launch_block<48>(st, a);
     if (need <= 65) return launch_block<65>(st, a);
     return hipErrorInvalidValue;
 }

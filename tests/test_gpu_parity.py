@@ -224,17 +224,23 @@ def test_c_abi_rejects_bad_calls():
     from demuxalot_amd.device import DeviceContext
     ctx = DeviceContext(0)
     try:
-        with pytest.raises(_lib.DemuxHipError, match='call order'):
-            ctx.estep(np.zeros(3, dtype=np.float32), with_doublets=False)
         with pytest.raises(_lib.DemuxHipError, match='outside'):
             ctx.set_problem(2, 3, 2, np.array([0, 5]), np.array([0, 1]), np.array([.1, .1], dtype='f4'), np.zeros(3, dtype='i4'))
         with pytest.raises(_lib.DemuxHipError, match='outside'):
             ctx.set_problem(2, 3, 2, np.array([0, 1]), np.array([0, 2]), np.array([.1, .1], dtype='f4'), np.zeros(3, dtype='i4'))
+        with pytest.raises(_lib.DemuxHipError, match='call order'):
+            _lib.check(_lib.load().dmx_set_betas(ctx._h, None))  # no problem resident after the failed uploads
         ctx.set_problem(2, 3, 2, np.array([0, 1]), np.array([0, 1]), np.array([.1, .1], dtype='f4'), np.zeros(3, dtype='i4'))
+        with pytest.raises(_lib.DemuxHipError, match='call order'):
+            ctx.estep(np.zeros(2, dtype=np.float32), with_doublets=False)  # no probabilities yet
         with pytest.raises(_lib.DemuxHipError, match='call order'):
             ctx.mstep()
         with pytest.raises(_lib.DemuxHipError, match='call order'):
-            ctx.probs_from_betas(0.01)
+            ctx.probs_from_betas(0.01)  # no betas yet
+        ctx.set_betas(np.ones((3, 2), dtype=np.float32))
+        ctx.probs_from_betas(0.01)
+        logits, probs = ctx.estep(np.zeros(2, dtype=np.float32), with_doublets=False)
+        assert np.isfinite(logits).all() and np.allclose(probs.sum(axis=1), 1)
         assert ctx.device_bytes() > 0
     finally:
         ctx.close()
