@@ -410,5 +410,53 @@ def main():
     save('f1_from_assignment.npz', keep)
 
 
+def synthetic_generator_case():
+    """F5: a mid-size problem from the benchmark generator (demuxalot_amd/synth.py) pushed
+    through the REFERENCE's full entry points, so that the generator's object form, the host repack and
+    the kernels are pinned at a size with thousands of calls per variant. Inputs are regenerated by the
+    deterministic generator at test time (a hash of them is stored); only outputs are saved."""
+    import hashlib
+    ref, _ = import_reference()
+    sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
+    from demuxalot_amd import synth
+    problem = synth.generate(2000, 5000, 16, calls_per_barcode=300, doublets=True, seed=4242)
+    calls_amd, genotypes_amd, handler_amd = synth.as_objects(problem)
+    # rebuild the same inputs as reference objects
+    from demuxalot.snp_counter import CompressedSNPCalls
+    calls = {}
+    for chrom, c in calls_amd.items():
+        cc = CompressedSNPCalls()
+        cc.molecules, cc.snp_calls = c.molecules.copy(), c.snp_calls.copy()
+        cc.n_molecules, cc.n_snp_calls = c.n_molecules, c.n_snp_calls
+        calls[chrom] = cc
+    g = ref.ProbabilisticGenotypes(genotypes_amd.genotype_names)
+    g.var2varid = dict(genotypes_amd.var2varid)
+    g.variant_betas = genotypes_amd.variant_betas.copy()
+    handler = ref.BarcodeHandler(handler_amd.ordered_barcodes)
+    h = hashlib.sha256()
+    for arr in (problem.variant_id, problem.compressed_cb, problem.p_base_wrong, problem.raw_betas):
+        h.update(np.ascontiguousarray(arr).tobytes())
+    out = {'input_sha256': np.asarray(h.hexdigest())}
+    D = ref.Demultiplexer
+    v2snp, betas, _mol, bc = D.pack_calls(calls, g, add_data_prior=True)
+    assert np.array_equal(bc['variant_id'], problem.variant_id) and np.array_equal(bc['compressed_cb'], problem.compressed_cb)
+    assert np.array_equal(bc['p_base_wrong'], problem.p_base_wrong)
+    out['pack1_betas'] = np.array(betas)
+    for i, dp in enumerate((0., 0.3)):
+        logits, probs = D.predict_posteriors(calls, g, handler, doublet_prior=dp)
+        out[f'predict{i}_dp'] = np.float64(dp)
+        out[f'predict{i}_logits'] = logits.values
+        out[f'predict{i}_probs'] = probs.values
+    learnt, probs = D.learn_genotypes(calls, g, handler, n_iterations=3)
+    out['em_learnt_betas'] = np.array(learnt.variant_betas)
+    out['em_probs'] = probs.values
+    print('F5: N', problem.n_calls, 'max calls per variant', np.bincount(problem.variant_id).max())
+    save('f5_generator_2k_5k_16.npz', out)
+
+
 if __name__ == '__main__':
-    main()
+    if len(sys.argv) > 1 and sys.argv[1] == 'f5':
+        synthetic_generator_case()
+    else:
+        main()
+        synthetic_generator_case()

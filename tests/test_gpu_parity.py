@@ -130,6 +130,34 @@ def test_learning_from_assignment_matches_reference():
     assert np.abs(probs64.values - probs.values).max() <= TOL_POSTERIOR
 
 
+def test_generator_problem_matches_reference():
+    """F5: a benchmark-generator problem (2k barcodes x 5k SNPs x 16 donors, 504k calls, up to 1768 calls
+    per variant -> chunked M-step items) run through the reference's full entry points."""
+    import hashlib
+    from demuxalot_amd import Demultiplexer, synth
+    fx = fio.load('f5_generator_2k_5k_16.npz')
+    problem = synth.generate(2000, 5000, 16, calls_per_barcode=300, doublets=True, seed=4242)
+    h = hashlib.sha256()
+    for arr in (problem.variant_id, problem.compressed_cb, problem.p_base_wrong, problem.raw_betas):
+        h.update(np.ascontiguousarray(arr).tobytes())
+    if h.hexdigest() != str(fx['input_sha256']):
+        pytest.skip('numpy on this host generates a different random stream than the fixture was made with')
+    calls, genotypes, handler = synth.as_objects(problem)
+    v2snp, betas, _mol, bc = Demultiplexer.pack_calls(calls, genotypes, add_data_prior=True)
+    fio.assert_bitwise(betas, fx['pack1_betas'], 'prior betas')
+    assert np.array_equal(bc['variant_id'], problem.variant_id) and np.array_equal(bc['compressed_cb'], problem.compressed_cb)
+    for i in range(2):
+        logits, probs = Demultiplexer.predict_posteriors(calls, genotypes, handler, doublet_prior=float(fx[f'predict{i}_dp']))
+        check_posteriors(logits.values, probs.values, fx[f'predict{i}_logits'], fx[f'predict{i}_probs'], f'F5 predict {i}')
+    learnt, probs = Demultiplexer.learn_genotypes(calls, genotypes, handler, n_iterations=3)
+    assert np.array_equal(probs.values.argmax(1), fx['em_probs'].argmax(1))
+    assert np.abs(probs.values - fx['em_probs']).max() <= TOL_POSTERIOR
+    # variants with > 1024 calls are summed in chunks: a beta may differ by one float32 ulp at exact ties
+    diff = learnt.variant_betas != fx['em_learnt_betas']
+    assert diff.mean() < 1e-3 and np.allclose(learnt.variant_betas, fx['em_learnt_betas'], rtol=2e-7, atol=0)
+    fio.assert_bitwise(probs.values, fx['em_probs'], 'F5 EM posteriors')
+
+
 def test_front_end_asserts_like_reference():
     from demuxalot_amd import Demultiplexer
     fx = fio.load('f3_small_0.npz')
