@@ -10,8 +10,7 @@
 #include <string>
 #include <vector>
 
-#include "dmx_internal.h"
-#include "kernels.h"
+#include "dmx_ctx.h"
 
 // ------------------------------------------------------------------------------------
 // error handling
@@ -31,19 +30,6 @@ int fail(int code, const char *fmt, ...)
 }
 }  // namespace dmx
 
-using dmx::fail;
-
-#define HIP_TRY(expr)                                                                                   \
-    do {                                                                                                \
-        hipError_t _e = (expr);                                                                         \
-        if (_e != hipSuccess) return fail(DMX_ERR_HIP, "%s failed: %s", #expr, hipGetErrorString(_e)); \
-    } while (0)
-
-#define DMX_TRY(expr)         \
-    do {                      \
-        int _s = (expr);      \
-        if (_s != 0) return _s; \
-    } while (0)
 
 // ------------------------------------------------------------------------------------
 // RCCL, loaded on demand so that single-GPU use has no dependency on it
@@ -88,78 +74,7 @@ int load_rccl()
 }
 }  // namespace
 
-// ------------------------------------------------------------------------------------
-// context
-// ------------------------------------------------------------------------------------
-struct TimerSlot {
-    std::vector<std::pair<hipEvent_t, hipEvent_t>> pending;
-    std::vector<std::pair<hipEvent_t, hipEvent_t>> free_list;
-    double ms = 0.0;
-    int64_t launches = 0;
-};
-
-struct dmx_ctx {
-    int device = 0;
-    hipStream_t stream = nullptr;
-    long long B = 0, V = 0, N = 0, S = 0;
-    int G = 0, K = 0;
-    bool have_problem = false, have_betas = false, have_probs = false, have_post = false;
-
-    long long *d_pair_ptr = nullptr;
-    dmx::CallPair *d_call_pairs = nullptr;
-    long long n_pairs = 0;
-    uint2 *d_csc = nullptr;
-    long long *d_item_start = nullptr;
-    int *d_item_len = nullptr;
-    long long *d_item_ptr = nullptr;
-    int *d_bc_order = nullptr, *d_item_order = nullptr;
-    long long n_items = 0;
-    int *d_v2snp = nullptr, *d_snp_ptr = nullptr, *d_snp_vars = nullptr;
-    float *d_prior = nullptr, *d_add = nullptr, *d_prob = nullptr;
-    double *d_add64 = nullptr, *d_partial = nullptr;
-    float *d_logits = nullptr, *d_post = nullptr;
-    unsigned long long *d_nz = nullptr;
-    long long cap_bk = 0;
-    float *d_pen = nullptr;
-    unsigned *d_pairs = nullptr;
-    int cap_k = 0;
-    void *d_prior_logits = nullptr;
-    size_t cap_prior = 0;
-    int *d_best = nullptr;
-    float *d_bestp = nullptr;
-    void *d_scratch = nullptr;  // self tests
-    size_t cap_scratch = 0;
-
-    ncclComm_t comm = nullptr;
-    int rank = 0, nranks = 1, reduce_dtype = DMX_F64;
-
-    int64_t bytes = 0;
-    TimerSlot timers[DMX_T_COUNT];
-};
-
 namespace {
-
-template <typename T>
-int dev_alloc(dmx_ctx *c, T **p, size_t count)
-{
-    *p = nullptr;
-    if (count == 0) count = 1;
-    hipError_t e = hipMalloc((void **)p, count * sizeof(T));
-    if (e != hipSuccess)
-        return fail(DMX_ERR_HIP, "hipMalloc of %zu bytes failed: %s", count * sizeof(T), hipGetErrorString(e));
-    c->bytes += (int64_t)(count * sizeof(T));
-    return 0;
-}
-
-template <typename T>
-void dev_free(dmx_ctx *c, T **p, size_t count)
-{
-    if (*p) {
-        (void)hipFree(*p);
-        c->bytes -= (int64_t)((count ? count : 1) * sizeof(T));
-        *p = nullptr;
-    }
-}
 
 int bind(dmx_ctx *c)
 {
@@ -492,71 +407,6 @@ int dmx_set_problem(dmx_ctx *c, int64_t B, int64_t V, int32_t G, int64_t N, cons
     HIP_TRY(hipStreamSynchronize(c->stream));
     release_problem(c);
 
-    // ---- host side: CSR by barcode and CSC by variant, both stable in the input order ----
-    std::vector<long long> row_ptr((size_t)B + 1, 0), col_ptr((size_t)V + 1, 0);
-    for (int64_t i = 0; i < N; i++) {
-        const int32_t b = cb[i], v = variant_id[i];
-        if (b < 0 || b >= B) return fail(DMX_ERR_INVALID, "compressed_cb[%lld]=%d outside [0,%lld)", (long long)i, b, (long long)B);
-        if (v < 0 || v >= V) return fail(DMX_ERR_INVALID, "variant_id[%lld]=%d outside [0,%lld)", (long long)i, v, (long long)V);
-        row_ptr[(size_t)b + 1]++;
-        col_ptr[(size_t)v + 1]++;
-    }
-    for (int64_t b = 0; b < B; b++) row_ptr[b + 1] += row_ptr[b];
-    for (int64_t v = 0; v < V; v++) col_ptr[v + 1] += col_ptr[v];
-    // E-step records: rows padded to 8 calls with neutral calls, two calls per CallPair
-    std::vector<long long> pair_ptr((size_t)B + 1, 0);
-    for (int64_t b = 0; b < B; b++) pair_ptr[b + 1] = pair_ptr[b] + ((row_ptr[b + 1] - row_ptr[b] + 7) / 8) * 4;
-    const long long n_pairs = pair_ptr[B];
-    std::vector<dmx::CallPair> pairs((size_t)n_pairs);
-    for (auto &pr : pairs) {
-        pr.row_off[0] = pr.row_off[1] = 0u;
-        pr.keep[0] = pr.keep[1] = 0.0f;
-        pr.floor[0] = pr.floor[1] = 1.0f;
-        pr.reserved[0] = pr.reserved[1] = 0u;
-    }
-    std::vector<uint2> csc((size_t)N);
-    {
-        std::vector<long long> rcur((size_t)B, 0), ccur(col_ptr.begin(), col_ptr.end() - 1);
-        for (int64_t i = 0; i < N; i++) {
-            const float e = p_wrong[i];
-            uint32_t ebits;
-            std::memcpy(&ebits, &e, 4);
-            const long long j = rcur[cb[i]]++;  // position inside the barcode's row (input order)
-            dmx::CallPair &pr = pairs[(size_t)(pair_ptr[cb[i]] + (j >> 1))];
-            // byte offset of the variant's row in the [V, G] float32 prob table
-            pr.row_off[j & 1] = (uint32_t)variant_id[i] * (uint32_t)G * 4u;
-            pr.keep[j & 1] = 1.0f - e;                    // float32, numpy's `1 - e`
-            pr.floor[j & 1] = e > 1e-4f ? e : 1e-4f;      // numpy's `e.clip(1e-4)`
-            const float keep = 1.0f - e;  // the M-step only ever needs 1 - e
-            std::memcpy(&ebits, &keep, 4);
-            csc[(size_t)ccur[variant_id[i]]++] = make_uint2((uint32_t)cb[i], ebits);
-        }
-    }
-    // M-step work items: runs of <= ITEM_CALLS calls of one variant
-    std::vector<long long> item_start, item_ptr((size_t)V + 1, 0);
-    std::vector<int> item_len;
-    for (int64_t v = 0; v < V; v++) {
-        item_ptr[v] = (long long)item_start.size();
-        for (long long s = col_ptr[v]; s < col_ptr[v + 1]; s += dmx::ITEM_CALLS) {
-            item_start.push_back(s);
-            item_len.push_back((int)std::min<long long>(dmx::ITEM_CALLS, col_ptr[v + 1] - s));
-        }
-    }
-    item_ptr[V] = (long long)item_start.size();
-    if (item_start.size() >= (size_t(1) << 31)) return fail(DMX_ERR_UNSUPPORTED, "too many M-step work items");
-    // work distribution: longest rows / items first, neighbours of similar length (counting sort by length)
-    auto by_decreasing_length = [](size_t count, auto length_of) {
-        long long max_len = 0;
-        for (size_t i = 0; i < count; i++) max_len = std::max<long long>(max_len, length_of(i));
-        std::vector<long long> start((size_t)max_len + 2, 0);
-        for (size_t i = 0; i < count; i++) start[(size_t)(max_len - length_of(i)) + 1]++;
-        for (size_t l = 0; l + 1 < start.size(); l++) start[l + 1] += start[l];
-        std::vector<int> order(count);
-        for (size_t i = 0; i < count; i++) order[(size_t)start[(size_t)(max_len - length_of(i))]++] = (int)i;
-        return order;
-    };
-    std::vector<int> bc_order = by_decreasing_length((size_t)B, [&](size_t b) { return row_ptr[b + 1] - row_ptr[b]; });
-    std::vector<int> item_order = by_decreasing_length(item_len.size(), [&](size_t i) { return (long long)item_len[i]; });
     // SNP groups: variants of each SNP in increasing variant index (np.bincount order)
     long long S = 0;
     for (int64_t v = 0; v < V; v++) {
@@ -577,17 +427,9 @@ int dmx_set_problem(dmx_ctx *c, int64_t B, int64_t V, int32_t G, int64_t N, cons
     c->G = G;
     c->N = N;
     c->S = S;
-    c->n_items = (long long)item_start.size();
+    // call records, work items and work lists are derived on the GPU (repack_device.hip)
+    DMX_TRY(dmx::repack_on_device(c, variant_id, cb, p_wrong));
     const size_t vg = (size_t)V * G;
-    c->n_pairs = n_pairs;
-    DMX_TRY(dev_alloc(c, &c->d_pair_ptr, (size_t)B + 1));
-    DMX_TRY(dev_alloc(c, &c->d_call_pairs, (size_t)n_pairs));
-    DMX_TRY(dev_alloc(c, &c->d_csc, (size_t)N));
-    DMX_TRY(dev_alloc(c, &c->d_item_start, (size_t)c->n_items));
-    DMX_TRY(dev_alloc(c, &c->d_item_len, (size_t)c->n_items));
-    DMX_TRY(dev_alloc(c, &c->d_item_ptr, (size_t)V + 1));
-    DMX_TRY(dev_alloc(c, &c->d_bc_order, (size_t)B));
-    DMX_TRY(dev_alloc(c, &c->d_item_order, (size_t)c->n_items));
     DMX_TRY(dev_alloc(c, &c->d_v2snp, (size_t)V));
     DMX_TRY(dev_alloc(c, &c->d_snp_ptr, (size_t)S + 1));
     DMX_TRY(dev_alloc(c, &c->d_snp_vars, (size_t)V));
@@ -600,24 +442,13 @@ int dmx_set_problem(dmx_ctx *c, int64_t B, int64_t V, int32_t G, int64_t N, cons
     DMX_TRY(dev_alloc(c, &c->d_best, (size_t)B));
     DMX_TRY(dev_alloc(c, &c->d_bestp, (size_t)B));
     hipStream_t st = c->stream;
-    HIP_TRY(hipMemcpyAsync(c->d_pair_ptr, pair_ptr.data(), sizeof(long long) * (B + 1), hipMemcpyHostToDevice, st));
-    if (n_pairs)
-        HIP_TRY(hipMemcpyAsync(c->d_call_pairs, pairs.data(), sizeof(dmx::CallPair) * n_pairs, hipMemcpyHostToDevice, st));
-    if (N) HIP_TRY(hipMemcpyAsync(c->d_csc, csc.data(), sizeof(uint2) * N, hipMemcpyHostToDevice, st));
-    if (c->n_items) {
-        HIP_TRY(hipMemcpyAsync(c->d_item_start, item_start.data(), sizeof(long long) * c->n_items, hipMemcpyHostToDevice, st));
-        HIP_TRY(hipMemcpyAsync(c->d_item_len, item_len.data(), sizeof(int) * c->n_items, hipMemcpyHostToDevice, st));
-    }
-    HIP_TRY(hipMemcpyAsync(c->d_item_ptr, item_ptr.data(), sizeof(long long) * (V + 1), hipMemcpyHostToDevice, st));
-    if (B) HIP_TRY(hipMemcpyAsync(c->d_bc_order, bc_order.data(), sizeof(int) * B, hipMemcpyHostToDevice, st));
-    if (c->n_items)
-        HIP_TRY(hipMemcpyAsync(c->d_item_order, item_order.data(), sizeof(int) * c->n_items, hipMemcpyHostToDevice, st));
     if (V) {
         HIP_TRY(hipMemcpyAsync(c->d_v2snp, v2snp, sizeof(int) * V, hipMemcpyHostToDevice, st));
         HIP_TRY(hipMemcpyAsync(c->d_snp_vars, snp_vars.data(), sizeof(int) * V, hipMemcpyHostToDevice, st));
     }
     HIP_TRY(hipMemcpyAsync(c->d_snp_ptr, snp_ptr.data(), sizeof(int) * (S + 1), hipMemcpyHostToDevice, st));
     HIP_TRY(hipMemsetAsync(c->d_add, 0, sizeof(float) * (vg ? vg : 1), st));
+    if (B) HIP_TRY(hipMemsetAsync(c->d_nz, 0, sizeof(unsigned long long) * (size_t)B * ((G + 63) / 64), st));
     HIP_TRY(hipStreamSynchronize(st));  // host staging vectors die here
     c->have_problem = true;
     return 0;

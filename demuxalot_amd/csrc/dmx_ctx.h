@@ -1,0 +1,105 @@
+// dmx_ctx.h -- the context object behind the opaque dmx_ctx of the C ABI, shared by the
+// translation units of libdemux_hip.so (dmx_api.cpp, repack_device.hip).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <rccl/rccl.h>
+
+#include <string>
+#include <utility>
+#include <vector>
+
+#include "dmx_internal.h"
+#include "kernels.h"
+
+using dmx::fail;
+
+#define HIP_TRY(expr)                                                                                   \
+    do {                                                                                                \
+        hipError_t _e = (expr);                                                                         \
+        if (_e != hipSuccess) return fail(DMX_ERR_HIP, "%s failed: %s", #expr, hipGetErrorString(_e)); \
+    } while (0)
+
+#define DMX_TRY(expr)         \
+    do {                      \
+        int _s = (expr);      \
+        if (_s != 0) return _s; \
+    } while (0)
+
+// ------------------------------------------------------------------------------------
+// context
+// ------------------------------------------------------------------------------------
+struct TimerSlot {
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> pending;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> free_list;
+    double ms = 0.0;
+    int64_t launches = 0;
+};
+
+struct dmx_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    long long B = 0, V = 0, N = 0, S = 0;
+    int G = 0, K = 0;
+    bool have_problem = false, have_betas = false, have_probs = false, have_post = false;
+
+    long long *d_pair_ptr = nullptr;
+    dmx::CallPair *d_call_pairs = nullptr;
+    long long n_pairs = 0;
+    uint2 *d_csc = nullptr;
+    long long *d_item_start = nullptr;
+    int *d_item_len = nullptr;
+    long long *d_item_ptr = nullptr;
+    int *d_bc_order = nullptr, *d_item_order = nullptr;
+    long long n_items = 0;
+    int *d_v2snp = nullptr, *d_snp_ptr = nullptr, *d_snp_vars = nullptr;
+    float *d_prior = nullptr, *d_add = nullptr, *d_prob = nullptr;
+    double *d_add64 = nullptr, *d_partial = nullptr;
+    float *d_logits = nullptr, *d_post = nullptr;
+    unsigned long long *d_nz = nullptr;
+    long long cap_bk = 0;
+    float *d_pen = nullptr;
+    unsigned *d_pairs = nullptr;
+    int cap_k = 0;
+    void *d_prior_logits = nullptr;
+    size_t cap_prior = 0;
+    int *d_best = nullptr;
+    float *d_bestp = nullptr;
+    void *d_scratch = nullptr;  // self tests
+    size_t cap_scratch = 0;
+
+    ncclComm_t comm = nullptr;
+    int rank = 0, nranks = 1, reduce_dtype = DMX_F64;
+
+    int64_t bytes = 0;
+    TimerSlot timers[DMX_T_COUNT];
+};
+
+template <typename T>
+inline int dev_alloc(dmx_ctx *c, T **p, size_t count)
+{
+    *p = nullptr;
+    if (count == 0) count = 1;
+    hipError_t e = hipMalloc((void **)p, count * sizeof(T));
+    if (e != hipSuccess)
+        return fail(DMX_ERR_HIP, "hipMalloc of %zu bytes failed: %s", count * sizeof(T), hipGetErrorString(e));
+    c->bytes += (int64_t)(count * sizeof(T));
+    return 0;
+}
+
+template <typename T>
+inline void dev_free(dmx_ctx *c, T **p, size_t count)
+{
+    if (*p) {
+        (void)hipFree(*p);
+        c->bytes -= (int64_t)((count ? count : 1) * sizeof(T));
+        *p = nullptr;
+    }
+}
+
+
+namespace dmx {
+// Derives the E-step call records (barcode-major, padded pairs), the M-step records
+// (variant-major), the work items and the length-sorted work lists on the GPU from the
+// uploaded COO columns, and stores them in the ctx (repack_device.hip).
+int repack_on_device(dmx_ctx *c, const int32_t *h_variant, const int32_t *h_cb, const float *h_p);
+}  // namespace dmx
