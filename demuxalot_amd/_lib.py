@@ -30,6 +30,9 @@ SIGNATURES = {
     'dmx_pack_calls_host': (c_int, [c_int64, _P, _P, _P, c_int64, _P, _P, _P, _P, _P, _P,
                                     POINTER(c_int64), POINTER(c_int64), _P, _P, _P, _P, _P]),
     'dmx_set_problem': (c_int, [_P, c_int64, c_int64, c_int32, c_int64, _P, _P, _P, _P]),
+    'dmx_pack_and_set_problem': (c_int, [_P, c_int64, c_int64, c_int32, _P, _P, _P, _P, c_int64, _P, _P, _P, _P, _P,
+                                         POINTER(c_int64), POINTER(c_int64), _P]),
+    'dmx_get_packed_calls': (c_int, [_P, _P, _P, _P, _P]),
     'dmx_set_betas': (c_int, [_P, _P]),
     'dmx_set_addition': (c_int, [_P, _P]),
     'dmx_probs_from_betas': (c_int, [_P, c_float, c_float, _P]),

@@ -152,6 +152,11 @@ void release_problem(dmx_ctx *c)
     }
     dev_free(c, &c->d_best, (size_t)c->B);
     dev_free(c, &c->d_bestp, (size_t)c->B);
+    dev_free(c, &c->d_u_variant, (size_t)c->n_u);
+    dev_free(c, &c->d_u_cb, (size_t)c->n_u);
+    dev_free(c, &c->d_u_p, (size_t)c->n_u);
+    dev_free(c, &c->d_u_count, (size_t)c->n_u);
+    c->n_u = 0;
     c->have_problem = c->have_betas = c->have_probs = c->have_post = false;
     c->B = c->V = c->N = c->S = 0;
     c->G = c->K = 0;
@@ -392,43 +397,43 @@ int dmx_synchronize(dmx_ctx *c)
     return 0;
 }
 
-int dmx_set_problem(dmx_ctx *c, int64_t B, int64_t V, int32_t G, int64_t N, const int32_t *variant_id,
-                    const int32_t *cb, const float *p_wrong, const int32_t *v2snp)
+// validations shared by the two ways of installing a problem + SNP groups (variants of each SNP in
+// increasing variant index = np.bincount order), built on the host: O(V)
+static int begin_problem(dmx_ctx *c, int64_t B, int64_t V, int32_t G, const int32_t *v2snp, std::vector<int> &snp_ptr,
+                         std::vector<int> &snp_vars, long long &S)
 {
-    DMX_TRY(bind(c));
-    if (B < 0 || V < 0 || G <= 0 || N < 0) return fail(DMX_ERR_INVALID, "bad problem sizes B=%lld V=%lld G=%d N=%lld", (long long)B, (long long)V, G, (long long)N);
+    if (B < 0 || V < 0 || G <= 0) return fail(DMX_ERR_INVALID, "bad problem sizes B=%lld V=%lld G=%d", (long long)B, (long long)V, G);
     if (G > 65535) return fail(DMX_ERR_UNSUPPORTED, "G=%d genotypes exceed the 16-bit option encoding", G);
     if (B >= (int64_t(1) << 31) || V >= (int64_t(1) << 31)) return fail(DMX_ERR_UNSUPPORTED, "B and V must fit int32");
     if ((long long)V * G * 4 >= (1LL << 32))
         return fail(DMX_ERR_UNSUPPORTED, "genotype table of %lld x %d floats exceeds the 4 GiB reachable by 32-bit row offsets",
                     (long long)V, G);
-    if (N > 0 && (!variant_id || !cb || !p_wrong)) return fail(DMX_ERR_INVALID, "null call arrays");
     if (V > 0 && !v2snp) return fail(DMX_ERR_INVALID, "null v2snp");
     HIP_TRY(hipStreamSynchronize(c->stream));
     release_problem(c);
-
-    // SNP groups: variants of each SNP in increasing variant index (np.bincount order)
-    long long S = 0;
+    S = 0;
     for (int64_t v = 0; v < V; v++) {
         if (v2snp[v] < 0) return fail(DMX_ERR_INVALID, "v2snp[%lld] negative", (long long)v);
         S = std::max<long long>(S, (long long)v2snp[v] + 1);
     }
-    std::vector<int> snp_ptr((size_t)S + 1, 0), snp_vars((size_t)V);
+    snp_ptr.assign((size_t)S + 1, 0);
+    snp_vars.assign((size_t)V, 0);
     for (int64_t v = 0; v < V; v++) snp_ptr[(size_t)v2snp[v] + 1]++;
     for (long long s = 0; s < S; s++) snp_ptr[s + 1] += snp_ptr[s];
-    {
-        std::vector<int> cur(snp_ptr.begin(), snp_ptr.end() - 1);
-        for (int64_t v = 0; v < V; v++) snp_vars[(size_t)cur[v2snp[v]]++] = (int)v;
-    }
-
-    // ---- device ----
+    std::vector<int> cur(snp_ptr.begin(), snp_ptr.end() - 1);
+    for (int64_t v = 0; v < V; v++) snp_vars[(size_t)cur[v2snp[v]]++] = (int)v;
     c->B = B;
     c->V = V;
     c->G = G;
-    c->N = N;
     c->S = S;
-    // call records, work items and work lists are derived on the GPU (repack_device.hip)
-    DMX_TRY(dmx::repack_on_device(c, variant_id, cb, p_wrong));
+    return 0;
+}
+
+// genotype tables and per-barcode outputs; called once the call layouts are on the device
+static int finish_problem(dmx_ctx *c, const int32_t *v2snp, const std::vector<int> &snp_ptr, const std::vector<int> &snp_vars)
+{
+    const long long B = c->B, V = c->V, S = c->S;
+    const int G = c->G;
     const size_t vg = (size_t)V * G;
     DMX_TRY(dev_alloc(c, &c->d_v2snp, (size_t)V));
     DMX_TRY(dev_alloc(c, &c->d_snp_ptr, (size_t)S + 1));
@@ -449,8 +454,57 @@ int dmx_set_problem(dmx_ctx *c, int64_t B, int64_t V, int32_t G, int64_t N, cons
     HIP_TRY(hipMemcpyAsync(c->d_snp_ptr, snp_ptr.data(), sizeof(int) * (S + 1), hipMemcpyHostToDevice, st));
     HIP_TRY(hipMemsetAsync(c->d_add, 0, sizeof(float) * (vg ? vg : 1), st));
     if (B) HIP_TRY(hipMemsetAsync(c->d_nz, 0, sizeof(unsigned long long) * (size_t)B * ((G + 63) / 64), st));
-    HIP_TRY(hipStreamSynchronize(st));  // host staging vectors die here
+    HIP_TRY(hipStreamSynchronize(st));  // host staging vectors die in the caller
     c->have_problem = true;
+    return 0;
+}
+
+int dmx_set_problem(dmx_ctx *c, int64_t B, int64_t V, int32_t G, int64_t N, const int32_t *variant_id,
+                    const int32_t *cb, const float *p_wrong, const int32_t *v2snp)
+{
+    DMX_TRY(bind(c));
+    if (N < 0) return fail(DMX_ERR_INVALID, "negative number of calls");
+    if (N > 0 && (!variant_id || !cb || !p_wrong)) return fail(DMX_ERR_INVALID, "null call arrays");
+    std::vector<int> snp_ptr, snp_vars;
+    long long S = 0;
+    DMX_TRY(begin_problem(c, B, V, G, v2snp, snp_ptr, snp_vars, S));
+    c->N = N;
+    // call records, work items and work lists are derived on the GPU (repack_device.hip)
+    DMX_TRY(dmx::repack_on_device(c, variant_id, cb, p_wrong));
+    return finish_problem(c, v2snp, snp_ptr, snp_vars);
+}
+
+int dmx_pack_and_set_problem(dmx_ctx *c, int64_t B, int64_t V, int32_t G, const int32_t *var_chrom, const int32_t *var_pos,
+                             const uint8_t *var_base, const int32_t *v2snp, int64_t n_calls, const int32_t *call_chrom,
+                             const int32_t *call_pos, const uint8_t *call_base, const int32_t *call_cb, const float *call_p,
+                             int64_t *n_matched, int64_t *n_unique, int64_t *mol_per_variant)
+{
+    DMX_TRY(bind(c));
+    if (n_calls < 0 || !n_matched || !n_unique) return fail(DMX_ERR_INVALID, "bad sizes or null counters");
+    if (n_calls > 0 && (!call_chrom || !call_pos || !call_base || !call_cb || !call_p)) return fail(DMX_ERR_INVALID, "null call arrays");
+    if (V > 0 && (!var_chrom || !var_pos || !var_base)) return fail(DMX_ERR_INVALID, "null variant arrays");
+    std::vector<int> snp_ptr, snp_vars;
+    long long S = 0;
+    DMX_TRY(begin_problem(c, B, V, G, v2snp, snp_ptr, snp_vars, S));
+    long long matched = 0, unique = 0;
+    DMX_TRY(dmx::pack_on_device(c, V, var_chrom, var_pos, var_base, n_calls, call_chrom, call_pos, call_base, call_cb, call_p,
+                                &matched, &unique, (long long *)mol_per_variant));
+    *n_matched = matched;
+    *n_unique = unique;
+    return finish_problem(c, v2snp, snp_ptr, snp_vars);
+}
+
+int dmx_get_packed_calls(dmx_ctx *c, int32_t *variant_id, int32_t *cb, float *p_wrong, int64_t *count)
+{
+    DMX_TRY(bind(c));
+    DMX_TRY(need(c, c->have_problem && (c->d_u_variant || c->n_u == 0) && c->n_u == c->N,
+                 "dmx_pack_and_set_problem before dmx_get_packed_calls"));
+    const size_t n = (size_t)c->n_u;
+    if (variant_id && n) HIP_TRY(hipMemcpyAsync(variant_id, c->d_u_variant, sizeof(int) * n, hipMemcpyDeviceToHost, c->stream));
+    if (cb && n) HIP_TRY(hipMemcpyAsync(cb, c->d_u_cb, sizeof(int) * n, hipMemcpyDeviceToHost, c->stream));
+    if (p_wrong && n) HIP_TRY(hipMemcpyAsync(p_wrong, c->d_u_p, sizeof(float) * n, hipMemcpyDeviceToHost, c->stream));
+    if (count && n) HIP_TRY(hipMemcpyAsync(count, c->d_u_count, sizeof(long long) * n, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
     return 0;
 }
 

@@ -64,6 +64,11 @@ struct dmx_ctx {
     size_t cap_prior = 0;
     int *d_best = nullptr;
     float *d_bestp = nullptr;
+    // unique (variant, barcode) calls left by the device pack (variant-major), kept for dmx_get_packed_calls
+    int *d_u_variant = nullptr, *d_u_cb = nullptr;
+    float *d_u_p = nullptr;
+    long long *d_u_count = nullptr;
+    long long n_u = 0;
     void *d_scratch = nullptr;  // self tests
     size_t cap_scratch = 0;
 
@@ -102,4 +107,10 @@ namespace dmx {
 // (variant-major), the work items and the length-sorted work lists on the GPU from the
 // uploaded COO columns, and stores them in the ctx (repack_device.hip).
 int repack_on_device(dmx_ctx *c, const int32_t *h_variant, const int32_t *h_cb, const float *h_p);
+// Variant matching + de-duplication of molecule calls on the GPU (demux.py:276-300, 332-365), then the
+// layouts; sets c->N to the number of unique calls.
+int pack_on_device(dmx_ctx *c, long long V, const int *var_chrom, const int *var_pos, const unsigned char *var_base,
+                   long long n_calls, const int *call_chrom, const int *call_pos, const unsigned char *call_base,
+                   const int *call_cb, const float *call_p, long long *n_matched, long long *n_unique,
+                   long long *mol_per_variant);
 }  // namespace dmx

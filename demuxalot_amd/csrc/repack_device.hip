@@ -185,24 +185,12 @@ int scan_with_total(Scratch &sc, const long long *in, long long *out, size_t n, 
 
 }  // namespace
 
-int repack_on_device(dmx_ctx *c, const int32_t *h_variant, const int32_t *h_cb, const float *h_p)
+// Core: COO columns already on the device (d_variant / d_cb / d_p, N = c->N entries).
+static int repack_core(dmx_ctx *c, Scratch &sc, const int *d_variant, const int *d_cb, const float *d_p)
 {
     const long long B = c->B, V = c->V, N = c->N;
     const int G = c->G;
     hipStream_t st = c->stream;
-    Scratch sc;
-
-    // ---- upload the COO columns ----
-    int *d_variant = nullptr, *d_cb = nullptr;
-    float *d_p = nullptr;
-    DMX_TRY(sc.get(&d_variant, (size_t)N));
-    DMX_TRY(sc.get(&d_cb, (size_t)N));
-    DMX_TRY(sc.get(&d_p, (size_t)N));
-    if (N) {
-        HIP_TRY(hipMemcpyAsync(d_variant, h_variant, sizeof(int) * N, hipMemcpyHostToDevice, st));
-        HIP_TRY(hipMemcpyAsync(d_cb, h_cb, sizeof(int) * N, hipMemcpyHostToDevice, st));
-        HIP_TRY(hipMemcpyAsync(d_p, h_p, sizeof(float) * N, hipMemcpyHostToDevice, st));
-    }
 
     // ---- counts (integer atomics) + range check ----
     unsigned *row_cnt = nullptr, *col_cnt = nullptr;
@@ -218,8 +206,12 @@ int repack_on_device(dmx_ctx *c, const int32_t *h_variant, const int32_t *h_cb, 
     int h_bad[3];
     HIP_TRY(hipMemcpyAsync(h_bad, bad, sizeof h_bad, hipMemcpyDeviceToHost, st));
     HIP_TRY(hipStreamSynchronize(st));
-    if (h_bad[0]) return fail(DMX_ERR_INVALID, "compressed_cb[%d]=%d outside [0,%lld)", h_bad[2], h_cb[h_bad[2]], B);
-    if (h_bad[1]) return fail(DMX_ERR_INVALID, "variant_id[%d]=%d outside [0,%lld)", h_bad[2], h_variant[h_bad[2]], V);
+    if (h_bad[0] || h_bad[1]) {
+        int value = 0;
+        (void)hipMemcpy(&value, (h_bad[0] ? d_cb : d_variant) + h_bad[2], sizeof(int), hipMemcpyDeviceToHost);
+        return fail(DMX_ERR_INVALID, "%s[%d]=%d outside [0,%lld)", h_bad[0] ? "compressed_cb" : "variant_id", h_bad[2],
+                    value, h_bad[0] ? B : V);
+    }
 
     // ---- prefix sums: raw row / column starts, padded pair offsets, items per variant ----
     long long *row_raw = nullptr, *row_pairs = nullptr, *col_raw = nullptr, *col_items = nullptr, *row_start = nullptr,
@@ -285,8 +277,243 @@ int repack_on_device(dmx_ctx *c, const int32_t *h_variant, const int32_t *h_cb, 
     DMX_TRY(sort_pairs(sc, inv, inv_sorted, ids, (unsigned *)c->d_bc_order, (size_t)B, 32, st));
 
     HIP_TRY(hipGetLastError());
-    HIP_TRY(hipStreamSynchronize(st));  // host source buffers and scratch are released on return
+    HIP_TRY(hipStreamSynchronize(st));  // scratch is released by the caller's Scratch
     return 0;
+}
+
+int repack_on_device(dmx_ctx *c, const int32_t *h_variant, const int32_t *h_cb, const float *h_p)
+{
+    const long long N = c->N;
+    hipStream_t st = c->stream;
+    Scratch sc;
+    int *d_variant = nullptr, *d_cb = nullptr;
+    float *d_p = nullptr;
+    DMX_TRY(sc.get(&d_variant, (size_t)N));
+    DMX_TRY(sc.get(&d_cb, (size_t)N));
+    DMX_TRY(sc.get(&d_p, (size_t)N));
+    if (N) {
+        HIP_TRY(hipMemcpyAsync(d_variant, h_variant, sizeof(int) * N, hipMemcpyHostToDevice, st));
+        HIP_TRY(hipMemcpyAsync(d_cb, h_cb, sizeof(int) * N, hipMemcpyHostToDevice, st));
+        HIP_TRY(hipMemcpyAsync(d_p, h_p, sizeof(float) * N, hipMemcpyHostToDevice, st));
+    }
+    return repack_core(c, sc, d_variant, d_cb, d_p);
+}
+
+// ------------------------------------------------------------------------------------
+// Device pack: Demultiplexer.pack_calls' variant matching + molecule_calls2barcode_calls
+// (demuxalot/demux.py:276-300, 332-365) on the GPU, feeding repack_core without a round trip:
+//   1. 64-bit keys (chromosome, position, base) of the variants, sorted (rocPRIM) -> binary search
+//      of every molecule call -> variant row or "no match";
+//   2. order-preserving compaction of the matched calls (prefix sum of the match flags);
+//   3. stable radix sort of (variant << 32 | barcode, input index);
+//   4. one thread per run of equal keys multiplies the members' p_base_wrong in input order,
+//      starting from 1.0f (np.multiply.at semantics) -> unique calls, variant-major.
+// ------------------------------------------------------------------------------------
+namespace {
+
+__host__ __device__ inline unsigned long long variant_key(int chrom, int pos, unsigned char base)
+{
+    return ((unsigned long long)(unsigned)chrom << 35) | ((unsigned long long)(unsigned)pos << 3) | (unsigned long long)(base & 7);
+}
+
+__global__ __launch_bounds__(256) void k_variant_keys(const int *chrom, const int *pos, const unsigned char *base, long long n,
+                                                      unsigned long long *keys, unsigned *rows)
+{
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    keys[i] = variant_key(chrom[i], pos[i], base[i]);
+    rows[i] = (unsigned)i;
+}
+
+__global__ __launch_bounds__(256) void k_match(const int *chrom, const int *pos, const unsigned char *base, const int *cb,
+                                               long long n, const unsigned long long *vkeys, const unsigned *vrows,
+                                               long long V, int *call_variant, unsigned *flag,
+                                               unsigned long long *mol_per_variant, int *bad)
+{
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const unsigned long long q = variant_key(chrom[i], pos[i], base[i]);
+    long long lo = 0, hi = V;  // lower_bound
+    while (lo < hi) {
+        const long long mid = (lo + hi) >> 1;
+        if (vkeys[mid] < q) lo = mid + 1; else hi = mid;
+    }
+    const bool hit = lo < V && vkeys[lo] == q;
+    const int v = hit ? (int)vrows[lo] : -1;
+    call_variant[i] = v;
+    flag[i] = hit ? 1u : 0u;
+    if (hit) {
+        if (cb[i] < 0) atomicMax(bad, 1);
+        atomicAdd(&mol_per_variant[v], 1ull);
+    }
+}
+
+__global__ __launch_bounds__(256) void k_compact_keys(const int *call_variant, const int *cb, const unsigned *flag,
+                                                      const unsigned *pos_excl, long long n, unsigned long long *keys,
+                                                      unsigned *idx)
+{
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n || !flag[i]) return;
+    const unsigned o = pos_excl[i];
+    keys[o] = ((unsigned long long)(unsigned)call_variant[i] << 32) | (unsigned)cb[i];
+    idx[o] = (unsigned)i;
+}
+
+__global__ __launch_bounds__(256) void k_heads(const unsigned long long *keys, long long m, unsigned *head)
+{
+    const long long s = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (s < m) head[s] = (s == 0 || keys[s] != keys[s - 1]) ? 1u : 0u;
+}
+
+__global__ __launch_bounds__(256) void k_products(const unsigned long long *keys, const unsigned *perm, const unsigned *head,
+                                                  const unsigned *seg_incl, const float *call_p, long long m,
+                                                  int *u_variant, int *u_cb, float *u_p, long long *u_count)
+{
+    const long long s = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= m || !head[s]) return;
+    float p = 1.0f;
+    long long t = s;
+    do {
+        p = p * call_p[perm[t]];  // float32, sequential in input order
+        t++;
+    } while (t < m && !head[t]);
+    const unsigned u = seg_incl[s] - 1u;
+    u_variant[u] = (int)(keys[s] >> 32);
+    u_cb[u] = (int)(keys[s] & 0xFFFFFFFFull);
+    u_p[u] = p;
+    u_count[u] = t - s;
+}
+
+template <typename T>
+int upload(Scratch &sc, T **dst, const T *src, size_t n, hipStream_t st)
+{
+    DMX_TRY(sc.get(dst, n));
+    if (n) HIP_TRY(hipMemcpyAsync(*dst, src, sizeof(T) * n, hipMemcpyHostToDevice, st));
+    return 0;
+}
+
+}  // namespace
+
+int pack_on_device(dmx_ctx *c, long long V, const int *var_chrom, const int *var_pos, const unsigned char *var_base,
+                   long long n_calls, const int *call_chrom, const int *call_pos, const unsigned char *call_base,
+                   const int *call_cb, const float *call_p, long long *n_matched, long long *n_unique,
+                   long long *mol_per_variant)
+{
+    hipStream_t st = c->stream;
+    Scratch sc;
+    if (n_calls >= (1LL << 32)) return fail(DMX_ERR_UNSUPPORTED, "more than 2^32 molecule calls in one batch");
+    // 1. sorted variant keys
+    int *d_vchrom, *d_vpos;
+    unsigned char *d_vbase;
+    DMX_TRY(upload(sc, &d_vchrom, var_chrom, (size_t)V, st));
+    DMX_TRY(upload(sc, &d_vpos, var_pos, (size_t)V, st));
+    DMX_TRY(upload(sc, &d_vbase, var_base, (size_t)V, st));
+    unsigned long long *vkeys, *vkeys_sorted;
+    unsigned *vrows, *vrows_sorted;
+    DMX_TRY(sc.get(&vkeys, (size_t)V));
+    DMX_TRY(sc.get(&vkeys_sorted, (size_t)V));
+    DMX_TRY(sc.get(&vrows, (size_t)V));
+    DMX_TRY(sc.get(&vrows_sorted, (size_t)V));
+    if (V) {
+        hipLaunchKernelGGL(k_variant_keys, dim3(grid_for(V)), dim3(256), 0, st, d_vchrom, d_vpos, d_vbase, V, vkeys, vrows);
+        size_t bytes = 0;
+        HIP_TRY(rocprim::radix_sort_pairs(nullptr, bytes, vkeys, vkeys_sorted, vrows, vrows_sorted, (size_t)V, 0u, 64u, st));
+        char *tmp;
+        DMX_TRY(sc.get(&tmp, bytes));
+        HIP_TRY(rocprim::radix_sort_pairs(tmp, bytes, vkeys, vkeys_sorted, vrows, vrows_sorted, (size_t)V, 0u, 64u, st));
+    }
+    // 2. match + order-preserving compaction
+    int *d_cchrom, *d_cpos, *d_ccb;
+    unsigned char *d_cbase;
+    float *d_cp;
+    DMX_TRY(upload(sc, &d_cchrom, call_chrom, (size_t)n_calls, st));
+    DMX_TRY(upload(sc, &d_cpos, call_pos, (size_t)n_calls, st));
+    DMX_TRY(upload(sc, &d_cbase, call_base, (size_t)n_calls, st));
+    DMX_TRY(upload(sc, &d_ccb, call_cb, (size_t)n_calls, st));
+    DMX_TRY(upload(sc, &d_cp, call_p, (size_t)n_calls, st));
+    int *call_variant, *bad;
+    unsigned *flag, *pos_excl;
+    unsigned long long *d_mol;
+    DMX_TRY(sc.get(&call_variant, (size_t)n_calls));
+    DMX_TRY(sc.get(&flag, (size_t)n_calls + 1));
+    DMX_TRY(sc.get(&pos_excl, (size_t)n_calls + 1));
+    DMX_TRY(sc.get(&d_mol, (size_t)V));
+    DMX_TRY(sc.get(&bad, 1));
+    HIP_TRY(hipMemsetAsync(d_mol, 0, sizeof(unsigned long long) * (V ? V : 1), st));
+    HIP_TRY(hipMemsetAsync(bad, 0, sizeof(int), st));
+    HIP_TRY(hipMemsetAsync(flag, 0, sizeof(unsigned) * ((size_t)n_calls + 1), st));
+    if (n_calls)
+        hipLaunchKernelGGL(k_match, dim3(grid_for(n_calls)), dim3(256), 0, st, d_cchrom, d_cpos, d_cbase, d_ccb, n_calls,
+                           vkeys_sorted, vrows_sorted, V, call_variant, flag, d_mol, bad);
+    {
+        size_t bytes = 0;
+        HIP_TRY(rocprim::exclusive_scan(nullptr, bytes, flag, pos_excl, 0u, (size_t)n_calls + 1, rocprim::plus<unsigned>(), st));
+        char *tmp;
+        DMX_TRY(sc.get(&tmp, bytes));
+        HIP_TRY(rocprim::exclusive_scan(tmp, bytes, flag, pos_excl, 0u, (size_t)n_calls + 1, rocprim::plus<unsigned>(), st));
+    }
+    unsigned h_matched = 0;
+    int h_bad = 0;
+    HIP_TRY(hipMemcpyAsync(&h_matched, pos_excl + n_calls, sizeof(unsigned), hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipMemcpyAsync(&h_bad, bad, sizeof(int), hipMemcpyDeviceToHost, st));
+    if (mol_per_variant && V)
+        HIP_TRY(hipMemcpyAsync(mol_per_variant, d_mol, sizeof(long long) * V, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    if (h_bad) return fail(DMX_ERR_INVALID, "negative barcode index among the matched calls");
+    const long long m = h_matched;
+    *n_matched = m;
+    // 3. stable sort by (variant, barcode)
+    unsigned long long *keys, *keys_sorted;
+    unsigned *idx, *perm;
+    DMX_TRY(sc.get(&keys, (size_t)m));
+    DMX_TRY(sc.get(&keys_sorted, (size_t)m));
+    DMX_TRY(sc.get(&idx, (size_t)m));
+    DMX_TRY(sc.get(&perm, (size_t)m));
+    if (n_calls)
+        hipLaunchKernelGGL(k_compact_keys, dim3(grid_for(n_calls)), dim3(256), 0, st, call_variant, d_ccb, flag, pos_excl,
+                           n_calls, keys, idx);
+    if (m) {
+        size_t bytes = 0;
+        const unsigned end_bit = 32 + bits_for(V ? V - 1 : 0);
+        HIP_TRY(rocprim::radix_sort_pairs(nullptr, bytes, keys, keys_sorted, idx, perm, (size_t)m, 0u, end_bit, st));
+        char *tmp;
+        DMX_TRY(sc.get(&tmp, bytes));
+        HIP_TRY(rocprim::radix_sort_pairs(tmp, bytes, keys, keys_sorted, idx, perm, (size_t)m, 0u, end_bit, st));
+    }
+    // 4. runs of equal keys -> products in input order
+    unsigned *head, *seg_incl;
+    DMX_TRY(sc.get(&head, (size_t)m));
+    DMX_TRY(sc.get(&seg_incl, (size_t)m));
+    long long n_u = 0;
+    if (m) {
+        hipLaunchKernelGGL(k_heads, dim3(grid_for(m)), dim3(256), 0, st, keys_sorted, m, head);
+        size_t bytes = 0;
+        HIP_TRY(rocprim::inclusive_scan(nullptr, bytes, head, seg_incl, (size_t)m, rocprim::plus<unsigned>(), st));
+        char *tmp;
+        DMX_TRY(sc.get(&tmp, bytes));
+        HIP_TRY(rocprim::inclusive_scan(tmp, bytes, head, seg_incl, (size_t)m, rocprim::plus<unsigned>(), st));
+        unsigned last = 0;
+        HIP_TRY(hipMemcpyAsync(&last, seg_incl + (m - 1), sizeof(unsigned), hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipStreamSynchronize(st));
+        n_u = last;
+    }
+    *n_unique = n_u;
+    // unique calls stay resident in the ctx (dmx_get_packed_calls) and feed the layout derivation directly
+    dev_free(c, &c->d_u_variant, (size_t)c->n_u);
+    dev_free(c, &c->d_u_cb, (size_t)c->n_u);
+    dev_free(c, &c->d_u_p, (size_t)c->n_u);
+    dev_free(c, &c->d_u_count, (size_t)c->n_u);
+    c->n_u = n_u;
+    DMX_TRY(dev_alloc(c, &c->d_u_variant, (size_t)n_u));
+    DMX_TRY(dev_alloc(c, &c->d_u_cb, (size_t)n_u));
+    DMX_TRY(dev_alloc(c, &c->d_u_p, (size_t)n_u));
+    DMX_TRY(dev_alloc(c, &c->d_u_count, (size_t)n_u));
+    if (m)
+        hipLaunchKernelGGL(k_products, dim3(grid_for(m)), dim3(256), 0, st, keys_sorted, perm, head, seg_incl, d_cp, m,
+                           c->d_u_variant, c->d_u_cb, c->d_u_p, c->d_u_count);
+    HIP_TRY(hipGetLastError());
+    c->N = n_u;
+    return repack_core(c, sc, c->d_u_variant, c->d_u_cb, c->d_u_p);
 }
 
 }  // namespace dmx

@@ -7,8 +7,10 @@ import).  Inputs are duck-typed: the reference's own CompressedSNPCalls / Probab
 BarcodeHandler objects work as well as this package's mirrors.
 
 What runs where
-  host, C++  (libdemux_hip.so, dmx_pack_calls_host): variant matching, de-duplication with float32
-             products, CSR/CSC derivation                      -> demux.py:276-300, 332-365
+  GPU (rocPRIM sorts/scans + HIP kernels, dmx_pack_and_set_problem): variant matching, de-duplication
+             with float32 products in call order, CSR/CSC derivation -> demux.py:276-300, 332-365
+             (the public pack_calls(), whose results are host arrays, uses the C++ host twin
+             dmx_pack_calls_host, which also works without a GPU)
   host, numpy: regularised prior betas (O(V*G), one-off)       -> demux.py:367-388
   GPU (HIP):  beta -> probability normalisation                -> demux.py:267-274
               per-barcode log-likelihood accumulation + softmax -> demux.py:246-265, :101, :152
@@ -148,6 +150,22 @@ def _pack(chromosome2compressed_snp_calls, genotypes, add_data_prior, want_molec
     return packed
 
 
+def _pack_on_device(chromosome2compressed_snp_calls, genotypes, n_barcodes, add_data_prior):
+    """The repack of predict / learn: flattening on the host, matching + de-duplication + layout
+    derivation on the GPU (dmx_pack_and_set_problem), the O(V*G) prior betas in numpy.
+    Returns (ctx with the problem and betas resident, regularised prior betas)."""
+    (var_chrom, var_pos, var_base), flat = _flatten_inputs(chromosome2compressed_snp_calls, genotypes, False)
+    v2snp = genotypes.get_snp_ids_for_variants()
+    assert np.all(v2snp >= 0)
+    ctx = get_context()
+    _n_matched, _n_unique, mol_per_variant = ctx.pack_and_set_problem(
+        n_barcodes, genotypes.n_genotypes, var_chrom, var_pos, var_base, v2snp,
+        flat['chrom'], flat['pos'], flat['base'], flat['cb'], flat['p'])
+    betas = _prior_betas(genotypes, v2snp, mol_per_variant, add_data_prior)
+    ctx.set_betas(betas)
+    return ctx, betas
+
+
 def _option_names(genotype_names, doublet_prior):
     """Column names: singlets, then 'A+B' for A before B (demux.py:175-191)."""
     names = list(genotype_names)
@@ -191,8 +209,7 @@ class Demultiplexer:
             assert barcode_prior_logits.shape == (barcode_handler.n_barcodes, len(penalties)), 'wrong shape of priors'
         assert n_iterations >= 1, 'n_iterations should be positive'  # the reference fails to unpack an empty run
 
-        packed = _pack(chromosome2compressed_snp_calls, genotypes, add_data_prior=True)
-        ctx = Demultiplexer._upload(packed, barcode_handler.n_barcodes, n_genotypes)
+        ctx, _betas = _pack_on_device(chromosome2compressed_snp_calls, genotypes, barcode_handler.n_barcodes, True)
         _logits, probs, addition = ctx.em(
             n_iterations, p_genotype_clip, penalties, with_doublets=doublet_prior != 0,
             prior_logits=barcode_prior_logits, contribution_power=Demultiplexer.contribution_power,
@@ -220,10 +237,9 @@ class Demultiplexer:
         if barcode_prior_logits is not None:
             assert barcode_prior_logits.shape == (barcode_handler.n_barcodes, len(penalties)), 'wrong shape of priors'
 
-        packed = _pack(chromosome2compressed_snp_calls, genotypes, add_data_prior=True)
-        ctx = Demultiplexer._upload(packed, barcode_handler.n_barcodes, n_genotypes)
+        ctx, prior_betas = _pack_on_device(chromosome2compressed_snp_calls, genotypes, barcode_handler.n_barcodes, True)
         column_names = _option_names(genotypes.genotype_names, doublet_prior)
-        genotype_addition = np.zeros_like(packed.betas)
+        genotype_addition = np.zeros_like(prior_betas)
         ctx.set_addition(None)
 
         for iteration in range(n_iterations):
@@ -233,7 +249,7 @@ class Demultiplexer:
             probs_df = pd.DataFrame(data=probs, index=barcode_handler.ordered_barcodes, columns=column_names)
             yield probs_df, {
                 'barcode_logits': logits,
-                'genotype_prior': packed.betas,
+                'genotype_prior': prior_betas,
                 'genotype_addition': genotype_addition,
             }
             genotype_addition = ctx.mstep(Demultiplexer.contribution_power)
@@ -248,8 +264,7 @@ class Demultiplexer:
         barcode_handler.ordered_barcodes order, index named 'BARCODE'."""
         Demultiplexer._check_not_aggregating()
         penalties = Demultiplexer._doublet_penalties(genotypes.n_genotypes, doublet_prior)
-        packed = _pack(chromosome2compressed_snp_calls, genotypes, add_data_prior=False)
-        ctx = Demultiplexer._upload(packed, barcode_handler.n_barcodes, genotypes.n_genotypes)
+        ctx, _betas = _pack_on_device(chromosome2compressed_snp_calls, genotypes, barcode_handler.n_barcodes, False)
         ctx.set_addition(None)
         genotype_prob = ctx.probs_from_betas(p_genotype_clip)
         assert np.isfinite(genotype_prob).all()
@@ -392,11 +407,3 @@ class Demultiplexer:
             raise NotImplementedError(
                 'aggregate_on_snps=True (demux.py:204-244, off by default and slated for removal in the '
                 'reference) is not part of the MI355X hot path')
-
-    @staticmethod
-    def _upload(packed: _Packed, n_barcodes, n_genotypes):
-        ctx = get_context()
-        ctx.set_problem(n_barcodes, len(packed.v2snp), n_genotypes, packed.variant_id, packed.compressed_cb,
-                        packed.p_base_wrong, packed.v2snp)
-        ctx.set_betas(packed.betas)
-        return ctx

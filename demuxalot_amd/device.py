@@ -42,6 +42,33 @@ class DeviceContext:
                                         ptr(variant_id), ptr(compressed_cb), ptr(p_base_wrong), ptr(v2snp)))
         self.B, self.V, self.G, self.N = int(n_barcodes), int(n_variants), int(n_genotypes), len(variant_id)
 
+    def pack_and_set_problem(self, n_barcodes, n_genotypes, var_chrom, var_pos, var_base, v2snp,
+                             call_chrom, call_pos, call_base, call_cb, call_p):
+        """Device pack (variant matching + de-duplication, demux.py:276-300, 332-365) installed directly as
+        the resident problem. Returns (n_matched, n_unique, molecules per variant)."""
+        var_chrom, var_pos, var_base = as_c(var_chrom, np.int32), as_c(var_pos, np.int32), as_c(var_base, np.uint8)
+        v2snp = as_c(v2snp, np.int32)
+        call_chrom, call_pos = as_c(call_chrom, np.int32), as_c(call_pos, np.int32)
+        call_base, call_cb, call_p = as_c(call_base, np.uint8), as_c(call_cb, np.int32), as_c(call_p, np.float32)
+        n_variants, n_calls = len(var_pos), len(call_pos)
+        assert len(v2snp) == n_variants
+        mol_per_variant = np.zeros(n_variants, dtype=np.int64)
+        n_matched, n_unique = ctypes.c_int64(0), ctypes.c_int64(0)
+        check(self._lib.dmx_pack_and_set_problem(
+            self._h, n_barcodes, n_variants, n_genotypes, ptr(var_chrom), ptr(var_pos), ptr(var_base), ptr(v2snp),
+            n_calls, ptr(call_chrom), ptr(call_pos), ptr(call_base), ptr(call_cb), ptr(call_p),
+            ctypes.byref(n_matched), ctypes.byref(n_unique), ptr(mol_per_variant)))
+        self.B, self.V, self.G, self.N = int(n_barcodes), int(n_variants), int(n_genotypes), n_unique.value
+        return n_matched.value, n_unique.value, mol_per_variant
+
+    def get_packed_calls(self):
+        """Unique (variant, barcode) calls left on the device by pack_and_set_problem, variant-major."""
+        n = self.N
+        variant, cb = np.empty(n, dtype=np.int32), np.empty(n, dtype=np.int32)
+        p, count = np.empty(n, dtype=np.float32), np.empty(n, dtype=np.int64)
+        check(self._lib.dmx_get_packed_calls(self._h, ptr(variant), ptr(cb), ptr(p), ptr(count)))
+        return variant, cb, p, count
+
     def set_betas(self, betas):
         betas = as_c(betas, np.float32)
         assert betas.shape == (self.V, self.G)

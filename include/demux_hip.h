@@ -91,6 +91,19 @@ int dmx_set_problem(dmx_ctx *ctx, int64_t n_barcodes, int64_t n_variants, int32_
                     int64_t n_calls, const int32_t *variant_id, const int32_t *compressed_cb,
                     const float *p_base_wrong, const int32_t *v2snp);
 
+/* Device pack: dmx_pack_calls_host's matching + de-duplication done on the GPU and installed
+ * directly as the resident problem (as dmx_set_problem would with the unique calls), without a
+ * host round trip.  mol_per_variant [n_variants] as in dmx_pack_calls_host.  The unique calls can be
+ * read back with dmx_get_packed_calls (variant-major; arrays of *n_unique entries, each nullable). */
+int dmx_pack_and_set_problem(dmx_ctx *ctx, int64_t n_barcodes, int64_t n_variants, int32_t n_genotypes,
+                             const int32_t *var_chrom, const int32_t *var_pos, const uint8_t *var_base,
+                             const int32_t *v2snp, int64_t n_calls, const int32_t *call_chrom,
+                             const int32_t *call_pos, const uint8_t *call_base, const int32_t *call_cb,
+                             const float *call_p, int64_t *n_matched, int64_t *n_unique,
+                             int64_t *mol_per_variant);
+int dmx_get_packed_calls(dmx_ctx *ctx, int32_t *variant_id, int32_t *compressed_cb, float *p_base_wrong,
+                         int64_t *barcode_variant_count);
+
 /* Regularised prior betas float32[V*G] (output of pack_calls, demux.py:372-388). */
 int dmx_set_betas(dmx_ctx *ctx, const float *prior_betas);
 

@@ -158,6 +158,21 @@ def test_generator_problem_matches_reference():
     fio.assert_bitwise(probs.values, fx['em_probs'], 'F5 EM posteriors')
 
 
+@pytest.mark.parametrize('name', fio.SMALL + fio.SYNTH)
+def test_device_pack_matches_reference(name):
+    """dmx_pack_and_set_problem (matching + de-duplication on the GPU) against the reference's pack_calls."""
+    from demuxalot_amd.demux import _pack_on_device
+    fx = fio.load(name)
+    calls, genotypes, handler = fio.product_inputs(fx)
+    for flag in (False, True):
+        ctx, betas = _pack_on_device(calls, genotypes, handler.n_barcodes, flag)
+        fio.assert_bitwise(betas, fx[f'pack{int(flag)}_betas'], 'prior betas')
+        variant, cb, p, count = ctx.get_packed_calls()
+        assert np.array_equal(variant, fx['pack_bc_variant_id']) and np.array_equal(cb, fx['pack_bc_cb'])
+        fio.assert_bitwise(p, fx['pack_bc_p'], 'p_base_wrong products')
+        assert np.array_equal(count, fx['pack_bc_variant_count'])
+
+
 def test_front_end_asserts_like_reference():
     from demuxalot_amd import Demultiplexer
     fx = fio.load('f3_small_0.npz')
