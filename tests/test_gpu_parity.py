@@ -216,6 +216,42 @@ def test_unit_steps_match_oracle(oracle, G, dp):
     fio.assert_bitwise(got, want, f'logits G={G} dp={dp}')
 
 
+@pytest.mark.parametrize('seed', range(6))
+def test_randomised_em_against_oracle(oracle, seed):
+    """Random shapes: ragged rows (some barcodes and variants without calls), multi-allelic SNPs,
+    G from 1 to 70, with / without doublets and prior logits, 1-4 EM iterations; everything bitwise."""
+    from demuxalot_amd import Demultiplexer
+    from demuxalot_amd.device import get_context
+    rng = np.random.default_rng(1000 + seed)
+    G = int(rng.choice([1, 2, 3, 5, 7, 12, 17, 31, 33, 64, 65, 70]))
+    B, V = int(rng.integers(5, 400)), int(rng.integers(4, 300))
+    dp = float(rng.choice([0., 0., 0.2, 0.45])) if G > 1 else 0.
+    K = G if dp == 0 else G * (G + 1) // 2
+    n_it = int(rng.integers(1, 5))
+    N = int(rng.integers(1, 6000))
+    # unique (variant, barcode) pairs, variant-major like the reference's barcode_calls; leave gaps
+    pairs = np.unique(np.stack([rng.integers(0, max(1, V - 2), N), rng.integers(0, max(1, B - 3), N)], axis=1), axis=0)
+    variant_id, cb = pairs[:, 0].astype(np.int32), pairs[:, 1].astype(np.int32)
+    e = (10.0 ** (-rng.integers(3, 45, len(cb)) / 10.0)).astype(np.float32)
+    e[rng.random(len(e)) < 0.05] = np.float32(1e-38)
+    e[rng.random(len(e)) < 0.02] = np.float32(0.0)
+    v2snp = np.sort(rng.integers(0, max(1, V // 2), V)).astype(np.int32)  # SNPs with 1..several variants
+    betas = (rng.gamma(0.5, 30.0, size=(V, G)) + 0.01).astype(np.float32)
+    betas[rng.random((V, G)) < 0.1] = 0
+    prior = (rng.normal(size=(B, K)) * 5).astype(np.float32) if rng.random() < 0.5 else None
+    clip = float(rng.choice([0.01, 0.0, 0.1]))
+    ctx = get_context()
+    ctx.set_problem(B, V, G, variant_id, cb, e, v2snp)
+    ctx.set_betas(betas)
+    pen = Demultiplexer._doublet_penalties(G, dp)
+    logits, probs, addition = ctx.em(n_it, clip, pen, with_doublets=dp != 0, prior_logits=prior)
+    packed = dict(variant_id=variant_id, compressed_cb=cb, p_base_wrong=e, betas=betas, v2snp=v2snp)
+    hist = oracle.em(packed, B, n_it, clip, dp, prior_logits=None if prior is None else prior.copy(), impl='npsimd')
+    what = f'seed {seed}: G={G} B={B} V={V} N={len(cb)} dp={dp} it={n_it} prior={prior is not None} clip={clip}'
+    check_posteriors(logits, probs, hist[-1]['logits'], hist[-1]['probs'], what)
+    fio.assert_bitwise(addition, hist[-1]['addition'], what + ' addition')
+
+
 def test_contribution_power_is_honoured(ctx, oracle):
     from demuxalot_amd import Demultiplexer
     fx = fio.load('f3_small_2.npz')
