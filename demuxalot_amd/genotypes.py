@@ -4,9 +4,11 @@ with a dict (chrom, pos, base) -> row.  `var2varid`, `variant_betas`, `genotype_
 `default_prior` stay plain writable attributes because callers (and the reference's tests,
 tests/test_synthetic.py:101-102, 182, 213) assign them directly.
 
-VCF / bead-array importers of the reference (genotypes.py:112-265) need pysam/htslib and are out
-of scope; the parquet round-trip (save_betas / add_prior_betas, genotypes.py:267-299, 336-358) is
-kept because it is the checkpoint format of learnt genotypes."""
+The bead-array / assignment-table importers of the reference (genotypes.py:170-265) are out of
+scope.  Kept because they make the package usable without pysam/htslib: the parquet round-trip
+(save_betas / add_prior_betas, genotypes.py:267-299, 336-358), which is the checkpoint format of
+learnt genotypes, and `add_vcf` with a plain-text VCF parser that follows the reference's import
+rules (genotypes.py:112-168)."""
 from collections import defaultdict
 from copy import deepcopy
 from typing import Dict, List, Tuple
@@ -62,6 +64,84 @@ class ProbabilisticGenotypes:
     def extend_variants(self, n_samples=1):
         while n_samples + self.n_variants > len(self.variant_betas):
             self.variant_betas = np.concatenate([self.variant_betas, np.zeros_like(self.variant_betas)], axis=0)
+
+    # ---- VCF import without htslib -----------------------------------------------------------
+    def _check_imported_genotypes(self, imported_genotypes, allow_duplicates=False) -> Dict[str, int]:
+        """Which of the imported sample names are ours (genotypes.py:80-110); returns name -> column."""
+        seen, duplicates = set(), []
+        for name in imported_genotypes:
+            if name in seen and name not in duplicates:
+                duplicates.append(name)
+            seen.add(name)
+        if duplicates:
+            if allow_duplicates:
+                warn(f'Duplicate genotypes found will be imported: {duplicates}')
+            else:
+                raise RuntimeError(f'Duplicate genotypes found in imported data: {duplicates}')
+        ours = set(self.genotype_names)
+        common = seen & ours
+        if not common:
+            raise RuntimeError(f'No genotypes to import, expected {ours}, got {seen}')
+        if seen - ours:
+            warn(f'Genotypes will not be imported: {seen - ours}')
+        if ours - seen:
+            print(f'Some of genotypes are not provided during import: {ours - seen}')
+        return {name: self.genotype_names.index(name) for name in common}
+
+    def add_vcf(self, vcf_file_name, prior_strength: float = 100.):
+        """Adds the calls of a (plain-text or gzipped) VCF, following the reference's rules
+        (genotypes.py:112-168): only records whose alleles are all single A/C/G/T bases and distinct;
+        each donor's called alleles share `prior_strength` (a missing allele of a diploid call leaves
+        its half unassigned); records with fewer than two genotyped donors are skipped (their variant
+        rows stay allocated, as in the reference); donors without a call at a kept record receive
+        0.1 x the mean of the genotyped donors. Positions are stored 0-based."""
+        import gzip
+        opener = gzip.open if str(vcf_file_name).endswith('.gz') else open
+        samples, donor2column = None, None
+        n_records = n_skipped = 0
+        n_before = self.n_variants
+        with opener(vcf_file_name, 'rt') as handle:
+            for line in handle:
+                if line.startswith('##') or not line.strip():
+                    continue
+                fields = line.rstrip('\n').split('\t')
+                if line.startswith('#'):
+                    samples = fields[9:]
+                    continue
+                assert samples is not None, 'VCF header line (#CHROM ...) is missing'
+                n_records += 1
+                chrom, pos1 = fields[0], int(fields[1])
+                alleles = [fields[3]] + ([] if fields[4] in ('.', '') else fields[4].split(','))
+                if any(len(a) != 1 for a in alleles):
+                    print('skipping non-snp, alleles = ', tuple(alleles), chrom, pos1)
+                    continue
+                if donor2column is None:
+                    donor2column = self._check_imported_genotypes(imported_genotypes=list(samples))
+                if len(set(alleles)) != len(alleles) or any(a not in 'ACGT' for a in alleles):
+                    n_skipped += 1
+                    continue
+                rows = [self.get_variant_id(chrom, pos1 - 1, a) for a in alleles]
+                keys = fields[8].split(':')
+                gt_slot = keys.index('GT')
+                contribution = np.zeros([len(rows), self.n_genotypes], dtype='float32')
+                for name, entry in zip(samples, fields[9:]):
+                    if name not in donor2column:
+                        continue
+                    parts = entry.split(':')
+                    gt = parts[gt_slot] if gt_slot < len(parts) else '.'
+                    called = gt.replace('|', '/').split('/')
+                    for token in called:
+                        if token not in ('.', ''):
+                            contribution[int(token), donor2column[name]] += prior_strength / len(called)
+                not_provided = contribution.sum(axis=0) == 0
+                if np.sum(~not_provided) < 2:
+                    n_skipped += 1
+                    continue
+                contribution[:, not_provided] = contribution[:, ~not_provided].mean(axis=1, keepdims=True) * 0.1
+                self.variant_betas[rows] += contribution
+        if n_skipped > 0:
+            print('skipped', n_skipped, 'SNVs')
+        print(f'Parsed {n_records} SNPs, got {self.n_variants - n_before} novel variants')
 
     def get_chromosome2positions(self):
         by_chrom = defaultdict(list)

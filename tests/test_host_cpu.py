@@ -121,6 +121,34 @@ def test_genotypes_store_and_roundtrip(tmp_path):
         genotypes._with_betas(np.zeros((3, 4), dtype=np.float32))
 
 
+def test_add_vcf_plain_text(tmp_path):
+    """Import rules of the reference's add_vcf (genotypes.py:112-168) on a hand-checked file."""
+    from demuxalot_amd import ProbabilisticGenotypes
+    vcf = tmp_path / 'toy.vcf'
+    vcf.write_text('\n'.join([
+        '##fileformat=VCFv4.2',
+        '#CHROM\tPOS\tID\tREF\tALT\tQUAL\tFILTER\tINFO\tFORMAT\tD1\tD2\tD3\tExtra',
+        'chr1\t10\ts0\tG\tT\t.\t.\t.\tGT\t0/0\t1/1\t0/1\t1/1',           # plain biallelic
+        'chr1\t20\ts1\tA\tC,G\t.\t.\t.\tGT:DP\t0|2:5\t./.:0\t1/1:7\t0/0:1',  # tri-allelic, phased, missing donor
+        'chr1\t30\ts2\tAT\tA\t.\t.\t.\tGT\t0/0\t1/1\t0/0\t0/0',           # indel: skipped as non-SNP
+        'chr2\t5\ts3\tC\tT\t.\t.\t.\tGT\t0/1\t./.\t./.\t1/1',             # one genotyped donor of ours: skipped, rows stay
+        'chr2\t7\ts4\tC\tT\t.\t.\t.\tGT\t./1\t0/0\t./.\t0/0',             # half-missing call
+    ]) + '\n')
+    g = ProbabilisticGenotypes(['D1', 'D2', 'D3'])
+    with pytest.warns(UserWarning, match='will not be imported'):
+        g.add_vcf(str(vcf))
+    assert list(g.var2varid) == [('chr1', 9, 'G'), ('chr1', 9, 'T'), ('chr1', 19, 'A'), ('chr1', 19, 'C'), ('chr1', 19, 'G'),
+                                 ('chr2', 4, 'C'), ('chr2', 4, 'T'), ('chr2', 6, 'C'), ('chr2', 6, 'T')]
+    b = g.get_betas()
+    assert np.array_equal(b[0], [100, 0, 50]) and np.array_equal(b[1], [0, 100, 50])
+    # tri-allelic: D1 = A/G, D3 = C/C, D2 not provided -> 0.1 x mean of the provided donors per allele
+    assert np.allclose(b[2], [50, 2.5, 0]) and np.allclose(b[3], [0, 5.0, 100]) and np.allclose(b[4], [50, 2.5, 0])
+    assert np.array_equal(b[5:7], np.zeros((2, 3)))                      # skipped record keeps zero rows
+    assert np.allclose(b[7], [0, 100, 5.0]) and np.allclose(b[8], [50, 0, 2.5])   # './1' assigns only half
+    assert list(g.get_snp_ids_for_variants()) == [0, 0, 1, 1, 1, 2, 2, 3, 3]
+    assert {k: list(v) for k, v in g.get_chromosome2positions().items()} == {'chr1': [9, 19], 'chr2': [4, 6]}
+
+
 def test_barcode_handler_and_container():
     from demuxalot_amd import BarcodeHandler, CompressedSNPCalls
     h = BarcodeHandler(['T-1', 'A-1', 'G-1'])
