@@ -5,7 +5,7 @@ import numpy as np
 
 GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden')
 SMALL = [f'f3_small_{i}.npz' for i in range(5)]
-SYNTH = ['f2_synthetic_g4.npz', 'f1_synthetic_default.npz']
+SYNTH = ['f2_synthetic_g4.npz', 'f1_synthetic_default.npz', 'f6_shipped_example.npz']
 
 
 def load(name):

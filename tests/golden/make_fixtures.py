@@ -80,12 +80,70 @@ def _install_pysam_standin():
         def __init__(self, contig, mapped):
             self.contig, self.mapped = contig, mapped
 
+    def decode_bam(path):
+        """Minimal BAM reader (BGZF = concatenated gzip members; record layout of the SAM/BAM spec)
+        for the reference's shipped example data."""
+        import gzip
+        import struct
+        data = gzip.open(path, 'rb').read()
+        assert data[:4] == b'BAM\x01'
+        off = 4
+        l_text, = struct.unpack_from('<i', data, off)
+        off += 4 + l_text
+        n_ref, = struct.unpack_from('<i', data, off)
+        off += 4
+        sq = []
+        for _ in range(n_ref):
+            l_name, = struct.unpack_from('<i', data, off)
+            name = data[off + 4:off + 4 + l_name - 1].decode()
+            l_ref, = struct.unpack_from('<i', data, off + 4 + l_name)
+            off += 8 + l_name
+            sq.append(dict(SN=name, LN=l_ref))
+        reads = []
+        tag_fmt = {'c': '<b', 'C': '<B', 's': '<h', 'S': '<H', 'i': '<i', 'I': '<I', 'f': '<f'}
+        while off < len(data):
+            size, = struct.unpack_from('<i', data, off)
+            rec = data[off + 4:off + 4 + size]
+            off += 4 + size
+            ref_id, pos, l_name, mapq, _bin, n_cigar, flag, l_seq, _nr, _np, tlen = struct.unpack_from('<iiBBHHHiiii', rec, 0)
+            p = 32
+            seg = AlignedSegment()
+            seg.query_name = rec[p:p + l_name - 1].decode()
+            p += l_name
+            seg.cigar = tuple((c & 0xF, c >> 4) for c in struct.unpack_from(f'<{n_cigar}I', rec, p))
+            p += 4 * n_cigar
+            packed = rec[p:p + (l_seq + 1) // 2]
+            p += (l_seq + 1) // 2
+            seg.query_sequence = ''.join('=ACMGRSVTWYHKDBN'[(packed[i >> 1] >> (4 if i % 2 == 0 else 0)) & 0xF] for i in range(l_seq))
+            seg.query_qualities = np.frombuffer(rec[p:p + l_seq], dtype=np.uint8).astype(np.int64)
+            p += l_seq
+            tags = []
+            while p < len(rec):
+                key, typ = rec[p:p + 2].decode(), chr(rec[p + 2])
+                p += 3
+                if typ == 'A':
+                    val = chr(rec[p]); p += 1
+                elif typ in tag_fmt:
+                    val, = struct.unpack_from(tag_fmt[typ], rec, p); p += struct.calcsize(tag_fmt[typ])
+                elif typ in 'ZH':
+                    end = rec.index(b'\x00', p)
+                    val = rec[p:end].decode(); p = end + 1
+                else:
+                    raise NotImplementedError(f'BAM tag type {typ}')
+                tags.append((key, val))
+            seg.tags = tuple(tags)
+            seg.flag, seg.reference_id, seg.reference_start, seg.mapping_quality, seg.template_length = flag, ref_id, pos, mapq, tlen
+            reads.append(seg)
+        return {'header': {'SQ': sq}, 'reads': reads}
+
     class AlignmentFile:
         def __init__(self, filename, mode='rb', header=None):
             self.filename = str(filename)
             self.mode = mode
             if 'w' in mode:
                 store[self.filename] = {'header': header, 'reads': []}
+            elif self.filename not in store:
+                store[self.filename] = decode_bam(self.filename)
             self._data = store[self.filename]
 
         def __enter__(self):
@@ -139,7 +197,35 @@ def _install_pysam_standin():
     mod.AlignedSegment = AlignedSegment
     mod.AlignedRead = AlignedSegment
     mod.AlignmentFile = AlignmentFile
-    mod.VariantFile = type('VariantFile', (), {})
+    class _VcfRecord:
+        def __init__(self, chrom, pos, alleles, samples):
+            self.chrom, self.pos, self.alleles, self.samples = chrom, pos, alleles, samples
+
+    class VariantFile:
+        """Text VCF -> the record surface the reference's add_vcf reads (genotypes.py:123-154):
+        .chrom, .pos (1-based), .alleles, .samples[name]['GT'] (allele indices, None when missing)."""
+
+        def __init__(self, path):
+            self.path = path
+
+        def fetch(self):
+            names = None
+            for line in open(self.path):
+                if line.startswith('##') or not line.strip():
+                    continue
+                f = line.rstrip('\n').split('\t')
+                if line.startswith('#'):
+                    names = f[9:]
+                    continue
+                alleles = tuple([f[3]] + ([] if f[4] == '.' else f[4].split(',')))
+                slot = f[8].split(':').index('GT')
+                samples = {}
+                for name, entry in zip(names, f[9:]):
+                    gt = entry.split(':')[slot].replace('|', '/').split('/')
+                    samples[name] = {'GT': tuple(None if t == '.' else int(t) for t in gt)}
+                yield _VcfRecord(f[0], int(f[1]), alleles, samples)
+
+    mod.VariantFile = VariantFile
     mod.sort = sort
     mod.index = index
     mod.qualitystring_to_array = qualitystring_to_array
@@ -454,9 +540,36 @@ def synthetic_generator_case():
     save('f5_generator_2k_5k_16.npz', out)
 
 
+def shipped_example_case():
+    """F6: the reference's CI example (examples/1-plain_demultiplexing.py on examples/example_data):
+    the reference's own add_vcf / BarcodeHandler.from_file / count_snps (through the stand-in pysam that
+    decodes the shipped BAM and VCF) and learn_genotypes(doublet_prior=0.25)."""
+    import shutil
+    ref, _ = import_reference()
+    data = f'{REFERENCE}/examples/example_data'
+    genotypes = ref.ProbabilisticGenotypes(genotype_names=['Donor01', 'Donor02', 'Donor03', 'Donor04'])
+    genotypes.add_vcf(f'{data}/test_genotypes.vcf')
+    handler = ref.BarcodeHandler.from_file(f'{data}/test_barcodes.csv')
+    calls = ref.count_snps(bamfile_location=f'{data}/test_bamfile.bam',
+                           chromosome2positions=genotypes.get_chromosome2positions(), barcode_handler=handler,
+                           joblib_n_jobs=1, joblib_verbosity=0)
+    arrays = capture(ref, calls, genotypes, handler, predict_dps=(0.35, 0.),
+                     em_runs=(dict(n_iterations=5, dp=0.25), dict(n_iterations=5, dp=0.)))
+    print('F6: V', genotypes.n_variants, 'B', handler.n_barcodes, 'M', int(arrays['pack_n_molecule_calls']),
+          'N', len(arrays['pack_bc_cb']))
+    save('f6_shipped_example.npz', arrays)
+    # the two small text inputs of the example are data files of the reference's CI run: kept as fixtures
+    # so that add_vcf / BarcodeHandler.from_file of this package can be checked against the captured genotypes
+    shutil.copy(f'{data}/test_genotypes.vcf', os.path.join(HERE, 'example_genotypes.vcf'))
+    shutil.copy(f'{data}/test_barcodes.csv', os.path.join(HERE, 'example_barcodes.csv'))
+
+
 if __name__ == '__main__':
-    if len(sys.argv) > 1 and sys.argv[1] == 'f5':
+    if len(sys.argv) > 1 and sys.argv[1] == 'f6':
+        shipped_example_case()
+    elif len(sys.argv) > 1 and sys.argv[1] == 'f5':
         synthetic_generator_case()
     else:
         main()
         synthetic_generator_case()
+        shipped_example_case()

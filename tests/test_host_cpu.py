@@ -149,6 +149,20 @@ def test_add_vcf_plain_text(tmp_path):
     assert {k: list(v) for k, v in g.get_chromosome2positions().items()} == {'chr1': [9, 19], 'chr2': [4, 6]}
 
 
+def test_shipped_example_inputs_match_reference_import():
+    """The reference's CI example data: add_vcf (own text parser) and BarcodeHandler.from_file of this
+    package against the genotypes / barcode order the reference produced from the same two files (F6)."""
+    from demuxalot_amd import BarcodeHandler, ProbabilisticGenotypes
+    fx = fio.load('f6_shipped_example.npz')
+    g = ProbabilisticGenotypes(genotype_names=['Donor01', 'Donor02', 'Donor03', 'Donor04'])
+    g.add_vcf(os.path.join(fio.GOLDEN, 'example_genotypes.vcf'))
+    want_keys = [(str(c), int(p), 'ACGTN'[int(b)]) for c, p, b in zip(fx['var_chrom'], fx['var_pos'], fx['var_base'])]
+    assert list(g.var2varid) == want_keys and list(g.var2varid.values()) == list(fx['var_row'])
+    fio.assert_bitwise(np.array(g.get_betas()), fx['betas'], 'betas imported from the VCF')
+    handler = BarcodeHandler.from_file(os.path.join(fio.GOLDEN, 'example_barcodes.csv'))
+    assert handler.ordered_barcodes == [str(b) for b in fx['barcodes']]
+
+
 def test_barcode_handler_and_container():
     from demuxalot_amd import BarcodeHandler, CompressedSNPCalls
     h = BarcodeHandler(['T-1', 'A-1', 'G-1'])
