@@ -11,7 +11,7 @@ from ctypes import POINTER, c_char_p, c_double, c_float, c_int, c_int32, c_int64
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, 'libdemux_hip.so')
+LIB_PATH = os.environ.get('DEMUXALOT_AMD_LIB') or os.path.join(_HERE, 'libdemux_hip.so')
 
 DMX_F32, DMX_F64 = 0, 1
 T_PSTEP, T_ESTEP, T_MSTEP, T_MCOMBINE, T_ALLREDUCE, T_COUNT = 0, 1, 2, 3, 4, 5

@@ -99,12 +99,19 @@ __device__ __forceinline__ f32x2 log_f32_hot2(f32x2 v)
     const float LN2 = 0.693147180559945309417232121458176568f;
     const int SPLIT = 0x3f3504f4;  // bits of the float32 just above 1/sqrt(2) (0x3f3504f3)
 
-    const int ia = __float_as_int(v.x) - SPLIT, ib = __float_as_int(v.y) - SPLIT;
+    // x = m' * 2^k: k = floor((bits - SPLIT) / 2^23); m' = bits - k * 2^23 (one v_mad_i32_i24: |k| < 2^8)
+    const int xa = __float_as_int(v.x), xb = __float_as_int(v.y);
+    const int ka = (xa - SPLIT) >> 23, kb = (xb - SPLIT) >> 23;
     f32x2 k, m;
-    k.x = (float)(ia >> 23);
-    k.y = (float)(ib >> 23);
-    m.x = __int_as_float((ia & 0x007fffff) + SPLIT);
-    m.y = __int_as_float((ib & 0x007fffff) + SPLIT);
+    k.x = (float)ka;
+    k.y = (float)kb;
+    // (inline asm: the compiler otherwise rewrites the expression back into and + add)
+    const int neg_2p23 = -8388608;
+    int ma, mb;
+    asm("v_mad_i32_i24 %0, %1, %2, %3" : "=v"(ma) : "v"(ka), "s"(neg_2p23), "v"(xa));
+    asm("v_mad_i32_i24 %0, %1, %2, %3" : "=v"(mb) : "v"(kb), "s"(neg_2p23), "v"(xb));
+    m.x = __int_as_float(ma);
+    m.y = __int_as_float(mb);
     const f32x2 r = m - 1.0f;
     f32x2 num = pk_fma((f32x2)(P5), r, (f32x2)(P4));
     f32x2 den = pk_fma((f32x2)(Q5), r, (f32x2)(Q4));
@@ -120,8 +127,13 @@ __device__ __forceinline__ f32x2 log_f32_hot2(f32x2 v)
     rc.x = __builtin_amdgcn_rcpf(den.x);
     rc.y = __builtin_amdgcn_rcpf(den.y);
     const f32x2 nden = -den;
+#if defined(DMX_DIV_REFINE)
     const f32x2 e0 = pk_fma(nden, rc, (f32x2)(1.0f));
     rc = pk_fma(e0, rc, rc);
+#endif
+    // quotient estimate, exact remainder, one correction.  With the 1-ulp hardware reciprocal the
+    // corrected quotient equals the IEEE quotient for every (num, den) that the 2^24 reduced
+    // arguments can produce -- checked exhaustively on the device (test_device_log_hot_path_exhaustive)
     const f32x2 q0 = num * rc;
     const f32x2 rem = pk_fma(nden, q0, num);
     const f32x2 q = pk_fma(rem, rc, q0);
