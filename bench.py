@@ -181,8 +181,9 @@ def main():
         m_ms = timers['mstep']['ms'] / max(1, timers['mstep']['launches'])
         achieved = ab['estep'] / (e_ms * 1e-3) / 1e9
         out = {
-            'metric': 'barcodes/s through one EM iteration (P-step + E-step + softmax + M-step) of learn_genotypes, '
-                      f'{B // 1000}k barcodes x {S // 1000}k SNPs x {G} genotypes per GPU',
+            'metric': f'EM iterations/sec + barcodes demuxed/sec, {B // 1000}k bc x {S // 1000}k SNP x {G} gt per GPU: '
+                      'value = barcodes/s through full learn_genotypes EM iterations (P-step + E-step + softmax + '
+                      'M-step [+ all-reduce]) = barcodes x em_iterations_per_s; predict-only rate in predict_barcodes_per_s',
             'value': world * B * args.steps / elapsed,
             'unit': 'barcodes/s',
             'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,

@@ -474,13 +474,22 @@ template <int A, int U, bool SQUARE>
 static __device__ __forceinline__ void mstep_terms(const float (&p)[U][A], const float (&keep)[U], float power,
                                                    double (&acc)[A])
 {
+    static_assert(U % 2 == 0, "calls are processed in pairs");
 #pragma unroll
-    for (int u = 0; u < U; u++) {
+    for (int u = 0; u < U; u += 2) {
+        const npm::f32x2 keep2 = {keep[u], keep[u + 1]};
 #pragma unroll
         for (int s = 0; s < A; s++) {
-            float c = p[u][s] * keep[u];
-            c = SQUARE ? c * c : powf(c, power);
-            acc[s] += (double)c;
+            const npm::f32x2 p2 = {p[u][s], p[u + 1][s]};
+            npm::f32x2 c = p2 * keep2;  // v_pk_mul_f32: calls u and u+1
+            if (SQUARE) {
+                c = c * c;
+            } else {
+                c.x = powf(c.x, power);
+                c.y = powf(c.y, power);
+            }
+            acc[s] += (double)c.x;  // call order preserved
+            acc[s] += (double)c.y;
         }
     }
 }
