@@ -203,10 +203,10 @@ def main():
                          'iteration_frac': ab['iteration'] / (1e-3 * (e_ms + m_ms + timers['pstep']['ms'] / max(1, timers['pstep']['launches']) + timers['mcombine']['ms'] / max(1, timers['mcombine']['launches']))) / 1e9 / 8000.0,
                          'log_terms_per_s': N * K / (e_ms * 1e-3),
                          'delivered_gather_GBps': (N * 4 * G) / (e_ms * 1e-3) / 1e9,
-                         # VALU-issue view (what actually binds the kernel): 17.8 VALU instructions per 64-lane
+                         # VALU-issue view (what actually binds the kernel): 16.0 VALU instructions per 64-lane
                          # term row (ISA count, confirmed by SQ_INSTS_VALU in profiles/), ~4 issue cycles each,
                          # 1024 SIMDs at the 2.4 GHz peak clock
-                         'valu_issue_frac': (N * max(1, (K + 63) // 64) * 17.8 * 4) / (1024 * 2.4e9 * e_ms * 1e-3) if K <= 256 else None,
+                         'valu_issue_frac': (N * max(1, (K + 63) // 64) * 16.0 * 4) / (1024 * 2.4e9 * e_ms * 1e-3) if K <= 256 else None,
                          'note': 'the E-step is bound by VALU issue of N*K numpy-exact float32 log terms and by the '
                                  'indexed row gather from L2/Infinity Cache (N*4G delivered bytes), not by HBM: see DESIGN.md 4'},
             'setup_s': {'generate': t_gen, 'upload': t_up},

@@ -9,8 +9,9 @@
 //
 // "In input order" is what makes the float64 sums of the kernels run in np.bincount's order, so the
 // two re-orderings are STABLE sorts (rocPRIM LSD radix sort of (key, input index) pairs; the one-time
-// repack uses the library primitive, the per-iteration kernels are hand-written).  Counting is done
-// with integer atomics (exact, order-free).  Everything stays on the ctx stream.
+// repack uses the library primitive, the per-iteration kernels are hand-written).  Row / column
+// offsets are read off the sorted keys by binary search (no atomic counters).  Everything stays on
+// the ctx stream.
 #include <cstring>
 
 #include <hip/hip_runtime.h>
@@ -21,37 +22,54 @@
 namespace dmx {
 namespace {
 
-__global__ __launch_bounds__(256) void k_count(const int *__restrict__ variant, const int *__restrict__ cb, long long N,
-                                               long long B, long long V, unsigned *__restrict__ row_cnt,
-                                               unsigned *__restrict__ col_cnt, int *__restrict__ bad)
+// range check without atomics in the good case: a wave only touches memory when it saw a bad index
+__global__ __launch_bounds__(256) void k_validate(const int *__restrict__ variant, const int *__restrict__ cb, long long N,
+                                                  long long B, long long V, int *__restrict__ bad)
 {
     const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= N) return;
-    const int b = cb[i], v = variant[i];
-    if (b < 0 || b >= B) {
+    const bool in = i < N;
+    const bool bad_b = in && ((unsigned)cb[in ? i : 0] >= (unsigned long long)B);
+    const bool bad_v = in && ((unsigned)variant[in ? i : 0] >= (unsigned long long)V);
+    if (__ballot(bad_b || bad_v) == 0ull) return;
+    if (bad_b) {
         atomicMax(&bad[0], 1);
         atomicMin(&bad[2], (int)(i < 0x7fffffff ? i : 0x7fffffff));
-        return;
-    }
-    if (v < 0 || v >= V) {
+    } else if (bad_v) {
         atomicMax(&bad[1], 1);
         atomicMin(&bad[2], (int)(i < 0x7fffffff ? i : 0x7fffffff));
-        return;
     }
-    atomicAdd(&row_cnt[b], 1u);
-    atomicAdd(&col_cnt[v], 1u);
 }
 
-// per-row padded pair counts, per-variant item counts, 64-bit copies of the raw counts
-__global__ __launch_bounds__(256) void k_derive_counts(const unsigned *__restrict__ cnt, long long n, int mode,
-                                                       long long *__restrict__ raw, long long *__restrict__ derived)
+// start[k] = first position of key k in the sorted key array (lower bound), k = 0..n_keys (start[n_keys] = N):
+// row / column offsets from the sorted order, no atomic counters
+__global__ __launch_bounds__(256) void k_boundaries(const unsigned *__restrict__ sorted_keys, long long N, long long n_keys,
+                                                    long long *__restrict__ start)
+{
+    const long long k = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (k > n_keys) return;
+    long long lo = 0, hi = N;
+    while (lo < hi) {
+        const long long mid = (lo + hi) >> 1;
+        if ((long long)sorted_keys[mid] < k) lo = mid + 1; else hi = mid;
+    }
+    start[k] = lo;
+}
+
+// from offsets: per-row padded pair counts (mode 0) or per-variant item counts (mode 1), and ~count
+// (ascending sort of ~count = longest first) with the ids for the work lists
+__global__ __launch_bounds__(256) void k_derive_counts(const long long *__restrict__ start, long long n, int mode,
+                                                       long long *__restrict__ derived, unsigned *__restrict__ inv,
+                                                       unsigned *__restrict__ ids)
 {
     const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
-    const long long c = cnt[i];
-    raw[i] = c;
-    derived[i] = mode == 0 ? ((c + 7) / 8) * 4            // CallPairs of a barcode row padded to 8 calls
+    const long long c = start[i + 1] - start[i];
+    derived[i] = mode == 0 ? ((c + 7) / 8) * 4                  // CallPairs of a barcode row padded to 8 calls
                            : (c + ITEM_CALLS - 1) / ITEM_CALLS;  // work items of a variant
+    if (inv) {
+        inv[i] = ~(unsigned)c;
+        ids[i] = (unsigned)i;
+    }
 }
 
 __global__ __launch_bounds__(256) void k_iota(unsigned *__restrict__ out, long long n)
@@ -121,15 +139,6 @@ __global__ __launch_bounds__(256) void k_build_items(const long long *__restrict
     }
 }
 
-__global__ __launch_bounds__(256) void k_inv_counts(const unsigned *__restrict__ cnt, long long n,
-                                                    unsigned *__restrict__ inv, unsigned *__restrict__ ids)
-{
-    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    inv[i] = ~cnt[i];
-    ids[i] = (unsigned)i;
-}
-
 inline unsigned grid_for(long long n) { return (unsigned)((n + 255) / 256); }
 
 inline unsigned bits_for(unsigned long long max_value)
@@ -192,17 +201,12 @@ static int repack_core(dmx_ctx *c, Scratch &sc, const int *d_variant, const int 
     const int G = c->G;
     hipStream_t st = c->stream;
 
-    // ---- counts (integer atomics) + range check ----
-    unsigned *row_cnt = nullptr, *col_cnt = nullptr;
+    // ---- range check ----
     int *bad = nullptr;
-    DMX_TRY(sc.get(&row_cnt, (size_t)B));
-    DMX_TRY(sc.get(&col_cnt, (size_t)V));
     DMX_TRY(sc.get(&bad, 3));
-    HIP_TRY(hipMemsetAsync(row_cnt, 0, sizeof(unsigned) * (B ? B : 1), st));
-    HIP_TRY(hipMemsetAsync(col_cnt, 0, sizeof(unsigned) * (V ? V : 1), st));
     const int bad_init[3] = {0, 0, 0x7fffffff};
     HIP_TRY(hipMemcpyAsync(bad, bad_init, sizeof bad_init, hipMemcpyHostToDevice, st));
-    if (N) hipLaunchKernelGGL(k_count, dim3(grid_for(N)), dim3(256), 0, st, d_variant, d_cb, N, B, V, row_cnt, col_cnt, bad);
+    if (N) hipLaunchKernelGGL(k_validate, dim3(grid_for(N)), dim3(256), 0, st, d_variant, d_cb, N, B, V, bad);
     int h_bad[3];
     HIP_TRY(hipMemcpyAsync(h_bad, bad, sizeof h_bad, hipMemcpyDeviceToHost, st));
     HIP_TRY(hipStreamSynchronize(st));
@@ -213,23 +217,37 @@ static int repack_core(dmx_ctx *c, Scratch &sc, const int *d_variant, const int 
                     value, h_bad[0] ? B : V);
     }
 
-    // ---- prefix sums: raw row / column starts, padded pair offsets, items per variant ----
-    long long *row_raw = nullptr, *row_pairs = nullptr, *col_raw = nullptr, *col_items = nullptr, *row_start = nullptr,
-              *col_ptr = nullptr;
-    DMX_TRY(sc.get(&row_raw, (size_t)B));
-    DMX_TRY(sc.get(&row_pairs, (size_t)B));
-    DMX_TRY(sc.get(&col_raw, (size_t)V));
-    DMX_TRY(sc.get(&col_items, (size_t)V));
+    // ---- stable sorts of (key, input index); offsets from the sorted keys ----
+    unsigned *iota = nullptr, *keys_b = nullptr, *perm_b = nullptr, *keys_v = nullptr, *perm_v = nullptr;
+    DMX_TRY(sc.get(&iota, (size_t)N));
+    DMX_TRY(sc.get(&keys_b, (size_t)N));
+    DMX_TRY(sc.get(&perm_b, (size_t)N));
+    DMX_TRY(sc.get(&keys_v, (size_t)N));
+    DMX_TRY(sc.get(&perm_v, (size_t)N));
+    if (N) hipLaunchKernelGGL(k_iota, dim3(grid_for(N)), dim3(256), 0, st, iota, N);
+    DMX_TRY(sort_pairs(sc, (const unsigned *)d_cb, keys_b, iota, perm_b, (size_t)N, bits_for(B ? B - 1 : 0), st));
+    DMX_TRY(sort_pairs(sc, (const unsigned *)d_variant, keys_v, iota, perm_v, (size_t)N, bits_for(V ? V - 1 : 0), st));
+    long long *row_start = nullptr, *col_ptr = nullptr, *row_pairs = nullptr, *col_items = nullptr;
     DMX_TRY(sc.get(&row_start, (size_t)B + 1));
     DMX_TRY(sc.get(&col_ptr, (size_t)V + 1));
-    if (B) hipLaunchKernelGGL(k_derive_counts, dim3(grid_for(B)), dim3(256), 0, st, row_cnt, B, 0, row_raw, row_pairs);
-    if (V) hipLaunchKernelGGL(k_derive_counts, dim3(grid_for(V)), dim3(256), 0, st, col_cnt, V, 1, col_raw, col_items);
+    DMX_TRY(sc.get(&row_pairs, (size_t)B));
+    DMX_TRY(sc.get(&col_items, (size_t)V));
+    hipLaunchKernelGGL(k_boundaries, dim3(grid_for(B + 1)), dim3(256), 0, st, keys_b, N, B, row_start);
+    hipLaunchKernelGGL(k_boundaries, dim3(grid_for(V + 1)), dim3(256), 0, st, keys_v, N, V, col_ptr);
+    unsigned *inv = nullptr, *ids = nullptr, *inv_sorted = nullptr;
+    DMX_TRY(sc.get(&inv, (size_t)B));
+    DMX_TRY(sc.get(&ids, (size_t)B));
+    DMX_TRY(sc.get(&inv_sorted, (size_t)B));
+    if (B) hipLaunchKernelGGL(k_derive_counts, dim3(grid_for(B)), dim3(256), 0, st, row_start, B, 0, row_pairs, inv, ids);
+    if (V)
+        hipLaunchKernelGGL(k_derive_counts, dim3(grid_for(V)), dim3(256), 0, st, col_ptr, V, 1, col_items, (unsigned *)nullptr,
+                           (unsigned *)nullptr);
     DMX_TRY(dev_alloc(c, &c->d_pair_ptr, (size_t)B + 1));
     DMX_TRY(dev_alloc(c, &c->d_item_ptr, (size_t)V + 1));
-    DMX_TRY(scan_with_total(sc, row_raw, row_start, (size_t)B, st));
+    DMX_TRY(dev_alloc(c, &c->d_bc_order, (size_t)B));
     DMX_TRY(scan_with_total(sc, row_pairs, c->d_pair_ptr, (size_t)B, st));
-    DMX_TRY(scan_with_total(sc, col_raw, col_ptr, (size_t)V, st));
     DMX_TRY(scan_with_total(sc, col_items, c->d_item_ptr, (size_t)V, st));
+    DMX_TRY(sort_pairs(sc, inv, inv_sorted, ids, (unsigned *)c->d_bc_order, (size_t)B, 32, st));  // longest rows first
     long long n_pairs = 0, n_items = 0;
     HIP_TRY(hipMemcpyAsync(&n_pairs, c->d_pair_ptr + B, sizeof(long long), hipMemcpyDeviceToHost, st));
     HIP_TRY(hipMemcpyAsync(&n_items, c->d_item_ptr + V, sizeof(long long), hipMemcpyDeviceToHost, st));
@@ -238,43 +256,28 @@ static int repack_core(dmx_ctx *c, Scratch &sc, const int *d_variant, const int 
     c->n_pairs = n_pairs;
     c->n_items = n_items;
 
-    // ---- stable sorts of (key, input index) ----
-    unsigned *iota = nullptr, *keys_sorted = nullptr, *perm = nullptr;
-    DMX_TRY(sc.get(&iota, (size_t)N));
-    DMX_TRY(sc.get(&keys_sorted, (size_t)N));
-    DMX_TRY(sc.get(&perm, (size_t)N));
-    if (N) hipLaunchKernelGGL(k_iota, dim3(grid_for(N)), dim3(256), 0, st, iota, N);
-
     // barcode-major -> E-step records
     DMX_TRY(dev_alloc(c, &c->d_call_pairs, (size_t)n_pairs));
     if (n_pairs) hipLaunchKernelGGL(k_fill_neutral, dim3(grid_for(n_pairs)), dim3(256), 0, st, c->d_call_pairs, n_pairs);
-    DMX_TRY(sort_pairs(sc, (const unsigned *)d_cb, keys_sorted, iota, perm, (size_t)N, bits_for(B ? B - 1 : 0), st));
     if (N)
-        hipLaunchKernelGGL(k_build_pairs, dim3(grid_for(N)), dim3(256), 0, st, keys_sorted, perm, d_variant, d_p, row_start,
+        hipLaunchKernelGGL(k_build_pairs, dim3(grid_for(N)), dim3(256), 0, st, keys_b, perm_b, d_variant, d_p, row_start,
                            c->d_pair_ptr, N, (unsigned)G, c->d_call_pairs);
-
     // variant-major -> M-step records
     DMX_TRY(dev_alloc(c, &c->d_csc, (size_t)N));
-    DMX_TRY(sort_pairs(sc, (const unsigned *)d_variant, keys_sorted, iota, perm, (size_t)N, bits_for(V ? V - 1 : 0), st));
-    if (N) hipLaunchKernelGGL(k_build_csc, dim3(grid_for(N)), dim3(256), 0, st, perm, d_cb, d_p, N, c->d_csc);
+    if (N) hipLaunchKernelGGL(k_build_csc, dim3(grid_for(N)), dim3(256), 0, st, perm_v, d_cb, d_p, N, c->d_csc);
 
-    // ---- work items and length-sorted work lists ----
+    // ---- work items and their length-sorted list ----
     DMX_TRY(dev_alloc(c, &c->d_item_start, (size_t)n_items));
     DMX_TRY(dev_alloc(c, &c->d_item_len, (size_t)n_items));
     DMX_TRY(dev_alloc(c, &c->d_item_order, (size_t)n_items));
-    DMX_TRY(dev_alloc(c, &c->d_bc_order, (size_t)B));
-    unsigned *inv = nullptr, *ids = nullptr, *inv_sorted = nullptr;
-    const size_t m = (size_t)(n_items > B ? n_items : B);
-    DMX_TRY(sc.get(&inv, m));
-    DMX_TRY(sc.get(&ids, m));
-    DMX_TRY(sc.get(&inv_sorted, m));
+    unsigned *inv_i = nullptr, *ids_i = nullptr, *inv_i_sorted = nullptr;
+    DMX_TRY(sc.get(&inv_i, (size_t)n_items));
+    DMX_TRY(sc.get(&ids_i, (size_t)n_items));
+    DMX_TRY(sc.get(&inv_i_sorted, (size_t)n_items));
     if (V)
         hipLaunchKernelGGL(k_build_items, dim3(grid_for(V)), dim3(256), 0, st, col_ptr, c->d_item_ptr, V, c->d_item_start,
-                           c->d_item_len, inv, ids);
-    // ~len has its variable bits only in the low bits_for(ITEM_CALLS) positions; the high bits are all ones
-    DMX_TRY(sort_pairs(sc, inv, inv_sorted, ids, (unsigned *)c->d_item_order, (size_t)n_items, 32, st));
-    if (B) hipLaunchKernelGGL(k_inv_counts, dim3(grid_for(B)), dim3(256), 0, st, row_cnt, B, inv, ids);
-    DMX_TRY(sort_pairs(sc, inv, inv_sorted, ids, (unsigned *)c->d_bc_order, (size_t)B, 32, st));
+                           c->d_item_len, inv_i, ids_i);
+    DMX_TRY(sort_pairs(sc, inv_i, inv_i_sorted, ids_i, (unsigned *)c->d_item_order, (size_t)n_items, 32, st));
 
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipStreamSynchronize(st));  // scratch is released by the caller's Scratch
