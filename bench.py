@@ -103,6 +103,12 @@ def main():
                     help='testing aid: run the multi-rank control/collective path even with one rank')
     args = ap.parse_args()
 
+    # gloo and RCCL print banners on stdout; stdout must carry the one JSON line only, so fd 1 is pointed
+    # at stderr for the whole run and the line is written to the saved descriptor at the end
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
+
     rank = int(os.environ.get('RANK', '0'))
     world = int(os.environ.get('WORLD_SIZE', '1'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
@@ -223,7 +229,8 @@ def main():
             }
         else:
             out['cpu_baseline'] = None
-        print(json.dumps(out))
+        sys.stdout.flush()
+        os.write(json_fd, (json.dumps(out) + '\n').encode())
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
