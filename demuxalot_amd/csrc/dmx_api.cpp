@@ -128,6 +128,7 @@ void release_problem(dmx_ctx *c)
     dev_free(c, &c->d_item_ptr, (size_t)c->V + 1);
     dev_free(c, &c->d_bc_order, (size_t)c->B);
     dev_free(c, &c->d_item_order, (size_t)c->n_items);
+    dev_free(c, &c->d_item_order_chunked, (size_t)c->n_items);
     dev_free(c, &c->d_v2snp, (size_t)c->V);
     dev_free(c, &c->d_snp_ptr, (size_t)c->S + 1);
     dev_free(c, &c->d_snp_vars, (size_t)c->V);
@@ -278,34 +279,50 @@ int run_mstep(dmx_ctx *c, float power)
     a.square = (power == 2.0f);
     a.power = power;
     std::pair<hipEvent_t, hipEvent_t> ev;
-    timer_begin(c, DMX_T_MSTEP, &ev);
-    HIP_TRY(dmx::launch_mstep(c->stream, a));
-    timer_end(c, DMX_T_MSTEP, ev);
-
-    const long long vg = c->V * c->G;
     const bool dist = c->comm != nullptr;  // also with one rank: keeps the collective path testable on one GPU
-    timer_begin(c, DMX_T_MCOMBINE, &ev);
     if (!dist) {
-        HIP_TRY(dmx::launch_mcombine(c->stream, c->d_partial, c->d_item_ptr, c->V, c->G, c->d_add, nullptr));
-    } else if (c->reduce_dtype == DMX_F64) {
-        HIP_TRY(dmx::launch_mcombine(c->stream, c->d_partial, c->d_item_ptr, c->V, c->G, nullptr, c->d_add64));
-    } else {
-        HIP_TRY(dmx::launch_mcombine(c->stream, c->d_partial, c->d_item_ptr, c->V, c->G, c->d_add, nullptr));
+        timer_begin(c, DMX_T_MSTEP, &ev);
+        HIP_TRY(dmx::launch_mstep(c->stream, a));
+        timer_end(c, DMX_T_MSTEP, ev);
+        timer_begin(c, DMX_T_MCOMBINE, &ev);
+        HIP_TRY(dmx::launch_mcombine(c->stream, c->d_partial, c->d_item_ptr, 0, c->V, c->G, c->d_add, nullptr));
+        timer_end(c, DMX_T_MCOMBINE, ev);
+        return 0;
     }
-    timer_end(c, DMX_T_MCOMBINE, ev);
-    if (dist) {
-        timer_begin(c, DMX_T_ALLREDUCE, &ev);
-        ncclResult_t r;
-        if (c->reduce_dtype == DMX_F64) {
-            r = g_rccl.AllReduce(c->d_add64, c->d_add64, (size_t)vg, ncclDouble, ncclSum, c->comm, c->stream);
-            if (r == ncclSuccess) HIP_TRY(dmx::launch_f64_to_f32(c->stream, c->d_add64, c->d_add, vg));
+    // Multi-GPU: variants are cut into M_CHUNKS ranges with equal numbers of calls.  The M-step and the
+    // combine of range i+1 run on the compute stream while RCCL all-reduces range i on the comm stream,
+    // so only the last range's exchange is exposed.  Every variant belongs to exactly one range: the
+    // arithmetic is the same as in the single launch.
+    const bool f64 = c->reduce_dtype == DMX_F64;
+    ncclResult_t r = ncclSuccess;
+    timer_begin(c, DMX_T_MSTEP, &ev);
+    for (int k = 0; k < dmx::M_CHUNKS; k++) {
+        const long long v0 = c->chunk_v[k], v1 = c->chunk_v[k + 1];
+        a.order = c->d_item_order_chunked + c->chunk_item[k];
+        a.n_items = c->chunk_item[k + 1] - c->chunk_item[k];
+        HIP_TRY(dmx::launch_mstep(c->stream, a));
+        HIP_TRY(dmx::launch_mcombine(c->stream, c->d_partial, c->d_item_ptr, v0, v1, c->G, f64 ? nullptr : c->d_add,
+                                     f64 ? c->d_add64 : nullptr));
+        HIP_TRY(hipEventRecord(c->ev_chunk[k], c->stream));
+        HIP_TRY(hipStreamWaitEvent(c->comm_stream, c->ev_chunk[k], 0));
+        const size_t off = (size_t)v0 * c->G, cnt = (size_t)(v1 - v0) * c->G;
+        if (cnt == 0) continue;
+        if (f64) {
+            r = g_rccl.AllReduce(c->d_add64 + off, c->d_add64 + off, cnt, ncclDouble, ncclSum, c->comm, c->comm_stream);
+            if (r == ncclSuccess) HIP_TRY(dmx::launch_f64_to_f32(c->comm_stream, c->d_add64 + off, c->d_add + off, (long long)cnt));
         } else {
-            r = g_rccl.AllReduce(c->d_add, c->d_add, (size_t)vg, ncclFloat, ncclSum, c->comm, c->stream);
+            r = g_rccl.AllReduce(c->d_add + off, c->d_add + off, cnt, ncclFloat, ncclSum, c->comm, c->comm_stream);
         }
-        timer_end(c, DMX_T_ALLREDUCE, ev);
-        if (r != ncclSuccess)
-            return fail(DMX_ERR_RCCL, "ncclAllReduce failed: %s", g_rccl.GetErrorString ? g_rccl.GetErrorString(r) : "?");
+        if (r != ncclSuccess) break;
     }
+    timer_end(c, DMX_T_MSTEP, ev);
+    if (r != ncclSuccess)
+        return fail(DMX_ERR_RCCL, "ncclAllReduce failed: %s", g_rccl.GetErrorString ? g_rccl.GetErrorString(r) : "?");
+    // exposed part of the exchange: the compute stream waits for the last range
+    timer_begin(c, DMX_T_ALLREDUCE, &ev);
+    HIP_TRY(hipEventRecord(c->ev_comm, c->comm_stream));
+    HIP_TRY(hipStreamWaitEvent(c->stream, c->ev_comm, 0));
+    timer_end(c, DMX_T_ALLREDUCE, ev);
     return 0;
 }
 
@@ -372,7 +389,13 @@ int dmx_destroy(dmx_ctx *c)
     if (!c) return 0;
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
+    if (c->comm_stream) (void)hipStreamSynchronize(c->comm_stream);
     if (c->comm && g_rccl.CommDestroy) g_rccl.CommDestroy(c->comm);
+    if (c->comm_stream) {
+        for (auto &e : c->ev_chunk) (void)hipEventDestroy(e);
+        (void)hipEventDestroy(c->ev_comm);
+        (void)hipStreamDestroy(c->comm_stream);
+    }
     release_problem(c);
     if (c->d_scratch) (void)hipFree(c->d_scratch);
     for (auto &t : c->timers) {
@@ -686,6 +709,11 @@ int dmx_comm_init(dmx_ctx *c, int rank, int nranks, const void *unique_id, int r
     if (r != ncclSuccess) {
         c->comm = nullptr;
         return fail(DMX_ERR_RCCL, "ncclCommInitRank failed: %s", g_rccl.GetErrorString ? g_rccl.GetErrorString(r) : "?");
+    }
+    if (!c->comm_stream) {
+        HIP_TRY(hipStreamCreateWithFlags(&c->comm_stream, hipStreamNonBlocking));
+        for (auto &e : c->ev_chunk) HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        HIP_TRY(hipEventCreateWithFlags(&c->ev_comm, hipEventDisableTiming));
     }
     c->rank = rank;
     c->nranks = nranks;

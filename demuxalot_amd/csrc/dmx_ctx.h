@@ -50,6 +50,9 @@ struct dmx_ctx {
     int *d_item_len = nullptr;
     long long *d_item_ptr = nullptr;
     int *d_bc_order = nullptr, *d_item_order = nullptr;
+    int *d_item_order_chunked = nullptr;  // items by (variant chunk, decreasing length): multi-GPU M-step
+    long long chunk_v[dmx::M_CHUNKS + 1] = {0};     // variant boundaries of the chunks
+    long long chunk_item[dmx::M_CHUNKS + 1] = {0};  // offsets of the chunks in d_item_order_chunked
     long long n_items = 0;
     int *d_v2snp = nullptr, *d_snp_ptr = nullptr, *d_snp_vars = nullptr;
     float *d_prior = nullptr, *d_add = nullptr, *d_prob = nullptr;
@@ -72,6 +75,9 @@ struct dmx_ctx {
     void *d_scratch = nullptr;  // self tests
     size_t cap_scratch = 0;
 
+    hipStream_t comm_stream = nullptr;  // all-reduce of chunk i runs here while chunk i+1 is computed
+    hipEvent_t ev_chunk[dmx::M_CHUNKS] = {nullptr};
+    hipEvent_t ev_comm = nullptr;
     ncclComm_t comm = nullptr;
     int rank = 0, nranks = 1, reduce_dtype = DMX_F64;
 

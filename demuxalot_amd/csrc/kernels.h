@@ -56,14 +56,16 @@ struct MstepArgs {
 };
 
 constexpr int ITEM_CALLS = 1024;  // longest run of one variant's calls handled by one wavefront
+constexpr int M_CHUNKS = 4;       // variant ranges (equal numbers of calls) whose all-reduce overlaps the next range's M-step
 
 hipError_t launch_probs_from_betas(hipStream_t st, const float *prior, const float *addition, const int *v2snp,
                                    const int *snp_ptr, const int *snp_vars, long long V, int G, float lo, float hi,
                                    float *prob);
 hipError_t launch_estep(hipStream_t st, const EstepArgs &a, bool pairs);
 hipError_t launch_mstep(hipStream_t st, const MstepArgs &a);
-hipError_t launch_mcombine(hipStream_t st, const double *partial, const long long *item_ptr, long long V, int G,
-                           float *add32, double *add64);
+// sums the item partials of variants [v0, v1)
+hipError_t launch_mcombine(hipStream_t st, const double *partial, const long long *item_ptr, long long v0, long long v1,
+                           int G, float *add32, double *add64);
 hipError_t launch_f64_to_f32(hipStream_t st, const double *in, float *out, long long n);
 hipError_t launch_f32_to_f64(hipStream_t st, const float *in, double *out, long long n);
 hipError_t launch_assign(hipStream_t st, const float *post, long long B, int K, int *best, float *best_p);

@@ -626,17 +626,18 @@ __global__ __launch_bounds__(256) void k_mstep(MstepArgs a)
 // sums the item partials of each variant in item order; writes float32 (single GPU) or the
 // float64 total that goes into the all-reduce
 __global__ __launch_bounds__(256) void k_mcombine(const double *__restrict__ partial,
-                                                  const long long *__restrict__ item_ptr, long long V, int G,
+                                                  const long long *__restrict__ item_ptr, long long v0, long long v1, int G,
                                                   float *__restrict__ add32, double *__restrict__ add64)
 {
     const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= V * G) return;
-    const long long v = i / G;
-    const int g = (int)(i - v * G);
+    if (i >= (v1 - v0) * G) return;
+    const long long v = v0 + i / G;
+    const int g = (int)(i % G);
     double s = 0.0;
     for (long long it = item_ptr[v]; it < item_ptr[v + 1]; it++) s += partial[(size_t)it * G + g];
-    if (add64) add64[i] = s;
-    if (add32) add32[i] = (float)s;
+    const long long o = v * G + g;
+    if (add64) add64[o] = s;
+    if (add32) add32[o] = (float)s;
 }
 
 __global__ __launch_bounds__(256) void k_f64_to_f32(const double *__restrict__ in, float *__restrict__ out, long long n)
@@ -830,11 +831,12 @@ hipError_t launch_mstep(hipStream_t st, const MstepArgs &a)
     return hipGetLastError();
 }
 
-hipError_t launch_mcombine(hipStream_t st, const double *partial, const long long *item_ptr, long long V, int G,
-                           float *add32, double *add64)
+hipError_t launch_mcombine(hipStream_t st, const double *partial, const long long *item_ptr, long long v0, long long v1,
+                           int G, float *add32, double *add64)
 {
-    if (V * G == 0) return hipSuccess;
-    hipLaunchKernelGGL(k_mcombine, dim3(blocks_for(V * G, 256)), dim3(256), 0, st, partial, item_ptr, V, G, add32, add64);
+    if ((v1 - v0) * G <= 0) return hipSuccess;
+    hipLaunchKernelGGL(k_mcombine, dim3(blocks_for((v1 - v0) * G, 256)), dim3(256), 0, st, partial, item_ptr, v0, v1, G,
+                       add32, add64);
     return hipGetLastError();
 }
 
