@@ -99,22 +99,47 @@ static __device__ __forceinline__ int pw_half(int n)
     return h - (h % 8);
 }
 
-// np.sum of K <= 256 register-resident elements
+// np.sum of K <= 1024 register-resident elements (one 8192-element numpy chunk): the pairwise split
+// tree walked iteratively, leaves (<= 128 elements) summed by reg_block_sum.  Uniform control flow.
 template <int A>
 static __device__ __forceinline__ float reg_row_sum(const float (&x)[A], int K, int lane, int gbase)
 {
     if (K <= 128) return reg_block_sum<A>(x, 0, K, lane, gbase);
-    const int h = pw_half(K);
-    const float left = reg_block_sum<A>(x, 0, h, lane, gbase);
-    const int rn = K - h;
-    float right;
-    if (rn <= 128) {
-        right = reg_block_sum<A>(x, h, rn, lane, gbase);
-    } else {
-        const int h2 = pw_half(rn);
-        right = reg_block_sum<A>(x, h, h2, lane, gbase) + reg_block_sum<A>(x, h + h2, rn - h2, lane, gbase);
+    // explicit post-order traversal; depth <= 4 for K <= 1024
+    int st_start[6], st_len[6], st_state[6];
+    float st_left[6];
+    int sp = 0;
+    st_start[0] = 0;
+    st_len[0] = K;
+    st_state[0] = 0;
+    float ret = 0.0f;
+    while (sp >= 0) {
+        const int s0 = st_start[sp], len = st_len[sp];
+        if (len <= 128) {
+            ret = reg_block_sum<A>(x, s0, len, lane, gbase);
+            sp--;
+            continue;
+        }
+        const int half = pw_half(len);
+        if (st_state[sp] == 0) {
+            st_state[sp] = 1;
+            sp++;
+            st_start[sp] = s0;
+            st_len[sp] = half;
+            st_state[sp] = 0;
+        } else if (st_state[sp] == 1) {
+            st_left[sp] = ret;
+            st_state[sp] = 2;
+            sp++;
+            st_start[sp] = s0 + half;
+            st_len[sp] = len - half;
+            st_state[sp] = 0;
+        } else {
+            ret = st_left[sp] + ret;
+            sp--;
+        }
     }
-    return left + right;
+    return ret;
 }
 
 // value of lane (group base + i) for every lane of the group; i is wave-uniform
@@ -149,27 +174,25 @@ static __device__ __forceinline__ int group_max_over_wave(int v)
 //            call through ds_bpermute.
 // Per call the group reads G*4 contiguous bytes of the prob table (global_load_dword, SGPR base).
 // ------------------------------------------------------------------------------------
-template <int A, bool PAIRS, int U>
-static __device__ __forceinline__ void estep_terms(const float (&p1)[U][A], const float (&p2)[U][A],
-                                                   const float (&keep)[U], const float (&flo)[U], double (&acc)[A])
+// Operands are kept PAIR-MAJOR: element [q][s] holds calls 2q (.x) and 2q+1 (.y) of option slot s in
+// one 64-bit register pair, i.e. exactly the packed operand - no register shuffling between the
+// gather and the packed instructions (with call-major arrays the compiler staged them through LDS).
+template <int A, bool PAIRS, int H>
+static __device__ __forceinline__ void estep_terms(const npm::f32x2 (&p1)[H][A], const npm::f32x2 (&p2)[H][A],
+                                                   const npm::f32x2 (&keep)[H], const npm::f32x2 (&flo)[H],
+                                                   double (&acc)[A], int n_slots)
 {
-    // two terms per packed instruction: calls u and u+1 of the same option
-    static_assert(U % 2 == 0, "calls are processed in pairs");
 #pragma unroll
-    for (int u = 0; u < U; u += 2) {
-        const npm::f32x2 keep2 = {keep[u], keep[u + 1]};
-        const npm::f32x2 flo2 = {flo[u], flo[u + 1]};
+    for (int q = 0; q < H; q++) {
 #pragma unroll
         for (int s = 0; s < A; s++) {
-            npm::f32x2 p = {p1[u][s], p1[u + 1][s]};
-            if (PAIRS) {
-                const npm::f32x2 q = {p2[u][s], p2[u + 1][s]};
-                p = (p + q) * 0.5f;
-            }
-            npm::f32x2 t = p * keep2;
-            t = t + flo2;
+            if (A > 1 && s >= n_slots) continue;  // wave-uniform: slot entirely past the last option
+            npm::f32x2 p = p1[q][s];
+            if (PAIRS) p = (p + p2[q][s]) * 0.5f;
+            npm::f32x2 t = p * keep[q];
+            t = t + flo[q];
             const npm::f32x2 lp = npm::log_f32_hot2(t);
-            acc[s] += (double)lp.x;  // call order preserved: u before u+1
+            acc[s] += (double)lp.x;  // call order preserved: 2q before 2q+1
             acc[s] += (double)lp.y;
         }
     }
@@ -207,6 +230,7 @@ __global__ __launch_bounds__(256) void k_estep_direct(EstepArgs a)
 #pragma unroll
     for (int s = 0; s < A; s++) acc[s] = 0.0;
     const char *__restrict__ prob = (const char *)a.prob;
+    const int n_slots = (K + 63) >> 6;  // register slots that hold at least one option (A may be larger)
 
     long long b;
     bool live;
@@ -224,26 +248,26 @@ __global__ __launch_bounds__(256) void k_estep_direct(EstepArgs a)
         // soffset = the call's row offset straight from the scalar load -> no VALU work per load
         const __amdgpu_buffer_rsrc_t rsrc =
             __builtin_amdgcn_make_buffer_rsrc((void *)a.prob, 0, (int)a.prob_bytes, 0x00020000);
-        for (int j0 = 0; j0 < npairs; j0 += U / 2) {
-            float p1[U][A], p2[U][A], keep[U], flo[U];
+        constexpr int H = U / 2;
+        for (int j0 = 0; j0 < npairs; j0 += H) {
+            npm::f32x2 p1[H][A], p2[H][A], keep[H], flo[H];
 #pragma unroll
-            for (int q = 0; q < U / 2; q++) {
+            for (int q = 0; q < H; q++) {
                 const CallPair r = recs[j0 + q];
+                keep[q] = npm::f32x2{r.keep[0], r.keep[1]};
+                flo[q] = npm::f32x2{r.floor[0], r.floor[1]};
 #pragma unroll
-                for (int h = 0; h < 2; h++) {
-                    keep[2 * q + h] = r.keep[h];
-                    flo[2 * q + h] = r.floor[h];
-#pragma unroll
-                    for (int s = 0; s < A; s++) {
-                        p1[2 * q + h][s] = __builtin_bit_cast(
-                            float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, (int)o1[s], (int)r.row_off[h], 0));
-                        if (PAIRS)
-                            p2[2 * q + h][s] = __builtin_bit_cast(
-                                float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, (int)o2[s], (int)r.row_off[h], 0));
+                for (int s = 0; s < A; s++) {
+                    if (A > 1 && s >= n_slots) continue;
+                    p1[q][s].x = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, (int)o1[s], (int)r.row_off[0], 0));
+                    p1[q][s].y = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, (int)o1[s], (int)r.row_off[1], 0));
+                    if (PAIRS) {
+                        p2[q][s].x = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, (int)o2[s], (int)r.row_off[0], 0));
+                        p2[q][s].y = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, (int)o2[s], (int)r.row_off[1], 0));
                     }
                 }
             }
-            estep_terms<A, PAIRS, U>(p1, p2, keep, flo, acc);
+            estep_terms<A, PAIRS, H>(p1, p2, keep, flo, acc, n_slots);
         }
     } else {
         const long long slot = ((long long)blockIdx.x * 4 + (threadIdx.x >> 6)) * CPW + lane / L;
@@ -267,19 +291,27 @@ __global__ __launch_bounds__(256) void k_estep_direct(EstepArgs a)
             }
             const int cnt = (nmax - c0) < L ? (nmax - c0) : L;
             for (int i0 = 0; i0 < cnt; i0 += U) {
-                float p1[U][A], p2[U][A], keep[U], flo[U];
+                constexpr int H = U / 2;
+                npm::f32x2 p1[H][A], p2[H][A], keep[H], flo[H];
 #pragma unroll
-                for (int u = 0; u < U; u++) {
-                    const unsigned ro = group_bcast<L>(ro_v, i0 + u, gbase);
-                    keep[u] = group_bcast<L>(keep_v, i0 + u, gbase);
-                    flo[u] = group_bcast<L>(floor_v, i0 + u, gbase);
+                for (int q = 0; q < H; q++) {
+                    const unsigned ro0 = group_bcast<L>(ro_v, i0 + 2 * q, gbase);
+                    const unsigned ro1 = group_bcast<L>(ro_v, i0 + 2 * q + 1, gbase);
+                    keep[q].x = group_bcast<L>(keep_v, i0 + 2 * q, gbase);
+                    keep[q].y = group_bcast<L>(keep_v, i0 + 2 * q + 1, gbase);
+                    flo[q].x = group_bcast<L>(floor_v, i0 + 2 * q, gbase);
+                    flo[q].y = group_bcast<L>(floor_v, i0 + 2 * q + 1, gbase);
 #pragma unroll
                     for (int s = 0; s < A; s++) {
-                        p1[u][s] = *(const float *)(prob + (ro + o1[s]));
-                        if (PAIRS) p2[u][s] = *(const float *)(prob + (ro + o2[s]));
+                        p1[q][s].x = *(const float *)(prob + (ro0 + o1[s]));
+                        p1[q][s].y = *(const float *)(prob + (ro1 + o1[s]));
+                        if (PAIRS) {
+                            p2[q][s].x = *(const float *)(prob + (ro0 + o2[s]));
+                            p2[q][s].y = *(const float *)(prob + (ro1 + o2[s]));
+                        }
                     }
                 }
-                estep_terms<A, PAIRS, U>(p1, p2, keep, flo, acc);
+                estep_terms<A, PAIRS, H>(p1, p2, keep, flo, acc, n_slots);
             }
         }
     }
@@ -470,18 +502,16 @@ __global__ __launch_bounds__(256) void k_estep_block(EstepArgs a, int C)
 //            mask of the gather (inverse ballot), the row address is an SGPR soffset of a buffer load;
 //   L <  64: per-lane predicate.
 // ------------------------------------------------------------------------------------
-template <int A, int U, bool SQUARE>
-static __device__ __forceinline__ void mstep_terms(const float (&p)[U][A], const float (&keep)[U], float power,
+// pair-major operands, as in the E-step: [q][s] = calls 2q (.x) and 2q+1 (.y) of genotype slot s
+template <int A, int H, bool SQUARE>
+static __device__ __forceinline__ void mstep_terms(const npm::f32x2 (&p)[H][A], const npm::f32x2 (&keep)[H], float power,
                                                    double (&acc)[A])
 {
-    static_assert(U % 2 == 0, "calls are processed in pairs");
 #pragma unroll
-    for (int u = 0; u < U; u += 2) {
-        const npm::f32x2 keep2 = {keep[u], keep[u + 1]};
+    for (int q = 0; q < H; q++) {
 #pragma unroll
         for (int s = 0; s < A; s++) {
-            const npm::f32x2 p2 = {p[u][s], p[u + 1][s]};
-            npm::f32x2 c = p2 * keep2;  // v_pk_mul_f32: calls u and u+1
+            npm::f32x2 c = p[q][s] * keep[q];  // v_pk_mul_f32: calls 2q and 2q+1
             if (SQUARE) {
                 c = c * c;
             } else {
@@ -552,11 +582,13 @@ __global__ __launch_bounds__(256) void k_mstep(MstepArgs a)
             const float keep_v = __uint_as_float(d_cur.y);
             const int cnt = (n - c0) < 64 ? (n - c0) : 64;
             for (int i0 = 0; i0 < cnt; i0 += U) {
-                float p[U][A], keep[U];
+                constexpr int H = U / 2;
+                npm::f32x2 p[H][A], keep[H];
 #pragma unroll
                 for (int u = 0; u < U; u++) {
                     const unsigned cb = (unsigned)__builtin_amdgcn_readlane((int)d_cur.x, i0 + u);
-                    keep[u] = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, keep_v), i0 + u));
+                    const float kp = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, keep_v), i0 + u));
+                    if (u & 1) keep[u >> 1].y = kp; else keep[u >> 1].x = kp;
                     const unsigned long long row = (unsigned long long)cb * (unsigned long long)a.K * 4ull;
 #pragma unroll
                     for (int s = 0; s < A; s++) {
@@ -571,10 +603,10 @@ __global__ __launch_bounds__(256) void k_mstep(MstepArgs a)
                             else
                                 v = *(const float *)((const char *)a.post + row + voff[s]);
                         }
-                        p[u][s] = v;
+                        if (u & 1) p[u >> 1][s].y = v; else p[u >> 1][s].x = v;
                     }
                 }
-                mstep_terms<A, U, SQUARE>(p, keep, a.power, acc);
+                mstep_terms<A, H, SQUARE>(p, keep, a.power, acc);
             }
             d_cur = d_nxt;
             d_nxt = d_nn;
@@ -602,17 +634,24 @@ __global__ __launch_bounds__(256) void k_mstep(MstepArgs a)
             const unsigned lo_v = (unsigned)bits_v;
             const int cnt = (nmax - c0) < L ? (nmax - c0) : L;
             for (int i0 = 0; i0 < cnt; i0 += U) {
-                float p[U][A], keep[U];
+                constexpr int H = U / 2;
+                npm::f32x2 p[H][A], keep[H];
 #pragma unroll
                 for (int u = 0; u < U; u++) {
                     const unsigned cb = group_bcast<L>(d.x, i0 + u, gbase);
-                    keep[u] = group_bcast<L>(keep_v, i0 + u, gbase);
+                    const float kp = group_bcast<L>(keep_v, i0 + u, gbase);
                     const unsigned bits = group_bcast<L>(lo_v, i0 + u, gbase);
                     float v = 0.0f;
                     if ((bits >> li) & 1u) v = a.post[(size_t)cb * a.K + li];
-                    p[u][0] = v;
+                    if (u & 1) {
+                        keep[u >> 1].y = kp;
+                        p[u >> 1][0].y = v;
+                    } else {
+                        keep[u >> 1].x = kp;
+                        p[u >> 1][0].x = v;
+                    }
                 }
-                mstep_terms<A, U, SQUARE>(p, keep, a.power, acc);
+                mstep_terms<A, H, SQUARE>(p, keep, a.power, acc);
             }
         }
     }
@@ -785,7 +824,12 @@ hipError_t launch_estep(hipStream_t st, const EstepArgs &a, bool pairs)
         else launch_direct<64, 4, 2>(st, a, pairs);
         return hipGetLastError();
     }
-    if (!pairs) return hipErrorInvalidValue;  // K = G > 256 singlets: not supported (checked by the caller)
+    if (K <= 1024) {  // register-resident up to 16 options per lane; slots past K are skipped wave-uniformly
+        if (K <= 512) launch_direct<64, 8, 2>(st, a, pairs);
+        else launch_direct<64, 16, 2>(st, a, pairs);
+        return hipGetLastError();
+    }
+    if (!pairs) return hipErrorInvalidValue;  // K = G > 1024 singlets: not supported (checked by the caller)
     const int need = (K + 255) / 256;
     if (need <= 2) return launch_block<2>(st, a);
     if (need <= 3) return launch_block<3>(st, a);
@@ -827,6 +871,8 @@ hipError_t launch_mstep(hipStream_t st, const MstepArgs &a)
     else if (G <= 64) launch_m<64, 1, 8>(st, a);
     else if (G <= 128) launch_m<64, 2, 4>(st, a);
     else if (G <= 256) launch_m<64, 4, 2>(st, a);
+    else if (G <= 512) launch_m<64, 8, 2>(st, a);
+    else if (G <= 1024) launch_m<64, 16, 2>(st, a);
     else return hipErrorInvalidValue;
     return hipGetLastError();
 }
