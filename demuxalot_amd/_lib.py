@@ -34,6 +34,7 @@ SIGNATURES = {
                                          POINTER(c_int64), POINTER(c_int64), _P]),
     'dmx_get_packed_calls': (c_int, [_P, _P, _P, _P, _P]),
     'dmx_set_betas': (c_int, [_P, _P]),
+    'dmx_set_prior_betas': (c_int, [_P, _P, c_double, c_int, _P, _P]),
     'dmx_set_addition': (c_int, [_P, _P]),
     'dmx_probs_from_betas': (c_int, [_P, c_float, c_float, _P]),
     'dmx_set_probs': (c_int, [_P, _P]),

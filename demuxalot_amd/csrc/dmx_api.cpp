@@ -158,6 +158,7 @@ void release_problem(dmx_ctx *c)
     dev_free(c, &c->d_u_p, (size_t)c->n_u);
     dev_free(c, &c->d_u_count, (size_t)c->n_u);
     c->n_u = 0;
+    dev_free(c, &c->d_mol, (size_t)c->V);
     c->have_problem = c->have_betas = c->have_probs = c->have_post = false;
     c->B = c->V = c->N = c->S = 0;
     c->G = c->K = 0;
@@ -540,6 +541,62 @@ int dmx_set_betas(dmx_ctx *c, const float *prior)
     HIP_TRY(hipStreamSynchronize(c->stream));
     c->have_betas = true;
     return 0;
+}
+
+int dmx_set_prior_betas(dmx_ctx *c, const float *raw_betas, double default_prior, int add_data_prior,
+                        const int64_t *mol_per_variant, float *prior_out)
+{
+    DMX_TRY(bind(c));
+    DMX_TRY(need(c, c->have_problem, "a resident problem before dmx_set_prior_betas"));
+    const long long V = c->V;
+    const int G = c->G;
+    if (V > 0 && !raw_betas) return fail(DMX_ERR_INVALID, "null betas");
+    const size_t vg = (size_t)V * G;
+    float *d_raw = nullptr, *d_bsum = nullptr;
+    HIP_TRY(hipMalloc((void **)&d_raw, (vg ? vg : 1) * sizeof(float)));
+    hipError_t e = hipMalloc((void **)&d_bsum, (size_t)(V ? V : 1) * sizeof(float));
+    if (e != hipSuccess) {
+        (void)hipFree(d_raw);
+        return fail(DMX_ERR_HIP, "hipMalloc: %s", hipGetErrorString(e));
+    }
+    int rc = 0;
+    do {
+        if (vg && hipMemcpyAsync(d_raw, raw_betas, vg * sizeof(float), hipMemcpyHostToDevice, c->stream) != hipSuccess) {
+            rc = fail(DMX_ERR_HIP, "upload of the raw betas failed");
+            break;
+        }
+        const unsigned long long *n_mol = nullptr;
+        if (add_data_prior) {
+            if (mol_per_variant) {  // counts supplied by the caller (problem installed with dmx_set_problem)
+                dev_free(c, &c->d_mol, (size_t)V);
+                if ((rc = dev_alloc(c, &c->d_mol, (size_t)V)) != 0) break;
+                if (V && hipMemcpyAsync(c->d_mol, mol_per_variant, sizeof(long long) * V, hipMemcpyHostToDevice, c->stream) != hipSuccess) {
+                    rc = fail(DMX_ERR_HIP, "upload of the molecule counts failed");
+                    break;
+                }
+            } else if (!c->d_mol) {
+                rc = fail(DMX_ERR_INVALID, "add_data_prior needs molecule counts: pass them or install the problem with dmx_pack_and_set_problem");
+                break;
+            }
+            n_mol = c->d_mol;
+        }
+        e = dmx::launch_prior_betas(c->stream, d_raw, d_bsum, n_mol, c->d_v2snp, c->d_snp_ptr, c->d_snp_vars, V, G,
+                                    default_prior, c->d_prior);
+        if (e != hipSuccess) {
+            rc = fail(DMX_ERR_HIP, "prior betas kernel: %s", hipGetErrorString(e));
+            break;
+        }
+        if (prior_out && vg && hipMemcpyAsync(prior_out, c->d_prior, vg * sizeof(float), hipMemcpyDeviceToHost, c->stream) != hipSuccess) {
+            rc = fail(DMX_ERR_HIP, "download of the prior betas failed");
+            break;
+        }
+        if (hipStreamSynchronize(c->stream) != hipSuccess) rc = fail(DMX_ERR_HIP, "synchronisation failed");
+    } while (false);
+    (void)hipStreamSynchronize(c->stream);
+    (void)hipFree(d_raw);
+    (void)hipFree(d_bsum);
+    if (rc == 0) c->have_betas = true;
+    return rc;
 }
 
 int dmx_set_addition(dmx_ctx *c, const float *addition)

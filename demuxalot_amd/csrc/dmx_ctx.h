@@ -72,6 +72,7 @@ struct dmx_ctx {
     float *d_u_p = nullptr;
     long long *d_u_count = nullptr;
     long long n_u = 0;
+    unsigned long long *d_mol = nullptr;  // matched molecule calls per variant (device pack), for the data prior
     void *d_scratch = nullptr;  // self tests
     size_t cap_scratch = 0;
 

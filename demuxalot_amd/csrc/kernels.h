@@ -68,6 +68,9 @@ hipError_t launch_mcombine(hipStream_t st, const double *partial, const long lon
                            int G, float *add32, double *add64);
 hipError_t launch_f64_to_f32(hipStream_t st, const double *in, float *out, long long n);
 hipError_t launch_f32_to_f64(hipStream_t st, const float *in, double *out, long long n);
+hipError_t launch_prior_betas(hipStream_t st, const float *betas, float *bsum, const unsigned long long *n_mol,
+                              const int *v2snp, const int *snp_ptr, const int *snp_vars, long long V, int G,
+                              double default_prior, float *out);
 hipError_t launch_assign(hipStream_t st, const float *post, long long B, int K, int *best, float *best_p);
 hipError_t launch_test_log(hipStream_t st, const float *in, float *out, long long n);
 hipError_t launch_test_log_hot(hipStream_t st, const float *in, float *out, long long n);

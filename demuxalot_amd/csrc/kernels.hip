@@ -56,6 +56,46 @@ __global__ __launch_bounds__(256) void k_probs_from_betas(const float *__restric
 }
 
 // ------------------------------------------------------------------------------------
+// Regularised prior betas (demuxalot/demux.py:367-388):
+//   scale[v] = 1 + [data] n_mol[v] / (sum_snp n_mol + 100) + f64(bsum[v]) / (sum_snp f64(bsum) + 100)
+//   beta'[v,g] = beta[v,g] + f32(scale[v] * default_prior)
+// bsum[v] = np.sum(beta[v,:]) in float32 with numpy's pairwise association; the per-SNP sums run over the
+// SNP's variants in increasing variant index in float64 (np.bincount order).
+// Two small kernels: row sums (one wavefront per variant), then one thread per (variant, genotype).
+// ------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_beta_rowsum(const float *__restrict__ betas, long long V, int G,
+                                                     float *__restrict__ bsum)
+{
+    const int lane = threadIdx.x & 63;
+    const long long v = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (v >= V) return;
+    const float tot = npm::row_sum_wave(betas + (size_t)v * G, G, lane);
+    if (lane == 0) bsum[v] = tot;
+}
+
+__global__ __launch_bounds__(256) void k_prior_betas(const float *__restrict__ betas, const float *__restrict__ bsum,
+                                                     const unsigned long long *__restrict__ n_mol,  // nullable
+                                                     const int *__restrict__ v2snp, const int *__restrict__ snp_ptr,
+                                                     const int *__restrict__ snp_vars, long long V, int G,
+                                                     double default_prior, float *__restrict__ out)
+{
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= V * G) return;
+    const long long v = i / G;
+    const int snp = v2snp[v];
+    double mol_snp = 0.0, beta_snp = 0.0;
+    for (int j = snp_ptr[snp]; j < snp_ptr[snp + 1]; j++) {
+        const int u = snp_vars[j];
+        if (n_mol) mol_snp += (double)n_mol[u];
+        beta_snp += (double)bsum[u];
+    }
+    double scale = 1.0;
+    if (n_mol) scale = scale + (double)n_mol[v] / (mol_snp + 100.0);
+    scale = scale + (double)bsum[v] / (beta_snp + 100.0);
+    out[i] = betas[i] + (float)(scale * default_prior);
+}
+
+// ------------------------------------------------------------------------------------
 // helpers for the in-register softmax of the direct kernel: option k of a lane group lives in
 // lane (group base + (k & 63)), register slot (k >> 6).
 // ------------------------------------------------------------------------------------
@@ -897,6 +937,17 @@ hipError_t launch_f32_to_f64(hipStream_t st, const float *in, double *out, long 
 {
     if (n == 0) return hipSuccess;
     hipLaunchKernelGGL(k_f32_to_f64, dim3(blocks_for(n, 256)), dim3(256), 0, st, in, out, n);
+    return hipGetLastError();
+}
+
+hipError_t launch_prior_betas(hipStream_t st, const float *betas, float *bsum, const unsigned long long *n_mol,
+                              const int *v2snp, const int *snp_ptr, const int *snp_vars, long long V, int G,
+                              double default_prior, float *out)
+{
+    if (V * G == 0) return hipSuccess;
+    hipLaunchKernelGGL(k_beta_rowsum, dim3(blocks_for(V, 4)), dim3(256), 0, st, betas, V, G, bsum);
+    hipLaunchKernelGGL(k_prior_betas, dim3(blocks_for(V * G, 256)), dim3(256), 0, st, betas, bsum, n_mol, v2snp, snp_ptr,
+                       snp_vars, V, G, default_prior, out);
     return hipGetLastError();
 }
 

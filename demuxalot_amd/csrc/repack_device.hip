@@ -468,11 +468,12 @@ int pack_on_device(dmx_ctx *c, long long V, const int *var_chrom, const int *var
     DMX_TRY(upload(sc, &d_cp, call_p, (size_t)n_calls, st));
     int *call_variant, *bad;
     unsigned *flag, *pos_excl;
-    unsigned long long *d_mol;
+    dev_free(c, &c->d_mol, (size_t)c->V);
+    DMX_TRY(dev_alloc(c, &c->d_mol, (size_t)V));
+    unsigned long long *d_mol = c->d_mol;
     DMX_TRY(sc.get(&call_variant, (size_t)n_calls));
     DMX_TRY(sc.get(&flag, (size_t)n_calls + 1));
     DMX_TRY(sc.get(&pos_excl, (size_t)n_calls + 1));
-    DMX_TRY(sc.get(&d_mol, (size_t)V));
     DMX_TRY(sc.get(&bad, 1));
     HIP_TRY(hipMemsetAsync(d_mol, 0, sizeof(unsigned long long) * (V ? V : 1), st));
     HIP_TRY(hipMemsetAsync(bad, 0, sizeof(int), st));

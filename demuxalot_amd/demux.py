@@ -11,7 +11,8 @@ What runs where
              with float32 products in call order, CSR/CSC derivation -> demux.py:276-300, 332-365
              (the public pack_calls(), whose results are host arrays, uses the C++ host twin
              dmx_pack_calls_host, which also works without a GPU)
-  host, numpy: regularised prior betas (O(V*G), one-off)       -> demux.py:367-388
+  GPU:        regularised prior betas (dmx_set_prior_betas)     -> demux.py:367-388
+              (numpy twin `_prior_betas` only inside the host-side pack_calls())
   GPU (HIP):  beta -> probability normalisation                -> demux.py:267-274
               per-barcode log-likelihood accumulation + softmax -> demux.py:246-265, :101, :152
               squared-posterior beta update (+ RCCL all-reduce) -> demux.py:113-118
@@ -150,19 +151,18 @@ def _pack(chromosome2compressed_snp_calls, genotypes, add_data_prior, want_molec
     return packed
 
 
-def _pack_on_device(chromosome2compressed_snp_calls, genotypes, n_barcodes, add_data_prior):
-    """The repack of predict / learn: flattening on the host, matching + de-duplication + layout
-    derivation on the GPU (dmx_pack_and_set_problem), the O(V*G) prior betas in numpy.
+def _pack_on_device(chromosome2compressed_snp_calls, genotypes, n_barcodes, add_data_prior, fetch_betas=True):
+    """The repack of predict / learn: flattening on the host; matching + de-duplication + layout
+    derivation (dmx_pack_and_set_problem) and the regularised prior betas (dmx_set_prior_betas) on the GPU.
     Returns (ctx with the problem and betas resident, regularised prior betas)."""
     (var_chrom, var_pos, var_base), flat = _flatten_inputs(chromosome2compressed_snp_calls, genotypes, False)
     v2snp = genotypes.get_snp_ids_for_variants()
     assert np.all(v2snp >= 0)
     ctx = get_context()
-    _n_matched, _n_unique, mol_per_variant = ctx.pack_and_set_problem(
-        n_barcodes, genotypes.n_genotypes, var_chrom, var_pos, var_base, v2snp,
-        flat['chrom'], flat['pos'], flat['base'], flat['cb'], flat['p'])
-    betas = _prior_betas(genotypes, v2snp, mol_per_variant, add_data_prior)
-    ctx.set_betas(betas)
+    ctx.pack_and_set_problem(n_barcodes, genotypes.n_genotypes, var_chrom, var_pos, var_base, v2snp,
+                             flat['chrom'], flat['pos'], flat['base'], flat['cb'], flat['p'])
+    # regularised prior on the GPU too (molecule counts per variant stay on the device)
+    betas = ctx.set_prior_betas(genotypes.get_betas(), genotypes.default_prior, add_data_prior, fetch=fetch_betas)
     return ctx, betas
 
 
@@ -209,7 +209,8 @@ class Demultiplexer:
             assert barcode_prior_logits.shape == (barcode_handler.n_barcodes, len(penalties)), 'wrong shape of priors'
         assert n_iterations >= 1, 'n_iterations should be positive'  # the reference fails to unpack an empty run
 
-        ctx, _betas = _pack_on_device(chromosome2compressed_snp_calls, genotypes, barcode_handler.n_barcodes, True)
+        ctx, _betas = _pack_on_device(chromosome2compressed_snp_calls, genotypes, barcode_handler.n_barcodes, True,
+                                      fetch_betas=False)
         _logits, probs, addition = ctx.em(
             n_iterations, p_genotype_clip, penalties, with_doublets=doublet_prior != 0,
             prior_logits=barcode_prior_logits, contribution_power=Demultiplexer.contribution_power,
@@ -264,7 +265,8 @@ class Demultiplexer:
         barcode_handler.ordered_barcodes order, index named 'BARCODE'."""
         Demultiplexer._check_not_aggregating()
         penalties = Demultiplexer._doublet_penalties(genotypes.n_genotypes, doublet_prior)
-        ctx, _betas = _pack_on_device(chromosome2compressed_snp_calls, genotypes, barcode_handler.n_barcodes, False)
+        ctx, _betas = _pack_on_device(chromosome2compressed_snp_calls, genotypes, barcode_handler.n_barcodes, False,
+                                      fetch_betas=False)
         ctx.set_addition(None)
         genotype_prob = ctx.probs_from_betas(p_genotype_clip)
         assert np.isfinite(genotype_prob).all()

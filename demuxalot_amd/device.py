@@ -74,6 +74,21 @@ class DeviceContext:
         assert betas.shape == (self.V, self.G)
         check(self._lib.dmx_set_betas(self._h, ptr(betas)))
 
+    def set_prior_betas(self, raw_betas, default_prior, add_data_prior, mol_per_variant=None, fetch=True):
+        """Regularised prior betas (demux.py:372-388) computed on the GPU from the raw betas."""
+        raw_betas = as_c(raw_betas, np.float32)
+        assert raw_betas.shape == (self.V, self.G)
+        assert np.all(raw_betas >= 0), 'bad genotypes provided, negative betas appeared'
+        if mol_per_variant is not None:
+            mol_per_variant = as_c(mol_per_variant, np.int64)
+            assert mol_per_variant.shape == (self.V,)
+        out = np.empty((self.V, self.G), dtype=np.float32) if fetch else None
+        check(self._lib.dmx_set_prior_betas(self._h, ptr(raw_betas), float(default_prior), int(bool(add_data_prior)),
+                                            ptr(mol_per_variant), ptr(out)))
+        if out is not None:
+            out.flags.writeable = False
+        return out
+
     def set_addition(self, addition=None):
         if addition is not None:
             addition = as_c(addition, np.float32)

@@ -107,6 +107,13 @@ int dmx_get_packed_calls(dmx_ctx *ctx, int32_t *variant_id, int32_t *compressed_
 /* Regularised prior betas float32[V*G] (output of pack_calls, demux.py:372-388). */
 int dmx_set_betas(dmx_ctx *ctx, const float *prior_betas);
 
+/* The same regularisation computed on the GPU from the raw betas (genotypes.get_betas(), float32[V*G]):
+ * compute_prior_betas of demux.py:372-388, including numpy's float32 pairwise row sums and float64
+ * per-SNP sums.  With add_data_prior the molecule counts per variant are those left by
+ * dmx_pack_and_set_problem, or mol_per_variant[V] when given.  prior_out (nullable) receives the result. */
+int dmx_set_prior_betas(dmx_ctx *ctx, const float *raw_betas, double default_prior, int add_data_prior,
+                        const int64_t *mol_per_variant, float *prior_out);
+
 /* genotype_addition float32[V*G]; NULL resets it to zero (demux.py:86). */
 int dmx_set_addition(dmx_ctx *ctx, const float *addition);
 
