@@ -326,6 +326,27 @@ def test_c_abi_rejects_bad_calls():
         ctx.close()
 
 
+def test_repeated_problems_do_not_leak_device_memory():
+    from demuxalot_amd import Demultiplexer, synth
+    from demuxalot_amd.device import DeviceContext
+    ctx = DeviceContext(0)
+    try:
+        sizes = []
+        for rep in range(6):
+            p = synth.generate(300 + 50 * (rep % 2), 200, 8 + 8 * (rep % 3), calls_per_barcode=40, seed=rep)
+            ctx.set_problem(p.n_barcodes, p.n_variants, p.n_genotypes, p.variant_id, p.compressed_cb, p.p_base_wrong, p.v2snp)
+            ctx.set_prior_betas(p.raw_betas, 1.0, True, mol_per_variant=np.bincount(p.variant_id, minlength=p.n_variants))
+            ctx.em(2, 0.01, Demultiplexer._doublet_penalties(p.n_genotypes, 0.2), with_doublets=True)
+            sizes.append((p.n_barcodes, p.n_genotypes, ctx.device_bytes()))
+        # identical shapes must account for identical bytes (nothing accumulates across uploads)
+        by_shape = {}
+        for b, g, n in sizes:
+            by_shape.setdefault((b, g), set()).add(n)
+        assert all(len(v) == 1 for v in by_shape.values()), sizes
+    finally:
+        ctx.close()
+
+
 # ---- multi-GPU plumbing on one GPU -----------------------------------------------------------------
 @pytest.mark.parametrize('reduce_dtype', ['f64', 'f32'])
 def test_rccl_communicator_single_rank(reduce_dtype):
