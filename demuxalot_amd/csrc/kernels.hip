@@ -660,18 +660,28 @@ __global__ __launch_bounds__(256) void k_mstep(MstepArgs a)
         const int n = live ? a.item_len[item] : 0;
         const uint2 *__restrict__ calls = a.calls + a.item_start[item];
         const int nmax = group_max_over_wave<L>(n);
+        const unsigned mybit = 1u << li, li4 = (unsigned)li * 4u, k4 = (unsigned)a.K * 4u;
+        const __amdgpu_buffer_rsrc_t rsrc =
+            __builtin_amdgcn_make_buffer_rsrc((void *)a.post, 0, SMALL ? (int)a.post_bytes : 0, 0x00020000);
+        // records two chunks ahead, bitmaps one chunk ahead (the record -> bitmap -> gather chain is three
+        // dependent loads; without the pipeline a group waits for all of them once per L calls)
+        auto load_records = [&](int c0) {
+            uint2 r = make_uint2(0u, 0u);  // keep bits 0 -> keep = +0: padding adds (p*0)^power = +0
+            if (c0 + li < n) r = calls[c0 + li];
+            return r;
+        };
+        auto load_bitmap = [&](int c0, uint2 r) {
+            unsigned m = 0u;
+            if (c0 + li < n) m = (unsigned)a.nz[(size_t)r.x];  // one word per barcode here (G <= 32)
+            return m;
+        };
+        uint2 d = load_records(0);
+        uint2 d_nxt = load_records(L);
+        unsigned lo_v = load_bitmap(0, d);
         for (int c0 = 0; c0 < nmax; c0 += L) {
-            int ci = c0 + li;
-            const bool mine = ci < n;
-            ci = mine ? ci : 0;
-            uint2 d = make_uint2(0u, 0u);
-            unsigned long long bits_v = 0ull;
-            if (mine) {
-                d = calls[ci];
-                bits_v = a.nz[(size_t)d.x];  // W == 1 here (G <= 32)
-            }
-            const float keep_v = mine ? __uint_as_float(d.y) : 0.0f;
-            const unsigned lo_v = (unsigned)bits_v;
+            const uint2 d_nn = load_records(c0 + 2 * L);
+            const unsigned lo_nxt = load_bitmap(c0 + L, d_nxt);
+            const float keep_v = __uint_as_float(d.y);
             const int cnt = (nmax - c0) < L ? (nmax - c0) : L;
             for (int i0 = 0; i0 < cnt; i0 += U) {
                 constexpr int H = U / 2;
@@ -681,8 +691,16 @@ __global__ __launch_bounds__(256) void k_mstep(MstepArgs a)
                     const unsigned cb = group_bcast<L>(d.x, i0 + u, gbase);
                     const float kp = group_bcast<L>(keep_v, i0 + u, gbase);
                     const unsigned bits = group_bcast<L>(lo_v, i0 + u, gbase);
-                    float v = 0.0f;
-                    if ((bits >> li) & 1u) v = a.post[(size_t)cb * a.K + li];
+                    float v;
+                    if (SMALL) {
+                        // straight-line form: lanes whose bit is clear aim past the end of the buffer; the
+                        // range check of the buffer load returns 0 for them without touching memory
+                        const unsigned off = (bits & mybit) ? __umul24(cb, k4) + li4 : 0xFFFFFFFFu;
+                        v = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, (int)off, 0, 0));
+                    } else {
+                        v = 0.0f;
+                        if (bits & mybit) v = a.post[(size_t)cb * a.K + li];
+                    }
                     if (u & 1) {
                         keep[u >> 1].y = kp;
                         p[u >> 1][0].y = v;
@@ -693,6 +711,9 @@ __global__ __launch_bounds__(256) void k_mstep(MstepArgs a)
                 }
                 mstep_terms<A, H, SQUARE>(p, keep, a.power, acc);
             }
+            d = d_nxt;
+            d_nxt = d_nn;
+            lo_v = lo_nxt;
         }
     }
 #pragma unroll
@@ -889,7 +910,8 @@ template <int L, int A, int U>
 static void launch_m(hipStream_t st, const MstepArgs &a)
 {
     const dim3 grid(blocks_for(a.n_items, 4 * (64 / L)));
-    const bool small = a.post_bytes < (1ull << 32);
+    // 32-bit row offsets (buffer soffset / v_mad_u32_u24): posterior table < 4 GiB and barcode ids < 2^24
+    const bool small = a.post_bytes < (1ull << 32) && a.post_bytes / (4ull * (unsigned long long)a.K) < (1ull << 24);
     if (a.square && small)
         hipLaunchKernelGGL((k_mstep<L, A, U, true, true>), grid, dim3(256), 0, st, a);
     else if (a.square)
