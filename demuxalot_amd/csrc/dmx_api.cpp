@@ -142,6 +142,7 @@ void release_problem(dmx_ctx *c)
     dev_free(c, &c->d_post, (size_t)c->cap_bk);
     c->cap_bk = 0;
     dev_free(c, &c->d_nz, (size_t)c->B * ((c->G + 63) / 64));
+    dev_free(c, &c->d_first, (size_t)c->B);
     dev_free(c, &c->d_pen, (size_t)c->cap_k);
     dev_free(c, &c->d_pairs, (size_t)c->cap_k);
     c->cap_k = 0;
@@ -237,7 +238,7 @@ int run_pstep(dmx_ctx *c, float lo, float hi, bool with_addition)
     return 0;
 }
 
-int run_estep(dmx_ctx *c, int with_doublets, bool with_prior, int prior_dtype)
+int run_estep(dmx_ctx *c, int with_doublets, bool with_prior, int prior_dtype, float power)
 {
     dmx::EstepArgs a;
     a.pair_ptr = c->d_pair_ptr;
@@ -251,6 +252,9 @@ int run_estep(dmx_ctx *c, int with_doublets, bool with_prior, int prior_dtype)
     a.logits = c->d_logits;
     a.post = c->d_post;
     a.nz = c->d_nz;
+    a.first = c->G <= 64 ? c->d_first : nullptr;
+    a.nz_floor = power == 2.0f ? dmx::NZ_FLOOR_SQUARE : 0.0f;
+    c->nz_floor = a.nz_floor;
     a.B = c->B;
     a.prob_bytes = (unsigned)((unsigned long long)c->V * c->G * 4ull);
     a.G = c->G;
@@ -272,6 +276,7 @@ int run_mstep(dmx_ctx *c, float power)
     a.calls = c->d_csc;
     a.post = c->d_post;
     a.nz = c->d_nz;
+    a.first = c->d_first;
     a.post_bytes = (unsigned long long)c->B * (unsigned long long)c->K * 4ull;
     a.partial = c->d_partial;
     a.n_items = c->n_items;
@@ -279,6 +284,12 @@ int run_mstep(dmx_ctx *c, float power)
     a.G = c->G;
     a.square = (power == 2.0f);
     a.power = power;
+    if (!a.square && c->nz_floor != 0.0f) {
+        // the E-step assumed a squaring M-step: rebuild the bitmap with the exact `!= 0` rule
+        HIP_TRY(dmx::launch_rebuild_nz(c->stream, c->d_post, c->B, c->K, c->G, 0.0f, c->d_nz,
+                                       c->G <= 64 ? c->d_first : nullptr));
+        c->nz_floor = 0.0f;
+    }
     std::pair<hipEvent_t, hipEvent_t> ev;
     const bool dist = c->comm != nullptr;  // also with one rank: keeps the collective path testable on one GPU
     if (!dist) {
@@ -468,6 +479,7 @@ static int finish_problem(dmx_ctx *c, const int32_t *v2snp, const std::vector<in
     DMX_TRY(dev_alloc(c, &c->d_add64, vg));
     DMX_TRY(dev_alloc(c, &c->d_partial, (size_t)c->n_items * G));
     DMX_TRY(dev_alloc(c, &c->d_nz, (size_t)B * ((G + 63) / 64)));
+    DMX_TRY(dev_alloc(c, &c->d_first, (size_t)B));
     DMX_TRY(dev_alloc(c, &c->d_best, (size_t)B));
     DMX_TRY(dev_alloc(c, &c->d_bestp, (size_t)B));
     hipStream_t st = c->stream;
@@ -642,7 +654,7 @@ int dmx_estep(dmx_ctx *c, int with_doublets, const float *penalties, const void 
     if (!penalties) return fail(DMX_ERR_INVALID, "null penalties");
     DMX_TRY(ensure_options(c, with_doublets, penalties));
     DMX_TRY(upload_prior_logits(c, prior_logits, prior_dtype));
-    DMX_TRY(run_estep(c, with_doublets, prior_logits != nullptr, prior_dtype));
+    DMX_TRY(run_estep(c, with_doublets, prior_logits != nullptr, prior_dtype, 2.0f));
     const size_t bk = (size_t)c->B * c->K;
     DMX_TRY(copy_out(c, logits_out, c->d_logits, bk));
     DMX_TRY(copy_out(c, probs_out, c->d_post, bk));
@@ -674,7 +686,7 @@ int dmx_em(dmx_ctx *c, int n_iterations, float lo, float hi, int with_doublets, 
     HIP_TRY(hipMemsetAsync(c->d_add, 0, sizeof(float) * (vg ? vg : 1), c->stream));  // demux.py:86
     for (int it = 0; it < n_iterations; it++) {
         DMX_TRY(run_pstep(c, lo, hi, true));
-        DMX_TRY(run_estep(c, with_doublets, it == 0 && prior_logits != nullptr, prior_dtype));
+        DMX_TRY(run_estep(c, with_doublets, it == 0 && prior_logits != nullptr, prior_dtype, power));
         if (it + 1 < n_iterations) DMX_TRY(run_mstep(c, power));  // the M-step after the last yield is dead
     }
     const size_t bk = (size_t)c->B * c->K;
@@ -694,7 +706,7 @@ int dmx_run_iterations(dmx_ctx *c, int n_iterations, float lo, float hi, float p
     const int with_doublets = c->K != c->G;
     for (int it = 0; it < n_iterations; it++) {
         DMX_TRY(run_pstep(c, lo, hi, true));
-        DMX_TRY(run_estep(c, with_doublets, false, DMX_F32));
+        DMX_TRY(run_estep(c, with_doublets, false, DMX_F32, power));
         DMX_TRY(run_mstep(c, power));
     }
     return 0;

@@ -59,6 +59,8 @@ struct dmx_ctx {
     double *d_add64 = nullptr, *d_partial = nullptr;
     float *d_logits = nullptr, *d_post = nullptr;
     unsigned long long *d_nz = nullptr;
+    float nz_floor = 0.0f;     // threshold the current d_nz / d_first were built with
+    float *d_first = nullptr;  // [B] posterior of the lowest non-zero singlet column (G <= 64)
     long long cap_bk = 0;
     float *d_pen = nullptr;
     unsigned *d_pairs = nullptr;

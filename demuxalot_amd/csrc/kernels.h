@@ -32,7 +32,9 @@ struct EstepArgs {
     int prior_dtype;            // DMX_F32 / DMX_F64
     float *logits;              // [B, K]
     float *post;                // [B, K]
-    unsigned long long *nz;     // [B, ceil(G/64)] bit g set <=> post[b, g] != 0 (singlet columns; read by the M-step)
+    unsigned long long *nz;     // [B, ceil(G/64)] bit g set <=> !(post[b, g] <= nz_floor) (singlet columns; read by the M-step)
+    float *first;               // nullable [B]: post[b, lowest set bit of nz[b]] (G <= 64; read by the M-step)
+    float nz_floor;             // 0, or NZ_FLOOR_SQUARE when the M-step squares (see below)
     long long B;
     unsigned prob_bytes;        // V * G * 4 (< 4 GiB): extent of the prob table for buffer addressing
     int G;
@@ -46,6 +48,7 @@ struct MstepArgs {
     const uint2 *calls;             // [N] (compressed_cb, bits of 1 - p_base_wrong), variant-major
     const float *post;              // [B, K] posteriors (singlet columns 0..G-1 are read)
     const unsigned long long *nz;   // [B, ceil(G/64)] non-zero bitmap of the singlet posteriors
+    const float *first;             // [B] posterior of the lowest non-zero singlet column (G <= 64)
     double *partial;                // [n_items, G]
     long long n_items;
     long long K;
@@ -54,6 +57,12 @@ struct MstepArgs {
     int square;   // contribution_power == 2
     float power;  // otherwise
 };
+
+// A posterior p <= 2^-80 contributes (p * keep)^2 = +0 exactly for |keep| <= 32 (|p * keep| <= 2^-75, and a
+// float32 square below 2^-150 rounds to +0), so with contribution_power == 2 the M-step may treat it as absent.
+// exp(-55) is about 2^-80: most barcodes then have ONE live posterior instead of one per genotype within 103
+// logit units of the best.
+constexpr float NZ_FLOOR_SQUARE = 8.271806125530277e-25f;  // 2^-80
 
 constexpr int ITEM_CALLS = 1024;  // longest run of one variant's calls handled by one wavefront
 constexpr int M_CHUNKS = 4;       // variant ranges (equal numbers of calls) whose all-reduce overlaps the next range's M-step
@@ -71,6 +80,9 @@ hipError_t launch_f32_to_f64(hipStream_t st, const float *in, double *out, long 
 hipError_t launch_prior_betas(hipStream_t st, const float *betas, float *bsum, const unsigned long long *n_mol,
                               const int *v2snp, const int *snp_ptr, const int *snp_vars, long long V, int G,
                               double default_prior, float *out);
+// recomputes the M-step's bitmap / first-posterior table from the stored posteriors
+hipError_t launch_rebuild_nz(hipStream_t st, const float *post, long long B, int K, int G, float nz_floor,
+                             unsigned long long *nz, float *first);
 hipError_t launch_assign(hipStream_t st, const float *post, long long B, int K, int *best, float *best_p);
 hipError_t launch_test_log(hipStream_t st, const float *in, float *out, long long n);
 hipError_t launch_test_log_hot(hipStream_t st, const float *in, float *out, long long n);

@@ -13,6 +13,9 @@
 // (np_math.h).  Built with -ffp-contract=off.
 #include <hip/hip_runtime.h>
 
+#include <cstdlib>
+#include <cstring>
+
 #include "kernels.h"
 #include "np_math.h"
 
@@ -388,11 +391,16 @@ __global__ __launch_bounds__(256) void k_estep_direct(EstepArgs a)
             a.post[o] = post;
         }
         // non-zero bitmap of the singlet columns (the M-step skips exact zeros: (0*keep)^2 = +0)
-        const unsigned long long bal = __ballot(live && valid[s] && (li + 64 * s) < a.G && post != 0.0f);
+        const unsigned long long bal = __ballot(live && valid[s] && (li + 64 * s) < a.G && !(post <= a.nz_floor));
         if (L == 64) {
             if (lane == 0 && s < W) a.nz[(size_t)b * W + s] = bal;
         } else {
             if (live && li == 0) a.nz[(size_t)b] = (bal >> gbase) & ((1ull << L) - 1ull);
+        }
+        if (s == 0 && a.first) {
+            // the one posterior most barcodes have, in a table small enough to stay in L2 (M-step)
+            const unsigned long long mine = L == 64 ? bal : ((bal >> gbase) & ((1ull << L) - 1ull));
+            if (live && mine != 0ull && li == __builtin_ctzll(mine)) a.first[b] = post;
         }
     }
 }
@@ -524,8 +532,9 @@ __global__ __launch_bounds__(256) void k_estep_block(EstepArgs a, int C)
             a.post[o] = post;
         }
         if (s == 0) {  // singlet columns k < G <= 256 all live in slot 0: one bitmap word per wave
-            const unsigned long long bal = __ballot(k < G && post != 0.0f);
+            const unsigned long long bal = __ballot(k < G && !(post <= a.nz_floor));
             if (lane == 0 && wave < W) a.nz[(size_t)b * W + wave] = bal;
+            if (a.first && wave == 0 && bal != 0ull && lane == __builtin_ctzll(bal)) a.first[b] = post;
         }
     }
 }
@@ -721,6 +730,253 @@ __global__ __launch_bounds__(256) void k_mstep(MstepArgs a)
         const int g = li + 64 * s;
         if (live && g < G) a.partial[(size_t)item * G + g] = acc[s];
     }
+}
+
+// ------------------------------------------------------------------------------------
+// M-step, call-parallel form (G <= 64).  The genotype-per-lane form above spends ~8 VALU
+// instructions per call although most barcodes have ONE non-zero posterior (measured on the
+// 200k x 100k x 64 workload: 60% of the barcodes have 1, 35% have all 64; the kernel is
+// issue-bound, not fetch-bound).  Here a wavefront still owns one work item and lane g still owns
+// the float64 accumulator of genotype g, but a chunk of 64 calls is first turned into per-genotype
+// QUEUES in LDS: val[r][g] = the r-th contribution (in call order) to genotype g.  Lane g then adds
+// val[0][g], val[1][g], ... -- exactly the addends of the sequential walk in exactly its order
+// (np.bincount order), so the sums stay bit-identical, in max-queue-length iterations of 3
+// instructions instead of 64 iterations of 8.
+//   queue position of call i for genotype g = number of calls j < i of the chunk with bit g set
+//                                           = popcount(colmask[g] & lanes below i),
+// colmask = the transposed 64 x 64 bit matrix of the calls' non-zero bitmaps:
+//   * sparse calls (<= NZ_S non-zeros) are handled one per lane: lane i ORs its bit into colmask[g]
+//     in LDS (ds_or_b64) for each of its genotypes, later gathers post[cb_i, g], squares and stores;
+//   * dense calls (uninformative barcodes, all genotypes alive) are handled one at a time by the
+//     whole wavefront, lane g fetching post[cb_i, g] from the coalesced row.
+// The queues hold R entries; a chunk that could overflow them is processed R calls at a time.
+// ------------------------------------------------------------------------------------
+template <bool SQUARE, int R, int D, bool PRE>
+__global__ __launch_bounds__(256) void k_mstep_calls(MstepArgs a)
+{
+    constexpr int NZ_S = 4;  // "sparse" call: at most this many non-zero posteriors
+    typedef unsigned long long u64;
+    __shared__ float sh_val[4][R * 64];
+    __shared__ u64 sh_colmask[4][64];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const long long slot = (long long)blockIdx.x * 4 + wave;
+    if (slot >= a.n_items) return;
+    const long long item = a.order[slot];
+    const int n = a.item_len[item];
+    const uint2 *__restrict__ calls = a.calls + a.item_start[item];
+    float *val = sh_val[wave];
+    u64 *colmask = sh_colmask[wave];
+    const int G = a.G;
+    const long long K = a.K;
+    const u64 bit = 1ull << lane;
+    const u64 below = bit - 1ull;
+    double acc = 0.0;
+
+    auto power_of = [&](float c) { return SQUARE ? c * c : powf(c, a.power); };
+    auto lane_u64 = [&](u64 v, int i) {
+        const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)v, i);
+        const unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(v >> 32), i);
+        return ((u64)hi << 32) | lo;
+    };
+    auto load_records = [&](int c0) {
+        uint2 d = make_uint2(0u, 0u);
+        if (c0 + lane < n) d = calls[c0 + lane];
+        return d;
+    };
+    auto load_bitmap = [&](int c0, uint2 d) {
+        u64 m = 0ull;  // padding lanes contribute nothing
+        if (c0 + lane < n) m = a.nz[(size_t)d.x];
+        return m;
+    };
+    // the <= NZ_S posteriors of this lane's call; the common single one comes from the L2-resident table.
+    // Every p[t] is written by exactly one conditional load, so that nothing waits for it here.
+    auto load_sparse = [&](u64 m, uint2 d, float (&p)[NZ_S]) {
+        const int nnz = __popcll(m);
+        const bool sparse = nnz >= 1 && nnz <= NZ_S;
+        const float *__restrict__ row = a.post + (size_t)d.x * K;
+        u64 mm = m;
+#pragma unroll
+        for (int t = 0; t < NZ_S; t++) {
+            const float *src = row + (mm ? __builtin_ctzll(mm) : 0);
+            if (t == 0 && nnz == 1) src = a.first + d.x;
+            p[t] = 0.0f;
+            if (sparse && mm != 0ull) p[t] = *src;
+            mm &= mm - 1ull;
+        }
+    };
+    // lane g's posterior of the call held by lane i (0 where the bitmap says so)
+    auto load_dense = [&](uint2 d, u64 m, int i) {
+        const unsigned cb = (unsigned)__builtin_amdgcn_readlane((int)d.x, i);
+        float v = 0.0f;
+        if (__builtin_amdgcn_inverse_ballot_w64(lane_u64(m, i))) v = a.post[(size_t)cb * K + lane];
+        return v;
+    };
+    auto load_dense_rows = [&](u64 dense, uint2 d, u64 m, float (&q)[D]) {
+#pragma unroll
+        for (int j = 0; j < D; j++) {
+            q[j] = 0.0f;
+            if (dense) {
+                q[j] = load_dense(d, m, __builtin_ctzll(dense));
+                dense &= dense - 1ull;
+            }
+        }
+    };
+
+    // software pipeline: records three chunks ahead, bitmaps two, posteriors one
+    uint2 d0 = load_records(0), d1 = load_records(64), d2 = load_records(128);
+    u64 m0 = load_bitmap(0, d0), m1 = load_bitmap(64, d1);
+    u64 dense0 = __ballot(__popcll(m0) > NZ_S);
+    float ps0[NZ_S], q0[D];
+    load_sparse(m0, d0, ps0);
+    if (PRE) load_dense_rows(dense0, d0, m0, q0);
+    for (int c0 = 0; c0 < n; c0 += 64) {
+        const uint2 d3 = load_records(c0 + 192);
+        const u64 m2 = load_bitmap(c0 + 128, d2);
+        const u64 dense1 = __ballot(__popcll(m1) > NZ_S);
+        float ps1[NZ_S], q1[D];
+        load_sparse(m1, d1, ps1);
+        if (PRE) load_dense_rows(dense1, d1, m1, q1);
+
+        const float keep = __uint_as_float(d0.y);
+        const bool is_dense = (dense0 & bit) != 0ull;
+        // one dense call: lane g appends its contribution to queue g
+        auto put_dense = [&](int i, float q, u64 &cm) {
+            const float kp = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, keep), i));
+            const bool alive = __builtin_amdgcn_inverse_ballot_w64(lane_u64(m0, i));
+            const u64 call_bit = 1ull << i;
+            const int pos = __popcll(cm & (call_bit - 1ull));
+            const float c = power_of(q * kp);
+            if (alive) {
+                val[pos * 64 + lane] = c;
+                cm |= call_bit;
+            }
+        };
+        auto transpose = [&](u64 mine) {
+            colmask[lane] = 0ull;
+            while (__any(mine != 0ull)) {
+                if (mine) {
+                    atomicOr(&colmask[__builtin_ctzll(mine)], bit);
+                    mine &= mine - 1ull;
+                }
+            }
+            return colmask[lane];
+        };
+        auto drain = [&](u64 cm) {  // absent entries add +0.0, which changes nothing
+            static_assert(R % 4 == 0, "the drain reads four queue rows at a time");
+            const int cnt = __popcll(cm);
+            for (int r = 0; __any(r < cnt); r += 4) {
+                float v0 = val[(r + 0) * 64 + lane];
+                float v1 = val[(r + 1) * 64 + lane];
+                float v2 = val[(r + 2) * 64 + lane];
+                float v3 = val[(r + 3) * 64 + lane];
+                v0 = r + 0 < cnt ? v0 : 0.0f;
+                v1 = r + 1 < cnt ? v1 : 0.0f;
+                v2 = r + 2 < cnt ? v2 : 0.0f;
+                v3 = r + 3 < cnt ? v3 : 0.0f;
+                acc += (double)v0;
+                acc += (double)v1;
+                acc += (double)v2;
+                acc += (double)v3;
+            }
+        };
+        auto put_sparse = [&](u64 mine) {
+#pragma unroll
+            for (int t = 0; t < NZ_S; t++) {
+                if (mine) {
+                    const int g = __builtin_ctzll(mine);
+                    mine &= mine - 1ull;
+                    const int pos = __popcll(colmask[g] & below);
+                    val[pos * 64 + g] = power_of(ps0[t] * keep);
+                }
+            }
+        };
+
+        u64 cm = transpose(is_dense ? 0ull : m0);
+        if (!__any(__popcll(cm) + __popcll(dense0) > R)) {
+            // ---- the whole chunk fits the queues ----
+            u64 todo = dense0;
+            if (PRE) {
+#pragma unroll
+                for (int j = 0; j < D; j++) {
+                    if (todo) {
+                        put_dense(__builtin_ctzll(todo), q0[j], cm);
+                        todo &= todo - 1ull;
+                    }
+                }
+            }
+            while (todo) {  // dense calls not prefetched: fetched here, D at a time
+                float q[D];
+                load_dense_rows(todo, d0, m0, q);
+#pragma unroll
+                for (int j = 0; j < D; j++) {
+                    if (todo) {
+                        put_dense(__builtin_ctzll(todo), q[j], cm);
+                        todo &= todo - 1ull;
+                    }
+                }
+            }
+            colmask[lane] = cm;
+            put_sparse(is_dense ? 0ull : m0);
+            drain(cm);
+        } else {
+            // ---- the queues could overflow: fewer calls at a time (R calls always fit) ----
+            int first_lane = 0, width = 32;
+            while (first_lane < 64) {
+                const u64 range = ((1ull << width) - 1ull) << first_lane;
+                const u64 mine = (is_dense || !(range & bit)) ? 0ull : m0;
+                u64 todo = dense0 & range;
+                cm = transpose(mine);
+                if (width > R && __any(__popcll(cm) + __popcll(todo) > R)) {
+                    width >>= 1;
+                    continue;
+                }
+                while (todo) {
+                    float q[D];
+                    load_dense_rows(todo, d0, m0, q);
+#pragma unroll
+                    for (int j = 0; j < D; j++) {
+                        if (todo) {
+                            put_dense(__builtin_ctzll(todo), q[j], cm);
+                            todo &= todo - 1ull;
+                        }
+                    }
+                }
+                colmask[lane] = cm;
+                put_sparse(mine);
+                drain(cm);
+                first_lane += width;
+            }
+        }
+        d0 = d1; d1 = d2; d2 = d3;
+        m0 = m1; m1 = m2;
+        dense0 = dense1;
+#pragma unroll
+        for (int t = 0; t < NZ_S; t++) ps0[t] = ps1[t];
+        if (PRE) {
+#pragma unroll
+            for (int j = 0; j < D; j++) q0[j] = q1[j];
+        }
+    }
+    if (lane < G) a.partial[(size_t)item * G + lane] = acc;
+}
+
+// one wavefront per (barcode, 64 genotypes): the bitmap and first-posterior table as the E-step writes them
+__global__ __launch_bounds__(256) void k_rebuild_nz(const float *__restrict__ post, long long B, int K, int G,
+                                                    float nz_floor, unsigned long long *__restrict__ nz,
+                                                    float *__restrict__ first)
+{
+    const int lane = threadIdx.x & 63;
+    const int W = (G + 63) >> 6;
+    const long long word = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (word >= B * W) return;
+    const long long b = word / W;
+    const int g = (int)(word % W) * 64 + lane;
+    float p = 0.0f;
+    if (g < G) p = post[(size_t)b * K + g];
+    const unsigned long long bal = __ballot(g < G && !(p <= nz_floor));
+    if (lane == 0) nz[word] = bal;
+    if (first && W == 1 && bal != 0ull && lane == __builtin_ctzll(bal)) first[b] = p;
 }
 
 // sums the item partials of each variant in item order; writes float32 (single GPU) or the
@@ -926,6 +1182,22 @@ hipError_t launch_mstep(hipStream_t st, const MstepArgs &a)
 {
     if (a.n_items == 0) return hipSuccess;
     const int G = a.G;
+    static const char *force = getenv("DMX_MSTEP");  // experiment switch: "lanes" = genotype-per-lane form
+    if (G <= 64 && !(force && std::strcmp(force, "lanes") == 0)) {
+        const dim3 grid(blocks_for(a.n_items, 4));
+        auto is = [&](const char *name) { return force && std::strcmp(force, name) == 0; };
+        if (!a.square)
+            hipLaunchKernelGGL((k_mstep_calls<false, 16, 4, false>), grid, dim3(256), 0, st, a);
+        else if (is("calls16p"))
+            hipLaunchKernelGGL((k_mstep_calls<true, 16, 8, true>), grid, dim3(256), 0, st, a);
+        else if (is("calls16d8"))
+            hipLaunchKernelGGL((k_mstep_calls<true, 16, 8, false>), grid, dim3(256), 0, st, a);
+        else if (is("calls32"))
+            hipLaunchKernelGGL((k_mstep_calls<true, 32, 4, false>), grid, dim3(256), 0, st, a);
+        else
+            hipLaunchKernelGGL((k_mstep_calls<true, 16, 4, false>), grid, dim3(256), 0, st, a);
+        return hipGetLastError();
+    }
     if (G <= 4) launch_m<4, 1, 4>(st, a);
     else if (G <= 8) launch_m<8, 1, 8>(st, a);
     else if (G <= 16) launch_m<16, 1, 8>(st, a);
@@ -970,6 +1242,15 @@ hipError_t launch_prior_betas(hipStream_t st, const float *betas, float *bsum, c
     hipLaunchKernelGGL(k_beta_rowsum, dim3(blocks_for(V, 4)), dim3(256), 0, st, betas, V, G, bsum);
     hipLaunchKernelGGL(k_prior_betas, dim3(blocks_for(V * G, 256)), dim3(256), 0, st, betas, bsum, n_mol, v2snp, snp_ptr,
                        snp_vars, V, G, default_prior, out);
+    return hipGetLastError();
+}
+
+hipError_t launch_rebuild_nz(hipStream_t st, const float *post, long long B, int K, int G, float nz_floor,
+                             unsigned long long *nz, float *first)
+{
+    const long long words = B * ((G + 63) / 64);
+    if (words == 0) return hipSuccess;
+    hipLaunchKernelGGL(k_rebuild_nz, dim3(blocks_for(words, 4)), dim3(256), 0, st, post, B, K, G, nz_floor, nz, first);
     return hipGetLastError();
 }
 

@@ -267,6 +267,39 @@ def test_contribution_power_is_honoured(ctx, oracle):
     assert np.allclose(stages[1][1]['genotype_addition'], hist[1]['addition'], rtol=2e-6, atol=1e-7)
 
 
+def test_mstep_underflow_floor_is_exact(oracle):
+    """With contribution_power == 2 the M-step skips posteriors <= 2^-80 (their squared contribution is +0).
+    The problem is built so that posteriors land on both sides of that floor, in (0, 2^-80] included;
+    the additions must stay bitwise those of the oracle, which skips nothing.  Small G with full 64-call
+    chunks also drives the per-genotype queues of the call-parallel kernel into their overflow path."""
+    from demuxalot_amd import synth
+    from demuxalot_amd.device import get_context
+    for G, cpb in ((64, 160), (6, 400), (33, 250)):
+        p = synth.generate(3000, 1500, G, calls_per_barcode=cpb, seed=G + 5)
+        betas = p.prior_betas()
+        ctx = get_context()
+        ctx.set_problem(p.n_barcodes, p.n_variants, G, p.variant_id, p.compressed_cb, p.p_base_wrong, p.v2snp)
+        ctx.set_betas(betas)
+        pen = np.zeros(G, dtype=np.float32)
+        logits, probs, addition = ctx.em(2, 0.01, pen, with_doublets=False)
+        packed = dict(variant_id=p.variant_id, compressed_cb=p.compressed_cb, p_base_wrong=p.p_base_wrong,
+                      betas=betas, v2snp=p.v2snp)
+        hist = oracle.em(packed, p.n_barcodes, 2, 0.01, 0., impl='npsimd')
+        first_pass = hist[0]['probs']
+        floor = np.float32(2.0 ** -80)
+        assert ((first_pass > 0) & (first_pass <= floor)).sum() > 100, 'no posterior under the floor: test is vacuous'
+        assert ((first_pass > floor) & (first_pass < 1e-12)).sum() > 100
+        fio.assert_bitwise(addition, hist[-1]['addition'], f'addition G={G}')
+        # any other power: the bitmap is rebuilt with the exact `!= 0` rule when the steps are called separately
+        ctx.set_addition(None)
+        ctx.probs_from_betas(0.01, fetch=False)
+        ctx.estep(pen, with_doublets=False)
+        got = ctx.mstep(contribution_power=1.0)
+        want = oracle.beta_addition(p.variant_id, p.compressed_cb, p.p_base_wrong, first_pass, p.n_variants, G, power=1.0)
+        assert np.allclose(got, want, rtol=1e-5, atol=0), f'power 1 G={G}'
+        assert (got > 0).sum() == (want > 0).sum()
+
+
 # ---- edge cases --------------------------------------------------------------------------------------
 def test_empty_and_degenerate_inputs(ctx, oracle):
     """No calls at all, a single genotype, barcodes without calls, variants without calls."""
