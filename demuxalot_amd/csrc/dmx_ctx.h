@@ -122,4 +122,7 @@ int pack_on_device(dmx_ctx *c, long long V, const int *var_chrom, const int *var
                    long long n_calls, const int *call_chrom, const int *call_pos, const unsigned char *call_base,
                    const int *call_cb, const float *call_p, long long *n_matched, long long *n_unique,
                    long long *mol_per_variant);
+int pack_containers_on_device(dmx_ctx *c, long long V, const int *var_chrom, const int *var_pos,
+                              const unsigned char *var_base, const dmx_call_container *parts, int n_parts,
+                              long long *n_matched, long long *n_unique, long long *mol_per_variant);
 }  // namespace dmx

@@ -429,13 +429,13 @@ int upload(Scratch &sc, T **dst, const T *src, size_t n, hipStream_t st)
 
 }  // namespace
 
-int pack_on_device(dmx_ctx *c, long long V, const int *var_chrom, const int *var_pos, const unsigned char *var_base,
-                   long long n_calls, const int *call_chrom, const int *call_pos, const unsigned char *call_base,
-                   const int *call_cb, const float *call_p, long long *n_matched, long long *n_unique,
-                   long long *mol_per_variant)
+// The calls are already on the device (flat arrays owned by `sc`).
+static int pack_core(dmx_ctx *c, Scratch &sc, long long V, const int *var_chrom, const int *var_pos,
+                     const unsigned char *var_base, long long n_calls, const int *d_cchrom, const int *d_cpos,
+                     const unsigned char *d_cbase, const int *d_ccb, const float *d_cp, long long *n_matched,
+                     long long *n_unique, long long *mol_per_variant)
 {
     hipStream_t st = c->stream;
-    Scratch sc;
     if (n_calls >= (1LL << 32)) return fail(DMX_ERR_UNSUPPORTED, "more than 2^32 molecule calls in one batch");
     // 1. sorted variant keys
     int *d_vchrom, *d_vpos;
@@ -458,14 +458,6 @@ int pack_on_device(dmx_ctx *c, long long V, const int *var_chrom, const int *var
         HIP_TRY(rocprim::radix_sort_pairs(tmp, bytes, vkeys, vkeys_sorted, vrows, vrows_sorted, (size_t)V, 0u, 64u, st));
     }
     // 2. match + order-preserving compaction
-    int *d_cchrom, *d_cpos, *d_ccb;
-    unsigned char *d_cbase;
-    float *d_cp;
-    DMX_TRY(upload(sc, &d_cchrom, call_chrom, (size_t)n_calls, st));
-    DMX_TRY(upload(sc, &d_cpos, call_pos, (size_t)n_calls, st));
-    DMX_TRY(upload(sc, &d_cbase, call_base, (size_t)n_calls, st));
-    DMX_TRY(upload(sc, &d_ccb, call_cb, (size_t)n_calls, st));
-    DMX_TRY(upload(sc, &d_cp, call_p, (size_t)n_calls, st));
     int *call_variant, *bad;
     unsigned *flag, *pos_excl;
     dev_free(c, &c->d_mol, (size_t)c->V);
@@ -550,6 +542,103 @@ int pack_on_device(dmx_ctx *c, long long V, const int *var_chrom, const int *var
     HIP_TRY(hipGetLastError());
     c->N = n_u;
     return repack_core(c, sc, c->d_u_variant, c->d_u_cb, c->d_u_p);
+}
+
+int pack_on_device(dmx_ctx *c, long long V, const int *var_chrom, const int *var_pos, const unsigned char *var_base,
+                   long long n_calls, const int *call_chrom, const int *call_pos, const unsigned char *call_base,
+                   const int *call_cb, const float *call_p, long long *n_matched, long long *n_unique,
+                   long long *mol_per_variant)
+{
+    hipStream_t st = c->stream;
+    Scratch sc;
+    int *d_cchrom, *d_cpos, *d_ccb;
+    unsigned char *d_cbase;
+    float *d_cp;
+    DMX_TRY(upload(sc, &d_cchrom, call_chrom, (size_t)n_calls, st));
+    DMX_TRY(upload(sc, &d_cpos, call_pos, (size_t)n_calls, st));
+    DMX_TRY(upload(sc, &d_cbase, call_base, (size_t)n_calls, st));
+    DMX_TRY(upload(sc, &d_ccb, call_cb, (size_t)n_calls, st));
+    DMX_TRY(upload(sc, &d_cp, call_p, (size_t)n_calls, st));
+    return pack_core(c, sc, V, var_chrom, var_pos, var_base, n_calls, d_cchrom, d_cpos, d_cbase, d_ccb, d_cp, n_matched,
+                     n_unique, mol_per_variant);
+}
+
+// ------------------------------------------------------------------------------------
+// The same from the reference's own containers (CompressedSNPCalls, snp_counter.py:77-139): the packed numpy
+// records are uploaded as they are and taken apart here, instead of being flattened field by field on the host
+// (demux.py:332-358 does that with one fancy-indexing pass per field).
+//   snp_calls record, 13 bytes: int32 molecule_index | int32 snp_position | uint8 base_index | float32 p_base_wrong
+//   molecule record, 12 bytes:  int32 compressed_cb  | int32 compressed_ub | float32 p_group_misaligned
+// ------------------------------------------------------------------------------------
+namespace {
+
+constexpr int SNP_CALL_BYTES = 13, MOLECULE_BYTES = 12;
+
+__global__ __launch_bounds__(256) void k_flatten_container(const unsigned char *__restrict__ snp_calls, long long n,
+                                                           const unsigned char *__restrict__ molecules, long long n_molecules,
+                                                           int chrom, int *__restrict__ out_chrom, int *__restrict__ out_pos,
+                                                           unsigned char *__restrict__ out_base, int *__restrict__ out_cb,
+                                                           float *__restrict__ out_p, int *bad)
+{
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const unsigned char *r = snp_calls + i * SNP_CALL_BYTES;
+    int mol, pos;
+    float p;
+    __builtin_memcpy(&mol, r, 4);
+    __builtin_memcpy(&pos, r + 4, 4);
+    __builtin_memcpy(&p, r + 9, 4);
+    int cb = 0;
+    if (mol < 0 || mol >= n_molecules)
+        atomicOr(bad, 1);
+    else
+        __builtin_memcpy(&cb, molecules + (long long)mol * MOLECULE_BYTES, 4);
+    out_chrom[i] = chrom;
+    out_pos[i] = pos;
+    out_base[i] = r[8];
+    out_cb[i] = cb;
+    out_p[i] = p;
+}
+
+}  // namespace
+
+int pack_containers_on_device(dmx_ctx *c, long long V, const int *var_chrom, const int *var_pos,
+                              const unsigned char *var_base, const dmx_call_container *parts, int n_parts,
+                              long long *n_matched, long long *n_unique, long long *mol_per_variant)
+{
+    hipStream_t st = c->stream;
+    Scratch sc;
+    long long n_calls = 0;
+    for (int k = 0; k < n_parts; k++) n_calls += parts[k].n_snp_calls;
+    int *d_cchrom, *d_cpos, *d_ccb, *bad;
+    unsigned char *d_cbase;
+    float *d_cp;
+    DMX_TRY(sc.get(&d_cchrom, (size_t)n_calls));
+    DMX_TRY(sc.get(&d_cpos, (size_t)n_calls));
+    DMX_TRY(sc.get(&d_cbase, (size_t)n_calls));
+    DMX_TRY(sc.get(&d_ccb, (size_t)n_calls));
+    DMX_TRY(sc.get(&d_cp, (size_t)n_calls));
+    DMX_TRY(sc.get(&bad, 1));
+    HIP_TRY(hipMemsetAsync(bad, 0, sizeof(int), st));
+    long long at = 0;
+    for (int k = 0; k < n_parts; k++) {
+        const dmx_call_container &part = parts[k];
+        if (part.n_snp_calls == 0) continue;
+        unsigned char *d_calls, *d_molecules;
+        DMX_TRY(upload(sc, &d_calls, (const unsigned char *)part.snp_calls, (size_t)part.n_snp_calls * SNP_CALL_BYTES, st));
+        DMX_TRY(upload(sc, &d_molecules, (const unsigned char *)part.molecules, (size_t)part.n_molecules * MOLECULE_BYTES, st));
+        hipLaunchKernelGGL(k_flatten_container, dim3(grid_for(part.n_snp_calls)), dim3(256), 0, st, d_calls, part.n_snp_calls,
+                           d_molecules, part.n_molecules, part.chrom, d_cchrom + at, d_cpos + at, d_cbase + at, d_ccb + at,
+                           d_cp + at, bad);
+        at += part.n_snp_calls;
+    }
+    HIP_TRY(hipGetLastError());
+    int h_bad = 0;
+    HIP_TRY(hipMemcpyAsync(&h_bad, bad, sizeof(int), hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));  // also: the caller's buffers are free to change from here on
+    if (h_bad) return fail(DMX_ERR_INVALID, "molecule_index outside the molecule table");
+    return pack_core(c, sc, V, var_chrom, var_pos, var_base, n_calls, d_cchrom, d_cpos, d_cbase, d_ccb, d_cp, n_matched,
+                     n_unique, mol_per_variant);
 }
 
 }  // namespace dmx

@@ -37,8 +37,8 @@ class _Packed:
                  'molecule_calls', 'n_molecule_calls')
 
 
-def _flatten_inputs(chromosome2compressed_snp_calls, genotypes, want_molecule_table):
-    """var2varid -> per-row key arrays; per-chromosome call containers -> flat call arrays."""
+def _variant_keys(genotypes):
+    """var2varid -> per-row key arrays (chromosome index, position, base code) and the chromosome numbering."""
     n_variants = genotypes.n_variants
     chrom_index = {}
     var_chrom = np.zeros(n_variants, dtype=np.int32)
@@ -52,6 +52,12 @@ def _flatten_inputs(chromosome2compressed_snp_calls, genotypes, want_molecule_ta
         var_pos[row] = pos
         var_base[row] = _BASES[base]
     assert seen.all(), 'var2varid rows must enumerate 0..n_variants-1'  # demux.py:317
+    return (var_chrom, var_pos, var_base), chrom_index
+
+
+def _flatten_inputs(chromosome2compressed_snp_calls, genotypes, want_molecule_table):
+    """var2varid -> per-row key arrays; per-chromosome call containers -> flat call arrays."""
+    (var_chrom, var_pos, var_base), chrom_index = _variant_keys(genotypes)
 
     parts = []
     n_expected = n_taken = 0
@@ -152,15 +158,30 @@ def _pack(chromosome2compressed_snp_calls, genotypes, add_data_prior, want_molec
 
 
 def _pack_on_device(chromosome2compressed_snp_calls, genotypes, n_barcodes, add_data_prior, fetch_betas=True):
-    """The repack of predict / learn: flattening on the host; matching + de-duplication + layout
-    derivation (dmx_pack_and_set_problem) and the regularised prior betas (dmx_set_prior_betas) on the GPU.
+    """The repack of predict / learn, on the GPU: flattening of the containers' records, matching +
+    de-duplication + layout derivation (dmx_pack_containers_and_set_problem) and the regularised prior betas
+    (dmx_set_prior_betas).
     Returns (ctx with the problem and betas resident, regularised prior betas)."""
-    (var_chrom, var_pos, var_base), flat = _flatten_inputs(chromosome2compressed_snp_calls, genotypes, False)
+    from .snp_counter import MOLECULE_DTYPE, SNP_CALL_DTYPE
     v2snp = genotypes.get_snp_ids_for_variants()
     assert np.all(v2snp >= 0)
     ctx = get_context()
-    ctx.pack_and_set_problem(n_barcodes, genotypes.n_genotypes, var_chrom, var_pos, var_base, v2snp,
-                             flat['chrom'], flat['pos'], flat['base'], flat['cb'], flat['p'])
+    containers = list(chromosome2compressed_snp_calls.values())
+    if all(c.snp_calls.dtype == SNP_CALL_DTYPE and c.molecules.dtype == MOLECULE_DTYPE for c in containers):
+        # the containers' packed records go to the GPU as they are and are taken apart there
+        (var_chrom, var_pos, var_base), chrom_index = _variant_keys(genotypes)
+        parts = []
+        for chrom, container in chromosome2compressed_snp_calls.items():
+            if chrom in chrom_index:
+                parts.append((chrom_index[chrom], container.snp_calls[:container.n_snp_calls],
+                              container.molecules[:container.n_molecules]))
+            else:  # demux.py:339-341, 359: calls on a chromosome without variants trip the reference's final assert
+                assert container.n_snp_calls == 0
+        ctx.pack_containers_and_set_problem(n_barcodes, genotypes.n_genotypes, var_chrom, var_pos, var_base, v2snp, parts)
+    else:
+        (var_chrom, var_pos, var_base), flat = _flatten_inputs(chromosome2compressed_snp_calls, genotypes, False)
+        ctx.pack_and_set_problem(n_barcodes, genotypes.n_genotypes, var_chrom, var_pos, var_base, v2snp,
+                                 flat['chrom'], flat['pos'], flat['base'], flat['cb'], flat['p'])
     # regularised prior on the GPU too (molecule counts per variant stay on the device)
     betas = ctx.set_prior_betas(genotypes.get_betas(), genotypes.default_prior, add_data_prior, fetch=fetch_betas)
     return ctx, betas

@@ -61,6 +61,35 @@ class DeviceContext:
         self.B, self.V, self.G, self.N = int(n_barcodes), int(n_variants), int(n_genotypes), n_unique.value
         return n_matched.value, n_unique.value, mol_per_variant
 
+    def pack_containers_and_set_problem(self, n_barcodes, n_genotypes, var_chrom, var_pos, var_base, v2snp, containers):
+        """pack_and_set_problem fed with the raw record arrays of the call containers:
+        `containers` = [(chromosome index, snp_calls[:n] (SNP_CALL_DTYPE), molecules[:m] (MOLECULE_DTYPE))].
+        The field extraction and the molecule -> barcode lookup happen on the GPU."""
+        from .snp_counter import MOLECULE_DTYPE, SNP_CALL_DTYPE
+
+        class Container(ctypes.Structure):
+            _fields_ = [('snp_calls', ctypes.c_void_p), ('n_snp_calls', ctypes.c_int64),
+                        ('molecules', ctypes.c_void_p), ('n_molecules', ctypes.c_int64), ('chrom', ctypes.c_int32)]
+
+        var_chrom, var_pos, var_base = as_c(var_chrom, np.int32), as_c(var_pos, np.int32), as_c(var_base, np.uint8)
+        v2snp = as_c(v2snp, np.int32)
+        n_variants = len(var_pos)
+        assert len(v2snp) == n_variants
+        keep_alive, parts = [], (Container * max(1, len(containers)))()
+        for k, (chrom, snp_calls, molecules) in enumerate(containers):
+            assert snp_calls.dtype == SNP_CALL_DTYPE and molecules.dtype == MOLECULE_DTYPE
+            snp_calls, molecules = np.ascontiguousarray(snp_calls), np.ascontiguousarray(molecules)
+            keep_alive += [snp_calls, molecules]
+            parts[k] = Container(snp_calls.ctypes.data, len(snp_calls), molecules.ctypes.data, len(molecules), int(chrom))
+        mol_per_variant = np.zeros(n_variants, dtype=np.int64)
+        n_matched, n_unique = ctypes.c_int64(0), ctypes.c_int64(0)
+        check(self._lib.dmx_pack_containers_and_set_problem(
+            self._h, n_barcodes, n_variants, n_genotypes, ptr(var_chrom), ptr(var_pos), ptr(var_base), ptr(v2snp),
+            ctypes.cast(parts, ctypes.c_void_p), len(containers), ctypes.byref(n_matched), ctypes.byref(n_unique),
+            ptr(mol_per_variant)))
+        self.B, self.V, self.G, self.N = int(n_barcodes), int(n_variants), int(n_genotypes), n_unique.value
+        return n_matched.value, n_unique.value, mol_per_variant
+
     def get_packed_calls(self):
         """Unique (variant, barcode) calls left on the device by pack_and_set_problem, variant-major."""
         n = self.N

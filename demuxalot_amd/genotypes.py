@@ -159,12 +159,26 @@ class ProbabilisticGenotypes:
         assert external_betas.shape == (self.n_variants, self.n_genotypes)
         assert external_betas.dtype == self.variant_betas.dtype
         assert np.min(external_betas) >= 0
-        out = self.clone()
+        out = self._clone(with_betas=False)
         out.variant_betas = external_betas.copy()
         return out
 
     def clone(self):
-        return deepcopy(self)
+        """Independent copy (genotypes.py:360-361 deep-copies)."""
+        return self._clone(with_betas=True)
+
+    def _clone(self, with_betas):
+        # The keys of var2varid are tuples of str / int: immutable, so sharing them between the copies cannot be
+        # observed, while deep-copying 10^5..10^6 of them dominated learn_genotypes end to end.
+        out = object.__new__(type(self))
+        for name, value in self.__dict__.items():
+            if name == 'var2varid':
+                out.var2varid = dict(value)
+            elif name == 'variant_betas':
+                out.variant_betas = value.copy() if with_betas else None
+            else:
+                setattr(out, name, deepcopy(value))
+        return out
 
     # ---- checkpoint format of learnt genotypes (parquet) ---------------------------------
     def as_pandas_dataframe(self):

@@ -104,6 +104,27 @@ int dmx_pack_and_set_problem(dmx_ctx *ctx, int64_t n_barcodes, int64_t n_variant
 int dmx_get_packed_calls(dmx_ctx *ctx, int32_t *variant_id, int32_t *compressed_cb, float *p_base_wrong,
                          int64_t *barcode_variant_count);
 
+/* The same, fed with the reference's containers as they are (one per chromosome: CompressedSNPCalls.snp_calls
+ * [:n_snp_calls] and .molecules[:n_molecules], demuxalot/snp_counter.py:77-139): the packed numpy records are
+ * uploaded raw and taken apart on the GPU, replacing the per-field flattening of demux.py:332-358.
+ *   snp_calls record (13 bytes, numpy packed): int32 molecule_index, int32 snp_position, uint8 base_index,
+ *                                             float32 p_base_wrong
+ *   molecules record (12 bytes):              int32 compressed_cb, int32 compressed_ub, float32 p_group_misaligned
+ * `chrom` is the chromosome's index in the numbering used by var_chrom.  Call order = container order, then
+ * record order (the order demux.py:339-358 writes molecule_calls in). */
+typedef struct dmx_call_container {
+    const void *snp_calls;
+    int64_t n_snp_calls;
+    const void *molecules;
+    int64_t n_molecules;
+    int32_t chrom;
+} dmx_call_container;
+int dmx_pack_containers_and_set_problem(dmx_ctx *ctx, int64_t n_barcodes, int64_t n_variants, int32_t n_genotypes,
+                                        const int32_t *var_chrom, const int32_t *var_pos, const uint8_t *var_base,
+                                        const int32_t *v2snp, const dmx_call_container *containers,
+                                        int32_t n_containers, int64_t *n_matched, int64_t *n_unique,
+                                        int64_t *mol_per_variant);
+
 /* Regularised prior betas float32[V*G] (output of pack_calls, demux.py:372-388). */
 int dmx_set_betas(dmx_ctx *ctx, const float *prior_betas);
 

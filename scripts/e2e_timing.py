@@ -5,7 +5,10 @@ import numpy as np
 from demuxalot_amd import Demultiplexer, synth
 from demuxalot_amd.demux import _flatten_inputs, _pack_on_device, _prior_betas
 
-for (B, S, G, dp) in ((20000, 20000, 8, 0.35), (50000, 50000, 32, 0.0)):
+sizes = ((20000, 20000, 8, 0.35), (50000, 50000, 32, 0.0))
+if len(sys.argv) > 1 and sys.argv[1] == 'big':
+    sizes = ((200000, 100000, 64, 0.0),)
+for (B, S, G, dp) in sizes:
     p = synth.generate(B, S, G, doublets=dp > 0, seed=7)
     calls, genotypes, handler = synth.as_objects(p)
     Demultiplexer.predict_posteriors(calls, genotypes, handler, doublet_prior=dp)  # warm-up (context, code objects)

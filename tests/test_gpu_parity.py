@@ -171,6 +171,29 @@ def test_device_pack_matches_reference(name):
         assert np.array_equal(variant, fx['pack_bc_variant_id']) and np.array_equal(cb, fx['pack_bc_cb'])
         fio.assert_bitwise(p, fx['pack_bc_p'], 'p_base_wrong products')
         assert np.array_equal(count, fx['pack_bc_variant_count'])
+    # the flat-array entry point (containers of a foreign dtype take it) gives the same problem
+    from demuxalot_amd.demux import _flatten_inputs
+    (var_chrom, var_pos, var_base), flat = _flatten_inputs(calls, genotypes, False)
+    n_matched, n_unique, mol = ctx.pack_and_set_problem(
+        handler.n_barcodes, genotypes.n_genotypes, var_chrom, var_pos, var_base, genotypes.get_snp_ids_for_variants(),
+        flat['chrom'], flat['pos'], flat['base'], flat['cb'], flat['p'])
+    variant2, cb2, p2, count2 = ctx.get_packed_calls()
+    assert np.array_equal(variant2, variant) and np.array_equal(cb2, cb) and np.array_equal(count2, count)
+    fio.assert_bitwise(p2, p, 'flat entry point')
+
+
+def test_container_pack_validates_molecule_index():
+    from demuxalot_amd import CompressedSNPCalls
+    from demuxalot_amd._lib import DemuxHipError
+    from demuxalot_amd.device import get_context
+    c = CompressedSNPCalls.from_arrays([0, 1], [0, 1, 5], [10, 10, 11], [0, 1, 2], [0.1, 0.1, 0.1])  # molecule 5 of 2
+    ctx = get_context()
+    keys = (np.zeros(2, np.int32), np.array([10, 11], np.int32), np.array([0, 2], np.uint8))
+    with pytest.raises(DemuxHipError, match='molecule_index'):
+        ctx.pack_containers_and_set_problem(2, 3, *keys, np.array([0, 1], np.int32),
+                                            [(0, c.snp_calls[:c.n_snp_calls], c.molecules[:c.n_molecules])])
+    # no containers at all: an empty problem
+    assert ctx.pack_containers_and_set_problem(2, 3, *keys, np.array([0, 1], np.int32), [])[:2] == (0, 0)
 
 
 def test_front_end_asserts_like_reference():

@@ -177,3 +177,21 @@ def test_barcode_handler_and_container():
     c.minimize_memory_footprint()
     joined = CompressedSNPCalls.concatenate([c, c])
     assert joined.n_molecules == 4 and list(joined.snp_calls['molecule_index']) == [0, 0, 0, 1, 2, 2, 2, 3]
+
+
+def test_genotype_clone_is_independent():
+    """clone / _with_betas (genotypes.py:327-334, 360-361): nothing is shared that a caller could mutate."""
+    from demuxalot_amd import ProbabilisticGenotypes
+    g = ProbabilisticGenotypes(['A', 'B'])
+    g.var2varid = {('chr1', 5, 'A'): 0, ('chr1', 5, 'C'): 1}
+    g.variant_betas = np.array([[1, 2], [3, 4]], dtype=np.float32)
+    g.extra = {'note': [1, 2]}
+    c = g.clone()
+    c.var2varid[('chr2', 1, 'G')] = 2
+    c.variant_betas[0, 0] = 9
+    c.genotype_names.append('C')
+    c.extra['note'].append(3)
+    assert len(g.var2varid) == 2 and g.variant_betas[0, 0] == 1 and g.genotype_names == ['A', 'B'] and g.extra == {'note': [1, 2]}
+    w = g._with_betas(np.full((2, 2), 7, dtype=np.float32))
+    assert (w.variant_betas == 7).all() and (g.variant_betas != 7).all() and w.var2varid == g.var2varid
+    assert w.var2varid is not g.var2varid and type(w) is type(g)
