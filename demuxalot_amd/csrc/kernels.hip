@@ -540,16 +540,15 @@ __global__ __launch_bounds__(256) void k_estep_block(EstepArgs a, int C)
 }
 
 // ------------------------------------------------------------------------------------
-// M-step.  Work item = a run of <= ITEM_CALLS consecutive CSC calls of one variant.  As in the
-// E-step a wavefront is cut into 64/L lane groups; a group owns one item and walks it in CSC
-// (= reference bincount) order, lane = genotype, float64 accumulation, one float64 partial per
-// item.  Items are handed out from a length-sorted list.
-// Posterior rows are mostly EXACT zeros once genotypes are informative (exp underflows below
-// -103.97), and (0 * keep)^2 = +0 leaves a float64 sum unchanged, so a lane only loads its
-// posterior when the barcode's non-zero bitmap (written by the E-step) has its bit set:
-//   L == 64: call records and bitmap words come through scalar loads, the bitmap becomes the EXEC
-//            mask of the gather (inverse ballot), the row address is an SGPR soffset of a buffer load;
-//   L <  64: per-lane predicate.
+// M-step.  Work item = a run of <= ITEM_CALLS consecutive CSC calls of one variant, owned by one
+// wavefront that walks it in CSC (= reference bincount) order with float64 accumulation and leaves
+// one float64 partial per item.  Items are handed out from a length-sorted list.
+// The E-step leaves a per-barcode bitmap of the posteriors that can contribute (kernels.h:
+// NZ_FLOOR_SQUARE); everything else adds exactly +0 and is never loaded.
+//
+// Genotype-per-lane form (G > 64; A = ceil(G / 64) accumulators per lane): 64 calls per chunk are
+// loaded one per lane, then handled call by call: v_readlane -> SGPRs, the call's bitmap word becomes
+// the EXEC mask of the row gather (inverse ballot), the row address is an SGPR soffset of a buffer load.
 // ------------------------------------------------------------------------------------
 // pair-major operands, as in the E-step: [q][s] = calls 2q (.x) and 2q+1 (.y) of genotype slot s
 template <int A, int H, bool SQUARE>
@@ -573,170 +572,96 @@ static __device__ __forceinline__ void mstep_terms(const npm::f32x2 (&p)[H][A], 
     }
 }
 
-template <int L, int A, int U, bool SQUARE, bool SMALL>
+template <int A, int U, bool SQUARE, bool SMALL>
 __global__ __launch_bounds__(256) void k_mstep(MstepArgs a)
 {
-    static_assert(A == 1 || L == 64, "several accumulators per lane only with 64 lanes per call");
-    static_assert(L % U == 0, "descriptor chunk must be a multiple of the unroll");
-    constexpr int CPW = 64 / L;
+    static_assert(64 % U == 0, "chunk must be a multiple of the unroll");
     const int lane = threadIdx.x & 63;
-    const int li = lane % L;
-    const int gbase = lane - li;
     const int G = a.G;
     const int W = (G + 63) >> 6;
     double acc[A];
 #pragma unroll
     for (int s = 0; s < A; s++) acc[s] = 0.0;
-    long long item;
-    bool live;
 
-    if constexpr (L == 64) {
-        const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-        const long long slot = (long long)blockIdx.x * 4 + wave;
-        if (slot >= a.n_items) return;
-        live = true;
-        item = a.order[slot];
-        const int n = a.item_len[item];
-        const uint2 *__restrict__ calls = a.calls + a.item_start[item];
-        // row offsets fit the 32-bit soffset of a buffer load when the posterior table is < 4 GiB
-        const __amdgpu_buffer_rsrc_t rsrc =
-            __builtin_amdgcn_make_buffer_rsrc((void *)a.post, 0, SMALL ? (int)a.post_bytes : 0, 0x00020000);
-        unsigned voff[A];
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const long long slot = (long long)blockIdx.x * 4 + wave;
+    if (slot >= a.n_items) return;
+    const long long item = a.order[slot];
+    const int n = a.item_len[item];
+    const uint2 *__restrict__ calls = a.calls + a.item_start[item];
+    // row offsets fit the 32-bit soffset of a buffer load when the posterior table is < 4 GiB
+    const __amdgpu_buffer_rsrc_t rsrc =
+        __builtin_amdgcn_make_buffer_rsrc((void *)a.post, 0, SMALL ? (int)a.post_bytes : 0, 0x00020000);
+    unsigned voff[A];
 #pragma unroll
-        for (int s = 0; s < A; s++) voff[s] = (unsigned)(lane + 64 * s) * 4u;
+    for (int s = 0; s < A; s++) voff[s] = (unsigned)(lane + 64 * s) * 4u;
 
-        // 64 calls per chunk, lane i <-> call c0+i: one coalesced load of the records, one gather of the
-        // barcodes' bitmap words, then call by call: readlane -> SGPRs -> EXEC-masked row gather.
-        // Software pipeline: records two chunks ahead, bitmaps one chunk ahead.
-        auto load_records = [&](int c0) {
-            const int ci = c0 + lane;
-            uint2 d = make_uint2(0u, 0u);  // keep bits 0 -> keep = +0: padding adds (p*0)^power = +0
-            if (ci < n) d = calls[ci];
-            return d;
-        };
-        auto load_bitmap = [&](int c0, uint2 d, int s) {
-            unsigned long long m = 0ull;
-            if (c0 + lane < n && (A == 1 || s < W)) m = a.nz[(size_t)d.x * W + s];
-            return m;
-        };
-        uint2 d_cur = load_records(0);
-        uint2 d_nxt = load_records(64);
-        unsigned long long m_cur[A], m_nxt[A];
+    // Software pipeline: records two chunks ahead, bitmaps one chunk ahead.
+    auto load_records = [&](int c0) {
+        const int ci = c0 + lane;
+        uint2 d = make_uint2(0u, 0u);  // keep bits 0 -> keep = +0: padding adds (p*0)^power = +0
+        if (ci < n) d = calls[ci];
+        return d;
+    };
+    auto load_bitmap = [&](int c0, uint2 d, int s) {
+        unsigned long long m = 0ull;
+        if (c0 + lane < n && s < W) m = a.nz[(size_t)d.x * W + s];
+        return m;
+    };
+    uint2 d_cur = load_records(0);
+    uint2 d_nxt = load_records(64);
+    unsigned long long m_cur[A], m_nxt[A];
 #pragma unroll
-        for (int s = 0; s < A; s++) m_cur[s] = load_bitmap(0, d_cur, s);
-        for (int c0 = 0; c0 < n; c0 += 64) {
-            const uint2 d_nn = load_records(c0 + 128);
+    for (int s = 0; s < A; s++) m_cur[s] = load_bitmap(0, d_cur, s);
+    for (int c0 = 0; c0 < n; c0 += 64) {
+        const uint2 d_nn = load_records(c0 + 128);
 #pragma unroll
-            for (int s = 0; s < A; s++) m_nxt[s] = load_bitmap(c0 + 64, d_nxt, s);
-            const float keep_v = __uint_as_float(d_cur.y);
-            const int cnt = (n - c0) < 64 ? (n - c0) : 64;
-            for (int i0 = 0; i0 < cnt; i0 += U) {
-                constexpr int H = U / 2;
-                npm::f32x2 p[H][A], keep[H];
+        for (int s = 0; s < A; s++) m_nxt[s] = load_bitmap(c0 + 64, d_nxt, s);
+        const float keep_v = __uint_as_float(d_cur.y);
+        const int cnt = (n - c0) < 64 ? (n - c0) : 64;
+        for (int i0 = 0; i0 < cnt; i0 += U) {
+            constexpr int H = U / 2;
+            npm::f32x2 p[H][A], keep[H];
 #pragma unroll
-                for (int u = 0; u < U; u++) {
-                    const unsigned cb = (unsigned)__builtin_amdgcn_readlane((int)d_cur.x, i0 + u);
-                    const float kp = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, keep_v), i0 + u));
-                    if (u & 1) keep[u >> 1].y = kp; else keep[u >> 1].x = kp;
-                    const unsigned long long row = (unsigned long long)cb * (unsigned long long)a.K * 4ull;
+            for (int u = 0; u < U; u++) {
+                const unsigned cb = (unsigned)__builtin_amdgcn_readlane((int)d_cur.x, i0 + u);
+                const float kp = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, keep_v), i0 + u));
+                if (u & 1) keep[u >> 1].y = kp; else keep[u >> 1].x = kp;
+                const unsigned long long row = (unsigned long long)cb * (unsigned long long)a.K * 4ull;
 #pragma unroll
-                    for (int s = 0; s < A; s++) {
-                        const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)m_cur[s], i0 + u);
-                        const unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(m_cur[s] >> 32), i0 + u);
-                        const unsigned long long m = ((unsigned long long)hi << 32) | lo;
-                        float v = 0.0f;
-                        if (__builtin_amdgcn_inverse_ballot_w64(m)) {  // EXEC := bitmap
-                            if (SMALL)
-                                v = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(
-                                                                  rsrc, (int)voff[s], (int)(unsigned)row, 0));
-                            else
-                                v = *(const float *)((const char *)a.post + row + voff[s]);
-                        }
-                        if (u & 1) p[u >> 1][s].y = v; else p[u >> 1][s].x = v;
+                for (int s = 0; s < A; s++) {
+                    const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)m_cur[s], i0 + u);
+                    const unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(m_cur[s] >> 32), i0 + u);
+                    const unsigned long long m = ((unsigned long long)hi << 32) | lo;
+                    float v = 0.0f;
+                    if (__builtin_amdgcn_inverse_ballot_w64(m)) {  // EXEC := bitmap
+                        if (SMALL)
+                            v = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(
+                                                              rsrc, (int)voff[s], (int)(unsigned)row, 0));
+                        else
+                            v = *(const float *)((const char *)a.post + row + voff[s]);
                     }
+                    if (u & 1) p[u >> 1][s].y = v; else p[u >> 1][s].x = v;
                 }
-                mstep_terms<A, H, SQUARE>(p, keep, a.power, acc);
             }
-            d_cur = d_nxt;
-            d_nxt = d_nn;
-#pragma unroll
-            for (int s = 0; s < A; s++) m_cur[s] = m_nxt[s];
+            mstep_terms<A, H, SQUARE>(p, keep, a.power, acc);
         }
-    } else {
-        const long long slot = ((long long)blockIdx.x * 4 + (threadIdx.x >> 6)) * CPW + lane / L;
-        live = slot < a.n_items;
-        item = a.order[live ? slot : a.n_items - 1];
-        const int n = live ? a.item_len[item] : 0;
-        const uint2 *__restrict__ calls = a.calls + a.item_start[item];
-        const int nmax = group_max_over_wave<L>(n);
-        const unsigned mybit = 1u << li, li4 = (unsigned)li * 4u, k4 = (unsigned)a.K * 4u;
-        const __amdgpu_buffer_rsrc_t rsrc =
-            __builtin_amdgcn_make_buffer_rsrc((void *)a.post, 0, SMALL ? (int)a.post_bytes : 0, 0x00020000);
-        // records two chunks ahead, bitmaps one chunk ahead (the record -> bitmap -> gather chain is three
-        // dependent loads; without the pipeline a group waits for all of them once per L calls)
-        auto load_records = [&](int c0) {
-            uint2 r = make_uint2(0u, 0u);  // keep bits 0 -> keep = +0: padding adds (p*0)^power = +0
-            if (c0 + li < n) r = calls[c0 + li];
-            return r;
-        };
-        auto load_bitmap = [&](int c0, uint2 r) {
-            unsigned m = 0u;
-            if (c0 + li < n) m = (unsigned)a.nz[(size_t)r.x];  // one word per barcode here (G <= 32)
-            return m;
-        };
-        uint2 d = load_records(0);
-        uint2 d_nxt = load_records(L);
-        unsigned lo_v = load_bitmap(0, d);
-        for (int c0 = 0; c0 < nmax; c0 += L) {
-            const uint2 d_nn = load_records(c0 + 2 * L);
-            const unsigned lo_nxt = load_bitmap(c0 + L, d_nxt);
-            const float keep_v = __uint_as_float(d.y);
-            const int cnt = (nmax - c0) < L ? (nmax - c0) : L;
-            for (int i0 = 0; i0 < cnt; i0 += U) {
-                constexpr int H = U / 2;
-                npm::f32x2 p[H][A], keep[H];
+        d_cur = d_nxt;
+        d_nxt = d_nn;
 #pragma unroll
-                for (int u = 0; u < U; u++) {
-                    const unsigned cb = group_bcast<L>(d.x, i0 + u, gbase);
-                    const float kp = group_bcast<L>(keep_v, i0 + u, gbase);
-                    const unsigned bits = group_bcast<L>(lo_v, i0 + u, gbase);
-                    float v;
-                    if (SMALL) {
-                        // straight-line form: lanes whose bit is clear aim past the end of the buffer; the
-                        // range check of the buffer load returns 0 for them without touching memory
-                        const unsigned off = (bits & mybit) ? __umul24(cb, k4) + li4 : 0xFFFFFFFFu;
-                        v = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, (int)off, 0, 0));
-                    } else {
-                        v = 0.0f;
-                        if (bits & mybit) v = a.post[(size_t)cb * a.K + li];
-                    }
-                    if (u & 1) {
-                        keep[u >> 1].y = kp;
-                        p[u >> 1][0].y = v;
-                    } else {
-                        keep[u >> 1].x = kp;
-                        p[u >> 1][0].x = v;
-                    }
-                }
-                mstep_terms<A, H, SQUARE>(p, keep, a.power, acc);
-            }
-            d = d_nxt;
-            d_nxt = d_nn;
-            lo_v = lo_nxt;
-        }
+        for (int s = 0; s < A; s++) m_cur[s] = m_nxt[s];
     }
 #pragma unroll
     for (int s = 0; s < A; s++) {
-        const int g = li + 64 * s;
-        if (live && g < G) a.partial[(size_t)item * G + g] = acc[s];
+        const int g = lane + 64 * s;
+        if (g < G) a.partial[(size_t)item * G + g] = acc[s];
     }
 }
 
 // ------------------------------------------------------------------------------------
-// M-step, call-parallel form (G <= 64).  The genotype-per-lane form above spends ~8 VALU
-// instructions per call although most barcodes have ONE non-zero posterior (measured on the
-// 200k x 100k x 64 workload: 60% of the barcodes have 1, 35% have all 64; the kernel is
-// issue-bound, not fetch-bound).  Here a wavefront still owns one work item and lane g still owns
+// M-step, call-parallel form (G <= 64).  The genotype-per-lane form above spends ~14 VALU
+// instructions per call although almost every call has ONE posterior that can contribute (200k x
+// 100k x 64 workload: 94.5% of the calls).  Here a wavefront still owns one work item and lane g still owns
 // the float64 accumulator of genotype g, but a chunk of 64 calls is first turned into per-genotype
 // QUEUES in LDS: val[r][g] = the r-th contribution (in call order) to genotype g.  Lane g then adds
 // val[0][g], val[1][g], ... -- exactly the addends of the sequential walk in exactly its order
@@ -751,7 +676,7 @@ __global__ __launch_bounds__(256) void k_mstep(MstepArgs a)
 //     whole wavefront, lane g fetching post[cb_i, g] from the coalesced row.
 // The queues hold R entries; a chunk that could overflow them is processed R calls at a time.
 // ------------------------------------------------------------------------------------
-template <bool SQUARE, int R, int D, bool PRE>
+template <bool SQUARE, int R, int D>
 __global__ __launch_bounds__(256) void k_mstep_calls(MstepArgs a)
 {
     constexpr int NZ_S = 4;  // "sparse" call: at most this many non-zero posteriors
@@ -823,20 +748,18 @@ __global__ __launch_bounds__(256) void k_mstep_calls(MstepArgs a)
         }
     };
 
-    // software pipeline: records three chunks ahead, bitmaps two, posteriors one
+    // software pipeline: records three chunks ahead, bitmaps two, the sparse calls' posteriors one
     uint2 d0 = load_records(0), d1 = load_records(64), d2 = load_records(128);
     u64 m0 = load_bitmap(0, d0), m1 = load_bitmap(64, d1);
     u64 dense0 = __ballot(__popcll(m0) > NZ_S);
-    float ps0[NZ_S], q0[D];
+    float ps0[NZ_S];
     load_sparse(m0, d0, ps0);
-    if (PRE) load_dense_rows(dense0, d0, m0, q0);
     for (int c0 = 0; c0 < n; c0 += 64) {
         const uint2 d3 = load_records(c0 + 192);
         const u64 m2 = load_bitmap(c0 + 128, d2);
         const u64 dense1 = __ballot(__popcll(m1) > NZ_S);
-        float ps1[NZ_S], q1[D];
+        float ps1[NZ_S];
         load_sparse(m1, d1, ps1);
-        if (PRE) load_dense_rows(dense1, d1, m1, q1);
 
         const float keep = __uint_as_float(d0.y);
         const bool is_dense = (dense0 & bit) != 0ull;
@@ -896,16 +819,7 @@ __global__ __launch_bounds__(256) void k_mstep_calls(MstepArgs a)
         if (!__any(__popcll(cm) + __popcll(dense0) > R)) {
             // ---- the whole chunk fits the queues ----
             u64 todo = dense0;
-            if (PRE) {
-#pragma unroll
-                for (int j = 0; j < D; j++) {
-                    if (todo) {
-                        put_dense(__builtin_ctzll(todo), q0[j], cm);
-                        todo &= todo - 1ull;
-                    }
-                }
-            }
-            while (todo) {  // dense calls not prefetched: fetched here, D at a time
+            while (todo) {  // dense calls: rows fetched here, D at a time
                 float q[D];
                 load_dense_rows(todo, d0, m0, q);
 #pragma unroll
@@ -953,10 +867,6 @@ __global__ __launch_bounds__(256) void k_mstep_calls(MstepArgs a)
         dense0 = dense1;
 #pragma unroll
         for (int t = 0; t < NZ_S; t++) ps0[t] = ps1[t];
-        if (PRE) {
-#pragma unroll
-            for (int j = 0; j < D; j++) q0[j] = q1[j];
-        }
     }
     if (lane < G) a.partial[(size_t)item * G + lane] = acc;
 }
@@ -1162,51 +1072,38 @@ hipError_t launch_estep(hipStream_t st, const EstepArgs &a, bool pairs)
     return hipErrorInvalidValue;
 }
 
-template <int L, int A, int U>
+template <int A, int U>
 static void launch_m(hipStream_t st, const MstepArgs &a)
 {
-    const dim3 grid(blocks_for(a.n_items, 4 * (64 / L)));
-    // 32-bit row offsets (buffer soffset / v_mad_u32_u24): posterior table < 4 GiB and barcode ids < 2^24
-    const bool small = a.post_bytes < (1ull << 32) && a.post_bytes / (4ull * (unsigned long long)a.K) < (1ull << 24);
+    const dim3 grid(blocks_for(a.n_items, 4));
+    const bool small = a.post_bytes < (1ull << 32);
     if (a.square && small)
-        hipLaunchKernelGGL((k_mstep<L, A, U, true, true>), grid, dim3(256), 0, st, a);
+        hipLaunchKernelGGL((k_mstep<A, U, true, true>), grid, dim3(256), 0, st, a);
     else if (a.square)
-        hipLaunchKernelGGL((k_mstep<L, A, U, true, false>), grid, dim3(256), 0, st, a);
+        hipLaunchKernelGGL((k_mstep<A, U, true, false>), grid, dim3(256), 0, st, a);
     else if (small)
-        hipLaunchKernelGGL((k_mstep<L, A, U, false, true>), grid, dim3(256), 0, st, a);
+        hipLaunchKernelGGL((k_mstep<A, U, false, true>), grid, dim3(256), 0, st, a);
     else
-        hipLaunchKernelGGL((k_mstep<L, A, U, false, false>), grid, dim3(256), 0, st, a);
+        hipLaunchKernelGGL((k_mstep<A, U, false, false>), grid, dim3(256), 0, st, a);
 }
 
 hipError_t launch_mstep(hipStream_t st, const MstepArgs &a)
 {
     if (a.n_items == 0) return hipSuccess;
     const int G = a.G;
-    static const char *force = getenv("DMX_MSTEP");  // experiment switch: "lanes" = genotype-per-lane form
-    if (G <= 64 && !(force && std::strcmp(force, "lanes") == 0)) {
+    if (G <= 64) {
+        // call-parallel form: 16-entry queues (8 waves per SIMD), dense rows fetched 4 at a time
         const dim3 grid(blocks_for(a.n_items, 4));
-        auto is = [&](const char *name) { return force && std::strcmp(force, name) == 0; };
-        if (!a.square)
-            hipLaunchKernelGGL((k_mstep_calls<false, 16, 4, false>), grid, dim3(256), 0, st, a);
-        else if (is("calls16p"))
-            hipLaunchKernelGGL((k_mstep_calls<true, 16, 8, true>), grid, dim3(256), 0, st, a);
-        else if (is("calls16d8"))
-            hipLaunchKernelGGL((k_mstep_calls<true, 16, 8, false>), grid, dim3(256), 0, st, a);
-        else if (is("calls32"))
-            hipLaunchKernelGGL((k_mstep_calls<true, 32, 4, false>), grid, dim3(256), 0, st, a);
+        if (a.square)
+            hipLaunchKernelGGL((k_mstep_calls<true, 16, 4>), grid, dim3(256), 0, st, a);
         else
-            hipLaunchKernelGGL((k_mstep_calls<true, 16, 4, false>), grid, dim3(256), 0, st, a);
+            hipLaunchKernelGGL((k_mstep_calls<false, 16, 4>), grid, dim3(256), 0, st, a);
         return hipGetLastError();
     }
-    if (G <= 4) launch_m<4, 1, 4>(st, a);
-    else if (G <= 8) launch_m<8, 1, 8>(st, a);
-    else if (G <= 16) launch_m<16, 1, 8>(st, a);
-    else if (G <= 32) launch_m<32, 1, 8>(st, a);
-    else if (G <= 64) launch_m<64, 1, 8>(st, a);
-    else if (G <= 128) launch_m<64, 2, 4>(st, a);
-    else if (G <= 256) launch_m<64, 4, 2>(st, a);
-    else if (G <= 512) launch_m<64, 8, 2>(st, a);
-    else if (G <= 1024) launch_m<64, 16, 2>(st, a);
+    if (G <= 128) launch_m<2, 4>(st, a);
+    else if (G <= 256) launch_m<4, 2>(st, a);
+    else if (G <= 512) launch_m<8, 2>(st, a);
+    else if (G <= 1024) launch_m<16, 2>(st, a);
     else return hipErrorInvalidValue;
     return hipGetLastError();
 }
