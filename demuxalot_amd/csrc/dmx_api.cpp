@@ -171,10 +171,8 @@ int ensure_options(dmx_ctx *c, int with_doublets, const float *penalties)
     const int G = c->G;
     const long long K = with_doublets ? (long long)G * (G + 1) / 2 : G;
     if (K > (1 << 24)) return fail(DMX_ERR_UNSUPPORTED, "too many options (%lld)", K);
-    if (!with_doublets && G > 1024)
-        return fail(DMX_ERR_UNSUPPORTED, "more than 1024 genotypes are not supported without doublets yet (G=%d)", G);
-    if (with_doublets && (K + 255) / 256 > 65)
-        return fail(DMX_ERR_UNSUPPORTED, "doublets with G=%d (K=%lld options) exceed the per-workgroup accumulator budget", G, K);
+    if (G > 1024)  // one lane holds at most 16 genotype accumulators (E- and M-step); the block form stages G rows in LDS
+        return fail(DMX_ERR_UNSUPPORTED, "more than 1024 genotypes are not supported (G=%d)", G);
     if (K > c->cap_k) {
         dev_free(c, &c->d_pen, (size_t)c->cap_k);
         dev_free(c, &c->d_pairs, (size_t)c->cap_k);

@@ -414,8 +414,10 @@ __global__ __launch_bounds__(256) void k_estep_direct(EstepArgs a)
 // consecutive pairs (g1, g2): g1 is (nearly) wave-uniform -> LDS broadcast; g2 is consecutive ->
 // lane stride (C+2) dwords, conflict-free inside each 32-lane service group of ds_read_b64.
 // ------------------------------------------------------------------------------------
-template <int A>
-__global__ __launch_bounds__(256) void k_estep_block(EstepArgs a, int C)
+// K > 33 * 256 options (doublets of more than 129 genotypes): the options are cut into tiles of 33 * 256, each
+// tile is one launch that only leaves its logits (TILED), and k_softmax_rows finishes the rows.
+template <int A, bool TILED>
+__global__ __launch_bounds__(256) void k_estep_block(EstepArgs a, int C, int k_base)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -432,7 +434,7 @@ __global__ __launch_bounds__(256) void k_estep_block(EstepArgs a, int C)
     unsigned a1[A], a2[A];  // LDS dword index of the (g1, .) and (g2, .) rows of this thread's options
 #pragma unroll
     for (int s = 0; s < A; s++) {
-        const int k = s * 256 + tid;
+        const int k = k_base + s * 256 + tid;
         const unsigned pr = a.opt_pairs[k < K ? k : K - 1];
         a1[s] = (pr & 0xFFFFu) * (unsigned)CS;
         a2[s] = (pr >> 16) * (unsigned)CS;
@@ -465,7 +467,7 @@ __global__ __launch_bounds__(256) void k_estep_block(EstepArgs a, int C)
             const npm::f32x2 flo2 = *(const npm::f32x2 *)(sh_floor + c);
 #pragma unroll
             for (int s = 0; s < A; s++) {
-                if (s * 256 + wave * 64 >= K) continue;  // wave-uniform: this wave's slot lies past the last option
+                if (k_base + s * 256 + wave * 64 >= K) continue;  // wave-uniform: this wave's slot lies past the last option
                 const npm::f32x2 pa = *(const npm::f32x2 *)(sh_t + a1[s] + c);
                 const npm::f32x2 pb = *(const npm::f32x2 *)(sh_t + a2[s] + c);
                 npm::f32x2 t = ((pa + pb) * 0.5f) * keep2;
@@ -485,7 +487,7 @@ __global__ __launch_bounds__(256) void k_estep_block(EstepArgs a, int C)
     float lg[A];
 #pragma unroll
     for (int s = 0; s < A; s++) {
-        const int k = s * 256 + tid;
+        const int k = k_base + s * 256 + tid;
         if (k < K) {
             const double t = (double)a.pen[k] + acc[s];
             float l = (float)t;
@@ -498,10 +500,12 @@ __global__ __launch_bounds__(256) void k_estep_block(EstepArgs a, int C)
             }
             lg[s] = l;
             mx = fmaxf(mx, l);
+            if (TILED) a.logits[(size_t)b * K + k] = l;
         } else {
             lg[s] = -__builtin_inff();
         }
     }
+    if (TILED) return;  // (uniform) the softmax needs all tiles: k_softmax_rows
 #pragma unroll
     for (int off = 1; off < 64; off <<= 1) mx = fmaxf(mx, __shfl_xor(mx, off));
     if (lane == 0) sh_red[wave] = mx;
@@ -535,6 +539,49 @@ __global__ __launch_bounds__(256) void k_estep_block(EstepArgs a, int C)
             const unsigned long long bal = __ballot(k < G && !(post <= a.nz_floor));
             if (lane == 0 && wave < W) a.nz[(size_t)b * W + wave] = bal;
             if (a.first && wave == 0 && bal != 0ull && lane == __builtin_ctzll(bal)) a.first[b] = post;
+        }
+    }
+}
+
+// Softmax of complete logit rows of any length (after the tiled block form): one workgroup per barcode, the
+// exponentials parked in the posterior row itself, numpy-ordered sum by wave 0, bitmap of the singlet columns.
+__global__ __launch_bounds__(256) void k_softmax_rows(EstepArgs a)
+{
+    __shared__ float sh_red[8];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const long long b = blockIdx.x;
+    const int K = a.K, G = a.G;
+    const float *__restrict__ lg = a.logits + (size_t)b * K;
+    float *post = a.post + (size_t)b * K;
+    float mx = -__builtin_inff();
+    for (int k = tid; k < K; k += 256) mx = fmaxf(mx, lg[k]);
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) mx = fmaxf(mx, __shfl_xor(mx, off));
+    if (lane == 0) sh_red[wave] = mx;
+    __syncthreads();
+    mx = fmaxf(fmaxf(sh_red[0], sh_red[1]), fmaxf(sh_red[2], sh_red[3]));
+    for (int k = tid; k < K; k += 256) post[k] = npm::exp_f32(lg[k] - mx);
+    __threadfence_block();
+    __syncthreads();
+    if (wave == 0) {
+        const float tot = npm::row_sum_wave(post, K, lane);
+        if (lane == 0) sh_red[4] = tot;
+    }
+    __syncthreads();
+    const float tot = sh_red[4];
+    const int W = (G + 63) >> 6;
+    for (int k0 = 0; k0 < K; k0 += 256) {  // uniform trip count: the ballots below need whole waves
+        const int k = k0 + tid;
+        float p = 0.0f;
+        if (k < K) {
+            p = post[k] / tot;
+            post[k] = p;
+        }
+        if (k0 < G) {
+            const unsigned long long bal = __ballot(k < G && !(p <= a.nz_floor));
+            const int word = (k0 >> 6) + wave;
+            if (lane == 0 && word < W) a.nz[(size_t)b * W + word] = bal;
+            if (a.first && word == 0 && bal != 0ull && lane == __builtin_ctzll(bal)) a.first[b] = p;
         }
     }
 }
@@ -1021,19 +1068,19 @@ static void launch_direct(hipStream_t st, const EstepArgs &a, bool pairs)
         hipLaunchKernelGGL((k_estep_direct<L, A, false, U>), grid, block, 0, st, a);
 }
 
-template <int A>
-static hipError_t launch_block(hipStream_t st, const EstepArgs &a)
+template <int A, bool TILED>
+static hipError_t launch_block(hipStream_t st, const EstepArgs &a, int k_base = 0)
 {
     int C = (16384 / (4 * a.G)) & ~7;  // calls staged per chunk: multiple of the 8-call row padding
     C = C < 8 ? 8 : (C > 128 ? 128 : C);
     size_t stage = (size_t)(C + 2) * a.G * 4 + (size_t)C * 12;
-    size_t soft = (size_t)a.K * 4 + 64;
+    size_t soft = TILED ? 0 : (size_t)a.K * 4 + 64;
     size_t bytes = stage > soft ? stage : soft;
     bytes = (bytes + 15) & ~size_t(15);
-    hipError_t e = hipFuncSetAttribute((const void *)k_estep_block<A>, hipFuncAttributeMaxDynamicSharedMemorySize,
+    hipError_t e = hipFuncSetAttribute((const void *)k_estep_block<A, TILED>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                        (int)bytes);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL((k_estep_block<A>), dim3((unsigned)a.B), dim3(256), bytes, st, a, C);
+    hipLaunchKernelGGL((k_estep_block<A, TILED>), dim3((unsigned)a.B), dim3(256), bytes, st, a, C, k_base);
     return hipGetLastError();
 }
 
@@ -1058,18 +1105,24 @@ hipError_t launch_estep(hipStream_t st, const EstepArgs &a, bool pairs)
     }
     if (!pairs) return hipErrorInvalidValue;  // K = G > 1024 singlets: not supported (checked by the caller)
     const int need = (K + 255) / 256;
-    if (need <= 2) return launch_block<2>(st, a);
-    if (need <= 3) return launch_block<3>(st, a);
-    if (need <= 4) return launch_block<4>(st, a);
-    if (need <= 6) return launch_block<6>(st, a);
-    if (need <= 8) return launch_block<8>(st, a);
-    if (need <= 12) return launch_block<12>(st, a);
-    if (need <= 16) return launch_block<16>(st, a);
-    if (need <= 24) return launch_block<24>(st, a);
-    if (need <= 33) return launch_block<33>(st, a);
-    if (need <= 48) return launch_block<48>(st, a);
-    if (need <= 65) return launch_block<65>(st, a);
-    return hipErrorInvalidValue;
+    if (need <= 2) return launch_block<2, false>(st, a);
+    if (need <= 3) return launch_block<3, false>(st, a);
+    if (need <= 4) return launch_block<4, false>(st, a);
+    if (need <= 6) return launch_block<6, false>(st, a);
+    if (need <= 8) return launch_block<8, false>(st, a);
+    if (need <= 12) return launch_block<12, false>(st, a);
+    if (need <= 16) return launch_block<16, false>(st, a);
+    if (need <= 24) return launch_block<24, false>(st, a);
+    if (need <= 33) return launch_block<33, false>(st, a);
+    // more options than 33 per thread: tiles of 33 * 256 options, each tile one launch that leaves its logits,
+    // then the softmax over complete rows.  (Tiles of 65 accumulators per thread -- 385 VGPRs plus SGPR spills --
+    // ended in GPU memory faults that 33-wide tiles of the same source do not show; cause not established.)
+    for (int k_base = 0; k_base < K; k_base += 33 * 256) {
+        const hipError_t e = launch_block<33, true>(st, a, k_base);
+        if (e != hipSuccess) return e;
+    }
+    hipLaunchKernelGGL(k_softmax_rows, dim3((unsigned)a.B), dim3(256), 0, st, a);
+    return hipGetLastError();
 }
 
 template <int A, int U>

@@ -1,0 +1,48 @@
+"""Wider randomised parity sweep than the test suite runs (GPU box): python scripts/parity_sweep.py [n_seeds]
+Reuses the suite's own randomised EM check with more seeds, then mid-size EM problems with random G, density and
+iteration counts against the numpy oracle (everything bitwise)."""
+import os
+import sys
+import time
+import numpy as np
+root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, root)
+sys.path.insert(0, os.path.join(root, 'tests'))
+import subprocess
+subprocess.check_call(["make", "-s", "-C", os.path.join(root, "oracle")])
+import fixture_io as fio
+import test_gpu_parity as T
+from oracle import demux_oracle as oracle
+
+oracle.load_npsimd()
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 100
+t0 = time.time()
+for seed in range(10, 10 + n):
+    print('seed', seed, flush=True)
+    T.test_randomised_em_against_oracle(oracle, seed)
+print(f'{n} randomised EM problems ok ({time.time() - t0:.0f} s)', flush=True)
+
+from demuxalot_amd import synth
+from demuxalot_amd.device import get_context
+rng = np.random.default_rng(5)
+for trial in range(int(sys.argv[2]) if len(sys.argv) > 2 else 12):
+    G = int(rng.choice([2, 3, 4, 6, 8, 12, 16, 24, 32, 33, 48, 63, 64, 65, 96, 128]))
+    B = int(rng.integers(500, 6000))
+    S = int(rng.integers(200, 3000))
+    cpb = int(rng.choice([20, 60, 150, 400, 900]))
+    n_it = int(rng.integers(1, 4))
+    clip = float(rng.choice([0.01, 0.0, 0.05]))
+    p = synth.generate(B, S, G, calls_per_barcode=min(cpb, S), seed=1000 + trial)
+    betas = p.prior_betas()
+    ctx = get_context()
+    ctx.set_problem(p.n_barcodes, p.n_variants, G, p.variant_id, p.compressed_cb, p.p_base_wrong, p.v2snp)
+    ctx.set_betas(betas)
+    pen = np.zeros(G, dtype=np.float32)
+    logits, probs, addition = ctx.em(n_it, clip, pen, with_doublets=False)
+    packed = dict(variant_id=p.variant_id, compressed_cb=p.compressed_cb, p_base_wrong=p.p_base_wrong, betas=betas, v2snp=p.v2snp)
+    hist = oracle.em(packed, p.n_barcodes, n_it, clip, 0., impl='npsimd')
+    what = f'trial {trial}: G={G} B={B} S={S} cpb={cpb} it={n_it} clip={clip} N={p.n_calls}'
+    T.check_posteriors(logits, probs, hist[-1]['logits'], hist[-1]['probs'], what)
+    fio.assert_bitwise(addition, hist[-1]['addition'], what + ' addition')
+    print('ok', what, flush=True)
+print(f'sweep done in {time.time() - t0:.0f} s')

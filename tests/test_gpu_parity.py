@@ -459,12 +459,14 @@ def test_midsize_em_matches_oracle(oracle):
 
 
 def test_doublets_block_kernel_matches_oracle(oracle):
-    """K > 256 options (block kernel): 40 genotypes with doublets (K = 820), and 128 (K = 8256 > 8192)."""
+    """K > 256 options (block kernel): 40 genotypes with doublets (K = 820), 128 (K = 8256 > 8192, the widest
+    single launch), and 140 / 190 / 270 (K = 9870 / 18 145 / 36 585 > 33 * 256: the options are tiled over several
+    launches and k_softmax_rows finishes the rows)."""
     from demuxalot_amd import synth
     from demuxalot_amd.device import get_context
     from demuxalot_amd import Demultiplexer
-    for G, B in ((40, 300), (128, 24)):
-        p = synth.generate(B, 500, G, calls_per_barcode=80, doublets=True, seed=G)
+    for G, B in ((40, 300), (128, 24), (140, 16), (190, 12), (270, 9)):
+        p = synth.generate(B, 500, G, calls_per_barcode=80 if G < 140 else 30, doublets=True, seed=G)
         betas = p.prior_betas()
         ctx = get_context()
         ctx.set_problem(B, p.n_variants, G, p.variant_id, p.compressed_cb, p.p_base_wrong, p.v2snp)
