@@ -53,6 +53,7 @@ SIGNATURES = {
     'dmx_get_timings': (c_int, [_P, POINTER(c_double), POINTER(c_int64)]),
     'dmx_reset_timings': (c_int, [_P]),
     'dmx_device_bytes': (c_int, [_P, POINTER(c_int64)]),
+    'dmx_set_exact_additions': (c_int, [_P, c_int]),
     'dmx_test_logf': (c_int, [_P, _P, _P, c_int64]),
     'dmx_test_logf_hot': (c_int, [_P, _P, _P, c_int64]),
     'dmx_test_expf': (c_int, [_P, _P, _P, c_int64]),

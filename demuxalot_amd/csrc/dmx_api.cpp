@@ -138,6 +138,9 @@ void release_problem(dmx_ctx *c)
     dev_free(c, &c->d_prob, vg);
     dev_free(c, &c->d_add64, vg);
     dev_free(c, &c->d_partial, (size_t)c->n_items * c->G);
+    dev_free(c, &c->d_redo, c->cap_redo);
+    dev_free(c, &c->d_n_redo, (size_t)1);
+    c->cap_redo = 0;
     dev_free(c, &c->d_logits, (size_t)c->cap_bk);
     dev_free(c, &c->d_post, (size_t)c->cap_bk);
     c->cap_bk = 0;
@@ -295,7 +298,7 @@ int run_mstep(dmx_ctx *c, float power)
         HIP_TRY(dmx::launch_mstep(c->stream, a));
         timer_end(c, DMX_T_MSTEP, ev);
         timer_begin(c, DMX_T_MCOMBINE, &ev);
-        HIP_TRY(dmx::launch_mcombine(c->stream, c->d_partial, c->d_item_ptr, 0, c->V, c->G, c->d_add, nullptr));
+        HIP_TRY(dmx::launch_mcombine(c->stream, a, c->d_item_ptr, 0, c->V, c->d_add, nullptr, c->exact_additions ? c->d_redo : nullptr, c->d_n_redo));
         timer_end(c, DMX_T_MCOMBINE, ev);
         return 0;
     }
@@ -311,8 +314,8 @@ int run_mstep(dmx_ctx *c, float power)
         a.order = c->d_item_order_chunked + c->chunk_item[k];
         a.n_items = c->chunk_item[k + 1] - c->chunk_item[k];
         HIP_TRY(dmx::launch_mstep(c->stream, a));
-        HIP_TRY(dmx::launch_mcombine(c->stream, c->d_partial, c->d_item_ptr, v0, v1, c->G, f64 ? nullptr : c->d_add,
-                                     f64 ? c->d_add64 : nullptr));
+        HIP_TRY(dmx::launch_mcombine(c->stream, a, c->d_item_ptr, v0, v1, f64 ? nullptr : c->d_add,
+                                     f64 ? c->d_add64 : nullptr, c->exact_additions ? c->d_redo : nullptr, c->d_n_redo));
         HIP_TRY(hipEventRecord(c->ev_chunk[k], c->stream));
         HIP_TRY(hipStreamWaitEvent(c->comm_stream, c->ev_chunk[k], 0));
         const size_t off = (size_t)v0 * c->G, cnt = (size_t)(v1 - v0) * c->G;
@@ -476,6 +479,9 @@ static int finish_problem(dmx_ctx *c, const int32_t *v2snp, const std::vector<in
     DMX_TRY(dev_alloc(c, &c->d_prob, vg));
     DMX_TRY(dev_alloc(c, &c->d_add64, vg));
     DMX_TRY(dev_alloc(c, &c->d_partial, (size_t)c->n_items * G));
+    c->cap_redo = ((size_t)c->n_items / 2 + 1) * (size_t)G;  // a variant queues at most G sums and only with >= 2 items
+    DMX_TRY(dev_alloc(c, &c->d_redo, c->cap_redo));
+    DMX_TRY(dev_alloc(c, &c->d_n_redo, (size_t)1));
     DMX_TRY(dev_alloc(c, &c->d_nz, (size_t)B * ((G + 63) / 64)));
     DMX_TRY(dev_alloc(c, &c->d_first, (size_t)B));
     DMX_TRY(dev_alloc(c, &c->d_best, (size_t)B));
@@ -565,6 +571,13 @@ int dmx_get_packed_calls(dmx_ctx *c, int32_t *variant_id, int32_t *cb, float *p_
     if (p_wrong && n) HIP_TRY(hipMemcpyAsync(p_wrong, c->d_u_p, sizeof(float) * n, hipMemcpyDeviceToHost, c->stream));
     if (count && n) HIP_TRY(hipMemcpyAsync(count, c->d_u_count, sizeof(long long) * n, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
+    return 0;
+}
+
+int dmx_set_exact_additions(dmx_ctx *c, int exact)
+{
+    if (!c) return fail(DMX_ERR_INVALID, "null context");
+    c->exact_additions = exact != 0;
     return 0;
 }
 

@@ -59,6 +59,10 @@ struct dmx_ctx {
     double *d_add64 = nullptr, *d_partial = nullptr;
     float *d_logits = nullptr, *d_post = nullptr;
     unsigned long long *d_nz = nullptr;
+    unsigned long long *d_redo = nullptr;  // (variant, genotype) sums to be redone in order (k_mcombine)
+    unsigned *d_n_redo = nullptr;
+    size_t cap_redo = 0;
+    bool exact_additions = false;  // dmx_set_exact_additions
     float nz_floor = 0.0f;     // threshold the current d_nz / d_first were built with
     float *d_first = nullptr;  // [B] posterior of the lowest non-zero singlet column (G <= 64)
     long long cap_bk = 0;

@@ -72,9 +72,10 @@ hipError_t launch_probs_from_betas(hipStream_t st, const float *prior, const flo
                                    float *prob);
 hipError_t launch_estep(hipStream_t st, const EstepArgs &a, bool pairs);
 hipError_t launch_mstep(hipStream_t st, const MstepArgs &a);
-// sums the item partials of variants [v0, v1)
-hipError_t launch_mcombine(hipStream_t st, const double *partial, const long long *item_ptr, long long v0, long long v1,
-                           int G, float *add32, double *add64);
+// sums the item partials of variants [v0, v1) and redoes, in the reference's order, the sums whose float32
+// rounding could depend on the order (redo: queue of capacity (n_items / 2 + 1) * G entries, n_redo: its counter)
+hipError_t launch_mcombine(hipStream_t st, const MstepArgs &a, const long long *item_ptr, long long v0, long long v1,
+                           float *add32, double *add64, unsigned long long *redo, unsigned *n_redo);
 hipError_t launch_f64_to_f32(hipStream_t st, const double *in, float *out, long long n);
 hipError_t launch_f32_to_f64(hipStream_t st, const float *in, double *out, long long n);
 hipError_t launch_prior_betas(hipStream_t st, const float *betas, float *bsum, const unsigned long long *n_mol,

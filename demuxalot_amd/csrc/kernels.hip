@@ -936,21 +936,112 @@ __global__ __launch_bounds__(256) void k_rebuild_nz(const float *__restrict__ po
     if (first && W == 1 && bal != 0ull && lane == __builtin_ctzll(bal)) first[b] = p;
 }
 
-// sums the item partials of each variant in item order; writes float32 (single GPU) or the
-// float64 total that goes into the all-reduce
+// Sums the item partials of each variant in item order; writes float32 (single GPU) or the float64 total
+// that goes into the all-reduce.
+// A variant with more than ITEM_CALLS calls has several items, and adding their float64 partials is not the
+// reference's single left-to-right float64 sum: the two can differ in the last bits, which matters exactly when
+// the total sits next to a float32 rounding boundary -- and it often sits ON one (a sum of a few hundred float32
+// squares of similar size is an exact float64 whose bits below the float32 precision are ...1000 about once in
+// as many entries as it has addends), where a contribution of 1e-20 decides the rounding.  In exact mode (dmx_set_exact_additions; `redo`
+// non-null) the combined sum is only accepted when no float32 rounding boundary lies within the error bound of
+// either summation order
+//     |S_seq - S_comb| <= 2 n u S   (non-negative addends, n calls, u = 2^-53; 4 n u S is used),
+// and the (variant, genotype) pair is otherwise queued for k_mstep_exact, which redoes that one sum in order.
 __global__ __launch_bounds__(256) void k_mcombine(const double *__restrict__ partial,
-                                                  const long long *__restrict__ item_ptr, long long v0, long long v1, int G,
-                                                  float *__restrict__ add32, double *__restrict__ add64)
+                                                  const long long *__restrict__ item_ptr,
+                                                  const long long *__restrict__ item_start,
+                                                  const int *__restrict__ item_len, long long v0, long long v1, int G,
+                                                  float *__restrict__ add32, double *__restrict__ add64,
+                                                  unsigned long long *__restrict__ redo, unsigned *__restrict__ n_redo)
 {
     const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= (v1 - v0) * G) return;
     const long long v = v0 + i / G;
     const int g = (int)(i % G);
+    const long long it0 = item_ptr[v], it1 = item_ptr[v + 1];
     double s = 0.0;
-    for (long long it = item_ptr[v]; it < item_ptr[v + 1]; it++) s += partial[(size_t)it * G + g];
+    for (long long it = it0; it < it1; it++) s += partial[(size_t)it * G + g];
     const long long o = v * G + g;
     if (add64) add64[o] = s;
     if (add32) add32[o] = (float)s;
+    if (redo && it1 - it0 > 1 && s > 0.0) {
+        const long long n = item_start[it1 - 1] + item_len[it1 - 1] - item_start[it0];
+        const double bound = 4.0 * (double)n * 1.1102230246251565e-16 * s;
+        const float f = (float)s;
+        const double lo = 0.5 * ((double)f + (double)nextafterf(f, 0.0f));  // rounding boundary towards zero
+        const double hi = 0.5 * ((double)f + (double)nextafterf(f, __builtin_inff()));
+        if (!(s - bound > lo && s + bound < hi))
+            redo[atomicAdd(n_redo, 1u)] = ((unsigned long long)v << 16) | (unsigned long long)g;
+    }
+}
+
+// The queued sums, redone exactly as the reference does them: all calls of the variant, in order, into ONE float64
+// accumulator.  A 512-thread workgroup per queued (variant, genotype) pair (persistent: the queue length is only
+// known on the device).  The variant is walked in segments of 8 x ITEM_CALLS calls: each of the 8 wavefronts
+// collects the non-zero contributions of its 1024 calls to the genotype in LDS (call order), then wavefront 0 adds
+// the 8 lists in order.  The gathers -- the expensive part -- run in parallel; only the additions are serial.
+constexpr int EXACT_WAVES = 8;
+template <bool SQUARE>
+__global__ __launch_bounds__(64 * EXACT_WAVES) void k_mstep_exact(MstepArgs a, const long long *__restrict__ item_ptr,
+                                                                  const unsigned long long *__restrict__ redo,
+                                                                  const unsigned *__restrict__ n_redo,
+                                                                  float *__restrict__ add32, double *__restrict__ add64)
+{
+    __shared__ float sh_c[EXACT_WAVES][ITEM_CALLS];
+    __shared__ int sh_cnt[EXACT_WAVES];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    float *mine = sh_c[wave];
+    const unsigned count = *n_redo;
+    const int W = (a.G + 63) >> 6;
+    for (unsigned e = blockIdx.x; e < count; e += gridDim.x) {
+        const unsigned long long entry = redo[e];
+        const long long v = (long long)(entry >> 16);
+        const int g = (int)(entry & 0xFFFFull);
+        const long long it0 = item_ptr[v], it1 = item_ptr[v + 1];
+        const long long first = a.item_start[it0];
+        const long long n = a.item_start[it1 - 1] + a.item_len[it1 - 1] - first;
+        const uint2 *__restrict__ calls = a.calls + first;
+        double acc = 0.0;  // meaningful in wavefront 0
+        for (long long seg = 0; seg < n; seg += (long long)EXACT_WAVES * ITEM_CALLS) {
+            const long long lo = seg + (long long)wave * ITEM_CALLS;
+            const long long hi = lo + ITEM_CALLS < n ? lo + ITEM_CALLS : n;
+            int cnt = 0;
+            for (long long c0 = lo; c0 < hi; c0 += 64) {
+                float c = 0.0f;
+                bool live = false;
+                if (c0 + lane < hi) {
+                    const uint2 d = calls[c0 + lane];
+                    live = (a.nz[(size_t)d.x * W + (g >> 6)] >> (g & 63)) & 1ull;
+                    if (live) {
+                        c = a.post[(size_t)d.x * a.K + g] * __uint_as_float(d.y);
+                        c = SQUARE ? c * c : powf(c, a.power);
+                    }
+                }
+                const unsigned long long bal = __ballot(live);
+                if (live) mine[cnt + __popcll(bal & ((1ull << lane) - 1ull))] = c;
+                cnt += __popcll(bal);
+            }
+            if (lane == 0) sh_cnt[wave] = cnt;
+            __syncthreads();
+            if (wave == 0) {
+                for (int w = 0; w < EXACT_WAVES; w++) {
+                    const int cw = sh_cnt[w];
+                    for (int base = 0; base < cw; base += 64) {
+                        const float x = base + lane < cw ? sh_c[w][base + lane] : 0.0f;
+                        const int m = (cw - base) < 64 ? (cw - base) : 64;
+                        for (int i = 0; i < m; i++)
+                            acc += (double)__builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, x), i));
+                    }
+                }
+            }
+            __syncthreads();
+        }
+        if (threadIdx.x == 0) {
+            if (add32) add32[v * a.G + g] = (float)acc;
+            if (add64) add64[v * a.G + g] = acc;
+        }
+    }
 }
 
 __global__ __launch_bounds__(256) void k_f64_to_f32(const double *__restrict__ in, float *__restrict__ out, long long n)
@@ -1161,12 +1252,23 @@ hipError_t launch_mstep(hipStream_t st, const MstepArgs &a)
     return hipGetLastError();
 }
 
-hipError_t launch_mcombine(hipStream_t st, const double *partial, const long long *item_ptr, long long v0, long long v1,
-                           int G, float *add32, double *add64)
+hipError_t launch_mcombine(hipStream_t st, const MstepArgs &a, const long long *item_ptr, long long v0, long long v1,
+                           float *add32, double *add64, unsigned long long *redo, unsigned *n_redo)
 {
-    if ((v1 - v0) * G <= 0) return hipSuccess;
-    hipLaunchKernelGGL(k_mcombine, dim3(blocks_for((v1 - v0) * G, 256)), dim3(256), 0, st, partial, item_ptr, v0, v1, G,
-                       add32, add64);
+    if ((v1 - v0) * a.G <= 0) return hipSuccess;
+    if (redo) {
+        const hipError_t e = hipMemsetAsync(n_redo, 0, sizeof(unsigned), st);
+        if (e != hipSuccess) return e;
+    }
+    hipLaunchKernelGGL(k_mcombine, dim3(blocks_for((v1 - v0) * a.G, 256)), dim3(256), 0, st, a.partial, item_ptr,
+                       a.item_start, a.item_len, v0, v1, a.G, add32, add64, redo, n_redo);
+    if (!redo) return hipGetLastError();
+    // exact mode: the sums that must be redone in the reference's order (see k_mcombine)
+    const dim3 grid(512), block(64 * EXACT_WAVES);
+    if (a.square)
+        hipLaunchKernelGGL((k_mstep_exact<true>), grid, block, 0, st, a, item_ptr, redo, n_redo, add32, add64);
+    else
+        hipLaunchKernelGGL((k_mstep_exact<false>), grid, block, 0, st, a, item_ptr, redo, n_redo, add32, add64);
     return hipGetLastError();
 }
 

@@ -228,6 +228,10 @@ class DeviceContext:
         buf = ctypes.create_string_buffer(unique_id, _lib.UNIQUE_ID_BYTES)
         check(self._lib.dmx_comm_init(self._h, int(rank), int(nranks), buf, DMX_F64 if reduce_dtype == 'f64' else DMX_F32))
 
+    def set_exact_additions(self, exact):
+        """M-step summation mode (include/demux_hip.h: dmx_set_exact_additions). Default: off."""
+        check(self._lib.dmx_set_exact_additions(self._h, int(bool(exact))))
+
     # ---- instrumentation ----------------------------------------------------------------
     def timings(self):
         ms = (ctypes.c_double * _lib.T_COUNT)()
@@ -285,4 +289,6 @@ def get_context(device=None) -> DeviceContext:
     device = default_device() if device is None else int(device)
     if device not in _contexts:
         _contexts[device] = DeviceContext(device)
+        # DEMUXALOT_AMD_EXACT_ADDITIONS=1: bit-identical genotype additions also for variants with > 1024 calls
+        _contexts[device].set_exact_additions(os.environ.get('DEMUXALOT_AMD_EXACT_ADDITIONS', '0') not in ('', '0'))
     return _contexts[device]

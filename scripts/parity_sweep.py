@@ -1,10 +1,11 @@
-"""Wider randomised parity sweep than the test suite runs (GPU box): python scripts/parity_sweep.py [n_seeds]
+"""Wider randomised parity sweep than the test suite runs (GPU box): python scripts/parity_sweep.py [n_seeds] [n_trials] [first_seed]
 Reuses the suite's own randomised EM check with more seeds, then mid-size EM problems with random G, density and
 iteration counts against the numpy oracle (everything bitwise)."""
 import os
 import sys
 import time
 import numpy as np
+os.environ.setdefault('DEMUXALOT_AMD_EXACT_ADDITIONS', '1')  # additions are compared bit for bit
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, root)
 sys.path.insert(0, os.path.join(root, 'tests'))
@@ -17,14 +18,15 @@ from oracle import demux_oracle as oracle
 oracle.load_npsimd()
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 100
 t0 = time.time()
-for seed in range(10, 10 + n):
+first = int(sys.argv[3]) if len(sys.argv) > 3 else 10
+for seed in range(first, first + n):
     print('seed', seed, flush=True)
     T.test_randomised_em_against_oracle(oracle, seed)
 print(f'{n} randomised EM problems ok ({time.time() - t0:.0f} s)', flush=True)
 
 from demuxalot_amd import synth
 from demuxalot_amd.device import get_context
-rng = np.random.default_rng(5)
+rng = np.random.default_rng(5 + first)
 for trial in range(int(sys.argv[2]) if len(sys.argv) > 2 else 12):
     G = int(rng.choice([2, 3, 4, 6, 8, 12, 16, 24, 32, 33, 48, 63, 64, 65, 96, 128]))
     B = int(rng.integers(500, 6000))
@@ -32,7 +34,7 @@ for trial in range(int(sys.argv[2]) if len(sys.argv) > 2 else 12):
     cpb = int(rng.choice([20, 60, 150, 400, 900]))
     n_it = int(rng.integers(1, 4))
     clip = float(rng.choice([0.01, 0.0, 0.05]))
-    p = synth.generate(B, S, G, calls_per_barcode=min(cpb, S), seed=1000 + trial)
+    p = synth.generate(B, S, G, calls_per_barcode=min(cpb, S), seed=1000 + first + trial)
     betas = p.prior_betas()
     ctx = get_context()
     ctx.set_problem(p.n_barcodes, p.n_variants, G, p.variant_id, p.compressed_cb, p.p_base_wrong, p.v2snp)
