@@ -64,7 +64,7 @@ struct MstepArgs {
 // logit units of the best.
 constexpr float NZ_FLOOR_SQUARE = 8.271806125530277e-25f;  // 2^-80
 
-constexpr int ITEM_CALLS = 1024;  // longest run of one variant's calls handled by one wavefront
+constexpr int ITEM_CALLS = 16384;  // longest run of one variant's calls handled by one wavefront
 constexpr int M_CHUNKS = 4;       // variant ranges (equal numbers of calls) whose all-reduce overlaps the next range's M-step
 
 hipError_t launch_probs_from_betas(hipStream_t st, const float *prior, const float *addition, const int *v2snp,

@@ -977,17 +977,18 @@ __global__ __launch_bounds__(256) void k_mcombine(const double *__restrict__ par
 
 // The queued sums, redone exactly as the reference does them: all calls of the variant, in order, into ONE float64
 // accumulator.  A 512-thread workgroup per queued (variant, genotype) pair (persistent: the queue length is only
-// known on the device).  The variant is walked in segments of 8 x ITEM_CALLS calls: each of the 8 wavefronts
+// known on the device).  The variant is walked in segments of 8 x 1024 calls: each of the 8 wavefronts
 // collects the non-zero contributions of its 1024 calls to the genotype in LDS (call order), then wavefront 0 adds
 // the 8 lists in order.  The gathers -- the expensive part -- run in parallel; only the additions are serial.
-constexpr int EXACT_WAVES = 8;
+constexpr int EXACT_WAVES = 16;
+constexpr int EXACT_SPAN = 512;  // calls per wavefront and segment (LDS: EXACT_WAVES * EXACT_SPAN floats)
 template <bool SQUARE>
 __global__ __launch_bounds__(64 * EXACT_WAVES) void k_mstep_exact(MstepArgs a, const long long *__restrict__ item_ptr,
                                                                   const unsigned long long *__restrict__ redo,
                                                                   const unsigned *__restrict__ n_redo,
                                                                   float *__restrict__ add32, double *__restrict__ add64)
 {
-    __shared__ float sh_c[EXACT_WAVES][ITEM_CALLS];
+    __shared__ float sh_c[EXACT_WAVES][EXACT_SPAN];
     __shared__ int sh_cnt[EXACT_WAVES];
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
@@ -1003,24 +1004,35 @@ __global__ __launch_bounds__(64 * EXACT_WAVES) void k_mstep_exact(MstepArgs a, c
         const long long n = a.item_start[it1 - 1] + a.item_len[it1 - 1] - first;
         const uint2 *__restrict__ calls = a.calls + first;
         double acc = 0.0;  // meaningful in wavefront 0
-        for (long long seg = 0; seg < n; seg += (long long)EXACT_WAVES * ITEM_CALLS) {
-            const long long lo = seg + (long long)wave * ITEM_CALLS;
-            const long long hi = lo + ITEM_CALLS < n ? lo + ITEM_CALLS : n;
+        for (long long seg = 0; seg < n; seg += (long long)EXACT_WAVES * EXACT_SPAN) {
+            const long long lo = seg + (long long)wave * EXACT_SPAN;
+            const long long hi = lo + EXACT_SPAN < n ? lo + EXACT_SPAN : n;
             int cnt = 0;
-            for (long long c0 = lo; c0 < hi; c0 += 64) {
-                float c = 0.0f;
-                bool live = false;
+            // records and bitmap words one chunk ahead of their use
+            auto fetch = [&](long long c0, uint2 &d, unsigned long long &word) {
+                d = make_uint2(0u, 0u);
+                word = 0ull;
                 if (c0 + lane < hi) {
-                    const uint2 d = calls[c0 + lane];
-                    live = (a.nz[(size_t)d.x * W + (g >> 6)] >> (g & 63)) & 1ull;
-                    if (live) {
-                        c = a.post[(size_t)d.x * a.K + g] * __uint_as_float(d.y);
-                        c = SQUARE ? c * c : powf(c, a.power);
-                    }
+                    d = calls[c0 + lane];
+                    word = a.nz[(size_t)d.x * W + (g >> 6)];
+                }
+            };
+            uint2 d, d_nxt;
+            unsigned long long word, word_nxt;
+            fetch(lo, d, word);
+            for (long long c0 = lo; c0 < hi; c0 += 64) {
+                fetch(c0 + 64, d_nxt, word_nxt);
+                const bool live = (word >> (g & 63)) & 1ull;
+                float c = 0.0f;
+                if (live) {
+                    c = a.post[(size_t)d.x * a.K + g] * __uint_as_float(d.y);
+                    c = SQUARE ? c * c : powf(c, a.power);
                 }
                 const unsigned long long bal = __ballot(live);
                 if (live) mine[cnt + __popcll(bal & ((1ull << lane) - 1ull))] = c;
                 cnt += __popcll(bal);
+                d = d_nxt;
+                word = word_nxt;
             }
             if (lane == 0) sh_cnt[wave] = cnt;
             __syncthreads();

@@ -18,6 +18,10 @@ class DeviceContext:
         self.device = int(device)
         self.B = self.V = self.G = self.N = 0
         self.K = 0
+        # DEMUXALOT_AMD_EXACT_ADDITIONS=0 trades the bit-identical genotype additions of variants with > 16384 calls
+        # for ~4 % per EM iteration (include/demux_hip.h: dmx_set_exact_additions)
+        if os.environ.get('DEMUXALOT_AMD_EXACT_ADDITIONS', '1') in ('0', ''):
+            self.set_exact_additions(False)
 
     def close(self):
         if getattr(self, '_h', None):
@@ -229,7 +233,7 @@ class DeviceContext:
         check(self._lib.dmx_comm_init(self._h, int(rank), int(nranks), buf, DMX_F64 if reduce_dtype == 'f64' else DMX_F32))
 
     def set_exact_additions(self, exact):
-        """M-step summation mode (include/demux_hip.h: dmx_set_exact_additions). Default: off."""
+        """M-step summation mode (include/demux_hip.h: dmx_set_exact_additions). Default: exact."""
         check(self._lib.dmx_set_exact_additions(self._h, int(bool(exact))))
 
     # ---- instrumentation ----------------------------------------------------------------
@@ -289,6 +293,4 @@ def get_context(device=None) -> DeviceContext:
     device = default_device() if device is None else int(device)
     if device not in _contexts:
         _contexts[device] = DeviceContext(device)
-        # DEMUXALOT_AMD_EXACT_ADDITIONS=1: bit-identical genotype additions also for variants with > 1024 calls
-        _contexts[device].set_exact_additions(os.environ.get('DEMUXALOT_AMD_EXACT_ADDITIONS', '0') not in ('', '0'))
     return _contexts[device]

@@ -5,7 +5,6 @@ import os
 import sys
 import time
 import numpy as np
-os.environ.setdefault('DEMUXALOT_AMD_EXACT_ADDITIONS', '1')  # additions are compared bit for bit
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, root)
 sys.path.insert(0, os.path.join(root, 'tests'))

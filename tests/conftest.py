@@ -3,9 +3,6 @@ import sys
 
 import pytest
 
-# The parity tests compare genotype additions bit for bit, also for variants with more than 1024 calls: that needs
-# the exact summation mode (include/demux_hip.h: dmx_set_exact_additions).  The default mode has its own test.
-os.environ.setdefault('DEMUXALOT_AMD_EXACT_ADDITIONS', '1')
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
