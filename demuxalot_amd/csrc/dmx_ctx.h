@@ -62,6 +62,7 @@ struct dmx_ctx {
     unsigned long long *d_redo = nullptr;  // (variant, genotype) sums to be redone in order (k_mcombine)
     unsigned *d_n_redo = nullptr;
     size_t cap_redo = 0;
+    int item_calls = 1024;  // work-item length of the resident problem (kernels.h: item_calls_for)
     bool exact_additions = true;  // dmx_set_exact_additions
     float nz_floor = 0.0f;     // threshold the current d_nz / d_first were built with
     float *d_first = nullptr;  // [B] posterior of the lowest non-zero singlet column (G <= 64)

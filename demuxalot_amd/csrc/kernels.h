@@ -44,7 +44,7 @@ struct EstepArgs {
 struct MstepArgs {
     const int *order;               // [n_items] items by decreasing length (work distribution)
     const long long *item_start;    // [n_items] first CSC call of the item
-    const int *item_len;            // [n_items] number of calls (<= ITEM_CALLS)
+    const int *item_len;            // [n_items] number of calls (<= item_calls_for(N))
     const uint2 *calls;             // [N] (compressed_cb, bits of 1 - p_base_wrong), variant-major
     const float *post;              // [B, K] posteriors (singlet columns 0..G-1 are read)
     const unsigned long long *nz;   // [B, ceil(G/64)] non-zero bitmap of the singlet posteriors
@@ -64,7 +64,17 @@ struct MstepArgs {
 // logit units of the best.
 constexpr float NZ_FLOOR_SQUARE = 8.271806125530277e-25f;  // 2^-80
 
-constexpr int ITEM_CALLS = 16384;  // longest run of one variant's calls handled by one wavefront
+// Longest run of one variant's calls handled by one wavefront.  Long items keep hot variants in few pieces (every
+// extra piece makes more sums order-sensitive, see k_mcombine), short items keep the tail of the launch short:
+// the length is chosen per problem so that the longest item is about a tenth of one wavefront's share of a full
+// launch, between these bounds.
+constexpr int MIN_ITEM_CALLS = 1024, MAX_ITEM_CALLS = 16384;
+inline int item_calls_for(long long n_calls)
+{
+    long long len = MIN_ITEM_CALLS;
+    while (len < MAX_ITEM_CALLS && len * 6000 < n_calls) len *= 2;
+    return (int)len;
+}
 constexpr int M_CHUNKS = 4;       // variant ranges (equal numbers of calls) whose all-reduce overlaps the next range's M-step
 
 hipError_t launch_probs_from_betas(hipStream_t st, const float *prior, const float *addition, const int *v2snp,

@@ -587,7 +587,7 @@ __global__ __launch_bounds__(256) void k_softmax_rows(EstepArgs a)
 }
 
 // ------------------------------------------------------------------------------------
-// M-step.  Work item = a run of <= ITEM_CALLS consecutive CSC calls of one variant, owned by one
+// M-step.  Work item = a run of <= item_calls (kernels.h) consecutive CSC calls of one variant, owned by one
 // wavefront that walks it in CSC (= reference bincount) order with float64 accumulation and leaves
 // one float64 partial per item.  Items are handed out from a length-sorted list.
 // The E-step leaves a per-barcode bitmap of the posteriors that can contribute (kernels.h:
@@ -938,7 +938,7 @@ __global__ __launch_bounds__(256) void k_rebuild_nz(const float *__restrict__ po
 
 // Sums the item partials of each variant in item order; writes float32 (single GPU) or the float64 total
 // that goes into the all-reduce.
-// A variant with more than ITEM_CALLS calls has several items, and adding their float64 partials is not the
+// A variant with more calls than the work-item length has several items, and adding their float64 partials is not the
 // reference's single left-to-right float64 sum: the two can differ in the last bits, which matters exactly when
 // the total sits next to a float32 rounding boundary -- and it often sits ON one (a sum of a few hundred float32
 // squares of similar size is an exact float64 whose bits below the float32 precision are ...1000 about once in

@@ -4,7 +4,7 @@
 //   E-step records  barcode-major, calls of a barcode in input order, rows padded to 8 calls, two
 //                   calls per 32-byte CallPair (kernels.h)
 //   M-step records  variant-major, calls of a variant in input order, {compressed_cb, bits(1 - e)}
-//   work items      runs of <= ITEM_CALLS calls of one variant; item_ptr per variant
+//   work items      runs of <= item_calls calls of one variant (dmx_ctx::item_calls); item_ptr per variant
 //   work lists      barcodes / items by decreasing length
 //
 // "In input order" is what makes the float64 sums of the kernels run in np.bincount's order, so the
@@ -58,14 +58,14 @@ __global__ __launch_bounds__(256) void k_boundaries(const unsigned *__restrict__
 // from offsets: per-row padded pair counts (mode 0) or per-variant item counts (mode 1), and ~count
 // (ascending sort of ~count = longest first) with the ids for the work lists
 __global__ __launch_bounds__(256) void k_derive_counts(const long long *__restrict__ start, long long n, int mode,
-                                                       long long *__restrict__ derived, unsigned *__restrict__ inv,
+                                                       int item_calls, long long *__restrict__ derived, unsigned *__restrict__ inv,
                                                        unsigned *__restrict__ ids)
 {
     const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     const long long c = start[i + 1] - start[i];
     derived[i] = mode == 0 ? ((c + 7) / 8) * 4                  // CallPairs of a barcode row padded to 8 calls
-                           : (c + ITEM_CALLS - 1) / ITEM_CALLS;  // work items of a variant
+                           : (c + item_calls - 1) / item_calls;  // work items of a variant
     if (inv) {
         inv[i] = ~(unsigned)c;
         ids[i] = (unsigned)i;
@@ -141,7 +141,7 @@ __global__ void k_chunk_bounds(const long long *__restrict__ col_ptr, long long 
 __global__ __launch_bounds__(256) void k_build_items(const long long *__restrict__ col_ptr,
                                                      const long long *__restrict__ item_ptr,
                                                      const long long *__restrict__ bounds, long long V,
-                                                     long long *__restrict__ item_start, int *__restrict__ item_len,
+                                                     int item_calls, long long *__restrict__ item_start, int *__restrict__ item_len,
                                                      unsigned *__restrict__ inv_len, unsigned *__restrict__ chunk_key,
                                                      unsigned *__restrict__ ids)
 {
@@ -150,12 +150,12 @@ __global__ __launch_bounds__(256) void k_build_items(const long long *__restrict
     unsigned chunk = 0;
     for (int c = 1; c < M_CHUNKS; c++) chunk += (v >= bounds[c]) ? 1u : 0u;
     long long it = item_ptr[v];
-    for (long long s = col_ptr[v]; s < col_ptr[v + 1]; s += ITEM_CALLS, it++) {
-        const long long len = (col_ptr[v + 1] - s) < ITEM_CALLS ? (col_ptr[v + 1] - s) : ITEM_CALLS;
+    for (long long s = col_ptr[v]; s < col_ptr[v + 1]; s += item_calls, it++) {
+        const long long len = (col_ptr[v + 1] - s) < item_calls ? (col_ptr[v + 1] - s) : item_calls;
         item_start[it] = s;
         item_len[it] = (int)len;
         inv_len[it] = ~(unsigned)len;                                      // ascending sort = longest first
-        chunk_key[it] = chunk * (2u * ITEM_CALLS) + (unsigned)(ITEM_CALLS - len);  // chunk-major, longest first inside
+        chunk_key[it] = chunk * (2u * MAX_ITEM_CALLS) + (unsigned)(MAX_ITEM_CALLS - len);  // chunk-major, longest first inside
         ids[it] = (unsigned)it;
     }
 }
@@ -221,6 +221,7 @@ static int repack_core(dmx_ctx *c, Scratch &sc, const int *d_variant, const int 
     const long long B = c->B, V = c->V, N = c->N;
     const int G = c->G;
     hipStream_t st = c->stream;
+    c->item_calls = item_calls_for(N);
 
     // ---- range check ----
     int *bad = nullptr;
@@ -259,9 +260,9 @@ static int repack_core(dmx_ctx *c, Scratch &sc, const int *d_variant, const int 
     DMX_TRY(sc.get(&inv, (size_t)B));
     DMX_TRY(sc.get(&ids, (size_t)B));
     DMX_TRY(sc.get(&inv_sorted, (size_t)B));
-    if (B) hipLaunchKernelGGL(k_derive_counts, dim3(grid_for(B)), dim3(256), 0, st, row_start, B, 0, row_pairs, inv, ids);
+    if (B) hipLaunchKernelGGL(k_derive_counts, dim3(grid_for(B)), dim3(256), 0, st, row_start, B, 0, 0, row_pairs, inv, ids);
     if (V)
-        hipLaunchKernelGGL(k_derive_counts, dim3(grid_for(V)), dim3(256), 0, st, col_ptr, V, 1, col_items, (unsigned *)nullptr,
+        hipLaunchKernelGGL(k_derive_counts, dim3(grid_for(V)), dim3(256), 0, st, col_ptr, V, 1, c->item_calls, col_items, (unsigned *)nullptr,
                            (unsigned *)nullptr);
     DMX_TRY(dev_alloc(c, &c->d_pair_ptr, (size_t)B + 1));
     DMX_TRY(dev_alloc(c, &c->d_item_ptr, (size_t)V + 1));
@@ -302,10 +303,10 @@ static int repack_core(dmx_ctx *c, Scratch &sc, const int *d_variant, const int 
     hipLaunchKernelGGL(k_chunk_bounds, dim3(1), dim3(64), 0, st, col_ptr, V, N, bounds);
     if (V)
         hipLaunchKernelGGL(k_build_items, dim3(grid_for(V)), dim3(256), 0, st, col_ptr, c->d_item_ptr, bounds, V,
-                           c->d_item_start, c->d_item_len, inv_i, key_c, ids_i);
+                           c->item_calls, c->d_item_start, c->d_item_len, inv_i, key_c, ids_i);
     DMX_TRY(sort_pairs(sc, inv_i, keys_out, ids_i, (unsigned *)c->d_item_order, (size_t)n_items, 32, st));
     DMX_TRY(sort_pairs(sc, key_c, keys_out, ids_i, (unsigned *)c->d_item_order_chunked, (size_t)n_items,
-                       bits_for((unsigned long long)M_CHUNKS * 2 * ITEM_CALLS), st));
+                       bits_for((unsigned long long)M_CHUNKS * 2 * MAX_ITEM_CALLS), st));
     HIP_TRY(hipMemcpyAsync(c->chunk_v, bounds, sizeof(long long) * (M_CHUNKS + 1), hipMemcpyDeviceToHost, st));
     HIP_TRY(hipStreamSynchronize(st));
     for (int k = 0; k <= M_CHUNKS; k++)  // items of variants [0, chunk_v[k]) = item_ptr[chunk_v[k]]

@@ -135,14 +135,15 @@ int dmx_set_betas(dmx_ctx *ctx, const float *prior_betas);
 int dmx_set_prior_betas(dmx_ctx *ctx, const float *raw_betas, double default_prior, int add_data_prior,
                         const int64_t *mol_per_variant, float *prior_out);
 
-/* M-step summation mode.  A variant with more than 16384 calls is summed by several wavefronts, and adding
+/* M-step summation mode.  A variant with more calls than the work-item length (1024 .. 16384, chosen from the
+ * problem size) is summed by several wavefronts, and adding
  * their float64 partial sums is not the reference's single left-to-right float64 sum (np.bincount,
  * utils.py:35-36): the two can differ in the last bits, which changes the float32 result when the total sits on a
  * float32 rounding boundary (seen on ~4e-5 of the [V, G] entries of a stress case, always by one float32 ulp).
  * exact != 0 (default): such sums are detected (error bound of either order versus the distance to the
  * boundary) and redone in the reference's order -- additions bit-identical to the reference for any input
- * (+3.6 % per EM iteration on the 200k x 100k x 64 workload).  exact == 0: accept the combined sum.  Variants
- * with at most 16384 calls, and everything in the E-step, are bit-identical in both modes. */
+ * (+3.6 % per EM iteration on the 200k x 100k x 64 workload).  exact == 0: accept the combined sum.  Single-item
+ * variants, and everything in the E-step, are bit-identical in both modes. */
 int dmx_set_exact_additions(dmx_ctx *ctx, int exact);
 
 /* genotype_addition float32[V*G]; NULL resets it to zero (demux.py:86). */

@@ -323,13 +323,14 @@ def test_mstep_underflow_floor_is_exact(oracle):
 
 @pytest.mark.parametrize('G', [63, 70])
 def test_summation_modes(oracle, G):
-    """Variants with more than ITEM_CALLS (16384) calls are summed from several float64 partial sums.  Exact mode
+    """Variants with more calls than the work-item length (1024 .. 16384, chosen from the problem size; 1024
+    here) are summed from several float64 partial sums.  Exact mode
     (default) redoes, in the reference's order, every sum whose float32 rounding could depend on that: additions
     bit-identical.  Fast mode (dmx_set_exact_additions(0)) accepts the combined sums: an addition may move by one
     float32 ulp when the total sits on a rounding boundary; posteriors stay far inside the 1e-5 tolerance."""
     from demuxalot_amd import synth
     from demuxalot_amd.device import get_context
-    B, S = 40000, 20  # ~20 000 calls per variant: two work items each (G = 70: the genotype-per-lane M-step)
+    B, S = 40000, 20  # ~20 000 calls per variant: twenty work items each (G = 70: the genotype-per-lane M-step)
     p = synth.generate(B, S, G, calls_per_barcode=S, seed=1203)
     betas = p.prior_betas()
     packed = dict(variant_id=p.variant_id, compressed_cb=p.compressed_cb, p_base_wrong=p.p_base_wrong, betas=betas, v2snp=p.v2snp)
