@@ -18,7 +18,7 @@ class DeviceContext:
         self.device = int(device)
         self.B = self.V = self.G = self.N = 0
         self.K = 0
-        # DEMUXALOT_AMD_EXACT_ADDITIONS=0 trades the bit-identical genotype additions of variants with > 16384 calls
+        # DEMUXALOT_AMD_EXACT_ADDITIONS=0 trades the bit-identical genotype additions of the hottest variants (several work items)
         # for ~4 % per EM iteration (include/demux_hip.h: dmx_set_exact_additions)
         if os.environ.get('DEMUXALOT_AMD_EXACT_ADDITIONS', '1') in ('0', ''):
             self.set_exact_additions(False)
