@@ -1017,22 +1017,29 @@ __global__ __launch_bounds__(64 * EXACT_WAVES) void k_mstep_exact(MstepArgs a, c
                     word = a.nz[(size_t)d.x * W + (g >> 6)];
                 }
             };
-            uint2 d, d_nxt;
-            unsigned long long word, word_nxt;
-            fetch(lo, d, word);
+            // three chunks in flight: records + bitmap word of chunk c+2, posterior gather of chunk c+1, compaction of c
+            uint2 d0, d1, d2;
+            unsigned long long w0, w1, w2;
+            fetch(lo, d0, w0);
+            fetch(lo + 64, d1, w1);
+            auto gather = [&](uint2 d, unsigned long long word, bool &live) {
+                live = (word >> (g & 63)) & 1ull;
+                float p = 0.0f;
+                if (live) p = a.post[(size_t)d.x * a.K + g];
+                return p;
+            };
+            bool live0, live1;
+            float p0 = gather(d0, w0, live0);
             for (long long c0 = lo; c0 < hi; c0 += 64) {
-                fetch(c0 + 64, d_nxt, word_nxt);
-                const bool live = (word >> (g & 63)) & 1ull;
-                float c = 0.0f;
-                if (live) {
-                    c = a.post[(size_t)d.x * a.K + g] * __uint_as_float(d.y);
-                    c = SQUARE ? c * c : powf(c, a.power);
-                }
-                const unsigned long long bal = __ballot(live);
-                if (live) mine[cnt + __popcll(bal & ((1ull << lane) - 1ull))] = c;
+                fetch(c0 + 128, d2, w2);
+                const float p1 = gather(d1, w1, live1);
+                float c = p0 * __uint_as_float(d0.y);
+                c = SQUARE ? c * c : powf(c, a.power);
+                const unsigned long long bal = __ballot(live0);
+                if (live0) mine[cnt + __popcll(bal & ((1ull << lane) - 1ull))] = c;
                 cnt += __popcll(bal);
-                d = d_nxt;
-                word = word_nxt;
+                d0 = d1; w0 = w1; live0 = live1; p0 = p1;
+                d1 = d2; w1 = w2;
             }
             if (lane == 0) sh_cnt[wave] = cnt;
             __syncthreads();
