@@ -768,11 +768,13 @@ __global__ __launch_bounds__(256) void k_mstep_calls(MstepArgs a)
         const bool sparse = nnz >= 1 && nnz <= NZ_S;
         const float *__restrict__ row = a.post + (size_t)d.x * K;
         u64 mm = m;
+        const bool more = __any(sparse && nnz > 1);  // (uniform) most chunks hold single-posterior calls only
 #pragma unroll
         for (int t = 0; t < NZ_S; t++) {
+            p[t] = 0.0f;
+            if (t > 0 && !more) continue;
             const float *src = row + (mm ? __builtin_ctzll(mm) : 0);
             if (t == 0 && nnz == 1) src = a.first + d.x;
-            p[t] = 0.0f;
             if (sparse && mm != 0ull) p[t] = *src;
             mm &= mm - 1ull;
         }
