@@ -302,10 +302,10 @@ int run_mstep(dmx_ctx *c, float power)
         timer_end(c, DMX_T_MCOMBINE, ev);
         return 0;
     }
-    // Multi-GPU: variants are cut into M_CHUNKS ranges with equal numbers of calls.  The M-step and the
-    // combine of range i+1 run on the compute stream while RCCL all-reduces range i on the comm stream,
-    // so only the last range's exchange is exposed.  Every variant belongs to exactly one range: the
-    // arithmetic is the same as in the single launch.
+    // Multi-GPU: the addition is all-reduced on the comm stream.  The variants can be cut into M_CHUNKS ranges with
+    // equal numbers of calls so that range i is exchanged while range i+1's M-step runs; every variant belongs to
+    // exactly one range, so the arithmetic is that of the single launch.  M_CHUNKS is 1 (each range
+    // pays its own straggler tail, which costs more than the overlap hides).
     const bool f64 = c->reduce_dtype == DMX_F64;
     ncclResult_t r = ncclSuccess;
     timer_begin(c, DMX_T_MSTEP, &ev);

@@ -75,7 +75,7 @@ inline int item_calls_for(long long n_calls)
     while (len < MAX_ITEM_CALLS && len * 6000 < n_calls) len *= 2;
     return (int)len;
 }
-constexpr int M_CHUNKS = 4;       // variant ranges (equal numbers of calls) whose all-reduce overlaps the next range's M-step
+constexpr int M_CHUNKS = 1;       // variant ranges whose all-reduce overlaps the next range's M-step (1: no split)
 
 hipError_t launch_probs_from_betas(hipStream_t st, const float *prior, const float *addition, const int *v2snp,
                                    const int *snp_ptr, const int *snp_vars, long long V, int G, float lo, float hi,
