@@ -199,6 +199,7 @@ def main():
             'dtype': 'f32 terms, f64 accumulate', 'data': 'synthetic',
             'config': {'workload': args.workload, 'barcodes_per_gpu': B, 'snps': S, 'variants': V, 'genotypes': G,
                        'options': K, 'calls_per_gpu': N, 'doublet_prior': dp,
+                       'summation': 'fast (DEMUXALOT_AMD_EXACT_ADDITIONS=0)' if os.environ.get('DEMUXALOT_AMD_EXACT_ADDITIONS', '1') in ('0', '') else 'exact: additions bit-identical to the reference (default)',
                        'parallelism': f'barcode shards x{world}' + (f', RCCL all-reduce {args.reduce_dtype}' if use_dist else '')},
             'em_iterations_per_s': args.steps / elapsed,
             'predict_barcodes_per_s': world * B / predict_s,
