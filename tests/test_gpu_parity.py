@@ -352,6 +352,11 @@ def test_summation_modes(oracle, G):
                 assert ulps.max() <= 1 and (ulps != 0).mean() < 1e-3, (ulps.max(), (ulps != 0).mean())
                 assert np.array_equal(probs.argmax(axis=1), hist[-1]['probs'].argmax(axis=1))
                 assert np.abs(probs - hist[-1]['probs']).max() <= 1e-5
+        # another contribution_power through the same redo path (powf: float32 accuracy, not bits)
+        ctx.set_exact_additions(True)
+        _, _, add15 = ctx.em(2, 0.0, pen, with_doublets=False, contribution_power=1.5)
+        want15 = oracle.em(packed, B, 2, 0.0, 0., power=1.5, impl='npsimd')[-1]['addition']
+        assert np.allclose(add15, want15, rtol=2e-6, atol=1e-30)
     finally:
         ctx.set_exact_additions(True)
 
@@ -468,6 +473,30 @@ def test_rccl_communicator_single_rank(reduce_dtype):
     em.ctx.close()
     fio.assert_bitwise(probs1, probs, 'ShardedEM world=1')
     fio.assert_bitwise(addition1, addition, 'ShardedEM world=1 addition')
+    # variants cut into several work items (order-sensitive sums redone exactly): the collective path
+    # must give what the single-stream path gives; with float64 on the wire that is bit for bit
+    from demuxalot_amd import synth
+    from demuxalot_amd.device import get_context
+    p = synth.generate(40000, 20, 63, calls_per_barcode=20, seed=1203)
+    prior = p.prior_betas()
+    pen = np.zeros(63, dtype=np.float32)
+    plain = get_context()
+    plain.set_problem(p.n_barcodes, p.n_variants, 63, p.variant_id, p.compressed_cb, p.p_base_wrong, p.v2snp)
+    plain.set_betas(prior)
+    _, probs_plain, add_plain = plain.em(2, 0.0, pen, with_doublets=False)
+    ctx = DeviceContext(0)
+    try:
+        ctx.set_problem(p.n_barcodes, p.n_variants, 63, p.variant_id, p.compressed_cb, p.p_base_wrong, p.v2snp)
+        ctx.set_betas(prior)
+        ctx.comm_init(0, 1, DeviceContext.new_unique_id(), reduce_dtype=reduce_dtype)
+        _, probs_coll, add_coll = ctx.em(2, 0.0, pen, with_doublets=False)
+    finally:
+        ctx.close()
+    if reduce_dtype == 'f64':
+        fio.assert_bitwise(add_coll, add_plain, 'multi-item variants through the RCCL path')
+        fio.assert_bitwise(probs_coll, probs_plain, 'multi-item variants through the RCCL path: posteriors')
+    else:
+        assert np.allclose(add_coll, add_plain, rtol=3e-7, atol=0)
 
 
 # ---- mid/large sizes ------------------------------------------------------------------------------
