@@ -47,7 +47,11 @@ SIGNATURES = {
     'dmx_get_logits': (c_int, [_P, _P]),
     'dmx_get_probs': (c_int, [_P, _P]),
     'dmx_get_addition': (c_int, [_P, _P]),
+    'dmx_get_block': (c_int, [_P, c_int, c_int64, c_int64, c_int64, c_int64, _P]),
     'dmx_get_assignments': (c_int, [_P, _P, _P]),
+    'dmx_get_assignments_above': (c_int, [_P, c_float, _P, _P, POINTER(c_int64)]),
+    'dmx_get_top_options': (c_int, [_P, c_int32, _P, _P]),
+    'dmx_get_option_sums': (c_int, [_P, _P]),
     'dmx_comm_unique_id': (c_int, [_P]),
     'dmx_comm_init': (c_int, [_P, c_int, c_int, _P, c_int]),
     'dmx_get_timings': (c_int, [_P, POINTER(c_double), POINTER(c_int64)]),

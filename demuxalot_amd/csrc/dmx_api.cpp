@@ -776,6 +776,23 @@ int dmx_get_addition(dmx_ctx *c, float *out)
     return 0;
 }
 
+int dmx_get_block(dmx_ctx *c, int what, int64_t b0, int64_t b1, int64_t k0, int64_t k1, float *out)
+{
+    DMX_TRY(bind(c));
+    DMX_TRY(need(c, c->have_post, "dmx_estep before dmx_get_block"));
+    if (what != DMX_LOGITS && what != DMX_PROBS) return fail(DMX_ERR_INVALID, "what must be DMX_LOGITS or DMX_PROBS");
+    if (b0 < 0 || b1 < b0 || b1 > c->B || k0 < 0 || k1 < k0 || k1 > c->K)
+        return fail(DMX_ERR_INVALID, "block [%lld,%lld) x [%lld,%lld) outside [0,%lld) x [0,%d)", (long long)b0, (long long)b1,
+                    (long long)k0, (long long)k1, c->B, c->K);
+    if (b1 == b0 || k1 == k0) return 0;
+    if (!out) return fail(DMX_ERR_INVALID, "null output");
+    const float *src = (what == DMX_LOGITS ? c->d_logits : c->d_post) + (size_t)b0 * c->K + k0;
+    HIP_TRY(hipMemcpy2DAsync(out, (size_t)(k1 - k0) * 4, src, (size_t)c->K * 4, (size_t)(k1 - k0) * 4, (size_t)(b1 - b0),
+                             hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return 0;
+}
+
 int dmx_get_assignments(dmx_ctx *c, int32_t *best, float *best_p)
 {
     DMX_TRY(bind(c));

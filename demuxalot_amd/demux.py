@@ -24,7 +24,7 @@ import numpy as np
 import pandas as pd
 
 from . import _lib
-from .device import get_context
+from .device import DeviceContext, default_device, get_context, shared_context_lock
 
 _MOLECULE_CALL_DTYPE = [('variant_id', 'int32'), ('snp_id', 'int32'), ('compressed_cb', 'int32'),
                         ('molecule_id', 'int32'), ('p_base_wrong', 'float32'), ('p_molecule_aligned_wrong', 'float32')]
@@ -157,15 +157,17 @@ def _pack(chromosome2compressed_snp_calls, genotypes, add_data_prior, want_molec
     return packed
 
 
-def _pack_on_device(chromosome2compressed_snp_calls, genotypes, n_barcodes, add_data_prior, fetch_betas=True):
+def _pack_on_device(chromosome2compressed_snp_calls, genotypes, n_barcodes, add_data_prior, fetch_betas=True, ctx=None):
     """The repack of predict / learn, on the GPU: flattening of the containers' records, matching +
     de-duplication + layout derivation (dmx_pack_containers_and_set_problem) and the regularised prior betas
     (dmx_set_prior_betas).
-    Returns (ctx with the problem and betas resident, regularised prior betas)."""
+    Returns (ctx with the problem and betas resident, regularised prior betas).  `ctx` None = the shared cached
+    context (the caller holds shared_context_lock)."""
     from .snp_counter import MOLECULE_DTYPE, SNP_CALL_DTYPE
     v2snp = genotypes.get_snp_ids_for_variants()
     assert np.all(v2snp >= 0)
-    ctx = get_context()
+    if ctx is None:
+        ctx = get_context()
     containers = list(chromosome2compressed_snp_calls.values())
     if all(c.snp_calls.dtype == SNP_CALL_DTYPE and c.molecules.dtype == MOLECULE_DTYPE for c in containers):
         # the containers' packed records go to the GPU as they are and are taken apart there
@@ -196,6 +198,78 @@ def _option_names(genotype_names, doublet_prior):
     return names
 
 
+class DevicePosteriors:
+    """Posteriors (and logits) of one predict_posteriors / learn_genotypes call, kept on the GPU
+    (`on_device=True`), with the reductions users of the reference apply to the DataFrame done there:
+    nothing of size [B, K] crosses PCIe unless to_dataframes() / rows() ask for it.
+    Owns a private device context; close() (or garbage collection) releases the GPU memory."""
+
+    def __init__(self, ctx, barcodes, column_names, index_name=None):
+        self._ctx = ctx
+        self.barcodes = list(barcodes)
+        self.columns = list(column_names)
+        self.index_name = index_name
+
+    @property
+    def shape(self):
+        return len(self.barcodes), len(self.columns)
+
+    def _index(self, barcodes=None):
+        index = pd.Index(self.barcodes if barcodes is None else barcodes)
+        index.name = self.index_name
+        return index
+
+    def assignments(self, threshold=0.9) -> pd.Series:
+        """probs[probs.max(axis=1).gt(threshold)].idxmax(axis=1)
+        (examples/2-with-detection-of-new-SNPs.ipynb cell 14; snp_detection.py:166)."""
+        best, _prob, _n = self._ctx.get_assignments_above(threshold)
+        rows = np.flatnonzero(best >= 0)
+        names = np.asarray(self.columns, dtype=object)[best[rows]]
+        return pd.Series(names, index=self._index([self.barcodes[i] for i in rows]))
+
+    def best(self) -> pd.DataFrame:
+        """Per barcode: the most probable option and its posterior (idxmax / max of every row)."""
+        best, prob = self._ctx.get_assignments()
+        return pd.DataFrame({'option': np.asarray(self.columns, dtype=object)[best], 'probability': prob},
+                            index=self._index())
+
+    def top_options(self, k=2) -> pd.DataFrame:
+        """The k <= 4 best options per barcode, best first: columns option_1, probability_1, option_2, ..."""
+        options, probs = self._ctx.get_top_options(k)
+        names = np.asarray(self.columns + [None], dtype=object)  # -1 (row shorter than k) -> None
+        data = {}
+        for j in range(options.shape[1]):
+            data[f'option_{j + 1}'] = names[options[:, j]]
+            data[f'probability_{j + 1}'] = probs[:, j]
+        return pd.DataFrame(data, index=self._index())
+
+    def option_sums(self) -> pd.Series:
+        """probs.sum(axis=0) (`probs[genotype_names].sum()`, same notebook cells 19 / 21), float64."""
+        return pd.Series(self._ctx.get_option_sums(), index=self.columns)
+
+    def rows(self, lo, hi, what='probs') -> pd.DataFrame:
+        """Rows [lo, hi) of the 'probs' or 'logits' matrix as a DataFrame."""
+        block = self._ctx.get_block(what, lo, hi)
+        return pd.DataFrame(block, index=self._index(self.barcodes[lo:hi]), columns=self.columns)
+
+    def to_dataframes(self):
+        """(logits_df, probs_df) as the host-side entry points return them."""
+        index = self._index()
+        return (pd.DataFrame(self._ctx.get_logits(), index=index, columns=self.columns),
+                pd.DataFrame(self._ctx.get_probs(), index=index.copy(), columns=self.columns))
+
+    def close(self):
+        if self._ctx is not None:
+            self._ctx.close()
+            self._ctx = None
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+
 class Demultiplexer:
     """
     Demultiplexer that can infer (learn) additional information about genotypes to achieve better quality.
@@ -215,12 +289,15 @@ class Demultiplexer:
                         p_genotype_clip=0.01,
                         doublet_prior=0.,
                         barcode_prior_logits: np.ndarray = None,
+                        on_device: bool = False,
                         ) -> Tuple[object, pd.DataFrame]:
         """
         Learn genotypes starting from an initial guess (demux.py:35-66).
         :return: learnt genotypes (a copy of `genotypes` with betas = raw betas + the addition used by the
             last E-step) and the barcode-to-donor posteriors of the last iteration.
         The whole loop runs on the GPU (dmx_em); only the last iteration's results come back.
+        :param on_device: (not in the reference) leave the posteriors on the GPU and return a DevicePosteriors
+            in place of the DataFrame.
         """
         Demultiplexer._check_not_aggregating()
         assert 0 <= doublet_prior < 1
@@ -230,14 +307,29 @@ class Demultiplexer:
             assert barcode_prior_logits.shape == (barcode_handler.n_barcodes, len(penalties)), 'wrong shape of priors'
         assert n_iterations >= 1, 'n_iterations should be positive'  # the reference fails to unpack an empty run
 
-        ctx, _betas = _pack_on_device(chromosome2compressed_snp_calls, genotypes, barcode_handler.n_barcodes, True,
-                                      fetch_betas=False)
-        _logits, probs, addition = ctx.em(
-            n_iterations, p_genotype_clip, penalties, with_doublets=doublet_prior != 0,
-            prior_logits=barcode_prior_logits, contribution_power=Demultiplexer.contribution_power,
-            fetch_logits=False)
-        probs_df = pd.DataFrame(data=probs, index=barcode_handler.ordered_barcodes,
-                                columns=_option_names(genotypes.genotype_names, doublet_prior))
+        column_names = _option_names(genotypes.genotype_names, doublet_prior)
+        if on_device:
+            ctx = DeviceContext(default_device())
+            try:
+                _pack_on_device(chromosome2compressed_snp_calls, genotypes, barcode_handler.n_barcodes, True,
+                                fetch_betas=False, ctx=ctx)
+                _l, _p, addition = ctx.em(
+                    n_iterations, p_genotype_clip, penalties, with_doublets=doublet_prior != 0,
+                    prior_logits=barcode_prior_logits, contribution_power=Demultiplexer.contribution_power,
+                    fetch_logits=False, fetch_probs=False)
+            except BaseException:
+                ctx.close()
+                raise
+            learnt_genotypes = genotypes._with_betas(genotypes.get_betas() + addition)
+            return learnt_genotypes, DevicePosteriors(ctx, barcode_handler.ordered_barcodes, column_names)
+        with shared_context_lock:
+            ctx, _betas = _pack_on_device(chromosome2compressed_snp_calls, genotypes, barcode_handler.n_barcodes, True,
+                                          fetch_betas=False)
+            _logits, probs, addition = ctx.em(
+                n_iterations, p_genotype_clip, penalties, with_doublets=doublet_prior != 0,
+                prior_logits=barcode_prior_logits, contribution_power=Demultiplexer.contribution_power,
+                fetch_logits=False)
+        probs_df = pd.DataFrame(data=probs, index=barcode_handler.ordered_barcodes, columns=column_names)
         learnt_genotypes = genotypes._with_betas(genotypes.get_betas() + addition)
         return learnt_genotypes, probs_df
 
@@ -251,7 +343,9 @@ class Demultiplexer:
                                  barcode_prior_logits: np.ndarray = None):
         """Generator over EM iterations (demux.py:69-118): yields (posterior DataFrame, debug dict with
         'barcode_logits', 'genotype_prior', 'genotype_addition'), aligned as in the reference: the yielded
-        addition is the one the iteration's E-step used."""
+        addition is the one the iteration's E-step used.
+        The EM state lives on the GPU between yields, in a device context private to this generator: like the
+        reference's (pure) generator it is unaffected by other Demultiplexer calls made between iterations."""
         Demultiplexer._check_not_aggregating()
         assert 0 <= doublet_prior < 1
         n_genotypes = genotypes.n_genotypes
@@ -259,41 +353,62 @@ class Demultiplexer:
         if barcode_prior_logits is not None:
             assert barcode_prior_logits.shape == (barcode_handler.n_barcodes, len(penalties)), 'wrong shape of priors'
 
-        ctx, prior_betas = _pack_on_device(chromosome2compressed_snp_calls, genotypes, barcode_handler.n_barcodes, True)
-        column_names = _option_names(genotypes.genotype_names, doublet_prior)
-        genotype_addition = np.zeros_like(prior_betas)
-        ctx.set_addition(None)
+        ctx = DeviceContext(default_device())
+        try:
+            _ctx, prior_betas = _pack_on_device(chromosome2compressed_snp_calls, genotypes, barcode_handler.n_barcodes,
+                                                True, ctx=ctx)
+            column_names = _option_names(genotypes.genotype_names, doublet_prior)
+            genotype_addition = np.zeros_like(prior_betas)
+            ctx.set_addition(None)
 
-        for iteration in range(n_iterations):
-            ctx.probs_from_betas(p_genotype_clip, fetch=False)
-            prior = barcode_prior_logits if iteration == 0 else None
-            logits, probs = ctx.estep(penalties, with_doublets=doublet_prior != 0, prior_logits=prior)
-            probs_df = pd.DataFrame(data=probs, index=barcode_handler.ordered_barcodes, columns=column_names)
-            yield probs_df, {
-                'barcode_logits': logits,
-                'genotype_prior': prior_betas,
-                'genotype_addition': genotype_addition,
-            }
-            genotype_addition = ctx.mstep(Demultiplexer.contribution_power)
+            for iteration in range(n_iterations):
+                ctx.probs_from_betas(p_genotype_clip, fetch=False)
+                prior = barcode_prior_logits if iteration == 0 else None
+                logits, probs = ctx.estep(penalties, with_doublets=doublet_prior != 0, prior_logits=prior)
+                probs_df = pd.DataFrame(data=probs, index=barcode_handler.ordered_barcodes, columns=column_names)
+                yield probs_df, {
+                    'barcode_logits': logits,
+                    'genotype_prior': prior_betas,
+                    'genotype_addition': genotype_addition,
+                }
+                genotype_addition = ctx.mstep(Demultiplexer.contribution_power)
+        finally:
+            ctx.close()
 
     @staticmethod
     def predict_posteriors(chromosome2compressed_snp_calls,
                            genotypes,
                            barcode_handler,
                            p_genotype_clip=0.01,
-                           doublet_prior=0.35):
+                           doublet_prior=0.35,
+                           on_device: bool = False):
         """One P + E pass (demux.py:120-156). Returns (logits_df, probs_df), rows in
-        barcode_handler.ordered_barcodes order, index named 'BARCODE'."""
+        barcode_handler.ordered_barcodes order, index named 'BARCODE'.
+        :param on_device: (not in the reference) keep logits and posteriors on the GPU and return ONE
+            DevicePosteriors object (assignments / top options / column sums are then computed there)."""
         Demultiplexer._check_not_aggregating()
         penalties = Demultiplexer._doublet_penalties(genotypes.n_genotypes, doublet_prior)
-        ctx, _betas = _pack_on_device(chromosome2compressed_snp_calls, genotypes, barcode_handler.n_barcodes, False,
-                                      fetch_betas=False)
-        ctx.set_addition(None)
-        genotype_prob = ctx.probs_from_betas(p_genotype_clip)
-        assert np.isfinite(genotype_prob).all()
-        logits, probs = ctx.estep(penalties, with_doublets=doublet_prior != 0)
-
         column_names = _option_names(genotypes.genotype_names, doublet_prior)
+
+        def run(ctx, fetch):
+            _pack_on_device(chromosome2compressed_snp_calls, genotypes, barcode_handler.n_barcodes, False,
+                            fetch_betas=False, ctx=ctx)
+            ctx.set_addition(None)
+            genotype_prob = ctx.probs_from_betas(p_genotype_clip)
+            assert np.isfinite(genotype_prob).all()
+            return ctx.estep(penalties, with_doublets=doublet_prior != 0, fetch_logits=fetch, fetch_probs=fetch)
+
+        if on_device:
+            ctx = DeviceContext(default_device())
+            try:
+                run(ctx, False)
+            except BaseException:
+                ctx.close()
+                raise
+            return DevicePosteriors(ctx, barcode_handler.ordered_barcodes, column_names, index_name='BARCODE')
+        with shared_context_lock:
+            logits, probs = run(get_context(), True)
+
         logits_df = pd.DataFrame(data=logits, index=list(barcode_handler.ordered_barcodes), columns=column_names)
         logits_df.index.name = 'BARCODE'
         probs_df = pd.DataFrame(data=probs, index=list(barcode_handler.ordered_barcodes), columns=column_names)
@@ -347,26 +462,28 @@ class Demultiplexer:
         'variant_id', 'compressed_cb', 'p_base_wrong'; genotype_prob is float32[V, G]."""
         genotype_prob = np.asarray(genotype_prob)
         assert genotype_prob.shape[1] == n_genotypes == len(genotype_names)
-        ctx = get_context()
-        ctx.set_problem(n_barcodes, genotype_prob.shape[0], n_genotypes, barcode_calls['variant_id'],
-                        barcode_calls['compressed_cb'], barcode_calls['p_base_wrong'],
-                        np.zeros(genotype_prob.shape[0], dtype=np.int32))
-        ctx.set_probs(genotype_prob)
         penalties = Demultiplexer._doublet_penalties(n_genotypes, doublet_prior=doublet_prior)
-        logits, _ = ctx.estep(penalties, with_doublets=doublet_prior != 0, fetch_probs=False)
+        with shared_context_lock:
+            ctx = get_context()
+            ctx.set_problem(n_barcodes, genotype_prob.shape[0], n_genotypes, barcode_calls['variant_id'],
+                            barcode_calls['compressed_cb'], barcode_calls['p_base_wrong'],
+                            np.zeros(genotype_prob.shape[0], dtype=np.int32))
+            ctx.set_probs(genotype_prob)
+            logits, _ = ctx.estep(penalties, with_doublets=doublet_prior != 0, fetch_probs=False)
         return logits, _option_names(genotype_names, doublet_prior)
 
     @staticmethod
     def _compute_probs_from_betas(variant_index2snp_index, variant_index2betas, p_genotype_clip):
         """P-step on caller-supplied tables (demux.py:267-274)."""
         betas = np.asarray(variant_index2betas, dtype=np.float32)
-        ctx = get_context()
         empty_i = np.zeros(0, dtype=np.int32)
-        ctx.set_problem(0, betas.shape[0], betas.shape[1], empty_i, empty_i, np.zeros(0, dtype=np.float32),
-                        variant_index2snp_index)
-        ctx.set_betas(betas)
-        ctx.set_addition(None)
-        return ctx.probs_from_betas(p_genotype_clip)
+        with shared_context_lock:
+            ctx = get_context()
+            ctx.set_problem(0, betas.shape[0], betas.shape[1], empty_i, empty_i, np.zeros(0, dtype=np.float32),
+                            variant_index2snp_index)
+            ctx.set_betas(betas)
+            ctx.set_addition(None)
+            return ctx.probs_from_betas(p_genotype_clip)
 
     @staticmethod
     def molecule_calls2barcode_calls(molecule_calls, _prepacked=None):

@@ -2,6 +2,7 @@
 stream + one resident problem (calls CSR/CSC, beta tables, logits/posteriors)."""
 import ctypes
 import os
+import threading
 
 import numpy as np
 
@@ -211,11 +212,40 @@ class DeviceContext:
         check(self._lib.dmx_get_addition(self._h, ptr(out)))
         return out
 
+    def get_block(self, what, b0=0, b1=None, k0=0, k1=None):
+        """Rows [b0, b1) x columns [k0, k1) of the resident 'logits' or 'probs' (dmx_get_block)."""
+        b1 = self.B if b1 is None else b1
+        k1 = self.K if k1 is None else k1
+        out = np.empty((b1 - b0, k1 - k0), dtype=np.float32)
+        check(self._lib.dmx_get_block(self._h, {'logits': 0, 'probs': 1}[what], b0, b1, k0, k1, ptr(out)))
+        return out
+
     def get_assignments(self):
         best = np.empty(self.B, dtype=np.int32)
         prob = np.empty(self.B, dtype=np.float32)
         check(self._lib.dmx_get_assignments(self._h, ptr(best), ptr(prob)))
         return best, prob
+
+    def get_assignments_above(self, threshold):
+        """(best option or -1 where the row maximum is not > threshold, row maximum, number assigned)."""
+        best = np.empty(self.B, dtype=np.int32)
+        prob = np.empty(self.B, dtype=np.float32)
+        n = ctypes.c_int64(0)
+        check(self._lib.dmx_get_assignments_above(self._h, float(threshold), ptr(best), ptr(prob), ctypes.byref(n)))
+        return best, prob, n.value
+
+    def get_top_options(self, k):
+        """The k (<= 4) best options per barcode, best first: (int32[B, k], float32[B, k])."""
+        options = np.empty((self.B, int(k)), dtype=np.int32)
+        probs = np.empty((self.B, int(k)), dtype=np.float32)
+        check(self._lib.dmx_get_top_options(self._h, int(k), ptr(options), ptr(probs)))
+        return options, probs
+
+    def get_option_sums(self):
+        """probs.sum(axis=0) as float64[K]."""
+        out = np.empty(self.K, dtype=np.float64)
+        check(self._lib.dmx_get_option_sums(self._h, ptr(out)))
+        return out
 
     def synchronize(self):
         check(self._lib.dmx_synchronize(self._h))
@@ -278,19 +308,32 @@ class DeviceContext:
 
 
 _contexts = {}
+_contexts_lock = threading.RLock()
 
 
 def default_device():
-    """GPU used by the Demultiplexer front-end: DEMUXALOT_AMD_DEVICE, else LOCAL_RANK, else 0."""
-    for var in ('DEMUXALOT_AMD_DEVICE', 'LOCAL_RANK'):
-        if os.environ.get(var, '') != '':
-            return int(os.environ[var])
+    """GPU used by the Demultiplexer front-end: DEMUXALOT_AMD_DEVICE (taken as is), else LOCAL_RANK, else 0.
+    Launchers often set HIP_VISIBLE_DEVICES / ROCR_VISIBLE_DEVICES per rank as well, so that every rank sees
+    ONE GPU as ordinal 0 while LOCAL_RANK still counts up: LOCAL_RANK is therefore folded into the visible
+    device count."""
+    if os.environ.get('DEMUXALOT_AMD_DEVICE', '') != '':
+        return int(os.environ['DEMUXALOT_AMD_DEVICE'])
+    if os.environ.get('LOCAL_RANK', '') != '':
+        n = _lib.device_count()
+        return int(os.environ['LOCAL_RANK']) % n if n > 0 else 0
     return 0
 
 
 def get_context(device=None) -> DeviceContext:
-    """Process-wide cached context per device. Raises when no GPU is visible (no CPU fallback)."""
+    """Process-wide cached context per device. Raises when no GPU is visible (no CPU fallback).
+    The cached context holds ONE resident problem: callers that keep state on the GPU across calls of other
+    entry points (the staged_genotype_learning generator, DevicePosteriors) own a private DeviceContext
+    instead, and the Demultiplexer entry points that use this one serialise on `shared_context_lock`."""
     device = default_device() if device is None else int(device)
-    if device not in _contexts:
-        _contexts[device] = DeviceContext(device)
-    return _contexts[device]
+    with _contexts_lock:
+        if device not in _contexts:
+            _contexts[device] = DeviceContext(device)
+        return _contexts[device]
+
+
+shared_context_lock = threading.RLock()

@@ -194,9 +194,32 @@ int dmx_get_logits(dmx_ctx *ctx, float *logits_out);
 int dmx_get_probs(dmx_ctx *ctx, float *probs_out);
 int dmx_get_addition(dmx_ctx *ctx, float *addition_out);
 
+/* A sub-block of the logits (what = DMX_LOGITS) or posteriors (DMX_PROBS) of the last E-step: rows
+ * [b0, b1) x columns [k0, k1) into out float32[(b1-b0)*(k1-k0)], row-major.  Lets a caller read sampled
+ * barcodes or the singlet columns only, without moving the whole [B, K] matrix over PCIe. */
+#define DMX_LOGITS 0
+#define DMX_PROBS 1
+int dmx_get_block(dmx_ctx *ctx, int what, int64_t b0, int64_t b1, int64_t k0, int64_t k1, float *out);
+
 /* Per-barcode reduction of the posterior on the GPU: argmax option and its
  * probability (what users take from the DataFrame: probs.idxmax(axis=1)). */
 int dmx_get_assignments(dmx_ctx *ctx, int32_t *best_option, float *best_prob);
+
+/* The reductions users of the reference apply to the posterior DataFrame, done on the GPU so that the [B, K]
+ * matrix (4.3 GB per rank at 130k barcodes x 8256 options) never has to cross PCIe:
+ *   dmx_get_assignments_above  probs[probs.max(axis=1).gt(threshold)].idxmax(axis=1)
+ *                              (examples/2-with-detection-of-new-SNPs.ipynb cell 14, demuxalot/snp_detection.py:166):
+ *                              best_option[b] = first arg-max column if its posterior is > threshold, else -1;
+ *                              best_prob[b] = the row maximum either way; *n_assigned = rows above the threshold.
+ *   dmx_get_top_options        the k (1..4) best options of every barcode, best first, ties to the lower column:
+ *                              options int32[B*k] (-1 past the end of a short row), probs float32[B*k].
+ *   dmx_get_option_sums        probs.sum(axis=0) (`probs[genotype_names].sum()`, same notebook cells 19/21) as
+ *                              float64[K], added in a fixed order (reproducible run to run).
+ * All outputs except the sums are nullable. */
+int dmx_get_assignments_above(dmx_ctx *ctx, float threshold, int32_t *best_option, float *best_prob,
+                              int64_t *n_assigned);
+int dmx_get_top_options(dmx_ctx *ctx, int32_t k, int32_t *options, float *probs);
+int dmx_get_option_sums(dmx_ctx *ctx, double *sums);
 
 /* ------------------------------------------------------------------------- *
  * Multi-GPU: one ctx per rank, barcodes sharded by the caller; the only exchange

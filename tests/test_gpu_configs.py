@@ -1,0 +1,221 @@
+"""GPU parity at the sizes BASELINE.json names (run with -m gpu on an MI355X).
+
+configs[1]  20k x 20k x 8, predict_posteriors, doublet_prior .35          -> whole result vs the oracle, bitwise
+configs[2]  200k x 100k x 32, learn_genotypes                             -> every step of three EM iterations
+configs[3]  200k x 100k x 64 (the headline shape)                          -> same, plus size-independent properties
+configs[4]  1M x 650k x 128 with doublets: one rank's share (130k barcodes) -> sampled rows + M-step rows
+
+At the full sizes the oracle cannot redo the whole problem in seconds, so each step is checked against the
+oracle GIVEN THE GPU'S OWN PREVIOUS STATE (the steps are pure functions of it):
+  P-step   the whole [V, G] table from prior + the GPU's addition                       (bitwise)
+  E-step   logits / posteriors of sampled barcode ranges from that table (rows are independent) (bitwise)
+  M-step   addition rows of EVERY variant that is cut into several work items (the 16 384-call items and the
+           exact in-order redo), the hottest single-item variants and 1 000 random ones, from the
+           GPU's posteriors with np.bincount                                             (bitwise)
+"""
+import numpy as np
+import pytest
+
+from tests import fixture_io as fio
+from tests.test_gpu_parity import check_posteriors
+
+pytestmark = pytest.mark.gpu
+
+
+def item_calls_for(n_calls):
+    """Work-item length of the M-step for a problem of n_calls calls (csrc/kernels.h: item_calls_for)."""
+    length = 1024
+    while length < 16384 and length * 6000 < n_calls:
+        length *= 2
+    return length
+
+
+def variants_to_check(p, rng, n_random=1000, n_hot=20):
+    """(sorted variant ids to recompute, number of them that span several work items)."""
+    counts = np.bincount(p.variant_id, minlength=p.n_variants)
+    multi = np.flatnonzero(counts > item_calls_for(p.n_calls))
+    hot = np.argsort(counts)[-n_hot:]
+    some = rng.choice(p.n_variants, size=min(n_random, p.n_variants), replace=False)
+    return np.unique(np.concatenate([multi, hot, some])), len(multi)
+
+
+def addition_rows(p, post_singlets, variants, power=2.):
+    """demux.py:113-118 restricted to `variants` (sorted): calls keep the reference's order (variant-major,
+    barcodes ascending), so np.bincount adds them exactly as the reference's full pass does."""
+    sel = np.flatnonzero(np.isin(p.variant_id, variants))
+    idx = np.searchsorted(variants, p.variant_id[sel])
+    cb = p.compressed_cb[sel]
+    keep = 1 - p.p_base_wrong[sel]
+    G = post_singlets.shape[1]
+    out = np.zeros((len(variants), G), dtype=np.float32)
+    for g in range(G):
+        w = post_singlets[cb, g] * keep
+        w **= power
+        out[:, g] = out[:, g] + np.bincount(idx, weights=w, minlength=len(variants))
+    return out
+
+
+def check_e_rows(ctx, oracle, p, prob, lo, hi, doublet_prior, what):
+    v, cb, e = p.subset_barcodes(lo, hi)
+    # the oracle builds one full-length column per option: hand it only the rows these barcodes touch
+    rows, v = np.unique(v, return_inverse=True)
+    want_logits = oracle.barcode_logits(v, cb, e, prob[rows], hi - lo, doublet_prior, log_impl='npsimd')
+    want_post = oracle.softmax_rows(want_logits, impl='npsimd')
+    check_posteriors(ctx.get_block('logits', lo, hi), ctx.get_block('probs', lo, hi), want_logits, want_post, what)
+
+
+def staged_em_against_oracle(oracle, p, n_iterations, doublet_prior, samples, seed, p_rows=None):
+    """Drives P / E / M by hand through the C ABI and checks every step as described in the module docstring.
+    Returns (ctx, last addition, posteriors of the singlet columns)."""
+    from demuxalot_amd import Demultiplexer
+    from demuxalot_amd.device import get_context
+    rng = np.random.default_rng(seed)
+    G = p.n_genotypes
+    prior = p.prior_betas()
+    pen = Demultiplexer._doublet_penalties(G, doublet_prior)
+    variants, n_multi = variants_to_check(p, rng)
+    ctx = get_context()
+    ctx.set_problem(p.n_barcodes, p.n_variants, G, p.variant_id, p.compressed_cb, p.p_base_wrong, p.v2snp)
+    ctx.set_betas(prior)
+    ctx.set_addition(None)
+    addition = np.zeros_like(prior)
+    singlets = None
+    for it in range(n_iterations):
+        prob = ctx.probs_from_betas(0.01)
+        for v0, v1 in (p_rows or [(0, p.n_variants)]):  # whole SNP groups (variants 2s, 2s+1)
+            want = oracle.probs_from_betas(p.v2snp[v0:v1] - p.v2snp[v0], (prior + addition)[v0:v1], 0.01)
+            fio.assert_bitwise(prob[v0:v1], want, f'it {it} P-step rows [{v0},{v1})')
+        ctx.estep(pen, with_doublets=doublet_prior != 0, fetch_logits=False, fetch_probs=False)
+        for lo, hi in samples[it % len(samples)]:
+            check_e_rows(ctx, oracle, p, prob, lo, hi, doublet_prior, f'it {it} E rows [{lo},{hi})')
+        singlets = ctx.get_block('probs', 0, p.n_barcodes, 0, G)
+        addition = ctx.mstep(2.)
+        fio.assert_bitwise(addition[variants], addition_rows(p, singlets, variants), f'it {it} M-step rows')
+    return ctx, addition, singlets, n_multi
+
+
+# ---- configs[1] ------------------------------------------------------------------------------------------
+def test_config1_predict_20k_20k_8_doublets(oracle):
+    """20k barcodes x 20k SNPs x 8 donors (N ~ 7.4 M), doublet_prior .35 (K = 36): the whole predict_posteriors
+    result through the Python front-end (objects in, DataFrames out) against the oracle, bitwise."""
+    from demuxalot_amd import Demultiplexer, synth
+    p = synth.generate(20_000, 20_000, 8, doublets=True, seed=1235)
+    calls, genotypes, handler = synth.as_objects(p)
+    logits_df, probs_df = Demultiplexer.predict_posteriors(calls, genotypes, handler, doublet_prior=0.35)
+    packed = dict(variant_id=p.variant_id, compressed_cb=p.compressed_cb, p_base_wrong=p.p_base_wrong,
+                  betas=p.prior_betas(add_data_prior=False), v2snp=p.v2snp)
+    want_logits, want_probs, _ = oracle.predict(packed, p.n_barcodes, 0.01, 0.35, impl='npsimd')
+    assert logits_df.shape == (20_000, 36) and list(probs_df.columns[:2]) == ['Donor001', 'Donor002']
+    assert probs_df.columns[8] == 'Donor001+Donor002'
+    check_posteriors(logits_df.values, probs_df.values, want_logits, want_probs, 'configs[1] predict')
+    # the device-side reductions users apply to this matrix agree with pandas on it
+    from demuxalot_amd.device import get_context
+    best, best_p = get_context().get_assignments()
+    assert np.array_equal(best, probs_df.values.argmax(axis=1)) and np.array_equal(best_p, probs_df.values.max(axis=1))
+
+
+# ---- configs[2] ------------------------------------------------------------------------------------------
+def test_config2_em_200k_100k_32(oracle):
+    """200k x 100k x 32 (N ~ 78 M): three EM iterations step by step, then the fused driver (dmx_em) must
+    reproduce the staged run bit for bit."""
+    from demuxalot_amd import synth
+    p = synth.generate(200_000, 100_000, 32, seed=1236)
+    samples = [[(0, 3000), (150_000, 152_000)], [(60_000, 62_500)], [(197_500, 200_000)]]
+    ctx, addition, singlets, n_multi = staged_em_against_oracle(oracle, p, 3, 0., samples, seed=11)
+    assert n_multi >= 20, n_multi  # the workload does have variants of several 16 384-call items
+    pen = np.zeros(32, dtype=np.float32)
+    _, probs_fused, addition_fused = ctx.em(4, 0.01, pen, with_doublets=False, fetch_logits=False)
+    # dmx_em skips the dead last M-step: after 4 iterations its addition is the one of the staged 3rd M-step
+    fio.assert_bitwise(addition_fused, addition, 'fused driver: addition')
+    assert np.abs(probs_fused.sum(axis=1) - 1).max() < 1e-5
+
+
+# ---- configs[3] shape on one GPU -------------------------------------------------------------------------
+@pytest.fixture(scope='module')
+def problem64():
+    from demuxalot_amd import synth
+    return synth.generate(200_000, 100_000, 64, seed=1237)
+
+
+def test_config3_em_200k_100k_64_steps(oracle, problem64):
+    """The headline shape (200k x 100k x 64, N ~ 78.6 M, hottest variant 72 863 calls = five work items):
+    two EM iterations step by step."""
+    samples = [[(0, 2500), (100_000, 101_500)], [(198_000, 200_000)]]
+    _ctx, _addition, _singlets, n_multi = staged_em_against_oracle(oracle, problem64, 2, 0., samples, seed=12)
+    assert n_multi >= 20, n_multi
+
+
+def test_config3_uninformative_posteriors_mstep(oracle, problem64):
+    """M-step worst case: posteriors from a flat genotype table (every donor equally likely at every variant,
+    the start-from-assignment scenario of tests/test_synthetic.py:200-239 before any label is used): every call
+    has all 64 posteriors alive, so every call takes the dense path of the call-parallel M-step."""
+    from demuxalot_amd.device import get_context
+    p = problem64
+    rng = np.random.default_rng(5)
+    ctx = get_context()
+    ctx.set_problem(p.n_barcodes, p.n_variants, 64, p.variant_id, p.compressed_cb, p.p_base_wrong, p.v2snp)
+    flat = np.ones((p.n_variants, 64), dtype=np.float32)
+    ctx.set_betas(flat)
+    ctx.set_addition(None)
+    ctx.probs_from_betas(0.01, fetch=False)
+    pen = np.zeros(64, dtype=np.float32)
+    ctx.estep(pen, with_doublets=False, fetch_logits=False, fetch_probs=False)
+    singlets = ctx.get_block('probs', 0, p.n_barcodes, 0, 64)
+    assert np.array_equal(singlets, np.full_like(singlets, 1 / 64))
+    addition = ctx.mstep(2.)
+    variants, _ = variants_to_check(p, rng, n_random=300)
+    fio.assert_bitwise(addition[variants], addition_rows(p, singlets, variants), 'dense M-step rows')
+
+
+def test_config3_full_size_properties(problem64):
+    """Size-independent properties at the headline size: posteriors are distributions; a barcode shard computed
+    alone gives the same rows (E-step rows are independent); the beta addition is additive over barcode shards
+    (what the multi-GPU exchange relies on); results are reproducible run to run."""
+    from demuxalot_amd.device import get_context
+    p = problem64
+    betas = p.prior_betas()
+    ctx = get_context()
+    pen = np.zeros(64, dtype=np.float32)
+    ctx.set_problem(p.n_barcodes, p.n_variants, 64, p.variant_id, p.compressed_cb, p.p_base_wrong, p.v2snp)
+    ctx.set_betas(betas)
+    ctx.set_addition(None)
+    ctx.probs_from_betas(0.01, fetch=False)
+    logits, probs = ctx.estep(pen, with_doublets=False)
+    addition = ctx.mstep(2.)
+    assert np.isfinite(logits).all() and np.abs(probs.sum(axis=1) - 1).max() < 1e-5
+    assert (probs >= 0).all() and (addition >= 0).all()
+    truth_hit = (probs.argmax(axis=1) == p.truth[:, 0]).mean()
+    assert truth_hit > 0.95, truth_hit
+    # run-to-run determinism (no atomics anywhere)
+    logits2, probs2 = ctx.estep(pen, with_doublets=False)
+    addition2 = ctx.mstep(2.)
+    fio.assert_bitwise(logits2, logits, 'E determinism')
+    fio.assert_bitwise(addition2, addition, 'M determinism')
+    # shard independence / additivity on two halves of the barcodes
+    cut = 100_000
+    total = np.zeros_like(addition, dtype=np.float64)
+    for lo, hi in ((0, cut), (cut, p.n_barcodes)):
+        v, cb, e = p.subset_barcodes(lo, hi)
+        ctx.set_problem(hi - lo, p.n_variants, 64, v, cb, e, p.v2snp)
+        ctx.set_betas(betas)
+        ctx.set_addition(None)
+        ctx.probs_from_betas(0.01, fetch=False)
+        l_s, p_s = ctx.estep(pen, with_doublets=False)
+        fio.assert_bitwise(l_s, logits[lo:hi], f'shard [{lo},{hi}) logits')
+        fio.assert_bitwise(p_s, probs[lo:hi], f'shard [{lo},{hi}) probs')
+        total += ctx.mstep(2.)
+    assert np.allclose(total, addition, rtol=3e-7, atol=1e-6)
+
+
+# ---- configs[4]: one rank's share --------------------------------------------------------------------------
+def test_config4_rank_share_130k_650k_128_doublets(oracle):
+    """One rank's share of 1M x 650k x 128 with doublets on 8 GPUs: 130k barcodes, 650k SNPs (V = 1.3 M, the
+    666 MB genotype table lives in HBM, not in the Infinity Cache), K = 8256 options, 4.3 GB of posteriors.
+    Sampled barcode rows against the oracle (8256 column passes each), M-step rows (genotype-per-lane kernel,
+    G > 64) from the GPU's singlet posteriors."""
+    from demuxalot_amd import synth
+    p = synth.generate(130_000, 650_000, 128, doublets=True, seed=1242)
+    samples = [[(0, 40), (129_950, 130_000)]]
+    p_rows = [(0, 200_000), (1_200_000, 1_300_000)]
+    _ctx, addition, singlets, _n_multi = staged_em_against_oracle(oracle, p, 1, 0.25, samples, seed=13, p_rows=p_rows)
+    assert singlets.shape == (130_000, 128) and (addition >= 0).all()
