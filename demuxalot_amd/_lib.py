@@ -39,6 +39,7 @@ SIGNATURES = {
     'dmx_set_prior_betas': (c_int, [_P, _P, c_double, c_int, _P, _P]),
     'dmx_set_addition': (c_int, [_P, _P]),
     'dmx_probs_from_betas': (c_int, [_P, c_float, c_float, _P]),
+    'dmx_probs_from_betas_f64': (c_int, [_P, _P, c_float, c_float, _P]),
     'dmx_set_probs': (c_int, [_P, _P]),
     'dmx_estep': (c_int, [_P, c_int, _P, _P, c_int, _P, _P]),
     'dmx_mstep': (c_int, [_P, c_float, _P]),

@@ -678,7 +678,34 @@ int dmx_set_probs(dmx_ctx *c, const float *prob)
     DMX_TRY(need(c, c->have_problem, "dmx_set_problem before dmx_set_probs"));
     if (!prob && c->V > 0) return fail(DMX_ERR_INVALID, "null prob table");
     HIP_TRY(hipMemcpyAsync(c->d_prob, prob, sizeof(float) * c->V * c->G, hipMemcpyHostToDevice, c->stream));
+    // the E-step's log is the hot-path form (finite argument >= 1e-4): a table with entries outside [0, 1]
+    // (or NaN) is refused rather than answered with numbers that mean nothing
+    HIP_TRY(hipMemsetAsync(c->d_best, 0, sizeof(int), c->stream));
+    HIP_TRY(dmx::launch_check_unit_range(c->stream, c->d_prob, c->V * c->G, c->d_best));
+    int flag = 0;
+    HIP_TRY(hipMemcpyAsync(&flag, c->d_best, sizeof(int), hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
+    if (flag) return fail(DMX_ERR_INVALID, "genotype_prob has entries outside [0, 1] (or NaN)");
+    c->have_probs = true;
+    return 0;
+}
+
+int dmx_probs_from_betas_f64(dmx_ctx *c, const double *betas, float lo, float hi, float *prob_out)
+{
+    DMX_TRY(bind(c));
+    DMX_TRY(need(c, c->have_problem, "dmx_set_problem before dmx_probs_from_betas_f64"));
+    const size_t vg = (size_t)c->V * c->G;
+    if (!betas && vg) return fail(DMX_ERR_INVALID, "null betas");
+    double *d_b = nullptr;
+    HIP_TRY(hipMalloc((void **)&d_b, (vg ? vg : 1) * sizeof(double)));
+    hipError_t e = vg ? hipMemcpyAsync(d_b, betas, vg * sizeof(double), hipMemcpyHostToDevice, c->stream) : hipSuccess;
+    if (e == hipSuccess)
+        e = dmx::launch_probs_from_betas_f64(c->stream, d_b, c->d_v2snp, c->d_snp_ptr, c->d_snp_vars, c->V, c->G, lo, hi, c->d_prob);
+    if (e == hipSuccess && prob_out && vg) e = hipMemcpyAsync(prob_out, c->d_prob, vg * sizeof(float), hipMemcpyDeviceToHost, c->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    (void)hipStreamSynchronize(c->stream);
+    (void)hipFree(d_b);
+    if (e != hipSuccess) return fail(DMX_ERR_HIP, "P-step from float64 betas: %s", hipGetErrorString(e));
     c->have_probs = true;
     return 0;
 }

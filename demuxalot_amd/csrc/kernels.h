@@ -80,6 +80,11 @@ constexpr int M_CHUNKS = 1;       // variant ranges whose all-reduce overlaps th
 hipError_t launch_probs_from_betas(hipStream_t st, const float *prior, const float *addition, const int *v2snp,
                                    const int *snp_ptr, const int *snp_vars, long long V, int G, float lo, float hi,
                                    float *prob);
+// the same from caller-supplied float64 betas (no addition): numpy divides float64 / float64 and rounds once
+hipError_t launch_probs_from_betas_f64(hipStream_t st, const double *betas, const int *v2snp, const int *snp_ptr,
+                                       const int *snp_vars, long long V, int G, float lo, float hi, float *prob);
+// sets flags[0] bit 0 when a value lies outside [0, 1] or is not finite
+hipError_t launch_check_unit_range(hipStream_t st, const float *x, long long n, int *flags);
 hipError_t launch_estep(hipStream_t st, const EstepArgs &a, bool pairs);
 hipError_t launch_mstep(hipStream_t st, const MstepArgs &a);
 // sums the item partials of variants [v0, v1) and redoes, in the reference's order, the sums whose float32

@@ -1,11 +1,13 @@
 // kernels.hip -- gfx950 kernels of the Demultiplexer EM hot path.
 //
 //   k_probs_from_betas   P-step   demuxalot/demux.py:267-274
-//   k_estep_direct       E-step + softmax, one wavefront per barcode, options on lanes
-//                        (K <= 256)                         demux.py:246-265, :101/:152
+//   k_estep_direct       E-step + softmax, one lane group (4..64 lanes) per barcode, options on lanes,
+//                        up to 16 options per lane (K <= 1024)   demux.py:246-265, :101/:152
 //   k_estep_block        E-step + softmax, one 256-thread workgroup per barcode, genotype
-//                        rows staged in LDS (K > 256: doublets of many genotypes)
-//   k_mstep / k_mcombine M-step (variant-major, no atomics)  demux.py:113-118
+//                        rows staged in LDS (K > 1024: doublets of 45 or more genotypes)
+//   k_softmax_rows       finishes rows whose options were tiled over several k_estep_block launches (K > 8448)
+//   k_mstep_calls / k_mstep / k_mcombine / k_mstep_exact
+//                        M-step (variant-major, no atomics)      demux.py:113-118
 //   k_assign             per-barcode argmax of the posterior
 //
 // Numerics: float32 element-wise work in the reference's operation order, float64
@@ -33,8 +35,11 @@ static __device__ __forceinline__ double shfl_xor_f64(double v, int mask)
 // P-step.  One thread per (variant, genotype).  The per-SNP denominator is the float64 sum
 // of beta over the SNP's variants in increasing variant index (np.bincount order).
 // ------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_probs_from_betas(const float *__restrict__ prior,
-                                                          const float *__restrict__ addition,
+// T = float: the EM path (betas + addition, both float32).  T = double: caller-supplied float64 betas
+// (numpy then divides float64 by float64 and rounds once to float32; no addition).
+template <typename T>
+__global__ __launch_bounds__(256) void k_probs_from_betas(const T *__restrict__ prior,
+                                                          const T *__restrict__ addition,
                                                           const int *__restrict__ v2snp,
                                                           const int *__restrict__ snp_ptr,
                                                           const int *__restrict__ snp_vars, long long V, int G,
@@ -48,10 +53,10 @@ __global__ __launch_bounds__(256) void k_probs_from_betas(const float *__restric
     double den = 0.0;
     for (int j = snp_ptr[snp]; j < snp_ptr[snp + 1]; j++) {
         const long long o = (long long)snp_vars[j] * G + g;
-        const float b = addition ? prior[o] + addition[o] : prior[o];  // float32 add, demux.py:90
+        const T b = addition ? prior[o] + addition[o] : prior[o];  // float32 add, demux.py:90
         den += (double)b;
     }
-    const float beta = addition ? prior[i] + addition[i] : prior[i];
+    const T beta = addition ? prior[i] + addition[i] : prior[i];
     const double q = (double)beta / fmax(den, 1e-7);
     float p = (float)q;
     p = fminf(fmaxf(p, clip_lo), clip_hi);  // ndarray.clip(lo, hi) = minimum(maximum(x, lo), hi)
@@ -206,7 +211,7 @@ static __device__ __forceinline__ int group_max_over_wave(int v)
 }
 
 // ------------------------------------------------------------------------------------
-// E-step, direct form (K <= 256).  A wavefront is cut into 64/L lane groups; every group owns
+// E-step, direct form (K <= 1024).  A wavefront is cut into 64/L lane groups; every group owns
 // one barcode and walks its calls IN ORDER (so the float64 sum has the reference's bincount
 // association), lane l of the group accumulates option l (+64*s).  Barcodes are handed out from
 // a row-length-sorted list, so the groups of a wave (and neighbouring waves) finish together.
@@ -241,7 +246,55 @@ static __device__ __forceinline__ void estep_terms(const npm::f32x2 (&p1)[H][A],
     }
 }
 
-template <int L, int A, bool PAIRS, int U>
+// ------------------------------------------------------------------------------------
+// Tolerance mode of the E-step (dmx_set_estep_mode(ctx, DMX_ESTEP_FAST)).  The contract of the path is
+// "assignments identical, posteriors within 1e-5" (BASELINE.json north_star); the default mode above pays
+// ~68 VALU issue cycles per term to repeat numpy's float32 log bit for bit.  Here the terms of 8 consecutive
+// calls are MULTIPLIED (two float32 chains, even / odd calls, packed), and one hardware log2 is taken per 8 calls:
+//     sum_c log(t_c) = ln2 * sum_chunks [ exponent(P) + log2(mantissa(P)) ],   P = prod of the chunk's 8 terms.
+// t_c >= 1e-4, so P >= 1e-32 never underflows; t_c <= 2, so P <= 256.  The mantissa logs (in [-1, 0]) are
+// accumulated in float64, the exponents as integers.  7 roundings of relative size 2^-24 and one 1-ulp log2 per
+// 8 terms are smaller than the rounding noise numpy's own float32 log leaves in the reference's terms.
+// ------------------------------------------------------------------------------------
+struct FastAcc {
+    double mant;  // sum of log2(mantissa) of the flushed chunk products
+    int expo;     // sum of their binary exponents
+};
+
+template <int A, bool PAIRS, int H>
+static __device__ __forceinline__ void estep_products(const npm::f32x2 (&p1)[H][A], const npm::f32x2 (&p2)[H][A],
+                                                      const npm::f32x2 (&keep)[H], const npm::f32x2 (&flo)[H],
+                                                      npm::f32x2 (&prod)[A], int n_slots)
+{
+#pragma unroll
+    for (int q = 0; q < H; q++) {
+#pragma unroll
+        for (int s = 0; s < A; s++) {
+            if (A > 1 && s >= n_slots) continue;
+            npm::f32x2 p = p1[q][s];
+            if (PAIRS) p = (p + p2[q][s]) * 0.5f;
+            npm::f32x2 t = p * keep[q];
+            t = t + flo[q];
+            prod[s] = prod[s] * t;
+        }
+    }
+}
+
+template <int A>
+static __device__ __forceinline__ void estep_flush(npm::f32x2 (&prod)[A], FastAcc (&acc)[A], int n_slots)
+{
+#pragma unroll
+    for (int s = 0; s < A; s++) {
+        if (A > 1 && s >= n_slots) continue;
+        const float pr = prod[s].x * prod[s].y;
+        const float m = __builtin_amdgcn_frexp_mantf(pr);  // [0.5, 1); NaN stays NaN
+        acc[s].expo += __builtin_amdgcn_frexp_expf(pr);
+        acc[s].mant += (double)__builtin_amdgcn_logf(m);   // v_log_f32 = log2
+        prod[s] = npm::f32x2{1.0f, 1.0f};
+    }
+}
+
+template <int L, int A, bool PAIRS, int U, bool FAST>
 __global__ __launch_bounds__(256) void k_estep_direct(EstepArgs a)
 {
     static_assert(A == 1 || L == 64, "several accumulators per lane only with 64 lanes per call");
@@ -270,8 +323,15 @@ __global__ __launch_bounds__(256) void k_estep_direct(EstepArgs a)
         }
     }
     double acc[A];
+    FastAcc facc[A];
+    npm::f32x2 prod[A];
 #pragma unroll
-    for (int s = 0; s < A; s++) acc[s] = 0.0;
+    for (int s = 0; s < A; s++) {
+        acc[s] = 0.0;
+        facc[s].mant = 0.0;
+        facc[s].expo = 0;
+        prod[s] = npm::f32x2{1.0f, 1.0f};
+    }
     const char *__restrict__ prob = (const char *)a.prob;
     const int n_slots = (K + 63) >> 6;  // register slots that hold at least one option (A may be larger)
 
@@ -310,7 +370,12 @@ __global__ __launch_bounds__(256) void k_estep_direct(EstepArgs a)
                     }
                 }
             }
-            estep_terms<A, PAIRS, H>(p1, p2, keep, flo, acc, n_slots);
+            if constexpr (FAST) {
+                estep_products<A, PAIRS, H>(p1, p2, keep, flo, prod, n_slots);
+                if (((j0 + H) & 3) == 0) estep_flush<A>(prod, facc, n_slots);  // every 8 calls (rows are padded to 8)
+            } else {
+                estep_terms<A, PAIRS, H>(p1, p2, keep, flo, acc, n_slots);
+            }
         }
     } else {
         const long long slot = ((long long)blockIdx.x * 4 + (threadIdx.x >> 6)) * CPW + lane / L;
@@ -354,9 +419,19 @@ __global__ __launch_bounds__(256) void k_estep_direct(EstepArgs a)
                         }
                     }
                 }
-                estep_terms<A, PAIRS, H>(p1, p2, keep, flo, acc, n_slots);
+                if constexpr (FAST) {
+                    estep_products<A, PAIRS, H>(p1, p2, keep, flo, prod, n_slots);
+                    if (((c0 + i0 + U) & 7) == 0) estep_flush<A>(prod, facc, n_slots);
+                } else {
+                    estep_terms<A, PAIRS, H>(p1, p2, keep, flo, acc, n_slots);
+                }
             }
         }
+    }
+    if constexpr (FAST) {
+        const double LN2 = 0.693147180559945309417232121458176568;
+#pragma unroll
+        for (int s = 0; s < A; s++) acc[s] = (facc[s].mant + (double)facc[s].expo) * LN2;
     }
 
     // epilogue: penalties, optional prior, softmax as scipy evaluates it
@@ -406,7 +481,7 @@ __global__ __launch_bounds__(256) void k_estep_direct(EstepArgs a)
 }
 
 // ------------------------------------------------------------------------------------
-// E-step, block form (K > 256).  One 256-thread workgroup per barcode, option k = s*256 + tid.
+// E-step, block form (K > 1024).  One 256-thread workgroup per barcode, option k = s*256 + tid.
 // A chunk of C calls (C a multiple of 8 = the row padding) is staged in LDS TRANSPOSED:
 // sh_t[g][c], row stride C+2 dwords, so that the probabilities of genotype g for the call pair
 // (c, c+1) are one aligned 8-byte word = exactly the packed operand of the two-term log.  Every
@@ -978,10 +1053,11 @@ __global__ __launch_bounds__(256) void k_mcombine(const double *__restrict__ par
 }
 
 // The queued sums, redone exactly as the reference does them: all calls of the variant, in order, into ONE float64
-// accumulator.  A 512-thread workgroup per queued (variant, genotype) pair (persistent: the queue length is only
-// known on the device).  The variant is walked in segments of 8 x 1024 calls: each of the 8 wavefronts
-// collects the non-zero contributions of its 1024 calls to the genotype in LDS (call order), then wavefront 0 adds
-// the 8 lists in order.  The gathers -- the expensive part -- run in parallel; only the additions are serial.
+// accumulator.  A workgroup of EXACT_WAVES wavefronts per queued (variant, genotype) pair (persistent: the queue
+// length is only known on the device).  The variant is walked in segments of EXACT_WAVES x EXACT_SPAN calls: each
+// wavefront collects the non-zero contributions of its EXACT_SPAN calls to the genotype in LDS (call order), then
+// wavefront 0 adds the lists in order.  The gathers -- the expensive part -- run in parallel; only the additions
+// are serial.
 constexpr int EXACT_WAVES = 16;
 constexpr int EXACT_SPAN = 512;  // calls per wavefront and segment (LDS: EXACT_WAVES * EXACT_SPAN floats)
 template <bool SQUARE>
@@ -1165,8 +1241,32 @@ hipError_t launch_probs_from_betas(hipStream_t st, const float *prior, const flo
                                    float *prob)
 {
     if (V * G == 0) return hipSuccess;
-    hipLaunchKernelGGL(k_probs_from_betas, dim3(blocks_for(V * G, 256)), dim3(256), 0, st, prior, addition, v2snp,
+    hipLaunchKernelGGL(k_probs_from_betas<float>, dim3(blocks_for(V * G, 256)), dim3(256), 0, st, prior, addition, v2snp,
                        snp_ptr, snp_vars, V, G, lo, hi, prob);
+    return hipGetLastError();
+}
+
+hipError_t launch_probs_from_betas_f64(hipStream_t st, const double *betas, const int *v2snp, const int *snp_ptr,
+                                       const int *snp_vars, long long V, int G, float lo, float hi, float *prob)
+{
+    if (V * G == 0) return hipSuccess;
+    hipLaunchKernelGGL(k_probs_from_betas<double>, dim3(blocks_for(V * G, 256)), dim3(256), 0, st, betas,
+                       (const double *)nullptr, v2snp, snp_ptr, snp_vars, V, G, lo, hi, prob);
+    return hipGetLastError();
+}
+
+// flags[0] |= 1 when any of the n values is outside [0, 1] or not finite (caller-supplied probability tables)
+__global__ __launch_bounds__(256) void k_check_unit_range(const float *__restrict__ x, long long n, int *__restrict__ flags)
+{
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const bool bad = i < n && !(x[i < n ? i : 0] >= 0.0f && x[i < n ? i : 0] <= 1.0f);
+    if (__ballot(bad) != 0ull && (threadIdx.x & 63) == 0) atomicOr(flags, 1);
+}
+
+hipError_t launch_check_unit_range(hipStream_t st, const float *x, long long n, int *flags)
+{
+    if (n == 0) return hipSuccess;
+    hipLaunchKernelGGL(k_check_unit_range, dim3(blocks_for(n, 256)), dim3(256), 0, st, x, n, flags);
     return hipGetLastError();
 }
 

@@ -23,20 +23,23 @@ namespace dmx {
 namespace {
 
 // range check without atomics in the good case: a wave only touches memory when it saw a bad index
-__global__ __launch_bounds__(256) void k_validate(const int *__restrict__ variant, const int *__restrict__ cb, long long N,
-                                                  long long B, long long V, int *__restrict__ bad)
+// bad[0..2] = flags (barcode, variant, p_base_wrong out of range), bad[3] = lowest offending call index.
+// p_base_wrong must be a probability: the E-step's log assumes a finite argument >= 1e-4, which
+// p * (1 - e) + max(e, 1e-4) is exactly when 0 <= e <= 1 (NaN fails both comparisons).
+__global__ __launch_bounds__(256) void k_validate(const int *__restrict__ variant, const int *__restrict__ cb,
+                                                  const float *__restrict__ p_wrong, long long N, long long B, long long V,
+                                                  unsigned long long *__restrict__ bad)
 {
     const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     const bool in = i < N;
     const bool bad_b = in && ((unsigned)cb[in ? i : 0] >= (unsigned long long)B);
     const bool bad_v = in && ((unsigned)variant[in ? i : 0] >= (unsigned long long)V);
-    if (__ballot(bad_b || bad_v) == 0ull) return;
-    if (bad_b) {
-        atomicMax(&bad[0], 1);
-        atomicMin(&bad[2], (int)(i < 0x7fffffff ? i : 0x7fffffff));
-    } else if (bad_v) {
-        atomicMax(&bad[1], 1);
-        atomicMin(&bad[2], (int)(i < 0x7fffffff ? i : 0x7fffffff));
+    const float e = p_wrong[in ? i : 0];
+    const bool bad_p = in && !(e >= 0.0f && e <= 1.0f);
+    if (__ballot(bad_b || bad_v || bad_p) == 0ull) return;
+    if (bad_b || bad_v || bad_p) {
+        atomicMax(&bad[bad_b ? 0 : (bad_v ? 1 : 2)], 1ull);
+        atomicMin(&bad[3], (unsigned long long)i);
     }
 }
 
@@ -223,20 +226,28 @@ static int repack_core(dmx_ctx *c, Scratch &sc, const int *d_variant, const int 
     hipStream_t st = c->stream;
     c->item_calls = item_calls_for(N);
 
+    // the sorts below carry call indices as 32-bit values
+    if (N >= (1LL << 32)) return fail(DMX_ERR_UNSUPPORTED, "%lld calls: one context holds fewer than 2^32 (shard the barcodes)", N);
+
     // ---- range check ----
-    int *bad = nullptr;
-    DMX_TRY(sc.get(&bad, 3));
-    const int bad_init[3] = {0, 0, 0x7fffffff};
+    unsigned long long *bad = nullptr;
+    DMX_TRY(sc.get(&bad, 4));
+    const unsigned long long bad_init[4] = {0, 0, 0, ~0ull};
     HIP_TRY(hipMemcpyAsync(bad, bad_init, sizeof bad_init, hipMemcpyHostToDevice, st));
-    if (N) hipLaunchKernelGGL(k_validate, dim3(grid_for(N)), dim3(256), 0, st, d_variant, d_cb, N, B, V, bad);
-    int h_bad[3];
+    if (N) hipLaunchKernelGGL(k_validate, dim3(grid_for(N)), dim3(256), 0, st, d_variant, d_cb, d_p, N, B, V, bad);
+    unsigned long long h_bad[4];
     HIP_TRY(hipMemcpyAsync(h_bad, bad, sizeof h_bad, hipMemcpyDeviceToHost, st));
     HIP_TRY(hipStreamSynchronize(st));
     if (h_bad[0] || h_bad[1]) {
         int value = 0;
-        (void)hipMemcpy(&value, (h_bad[0] ? d_cb : d_variant) + h_bad[2], sizeof(int), hipMemcpyDeviceToHost);
-        return fail(DMX_ERR_INVALID, "%s[%d]=%d outside [0,%lld)", h_bad[0] ? "compressed_cb" : "variant_id", h_bad[2],
+        (void)hipMemcpy(&value, (h_bad[0] ? d_cb : d_variant) + h_bad[3], sizeof(int), hipMemcpyDeviceToHost);
+        return fail(DMX_ERR_INVALID, "%s[%llu]=%d outside [0,%lld)", h_bad[0] ? "compressed_cb" : "variant_id", h_bad[3],
                     value, h_bad[0] ? B : V);
+    }
+    if (h_bad[2]) {
+        float value = 0.0f;
+        (void)hipMemcpy(&value, d_p + h_bad[3], sizeof(float), hipMemcpyDeviceToHost);
+        return fail(DMX_ERR_INVALID, "p_base_wrong[%llu]=%g outside [0,1]", h_bad[3], (double)value);
     }
 
     // ---- stable sorts of (key, input index); offsets from the sorted keys ----

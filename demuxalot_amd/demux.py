@@ -474,13 +474,18 @@ class Demultiplexer:
 
     @staticmethod
     def _compute_probs_from_betas(variant_index2snp_index, variant_index2betas, p_genotype_clip):
-        """P-step on caller-supplied tables (demux.py:267-274)."""
-        betas = np.asarray(variant_index2betas, dtype=np.float32)
+        """P-step on caller-supplied tables (demux.py:267-274).  float32 betas take the EM path's kernel; any
+        other dtype is carried as float64, as numpy's own promotion does (float64 division, one rounding)."""
+        betas = np.asarray(variant_index2betas)
+        as_f32 = betas.dtype == np.float32
+        betas = np.ascontiguousarray(betas, dtype=np.float32 if as_f32 else np.float64)
         empty_i = np.zeros(0, dtype=np.int32)
         with shared_context_lock:
             ctx = get_context()
             ctx.set_problem(0, betas.shape[0], betas.shape[1], empty_i, empty_i, np.zeros(0, dtype=np.float32),
                             variant_index2snp_index)
+            if not as_f32:
+                return ctx.probs_from_betas_f64(betas, p_genotype_clip)
             ctx.set_betas(betas)
             ctx.set_addition(None)
             return ctx.probs_from_betas(p_genotype_clip)

@@ -146,6 +146,15 @@ class DeviceContext:
         check(self._lib.dmx_probs_from_betas(self._h, lo, hi, ptr(out)))
         return out
 
+    def probs_from_betas_f64(self, betas, p_genotype_clip):
+        """P-step on caller-supplied float64 betas (dmx_probs_from_betas_f64)."""
+        betas = as_c(betas, np.float64)
+        assert betas.shape == (self.V, self.G)
+        lo, hi = self.clip_bounds(p_genotype_clip)
+        out = np.empty((self.V, self.G), dtype=np.float32)
+        check(self._lib.dmx_probs_from_betas_f64(self._h, ptr(betas), lo, hi, ptr(out)))
+        return out
+
     def _n_options(self, with_doublets):
         return self.G * (self.G + 1) // 2 if with_doublets else self.G
 

@@ -155,8 +155,14 @@ int dmx_set_addition(dmx_ctx *ctx, const float *addition);
  * nullable) receives a copy of the table. */
 int dmx_probs_from_betas(dmx_ctx *ctx, float clip_lo, float clip_hi, float *prob_out);
 
+/* The same P-step on caller-supplied float64 betas[V*G] (the public helper Demultiplexer._compute_probs_from_betas
+ * accepts any dtype; numpy then divides float64 by float64 and rounds to float32 once): no addition is applied,
+ * the resident prior betas are left alone. */
+int dmx_probs_from_betas_f64(dmx_ctx *ctx, const double *betas, float clip_lo, float clip_hi, float *prob_out);
+
 /* Direct upload of a genotype_prob table float32[V*G] (for callers of
- * compute_barcode_logits_using_barcode_calls that bring their own table). */
+ * compute_barcode_logits_using_barcode_calls that bring their own table).  Entries must be probabilities:
+ * a table with values outside [0, 1] or NaN is refused (DMX_ERR_INVALID). */
 int dmx_set_probs(dmx_ctx *ctx, const float *prob);
 
 /* E-step + posterior: Demultiplexer.compute_barcode_logits_using_barcode_calls

@@ -540,45 +540,3 @@ def test_doublets_block_kernel_matches_oracle(oracle):
         hist = oracle.em(packed, B, 2, 0.01, 0.3, impl='npsimd')
         check_posteriors(logits, probs, hist[-1]['logits'], hist[-1]['probs'], f'doublets G={G}')
         fio.assert_bitwise(addition, hist[-1]['addition'], f'doublets G={G} addition')
-
-
-def test_full_size_properties():
-    """BASELINE.json size (200k barcodes x 100k SNPs x 64 genotypes, N ~ 78M): size-independent
-    properties instead of an oracle run -- posteriors are distributions; a barcode shard computed
-    alone gives the same rows (E-step rows are independent); the beta addition is additive over
-    barcode shards (what the multi-GPU all-reduce relies on); results are reproducible run to run."""
-    from demuxalot_amd import synth
-    from demuxalot_amd.device import get_context
-    p = synth.generate(200_000, 100_000, 64, seed=1237)
-    betas = p.prior_betas()
-    ctx = get_context()
-    pen = np.zeros(64, dtype=np.float32)
-    ctx.set_problem(p.n_barcodes, p.n_variants, 64, p.variant_id, p.compressed_cb, p.p_base_wrong, p.v2snp)
-    ctx.set_betas(betas)
-    ctx.set_addition(None)
-    ctx.probs_from_betas(0.01, fetch=False)
-    logits, probs = ctx.estep(pen, with_doublets=False)
-    addition = ctx.mstep(2.)
-    assert np.isfinite(logits).all() and np.abs(probs.sum(axis=1) - 1).max() < 1e-5
-    assert (probs >= 0).all() and (addition >= 0).all()
-    truth_hit = (probs.argmax(axis=1) == p.truth[:, 0]).mean()
-    assert truth_hit > 0.95, truth_hit
-    # run-to-run determinism (no atomics anywhere)
-    logits2, probs2 = ctx.estep(pen, with_doublets=False)
-    addition2 = ctx.mstep(2.)
-    fio.assert_bitwise(logits2, logits, 'E determinism')
-    fio.assert_bitwise(addition2, addition, 'M determinism')
-    # shard independence / additivity on two halves of the barcodes
-    cut = 100_000
-    total = np.zeros_like(addition, dtype=np.float64)
-    for lo, hi in ((0, cut), (cut, p.n_barcodes)):
-        v, cb, e = p.subset_barcodes(lo, hi)
-        ctx.set_problem(hi - lo, p.n_variants, 64, v, cb, e, p.v2snp)
-        ctx.set_betas(betas)
-        ctx.set_addition(None)
-        ctx.probs_from_betas(0.01, fetch=False)
-        l_s, p_s = ctx.estep(pen, with_doublets=False)
-        fio.assert_bitwise(l_s, logits[lo:hi], f'shard [{lo},{hi}) logits')
-        fio.assert_bitwise(p_s, probs[lo:hi], f'shard [{lo},{hi}) probs')
-        total += ctx.mstep(2.)
-    assert np.allclose(total, addition, rtol=3e-7, atol=1e-6)

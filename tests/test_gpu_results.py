@@ -124,3 +124,43 @@ def test_generator_survives_other_calls_between_iterations():
         fio.assert_bitwise(logits_df.values, other['predict0_logits'], 'interleaved predict')
         Demultiplexer.learn_genotypes(o_calls, o_genotypes, o_handler, n_iterations=2)
     assert it == kwargs['n_iterations'] - 1
+
+
+# ---- input validation and the public helpers on caller-supplied tables --------------------------------------
+def test_inputs_outside_their_domain_are_refused():
+    """The E-step's log is the hot-path form (finite argument >= 1e-4): p_base_wrong outside [0, 1] and caller-supplied
+    probability tables with entries outside [0, 1] (or NaN) are refused instead of answered with meaningless numbers."""
+    from demuxalot_amd import _lib
+    from demuxalot_amd.device import DeviceContext
+    ctx = DeviceContext(0)
+    try:
+        args = (2, 3, 2, np.array([0, 1]), np.array([0, 1]))
+        for bad in (1.5, -0.1, np.nan, np.inf):
+            with pytest.raises(_lib.DemuxHipError, match=r'p_base_wrong\[1\]'):
+                ctx.set_problem(*args, np.array([.1, bad], dtype='f4'), np.zeros(3, dtype='i4'))
+        ctx.set_problem(*args, np.array([0., 1.], dtype='f4'), np.zeros(3, dtype='i4'))  # the closed interval is fine
+        for bad in (1.0000001, -1e-9, np.nan):
+            table = np.full((3, 2), 0.5, dtype=np.float32)
+            table[2, 1] = bad
+            with pytest.raises(_lib.DemuxHipError, match='outside'):
+                ctx.set_probs(table)
+        ctx.set_probs(np.array([[0, 1], [.5, .5], [1, 0]], dtype=np.float32))
+        logits, _ = ctx.estep(np.zeros(2, dtype=np.float32), with_doublets=False)
+        assert np.isfinite(logits).all()
+    finally:
+        ctx.close()
+
+
+def test_compute_probs_from_betas_float64_input(oracle):
+    """Demultiplexer._compute_probs_from_betas with float64 betas: numpy divides float64 by float64 and rounds
+    once (demux.py:267-274), which differs from casting the betas to float32 first."""
+    from demuxalot_amd import Demultiplexer
+    rng = np.random.default_rng(8)
+    v2snp = np.repeat(np.arange(400, dtype=np.int32), rng.integers(1, 4, size=400))
+    betas64 = rng.gamma(2.0, 30.0, size=(len(v2snp), 7)) * (rng.random((len(v2snp), 7)) > 0.1)
+    want = oracle.probs_from_betas(v2snp, betas64, 0.02)
+    got = Demultiplexer._compute_probs_from_betas(v2snp, betas64, 0.02)
+    fio.assert_bitwise(got, want, 'float64 betas')
+    assert not np.array_equal(want, oracle.probs_from_betas(v2snp, betas64.astype(np.float32), 0.02))
+    got32 = Demultiplexer._compute_probs_from_betas(v2snp, betas64.astype(np.float32), 0.02)
+    fio.assert_bitwise(got32, oracle.probs_from_betas(v2snp, betas64.astype(np.float32), 0.02), 'float32 betas')

@@ -169,14 +169,11 @@ def test_barcode_handler_and_container():
     assert h.ordered_barcodes == ['A-1', 'G-1', 'T-1'] and h.n_barcodes == 3 and h.barcode2index['G-1'] == 1
     with pytest.raises(AssertionError):
         BarcodeHandler(['A', 'A'])
-    c = CompressedSNPCalls(start_snps_size=2, start_molecule_size=1)
-    c.add_calls_from_read_group(3, 77, 0.01, [(10, 'A', 0.1), (11, 'T', 0.2), (15, 'G', 0.3)])
-    c.add_calls_from_read_group(1, 78, 0.02, [(10, 'C', 0.1)])
-    assert (c.n_molecules, c.n_snp_calls) == (2, 4)
-    assert list(c.snp_calls[:4]['base_index']) == [0, 3, 2, 1] and list(c.snp_calls[:4]['molecule_index']) == [0, 0, 0, 1]
-    c.minimize_memory_footprint()
-    joined = CompressedSNPCalls.concatenate([c, c])
-    assert joined.n_molecules == 4 and list(joined.snp_calls['molecule_index']) == [0, 0, 0, 1, 2, 2, 2, 3]
+    c = CompressedSNPCalls.from_arrays([3, 1], [0, 0, 0, 1], [10, 11, 15, 10], [0, 3, 2, 1], [0.1, 0.2, 0.3, 0.1])
+    assert (c.n_molecules, c.n_snp_calls) == (2, 4) and c.snp_calls.dtype.itemsize == 13 and c.molecules.dtype.itemsize == 12
+    assert list(c.snp_calls['base_index']) == [0, 3, 2, 1] and list(c.molecules['compressed_cb']) == [3, 1]
+    empty = CompressedSNPCalls()
+    assert (empty.n_molecules, empty.n_snp_calls) == (0, 0)
 
 
 def test_genotype_clone_is_independent():
