@@ -8,9 +8,11 @@
 One "step" = one EM iteration of learn_genotypes on device-resident inputs: P-step (beta ->
 probability), E-step + softmax, M-step (+ RCCL all-reduce of the beta addition when N > 1).
 Workload (BASELINE.json metric): 200k barcodes x 100k SNPs x 64 genotypes per GPU, synthetic
-(demuxalot_amd/synth.py).  With N GPUs every rank owns its own 200k-barcode shard
-of an N x 200k-barcode experiment (weak scaling); the genotype tables are replicated and the
-per-rank beta additions are all-reduced every iteration.
+(demuxalot_amd/synth.py).  With N GPUs (--scaling weak, the default) every rank owns its
+own 200k-barcode shard of an N x 200k-barcode experiment; the beta tables are replicated and the per-rank
+beta additions are exchanged every iteration (reduce-scatter over variant slices, P-step on the owned slice,
+all-gather of genotype_prob: include/demux_hip.h "Multi-GPU").  --scaling strong is BASELINE.json configs[3]
+as written: ONE 200k-barcode experiment cut into N barcode ranges with equal numbers of calls.
 
 Prints ONE JSON line on rank 0 (contract in the task statement) with `roofline` (E-step kernel,
 HIP-event timed on the stream it runs on) and `cpu_baseline` (the numpy oracle, one core, on a
@@ -92,6 +94,11 @@ def measured_traffic(workload, kernel):
         return None
 
 
+def _lib_device_count():
+    from demuxalot_amd import _lib
+    return _lib.device_count()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -99,7 +106,10 @@ def main():
     ap.add_argument('--warmup', type=int, default=2)
     ap.add_argument('--workload', default='em_200k_100k_64', choices=sorted(WORKLOADS))
     ap.add_argument('--reduce-dtype', default='f64', choices=['f64', 'f32'])
+    ap.add_argument('--scaling', default='weak', choices=['weak', 'strong'],
+                    help='weak: the workload per GPU; strong: the workload in total, barcodes sharded over the GPUs')
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-fast-mode', action='store_true', help='skip the second timed region (tolerance-mode E-step)')
     ap.add_argument('--force-dist', action='store_true',
                     help='testing aid: run the multi-rank control/collective path even with one rank')
     args = ap.parse_args()
@@ -129,23 +139,36 @@ def main():
     from demuxalot_amd.device import DeviceContext
 
     B, S, G, dp, seed = WORKLOADS[args.workload]
+    B_total = B  # barcodes of the whole job: per GPU x GPUs (weak) or the workload's own count (strong)
     t_gen = time.perf_counter()
-    problem = synth.generate(B, S, G, doublets=dp > 0, seed=seed, seed_calls=seed * 1000 + rank)
-    betas = problem.prior_betas(add_data_prior=False)  # identical on every rank
+    if args.scaling == 'strong' and world > 1:
+        from demuxalot_amd.distributed import partition_barcodes
+        whole = synth.generate(B, S, G, doublets=dp > 0, seed=seed)  # the same experiment on every rank
+        betas = whole.prior_betas(add_data_prior=False)
+        bounds = partition_barcodes(np.bincount(whole.compressed_cb, minlength=B), world)
+        lo, hi = int(bounds[rank]), int(bounds[rank + 1])
+        v_s, cb_s, e_s = whole.subset_barcodes(lo, hi)
+        problem = synth.SyntheticProblem(hi - lo, S, G, whole.v2snp, whole.raw_betas, v_s, cb_s, e_s, whole.truth[lo:hi])
+        del whole
+        B = hi - lo
+    else:
+        problem = synth.generate(B, S, G, doublets=dp > 0, seed=seed, seed_calls=seed * 1000 + rank)
+        betas = problem.prior_betas(add_data_prior=False)  # identical on every rank
+        B_total = B * world
     t_gen = time.perf_counter() - t_gen
     V, N = problem.n_variants, problem.n_calls
     pen = Demultiplexer._doublet_penalties(G, dp)
     K = len(pen)
 
-    ctx = DeviceContext(local_rank)
-    t_up = time.perf_counter()
-    ctx.set_problem(B, V, G, problem.variant_id, problem.compressed_cb, problem.p_base_wrong, problem.v2snp)
-    ctx.set_betas(betas)
-    t_up = time.perf_counter() - t_up
+    ctx = DeviceContext(local_rank % max(1, _lib_device_count()))
     if use_dist:
         ids = [DeviceContext.new_unique_id() if rank == 0 else None]
         dist.broadcast_object_list(ids, src=0)
         ctx.comm_init(rank, world, ids[0], reduce_dtype=args.reduce_dtype)
+    t_up = time.perf_counter()
+    ctx.set_problem(B, V, G, problem.variant_id, problem.compressed_cb, problem.p_base_wrong, problem.v2snp)
+    ctx.set_betas(betas)
+    t_up = time.perf_counter() - t_up
 
     # first pass fixes the options and gives the outputs used for the sanity check below
     ctx.set_addition(None)
@@ -173,6 +196,42 @@ def main():
         elapsed = float(t[0])
     timers = ctx.timings()
 
+    # the tolerance-mode E-step (dmx_set_estep_mode: assignments identical, posteriors within the contract's 1e-5)
+    # with the fast summation mode, timed the same way on the same resident problem; the default (bit-exact)
+    # mode above stays the headline `value`
+    fast = None
+    if not args.no_fast_mode:
+        ctx.set_estep_mode('fast')
+        ctx.set_exact_additions(False)
+        ctx.set_addition(None)
+        ctx.probs_from_betas(0.01, fetch=False)
+        _lf, probs_fast = ctx.estep(pen, with_doublets=dp > 0)
+        ctx.run_iterations(args.warmup, 0.01)
+        ctx.synchronize()
+        ctx.reset_timings()
+        barrier()
+        ctx.synchronize()
+        t0f = time.perf_counter()
+        ctx.run_iterations(args.steps, 0.01)
+        ctx.synchronize()
+        barrier()
+        elapsed_fast = time.perf_counter() - t0f
+        if dist is not None:
+            import torch
+            t = torch.tensor([elapsed_fast], dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            elapsed_fast = float(t[0])
+        timers_fast = ctx.timings()
+        fast = dict(value=B_total * args.steps / elapsed_fast, ms_per_step=1e3 * elapsed_fast / args.steps,
+                    em_iterations_per_s=args.steps / elapsed_fast,
+                    kernel_ms={k: (v['ms'] / max(1, v['launches'])) for k, v in timers_fast.items()},
+                    vs_exact_first_pass=dict(
+                        argmax_identical=bool(np.array_equal(probs_fast.argmax(1), probs0.argmax(1))),
+                        max_abs_posterior_diff=float(np.abs(probs_fast - probs0).max())))
+        ctx.set_estep_mode('exact')
+        ctx.set_exact_additions(os.environ.get('DEMUXALOT_AMD_EXACT_ADDITIONS', '1') not in ('0', ''))
+        ctx.reset_timings()
+
     # predict_posteriors throughput on the same resident problem (P + E only), rank-local
     ctx.synchronize()
     t1 = time.perf_counter()
@@ -188,22 +247,24 @@ def main():
         m_ms = timers['mstep']['ms'] / max(1, timers['mstep']['launches'])
         achieved = ab['estep'] / (e_ms * 1e-3) / 1e9
         out = {
-            'metric': f'EM iterations/sec + barcodes demuxed/sec, {B // 1000}k bc x {S // 1000}k SNP x {G} gt per GPU: '
-                      'value = barcodes/s through full learn_genotypes EM iterations (P-step + E-step + softmax + '
-                      'M-step [+ all-reduce]) = barcodes x em_iterations_per_s; predict-only rate in predict_barcodes_per_s',
-            'value': world * B * args.steps / elapsed,
+            'metric': f'EM iterations/sec + barcodes demuxed/sec, {WORKLOADS[args.workload][0] // 1000}k bc x {S // 1000}k SNP x {G} gt '
+                      + ('per GPU' if args.scaling == 'weak' else f'in total over {world} GPUs') +
+                      ': value = barcodes/s through full learn_genotypes EM iterations (P-step + E-step + softmax + '
+                      'M-step [+ exchange]) = barcodes x em_iterations_per_s; predict-only rate in predict_barcodes_per_s',
+            'value': B_total * args.steps / elapsed,
             'unit': 'barcodes/s',
             'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
             'ms_per_step': 1e3 * elapsed / args.steps,
-            'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
+            'higher_is_better': True, 'scaling': args.scaling, 'vs_baseline': None,
             'dtype': 'f32 terms, f64 accumulate', 'data': 'synthetic',
-            'config': {'workload': args.workload, 'barcodes_per_gpu': B, 'snps': S, 'variants': V, 'genotypes': G,
+            'config': {'workload': args.workload, 'barcodes_total': B_total, 'barcodes_per_gpu': B, 'snps': S, 'variants': V, 'genotypes': G,
                        'options': K, 'calls_per_gpu': N, 'doublet_prior': dp,
                        'summation': 'fast (DEMUXALOT_AMD_EXACT_ADDITIONS=0)' if os.environ.get('DEMUXALOT_AMD_EXACT_ADDITIONS', '1') in ('0', '') else 'exact: additions bit-identical to the reference (default)',
-                       'parallelism': f'barcode shards x{world}' + (f', RCCL all-reduce {args.reduce_dtype}' if use_dist else '')},
+                       'parallelism': f'barcode shards x{world}' + (f', RCCL reduce-scatter {args.reduce_dtype} + all-gather f32 of variant slices' if use_dist else '')},
             'em_iterations_per_s': args.steps / elapsed,
-            'predict_barcodes_per_s': world * B / predict_s,
+            'predict_barcodes_per_s': B_total / predict_s,
             'kernel_ms': {k: (v['ms'] / max(1, v['launches'])) for k, v in timers.items()},
+            'exchange_ms_per_step': timers['allreduce']['ms'] / max(1, args.steps),
             'roofline': {'bound': 'hbm', 'kernel': 'k_estep_direct' if K <= 256 else 'k_estep_block', 'achieved': achieved, 'peak': 8000.0, 'unit': 'GB/s',
                          'frac': achieved / 8000.0, 'traffic': measured_traffic(args.workload, 'k_estep_direct'),
                          'algorithmic_bytes_per_launch': ab['estep'],
@@ -218,7 +279,12 @@ def main():
                          'note': 'the E-step is bound by VALU issue of N*K numpy-exact float32 log terms and by the '
                                  'indexed row gather from L2/Infinity Cache (N*4G delivered bytes), not by HBM: see DESIGN.md 4'},
             'setup_s': {'generate': t_gen, 'upload': t_up},
+            'fast_mode': fast,
         }
+        if fast is not None:
+            e_fast = fast['kernel_ms']['estep']
+            fast['estep_hbm_frac'] = ab['estep'] / (e_fast * 1e-3) / 1e9 / 8000.0
+            fast['delivered_gather_GBps'] = (N * 4 * G) / (e_fast * 1e-3) / 1e9
         if world == 1 and not args.no_cpu_baseline:
             base, ref_logits, ref_post, n_s = cpu_baseline(problem, betas, dp)
             out['cpu_baseline'] = base

@@ -53,12 +53,14 @@ SIGNATURES = {
     'dmx_get_assignments_above': (c_int, [_P, c_float, _P, _P, POINTER(c_int64)]),
     'dmx_get_top_options': (c_int, [_P, c_int32, _P, _P]),
     'dmx_get_option_sums': (c_int, [_P, _P]),
+    'dmx_exchange_slices': (c_int, [c_int64, _P, c_int32, _P, POINTER(c_int64), POINTER(c_int32)]),
     'dmx_comm_unique_id': (c_int, [_P]),
     'dmx_comm_init': (c_int, [_P, c_int, c_int, _P, c_int]),
     'dmx_get_timings': (c_int, [_P, POINTER(c_double), POINTER(c_int64)]),
     'dmx_reset_timings': (c_int, [_P]),
     'dmx_device_bytes': (c_int, [_P, POINTER(c_int64)]),
     'dmx_set_exact_additions': (c_int, [_P, c_int]),
+    'dmx_set_estep_mode': (c_int, [_P, c_int]),
     'dmx_test_logf': (c_int, [_P, _P, _P, c_int64]),
     'dmx_test_logf_hot': (c_int, [_P, _P, _P, c_int64]),
     'dmx_test_expf': (c_int, [_P, _P, _P, c_int64]),

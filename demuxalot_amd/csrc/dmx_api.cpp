@@ -40,6 +40,8 @@ struct RcclApi {
     ncclResult_t (*GetUniqueId)(ncclUniqueId *) = nullptr;
     ncclResult_t (*CommInitRank)(ncclComm_t *, int, ncclUniqueId, int) = nullptr;
     ncclResult_t (*AllReduce)(const void *, void *, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*ReduceScatter)(const void *, void *, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*AllGather)(const void *, void *, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
     ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
     const char *(*GetErrorString)(ncclResult_t) = nullptr;
 };
@@ -65,9 +67,12 @@ int load_rccl()
     g_rccl.GetUniqueId = (decltype(g_rccl.GetUniqueId))dlsym(h, "ncclGetUniqueId");
     g_rccl.CommInitRank = (decltype(g_rccl.CommInitRank))dlsym(h, "ncclCommInitRank");
     g_rccl.AllReduce = (decltype(g_rccl.AllReduce))dlsym(h, "ncclAllReduce");
+    g_rccl.ReduceScatter = (decltype(g_rccl.ReduceScatter))dlsym(h, "ncclReduceScatter");
+    g_rccl.AllGather = (decltype(g_rccl.AllGather))dlsym(h, "ncclAllGather");
     g_rccl.CommDestroy = (decltype(g_rccl.CommDestroy))dlsym(h, "ncclCommDestroy");
     g_rccl.GetErrorString = (decltype(g_rccl.GetErrorString))dlsym(h, "ncclGetErrorString");
-    if (!g_rccl.GetUniqueId || !g_rccl.CommInitRank || !g_rccl.AllReduce || !g_rccl.CommDestroy)
+    if (!g_rccl.GetUniqueId || !g_rccl.CommInitRank || !g_rccl.AllReduce || !g_rccl.ReduceScatter || !g_rccl.AllGather ||
+        !g_rccl.CommDestroy)
         return fail(DMX_ERR_RCCL, "librccl lacks a required symbol");
     g_rccl.handle = h;
     return 0;
@@ -128,15 +133,31 @@ void release_problem(dmx_ctx *c)
     dev_free(c, &c->d_item_ptr, (size_t)c->V + 1);
     dev_free(c, &c->d_bc_order, (size_t)c->B);
     dev_free(c, &c->d_item_order, (size_t)c->n_items);
-    dev_free(c, &c->d_item_order_chunked, (size_t)c->n_items);
     dev_free(c, &c->d_v2snp, (size_t)c->V);
     dev_free(c, &c->d_snp_ptr, (size_t)c->S + 1);
     dev_free(c, &c->d_snp_vars, (size_t)c->V);
     const size_t vg = (size_t)c->V * c->G;
     dev_free(c, &c->d_prior, vg);
     dev_free(c, &c->d_add, vg);
-    dev_free(c, &c->d_prob, vg);
+    dev_free(c, &c->d_prob, (size_t)c->prob_rows * c->G);
     dev_free(c, &c->d_add64, vg);
+    dev_free(c, &c->d_prow, (size_t)c->V);
+    if (c->d_exch) {
+        (void)hipFree(c->d_exch);
+        c->bytes -= (int64_t)c->exch_bytes;
+        c->d_exch = nullptr;
+        c->exch_bytes = 0;
+    }
+    if (c->d_recv) {
+        (void)hipFree(c->d_recv);
+        c->bytes -= (int64_t)c->recv_bytes;
+        c->d_recv = nullptr;
+        c->recv_bytes = 0;
+    }
+    c->sliced = c->add_partial = false;
+    c->slice_rows = c->prob_rows = 0;
+    c->cut.clear();
+    c->h_v2snp.clear();
     dev_free(c, &c->d_partial, (size_t)c->n_items * c->G);
     dev_free(c, &c->d_redo, c->cap_redo);
     dev_free(c, &c->d_n_redo, (size_t)1);
@@ -228,13 +249,175 @@ int upload_prior_logits(dmx_ctx *c, const void *prior, int dtype)
     return 0;
 }
 
+int copy_out(dmx_ctx *c, float *dst, const float *src, size_t count)
+{
+    if (!dst) return 0;
+    HIP_TRY(hipMemcpyAsync(dst, src, count * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+    return 0;
+}
+
+int need(dmx_ctx *c, bool cond, const char *what)
+{
+    (void)c;
+    if (!cond) return fail(DMX_ERR_INVALID, "call order: %s", what);
+    return 0;
+}
+
+const char *rccl_error(ncclResult_t r) { return g_rccl.GetErrorString ? g_rccl.GetErrorString(r) : "?"; }
+
+// ------------------------------------------------------------------------------------
+// Multi-GPU exchange.  Every EM iteration needs, on every rank, the genotype_prob table computed from
+// prior + the sum over ranks of the per-rank beta additions.  Instead of all-reducing the [V, G] float64 sums and
+// running the P-step on every rank (2 (n-1)/n x 8 bytes per entry on the wire, the P-step replicated), the variants
+// are cut into one slice per rank at SNP boundaries:
+//     reduce-scatter (float64 partial sums, or float32)  ->  rank r owns the summed addition of slice r
+//     round to float32, P-step of slice r                ->  rank r owns genotype_prob of slice r
+//     all-gather (float32 genotype_prob)                 ->  everybody has the table for the next E-step
+// = (n-1)/n x (8 + 4) bytes per entry, the P-step done once.  ncclReduceScatter / ncclAllGather want equal,
+// contiguous blocks, so the tables that travel (the exchange buffer of the M-step, genotype_prob) are kept in a
+// padded row layout: slice r = rows [r * slice_rows, (r + 1) * slice_rows).  Only the E-step records (row byte
+// offsets) and the kernels that write those two tables know about it (prow).  The full addition is assembled
+// (all-gather of the float32 slices) only when a caller asks for it.
+// Requires every SNP's variants to be contiguous in the variant numbering (they are when genotypes come from a
+// VCF: genotypes.py:112-168); otherwise `sliced` is false and the exchange is the all-reduce + replicated P-step.
+// ------------------------------------------------------------------------------------
+// Variant slices of the exchange (host only): cut[r] = first variant of slice r, every cut at the first variant of
+// a SNP; rows = the longest slice.  contiguous = every SNP id forms exactly one run of v2snp.
+void exchange_slices(const int *v2snp, long long V, int n, std::vector<long long> &cut, long long &rows, bool &contiguous)
+{
+    contiguous = true;
+    int max_snp = -1;
+    for (long long v = 0; v < V; v++) max_snp = std::max(max_snp, v2snp[v]);
+    std::vector<char> seen((size_t)max_snp + 1, 0);
+    for (long long v = 0; v < V && contiguous; v++) {
+        if (v > 0 && v2snp[v] == v2snp[v - 1]) continue;
+        if (seen[v2snp[v]]) contiguous = false;
+        seen[v2snp[v]] = 1;
+    }
+    cut.assign((size_t)n + 1, 0);
+    cut[n] = V;
+    for (int r = 1; r < n; r++) {
+        long long v = V * r / n;
+        while (v > 0 && v < V && v2snp[v] == v2snp[v - 1]) v--;  // back to the first variant of the SNP
+        cut[r] = std::max(v, cut[r - 1]);
+    }
+    rows = 1;
+    for (int r = 0; r < n; r++) rows = std::max(rows, cut[r + 1] - cut[r]);
+}
+
+int layout_exchange(dmx_ctx *c)
+{
+    const long long V = c->V;
+    const int G = c->G, n = c->comm ? c->nranks : 1;
+    hipStream_t st = c->stream;
+    HIP_TRY(hipStreamSynchronize(st));
+    if (c->d_prow) return fail(DMX_ERR_INVALID, "the resident problem is already laid out for a communicator: install it again");
+    bool contiguous = true;
+    long long rows = V;
+    exchange_slices(c->h_v2snp.data(), V, n, c->cut, rows, contiguous);
+    c->sliced = c->comm != nullptr && contiguous && V > 0;
+    if (!c->sliced) {
+        c->cut.assign((size_t)n + 1, 0);
+        c->cut[n] = V;
+    } else {
+        if ((unsigned long long)rows * n * G * 4ull >= (1ull << 32))
+            return fail(DMX_ERR_UNSUPPORTED, "padded genotype table of %lld x %d floats exceeds the 4 GiB reachable by 32-bit row offsets",
+                        rows * n, G);
+    }
+    c->slice_rows = c->sliced ? rows : V;
+    const long long new_rows = c->sliced ? rows * n : V;
+    if (new_rows != c->prob_rows || !c->d_prob) {
+        dev_free(c, &c->d_prob, (size_t)c->prob_rows * G);
+        c->prob_rows = new_rows;
+        DMX_TRY(dev_alloc(c, &c->d_prob, (size_t)new_rows * G));
+    }
+    c->have_probs = false;
+    HIP_TRY(hipMemsetAsync(c->d_prob, 0, sizeof(float) * (size_t)(new_rows ? new_rows * G : 1), st));
+    if (c->sliced) {
+        std::vector<int> prow((size_t)V);
+        for (int r = 0; r < n; r++)
+            for (long long v = c->cut[r]; v < c->cut[r + 1]; v++) prow[v] = (int)(r * rows + (v - c->cut[r]));
+        DMX_TRY(dev_alloc(c, &c->d_prow, (size_t)V));
+        HIP_TRY(hipMemcpyAsync(c->d_prow, prow.data(), sizeof(int) * V, hipMemcpyHostToDevice, st));
+        HIP_TRY(dmx::launch_remap_row_offsets(st, c->d_call_pairs, c->n_pairs, (unsigned)G * 4u, c->d_prow));
+        const size_t elem = c->reduce_dtype == DMX_F64 ? 8 : 4;
+        c->exch_bytes = (size_t)new_rows * G * 8;  // float64 sums; also the float32 staging of the addition gather
+        c->recv_bytes = (size_t)rows * G * elem;
+        HIP_TRY(hipMalloc(&c->d_exch, c->exch_bytes));
+        c->bytes += (int64_t)c->exch_bytes;
+        HIP_TRY(hipMalloc(&c->d_recv, c->recv_bytes));
+        c->bytes += (int64_t)c->recv_bytes;
+        HIP_TRY(hipMemsetAsync(c->d_exch, 0, c->exch_bytes, st));  // padding rows stay zero
+        HIP_TRY(hipStreamSynchronize(st));                          // `prow` is a local
+    }
+    c->add_partial = false;
+    return 0;
+}
+
+// [V, G] float32 table in the layout of d_prob <-> dense host table
+int copy_prob_out(dmx_ctx *c, float *dst)
+{
+    if (!dst) return 0;
+    const int G = c->G;
+    if (!c->sliced) return copy_out(c, dst, c->d_prob, (size_t)c->V * G);
+    for (int r = 0; r < c->nranks; r++) {
+        const long long rows = c->cut[r + 1] - c->cut[r];
+        if (rows) HIP_TRY(hipMemcpyAsync(dst + c->cut[r] * G, c->d_prob + (size_t)r * c->slice_rows * G, sizeof(float) * rows * G, hipMemcpyDeviceToHost, c->stream));
+    }
+    return 0;
+}
+
+int copy_prob_in(dmx_ctx *c, const float *src)
+{
+    const int G = c->G;
+    if (!c->sliced) {
+        HIP_TRY(hipMemcpyAsync(c->d_prob, src, sizeof(float) * c->V * G, hipMemcpyHostToDevice, c->stream));
+        return 0;
+    }
+    for (int r = 0; r < c->nranks; r++) {
+        const long long rows = c->cut[r + 1] - c->cut[r];
+        if (rows) HIP_TRY(hipMemcpyAsync(c->d_prob + (size_t)r * c->slice_rows * G, src + c->cut[r] * G, sizeof(float) * rows * G, hipMemcpyHostToDevice, c->stream));
+    }
+    return 0;
+}
+
+// sliced mode: after an M-step only this rank's slice of d_add is current; assemble the whole table (collective:
+// every rank must get here)
+int ensure_full_addition(dmx_ctx *c)
+{
+    if (!c->add_partial) return 0;
+    const int G = c->G, n = c->nranks;
+    float *stage = (float *)c->d_exch;
+    const size_t block = (size_t)c->slice_rows * G;
+    const long long mine = c->cut[c->rank + 1] - c->cut[c->rank];
+    if (mine) HIP_TRY(hipMemcpyAsync(stage + c->rank * block, c->d_add + c->cut[c->rank] * G, sizeof(float) * mine * G, hipMemcpyDeviceToDevice, c->stream));
+    ncclResult_t r = g_rccl.AllGather(stage + c->rank * block, stage, block, ncclFloat, c->comm, c->stream);
+    if (r != ncclSuccess) return fail(DMX_ERR_RCCL, "ncclAllGather (addition) failed: %s", rccl_error(r));
+    for (int k = 0; k < n; k++) {
+        const long long rows = c->cut[k + 1] - c->cut[k];
+        if (rows && k != c->rank) HIP_TRY(hipMemcpyAsync(c->d_add + c->cut[k] * G, stage + k * block, sizeof(float) * rows * G, hipMemcpyDeviceToDevice, c->stream));
+    }
+    // the exchange buffer's padding rows must be zero again before the next reduce-scatter
+    HIP_TRY(hipMemsetAsync(c->d_exch, 0, c->exch_bytes, c->stream));
+    c->add_partial = false;
+    return 0;
+}
+
 int run_pstep(dmx_ctx *c, float lo, float hi, bool with_addition)
 {
     std::pair<hipEvent_t, hipEvent_t> ev;
     timer_begin(c, DMX_T_PSTEP, &ev);
+    const long long v0 = c->sliced ? c->cut[c->rank] : 0, v1 = c->sliced ? c->cut[c->rank + 1] : c->V;
     HIP_TRY(dmx::launch_probs_from_betas(c->stream, c->d_prior, with_addition ? c->d_add : nullptr, c->d_v2snp,
-                                         c->d_snp_ptr, c->d_snp_vars, c->V, c->G, lo, hi, c->d_prob));
+                                         c->d_snp_ptr, c->d_snp_vars, v0, v1 - v0, c->G, c->d_prow, lo, hi, c->d_prob));
     timer_end(c, DMX_T_PSTEP, ev);
+    if (c->sliced) {  // everybody gets everybody's slice of genotype_prob
+        timer_begin(c, DMX_T_ALLREDUCE, &ev);
+        const size_t block = (size_t)c->slice_rows * c->G;
+        ncclResult_t r = g_rccl.AllGather(c->d_prob + c->rank * block, c->d_prob, block, ncclFloat, c->comm, c->stream);
+        timer_end(c, DMX_T_ALLREDUCE, ev);
+        if (r != ncclSuccess) return fail(DMX_ERR_RCCL, "ncclAllGather (genotype_prob) failed: %s", rccl_error(r));
+    }
     c->have_probs = true;
     return 0;
 }
@@ -257,9 +440,10 @@ int run_estep(dmx_ctx *c, int with_doublets, bool with_prior, int prior_dtype, f
     a.nz_floor = power == 2.0f ? dmx::NZ_FLOOR_SQUARE : 0.0f;
     c->nz_floor = a.nz_floor;
     a.B = c->B;
-    a.prob_bytes = (unsigned)((unsigned long long)c->V * c->G * 4ull);
+    a.prob_bytes = (unsigned)((unsigned long long)c->prob_rows * c->G * 4ull);
     a.G = c->G;
     a.K = c->K;
+    a.fast = c->estep_mode == DMX_ESTEP_FAST;
     std::pair<hipEvent_t, hipEvent_t> ev;
     timer_begin(c, DMX_T_ESTEP, &ev);
     HIP_TRY(dmx::launch_estep(c->stream, a, with_doublets != 0));
@@ -293,63 +477,49 @@ int run_mstep(dmx_ctx *c, float power)
     }
     std::pair<hipEvent_t, hipEvent_t> ev;
     const bool dist = c->comm != nullptr;  // also with one rank: keeps the collective path testable on one GPU
+    unsigned long long *redo = c->exact_additions ? c->d_redo : nullptr;
+    timer_begin(c, DMX_T_MSTEP, &ev);
+    HIP_TRY(dmx::launch_mstep(c->stream, a));
+    timer_end(c, DMX_T_MSTEP, ev);
     if (!dist) {
-        timer_begin(c, DMX_T_MSTEP, &ev);
-        HIP_TRY(dmx::launch_mstep(c->stream, a));
-        timer_end(c, DMX_T_MSTEP, ev);
         timer_begin(c, DMX_T_MCOMBINE, &ev);
-        HIP_TRY(dmx::launch_mcombine(c->stream, a, c->d_item_ptr, 0, c->V, c->d_add, nullptr, c->exact_additions ? c->d_redo : nullptr, c->d_n_redo));
+        HIP_TRY(dmx::launch_mcombine(c->stream, a, c->d_item_ptr, 0, c->V, nullptr, c->d_add, nullptr, redo, c->d_n_redo));
         timer_end(c, DMX_T_MCOMBINE, ev);
         return 0;
     }
-    // Multi-GPU: the addition is all-reduced on the comm stream.  The variants can be cut into M_CHUNKS ranges with
-    // equal numbers of calls so that range i is exchanged while range i+1's M-step runs; every variant belongs to
-    // exactly one range, so the arithmetic is that of the single launch.  M_CHUNKS is 1 (each range
-    // pays its own straggler tail, which costs more than the overlap hides).
     const bool f64 = c->reduce_dtype == DMX_F64;
     ncclResult_t r = ncclSuccess;
-    timer_begin(c, DMX_T_MSTEP, &ev);
-    for (int k = 0; k < dmx::M_CHUNKS; k++) {
-        const long long v0 = c->chunk_v[k], v1 = c->chunk_v[k + 1];
-        a.order = c->d_item_order_chunked + c->chunk_item[k];
-        a.n_items = c->chunk_item[k + 1] - c->chunk_item[k];
-        HIP_TRY(dmx::launch_mstep(c->stream, a));
-        HIP_TRY(dmx::launch_mcombine(c->stream, a, c->d_item_ptr, v0, v1, f64 ? nullptr : c->d_add,
-                                     f64 ? c->d_add64 : nullptr, c->exact_additions ? c->d_redo : nullptr, c->d_n_redo));
-        HIP_TRY(hipEventRecord(c->ev_chunk[k], c->stream));
-        HIP_TRY(hipStreamWaitEvent(c->comm_stream, c->ev_chunk[k], 0));
-        const size_t off = (size_t)v0 * c->G, cnt = (size_t)(v1 - v0) * c->G;
-        if (cnt == 0) continue;
-        if (f64) {
-            r = g_rccl.AllReduce(c->d_add64 + off, c->d_add64 + off, cnt, ncclDouble, ncclSum, c->comm, c->comm_stream);
-            if (r == ncclSuccess) HIP_TRY(dmx::launch_f64_to_f32(c->comm_stream, c->d_add64 + off, c->d_add + off, (long long)cnt));
-        } else {
-            r = g_rccl.AllReduce(c->d_add + off, c->d_add + off, cnt, ncclFloat, ncclSum, c->comm, c->comm_stream);
-        }
-        if (r != ncclSuccess) break;
+    if (c->sliced) {
+        // partial sums straight into the padded exchange buffer, reduce-scatter, this rank's slice rounded into d_add
+        timer_begin(c, DMX_T_MCOMBINE, &ev);
+        HIP_TRY(dmx::launch_mcombine(c->stream, a, c->d_item_ptr, 0, c->V, c->d_prow, f64 ? nullptr : (float *)c->d_exch,
+                                     f64 ? (double *)c->d_exch : nullptr, redo, c->d_n_redo));
+        timer_end(c, DMX_T_MCOMBINE, ev);
+        timer_begin(c, DMX_T_ALLREDUCE, &ev);
+        const size_t block = (size_t)c->slice_rows * c->G;
+        r = g_rccl.ReduceScatter(c->d_exch, c->d_recv, block, f64 ? ncclDouble : ncclFloat, ncclSum, c->comm, c->stream);
+        if (r == ncclSuccess)
+            HIP_TRY(dmx::launch_store_slice(c->stream, c->d_recv, f64, c->cut[c->rank], c->cut[c->rank + 1] - c->cut[c->rank], c->G, c->d_add));
+        timer_end(c, DMX_T_ALLREDUCE, ev);
+        if (r != ncclSuccess) return fail(DMX_ERR_RCCL, "ncclReduceScatter failed: %s", rccl_error(r));
+        c->add_partial = c->nranks > 1;
+        return 0;
     }
-    timer_end(c, DMX_T_MSTEP, ev);
-    if (r != ncclSuccess)
-        return fail(DMX_ERR_RCCL, "ncclAllReduce failed: %s", g_rccl.GetErrorString ? g_rccl.GetErrorString(r) : "?");
-    // exposed part of the exchange: the compute stream waits for the last range
+    // SNPs with scattered variants: all-reduce of the dense sums, P-step on every rank
+    timer_begin(c, DMX_T_MCOMBINE, &ev);
+    HIP_TRY(dmx::launch_mcombine(c->stream, a, c->d_item_ptr, 0, c->V, nullptr, f64 ? nullptr : c->d_add, f64 ? c->d_add64 : nullptr, redo,
+                                 c->d_n_redo));
+    timer_end(c, DMX_T_MCOMBINE, ev);
     timer_begin(c, DMX_T_ALLREDUCE, &ev);
-    HIP_TRY(hipEventRecord(c->ev_comm, c->comm_stream));
-    HIP_TRY(hipStreamWaitEvent(c->stream, c->ev_comm, 0));
+    const size_t cnt = (size_t)c->V * c->G;
+    if (f64) {
+        r = g_rccl.AllReduce(c->d_add64, c->d_add64, cnt, ncclDouble, ncclSum, c->comm, c->stream);
+        if (r == ncclSuccess) HIP_TRY(dmx::launch_f64_to_f32(c->stream, c->d_add64, c->d_add, (long long)cnt));
+    } else {
+        r = g_rccl.AllReduce(c->d_add, c->d_add, cnt, ncclFloat, ncclSum, c->comm, c->stream);
+    }
     timer_end(c, DMX_T_ALLREDUCE, ev);
-    return 0;
-}
-
-int copy_out(dmx_ctx *c, float *dst, const float *src, size_t count)
-{
-    if (!dst) return 0;
-    HIP_TRY(hipMemcpyAsync(dst, src, count * sizeof(float), hipMemcpyDeviceToHost, c->stream));
-    return 0;
-}
-
-int need(dmx_ctx *c, bool cond, const char *what)
-{
-    (void)c;
-    if (!cond) return fail(DMX_ERR_INVALID, "call order: %s", what);
+    if (r != ncclSuccess) return fail(DMX_ERR_RCCL, "ncclAllReduce failed: %s", rccl_error(r));
     return 0;
 }
 
@@ -402,13 +572,7 @@ int dmx_destroy(dmx_ctx *c)
     if (!c) return 0;
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
-    if (c->comm_stream) (void)hipStreamSynchronize(c->comm_stream);
     if (c->comm && g_rccl.CommDestroy) g_rccl.CommDestroy(c->comm);
-    if (c->comm_stream) {
-        for (auto &e : c->ev_chunk) (void)hipEventDestroy(e);
-        (void)hipEventDestroy(c->ev_comm);
-        (void)hipStreamDestroy(c->comm_stream);
-    }
     release_problem(c);
     if (c->d_scratch) (void)hipFree(c->d_scratch);
     for (auto &t : c->timers) {
@@ -462,6 +626,7 @@ static int begin_problem(dmx_ctx *c, int64_t B, int64_t V, int32_t G, const int3
     c->V = V;
     c->G = G;
     c->S = S;
+    c->h_v2snp.assign(v2snp, v2snp + V);
     return 0;
 }
 
@@ -476,7 +641,6 @@ static int finish_problem(dmx_ctx *c, const int32_t *v2snp, const std::vector<in
     DMX_TRY(dev_alloc(c, &c->d_snp_vars, (size_t)V));
     DMX_TRY(dev_alloc(c, &c->d_prior, vg));
     DMX_TRY(dev_alloc(c, &c->d_add, vg));
-    DMX_TRY(dev_alloc(c, &c->d_prob, vg));
     DMX_TRY(dev_alloc(c, &c->d_add64, vg));
     DMX_TRY(dev_alloc(c, &c->d_partial, (size_t)c->n_items * G));
     c->cap_redo = ((size_t)c->n_items / 2 + 1) * (size_t)G;  // a variant queues at most G sums and only with >= 2 items
@@ -495,6 +659,7 @@ static int finish_problem(dmx_ctx *c, const int32_t *v2snp, const std::vector<in
     HIP_TRY(hipMemsetAsync(c->d_add, 0, sizeof(float) * (vg ? vg : 1), st));
     if (B) HIP_TRY(hipMemsetAsync(c->d_nz, 0, sizeof(unsigned long long) * (size_t)B * ((G + 63) / 64), st));
     HIP_TRY(hipStreamSynchronize(st));  // host staging vectors die in the caller
+    DMX_TRY(layout_exchange(c));        // genotype_prob table (padded when a communicator is attached)
     c->have_problem = true;
     return 0;
 }
@@ -581,6 +746,14 @@ int dmx_set_exact_additions(dmx_ctx *c, int exact)
     return 0;
 }
 
+int dmx_set_estep_mode(dmx_ctx *c, int mode)
+{
+    if (!c) return fail(DMX_ERR_INVALID, "null context");
+    if (mode != DMX_ESTEP_EXACT && mode != DMX_ESTEP_FAST) return fail(DMX_ERR_INVALID, "unknown E-step mode %d", mode);
+    c->estep_mode = mode;
+    return 0;
+}
+
 int dmx_set_betas(dmx_ctx *c, const float *prior)
 {
     DMX_TRY(bind(c));
@@ -659,6 +832,7 @@ int dmx_set_addition(dmx_ctx *c, const float *addition)
     } else {
         HIP_TRY(hipMemsetAsync(c->d_add, 0, sizeof(float) * (vg ? vg : 1), c->stream));
     }
+    c->add_partial = false;
     return 0;
 }
 
@@ -667,7 +841,7 @@ int dmx_probs_from_betas(dmx_ctx *c, float lo, float hi, float *prob_out)
     DMX_TRY(bind(c));
     DMX_TRY(need(c, c->have_problem && c->have_betas, "dmx_set_problem + dmx_set_betas before dmx_probs_from_betas"));
     DMX_TRY(run_pstep(c, lo, hi, true));
-    DMX_TRY(copy_out(c, prob_out, c->d_prob, (size_t)c->V * c->G));
+    DMX_TRY(copy_prob_out(c, prob_out));
     HIP_TRY(hipStreamSynchronize(c->stream));
     return 0;
 }
@@ -677,11 +851,11 @@ int dmx_set_probs(dmx_ctx *c, const float *prob)
     DMX_TRY(bind(c));
     DMX_TRY(need(c, c->have_problem, "dmx_set_problem before dmx_set_probs"));
     if (!prob && c->V > 0) return fail(DMX_ERR_INVALID, "null prob table");
-    HIP_TRY(hipMemcpyAsync(c->d_prob, prob, sizeof(float) * c->V * c->G, hipMemcpyHostToDevice, c->stream));
+    if (c->V) DMX_TRY(copy_prob_in(c, prob));
     // the E-step's log is the hot-path form (finite argument >= 1e-4): a table with entries outside [0, 1]
     // (or NaN) is refused rather than answered with numbers that mean nothing
     HIP_TRY(hipMemsetAsync(c->d_best, 0, sizeof(int), c->stream));
-    HIP_TRY(dmx::launch_check_unit_range(c->stream, c->d_prob, c->V * c->G, c->d_best));
+    HIP_TRY(dmx::launch_check_unit_range(c->stream, c->d_prob, c->prob_rows * c->G, c->d_best));
     int flag = 0;
     HIP_TRY(hipMemcpyAsync(&flag, c->d_best, sizeof(int), hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
@@ -700,12 +874,14 @@ int dmx_probs_from_betas_f64(dmx_ctx *c, const double *betas, float lo, float hi
     HIP_TRY(hipMalloc((void **)&d_b, (vg ? vg : 1) * sizeof(double)));
     hipError_t e = vg ? hipMemcpyAsync(d_b, betas, vg * sizeof(double), hipMemcpyHostToDevice, c->stream) : hipSuccess;
     if (e == hipSuccess)
-        e = dmx::launch_probs_from_betas_f64(c->stream, d_b, c->d_v2snp, c->d_snp_ptr, c->d_snp_vars, c->V, c->G, lo, hi, c->d_prob);
-    if (e == hipSuccess && prob_out && vg) e = hipMemcpyAsync(prob_out, c->d_prob, vg * sizeof(float), hipMemcpyDeviceToHost, c->stream);
+        e = dmx::launch_probs_from_betas_f64(c->stream, d_b, c->d_v2snp, c->d_snp_ptr, c->d_snp_vars, c->V, c->G, c->d_prow, lo, hi, c->d_prob);
+    int rc_copy = 0;
+    if (e == hipSuccess && vg) rc_copy = copy_prob_out(c, prob_out);
     if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
     (void)hipStreamSynchronize(c->stream);
     (void)hipFree(d_b);
     if (e != hipSuccess) return fail(DMX_ERR_HIP, "P-step from float64 betas: %s", hipGetErrorString(e));
+    if (rc_copy) return rc_copy;
     c->have_probs = true;
     return 0;
 }
@@ -731,6 +907,7 @@ int dmx_mstep(dmx_ctx *c, float power, float *addition_out)
     DMX_TRY(bind(c));
     DMX_TRY(need(c, c->have_problem && c->have_post, "dmx_estep before dmx_mstep"));
     DMX_TRY(run_mstep(c, power));
+    if (addition_out) DMX_TRY(ensure_full_addition(c));  // collective when sliced: all ranks pass it, or none does
     DMX_TRY(copy_out(c, addition_out, c->d_add, (size_t)c->V * c->G));
     HIP_TRY(hipStreamSynchronize(c->stream));
     return 0;
@@ -748,6 +925,7 @@ int dmx_em(dmx_ctx *c, int n_iterations, float lo, float hi, int with_doublets, 
     DMX_TRY(upload_prior_logits(c, prior_logits, prior_dtype));
     const size_t vg = (size_t)c->V * c->G;
     HIP_TRY(hipMemsetAsync(c->d_add, 0, sizeof(float) * (vg ? vg : 1), c->stream));  // demux.py:86
+    c->add_partial = false;
     for (int it = 0; it < n_iterations; it++) {
         DMX_TRY(run_pstep(c, lo, hi, true));
         DMX_TRY(run_estep(c, with_doublets, it == 0 && prior_logits != nullptr, prior_dtype, power));
@@ -756,6 +934,7 @@ int dmx_em(dmx_ctx *c, int n_iterations, float lo, float hi, int with_doublets, 
     const size_t bk = (size_t)c->B * c->K;
     DMX_TRY(copy_out(c, logits_out, c->d_logits, bk));
     DMX_TRY(copy_out(c, probs_out, c->d_post, bk));
+    DMX_TRY(ensure_full_addition(c));  // (collective when sliced) the slices of the last M-step, on every rank
     DMX_TRY(copy_out(c, addition_out, c->d_add, vg));
     HIP_TRY(hipStreamSynchronize(c->stream));
     return 0;
@@ -798,6 +977,7 @@ int dmx_get_addition(dmx_ctx *c, float *out)
 {
     DMX_TRY(bind(c));
     DMX_TRY(need(c, c->have_problem, "dmx_set_problem before dmx_get_addition"));
+    DMX_TRY(ensure_full_addition(c));  // collective when sliced
     DMX_TRY(copy_out(c, out, c->d_add, (size_t)c->V * c->G));
     HIP_TRY(hipStreamSynchronize(c->stream));
     return 0;
@@ -831,6 +1011,22 @@ int dmx_get_assignments(dmx_ctx *c, int32_t *best, float *best_p)
     return 0;
 }
 
+int dmx_exchange_slices(int64_t n_variants, const int32_t *v2snp, int32_t nranks, int64_t *cuts, int64_t *slice_rows,
+                        int32_t *contiguous)
+{
+    if (n_variants < 0 || nranks < 1 || !cuts || (n_variants > 0 && !v2snp)) return fail(DMX_ERR_INVALID, "bad arguments");
+    for (int64_t v = 0; v < n_variants; v++)
+        if (v2snp[v] < 0) return fail(DMX_ERR_INVALID, "v2snp[%lld] negative", (long long)v);
+    std::vector<long long> cut;
+    long long rows = 0;
+    bool contig = true;
+    exchange_slices(v2snp, n_variants, nranks, cut, rows, contig);
+    for (int r = 0; r <= nranks; r++) cuts[r] = cut[r];
+    if (slice_rows) *slice_rows = rows;
+    if (contiguous) *contiguous = contig ? 1 : 0;
+    return 0;
+}
+
 int dmx_comm_unique_id(void *id_out)
 {
     if (!id_out) return fail(DMX_ERR_INVALID, "null id buffer");
@@ -860,14 +1056,12 @@ int dmx_comm_init(dmx_ctx *c, int rank, int nranks, const void *unique_id, int r
         c->comm = nullptr;
         return fail(DMX_ERR_RCCL, "ncclCommInitRank failed: %s", g_rccl.GetErrorString ? g_rccl.GetErrorString(r) : "?");
     }
-    if (!c->comm_stream) {
-        HIP_TRY(hipStreamCreateWithFlags(&c->comm_stream, hipStreamNonBlocking));
-        for (auto &e : c->ev_chunk) HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
-        HIP_TRY(hipEventCreateWithFlags(&c->ev_comm, hipEventDisableTiming));
-    }
     c->rank = rank;
     c->nranks = nranks;
     c->reduce_dtype = reduce_dtype;
+    // a problem installed before the communicator gets its exchange layout now (the E-step records are rewritten
+    // in place for the padded genotype table)
+    if (c->have_problem) DMX_TRY(layout_exchange(c));
     return 0;
 }
 

@@ -50,9 +50,6 @@ struct dmx_ctx {
     int *d_item_len = nullptr;
     long long *d_item_ptr = nullptr;
     int *d_bc_order = nullptr, *d_item_order = nullptr;
-    int *d_item_order_chunked = nullptr;  // items by (variant chunk, decreasing length): multi-GPU M-step
-    long long chunk_v[dmx::M_CHUNKS + 1] = {0};     // variant boundaries of the chunks
-    long long chunk_item[dmx::M_CHUNKS + 1] = {0};  // offsets of the chunks in d_item_order_chunked
     long long n_items = 0;
     int *d_v2snp = nullptr, *d_snp_ptr = nullptr, *d_snp_vars = nullptr;
     float *d_prior = nullptr, *d_add = nullptr, *d_prob = nullptr;
@@ -64,6 +61,7 @@ struct dmx_ctx {
     size_t cap_redo = 0;
     int item_calls = 1024;  // work-item length of the resident problem (kernels.h: item_calls_for)
     bool exact_additions = true;  // dmx_set_exact_additions
+    int estep_mode = DMX_ESTEP_EXACT;  // dmx_set_estep_mode
     float nz_floor = 0.0f;     // threshold the current d_nz / d_first were built with
     float *d_first = nullptr;  // [B] posterior of the lowest non-zero singlet column (G <= 64)
     long long cap_bk = 0;
@@ -83,11 +81,23 @@ struct dmx_ctx {
     void *d_scratch = nullptr;  // self tests
     size_t cap_scratch = 0;
 
-    hipStream_t comm_stream = nullptr;  // all-reduce of chunk i runs here while chunk i+1 is computed
-    hipEvent_t ev_chunk[dmx::M_CHUNKS] = {nullptr};
-    hipEvent_t ev_comm = nullptr;
+    // ---- multi-GPU (dmx_api.cpp: "exchange") ----
+    // The [V, G] tables that cross ranks live in a PADDED row layout: the variants are cut into nranks slices at
+    // SNP boundaries, every slice padded to slice_rows rows, so that slice r of any such table is the contiguous,
+    // equally sized block ncclReduceScatter / ncclAllGather want.  prow(v) = padded row of variant v.  With one
+    // rank (or SNPs whose variants are not contiguous: `sliced` false) the layout is the dense one.
     ncclComm_t comm = nullptr;
     int rank = 0, nranks = 1, reduce_dtype = DMX_F64;
+    bool sliced = false;            // reduce-scatter + sliced P-step + all-gather (else: all-reduce + replicated P-step)
+    bool add_partial = false;       // only this rank's slice of d_add is current (sliced mode, after an M-step)
+    long long slice_rows = 0;       // rows per slice of the padded tables
+    long long prob_rows = 0;        // rows of d_prob (= nranks * slice_rows when sliced, else V)
+    std::vector<long long> cut;     // [nranks + 1] first variant of every slice
+    std::vector<int> h_v2snp;       // host copy of v2snp (layout decisions)
+    int *d_prow = nullptr;          // [V] padded row of every variant (sliced mode)
+    void *d_exch = nullptr;         // padded send buffer of the reduce-scatter (float64 or float32 partial sums)
+    void *d_recv = nullptr;         // this rank's reduced slice
+    size_t exch_bytes = 0, recv_bytes = 0;
 
     int64_t bytes = 0;
     TimerSlot timers[DMX_T_COUNT];

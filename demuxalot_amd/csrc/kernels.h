@@ -39,6 +39,7 @@ struct EstepArgs {
     unsigned prob_bytes;        // V * G * 4 (< 4 GiB): extent of the prob table for buffer addressing
     int G;
     int K;
+    int fast;                   // DMX_ESTEP_FAST: tolerance mode (products of 8 terms + hardware log2), see kernels.hip
 };
 
 struct MstepArgs {
@@ -75,22 +76,27 @@ inline int item_calls_for(long long n_calls)
     while (len < MAX_ITEM_CALLS && len * 6000 < n_calls) len *= 2;
     return (int)len;
 }
-constexpr int M_CHUNKS = 1;       // variant ranges whose all-reduce overlaps the next range's M-step (1: no split)
 
+// P-step of variants [v_begin, v_begin + n_rows) (whole SNP groups); the result goes to row prow[v] of `prob`
+// (padded multi-GPU layout) or row v when prow is null
 hipError_t launch_probs_from_betas(hipStream_t st, const float *prior, const float *addition, const int *v2snp,
-                                   const int *snp_ptr, const int *snp_vars, long long V, int G, float lo, float hi,
-                                   float *prob);
+                                   const int *snp_ptr, const int *snp_vars, long long v_begin, long long n_rows, int G,
+                                   const int *prow, float lo, float hi, float *prob);
 // the same from caller-supplied float64 betas (no addition): numpy divides float64 / float64 and rounds once
 hipError_t launch_probs_from_betas_f64(hipStream_t st, const double *betas, const int *v2snp, const int *snp_ptr,
-                                       const int *snp_vars, long long V, int G, float lo, float hi, float *prob);
+                                       const int *snp_vars, long long V, int G, const int *prow, float lo, float hi,
+                                       float *prob);
 // sets flags[0] bit 0 when a value lies outside [0, 1] or is not finite
 hipError_t launch_check_unit_range(hipStream_t st, const float *x, long long n, int *flags);
 hipError_t launch_estep(hipStream_t st, const EstepArgs &a, bool pairs);
 hipError_t launch_mstep(hipStream_t st, const MstepArgs &a);
 // sums the item partials of variants [v0, v1) and redoes, in the reference's order, the sums whose float32
 // rounding could depend on the order (redo: queue of capacity (n_items / 2 + 1) * G entries, n_redo: its counter)
+// prow (nullable): row of every variant in the output tables (padded multi-GPU exchange buffer)
 hipError_t launch_mcombine(hipStream_t st, const MstepArgs &a, const long long *item_ptr, long long v0, long long v1,
-                           float *add32, double *add64, unsigned long long *redo, unsigned *n_redo);
+                           const int *prow, float *add32, double *add64, unsigned long long *redo, unsigned *n_redo);
+hipError_t launch_store_slice(hipStream_t st, const void *slice, bool f64, long long v_begin, long long n_rows, int G, float *add);
+hipError_t launch_remap_row_offsets(hipStream_t st, CallPair *pairs, long long n_pairs, unsigned row_bytes, const int *new_rows);
 hipError_t launch_f64_to_f32(hipStream_t st, const double *in, float *out, long long n);
 hipError_t launch_f32_to_f64(hipStream_t st, const float *in, double *out, long long n);
 hipError_t launch_prior_betas(hipStream_t st, const float *betas, float *bsum, const unsigned long long *n_mol,

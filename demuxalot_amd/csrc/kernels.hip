@@ -42,13 +42,16 @@ __global__ __launch_bounds__(256) void k_probs_from_betas(const T *__restrict__ 
                                                           const T *__restrict__ addition,
                                                           const int *__restrict__ v2snp,
                                                           const int *__restrict__ snp_ptr,
-                                                          const int *__restrict__ snp_vars, long long V, int G,
+                                                          const int *__restrict__ snp_vars, long long v_begin,
+                                                          long long n_rows, int G, const int *__restrict__ prow,
                                                           float clip_lo, float clip_hi, float *__restrict__ prob)
 {
-    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= V * G) return;
-    const long long v = i / G;
-    const int g = (int)(i - v * G);
+    // variants [v_begin, v_begin + n_rows); prob row of variant v = prow[v] (padded multi-GPU layout) or v
+    const long long j = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= n_rows * G) return;
+    const long long v = v_begin + j / G;
+    const int g = (int)(j % G);
+    const long long i = v * G + g;
     const int snp = v2snp[v];
     double den = 0.0;
     for (int j = snp_ptr[snp]; j < snp_ptr[snp + 1]; j++) {
@@ -60,7 +63,7 @@ __global__ __launch_bounds__(256) void k_probs_from_betas(const T *__restrict__ 
     const double q = (double)beta / fmax(den, 1e-7);
     float p = (float)q;
     p = fminf(fmaxf(p, clip_lo), clip_hi);  // ndarray.clip(lo, hi) = minimum(maximum(x, lo), hi)
-    prob[i] = p;
+    prob[(prow ? (long long)prow[v] : v) * G + g] = p;
 }
 
 // ------------------------------------------------------------------------------------
@@ -250,7 +253,7 @@ static __device__ __forceinline__ void estep_terms(const npm::f32x2 (&p1)[H][A],
 // Tolerance mode of the E-step (dmx_set_estep_mode(ctx, DMX_ESTEP_FAST)).  The contract of the path is
 // "assignments identical, posteriors within 1e-5" (BASELINE.json north_star); the default mode above pays
 // ~68 VALU issue cycles per term to repeat numpy's float32 log bit for bit.  Here the terms of 8 consecutive
-// calls are MULTIPLIED (two float32 chains, even / odd calls, packed), and one hardware log2 is taken per 8 calls:
+// calls are MULTIPLIED in float32 and one hardware log2 is taken per 8 calls:
 //     sum_c log(t_c) = ln2 * sum_chunks [ exponent(P) + log2(mantissa(P)) ],   P = prod of the chunk's 8 terms.
 // t_c >= 1e-4, so P >= 1e-32 never underflows; t_c <= 2, so P <= 256.  The mantissa logs (in [-1, 0]) are
 // accumulated in float64, the exponents as integers.  7 roundings of relative size 2^-24 and one 1-ulp log2 per
@@ -264,7 +267,7 @@ struct FastAcc {
 template <int A, bool PAIRS, int H>
 static __device__ __forceinline__ void estep_products(const npm::f32x2 (&p1)[H][A], const npm::f32x2 (&p2)[H][A],
                                                       const npm::f32x2 (&keep)[H], const npm::f32x2 (&flo)[H],
-                                                      npm::f32x2 (&prod)[A], int n_slots)
+                                                      float (&prod)[A], int n_slots)
 {
 #pragma unroll
     for (int q = 0; q < H; q++) {
@@ -275,22 +278,21 @@ static __device__ __forceinline__ void estep_products(const npm::f32x2 (&p1)[H][
             if (PAIRS) p = (p + p2[q][s]) * 0.5f;
             npm::f32x2 t = p * keep[q];
             t = t + flo[q];
-            prod[s] = prod[s] * t;
+            prod[s] = (prod[s] * t.x) * t.y;
         }
     }
 }
 
 template <int A>
-static __device__ __forceinline__ void estep_flush(npm::f32x2 (&prod)[A], FastAcc (&acc)[A], int n_slots)
+static __device__ __forceinline__ void estep_flush(float (&prod)[A], FastAcc (&acc)[A], int n_slots)
 {
 #pragma unroll
     for (int s = 0; s < A; s++) {
         if (A > 1 && s >= n_slots) continue;
-        const float pr = prod[s].x * prod[s].y;
-        const float m = __builtin_amdgcn_frexp_mantf(pr);  // [0.5, 1); NaN stays NaN
-        acc[s].expo += __builtin_amdgcn_frexp_expf(pr);
-        acc[s].mant += (double)__builtin_amdgcn_logf(m);   // v_log_f32 = log2
-        prod[s] = npm::f32x2{1.0f, 1.0f};
+        const float m = __builtin_amdgcn_frexp_mantf(prod[s]);  // [0.5, 1); NaN stays NaN
+        acc[s].expo += __builtin_amdgcn_frexp_expf(prod[s]);
+        acc[s].mant += (double)__builtin_amdgcn_logf(m);        // v_log_f32 = log2
+        prod[s] = 1.0f;
     }
 }
 
@@ -324,13 +326,13 @@ __global__ __launch_bounds__(256) void k_estep_direct(EstepArgs a)
     }
     double acc[A];
     FastAcc facc[A];
-    npm::f32x2 prod[A];
+    float prod[A];
 #pragma unroll
     for (int s = 0; s < A; s++) {
         acc[s] = 0.0;
         facc[s].mant = 0.0;
         facc[s].expo = 0;
-        prod[s] = npm::f32x2{1.0f, 1.0f};
+        prod[s] = 1.0f;
     }
     const char *__restrict__ prob = (const char *)a.prob;
     const int n_slots = (K + 63) >> 6;  // register slots that hold at least one option (A may be larger)
@@ -491,7 +493,7 @@ __global__ __launch_bounds__(256) void k_estep_direct(EstepArgs a)
 // ------------------------------------------------------------------------------------
 // K > 33 * 256 options (doublets of more than 129 genotypes): the options are cut into tiles of 33 * 256, each
 // tile is one launch that only leaves its logits (TILED), and k_softmax_rows finishes the rows.
-template <int A, bool TILED>
+template <int A, bool TILED, bool FAST>
 __global__ __launch_bounds__(256) void k_estep_block(EstepArgs a, int C, int k_base)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -515,8 +517,14 @@ __global__ __launch_bounds__(256) void k_estep_block(EstepArgs a, int C, int k_b
         a2[s] = (pr >> 16) * (unsigned)CS;
     }
     double acc[A];
+    int acc_e[A];          // FAST: binary exponents of the flushed products
+    float prod[A];         // FAST: running product of the terms since the last flush
 #pragma unroll
-    for (int s = 0; s < A; s++) acc[s] = 0.0;
+    for (int s = 0; s < A; s++) {
+        acc[s] = 0.0;
+        acc_e[s] = 0;
+        prod[s] = 1.0f;
+    }
 
     const unsigned *__restrict__ words = (const unsigned *)(a.pairs + a.pair_ptr[b]);
     const int n_calls = 2 * (int)(a.pair_ptr[b + 1] - a.pair_ptr[b]);  // incl. neutral padding, multiple of 8
@@ -547,11 +555,25 @@ __global__ __launch_bounds__(256) void k_estep_block(EstepArgs a, int C, int k_b
                 const npm::f32x2 pb = *(const npm::f32x2 *)(sh_t + a2[s] + c);
                 npm::f32x2 t = ((pa + pb) * 0.5f) * keep2;
                 t = t + flo2;
-                const npm::f32x2 lp = npm::log_f32_hot2(t);
-                acc[s] += (double)lp.x;
-                acc[s] += (double)lp.y;
+                if constexpr (FAST) {  // see estep_products / estep_flush: one log2 per 8 calls
+                    prod[s] = (prod[s] * t.x) * t.y;
+                    if ((c & 7) == 6) {
+                        acc_e[s] += __builtin_amdgcn_frexp_expf(prod[s]);
+                        acc[s] += (double)__builtin_amdgcn_logf(__builtin_amdgcn_frexp_mantf(prod[s]));
+                        prod[s] = 1.0f;
+                    }
+                } else {
+                    const npm::f32x2 lp = npm::log_f32_hot2(t);
+                    acc[s] += (double)lp.x;
+                    acc[s] += (double)lp.y;
+                }
             }
         }
+    }
+    if constexpr (FAST) {
+        const double LN2 = 0.693147180559945309417232121458176568;
+#pragma unroll
+        for (int s = 0; s < A; s++) acc[s] = (acc[s] + (double)acc_e[s]) * LN2;
     }
     __syncthreads();
 
@@ -1028,8 +1050,9 @@ __global__ __launch_bounds__(256) void k_mcombine(const double *__restrict__ par
                                                   const long long *__restrict__ item_ptr,
                                                   const long long *__restrict__ item_start,
                                                   const int *__restrict__ item_len, long long v0, long long v1, int G,
-                                                  float *__restrict__ add32, double *__restrict__ add64,
-                                                  unsigned long long *__restrict__ redo, unsigned *__restrict__ n_redo)
+                                                  const int *__restrict__ prow, float *__restrict__ add32,
+                                                  double *__restrict__ add64, unsigned long long *__restrict__ redo,
+                                                  unsigned *__restrict__ n_redo)
 {
     const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= (v1 - v0) * G) return;
@@ -1038,7 +1061,7 @@ __global__ __launch_bounds__(256) void k_mcombine(const double *__restrict__ par
     const long long it0 = item_ptr[v], it1 = item_ptr[v + 1];
     double s = 0.0;
     for (long long it = it0; it < it1; it++) s += partial[(size_t)it * G + g];
-    const long long o = v * G + g;
+    const long long o = (prow ? (long long)prow[v] : v) * G + g;  // prow: padded rows of the multi-GPU exchange buffer
     if (add64) add64[o] = s;
     if (add32) add32[o] = (float)s;
     if (redo && it1 - it0 > 1 && s > 0.0) {
@@ -1064,6 +1087,7 @@ template <bool SQUARE>
 __global__ __launch_bounds__(64 * EXACT_WAVES) void k_mstep_exact(MstepArgs a, const long long *__restrict__ item_ptr,
                                                                   const unsigned long long *__restrict__ redo,
                                                                   const unsigned *__restrict__ n_redo,
+                                                                  const int *__restrict__ prow,
                                                                   float *__restrict__ add32, double *__restrict__ add64)
 {
     __shared__ float sh_c[EXACT_WAVES][EXACT_SPAN];
@@ -1135,8 +1159,9 @@ __global__ __launch_bounds__(64 * EXACT_WAVES) void k_mstep_exact(MstepArgs a, c
             __syncthreads();
         }
         if (threadIdx.x == 0) {
-            if (add32) add32[v * a.G + g] = (float)acc;
-            if (add64) add64[v * a.G + g] = acc;
+            const long long o = (prow ? (long long)prow[v] : v) * a.G + g;
+            if (add32) add32[o] = (float)acc;
+            if (add64) add64[o] = acc;
         }
     }
 }
@@ -1145,6 +1170,28 @@ __global__ __launch_bounds__(256) void k_f64_to_f32(const double *__restrict__ i
 {
     const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) out[i] = (float)in[i];
+}
+
+// Multi-GPU: this rank's reduced slice (rows [0, n_rows) of the padded layout, float64 or float32 sums) rounded
+// into rows [v_begin, v_begin + n_rows) of the dense float32 addition.
+template <typename T>
+__global__ __launch_bounds__(256) void k_store_slice(const T *__restrict__ slice, long long v_begin, long long n_rows, int G,
+                                                     float *__restrict__ add)
+{
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n_rows * G) add[v_begin * G + i] = (float)slice[i];
+}
+
+// Multi-GPU: the E-step records address the genotype table by byte offset of the variant's row; when the table
+// changes from the dense to the padded layout the offsets are rewritten in place (new_rows[v] = padded row of
+// variant v; neutral padding calls point at row 0, which stays row 0).
+__global__ __launch_bounds__(256) void k_remap_row_offsets(CallPair *__restrict__ pairs, long long n_pairs, unsigned row_bytes,
+                                                           const int *__restrict__ new_rows)
+{
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_pairs) return;
+#pragma unroll
+    for (int h = 0; h < 2; h++) pairs[i].row_off[h] = (unsigned)new_rows[pairs[i].row_off[h] / row_bytes] * row_bytes;
 }
 
 __global__ __launch_bounds__(256) void k_f32_to_f64(const float *__restrict__ in, double *__restrict__ out, long long n)
@@ -1237,21 +1284,22 @@ __global__ __launch_bounds__(64) void k_test_softmax(const float *in, float *out
 static inline unsigned blocks_for(long long n, int per_block) { return (unsigned)((n + per_block - 1) / per_block); }
 
 hipError_t launch_probs_from_betas(hipStream_t st, const float *prior, const float *addition, const int *v2snp,
-                                   const int *snp_ptr, const int *snp_vars, long long V, int G, float lo, float hi,
-                                   float *prob)
+                                   const int *snp_ptr, const int *snp_vars, long long v_begin, long long n_rows, int G,
+                                   const int *prow, float lo, float hi, float *prob)
 {
-    if (V * G == 0) return hipSuccess;
-    hipLaunchKernelGGL(k_probs_from_betas<float>, dim3(blocks_for(V * G, 256)), dim3(256), 0, st, prior, addition, v2snp,
-                       snp_ptr, snp_vars, V, G, lo, hi, prob);
+    if (n_rows * G == 0) return hipSuccess;
+    hipLaunchKernelGGL(k_probs_from_betas<float>, dim3(blocks_for(n_rows * G, 256)), dim3(256), 0, st, prior, addition, v2snp,
+                       snp_ptr, snp_vars, v_begin, n_rows, G, prow, lo, hi, prob);
     return hipGetLastError();
 }
 
 hipError_t launch_probs_from_betas_f64(hipStream_t st, const double *betas, const int *v2snp, const int *snp_ptr,
-                                       const int *snp_vars, long long V, int G, float lo, float hi, float *prob)
+                                       const int *snp_vars, long long V, int G, const int *prow, float lo, float hi,
+                                       float *prob)
 {
     if (V * G == 0) return hipSuccess;
     hipLaunchKernelGGL(k_probs_from_betas<double>, dim3(blocks_for(V * G, 256)), dim3(256), 0, st, betas,
-                       (const double *)nullptr, v2snp, snp_ptr, snp_vars, V, G, lo, hi, prob);
+                       (const double *)nullptr, v2snp, snp_ptr, snp_vars, 0LL, V, G, prow, lo, hi, prob);
     return hipGetLastError();
 }
 
@@ -1274,10 +1322,17 @@ template <int L, int A, int U>
 static void launch_direct(hipStream_t st, const EstepArgs &a, bool pairs)
 {
     const dim3 grid(blocks_for(a.B, 4 * (64 / L))), block(256);
-    if (pairs)
-        hipLaunchKernelGGL((k_estep_direct<L, A, true, U>), grid, block, 0, st, a);
-    else
-        hipLaunchKernelGGL((k_estep_direct<L, A, false, U>), grid, block, 0, st, a);
+    if (a.fast) {
+        if (pairs)
+            hipLaunchKernelGGL((k_estep_direct<L, A, true, U, true>), grid, block, 0, st, a);
+        else
+            hipLaunchKernelGGL((k_estep_direct<L, A, false, U, true>), grid, block, 0, st, a);
+    } else {
+        if (pairs)
+            hipLaunchKernelGGL((k_estep_direct<L, A, true, U, false>), grid, block, 0, st, a);
+        else
+            hipLaunchKernelGGL((k_estep_direct<L, A, false, U, false>), grid, block, 0, st, a);
+    }
 }
 
 template <int A, bool TILED>
@@ -1289,10 +1344,13 @@ static hipError_t launch_block(hipStream_t st, const EstepArgs &a, int k_base = 
     size_t soft = TILED ? 0 : (size_t)a.K * 4 + 64;
     size_t bytes = stage > soft ? stage : soft;
     bytes = (bytes + 15) & ~size_t(15);
-    hipError_t e = hipFuncSetAttribute((const void *)k_estep_block<A, TILED>, hipFuncAttributeMaxDynamicSharedMemorySize,
+    // The tolerance mode (a.fast) is not used here: this form is bound by its LDS reads (two ds_read_b64 per term
+    // pair and option), not by the log, and the extra registers of the running products halve its occupancy
+    // (measured on 130k x 650k x 128 with doublets: 344 ms against 299 ms).  K > 1024 always runs the exact arithmetic.
+    hipError_t e = hipFuncSetAttribute((const void *)k_estep_block<A, TILED, false>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                        (int)bytes);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL((k_estep_block<A, TILED>), dim3((unsigned)a.B), dim3(256), bytes, st, a, C, k_base);
+    hipLaunchKernelGGL((k_estep_block<A, TILED, false>), dim3((unsigned)a.B), dim3(256), bytes, st, a, C, k_base);
     return hipGetLastError();
 }
 
@@ -1374,7 +1432,7 @@ hipError_t launch_mstep(hipStream_t st, const MstepArgs &a)
 }
 
 hipError_t launch_mcombine(hipStream_t st, const MstepArgs &a, const long long *item_ptr, long long v0, long long v1,
-                           float *add32, double *add64, unsigned long long *redo, unsigned *n_redo)
+                           const int *prow, float *add32, double *add64, unsigned long long *redo, unsigned *n_redo)
 {
     if ((v1 - v0) * a.G <= 0) return hipSuccess;
     if (redo) {
@@ -1382,14 +1440,31 @@ hipError_t launch_mcombine(hipStream_t st, const MstepArgs &a, const long long *
         if (e != hipSuccess) return e;
     }
     hipLaunchKernelGGL(k_mcombine, dim3(blocks_for((v1 - v0) * a.G, 256)), dim3(256), 0, st, a.partial, item_ptr,
-                       a.item_start, a.item_len, v0, v1, a.G, add32, add64, redo, n_redo);
+                       a.item_start, a.item_len, v0, v1, a.G, prow, add32, add64, redo, n_redo);
     if (!redo) return hipGetLastError();
     // exact mode: the sums that must be redone in the reference's order (see k_mcombine)
     const dim3 grid(512), block(64 * EXACT_WAVES);
     if (a.square)
-        hipLaunchKernelGGL((k_mstep_exact<true>), grid, block, 0, st, a, item_ptr, redo, n_redo, add32, add64);
+        hipLaunchKernelGGL((k_mstep_exact<true>), grid, block, 0, st, a, item_ptr, redo, n_redo, prow, add32, add64);
     else
-        hipLaunchKernelGGL((k_mstep_exact<false>), grid, block, 0, st, a, item_ptr, redo, n_redo, add32, add64);
+        hipLaunchKernelGGL((k_mstep_exact<false>), grid, block, 0, st, a, item_ptr, redo, n_redo, prow, add32, add64);
+    return hipGetLastError();
+}
+
+hipError_t launch_store_slice(hipStream_t st, const void *slice, bool f64, long long v_begin, long long n_rows, int G, float *add)
+{
+    if (n_rows * G == 0) return hipSuccess;
+    if (f64)
+        hipLaunchKernelGGL(k_store_slice<double>, dim3(blocks_for(n_rows * G, 256)), dim3(256), 0, st, (const double *)slice, v_begin, n_rows, G, add);
+    else
+        hipLaunchKernelGGL(k_store_slice<float>, dim3(blocks_for(n_rows * G, 256)), dim3(256), 0, st, (const float *)slice, v_begin, n_rows, G, add);
+    return hipGetLastError();
+}
+
+hipError_t launch_remap_row_offsets(hipStream_t st, CallPair *pairs, long long n_pairs, unsigned row_bytes, const int *new_rows)
+{
+    if (n_pairs == 0) return hipSuccess;
+    hipLaunchKernelGGL(k_remap_row_offsets, dim3(blocks_for(n_pairs, 256)), dim3(256), 0, st, pairs, n_pairs, row_bytes, new_rows);
     return hipGetLastError();
 }
 

@@ -125,40 +125,19 @@ __global__ __launch_bounds__(256) void k_build_csc(const unsigned *__restrict__ 
     csc[s] = make_uint2((unsigned)cb[i], __float_as_uint(keep));
 }
 
-// variant boundaries of the M_CHUNKS ranges: bounds[c] = first variant whose calls start at or after c*N/M_CHUNKS
-__global__ void k_chunk_bounds(const long long *__restrict__ col_ptr, long long V, long long N, long long *__restrict__ bounds)
-{
-    const int c = threadIdx.x;
-    if (c > M_CHUNKS) return;
-    if (c == 0) { bounds[0] = 0; return; }
-    if (c == M_CHUNKS) { bounds[c] = V; return; }
-    const long long target = (N * c) / M_CHUNKS;
-    long long lo = 0, hi = V;
-    while (lo < hi) {
-        const long long mid = (lo + hi) >> 1;
-        if (col_ptr[mid] < target) lo = mid + 1; else hi = mid;
-    }
-    bounds[c] = lo;
-}
-
 __global__ __launch_bounds__(256) void k_build_items(const long long *__restrict__ col_ptr,
-                                                     const long long *__restrict__ item_ptr,
-                                                     const long long *__restrict__ bounds, long long V,
+                                                     const long long *__restrict__ item_ptr, long long V,
                                                      int item_calls, long long *__restrict__ item_start, int *__restrict__ item_len,
-                                                     unsigned *__restrict__ inv_len, unsigned *__restrict__ chunk_key,
-                                                     unsigned *__restrict__ ids)
+                                                     unsigned *__restrict__ inv_len, unsigned *__restrict__ ids)
 {
     const long long v = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (v >= V) return;
-    unsigned chunk = 0;
-    for (int c = 1; c < M_CHUNKS; c++) chunk += (v >= bounds[c]) ? 1u : 0u;
     long long it = item_ptr[v];
     for (long long s = col_ptr[v]; s < col_ptr[v + 1]; s += item_calls, it++) {
         const long long len = (col_ptr[v + 1] - s) < item_calls ? (col_ptr[v + 1] - s) : item_calls;
         item_start[it] = s;
         item_len[it] = (int)len;
-        inv_len[it] = ~(unsigned)len;                                      // ascending sort = longest first
-        chunk_key[it] = chunk * (2u * MAX_ITEM_CALLS) + (unsigned)(MAX_ITEM_CALLS - len);  // chunk-major, longest first inside
+        inv_len[it] = ~(unsigned)len;  // ascending sort = longest first
         ids[it] = (unsigned)it;
     }
 }
@@ -299,29 +278,18 @@ static int repack_core(dmx_ctx *c, Scratch &sc, const int *d_variant, const int 
     DMX_TRY(dev_alloc(c, &c->d_csc, (size_t)N));
     if (N) hipLaunchKernelGGL(k_build_csc, dim3(grid_for(N)), dim3(256), 0, st, perm_v, d_cb, d_p, N, c->d_csc);
 
-    // ---- work items, their length-sorted list, and the chunk-major list for the overlapped all-reduce ----
+    // ---- work items and their length-sorted list ----
     DMX_TRY(dev_alloc(c, &c->d_item_start, (size_t)n_items));
     DMX_TRY(dev_alloc(c, &c->d_item_len, (size_t)n_items));
     DMX_TRY(dev_alloc(c, &c->d_item_order, (size_t)n_items));
-    DMX_TRY(dev_alloc(c, &c->d_item_order_chunked, (size_t)n_items));
-    unsigned *inv_i = nullptr, *key_c = nullptr, *ids_i = nullptr, *keys_out = nullptr;
-    long long *bounds = nullptr;
+    unsigned *inv_i = nullptr, *ids_i = nullptr, *keys_out = nullptr;
     DMX_TRY(sc.get(&inv_i, (size_t)n_items));
-    DMX_TRY(sc.get(&key_c, (size_t)n_items));
     DMX_TRY(sc.get(&ids_i, (size_t)n_items));
     DMX_TRY(sc.get(&keys_out, (size_t)n_items));
-    DMX_TRY(sc.get(&bounds, (size_t)M_CHUNKS + 1));
-    hipLaunchKernelGGL(k_chunk_bounds, dim3(1), dim3(64), 0, st, col_ptr, V, N, bounds);
     if (V)
-        hipLaunchKernelGGL(k_build_items, dim3(grid_for(V)), dim3(256), 0, st, col_ptr, c->d_item_ptr, bounds, V,
-                           c->item_calls, c->d_item_start, c->d_item_len, inv_i, key_c, ids_i);
+        hipLaunchKernelGGL(k_build_items, dim3(grid_for(V)), dim3(256), 0, st, col_ptr, c->d_item_ptr, V, c->item_calls,
+                           c->d_item_start, c->d_item_len, inv_i, ids_i);
     DMX_TRY(sort_pairs(sc, inv_i, keys_out, ids_i, (unsigned *)c->d_item_order, (size_t)n_items, 32, st));
-    DMX_TRY(sort_pairs(sc, key_c, keys_out, ids_i, (unsigned *)c->d_item_order_chunked, (size_t)n_items,
-                       bits_for((unsigned long long)M_CHUNKS * 2 * MAX_ITEM_CALLS), st));
-    HIP_TRY(hipMemcpyAsync(c->chunk_v, bounds, sizeof(long long) * (M_CHUNKS + 1), hipMemcpyDeviceToHost, st));
-    HIP_TRY(hipStreamSynchronize(st));
-    for (int k = 0; k <= M_CHUNKS; k++)  // items of variants [0, chunk_v[k]) = item_ptr[chunk_v[k]]
-        HIP_TRY(hipMemcpyAsync(&c->chunk_item[k], c->d_item_ptr + c->chunk_v[k], sizeof(long long), hipMemcpyDeviceToHost, st));
 
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipStreamSynchronize(st));  // scratch is released by the caller's Scratch

@@ -157,12 +157,15 @@ def _pack(chromosome2compressed_snp_calls, genotypes, add_data_prior, want_molec
     return packed
 
 
-def _pack_on_device(chromosome2compressed_snp_calls, genotypes, n_barcodes, add_data_prior, fetch_betas=True, ctx=None):
+def _pack_on_device(chromosome2compressed_snp_calls, genotypes, n_barcodes, add_data_prior, fetch_betas=True, ctx=None,
+                    reduce_molecule_counts=None):
     """The repack of predict / learn, on the GPU: flattening of the containers' records, matching +
     de-duplication + layout derivation (dmx_pack_containers_and_set_problem) and the regularised prior betas
     (dmx_set_prior_betas).
     Returns (ctx with the problem and betas resident, regularised prior betas).  `ctx` None = the shared cached
-    context (the caller holds shared_context_lock)."""
+    context (the caller holds shared_context_lock).  `reduce_molecule_counts` (barcode-sharded runs): maps this
+    shard's molecule counts per variant to the counts of the whole experiment, which the data term of the
+    prior is made of (demux.py:381-384)."""
     from .snp_counter import MOLECULE_DTYPE, SNP_CALL_DTYPE
     v2snp = genotypes.get_snp_ids_for_variants()
     assert np.all(v2snp >= 0)
@@ -179,13 +182,19 @@ def _pack_on_device(chromosome2compressed_snp_calls, genotypes, n_barcodes, add_
                               container.molecules[:container.n_molecules]))
             else:  # demux.py:339-341, 359: calls on a chromosome without variants trip the reference's final assert
                 assert container.n_snp_calls == 0
-        ctx.pack_containers_and_set_problem(n_barcodes, genotypes.n_genotypes, var_chrom, var_pos, var_base, v2snp, parts)
+        _m, _u, molecules = ctx.pack_containers_and_set_problem(n_barcodes, genotypes.n_genotypes, var_chrom, var_pos,
+                                                                var_base, v2snp, parts)
     else:
         (var_chrom, var_pos, var_base), flat = _flatten_inputs(chromosome2compressed_snp_calls, genotypes, False)
-        ctx.pack_and_set_problem(n_barcodes, genotypes.n_genotypes, var_chrom, var_pos, var_base, v2snp,
-                                 flat['chrom'], flat['pos'], flat['base'], flat['cb'], flat['p'])
-    # regularised prior on the GPU too (molecule counts per variant stay on the device)
-    betas = ctx.set_prior_betas(genotypes.get_betas(), genotypes.default_prior, add_data_prior, fetch=fetch_betas)
+        _m, _u, molecules = ctx.pack_and_set_problem(n_barcodes, genotypes.n_genotypes, var_chrom, var_pos, var_base, v2snp,
+                                                     flat['chrom'], flat['pos'], flat['base'], flat['cb'], flat['p'])
+    # regularised prior on the GPU too (a single rank's molecule counts per variant stay on the device)
+    if reduce_molecule_counts is not None and add_data_prior:
+        molecules = reduce_molecule_counts(molecules)
+    else:
+        molecules = None
+    betas = ctx.set_prior_betas(genotypes.get_betas(), genotypes.default_prior, add_data_prior,
+                                mol_per_variant=molecules, fetch=fetch_betas)
     return ctx, betas
 
 

@@ -23,6 +23,9 @@ class DeviceContext:
         # for ~4 % per EM iteration (include/demux_hip.h: dmx_set_exact_additions)
         if os.environ.get('DEMUXALOT_AMD_EXACT_ADDITIONS', '1') in ('0', ''):
             self.set_exact_additions(False)
+        # DEMUXALOT_AMD_ESTEP=fast selects the tolerance-mode E-step (include/demux_hip.h: dmx_set_estep_mode)
+        if os.environ.get('DEMUXALOT_AMD_ESTEP', 'exact') == 'fast':
+            self.set_estep_mode('fast')
 
     def close(self):
         if getattr(self, '_h', None):
@@ -270,6 +273,11 @@ class DeviceContext:
         assert len(unique_id) == _lib.UNIQUE_ID_BYTES
         buf = ctypes.create_string_buffer(unique_id, _lib.UNIQUE_ID_BYTES)
         check(self._lib.dmx_comm_init(self._h, int(rank), int(nranks), buf, DMX_F64 if reduce_dtype == 'f64' else DMX_F32))
+
+    def set_estep_mode(self, mode):
+        """'exact' (default: logits / posteriors bit-identical to the reference) or 'fast' (tolerance mode:
+        assignments identical, posteriors within the contract's 1e-5); include/demux_hip.h: dmx_set_estep_mode."""
+        check(self._lib.dmx_set_estep_mode(self._h, {'exact': 0, 'fast': 1}[mode]))
 
     def set_exact_additions(self, exact):
         """M-step summation mode (include/demux_hip.h: dmx_set_exact_additions). Default: exact."""

@@ -45,6 +45,7 @@ typedef enum {
 #define DMX_F64 1
 
 /* timing slots of dmx_get_timings */
+/* DMX_T_ALLREDUCE: the collectives of the multi-GPU exchange (reduce-scatter + all-gather, or the all-reduce) */
 enum { DMX_T_PSTEP = 0, DMX_T_ESTEP = 1, DMX_T_MSTEP = 2, DMX_T_MCOMBINE = 3, DMX_T_ALLREDUCE = 4, DMX_T_COUNT = 5 };
 
 const char *dmx_last_error(void);
@@ -146,6 +147,19 @@ int dmx_set_prior_betas(dmx_ctx *ctx, const float *raw_betas, double default_pri
  * variants, and everything in the E-step, are bit-identical in both modes. */
 int dmx_set_exact_additions(dmx_ctx *ctx, int exact);
 
+/* E-step arithmetic.
+ * DMX_ESTEP_EXACT (default): every term log(p (1 - e) + max(e, 1e-4)) is evaluated with numpy's float32 log
+ *   operation for operation and accumulated in float64 in the reference's order: logits and posteriors are
+ *   bit-identical to the reference's (demux.py:246-265).
+ * DMX_ESTEP_FAST: the contract of the path only (assignments identical, posteriors within 1e-5 on the reference's
+ *   test inputs): the terms of 8 consecutive calls are multiplied in float32 and one hardware log2 is taken of the
+ *   product's mantissa (exponents summed as integers, mantissa logs in float64).  Deviations from the reference
+ *   are of the size of one float32 rounding of the logit (the reference's own logits carry that much rounding
+ *   noise); roughly 6x less VALU work per term, which leaves the E-step bound by the genotype-row gather. */
+#define DMX_ESTEP_EXACT 0
+#define DMX_ESTEP_FAST 1
+int dmx_set_estep_mode(dmx_ctx *ctx, int mode);
+
 /* genotype_addition float32[V*G]; NULL resets it to zero (demux.py:86). */
 int dmx_set_addition(dmx_ctx *ctx, const float *addition);
 
@@ -228,13 +242,27 @@ int dmx_get_top_options(dmx_ctx *ctx, int32_t k, int32_t *options, float *probs)
 int dmx_get_option_sums(dmx_ctx *ctx, double *sums);
 
 /* ------------------------------------------------------------------------- *
- * Multi-GPU: one ctx per rank, barcodes sharded by the caller; the only exchange
- * is the all-reduce of the beta addition inside dmx_mstep / dmx_em.
- * dmx_comm_unique_id fills 128 bytes on rank 0 (ncclGetUniqueId); the caller
- * broadcasts them and every rank calls dmx_comm_init.
- * reduce_dtype: DMX_F64 all-reduces the float64 partial sums and rounds once
- * (rank-count independent up to float64 re-association); DMX_F32 halves the bytes.
+ * Multi-GPU: one ctx per rank, barcodes sharded by the caller (every rank holds the calls of its barcodes, all
+ * variants, the whole beta table).  E-step rows need nothing from other ranks; the M-step sums over barcodes, so
+ * the per-rank sums are exchanged once per EM iteration, inside dmx_mstep / dmx_probs_from_betas / dmx_em:
+ *   reduce-scatter of the partial sums (variant slices cut at SNP boundaries, one per rank)
+ *   -> the owner rounds its slice to float32 and runs the P-step (demux.py:267-274) on it
+ *   -> all-gather of the float32 genotype_prob slices.
+ * When some SNP's variants are not contiguous in the variant numbering the slices cannot be cut and the exchange
+ * falls back to an all-reduce of the sums with the P-step on every rank.  Results are the same either way.
+ * dmx_comm_unique_id fills 128 bytes on rank 0 (ncclGetUniqueId); the caller broadcasts them and every rank calls
+ * dmx_comm_init (before or after installing the problem; once per installed problem).
+ * reduce_dtype: DMX_F64 exchanges the float64 partial sums and rounds once (rank-count independent up to float64
+ * re-association); DMX_F32 halves the reduce-scatter bytes.
+ * Collective calls -- every rank must make them, in the same order: dmx_probs_from_betas, dmx_mstep (all ranks
+ * pass addition_out or none does), dmx_em, dmx_run_iterations, dmx_get_addition.
  * ------------------------------------------------------------------------- */
+/* Host only: the variant slices dmx_comm_init would cut for nranks ranks: cuts int64[nranks + 1] (first variant of
+ * every slice, each at the first variant of a SNP), *slice_rows = rows of the longest slice (nullable),
+ * *contiguous = 1 when every SNP's variants are contiguous in the numbering (nullable). */
+int dmx_exchange_slices(int64_t n_variants, const int32_t *v2snp, int32_t nranks, int64_t *cuts, int64_t *slice_rows,
+                        int32_t *contiguous);
+
 #define DMX_UNIQUE_ID_BYTES 128
 int dmx_comm_unique_id(void *id_out);
 int dmx_comm_init(dmx_ctx *ctx, int rank, int nranks, const void *unique_id, int reduce_dtype);

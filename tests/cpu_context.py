@@ -1,0 +1,160 @@
+"""TEST INFRASTRUCTURE: a CPU stand-in for demuxalot_amd.device.DeviceContext, used to drive the multi-rank host
+code (demuxalot_amd/distributed.py) over a gloo process group on a box without GPUs.
+
+The arithmetic is the oracle's.  The multi-rank exchange repeats, step for step and over torch.distributed, the
+sequence libdemux_hip.so runs over RCCL (csrc/dmx_api.cpp "Multi-GPU exchange"): per-rank float64 partial sums in
+the PADDED slice layout (slices from the library's own dmx_exchange_slices) -> reduce-scatter -> float32 slice ->
+P-step on the owned slice -> all-gather of genotype_prob.  gloo has no reduce_scatter; it is spelled as one
+dist.reduce per slice."""
+import numpy as np
+
+from demuxalot_amd import _lib
+from demuxalot_amd.distributed import exchange_slices
+from oracle import demux_oracle as oracle
+
+
+class OracleContext:
+    def __init__(self, device=0):
+        self.rank, self.world, self.dist = 0, 1, None
+        self.addition = None
+
+    @staticmethod
+    def new_unique_id():
+        return b'cpu-stand-in'.ljust(_lib.UNIQUE_ID_BYTES, b'.')
+
+    def comm_init(self, rank, nranks, unique_id, reduce_dtype='f64'):
+        import torch.distributed as dist
+        assert len(unique_id) == _lib.UNIQUE_ID_BYTES and unique_id.startswith(b'cpu-stand-in')  # rank 0's bytes arrived
+        self.rank, self.world, self.dist = rank, nranks, dist
+
+    def close(self):
+        pass
+
+    # ---- problem ------------------------------------------------------------------------------------------
+    def set_problem(self, n_barcodes, n_variants, n_genotypes, variant_id, compressed_cb, p_base_wrong, v2snp):
+        self.B, self.V, self.G = n_barcodes, n_variants, n_genotypes
+        order = np.lexsort((compressed_cb, variant_id))  # the reference's barcode_calls order
+        self.calls = (np.asarray(variant_id)[order], np.asarray(compressed_cb)[order], np.asarray(p_base_wrong, dtype=np.float32)[order])
+        self.v2snp = np.asarray(v2snp, dtype=np.int32)
+        self.cuts, self.slice_rows, self.sliced = exchange_slices(self.v2snp, self.world)
+        self.sliced = self.sliced and self.dist is not None
+
+    def pack_containers_and_set_problem(self, n_barcodes, n_genotypes, var_chrom, var_pos, var_base, v2snp, containers):
+        """The host twin of the device pack (dmx_pack_calls_host: product code that needs no GPU)."""
+        import ctypes
+        chrom = np.concatenate([np.full(len(c), k, dtype=np.int32) for k, c, _m in containers] or [np.zeros(0, np.int32)])
+        pos = np.concatenate([c['snp_position'] for _k, c, _m in containers] or [np.zeros(0, np.int32)]).astype(np.int32)
+        base = np.concatenate([c['base_index'] for _k, c, _m in containers] or [np.zeros(0, np.uint8)]).astype(np.uint8)
+        cb = np.concatenate([m['compressed_cb'][c['molecule_index']] for _k, c, m in containers] or [np.zeros(0, np.int32)]).astype(np.int32)
+        p = np.concatenate([c['p_base_wrong'] for _k, c, _m in containers] or [np.zeros(0, np.float32)]).astype(np.float32)
+        n, V = len(pos), len(var_pos)
+        out_v, out_cb = np.empty(n, np.int32), np.empty(n, np.int32)
+        out_p, out_count, mol = np.empty(n, np.float32), np.empty(n, np.int64), np.zeros(V, np.int64)
+        n_matched, n_unique = ctypes.c_int64(0), ctypes.c_int64(0)
+        as_c = np.ascontiguousarray
+        _lib.check(_lib.load().dmx_pack_calls_host(
+            V, _lib.ptr(as_c(var_chrom, np.int32)), _lib.ptr(as_c(var_pos, np.int32)), _lib.ptr(as_c(var_base, np.uint8)), n,
+            _lib.ptr(as_c(chrom)), _lib.ptr(as_c(pos)), _lib.ptr(as_c(base)), _lib.ptr(as_c(cb)), _lib.ptr(as_c(p)), None,
+            ctypes.byref(n_matched), ctypes.byref(n_unique), _lib.ptr(out_v), _lib.ptr(out_cb), _lib.ptr(out_p),
+            _lib.ptr(out_count), _lib.ptr(mol)))
+        k = n_unique.value
+        self.local_mol = mol
+        self.set_problem(n_barcodes, V, n_genotypes, out_v[:k], out_cb[:k], out_p[:k], v2snp)
+        return n_matched.value, k, mol
+
+    def set_betas(self, betas):
+        self.prior = np.asarray(betas, dtype=np.float32)
+
+    def set_prior_betas(self, raw_betas, default_prior, add_data_prior, mol_per_variant=None, fetch=True):
+        mol = self.local_mol if mol_per_variant is None else mol_per_variant
+        self.prior = oracle.prior_betas(np.asarray(raw_betas, dtype=np.float32), self.v2snp,
+                                        np.repeat(np.arange(self.V), mol), default_prior, add_data_prior)
+        return self.prior if fetch else None
+
+    def set_addition(self, addition=None):
+        self.addition = np.zeros_like(self.prior) if addition is None else np.asarray(addition, dtype=np.float32)
+
+    # ---- steps --------------------------------------------------------------------------------------------
+    def _slice(self, r):
+        return int(self.cuts[r]), int(self.cuts[r + 1])
+
+    def probs_from_betas(self, p_genotype_clip, fetch=True):
+        betas = self.prior + self.addition
+        if not self.sliced:
+            self.prob = oracle.probs_from_betas(self.v2snp, betas, p_genotype_clip)
+            return self.prob
+        import torch
+        lo, hi = self._slice(self.rank)  # the P-step of the owned slice only (whole SNP groups)
+        mine = np.zeros((self.slice_rows, self.G), dtype=np.float32)
+        if hi > lo:
+            mine[:hi - lo] = oracle.probs_from_betas(self.v2snp[lo:hi] - self.v2snp[lo], betas[lo:hi], p_genotype_clip)
+        parts = [torch.zeros(mine.shape, dtype=torch.float32) for _ in range(self.world)]
+        self.dist.all_gather(parts, torch.from_numpy(mine))
+        self.prob = np.concatenate([parts[r].numpy()[:self._slice(r)[1] - self._slice(r)[0]] for r in range(self.world)])
+        return self.prob
+
+    def estep(self, penalties, with_doublets, prior_logits=None, fetch_logits=True, fetch_probs=True):
+        v, cb, e = self.calls
+        # oracle.barcode_logits with the caller's penalties (demux.py:252-263)
+        g1, g2 = oracle.option_pairs(self.G, 0.5 if with_doublets else 0.)
+        logits = np.zeros([self.B, 1], dtype='float32') + np.asarray(penalties, dtype=np.float32)
+        keep, floor = 1 - e, e.clip(1e-4)
+        for k, (a, b) in enumerate(zip(g1, g2)):
+            col = self.prob[:, a] if a == b else (self.prob[:, a] + self.prob[:, b]) * 0.5
+            logits[:, k] = logits[:, k] + np.bincount(cb, weights=np.log(col[v] * keep + floor), minlength=self.B)
+        if prior_logits is not None:
+            logits += prior_logits
+        self.logits, self.post = logits, oracle.softmax_rows(logits)
+        return self.logits, self.post
+
+    def mstep(self, contribution_power=2., fetch=True):
+        v, cb, e = self.calls
+        keep = 1 - e
+        part = np.zeros((self.V, self.G))
+        for g in range(self.G):
+            w = self.post[cb, g] * keep
+            w **= contribution_power
+            part[:, g] = np.bincount(v, weights=w, minlength=self.V)
+        if self.dist is None:
+            self.addition = part.astype(np.float32)
+        elif not self.sliced:
+            import torch
+            t = torch.from_numpy(part)
+            self.dist.all_reduce(t)
+            self.addition = t.numpy().astype(np.float32)
+        else:
+            import torch
+            self.addition = np.full((self.V, self.G), np.nan, dtype=np.float32)  # foreign slices are NOT current
+            for r in range(self.world):  # reduce-scatter of the padded slices
+                lo, hi = self._slice(r)
+                padded = np.zeros((self.slice_rows, self.G))
+                padded[:hi - lo] = part[lo:hi]
+                t = torch.from_numpy(padded)
+                self.dist.reduce(t, dst=r)
+                if r == self.rank:
+                    self.addition[lo:hi] = t.numpy()[:hi - lo].astype(np.float32)
+            self.partial = True
+        return self.addition
+
+    def _full_addition(self):
+        if self.dist is not None and self.sliced and getattr(self, 'partial', False):
+            import torch
+            lo, hi = self._slice(self.rank)
+            mine = np.zeros((self.slice_rows, self.G), dtype=np.float32)
+            mine[:hi - lo] = self.addition[lo:hi]
+            parts = [torch.zeros(mine.shape, dtype=torch.float32) for _ in range(self.world)]
+            self.dist.all_gather(parts, torch.from_numpy(mine))
+            self.addition = np.concatenate([parts[r].numpy()[:self._slice(r)[1] - self._slice(r)[0]] for r in range(self.world)])
+            self.partial = False
+        return self.addition
+
+    def em(self, n_iterations, p_genotype_clip, penalties, with_doublets, prior_logits=None, contribution_power=2.,
+           fetch_logits=True, fetch_probs=True, fetch_addition=True):
+        self.set_addition(None)
+        self.partial = False
+        for it in range(n_iterations):
+            self.probs_from_betas(p_genotype_clip)
+            self.estep(penalties, with_doublets, prior_logits if it == 0 else None)
+            if it + 1 < n_iterations:
+                self.mstep(contribution_power)
+        return self.logits, self.post, self._full_addition()

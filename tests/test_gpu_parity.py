@@ -444,9 +444,11 @@ def test_repeated_problems_do_not_leak_device_memory():
 # ---- multi-GPU plumbing on one GPU -----------------------------------------------------------------
 @pytest.mark.parametrize('reduce_dtype', ['f64', 'f32'])
 def test_rccl_communicator_single_rank(reduce_dtype):
-    """A one-rank RCCL communicator exercises the whole collective path of dmx_mstep (dlopen of
-    librccl, ncclGetUniqueId / ncclCommInitRank, float64 combine -> ncclAllReduce -> float32) on the one
-    GPU a test box has; with one rank the all-reduce is the identity, so results stay bit-exact."""
+    """A one-rank RCCL communicator exercises the whole collective path (dlopen of librccl, ncclGetUniqueId /
+    ncclCommInitRank, padded exchange layout, partial sums -> ncclReduceScatter -> float32 slice -> sliced P-step ->
+    ncclAllGather) on the one GPU a test box has; with one rank the collectives are copies, so results stay
+    bit-exact.  The communicator is attached AFTER the problem here (the E-step records are re-laid in place) and
+    before it in ShardedEM below."""
     from demuxalot_amd.device import DeviceContext
     from demuxalot_amd.distributed import ShardedEM
     from demuxalot_amd import Demultiplexer
@@ -464,15 +466,18 @@ def test_rccl_communicator_single_rank(reduce_dtype):
                                          with_doublets=False)
         fio.assert_bitwise(probs, fx[f'em0_it{n_it - 1}_probs'], 'probs through the RCCL path')
         fio.assert_bitwise(addition, fx[f'em0_it{n_it - 1}_addition'], 'addition through the RCCL path')
-        assert ctx.timings()['allreduce']['launches'] == n_it - 1
+        assert ctx.timings()['allreduce']['launches'] == n_it + (n_it - 1)  # an all-gather per P-step, a reduce-scatter per M-step
     finally:
         ctx.close()
-    # the sharded front-end with world size 1 (no communicator) gives the same rows
-    em = ShardedEM(0, 1, handler.n_barcodes, v2snp, betas, bc['variant_id'], bc['compressed_cb'], bc['p_base_wrong'], device=0)
-    probs1, addition1 = em.learn(n_it, float(fx['em0_clip']), np.zeros(genotypes.n_genotypes, dtype=np.float32), False)
-    em.ctx.close()
-    fio.assert_bitwise(probs1, probs, 'ShardedEM world=1')
-    fio.assert_bitwise(addition1, addition, 'ShardedEM world=1 addition')
+    # the sharded front-end with world size 1, without and with a (one-rank) communicator, gives the same rows
+    from demuxalot_amd.distributed import SingleProcess
+    for force in (False, True):
+        em = ShardedEM(SingleProcess(), handler.n_barcodes, v2snp, betas, bc['variant_id'], bc['compressed_cb'],
+                       bc['p_base_wrong'], device=0, reduce_dtype=reduce_dtype, force_comm=force)
+        probs1, addition1 = em.learn(n_it, float(fx['em0_clip']), np.zeros(genotypes.n_genotypes, dtype=np.float32), False)
+        em.ctx.close()
+        fio.assert_bitwise(probs1, probs, f'ShardedEM world=1 comm={force}')
+        fio.assert_bitwise(addition1, addition, f'ShardedEM world=1 comm={force} addition')
     # variants cut into several work items (order-sensitive sums redone exactly): the collective path
     # must give what the single-stream path gives; with float64 on the wire that is bit for bit
     from demuxalot_amd import synth

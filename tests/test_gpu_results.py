@@ -164,3 +164,29 @@ def test_compute_probs_from_betas_float64_input(oracle):
     assert not np.array_equal(want, oracle.probs_from_betas(v2snp, betas64.astype(np.float32), 0.02))
     got32 = Demultiplexer._compute_probs_from_betas(v2snp, betas64.astype(np.float32), 0.02)
     fio.assert_bitwise(got32, oracle.probs_from_betas(v2snp, betas64.astype(np.float32), 0.02), 'float32 betas')
+
+
+# ---- the sharded front-end on one GPU -----------------------------------------------------------------------
+@pytest.mark.parametrize('name', ['f1_synthetic_default.npz', 'f3_small_3.npz', 'f6_shipped_example.npz'])
+@pytest.mark.parametrize('reduce_dtype', ['f64', 'f32'])
+def test_sharded_entry_points_with_one_rank_communicator(name, reduce_dtype):
+    """distributed.learn_genotypes / predict_posteriors with a one-rank RCCL communicator attached (force_comm):
+    the whole multi-GPU code path -- sharding of the containers, padded exchange layout, reduce-scatter, sliced
+    P-step, all-gather (F1 / F6: SNP groups contiguous) or the all-reduce fallback (F3: scattered) -- with the
+    reference's captured outputs as the checker.  One rank's collectives are copies: results stay bit-exact."""
+    from demuxalot_amd import distributed
+    fx = fio.load(name)
+    calls, genotypes, handler = fio.product_inputs(fx)
+    kwargs = dict(n_iterations=int(fx['em0_n_iterations']), p_genotype_clip=float(fx['em0_clip']),
+                  doublet_prior=float(fx['em0_dp']))
+    prior = fx.get('em0_prior_logits')
+    learnt, probs_df = distributed.learn_genotypes(calls, genotypes, handler, distributed.SingleProcess(), device=0,
+                                                   barcode_prior_logits=prior, reduce_dtype=reduce_dtype, force_comm=True,
+                                                   **kwargs)
+    fio.assert_bitwise(learnt.variant_betas, fx['em0_learnt_betas'], 'learnt betas')
+    fio.assert_bitwise(probs_df.values, fx[f'em0_it{kwargs["n_iterations"] - 1}_probs'], 'posteriors')
+    logits_df, p_df = distributed.predict_posteriors(calls, genotypes, handler, distributed.SingleProcess(), device=0,
+                                                     p_genotype_clip=float(fx['predict0_clip']),
+                                                     doublet_prior=float(fx['predict0_dp']))
+    fio.assert_bitwise(logits_df.values, fx['predict0_logits'], 'predict logits')
+    fio.assert_bitwise(p_df.values, fx['predict0_probs'], 'predict probs')
