@@ -132,6 +132,11 @@ void release_problem(dmx_ctx *c)
     dev_free(c, &c->d_item_len, (size_t)c->n_items);
     dev_free(c, &c->d_item_ptr, (size_t)c->V + 1);
     dev_free(c, &c->d_bc_order, (size_t)c->B);
+    dev_free(c, &c->d_bin_rows, (size_t)c->n_bins * dmx::TILE_R);
+    dev_free(c, &c->d_bin_order, (size_t)c->n_bins);
+    dev_free(c, &c->d_bin_cnt, (size_t)c->n_bins * c->n_tiles * dmx::TILE_R);
+    c->n_bins = 0;
+    c->n_tiles = 0;
     dev_free(c, &c->d_item_order, (size_t)c->n_items);
     dev_free(c, &c->d_v2snp, (size_t)c->V);
     dev_free(c, &c->d_snp_ptr, (size_t)c->S + 1);
@@ -444,6 +449,11 @@ int run_estep(dmx_ctx *c, int with_doublets, bool with_prior, int prior_dtype, f
     a.G = c->G;
     a.K = c->K;
     a.fast = c->estep_mode == DMX_ESTEP_FAST;
+    a.n_bins = c->tiled_estep ? c->n_bins : 0;
+    a.n_tiles = c->n_tiles;
+    a.bin_order = c->d_bin_order;
+    a.bin_rows = c->d_bin_rows;
+    a.bin_cnt = c->d_bin_cnt;
     std::pair<hipEvent_t, hipEvent_t> ev;
     timer_begin(c, DMX_T_ESTEP, &ev);
     HIP_TRY(dmx::launch_estep(c->stream, a, with_doublets != 0));
@@ -751,6 +761,13 @@ int dmx_set_estep_mode(dmx_ctx *c, int mode)
     if (!c) return fail(DMX_ERR_INVALID, "null context");
     if (mode != DMX_ESTEP_EXACT && mode != DMX_ESTEP_FAST) return fail(DMX_ERR_INVALID, "unknown E-step mode %d", mode);
     c->estep_mode = mode;
+    return 0;
+}
+
+int dmx_set_estep_schedule(dmx_ctx *c, int tiled)
+{
+    if (!c) return fail(DMX_ERR_INVALID, "null context");
+    c->tiled_estep = tiled != 0;
     return 0;
 }
 

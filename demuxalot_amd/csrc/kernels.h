@@ -40,7 +40,18 @@ struct EstepArgs {
     int G;
     int K;
     int fast;                   // DMX_ESTEP_FAST: tolerance mode (products of 8 terms + hardware log2), see kernels.hip
+    // tile-major schedule (k_estep_tiled); n_bins == 0: not built for this problem
+    long long n_bins;
+    int n_tiles;
+    const int *bin_order;       // [n_bins] bins by decreasing number of calls
+    const int *bin_rows;        // [n_bins][TILE_R] barcodes of the bin (-1: empty slot)
+    const unsigned *bin_cnt;    // [n_bins][n_tiles][TILE_R] 8-call groups of the slot's barcode in the tile
 };
+
+constexpr int TILE_R = 8;                    // barcodes per bin
+constexpr long long TILE_BYTES = 2 << 20;    // genotype-table bytes per variant tile (half of an XCD's 4 MB L2)
+constexpr long long TILE_MIN_BARCODES = 65536;   // below this there are too few bins to fill the chip
+constexpr long long TILE_MIN_TABLE_BYTES = 8 << 20;  // a table this small is L2 / L1 resident anyway
 
 struct MstepArgs {
     const int *order;               // [n_items] items by decreasing length (work distribution)

@@ -296,6 +296,58 @@ static __device__ __forceinline__ void estep_flush(float (&prod)[A], FastAcc (&a
     }
 }
 
+// Epilogue of the direct forms: penalties, optional prior, softmax as scipy evaluates it, the M-step's bitmap.
+// acc[s] = float64 sum of the log terms of option kk[s] of barcode b (one lane group of L lanes per barcode).
+template <int L, int A>
+static __device__ __forceinline__ void estep_epilogue(const EstepArgs &a, long long b, bool live, const double (&acc)[A],
+                                                      const int (&kk)[A], const bool (&valid)[A], int lane, int li, int gbase)
+{
+    const int K = a.K;
+    float lg[A], x[A];
+    float mx = -__builtin_inff();
+#pragma unroll
+    for (int s = 0; s < A; s++) {
+        const double t = (double)a.pen[kk[s]] + acc[s];
+        float l = (float)t;
+        if (a.prior) {
+            const size_t o = (size_t)b * K + kk[s];
+            if (a.prior_dtype == DMX_F32)
+                l = l + ((const float *)a.prior)[o];
+            else
+                l = (float)((double)l + ((const double *)a.prior)[o]);
+        }
+        lg[s] = l;
+        mx = valid[s] ? fmaxf(mx, l) : mx;
+    }
+#pragma unroll
+    for (int off = 1; off < L; off <<= 1) mx = fmaxf(mx, __shfl_xor(mx, off));
+#pragma unroll
+    for (int s = 0; s < A; s++) x[s] = npm::exp_f32(lg[s] - mx);
+    const float tot = reg_row_sum<A>(x, K, lane, gbase);
+    const int W = (a.G + 63) >> 6;
+#pragma unroll
+    for (int s = 0; s < A; s++) {
+        const float post = x[s] / tot;
+        if (live && valid[s]) {
+            const size_t o = (size_t)b * K + kk[s];
+            a.logits[o] = lg[s];
+            a.post[o] = post;
+        }
+        // non-zero bitmap of the singlet columns (the M-step skips exact zeros: (0*keep)^2 = +0)
+        const unsigned long long bal = __ballot(live && valid[s] && (li + 64 * s) < a.G && !(post <= a.nz_floor));
+        if (L == 64) {
+            if (lane == 0 && s < W) a.nz[(size_t)b * W + s] = bal;
+        } else {
+            if (live && li == 0) a.nz[(size_t)b] = (bal >> gbase) & ((1ull << L) - 1ull);
+        }
+        if (s == 0 && a.first) {
+            // the one posterior most barcodes have, in a table small enough to stay in L2 (M-step)
+            const unsigned long long mine = L == 64 ? bal : ((bal >> gbase) & ((1ull << L) - 1ull));
+            if (live && mine != 0ull && li == __builtin_ctzll(mine)) a.first[b] = post;
+        }
+    }
+}
+
 template <int L, int A, bool PAIRS, int U, bool FAST>
 __global__ __launch_bounds__(256) void k_estep_direct(EstepArgs a)
 {
@@ -436,49 +488,121 @@ __global__ __launch_bounds__(256) void k_estep_direct(EstepArgs a)
         for (int s = 0; s < A; s++) acc[s] = (facc[s].mant + (double)facc[s].expo) * LN2;
     }
 
-    // epilogue: penalties, optional prior, softmax as scipy evaluates it
-    float lg[A], x[A];
-    float mx = -__builtin_inff();
+    estep_epilogue<L, A>(a, b, live, acc, kk, valid, lane, li, gbase);
+}
+
+// ------------------------------------------------------------------------------------
+// E-step, tile-major form (singlets, 33 <= K <= 128, many barcodes, genotype table larger than an XCD's L2).
+// The direct form gathers one genotype row (K * 4 bytes) per call from a table of V rows that no L2 holds (51 MB at
+// 200k x 64; an XCD's L2 is 4 MB): its 8192 resident wavefronts are at 8192 unrelated places of the variant axis, so
+// more than half of the row reads miss L2 and cross the fabric (measured: 7 GB per launch for 0.8 GB of algorithmic
+// bytes).  Here the variant axis is cut into TILES of ~2 MB of table, and every wavefront owns a BIN of up to
+// TILE_R barcodes which it walks tile by tile: the calls of barcode 0 that fall into tile 0, of barcode 1 in tile 0,
+// ... then tile 1, and so on (rows are variant-sorted, so that is a sequential walk of every row, resumed TILE_R
+// times per tile).  The bins are built with equal numbers of calls (repack_device.hip), all wavefronts run the same
+// instruction stream at the same rate, so at any moment the resident wavefronts of an XCD are working in the same
+// one or two tiles, which its L2 holds.  No synchronisation is involved: alignment is statistical and only affects
+// speed.  The float64 accumulator of each of the bin's barcodes is parked in LDS between its visits; every barcode's
+// calls are still added strictly in order, so the sums are bit-identical to the direct form's.
+//   bin_rows [n_bins][TILE_R]        barcode of every slot (-1: empty)
+//   bin_cnt  [n_bins][n_tiles][TILE_R]  8-call groups of that barcode assigned to that tile (by their first call)
+// ------------------------------------------------------------------------------------
+template <int A, bool FAST>
+__global__ __launch_bounds__(256) void k_estep_tiled(EstepArgs a)
+{
+    constexpr int R = TILE_R;
+    __shared__ double sh_acc[4][R][A][64];
+    const int lane = threadIdx.x & 63;
+    const int K = a.K;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const long long slot = (long long)blockIdx.x * 4 + wave;
+    if (slot >= a.n_bins) return;
+    const long long bin = a.bin_order[slot];
+
+    unsigned o1[A];
+    int kk[A];
+    bool valid[A];
 #pragma unroll
     for (int s = 0; s < A; s++) {
-        const double t = (double)a.pen[kk[s]] + acc[s];
-        float l = (float)t;
-        if (a.prior) {
-            const size_t o = (size_t)b * K + kk[s];
-            if (a.prior_dtype == DMX_F32)
-                l = l + ((const float *)a.prior)[o];
-            else
-                l = (float)((double)l + ((const double *)a.prior)[o]);
-        }
-        lg[s] = l;
-        mx = valid[s] ? fmaxf(mx, l) : mx;
+        const int k = lane + 64 * s;
+        valid[s] = k < K;
+        kk[s] = valid[s] ? k : K - 1;
+        o1[s] = (unsigned)kk[s] * 4u;
     }
+    const int n_slots = (K + 63) >> 6;
+    // lane r < R: barcode of slot r and the cursor (pair index) into its records
+    const int my_row = lane < R ? a.bin_rows[bin * R + lane] : -1;
+    long long cursor = my_row >= 0 ? a.pair_ptr[my_row] : 0;
 #pragma unroll
-    for (int off = 1; off < L; off <<= 1) mx = fmaxf(mx, __shfl_xor(mx, off));
+    for (int r = 0; r < R; r++)
 #pragma unroll
-    for (int s = 0; s < A; s++) x[s] = npm::exp_f32(lg[s] - mx);
-    const float tot = reg_row_sum<A>(x, K, lane, gbase);
-    const int W = (a.G + 63) >> 6;
+        for (int s = 0; s < A; s++) sh_acc[wave][r][s][lane] = 0.0;
+
+    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void *)a.prob, 0, (int)a.prob_bytes, 0x00020000);
+    const unsigned *__restrict__ cnt = a.bin_cnt + (size_t)bin * a.n_tiles * R;
+    unsigned cnt_next = lane < R ? cnt[lane] : 0u;
+    for (int t = 0; t < a.n_tiles; t++) {
+        const unsigned cnt_cur = cnt_next;
+        if (t + 1 < a.n_tiles) cnt_next = lane < R ? cnt[(size_t)(t + 1) * R + lane] : 0u;
+        if (__builtin_amdgcn_readfirstlane((int)(__ballot(cnt_cur != 0u) != 0ull)) == 0) continue;  // nothing of this bin in the tile
+        for (int r = 0; r < R; r++) {
+            const int n_groups = __builtin_amdgcn_readlane((int)cnt_cur, r);
+            if (n_groups == 0) continue;
+            const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)cursor, r);
+            const unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(cursor >> 32), r);
+            const CallPair *__restrict__ recs = a.pairs + (((unsigned long long)hi << 32) | lo);
+            double acc[A];
 #pragma unroll
-    for (int s = 0; s < A; s++) {
-        const float post = x[s] / tot;
-        if (live && valid[s]) {
-            const size_t o = (size_t)b * K + kk[s];
-            a.logits[o] = lg[s];
-            a.post[o] = post;
+            for (int s = 0; s < A; s++) acc[s] = sh_acc[wave][r][s][lane];
+            FastAcc facc[A];
+            float prod[A];
+#pragma unroll
+            for (int s = 0; s < A; s++) {
+                facc[s].mant = 0.0;
+                facc[s].expo = 0;
+                prod[s] = 1.0f;
+            }
+            constexpr int H = A == 1 ? 4 : 2;  // pairs per load batch; a group = 4 pairs = 8 calls
+            for (int j0 = 0; j0 < n_groups * 4; j0 += H) {
+                npm::f32x2 p1[H][A], keep[H], flo[H];
+#pragma unroll
+                for (int q = 0; q < H; q++) {
+                    const CallPair rec = recs[j0 + q];
+                    keep[q] = npm::f32x2{rec.keep[0], rec.keep[1]};
+                    flo[q] = npm::f32x2{rec.floor[0], rec.floor[1]};
+#pragma unroll
+                    for (int s = 0; s < A; s++) {
+                        if (A > 1 && s >= n_slots) continue;
+                        p1[q][s].x = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, (int)o1[s], (int)rec.row_off[0], 0));
+                        p1[q][s].y = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, (int)o1[s], (int)rec.row_off[1], 0));
+                    }
+                }
+                if constexpr (FAST) {
+                    estep_products<A, false, H>(p1, p1, keep, flo, prod, n_slots);
+                    if (((j0 + H) & 3) == 0) estep_flush<A>(prod, facc, n_slots);
+                } else {
+                    estep_terms<A, false, H>(p1, p1, keep, flo, acc, n_slots);
+                }
+            }
+            if constexpr (FAST) {  // the LDS slot holds log2 units: mantissa logs + exponents
+#pragma unroll
+                for (int s = 0; s < A; s++) acc[s] += facc[s].mant + (double)facc[s].expo;
+            }
+#pragma unroll
+            for (int s = 0; s < A; s++) sh_acc[wave][r][s][lane] = acc[s];
+            if (lane == r) cursor += (long long)n_groups * 4;
         }
-        // non-zero bitmap of the singlet columns (the M-step skips exact zeros: (0*keep)^2 = +0)
-        const unsigned long long bal = __ballot(live && valid[s] && (li + 64 * s) < a.G && !(post <= a.nz_floor));
-        if (L == 64) {
-            if (lane == 0 && s < W) a.nz[(size_t)b * W + s] = bal;
-        } else {
-            if (live && li == 0) a.nz[(size_t)b] = (bal >> gbase) & ((1ull << L) - 1ull);
+    }
+    for (int r = 0; r < R; r++) {
+        const int row = __builtin_amdgcn_readlane(my_row, r);
+        if (row < 0) continue;
+        double acc[A];
+#pragma unroll
+        for (int s = 0; s < A; s++) {
+            acc[s] = sh_acc[wave][r][s][lane];
+            if (FAST) acc[s] *= 0.693147180559945309417232121458176568;
         }
-        if (s == 0 && a.first) {
-            // the one posterior most barcodes have, in a table small enough to stay in L2 (M-step)
-            const unsigned long long mine = L == 64 ? bal : ((bal >> gbase) & ((1ull << L) - 1ull));
-            if (live && mine != 0ull && li == __builtin_ctzll(mine)) a.first[b] = post;
-        }
+        estep_epilogue<64, A>(a, (long long)row, true, acc, kk, valid, lane, lane, 0);
     }
 }
 
@@ -1354,10 +1478,25 @@ static hipError_t launch_block(hipStream_t st, const EstepArgs &a, int k_base = 
     return hipGetLastError();
 }
 
+template <int A>
+static void launch_tiled(hipStream_t st, const EstepArgs &a)
+{
+    const dim3 grid(blocks_for(a.n_bins, 4)), block(256);
+    if (a.fast)
+        hipLaunchKernelGGL((k_estep_tiled<A, true>), grid, block, 0, st, a);
+    else
+        hipLaunchKernelGGL((k_estep_tiled<A, false>), grid, block, 0, st, a);
+}
+
 hipError_t launch_estep(hipStream_t st, const EstepArgs &a, bool pairs)
 {
     if (a.B == 0) return hipSuccess;
     const int K = a.K;
+    if (a.n_bins > 0 && !pairs && K > 32 && K <= 128) {  // tile-major schedule (built by the repack when it pays)
+        if (K <= 64) launch_tiled<1>(st, a);
+        else launch_tiled<2>(st, a);
+        return hipGetLastError();
+    }
     if (K <= 256) {
         if (K <= 4) launch_direct<4, 1, 4>(st, a, pairs);
         else if (K <= 8) launch_direct<8, 1, 8>(st, a, pairs);

@@ -142,6 +142,56 @@ __global__ __launch_bounds__(256) void k_build_items(const long long *__restrict
     }
 }
 
+// ---- tile-major E-step schedule (kernels.hip: k_estep_tiled) ------------------------------------------------
+// Bins of TILE_R barcodes with (nearly) equal numbers of 8-call groups: the barcodes, sorted by decreasing length,
+// are dealt in TILE_R strata of n_bins rows; inside a stratum the longest row goes to the bin that is lightest so
+// far (bins sorted by load before every stratum).
+__global__ __launch_bounds__(256) void k_assign_stratum(const int *__restrict__ order, const unsigned *__restrict__ sorted_bins,
+                                                        int stratum, long long n_bins, long long B,
+                                                        const long long *__restrict__ pair_ptr, int *__restrict__ bin_rows,
+                                                        unsigned *__restrict__ loads, int *__restrict__ row_slot)
+{
+    const long long j = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= n_bins) return;
+    const unsigned bin = sorted_bins[j];
+    const long long idx = (long long)stratum * n_bins + j;
+    int row = -1;
+    if (idx < B) {
+        row = order[idx];
+        loads[bin] += (unsigned)((pair_ptr[row + 1] - pair_ptr[row]) >> 2);
+        row_slot[row] = (int)(bin * TILE_R + stratum);
+    }
+    bin_rows[(size_t)bin * TILE_R + stratum] = row;
+}
+
+__global__ __launch_bounds__(256) void k_bin_keys(const unsigned *__restrict__ loads, long long n_bins, unsigned *__restrict__ inv,
+                                                  unsigned *__restrict__ ids)
+{
+    const long long j = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= n_bins) return;
+    inv[j] = ~loads[j];
+    ids[j] = (unsigned)j;
+}
+
+// one wavefront per barcode: its 8-call groups counted per variant tile (tile of a group = tile of its first call)
+__global__ __launch_bounds__(256) void k_count_groups(const CallPair *__restrict__ pairs, const long long *__restrict__ pair_ptr,
+                                                      const int *__restrict__ row_slot, long long B, unsigned row_bytes,
+                                                      unsigned tile_rows, int n_tiles, unsigned *__restrict__ cnt)
+{
+    const int lane = threadIdx.x & 63;
+    const long long b = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (b >= B) return;
+    const int slot = row_slot[b];
+    const long long bin = slot / TILE_R;
+    const int r = slot % TILE_R;
+    const long long p0 = pair_ptr[b];
+    const long long n_groups = (pair_ptr[b + 1] - p0) >> 2;
+    for (long long j = lane; j < n_groups; j += 64) {
+        const unsigned tile = pairs[p0 + 4 * j].row_off[0] / row_bytes / tile_rows;
+        atomicAdd(&cnt[((size_t)bin * n_tiles + tile) * TILE_R + r], 1u);
+    }
+}
+
 inline unsigned grid_for(long long n) { return (unsigned)((n + 255) / 256); }
 
 inline unsigned bits_for(unsigned long long max_value)
@@ -274,6 +324,40 @@ static int repack_core(dmx_ctx *c, Scratch &sc, const int *d_variant, const int 
     if (N)
         hipLaunchKernelGGL(k_build_pairs, dim3(grid_for(N)), dim3(256), 0, st, keys_b, perm_b, d_variant, d_p, row_start,
                            c->d_pair_ptr, N, (unsigned)G, c->d_call_pairs);
+    // ---- tile-major E-step schedule, when the shape calls for it ----
+    c->n_bins = 0;
+    c->n_tiles = 0;
+    if (G > 32 && G <= 128 && B >= TILE_MIN_BARCODES && V * (long long)G * 4 >= TILE_MIN_TABLE_BYTES) {
+        const long long n_bins = (B + TILE_R - 1) / TILE_R;
+        const unsigned tile_rows = (unsigned)std::max<long long>(1, TILE_BYTES / ((long long)G * 4));
+        const int n_tiles = (int)((V + tile_rows - 1) / tile_rows);
+        DMX_TRY(dev_alloc(c, &c->d_bin_rows, (size_t)n_bins * TILE_R));
+        DMX_TRY(dev_alloc(c, &c->d_bin_order, (size_t)n_bins));
+        DMX_TRY(dev_alloc(c, &c->d_bin_cnt, (size_t)n_bins * n_tiles * TILE_R));
+        c->n_bins = n_bins;  // (set before any failure below so that release_problem frees with the right sizes)
+        c->n_tiles = n_tiles;
+        unsigned *loads = nullptr, *bin_ids = nullptr, *keys_tmp = nullptr, *sorted_bins = nullptr, *inv_l = nullptr;
+        int *row_slot = nullptr;
+        DMX_TRY(sc.get(&loads, (size_t)n_bins));
+        DMX_TRY(sc.get(&bin_ids, (size_t)n_bins));
+        DMX_TRY(sc.get(&keys_tmp, (size_t)n_bins));
+        DMX_TRY(sc.get(&sorted_bins, (size_t)n_bins));
+        DMX_TRY(sc.get(&inv_l, (size_t)n_bins));
+        DMX_TRY(sc.get(&row_slot, (size_t)B));
+        HIP_TRY(hipMemsetAsync(loads, 0, sizeof(unsigned) * n_bins, st));
+        hipLaunchKernelGGL(k_iota, dim3(grid_for(n_bins)), dim3(256), 0, st, bin_ids, n_bins);
+        for (int stratum = 0; stratum < TILE_R; stratum++) {
+            DMX_TRY(sort_pairs(sc, loads, keys_tmp, bin_ids, sorted_bins, (size_t)n_bins, 32, st));  // lightest bin first (stable)
+            hipLaunchKernelGGL(k_assign_stratum, dim3(grid_for(n_bins)), dim3(256), 0, st, c->d_bc_order, sorted_bins, stratum, n_bins, B,
+                               c->d_pair_ptr, c->d_bin_rows, loads, row_slot);
+        }
+        hipLaunchKernelGGL(k_bin_keys, dim3(grid_for(n_bins)), dim3(256), 0, st, loads, n_bins, inv_l, bin_ids);
+        DMX_TRY(sort_pairs(sc, inv_l, keys_tmp, bin_ids, (unsigned *)c->d_bin_order, (size_t)n_bins, 32, st));  // heaviest bin first
+        HIP_TRY(hipMemsetAsync(c->d_bin_cnt, 0, sizeof(unsigned) * (size_t)n_bins * n_tiles * TILE_R, st));
+        hipLaunchKernelGGL(k_count_groups, dim3((unsigned)((B + 3) / 4)), dim3(256), 0, st, c->d_call_pairs, c->d_pair_ptr, row_slot, B,
+                           (unsigned)G * 4u, tile_rows, n_tiles, c->d_bin_cnt);
+    }
+
     // variant-major -> M-step records
     DMX_TRY(dev_alloc(c, &c->d_csc, (size_t)N));
     if (N) hipLaunchKernelGGL(k_build_csc, dim3(grid_for(N)), dim3(256), 0, st, perm_v, d_cb, d_p, N, c->d_csc);

@@ -26,6 +26,8 @@ class DeviceContext:
         # DEMUXALOT_AMD_ESTEP=fast selects the tolerance-mode E-step (include/demux_hip.h: dmx_set_estep_mode)
         if os.environ.get('DEMUXALOT_AMD_ESTEP', 'exact') == 'fast':
             self.set_estep_mode('fast')
+        if os.environ.get('DEMUXALOT_AMD_ESTEP_SCHEDULE', 'tiled') == 'direct':
+            self.set_estep_schedule(False)
 
     def close(self):
         if getattr(self, '_h', None):
@@ -278,6 +280,10 @@ class DeviceContext:
         """'exact' (default: logits / posteriors bit-identical to the reference) or 'fast' (tolerance mode:
         assignments identical, posteriors within the contract's 1e-5); include/demux_hip.h: dmx_set_estep_mode."""
         check(self._lib.dmx_set_estep_mode(self._h, {'exact': 0, 'fast': 1}[mode]))
+
+    def set_estep_schedule(self, tiled):
+        """Tile-major E-step schedule on (default) / off (include/demux_hip.h: dmx_set_estep_schedule)."""
+        check(self._lib.dmx_set_estep_schedule(self._h, int(bool(tiled))))
 
     def set_exact_additions(self, exact):
         """M-step summation mode (include/demux_hip.h: dmx_set_exact_additions). Default: exact."""

@@ -160,6 +160,13 @@ int dmx_set_exact_additions(dmx_ctx *ctx, int exact);
 #define DMX_ESTEP_FAST 1
 int dmx_set_estep_mode(dmx_ctx *ctx, int mode);
 
+/* E-step work distribution.  For singlet runs of 33..128 genotypes on at least 65 536 barcodes with a genotype table
+ * of 8 MB or more, the problem upload also builds a tile-major schedule (bins of 8 barcodes with equal numbers of
+ * calls, walked variant tile by variant tile, so that the wavefronts of an XCD gather genotype rows from the same
+ * ~2 MB of the table at any time: csrc/kernels.hip, k_estep_tiled).  tiled != 0 (default) uses it when present;
+ * tiled == 0 always runs one barcode per wavefront.  Results are bit-identical either way. */
+int dmx_set_estep_schedule(dmx_ctx *ctx, int tiled);
+
 /* genotype_addition float32[V*G]; NULL resets it to zero (demux.py:86). */
 int dmx_set_addition(dmx_ctx *ctx, const float *addition);
 

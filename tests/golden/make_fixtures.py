@@ -496,6 +496,82 @@ def main():
     save('f1_from_assignment.npz', keep)
 
 
+def reference_inputs(ref, fx):
+    """The reference's own objects rebuilt from the stored inputs of an existing fixture (inputs_as_arrays)."""
+    calls = {}
+    for i, chrom in enumerate(fx['chroms']):
+        c = ref.snp_counter.CompressedSNPCalls()
+        c.molecules = np.zeros(len(fx[f'c{i}_mol_cb']), dtype=c.molecules.dtype)
+        c.molecules['compressed_cb'] = fx[f'c{i}_mol_cb']
+        c.molecules['compressed_ub'] = fx[f'c{i}_mol_ub']
+        c.molecules['p_group_misaligned'] = fx[f'c{i}_mol_pmis']
+        c.snp_calls = np.zeros(len(fx[f'c{i}_call_mol']), dtype=c.snp_calls.dtype)
+        c.snp_calls['molecule_index'] = fx[f'c{i}_call_mol']
+        c.snp_calls['snp_position'] = fx[f'c{i}_call_pos']
+        c.snp_calls['base_index'] = fx[f'c{i}_call_base']
+        c.snp_calls['p_base_wrong'] = fx[f'c{i}_call_p']
+        c.n_molecules, c.n_snp_calls = len(c.molecules), len(c.snp_calls)
+        calls[str(chrom)] = c
+    g = ref.ProbabilisticGenotypes([str(n) for n in fx['genotype_names']], default_prior=float(fx['default_prior']))
+    g.var2varid = {(str(c), int(p), 'ACGTN'[int(b)]): int(r)
+                   for c, p, b, r in zip(fx['var_chrom'], fx['var_pos'], fx['var_base'], fx['var_row'])}
+    g.variant_betas = np.array(fx['betas'], dtype=np.float32)
+    handler = ref.BarcodeHandler([str(b) for b in fx['barcodes']])
+    assert handler.ordered_barcodes == [str(b) for b in fx['barcodes']]
+    return calls, g, handler
+
+
+def aggregate_on_snps_cases():
+    """F7: Demultiplexer.aggregate_on_snps = True (demux.py:204-244) on the inputs of existing fixtures; only the
+    outputs are stored (float64 logits / posteriors, float32 additions and learnt betas), the inputs are those of
+    the named fixture."""
+    ref, _ = import_reference()
+    D = ref.Demultiplexer
+    rng = np.random.default_rng(77)
+    for name, predict_dps, em_runs in (
+            ('f3_small_2.npz', (0., 0.35), (dict(n_iterations=3, dp=0.), dict(n_iterations=2, dp=0.3, prior=True))),
+            ('f3_small_4.npz', (0., 0.2), (dict(n_iterations=2, dp=0.),)),
+            ('f2_synthetic_g4.npz', (0., 0.35), (dict(n_iterations=3, dp=0.), dict(n_iterations=2, dp=0.25))),
+            ('f1_synthetic_default.npz', (0., 0.25), (dict(n_iterations=3, dp=0., prior=True),)),
+    ):
+        with np.load(os.path.join(HERE, name), allow_pickle=False) as z:
+            fx = {k: z[k] for k in z.files}
+        calls, g, handler = reference_inputs(ref, fx)
+        out = {'inputs_of': np.asarray(name)}
+        D.aggregate_on_snps = True
+        try:
+            for i, dp in enumerate(predict_dps):
+                logits, probs = D.predict_posteriors(calls, g, handler, doublet_prior=dp)
+                assert logits.values.dtype == np.float64 and probs.values.dtype == np.float64
+                out[f'predict{i}_dp'] = np.float64(dp)
+                out[f'predict{i}_logits'] = logits.values
+                out[f'predict{i}_probs'] = probs.values
+                out[f'predict{i}_columns'] = np.asarray(list(logits.columns), dtype=str)
+            out['n_predict'] = np.int64(len(predict_dps))
+            for i, run in enumerate(em_runs):
+                K = len(D._doublet_penalties(g.n_genotypes, run['dp']))
+                prior = (rng.normal(size=(handler.n_barcodes, K)) * 3).astype('float32') if run.get('prior') else None
+                kwargs = dict(n_iterations=run['n_iterations'], doublet_prior=run['dp'])
+                stages = list(D.staged_genotype_learning(calls, g, handler,
+                                                         barcode_prior_logits=None if prior is None else prior.copy(), **kwargs))
+                for it, (probs_df, dbg) in enumerate(stages):
+                    out[f'em{i}_it{it}_logits'] = np.array(dbg['barcode_logits'])
+                    out[f'em{i}_it{it}_probs'] = probs_df.values.copy()
+                    out[f'em{i}_it{it}_addition'] = np.array(dbg['genotype_addition'])
+                learnt, last = D.learn_genotypes(calls, g, handler, barcode_prior_logits=None if prior is None else prior.copy(),
+                                                 **kwargs)
+                assert np.array_equal(last.values, stages[-1][0].values)
+                out[f'em{i}_learnt_betas'] = np.array(learnt.variant_betas)
+                out[f'em{i}_n_iterations'] = np.int64(run['n_iterations'])
+                out[f'em{i}_dp'] = np.float64(run['dp'])
+                if prior is not None:
+                    out[f'em{i}_prior_logits'] = prior
+            out['n_em'] = np.int64(len(em_runs))
+        finally:
+            D.aggregate_on_snps = False
+        save('f7_aggregate_' + name.split('_', 1)[1], out)
+
+
 def synthetic_generator_case():
     """F5: a mid-size problem from the benchmark generator (demuxalot_amd/synth.py) pushed
     through the REFERENCE's full entry points, so that the generator's object form, the host repack and
@@ -569,7 +645,10 @@ if __name__ == '__main__':
         shipped_example_case()
     elif len(sys.argv) > 1 and sys.argv[1] == 'f5':
         synthetic_generator_case()
+    elif len(sys.argv) > 1 and sys.argv[1] == 'f7':
+        aggregate_on_snps_cases()
     else:
         main()
         synthetic_generator_case()
         shipped_example_case()
+        aggregate_on_snps_cases()  # reads the inputs of the fixtures written above
