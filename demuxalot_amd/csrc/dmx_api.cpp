@@ -126,17 +126,18 @@ void release_problem(dmx_ctx *c)
 {
     dev_free(c, &c->d_pair_ptr, (size_t)c->B + 1);
     dev_free(c, &c->d_call_pairs, (size_t)c->n_pairs);
+    dev_free(c, &c->d_tile_stream, (size_t)c->n_pairs);
     c->n_pairs = 0;
     dev_free(c, &c->d_csc, (size_t)c->N);
     dev_free(c, &c->d_item_start, (size_t)c->n_items);
     dev_free(c, &c->d_item_len, (size_t)c->n_items);
     dev_free(c, &c->d_item_ptr, (size_t)c->V + 1);
     dev_free(c, &c->d_bc_order, (size_t)c->B);
-    dev_free(c, &c->d_bin_rows, (size_t)c->n_bins * dmx::TILE_R);
+    dev_free(c, &c->d_bin_rows, (size_t)c->n_bins * c->bin_rows_cap);
     dev_free(c, &c->d_bin_order, (size_t)c->n_bins);
-    dev_free(c, &c->d_bin_cnt, (size_t)c->n_bins * c->n_tiles * dmx::TILE_R);
+    dev_free(c, &c->d_bin_ptr, (size_t)c->n_bins + 1);
     c->n_bins = 0;
-    c->n_tiles = 0;
+    c->n_tiles = c->bin_rows_cap = 0;
     dev_free(c, &c->d_item_order, (size_t)c->n_items);
     dev_free(c, &c->d_v2snp, (size_t)c->V);
     dev_free(c, &c->d_snp_ptr, (size_t)c->S + 1);
@@ -345,6 +346,7 @@ int layout_exchange(dmx_ctx *c)
         DMX_TRY(dev_alloc(c, &c->d_prow, (size_t)V));
         HIP_TRY(hipMemcpyAsync(c->d_prow, prow.data(), sizeof(int) * V, hipMemcpyHostToDevice, st));
         HIP_TRY(dmx::launch_remap_row_offsets(st, c->d_call_pairs, c->n_pairs, (unsigned)G * 4u, c->d_prow));
+        if (c->d_tile_stream) HIP_TRY(dmx::launch_remap_row_offsets(st, c->d_tile_stream, c->n_pairs, (unsigned)G * 4u, c->d_prow));
         const size_t elem = c->reduce_dtype == DMX_F64 ? 8 : 4;
         c->exch_bytes = (size_t)new_rows * G * 8;  // float64 sums; also the float32 staging of the addition gather
         c->recv_bytes = (size_t)rows * G * elem;
@@ -449,11 +451,13 @@ int run_estep(dmx_ctx *c, int with_doublets, bool with_prior, int prior_dtype, f
     a.G = c->G;
     a.K = c->K;
     a.fast = c->estep_mode == DMX_ESTEP_FAST;
+    a.tiled = c->tiled_estep;
     a.n_bins = c->tiled_estep ? c->n_bins : 0;
-    a.n_tiles = c->n_tiles;
+    a.bin_rows_cap = c->bin_rows_cap;
     a.bin_order = c->d_bin_order;
     a.bin_rows = c->d_bin_rows;
-    a.bin_cnt = c->d_bin_cnt;
+    a.bin_ptr = c->d_bin_ptr;
+    a.tile_stream = c->d_tile_stream;
     std::pair<hipEvent_t, hipEvent_t> ev;
     timer_begin(c, DMX_T_ESTEP, &ev);
     HIP_TRY(dmx::launch_estep(c->stream, a, with_doublets != 0));
@@ -767,7 +771,8 @@ int dmx_set_estep_mode(dmx_ctx *c, int mode)
 int dmx_set_estep_schedule(dmx_ctx *c, int tiled)
 {
     if (!c) return fail(DMX_ERR_INVALID, "null context");
-    c->tiled_estep = tiled != 0;
+    if (tiled < 0 || tiled > 2) return fail(DMX_ERR_INVALID, "schedule must be 0, 1 or 2");
+    c->tiled_estep = tiled;
     return 0;
 }
 

@@ -53,9 +53,10 @@ struct dmx_ctx {
     long long n_items = 0;
     // tile-major E-step schedule (repack_device.hip; n_bins == 0: not built)
     long long n_bins = 0;
-    int n_tiles = 0;
+    int n_tiles = 0, bin_rows_cap = 0;       // rows per bin (<= TILE_R_MAX)
     int *d_bin_rows = nullptr, *d_bin_order = nullptr;
-    unsigned *d_bin_cnt = nullptr;
+    long long *d_bin_ptr = nullptr;          // [n_bins + 1] first stream group of every bin
+    dmx::CallPair *d_tile_stream = nullptr;  // the E-step records once more, in the order the bins consume them
     int *d_v2snp = nullptr, *d_snp_ptr = nullptr, *d_snp_vars = nullptr;
     float *d_prior = nullptr, *d_add = nullptr, *d_prob = nullptr;
     double *d_add64 = nullptr, *d_partial = nullptr;
@@ -67,7 +68,7 @@ struct dmx_ctx {
     int item_calls = 1024;  // work-item length of the resident problem (kernels.h: item_calls_for)
     bool exact_additions = true;  // dmx_set_exact_additions
     int estep_mode = DMX_ESTEP_EXACT;  // dmx_set_estep_mode
-    bool tiled_estep = true;           // use the tile-major schedule when the repack built one (dmx_set_estep_schedule)
+    int tiled_estep = 1;               // dmx_set_estep_schedule: 0 never, 1 when it pays, 2 whenever the repack built one
     float nz_floor = 0.0f;     // threshold the current d_nz / d_first were built with
     float *d_first = nullptr;  // [B] posterior of the lowest non-zero singlet column (G <= 64)
     long long cap_bk = 0;

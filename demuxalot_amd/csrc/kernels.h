@@ -41,14 +41,17 @@ struct EstepArgs {
     int K;
     int fast;                   // DMX_ESTEP_FAST: tolerance mode (products of 8 terms + hardware log2), see kernels.hip
     // tile-major schedule (k_estep_tiled); n_bins == 0: not built for this problem
+    int tiled;                  // dmx_set_estep_schedule: 0 never, 1 when it pays (tolerance mode), 2 whenever built
     long long n_bins;
-    int n_tiles;
+    int bin_rows_cap;           // R: barcode slots per bin (<= TILE_R_MAX)
     const int *bin_order;       // [n_bins] bins by decreasing number of calls
-    const int *bin_rows;        // [n_bins][TILE_R] barcodes of the bin (-1: empty slot)
-    const unsigned *bin_cnt;    // [n_bins][n_tiles][TILE_R] 8-call groups of the slot's barcode in the tile
+    const int *bin_rows;        // [n_bins][R] barcodes of the bin (-1: empty slot)
+    const long long *bin_ptr;   // [n_bins + 1] first group (4 CallPairs = 8 calls) of every bin in tile_stream
+    const CallPair *tile_stream;  // the call records in bin-major, tile-major, slot-minor order; reserved[0] of a
+                                  // group's first pair = the slot (accumulator) the group belongs to
 };
 
-constexpr int TILE_R = 8;                    // barcodes per bin
+constexpr int TILE_R_MAX = 9;                // barcodes per bin at most (LDS: 4 waves x 9 x 64 doubles = 18 KB per block)
 constexpr long long TILE_BYTES = 2 << 20;    // genotype-table bytes per variant tile (half of an XCD's 4 MB L2)
 constexpr long long TILE_MIN_BARCODES = 65536;   // below this there are too few bins to fill the chip
 constexpr long long TILE_MIN_TABLE_BYTES = 8 << 20;  // a table this small is L2 / L1 resident anyway

@@ -296,6 +296,121 @@ static __device__ __forceinline__ void estep_flush(float (&prod)[A], FastAcc (&a
     }
 }
 
+// One batch of H call pairs (2H calls) of a wave-uniform record stream: keep / floor stay in SGPRs, the genotype
+// rows are gathered with the row offset as the buffer load's scalar offset.
+template <int A, int H, bool PAIRS>
+struct RecBatch {
+    npm::f32x2 p1[H][A], p2[H][A], keep[H], flo[H];
+};
+
+template <int A, int H, bool PAIRS>
+static __device__ __forceinline__ void load_batch(RecBatch<A, H, PAIRS> &x, const CallPair *__restrict__ recs, int j,
+                                                  __amdgpu_buffer_rsrc_t rsrc, const unsigned (&o1)[A], const unsigned (&o2)[A],
+                                                  int n_slots)
+{
+    j = __builtin_amdgcn_readfirstlane(j);  // wave-uniform by construction; says so to the compiler (scalar loads)
+#pragma unroll
+    for (int q = 0; q < H; q++) {
+        const CallPair r = recs[j + q];
+        x.keep[q] = npm::f32x2{r.keep[0], r.keep[1]};
+        x.flo[q] = npm::f32x2{r.floor[0], r.floor[1]};
+#pragma unroll
+        for (int s = 0; s < A; s++) {
+            if (A > 1 && s >= n_slots) continue;
+            x.p1[q][s].x = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, (int)o1[s], (int)r.row_off[0], 0));
+            x.p1[q][s].y = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, (int)o1[s], (int)r.row_off[1], 0));
+            if (PAIRS) {
+                x.p2[q][s].x = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, (int)o2[s], (int)r.row_off[0], 0));
+                x.p2[q][s].y = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, (int)o2[s], (int)r.row_off[1], 0));
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------
+// Tolerance mode, K <= 64 singlets (one accumulator per lane): the software pipeline of the record stream.
+// With ~10 VALU cycles per term there is nothing to hide latency behind, and the chain
+//     scalar load of the call records (misses the scalar cache: the 1.3 GB stream is read once, from HBM)
+//     -> row gathers (their addresses come from the records) -> arithmetic
+// is paid in full for every batch of 8 calls (measured: 1.72 ms, the same as the gathers alone in round 1).  Here
+// the records travel through the VECTOR memory path instead: a batch of 8 calls is 32 dwords, loaded by one
+// coalesced 128-byte load (lane l holds dword l), 7 batches ahead of their use; row offsets, keep and floor are then
+// moved to SGPRs with v_readlane (24 per batch); the gathers of batches k+1 .. k+3 are in flight while batch k is consumed.
+//   on_group(k, tag)  called before batch k is consumed with the slot tag of its records (tile-major form)
+// ------------------------------------------------------------------------------------
+struct FastBatch {
+    npm::f32x2 p[4];  // gathered genotype probabilities of the batch's 8 calls (call 2q in .x, 2q+1 in .y)
+    int rec;          // the batch's records: lane l holds dword l of its 4 CallPairs
+};
+
+template <typename OnGroup>
+static __device__ __forceinline__ void fast_walk_single(const CallPair *__restrict__ recs, int n_batches,
+                                                        __amdgpu_buffer_rsrc_t rsrc, unsigned lane_off, int lane, float &prod,
+                                                        FastAcc &facc, OnGroup on_group)
+{
+    if (n_batches <= 0) return;
+    const unsigned *__restrict__ words = (const unsigned *)recs;
+    const int l32 = lane & 31;
+    auto fetch = [&](int k) {  // dword (lane % 32) of batch k; batches past the end re-read the last one
+        const int kk = k < n_batches ? k : n_batches - 1;
+        return (int)words[(size_t)kk * 32 + l32];
+    };
+    auto issue = [&](int w, FastBatch &g) {  // row offsets of a batch -> SGPRs -> its 8 gathers in flight
+        g.rec = w;
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            const int r0 = __builtin_amdgcn_readlane(w, 8 * q), r1 = __builtin_amdgcn_readlane(w, 8 * q + 1);
+            g.p[q].x = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, (int)lane_off, r0, 0));
+            g.p[q].y = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, (int)lane_off, r1, 0));
+        }
+    };
+    auto consume = [&](int k, const FastBatch &g) {
+        on_group(k, __builtin_amdgcn_readlane(g.rec, 6));
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            npm::f32x2 keep, flo;
+            keep.x = __builtin_bit_cast(float, __builtin_amdgcn_readlane(g.rec, 8 * q + 2));
+            keep.y = __builtin_bit_cast(float, __builtin_amdgcn_readlane(g.rec, 8 * q + 3));
+            flo.x = __builtin_bit_cast(float, __builtin_amdgcn_readlane(g.rec, 8 * q + 4));
+            flo.y = __builtin_bit_cast(float, __builtin_amdgcn_readlane(g.rec, 8 * q + 5));
+            npm::f32x2 t = g.p[q] * keep;
+            t = t + flo;
+            prod = (prod * t.x) * t.y;
+        }
+        const float m = __builtin_amdgcn_frexp_mantf(prod);
+        facc.expo += __builtin_amdgcn_frexp_expf(prod);
+        facc.mant += (double)__builtin_amdgcn_logf(m);
+        prod = 1.0f;
+    };
+    // records of batches k+4 .. k+7 on their way, gathers of batches k+1 .. k+3 in flight while batch k is consumed;
+    // the loop is unrolled by 4 so that every ring slot is a fixed register
+    int w0 = fetch(0), w1 = fetch(1), w2 = fetch(2), w3 = fetch(3);
+    FastBatch g0, g1, g2, g3;
+    issue(w0, g0);
+    w0 = fetch(4);
+    issue(w1, g1);
+    w1 = fetch(5);
+    issue(w2, g2);
+    w2 = fetch(6);
+    for (int k = 0; k < n_batches; k += 4) {
+        issue(w3, g3);
+        w3 = fetch(k + 7);
+        consume(k, g0);
+        if (k + 1 >= n_batches) break;
+        issue(w0, g0);
+        w0 = fetch(k + 8);
+        consume(k + 1, g1);
+        if (k + 2 >= n_batches) break;
+        issue(w1, g1);
+        w1 = fetch(k + 9);
+        consume(k + 2, g2);
+        if (k + 3 >= n_batches) break;
+        issue(w2, g2);
+        w2 = fetch(k + 10);
+        consume(k + 3, g3);
+    }
+}
+
 // Epilogue of the direct forms: penalties, optional prior, softmax as scipy evaluates it, the M-step's bitmap.
 // acc[s] = float64 sum of the log terms of option kk[s] of barcode b (one lane group of L lanes per barcode).
 template <int L, int A>
@@ -406,29 +521,29 @@ __global__ __launch_bounds__(256) void k_estep_direct(EstepArgs a)
         const __amdgpu_buffer_rsrc_t rsrc =
             __builtin_amdgcn_make_buffer_rsrc((void *)a.prob, 0, (int)a.prob_bytes, 0x00020000);
         constexpr int H = U / 2;
-        for (int j0 = 0; j0 < npairs; j0 += H) {
-            npm::f32x2 p1[H][A], p2[H][A], keep[H], flo[H];
-#pragma unroll
-            for (int q = 0; q < H; q++) {
-                const CallPair r = recs[j0 + q];
-                keep[q] = npm::f32x2{r.keep[0], r.keep[1]};
-                flo[q] = npm::f32x2{r.floor[0], r.floor[1]};
-#pragma unroll
-                for (int s = 0; s < A; s++) {
-                    if (A > 1 && s >= n_slots) continue;
-                    p1[q][s].x = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, (int)o1[s], (int)r.row_off[0], 0));
-                    p1[q][s].y = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, (int)o1[s], (int)r.row_off[1], 0));
-                    if (PAIRS) {
-                        p2[q][s].x = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, (int)o2[s], (int)r.row_off[0], 0));
-                        p2[q][s].y = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, (int)o2[s], (int)r.row_off[1], 0));
-                    }
+        if constexpr (FAST) {
+            // The tolerance mode has little arithmetic per call, so the row gathers' latency is what it waits for:
+            // two batches in flight (ping-pong), the gathers of batch i+1 issued before batch i is consumed.  Reads past
+            // the row's last batch are redirected to it (valid records, results unused).
+            if (npairs > 0) {
+                RecBatch<A, H, PAIRS> x, y;
+                load_batch<A, H, PAIRS>(x, recs, 0, rsrc, o1, o2, n_slots);
+                for (int j0 = 0; j0 < npairs; j0 += 2 * H) {
+                    const int j1 = j0 + H;
+                    load_batch<A, H, PAIRS>(y, recs, min(j1, npairs - H), rsrc, o1, o2, n_slots);
+                    estep_products<A, PAIRS, H>(x.p1, x.p2, x.keep, x.flo, prod, n_slots);
+                    if (((j0 + H) & 3) == 0) estep_flush<A>(prod, facc, n_slots);  // every 8 calls (rows are padded to 8)
+                    if (j1 >= npairs) break;
+                    load_batch<A, H, PAIRS>(x, recs, min(j1 + H, npairs - H), rsrc, o1, o2, n_slots);
+                    estep_products<A, PAIRS, H>(y.p1, y.p2, y.keep, y.flo, prod, n_slots);
+                    if (((j1 + H) & 3) == 0) estep_flush<A>(prod, facc, n_slots);
                 }
             }
-            if constexpr (FAST) {
-                estep_products<A, PAIRS, H>(p1, p2, keep, flo, prod, n_slots);
-                if (((j0 + H) & 3) == 0) estep_flush<A>(prod, facc, n_slots);  // every 8 calls (rows are padded to 8)
-            } else {
-                estep_terms<A, PAIRS, H>(p1, p2, keep, flo, acc, n_slots);
+        } else {
+            for (int j0 = 0; j0 < npairs; j0 += H) {
+                RecBatch<A, H, PAIRS> x;
+                load_batch<A, H, PAIRS>(x, recs, j0, rsrc, o1, o2, n_slots);
+                estep_terms<A, PAIRS, H>(x.p1, x.p2, x.keep, x.flo, acc, n_slots);
             }
         }
     } else {
@@ -497,27 +612,29 @@ __global__ __launch_bounds__(256) void k_estep_direct(EstepArgs a)
 // 200k x 64; an XCD's L2 is 4 MB): its 8192 resident wavefronts are at 8192 unrelated places of the variant axis, so
 // more than half of the row reads miss L2 and cross the fabric (measured: 7 GB per launch for 0.8 GB of algorithmic
 // bytes).  Here the variant axis is cut into TILES of ~2 MB of table, and every wavefront owns a BIN of up to
-// TILE_R barcodes which it walks tile by tile: the calls of barcode 0 that fall into tile 0, of barcode 1 in tile 0,
-// ... then tile 1, and so on (rows are variant-sorted, so that is a sequential walk of every row, resumed TILE_R
-// times per tile).  The bins are built with equal numbers of calls (repack_device.hip), all wavefronts run the same
-// instruction stream at the same rate, so at any moment the resident wavefronts of an XCD are working in the same
-// one or two tiles, which its L2 holds.  No synchronisation is involved: alignment is statistical and only affects
-// speed.  The float64 accumulator of each of the bin's barcodes is parked in LDS between its visits; every barcode's
-// calls are still added strictly in order, so the sums are bit-identical to the direct form's.
-//   bin_rows [n_bins][TILE_R]        barcode of every slot (-1: empty)
-//   bin_cnt  [n_bins][n_tiles][TILE_R]  8-call groups of that barcode assigned to that tile (by their first call)
+// TILE_R_MAX barcodes which it walks tile by tile: the calls of barcode 0 that fall into tile 0, of barcode 1 in tile
+// 0, ... then tile 1, and so on (rows are variant-sorted, so that is a sequential walk of every row, resumed once per
+// tile).  The bins hold equal numbers of calls and there are (rounds x resident wavefronts) of them, all wavefronts
+// run the same instruction stream at the same rate, so at any moment the resident wavefronts of an XCD are working in
+// the same one or two tiles, which its L2 holds.  No synchronisation is involved: the alignment is statistical and
+// only affects speed.
+// The repack materialises that walk: tile_stream holds the call records of a bin in exactly the order the wavefront
+// consumes them (so the kernel reads one contiguous record stream, like the direct form), each 8-call group tagged
+// with the barcode slot it belongs to.  The float64 accumulator of the current slot lives in registers; on a slot
+// change it is swapped with the slot's copy in LDS.  Every barcode's calls are still added strictly in order, so
+// the sums are bit-identical to the direct form's.
 // ------------------------------------------------------------------------------------
 template <int A, bool FAST>
 __global__ __launch_bounds__(256) void k_estep_tiled(EstepArgs a)
 {
-    constexpr int R = TILE_R;
-    __shared__ double sh_acc[4][R][A][64];
+    __shared__ double sh_acc[4][TILE_R_MAX][A][64];
     const int lane = threadIdx.x & 63;
     const int K = a.K;
+    const int R = a.bin_rows_cap;
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    const long long slot = (long long)blockIdx.x * 4 + wave;
-    if (slot >= a.n_bins) return;
-    const long long bin = a.bin_order[slot];
+    const long long slot_id = (long long)blockIdx.x * 4 + wave;
+    if (slot_id >= a.n_bins) return;
+    const long long bin = a.bin_order[slot_id];
 
     unsigned o1[A];
     int kk[A];
@@ -530,79 +647,88 @@ __global__ __launch_bounds__(256) void k_estep_tiled(EstepArgs a)
         o1[s] = (unsigned)kk[s] * 4u;
     }
     const int n_slots = (K + 63) >> 6;
-    // lane r < R: barcode of slot r and the cursor (pair index) into its records
-    const int my_row = lane < R ? a.bin_rows[bin * R + lane] : -1;
-    long long cursor = my_row >= 0 ? a.pair_ptr[my_row] : 0;
-#pragma unroll
     for (int r = 0; r < R; r++)
 #pragma unroll
         for (int s = 0; s < A; s++) sh_acc[wave][r][s][lane] = 0.0;
 
     const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void *)a.prob, 0, (int)a.prob_bytes, 0x00020000);
-    const unsigned *__restrict__ cnt = a.bin_cnt + (size_t)bin * a.n_tiles * R;
-    unsigned cnt_next = lane < R ? cnt[lane] : 0u;
-    for (int t = 0; t < a.n_tiles; t++) {
-        const unsigned cnt_cur = cnt_next;
-        if (t + 1 < a.n_tiles) cnt_next = lane < R ? cnt[(size_t)(t + 1) * R + lane] : 0u;
-        if (__builtin_amdgcn_readfirstlane((int)(__ballot(cnt_cur != 0u) != 0ull)) == 0) continue;  // nothing of this bin in the tile
-        for (int r = 0; r < R; r++) {
-            const int n_groups = __builtin_amdgcn_readlane((int)cnt_cur, r);
-            if (n_groups == 0) continue;
-            const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)cursor, r);
-            const unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(cursor >> 32), r);
-            const CallPair *__restrict__ recs = a.pairs + (((unsigned long long)hi << 32) | lo);
-            double acc[A];
+    const long long g0 = a.bin_ptr[bin];
+    const int n_pairs = (int)(a.bin_ptr[bin + 1] - g0) * 4;
+    const CallPair *__restrict__ recs = a.tile_stream + g0 * 4;
+    double acc[A];
+    FastAcc facc[A];
+    float prod[A];
 #pragma unroll
-            for (int s = 0; s < A; s++) acc[s] = sh_acc[wave][r][s][lane];
-            FastAcc facc[A];
-            float prod[A];
-#pragma unroll
-            for (int s = 0; s < A; s++) {
-                facc[s].mant = 0.0;
-                facc[s].expo = 0;
-                prod[s] = 1.0f;
-            }
-            constexpr int H = A == 1 ? 4 : 2;  // pairs per load batch; a group = 4 pairs = 8 calls
-            for (int j0 = 0; j0 < n_groups * 4; j0 += H) {
-                npm::f32x2 p1[H][A], keep[H], flo[H];
-#pragma unroll
-                for (int q = 0; q < H; q++) {
-                    const CallPair rec = recs[j0 + q];
-                    keep[q] = npm::f32x2{rec.keep[0], rec.keep[1]};
-                    flo[q] = npm::f32x2{rec.floor[0], rec.floor[1]};
-#pragma unroll
-                    for (int s = 0; s < A; s++) {
-                        if (A > 1 && s >= n_slots) continue;
-                        p1[q][s].x = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, (int)o1[s], (int)rec.row_off[0], 0));
-                        p1[q][s].y = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, (int)o1[s], (int)rec.row_off[1], 0));
-                    }
-                }
-                if constexpr (FAST) {
-                    estep_products<A, false, H>(p1, p1, keep, flo, prod, n_slots);
-                    if (((j0 + H) & 3) == 0) estep_flush<A>(prod, facc, n_slots);
-                } else {
-                    estep_terms<A, false, H>(p1, p1, keep, flo, acc, n_slots);
-                }
-            }
-            if constexpr (FAST) {  // the LDS slot holds log2 units: mantissa logs + exponents
-#pragma unroll
-                for (int s = 0; s < A; s++) acc[s] += facc[s].mant + (double)facc[s].expo;
-            }
-#pragma unroll
-            for (int s = 0; s < A; s++) sh_acc[wave][r][s][lane] = acc[s];
-            if (lane == r) cursor += (long long)n_groups * 4;
-        }
+    for (int s = 0; s < A; s++) {
+        acc[s] = 0.0;
+        facc[s].mant = 0.0;
+        facc[s].expo = 0;
+        prod[s] = 1.0f;
     }
-    for (int r = 0; r < R; r++) {
-        const int row = __builtin_amdgcn_readlane(my_row, r);
-        if (row < 0) continue;
-        double acc[A];
+    int cur = 0;  // slot whose accumulator is in registers
+    constexpr int H = A == 1 ? 4 : 2;  // pairs per load batch; a group = 4 pairs = 8 calls
+    const unsigned zero[A] = {};
+    // a batch starting a group (j % 4 == 0) carries the group's slot tag; on a slot change the accumulators are
+    // swapped through LDS (wave-uniform branch)
+    auto enter = [&](int j, int tag) {
+        if ((j & 3) != 0 || tag == cur) return;
 #pragma unroll
         for (int s = 0; s < A; s++) {
-            acc[s] = sh_acc[wave][r][s][lane];
-            if (FAST) acc[s] *= 0.693147180559945309417232121458176568;
+            if (FAST) acc[s] += facc[s].mant + (double)facc[s].expo;  // the parked value is in log2 units
+            sh_acc[wave][cur][s][lane] = acc[s];
+            acc[s] = sh_acc[wave][tag][s][lane];
+            facc[s].mant = 0.0;
+            facc[s].expo = 0;
         }
-        estep_epilogue<64, A>(a, (long long)row, true, acc, kk, valid, lane, lane, 0);
+        cur = tag;
+    };
+    if constexpr (FAST && A == 1) {
+        fast_walk_single(recs, n_pairs >> 2, rsrc, o1[0], lane, prod[0], facc[0], [&](int, int tag) { enter(0, tag); });
+    } else if constexpr (FAST) {
+        // two batches in flight (see k_estep_direct); reads past the bin's last batch are redirected to it
+        if (n_pairs > 0) {
+            RecBatch<A, H, false> x, y;
+            load_batch<A, H, false>(x, recs, 0, rsrc, o1, zero, n_slots);
+            int tag_x = (int)recs[0].reserved[0], tag_y = 0;
+            for (int j0 = 0; j0 < n_pairs; j0 += 2 * H) {
+                const int j1 = j0 + H, jy = min(j1, n_pairs - H);
+                load_batch<A, H, false>(y, recs, jy, rsrc, o1, zero, n_slots);
+                tag_y = (int)recs[jy].reserved[0];
+                enter(j0, tag_x);
+                estep_products<A, false, H>(x.p1, x.p2, x.keep, x.flo, prod, n_slots);
+                if (((j0 + H) & 3) == 0) estep_flush<A>(prod, facc, n_slots);
+                if (j1 >= n_pairs) break;
+                const int jx = min(j1 + H, n_pairs - H);
+                load_batch<A, H, false>(x, recs, jx, rsrc, o1, zero, n_slots);
+                tag_x = (int)recs[jx].reserved[0];
+                enter(j1, tag_y);
+                estep_products<A, false, H>(y.p1, y.p2, y.keep, y.flo, prod, n_slots);
+                if (((j1 + H) & 3) == 0) estep_flush<A>(prod, facc, n_slots);
+            }
+        }
+    } else {
+        for (int j0 = 0; j0 < n_pairs; j0 += H) {
+            RecBatch<A, H, false> x;
+            load_batch<A, H, false>(x, recs, j0, rsrc, o1, zero, n_slots);
+            enter(j0, (int)recs[j0].reserved[0]);
+            estep_terms<A, false, H>(x.p1, x.p2, x.keep, x.flo, acc, n_slots);
+        }
+    }
+#pragma unroll
+    for (int s = 0; s < A; s++) {
+        if (FAST) acc[s] += facc[s].mant + (double)facc[s].expo;
+        sh_acc[wave][cur][s][lane] = acc[s];
+    }
+    for (int r = 0; r < R; r++) {
+        const int row = a.bin_rows[bin * R + r];
+        if (row < 0) continue;
+        double out[A];
+#pragma unroll
+        for (int s = 0; s < A; s++) {
+            out[s] = sh_acc[wave][r][s][lane];
+            if (FAST) out[s] *= 0.693147180559945309417232121458176568;
+        }
+        estep_epilogue<64, A>(a, (long long)row, true, out, kk, valid, lane, lane, 0);
     }
 }
 
@@ -1492,7 +1618,11 @@ hipError_t launch_estep(hipStream_t st, const EstepArgs &a, bool pairs)
 {
     if (a.B == 0) return hipSuccess;
     const int K = a.K;
-    if (a.n_bins > 0 && !pairs && K > 32 && K <= 128) {  // tile-major schedule (built by the repack when it pays)
+    // tile-major schedule (built by the repack for large singlet problems).  It pays in the tolerance mode, whose
+    // time is the row gathers (1.50 ms against 1.72 ms on 200k x 100k x 64: L2 hit rate 44 % -> 68 %); the exact mode
+    // is bound by its arithmetic and only pays the schedule's overhead (2.78 against 2.72 ms), so it keeps one
+    // barcode per wavefront unless the schedule is forced (a.tiled == 2: tests).
+    if (a.n_bins > 0 && !pairs && K > 32 && K <= 128 && (a.fast || a.tiled == 2)) {
         if (K <= 64) launch_tiled<1>(st, a);
         else launch_tiled<2>(st, a);
         return hipGetLastError();

@@ -143,11 +143,11 @@ __global__ __launch_bounds__(256) void k_build_items(const long long *__restrict
 }
 
 // ---- tile-major E-step schedule (kernels.hip: k_estep_tiled) ------------------------------------------------
-// Bins of TILE_R barcodes with (nearly) equal numbers of 8-call groups: the barcodes, sorted by decreasing length,
-// are dealt in TILE_R strata of n_bins rows; inside a stratum the longest row goes to the bin that is lightest so
+// Bins of R barcodes with (nearly) equal numbers of 8-call groups: the barcodes, sorted by decreasing length,
+// are dealt in R strata of n_bins rows; inside a stratum the longest row goes to the bin that is lightest so
 // far (bins sorted by load before every stratum).
 __global__ __launch_bounds__(256) void k_assign_stratum(const int *__restrict__ order, const unsigned *__restrict__ sorted_bins,
-                                                        int stratum, long long n_bins, long long B,
+                                                        int stratum, int R, long long n_bins, long long B,
                                                         const long long *__restrict__ pair_ptr, int *__restrict__ bin_rows,
                                                         unsigned *__restrict__ loads, int *__restrict__ row_slot)
 {
@@ -159,9 +159,9 @@ __global__ __launch_bounds__(256) void k_assign_stratum(const int *__restrict__ 
     if (idx < B) {
         row = order[idx];
         loads[bin] += (unsigned)((pair_ptr[row + 1] - pair_ptr[row]) >> 2);
-        row_slot[row] = (int)(bin * TILE_R + stratum);
+        row_slot[row] = (int)(bin * R + stratum);
     }
-    bin_rows[(size_t)bin * TILE_R + stratum] = row;
+    bin_rows[(size_t)bin * R + stratum] = row;
 }
 
 __global__ __launch_bounds__(256) void k_bin_keys(const unsigned *__restrict__ loads, long long n_bins, unsigned *__restrict__ inv,
@@ -173,23 +173,76 @@ __global__ __launch_bounds__(256) void k_bin_keys(const unsigned *__restrict__ l
     ids[j] = (unsigned)j;
 }
 
-// one wavefront per barcode: its 8-call groups counted per variant tile (tile of a group = tile of its first call)
-__global__ __launch_bounds__(256) void k_count_groups(const CallPair *__restrict__ pairs, const long long *__restrict__ pair_ptr,
-                                                      const int *__restrict__ row_slot, long long B, unsigned row_bytes,
-                                                      unsigned tile_rows, int n_tiles, unsigned *__restrict__ cnt)
+// Tile of every 8-call group of a barcode, made monotone along the row (running maximum), so that "the groups of
+// row r in tile t" is always a contiguous run of the row even when the caller's calls are not variant-sorted.
+// One wavefront per barcode; MODE 0 counts the groups per (bin, tile, slot) cell, MODE 1 copies them into the
+// bin-major stream: cell_start = first stream group of the cell, row_tile_start = groups of the row before the tile.
+template <int MODE>
+__global__ __launch_bounds__(256) void k_tile_groups(const CallPair *__restrict__ pairs, const long long *__restrict__ pair_ptr,
+                                                     const int *__restrict__ row_slot, long long B, unsigned row_bytes,
+                                                     unsigned tile_rows, int n_tiles, int R, unsigned *__restrict__ cnt,
+                                                     const unsigned *__restrict__ cell_start,
+                                                     const unsigned *__restrict__ row_tile_start, CallPair *__restrict__ stream)
 {
     const int lane = threadIdx.x & 63;
     const long long b = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (b >= B) return;
     const int slot = row_slot[b];
-    const long long bin = slot / TILE_R;
-    const int r = slot % TILE_R;
+    const long long bin = slot / R;
+    const int r = slot % R;
     const long long p0 = pair_ptr[b];
     const long long n_groups = (pair_ptr[b + 1] - p0) >> 2;
-    for (long long j = lane; j < n_groups; j += 64) {
-        const unsigned tile = pairs[p0 + 4 * j].row_off[0] / row_bytes / tile_rows;
-        atomicAdd(&cnt[((size_t)bin * n_tiles + tile) * TILE_R + r], 1u);
+    unsigned carry = 0;  // largest tile seen in earlier groups of the row
+    for (long long j0 = 0; j0 < n_groups; j0 += 64) {
+        const long long j = j0 + lane;
+        unsigned tile = j < n_groups ? pairs[p0 + 4 * j].row_off[0] / row_bytes / tile_rows : 0u;
+        tile = max(tile, carry);
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {  // inclusive prefix maximum over the lanes
+            const unsigned other = __shfl_up(tile, off);
+            if (lane >= off) tile = max(tile, other);
+        }
+        carry = __shfl(tile, 63);
+        if (j >= n_groups) continue;
+        const size_t cell = ((size_t)bin * n_tiles + tile) * R + r;
+        if (MODE == 0) {
+            atomicAdd(&cnt[cell], 1u);
+        } else {
+            const size_t dst = (size_t)cell_start[cell] + (size_t)(j - row_tile_start[cell]);
+            const uint4 *src4 = (const uint4 *)(pairs + p0 + 4 * j);
+            uint4 *dst4 = (uint4 *)(stream + 4 * dst);
+#pragma unroll
+            for (int q = 0; q < 8; q++) {
+                uint4 w = src4[q];
+                if (q == 1) w.z = (unsigned)r;  // CallPair.reserved[0] of the group's first pair: accumulator slot
+                dst4[q] = w;
+            }
+        }
     }
+}
+
+// row_tile_start[bin][t][r] = groups of the slot's barcode in tiles < t (one thread per (bin, slot))
+__global__ __launch_bounds__(256) void k_row_tile_starts(const unsigned *__restrict__ cnt, long long n_bins, int n_tiles, int R,
+                                                         unsigned *__restrict__ row_tile_start)
+{
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_bins * R) return;
+    const long long bin = i / R;
+    const int r = (int)(i % R);
+    unsigned run = 0;
+    for (int t = 0; t < n_tiles; t++) {
+        const size_t cell = ((size_t)bin * n_tiles + t) * R + r;
+        row_tile_start[cell] = run;
+        run += cnt[cell];
+    }
+}
+
+__global__ __launch_bounds__(256) void k_bin_ptr(const unsigned *__restrict__ cell_start, long long n_bins, size_t cells_per_bin,
+                                                 long long total_groups, long long *__restrict__ bin_ptr)
+{
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i > n_bins) return;
+    bin_ptr[i] = i < n_bins ? (long long)cell_start[(size_t)i * cells_per_bin] : total_groups;
 }
 
 inline unsigned grid_for(long long n) { return (unsigned)((n + 255) / 256); }
@@ -327,16 +380,30 @@ static int repack_core(dmx_ctx *c, Scratch &sc, const int *d_variant, const int 
     // ---- tile-major E-step schedule, when the shape calls for it ----
     c->n_bins = 0;
     c->n_tiles = 0;
+    c->bin_rows_cap = 0;
     if (G > 32 && G <= 128 && B >= TILE_MIN_BARCODES && V * (long long)G * 4 >= TILE_MIN_TABLE_BYTES) {
-        const long long n_bins = (B + TILE_R - 1) / TILE_R;
+        // as many bins as wavefronts the chip holds, times a whole number of rounds: bins have equal work, so a
+        // launch is that many rounds long, and a partly filled last round would cost a whole one
+        hipDeviceProp_t prop;
+        HIP_TRY(hipGetDeviceProperties(&prop, c->device));
+        const long long wave_slots = (long long)prop.multiProcessorCount * 32;
+        const long long rounds = (B + TILE_R_MAX * wave_slots - 1) / (TILE_R_MAX * wave_slots);
+        const long long n_bins = rounds * wave_slots;
+        const int R = (int)((B + n_bins - 1) / n_bins);  // <= TILE_R_MAX
         const unsigned tile_rows = (unsigned)std::max<long long>(1, TILE_BYTES / ((long long)G * 4));
         const int n_tiles = (int)((V + tile_rows - 1) / tile_rows);
-        DMX_TRY(dev_alloc(c, &c->d_bin_rows, (size_t)n_bins * TILE_R));
+        const size_t cells = (size_t)n_bins * n_tiles * R;
+        const long long total_groups = n_pairs >> 2;
+        if (total_groups >= (1LL << 32)) return fail(DMX_ERR_UNSUPPORTED, "too many call groups for the tile-major schedule");
+        DMX_TRY(dev_alloc(c, &c->d_bin_rows, (size_t)n_bins * R));
         DMX_TRY(dev_alloc(c, &c->d_bin_order, (size_t)n_bins));
-        DMX_TRY(dev_alloc(c, &c->d_bin_cnt, (size_t)n_bins * n_tiles * TILE_R));
+        DMX_TRY(dev_alloc(c, &c->d_bin_ptr, (size_t)n_bins + 1));
+        DMX_TRY(dev_alloc(c, &c->d_tile_stream, (size_t)n_pairs));
         c->n_bins = n_bins;  // (set before any failure below so that release_problem frees with the right sizes)
         c->n_tiles = n_tiles;
+        c->bin_rows_cap = R;
         unsigned *loads = nullptr, *bin_ids = nullptr, *keys_tmp = nullptr, *sorted_bins = nullptr, *inv_l = nullptr;
+        unsigned *cnt = nullptr, *cell_start = nullptr, *row_tile_start = nullptr;
         int *row_slot = nullptr;
         DMX_TRY(sc.get(&loads, (size_t)n_bins));
         DMX_TRY(sc.get(&bin_ids, (size_t)n_bins));
@@ -344,18 +411,35 @@ static int repack_core(dmx_ctx *c, Scratch &sc, const int *d_variant, const int 
         DMX_TRY(sc.get(&sorted_bins, (size_t)n_bins));
         DMX_TRY(sc.get(&inv_l, (size_t)n_bins));
         DMX_TRY(sc.get(&row_slot, (size_t)B));
+        DMX_TRY(sc.get(&cnt, cells));
+        DMX_TRY(sc.get(&cell_start, cells));
+        DMX_TRY(sc.get(&row_tile_start, cells));
         HIP_TRY(hipMemsetAsync(loads, 0, sizeof(unsigned) * n_bins, st));
         hipLaunchKernelGGL(k_iota, dim3(grid_for(n_bins)), dim3(256), 0, st, bin_ids, n_bins);
-        for (int stratum = 0; stratum < TILE_R; stratum++) {
+        for (int stratum = 0; stratum < R; stratum++) {
             DMX_TRY(sort_pairs(sc, loads, keys_tmp, bin_ids, sorted_bins, (size_t)n_bins, 32, st));  // lightest bin first (stable)
-            hipLaunchKernelGGL(k_assign_stratum, dim3(grid_for(n_bins)), dim3(256), 0, st, c->d_bc_order, sorted_bins, stratum, n_bins, B,
-                               c->d_pair_ptr, c->d_bin_rows, loads, row_slot);
+            hipLaunchKernelGGL(k_assign_stratum, dim3(grid_for(n_bins)), dim3(256), 0, st, c->d_bc_order, sorted_bins, stratum, R, n_bins,
+                               B, c->d_pair_ptr, c->d_bin_rows, loads, row_slot);
         }
         hipLaunchKernelGGL(k_bin_keys, dim3(grid_for(n_bins)), dim3(256), 0, st, loads, n_bins, inv_l, bin_ids);
         DMX_TRY(sort_pairs(sc, inv_l, keys_tmp, bin_ids, (unsigned *)c->d_bin_order, (size_t)n_bins, 32, st));  // heaviest bin first
-        HIP_TRY(hipMemsetAsync(c->d_bin_cnt, 0, sizeof(unsigned) * (size_t)n_bins * n_tiles * TILE_R, st));
-        hipLaunchKernelGGL(k_count_groups, dim3((unsigned)((B + 3) / 4)), dim3(256), 0, st, c->d_call_pairs, c->d_pair_ptr, row_slot, B,
-                           (unsigned)G * 4u, tile_rows, n_tiles, c->d_bin_cnt);
+        // groups per (bin, tile, slot) cell -> position of every cell / of every row's tile run in the bin-major stream
+        HIP_TRY(hipMemsetAsync(cnt, 0, sizeof(unsigned) * cells, st));
+        const dim3 row_grid((unsigned)((B + 3) / 4));
+        hipLaunchKernelGGL(k_tile_groups<0>, row_grid, dim3(256), 0, st, c->d_call_pairs, c->d_pair_ptr, row_slot, B, (unsigned)G * 4u,
+                           tile_rows, n_tiles, R, cnt, (const unsigned *)nullptr, (const unsigned *)nullptr, (CallPair *)nullptr);
+        {
+            size_t bytes = 0;
+            HIP_TRY(rocprim::exclusive_scan(nullptr, bytes, cnt, cell_start, 0u, cells, rocprim::plus<unsigned>(), st));
+            char *tmp;
+            DMX_TRY(sc.get(&tmp, bytes));
+            HIP_TRY(rocprim::exclusive_scan(tmp, bytes, cnt, cell_start, 0u, cells, rocprim::plus<unsigned>(), st));
+        }
+        hipLaunchKernelGGL(k_row_tile_starts, dim3(grid_for(n_bins * R)), dim3(256), 0, st, cnt, n_bins, n_tiles, R, row_tile_start);
+        hipLaunchKernelGGL(k_bin_ptr, dim3(grid_for(n_bins + 1)), dim3(256), 0, st, cell_start, n_bins, (size_t)n_tiles * R, total_groups,
+                           c->d_bin_ptr);
+        hipLaunchKernelGGL(k_tile_groups<1>, row_grid, dim3(256), 0, st, c->d_call_pairs, c->d_pair_ptr, row_slot, B, (unsigned)G * 4u,
+                           tile_rows, n_tiles, R, (unsigned *)nullptr, cell_start, row_tile_start, c->d_tile_stream);
     }
 
     // variant-major -> M-step records

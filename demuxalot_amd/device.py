@@ -26,8 +26,8 @@ class DeviceContext:
         # DEMUXALOT_AMD_ESTEP=fast selects the tolerance-mode E-step (include/demux_hip.h: dmx_set_estep_mode)
         if os.environ.get('DEMUXALOT_AMD_ESTEP', 'exact') == 'fast':
             self.set_estep_mode('fast')
-        if os.environ.get('DEMUXALOT_AMD_ESTEP_SCHEDULE', 'tiled') == 'direct':
-            self.set_estep_schedule(False)
+        if os.environ.get('DEMUXALOT_AMD_ESTEP_SCHEDULE', 'auto') != 'auto':
+            self.set_estep_schedule(os.environ['DEMUXALOT_AMD_ESTEP_SCHEDULE'])
 
     def close(self):
         if getattr(self, '_h', None):
@@ -281,9 +281,10 @@ class DeviceContext:
         assignments identical, posteriors within the contract's 1e-5); include/demux_hip.h: dmx_set_estep_mode."""
         check(self._lib.dmx_set_estep_mode(self._h, {'exact': 0, 'fast': 1}[mode]))
 
-    def set_estep_schedule(self, tiled):
-        """Tile-major E-step schedule on (default) / off (include/demux_hip.h: dmx_set_estep_schedule)."""
-        check(self._lib.dmx_set_estep_schedule(self._h, int(bool(tiled))))
+    def set_estep_schedule(self, schedule):
+        """'auto' (default: tile-major schedule where it pays), 'tiled' (whenever built), 'direct' (never);
+        include/demux_hip.h: dmx_set_estep_schedule."""
+        check(self._lib.dmx_set_estep_schedule(self._h, {'direct': 0, 'auto': 1, 'tiled': 2}[schedule]))
 
     def set_exact_additions(self, exact):
         """M-step summation mode (include/demux_hip.h: dmx_set_exact_additions). Default: exact."""

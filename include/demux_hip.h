@@ -163,8 +163,10 @@ int dmx_set_estep_mode(dmx_ctx *ctx, int mode);
 /* E-step work distribution.  For singlet runs of 33..128 genotypes on at least 65 536 barcodes with a genotype table
  * of 8 MB or more, the problem upload also builds a tile-major schedule (bins of 8 barcodes with equal numbers of
  * calls, walked variant tile by variant tile, so that the wavefronts of an XCD gather genotype rows from the same
- * ~2 MB of the table at any time: csrc/kernels.hip, k_estep_tiled).  tiled != 0 (default) uses it when present;
- * tiled == 0 always runs one barcode per wavefront.  Results are bit-identical either way. */
+ * ~2 MB of the table at any time: csrc/kernels.hip, k_estep_tiled).  tiled = 1 (default): used where it pays, i.e.
+ * in the tolerance mode (DMX_ESTEP_FAST), whose time is the row gathers; the exact mode is bound by its arithmetic
+ * and keeps one barcode per wavefront.  tiled = 2: used whenever built; tiled = 0: never.  Results of a given
+ * E-step mode are bit-identical under every schedule. */
 int dmx_set_estep_schedule(dmx_ctx *ctx, int tiled);
 
 /* genotype_addition float32[V*G]; NULL resets it to zero (demux.py:86). */

@@ -137,12 +137,49 @@ def problem64():
     return synth.generate(200_000, 100_000, 64, seed=1237)
 
 
-def test_config3_em_200k_100k_64_steps(oracle, problem64):
+@pytest.mark.parametrize('schedule', ['auto', 'tiled'])
+def test_config3_em_200k_100k_64_steps(oracle, problem64, schedule):
     """The headline shape (200k x 100k x 64, N ~ 78.6 M, hottest variant 72 863 calls = five work items):
-    two EM iterations step by step."""
+    two EM iterations step by step; once with the default work distribution (one barcode per wavefront in the
+    exact mode) and once with the tile-major schedule forced (bins of barcodes walked variant tile by tile,
+    accumulators parked in LDS): the sums must be bit-identical under either."""
+    from demuxalot_amd.device import get_context
     samples = [[(0, 2500), (100_000, 101_500)], [(198_000, 200_000)]]
-    _ctx, _addition, _singlets, n_multi = staged_em_against_oracle(oracle, problem64, 2, 0., samples, seed=12)
+    get_context().set_estep_schedule(schedule)
+    try:
+        _ctx, _addition, _singlets, n_multi = staged_em_against_oracle(oracle, problem64, 2, 0., samples, seed=12)
+    finally:
+        get_context().set_estep_schedule('auto')
     assert n_multi >= 20, n_multi
+
+
+def test_config3_fast_mode_within_contract(oracle, problem64):
+    """The tolerance-mode E-step at the headline size (tile-major schedule, pipelined record stream): sampled
+    barcode rows against the oracle -- assignments identical, posteriors within the ulp-scaled bound of
+    tests/test_gpu_fast_mode.py -- and against the exact mode on all 200k barcodes."""
+    from demuxalot_amd.device import get_context
+    from tests.test_gpu_fast_mode import check_contract
+    p = problem64
+    ctx = get_context()
+    ctx.set_problem(p.n_barcodes, p.n_variants, 64, p.variant_id, p.compressed_cb, p.p_base_wrong, p.v2snp)
+    ctx.set_betas(p.prior_betas())
+    ctx.set_addition(None)
+    prob = ctx.probs_from_betas(0.01)
+    pen = np.zeros(64, dtype=np.float32)
+    logits_exact, probs_exact = ctx.estep(pen, with_doublets=False)
+    ctx.set_estep_mode('fast')
+    try:
+        logits_fast, probs_fast = ctx.estep(pen, with_doublets=False)
+    finally:
+        ctx.set_estep_mode('exact')
+    ulps, dev = check_contract(logits_fast, probs_fast, logits_exact, probs_exact, 'fast vs exact, all barcodes', strict=False)
+    for lo, hi in ((0, 1500), (120_000, 121_500)):
+        v, cb, e = p.subset_barcodes(lo, hi)
+        rows, v = np.unique(v, return_inverse=True)
+        want = oracle.barcode_logits(v, cb, e, prob[rows], hi - lo, 0., log_impl='npsimd')
+        check_contract(logits_fast[lo:hi], probs_fast[lo:hi], want, oracle.softmax_rows(want, impl='npsimd'),
+                       f'fast rows [{lo},{hi})', strict=False)
+    print(f'fast mode at 200k x 100k x 64: logits within {ulps:.1f} ulp of the exact mode, posteriors within {dev:.3g}')
 
 
 def test_config3_uninformative_posteriors_mstep(oracle, problem64):
