@@ -53,6 +53,11 @@ SIGNATURES = {
     'dmx_get_assignments_above': (c_int, [_P, c_float, _P, _P, POINTER(c_int64)]),
     'dmx_get_top_options': (c_int, [_P, c_int32, _P, _P]),
     'dmx_get_option_sums': (c_int, [_P, _P]),
+    'dmx_set_keep_molecule_calls': (c_int, [_P, c_int]),
+    'dmx_set_molecule_calls': (c_int, [_P, c_int64, _P, _P, _P]),
+    'dmx_get_max_pair_count': (c_int, [_P, POINTER(c_int64)]),
+    'dmx_estep_snp': (c_int, [_P, c_int, _P, c_int64, _P, c_int, _P, _P]),
+    'dmx_mstep_f64': (c_int, [_P, c_double, _P]),
     'dmx_exchange_slices': (c_int, [c_int64, _P, c_int32, _P, POINTER(c_int64), POINTER(c_int32)]),
     'dmx_comm_unique_id': (c_int, [_P]),
     'dmx_comm_init': (c_int, [_P, c_int, c_int, _P, c_int]),

@@ -190,6 +190,15 @@ void release_problem(dmx_ctx *c)
     dev_free(c, &c->d_u_count, (size_t)c->n_u);
     c->n_u = 0;
     dev_free(c, &c->d_mol, (size_t)c->V);
+    dev_free(c, &c->d_mc_variant, (size_t)c->n_mc);
+    dev_free(c, &c->d_mc_e, (size_t)c->n_mc);
+    dev_free(c, &c->d_mc_start, (size_t)c->B + 1);
+    c->n_mc = 0;
+    c->mc_max_count = 0;
+    dev_free(c, &c->d_logits64, c->cap_bk64);
+    dev_free(c, &c->d_post64, c->cap_bk64);
+    c->cap_bk64 = 0;
+    c->have_post64 = false;
     c->have_problem = c->have_betas = c->have_probs = c->have_post = false;
     c->B = c->V = c->N = c->S = 0;
     c->G = c->K = 0;

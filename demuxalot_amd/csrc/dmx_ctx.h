@@ -85,6 +85,16 @@ struct dmx_ctx {
     long long *d_u_count = nullptr;
     long long n_u = 0;
     unsigned long long *d_mol = nullptr;  // matched molecule calls per variant (device pack), for the data prior
+    // aggregate_on_snps (snp_aggregate.hip): matched molecule calls grouped by (barcode, SNP)
+    bool keep_molecule_calls = false;     // dmx_set_keep_molecule_calls: the device pack leaves them behind
+    int *d_mc_variant = nullptr;          // [n_mc] variant row | 0x80000000 on the first call of a pair
+    float *d_mc_e = nullptr;              // [n_mc] p_base_wrong
+    long long *d_mc_start = nullptr;      // [B + 1] first call of every barcode
+    long long n_mc = 0;
+    unsigned mc_max_count = 0;            // most molecule calls in one (barcode, SNP) pair
+    double *d_logits64 = nullptr, *d_post64 = nullptr;  // float64 results of dmx_estep_snp
+    size_t cap_bk64 = 0;
+    bool have_post64 = false;
     void *d_scratch = nullptr;  // self tests
     size_t cap_scratch = 0;
 
@@ -144,6 +154,8 @@ int pack_on_device(dmx_ctx *c, long long V, const int *var_chrom, const int *var
                    long long n_calls, const int *call_chrom, const int *call_pos, const unsigned char *call_base,
                    const int *call_cb, const float *call_p, long long *n_matched, long long *n_unique,
                    long long *mol_per_variant);
+// matched molecule calls (molecule order) -> the (barcode, SNP)-grouped layout of the aggregate_on_snps E-step
+int build_snp_groups(dmx_ctx *c, const unsigned long long *vb_keys, const unsigned *src_idx, const float *src_p, long long m);
 int pack_containers_on_device(dmx_ctx *c, long long V, const int *var_chrom, const int *var_pos,
                               const unsigned char *var_base, const dmx_call_container *parts, int n_parts,
                               long long *n_matched, long long *n_unique, long long *mol_per_variant);

@@ -648,6 +648,8 @@ static int pack_core(dmx_ctx *c, Scratch &sc, long long V, const int *var_chrom,
     if (n_calls)
         hipLaunchKernelGGL(k_compact_keys, dim3(grid_for(n_calls)), dim3(256), 0, st, call_variant, d_ccb, flag, pos_excl,
                            n_calls, keys, idx);
+    // aggregate_on_snps wants the matched molecule calls themselves, grouped by (barcode, SNP)
+    if (c->keep_molecule_calls) DMX_TRY(build_snp_groups(c, keys, idx, d_cp, m));
     if (m) {
         size_t bytes = 0;
         const unsigned end_bit = 32 + bits_for(V ? V - 1 : 0);

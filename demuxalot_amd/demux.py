@@ -16,6 +16,8 @@ What runs where
   GPU (HIP):  beta -> probability normalisation                -> demux.py:267-274
               per-barcode log-likelihood accumulation + softmax -> demux.py:246-265, :101, :152
               squared-posterior beta update (+ RCCL all-reduce) -> demux.py:113-118
+  GPU (HIP):  Demultiplexer.aggregate_on_snps = True: per-(barcode, SNP) regularised E-step over the molecule
+              calls and the float64 M-step that follows it                   -> demux.py:204-244
 There is no CPU fallback for the GPU steps.
 """
 from typing import Dict, Tuple
@@ -308,7 +310,6 @@ class Demultiplexer:
         :param on_device: (not in the reference) leave the posteriors on the GPU and return a DevicePosteriors
             in place of the DataFrame.
         """
-        Demultiplexer._check_not_aggregating()
         assert 0 <= doublet_prior < 1
         n_genotypes = genotypes.n_genotypes
         penalties = Demultiplexer._doublet_penalties(n_genotypes, doublet_prior)
@@ -317,6 +318,12 @@ class Demultiplexer:
         assert n_iterations >= 1, 'n_iterations should be positive'  # the reference fails to unpack an empty run
 
         column_names = _option_names(genotypes.genotype_names, doublet_prior)
+        if Demultiplexer.aggregate_on_snps:  # the staged loop is the implementation (float64 posteriors, no fused driver)
+            assert not on_device, 'on_device results are float32; aggregate_on_snps yields float64 posteriors'
+            *_, (probs_df, last) = Demultiplexer.staged_genotype_learning(
+                chromosome2compressed_snp_calls, genotypes, barcode_handler, n_iterations=n_iterations,
+                p_genotype_clip=p_genotype_clip, doublet_prior=doublet_prior, barcode_prior_logits=barcode_prior_logits)
+            return genotypes._with_betas(genotypes.get_betas() + last['genotype_addition']), probs_df
         if on_device:
             ctx = DeviceContext(default_device())
             try:
@@ -355,15 +362,16 @@ class Demultiplexer:
         addition is the one the iteration's E-step used.
         The EM state lives on the GPU between yields, in a device context private to this generator: like the
         reference's (pure) generator it is unaffected by other Demultiplexer calls made between iterations."""
-        Demultiplexer._check_not_aggregating()
         assert 0 <= doublet_prior < 1
         n_genotypes = genotypes.n_genotypes
         penalties = Demultiplexer._doublet_penalties(n_genotypes, doublet_prior)
         if barcode_prior_logits is not None:
             assert barcode_prior_logits.shape == (barcode_handler.n_barcodes, len(penalties)), 'wrong shape of priors'
+        aggregate = bool(Demultiplexer.aggregate_on_snps)  # read once, like the other class-level knobs of a run
 
         ctx = DeviceContext(default_device())
         try:
+            ctx.set_keep_molecule_calls(aggregate)
             _ctx, prior_betas = _pack_on_device(chromosome2compressed_snp_calls, genotypes, barcode_handler.n_barcodes,
                                                 True, ctx=ctx)
             column_names = _option_names(genotypes.genotype_names, doublet_prior)
@@ -373,6 +381,17 @@ class Demultiplexer:
             for iteration in range(n_iterations):
                 ctx.probs_from_betas(p_genotype_clip, fetch=False)
                 prior = barcode_prior_logits if iteration == 0 else None
+                if aggregate:  # demux.py:204-244: float64 logits / posteriors, float64 M-step
+                    logits, probs = ctx.estep_snp(doublet_prior != 0, Demultiplexer.compensation_during_computing_barcode_logits,
+                                                  prior_logits=prior)
+                    probs_df = pd.DataFrame(data=probs, index=barcode_handler.ordered_barcodes, columns=column_names)
+                    yield probs_df, {
+                        'barcode_logits': logits,
+                        'genotype_prior': prior_betas,
+                        'genotype_addition': genotype_addition,
+                    }
+                    genotype_addition = ctx.mstep_f64(Demultiplexer.contribution_power)
+                    continue
                 logits, probs = ctx.estep(penalties, with_doublets=doublet_prior != 0, prior_logits=prior)
                 probs_df = pd.DataFrame(data=probs, index=barcode_handler.ordered_barcodes, columns=column_names)
                 yield probs_df, {
@@ -395,16 +414,23 @@ class Demultiplexer:
         barcode_handler.ordered_barcodes order, index named 'BARCODE'.
         :param on_device: (not in the reference) keep logits and posteriors on the GPU and return ONE
             DevicePosteriors object (assignments / top options / column sums are then computed there)."""
-        Demultiplexer._check_not_aggregating()
         penalties = Demultiplexer._doublet_penalties(genotypes.n_genotypes, doublet_prior)
         column_names = _option_names(genotypes.genotype_names, doublet_prior)
+        aggregate = bool(Demultiplexer.aggregate_on_snps)
+        assert not (aggregate and on_device), 'on_device results are float32; aggregate_on_snps yields float64 posteriors'
 
         def run(ctx, fetch):
-            _pack_on_device(chromosome2compressed_snp_calls, genotypes, barcode_handler.n_barcodes, False,
-                            fetch_betas=False, ctx=ctx)
+            ctx.set_keep_molecule_calls(aggregate)
+            try:
+                _pack_on_device(chromosome2compressed_snp_calls, genotypes, barcode_handler.n_barcodes, False,
+                                fetch_betas=False, ctx=ctx)
+            finally:
+                ctx.set_keep_molecule_calls(False)
             ctx.set_addition(None)
             genotype_prob = ctx.probs_from_betas(p_genotype_clip)
             assert np.isfinite(genotype_prob).all()
+            if aggregate:  # demux.py:204-244
+                return ctx.estep_snp(doublet_prior != 0, Demultiplexer.compensation_during_computing_barcode_logits)
             return ctx.estep(penalties, with_doublets=doublet_prior != 0, fetch_logits=fetch, fetch_probs=fetch)
 
         if on_device:
@@ -458,11 +484,26 @@ class Demultiplexer:
     @staticmethod
     def compute_barcode_logits(genotype_names, barcode_calls, molecule_calls, doublet_prior: float,
                                genotype_prob: np.ndarray, n_barcodes: int, n_genotypes: int):
-        """Dispatcher of demux.py:193-202."""
-        Demultiplexer._check_not_aggregating()
-        return Demultiplexer.compute_barcode_logits_using_barcode_calls(
-            genotype_names, barcode_calls=barcode_calls, doublet_prior=doublet_prior,
-            genotype_prob=genotype_prob, n_barcodes=n_barcodes, n_genotypes=n_genotypes)
+        """Dispatcher of demux.py:193-202; with Demultiplexer.aggregate_on_snps the per-(barcode, SNP)
+        regularised form of demux.py:204-244 over `molecule_calls` (float64 logits)."""
+        if not Demultiplexer.aggregate_on_snps:
+            return Demultiplexer.compute_barcode_logits_using_barcode_calls(
+                genotype_names, barcode_calls=barcode_calls, doublet_prior=doublet_prior,
+                genotype_prob=genotype_prob, n_barcodes=n_barcodes, n_genotypes=n_genotypes)
+        genotype_prob = np.asarray(genotype_prob)
+        assert genotype_prob.shape[1] == n_genotypes == len(genotype_names)
+        n_variants = genotype_prob.shape[0]
+        # SNP of every variant, from the molecule calls themselves (snp_id is a function of variant_id)
+        v2snp = np.arange(n_variants, dtype=np.int32) + (int(np.max(molecule_calls['snp_id'])) + 1 if len(molecule_calls) else 0)
+        v2snp[np.asarray(molecule_calls['variant_id'])] = molecule_calls['snp_id']
+        with shared_context_lock:
+            ctx = get_context()
+            empty_i = np.zeros(0, dtype=np.int32)
+            ctx.set_problem(n_barcodes, n_variants, n_genotypes, empty_i, empty_i, np.zeros(0, dtype=np.float32), v2snp)
+            ctx.set_probs(genotype_prob)
+            ctx.set_molecule_calls(molecule_calls['variant_id'], molecule_calls['compressed_cb'], molecule_calls['p_base_wrong'])
+            logits, _ = ctx.estep_snp(doublet_prior != 0, Demultiplexer.compensation_during_computing_barcode_logits)
+        return logits, _option_names(genotype_names, doublet_prior)
 
     @staticmethod
     def compute_barcode_logits_using_barcode_calls(genotype_names, barcode_calls, doublet_prior,
@@ -553,11 +594,3 @@ class Demultiplexer:
             packed.molecule_calls,
             _prepacked=(packed.variant_id, packed.compressed_cb, packed.p_base_wrong, packed.variant_count))
         return packed.v2snp, packed.betas, packed.molecule_calls, barcode_calls
-
-    # ------------------------------------------------------------------------------------
-    @staticmethod
-    def _check_not_aggregating():
-        if Demultiplexer.aggregate_on_snps:
-            raise NotImplementedError(
-                'aggregate_on_snps=True (demux.py:204-244, off by default and slated for removal in the '
-                'reference) is not part of the MI355X hot path')

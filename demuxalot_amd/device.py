@@ -240,6 +240,37 @@ class DeviceContext:
         check(self._lib.dmx_get_assignments(self._h, ptr(best), ptr(prob)))
         return best, prob
 
+    # ---- aggregate_on_snps (demux.py:204-244) --------------------------------------------------------
+    def set_keep_molecule_calls(self, keep):
+        check(self._lib.dmx_set_keep_molecule_calls(self._h, int(bool(keep))))
+
+    def set_molecule_calls(self, variant_id, compressed_cb, p_base_wrong):
+        variant_id, compressed_cb = as_c(variant_id, np.int32), as_c(compressed_cb, np.int32)
+        p_base_wrong = as_c(p_base_wrong, np.float32)
+        assert len(variant_id) == len(compressed_cb) == len(p_base_wrong)
+        check(self._lib.dmx_set_molecule_calls(self._h, len(variant_id), ptr(variant_id), ptr(compressed_cb), ptr(p_base_wrong)))
+
+    def estep_snp(self, with_doublets, compensation, prior_logits=None):
+        """E-step of aggregate_on_snps: (logits float64[B, K], posteriors float64[B, K])."""
+        K = self._n_options(with_doublets)
+        n = ctypes.c_int64(0)
+        check(self._lib.dmx_get_max_pair_count(self._h, ctypes.byref(n)))
+        # `counts[:, None] ** compensation` of demux.py:232 for every count that occurs, evaluated by numpy itself
+        # on an int64 array like the reference's, so that its pow() is repeated to the last bit
+        count_pow = np.ascontiguousarray(np.arange(n.value + 1, dtype=np.int64) ** compensation, dtype=np.float64)
+        prior, prior_dtype = self._prior_arg(prior_logits, (self.B, K))
+        logits = np.empty((self.B, K), dtype=np.float64)
+        probs = np.empty((self.B, K), dtype=np.float64)
+        check(self._lib.dmx_estep_snp(self._h, int(with_doublets), ptr(count_pow), len(count_pow), ptr(prior), prior_dtype,
+                                      ptr(logits), ptr(probs)))
+        self.K = K
+        return logits, probs
+
+    def mstep_f64(self, contribution_power=2.):
+        out = np.empty((self.V, self.G), dtype=np.float32)
+        check(self._lib.dmx_mstep_f64(self._h, float(contribution_power), ptr(out)))
+        return out
+
     def get_assignments_above(self, threshold):
         """(best option or -1 where the row maximum is not > threshold, row maximum, number assigned)."""
         best = np.empty(self.B, dtype=np.int32)

@@ -251,6 +251,34 @@ int dmx_get_top_options(dmx_ctx *ctx, int32_t k, int32_t *options, float *probs)
 int dmx_get_option_sums(dmx_ctx *ctx, double *sums);
 
 /* ------------------------------------------------------------------------- *
+ * The alternative E-step of the reference, Demultiplexer.aggregate_on_snps = True (demux.py:204-244): likelihoods
+ * are summed per (barcode, SNP) pair over the MOLECULE calls (not the de-duplicated barcode calls), divided by
+ * count ** compensation, passed through log_softmax, mixed with a 1 % "bad SNP" floor (np.logaddexp, float64 from
+ * here on), log_softmax again, and summed per barcode.  Logits and posteriors are float64, as the reference's are;
+ * the doublet penalties are not applied (the reference computes and then ignores them in this mode).
+ *   dmx_set_keep_molecule_calls  before dmx_pack_and_set_problem / dmx_pack_containers_and_set_problem: keep the
+ *                                matched molecule calls on the device, grouped by (barcode, SNP)
+ *   dmx_set_molecule_calls       the same from caller-supplied matched molecule calls (pack_calls' molecule_calls
+ *                                columns variant_id / compressed_cb / p_base_wrong, in their order)
+ *   dmx_get_max_pair_count       most molecule calls in one pair (length of the table below, minus one)
+ *   dmx_estep_snp                count_pow[c] = c ** compensation_during_computing_barcode_logits as numpy evaluates
+ *                                `counts ** 0.5` for an int64 array (the caller builds the table with numpy so that
+ *                                the reference's pow() rounding is repeated exactly); prior_logits (nullable) are
+ *                                added to the float64 logits before the softmax (demux.py:97-99)
+ *   dmx_mstep_f64                demux.py:113-118 on those float64 posteriors (the products and powers are float64 in
+ *                                the reference when the posteriors are); single GPU
+ * Everything up to the first log_softmax is float32 and bit-identical to numpy; the float64 part agrees with the
+ * reference to a few ulps (numpy's float64 exp / log1p are its own SIMD kernels or libm, depending on the host).
+ * Supported up to 1024 options. */
+int dmx_set_keep_molecule_calls(dmx_ctx *ctx, int keep);
+int dmx_set_molecule_calls(dmx_ctx *ctx, int64_t n, const int32_t *variant_id, const int32_t *compressed_cb,
+                           const float *p_base_wrong);
+int dmx_get_max_pair_count(dmx_ctx *ctx, int64_t *max_count);
+int dmx_estep_snp(dmx_ctx *ctx, int with_doublets, const double *count_pow, int64_t n_count_pow,
+                  const void *prior_logits, int prior_dtype, double *logits_out, double *probs_out);
+int dmx_mstep_f64(dmx_ctx *ctx, double contribution_power, float *addition_out);
+
+/* ------------------------------------------------------------------------- *
  * Multi-GPU: one ctx per rank, barcodes sharded by the caller (every rank holds the calls of its barcodes, all
  * variants, the whole beta table).  E-step rows need nothing from other ranks; the M-step sums over barcodes, so
  * the per-rank sums are exchanged once per EM iteration, inside dmx_mstep / dmx_probs_from_betas / dmx_em:

@@ -286,3 +286,68 @@ def predict(packed, n_barcodes, p_clip, doublet_prior, impl='numpy'):
     logits = barcode_logits(packed['variant_id'], packed['compressed_cb'], packed['p_base_wrong'], prob,
                             n_barcodes, doublet_prior, log_impl=impl)
     return logits, softmax_rows(logits, impl=impl), prob
+
+
+# --------------------------------------------------------------------------- #
+# Demultiplexer.aggregate_on_snps = True  (reference demux.py:204-244)
+# --------------------------------------------------------------------------- #
+
+def barcode_logits_aggregated(mol_variant, mol_cb, mol_p, v2snp, prob, n_barcodes, doublet_prior, compensation=0.5):
+    """reference demux.py:212-242: per (barcode, SNP) pair, float64 sums over the MOLECULE calls of
+    log(p_k[variant] + p_base_wrong) (float32 terms), divided by count ** compensation, log_softmax (float32),
+    logaddexp with log(0.01 / K) (float64 from there on), log_softmax, summed per barcode.  float64 [B, K];
+    the doublet penalties are not applied (the reference computes them and uses only their length)."""
+    n_genotypes = prob.shape[1]
+    g1, g2 = option_pairs(n_genotypes, doublet_prior)
+    n_options = len(g1)
+    snp = v2snp[mol_variant]
+    # FeatureLookup(compressed_cb, snp_id): dense ids of the (barcode, SNP) pairs, sorted by barcode then SNP
+    key = mol_cb.astype(np.int64) * (int(snp.max()) + 1 if len(snp) else 1) + snp
+    pairs, pair_of_call = np.unique(key, return_inverse=True)
+    counts = np.bincount(pair_of_call, minlength=len(pairs))
+    pair_barcode = (pairs // (int(snp.max()) + 1 if len(snp) else 1)).astype(np.int64)
+    pair_logits = np.zeros([len(pairs), n_options], dtype='float32')
+    for k, (a, b) in enumerate(zip(g1, g2)):
+        col = prob[:, a] if a == b else (prob[:, a] + prob[:, b]) * 0.5
+        terms = np.log(col[mol_variant] + mol_p)
+        pair_logits[:, k] = pair_logits[:, k] + np.bincount(pair_of_call, weights=terms, minlength=len(pairs))
+    pair_logits /= counts[:, None] ** compensation
+
+    def log_softmax_rows(x):  # scipy.special.log_softmax(x, axis=1)
+        top = np.amax(x, axis=1, keepdims=True)
+        top[~np.isfinite(top)] = 0
+        shifted = x - top
+        with np.errstate(divide='ignore'):
+            return shifted - np.log(np.sum(np.exp(shifted), axis=1, keepdims=True))
+
+    pair_logits = log_softmax_rows(pair_logits)
+    pair_logits = np.logaddexp(pair_logits, np.log(0.01 / n_options))
+    pair_logits = log_softmax_rows(pair_logits)
+    return np.stack([np.bincount(pair_barcode, weights=col, minlength=n_barcodes) for col in pair_logits.T], axis=1)
+
+
+def em_aggregated(packed, n_barcodes, n_iterations, p_clip, doublet_prior, prior_logits=None, power=2., compensation=0.5):
+    """reference demux.py:86-118 with aggregate_on_snps: float64 logits / posteriors, and therefore float64
+    products in the M-step (float64 posterior * float32 (1 - e))."""
+    v, cb, e = packed['variant_id'], packed['compressed_cb'], packed['p_base_wrong']
+    betas, v2snp = packed['betas'], packed['v2snp']
+    n_variants, n_genotypes = betas.shape
+    addition = np.zeros_like(betas)
+    history = []
+    for it in range(n_iterations):
+        prob = probs_from_betas(v2snp, betas + addition, p_clip)
+        logits = barcode_logits_aggregated(packed['mol_variant'], packed['mol_cb'], packed['mol_p'], v2snp, prob,
+                                           n_barcodes, doublet_prior, compensation)
+        if it == 0 and prior_logits is not None:
+            logits += prior_logits
+        top = np.amax(logits, axis=-1, keepdims=True)
+        shifted = np.exp(logits - top)
+        post = shifted / np.sum(shifted, axis=-1, keepdims=True)
+        history.append(dict(logits=logits, probs=post, addition=addition))
+        addition = np.zeros_like(betas)
+        keep = 1 - e
+        for g in range(n_genotypes):
+            w = post[cb, g] * keep
+            w **= power
+            addition[:, g] = addition[:, g] + np.bincount(v, weights=w, minlength=n_variants)
+    return history

@@ -202,12 +202,6 @@ def test_front_end_asserts_like_reference():
         Demultiplexer.predict_posteriors(calls, genotypes, handler, doublet_prior=1.0)
     with pytest.raises(AssertionError, match='wrong shape of priors'):
         Demultiplexer.learn_genotypes(calls, genotypes, handler, barcode_prior_logits=np.zeros((3, 3), dtype='float32'))
-    Demultiplexer.aggregate_on_snps = True
-    try:
-        with pytest.raises(NotImplementedError):
-            Demultiplexer.predict_posteriors(calls, genotypes, handler)
-    finally:
-        Demultiplexer.aggregate_on_snps = False
 
 
 # ---- unit entry points on caller-supplied tables vs the oracle -------------------------------

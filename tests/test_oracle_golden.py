@@ -92,3 +92,27 @@ def test_em_from_assignment(oracle):
         assert_bitwise(rec['logits'], out[f'em0_it{it}_logits'], f'it {it} logits')
         assert_bitwise(rec['probs'], out[f'em0_it{it}_probs'], f'it {it} probs')
         assert_bitwise(rec['addition'], out[f'em0_it{it}_addition'], f'it {it} addition')
+
+
+@pytest.mark.parametrize('name', ['f7_aggregate_small_2.npz', 'f7_aggregate_small_4.npz', 'f7_aggregate_synthetic_g4.npz'])
+def test_oracle_aggregate_on_snps_matches_reference(oracle, name):
+    """Demultiplexer.aggregate_on_snps = True (demux.py:204-244): the restatement against the reference's captured
+    float64 logits / posteriors and float32 additions, bit for bit (same numpy, same machine class)."""
+    out = fio.load(name)
+    fx = fio.load(str(out['inputs_of']))
+    n_barcodes = len(fx['barcodes'])
+    for i in range(int(out['n_predict'])):
+        packed = oracle.pack(fio.oracle_calls(fx), fio.oracle_geno(fx), add_data_prior=False)
+        prob = oracle.probs_from_betas(packed['v2snp'], packed['betas'], 0.01)
+        logits = oracle.barcode_logits_aggregated(packed['mol_variant'], packed['mol_cb'], packed['mol_p'], packed['v2snp'],
+                                                  prob, n_barcodes, float(out[f'predict{i}_dp']))
+        fio.assert_bitwise(logits, out[f'predict{i}_logits'], f'{name} predict {i} logits')
+    packed = oracle.pack(fio.oracle_calls(fx), fio.oracle_geno(fx), add_data_prior=True)
+    for i in range(int(out['n_em'])):
+        n_it = int(out[f'em{i}_n_iterations'])
+        prior = out.get(f'em{i}_prior_logits')
+        hist = oracle.em_aggregated(packed, n_barcodes, n_it, 0.01, float(out[f'em{i}_dp']), prior_logits=prior)
+        for it in range(n_it):
+            fio.assert_bitwise(hist[it]['logits'], out[f'em{i}_it{it}_logits'], f'{name} run {i} it {it} logits')
+            fio.assert_bitwise(hist[it]['probs'], out[f'em{i}_it{it}_probs'], f'{name} run {i} it {it} probs')
+            fio.assert_bitwise(hist[it]['addition'], out[f'em{i}_it{it}_addition'], f'{name} run {i} it {it} addition')
