@@ -84,6 +84,41 @@ def cpu_baseline(problem, betas, doublet_prior, target_seconds=15.0):
                 host_cores=os.cpu_count()), logits, post, n_sample
 
 
+# VALU issue model of the exact-mode E-step term (direct kernels, K <= 1024), from the instruction count of
+# estep_terms + log_f32_hot2 per two terms (17 packed float32, 4 plain integer, 2 v_cvt_f32_i32, 2 v_mad_i32_i24,
+# 2 v_rcp_f32, 2 v_cvt_f64_f32, 2 v_add_f64) and the issue costs measured by scripts/valu_issue_bench.hip on this
+# chip with >= 2 waves per SIMD (profiles/r2_valu_issue_bench.txt): plain 2.4 cycles, packed float32 / float64 /
+# conversions / v_mad_i32_i24 4.4, transcendental 8.3.
+VALU_CYCLES_PER_TERM = (17 * 4.4 + 4 * 2.4 + 2 * 4.4 + 2 * 4.4 + 2 * 8.3 + 2 * 4.4 + 2 * 4.4) / 2
+N_SIMD, PEAK_CLOCK_HZ = 1024, 2.4e9
+
+
+def roofline(workload, ab, e_ms, m_ms, timers, N, G, K):
+    """The contract's HBM figures for the dominant kernel (the E-step) on ALGORITHMIC bytes, plus what actually binds
+    it: VALU issue of the N*K numpy-exact float32 log terms."""
+    achieved = ab['estep'] / (e_ms * 1e-3) / 1e9
+    per_launch = lambda name: timers[name]['ms'] / max(1, timers[name]['launches'])
+    terms_per_s = N * K / (e_ms * 1e-3)
+    peak_terms = N_SIMD * PEAK_CLOCK_HZ * 64 / VALU_CYCLES_PER_TERM
+    kernel = 'k_estep_direct' if K <= 1024 else 'k_estep_block'
+    return {
+        'bound': 'valu-issue',
+        'kernel': kernel, 'achieved': achieved, 'peak': 8000.0, 'unit': 'GB/s', 'frac': achieved / 8000.0,
+        'traffic': measured_traffic(workload, kernel),
+        'algorithmic_bytes_per_launch': ab['estep'],
+        'iteration_bytes': ab['iteration'],
+        'iteration_frac': ab['iteration'] / (1e-3 * (e_ms + m_ms + per_launch('pstep') + per_launch('mcombine'))) / 1e9 / 8000.0,
+        'delivered_gather_GBps': (N * 4 * G) / (e_ms * 1e-3) / 1e9,
+        'valu': {'log_terms_per_s': terms_per_s, 'peak_terms_per_s': peak_terms, 'frac': terms_per_s / peak_terms,
+                 'cycles_per_term_model': VALU_CYCLES_PER_TERM,
+                 'note': 'exact-mode term = numpy float32 log repeated operation for operation + float64 accumulate; issue costs '
+                         'from profiles/r2_valu_issue_bench.txt; peak at the nominal 2.4 GHz (the kernel sustains ~2.0-2.1 GHz); '
+                         'K > 1024 (k_estep_block) adds two LDS reads per term pair'},
+        'note': 'frac is the HBM fraction the contract asks for (algorithmic bytes / time / 8 TB/s); the kernel is bound by '
+                'VALU issue (valu.frac), not by HBM: see DESIGN.md 4',
+    }
+
+
 def measured_traffic(workload, kernel):
     """HBM-side bytes per launch from the rocprofv3 PMC passes committed under profiles/ (FETCH_SIZE +
     WRITE_SIZE, see profiles/README.md); None when no profile of this workload/kernel is recorded."""
@@ -111,6 +146,10 @@ def main():
                     help='weak: the workload per GPU; strong: the workload in total, barcodes sharded over the GPUs')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-fast-mode', action='store_true', help='skip the second timed region (tolerance-mode E-step)')
+    ap.add_argument('--flat-genotypes', action='store_true',
+                    help='worst case of the M-step: all-equal betas, so every posterior is 1/G and every call contributes to '
+                         'every genotype (the start-from-assignment scenario of tests/test_synthetic.py:200-239 before any label '
+                         'is used); the additions are then equal for all genotypes, so the posteriors stay uniform iteration after iteration')
     ap.add_argument('--force-dist', action='store_true',
                     help='testing aid: run the multi-rank control/collective path even with one rank')
     args = ap.parse_args()
@@ -156,6 +195,8 @@ def main():
         problem = synth.generate(B, S, G, doublets=dp > 0, seed=seed, seed_calls=seed * 1000 + rank)
         betas = problem.prior_betas(add_data_prior=False)  # identical on every rank
         B_total = B * world
+    if args.flat_genotypes:
+        betas = np.ones_like(betas)
     t_gen = time.perf_counter() - t_gen
     V, N = problem.n_variants, problem.n_calls
     pen = Demultiplexer._doublet_penalties(G, dp)
@@ -266,19 +307,7 @@ def main():
             'predict_barcodes_per_s': B_total / predict_s,
             'kernel_ms': {k: (v['ms'] / max(1, v['launches'])) for k, v in timers.items()},
             'exchange_ms_per_step': timers['allreduce']['ms'] / max(1, args.steps),
-            'roofline': {'bound': 'hbm', 'kernel': 'k_estep_direct' if K <= 256 else 'k_estep_block', 'achieved': achieved, 'peak': 8000.0, 'unit': 'GB/s',
-                         'frac': achieved / 8000.0, 'traffic': measured_traffic(args.workload, 'k_estep_direct'),
-                         'algorithmic_bytes_per_launch': ab['estep'],
-                         'iteration_bytes': ab['iteration'],
-                         'iteration_frac': ab['iteration'] / (1e-3 * (e_ms + m_ms + timers['pstep']['ms'] / max(1, timers['pstep']['launches']) + timers['mcombine']['ms'] / max(1, timers['mcombine']['launches']))) / 1e9 / 8000.0,
-                         'log_terms_per_s': N * K / (e_ms * 1e-3),
-                         'delivered_gather_GBps': (N * 4 * G) / (e_ms * 1e-3) / 1e9,
-                         # VALU-issue view (what actually binds the kernel): 16.0 VALU instructions per 64-lane
-                         # term row (ISA count, confirmed by SQ_INSTS_VALU in profiles/), ~4 issue cycles each,
-                         # 1024 SIMDs at the 2.4 GHz peak clock
-                         'valu_issue_frac': (N * max(1, (K + 63) // 64) * 16.0 * 4) / (1024 * 2.4e9 * e_ms * 1e-3) if K <= 256 else None,
-                         'note': 'the E-step is bound by VALU issue of N*K numpy-exact float32 log terms and by the '
-                                 'indexed row gather from L2/Infinity Cache (N*4G delivered bytes), not by HBM: see DESIGN.md 4'},
+            'roofline': roofline(args.workload, ab, e_ms, m_ms, timers, N, G, K),
             'setup_s': {'generate': t_gen, 'upload': t_up},
             'fast_mode': fast,
         }

@@ -173,6 +173,8 @@ void release_problem(dmx_ctx *c)
     c->cap_bk = 0;
     dev_free(c, &c->d_nz, (size_t)c->B * ((c->G + 63) / 64));
     dev_free(c, &c->d_first, (size_t)c->B);
+    dev_free(c, &c->d_dense_calls, (size_t)1 + dmx::DENSE_SLOTS);
+    c->dense_stat_valid = false;
     dev_free(c, &c->d_pen, (size_t)c->cap_k);
     dev_free(c, &c->d_pairs, (size_t)c->cap_k);
     c->cap_k = 0;
@@ -453,6 +455,9 @@ int run_estep(dmx_ctx *c, int with_doublets, bool with_prior, int prior_dtype, f
     a.post = c->d_post;
     a.nz = c->d_nz;
     a.first = c->G <= 64 ? c->d_first : nullptr;
+    a.dense_calls = c->G <= 64 ? c->d_dense_calls : nullptr;
+    if (a.dense_calls) HIP_TRY(hipMemsetAsync(c->d_dense_calls, 0, sizeof(unsigned long long) * (1 + dmx::DENSE_SLOTS), c->stream));
+    c->dense_stat_valid = a.dense_calls != nullptr;
     a.nz_floor = power == 2.0f ? dmx::NZ_FLOOR_SQUARE : 0.0f;
     c->nz_floor = a.nz_floor;
     a.B = c->B;
@@ -470,6 +475,7 @@ int run_estep(dmx_ctx *c, int with_doublets, bool with_prior, int prior_dtype, f
     std::pair<hipEvent_t, hipEvent_t> ev;
     timer_begin(c, DMX_T_ESTEP, &ev);
     HIP_TRY(dmx::launch_estep(c->stream, a, with_doublets != 0));
+    if (a.dense_calls) HIP_TRY(dmx::launch_sum_dense(c->stream, c->d_dense_calls));
     timer_end(c, DMX_T_ESTEP, ev);
     c->have_post = true;
     return 0;
@@ -492,6 +498,8 @@ int run_mstep(dmx_ctx *c, float power)
     a.G = c->G;
     a.square = (power == 2.0f);
     a.power = power;
+    a.dense_calls = c->dense_stat_valid && a.post_bytes < (1ull << 32) ? c->d_dense_calls : nullptr;
+    a.total_calls = 2ull * (unsigned long long)c->n_pairs;
     if (!a.square && c->nz_floor != 0.0f) {
         // the E-step assumed a squaring M-step: rebuild the bitmap with the exact `!= 0` rule
         HIP_TRY(dmx::launch_rebuild_nz(c->stream, c->d_post, c->B, c->K, c->G, 0.0f, c->d_nz,
@@ -671,6 +679,7 @@ static int finish_problem(dmx_ctx *c, const int32_t *v2snp, const std::vector<in
     DMX_TRY(dev_alloc(c, &c->d_n_redo, (size_t)1));
     DMX_TRY(dev_alloc(c, &c->d_nz, (size_t)B * ((G + 63) / 64)));
     DMX_TRY(dev_alloc(c, &c->d_first, (size_t)B));
+    DMX_TRY(dev_alloc(c, &c->d_dense_calls, (size_t)1 + dmx::DENSE_SLOTS));
     DMX_TRY(dev_alloc(c, &c->d_best, (size_t)B));
     DMX_TRY(dev_alloc(c, &c->d_bestp, (size_t)B));
     hipStream_t st = c->stream;

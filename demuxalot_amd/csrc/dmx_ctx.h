@@ -71,6 +71,8 @@ struct dmx_ctx {
     int tiled_estep = 1;               // dmx_set_estep_schedule: 0 never, 1 when it pays, 2 whenever the repack built one
     float nz_floor = 0.0f;     // threshold the current d_nz / d_first were built with
     float *d_first = nullptr;  // [B] posterior of the lowest non-zero singlet column (G <= 64)
+    unsigned long long *d_dense_calls = nullptr;  // [1] E-step statistic read by the M-step kernels (kernels.h)
+    bool dense_stat_valid = false;
     long long cap_bk = 0;
     float *d_pen = nullptr;
     unsigned *d_pairs = nullptr;

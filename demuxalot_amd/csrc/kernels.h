@@ -35,6 +35,8 @@ struct EstepArgs {
     unsigned long long *nz;     // [B, ceil(G/64)] bit g set <=> !(post[b, g] <= nz_floor) (singlet columns; read by the M-step)
     float *first;               // nullable [B]: post[b, lowest set bit of nz[b]] (G <= 64; read by the M-step)
     float nz_floor;             // 0, or NZ_FLOOR_SQUARE when the M-step squares (see below)
+    unsigned long long *dense_calls;  // nullable [1 + DENSE_SLOTS]: slot 1 + (b % DENSE_SLOTS) += (padded) calls of every
+                                      // barcode b with more than 4 live posteriors (G <= 64); slot 0: their sum (launch_sum_dense)
     long long B;
     unsigned prob_bytes;        // V * G * 4 (< 4 GiB): extent of the prob table for buffer addressing
     int G;
@@ -51,6 +53,8 @@ struct EstepArgs {
                                   // group's first pair = the slot (accumulator) the group belongs to
 };
 
+constexpr int DENSE_SLOTS = 1024;            // hashed counters of the dense-call statistic
+hipError_t launch_sum_dense(hipStream_t st, unsigned long long *counters);
 constexpr int TILE_R_MAX = 9;                // barcodes per bin at most (LDS: 4 waves x 9 x 64 doubles = 18 KB per block)
 constexpr long long TILE_BYTES = 2 << 20;    // genotype-table bytes per variant tile (half of an XCD's 4 MB L2)
 constexpr long long TILE_MIN_BARCODES = 65536;   // below this there are too few bins to fill the chip
@@ -71,6 +75,11 @@ struct MstepArgs {
     int G;
     int square;   // contribution_power == 2
     float power;  // otherwise
+    // G <= 64: statistic of the last E-step (EstepArgs::dense_calls) and the number of (padded) E-step calls; the
+    // call-parallel kernel runs when few calls are dense, the dense kernel otherwise.  dense_calls == nullptr (or a
+    // posterior table beyond 4 GiB): always the call-parallel kernel.
+    const unsigned long long *dense_calls;
+    unsigned long long total_calls;
 };
 
 // A posterior p <= 2^-80 contributes (p * keep)^2 = +0 exactly for |keep| <= 32 (|p * keep| <= 2^-75, and a

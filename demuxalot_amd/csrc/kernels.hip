@@ -415,7 +415,8 @@ static __device__ __forceinline__ void fast_walk_single(const CallPair *__restri
 // acc[s] = float64 sum of the log terms of option kk[s] of barcode b (one lane group of L lanes per barcode).
 template <int L, int A>
 static __device__ __forceinline__ void estep_epilogue(const EstepArgs &a, long long b, bool live, const double (&acc)[A],
-                                                      const int (&kk)[A], const bool (&valid)[A], int lane, int li, int gbase)
+                                                      const int (&kk)[A], const bool (&valid)[A], int lane, int li, int gbase,
+                                                      int row_calls)
 {
     const int K = a.K;
     float lg[A], x[A];
@@ -459,6 +460,9 @@ static __device__ __forceinline__ void estep_epilogue(const EstepArgs &a, long l
             // the one posterior most barcodes have, in a table small enough to stay in L2 (M-step)
             const unsigned long long mine = L == 64 ? bal : ((bal >> gbase) & ((1ull << L) - 1ull));
             if (live && mine != 0ull && li == __builtin_ctzll(mine)) a.first[b] = post;
+            // statistic for the M-step's choice of kernel (G <= 64): calls whose barcode has more than 4 live posteriors
+            if (a.dense_calls && live && li == 0 && __popcll(mine) > 4)
+                atomicAdd(a.dense_calls + 1 + (b & (DENSE_SLOTS - 1)), (unsigned long long)row_calls);
         }
     }
 }
@@ -506,6 +510,7 @@ __global__ __launch_bounds__(256) void k_estep_direct(EstepArgs a)
 
     long long b;
     bool live;
+    int row_calls = 0;  // calls of this lane group's barcode (incl. padding)
     if constexpr (L == 64) {
         // ---- wave-uniform path: everything about the row lives in SGPRs ----
         const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
@@ -515,6 +520,7 @@ __global__ __launch_bounds__(256) void k_estep_direct(EstepArgs a)
         b = a.order[slot];
         const long long pbeg = a.pair_ptr[b];
         const int npairs = (int)(a.pair_ptr[b + 1] - pbeg);
+        row_calls = 2 * npairs;
         const CallPair *__restrict__ recs = a.pairs + pbeg;
         // buffer addressing: descriptor base = prob table, voffset = this lane's genotype (VGPR, fixed),
         // soffset = the call's row offset straight from the scalar load -> no VALU work per load
@@ -552,6 +558,7 @@ __global__ __launch_bounds__(256) void k_estep_direct(EstepArgs a)
         b = a.order[live ? slot : a.B - 1];
         const long long pbeg = a.pair_ptr[b];
         const int n = live ? 2 * (int)(a.pair_ptr[b + 1] - pbeg) : 0;  // calls incl. padding, multiple of 8
+        row_calls = n;
         const unsigned *__restrict__ words = (const unsigned *)(a.pairs + pbeg);
         const int nmax = group_max_over_wave<L>(n);
         for (int c0 = 0; c0 < nmax; c0 += L) {
@@ -603,7 +610,7 @@ __global__ __launch_bounds__(256) void k_estep_direct(EstepArgs a)
         for (int s = 0; s < A; s++) acc[s] = (facc[s].mant + (double)facc[s].expo) * LN2;
     }
 
-    estep_epilogue<L, A>(a, b, live, acc, kk, valid, lane, li, gbase);
+    estep_epilogue<L, A>(a, b, live, acc, kk, valid, lane, li, gbase, row_calls);
 }
 
 // ------------------------------------------------------------------------------------
@@ -728,7 +735,8 @@ __global__ __launch_bounds__(256) void k_estep_tiled(EstepArgs a)
             out[s] = sh_acc[wave][r][s][lane];
             if (FAST) out[s] *= 0.693147180559945309417232121458176568;
         }
-        estep_epilogue<64, A>(a, (long long)row, true, out, kk, valid, lane, lane, 0);
+        estep_epilogue<64, A>(a, (long long)row, true, out, kk, valid, lane, lane, 0,
+                              2 * (int)(a.pair_ptr[row + 1] - a.pair_ptr[row]));
     }
 }
 
@@ -885,7 +893,11 @@ __global__ __launch_bounds__(256) void k_estep_block(EstepArgs a, int C, int k_b
         if (s == 0) {  // singlet columns k < G <= 256 all live in slot 0: one bitmap word per wave
             const unsigned long long bal = __ballot(k < G && !(post <= a.nz_floor));
             if (lane == 0 && wave < W) a.nz[(size_t)b * W + wave] = bal;
-            if (a.first && wave == 0 && bal != 0ull && lane == __builtin_ctzll(bal)) a.first[b] = post;
+            if (a.first && wave == 0 && bal != 0ull && lane == __builtin_ctzll(bal)) {
+                a.first[b] = post;
+                if (a.dense_calls && __popcll(bal) > 4)
+                    atomicAdd(a.dense_calls + 1 + (b & (DENSE_SLOTS - 1)), (unsigned long long)n_calls);
+            }
         }
     }
 }
@@ -928,7 +940,11 @@ __global__ __launch_bounds__(256) void k_softmax_rows(EstepArgs a)
             const unsigned long long bal = __ballot(k < G && !(p <= a.nz_floor));
             const int word = (k0 >> 6) + wave;
             if (lane == 0 && word < W) a.nz[(size_t)b * W + word] = bal;
-            if (a.first && word == 0 && bal != 0ull && lane == __builtin_ctzll(bal)) a.first[b] = p;
+            if (a.first && word == 0 && bal != 0ull && lane == __builtin_ctzll(bal)) {
+                a.first[b] = p;
+                if (a.dense_calls && __popcll(bal) > 4)
+                    atomicAdd(a.dense_calls + 1 + (b & (DENSE_SLOTS - 1)), (unsigned long long)(2 * (a.pair_ptr[b + 1] - a.pair_ptr[b])));
+            }
         }
     }
 }
@@ -1070,9 +1086,91 @@ __global__ __launch_bounds__(256) void k_mstep(MstepArgs a)
 //     whole wavefront, lane g fetching post[cb_i, g] from the coalesced row.
 // The queues hold R entries; a chunk that could overflow them is processed R calls at a time.
 // ------------------------------------------------------------------------------------
+// counters[0] = sum of the DENSE_SLOTS hashed counters the E-step epilogues add to (one address would serialise
+// 200k atomics: +0.65 ms measured)
+__global__ __launch_bounds__(256) void k_sum_dense(unsigned long long *counters)
+{
+    __shared__ unsigned long long part[4];
+    unsigned long long s = 0;
+    for (int i = threadIdx.x; i < DENSE_SLOTS; i += 256) s += counters[1 + i];
+    for (int off = 32; off > 0; off >>= 1) {
+        const unsigned lo = __shfl_down((unsigned)s, off), hi = __shfl_down((unsigned)(s >> 32), off);
+        s += ((unsigned long long)hi << 32) | lo;
+    }
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) counters[0] = part[0] + part[1] + part[2] + part[3];
+}
+
+hipError_t launch_sum_dense(hipStream_t st, unsigned long long *counters)
+{
+    hipLaunchKernelGGL(k_sum_dense, dim3(1), dim3(256), 0, st, counters);
+    return hipGetLastError();
+}
+
+// Which of the two G <= 64 kernels runs is decided on the device, from the statistic the E-step left: both are
+// launched, one returns at once.  dense: more than a quarter of the (padded) calls belong to barcodes with more than
+// 4 live posteriors (uninformative genotypes, first iterations of a run that starts from barcode labels).
+static __device__ __forceinline__ bool dense_regime(const MstepArgs &a)
+{
+    return a.dense_calls != nullptr && 4ull * *a.dense_calls > a.total_calls;
+}
+
+// ------------------------------------------------------------------------------------
+// M-step, dense form (G <= 64, most posteriors alive): the call-parallel form below handles a call with more than 4
+// live posteriors one at a time through its queues (4.2 ms on 200k x 100k x 64 with uniform posteriors); here a
+// wavefront simply walks its work item in order, gathers the whole posterior row of every call (lane g = genotype g,
+// row offset as the buffer load's scalar offset), and adds (p keep)^2 in float64.  Posteriors at or below the
+// contribution floor add exactly +0, so the sums are bit-identical to the sparse form's.
+// ------------------------------------------------------------------------------------
+template <bool SQUARE>
+__global__ __launch_bounds__(256) void k_mstep_dense(MstepArgs a)
+{
+    if (!dense_regime(a)) return;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const long long slot = (long long)blockIdx.x * 4 + wave;
+    if (slot >= a.n_items) return;
+    const long long item = a.order[slot];
+    const int n = a.item_len[item];
+    const uint2 *__restrict__ calls = a.calls + a.item_start[item];
+    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void *)a.post, 0, (int)a.post_bytes, 0x00020000);
+    const unsigned row_bytes = (unsigned)a.K * 4u;
+    const unsigned voff = (unsigned)(lane < a.G ? lane : 0) * 4u;
+    double acc = 0.0;
+    auto records = [&](int c0) {
+        uint2 d = make_uint2(0u, 0u);  // padding: keep bits 0 -> (p * 0)^power = +0
+        if (c0 + lane < n) d = calls[c0 + lane];
+        return d;
+    };
+    uint2 d_cur = records(0);
+    for (int c0 = 0; c0 < n; c0 += 64) {
+        const uint2 d_nxt = records(c0 + 64);
+        const int cnt = (n - c0) < 64 ? (n - c0) : 64;
+        for (int i0 = 0; i0 < cnt; i0 += 8) {
+            float p[8];
+#pragma unroll
+            for (int u = 0; u < 8; u++) {
+                const unsigned cb = (unsigned)__builtin_amdgcn_readlane((int)d_cur.x, i0 + u);
+                p[u] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, (int)voff, (int)(cb * row_bytes), 0));
+            }
+#pragma unroll
+            for (int u = 0; u < 8; u++) {
+                const float keep = __builtin_bit_cast(float, __builtin_amdgcn_readlane((int)d_cur.y, i0 + u));
+                float c = p[u] * keep;
+                c = SQUARE ? c * c : powf(c, a.power);
+                acc += (double)c;
+            }
+        }
+        d_cur = d_nxt;
+    }
+    if (lane < a.G) a.partial[(size_t)item * a.G + lane] = acc;
+}
+
 template <bool SQUARE, int R, int D>
 __global__ __launch_bounds__(256) void k_mstep_calls(MstepArgs a)
 {
+    if (dense_regime(a)) return;
     constexpr int NZ_S = 4;  // "sparse" call: at most this many non-zero posteriors
     typedef unsigned long long u64;
     __shared__ float sh_val[4][R * 64];
@@ -1690,6 +1788,12 @@ hipError_t launch_mstep(hipStream_t st, const MstepArgs &a)
             hipLaunchKernelGGL((k_mstep_calls<true, 16, 4>), grid, dim3(256), 0, st, a);
         else
             hipLaunchKernelGGL((k_mstep_calls<false, 16, 4>), grid, dim3(256), 0, st, a);
+        if (a.dense_calls) {  // the dense regime's kernel; exactly one of the two does the work (dense_regime)
+            if (a.square)
+                hipLaunchKernelGGL((k_mstep_dense<true>), grid, dim3(256), 0, st, a);
+            else
+                hipLaunchKernelGGL((k_mstep_dense<false>), grid, dim3(256), 0, st, a);
+        }
         return hipGetLastError();
     }
     if (G <= 128) launch_m<2, 4>(st, a);

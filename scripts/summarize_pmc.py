@@ -18,7 +18,8 @@ def short(name):
 
 
 lines = []
-stats = glob.glob(os.path.join(root, 'gpurun_out', f'prof_{tag}_trace', '*', '*kernel_stats.csv'))
+stats = glob.glob(os.path.join(root, 'gpurun_out', f'prof_{tag}_trace', '*', '*kernel_stats.csv')) or \
+    glob.glob(os.path.join(root, 'gpurun_out', f'prof_{tag}_em_200k_100k_64', '*', '*kernel_stats.csv'))
 if stats:
     lines.append('== rocprofv3 --kernel-trace --stats (python3 bench.py --steps 10 --warmup 2 --no-cpu-baseline) ==')
     lines.append(open(stats[0]).read())

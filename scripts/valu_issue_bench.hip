@@ -8,8 +8,9 @@
 // (8 register chains, so dependent-issue latency never binds) between two s_memtime stamps.
 // Reported: shader cycles per wave-instruction PER SIMD = wave cycles / (w * instructions per wave),
 // median over the waves of the launch.  2.0 means the SIMD retires one wave64 instruction every 2
-// cycles (the 32-lane-per-cycle rate), 4.0 one every 4 cycles.  The last line of every block checks the
-// premise (all waves of a SIMD run side by side): `conc` = median wave duration / span of the launch in
+// cycles (the 32-lane-per-cycle rate), 4.0 one every 4 cycles.  In parentheses: the same from the whole launch
+// (first wave start to last wave end), an upper bound that does not depend on all waves running side by side.
+// The last line of every block checks that premise: `conc` = median wave duration / span of the launch in
 // s_memrealtime ticks, `clk` = the shader clock the waves saw.
 #include <hip/hip_runtime.h>
 
@@ -201,7 +202,7 @@ __global__ __launch_bounds__(256, 8) void k_issue(unsigned long long *cycles, fl
 template <int OP>
 static int run_one(unsigned long long *d_cycles, float *d_sink, int n_cu)
 {
-    const int iters = 400;
+    const int iters = 3000;
     int per_iter = 64;
     if (OP == MIX_E_STEP) per_iter = 62;
     printf("%-44s", NAMES[OP]);
@@ -226,9 +227,13 @@ static int run_one(unsigned long long *d_cycles, float *d_sink, int n_cu)
         std::sort(h.begin(), h.end());
         std::sort(dur.begin(), dur.end());
         const double med = (double)h[waves / 2];
-        printf("  w=%d: %6.2f", w, med / ((double)w * iters * per_iter));
+        const double clk = med / (double)dur[waves / 2];  // shader cycles per 100 MHz tick
+        // whole-launch figure: every SIMD retired w * iters * per_iter wave-instructions between the first start and the
+        // last end of the launch (upper bound of the cost: includes the ramp-up and the tail)
+        const double agg = (double)(last - first) * clk / ((double)w * iters * per_iter);
+        printf("  w=%d: %5.2f (%5.2f)", w, med / ((double)w * iters * per_iter), agg);
         pos += snprintf(check + pos, sizeof check - pos, "  w=%d: conc %.2f clk %.2f GHz", w, (double)dur[waves / 2] / (double)(last - first),
-                        med / (double)dur[waves / 2] * 0.1);
+                        clk * 0.1);
     }
     printf("   cycles per wave-instruction per SIMD\n%-44s%s\n", "", check);
     return 0;
