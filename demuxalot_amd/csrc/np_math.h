@@ -99,19 +99,17 @@ __device__ __forceinline__ f32x2 log_f32_hot2(f32x2 v)
     const float LN2 = 0.693147180559945309417232121458176568f;
     const int SPLIT = 0x3f3504f4;  // bits of the float32 just above 1/sqrt(2) (0x3f3504f3)
 
-    // x = m' * 2^k: k = floor((bits - SPLIT) / 2^23); m' = bits - k * 2^23 (one v_mad_i32_i24: |k| < 2^8)
+    // x = m' * 2^k with m' in (1/sqrt2, sqrt2]: d = bits - SPLIT = k * 2^23 + fraction, so the top 9 bits of d are
+    // k * 2^23 itself (as an integer), m' = bits - k * 2^23, and float(k * 2^23) is exact (|k| < 2^8).  The factor 2^23
+    // is taken out of LN2 in the final fma: fma(k * 2^23, LN2 * 2^-23, q) rounds the same real number as
+    // fma(k, LN2, q) (both scalings are exact).  Four plain integer ops and one conversion per argument.
     const int xa = __float_as_int(v.x), xb = __float_as_int(v.y);
-    const int ka = (xa - SPLIT) >> 23, kb = (xb - SPLIT) >> 23;
+    const int ha = (xa - SPLIT) & (int)0xFF800000, hb = (xb - SPLIT) & (int)0xFF800000;
     f32x2 k, m;
-    k.x = (float)ka;
-    k.y = (float)kb;
-    // (inline asm: the compiler otherwise rewrites the expression back into and + add)
-    const int neg_2p23 = -8388608;
-    int ma, mb;
-    asm("v_mad_i32_i24 %0, %1, %2, %3" : "=v"(ma) : "v"(ka), "s"(neg_2p23), "v"(xa));
-    asm("v_mad_i32_i24 %0, %1, %2, %3" : "=v"(mb) : "v"(kb), "s"(neg_2p23), "v"(xb));
-    m.x = __int_as_float(ma);
-    m.y = __int_as_float(mb);
+    k.x = (float)ha;
+    k.y = (float)hb;
+    m.x = __int_as_float(xa - ha);
+    m.y = __int_as_float(xb - hb);
     const f32x2 r = m - 1.0f;
     f32x2 num = pk_fma((f32x2)(P5), r, (f32x2)(P4));
     f32x2 den = pk_fma((f32x2)(Q5), r, (f32x2)(Q4));
@@ -137,7 +135,7 @@ __device__ __forceinline__ f32x2 log_f32_hot2(f32x2 v)
     const f32x2 q0 = num * rc;
     const f32x2 rem = pk_fma(nden, q0, num);
     const f32x2 q = pk_fma(rem, rc, q0);
-    return pk_fma(k, (f32x2)(LN2), q);
+    return pk_fma(k, (f32x2)(LN2 * 1.1920928955078125e-07f), q);  // LN2 * 2^-23, exact
 }
 
 __device__ __forceinline__ float exp_f32(float v)
