@@ -17,19 +17,25 @@ from warnings import warn
 import numpy as np
 
 
+_INITIAL_ROWS = 32768  # capacity the reference starts with (genotypes.py:33); doubled on demand
+
+
 class ProbabilisticGenotypes:
+    """Dirichlet-beta table float32[capacity, G] + (chrom, pos, base) -> row.  Only the first n_variants rows are
+    meaningful; genotype names must come sorted and unique (they are the posterior columns)."""
+
     def __init__(self, genotype_names: List[str], default_prior=1.):
-        self.var2varid: Dict[Tuple, int] = {}
-        self.genotype_names: List[str] = list(genotype_names)
-        assert (np.sort(self.genotype_names) == self.genotype_names).all(), 'please order genotype names'
-        assert len(set(genotype_names)) == len(genotype_names), f'Duplicates in genotypes: {genotype_names}'
-        self.variant_betas: np.ndarray = np.zeros([32768, self.n_genotypes], 'float32')
+        names = list(genotype_names)
+        assert names == sorted(names), 'please order genotype names'
+        assert len(set(names)) == len(names), f'Duplicates in genotypes: {genotype_names}'
+        self.genotype_names: List[str] = names
         self.default_prior: float = default_prior
+        self.var2varid: Dict[Tuple, int] = {}
+        self.variant_betas: np.ndarray = np.zeros((_INITIAL_ROWS, len(names)), dtype=np.float32)
 
     def __repr__(self):
-        contigs = {chrom for chrom, _, _ in self.var2varid}
-        return (f'<Genotypes with {self.n_variants} variants on {len(contigs)} contigs ("chromosomes") '
-                f'and {self.n_genotypes} genotypes: \n{self.genotype_names}')
+        n_contigs = len({key[0] for key in self.var2varid})
+        return f'<ProbabilisticGenotypes: {self.n_variants} variants on {n_contigs} contigs, genotypes {self.genotype_names}>'
 
     @property
     def n_genotypes(self):
@@ -40,30 +46,46 @@ class ProbabilisticGenotypes:
         return len(self.var2varid)
 
     def get_betas(self) -> np.ndarray:
-        view = self.variant_betas[:self.n_variants]
-        view.flags.writeable = False
-        return view
+        """Read-only view of the rows in use (callers must not write through it: genotypes.py:50-54)."""
+        used = self.variant_betas[:self.n_variants]
+        used.setflags(write=False)
+        return used
 
     def get_snp_ids_for_variants(self) -> np.ndarray:
-        """SNP id of every variant row; ids are handed out in first-seen order of var2varid."""
-        ids = {}
-        out = np.full(self.n_variants, -1, dtype='int32')
-        for (chrom, pos, _base), row in self.var2varid.items():
-            out[row] = ids.setdefault((chrom, pos), len(ids))
-        assert np.all(out >= 0)
-        assert np.all(out < self.n_variants)
+        """SNP (= chromosome, position) of every variant row, numbered in the order the SNPs first appear in
+        var2varid (genotypes.py:56-66; the E-step never looks at the numbers, the P-step only groups by them)."""
+        if not self.var2varid:
+            return np.zeros(0, dtype=np.int32)
+        keys = list(self.var2varid)
+        rows = np.fromiter(self.var2varid.values(), dtype=np.int64, count=len(keys))
+        numbering, snp_of_key = {}, np.empty(len(keys), dtype=np.int32)
+        for i, (chrom, pos, _base) in enumerate(keys):
+            snp_of_key[i] = numbering.setdefault((chrom, pos), len(numbering))
+        out = np.full(len(keys), -1, dtype=np.int32)
+        out[rows] = snp_of_key
+        assert (out >= 0).all(), 'var2varid rows must enumerate 0..n_variants-1'
         return out
 
     def get_variant_id(self, chrom, pos, base):
-        key = chrom, pos, base
-        if key not in self.var2varid:
-            self.var2varid[key] = self.n_variants
-            self.extend_variants(1)
-        return self.var2varid[key]
+        """Row of a variant, allocated on first use."""
+        row = self.var2varid.get((chrom, pos, base))
+        if row is None:
+            row = len(self.var2varid)
+            self.var2varid[(chrom, pos, base)] = row
+            self.extend_variants(0)
+        return row
 
     def extend_variants(self, n_samples=1):
-        while n_samples + self.n_variants > len(self.variant_betas):
-            self.variant_betas = np.concatenate([self.variant_betas, np.zeros_like(self.variant_betas)], axis=0)
+        """Makes room for n_samples more rows than are registered (the table doubles, as the reference's does)."""
+        needed = self.n_variants + n_samples
+        capacity = len(self.variant_betas)
+        if needed <= capacity:
+            return
+        while capacity < needed:
+            capacity *= 2
+        grown = np.zeros((capacity, self.variant_betas.shape[1]), dtype=self.variant_betas.dtype)
+        grown[:len(self.variant_betas)] = self.variant_betas
+        self.variant_betas = grown
 
     # ---- VCF import without htslib -----------------------------------------------------------
     def _check_imported_genotypes(self, imported_genotypes, allow_duplicates=False) -> Dict[str, int]:
@@ -144,23 +166,25 @@ class ProbabilisticGenotypes:
         print(f'Parsed {n_records} SNPs, got {self.n_variants - n_before} novel variants')
 
     def get_chromosome2positions(self):
-        by_chrom = defaultdict(list)
+        """chromosome -> sorted unique SNP positions (what count_snps of the reference is handed)."""
+        positions = defaultdict(set)
         for chrom, pos, _base in self.var2varid:
-            by_chrom[chrom].append(pos)
-        if len(by_chrom) == 0:
+            positions[chrom].add(pos)
+        if not positions:
             warn('Genotypes are empty. Did you forget to add vcf/betas?')
-        return {chrom: np.unique(np.asarray(p, dtype=int)) for chrom, p in by_chrom.items()}
+        return {chrom: np.array(sorted(found), dtype=int) for chrom, found in positions.items()}
 
     def get_snp_positions_set(self) -> set:
-        return {(chrom, pos) for chrom, pos, _base in self.var2varid}
+        return {key[:2] for key in self.var2varid}
 
     def _with_betas(self, external_betas: np.ndarray) -> 'ProbabilisticGenotypes':
-        """Copy of the genotypes carrying new beta weights."""
+        """A copy of this object whose table is exactly `external_betas` ([n_variants, G] float32, non-negative):
+        how learn_genotypes hands back the learnt genotypes (genotypes.py:327-334)."""
         assert external_betas.shape == (self.n_variants, self.n_genotypes)
         assert external_betas.dtype == self.variant_betas.dtype
-        assert np.min(external_betas) >= 0
+        assert external_betas.size == 0 or external_betas.min() >= 0
         out = self._clone(with_betas=False)
-        out.variant_betas = external_betas.copy()
+        out.variant_betas = np.array(external_betas, copy=True)
         return out
 
     def clone(self):

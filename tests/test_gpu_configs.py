@@ -256,3 +256,40 @@ def test_config4_rank_share_130k_650k_128_doublets(oracle):
     p_rows = [(0, 200_000), (1_200_000, 1_300_000)]
     _ctx, addition, singlets, _n_multi = staged_em_against_oracle(oracle, p, 1, 0.25, samples, seed=13, p_rows=p_rows)
     assert singlets.shape == (130_000, 128) and (addition >= 0).all()
+
+
+# ---- the tile-major schedule with two accumulators per lane (65..128 genotypes, singlets) ------------------
+def test_tiled_schedule_two_slots_per_lane(oracle):
+    """70k barcodes x 20k SNPs x 128 genotypes (K = 128 singlets: two options per lane; 20 MB genotype table, so the
+    repack builds the tile-major schedule): the exact mode under the forced tile-major schedule must equal the direct
+    schedule bit for bit and the oracle on sampled rows; the tolerance mode (which uses the schedule by default) must
+    stay within its contract against the exact mode."""
+    from demuxalot_amd import synth
+    from demuxalot_amd.device import get_context
+    from tests.test_gpu_fast_mode import check_contract
+    p = synth.generate(70_000, 20_000, 128, calls_per_barcode=100, seed=31)
+    ctx = get_context()
+    ctx.set_problem(p.n_barcodes, p.n_variants, 128, p.variant_id, p.compressed_cb, p.p_base_wrong, p.v2snp)
+    ctx.set_betas(p.prior_betas())
+    ctx.set_addition(None)
+    prob = ctx.probs_from_betas(0.01)
+    pen = np.zeros(128, dtype=np.float32)
+    try:
+        ctx.set_estep_schedule('direct')
+        logits_d, probs_d = ctx.estep(pen, with_doublets=False)
+        ctx.set_estep_schedule('tiled')
+        logits_t, probs_t = ctx.estep(pen, with_doublets=False)
+        fio.assert_bitwise(logits_t, logits_d, 'tile-major vs direct schedule: logits')
+        fio.assert_bitwise(probs_t, probs_d, 'tile-major vs direct schedule: posteriors')
+        check_e_rows(ctx, oracle, p, prob, 1000, 1400, 0., 'tile-major rows [1000,1400)')
+        addition_tiled = ctx.mstep(2.)
+        ctx.set_estep_schedule('auto')
+        ctx.set_estep_mode('fast')
+        logits_f, probs_f = ctx.estep(pen, with_doublets=False)
+    finally:
+        ctx.set_estep_mode('exact')
+        ctx.set_estep_schedule('auto')
+    check_contract(logits_f, probs_f, logits_d, probs_d, 'fast (tile-major, two slots) vs exact', strict=False)
+    rng = np.random.default_rng(3)
+    variants, _ = variants_to_check(p, rng, n_random=300)
+    fio.assert_bitwise(addition_tiled[variants], addition_rows(p, probs_t, variants), 'M-step rows (G = 128)')
