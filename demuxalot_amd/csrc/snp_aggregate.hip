@@ -34,6 +34,8 @@ namespace {
 
 using dmx::fail;
 
+constexpr int SNP_MAX_OPTIONS = 256 * 33;  // doublets of 128 genotypes: 8256 options, 99 KB of LDS per barcode
+
 inline unsigned grid_for(long long n) { return (unsigned)((n + 255) / 256); }
 
 // ---- layout -------------------------------------------------------------------------------------------------
@@ -309,6 +311,151 @@ __global__ __launch_bounds__(256) void k_estep_snp(SnpArgs a)
     }
 }
 
+// More than 1024 options (doublets of 45+ genotypes): one WORKGROUP walks one barcode, thread t holds options
+// t + 256 s.  Same arithmetic as k_estep_snp; the row maxima go through LDS, the numpy-ordered sums are done by
+// wavefront 0 over the LDS row.  LDS: K float64 + K float32.
+template <int A>
+__global__ __launch_bounds__(256) void k_estep_snp_block(SnpArgs a)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    __shared__ double red64[5];
+    __shared__ float red32[5];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int K = a.K, G = a.G;
+    double *sh64 = (double *)smem;
+    float *sh32 = (float *)(sh64 + K);
+    const long long b = blockIdx.x;
+
+    unsigned pr[A];
+    bool valid[A];
+#pragma unroll
+    for (int s = 0; s < A; s++) {
+        const int k = tid + 256 * s;
+        valid[s] = k < K;
+        pr[s] = a.opt_pairs[valid[s] ? k : K - 1];
+    }
+    double logit[A], acc[A];
+#pragma unroll
+    for (int s = 0; s < A; s++) logit[s] = acc[s] = 0.0;
+    int count = 0;
+
+    auto block_max32 = [&](float v) {
+        for (int off = 1; off < 64; off <<= 1) v = fmaxf(v, __shfl_xor(v, off));
+        if (lane == 0) red32[wave] = v;
+        __syncthreads();
+        return fmaxf(fmaxf(red32[0], red32[1]), fmaxf(red32[2], red32[3]));
+    };
+    auto block_max64 = [&](double v) {
+        v = wave_max64(v);
+        if (lane == 0) red64[wave] = v;
+        __syncthreads();
+        return fmax(fmax(red64[0], red64[1]), fmax(red64[2], red64[3]));
+    };
+    auto block_sum32 = [&]() {  // np.sum of sh32[0..K)
+        __syncthreads();
+        if (wave == 0) {
+            const float tot = npm::row_sum_wave(sh32, K, lane);
+            if (lane == 0) red32[4] = tot;
+        }
+        __syncthreads();
+        return red32[4];
+    };
+    auto block_sum64 = [&]() {
+        __syncthreads();
+        if (wave == 0) {
+            const double tot = row_sum64(sh64, K, lane);
+            if (lane == 0) red64[4] = tot;
+        }
+        __syncthreads();
+        return red64[4];
+    };
+
+    auto finish = [&]() {
+        const double div = a.count_pow[count];
+        float tmp[A];
+        float mx = -__builtin_inff();
+#pragma unroll
+        for (int s = 0; s < A; s++) {
+            const float s32 = (float)acc[s];
+            tmp[s] = (float)((double)s32 / div);
+            if (valid[s]) mx = fmaxf(mx, tmp[s]);
+        }
+        mx = block_max32(mx);
+        if (!(fabsf(mx) < __builtin_inff())) mx = 0.0f;
+#pragma unroll
+        for (int s = 0; s < A; s++) {
+            tmp[s] = tmp[s] - mx;
+            if (valid[s]) sh32[tid + 256 * s] = npm::exp_f32(tmp[s]);
+        }
+        const float lse = npm::log_f32<true, false>(block_sum32());
+        double t2[A];
+        double mx2 = -__builtin_inf();
+#pragma unroll
+        for (int s = 0; s < A; s++) {
+            const float y = tmp[s] - lse;
+            t2[s] = logaddexp_f64((double)y, a.log_bad);
+            if (valid[s]) mx2 = fmax(mx2, t2[s]);
+        }
+        mx2 = block_max64(mx2);
+        if (!(fabs(mx2) < __builtin_inf())) mx2 = 0.0;
+#pragma unroll
+        for (int s = 0; s < A; s++) {
+            t2[s] = t2[s] - mx2;
+            if (valid[s]) sh64[tid + 256 * s] = exp(t2[s]);
+        }
+        const double lse2 = log(block_sum64());
+#pragma unroll
+        for (int s = 0; s < A; s++) {
+            logit[s] += t2[s] - lse2;
+            acc[s] = 0.0;
+        }
+        count = 0;
+    };
+
+    const long long c0 = a.bc_start[b], c1 = a.bc_start[b + 1];
+    for (long long c = c0; c < c1; c++) {
+        const int tagged = a.variant[c];
+        if (tagged < 0 && c > c0) finish();
+        const int v = tagged & 0x7FFFFFFF;
+        const float e = a.e[c];
+        const float *row = a.prob + (size_t)(a.prow ? a.prow[v] : v) * G;
+#pragma unroll
+        for (int s = 0; s < A; s++) {
+            const float p = (row[pr[s] & 0xFFFFu] + row[pr[s] >> 16]) * 0.5f;  // g1 == g2 for the singlets: (p + p) / 2 = p
+            acc[s] += (double)npm::log_f32<true, false>(p + e);
+        }
+        count++;
+    }
+    if (c1 > c0) finish();
+
+    double mx = -__builtin_inf();
+#pragma unroll
+    for (int s = 0; s < A; s++) {
+        const int k = tid + 256 * s;
+        if (a.prior && valid[s]) {
+            const size_t o = (size_t)b * K + k;
+            logit[s] += a.prior_dtype == DMX_F32 ? (double)((const float *)a.prior)[o] : ((const double *)a.prior)[o];
+        }
+        if (valid[s]) mx = fmax(mx, logit[s]);
+    }
+    mx = block_max64(mx);
+    double ex[A];
+#pragma unroll
+    for (int s = 0; s < A; s++) {
+        ex[s] = exp(logit[s] - mx);
+        if (valid[s]) sh64[tid + 256 * s] = ex[s];
+    }
+    const double tot = block_sum64();
+#pragma unroll
+    for (int s = 0; s < A; s++) {
+        const int k = tid + 256 * s;
+        if (!valid[s]) continue;
+        const size_t o = (size_t)b * K + k;
+        a.logits[o] = logit[s];
+        a.post[o] = ex[s] / tot;
+    }
+}
+
 // ---- M-step on float64 posteriors -----------------------------------------------------------------------------
 // one wavefront per variant walks all its calls in order (items in order = CSC order), lane g (+64 s) = genotype
 template <int A, bool SQUARE>
@@ -351,6 +498,7 @@ int launch_snp(dmx_ctx *c, const SnpArgs &a, bool pairs)
 {
     const size_t bytes = (size_t)4 * a.K * (sizeof(double) + sizeof(float));
     const dim3 grid((unsigned)((a.B + 3) / 4)), block(256);
+    if (a.B == 0) return 0;
     if (pairs) {
         HIP_TRY(hipFuncSetAttribute((const void *)k_estep_snp<A, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
         hipLaunchKernelGGL((k_estep_snp<A, true>), grid, block, bytes, c->stream, a);
@@ -358,6 +506,16 @@ int launch_snp(dmx_ctx *c, const SnpArgs &a, bool pairs)
         HIP_TRY(hipFuncSetAttribute((const void *)k_estep_snp<A, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
         hipLaunchKernelGGL((k_estep_snp<A, false>), grid, block, bytes, c->stream, a);
     }
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+template <int A>
+int launch_snp_block(dmx_ctx *c, const SnpArgs &a)
+{
+    const size_t bytes = (size_t)a.K * (sizeof(double) + sizeof(float));
+    HIP_TRY(hipFuncSetAttribute((const void *)k_estep_snp_block<A>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
+    if (a.B) hipLaunchKernelGGL((k_estep_snp_block<A>), dim3((unsigned)a.B), dim3(256), bytes, c->stream, a);
     HIP_TRY(hipGetLastError());
     return 0;
 }
@@ -497,7 +655,7 @@ int dmx_estep_snp(dmx_ctx *c, int with_doublets, const double *count_pow, int64_
     if (prior_logits && prior_dtype != DMX_F32 && prior_dtype != DMX_F64) return fail(DMX_ERR_INVALID, "prior_dtype must be DMX_F32 or DMX_F64");
     const int G = c->G;
     const long long K = with_doublets ? (long long)G * (G + 1) / 2 : G;
-    if (K > 1024) return fail(DMX_ERR_UNSUPPORTED, "aggregate_on_snps supports up to 1024 options (K=%lld)", K);
+    if (K > SNP_MAX_OPTIONS) return fail(DMX_ERR_UNSUPPORTED, "aggregate_on_snps supports up to %d options (K=%lld)", SNP_MAX_OPTIONS, K);
     const size_t bk = (size_t)c->B * K;
     if (bk > c->cap_bk64) {
         dev_free(c, &c->d_logits64, c->cap_bk64);
@@ -548,7 +706,13 @@ int dmx_estep_snp(dmx_ctx *c, int with_doublets, const double *count_pow, int64_
         else if (K <= 128) rc = launch_snp<2>(c, a, pairs_on);
         else if (K <= 256) rc = launch_snp<4>(c, a, pairs_on);
         else if (K <= 512) rc = launch_snp<8>(c, a, pairs_on);
-        else rc = launch_snp<16>(c, a, pairs_on);
+        else if (K <= 1024) rc = launch_snp<16>(c, a, pairs_on);
+        else if (K <= 256 * 6) rc = launch_snp_block<6>(c, a);  // K > 1024 is always the doublet table
+        else if (K <= 256 * 9) rc = launch_snp_block<9>(c, a);
+        else if (K <= 256 * 12) rc = launch_snp_block<12>(c, a);
+        else if (K <= 256 * 17) rc = launch_snp_block<17>(c, a);
+        else if (K <= 256 * 24) rc = launch_snp_block<24>(c, a);
+        else rc = launch_snp_block<33>(c, a);
         if (rc) break;
         if (logits_out && bk) e = hipMemcpyAsync(logits_out, c->d_logits64, sizeof(double) * bk, hipMemcpyDeviceToHost, c->stream);
         if (e == hipSuccess && probs_out && bk) e = hipMemcpyAsync(probs_out, c->d_post64, sizeof(double) * bk, hipMemcpyDeviceToHost, c->stream);

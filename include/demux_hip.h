@@ -269,7 +269,7 @@ int dmx_get_option_sums(dmx_ctx *ctx, double *sums);
  *                                the reference when the posteriors are); single GPU
  * Everything up to the first log_softmax is float32 and bit-identical to numpy; the float64 part agrees with the
  * reference to a few ulps (numpy's float64 exp / log1p are its own SIMD kernels or libm, depending on the host).
- * Supported up to 1024 options. */
+ * Up to 8448 options (doublets of 128 genotypes: 8256); beyond 1024 options one workgroup walks one barcode. */
 int dmx_set_keep_molecule_calls(dmx_ctx *ctx, int keep);
 int dmx_set_molecule_calls(dmx_ctx *ctx, int64_t n, const int32_t *variant_id, const int32_t *compressed_cb,
                            const float *p_base_wrong);

@@ -41,11 +41,6 @@ def test_aggregate_on_snps_matches_reference(aggregating, name):
     calls, genotypes, handler = fio.product_inputs(fx)
     worst = 0.0
     for i in range(int(out['n_predict'])):
-        if out[f'predict{i}_logits'].shape[1] > 1024:  # stated limit of this mode (include/demux_hip.h)
-            from demuxalot_amd._lib import DemuxHipError
-            with pytest.raises(DemuxHipError, match='up to 1024 options'):
-                D.predict_posteriors(calls, genotypes, handler, doublet_prior=float(out[f'predict{i}_dp']))
-            continue
         logits_df, probs_df = D.predict_posteriors(calls, genotypes, handler, doublet_prior=float(out[f'predict{i}_dp']))
         assert logits_df.index.name == 'BARCODE' and list(logits_df.columns) == [str(c) for c in out[f'predict{i}_columns']]
         worst = max(worst, check64(logits_df.values, probs_df.values, out[f'predict{i}_logits'], out[f'predict{i}_probs'],
@@ -90,3 +85,32 @@ def test_aggregate_mode_refuses_what_it_cannot_do(aggregating):
     calls, genotypes, handler = fio.product_inputs(fx)
     with pytest.raises(AssertionError, match='float64'):
         aggregating.predict_posteriors(calls, genotypes, handler, on_device=True)
+
+
+@pytest.mark.parametrize('n_genotypes', [60, 75, 100, 128])
+def test_aggregate_wide_option_tables_against_the_oracle(oracle, n_genotypes):
+    """Doublets of 60 / 75 / 100 / 128 genotypes (1830 / 2850 / 5050 / 8256 options: the workgroup-per-barcode kernel
+    with 9 / 12 / 24 / 33 options per thread) on synthetic molecule calls with repeated (barcode, SNP) pairs."""
+    from demuxalot_amd import synth
+    from demuxalot_amd.device import get_context
+    p = synth.generate(40, 300, n_genotypes, calls_per_barcode=60, seed=n_genotypes)
+    rng = np.random.default_rng(n_genotypes)
+    # molecule calls: every barcode call 1..3 times, in shuffled (molecule) order
+    rep = rng.integers(1, 4, size=len(p.variant_id))
+    order = rng.permutation(int(rep.sum()))
+    mv, mcb = np.repeat(p.variant_id, rep)[order], np.repeat(p.compressed_cb, rep)[order]
+    mp = rng.uniform(0.001, 0.2, size=len(mv)).astype(np.float32)
+    ctx = get_context()
+    ctx.set_problem(p.n_barcodes, p.n_variants, n_genotypes, p.variant_id, p.compressed_cb, p.p_base_wrong, p.v2snp)
+    ctx.set_betas(p.prior_betas())
+    ctx.set_addition(None)
+    prob = ctx.probs_from_betas(0.01)
+    ctx.set_molecule_calls(mv, mcb, mp)
+    logits, probs = ctx.estep_snp(True, 0.5)
+    want = oracle.barcode_logits_aggregated(mv, mcb, mp, p.v2snp, prob, p.n_barcodes, 0.5)
+    assert logits.shape == want.shape == (40, n_genotypes * (n_genotypes + 1) // 2)
+    assert np.allclose(logits, want, rtol=1e-11, atol=1e-11), np.abs(logits - want).max()
+    shifted = np.exp(want - want.max(axis=1, keepdims=True))  # scipy softmax, float64
+    want_probs = shifted / shifted.sum(axis=1, keepdims=True)
+    assert np.array_equal(probs.argmax(axis=1), want_probs.argmax(axis=1)) and np.abs(probs - want_probs).max() <= 1e-12
+    print(f'G={n_genotypes}: float64 logits within {(np.abs(logits - want) / np.spacing(np.abs(want))).max():.1f} ulp of the oracle')
