@@ -16,6 +16,9 @@ LIB_PATH = os.environ.get('DEMUXALOT_AMD_LIB') or os.path.join(_HERE, 'libdemux_
 DMX_F32, DMX_F64 = 0, 1
 T_PSTEP, T_ESTEP, T_MSTEP, T_MCOMBINE, T_ALLREDUCE, T_COUNT = 0, 1, 2, 3, 4, 5
 TIMER_NAMES = ('pstep', 'estep', 'mstep', 'mcombine', 'allreduce')
+# int (*dmx_host_collective)(void *user, int op, void *buf, int64_t count, int dtype)
+HOST_COLLECTIVE = ctypes.CFUNCTYPE(ctypes.c_int, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_int64, ctypes.c_int)
+COLL_ALL_REDUCE, COLL_REDUCE_SCATTER, COLL_ALL_GATHER = 0, 1, 2
 UNIQUE_ID_BYTES = 128
 
 # every symbol include/demux_hip.h declares: (restype, argtypes)
@@ -61,6 +64,7 @@ SIGNATURES = {
     'dmx_exchange_slices': (c_int, [c_int64, _P, c_int32, _P, POINTER(c_int64), POINTER(c_int32)]),
     'dmx_comm_unique_id': (c_int, [_P]),
     'dmx_comm_init': (c_int, [_P, c_int, c_int, _P, c_int]),
+    'dmx_comm_init_host': (c_int, [_P, c_int, c_int, _P, _P, c_int]),
     'dmx_get_timings': (c_int, [_P, POINTER(c_double), POINTER(c_int64)]),
     'dmx_reset_timings': (c_int, [_P]),
     'dmx_device_bytes': (c_int, [_P, POINTER(c_int64)]),

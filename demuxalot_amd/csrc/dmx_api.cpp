@@ -322,17 +322,79 @@ void exchange_slices(const int *v2snp, long long V, int n, std::vector<long long
     for (int r = 0; r < n; r++) rows = std::max(rows, cut[r + 1] - cut[r]);
 }
 
+// ---- the three collectives of the exchange: RCCL on the ctx stream, or the caller's over pinned host memory --------
+int host_stage(dmx_ctx *c, size_t bytes)
+{
+    if (bytes <= c->h_stage_bytes) return 0;
+    if (c->h_stage) (void)hipHostFree(c->h_stage);
+    c->h_stage = nullptr;
+    c->h_stage_bytes = 0;
+    HIP_TRY(hipHostMalloc(&c->h_stage, bytes, hipHostMallocDefault));
+    c->h_stage_bytes = bytes;
+    return 0;
+}
+
+// runs `op` on the caller's collectives: device [src, src + bytes_in) -> host stage at byte offset off_in, callback,
+// host stage [off_out, off_out + bytes_out) -> device dst
+int host_collective(dmx_ctx *c, int op, const void *src, size_t off_in, size_t bytes_in, void *dst, size_t off_out, size_t bytes_out,
+                    size_t total_bytes, int64_t count, int dtype, const char *what)
+{
+    DMX_TRY(host_stage(c, total_bytes));
+    char *h = (char *)c->h_stage;
+    if (bytes_in) HIP_TRY(hipMemcpyAsync(h + off_in, src, bytes_in, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    const int rc = c->host_coll(c->host_user, op, h, count, dtype);
+    if (rc != 0) return fail(DMX_ERR_RCCL, "the caller's collective (%s) failed with %d", what, rc);
+    if (bytes_out) HIP_TRY(hipMemcpyAsync(dst, h + off_out, bytes_out, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));  // the stage is reused by the next collective
+    return 0;
+}
+
+// recv[block] = sum over ranks of their send[rank * block ...]
+int coll_reduce_scatter(dmx_ctx *c, const void *send, void *recv, size_t block, bool f64)
+{
+    const size_t elem = f64 ? 8 : 4;
+    if (c->comm) {
+        ncclResult_t r = g_rccl.ReduceScatter(send, recv, block, f64 ? ncclDouble : ncclFloat, ncclSum, c->comm, c->stream);
+        return r == ncclSuccess ? 0 : fail(DMX_ERR_RCCL, "ncclReduceScatter failed: %s", rccl_error(r));
+    }
+    const size_t total = block * elem * c->nranks;
+    return host_collective(c, DMX_COLL_REDUCE_SCATTER, send, 0, total, recv, block * elem * c->rank, block * elem, total, (int64_t)block,
+                           f64 ? DMX_F64 : DMX_F32, "reduce-scatter");
+}
+
+// float32 table of nranks blocks, this rank's block filled: everybody's blocks on return
+int coll_all_gather(dmx_ctx *c, float *table, size_t block, const char *what)
+{
+    if (c->comm) {
+        ncclResult_t r = g_rccl.AllGather(table + c->rank * block, table, block, ncclFloat, c->comm, c->stream);
+        return r == ncclSuccess ? 0 : fail(DMX_ERR_RCCL, "ncclAllGather (%s) failed: %s", what, rccl_error(r));
+    }
+    const size_t total = block * 4 * c->nranks, mine = block * 4 * c->rank;
+    return host_collective(c, DMX_COLL_ALL_GATHER, table + c->rank * block, mine, block * 4, table, 0, total, total, (int64_t)block, DMX_F32, what);
+}
+
+int coll_all_reduce(dmx_ctx *c, void *buf, size_t count, bool f64)
+{
+    if (c->comm) {
+        ncclResult_t r = g_rccl.AllReduce(buf, buf, count, f64 ? ncclDouble : ncclFloat, ncclSum, c->comm, c->stream);
+        return r == ncclSuccess ? 0 : fail(DMX_ERR_RCCL, "ncclAllReduce failed: %s", rccl_error(r));
+    }
+    const size_t total = count * (f64 ? 8 : 4);
+    return host_collective(c, DMX_COLL_ALL_REDUCE, buf, 0, total, buf, 0, total, total, (int64_t)count, f64 ? DMX_F64 : DMX_F32, "all-reduce");
+}
+
 int layout_exchange(dmx_ctx *c)
 {
     const long long V = c->V;
-    const int G = c->G, n = c->comm ? c->nranks : 1;
+    const int G = c->G, n = c->attached() ? c->nranks : 1;
     hipStream_t st = c->stream;
     HIP_TRY(hipStreamSynchronize(st));
     if (c->d_prow) return fail(DMX_ERR_INVALID, "the resident problem is already laid out for a communicator: install it again");
     bool contiguous = true;
     long long rows = V;
     exchange_slices(c->h_v2snp.data(), V, n, c->cut, rows, contiguous);
-    c->sliced = c->comm != nullptr && contiguous && V > 0;
+    c->sliced = c->attached() && contiguous && V > 0;
     if (!c->sliced) {
         c->cut.assign((size_t)n + 1, 0);
         c->cut[n] = V;
@@ -409,8 +471,7 @@ int ensure_full_addition(dmx_ctx *c)
     const size_t block = (size_t)c->slice_rows * G;
     const long long mine = c->cut[c->rank + 1] - c->cut[c->rank];
     if (mine) HIP_TRY(hipMemcpyAsync(stage + c->rank * block, c->d_add + c->cut[c->rank] * G, sizeof(float) * mine * G, hipMemcpyDeviceToDevice, c->stream));
-    ncclResult_t r = g_rccl.AllGather(stage + c->rank * block, stage, block, ncclFloat, c->comm, c->stream);
-    if (r != ncclSuccess) return fail(DMX_ERR_RCCL, "ncclAllGather (addition) failed: %s", rccl_error(r));
+    DMX_TRY(coll_all_gather(c, stage, block, "addition"));
     for (int k = 0; k < n; k++) {
         const long long rows = c->cut[k + 1] - c->cut[k];
         if (rows && k != c->rank) HIP_TRY(hipMemcpyAsync(c->d_add + c->cut[k] * G, stage + k * block, sizeof(float) * rows * G, hipMemcpyDeviceToDevice, c->stream));
@@ -432,9 +493,9 @@ int run_pstep(dmx_ctx *c, float lo, float hi, bool with_addition)
     if (c->sliced) {  // everybody gets everybody's slice of genotype_prob
         timer_begin(c, DMX_T_ALLREDUCE, &ev);
         const size_t block = (size_t)c->slice_rows * c->G;
-        ncclResult_t r = g_rccl.AllGather(c->d_prob + c->rank * block, c->d_prob, block, ncclFloat, c->comm, c->stream);
+        const int rc = coll_all_gather(c, c->d_prob, block, "genotype_prob");
         timer_end(c, DMX_T_ALLREDUCE, ev);
-        if (r != ncclSuccess) return fail(DMX_ERR_RCCL, "ncclAllGather (genotype_prob) failed: %s", rccl_error(r));
+        if (rc) return rc;
     }
     c->have_probs = true;
     return 0;
@@ -507,7 +568,7 @@ int run_mstep(dmx_ctx *c, float power)
         c->nz_floor = 0.0f;
     }
     std::pair<hipEvent_t, hipEvent_t> ev;
-    const bool dist = c->comm != nullptr;  // also with one rank: keeps the collective path testable on one GPU
+    const bool dist = c->attached();  // also with one rank: keeps the collective path testable on one GPU
     unsigned long long *redo = c->exact_additions ? c->d_redo : nullptr;
     timer_begin(c, DMX_T_MSTEP, &ev);
     HIP_TRY(dmx::launch_mstep(c->stream, a));
@@ -519,7 +580,7 @@ int run_mstep(dmx_ctx *c, float power)
         return 0;
     }
     const bool f64 = c->reduce_dtype == DMX_F64;
-    ncclResult_t r = ncclSuccess;
+    int rc = 0;
     if (c->sliced) {
         // partial sums straight into the padded exchange buffer, reduce-scatter, this rank's slice rounded into d_add
         timer_begin(c, DMX_T_MCOMBINE, &ev);
@@ -528,11 +589,11 @@ int run_mstep(dmx_ctx *c, float power)
         timer_end(c, DMX_T_MCOMBINE, ev);
         timer_begin(c, DMX_T_ALLREDUCE, &ev);
         const size_t block = (size_t)c->slice_rows * c->G;
-        r = g_rccl.ReduceScatter(c->d_exch, c->d_recv, block, f64 ? ncclDouble : ncclFloat, ncclSum, c->comm, c->stream);
-        if (r == ncclSuccess)
+        rc = coll_reduce_scatter(c, c->d_exch, c->d_recv, block, f64);
+        if (rc == 0)
             HIP_TRY(dmx::launch_store_slice(c->stream, c->d_recv, f64, c->cut[c->rank], c->cut[c->rank + 1] - c->cut[c->rank], c->G, c->d_add));
         timer_end(c, DMX_T_ALLREDUCE, ev);
-        if (r != ncclSuccess) return fail(DMX_ERR_RCCL, "ncclReduceScatter failed: %s", rccl_error(r));
+        if (rc) return rc;
         c->add_partial = c->nranks > 1;
         return 0;
     }
@@ -544,14 +605,13 @@ int run_mstep(dmx_ctx *c, float power)
     timer_begin(c, DMX_T_ALLREDUCE, &ev);
     const size_t cnt = (size_t)c->V * c->G;
     if (f64) {
-        r = g_rccl.AllReduce(c->d_add64, c->d_add64, cnt, ncclDouble, ncclSum, c->comm, c->stream);
-        if (r == ncclSuccess) HIP_TRY(dmx::launch_f64_to_f32(c->stream, c->d_add64, c->d_add, (long long)cnt));
+        rc = coll_all_reduce(c, c->d_add64, cnt, true);
+        if (rc == 0) HIP_TRY(dmx::launch_f64_to_f32(c->stream, c->d_add64, c->d_add, (long long)cnt));
     } else {
-        r = g_rccl.AllReduce(c->d_add, c->d_add, cnt, ncclFloat, ncclSum, c->comm, c->stream);
+        rc = coll_all_reduce(c, c->d_add, cnt, false);
     }
     timer_end(c, DMX_T_ALLREDUCE, ev);
-    if (r != ncclSuccess) return fail(DMX_ERR_RCCL, "ncclAllReduce failed: %s", rccl_error(r));
-    return 0;
+    return rc;
 }
 
 }  // namespace
@@ -604,6 +664,7 @@ int dmx_destroy(dmx_ctx *c)
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
     if (c->comm && g_rccl.CommDestroy) g_rccl.CommDestroy(c->comm);
+    if (c->h_stage) (void)hipHostFree(c->h_stage);
     release_problem(c);
     if (c->d_scratch) (void)hipFree(c->d_scratch);
     for (auto &t : c->timers) {
@@ -1089,6 +1150,7 @@ int dmx_comm_init(dmx_ctx *c, int rank, int nranks, const void *unique_id, int r
         g_rccl.CommDestroy(c->comm);
         c->comm = nullptr;
     }
+    c->host_coll = nullptr;
     ncclUniqueId id;
     std::memcpy(&id, unique_id, sizeof id);
     ncclResult_t r = g_rccl.CommInitRank(&c->comm, nranks, id, rank);
@@ -1101,6 +1163,24 @@ int dmx_comm_init(dmx_ctx *c, int rank, int nranks, const void *unique_id, int r
     c->reduce_dtype = reduce_dtype;
     // a problem installed before the communicator gets its exchange layout now (the E-step records are rewritten
     // in place for the padded genotype table)
+    if (c->have_problem) DMX_TRY(layout_exchange(c));
+    return 0;
+}
+
+int dmx_comm_init_host(dmx_ctx *c, int rank, int nranks, dmx_host_collective collective, void *user, int reduce_dtype)
+{
+    DMX_TRY(bind(c));
+    if (nranks < 1 || rank < 0 || rank >= nranks || !collective) return fail(DMX_ERR_INVALID, "bad communicator arguments");
+    if (reduce_dtype != DMX_F32 && reduce_dtype != DMX_F64) return fail(DMX_ERR_INVALID, "reduce_dtype must be DMX_F32 or DMX_F64");
+    if (c->comm) {
+        g_rccl.CommDestroy(c->comm);
+        c->comm = nullptr;
+    }
+    c->host_coll = collective;
+    c->host_user = user;
+    c->rank = rank;
+    c->nranks = nranks;
+    c->reduce_dtype = reduce_dtype;
     if (c->have_problem) DMX_TRY(layout_exchange(c));
     return 0;
 }

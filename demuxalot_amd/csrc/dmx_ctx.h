@@ -105,7 +105,12 @@ struct dmx_ctx {
     // SNP boundaries, every slice padded to slice_rows rows, so that slice r of any such table is the contiguous,
     // equally sized block ncclReduceScatter / ncclAllGather want.  prow(v) = padded row of variant v.  With one
     // rank (or SNPs whose variants are not contiguous: `sliced` false) the layout is the dense one.
-    ncclComm_t comm = nullptr;
+    ncclComm_t comm = nullptr;                // RCCL communicator (dmx_comm_init), or
+    dmx_host_collective host_coll = nullptr;  // the caller's collectives over host buffers (dmx_comm_init_host)
+    void *host_user = nullptr;
+    void *h_stage = nullptr;                  // pinned staging of the host collectives
+    size_t h_stage_bytes = 0;
+    bool attached() const { return comm != nullptr || host_coll != nullptr; }
     int rank = 0, nranks = 1, reduce_dtype = DMX_F64;
     bool sliced = false;            // reduce-scatter + sliced P-step + all-gather (else: all-reduce + replicated P-step)
     bool add_partial = false;       // only this rank's slice of d_add is current (sliced mode, after an M-step)

@@ -733,7 +733,7 @@ int dmx_mstep_f64(dmx_ctx *c, double contribution_power, float *addition_out)
     if (!c) return fail(DMX_ERR_INVALID, "null context");
     HIP_TRY(hipSetDevice(c->device));
     if (!c->have_problem || !c->have_post64) return fail(DMX_ERR_INVALID, "call order: dmx_estep_snp before dmx_mstep_f64");
-    if (c->comm) return fail(DMX_ERR_UNSUPPORTED, "aggregate_on_snps is single-GPU");
+    if (c->attached()) return fail(DMX_ERR_UNSUPPORTED, "aggregate_on_snps is single-GPU");
     const int G = c->G;
     if (G <= 64) launch_m64<1>(c, contribution_power);
     else if (G <= 128) launch_m64<2>(c, contribution_power);

@@ -29,6 +29,12 @@ class DeviceContext:
         if os.environ.get('DEMUXALOT_AMD_ESTEP_SCHEDULE', 'auto') != 'auto':
             self.set_estep_schedule(os.environ['DEMUXALOT_AMD_ESTEP_SCHEDULE'])
 
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *_exc):
+        self.close()
+
     def close(self):
         if getattr(self, '_h', None):
             self._lib.dmx_destroy(self._h)
@@ -306,6 +312,30 @@ class DeviceContext:
         assert len(unique_id) == _lib.UNIQUE_ID_BYTES
         buf = ctypes.create_string_buffer(unique_id, _lib.UNIQUE_ID_BYTES)
         check(self._lib.dmx_comm_init(self._h, int(rank), int(nranks), buf, DMX_F64 if reduce_dtype == 'f64' else DMX_F32))
+
+    def comm_init_host(self, rank, nranks, collective, reduce_dtype='f64'):
+        """The exchange over the caller's collectives instead of RCCL (include/demux_hip.h: dmx_comm_init_host).
+        collective(op, array): op in ('all_reduce', 'reduce_scatter', 'all_gather'); array is the host buffer as a
+        numpy view, float32 or float64 - [count] for all_reduce (sum in place), [nranks, count] otherwise
+        (reduce_scatter: row `rank` must hold the sum over ranks of their row `rank`; all_gather: row `rank` is
+        filled, every row must be on return).  An exception fails the calling step."""
+        names = {_lib.COLL_ALL_REDUCE: 'all_reduce', _lib.COLL_REDUCE_SCATTER: 'reduce_scatter', _lib.COLL_ALL_GATHER: 'all_gather'}
+
+        def trampoline(_user, op, buf, count, dtype):
+            try:
+                kind = np.float64 if dtype == DMX_F64 else np.float32
+                n = count if op == _lib.COLL_ALL_REDUCE else count * nranks
+                raw = (ctypes.c_char * (n * np.dtype(kind).itemsize)).from_address(buf)
+                view = np.frombuffer(raw, dtype=kind)
+                collective(names[op], view if op == _lib.COLL_ALL_REDUCE else view.reshape(nranks, count))
+                return 0
+            except Exception:  # noqa: BLE001 - the C side turns the code into DemuxHipError
+                import traceback
+                traceback.print_exc()
+                return 1
+        self._host_collective = _lib.HOST_COLLECTIVE(trampoline)  # kept alive with the context
+        check(self._lib.dmx_comm_init_host(self._h, int(rank), int(nranks), self._host_collective, None,
+                                           DMX_F64 if reduce_dtype == 'f64' else DMX_F32))
 
     def set_estep_mode(self, mode):
         """'exact' (default: logits / posteriors bit-identical to the reference) or 'fast' (tolerance mode:

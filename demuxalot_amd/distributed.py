@@ -14,7 +14,9 @@ libdemux_hip.so over RCCL (include/demux_hip.h: "Multi-GPU").  What is left for 
   * `learn_genotypes` / `predict_posteriors` with the reference's signatures plus a `plane` argument.
 
 The control plane is any object with the four methods of `SingleProcess`; `TorchControlPlane` runs them over a
-torch.distributed process group (gloo on the host; the data plane never touches it).
+torch.distributed process group (gloo on the host; the data plane never touches it).  A plane that also has a
+`host_collective(op, array)` method carries the per-iteration exchange itself (staged through host memory) in place
+of RCCL: `TorchControlPlane(host_collectives=True)`, or the thread plane of tests/test_gpu_ranks_on_one_gpu.py.
 """
 import numpy as np
 import pandas as pd
@@ -41,13 +43,28 @@ class SingleProcess:
 
 
 class TorchControlPlane:
-    """Control plane over the default torch.distributed process group (CPU tensors: use a gloo group)."""
+    """Control plane over the default torch.distributed process group (CPU tensors: use a gloo group).
+    With host_collectives=True the per-iteration exchange of the library runs over this group as well (staged through
+    host memory, include/demux_hip.h: dmx_comm_init_host) instead of RCCL - for hosts without a usable RCCL fabric."""
 
-    def __init__(self):
+    def __init__(self, host_collectives=False):
         import torch.distributed as dist
         assert dist.is_initialized(), 'torch.distributed.init_process_group first'
         self._dist = dist
         self.rank, self.world = dist.get_rank(), dist.get_world_size()
+        if host_collectives:
+            self.host_collective = self._host_collective
+
+    def _host_collective(self, op, array):
+        import torch
+        t = torch.from_numpy(array)  # shares the library's staging buffer
+        if op in ('all_reduce', 'reduce_scatter'):  # gloo has no reduce_scatter: row `rank` of the full sum is it
+            self._dist.all_reduce(t)
+        else:
+            parts = [torch.empty_like(t[0]) for _ in range(self.world)]
+            self._dist.all_gather(parts, t[self.rank].clone())
+            for r, part in enumerate(parts):
+                t[r] = part
 
     def broadcast_bytes(self, payload):
         box = [payload if self.rank == 0 else None]
@@ -178,6 +195,9 @@ class ShardedEM:
 
 def attach_communicator(ctx, plane, reduce_dtype='f64', force=False):
     if plane.world == 1 and not force:
+        return
+    if getattr(plane, 'host_collective', None) is not None:  # the plane brings its own collectives
+        ctx.comm_init_host(plane.rank, plane.world, plane.host_collective, reduce_dtype=reduce_dtype)
         return
     make_id = type(ctx).new_unique_id
     unique_id = plane.broadcast_bytes(make_id() if plane.rank == 0 else None)

@@ -304,6 +304,18 @@ int dmx_exchange_slices(int64_t n_variants, const int32_t *v2snp, int32_t nranks
 int dmx_comm_unique_id(void *id_out);
 int dmx_comm_init(dmx_ctx *ctx, int rank, int nranks, const void *unique_id, int reduce_dtype);
 
+/* The same exchange over collectives the CALLER provides (MPI, gloo, a test harness running several ranks on one
+ * GPU ...) instead of RCCL: the library stages the buffer through pinned host memory and calls `collective` on the
+ * ctx stream's host thread; every rank's callback must complete the same collective.  `buf` is a host array:
+ *   DMX_COLL_ALL_REDUCE      buf[count]            in-place sum over ranks
+ *   DMX_COLL_REDUCE_SCATTER  buf[nranks * count]   on return block `rank` (buf + rank * count) = sum over ranks of
+ *                                                   their block `rank`; the other blocks are scratch
+ *   DMX_COLL_ALL_GATHER      buf[nranks * count]   on entry block `rank` is filled; on return every block is
+ * dtype = DMX_F32 or DMX_F64 (element type of buf).  Return 0, or non-zero to fail the calling dmx_* function. */
+enum { DMX_COLL_ALL_REDUCE = 0, DMX_COLL_REDUCE_SCATTER = 1, DMX_COLL_ALL_GATHER = 2 };
+typedef int (*dmx_host_collective)(void *user, int op, void *buf, int64_t count, int dtype);
+int dmx_comm_init_host(dmx_ctx *ctx, int rank, int nranks, dmx_host_collective collective, void *user, int reduce_dtype);
+
 /* Accumulated kernel time per slot (ms, from HIP events on the ctx stream) and launch
  * counts since the last dmx_reset_timings. Arrays of DMX_T_COUNT entries. */
 int dmx_get_timings(dmx_ctx *ctx, double *ms, int64_t *launches);

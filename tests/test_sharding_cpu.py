@@ -78,6 +78,18 @@ def _worker(rank, world, port, out):
     try:
         plane = distributed.TorchControlPlane()
         report = {}
+        # the gloo data plane (dmx_host_collective semantics: include/demux_hip.h)
+        host = distributed.TorchControlPlane(host_collectives=True).host_collective
+        buf = np.arange(world * 5, dtype=np.float64).reshape(world, 5) * (rank + 1)
+        host('reduce_scatter', buf)
+        assert np.array_equal(buf[rank], np.arange(world * 5).reshape(world, 5)[rank] * sum(range(1, world + 1)))
+        buf = np.zeros((world, 3), dtype=np.float32)
+        buf[rank] = rank + 1
+        host('all_gather', buf)
+        assert np.array_equal(buf, np.repeat(np.arange(1, world + 1, dtype=np.float32)[:, None], 3, axis=1))
+        buf = np.full(4, rank + 1, dtype=np.float32)
+        host('all_reduce', buf)
+        assert np.array_equal(buf, np.full(4, sum(range(1, world + 1)), dtype=np.float32))
         # F2 / F1: SNP groups contiguous -> reduce-scatter / sliced P-step / all-gather; F3: scattered -> all-reduce
         for name in ('f2_synthetic_g4.npz', 'f3_small_3.npz', 'f1_synthetic_default.npz'):
             fx = fio.load(name)
