@@ -751,6 +751,7 @@ static int finish_problem(dmx_ctx *c, const int32_t *v2snp, const std::vector<in
     HIP_TRY(hipMemcpyAsync(c->d_snp_ptr, snp_ptr.data(), sizeof(int) * (S + 1), hipMemcpyHostToDevice, st));
     HIP_TRY(hipMemsetAsync(c->d_add, 0, sizeof(float) * (vg ? vg : 1), st));
     if (B) HIP_TRY(hipMemsetAsync(c->d_nz, 0, sizeof(unsigned long long) * (size_t)B * ((G + 63) / 64), st));
+    if (B) HIP_TRY(hipMemsetAsync(c->d_first, 0, sizeof(uint4) * (size_t)B, st));
     HIP_TRY(hipStreamSynchronize(st));  // host staging vectors die in the caller
     DMX_TRY(layout_exchange(c));        // genotype_prob table (padded when a communicator is attached)
     c->have_problem = true;

@@ -457,9 +457,11 @@ static __device__ __forceinline__ void estep_epilogue(const EstepArgs &a, long l
             if (live && li == 0) a.nz[(size_t)b] = (bal >> gbase) & ((1ull << L) - 1ull);
         }
         if (s == 0 && a.first) {
-            // the one posterior most barcodes have, in a table small enough to stay in L2 (M-step)
+            // bitmap + the one posterior most barcodes have, 16 bytes per barcode: ONE gather per call in the M-step,
+            // from a table small enough to stay in L2
             const unsigned long long mine = L == 64 ? bal : ((bal >> gbase) & ((1ull << L) - 1ull));
-            if (live && mine != 0ull && li == __builtin_ctzll(mine)) a.first[b] = post;
+            if (live && li == (mine ? __builtin_ctzll(mine) : 0))
+                a.first[b] = make_uint4((unsigned)mine, (unsigned)(mine >> 32), mine ? __float_as_uint(post) : 0u, 0u);
             // statistic for the M-step's choice of kernel (G <= 64): calls whose barcode has more than 4 live posteriors
             if (a.dense_calls && live && li == 0 && __popcll(mine) > 4)
                 atomicAdd(a.dense_calls + 1 + (b & (DENSE_SLOTS - 1)), (unsigned long long)row_calls);
@@ -893,8 +895,8 @@ __global__ __launch_bounds__(256) void k_estep_block(EstepArgs a, int C, int k_b
         if (s == 0) {  // singlet columns k < G <= 256 all live in slot 0: one bitmap word per wave
             const unsigned long long bal = __ballot(k < G && !(post <= a.nz_floor));
             if (lane == 0 && wave < W) a.nz[(size_t)b * W + wave] = bal;
-            if (a.first && wave == 0 && bal != 0ull && lane == __builtin_ctzll(bal)) {
-                a.first[b] = post;
+            if (a.first && wave == 0 && lane == (bal ? __builtin_ctzll(bal) : 0)) {
+                a.first[b] = make_uint4((unsigned)bal, (unsigned)(bal >> 32), bal ? __float_as_uint(post) : 0u, 0u);
                 if (a.dense_calls && __popcll(bal) > 4)
                     atomicAdd(a.dense_calls + 1 + (b & (DENSE_SLOTS - 1)), (unsigned long long)n_calls);
             }
@@ -940,8 +942,8 @@ __global__ __launch_bounds__(256) void k_softmax_rows(EstepArgs a)
             const unsigned long long bal = __ballot(k < G && !(p <= a.nz_floor));
             const int word = (k0 >> 6) + wave;
             if (lane == 0 && word < W) a.nz[(size_t)b * W + word] = bal;
-            if (a.first && word == 0 && bal != 0ull && lane == __builtin_ctzll(bal)) {
-                a.first[b] = p;
+            if (a.first && word == 0 && lane == (bal ? __builtin_ctzll(bal) : 0)) {
+                a.first[b] = make_uint4((unsigned)bal, (unsigned)(bal >> 32), bal ? __float_as_uint(p) : 0u, 0u);
                 if (a.dense_calls && __popcll(bal) > 4)
                     atomicAdd(a.dense_calls + 1 + (b & (DENSE_SLOTS - 1)), (unsigned long long)(2 * (a.pair_ptr[b + 1] - a.pair_ptr[b])));
             }
@@ -1201,26 +1203,28 @@ __global__ __launch_bounds__(256) void k_mstep_calls(MstepArgs a)
         if (c0 + lane < n) d = calls[c0 + lane];
         return d;
     };
-    auto load_bitmap = [&](int c0, uint2 d) {
-        u64 m = 0ull;  // padding lanes contribute nothing
-        if (c0 + lane < n) m = a.nz[(size_t)d.x];
-        return m;
+    // bitmap and first live posterior of this lane's barcode: one 16-byte gather (the kernel is bound by the number of
+    // gather requests the L2s take: two 4/8-byte gathers per call cost 0.85 ms where this one costs 0.5)
+    auto load_bitmap = [&](int c0, uint2 d, float &pf) {
+        uint4 r = make_uint4(0u, 0u, 0u, 0u);  // padding lanes contribute nothing
+        if (c0 + lane < n) r = a.first[(size_t)d.x];
+        pf = __uint_as_float(r.z);
+        return ((u64)r.y << 32) | r.x;
     };
     // the <= NZ_S posteriors of this lane's call; the common single one comes from the L2-resident table.
     // Every p[t] is written by exactly one conditional load, so that nothing waits for it here.
-    auto load_sparse = [&](u64 m, uint2 d, float (&p)[NZ_S]) {
+    auto load_sparse = [&](u64 m, float pf, uint2 d, float (&p)[NZ_S]) {
         const int nnz = __popcll(m);
         const bool sparse = nnz >= 1 && nnz <= NZ_S;
         const float *__restrict__ row = a.post + (size_t)d.x * K;
-        u64 mm = m;
+        u64 mm = m & (m - 1ull);  // the lowest live posterior came with the bitmap
+        p[0] = sparse ? pf : 0.0f;
         const bool more = __any(sparse && nnz > 1);  // (uniform) most chunks hold single-posterior calls only
 #pragma unroll
-        for (int t = 0; t < NZ_S; t++) {
+        for (int t = 1; t < NZ_S; t++) {
             p[t] = 0.0f;
-            if (t > 0 && !more) continue;
-            const float *src = row + (mm ? __builtin_ctzll(mm) : 0);
-            if (t == 0 && nnz == 1) src = a.first + d.x;
-            if (sparse && mm != 0ull) p[t] = *src;
+            if (!more) continue;
+            if (sparse && mm != 0ull) p[t] = row[__builtin_ctzll(mm)];
             mm &= mm - 1ull;
         }
     };
@@ -1244,16 +1248,17 @@ __global__ __launch_bounds__(256) void k_mstep_calls(MstepArgs a)
 
     // software pipeline: records three chunks ahead, bitmaps two, the sparse calls' posteriors one
     uint2 d0 = load_records(0), d1 = load_records(64), d2 = load_records(128);
-    u64 m0 = load_bitmap(0, d0), m1 = load_bitmap(64, d1);
+    float f0, f1, f2;
+    u64 m0 = load_bitmap(0, d0, f0), m1 = load_bitmap(64, d1, f1);
     u64 dense0 = __ballot(__popcll(m0) > NZ_S);
     float ps0[NZ_S];
-    load_sparse(m0, d0, ps0);
+    load_sparse(m0, f0, d0, ps0);
     for (int c0 = 0; c0 < n; c0 += 64) {
         const uint2 d3 = load_records(c0 + 192);
-        const u64 m2 = load_bitmap(c0 + 128, d2);
+        const u64 m2 = load_bitmap(c0 + 128, d2, f2);
         const u64 dense1 = __ballot(__popcll(m1) > NZ_S);
         float ps1[NZ_S];
-        load_sparse(m1, d1, ps1);
+        load_sparse(m1, f1, d1, ps1);
 
         const float keep = __uint_as_float(d0.y);
         const bool is_dense = (dense0 & bit) != 0ull;
@@ -1358,6 +1363,7 @@ __global__ __launch_bounds__(256) void k_mstep_calls(MstepArgs a)
         }
         d0 = d1; d1 = d2; d2 = d3;
         m0 = m1; m1 = m2;
+        f1 = f2;
         dense0 = dense1;
 #pragma unroll
         for (int t = 0; t < NZ_S; t++) ps0[t] = ps1[t];
@@ -1368,7 +1374,7 @@ __global__ __launch_bounds__(256) void k_mstep_calls(MstepArgs a)
 // one wavefront per (barcode, 64 genotypes): the bitmap and first-posterior table as the E-step writes them
 __global__ __launch_bounds__(256) void k_rebuild_nz(const float *__restrict__ post, long long B, int K, int G,
                                                     float nz_floor, unsigned long long *__restrict__ nz,
-                                                    float *__restrict__ first)
+                                                    uint4 *__restrict__ first)
 {
     const int lane = threadIdx.x & 63;
     const int W = (G + 63) >> 6;
@@ -1380,7 +1386,8 @@ __global__ __launch_bounds__(256) void k_rebuild_nz(const float *__restrict__ po
     if (g < G) p = post[(size_t)b * K + g];
     const unsigned long long bal = __ballot(g < G && !(p <= nz_floor));
     if (lane == 0) nz[word] = bal;
-    if (first && W == 1 && bal != 0ull && lane == __builtin_ctzll(bal)) first[b] = p;
+    if (first && W == 1 && lane == (bal ? __builtin_ctzll(bal) : 0))
+        first[b] = make_uint4((unsigned)bal, (unsigned)(bal >> 32), bal ? __float_as_uint(p) : 0u, 0u);
 }
 
 // Sums the item partials of each variant in item order; writes float32 (single GPU) or the float64 total
@@ -1867,7 +1874,7 @@ hipError_t launch_prior_betas(hipStream_t st, const float *betas, float *bsum, c
 }
 
 hipError_t launch_rebuild_nz(hipStream_t st, const float *post, long long B, int K, int G, float nz_floor,
-                             unsigned long long *nz, float *first)
+                             unsigned long long *nz, uint4 *first)
 {
     const long long words = B * ((G + 63) / 64);
     if (words == 0) return hipSuccess;
