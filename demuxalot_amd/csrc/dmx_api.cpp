@@ -552,6 +552,7 @@ int run_mstep(dmx_ctx *c, float power)
     a.post = c->d_post;
     a.nz = c->d_nz;
     a.first = c->d_first;
+    a.first_bytes = 8ull * (unsigned long long)c->B;
     a.post_bytes = (unsigned long long)c->B * (unsigned long long)c->K * 4ull;
     a.partial = c->d_partial;
     a.n_items = c->n_items;
@@ -751,7 +752,7 @@ static int finish_problem(dmx_ctx *c, const int32_t *v2snp, const std::vector<in
     HIP_TRY(hipMemcpyAsync(c->d_snp_ptr, snp_ptr.data(), sizeof(int) * (S + 1), hipMemcpyHostToDevice, st));
     HIP_TRY(hipMemsetAsync(c->d_add, 0, sizeof(float) * (vg ? vg : 1), st));
     if (B) HIP_TRY(hipMemsetAsync(c->d_nz, 0, sizeof(unsigned long long) * (size_t)B * ((G + 63) / 64), st));
-    if (B) HIP_TRY(hipMemsetAsync(c->d_first, 0, sizeof(uint4) * (size_t)B, st));
+    if (B) HIP_TRY(hipMemsetAsync(c->d_first, 0, sizeof(uint2) * (size_t)B, st));
     HIP_TRY(hipStreamSynchronize(st));  // host staging vectors die in the caller
     DMX_TRY(layout_exchange(c));        // genotype_prob table (padded when a communicator is attached)
     c->have_problem = true;

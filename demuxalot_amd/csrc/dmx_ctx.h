@@ -70,7 +70,7 @@ struct dmx_ctx {
     int estep_mode = DMX_ESTEP_EXACT;  // dmx_set_estep_mode
     int tiled_estep = 1;               // dmx_set_estep_schedule: 0 never, 1 when it pays, 2 whenever the repack built one
     float nz_floor = 0.0f;     // threshold the current d_nz / d_first were built with
-    uint4 *d_first = nullptr;  // [B] {bitmap, posterior of the lowest non-zero singlet column, 0} (G <= 64): EstepArgs::first
+    uint2 *d_first = nullptr;  // [B] {posterior of the lowest live singlet column, count | first live columns} (G <= 64): EstepArgs::first
     unsigned long long *d_dense_calls = nullptr;  // [1] E-step statistic read by the M-step kernels (kernels.h)
     bool dense_stat_valid = false;
     long long cap_bk = 0;

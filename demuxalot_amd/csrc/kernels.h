@@ -33,8 +33,8 @@ struct EstepArgs {
     float *logits;              // [B, K]
     float *post;                // [B, K]
     unsigned long long *nz;     // [B, ceil(G/64)] bit g set <=> !(post[b, g] <= nz_floor) (singlet columns; read by the M-step)
-    uint4 *first;               // nullable [B] (G <= 64): {nz[b] low, high, bits of post[b, lowest set bit of nz[b]], 0}: the
-                                // M-step's one gather per call
+    uint2 *first;               // nullable [B] (G <= 64): {bits of post[b, lowest live genotype], count | first four live
+                                // genotypes} (kernels.hip: nz_code): the M-step's one gather per call
     float nz_floor;             // 0, or NZ_FLOOR_SQUARE when the M-step squares (see below)
     unsigned long long *dense_calls;  // nullable [1 + DENSE_SLOTS]: slot 1 + (b % DENSE_SLOTS) += (padded) calls of every
                                       // barcode b with more than 4 live posteriors (G <= 64); slot 0: their sum (launch_sum_dense)
@@ -68,7 +68,8 @@ struct MstepArgs {
     const uint2 *calls;             // [N] (compressed_cb, bits of 1 - p_base_wrong), variant-major
     const float *post;              // [B, K] posteriors (singlet columns 0..G-1 are read)
     const unsigned long long *nz;   // [B, ceil(G/64)] non-zero bitmap of the singlet posteriors
-    const uint4 *first;             // [B] bitmap + posterior of the lowest non-zero singlet column (G <= 64), as the E-step wrote them
+    unsigned long long first_bytes; // 8 B
+    const uint2 *first;             // [B] bitmap + posterior of the lowest non-zero singlet column (G <= 64), as the E-step wrote them
     double *partial;                // [n_items, G]
     long long n_items;
     long long K;
@@ -128,7 +129,7 @@ hipError_t launch_prior_betas(hipStream_t st, const float *betas, float *bsum, c
                               double default_prior, float *out);
 // recomputes the M-step's bitmap / first-posterior table from the stored posteriors
 hipError_t launch_rebuild_nz(hipStream_t st, const float *post, long long B, int K, int G, float nz_floor,
-                             unsigned long long *nz, uint4 *first);
+                             unsigned long long *nz, uint2 *first);
 hipError_t launch_assign(hipStream_t st, const float *post, long long B, int K, int *best, float *best_p);
 hipError_t launch_test_log(hipStream_t st, const float *in, float *out, long long n);
 hipError_t launch_test_log_hot(hipStream_t st, const float *in, float *out, long long n);

@@ -31,6 +31,24 @@ static __device__ __forceinline__ double shfl_xor_f64(double v, int mask)
     return __hiloint2double(hi, lo);
 }
 
+// What the M-step needs to know of a barcode whose row has at most NZ_CODE live posteriors, in 8 bytes
+// (EstepArgs::first, written by the E-step epilogues): x = bits of the posterior of the lowest live genotype,
+// y = count of live genotypes (7 bits) | the first four live genotypes (6 bits each).  One 8-byte gather per call
+// from a 1.6 MB table (200k barcodes) is what the call-parallel part runs on; the 64-bit bitmap is only read for
+// the dense calls (wave-uniform loads).  [The kernel is bound by the gathers: bitmap (8 B) + posterior (4 B) from
+// two tables took 0.85 ms, one 16-byte record 0.70 (fewer L2 requests, but a 3.2 MB table: 21 % L2 misses).]
+constexpr int NZ_CODE = 4;
+__device__ __forceinline__ uint2 nz_code(unsigned long long live, float first_posterior)
+{
+    unsigned code = (unsigned)__popcll(live);
+#pragma unroll
+    for (int t = 0; t < NZ_CODE; t++) {
+        if (live) code |= (unsigned)__builtin_ctzll(live) << (7 + 6 * t);
+        live &= live - 1ull;
+    }
+    return make_uint2(code & 127u ? __float_as_uint(first_posterior) : 0u, code);
+}
+
 // ------------------------------------------------------------------------------------
 // P-step.  One thread per (variant, genotype).  The per-SNP denominator is the float64 sum
 // of beta over the SNP's variants in increasing variant index (np.bincount order).
@@ -457,11 +475,10 @@ static __device__ __forceinline__ void estep_epilogue(const EstepArgs &a, long l
             if (live && li == 0) a.nz[(size_t)b] = (bal >> gbase) & ((1ull << L) - 1ull);
         }
         if (s == 0 && a.first) {
-            // bitmap + the one posterior most barcodes have, 16 bytes per barcode: ONE gather per call in the M-step,
+            // what the M-step's call-parallel part needs of this barcode, 8 bytes (nz_code): ONE gather per call there,
             // from a table small enough to stay in L2
             const unsigned long long mine = L == 64 ? bal : ((bal >> gbase) & ((1ull << L) - 1ull));
-            if (live && li == (mine ? __builtin_ctzll(mine) : 0))
-                a.first[b] = make_uint4((unsigned)mine, (unsigned)(mine >> 32), mine ? __float_as_uint(post) : 0u, 0u);
+            if (live && li == (mine ? __builtin_ctzll(mine) : 0)) a.first[b] = nz_code(mine, post);
             // statistic for the M-step's choice of kernel (G <= 64): calls whose barcode has more than 4 live posteriors
             if (a.dense_calls && live && li == 0 && __popcll(mine) > 4)
                 atomicAdd(a.dense_calls + 1 + (b & (DENSE_SLOTS - 1)), (unsigned long long)row_calls);
@@ -896,7 +913,7 @@ __global__ __launch_bounds__(256) void k_estep_block(EstepArgs a, int C, int k_b
             const unsigned long long bal = __ballot(k < G && !(post <= a.nz_floor));
             if (lane == 0 && wave < W) a.nz[(size_t)b * W + wave] = bal;
             if (a.first && wave == 0 && lane == (bal ? __builtin_ctzll(bal) : 0)) {
-                a.first[b] = make_uint4((unsigned)bal, (unsigned)(bal >> 32), bal ? __float_as_uint(post) : 0u, 0u);
+                a.first[b] = nz_code(bal, post);
                 if (a.dense_calls && __popcll(bal) > 4)
                     atomicAdd(a.dense_calls + 1 + (b & (DENSE_SLOTS - 1)), (unsigned long long)n_calls);
             }
@@ -943,7 +960,7 @@ __global__ __launch_bounds__(256) void k_softmax_rows(EstepArgs a)
             const int word = (k0 >> 6) + wave;
             if (lane == 0 && word < W) a.nz[(size_t)b * W + word] = bal;
             if (a.first && word == 0 && lane == (bal ? __builtin_ctzll(bal) : 0)) {
-                a.first[b] = make_uint4((unsigned)bal, (unsigned)(bal >> 32), bal ? __float_as_uint(p) : 0u, 0u);
+                a.first[b] = nz_code(bal, p);
                 if (a.dense_calls && __popcll(bal) > 4)
                     atomicAdd(a.dense_calls + 1 + (b & (DENSE_SLOTS - 1)), (unsigned long long)(2 * (a.pair_ptr[b + 1] - a.pair_ptr[b])));
             }
@@ -1169,11 +1186,16 @@ __global__ __launch_bounds__(256) void k_mstep_dense(MstepArgs a)
     if (lane < a.G) a.partial[(size_t)item * a.G + lane] = acc;
 }
 
-template <bool SQUARE, int R, int D>
+// BUF: the three per-lane loads of the call-parallel part (records, barcode code, extra posteriors) as raw buffer
+// loads with 32-bit offsets, inactive lanes pointed out of range (a buffer load past num_records returns 0 and makes
+// no request): no EXEC regions, nothing merged after a load (the compiler otherwise parks an s_waitcnt vmcnt(0)
+// behind the first conditional posterior gather of every chunk).  Needs the posterior table below 4 GiB and
+// barcode indices below 2^24 (launcher).
+template <bool SQUARE, int R, int D, bool BUF>
 __global__ __launch_bounds__(256) void k_mstep_calls(MstepArgs a)
 {
     if (dense_regime(a)) return;
-    constexpr int NZ_S = 4;  // "sparse" call: at most this many non-zero posteriors
+    constexpr int NZ_S = NZ_CODE;  // "sparse" call: at most this many non-zero posteriors
     typedef unsigned long long u64;
     __shared__ float sh_val[4][R * 64];
     __shared__ u64 sh_colmask[4][64];
@@ -1193,42 +1215,97 @@ __global__ __launch_bounds__(256) void k_mstep_calls(MstepArgs a)
     double acc = 0.0;
 
     auto power_of = [&](float c) { return SQUARE ? c * c : powf(c, a.power); };
+    auto genotype = [](unsigned code, int t) { return (int)((code >> (7 + 6 * t)) & 63u); };
     auto lane_u64 = [&](u64 v, int i) {
         const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)v, i);
         const unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(v >> 32), i);
         return ((u64)hi << 32) | lo;
     };
+    constexpr unsigned OOB = 0xFFFFFFFFu;
+    const __amdgpu_buffer_rsrc_t r_calls = __builtin_amdgcn_make_buffer_rsrc((void *)calls, 0, BUF ? n * 8 : 0, 0x00020000);
+    const __amdgpu_buffer_rsrc_t r_first = __builtin_amdgcn_make_buffer_rsrc((void *)a.first, 0, BUF ? (int)a.first_bytes : 0, 0x00020000);
+    const __amdgpu_buffer_rsrc_t r_post = __builtin_amdgcn_make_buffer_rsrc((void *)a.post, 0, BUF ? (int)a.post_bytes : 0, 0x00020000);
+    const unsigned row_bytes = (unsigned)K * 4u;
     auto load_records = [&](int c0) {
-        uint2 d = make_uint2(0u, 0u);
-        if (c0 + lane < n) d = calls[c0 + lane];
-        return d;
-    };
-    // bitmap and first live posterior of this lane's barcode: one 16-byte gather (the kernel is bound by the number of
-    // gather requests the L2s take: two 4/8-byte gathers per call cost 0.85 ms where this one costs 0.5)
-    auto load_bitmap = [&](int c0, uint2 d, float &pf) {
-        uint4 r = make_uint4(0u, 0u, 0u, 0u);  // padding lanes contribute nothing
-        if (c0 + lane < n) r = a.first[(size_t)d.x];
-        pf = __uint_as_float(r.z);
-        return ((u64)r.y << 32) | r.x;
-    };
-    // the <= NZ_S posteriors of this lane's call; the common single one comes from the L2-resident table.
-    // Every p[t] is written by exactly one conditional load, so that nothing waits for it here.
-    auto load_sparse = [&](u64 m, float pf, uint2 d, float (&p)[NZ_S]) {
-        const int nnz = __popcll(m);
-        const bool sparse = nnz >= 1 && nnz <= NZ_S;
-        const float *__restrict__ row = a.post + (size_t)d.x * K;
-        u64 mm = m & (m - 1ull);  // the lowest live posterior came with the bitmap
-        p[0] = sparse ? pf : 0.0f;
-        const bool more = __any(sparse && nnz > 1);  // (uniform) most chunks hold single-posterior calls only
-#pragma unroll
-        for (int t = 1; t < NZ_S; t++) {
-            p[t] = 0.0f;
-            if (!more) continue;
-            if (sparse && mm != 0ull) p[t] = row[__builtin_ctzll(mm)];
-            mm &= mm - 1ull;
+        if constexpr (BUF) {  // past the item's end: zeros (keep bits 0)
+            const auto r = __builtin_amdgcn_raw_buffer_load_b64(r_calls, lane * 8, c0 * 8, 0);
+            return make_uint2(r[0], r[1]);
+        } else {
+            uint2 d = make_uint2(0u, 0u);
+            if (c0 + lane < n) d = calls[c0 + lane];
+            return d;
         }
     };
-    // lane g's posterior of the call held by lane i (0 where the bitmap says so)
+    // {first live posterior, code} of this lane's barcode; padding lanes: no live genotype
+    auto load_code = [&](int c0, uint2 d) {
+        if constexpr (BUF) {
+            const auto q = __builtin_amdgcn_raw_buffer_load_b64(r_first, (int)(c0 + lane < n ? d.x * 8u : OOB), 0, 0);
+            return make_uint2(q[0], q[1]);
+        } else {
+            uint2 r = make_uint2(0u, 0u);
+            if (c0 + lane < n) r = a.first[(size_t)d.x];
+            return r;
+        }
+    };
+    // the <= NZ_S posteriors of this lane's call; the lowest one came with the code.
+    // Every p[t] is written by exactly one load, so that nothing waits for it here.
+    auto load_sparse = [&](uint2 fc, uint2 d, float (&p)[NZ_S]) {
+        const int nnz = (int)(fc.y & 127u);
+        const bool sparse = nnz >= 1 && nnz <= NZ_S;
+        p[0] = sparse ? __uint_as_float(fc.x) : 0.0f;
+        if constexpr (BUF) {  // straight-line: a load with every lane out of range costs its issue only
+            const unsigned base = __umul24(d.x, row_bytes);
+#pragma unroll
+            for (int t = 1; t < NZ_S; t++) {
+                const unsigned off = sparse && t < nnz ? base + 4u * (unsigned)genotype(fc.y, t) : OOB;
+                p[t] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r_post, (int)off, 0, 0));
+            }
+        } else {
+            const bool more = __any(sparse && nnz > 1);  // (uniform) most chunks hold single-posterior calls only
+            const float *__restrict__ row = a.post + (size_t)d.x * K;
+#pragma unroll
+            for (int t = 1; t < NZ_S; t++) {
+                p[t] = 0.0f;
+                if (!more) continue;
+                if (sparse && t < nnz) p[t] = row[genotype(fc.y, t)];
+            }
+        }
+    };
+    // Dense calls (more than NZ_S live posteriors; 3.6 % of the calls of the 200k x 100k x 64 workload once it has
+    // converged, i.e. two or three in nine chunks out of ten) are handled one at a time by the whole wavefront, lane
+    // g taking post[cb, g].  Their rows come from the 51 MB posterior table, i.e. over the fabric: fetched inside
+    // the iteration that needs them, that latency was what the kernel ran on.  So the rows of the first DP dense
+    // calls of a chunk are requested one iteration ahead, unmasked (a dead posterior is simply not used), and the
+    // bitmaps of the dense lanes with them (per-lane gather, other lanes out of range).
+    const __amdgpu_buffer_rsrc_t r_nz = __builtin_amdgcn_make_buffer_rsrc((void *)a.nz, 0, BUF ? (int)a.first_bytes : 0, 0x00020000);
+    auto load_dense_bitmap = [&](uint2 fc, uint2 d) {
+        const bool dense = (int)(fc.y & 127u) > NZ_S;
+        if constexpr (BUF) {
+            const auto q = __builtin_amdgcn_raw_buffer_load_b64(r_nz, (int)(dense ? d.x * 8u : OOB), 0, 0);
+            return ((u64)q[1] << 32) | q[0];
+        } else {
+            u64 m = 0ull;
+            if (dense) m = a.nz[(size_t)d.x];
+            return m;
+        }
+    };
+    constexpr int DP = 2;  // dense rows requested one iteration ahead (registers: 2 DP)
+    auto prefetch_dense_rows = [&](u64 dense, uint2 d, float (&q)[DP]) {
+#pragma unroll
+        for (int j = 0; j < DP; j++) {
+            const bool have = dense != 0ull;  // uniform
+            const unsigned cb = (unsigned)__builtin_amdgcn_readlane((int)d.x, have ? __builtin_ctzll(dense) : 0);
+            dense &= dense - 1ull;
+            if constexpr (BUF) {
+                q[j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r_post, (int)(have && lane < G ? lane * 4u : OOB),
+                                                                                     (int)(cb * row_bytes), 0));
+            } else {
+                q[j] = 0.0f;
+                if (have && lane < G) q[j] = a.post[(size_t)cb * K + lane];
+            }
+        }
+    };
+    // lane g's posterior of the dense call held by lane i, fetched now (calls past the first D of a chunk)
     auto load_dense = [&](uint2 d, u64 m, int i) {
         const unsigned cb = (unsigned)__builtin_amdgcn_readlane((int)d.x, i);
         float v = 0.0f;
@@ -1246,26 +1323,34 @@ __global__ __launch_bounds__(256) void k_mstep_calls(MstepArgs a)
         }
     };
 
-    // software pipeline: records three chunks ahead, bitmaps two, the sparse calls' posteriors one
+#pragma unroll
+    for (int r = 0; r < R; r++) val[r * 64 + lane] = 0.0f;
+    // software pipeline: records three chunks ahead, codes two, the extra posteriors of the sparse calls and the
+    // first rows of the dense ones one
     uint2 d0 = load_records(0), d1 = load_records(64), d2 = load_records(128);
-    float f0, f1, f2;
-    u64 m0 = load_bitmap(0, d0, f0), m1 = load_bitmap(64, d1, f1);
-    u64 dense0 = __ballot(__popcll(m0) > NZ_S);
-    float ps0[NZ_S];
-    load_sparse(m0, f0, d0, ps0);
+    uint2 fc0 = load_code(0, d0), fc1 = load_code(64, d1);
+    u64 dense0 = __ballot((int)(fc0.y & 127u) > NZ_S);
+    float ps0[NZ_S], q0[DP];
+    load_sparse(fc0, d0, ps0);
+    u64 bm0 = load_dense_bitmap(fc0, d0);
+    prefetch_dense_rows(dense0, d0, q0);
     for (int c0 = 0; c0 < n; c0 += 64) {
         const uint2 d3 = load_records(c0 + 192);
-        const u64 m2 = load_bitmap(c0 + 128, d2, f2);
-        const u64 dense1 = __ballot(__popcll(m1) > NZ_S);
-        float ps1[NZ_S];
-        load_sparse(m1, f1, d1, ps1);
+        const uint2 fc2 = load_code(c0 + 128, d2);
+        const u64 dense1 = __ballot((int)(fc1.y & 127u) > NZ_S);
+        float ps1[NZ_S], q1[DP];
+        load_sparse(fc1, d1, ps1);
+        const u64 bm1 = load_dense_bitmap(fc1, d1);
+        prefetch_dense_rows(dense1, d1, q1);
 
         const float keep = __uint_as_float(d0.y);
-        const bool is_dense = (dense0 & bit) != 0ull;
+        const unsigned code = fc0.y;
+        const int nnz = (int)(code & 127u);
+        const int mine_all = nnz <= NZ_S ? nnz : 0;  // queue entries this lane's (sparse) call makes
         // one dense call: lane g appends its contribution to queue g
         auto put_dense = [&](int i, float q, u64 &cm) {
             const float kp = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, keep), i));
-            const bool alive = __builtin_amdgcn_inverse_ballot_w64(lane_u64(m0, i));
+            const bool alive = __builtin_amdgcn_inverse_ballot_w64(lane_u64(bm0, i));
             const u64 call_bit = 1ull << i;
             const int pos = __popcll(cm & (call_bit - 1ull));
             const float c = power_of(q * kp);
@@ -1274,53 +1359,59 @@ __global__ __launch_bounds__(256) void k_mstep_calls(MstepArgs a)
                 cm |= call_bit;
             }
         };
-        auto transpose = [&](u64 mine) {
+        auto transpose = [&](int mine) {
             colmask[lane] = 0ull;
-            while (__any(mine != 0ull)) {
-                if (mine) {
-                    atomicOr(&colmask[__builtin_ctzll(mine)], bit);
-                    mine &= mine - 1ull;
-                }
+#pragma unroll
+            for (int t = 0; t < NZ_S; t++) {
+                if (t > 0 && !__any(t < mine)) break;
+                if (t < mine) atomicOr(&colmask[genotype(code, t)], bit);
             }
             return colmask[lane];
         };
-        auto drain = [&](u64 cm) {  // absent entries add +0.0, which changes nothing
+        auto drain = [&](u64 cm) {
             static_assert(R % 4 == 0, "the drain reads four queue rows at a time");
+            // every queue entry is zero outside [put, drain): what is read is cleared again, so that the rows past a
+            // lane's count need no select (absent entries add +0.0, which changes nothing)
             const int cnt = __popcll(cm);
             for (int r = 0; __any(r < cnt); r += 4) {
-                float v0 = val[(r + 0) * 64 + lane];
-                float v1 = val[(r + 1) * 64 + lane];
-                float v2 = val[(r + 2) * 64 + lane];
-                float v3 = val[(r + 3) * 64 + lane];
-                v0 = r + 0 < cnt ? v0 : 0.0f;
-                v1 = r + 1 < cnt ? v1 : 0.0f;
-                v2 = r + 2 < cnt ? v2 : 0.0f;
-                v3 = r + 3 < cnt ? v3 : 0.0f;
+                const float v0 = val[(r + 0) * 64 + lane];
+                const float v1 = val[(r + 1) * 64 + lane];
+                const float v2 = val[(r + 2) * 64 + lane];
+                const float v3 = val[(r + 3) * 64 + lane];
+                val[(r + 0) * 64 + lane] = 0.0f;
+                val[(r + 1) * 64 + lane] = 0.0f;
+                val[(r + 2) * 64 + lane] = 0.0f;
+                val[(r + 3) * 64 + lane] = 0.0f;
                 acc += (double)v0;
                 acc += (double)v1;
                 acc += (double)v2;
                 acc += (double)v3;
             }
         };
-        auto put_sparse = [&](u64 mine) {
+        auto put_sparse = [&](int mine) {
 #pragma unroll
             for (int t = 0; t < NZ_S; t++) {
-                if (mine) {
-                    const int g = __builtin_ctzll(mine);
-                    mine &= mine - 1ull;
+                if (t > 0 && !__any(t < mine)) break;
+                if (t < mine) {
+                    const int g = genotype(code, t);
                     const int pos = __popcll(colmask[g] & below);
                     val[pos * 64 + g] = power_of(ps0[t] * keep);
                 }
             }
         };
-
-        u64 cm = transpose(is_dense ? 0ull : m0);
-        if (!__any(__popcll(cm) + __popcll(dense0) > R)) {
-            // ---- the whole chunk fits the queues ----
-            u64 todo = dense0;
-            while (todo) {  // dense calls: rows fetched here, D at a time
+        auto put_dense_calls = [&](u64 todo, u64 &cm, bool prefetched) {
+            if (prefetched) {  // the first DP dense calls of the chunk: their rows are here already
+#pragma unroll
+                for (int j = 0; j < DP; j++) {
+                    if (todo) {
+                        put_dense(__builtin_ctzll(todo), q0[j], cm);
+                        todo &= todo - 1ull;
+                    }
+                }
+            }
+            while (todo) {  // rows fetched here, D at a time
                 float q[D];
-                load_dense_rows(todo, d0, m0, q);
+                load_dense_rows(todo, d0, bm0, q);
 #pragma unroll
                 for (int j = 0; j < D; j++) {
                     if (todo) {
@@ -1329,32 +1420,27 @@ __global__ __launch_bounds__(256) void k_mstep_calls(MstepArgs a)
                     }
                 }
             }
+        };
+
+        u64 cm = transpose(mine_all);
+        if (!__any(__popcll(cm) + __popcll(dense0) > R)) {
+            // ---- the whole chunk fits the queues ----
+            put_dense_calls(dense0, cm, true);
             colmask[lane] = cm;
-            put_sparse(is_dense ? 0ull : m0);
+            put_sparse(mine_all);
             drain(cm);
         } else {
             // ---- the queues could overflow: fewer calls at a time (R calls always fit) ----
             int first_lane = 0, width = 32;
             while (first_lane < 64) {
                 const u64 range = ((1ull << width) - 1ull) << first_lane;
-                const u64 mine = (is_dense || !(range & bit)) ? 0ull : m0;
-                u64 todo = dense0 & range;
+                const int mine = (range & bit) ? mine_all : 0;
                 cm = transpose(mine);
-                if (width > R && __any(__popcll(cm) + __popcll(todo) > R)) {
+                if (width > R && __any(__popcll(cm) + __popcll(dense0 & range) > R)) {
                     width >>= 1;
                     continue;
                 }
-                while (todo) {
-                    float q[D];
-                    load_dense_rows(todo, d0, m0, q);
-#pragma unroll
-                    for (int j = 0; j < D; j++) {
-                        if (todo) {
-                            put_dense(__builtin_ctzll(todo), q[j], cm);
-                            todo &= todo - 1ull;
-                        }
-                    }
-                }
+                put_dense_calls(dense0 & range, cm, false);
                 colmask[lane] = cm;
                 put_sparse(mine);
                 drain(cm);
@@ -1362,9 +1448,11 @@ __global__ __launch_bounds__(256) void k_mstep_calls(MstepArgs a)
             }
         }
         d0 = d1; d1 = d2; d2 = d3;
-        m0 = m1; m1 = m2;
-        f1 = f2;
+        fc0 = fc1; fc1 = fc2;
         dense0 = dense1;
+        bm0 = bm1;
+#pragma unroll
+        for (int j = 0; j < DP; j++) q0[j] = q1[j];
 #pragma unroll
         for (int t = 0; t < NZ_S; t++) ps0[t] = ps1[t];
     }
@@ -1374,7 +1462,7 @@ __global__ __launch_bounds__(256) void k_mstep_calls(MstepArgs a)
 // one wavefront per (barcode, 64 genotypes): the bitmap and first-posterior table as the E-step writes them
 __global__ __launch_bounds__(256) void k_rebuild_nz(const float *__restrict__ post, long long B, int K, int G,
                                                     float nz_floor, unsigned long long *__restrict__ nz,
-                                                    uint4 *__restrict__ first)
+                                                    uint2 *__restrict__ first)
 {
     const int lane = threadIdx.x & 63;
     const int W = (G + 63) >> 6;
@@ -1387,7 +1475,7 @@ __global__ __launch_bounds__(256) void k_rebuild_nz(const float *__restrict__ po
     const unsigned long long bal = __ballot(g < G && !(p <= nz_floor));
     if (lane == 0) nz[word] = bal;
     if (first && W == 1 && lane == (bal ? __builtin_ctzll(bal) : 0))
-        first[b] = make_uint4((unsigned)bal, (unsigned)(bal >> 32), bal ? __float_as_uint(p) : 0u, 0u);
+        first[b] = nz_code(bal, p);
 }
 
 // Sums the item partials of each variant in item order; writes float32 (single GPU) or the float64 total
@@ -1791,10 +1879,18 @@ hipError_t launch_mstep(hipStream_t st, const MstepArgs &a)
     if (G <= 64) {
         // call-parallel form: 16-entry queues (8 waves per SIMD), dense rows fetched 4 at a time
         const dim3 grid(blocks_for(a.n_items, 4));
+        // 32-bit offsets: posterior table below 4 GiB, barcode index below 2^24 (v_mul_u32_u24), row below 2^24 bytes
+        const bool buf = a.post_bytes < (1ull << 32) && a.first_bytes < (8ull << 24) && a.K < (1 << 22);
+#define MSTEP_CALLS(SQ)                                                                             \
+    do {                                                                                            \
+        if (buf) hipLaunchKernelGGL((k_mstep_calls<SQ, 16, 4, true>), grid, dim3(256), 0, st, a);   \
+        else hipLaunchKernelGGL((k_mstep_calls<SQ, 16, 4, false>), grid, dim3(256), 0, st, a);      \
+    } while (0)
         if (a.square)
-            hipLaunchKernelGGL((k_mstep_calls<true, 16, 4>), grid, dim3(256), 0, st, a);
+            MSTEP_CALLS(true);
         else
-            hipLaunchKernelGGL((k_mstep_calls<false, 16, 4>), grid, dim3(256), 0, st, a);
+            MSTEP_CALLS(false);
+#undef MSTEP_CALLS
         if (a.dense_calls) {  // the dense regime's kernel; exactly one of the two does the work (dense_regime)
             if (a.square)
                 hipLaunchKernelGGL((k_mstep_dense<true>), grid, dim3(256), 0, st, a);
@@ -1874,7 +1970,7 @@ hipError_t launch_prior_betas(hipStream_t st, const float *betas, float *bsum, c
 }
 
 hipError_t launch_rebuild_nz(hipStream_t st, const float *post, long long B, int K, int G, float nz_floor,
-                             unsigned long long *nz, uint4 *first)
+                             unsigned long long *nz, uint2 *first)
 {
     const long long words = B * ((G + 63) / 64);
     if (words == 0) return hipSuccess;

@@ -14,6 +14,8 @@
 // the ctx stream.
 #include <cstring>
 
+#include <cstdlib>
+#include <algorithm>
 #include <hip/hip_runtime.h>
 #include <rocprim/rocprim.hpp>
 
@@ -307,6 +309,7 @@ static int repack_core(dmx_ctx *c, Scratch &sc, const int *d_variant, const int 
     const int G = c->G;
     hipStream_t st = c->stream;
     c->item_calls = item_calls_for(N);
+    if (const char *forced = std::getenv("DEMUXALOT_AMD_ITEM_CALLS")) c->item_calls = std::max(64, std::atoi(forced));  // experiments
 
     // the sorts below carry call indices as 32-bit values
     if (N >= (1LL << 32)) return fail(DMX_ERR_UNSUPPORTED, "%lld calls: one context holds fewer than 2^32 (shard the barcodes)", N);
