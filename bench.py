@@ -84,12 +84,12 @@ def cpu_baseline(problem, betas, doublet_prior, target_seconds=15.0):
                 host_cores=os.cpu_count()), logits, post, n_sample
 
 
-# VALU issue model of the exact-mode E-step term (direct kernels, K <= 1024), from the instruction count of
-# estep_terms + log_f32_hot2 per two terms (17 packed float32, 4 plain integer, 2 v_cvt_f32_i32, 2 v_mad_i32_i24,
-# 2 v_rcp_f32, 2 v_cvt_f64_f32, 2 v_add_f64) and the issue costs measured by scripts/valu_issue_bench.hip on this
-# chip with >= 2 waves per SIMD (profiles/r2_valu_issue_bench.txt): plain 2.4 cycles, packed float32 / float64 /
-# conversions / v_mad_i32_i24 4.4, transcendental 8.3.
-VALU_CYCLES_PER_TERM = (17 * 4.4 + 4 * 2.4 + 2 * 4.4 + 2 * 4.4 + 2 * 8.3 + 2 * 4.4 + 2 * 4.4) / 2
+# VALU issue model of the exact-mode E-step term (direct kernels, K <= 1024), from the instruction count of the main
+# loop of k_estep_direct<64,1,false,8,false> per two terms (ISA: 124 VALU per 8 calls = 15.5 per term: 17 packed
+# float32, 6 plain integer, 2 v_cvt_f32_i32, 2 v_rcp_f32, 2 v_cvt_f64_f32, 2 v_add_f64) and the issue costs measured by
+# scripts/valu_issue_bench.hip on this chip with >= 2 waves per SIMD (profiles/r2_valu_issue_bench.txt): plain 2.4
+# cycles, packed float32 / float64 / conversions 4.4, transcendental 8.3.
+VALU_CYCLES_PER_TERM = (17 * 4.4 + 6 * 2.4 + 2 * 4.4 + 2 * 8.3 + 2 * 4.4 + 2 * 4.4) / 2
 N_SIMD, PEAK_CLOCK_HZ = 1024, 2.4e9
 
 

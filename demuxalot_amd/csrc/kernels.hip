@@ -35,8 +35,8 @@ static __device__ __forceinline__ double shfl_xor_f64(double v, int mask)
 // (EstepArgs::first, written by the E-step epilogues): x = bits of the posterior of the lowest live genotype,
 // y = count of live genotypes (7 bits) | the first four live genotypes (6 bits each).  One 8-byte gather per call
 // from a 1.6 MB table (200k barcodes) is what the call-parallel part runs on; the 64-bit bitmap is only read for
-// the dense calls (wave-uniform loads).  [The kernel is bound by the gathers: bitmap (8 B) + posterior (4 B) from
-// two tables took 0.85 ms, one 16-byte record 0.70 (fewer L2 requests, but a 3.2 MB table: 21 % L2 misses).]
+// the dense calls.  [The M-step runs on its loads, not on its arithmetic: bitmap (8 B) + posterior
+// (4 B) from two tables took 0.85 ms - the L2s at 65 % of their request rate -, one gather 0.70.]
 constexpr int NZ_CODE = 4;
 __device__ __forceinline__ uint2 nz_code(unsigned long long live, float first_posterior)
 {
