@@ -55,7 +55,9 @@ __device__ __forceinline__ uint2 nz_code(unsigned long long live, float first_po
 // ------------------------------------------------------------------------------------
 // T = float: the EM path (betas + addition, both float32).  T = double: caller-supplied float64 betas
 // (numpy then divides float64 by float64 and rounds once to float32; no addition).
-template <typename T>
+// L lanes share one variant row (genotypes li, li + L, ...); the row of a SNP's FIRST variant does the whole group, so
+// that every beta is read once and the denominator is formed once per SNP (two variants per SNP: half the rows exit).
+template <typename T, int L>
 __global__ __launch_bounds__(256) void k_probs_from_betas(const T *__restrict__ prior,
                                                           const T *__restrict__ addition,
                                                           const int *__restrict__ v2snp,
@@ -64,24 +66,40 @@ __global__ __launch_bounds__(256) void k_probs_from_betas(const T *__restrict__ 
                                                           long long n_rows, int G, const int *__restrict__ prow,
                                                           float clip_lo, float clip_hi, float *__restrict__ prob)
 {
-    // variants [v_begin, v_begin + n_rows); prob row of variant v = prow[v] (padded multi-GPU layout) or v
-    const long long j = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (j >= n_rows * G) return;
-    const long long v = v_begin + j / G;
-    const int g = (int)(j % G);
-    const long long i = v * G + g;
+    // variants [v_begin, v_begin + n_rows): whole SNP groups; prob row of variant v = prow[v] (padded multi-GPU
+    // layout) or v
+    const int lane = threadIdx.x & 63, li = lane & (L - 1);
+    const long long r = ((long long)blockIdx.x * 4 + (threadIdx.x >> 6)) * (64 / L) + lane / L;
+    if (r >= n_rows) return;
+    const long long v = v_begin + r;
     const int snp = v2snp[v];
-    double den = 0.0;
-    for (int j = snp_ptr[snp]; j < snp_ptr[snp + 1]; j++) {
-        const long long o = (long long)snp_vars[j] * G + g;
-        const T b = addition ? prior[o] + addition[o] : prior[o];  // float32 add, demux.py:90
-        den += (double)b;
+    const int j0 = snp_ptr[snp], j1 = snp_ptr[snp + 1];
+    if (snp_vars[j0] != v) return;
+    constexpr int HELD = 4;  // betas of the first variants of the group stay in registers
+    for (int g = li; g < G; g += L) {
+        T held[HELD];
+        double den = 0.0;
+        for (int j = j0; j < j1; j++) {  // increasing variant index (np.bincount order)
+            const long long o = (long long)snp_vars[j] * G + g;
+            const T b = addition ? prior[o] + addition[o] : prior[o];  // float32 add, demux.py:90
+            if (j - j0 < HELD) held[j - j0] = b;
+            den += (double)b;
+        }
+        den = fmax(den, 1e-7);
+        for (int j = j0; j < j1; j++) {
+            const long long w = snp_vars[j];
+            T beta;
+            if (j - j0 < HELD) {
+                beta = held[j - j0];
+            } else {
+                const long long o = w * G + g;
+                beta = addition ? prior[o] + addition[o] : prior[o];
+            }
+            float p = (float)((double)beta / den);
+            p = fminf(fmaxf(p, clip_lo), clip_hi);  // ndarray.clip(lo, hi) = minimum(maximum(x, lo), hi)
+            prob[(prow ? (long long)prow[w] : w) * G + g] = p;
+        }
     }
-    const T beta = addition ? prior[i] + addition[i] : prior[i];
-    const double q = (double)beta / fmax(den, 1e-7);
-    float p = (float)q;
-    p = fminf(fmaxf(p, clip_lo), clip_hi);  // ndarray.clip(lo, hi) = minimum(maximum(x, lo), hi)
-    prob[(prow ? (long long)prow[v] : v) * G + g] = p;
 }
 
 // ------------------------------------------------------------------------------------
@@ -1726,24 +1744,36 @@ __global__ __launch_bounds__(64) void k_test_softmax(const float *in, float *out
 // ------------------------------------------------------------------------------------
 static inline unsigned blocks_for(long long n, int per_block) { return (unsigned)((n + per_block - 1) / per_block); }
 
+template <typename T>
+static hipError_t launch_pstep(hipStream_t st, const T *prior, const T *addition, const int *v2snp, const int *snp_ptr,
+                               const int *snp_vars, long long v_begin, long long n_rows, int G, const int *prow, float lo, float hi,
+                               float *prob)
+{
+    if (n_rows * G == 0) return hipSuccess;
+#define PSTEP(L)                                                                                                          \
+    hipLaunchKernelGGL((k_probs_from_betas<T, L>), dim3(blocks_for(n_rows, 4 * (64 / L))), dim3(256), 0, st, prior, addition, \
+                       v2snp, snp_ptr, snp_vars, v_begin, n_rows, G, prow, lo, hi, prob)
+    if (G <= 4) PSTEP(4);
+    else if (G <= 8) PSTEP(8);
+    else if (G <= 16) PSTEP(16);
+    else if (G <= 32) PSTEP(32);
+    else PSTEP(64);
+#undef PSTEP
+    return hipGetLastError();
+}
+
 hipError_t launch_probs_from_betas(hipStream_t st, const float *prior, const float *addition, const int *v2snp,
                                    const int *snp_ptr, const int *snp_vars, long long v_begin, long long n_rows, int G,
                                    const int *prow, float lo, float hi, float *prob)
 {
-    if (n_rows * G == 0) return hipSuccess;
-    hipLaunchKernelGGL(k_probs_from_betas<float>, dim3(blocks_for(n_rows * G, 256)), dim3(256), 0, st, prior, addition, v2snp,
-                       snp_ptr, snp_vars, v_begin, n_rows, G, prow, lo, hi, prob);
-    return hipGetLastError();
+    return launch_pstep<float>(st, prior, addition, v2snp, snp_ptr, snp_vars, v_begin, n_rows, G, prow, lo, hi, prob);
 }
 
 hipError_t launch_probs_from_betas_f64(hipStream_t st, const double *betas, const int *v2snp, const int *snp_ptr,
                                        const int *snp_vars, long long V, int G, const int *prow, float lo, float hi,
                                        float *prob)
 {
-    if (V * G == 0) return hipSuccess;
-    hipLaunchKernelGGL(k_probs_from_betas<double>, dim3(blocks_for(V * G, 256)), dim3(256), 0, st, betas,
-                       (const double *)nullptr, v2snp, snp_ptr, snp_vars, 0LL, V, G, prow, lo, hi, prob);
-    return hipGetLastError();
+    return launch_pstep<double>(st, betas, (const double *)nullptr, v2snp, snp_ptr, snp_vars, 0LL, V, G, prow, lo, hi, prob);
 }
 
 // flags[0] |= 1 when any of the n values is outside [0, 1] or not finite (caller-supplied probability tables)
