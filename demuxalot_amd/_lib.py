@@ -71,6 +71,7 @@ SIGNATURES = {
     'dmx_set_exact_additions': (c_int, [_P, c_int]),
     'dmx_set_estep_mode': (c_int, [_P, c_int]),
     'dmx_set_estep_schedule': (c_int, [_P, c_int]),
+    'dmx_set_mstep_wide_addresses': (c_int, [_P, c_int]),
     'dmx_test_logf': (c_int, [_P, _P, _P, c_int64]),
     'dmx_test_logf_hot': (c_int, [_P, _P, _P, c_int64]),
     'dmx_test_expf': (c_int, [_P, _P, _P, c_int64]),

@@ -553,6 +553,7 @@ int run_mstep(dmx_ctx *c, float power)
     a.nz = c->d_nz;
     a.first = c->d_first;
     a.first_bytes = 8ull * (unsigned long long)c->B;
+    a.wide = c->mstep_wide;
     a.post_bytes = (unsigned long long)c->B * (unsigned long long)c->K * 4ull;
     a.partial = c->d_partial;
     a.n_items = c->n_items;
@@ -854,6 +855,13 @@ int dmx_set_estep_schedule(dmx_ctx *c, int tiled)
     if (!c) return fail(DMX_ERR_INVALID, "null context");
     if (tiled < 0 || tiled > 2) return fail(DMX_ERR_INVALID, "schedule must be 0, 1 or 2");
     c->tiled_estep = tiled;
+    return 0;
+}
+
+int dmx_set_mstep_wide_addresses(dmx_ctx *c, int wide)
+{
+    if (!c) return fail(DMX_ERR_INVALID, "null context");
+    c->mstep_wide = wide != 0;
     return 0;
 }
 

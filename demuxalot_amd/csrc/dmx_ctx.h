@@ -65,6 +65,7 @@ struct dmx_ctx {
     unsigned long long *d_redo = nullptr;  // (variant, genotype) sums to be redone in order (k_mcombine)
     unsigned *d_n_redo = nullptr;
     size_t cap_redo = 0;
+    bool mstep_wide = false;  // dmx_set_mstep_wide_addresses
     int item_calls = 1024;  // work-item length of the resident problem (kernels.h: item_calls_for)
     bool exact_additions = true;  // dmx_set_exact_additions
     int estep_mode = DMX_ESTEP_EXACT;  // dmx_set_estep_mode

@@ -68,6 +68,7 @@ struct MstepArgs {
     const uint2 *calls;             // [N] (compressed_cb, bits of 1 - p_base_wrong), variant-major
     const float *post;              // [B, K] posteriors (singlet columns 0..G-1 are read)
     const unsigned long long *nz;   // [B, ceil(G/64)] non-zero bitmap of the singlet posteriors
+    bool wide;                      // never use 32-bit buffer offsets (dmx_set_mstep_wide_addresses)
     unsigned long long first_bytes; // 8 B
     const uint2 *first;             // [B] bitmap + posterior of the lowest non-zero singlet column (G <= 64), as the E-step wrote them
     double *partial;                // [n_items, G]

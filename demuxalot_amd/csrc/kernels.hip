@@ -1910,7 +1910,7 @@ hipError_t launch_mstep(hipStream_t st, const MstepArgs &a)
         // call-parallel form: 16-entry queues (8 waves per SIMD), dense rows fetched 4 at a time
         const dim3 grid(blocks_for(a.n_items, 4));
         // 32-bit offsets: posterior table below 4 GiB, barcode index below 2^24 (v_mul_u32_u24), row below 2^24 bytes
-        const bool buf = a.post_bytes < (1ull << 32) && a.first_bytes < (8ull << 24) && a.K < (1 << 22);
+        const bool buf = !a.wide && a.post_bytes < (1ull << 32) && a.first_bytes < (8ull << 24) && a.K < (1 << 22);
 #define MSTEP_CALLS(SQ)                                                                             \
     do {                                                                                            \
         if (buf) hipLaunchKernelGGL((k_mstep_calls<SQ, 16, 4, true>), grid, dim3(256), 0, st, a);   \

@@ -347,6 +347,10 @@ class DeviceContext:
         include/demux_hip.h: dmx_set_estep_schedule."""
         check(self._lib.dmx_set_estep_schedule(self._h, {'direct': 0, 'auto': 1, 'tiled': 2}[schedule]))
 
+    def set_mstep_wide_addresses(self, wide):
+        """include/demux_hip.h: dmx_set_mstep_wide_addresses (the M-step form of the largest problems, at any size)."""
+        check(self._lib.dmx_set_mstep_wide_addresses(self._h, int(bool(wide))))
+
     def set_exact_additions(self, exact):
         """M-step summation mode (include/demux_hip.h: dmx_set_exact_additions). Default: exact."""
         check(self._lib.dmx_set_exact_additions(self._h, int(bool(exact))))

@@ -169,6 +169,11 @@ int dmx_set_estep_mode(dmx_ctx *ctx, int mode);
  * E-step mode are bit-identical under every schedule. */
 int dmx_set_estep_schedule(dmx_ctx *ctx, int tiled);
 
+/* M-step loads (G <= 64).  wide = 0 (default): 32-bit buffer offsets wherever the tables allow (posterior table below
+ * 4 GiB, fewer than 2^24 barcodes), 64-bit addresses otherwise.  wide = 1: always 64-bit addresses - the form the
+ * largest problems run, selectable so that it can be exercised at any size.  Results are bit-identical. */
+int dmx_set_mstep_wide_addresses(dmx_ctx *ctx, int wide);
+
 /* genotype_addition float32[V*G]; NULL resets it to zero (demux.py:86). */
 int dmx_set_addition(dmx_ctx *ctx, const float *addition);
 

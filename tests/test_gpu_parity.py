@@ -543,3 +543,29 @@ def test_doublets_block_kernel_matches_oracle(oracle):
         hist = oracle.em(packed, B, 2, 0.01, 0.3, impl='npsimd')
         check_posteriors(logits, probs, hist[-1]['logits'], hist[-1]['probs'], f'doublets G={G}')
         fio.assert_bitwise(addition, hist[-1]['addition'], f'doublets G={G} addition')
+
+
+@pytest.mark.parametrize('G,cpb,power', [(64, 160, 2.), (6, 400, 2.), (33, 250, 2.), (20, 120, 1.5)])
+def test_mstep_wide_addresses_are_the_same_sums(G, cpb, power):
+    """The call-parallel M-step has two forms of its loads: 32-bit buffer offsets (tables below 4 GiB) and 64-bit
+    addresses (the largest problems).  dmx_set_mstep_wide_addresses selects the second at any size: both must give
+    the same bits - on problems with sparse, multi-posterior and dense calls and queue overflows (small G)."""
+    from demuxalot_amd import synth
+    from demuxalot_amd.device import get_context
+    p = synth.generate(3000, 1500, G, calls_per_barcode=cpb, seed=G + 5)
+    ctx = get_context()
+    ctx.set_problem(p.n_barcodes, p.n_variants, G, p.variant_id, p.compressed_cb, p.p_base_wrong, p.v2snp)
+    ctx.set_betas(p.prior_betas())
+    ctx.set_addition(None)
+    ctx.probs_from_betas(0.01, fetch=False)
+    _logits, probs = ctx.estep(np.zeros(G, dtype=np.float32), with_doublets=False)
+    nnz = (probs > np.float32(2.0 ** -80)).sum(1) if power == 2. else (probs != 0).sum(1)
+    assert (nnz == 1).any() and ((nnz > 1) & (nnz <= 4)).any() and (nnz > 4).any(), 'the problem must mix the three kinds of calls'
+    narrow = ctx.mstep(power)
+    try:
+        ctx.set_mstep_wide_addresses(True)
+        wide = ctx.mstep(power)
+    finally:
+        ctx.set_mstep_wide_addresses(False)
+    fio.assert_bitwise(wide, narrow, f'wide vs 32-bit M-step loads, G={G}')
+    assert np.array_equal(narrow, ctx.mstep(power))
