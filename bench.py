@@ -113,7 +113,7 @@ def roofline(workload, ab, e_ms, m_ms, timers, N, G, K):
                  'cycles_per_term_model': VALU_CYCLES_PER_TERM,
                  'note': 'exact-mode term = numpy float32 log repeated operation for operation + float64 accumulate; issue costs '
                          'from profiles/r2_valu_issue_bench.txt; peak at the nominal 2.4 GHz (the kernel sustains ~2.0-2.1 GHz); '
-                         'K > 1024 (k_estep_block) adds two LDS reads per term pair'},
+                         'K > 1024 (k_estep_block) adds two LDS reads per term pair and option'},
         'note': 'frac is the HBM fraction the contract asks for (algorithmic bytes / time / 8 TB/s); the kernel is bound by '
                 'VALU issue (valu.frac), not by HBM: see DESIGN.md 4',
     }

@@ -5,7 +5,7 @@
 //                        up to 16 options per lane (K <= 1024)   demux.py:246-265, :101/:152
 //   k_estep_block        E-step + softmax, one 256-thread workgroup per barcode, genotype
 //                        rows staged in LDS (K > 1024: doublets of 45 or more genotypes)
-//   k_softmax_rows       finishes rows whose options were tiled over several k_estep_block launches (K > 8448)
+//   k_softmax_rows       finishes rows whose options were tiled over several k_estep_block launches (K > 4096)
 //   k_mstep_calls / k_mstep / k_mcombine / k_mstep_exact
 //                        M-step (variant-major, no atomics)      demux.py:113-118
 //   k_assign             per-barcode argmax of the posterior
@@ -1818,13 +1818,16 @@ static hipError_t launch_block(hipStream_t st, const EstepArgs &a, int k_base = 
     size_t soft = TILED ? 0 : (size_t)a.K * 4 + 64;
     size_t bytes = stage > soft ? stage : soft;
     bytes = (bytes + 15) & ~size_t(15);
-    // The tolerance mode (a.fast) is not used here: this form is bound by its LDS reads (two ds_read_b64 per term
-    // pair and option), not by the log, and the extra registers of the running products halve its occupancy
-    // (measured on 130k x 650k x 128 with doublets: 344 ms against 299 ms).  K > 1024 always runs the exact arithmetic.
-    hipError_t e = hipFuncSetAttribute((const void *)k_estep_block<A, TILED, false>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                       (int)bytes);
+    // Tolerance mode (a.fast): with 33 accumulators per thread the running products' registers halved the occupancy and
+    // the mode did not pay (344 ms against 299 ms on 130k x 650k x 128 with doublets); with tiles of at most 17 it does
+    // (212 ms against 257 ms).
+    const void *kernel = a.fast ? (const void *)k_estep_block<A, TILED, true> : (const void *)k_estep_block<A, TILED, false>;
+    hipError_t e = hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL((k_estep_block<A, TILED, false>), dim3((unsigned)a.B), dim3(256), bytes, st, a, C, k_base);
+    if (a.fast)
+        hipLaunchKernelGGL((k_estep_block<A, TILED, true>), dim3((unsigned)a.B), dim3(256), bytes, st, a, C, k_base);
+    else
+        hipLaunchKernelGGL((k_estep_block<A, TILED, false>), dim3((unsigned)a.B), dim3(256), bytes, st, a, C, k_base);
     return hipGetLastError();
 }
 
@@ -1875,13 +1878,15 @@ hipError_t launch_estep(hipStream_t st, const EstepArgs &a, bool pairs)
     if (need <= 8) return launch_block<8, false>(st, a);
     if (need <= 12) return launch_block<12, false>(st, a);
     if (need <= 16) return launch_block<16, false>(st, a);
-    if (need <= 24) return launch_block<24, false>(st, a);
-    if (need <= 33) return launch_block<33, false>(st, a);
-    // more options than 33 per thread: tiles of 33 * 256 options, each tile one launch that leaves its logits,
-    // then the softmax over complete rows.  (Tiles of 65 accumulators per thread -- 385 VGPRs plus SGPR spills --
-    // ended in GPU memory faults that 33-wide tiles of the same source do not show; cause not established.)
-    for (int k_base = 0; k_base < K; k_base += 33 * 256) {
-        const hipError_t e = launch_block<33, true>(st, a, k_base);
+    // More than 16 options per thread: the options are cut into tiles of 12 or 17 per thread, each tile one launch that
+    // leaves its logits, then the softmax over complete rows.  With 33 accumulators per thread (236 VGPRs, 2 waves per
+    // SIMD) one launch took 297 ms on 130k x 650k x 128 with doublets (K = 8256); two launches of 17 (4 waves per
+    // SIMD) take 257 ms although every tile stages the barcode's genotype rows again; three of 12: 264 ms.
+    // (Tiles of 65 accumulators per thread -- 385 VGPRs plus SGPR spills -- ended in GPU memory faults that narrower
+    // tiles of the same source do not show: profiles/r2_block_tile65_experiment.txt.)
+    const int tile = need <= 24 ? 12 : 17;
+    for (int k_base = 0; k_base < K; k_base += tile * 256) {
+        const hipError_t e = tile == 12 ? launch_block<12, true>(st, a, k_base) : launch_block<17, true>(st, a, k_base);
         if (e != hipSuccess) return e;
     }
     hipLaunchKernelGGL(k_softmax_rows, dim3((unsigned)a.B), dim3(256), 0, st, a);
