@@ -38,6 +38,7 @@ WORKLOADS = {
     'em_20k_10k_64': (20_000, 10_000, 64, 0.0, 77),         # quick check
     'em_200k_4k_64': (200_000, 4_000, 64, 0.0, 78),         # diagnostic: 2 MB genotype table (every row gather hits L2)
     'predict_20k_20k_32_doublets': (20_000, 20_000, 32, 0.25, 1240),   # K = 528: workgroup-per-barcode kernel
+    'predict_20k_20k_64_doublets': (20_000, 20_000, 64, 0.25, 1243),   # K = 2080: doublets of 64 genotypes
     'predict_5k_20k_128_doublets': (5_000, 20_000, 128, 0.25, 1241),   # K = 8256 (configs[4] option count)
     'em_130k_650k_128_doublets': (130_000, 650_000, 128, 0.25, 1242),  # one rank's share of configs[4] (1M x 650k x 128 on 8 GPUs)
 }

@@ -3,9 +3,9 @@
 //   k_probs_from_betas   P-step   demuxalot/demux.py:267-274
 //   k_estep_direct       E-step + softmax, one lane group (4..64 lanes) per barcode, options on lanes,
 //                        up to 16 options per lane (K <= 1024)   demux.py:246-265, :101/:152
-//   k_estep_block        E-step + softmax, one 256-thread workgroup per barcode, genotype
+//   k_estep_block        E-step logits, one 256-thread workgroup per barcode and tile of options, genotype
 //                        rows staged in LDS (K > 1024: doublets of 45 or more genotypes)
-//   k_softmax_rows       finishes rows whose options were tiled over several k_estep_block launches (K > 4096)
+//   k_softmax_rows       softmax, bitmaps and codes of the rows k_estep_block left as logits
 //   k_mstep_calls / k_mstep / k_mcombine / k_mstep_exact
 //                        M-step (variant-major, no atomics)      demux.py:113-118
 //   k_assign             per-barcode argmax of the posterior
@@ -788,7 +788,7 @@ __global__ __launch_bounds__(256) void k_estep_tiled(EstepArgs a)
 // ------------------------------------------------------------------------------------
 // K > 33 * 256 options (doublets of more than 129 genotypes): the options are cut into tiles of 33 * 256, each
 // tile is one launch that only leaves its logits (TILED), and k_softmax_rows finishes the rows.
-template <int A, bool TILED, bool FAST>
+template <int A, bool FAST>
 __global__ __launch_bounds__(256) void k_estep_block(EstepArgs a, int C, int k_base)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -796,8 +796,7 @@ __global__ __launch_bounds__(256) void k_estep_block(EstepArgs a, int C, int k_b
     const long long b = a.order[blockIdx.x];
     const int K = a.K, G = a.G;
     const int CS = C + 2;
-    // LDS carve: sh_t [G*CS] f32 | keep [C] | floor [C] | row offsets [C]; the softmax reuses the
-    // front of the buffer for K floats + 8 (launcher sizes smem for the larger of the two).
+    // LDS carve: sh_t [G*CS] f32 | keep [C] | floor [C] | row offsets [C]
     float *sh_t = (float *)smem;
     float *sh_keep = sh_t + (size_t)G * CS;
     float *sh_floor = sh_keep + C;
@@ -872,11 +871,8 @@ __global__ __launch_bounds__(256) void k_estep_block(EstepArgs a, int C, int k_b
     }
     __syncthreads();
 
-    // logits -> LDS, block max, exp, numpy-ordered sum by wave 0, divide
-    float *sh_x = (float *)smem;  // K floats
-    float *sh_red = sh_x + K;     // 8 floats
-    float mx = -__builtin_inff();
-    float lg[A];
+    // logits of this tile of options; the softmax over complete rows is k_softmax_rows' (fused into this kernel it
+    // cost 40 more VGPRs, i.e. a wavefront per SIMD: 12.2 ms against 10.4 ms on 20k x 20k x 64 with doublets)
 #pragma unroll
     for (int s = 0; s < A; s++) {
         const int k = k_base + s * 256 + tid;
@@ -890,51 +886,7 @@ __global__ __launch_bounds__(256) void k_estep_block(EstepArgs a, int C, int k_b
                 else
                     l = (float)((double)l + ((const double *)a.prior)[o]);
             }
-            lg[s] = l;
-            mx = fmaxf(mx, l);
-            if (TILED) a.logits[(size_t)b * K + k] = l;
-        } else {
-            lg[s] = -__builtin_inff();
-        }
-    }
-    if (TILED) return;  // (uniform) the softmax needs all tiles: k_softmax_rows
-#pragma unroll
-    for (int off = 1; off < 64; off <<= 1) mx = fmaxf(mx, __shfl_xor(mx, off));
-    if (lane == 0) sh_red[wave] = mx;
-    __syncthreads();
-    mx = fmaxf(fmaxf(sh_red[0], sh_red[1]), fmaxf(sh_red[2], sh_red[3]));
-    float x[A];
-#pragma unroll
-    for (int s = 0; s < A; s++) {
-        const int k = s * 256 + tid;
-        x[s] = npm::exp_f32(lg[s] - mx);
-        if (k < K) sh_x[k] = x[s];
-    }
-    __syncthreads();
-    if (wave == 0) {
-        const float tot = npm::row_sum_wave(sh_x, K, lane);
-        if (lane == 0) sh_red[4] = tot;
-    }
-    __syncthreads();
-    const float tot = sh_red[4];
-    const int W = (G + 63) >> 6;
-#pragma unroll
-    for (int s = 0; s < A; s++) {
-        const int k = s * 256 + tid;
-        const float post = x[s] / tot;
-        if (k < K) {
-            const size_t o = (size_t)b * K + k;
-            a.logits[o] = lg[s];
-            a.post[o] = post;
-        }
-        if (s == 0) {  // singlet columns k < G <= 256 all live in slot 0: one bitmap word per wave
-            const unsigned long long bal = __ballot(k < G && !(post <= a.nz_floor));
-            if (lane == 0 && wave < W) a.nz[(size_t)b * W + wave] = bal;
-            if (a.first && wave == 0 && lane == (bal ? __builtin_ctzll(bal) : 0)) {
-                a.first[b] = nz_code(bal, post);
-                if (a.dense_calls && __popcll(bal) > 4)
-                    atomicAdd(a.dense_calls + 1 + (b & (DENSE_SLOTS - 1)), (unsigned long long)n_calls);
-            }
+            a.logits[(size_t)b * K + k] = l;
         }
     }
 }
@@ -1809,25 +1761,23 @@ static void launch_direct(hipStream_t st, const EstepArgs &a, bool pairs)
     }
 }
 
-template <int A, bool TILED>
-static hipError_t launch_block(hipStream_t st, const EstepArgs &a, int k_base = 0)
+template <int A>
+static hipError_t launch_block(hipStream_t st, const EstepArgs &a, int k_base)
 {
     int C = (16384 / (4 * a.G)) & ~7;  // calls staged per chunk: multiple of the 8-call row padding
     C = C < 8 ? 8 : (C > 128 ? 128 : C);
-    size_t stage = (size_t)(C + 2) * a.G * 4 + (size_t)C * 12;
-    size_t soft = TILED ? 0 : (size_t)a.K * 4 + 64;
-    size_t bytes = stage > soft ? stage : soft;
+    size_t bytes = (size_t)(C + 2) * a.G * 4 + (size_t)C * 12;
     bytes = (bytes + 15) & ~size_t(15);
     // Tolerance mode (a.fast): with 33 accumulators per thread the running products' registers halved the occupancy and
     // the mode did not pay (344 ms against 299 ms on 130k x 650k x 128 with doublets); with tiles of at most 17 it does
     // (212 ms against 257 ms).
-    const void *kernel = a.fast ? (const void *)k_estep_block<A, TILED, true> : (const void *)k_estep_block<A, TILED, false>;
+    const void *kernel = a.fast ? (const void *)k_estep_block<A, true> : (const void *)k_estep_block<A, false>;
     hipError_t e = hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
     if (e != hipSuccess) return e;
     if (a.fast)
-        hipLaunchKernelGGL((k_estep_block<A, TILED, true>), dim3((unsigned)a.B), dim3(256), bytes, st, a, C, k_base);
+        hipLaunchKernelGGL((k_estep_block<A, true>), dim3((unsigned)a.B), dim3(256), bytes, st, a, C, k_base);
     else
-        hipLaunchKernelGGL((k_estep_block<A, TILED, false>), dim3((unsigned)a.B), dim3(256), bytes, st, a, C, k_base);
+        hipLaunchKernelGGL((k_estep_block<A, false>), dim3((unsigned)a.B), dim3(256), bytes, st, a, C, k_base);
     return hipGetLastError();
 }
 
@@ -1870,23 +1820,20 @@ hipError_t launch_estep(hipStream_t st, const EstepArgs &a, bool pairs)
         return hipGetLastError();
     }
     if (!pairs) return hipErrorInvalidValue;  // K = G > 1024 singlets: not supported (checked by the caller)
-    const int need = (K + 255) / 256;
-    if (need <= 2) return launch_block<2, false>(st, a);
-    if (need <= 3) return launch_block<3, false>(st, a);
-    if (need <= 4) return launch_block<4, false>(st, a);
-    if (need <= 6) return launch_block<6, false>(st, a);
-    if (need <= 8) return launch_block<8, false>(st, a);
-    if (need <= 12) return launch_block<12, false>(st, a);
-    if (need <= 16) return launch_block<16, false>(st, a);
-    // More than 16 options per thread: the options are cut into tiles of 12 or 17 per thread, each tile one launch that
-    // leaves its logits, then the softmax over complete rows.  With 33 accumulators per thread (236 VGPRs, 2 waves per
-    // SIMD) one launch took 297 ms on 130k x 650k x 128 with doublets (K = 8256); two launches of 17 (4 waves per
-    // SIMD) take 257 ms although every tile stages the barcode's genotype rows again; three of 12: 264 ms.
+    // K > 1024: the options in tiles of up to 17 per thread, one launch of k_estep_block per tile leaving its logits,
+    // then the softmax over complete rows.  What this form runs on is registers per thread, i.e. resident wavefronts:
+    //   * the softmax fused into a single launch costs 40 VGPRs (3 waves per SIMD instead of 4): 12.2 ms against
+    //     10.4 ms on 20k x 20k x 64 with doublets (K = 2080);
+    //   * one launch with 33 accumulators per thread (236 VGPRs, 2 waves per SIMD) took 297 ms on 130k x 650k x 128 with
+    //     doublets (K = 8256); two launches of 17 take 257 ms although every tile stages the barcode's genotype rows
+    //     again; three of 12: 264 ms.
     // (Tiles of 65 accumulators per thread -- 385 VGPRs plus SGPR spills -- ended in GPU memory faults that narrower
     // tiles of the same source do not show: profiles/r2_block_tile65_experiment.txt.)
-    const int tile = need <= 24 ? 12 : 17;
+    const int need = (K + 255) / 256;
+    const int tile = need <= 6 ? 6 : need <= 8 ? 8 : need <= 12 ? 12 : need <= 17 ? 17 : need <= 24 ? 12 : 17;
     for (int k_base = 0; k_base < K; k_base += tile * 256) {
-        const hipError_t e = tile == 12 ? launch_block<12, true>(st, a, k_base) : launch_block<17, true>(st, a, k_base);
+        const hipError_t e = tile == 6 ? launch_block<6>(st, a, k_base) : tile == 8 ? launch_block<8>(st, a, k_base)
+                           : tile == 12 ? launch_block<12>(st, a, k_base) : launch_block<17>(st, a, k_base);
         if (e != hipSuccess) return e;
     }
     hipLaunchKernelGGL(k_softmax_rows, dim3((unsigned)a.B), dim3(256), 0, st, a);
