@@ -1814,7 +1814,12 @@ hipError_t launch_estep(hipStream_t st, const EstepArgs &a, bool pairs)
         else launch_direct<64, 4, 2>(st, a, pairs);
         return hipGetLastError();
     }
-    if (K <= 1024) {  // register-resident up to 16 options per lane; slots past K are skipped wave-uniformly
+    // Doublet tables of more than 512 options (256 in the tolerance mode) already go to the workgroup-per-barcode form
+    // below: with 16 accumulators + two row offsets per lane the lane-per-option form is down to 2 (1) waves per SIMD
+    // (20k x 20k x 32 with doublets, K = 528: 3.50 -> 2.97 ms, tolerance mode 4.54 -> 1.49 ms; at K = 496 it is still
+    // ahead in the exact mode, 2.44 against 2.65 ms, and behind in the tolerance mode, 2.04 against 1.20 ms).
+    const bool to_block = pairs && (K > 512 || (a.fast && K > 256));
+    if (K <= 1024 && !to_block) {  // register-resident up to 16 options per lane; slots past K are skipped wave-uniformly
         if (K <= 512) launch_direct<64, 8, 2>(st, a, pairs);
         else launch_direct<64, 16, 2>(st, a, pairs);
         return hipGetLastError();
@@ -1830,9 +1835,9 @@ hipError_t launch_estep(hipStream_t st, const EstepArgs &a, bool pairs)
     // (Tiles of 65 accumulators per thread -- 385 VGPRs plus SGPR spills -- ended in GPU memory faults that narrower
     // tiles of the same source do not show: profiles/r2_block_tile65_experiment.txt.)
     const int need = (K + 255) / 256;
-    const int tile = need <= 6 ? 6 : need <= 8 ? 8 : need <= 12 ? 12 : need <= 17 ? 17 : need <= 24 ? 12 : 17;
+    const int tile = need <= 2 ? 2 : need <= 4 ? 4 : need <= 6 ? 6 : need <= 8 ? 8 : need <= 12 ? 12 : need <= 17 ? 17 : need <= 24 ? 12 : 17;
     for (int k_base = 0; k_base < K; k_base += tile * 256) {
-        const hipError_t e = tile == 6 ? launch_block<6>(st, a, k_base) : tile == 8 ? launch_block<8>(st, a, k_base)
+        const hipError_t e = tile == 2 ? launch_block<2>(st, a, k_base) : tile == 4 ? launch_block<4>(st, a, k_base) : tile == 6 ? launch_block<6>(st, a, k_base) : tile == 8 ? launch_block<8>(st, a, k_base)
                            : tile == 12 ? launch_block<12>(st, a, k_base) : launch_block<17>(st, a, k_base);
         if (e != hipSuccess) return e;
     }
