@@ -66,6 +66,10 @@ struct dmx_ctx {
     unsigned *d_n_redo = nullptr;
     size_t cap_redo = 0;
     bool mstep_wide = false;  // dmx_set_mstep_wide_addresses
+    int *d_sum_plan = nullptr;  // np.sum over a row of K values as a leaf / level plan (dmx_api.cpp: ensure_options)
+    size_t cap_sum_plan = 0;
+    long long sum_plan_k = -1;
+    int sum_plan_values = 0;    // leaves + inner nodes
     int item_calls = 1024;  // work-item length of the resident problem (kernels.h: item_calls_for)
     bool exact_additions = true;  // dmx_set_exact_additions
     int estep_mode = DMX_ESTEP_EXACT;  // dmx_set_estep_mode

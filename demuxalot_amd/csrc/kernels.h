@@ -26,6 +26,9 @@ struct EstepArgs {
     const int *order;           // [B] barcodes by decreasing row length (work distribution)
     const CallPair *pairs;      // call records, see above
     const float *prob;          // [V, G] genotype_prob, row-major
+    const int *sum_plan;        // np.sum over a row of K values: {n_leaves, n_levels, n_roots, level offsets [n_levels + 1],
+                                // leaves (start, length), inner nodes (left value, right value) level by level, roots}
+    int sum_plan_values;        // leaves + inner nodes
     const unsigned *opt_pairs;  // [K] g1 | g2 << 16 (doublet runs only)
     const float *pen;           // [K] doublet penalties
     const void *prior;          // nullable [B, K] prior logits (device)

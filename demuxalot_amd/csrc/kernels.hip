@@ -893,8 +893,13 @@ __global__ __launch_bounds__(256) void k_estep_block(EstepArgs a, int C, int k_b
 
 // Softmax of complete logit rows of any length (after the tiled block form): one workgroup per barcode, the
 // exponentials parked in the posterior row itself, numpy-ordered sum by wave 0, bitmap of the singlet columns.
+// STAGED: the row goes to LDS (K floats) once, the workgroup forms numpy's pairwise sum of the exponentials there, and
+// the posteriors are written once.  (Through global memory - the form kept for rows that do not fit, K > 37 000 - the
+// sum is a chain of dependent 4-byte loads by one wavefront: 44 ms on 130k barcodes x 8256 options.)
+template <bool STAGED>
 __global__ __launch_bounds__(256) void k_softmax_rows(EstepArgs a)
 {
+    extern __shared__ __attribute__((aligned(16))) float sh_row[];
     __shared__ float sh_red[8];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const long long b = blockIdx.x;
@@ -902,17 +907,69 @@ __global__ __launch_bounds__(256) void k_softmax_rows(EstepArgs a)
     const float *__restrict__ lg = a.logits + (size_t)b * K;
     float *post = a.post + (size_t)b * K;
     float mx = -__builtin_inff();
-    for (int k = tid; k < K; k += 256) mx = fmaxf(mx, lg[k]);
+    // the logits are read once, eight independent loads in flight per thread (one at a time, a row of 8256 options
+    // took 150 us: 33 load latencies per pass)
+    for (int k0 = tid; k0 < K; k0 += 256 * 8) {
+        float v[8];
+#pragma unroll
+        for (int u = 0; u < 8; u++) v[u] = k0 + 256 * u < K ? lg[k0 + 256 * u] : -__builtin_inff();
+#pragma unroll
+        for (int u = 0; u < 8; u++) {
+            mx = fmaxf(mx, v[u]);
+            if (STAGED && k0 + 256 * u < K) sh_row[k0 + 256 * u] = v[u];
+        }
+    }
 #pragma unroll
     for (int off = 1; off < 64; off <<= 1) mx = fmaxf(mx, __shfl_xor(mx, off));
     if (lane == 0) sh_red[wave] = mx;
     __syncthreads();
     mx = fmaxf(fmaxf(sh_red[0], sh_red[1]), fmaxf(sh_red[2], sh_red[3]));
-    for (int k = tid; k < K; k += 256) post[k] = npm::exp_f32(lg[k] - mx);
+    float *x = STAGED ? sh_row : post;
+    for (int k = tid; k < K; k += 256) x[k] = npm::exp_f32((STAGED ? sh_row[k] : lg[k]) - mx);
     __threadfence_block();
     __syncthreads();
-    if (wave == 0) {
-        const float tot = npm::row_sum_wave(post, K, lane);
+    if constexpr (STAGED) {
+        // np.sum(x) by the whole workgroup along the plan of the host (EstepArgs::sum_plan: numpy's pairwise tree spelled
+        // out): the blocks of <= 128 elements by groups of 8 lanes, 32 at a time, then the inner nodes level by level,
+        // then the 8192-element chunks left to right.  One wavefront walking the tree with an explicit stack took
+        // 180 us per row of 8256 options - 30 ms of the 257 ms E-step of 130k x 650k x 128 with doublets.
+        const int *__restrict__ plan = a.sum_plan;
+        const int n_leaves = plan[0], n_levels = plan[1], n_roots = plan[2];
+        const int *__restrict__ level_off = plan + 3;
+        const int *__restrict__ leaves = level_off + n_levels + 1;
+        const int *__restrict__ nodes = leaves + 2 * n_leaves;
+        const int *__restrict__ roots = nodes + 2 * level_off[n_levels];
+        float *val = sh_row + K;
+        const int j = tid & 7;
+        for (int l = tid >> 3; l < n_leaves; l += 32) {
+            const float *blk = x + leaves[2 * l];
+            const int n = leaves[2 * l + 1];
+            float r = 0.0f;
+            if (n < 8) {  // np_math.h: short_sum
+                for (int i = 0; i < n; i++) r += blk[i];
+            } else {      // np_math.h: leaf_sum_wave8
+                const int nfull = n - (n & 7);
+                r = blk[j];
+                for (int i = 8 + j; i < nfull; i += 8) r += blk[i];
+                r = r + __shfl_xor(r, 1);
+                r = r + __shfl_xor(r, 2);
+                r = r + __shfl_xor(r, 4);
+                for (int i = nfull; i < n; i++) r += blk[i];
+            }
+            if (j == 0) val[l] = r;
+        }
+        __syncthreads();
+        for (int h = 0; h < n_levels; h++) {
+            for (int q = level_off[h] + tid; q < level_off[h + 1]; q += 256) val[n_leaves + q] = val[nodes[2 * q]] + val[nodes[2 * q + 1]];
+            __syncthreads();
+        }
+        if (tid == 0) {
+            float res = 0.0f;
+            for (int r = 0; r < n_roots; r++) res = res + val[roots[r]];
+            sh_red[4] = res;
+        }
+    } else if (wave == 0) {
+        const float tot = npm::row_sum_wave(x, K, lane);
         if (lane == 0) sh_red[4] = tot;
     }
     __syncthreads();
@@ -922,7 +979,7 @@ __global__ __launch_bounds__(256) void k_softmax_rows(EstepArgs a)
         const int k = k0 + tid;
         float p = 0.0f;
         if (k < K) {
-            p = post[k] / tot;
+            p = x[k] / tot;
             post[k] = p;
         }
         if (k0 < G) {
@@ -1841,7 +1898,14 @@ hipError_t launch_estep(hipStream_t st, const EstepArgs &a, bool pairs)
                            : tile == 12 ? launch_block<12>(st, a, k_base) : launch_block<17>(st, a, k_base);
         if (e != hipSuccess) return e;
     }
-    hipLaunchKernelGGL(k_softmax_rows, dim3((unsigned)a.B), dim3(256), 0, st, a);
+    const size_t row_bytes = ((size_t)K + (size_t)a.sum_plan_values) * 4;  // the row + the values of the sum plan
+    if (row_bytes <= 150 * 1024 && a.sum_plan) {
+        const hipError_t e = hipFuncSetAttribute((const void *)k_softmax_rows<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)row_bytes);
+        if (e != hipSuccess) return e;
+        hipLaunchKernelGGL(k_softmax_rows<true>, dim3((unsigned)a.B), dim3(256), row_bytes, st, a);
+    } else {
+        hipLaunchKernelGGL(k_softmax_rows<false>, dim3((unsigned)a.B), dim3(256), 0, st, a);
+    }
     return hipGetLastError();
 }
 
