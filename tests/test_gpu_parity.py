@@ -524,13 +524,14 @@ def test_midsize_em_matches_oracle(oracle):
 
 
 def test_doublets_block_kernel_matches_oracle(oracle):
-    """K > 256 options (block kernel): 40 genotypes with doublets (K = 820), 128 (K = 8256 > 8192, the widest
-    single launch), and 140 / 190 / 270 (K = 9870 / 18 145 / 36 585 > 33 * 256: the options are tiled over several
-    launches and k_softmax_rows finishes the rows)."""
+    """Wide option tables (workgroup-per-barcode E-step: option tiles of up to 17 per thread, then k_softmax_rows):
+    40 genotypes with doublets (K = 820, one tile), 128 (K = 8256, two tiles), 140 / 190 / 270 (K = 9870 / 18 145 /
+    36 585, several tiles; rows staged in LDS for the softmax) and 285 (K = 40 755: the row does not fit LDS, the
+    softmax works through global memory)."""
     from demuxalot_amd import synth
     from demuxalot_amd.device import get_context
     from demuxalot_amd import Demultiplexer
-    for G, B in ((40, 300), (128, 24), (140, 16), (190, 12), (270, 9)):
+    for G, B in ((40, 300), (128, 24), (140, 16), (190, 12), (270, 9), (285, 6)):
         p = synth.generate(B, 500, G, calls_per_barcode=80 if G < 140 else 30, doublets=True, seed=G)
         betas = p.prior_betas()
         ctx = get_context()
