@@ -1,6 +1,9 @@
-# M-step ablations (timing only; the ablated kernels' results are wrong by construction).  Variants of kernels.hip built
-# with -DABLATE_* into build/ablate_*/ (here: bash scripts/ablate_mstep.sh build V1 V2 ...), timed on the GPU box on
-# the posteriors of the first E-step of the headline workload (bash scripts/ablate_mstep.sh run V1 V2 ...).
+# M-step ablations (timing only; an ablated kernel gives wrong results by construction).  Put `#ifdef ABLATE_<NAME>` blocks
+# at the points of interest in csrc/kernels.hip (e.g. skip the queue machinery, replace a gather by arithmetic: the
+# variants behind the figures of DESIGN.md 4.2 were LOADS_ONLY, NO_GATHER, NO_EXTRAS, NO_DENSE), then here:
+#   bash scripts/ablate_mstep.sh build NAME1 NAME2 ...      (builds build/ablate_NAME/libdemux_hip.so)
+# and on the GPU box, timed on the posteriors of the first E-step of the headline workload:
+#   bash scripts/ablate_mstep.sh run NAME1 NAME2 ...
 set -e
 cd "$(dirname "$0")/.."
 SRC=demuxalot_amd/csrc
