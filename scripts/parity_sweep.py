@@ -1,4 +1,4 @@
-"""Wider randomised parity sweep than the test suite runs (GPU box): python scripts/parity_sweep.py [n_seeds] [n_trials] [first_seed]
+"""Wider randomised parity sweep than the test suite runs (GPU box): python scripts/parity_sweep.py [n_seeds] [n_trials] [first_seed] [n_doublet_trials]
 Reuses the suite's own randomised EM check with more seeds, then mid-size EM problems with random G, density and
 iteration counts against the numpy oracle (everything bitwise)."""
 import os
@@ -47,3 +47,28 @@ for trial in range(int(sys.argv[2]) if len(sys.argv) > 2 else 12):
     fio.assert_bitwise(addition, hist[-1]['addition'], what + ' addition')
     print('ok', what, flush=True)
 print(f'sweep done in {time.time() - t0:.0f} s')
+
+# doublet tables across the kernel forms (lane-per-option up to 512 options, workgroup-per-barcode tiles beyond)
+from demuxalot_amd import Demultiplexer
+n_doublet = int(sys.argv[4]) if len(sys.argv) > 4 else 16
+for trial in range(n_doublet):
+    G = int(rng.choice([5, 9, 16, 22, 23, 31, 32, 33, 40, 45, 46, 52, 64, 70, 90, 91]))
+    B = int(rng.integers(60, 400))
+    S = int(rng.integers(100, 600))
+    cpb = int(rng.choice([20, 50, 90]))
+    dp = float(rng.choice([0.1, 0.3, 0.5]))
+    n_it = int(rng.integers(1, 3))
+    p = synth.generate(B, S, G, calls_per_barcode=min(cpb, S), doublets=True, seed=3000 + first + trial)
+    betas = p.prior_betas()
+    ctx = get_context()
+    ctx.set_problem(p.n_barcodes, p.n_variants, G, p.variant_id, p.compressed_cb, p.p_base_wrong, p.v2snp)
+    ctx.set_betas(betas)
+    pen = Demultiplexer._doublet_penalties(G, dp)
+    logits, probs, addition = ctx.em(n_it, 0.01, pen, with_doublets=True)
+    packed = dict(variant_id=p.variant_id, compressed_cb=p.compressed_cb, p_base_wrong=p.p_base_wrong, betas=betas, v2snp=p.v2snp)
+    hist = oracle.em(packed, p.n_barcodes, n_it, 0.01, dp, impl='npsimd')
+    what = f'doublets {trial}: G={G} K={G * (G + 1) // 2} B={B} S={S} cpb={cpb} it={n_it} dp={dp} N={p.n_calls}'
+    T.check_posteriors(logits, probs, hist[-1]['logits'], hist[-1]['probs'], what)
+    fio.assert_bitwise(addition, hist[-1]['addition'], what + ' addition')
+    print('ok', what, flush=True)
+print(f'all done in {time.time() - t0:.0f} s')
