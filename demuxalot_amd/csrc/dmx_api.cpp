@@ -82,6 +82,72 @@ int load_rccl()
 }
 }  // namespace
 
+namespace dmx {
+
+// np.sum over a row of K values as a plan a whole workgroup executes (np_math.h: plan_sum_block): numpy's pairwise tree
+// spelled out - the blocks of <= 128 elements, then the inner nodes level by level from the deepest, then the roots of
+// the 8192-element chunks, which are added left to right.
+int ensure_sum_plan(dmx_ctx *c, long long K)
+{
+    if (K == c->sum_plan_k) return 0;
+    std::vector<int> leaves;                  // (start, length) of the blocks of <= 128 elements
+    std::vector<int> roots;
+    // values: [0, n_leaves) the leaf sums, then one value per inner node
+    std::vector<std::array<int, 3>> inner;  // left, right, height (leaf = 0)
+    std::function<std::pair<int, int>(int, int)> build = [&](int start, int n) -> std::pair<int, int> {  // (value, height)
+        if (n <= 128) {
+            leaves.push_back(start);
+            leaves.push_back(n);
+            return {(int)leaves.size() / 2 - 1, 0};
+        }
+        int half = n / 2;
+        half -= half % 8;
+        const auto l = build(start, half), r = build(start + half, n - half);
+        inner.push_back({l.first, r.first, std::max(l.second, r.second) + 1});
+        return {-(int)inner.size(), std::max(l.second, r.second) + 1};  // inner nodes: negative handles, resolved below
+    };
+    for (long long s0 = 0; s0 < K; s0 += 8192) roots.push_back(build((int)s0, (int)std::min<long long>(8192, K - s0)).first);
+    const int n_leaves = (int)leaves.size() / 2;
+    int max_h = 0;
+    for (auto &nd : inner) max_h = std::max(max_h, nd[2]);
+    // order the inner nodes by height (children before parents), remember where each went
+    std::vector<int> place(inner.size());
+    std::vector<int> level_off(1, 0);
+    std::vector<int> ordered;
+    for (int h = 1; h <= max_h; h++) {
+        for (size_t i = 0; i < inner.size(); i++)
+            if (inner[i][2] == h) {
+                place[i] = n_leaves + (int)ordered.size() / 2;
+                ordered.push_back((int)i);
+                ordered.push_back(0);
+            }
+        level_off.push_back((int)ordered.size() / 2);
+    }
+    auto value_of = [&](int handle) { return handle >= 0 ? handle : place[(size_t)(-handle - 1)]; };
+    std::vector<int> plan;
+    plan.push_back(n_leaves);
+    plan.push_back(max_h);
+    plan.push_back((int)roots.size());
+    for (int h = 0; h <= max_h; h++) plan.push_back(level_off[(size_t)h]);
+    plan.insert(plan.end(), leaves.begin(), leaves.end());
+    for (size_t q = 0; q < ordered.size(); q += 2) {
+        const auto &nd = inner[(size_t)ordered[q]];
+        plan.push_back(value_of(nd[0]));
+        plan.push_back(value_of(nd[1]));
+    }
+    for (int r : roots) plan.push_back(value_of(r));
+    dev_free(c, &c->d_sum_plan, c->cap_sum_plan);
+    c->cap_sum_plan = plan.size();
+    DMX_TRY(dev_alloc(c, &c->d_sum_plan, plan.size()));
+    HIP_TRY(hipMemcpyAsync(c->d_sum_plan, plan.data(), sizeof(int) * plan.size(), hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    c->sum_plan_k = K;
+    c->sum_plan_values = n_leaves + (int)inner.size();
+    return 0;
+}
+
+}  // namespace dmx
+
 namespace {
 
 int bind(dmx_ctx *c)
@@ -246,64 +312,7 @@ int ensure_options(dmx_ctx *c, int with_doublets, const float *penalties)
     }
     HIP_TRY(hipMemcpyAsync(c->d_pairs, pairs.data(), sizeof(unsigned) * K, hipMemcpyHostToDevice, c->stream));
     HIP_TRY(hipMemcpyAsync(c->d_pen, penalties, sizeof(float) * K, hipMemcpyHostToDevice, c->stream));
-    // np.sum over a row of K float32 values as a plan the softmax of wide rows executes with a whole workgroup
-    // (kernels.hip: k_softmax_rows): numpy's pairwise tree (np_math.h) spelled out - leaves, then the inner nodes level
-    // by level from the deepest, then the roots of the 8192-element chunks, which are added left to right.
-    if (K != c->sum_plan_k) {
-        std::vector<int> leaves;                  // (start, length) of the blocks of <= 128 elements
-        std::vector<int> roots;
-        // values: [0, n_leaves) the leaf sums, then one value per inner node
-        std::vector<std::array<int, 3>> inner;  // left, right, height (leaf = 0)
-        std::function<std::pair<int, int>(int, int)> build = [&](int start, int n) -> std::pair<int, int> {  // (value, height)
-            if (n <= 128) {
-                leaves.push_back(start);
-                leaves.push_back(n);
-                return {(int)leaves.size() / 2 - 1, 0};
-            }
-            int half = n / 2;
-            half -= half % 8;
-            const auto l = build(start, half), r = build(start + half, n - half);
-            inner.push_back({l.first, r.first, std::max(l.second, r.second) + 1});
-            return {-(int)inner.size(), std::max(l.second, r.second) + 1};  // inner nodes: negative handles, resolved below
-        };
-        for (long long s0 = 0; s0 < K; s0 += 8192) roots.push_back(build((int)s0, (int)std::min<long long>(8192, K - s0)).first);
-        const int n_leaves = (int)leaves.size() / 2;
-        int max_h = 0;
-        for (auto &nd : inner) max_h = std::max(max_h, nd[2]);
-        // order the inner nodes by height (children before parents), remember where each went
-        std::vector<int> place(inner.size());
-        std::vector<int> level_off(1, 0);
-        std::vector<int> ordered;
-        for (int h = 1; h <= max_h; h++) {
-            for (size_t i = 0; i < inner.size(); i++)
-                if (inner[i][2] == h) {
-                    place[i] = n_leaves + (int)ordered.size() / 2;
-                    ordered.push_back((int)i);
-                    ordered.push_back(0);
-                }
-            level_off.push_back((int)ordered.size() / 2);
-        }
-        auto value_of = [&](int handle) { return handle >= 0 ? handle : place[(size_t)(-handle - 1)]; };
-        std::vector<int> plan;
-        plan.push_back(n_leaves);
-        plan.push_back(max_h);
-        plan.push_back((int)roots.size());
-        for (int h = 0; h <= max_h; h++) plan.push_back(level_off[(size_t)h]);
-        plan.insert(plan.end(), leaves.begin(), leaves.end());
-        for (size_t q = 0; q < ordered.size(); q += 2) {
-            const auto &nd = inner[(size_t)ordered[q]];
-            plan.push_back(value_of(nd[0]));
-            plan.push_back(value_of(nd[1]));
-        }
-        for (int r : roots) plan.push_back(value_of(r));
-        dev_free(c, &c->d_sum_plan, c->cap_sum_plan);
-        c->cap_sum_plan = plan.size();
-        DMX_TRY(dev_alloc(c, &c->d_sum_plan, plan.size()));
-        HIP_TRY(hipMemcpyAsync(c->d_sum_plan, plan.data(), sizeof(int) * plan.size(), hipMemcpyHostToDevice, c->stream));
-        HIP_TRY(hipStreamSynchronize(c->stream));
-        c->sum_plan_k = K;
-        c->sum_plan_values = n_leaves + (int)inner.size();
-    }
+    DMX_TRY(dmx::ensure_sum_plan(c, K));
     HIP_TRY(hipStreamSynchronize(c->stream));  // `pairs` is a local
     c->K = (int)K;
     return 0;

@@ -167,6 +167,7 @@ int pack_on_device(dmx_ctx *c, long long V, const int *var_chrom, const int *var
                    const int *call_cb, const float *call_p, long long *n_matched, long long *n_unique,
                    long long *mol_per_variant);
 // matched molecule calls (molecule order) -> the (barcode, SNP)-grouped layout of the aggregate_on_snps E-step
+int ensure_sum_plan(dmx_ctx *c, long long K);  // dmx_api.cpp
 int build_snp_groups(dmx_ctx *c, const unsigned long long *vb_keys, const unsigned *src_idx, const float *src_p, long long m);
 int pack_containers_on_device(dmx_ctx *c, long long V, const int *var_chrom, const int *var_pos,
                               const unsigned char *var_base, const dmx_call_container *parts, int n_parts,

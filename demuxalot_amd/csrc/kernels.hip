@@ -933,41 +933,8 @@ __global__ __launch_bounds__(256) void k_softmax_rows(EstepArgs a)
         // out): the blocks of <= 128 elements by groups of 8 lanes, 32 at a time, then the inner nodes level by level,
         // then the 8192-element chunks left to right.  One wavefront walking the tree with an explicit stack took
         // 180 us per row of 8256 options - 30 ms of the 257 ms E-step of 130k x 650k x 128 with doublets.
-        const int *__restrict__ plan = a.sum_plan;
-        const int n_leaves = plan[0], n_levels = plan[1], n_roots = plan[2];
-        const int *__restrict__ level_off = plan + 3;
-        const int *__restrict__ leaves = level_off + n_levels + 1;
-        const int *__restrict__ nodes = leaves + 2 * n_leaves;
-        const int *__restrict__ roots = nodes + 2 * level_off[n_levels];
-        float *val = sh_row + K;
-        const int j = tid & 7;
-        for (int l = tid >> 3; l < n_leaves; l += 32) {
-            const float *blk = x + leaves[2 * l];
-            const int n = leaves[2 * l + 1];
-            float r = 0.0f;
-            if (n < 8) {  // np_math.h: short_sum
-                for (int i = 0; i < n; i++) r += blk[i];
-            } else {      // np_math.h: leaf_sum_wave8
-                const int nfull = n - (n & 7);
-                r = blk[j];
-                for (int i = 8 + j; i < nfull; i += 8) r += blk[i];
-                r = r + __shfl_xor(r, 1);
-                r = r + __shfl_xor(r, 2);
-                r = r + __shfl_xor(r, 4);
-                for (int i = nfull; i < n; i++) r += blk[i];
-            }
-            if (j == 0) val[l] = r;
-        }
-        __syncthreads();
-        for (int h = 0; h < n_levels; h++) {
-            for (int q = level_off[h] + tid; q < level_off[h + 1]; q += 256) val[n_leaves + q] = val[nodes[2 * q]] + val[nodes[2 * q + 1]];
-            __syncthreads();
-        }
-        if (tid == 0) {
-            float res = 0.0f;
-            for (int r = 0; r < n_roots; r++) res = res + val[roots[r]];
-            sh_red[4] = res;
-        }
+        const float tot = npm::plan_sum_block<float>(x, a.sum_plan, sh_row + K, tid);
+        if (tid == 0) sh_red[4] = tot;
     } else if (wave == 0) {
         const float tot = npm::row_sum_wave(x, K, lane);
         if (lane == 0) sh_red[4] = tot;

@@ -260,4 +260,58 @@ __device__ __forceinline__ float row_sum_wave(const float *a, int n, int lane)
     return res;
 }
 
+
+// ---------------------------------------------------------------------------------------
+// np.sum over a row of n values in LDS by a whole 256-thread workgroup, along a PLAN the host spelled out for this n
+// (dmx_api.cpp: ensure_sum_plan): {n_leaves, n_levels, n_roots, level offsets [n_levels + 1], leaves (start, length),
+// inner nodes (left value, right value) level by level from the deepest, roots of the 8192-element chunks}.
+// Blocks of <= 128 elements are summed by groups of 8 lanes (32 at a time), the inner nodes of numpy's pairwise tree
+// level by level, the chunk roots left to right: the same additions in the same association as row_sum_wave /
+// np.add.reduce, for float32 and float64 alike (numpy blocks both by 128 elements and 8 partial sums).
+// val: LDS scratch of n_leaves + n_inner values; the result is returned to every thread.  Uniform control flow.
+// ---------------------------------------------------------------------------------------
+__device__ __forceinline__ float plan_shfl_xor(float v, int m) { return __shfl_xor(v, m); }
+__device__ __forceinline__ double plan_shfl_xor(double v, int m)
+{
+    const int lo = __shfl_xor(__double2loint(v), m), hi = __shfl_xor(__double2hiint(v), m);
+    return __hiloint2double(hi, lo);
+}
+
+template <typename T>
+__device__ __forceinline__ T plan_sum_block(const T *x, const int *__restrict__ plan, T *val, int tid)
+{
+    const int n_leaves = plan[0], n_levels = plan[1], n_roots = plan[2];
+    const int *__restrict__ level_off = plan + 3;
+    const int *__restrict__ leaves = level_off + n_levels + 1;
+    const int *__restrict__ nodes = leaves + 2 * n_leaves;
+    const int *__restrict__ roots = nodes + 2 * level_off[n_levels];
+    const int j = tid & 7;
+    for (int l = tid >> 3; l < n_leaves; l += 32) {
+        const T *blk = x + leaves[2 * l];
+        const int n = leaves[2 * l + 1];
+        T r = (T)0;
+        if (n < 8) {  // short_sum
+            for (int i = 0; i < n; i++) r += blk[i];
+        } else {      // leaf_sum_wave8
+            const int nfull = n - (n & 7);
+            r = blk[j];
+            for (int i = 8 + j; i < nfull; i += 8) r += blk[i];
+            r = r + plan_shfl_xor(r, 1);
+            r = r + plan_shfl_xor(r, 2);
+            r = r + plan_shfl_xor(r, 4);
+            for (int i = nfull; i < n; i++) r += blk[i];
+        }
+        if (j == 0) val[l] = r;
+    }
+    __syncthreads();
+    for (int h = 0; h < n_levels; h++) {
+        for (int q = level_off[h] + tid; q < level_off[h + 1]; q += 256) val[n_leaves + q] = val[nodes[2 * q]] + val[nodes[2 * q + 1]];
+        __syncthreads();
+    }
+    T res = (T)0;
+    for (int r = 0; r < n_roots; r++) res = res + val[roots[r]];  // every thread: a handful of LDS broadcasts
+    __syncthreads();                                              // val may be reused right away
+    return res;
+}
+
 }  // namespace npm

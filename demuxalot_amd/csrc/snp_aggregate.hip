@@ -34,7 +34,7 @@ namespace {
 
 using dmx::fail;
 
-constexpr int SNP_MAX_OPTIONS = 256 * 33;  // doublets of 128 genotypes: 8256 options, 99 KB of LDS per barcode
+constexpr int SNP_MAX_OPTIONS = 256 * 33;  // doublets of 128 genotypes: 8256 options, about 100 KB of LDS per barcode
 
 inline unsigned grid_for(long long n) { return (unsigned)((n + 255) / 256); }
 
@@ -173,6 +173,8 @@ struct SnpArgs {
     const float *prob;          // genotype_prob, padded row layout
     const int *prow;            // nullable: padded row of every variant
     const unsigned *opt_pairs;  // [K] g1 | g2 << 16
+    const int *sum_plan;        // np.sum over K values as a workgroup plan (np_math.h: plan_sum_block); block kernel only
+    int sum_plan_values;
     const double *count_pow;    // [max_count + 1] count ** compensation as numpy computes it
     const void *prior;          // nullable [B, K] prior logits
     int prior_dtype;
@@ -323,7 +325,9 @@ __global__ __launch_bounds__(256) void k_estep_snp_block(SnpArgs a)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int K = a.K, G = a.G;
     double *sh64 = (double *)smem;
-    float *sh32 = (float *)(sh64 + K);
+    double *val64 = sh64 + K;                       // scratch of the sum plan
+    float *sh32 = (float *)(val64 + a.sum_plan_values);
+    float *val32 = sh32 + K;
     const long long b = blockIdx.x;
 
     unsigned pr[A];
@@ -353,21 +357,11 @@ __global__ __launch_bounds__(256) void k_estep_snp_block(SnpArgs a)
     };
     auto block_sum32 = [&]() {  // np.sum of sh32[0..K)
         __syncthreads();
-        if (wave == 0) {
-            const float tot = npm::row_sum_wave(sh32, K, lane);
-            if (lane == 0) red32[4] = tot;
-        }
-        __syncthreads();
-        return red32[4];
+        return npm::plan_sum_block<float>(sh32, a.sum_plan, val32, tid);
     };
     auto block_sum64 = [&]() {
         __syncthreads();
-        if (wave == 0) {
-            const double tot = row_sum64(sh64, K, lane);
-            if (lane == 0) red64[4] = tot;
-        }
-        __syncthreads();
-        return red64[4];
+        return npm::plan_sum_block<double>(sh64, a.sum_plan, val64, tid);
     };
 
     auto finish = [&]() {
@@ -513,7 +507,7 @@ int launch_snp(dmx_ctx *c, const SnpArgs &a, bool pairs)
 template <int A>
 int launch_snp_block(dmx_ctx *c, const SnpArgs &a)
 {
-    const size_t bytes = (size_t)a.K * (sizeof(double) + sizeof(float));
+    const size_t bytes = ((size_t)a.K + (size_t)a.sum_plan_values) * (sizeof(double) + sizeof(float));
     HIP_TRY(hipFuncSetAttribute((const void *)k_estep_snp_block<A>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
     if (a.B) hipLaunchKernelGGL((k_estep_snp_block<A>), dim3((unsigned)a.B), dim3(256), bytes, c->stream, a);
     HIP_TRY(hipGetLastError());
@@ -698,6 +692,14 @@ int dmx_estep_snp(dmx_ctx *c, int with_doublets, const double *count_pow, int64_
         a.logits = c->d_logits64;
         a.post = c->d_post64;
         a.log_bad = std::log(0.01 / (double)K);
+        a.sum_plan = nullptr;
+        a.sum_plan_values = 0;
+        if (K > 1024) {
+            rc = dmx::ensure_sum_plan(c, K);
+            if (rc) break;
+            a.sum_plan = c->d_sum_plan;
+            a.sum_plan_values = c->sum_plan_values;
+        }
         a.B = c->B;
         a.G = G;
         a.K = (int)K;
