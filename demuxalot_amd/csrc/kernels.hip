@@ -1859,7 +1859,11 @@ hipError_t launch_estep(hipStream_t st, const EstepArgs &a, bool pairs)
     // (Tiles of 65 accumulators per thread -- 385 VGPRs plus SGPR spills -- ended in GPU memory faults that narrower
     // tiles of the same source do not show: profiles/r2_block_tile65_experiment.txt.)
     const int need = (K + 255) / 256;
-    const int tile = need <= 2 ? 2 : need <= 4 ? 4 : need <= 6 ? 6 : need <= 8 ? 8 : need <= 12 ? 12 : need <= 17 ? 17 : need <= 24 ? 12 : 17;
+    int tile = need <= 2 ? 2 : need <= 4 ? 4 : need <= 6 ? 6 : need <= 8 ? 8 : need <= 12 ? 12 : need <= 17 ? 17 : need <= 24 ? 12 : 17;
+    // the tolerance mode carries a running product and an exponent per option besides the accumulator: tiles of 6
+    // keep it at 4+ waves per SIMD (K = 8256: 170 ms with tiles of 17, 103 with 12, 87 with 6, 98 with 4; the exact
+    // mode does not care: 214 / 220 / 218 / 230 ms)
+    if (a.fast && need > 6) tile = 6;
     for (int k_base = 0; k_base < K; k_base += tile * 256) {
         const hipError_t e = tile == 2 ? launch_block<2>(st, a, k_base) : tile == 4 ? launch_block<4>(st, a, k_base) : tile == 6 ? launch_block<6>(st, a, k_base) : tile == 8 ? launch_block<8>(st, a, k_base)
                            : tile == 12 ? launch_block<12>(st, a, k_base) : launch_block<17>(st, a, k_base);
