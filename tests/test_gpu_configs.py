@@ -293,3 +293,15 @@ def test_tiled_schedule_two_slots_per_lane(oracle):
     rng = np.random.default_rng(3)
     variants, _ = variants_to_check(p, rng, n_random=300)
     fio.assert_bitwise(addition_tiled[variants], addition_rows(p, probs_t, variants), 'M-step rows (G = 128)')
+
+
+def test_posterior_table_beyond_4_gib(oracle):
+    """132k barcodes x 128 genotypes with doublets: 4.36 GB of posteriors, i.e. byte offsets into the [B, K] tables
+    that no longer fit 32 bits (the configs[4] share above stays 2 MB below 4 GiB): the wide-row E-step, its softmax
+    and the genotype-per-lane M-step with 64-bit addressing, rows from both ends of the table against the oracle."""
+    from demuxalot_amd import synth
+    p = synth.generate(132_000, 6_000, 128, calls_per_barcode=120, doublets=True, seed=1250)
+    assert p.n_barcodes * 8256 * 4 > 2 ** 32
+    samples = [[(0, 30), (131_960, 132_000)]]
+    _ctx, addition, singlets, _n_multi = staged_em_against_oracle(oracle, p, 1, 0.25, samples, seed=17, p_rows=[(0, 12_000)])
+    assert singlets.shape == (132_000, 128) and (addition >= 0).all()
