@@ -87,3 +87,49 @@ def test_sharded_em_equals_the_single_context_run(world, reduce_dtype):
         assert np.array_equal(addition, results[0][3])  # identical on every rank
     kinds = {(op, dtype) for op, dtype, _shape in shared.collectives}
     assert ('reduce_scatter', 'float64' if reduce_dtype == 'f64' else 'float32') in kinds and ('all_gather', 'float32') in kinds
+
+
+def _gloo_rank(rank, world, port, out):
+    import os
+    import torch.distributed as dist
+    from demuxalot_amd import distributed
+    os.environ['MASTER_ADDR'], os.environ['MASTER_PORT'] = '127.0.0.1', str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        plane = distributed.TorchControlPlane(host_collectives=True)  # the exchange over gloo, no RCCL
+        report = {}
+        for name in ('f2_synthetic_g4.npz', 'f3_small_3.npz'):
+            fx = fio.load(name)
+            calls, genotypes, handler = fio.product_inputs(fx)
+            kwargs = dict(n_iterations=int(fx['em0_n_iterations']), p_genotype_clip=float(fx['em0_clip']),
+                          doublet_prior=float(fx['em0_dp']))
+            learnt, probs_df = distributed.learn_genotypes(calls, genotypes, handler, plane, device=0,
+                                                           barcode_prior_logits=fx.get('em0_prior_logits'), **kwargs)
+            want = fx[f'em0_it{kwargs["n_iterations"] - 1}_probs']
+            report[name] = (bool(np.allclose(learnt.variant_betas, fx['em0_learnt_betas'], rtol=3e-7, atol=0)),
+                            bool(np.array_equal(probs_df.values.argmax(1), want.argmax(1))),
+                            float(np.abs(probs_df.values - want).max()))
+        out.put((rank, report))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_processes_one_gpu_exchange_over_gloo():
+    """Two PROCESSES on the one GPU, the per-iteration exchange carried by gloo through the caller-provided-collectives
+    entry (TorchControlPlane(host_collectives=True)): the sharded learn_genotypes against the reference's outputs."""
+    import socket
+    import torch.multiprocessing as mp
+    with socket.socket() as s:
+        s.bind(('127.0.0.1', 0))
+        port = s.getsockname()[1]
+    ctx = mp.get_context('spawn')
+    out = ctx.Queue()
+    procs = [ctx.Process(target=_gloo_rank, args=(r, 2, port, out)) for r in range(2)]
+    for pr in procs:
+        pr.start()
+    for pr in procs:
+        pr.join(timeout=600)
+        assert pr.exitcode == 0
+    for _rank, report in (out.get(timeout=10) for _ in range(2)):
+        for name, (betas_close, argmax_same, max_dev) in report.items():
+            assert betas_close and argmax_same and max_dev <= 1e-5, (name, betas_close, argmax_same, max_dev)
