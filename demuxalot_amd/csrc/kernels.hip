@@ -1,12 +1,15 @@
 // kernels.hip -- gfx950 kernels of the Demultiplexer EM hot path.
 //
-//   k_probs_from_betas   P-step   demuxalot/demux.py:267-274
+//   k_probs_from_betas   P-step, one lane group per SNP group   demuxalot/demux.py:267-274
 //   k_estep_direct       E-step + softmax, one lane group (4..64 lanes) per barcode, options on lanes,
-//                        up to 16 options per lane (K <= 1024)   demux.py:246-265, :101/:152
+//                        up to 16 options per lane (K <= 1024; doublet tables up to 512)   demux.py:246-265, :101/:152
+//   k_estep_tiled        the same for singlet tables of 33..128 genotypes on many barcodes, bins of barcodes walked
+//                        variant tile by variant tile (tolerance mode)
 //   k_estep_block        E-step logits, one 256-thread workgroup per barcode and tile of options, genotype
-//                        rows staged in LDS (K > 1024: doublets of 45 or more genotypes)
-//   k_softmax_rows       softmax, bitmaps and codes of the rows k_estep_block left as logits
-//   k_mstep_calls / k_mstep / k_mcombine / k_mstep_exact
+//                        rows staged in LDS (wider option tables)
+//   k_softmax_rows       softmax, bitmaps and barcode codes of the rows k_estep_block left as logits
+//   k_mstep_calls / k_mstep_dense (G <= 64, few / many live posteriors per barcode), k_mstep (G > 64),
+//   k_mcombine, k_mstep_exact
 //                        M-step (variant-major, no atomics)      demux.py:113-118
 //   k_assign             per-barcode argmax of the posterior
 //
