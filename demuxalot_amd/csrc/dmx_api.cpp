@@ -561,7 +561,8 @@ int run_pstep(dmx_ctx *c, float lo, float hi, bool with_addition)
     timer_begin(c, DMX_T_PSTEP, &ev);
     const long long v0 = c->sliced ? c->cut[c->rank] : 0, v1 = c->sliced ? c->cut[c->rank + 1] : c->V;
     HIP_TRY(dmx::launch_probs_from_betas(c->stream, c->d_prior, with_addition ? c->d_add : nullptr, c->d_v2snp,
-                                         c->d_snp_ptr, c->d_snp_vars, v0, v1 - v0, c->G, c->d_prow, lo, hi, c->d_prob));
+                                         c->d_snp_ptr, c->d_snp_vars, v0, v1 - v0, c->sliced ? -1LL : (long long)c->S, c->G, c->d_prow, lo, hi,
+                                         c->d_prob));
     timer_end(c, DMX_T_PSTEP, ev);
     if (c->sliced) {  // everybody gets everybody's slice of genotype_prob
         timer_begin(c, DMX_T_ALLREDUCE, &ev);
@@ -1060,7 +1061,7 @@ int dmx_probs_from_betas_f64(dmx_ctx *c, const double *betas, float lo, float hi
     HIP_TRY(hipMalloc((void **)&d_b, (vg ? vg : 1) * sizeof(double)));
     hipError_t e = vg ? hipMemcpyAsync(d_b, betas, vg * sizeof(double), hipMemcpyHostToDevice, c->stream) : hipSuccess;
     if (e == hipSuccess)
-        e = dmx::launch_probs_from_betas_f64(c->stream, d_b, c->d_v2snp, c->d_snp_ptr, c->d_snp_vars, c->V, c->G, c->d_prow, lo, hi, c->d_prob);
+        e = dmx::launch_probs_from_betas_f64(c->stream, d_b, c->d_v2snp, c->d_snp_ptr, c->d_snp_vars, c->V, c->S, c->G, c->d_prow, lo, hi, c->d_prob);
     int rc_copy = 0;
     if (e == hipSuccess && vg) rc_copy = copy_prob_out(c, prob_out);
     if (e == hipSuccess) e = hipStreamSynchronize(c->stream);

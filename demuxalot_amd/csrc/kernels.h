@@ -109,12 +109,12 @@ inline int item_calls_for(long long n_calls)
 // P-step of variants [v_begin, v_begin + n_rows) (whole SNP groups); the result goes to row prow[v] of `prob`
 // (padded multi-GPU layout) or row v when prow is null
 hipError_t launch_probs_from_betas(hipStream_t st, const float *prior, const float *addition, const int *v2snp,
-                                   const int *snp_ptr, const int *snp_vars, long long v_begin, long long n_rows, int G,
-                                   const int *prow, float lo, float hi, float *prob);
+                                   const int *snp_ptr, const int *snp_vars, long long v_begin, long long n_rows, long long n_snps,
+                                   int G, const int *prow, float lo, float hi, float *prob);
 // the same from caller-supplied float64 betas (no addition): numpy divides float64 / float64 and rounds once
 hipError_t launch_probs_from_betas_f64(hipStream_t st, const double *betas, const int *v2snp, const int *snp_ptr,
-                                       const int *snp_vars, long long V, int G, const int *prow, float lo, float hi,
-                                       float *prob);
+                                       const int *snp_vars, long long V, long long n_snps, int G, const int *prow, float lo,
+                                       float hi, float *prob);
 // sets flags[0] bit 0 when a value lies outside [0, 1] or is not finite
 hipError_t launch_check_unit_range(hipStream_t st, const float *x, long long n, int *flags);
 hipError_t launch_estep(hipStream_t st, const EstepArgs &a, bool pairs);

@@ -66,41 +66,56 @@ __global__ __launch_bounds__(256) void k_probs_from_betas(const T *__restrict__ 
                                                           const int *__restrict__ v2snp,
                                                           const int *__restrict__ snp_ptr,
                                                           const int *__restrict__ snp_vars, long long v_begin,
-                                                          long long n_rows, int G, const int *__restrict__ prow,
-                                                          float clip_lo, float clip_hi, float *__restrict__ prob)
+                                                          long long n_rows, long long n_snps, int G,
+                                                          const int *__restrict__ prow, float clip_lo, float clip_hi,
+                                                          float *__restrict__ prob)
 {
-    // variants [v_begin, v_begin + n_rows): whole SNP groups; prob row of variant v = prow[v] (padded multi-GPU
-    // layout) or v
+    // n_snps >= 0: the whole table, one lane group per SNP 0 .. n_snps - 1.  Otherwise variants [v_begin, v_begin +
+    // n_rows) (whole SNP groups: a rank's slice), one lane group per variant, the SNP's first variant working.
+    // prob row of variant v = prow[v] (padded multi-GPU layout) or v.
     const int lane = threadIdx.x & 63, li = lane & (L - 1);
     const long long r = ((long long)blockIdx.x * 4 + (threadIdx.x >> 6)) * (64 / L) + lane / L;
-    if (r >= n_rows) return;
-    const long long v = v_begin + r;
-    const int snp = v2snp[v];
+    if (r >= (n_snps >= 0 ? n_snps : n_rows)) return;
+    const int snp = n_snps >= 0 ? (int)r : v2snp[v_begin + r];
     const int j0 = snp_ptr[snp], j1 = snp_ptr[snp + 1];
-    if (snp_vars[j0] != v) return;
-    constexpr int HELD = 4;  // betas of the first variants of the group stay in registers
+    if (n_snps < 0 && snp_vars[j0] != v_begin + r) return;
+    constexpr int HELD = 4;  // the first variants of the group: their loads are issued together, their betas stay in registers
+    const int cnt = j1 - j0;
+    long long w[HELD];
+#pragma unroll
+    for (int q = 0; q < HELD; q++) w[q] = q < cnt ? (long long)snp_vars[j0 + q] : -1;
     for (int g = li; g < G; g += L) {
         T held[HELD];
+#pragma unroll
+        for (int q = 0; q < HELD; q++) {
+            held[q] = (T)0;
+            if (w[q] >= 0) {
+                const long long o = w[q] * G + g;
+                held[q] = addition ? prior[o] + addition[o] : prior[o];  // float32 add, demux.py:90
+            }
+        }
         double den = 0.0;
-        for (int j = j0; j < j1; j++) {  // increasing variant index (np.bincount order)
+#pragma unroll
+        for (int q = 0; q < HELD; q++) den += (double)held[q];  // increasing variant index (np.bincount order); absent: + 0
+        for (int j = j0 + HELD; j < j1; j++) {
             const long long o = (long long)snp_vars[j] * G + g;
-            const T b = addition ? prior[o] + addition[o] : prior[o];  // float32 add, demux.py:90
-            if (j - j0 < HELD) held[j - j0] = b;
-            den += (double)b;
+            den += (double)(addition ? prior[o] + addition[o] : prior[o]);
         }
         den = fmax(den, 1e-7);
-        for (int j = j0; j < j1; j++) {
-            const long long w = snp_vars[j];
-            T beta;
-            if (j - j0 < HELD) {
-                beta = held[j - j0];
-            } else {
-                const long long o = w * G + g;
-                beta = addition ? prior[o] + addition[o] : prior[o];
-            }
-            float p = (float)((double)beta / den);
+#pragma unroll
+        for (int q = 0; q < HELD; q++) {
+            if (w[q] < 0) continue;
+            float p = (float)((double)held[q] / den);
             p = fminf(fmaxf(p, clip_lo), clip_hi);  // ndarray.clip(lo, hi) = minimum(maximum(x, lo), hi)
-            prob[(prow ? (long long)prow[w] : w) * G + g] = p;
+            prob[(prow ? (long long)prow[w[q]] : w[q]) * G + g] = p;
+        }
+        for (int j = j0 + HELD; j < j1; j++) {
+            const long long v_j = snp_vars[j];
+            const long long o = v_j * G + g;
+            const T beta = addition ? prior[o] + addition[o] : prior[o];
+            float p = (float)((double)beta / den);
+            p = fminf(fmaxf(p, clip_lo), clip_hi);
+            prob[(prow ? (long long)prow[v_j] : v_j) * G + g] = p;
         }
     }
 }
@@ -1726,13 +1741,14 @@ static inline unsigned blocks_for(long long n, int per_block) { return (unsigned
 
 template <typename T>
 static hipError_t launch_pstep(hipStream_t st, const T *prior, const T *addition, const int *v2snp, const int *snp_ptr,
-                               const int *snp_vars, long long v_begin, long long n_rows, int G, const int *prow, float lo, float hi,
-                               float *prob)
+                               const int *snp_vars, long long v_begin, long long n_rows, long long n_snps, int G, const int *prow,
+                               float lo, float hi, float *prob)
 {
     if (n_rows * G == 0) return hipSuccess;
+    const long long groups = n_snps >= 0 ? n_snps : n_rows;
 #define PSTEP(L)                                                                                                          \
-    hipLaunchKernelGGL((k_probs_from_betas<T, L>), dim3(blocks_for(n_rows, 4 * (64 / L))), dim3(256), 0, st, prior, addition, \
-                       v2snp, snp_ptr, snp_vars, v_begin, n_rows, G, prow, lo, hi, prob)
+    hipLaunchKernelGGL((k_probs_from_betas<T, L>), dim3(blocks_for(groups, 4 * (64 / L))), dim3(256), 0, st, prior, addition, \
+                       v2snp, snp_ptr, snp_vars, v_begin, n_rows, n_snps, G, prow, lo, hi, prob)
     if (G <= 4) PSTEP(4);
     else if (G <= 8) PSTEP(8);
     else if (G <= 16) PSTEP(16);
@@ -1742,18 +1758,19 @@ static hipError_t launch_pstep(hipStream_t st, const T *prior, const T *addition
     return hipGetLastError();
 }
 
+// n_snps >= 0: [v_begin, v_begin + n_rows) is the whole table and the SNPs are numbered 0 .. n_snps - 1
 hipError_t launch_probs_from_betas(hipStream_t st, const float *prior, const float *addition, const int *v2snp,
-                                   const int *snp_ptr, const int *snp_vars, long long v_begin, long long n_rows, int G,
-                                   const int *prow, float lo, float hi, float *prob)
+                                   const int *snp_ptr, const int *snp_vars, long long v_begin, long long n_rows, long long n_snps,
+                                   int G, const int *prow, float lo, float hi, float *prob)
 {
-    return launch_pstep<float>(st, prior, addition, v2snp, snp_ptr, snp_vars, v_begin, n_rows, G, prow, lo, hi, prob);
+    return launch_pstep<float>(st, prior, addition, v2snp, snp_ptr, snp_vars, v_begin, n_rows, n_snps, G, prow, lo, hi, prob);
 }
 
 hipError_t launch_probs_from_betas_f64(hipStream_t st, const double *betas, const int *v2snp, const int *snp_ptr,
-                                       const int *snp_vars, long long V, int G, const int *prow, float lo, float hi,
+                                       const int *snp_vars, long long V, long long n_snps, int G, const int *prow, float lo, float hi,
                                        float *prob)
 {
-    return launch_pstep<double>(st, betas, (const double *)nullptr, v2snp, snp_ptr, snp_vars, 0LL, V, G, prow, lo, hi, prob);
+    return launch_pstep<double>(st, betas, (const double *)nullptr, v2snp, snp_ptr, snp_vars, 0LL, V, n_snps, G, prow, lo, hi, prob);
 }
 
 // flags[0] |= 1 when any of the n values is outside [0, 1] or not finite (caller-supplied probability tables)
