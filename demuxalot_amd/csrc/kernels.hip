@@ -1514,8 +1514,16 @@ __global__ __launch_bounds__(256) void k_mcombine(const double *__restrict__ par
 {
     const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= (v1 - v0) * G) return;
-    const long long v = v0 + i / G;
-    const int g = (int)(i % G);
+    long long row;
+    int g;
+    if ((v1 - v0) * G < (1ll << 31)) {  // (uniform) the 64-bit division is a hundred instructions
+        row = (unsigned)i / (unsigned)G;
+        g = (int)((unsigned)i - (unsigned)row * (unsigned)G);
+    } else {
+        row = i / G;
+        g = (int)(i % G);
+    }
+    const long long v = v0 + row;
     const long long it0 = item_ptr[v], it1 = item_ptr[v + 1];
     double s = 0.0;
     for (long long it = it0; it < it1; it++) s += partial[(size_t)it * G + g];
