@@ -69,6 +69,7 @@ SIGNATURES = {
     'dmx_reset_timings': (c_int, [_P]),
     'dmx_device_bytes': (c_int, [_P, POINTER(c_int64)]),
     'dmx_set_exact_additions': (c_int, [_P, c_int]),
+    'dmx_get_redo_count': (c_int, [_P, POINTER(c_int64)]),
     'dmx_set_estep_mode': (c_int, [_P, c_int]),
     'dmx_set_estep_schedule': (c_int, [_P, c_int]),
     'dmx_set_mstep_wide_addresses': (c_int, [_P, c_int]),

@@ -934,6 +934,19 @@ int dmx_set_estep_schedule(dmx_ctx *c, int tiled)
     return 0;
 }
 
+int dmx_get_redo_count(dmx_ctx *c, int64_t *count)
+{
+    DMX_TRY(bind(c));
+    if (!count) return fail(DMX_ERR_INVALID, "null argument");
+    unsigned n = 0;
+    if (c->d_n_redo) {
+        HIP_TRY(hipMemcpyAsync(&n, c->d_n_redo, sizeof(unsigned), hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(hipStreamSynchronize(c->stream));
+    }
+    *count = (int64_t)n;
+    return 0;
+}
+
 int dmx_set_mstep_wide_addresses(dmx_ctx *c, int wide)
 {
     if (!c) return fail(DMX_ERR_INVALID, "null context");

@@ -351,6 +351,12 @@ class DeviceContext:
         """include/demux_hip.h: dmx_set_mstep_wide_addresses (the M-step form of the largest problems, at any size)."""
         check(self._lib.dmx_set_mstep_wide_addresses(self._h, int(bool(wide))))
 
+    def redo_count(self):
+        """Sums the last exact-mode M-step redid in the reference's order (include/demux_hip.h: dmx_get_redo_count)."""
+        n = ctypes.c_int64(0)
+        check(self._lib.dmx_get_redo_count(self._h, ctypes.byref(n)))
+        return n.value
+
     def set_exact_additions(self, exact):
         """M-step summation mode (include/demux_hip.h: dmx_set_exact_additions). Default: exact."""
         check(self._lib.dmx_set_exact_additions(self._h, int(bool(exact))))

@@ -146,6 +146,8 @@ int dmx_set_prior_betas(dmx_ctx *ctx, const float *raw_betas, double default_pri
  * (+3.6 % per EM iteration on the 200k x 100k x 64 workload).  exact == 0: accept the combined sum.  Single-item
  * variants, and everything in the E-step, are bit-identical in both modes. */
 int dmx_set_exact_additions(dmx_ctx *ctx, int exact);
+/* Number of (variant, genotype) sums the last exact-mode M-step redid in the reference's order (instrumentation). */
+int dmx_get_redo_count(dmx_ctx *ctx, int64_t *count);
 
 /* E-step arithmetic.
  * DMX_ESTEP_EXACT (default): every term log(p (1 - e) + max(e, 1e-4)) is evaluated with numpy's float32 log
