@@ -131,6 +131,44 @@ def measured_traffic(workload, kernel):
         return None
 
 
+def live_traffic(args, kernel):
+    """HBM-side bytes per launch of `kernel`, measured now: two child runs of this script under
+    `rocprofv3 --kernel-trace --pmc` (FETCH_SIZE and WRITE_SIZE in separate passes, as MI355X_MICROARCH.md prescribes;
+    both are reported in KiB; the row gathers are 4-byte-per-lane reads, not the 16-byte streams with the documented 2x
+    under-count).  None when the profiler is not available or a pass fails - the caller then falls back to the
+    figures committed under profiles/."""
+    import csv
+    import glob
+    import shutil
+    import subprocess
+    import tempfile
+    if shutil.which('rocprofv3') is None:
+        return None
+    out_dir = tempfile.mkdtemp(prefix='bench_pmc_', dir='/tmp')
+    child = ['python3', os.path.join(ROOT, 'bench.py'), '--workload', args.workload, '--steps', '2', '--warmup', '1',
+             '--no-cpu-baseline', '--no-fast-mode', '--no-live-traffic'] + (['--flat-genotypes'] if args.flat_genotypes else [])
+    env = dict(os.environ, TMPDIR='/tmp')
+    total = 0.0
+    try:
+        for counter in ('FETCH_SIZE', 'WRITE_SIZE'):
+            where = os.path.join(out_dir, counter)
+            subprocess.run(['rocprofv3', '--kernel-trace', '--pmc', counter, '--output-format', 'csv', '-d', where, '--'] + child,
+                           env=env, cwd=ROOT, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=600, check=True)
+            values = []
+            for path in glob.glob(os.path.join(where, '**', '*counter_collection.csv'), recursive=True):
+                for row in csv.DictReader(open(path)):
+                    if kernel in row['Kernel_Name'] and row['Counter_Name'] == counter:
+                        values.append(float(row['Counter_Value']))
+            if not values:
+                return None
+            total += 1024.0 * sum(values) / len(values)
+        return total
+    except (OSError, subprocess.SubprocessError, KeyError, ValueError):
+        return None
+    finally:
+        shutil.rmtree(out_dir, ignore_errors=True)
+
+
 def _lib_device_count():
     from demuxalot_amd import _lib
     return _lib.device_count()
@@ -147,6 +185,8 @@ def main():
                     help='weak: the workload per GPU; strong: the workload in total, barcodes sharded over the GPUs')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-fast-mode', action='store_true', help='skip the second timed region (tolerance-mode E-step)')
+    ap.add_argument('--no-live-traffic', action='store_true',
+                    help='roofline.traffic from profiles/pmc_traffic.json instead of two rocprofv3 --pmc child runs')
     ap.add_argument('--flat-genotypes', action='store_true',
                     help='worst case of the M-step: all-equal betas, so every posterior is 1/G and every call contributes to '
                          'every genotype (the start-from-assignment scenario of tests/test_synthetic.py:200-239 before any label '
@@ -316,6 +356,12 @@ def main():
             e_fast = fast['kernel_ms']['estep']
             fast['estep_hbm_frac'] = ab['estep'] / (e_fast * 1e-3) / 1e9 / 8000.0
             fast['delivered_gather_GBps'] = (N * 4 * G) / (e_fast * 1e-3) / 1e9
+        out['roofline']['traffic_source'] = 'profiles/pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE + WRITE_SIZE of an earlier run)'
+        if world == 1 and not args.no_live_traffic and not args.no_cpu_baseline:
+            live = live_traffic(args, out['roofline']['kernel'])
+            if live is not None:
+                out['roofline']['traffic'] = live
+                out['roofline']['traffic_source'] = 'rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, two child runs of this command (live)'
         if world == 1 and not args.no_cpu_baseline:
             base, ref_logits, ref_post, n_s = cpu_baseline(problem, betas, dp)
             out['cpu_baseline'] = base
