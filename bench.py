@@ -153,7 +153,7 @@ def live_traffic(args, kernel):
         for counter in ('FETCH_SIZE', 'WRITE_SIZE'):
             where = os.path.join(out_dir, counter)
             subprocess.run(['rocprofv3', '--kernel-trace', '--pmc', counter, '--output-format', 'csv', '-d', where, '--'] + child,
-                           env=env, cwd=ROOT, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=600, check=True)
+                           env=env, cwd=ROOT, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=180, check=True)
             values = []
             for path in glob.glob(os.path.join(where, '**', '*counter_collection.csv'), recursive=True):
                 for row in csv.DictReader(open(path)):
