@@ -101,7 +101,7 @@ def roofline(workload, ab, e_ms, m_ms, timers, N, G, K):
     per_launch = lambda name: timers[name]['ms'] / max(1, timers[name]['launches'])
     terms_per_s = N * K / (e_ms * 1e-3)
     peak_terms = N_SIMD * PEAK_CLOCK_HZ * 64 / VALU_CYCLES_PER_TERM
-    kernel = 'k_estep_direct' if K <= 1024 else 'k_estep_block'
+    kernel = 'k_estep_block' if K > 1024 or (K > G and K > 512) else 'k_estep_direct'  # kernels.hip: launch_estep
     return {
         'bound': 'valu-issue',
         'kernel': kernel, 'achieved': achieved, 'peak': 8000.0, 'unit': 'GB/s', 'frac': achieved / 8000.0,
