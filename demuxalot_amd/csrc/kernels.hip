@@ -1849,7 +1849,7 @@ hipError_t launch_estep(hipStream_t st, const EstepArgs &a, bool pairs)
     const int K = a.K;
     // tile-major schedule (built by the repack for large singlet problems).  It pays in the tolerance mode, whose
     // time is the row gathers (1.50 ms against 1.72 ms on 200k x 100k x 64: L2 hit rate 44 % -> 68 %); the exact mode
-    // is bound by its arithmetic and only pays the schedule's overhead (2.78 against 2.72 ms), so it keeps one
+    // is bound by its arithmetic and only pays the schedule's overhead (2.94 against 2.70 ms), so it keeps one
     // barcode per wavefront unless the schedule is forced (a.tiled == 2: tests).
     if (a.n_bins > 0 && !pairs && K > 32 && K <= 128 && (a.fast || a.tiled == 2)) {
         if (K <= 64) launch_tiled<1>(st, a);
