@@ -244,6 +244,15 @@ void release_problem(dmx_ctx *c)
     dev_free(c, &c->d_first, (size_t)c->B);
     dev_free(c, &c->d_dense_calls, (size_t)1 + dmx::DENSE_SLOTS);
     c->dense_stat_valid = false;
+    dev_free(c, &c->d_dict, c->cap_dict_rows * dmx::DICT_CAP);
+    dev_free(c, &c->d_codes, c->cap_dict_rows * (size_t)c->G);
+    dev_free(c, &c->d_ocodes, c->cap_ocodes);
+    dev_free(c, &c->d_dict_stat, (size_t)1);
+    c->cap_dict_rows = c->cap_ocodes = 0;
+    c->dict_candidate = false;
+    c->add_is_zero = true;
+    c->estep_form = DMX_FORM_NONE;
+    c->dict_distinct = 0;
     dev_free(c, &c->d_pen, (size_t)c->cap_k);
     dev_free(c, &c->d_pairs, (size_t)c->cap_k);
     dev_free(c, &c->d_sum_plan, c->cap_sum_plan);
@@ -314,6 +323,7 @@ int ensure_options(dmx_ctx *c, int with_doublets, const float *penalties)
     HIP_TRY(hipMemcpyAsync(c->d_pen, penalties, sizeof(float) * K, hipMemcpyHostToDevice, c->stream));
     DMX_TRY(dmx::ensure_sum_plan(c, K));
     HIP_TRY(hipStreamSynchronize(c->stream));  // `pairs` is a local
+    if ((int)K != c->K) c->have_post64 = false;  // the float64 results of dmx_estep_snp were laid out for another K
     c->K = (int)K;
     return 0;
 }
@@ -491,8 +501,8 @@ int layout_exchange(dmx_ctx *c)
             for (long long v = c->cut[r]; v < c->cut[r + 1]; v++) prow[v] = (int)(r * rows + (v - c->cut[r]));
         DMX_TRY(dev_alloc(c, &c->d_prow, (size_t)V));
         HIP_TRY(hipMemcpyAsync(c->d_prow, prow.data(), sizeof(int) * V, hipMemcpyHostToDevice, st));
-        HIP_TRY(dmx::launch_remap_row_offsets(st, c->d_call_pairs, c->n_pairs, (unsigned)G * 4u, c->d_prow));
-        if (c->d_tile_stream) HIP_TRY(dmx::launch_remap_row_offsets(st, c->d_tile_stream, c->n_pairs, (unsigned)G * 4u, c->d_prow));
+        HIP_TRY(dmx::launch_remap_row_offsets(st, c->d_call_pairs, c->n_pairs, (unsigned)G * 4u, c->d_prow, true));
+        if (c->d_tile_stream) HIP_TRY(dmx::launch_remap_row_offsets(st, c->d_tile_stream, c->n_pairs, (unsigned)G * 4u, c->d_prow, false));
         const size_t elem = c->reduce_dtype == DMX_F64 ? 8 : 4;
         c->exch_bytes = (size_t)new_rows * G * 8;  // float64 sums; also the float32 staging of the addition gather
         c->recv_bytes = (size_t)rows * G * elem;
@@ -572,6 +582,60 @@ int run_pstep(dmx_ctx *c, float lo, float hi, bool with_addition)
         if (rc) return rc;
     }
     c->have_probs = true;
+    c->dict_candidate = !with_addition || c->add_is_zero;
+    return 0;
+}
+
+// Dictionary form of the E-step (estep_dict.hip): distinct values per row of the current genotype table.  Returns
+// the form to run in *form (DMX_FORM_DIRECT when some row does not fit or the form does not exist for the shape).
+int prepare_dictionary(dmx_ctx *c, bool pairs, dmx::EstepArgs &a, int *form)
+{
+    *form = DMX_FORM_DIRECT;
+    a.dict_n = 0;
+    c->dict_distinct = 0;
+    const bool wanted = c->dict_mode == 2 || (c->dict_mode == 1 && c->dict_candidate);
+    if (!wanted || c->estep_mode != DMX_ESTEP_EXACT || c->B == 0 || c->prob_rows == 0) return 0;
+    const int G = c->G;
+    const long long K = c->K, rows = c->prob_rows;
+    const bool lane_form = !pairs || K <= dmx::DICT_PAIR_LANE_K;
+    if (!lane_form) return 0;
+    if ((unsigned long long)rows * (unsigned long long)(pairs ? K : G) >= (1ull << 32)) return 0;  // code table beyond buffer addressing
+    if ((size_t)rows > c->cap_dict_rows) {
+        dev_free(c, &c->d_dict, c->cap_dict_rows * dmx::DICT_CAP);
+        dev_free(c, &c->d_codes, c->cap_dict_rows * (size_t)G);
+        c->cap_dict_rows = 0;
+        DMX_TRY(dev_alloc(c, &c->d_dict, (size_t)rows * dmx::DICT_CAP));
+        DMX_TRY(dev_alloc(c, &c->d_codes, (size_t)rows * G));
+        c->cap_dict_rows = (size_t)rows;
+    }
+    if (!c->d_dict_stat) DMX_TRY(dev_alloc(c, &c->d_dict_stat, (size_t)1));
+    HIP_TRY(dmx::launch_build_dict(c->stream, c->d_prob, rows, G, c->d_dict, c->d_codes, c->d_dict_stat));
+    unsigned distinct = 0;
+    HIP_TRY(hipMemcpyAsync(&distinct, c->d_dict_stat, sizeof(unsigned), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    c->dict_distinct = (int)distinct;
+    if (distinct == 0 || (int)distinct > (pairs ? dmx::DICT_PAIR_CAP : dmx::DICT_CAP)) return 0;
+    a.dict_n = (int)distinct;
+    a.dict = c->d_dict;
+    a.codes = c->d_codes;
+    if (pairs) {
+        const size_t need_bytes = (size_t)rows * (size_t)K;
+        if (need_bytes > c->cap_ocodes) {
+            dev_free(c, &c->d_ocodes, c->cap_ocodes);
+            c->cap_ocodes = 0;
+            DMX_TRY(dev_alloc(c, &c->d_ocodes, need_bytes));
+            c->cap_ocodes = need_bytes;
+        }
+        HIP_TRY(dmx::launch_build_pair_codes(c->stream, c->d_codes, c->d_pairs, rows, G, (int)K, c->d_ocodes));
+        a.ocodes = c->d_ocodes;
+        a.ocode_pitch = (int)K;
+        a.ocode_bytes = (unsigned)need_bytes;
+    } else {
+        a.ocodes = c->d_codes;
+        a.ocode_pitch = G;
+        a.ocode_bytes = (unsigned)((size_t)rows * G);
+    }
+    *form = DMX_FORM_DICT;
     return 0;
 }
 
@@ -609,9 +673,20 @@ int run_estep(dmx_ctx *c, int with_doublets, bool with_prior, int prior_dtype, f
     a.bin_rows = c->d_bin_rows;
     a.bin_ptr = c->d_bin_ptr;
     a.tile_stream = c->d_tile_stream;
+    a.dict_n = 0;
+    a.dict = nullptr;
+    a.codes = a.ocodes = nullptr;
+    a.ocode_bytes = 0;
+    a.ocode_pitch = 0;
     std::pair<hipEvent_t, hipEvent_t> ev;
     timer_begin(c, DMX_T_ESTEP, &ev);
-    HIP_TRY(dmx::launch_estep(c->stream, a, with_doublets != 0));
+    int form = DMX_FORM_DIRECT;
+    DMX_TRY(prepare_dictionary(c, with_doublets != 0, a, &form));  // part of the E-step's time
+    if (form == DMX_FORM_DICT)
+        HIP_TRY(dmx::launch_estep_dict(c->stream, a, with_doublets != 0));
+    else
+        HIP_TRY(dmx::launch_estep(c->stream, a, with_doublets != 0));
+    c->estep_form = form;
     if (a.dense_calls) HIP_TRY(dmx::launch_sum_dense(c->stream, c->d_dense_calls));
     timer_end(c, DMX_T_ESTEP, ev);
     c->have_post = true;
@@ -645,6 +720,7 @@ int run_mstep(dmx_ctx *c, float power)
                                        c->G <= 64 ? c->d_first : nullptr));
         c->nz_floor = 0.0f;
     }
+    c->add_is_zero = false;
     std::pair<hipEvent_t, hipEvent_t> ev;
     const bool dist = c->attached();  // also with one rank: keeps the collective path testable on one GPU
     unsigned long long *redo = c->exact_additions ? c->d_redo : nullptr;
@@ -926,6 +1002,22 @@ int dmx_set_estep_mode(dmx_ctx *c, int mode)
     return 0;
 }
 
+int dmx_set_estep_dictionary(dmx_ctx *c, int mode)
+{
+    if (!c) return fail(DMX_ERR_INVALID, "null context");
+    if (mode < 0 || mode > 2) return fail(DMX_ERR_INVALID, "dictionary mode must be 0, 1 or 2");
+    c->dict_mode = mode;
+    return 0;
+}
+
+int dmx_get_estep_form(dmx_ctx *c, int32_t *form, int32_t *distinct_values)
+{
+    if (!c) return fail(DMX_ERR_INVALID, "null context");
+    if (form) *form = c->estep_form;
+    if (distinct_values) *distinct_values = c->dict_distinct;
+    return 0;
+}
+
 int dmx_set_estep_schedule(dmx_ctx *c, int tiled)
 {
     if (!c) return fail(DMX_ERR_INVALID, "null context");
@@ -1032,6 +1124,7 @@ int dmx_set_addition(dmx_ctx *c, const float *addition)
     } else {
         HIP_TRY(hipMemsetAsync(c->d_add, 0, sizeof(float) * (vg ? vg : 1), c->stream));
     }
+    c->add_is_zero = addition == nullptr;
     c->add_partial = false;
     return 0;
 }
@@ -1061,6 +1154,7 @@ int dmx_set_probs(dmx_ctx *c, const float *prob)
     HIP_TRY(hipStreamSynchronize(c->stream));
     if (flag) return fail(DMX_ERR_INVALID, "genotype_prob has entries outside [0, 1] (or NaN)");
     c->have_probs = true;
+    c->dict_candidate = true;
     return 0;
 }
 
@@ -1083,6 +1177,7 @@ int dmx_probs_from_betas_f64(dmx_ctx *c, const double *betas, float lo, float hi
     if (e != hipSuccess) return fail(DMX_ERR_HIP, "P-step from float64 betas: %s", hipGetErrorString(e));
     if (rc_copy) return rc_copy;
     c->have_probs = true;
+    c->dict_candidate = true;
     return 0;
 }
 
@@ -1125,6 +1220,7 @@ int dmx_em(dmx_ctx *c, int n_iterations, float lo, float hi, int with_doublets, 
     DMX_TRY(upload_prior_logits(c, prior_logits, prior_dtype));
     const size_t vg = (size_t)c->V * c->G;
     HIP_TRY(hipMemsetAsync(c->d_add, 0, sizeof(float) * (vg ? vg : 1), c->stream));  // demux.py:86
+    c->add_is_zero = true;
     c->add_partial = false;
     for (int it = 0; it < n_iterations; it++) {
         DMX_TRY(run_pstep(c, lo, hi, true));

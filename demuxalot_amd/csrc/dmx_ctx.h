@@ -74,6 +74,18 @@ struct dmx_ctx {
     bool exact_additions = true;  // dmx_set_exact_additions
     int estep_mode = DMX_ESTEP_EXACT;  // dmx_set_estep_mode
     int tiled_estep = 1;               // dmx_set_estep_schedule: 0 never, 1 when it pays, 2 whenever the repack built one
+    // dictionary form of the E-step (estep_dict.hip): tried when the genotype table was computed without a beta
+    // addition (or supplied by the caller), used when every row has few distinct values
+    int dict_mode = 1;            // dmx_set_estep_dictionary: 0 never, 1 when the table is a candidate, 2 try always
+    bool add_is_zero = true;      // d_add holds zeros (no M-step / dmx_set_addition since the last reset)
+    bool dict_candidate = false;  // the current d_prob was computed without an addition, or set by the caller
+    int estep_form = 0;           // form of the last E-step: DMX_FORM_*
+    int dict_distinct = 0;        // most distinct values per row found by the last dictionary build (0: none built)
+    float *d_dict = nullptr;             // [prob_rows, DICT_CAP]
+    unsigned char *d_codes = nullptr;    // [prob_rows, G]
+    unsigned char *d_ocodes = nullptr;   // [prob_rows, K] (doublet runs with K <= DICT_PAIR_LANE_K)
+    unsigned *d_dict_stat = nullptr;     // [1]
+    size_t cap_dict_rows = 0, cap_ocodes = 0;
     float nz_floor = 0.0f;     // threshold the current d_nz / d_first were built with
     uint2 *d_first = nullptr;  // [B] {posterior of the lowest live singlet column, count | first live columns} (G <= 64): EstepArgs::first
     unsigned long long *d_dense_calls = nullptr;  // [1] E-step statistic read by the M-step kernels (kernels.h)

@@ -1,0 +1,181 @@
+// estep_epilogue.h -- what the E-step kernels of kernels.hip and estep_dict.hip share: the 8-byte barcode code of the
+// M-step, numpy's pairwise row sum over register-resident values, and the softmax epilogue of the lane-per-option forms.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "kernels.h"
+#include "np_math.h"
+
+namespace dmx {
+
+static __device__ __forceinline__ double shfl_xor_f64(double v, int mask)
+{
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __shfl_xor(lo, mask);
+    hi = __shfl_xor(hi, mask);
+    return __hiloint2double(hi, lo);
+}
+
+// What the M-step needs to know of a barcode whose row has at most NZ_CODE live posteriors, in 8 bytes
+// (EstepArgs::first, written by the E-step epilogues): x = bits of the posterior of the lowest live genotype,
+// y = count of live genotypes (7 bits) | the first four live genotypes (6 bits each).  One 8-byte gather per call
+// from a 1.6 MB table (200k barcodes) is what the call-parallel part runs on; the 64-bit bitmap is only read for
+// the dense calls.  [The M-step runs on its loads, not on its arithmetic: bitmap (8 B) + posterior
+// (4 B) from two tables took 0.85 ms - the L2s at 65 % of their request rate -, one gather 0.70.]
+constexpr int NZ_CODE = 4;
+__device__ __forceinline__ uint2 nz_code(unsigned long long live, float first_posterior)
+{
+    unsigned code = (unsigned)__popcll(live);
+#pragma unroll
+    for (int t = 0; t < NZ_CODE; t++) {
+        if (live) code |= (unsigned)__builtin_ctzll(live) << (7 + 6 * t);
+        live &= live - 1ull;
+    }
+    return make_uint2(code & 127u ? __float_as_uint(first_posterior) : 0u, code);
+}
+
+// ------------------------------------------------------------------------------------
+// helpers for the in-register softmax of the direct kernel: option k of a lane group lives in
+// lane (group base + (k & 63)), register slot (k >> 6).
+// ------------------------------------------------------------------------------------
+template <int A>
+static __device__ __forceinline__ float reg_elem(const float (&x)[A], int i, int gbase)
+{
+    float v = 0.0f;
+#pragma unroll
+    for (int a = 0; a < A; a++) {
+        const float t = __shfl(x[a], gbase + (i & 63));
+        v = ((i >> 6) == a) ? t : v;
+    }
+    return v;
+}
+
+// numpy pairwise block (n <= 128) over elements [start, start+n) held in registers.
+// Lane groups are 8-aligned whenever n >= 8 can occur, so (lane & 7) indexes the 8 partial sums
+// and the xor butterflies stay inside the group.
+template <int A>
+static __device__ __forceinline__ float reg_block_sum(const float (&x)[A], int start, int n, int lane, int gbase)
+{
+    if (n < 8) {
+        float res = 0.0f;
+        for (int i = 0; i < n; i++) res += reg_elem<A>(x, start + i, gbase);
+        return res;
+    }
+    const int j = lane & 7;
+    const int nfull = n - (n & 7);
+    float r = reg_elem<A>(x, start + j, gbase);
+    for (int i = 8; i < nfull; i += 8) r += reg_elem<A>(x, start + i + j, gbase);
+    r = r + __shfl_xor(r, 1);
+    r = r + __shfl_xor(r, 2);
+    r = r + __shfl_xor(r, 4);
+    for (int i = nfull; i < n; i++) r += reg_elem<A>(x, start + i, gbase);
+    return r;
+}
+
+static __device__ __forceinline__ int pw_half(int n)
+{
+    int h = n / 2;
+    return h - (h % 8);
+}
+
+// np.sum of K <= 1024 register-resident elements (one 8192-element numpy chunk): the pairwise split
+// tree walked iteratively, leaves (<= 128 elements) summed by reg_block_sum.  Uniform control flow.
+template <int A>
+static __device__ __forceinline__ float reg_row_sum(const float (&x)[A], int K, int lane, int gbase)
+{
+    if (K <= 128) return reg_block_sum<A>(x, 0, K, lane, gbase);
+    // explicit post-order traversal; depth <= 4 for K <= 1024
+    int st_start[6], st_len[6], st_state[6];
+    float st_left[6];
+    int sp = 0;
+    st_start[0] = 0;
+    st_len[0] = K;
+    st_state[0] = 0;
+    float ret = 0.0f;
+    while (sp >= 0) {
+        const int s0 = st_start[sp], len = st_len[sp];
+        if (len <= 128) {
+            ret = reg_block_sum<A>(x, s0, len, lane, gbase);
+            sp--;
+            continue;
+        }
+        const int half = pw_half(len);
+        if (st_state[sp] == 0) {
+            st_state[sp] = 1;
+            sp++;
+            st_start[sp] = s0;
+            st_len[sp] = half;
+            st_state[sp] = 0;
+        } else if (st_state[sp] == 1) {
+            st_left[sp] = ret;
+            st_state[sp] = 2;
+            sp++;
+            st_start[sp] = s0 + half;
+            st_len[sp] = len - half;
+            st_state[sp] = 0;
+        } else {
+            ret = st_left[sp] + ret;
+            sp--;
+        }
+    }
+    return ret;
+}
+
+// Epilogue of the direct forms: penalties, optional prior, softmax as scipy evaluates it, the M-step's bitmap.
+// acc[s] = float64 sum of the log terms of option kk[s] of barcode b (one lane group of L lanes per barcode).
+template <int L, int A>
+static __device__ __forceinline__ void estep_epilogue(const EstepArgs &a, long long b, bool live, const double (&acc)[A],
+                                                      const int (&kk)[A], const bool (&valid)[A], int lane, int li, int gbase,
+                                                      int row_calls)
+{
+    const int K = a.K;
+    float lg[A], x[A];
+    float mx = -__builtin_inff();
+#pragma unroll
+    for (int s = 0; s < A; s++) {
+        const double t = (double)a.pen[kk[s]] + acc[s];
+        float l = (float)t;
+        if (a.prior) {
+            const size_t o = (size_t)b * K + kk[s];
+            if (a.prior_dtype == DMX_F32)
+                l = l + ((const float *)a.prior)[o];
+            else
+                l = (float)((double)l + ((const double *)a.prior)[o]);
+        }
+        lg[s] = l;
+        mx = valid[s] ? fmaxf(mx, l) : mx;
+    }
+#pragma unroll
+    for (int off = 1; off < L; off <<= 1) mx = fmaxf(mx, __shfl_xor(mx, off));
+#pragma unroll
+    for (int s = 0; s < A; s++) x[s] = npm::exp_f32(lg[s] - mx);
+    const float tot = reg_row_sum<A>(x, K, lane, gbase);
+    const int W = (a.G + 63) >> 6;
+#pragma unroll
+    for (int s = 0; s < A; s++) {
+        const float post = x[s] / tot;
+        if (live && valid[s]) {
+            const size_t o = (size_t)b * K + kk[s];
+            a.logits[o] = lg[s];
+            a.post[o] = post;
+        }
+        // non-zero bitmap of the singlet columns (the M-step skips exact zeros: (0*keep)^2 = +0)
+        const unsigned long long bal = __ballot(live && valid[s] && (li + 64 * s) < a.G && !(post <= a.nz_floor));
+        if (L == 64) {
+            if (lane == 0 && s < W) a.nz[(size_t)b * W + s] = bal;
+        } else {
+            if (live && li == 0) a.nz[(size_t)b] = (bal >> gbase) & ((1ull << L) - 1ull);
+        }
+        if (s == 0 && a.first) {
+            // what the M-step's call-parallel part needs of this barcode, 8 bytes (nz_code): ONE gather per call there,
+            // from a table small enough to stay in L2
+            const unsigned long long mine = L == 64 ? bal : ((bal >> gbase) & ((1ull << L) - 1ull));
+            if (live && li == (mine ? __builtin_ctzll(mine) : 0)) a.first[b] = nz_code(mine, post);
+            // statistic for the M-step's choice of kernel (G <= 64): calls whose barcode has more than 4 live posteriors
+            if (a.dense_calls && live && li == 0 && __popcll(mine) > 4)
+                atomicAdd(a.dense_calls + 1 + (b & (DENSE_SLOTS - 1)), (unsigned long long)row_calls);
+        }
+    }
+}
+
+}  // namespace dmx

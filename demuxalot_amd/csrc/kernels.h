@@ -55,7 +55,19 @@ struct EstepArgs {
     const long long *bin_ptr;   // [n_bins + 1] first group (4 CallPairs = 8 calls) of every bin in tile_stream
     const CallPair *tile_stream;  // the call records in bin-major, tile-major, slot-minor order; reserved[0] of a
                                   // group's first pair = the slot (accumulator) the group belongs to
+    // dictionary form (estep_dict.hip); dict_n == 0: not used by this launch
+    int dict_n;                   // most distinct values in a row of `prob` (<= DICT_CAP)
+    const float *dict;            // [rows, DICT_CAP] distinct values of every row
+    const unsigned char *codes;   // [rows, G] 8 x index of every genotype's value in its row's dictionary
+    const unsigned char *ocodes;  // [rows, ocode_pitch] 8 x index of every OPTION's log among a call's entries (singlet
+                                  // runs: `codes` itself; doublet runs with K <= DICT_PAIR_LANE_K: pair entries)
+    unsigned ocode_bytes;         // extent of ocodes (< 4 GiB: buffer addressing)
+    int ocode_pitch;
 };
+
+constexpr int DICT_CAP = 8;            // distinct values per row the dictionary form handles (singlet runs)
+constexpr int DICT_PAIR_CAP = 4;       // ... in doublet runs (10 pair values)
+constexpr int DICT_PAIR_LANE_K = 256;  // doublet tables up to this many options take the lane-per-option dictionary kernel
 
 constexpr int DENSE_SLOTS = 1024;            // hashed counters of the dense-call statistic
 hipError_t launch_sum_dense(hipStream_t st, unsigned long long *counters);
@@ -118,6 +130,12 @@ hipError_t launch_probs_from_betas_f64(hipStream_t st, const double *betas, cons
 // sets flags[0] bit 0 when a value lies outside [0, 1] or is not finite
 hipError_t launch_check_unit_range(hipStream_t st, const float *x, long long n, int *flags);
 hipError_t launch_estep(hipStream_t st, const EstepArgs &a, bool pairs);
+// dictionary form (estep_dict.hip): distinct values and codes of every row of `prob`; stat[0] = most distinct values
+// in a row (DICT_CAP + 1: some row has more)
+hipError_t launch_build_dict(hipStream_t st, const float *prob, long long rows, int G, float *dict, unsigned char *codes, unsigned *stat);
+hipError_t launch_build_pair_codes(hipStream_t st, const unsigned char *codes, const unsigned *opt_pairs, long long rows, int G, int K,
+                                   unsigned char *ocodes);
+hipError_t launch_estep_dict(hipStream_t st, const EstepArgs &a, bool pairs);
 hipError_t launch_mstep(hipStream_t st, const MstepArgs &a);
 // sums the item partials of variants [v0, v1) and redoes, in the reference's order, the sums whose float32
 // rounding could depend on the order (redo: queue of capacity (n_items / 2 + 1) * G entries, n_redo: its counter)
@@ -125,7 +143,8 @@ hipError_t launch_mstep(hipStream_t st, const MstepArgs &a);
 hipError_t launch_mcombine(hipStream_t st, const MstepArgs &a, const long long *item_ptr, long long v0, long long v1,
                            const int *prow, float *add32, double *add64, unsigned long long *redo, unsigned *n_redo);
 hipError_t launch_store_slice(hipStream_t st, const void *slice, bool f64, long long v_begin, long long n_rows, int G, float *add);
-hipError_t launch_remap_row_offsets(hipStream_t st, CallPair *pairs, long long n_pairs, unsigned row_bytes, const int *new_rows);
+// set_rows: also CallPair::reserved = the new row (the plain record stream; the tile stream keeps its slot tags there)
+hipError_t launch_remap_row_offsets(hipStream_t st, CallPair *pairs, long long n_pairs, unsigned row_bytes, const int *new_rows, bool set_rows);
 hipError_t launch_f64_to_f32(hipStream_t st, const double *in, float *out, long long n);
 hipError_t launch_f32_to_f64(hipStream_t st, const float *in, double *out, long long n);
 hipError_t launch_prior_betas(hipStream_t st, const float *betas, float *bsum, const unsigned long long *n_mol,

@@ -112,6 +112,7 @@ __global__ __launch_bounds__(256) void k_build_pairs(const unsigned *__restrict_
     CallPair &pr = pairs[pair_ptr[b] + (j >> 1)];
     const int h = (int)(j & 1);
     pr.row_off[h] = (unsigned)variant[i] * G * 4u;   // byte offset of the variant's row in prob[V, G]
+    pr.reserved[h] = (unsigned)variant[i];           // the row itself (dictionary form of the E-step: estep_dict.hip)
     pr.keep[h] = 1.0f - e;                          // float32, numpy's `1 - e`
     pr.floor[h] = e > 1e-4f ? e : 1e-4f;            // numpy's `e.clip(1e-4)`
 }

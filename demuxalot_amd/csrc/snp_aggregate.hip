@@ -720,6 +720,8 @@ int dmx_estep_snp(dmx_ctx *c, int with_doublets, const double *count_pow, int64_
         if (e == hipSuccess && probs_out && bk) e = hipMemcpyAsync(probs_out, c->d_post64, sizeof(double) * bk, hipMemcpyDeviceToHost, c->stream);
         if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
         if (e != hipSuccess) { rc = fail(DMX_ERR_HIP, "dmx_estep_snp: %s", hipGetErrorString(e)); break; }
+        // the float32 logits / posteriors of dmx_estep (and the M-step's bitmaps) were laid out for the previous K
+        if ((int)K != c->K) c->have_post = false;
         c->K = (int)K;
         c->have_post64 = true;
     } while (false);
@@ -744,6 +746,7 @@ int dmx_mstep_f64(dmx_ctx *c, double contribution_power, float *addition_out)
     else launch_m64<16>(c, contribution_power);
     HIP_TRY(hipGetLastError());
     c->add_partial = false;
+    c->add_is_zero = false;
     if (addition_out && c->V) HIP_TRY(hipMemcpyAsync(addition_out, c->d_add, sizeof(float) * (size_t)c->V * G, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
     return 0;

@@ -28,6 +28,9 @@ class DeviceContext:
             self.set_estep_mode('fast')
         if os.environ.get('DEMUXALOT_AMD_ESTEP_SCHEDULE', 'auto') != 'auto':
             self.set_estep_schedule(os.environ['DEMUXALOT_AMD_ESTEP_SCHEDULE'])
+        # DEMUXALOT_AMD_ESTEP_DICT = never | auto | always (include/demux_hip.h: dmx_set_estep_dictionary)
+        if os.environ.get('DEMUXALOT_AMD_ESTEP_DICT', 'auto') != 'auto':
+            self.set_estep_dictionary(os.environ['DEMUXALOT_AMD_ESTEP_DICT'])
 
     def __enter__(self):
         return self
@@ -341,6 +344,19 @@ class DeviceContext:
         """'exact' (default: logits / posteriors bit-identical to the reference) or 'fast' (tolerance mode:
         assignments identical, posteriors within the contract's 1e-5); include/demux_hip.h: dmx_set_estep_mode."""
         check(self._lib.dmx_set_estep_mode(self._h, {'exact': 0, 'fast': 1}[mode]))
+
+    def set_estep_dictionary(self, mode):
+        """'never' | 'auto' (default: tried for genotype tables computed without a beta addition) | 'always' (tried for
+        every E-step).  Bit-identical results in every mode; include/demux_hip.h: dmx_set_estep_dictionary."""
+        check(self._lib.dmx_set_estep_dictionary(self._h, {'never': 0, 'auto': 1, 'always': 2}[mode]))
+
+    def estep_form(self):
+        """(form, distinct) of the last E-step: form 'direct' | 'dict' | 'dict_block' | None, distinct = most distinct
+        values in a row of genotype_prob as counted by the last dictionary build (0: none was tried, 9: too many)."""
+        import ctypes
+        form, distinct = ctypes.c_int32(0), ctypes.c_int32(0)
+        check(self._lib.dmx_get_estep_form(self._h, ctypes.byref(form), ctypes.byref(distinct)))
+        return {0: None, 1: 'direct', 2: 'dict', 3: 'dict_block'}[form.value], distinct.value
 
     def set_estep_schedule(self, schedule):
         """'auto' (default: tile-major schedule where it pays), 'tiled' (whenever built), 'direct' (never);

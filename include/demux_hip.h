@@ -171,6 +171,22 @@ int dmx_set_estep_mode(dmx_ctx *ctx, int mode);
  * E-step mode are bit-identical under every schedule. */
 int dmx_set_estep_schedule(dmx_ctx *ctx, int tiled);
 
+/* Dictionary form of the exact E-step (csrc/estep_dict.hip).  Before the first M-step - predict_posteriors
+ * (demux.py:120-156) and iteration 0 of learn_genotypes (demux.py:86-101) - a row of genotype_prob holds a handful of
+ * distinct float32 values (the importers write betas from {0, s/2, s, 0.1 x mean}: genotypes.py:147-164).  When every
+ * row has at most 8 distinct values (singlet runs) or 4 (doublet runs: at most 10 values of (p1 + p2) * 0.5,
+ * demux.py:190) numpy's float32 log is evaluated once per (call, distinct value) instead of once per (call, option);
+ * every option still receives the same float32 addends in the same order, so logits and posteriors are bit-identical
+ * to the direct form's.  mode = 1 (default): the form is tried whenever the table was computed without a beta
+ * addition or supplied by the caller, and used when every row fits; 0: never; 2: tried for every E-step.
+ * dmx_get_estep_form reports what the last E-step ran. */
+#define DMX_FORM_NONE 0
+#define DMX_FORM_DIRECT 1   /* one numpy log per (call, option): k_estep_direct / k_estep_tiled / k_estep_block */
+#define DMX_FORM_DICT 2     /* dictionary form, lane-per-option kernel */
+#define DMX_FORM_DICT_BLOCK 3   /* dictionary form, workgroup-per-barcode kernel (wide doublet tables) */
+int dmx_set_estep_dictionary(dmx_ctx *ctx, int mode);
+int dmx_get_estep_form(dmx_ctx *ctx, int32_t *form, int32_t *distinct_values);
+
 /* M-step loads (G <= 64).  wide = 0 (default): 32-bit buffer offsets wherever the tables allow (posterior table below
  * 4 GiB, fewer than 2^24 barcodes), 64-bit addresses otherwise.  wide = 1: always 64-bit addresses - the form the
  * largest problems run, selectable so that it can be exercised at any size.  Results are bit-identical. */
