@@ -315,14 +315,32 @@ def main():
         ctx.set_exact_additions(os.environ.get('DEMUXALOT_AMD_EXACT_ADDITIONS', '1') not in ('0', ''))
         ctx.reset_timings()
 
-    # predict_posteriors throughput on the same resident problem (P + E only), rank-local
-    ctx.synchronize()
-    t1 = time.perf_counter()
+    # predict_posteriors throughput on the same resident problem (P + E only, no beta addition: demux.py:120-156),
+    # rank-local.  The genotype table is then the importers' (a handful of distinct values per row), which is the
+    # case the dictionary form of the exact E-step exists for (csrc/estep_dict.hip); timed with the form on (default)
+    # and off, same bits either way.
+    predict = {}
     n_pred = max(3, args.steps // 2)
-    for _ in range(n_pred):
+    for mode in ('auto', 'never'):
+        ctx.set_estep_dictionary(mode)
+        ctx.set_addition(None)
         ctx.probs_from_betas(0.01, fetch=False)
-        ctx.estep(pen, with_doublets=dp > 0, fetch_logits=False, fetch_probs=False)
-    predict_s = (time.perf_counter() - t1) / n_pred
+        ctx.estep(pen, with_doublets=dp > 0, fetch_logits=False, fetch_probs=False)  # untimed first pass
+        ctx.synchronize()
+        ctx.reset_timings()
+        t1 = time.perf_counter()
+        for _ in range(n_pred):
+            ctx.probs_from_betas(0.01, fetch=False)
+            ctx.estep(pen, with_doublets=dp > 0, fetch_logits=False, fetch_probs=False)
+        ctx.synchronize()
+        seconds = (time.perf_counter() - t1) / n_pred
+        t_pred = ctx.timings()
+        form, distinct = ctx.estep_form()
+        predict[mode] = dict(seconds=seconds, form=form, distinct_values_per_row=distinct,
+                             estep_ms=t_pred['estep']['ms'] / max(1, t_pred['estep']['launches']),
+                             pstep_ms=t_pred['pstep']['ms'] / max(1, t_pred['pstep']['launches']))
+    ctx.set_estep_dictionary('auto')
+    predict_s = predict['auto']['seconds']
 
     if rank == 0:
         ab = algorithmic_bytes(B, V, G, K, N)
@@ -346,6 +364,9 @@ def main():
                        'parallelism': f'barcode shards x{world}' + (f', RCCL reduce-scatter {args.reduce_dtype} + all-gather f32 of variant slices' if use_dist else '')},
             'em_iterations_per_s': args.steps / elapsed,
             'predict_barcodes_per_s': B_total / predict_s,
+            'predict': {'dictionary_form': predict['auto'], 'direct_form': predict['never'],
+                        'note': 'P-step + E-step on the table without beta addition (predict_posteriors, EM iteration 0); '
+                                'estep_ms includes building the dictionary'},
             'kernel_ms': {k: (v['ms'] / max(1, v['launches'])) for k, v in timers.items()},
             'exchange_ms_per_step': timers['allreduce']['ms'] / max(1, args.steps),
             'roofline': roofline(args.workload, ab, e_ms, m_ms, timers, N, G, K),

@@ -61,7 +61,10 @@ SIGNATURES = {
     'dmx_get_max_pair_count': (c_int, [_P, POINTER(c_int64)]),
     'dmx_estep_snp': (c_int, [_P, c_int, _P, c_int64, _P, c_int, _P, _P]),
     'dmx_mstep_f64': (c_int, [_P, c_double, _P]),
+    'dmx_mstep_f64_sums': (c_int, [_P, c_double, _P]),
+    'dmx_get_prior_betas': (c_int, [_P, _P]),
     'dmx_exchange_slices': (c_int, [c_int64, _P, c_int32, _P, POINTER(c_int64), POINTER(c_int32)]),
+    'dmx_runtime_info': (c_int, [c_char_p, c_int64]),
     'dmx_comm_unique_id': (c_int, [_P]),
     'dmx_comm_init': (c_int, [_P, c_int, c_int, _P, c_int]),
     'dmx_comm_init_host': (c_int, [_P, c_int, c_int, _P, _P, c_int]),
@@ -120,6 +123,21 @@ def ptr(a):
 
 def as_c(a, dtype):
     return np.ascontiguousarray(a, dtype=dtype)
+
+
+def runtime_info():
+    """{'hip': [files], 'rccl_mapped': [files], 'rccl_loaded': file or ''}: the HIP / RCCL runtime files this process
+    has mapped (include/demux_hip.h: dmx_runtime_info).  A multi-rank worker must show exactly one 'hip'."""
+    buf = ctypes.create_string_buffer(8192)
+    check(load().dmx_runtime_info(buf, len(buf)))
+    info = {'hip': [], 'rccl_mapped': [], 'rccl_loaded': ''}
+    for line in buf.value.decode().splitlines():
+        key, _, value = line.partition('=')
+        if key == 'rccl_loaded':
+            info[key] = value
+        elif key in info:
+            info[key].append(value)
+    return info
 
 
 def device_count():

@@ -9,6 +9,8 @@
 
 #include <algorithm>
 #include <cmath>
+#include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -47,26 +49,61 @@ struct RcclApi {
     ncclResult_t (*AllGather)(const void *, void *, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
     ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
     const char *(*GetErrorString)(ncclResult_t) = nullptr;
+    std::string path;
 };
 RcclApi g_rccl;
 
+// Files of the process image whose name contains `needle` (/proc/self/maps), each once.
+std::vector<std::string> mapped_files(const char *needle)
+{
+    std::vector<std::string> out;
+    FILE *f = std::fopen("/proc/self/maps", "r");
+    if (!f) return out;
+    char line[4096];
+    while (std::fgets(line, sizeof line, f)) {
+        const char *path = std::strchr(line, '/');
+        if (!path || !std::strstr(path, needle)) continue;
+        std::string p(path);
+        while (!p.empty() && (p.back() == '\n' || p.back() == ' ')) p.pop_back();
+        if (std::find(out.begin(), out.end(), p) == out.end()) out.push_back(p);
+    }
+    std::fclose(f);
+    return out;
+}
+
+// ONE HIP runtime per process.  libdemux_hip.so is linked against the ROCm installation's libamdhip64; the RCCL it
+// hands its streams and buffers to must sit on the same runtime.  So RCCL is taken from the directory of the HIP
+// runtime this library resolved (dladdr of hipGetDeviceCount), never from whatever copy a launcher happened to map (a
+// process that imported torch carries torch's own librccl + libamdhip64 + libhsa-runtime64: streams of one runtime
+// handed to collectives of the other is undefined, and round 2 did exactly that under `bench.py --gpus N`).
+// A process with two HIP runtimes mapped is refused - loudly - unless DEMUXALOT_AMD_ALLOW_FOREIGN_RCCL=1.
+// DEMUXALOT_AMD_RCCL=<path> overrides the library file.
 int load_rccl()
 {
     if (g_rccl.handle) return 0;
-    // Prefer a copy of RCCL that is already mapped into the process (e.g. by a launcher that imported
-    // torch.distributed for its control plane) so that only one RCCL runtime is ever active; otherwise
-    // load the ROCm one.  RTLD_LOCAL: the symbols are taken from the handle, nothing is interposed.
-    const char *names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
-    void *h = nullptr;
-    for (const char *n : names) {
-        h = dlopen(n, RTLD_NOW | RTLD_LOCAL | RTLD_NOLOAD);
-        if (h) break;
+    const bool lenient = std::getenv("DEMUXALOT_AMD_ALLOW_FOREIGN_RCCL") && std::atoi(std::getenv("DEMUXALOT_AMD_ALLOW_FOREIGN_RCCL")) != 0;
+    const std::vector<std::string> hips = mapped_files("libamdhip64");
+    if (hips.size() > 1 && !lenient) {
+        std::string all;
+        for (const auto &h : hips) all += (all.empty() ? "" : ", ") + h;
+        return fail(DMX_ERR_RCCL, "two HIP runtimes are mapped into this process (%s): a multi-rank worker must not import torch "
+                                  "(use demuxalot_amd.plane.SocketControlPlane for the control plane); set "
+                                  "DEMUXALOT_AMD_ALLOW_FOREIGN_RCCL=1 to run anyway", all.c_str());
     }
-    for (const char *n : names) {
-        if (h) break;
-        h = dlopen(n, RTLD_NOW | RTLD_LOCAL);
+    std::string path;
+    if (const char *forced = std::getenv("DEMUXALOT_AMD_RCCL")) {
+        path = forced;
+    } else {
+        Dl_info info;
+        if (dladdr((const void *)&hipGetDeviceCount, &info) && info.dli_fname && std::strchr(info.dli_fname, '/')) {
+            path = info.dli_fname;
+            path = path.substr(0, path.rfind('/')) + "/librccl.so.1";
+        } else {
+            path = "/opt/rocm/lib/librccl.so.1";
+        }
     }
-    if (!h) return fail(DMX_ERR_RCCL, "cannot load librccl: %s", dlerror());
+    void *h = dlopen(path.c_str(), RTLD_NOW | RTLD_LOCAL);
+    if (!h) return fail(DMX_ERR_RCCL, "cannot load %s: %s", path.c_str(), dlerror());
     g_rccl.GetUniqueId = (decltype(g_rccl.GetUniqueId))dlsym(h, "ncclGetUniqueId");
     g_rccl.CommInitRank = (decltype(g_rccl.CommInitRank))dlsym(h, "ncclCommInitRank");
     g_rccl.AllReduce = (decltype(g_rccl.AllReduce))dlsym(h, "ncclAllReduce");
@@ -76,8 +113,15 @@ int load_rccl()
     g_rccl.GetErrorString = (decltype(g_rccl.GetErrorString))dlsym(h, "ncclGetErrorString");
     if (!g_rccl.GetUniqueId || !g_rccl.CommInitRank || !g_rccl.AllReduce || !g_rccl.ReduceScatter || !g_rccl.AllGather ||
         !g_rccl.CommDestroy)
-        return fail(DMX_ERR_RCCL, "librccl lacks a required symbol");
+        return fail(DMX_ERR_RCCL, "%s lacks a required symbol", path.c_str());
+    // loading RCCL must not have brought a second runtime along either
+    const std::vector<std::string> after = mapped_files("libamdhip64");
+    if (after.size() > 1 && !lenient) {
+        dlclose(h);
+        return fail(DMX_ERR_RCCL, "%s depends on another HIP runtime (%s) than this library (%s)", path.c_str(), after.back().c_str(), after.front().c_str());
+    }
     g_rccl.handle = h;
+    g_rccl.path = path;
     return 0;
 }
 }  // namespace
@@ -194,7 +238,8 @@ void timer_end(dmx_ctx *c, int slot, const std::pair<hipEvent_t, hipEvent_t> &ev
 void release_problem(dmx_ctx *c)
 {
     dev_free(c, &c->d_pair_ptr, (size_t)c->B + 1);
-    dev_free(c, &c->d_call_pairs, (size_t)c->n_pairs);
+    dev_free(c, &c->d_call_pairs, (size_t)c->n_pairs + dmx::CALL_PAD_PAIRS);
+    dev_free(c, &c->d_call_rows, ((size_t)c->n_pairs + dmx::CALL_PAD_PAIRS) * 2);
     dev_free(c, &c->d_tile_stream, (size_t)c->n_pairs);
     c->n_pairs = 0;
     dev_free(c, &c->d_csc, (size_t)c->N);
@@ -245,10 +290,10 @@ void release_problem(dmx_ctx *c)
     dev_free(c, &c->d_dense_calls, (size_t)1 + dmx::DENSE_SLOTS);
     c->dense_stat_valid = false;
     dev_free(c, &c->d_dict, c->cap_dict_rows * dmx::DICT_CAP);
-    dev_free(c, &c->d_codes, c->cap_dict_rows * (size_t)c->G);
-    dev_free(c, &c->d_ocodes, c->cap_ocodes);
+    dev_free(c, &c->d_codes, c->cap_dict_rows * (size_t)dmx::dict_code_pitch(c->G));
+    dev_free(c, &c->d_dtab, c->cap_dtab);
     dev_free(c, &c->d_dict_stat, (size_t)1);
-    c->cap_dict_rows = c->cap_ocodes = 0;
+    c->cap_dict_rows = c->cap_dtab = 0;
     c->dict_candidate = false;
     c->add_is_zero = true;
     c->estep_form = DMX_FORM_NONE;
@@ -501,8 +546,8 @@ int layout_exchange(dmx_ctx *c)
             for (long long v = c->cut[r]; v < c->cut[r + 1]; v++) prow[v] = (int)(r * rows + (v - c->cut[r]));
         DMX_TRY(dev_alloc(c, &c->d_prow, (size_t)V));
         HIP_TRY(hipMemcpyAsync(c->d_prow, prow.data(), sizeof(int) * V, hipMemcpyHostToDevice, st));
-        HIP_TRY(dmx::launch_remap_row_offsets(st, c->d_call_pairs, c->n_pairs, (unsigned)G * 4u, c->d_prow, true));
-        if (c->d_tile_stream) HIP_TRY(dmx::launch_remap_row_offsets(st, c->d_tile_stream, c->n_pairs, (unsigned)G * 4u, c->d_prow, false));
+        HIP_TRY(dmx::launch_remap_row_offsets(st, c->d_call_pairs, c->n_pairs, (unsigned)G * 4u, c->d_prow, c->d_call_rows));
+        if (c->d_tile_stream) HIP_TRY(dmx::launch_remap_row_offsets(st, c->d_tile_stream, c->n_pairs, (unsigned)G * 4u, c->d_prow, nullptr));
         const size_t elem = c->reduce_dtype == DMX_F64 ? 8 : 4;
         c->exch_bytes = (size_t)new_rows * G * 8;  // float64 sums; also the float32 staging of the addition gather
         c->recv_bytes = (size_t)rows * G * elem;
@@ -597,15 +642,22 @@ int prepare_dictionary(dmx_ctx *c, bool pairs, dmx::EstepArgs &a, int *form)
     if (!wanted || c->estep_mode != DMX_ESTEP_EXACT || c->B == 0 || c->prob_rows == 0) return 0;
     const int G = c->G;
     const long long K = c->K, rows = c->prob_rows;
-    const bool lane_form = !pairs || K <= dmx::DICT_PAIR_LANE_K;
-    if (!lane_form) return 0;
-    if ((unsigned long long)rows * (unsigned long long)(pairs ? K : G) >= (1ull << 32)) return 0;  // code table beyond buffer addressing
+    if (K > dmx::DICT_LANE_K || rows >= (1 << 24) || a.pairs_bytes == 0) return 0;  // wider tables: the direct forms; 24-bit row x pitch; 32-bit record offsets
+    if (c->dict_mode == 1) {
+        // Where the form pays (measured): singlet runs with enough barcodes for several rounds of
+        // wavefronts.  A launch of one round lasts as long as its longest barcode, whose calls this form walks in
+        // batches with a memory latency each (20k x 10k x 64: 0.31 ms against 0.25 ms direct), and the 16 entry slots of
+        // a doublet run leave two calls per barcode and batch (20k x 20k x 8 with doublets: 0.60 against 0.28 ms).
+        const long long lanes = K <= 16 ? 4 : K <= 32 ? 8 : K <= 64 ? 16 : K <= 128 ? 32 : 64;
+        if (pairs || c->B * lanes / 64 < 8192) return 0;
+    }
+    const size_t code_pitch = (size_t)dmx::dict_code_pitch(G);
     if ((size_t)rows > c->cap_dict_rows) {
         dev_free(c, &c->d_dict, c->cap_dict_rows * dmx::DICT_CAP);
-        dev_free(c, &c->d_codes, c->cap_dict_rows * (size_t)G);
+        dev_free(c, &c->d_codes, c->cap_dict_rows * code_pitch);
         c->cap_dict_rows = 0;
         DMX_TRY(dev_alloc(c, &c->d_dict, (size_t)rows * dmx::DICT_CAP));
-        DMX_TRY(dev_alloc(c, &c->d_codes, (size_t)rows * G));
+        DMX_TRY(dev_alloc(c, &c->d_codes, (size_t)rows * code_pitch));
         c->cap_dict_rows = (size_t)rows;
     }
     if (!c->d_dict_stat) DMX_TRY(dev_alloc(c, &c->d_dict_stat, (size_t)1));
@@ -615,26 +667,19 @@ int prepare_dictionary(dmx_ctx *c, bool pairs, dmx::EstepArgs &a, int *form)
     HIP_TRY(hipStreamSynchronize(c->stream));
     c->dict_distinct = (int)distinct;
     if (distinct == 0 || (int)distinct > (pairs ? dmx::DICT_PAIR_CAP : dmx::DICT_CAP)) return 0;
-    a.dict_n = (int)distinct;
-    a.dict = c->d_dict;
-    a.codes = c->d_codes;
-    if (pairs) {
-        const size_t need_bytes = (size_t)rows * (size_t)K;
-        if (need_bytes > c->cap_ocodes) {
-            dev_free(c, &c->d_ocodes, c->cap_ocodes);
-            c->cap_ocodes = 0;
-            DMX_TRY(dev_alloc(c, &c->d_ocodes, need_bytes));
-            c->cap_ocodes = need_bytes;
-        }
-        HIP_TRY(dmx::launch_build_pair_codes(c->stream, c->d_codes, c->d_pairs, rows, G, (int)K, c->d_ocodes));
-        a.ocodes = c->d_ocodes;
-        a.ocode_pitch = (int)K;
-        a.ocode_bytes = (unsigned)need_bytes;
-    } else {
-        a.ocodes = c->d_codes;
-        a.ocode_pitch = G;
-        a.ocode_bytes = (unsigned)((size_t)rows * G);
+    const size_t pitch = (size_t)dmx::dict_table_pitch((int)distinct, (int)K, pairs), need_bytes = (size_t)rows * pitch;
+    if (need_bytes >= (1ull << 32)) return 0;  // buffer addressing
+    if (need_bytes > c->cap_dtab) {
+        dev_free(c, &c->d_dtab, c->cap_dtab);
+        c->cap_dtab = 0;
+        DMX_TRY(dev_alloc(c, &c->d_dtab, need_bytes));
+        c->cap_dtab = need_bytes;
     }
+    HIP_TRY(dmx::launch_pack_rows(c->stream, c->d_dict, c->d_codes, c->d_pairs, rows, G, (int)K, pairs, (int)distinct, c->d_dtab));
+    a.dict_n = (int)distinct;
+    a.dtab = c->d_dtab;
+    a.dtab_pitch = (int)pitch;
+    a.dtab_bytes = (unsigned)need_bytes;
     *form = DMX_FORM_DICT;
     return 0;
 }
@@ -645,6 +690,9 @@ int run_estep(dmx_ctx *c, int with_doublets, bool with_prior, int prior_dtype, f
     a.pair_ptr = c->d_pair_ptr;
     a.order = c->d_bc_order;
     a.pairs = c->d_call_pairs;
+    a.call_rows = c->d_call_rows;
+    const unsigned long long rec_bytes = ((unsigned long long)c->n_pairs + dmx::CALL_PAD_PAIRS) * sizeof(dmx::CallPair);
+    a.pairs_bytes = rec_bytes < (1ull << 32) ? (unsigned)rec_bytes : 0u;
     a.prob = c->d_prob;
     a.opt_pairs = c->d_pairs;
     a.sum_plan = c->d_sum_plan;
@@ -674,10 +722,9 @@ int run_estep(dmx_ctx *c, int with_doublets, bool with_prior, int prior_dtype, f
     a.bin_ptr = c->d_bin_ptr;
     a.tile_stream = c->d_tile_stream;
     a.dict_n = 0;
-    a.dict = nullptr;
-    a.codes = a.ocodes = nullptr;
-    a.ocode_bytes = 0;
-    a.ocode_pitch = 0;
+    a.dtab = nullptr;
+    a.dtab_bytes = 0;
+    a.dtab_pitch = 0;
     std::pair<hipEvent_t, hipEvent_t> ev;
     timer_begin(c, DMX_T_ESTEP, &ev);
     int form = DMX_FORM_DIRECT;
@@ -1113,6 +1160,15 @@ int dmx_set_prior_betas(dmx_ctx *c, const float *raw_betas, double default_prior
     return rc;
 }
 
+int dmx_get_prior_betas(dmx_ctx *c, float *out)
+{
+    DMX_TRY(bind(c));
+    DMX_TRY(need(c, c->have_problem && c->have_betas, "prior betas (dmx_set_betas / dmx_set_prior_betas) before dmx_get_prior_betas"));
+    DMX_TRY(copy_out(c, out, c->d_prior, (size_t)c->V * c->G));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return 0;
+}
+
 int dmx_set_addition(dmx_ctx *c, const float *addition)
 {
     DMX_TRY(bind(c));
@@ -1320,6 +1376,17 @@ int dmx_exchange_slices(int64_t n_variants, const int32_t *v2snp, int32_t nranks
     for (int r = 0; r <= nranks; r++) cuts[r] = cut[r];
     if (slice_rows) *slice_rows = rows;
     if (contiguous) *contiguous = contig ? 1 : 0;
+    return 0;
+}
+
+int dmx_runtime_info(char *out, int64_t capacity)
+{
+    if (!out || capacity <= 0) return fail(DMX_ERR_INVALID, "null buffer");
+    std::string text;
+    for (const auto &h : mapped_files("libamdhip64")) text += "hip=" + h + "\n";
+    for (const auto &h : mapped_files("librccl")) text += "rccl_mapped=" + h + "\n";
+    text += "rccl_loaded=" + (g_rccl.handle ? g_rccl.path : std::string("")) + "\n";
+    std::snprintf(out, (size_t)capacity, "%s", text.c_str());
     return 0;
 }
 

@@ -44,6 +44,7 @@ struct dmx_ctx {
 
     long long *d_pair_ptr = nullptr;
     dmx::CallPair *d_call_pairs = nullptr;
+    unsigned *d_call_rows = nullptr;  // table row of every call of d_call_pairs (EstepArgs::call_rows)
     long long n_pairs = 0;
     uint2 *d_csc = nullptr;
     long long *d_item_start = nullptr;
@@ -83,9 +84,9 @@ struct dmx_ctx {
     int dict_distinct = 0;        // most distinct values per row found by the last dictionary build (0: none built)
     float *d_dict = nullptr;             // [prob_rows, DICT_CAP]
     unsigned char *d_codes = nullptr;    // [prob_rows, G]
-    unsigned char *d_ocodes = nullptr;   // [prob_rows, K] (doublet runs with K <= DICT_PAIR_LANE_K)
+    unsigned char *d_dtab = nullptr;     // the packed table the kernel reads (estep_dict.hip: DictRow)
     unsigned *d_dict_stat = nullptr;     // [1]
-    size_t cap_dict_rows = 0, cap_ocodes = 0;
+    size_t cap_dict_rows = 0, cap_dtab = 0;
     float nz_floor = 0.0f;     // threshold the current d_nz / d_first were built with
     uint2 *d_first = nullptr;  // [B] {posterior of the lowest live singlet column, count | first live columns} (G <= 64): EstepArgs::first
     unsigned long long *d_dense_calls = nullptr;  // [1] E-step statistic read by the M-step kernels (kernels.h)

@@ -25,6 +25,8 @@
 // row fits (dmx_api.cpp: run_estep); after the first M-step rows are all-distinct and the direct kernels run.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
+#include <cstdlib>
 #include <type_traits>
 
 #include "estep_epilogue.h"
@@ -38,58 +40,73 @@ namespace dmx {
 // same value anyway, may take two entries).  stat[0] = max over rows of the number of distinct values
 // (DICT_CAP + 1: some row has more).  Unused entries repeat entry 0 so that every entry logs to a finite number.
 // ------------------------------------------------------------------------------------
-template <int A>
-__global__ __launch_bounds__(256) void k_build_dict(const float *__restrict__ prob, long long rows, int G,
+// ROWS rows per wavefront, their loads issued together (one row per wavefront left the launch bound by the rate at
+// which wavefronts start and by one load latency each: 0.13 ms for a 51 MB table).
+template <int A, int ROWS>
+__global__ __launch_bounds__(256) void k_build_dict(const float *__restrict__ prob, long long rows, int G, int pitch,
                                                     float *__restrict__ dict, unsigned char *__restrict__ codes,
                                                     unsigned *__restrict__ stat)
 {
     const int lane = threadIdx.x & 63;
-    const long long r = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (r >= rows) return;  // wave-uniform
-    unsigned x[A], code[A];
-    unsigned long long rem[A];
+    const long long r0 = ((long long)blockIdx.x * 4 + (threadIdx.x >> 6)) * ROWS;
+    if (r0 >= rows) return;  // wave-uniform
+    unsigned xs[ROWS][A];
 #pragma unroll
-    for (int s = 0; s < A; s++) {
-        const int g = lane + 64 * s;
-        const bool valid = g < G;
-        x[s] = valid ? __float_as_uint(prob[(size_t)r * G + g]) : 0u;
-        rem[s] = __ballot(valid);
-        code[s] = 0u;
-    }
-    unsigned mine = 0u, first = 0u;
-    int d = 0;
-    for (; d < DICT_CAP; d++) {
-        unsigned val = 0u;
-        bool found = false;
+    for (int i = 0; i < ROWS; i++) {
+        const long long r = r0 + i < rows ? r0 + i : rows - 1;
 #pragma unroll
         for (int s = 0; s < A; s++) {
-            if (!found && rem[s] != 0ull) {  // wave-uniform
-                val = (unsigned)__builtin_amdgcn_readlane((int)x[s], __builtin_ctzll(rem[s]));
-                found = true;
+            const int g = lane + 64 * s;
+            xs[i][s] = g < G ? __float_as_uint(prob[(size_t)r * G + g]) : 0u;
+        }
+    }
+    unsigned worst = 0;
+#pragma unroll
+    for (int i = 0; i < ROWS; i++) {
+        const long long r = r0 + i;
+        if (r >= rows) break;  // wave-uniform
+        unsigned code[A];
+        unsigned long long rem[A];
+#pragma unroll
+        for (int s = 0; s < A; s++) {
+            rem[s] = __ballot(lane + 64 * s < G);
+            code[s] = 0u;
+        }
+        unsigned mine = 0u, first = 0u;
+        int d = 0;
+        for (; d < DICT_CAP; d++) {
+            unsigned val = 0u;
+            bool found = false;
+#pragma unroll
+            for (int s = 0; s < A; s++) {
+                if (!found && rem[s] != 0ull) {  // wave-uniform
+                    val = (unsigned)__builtin_amdgcn_readlane((int)xs[i][s], __builtin_ctzll(rem[s]));
+                    found = true;
+                }
             }
+            if (!found) break;
+#pragma unroll
+            for (int s = 0; s < A; s++) {
+                const unsigned long long m = __ballot(xs[i][s] == val) & rem[s];
+                if ((m >> lane) & 1ull) code[s] = (unsigned)d;
+                rem[s] &= ~m;
+            }
+            if (lane == d) mine = val;
+            if (d == 0) first = val;
         }
-        if (!found) break;
+        bool overflow = false;
+#pragma unroll
+        for (int s = 0; s < A; s++) overflow = overflow || rem[s] != 0ull;
+        if (lane < DICT_CAP) dict[(size_t)r * DICT_CAP + lane] = __uint_as_float(lane < d ? mine : first);
 #pragma unroll
         for (int s = 0; s < A; s++) {
-            const unsigned long long m = __ballot(x[s] == val) & rem[s];
-            if ((m >> lane) & 1ull) code[s] = (unsigned)d;
-            rem[s] &= ~m;
+            const int g = lane + 64 * s;
+            if (g < pitch) codes[(size_t)r * pitch + g] = (unsigned char)(g < G ? code[s] * 8u : 0u);
         }
-        if (lane == d) mine = val;
-        if (d == 0) first = val;
+        worst = max(worst, overflow ? (unsigned)DICT_CAP + 1u : (unsigned)d);
     }
-    bool overflow = false;
-#pragma unroll
-    for (int s = 0; s < A; s++) overflow = overflow || rem[s] != 0ull;
-    if (lane < DICT_CAP) dict[(size_t)r * DICT_CAP + lane] = __uint_as_float(lane < d ? mine : first);
-#pragma unroll
-    for (int s = 0; s < A; s++) {
-        const int g = lane + 64 * s;
-        if (g < G) codes[(size_t)r * G + g] = (unsigned char)(code[s] * 8u);
-    }
-    const unsigned n = overflow ? (unsigned)DICT_CAP + 1u : (unsigned)d;
     // one shared maximum: after the first rows it is at its final value and nobody writes any more
-    if (lane == 0 && n > __hip_atomic_load(stat, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(stat, n);
+    if (lane == 0 && worst > __hip_atomic_load(stat, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(stat, worst);
 }
 
 // Pair values of a row with D <= 4 distinct singlet values: entry t(lo, hi), lo <= hi, holds (dict[lo] + dict[hi]) * 0.5
@@ -103,223 +120,382 @@ __host__ __device__ __forceinline__ unsigned pair_entry(unsigned c1, unsigned c2
 __device__ __forceinline__ unsigned pair_entry_lo(unsigned t) { return (unsigned)(0x3221110000ull >> (4u * t)) & 15u; }
 __device__ __forceinline__ unsigned pair_entry_hi(unsigned t) { return (unsigned)(0x3323213210ull >> (4u * t)) & 15u; }
 
-// ocodes[row, k] = 8 * pair_entry(code(g1), code(g2)) for every option k = (g1, g2) (singlets: g1 == g2)
-__global__ __launch_bounds__(256) void k_build_pair_codes(const unsigned char *__restrict__ codes, const unsigned *__restrict__ opt_pairs,
-                                                          long long rows, int G, int K, unsigned char *__restrict__ ocodes)
+// The table the E-step kernel reads: one row per row of genotype_prob,
+//     [DW float32 dictionary values][LB lanes x CBY bytes: the codes of the lane's four options, CBITS bits each]
+// padded to a multiple of 16 bytes - 32 bytes per row for 64 genotypes with <= 4 values, so that 200 000 rows are
+// 6.4 MB where genotype_prob is 51 MB: the row gathers of the direct form cross the fabric for half of their 128-byte
+// lines (no L2 holds 51 MB), and so did a byte per option (12.8 MB) + 32 bytes of values (6.4 MB) per row.
+//   NE = 4:  DW 4, 2-bit codes (the option's value);  NE = 8: DW 8, 4-bit codes;
+//   NE = 16 (doublets): DW 4, 4-bit codes = pair_entry of the option's two genotypes
+template <int NE>
+struct DictRow {
+    static constexpr int DW = NE == 8 ? 8 : 4;
+    static constexpr int CBITS = NE == 4 ? 2 : 4;
+    static constexpr int CBY = CBITS / 2;  // bytes of codes per lane (four options)
+    static __host__ __device__ int pitch(int LB) { return (DW * 4 + LB * CBY + 15) & ~15; }
+};
+
+template <int NE, bool PAIRS>
+__global__ __launch_bounds__(256) void k_pack_rows(const float *__restrict__ dict, const unsigned char *__restrict__ codes, int code_pitch,
+                                                   const unsigned *__restrict__ opt_pairs, long long rows, int K, int LB, int pitch,
+                                                   unsigned char *__restrict__ table)
 {
-    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= rows * K) return;
-    const long long r = i / K;
-    const unsigned pr = opt_pairs[(int)(i - r * K)];
-    const unsigned c1 = codes[(size_t)r * G + (pr & 0xFFFFu)] >> 3, c2 = codes[(size_t)r * G + (pr >> 16)] >> 3;
-    ocodes[i] = (unsigned char)(8u * pair_entry(c1, c2));
+    using R = DictRow<NE>;
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;  // (row, lane)
+    if (i >= rows * LB) return;
+    const long long r = i / LB;
+    const int li = (int)(i - r * LB);
+    unsigned packed = 0;
+#pragma unroll
+    for (int o = 0; o < 4; o++) {
+        const int k = 4 * li + o;
+        unsigned code = 0;
+        if (k < K) {
+            if (PAIRS) {
+                const unsigned pr = opt_pairs[k];
+                code = pair_entry(codes[(size_t)r * code_pitch + (pr & 0xFFFFu)] >> 3, codes[(size_t)r * code_pitch + (pr >> 16)] >> 3);
+            } else {
+                code = codes[(size_t)r * code_pitch + k] >> 3;
+            }
+        }
+        packed |= code << (R::CBITS * o);
+    }
+    unsigned char *row = table + (size_t)r * pitch;
+    if (R::CBY == 1) row[R::DW * 4 + li] = (unsigned char)packed;
+    else ((unsigned short *)(row + R::DW * 4))[li] = (unsigned short)packed;
+    if (li < R::DW) ((float *)row)[li] = dict[(size_t)r * DICT_CAP + li];
+    if (R::DW > LB && li == 0)  // fewer lanes than values (K <= 16 with 8 values)
+        for (int d = LB; d < R::DW; d++) ((float *)row)[d] = dict[(size_t)r * DICT_CAP + d];
 }
 
 // ------------------------------------------------------------------------------------
-// Lane-per-option form: one 64-thread workgroup (= one wavefront, so that the LDS address of a log IS its code) per
-// barcode; option k in lane k & 63, slot k >> 6 (A slots).
-//   NE      dictionary entries per call: 4 or 8 (singlets), 10 (pairs of <= 4 values)
-//   CB      = 64 / NE calls whose logs one 64-lane pass computes; the packed log handles two passes at once, so a
-//           super-batch of SB = 2 CB calls is produced at a time into one of two LDS buffers
-//   PU      calls whose option codes are in flight together (prefetch unit), PU | CB
-// Pipeline per super-batch i: the records of i + 2 and the dictionary rows of i + 1 are requested, the codes of the
-// next unit are requested before a unit is consumed, the logs of i + 1 are computed after the units of i.
+// Lane-per-four-options form (K <= 256).  What bounds a dictionary E-step is not arithmetic but the number of vector
+// memory instructions (a wave64 gather occupies the CU's address unit for ~8 cycles whatever its width) and LDS
+// reads, so every lane owns FOUR consecutive options: one dword gather brings their four codes, and a wavefront of
+// 64 lanes serves NB = 64 / LB barcodes at once (LB = lanes per barcode, 4 LB >= K).
+//   NE      entry slots per call in LDS: 4 or 8 (singlets), 16 (pairs of <= 4 values: 10 entries used)
+//   PC      = 64 / NE calls whose logs one 64-lane pass computes; the packed log does two passes at once
+//   CBB     = 2 PC / NB calls per barcode and batch
+// Phase A, lane (slot u of the batch, entry e): u -> (barcode u / CBB, call u % CBB of its batch); the lane loads that
+//   call's record, gathers its dictionary value(s), computes f64(np.log(p * keep + floor)) and parks it at
+//   [buffer][barcode][call][entry] in LDS (+0 for calls past the barcode's row: adding +0 leaves a sum unchanged, the
+//   sums start at +0 and never become -0).
+// Phase B, lane (barcode ga, option quad li): per call of the batch one dword of codes (the call's code-row offset
+//   comes from the group's lanes by ds_bpermute) and, per option, ds_read_b64 at (barcode base | code byte) + an
+//   immediate, v_add_f64 - call after call in the barcode's order.
+// The barcodes of a wavefront are neighbours in the length-sorted work list; the loop runs to the longest.
+// ABL != 0: timing ablations (DEMUXALOT_AMD_DICT_ABLATE; results are meaningless): 1 no code gathers, 2 no LDS
+// lookups, 3 no logs, 4 no record / dictionary loads inside the loop, 5 = 4 and no code gathers;
+// DEMUXALOT_AMD_DICT_BLOCKS=n launches the first n workgroups only (the longest barcodes)
 // ------------------------------------------------------------------------------------
-template <int NE, int A, bool PAIRS>
-struct DictShape {
-    static constexpr int CB = 64 / NE;
-    static constexpr int SB = 2 * CB;
-    static constexpr int PU_WANT = A <= 2 ? 16 : A <= 4 ? 8 : A <= 8 ? 4 : 2;
-    static constexpr int PU = CB % PU_WANT == 0 ? PU_WANT : CB;  // 16 / 8 / 6 calls for A <= 2
-    static constexpr int NU = SB / PU;                            // units per super-batch (even)
-};
-
 struct DictRec {
     unsigned row;   // table row of the call
     float keep, flo;
+    bool inside;    // the call exists (lies inside its barcode's row)
 };
 
-template <int NE, int A, bool PAIRS>
-__global__ __launch_bounds__(64) void k_estep_dict(EstepArgs a)
+// LDS addresses are computed as integers (barcode base | code byte); these turn them into pointers
+typedef const __attribute__((address_space(3))) double *LdsF64;
+typedef __attribute__((address_space(3))) double *LdsF64W;
+__device__ __forceinline__ LdsF64 lds_f64(unsigned byte_address) { return (LdsF64)(unsigned long long)byte_address; }
+__device__ __forceinline__ LdsF64W lds_f64w(unsigned byte_address) { return (LdsF64W)(unsigned long long)byte_address; }
+
+template <int NE, int LB, bool PAIRS, int ABL = 0>
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(LB <= 16 ? 4 : 3))) void k_estep_dictq(EstepArgs a)
 {
-    using S = DictShape<NE, A, PAIRS>;
-    constexpr int CB = S::CB, SB = S::SB, PU = S::PU, NU = S::NU;
-    static_assert(NU % 2 == 0 && CB % PU == 0, "units tile the half batches");
-    __shared__ __attribute__((aligned(16))) double sh_lp[2][SB * NE];
+    constexpr int NB = 64 / LB;
+    constexpr int PC = 64 / NE;
+    constexpr int CBB = 2 * PC / NB;
+    static_assert(CBB >= 1 && CBB * NB == 2 * PC, "a batch = two 64-lane passes of phase A");
+    constexpr int STRIDE = (CBB * NE * 8 + 127) / 128 * 128;  // LDS bytes per barcode and buffer; multiple of 128 so that
+    constexpr int BUFSZ = NB * STRIDE;                         // base | code (< 128) is base + code
+    constexpr int NEV = PAIRS ? 10 : NE;                       // entries that exist
+    constexpr int LE = 4 * LB < 64 ? 4 * LB : 64;              // epilogue: lanes per barcode,
+    constexpr int AE = 4 * LB / LE;                            // register slots per lane,
+    constexpr int GPC = 64 / LE;                               // barcodes per epilogue pass
+    constexpr int STAGE = NB * 4 * LB * 8;                     // bytes of the accumulator hand-over
+    __shared__ __attribute__((aligned(128))) unsigned char sh[2 * BUFSZ > STAGE ? 2 * BUFSZ : STAGE];
+    const unsigned sh_off = (unsigned)(unsigned long long)(__attribute__((address_space(3))) unsigned char *)sh;
     const int lane = threadIdx.x;
     const int K = a.K;
-    int kk[A];
-    bool valid[A];
-    unsigned voff[A];
-#pragma unroll
-    for (int s = 0; s < A; s++) {
-        const int k = lane + 64 * s;
-        valid[s] = k < K;
-        kk[s] = valid[s] ? k : K - 1;
-        voff[s] = (unsigned)kk[s];
-    }
-    double acc[A];
-#pragma unroll
-    for (int s = 0; s < A; s++) acc[s] = 0.0;
 
-    const long long b = a.order[blockIdx.x];
-    const long long pbeg = a.pair_ptr[b];
-    const int n = 2 * (int)(a.pair_ptr[b + 1] - pbeg);  // calls incl. neutral padding, multiple of 8
-    if (n > 0) {
-        const unsigned *__restrict__ words = (const unsigned *)(a.pairs + pbeg);
-        const __amdgpu_buffer_rsrc_t rsrc =
-            __builtin_amdgcn_make_buffer_rsrc((void *)a.ocodes, 0, (int)a.ocode_bytes, 0x00020000);
-        const unsigned pitch = (unsigned)a.ocode_pitch;
-        // phase A: this lane's (call, entry); lanes past CB * NE (NE = 10: 60..63) repeat a valid pair
-        const int ja = (lane / NE) < CB ? lane / NE : CB - 1;
-        const unsigned e = (unsigned)(lane % NE);
+    // ---- phase B identity: barcode slot ga, option quad li ----
+    const int li = lane % LB, ga = lane / LB, gbase = lane - li;
+    const long long slotB = (long long)blockIdx.x * NB + ga;
+    const bool liveB = slotB < a.B;
+    const long long bB = a.order[liveB ? slotB : a.B - 1];
+    const long long pbegB = a.pair_ptr[bB];
+    const int nB = liveB ? 2 * (int)(a.pair_ptr[bB + 1] - pbegB) : 0;  // calls incl. neutral padding, multiple of 8
+    int nmax = nB;
+#pragma unroll
+    for (int off = LB; off < 64; off <<= 1) nmax = max(nmax, __shfl_xor(nmax, off));
+    nmax = __builtin_amdgcn_readfirstlane(nmax);
+    double acc[4] = {0.0, 0.0, 0.0, 0.0};
+
+    if (nmax > 0) {
+        using R = DictRow<NE>;
+        const unsigned pitch = (unsigned)a.dtab_pitch;
+        const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void *)a.dtab, 0, (int)a.dtab_bytes, 0x00020000);
+        const unsigned quad_off = (unsigned)(R::DW * 4 + li * R::CBY);  // this lane's codes inside a table row
+        // records and rows through buffer loads (32-bit offsets: the arrays are below 4 GiB, checked by the host)
+        const __amdgpu_buffer_rsrc_t rsrc_rec = __builtin_amdgcn_make_buffer_rsrc((void *)a.pairs, 0, (int)a.pairs_bytes, 0x00020000);
+        const __amdgpu_buffer_rsrc_t rsrc_row = __builtin_amdgcn_make_buffer_rsrc((void *)a.call_rows, 0, (int)(a.pairs_bytes / 4u), 0x00020000);
+        const unsigned rowsB = (unsigned)pbegB * 8u;  // byte offset of this barcode's rows in call_rows
+        const int limB = max(nB - 1, 0);
+        const unsigned baseB = sh_off + (unsigned)(ga * STRIDE);
+
+        // ---- phase A identity: two (barcode, call of the batch) per lane, one per pass ----
+        const int tA = lane / NE;
+        const unsigned eslot = (unsigned)(lane % NE), e = eslot < (unsigned)NEV ? eslot : (unsigned)NEV - 1u;
         const unsigned d1 = PAIRS ? pair_entry_lo(e) : e, d2 = PAIRS ? pair_entry_hi(e) : e;
-        const int nsb = (n + SB - 1) / SB;
+        const int ux = tA, uy = PC + tA;
+        const int ax = ux / CBB, qx = ux % CBB, ay = uy / CBB, qy = uy % CBB;
+        const unsigned pbegX = (unsigned)__shfl((int)pbegB, ax * LB), pbegY = (unsigned)__shfl((int)pbegB, ay * LB);  // < 2^27 pairs
+        const int nX = __shfl(nB, ax * LB), nY = __shfl(nB, ay * LB);
+        const int limX = max(nX - 1, 0), limY = max(nY - 1, 0);
+        const unsigned ldsX = sh_off + (unsigned)(ax * STRIDE + qx * NE * 8) + eslot * 8u, ldsY = sh_off + (unsigned)(ay * STRIDE + qy * NE * 8) + eslot * 8u;
 
-        auto load_rec = [&](int sb, int half) {
-            int ci = sb * SB + half * CB + ja;
-            ci = ci < n ? ci : n - 1;  // past the row: the last call again (computed, never consumed)
-            const int w = (ci >> 1) * 8 + (ci & 1);
+        auto load_rec = [&](unsigned pbeg, int ci, int n, int lim) {
             DictRec r;
-            r.row = words[w + 6];
-            r.keep = __uint_as_float(words[w + 2]);
-            r.flo = __uint_as_float(words[w + 4]);
+            r.inside = ci < n;
+            ci = min(ci, lim);  // past the row: the last call again (an empty row: whatever record follows; +0 is parked)
+            const unsigned woff = pbeg * 32u + (unsigned)((ci >> 1) * 32 + (ci & 1) * 4);
+            r.row = (unsigned)__builtin_amdgcn_raw_buffer_load_b32(rsrc_row, (int)(pbeg * 8u + (unsigned)ci * 4u), 0, 0);
+            r.keep = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc_rec, (int)woff + 8, 0, 0));
+            r.flo = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc_rec, (int)woff + 16, 0, 0));
             return r;
         };
         auto load_p = [&](const DictRec &r) {
-            const float *row = a.dict + (size_t)r.row * DICT_CAP;
-            float p = row[d1];
-            if (PAIRS) p = (p + row[d2]) * 0.5f;  // demux.py:190
+            const unsigned off = __umul24(r.row, pitch);
+            float p = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, (int)(off + d1 * 4u), 0, 0));
+            if (PAIRS) p = (p + __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, (int)(off + d2 * 4u), 0, 0))) * 0.5f;  // demux.py:190
             return p;
         };
-        // logs of super-batch sb; calls past the row's end park +0 (adding +0 leaves a sum unchanged: the sums
-        // start at +0 and never become -0), so that phase B needs no per-call test
-        auto produce = [&](int buf, int sb, const DictRec &rx, const DictRec &ry, float px, float py) {
+        auto produce = [&](int buf, const DictRec &rx, const DictRec &ry, float px, float py) {
             npm::f32x2 t;
             t.x = px * rx.keep;
             t.y = py * ry.keep;
             t.x = t.x + rx.flo;
             t.y = t.y + ry.flo;
-            const npm::f32x2 lp = npm::log_f32_hot2(t);
-            const int cix = sb * SB + ja, ciy = cix + CB;
-            sh_lp[buf][ja * NE + e] = cix < n ? (double)lp.x : 0.0;
-            sh_lp[buf][(CB + ja) * NE + e] = ciy < n ? (double)lp.y : 0.0;
+            const npm::f32x2 l2 = ABL == 3 ? t : npm::log_f32_hot2(t);
+            *lds_f64w(ldsX + (unsigned)(buf * BUFSZ)) = rx.inside ? (double)l2.x : 0.0;
+            *lds_f64w(ldsY + (unsigned)(buf * BUFSZ)) = ry.inside ? (double)l2.y : 0.0;
         };
-        // option codes of unit u of a super-batch whose records are (rx, ry): call q of the unit is call
-        // u * PU + q of the super-batch = lane ((u * PU + q) % CB) * NE of rx (first half) or ry
-        auto load_codes = [&](unsigned (&c)[PU][A], const DictRec &rx, const DictRec &ry, int u) {
+        // code-row offsets of this barcode's calls of batch k, one per lane of the group (lane li: call li % CBB)
+        auto load_offsets = [&](int k) {
+            const unsigned row = (unsigned)__builtin_amdgcn_raw_buffer_load_b32(rsrc_row, (int)(rowsB + (unsigned)min(k * CBB + li % CBB, limB) * 4u), 0, 0);
+            return __umul24(row, pitch);
+        };
+        auto load_codes = [&](unsigned (&c)[CBB], unsigned offs) {
 #pragma unroll
-            for (int q = 0; q < PU; q++) {
-                const int jj = u * PU + q;
-                const int srow = __builtin_amdgcn_readlane((int)(jj < CB ? rx.row : ry.row), (jj % CB) * NE);
-                const int soff = (int)((unsigned)srow * pitch);
-#pragma unroll
-                for (int s = 0; s < A; s++)
-                    c[q][s] = (unsigned)__builtin_amdgcn_raw_buffer_load_b8(rsrc, (int)voff[s], soff, 0);
+            for (int q = 0; q < CBB; q++) {
+                const unsigned off = (unsigned)__builtin_amdgcn_ds_bpermute(4 * (gbase + q), (int)offs);
+                if (ABL == 1) c[q] = off & 0xFFu;
+                else if (R::CBY == 1) c[q] = (unsigned)__builtin_amdgcn_raw_buffer_load_b8(rsrc, (int)(off + quad_off), 0, 0);
+                else c[q] = (unsigned)__builtin_amdgcn_raw_buffer_load_b16(rsrc, (int)(off + quad_off), 0, 0);
             }
         };
-        auto consume = [&](const unsigned (&c)[PU][A], int buf, int sb, int u) {
-            if (sb * SB + u * PU >= n) return;  // wave-uniform: the whole unit lies past the row
-            const char *base = (const char *)&sh_lp[buf][0];
-            double v[PU][A];
-#pragma unroll
-            for (int q = 0; q < PU; q++)
-#pragma unroll
-                for (int s = 0; s < A; s++) v[q][s] = *(const double *)(base + (c[q][s] + (unsigned)((u * PU + q) * NE * 8)));
-#pragma unroll
-            for (int q = 0; q < PU; q++)  // call order
-#pragma unroll
-                for (int s = 0; s < A; s++) acc[s] += v[q][s];
-        };
-
-        DictRec cx = load_rec(0, 0), cy = load_rec(0, 1);  // records of the super-batch being consumed
-        DictRec nx = cx, ny = cy;                         // ... of the next one
-        if (nsb > 1) {
-            nx = load_rec(1, 0);
-            ny = load_rec(1, 1);
-        }
-        produce(0, 0, cx, cy, load_p(cx), load_p(cy));
-        unsigned c0[PU][A], c1[PU][A];
-        load_codes(c0, cx, cy, 0);
-        // one super-batch; BUF is a compile-time constant so that every LDS address is code + immediate
-        auto step = [&](auto buf_tag, int sb) {
+        auto consume = [&](const unsigned (&c)[CBB], auto buf_tag) {
             constexpr int BUF = decltype(buf_tag)::value;
-            const bool more = sb + 1 < nsb;  // wave-uniform
-            float px = 0.0f, py = 0.0f;
-            DictRec fx = nx, fy = ny;  // records of super-batch sb + 2
-            if (more) {
-                px = load_p(nx);
-                py = load_p(ny);
-                if (sb + 2 < nsb) {
-                    fx = load_rec(sb + 2, 0);
-                    fy = load_rec(sb + 2, 1);
+#pragma unroll
+            for (int q = 0; q < CBB; q++) {  // call order
+                double v[4];
+#pragma unroll
+                for (int o = 0; o < 4; o++) {
+                    const unsigned addr = baseB | (((c[q] >> (R::CBITS * o)) & ((1u << R::CBITS) - 1u)) << 3);
+                    v[o] = ABL == 2 ? (double)(int)addr : *lds_f64(addr + (unsigned)(BUF * BUFSZ + q * NE * 8));
+                }
+#pragma unroll
+                for (int o = 0; o < 4; o++) acc[o] += v[o];
+                // one call's lookups in flight: left alone the compiler issues all 4 CBB reads (2 VGPRs each) before
+                // the first addition and sinks the additions behind the loop's branch; registers are what this kernel
+                // runs out of (resident wavefronts hide its memory latency)
+                {
+#pragma unroll
+                    for (int o = 0; o < 4; o++) asm volatile("" : "+v"(acc[o]));
+                    __builtin_amdgcn_sched_barrier(0);
                 }
             }
-            __builtin_amdgcn_wave_barrier();  // the logs of this super-batch were stored by other lanes
-#pragma unroll
-            for (int u = 0; u < NU; u += 2) {
-                load_codes(c1, cx, cy, u + 1);
-                consume(c0, BUF, sb, u);
-                if (u + 2 < NU)
-                    load_codes(c0, cx, cy, u + 2);
-                else if (more)
-                    load_codes(c0, nx, ny, 0);
-                consume(c1, BUF, sb, u + 1);
-            }
-            if (more) produce(BUF ^ 1, sb + 1, nx, ny, px, py);
-            cx = nx;
-            cy = ny;
-            nx = fx;
-            ny = fy;
         };
-        for (int sb = 0; sb < nsb; sb += 2) {
-            step(std::integral_constant<int, 0>{}, sb);
-            if (sb + 1 < nsb) step(std::integral_constant<int, 1>{}, sb + 1);
+
+        // Software pipeline, two batches deep: what a wavefront waits for is memory latency (a gather that misses L2
+        // takes a few thousand cycles under load), and with 4-5 resident wavefronts per SIMD every request must be
+        // two batches of everybody's work old before its data is needed.
+        //   entering step k:  cc0 / cc1 = codes of batches k / k + 1, offs2 = code-row offsets of k + 2,
+        //                     (rA, pA) = records and dictionary values of k + 1, rB = records of k + 2,
+        //                     LDS buffer k & 1 = logs of batch k
+        const int nbatch = (nmax + CBB - 1) / CBB;
+        auto load_recs = [&](int k, DictRec &rx, DictRec &ry) {
+            if (ABL >= 4) k = 0;
+            rx = load_rec(pbegX, k * CBB + qx, nX, limX);
+            ry = load_rec(pbegY, k * CBB + qy, nY, limY);
+        };
+        // Batch-indexed state lives in register sets selected by (batch mod 3) / (batch mod 2) at compile time - the
+        // loop is unrolled six-fold - because MOVING a register that an outstanding load will write means waiting
+        // for that load (a rotating-register version spent every step's end in s_waitcnt vmcnt(0)).
+        //   codes[j], recs[j]: batch = j mod 3        pv[j], offs[j]: batch = j mod 2
+        unsigned codes[3][CBB];
+        DictRec recx[3], recy[3];
+        float pvx[2], pvy[2];
+        unsigned offs[2];
+        load_recs(0, recx[0], recy[0]);
+        produce(0, recx[0], recy[0], load_p(recx[0]), load_p(recy[0]));
+        load_codes(codes[0], load_offsets(0));
+        load_codes(codes[1], load_offsets(1));
+        offs[0] = load_offsets(2);
+        load_recs(1, recx[1], recy[1]);
+        pvx[1] = load_p(recx[1]);
+        pvy[1] = load_p(recy[1]);
+        load_recs(2, recx[2], recy[2]);
+        // step k (S = k mod 6): requests records of k + 3, offsets of k + 3, dictionary values of k + 2, codes of k + 2;
+        // consumes the codes and logs of k; parks the logs of k + 1
+        auto step = [&](auto s_tag, int k) {
+            constexpr int S = decltype(s_tag)::value;
+            if (ABL < 4) {
+                load_recs(k + 3, recx[S % 3], recy[S % 3]);
+                offs[(S + 1) % 2] = load_offsets(k + 3);
+                pvx[S % 2] = load_p(recx[(S + 2) % 3]);
+                pvy[S % 2] = load_p(recy[(S + 2) % 3]);
+            }
+            if (ABL != 5) load_codes(codes[(S + 2) % 3], offs[S % 2]);
+            __builtin_amdgcn_wave_barrier();  // the logs of this batch were parked by other lanes
+            consume(codes[S % 3], std::integral_constant<int, S % 2>{});
+            if (k + 1 < nbatch) produce((S + 1) % 2, recx[(S + 1) % 3], recy[(S + 1) % 3], pvx[(S + 1) % 2], pvy[(S + 1) % 2]);  // wave-uniform
+        };
+        for (int k = 0; k < nbatch; k += 6) {
+            step(std::integral_constant<int, 0>{}, k);
+            if (k + 1 < nbatch) step(std::integral_constant<int, 1>{}, k + 1);
+            if (k + 2 < nbatch) step(std::integral_constant<int, 2>{}, k + 2);
+            if (k + 3 < nbatch) step(std::integral_constant<int, 3>{}, k + 3);
+            if (k + 4 < nbatch) step(std::integral_constant<int, 4>{}, k + 4);
+            if (k + 5 < nbatch) step(std::integral_constant<int, 5>{}, k + 5);
         }
     }
-    estep_epilogue<64, A>(a, b, true, acc, kk, valid, lane, lane, 0, n);
+
+    // ---- hand the sums over to the epilogue's layout (option k of a barcode in lane k & 63, slot k >> 6) ----
+    __builtin_amdgcn_wave_barrier();
+    {
+        const LdsF64W stage = lds_f64w(sh_off + (unsigned)((ga * 4 * LB + 4 * li) * 8));
+#pragma unroll
+        for (int o = 0; o < 4; o++) stage[o] = acc[o];
+    }
+    __builtin_amdgcn_wave_barrier();
+    const int le = lane % LE, ge = lane / LE;
+    int kk[AE];
+    bool valid[AE];
+#pragma unroll
+    for (int s = 0; s < AE; s++) {
+        const int k = le + 64 * s;
+        valid[s] = k < K;
+        kk[s] = valid[s] ? k : K - 1;
+    }
+#pragma unroll
+    for (int r = 0; r < NB / GPC; r++) {
+        const int slot = r * GPC + ge;  // barcode slot of this lane in this pass
+        const long long b = __shfl(bB, slot * LB);
+        const int n_calls = __shfl(nB, slot * LB);
+        const bool live = __shfl((int)liveB, slot * LB) != 0;
+        if (GPC == 1 && !live) continue;  // wave-uniform (the 64-lane epilogue does not mask its bitmap stores)
+        double sums[AE];
+#pragma unroll
+        for (int s = 0; s < AE; s++) sums[s] = *lds_f64(sh_off + (unsigned)((slot * 4 * LB + kk[s]) * 8));
+        estep_epilogue<LE, AE>(a, b, live, sums, kk, valid, lane, le, lane - le, n_calls);
+    }
 }
 
 template <int A>
 static void launch_build_dict(hipStream_t st, const float *prob, long long rows, int G, float *dict, unsigned char *codes, unsigned *stat)
 {
-    hipLaunchKernelGGL((k_build_dict<A>), dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, st, prob, rows, G, dict, codes, stat);
+    constexpr int ROWS = A <= 2 ? 8 : A <= 4 ? 4 : 2;
+    hipLaunchKernelGGL((k_build_dict<A, ROWS>), dim3((unsigned)((rows + 4 * ROWS - 1) / (4 * ROWS))), dim3(256), 0, st, prob, rows, G,
+                       dict_code_pitch(G), dict, codes, stat);
 }
 
+// codes: [rows, dict_code_pitch(G)]
 hipError_t launch_build_dict(hipStream_t st, const float *prob, long long rows, int G, float *dict, unsigned char *codes, unsigned *stat)
 {
     hipError_t e = hipMemsetAsync(stat, 0, sizeof(unsigned), st);
     if (e != hipSuccess || rows == 0) return e;
-    if (G <= 64) launch_build_dict<1>(st, prob, rows, G, dict, codes, stat);
-    else if (G <= 128) launch_build_dict<2>(st, prob, rows, G, dict, codes, stat);
-    else if (G <= 256) launch_build_dict<4>(st, prob, rows, G, dict, codes, stat);
-    else if (G <= 512) launch_build_dict<8>(st, prob, rows, G, dict, codes, stat);
+    if (G <= 64 - 3) launch_build_dict<1>(st, prob, rows, G, dict, codes, stat);  // the pitch's tail is written by lanes >= G
+    else if (G <= 128 - 3) launch_build_dict<2>(st, prob, rows, G, dict, codes, stat);
+    else if (G <= 256 - 3) launch_build_dict<4>(st, prob, rows, G, dict, codes, stat);
+    else if (G <= 512 - 3) launch_build_dict<8>(st, prob, rows, G, dict, codes, stat);
     else if (G <= 1024) launch_build_dict<16>(st, prob, rows, G, dict, codes, stat);
     else return hipErrorInvalidValue;
     return hipGetLastError();
 }
 
-hipError_t launch_build_pair_codes(hipStream_t st, const unsigned char *codes, const unsigned *opt_pairs, long long rows, int G, int K,
-                                   unsigned char *ocodes)
+static int dict_lanes(int K, bool pairs)  // lanes per barcode of the E-step kernel
 {
-    const long long n = rows * K;
+    return K <= 16 && !pairs ? 4 : K <= 32 ? 8 : K <= 64 ? 16 : K <= 128 ? 32 : 64;
+}
+
+// distinct: what launch_build_dict found (<= DICT_CAP; <= DICT_PAIR_CAP for doublet runs); returns the row pitch
+int dict_table_pitch(int distinct, int K, bool pairs)
+{
+    const int LB = dict_lanes(K, pairs);
+    return pairs ? DictRow<16>::pitch(LB) : distinct <= 4 ? DictRow<4>::pitch(LB) : DictRow<8>::pitch(LB);
+}
+
+hipError_t launch_pack_rows(hipStream_t st, const float *dict, const unsigned char *codes, const unsigned *opt_pairs, long long rows, int G,
+                            int K, bool pairs, int distinct, unsigned char *table)
+{
+    const int LB = dict_lanes(K, pairs), pitch = dict_table_pitch(distinct, K, pairs);
+    const long long n = rows * LB;
     if (n == 0) return hipSuccess;
-    hipLaunchKernelGGL(k_build_pair_codes, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, codes, opt_pairs, rows, G, K, ocodes);
+    const dim3 grid((unsigned)((n + 255) / 256)), block(256);
+    hipError_t e = hipMemsetAsync(table, 0, (size_t)rows * pitch, st);
+    if (e != hipSuccess) return e;
+    if (pairs) hipLaunchKernelGGL((k_pack_rows<16, true>), grid, block, 0, st, dict, codes, dict_code_pitch(G), opt_pairs, rows, K, LB, pitch, table);
+    else if (distinct <= 4) hipLaunchKernelGGL((k_pack_rows<4, false>), grid, block, 0, st, dict, codes, dict_code_pitch(G), opt_pairs, rows, K, LB, pitch, table);
+    else hipLaunchKernelGGL((k_pack_rows<8, false>), grid, block, 0, st, dict, codes, dict_code_pitch(G), opt_pairs, rows, K, LB, pitch, table);
     return hipGetLastError();
+}
+
+template <int NE, int LB, bool PAIRS>
+static void launch_dictq(hipStream_t st, const EstepArgs &a)
+{
+    static const int ablate = std::getenv("DEMUXALOT_AMD_DICT_ABLATE") ? std::atoi(std::getenv("DEMUXALOT_AMD_DICT_ABLATE")) : 0;
+    constexpr int NB = 64 / LB;
+    static const long long max_blocks = std::getenv("DEMUXALOT_AMD_DICT_BLOCKS") ? std::atoll(std::getenv("DEMUXALOT_AMD_DICT_BLOCKS")) : (1LL << 40);
+    const dim3 grid((unsigned)std::min<long long>(max_blocks, (a.B + NB - 1) / NB)), block(64);
+    if constexpr (NE == 4 && LB == 16 && !PAIRS) {
+        if (ablate == 1) {
+            hipLaunchKernelGGL((k_estep_dictq<4, 16, false, 1>), grid, block, 0, st, a);
+            return;
+        }
+        if (ablate == 2) {
+            hipLaunchKernelGGL((k_estep_dictq<4, 16, false, 2>), grid, block, 0, st, a);
+            return;
+        }
+        if (ablate == 3) {
+            hipLaunchKernelGGL((k_estep_dictq<4, 16, false, 3>), grid, block, 0, st, a);
+            return;
+        }
+        if (ablate == 4) {
+            hipLaunchKernelGGL((k_estep_dictq<4, 16, false, 4>), grid, block, 0, st, a);
+            return;
+        }
+        if (ablate == 5) {
+            hipLaunchKernelGGL((k_estep_dictq<4, 16, false, 5>), grid, block, 0, st, a);
+            return;
+        }
+    }
+    hipLaunchKernelGGL((k_estep_dictq<NE, LB, PAIRS, 0>), grid, block, 0, st, a);
 }
 
 template <int NE, bool PAIRS>
 static hipError_t launch_dict_ne(hipStream_t st, const EstepArgs &a)
 {
-    const dim3 grid((unsigned)a.B), block(64);
     const int K = a.K;
-    if (K <= 64) hipLaunchKernelGGL((k_estep_dict<NE, 1, PAIRS>), grid, block, 0, st, a);
-    else if (K <= 128) hipLaunchKernelGGL((k_estep_dict<NE, 2, PAIRS>), grid, block, 0, st, a);
-    else if (K <= 256) hipLaunchKernelGGL((k_estep_dict<NE, 4, PAIRS>), grid, block, 0, st, a);
-    else if constexpr (PAIRS) return hipErrorInvalidValue;  // wider doublet tables: the workgroup-per-barcode form
-    else if (K <= 512) hipLaunchKernelGGL((k_estep_dict<NE, 8, false>), grid, block, 0, st, a);
-    else if (K <= 1024) hipLaunchKernelGGL((k_estep_dict<NE, 16, false>), grid, block, 0, st, a);
-    else return hipErrorInvalidValue;
+    if (K > DICT_LANE_K) return hipErrorInvalidValue;
+    const int LB = dict_lanes(K, PAIRS);
+    if (LB == 4) {
+        if constexpr (!PAIRS) launch_dictq<NE, 4, false>(st, a);
+    } else if (LB == 8) launch_dictq<NE, 8, PAIRS>(st, a);
+    else if (LB == 16) launch_dictq<NE, 16, PAIRS>(st, a);
+    else if (LB == 32) launch_dictq<NE, 32, PAIRS>(st, a);
+    else launch_dictq<NE, 64, PAIRS>(st, a);
     return hipGetLastError();
 }
 
@@ -327,7 +503,7 @@ static hipError_t launch_dict_ne(hipStream_t st, const EstepArgs &a)
 hipError_t launch_estep_dict(hipStream_t st, const EstepArgs &a, bool pairs)
 {
     if (a.B == 0) return hipSuccess;
-    if (pairs) return launch_dict_ne<10, true>(st, a);
+    if (pairs) return launch_dict_ne<16, true>(st, a);
     return a.dict_n <= 4 ? launch_dict_ne<4, false>(st, a) : launch_dict_ne<8, false>(st, a);
 }
 

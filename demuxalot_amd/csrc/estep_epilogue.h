@@ -121,6 +121,12 @@ static __device__ __forceinline__ float reg_row_sum(const float (&x)[A], int K, 
     return ret;
 }
 
+template <int L>
+static __device__ __forceinline__ unsigned long long group_mask()
+{
+    return L >= 64 ? ~0ull : (1ull << (L & 63)) - 1ull;
+}
+
 // Epilogue of the direct forms: penalties, optional prior, softmax as scipy evaluates it, the M-step's bitmap.
 // acc[s] = float64 sum of the log terms of option kk[s] of barcode b (one lane group of L lanes per barcode).
 template <int L, int A>
@@ -164,12 +170,12 @@ static __device__ __forceinline__ void estep_epilogue(const EstepArgs &a, long l
         if (L == 64) {
             if (lane == 0 && s < W) a.nz[(size_t)b * W + s] = bal;
         } else {
-            if (live && li == 0) a.nz[(size_t)b] = (bal >> gbase) & ((1ull << L) - 1ull);
+            if (live && li == 0) a.nz[(size_t)b] = (bal >> gbase) & group_mask<L>();
         }
         if (s == 0 && a.first) {
             // what the M-step's call-parallel part needs of this barcode, 8 bytes (nz_code): ONE gather per call there,
             // from a table small enough to stay in L2
-            const unsigned long long mine = L == 64 ? bal : ((bal >> gbase) & ((1ull << L) - 1ull));
+            const unsigned long long mine = L == 64 ? bal : ((bal >> gbase) & group_mask<L>());
             if (live && li == (mine ? __builtin_ctzll(mine) : 0)) a.first[b] = nz_code(mine, post);
             // statistic for the M-step's choice of kernel (G <= 64): calls whose barcode has more than 4 live posteriors
             if (a.dense_calls && live && li == 0 && __popcll(mine) > 4)

@@ -24,7 +24,9 @@ static_assert(sizeof(CallPair) == 32, "CallPair layout");
 struct EstepArgs {
     const long long *pair_ptr;  // [B+1] offsets into `pairs` (barcode-major, rows padded to 4 pairs)
     const int *order;           // [B] barcodes by decreasing row length (work distribution)
-    const CallPair *pairs;      // call records, see above
+    const CallPair *pairs;      // call records, see above (CALL_PAD_PAIRS neutral records behind the last row)
+    const unsigned *call_rows;  // [2 * (n_pairs + CALL_PAD_PAIRS)] table row of every call of `pairs` (dictionary form)
+    unsigned pairs_bytes;       // extent of `pairs` incl. the padding records when below 4 GiB (dictionary form: buffer addressing), else 0
     const float *prob;          // [V, G] genotype_prob, row-major
     const int *sum_plan;        // np.sum over a row of K values: {n_leaves, n_levels, n_roots, level offsets [n_levels + 1],
                                 // leaves (start, length), inner nodes (left value, right value) level by level, roots}
@@ -57,17 +59,17 @@ struct EstepArgs {
                                   // group's first pair = the slot (accumulator) the group belongs to
     // dictionary form (estep_dict.hip); dict_n == 0: not used by this launch
     int dict_n;                   // most distinct values in a row of `prob` (<= DICT_CAP)
-    const float *dict;            // [rows, DICT_CAP] distinct values of every row
-    const unsigned char *codes;   // [rows, G] 8 x index of every genotype's value in its row's dictionary
-    const unsigned char *ocodes;  // [rows, ocode_pitch] 8 x index of every OPTION's log among a call's entries (singlet
-                                  // runs: `codes` itself; doublet runs with K <= DICT_PAIR_LANE_K: pair entries)
-    unsigned ocode_bytes;         // extent of ocodes (< 4 GiB: buffer addressing)
-    int ocode_pitch;
+    const unsigned char *dtab;    // [rows, dtab_pitch] per row of `prob`: its distinct values, then the codes of the options
+                                  // (estep_dict.hip: DictRow)
+    unsigned dtab_bytes;          // extent of dtab (< 4 GiB: buffer addressing)
+    int dtab_pitch;
 };
 
+constexpr int CALL_PAD_PAIRS = 64;     // readable neutral records behind the last barcode's row (pairs and call_rows)
 constexpr int DICT_CAP = 8;            // distinct values per row the dictionary form handles (singlet runs)
 constexpr int DICT_PAIR_CAP = 4;       // ... in doublet runs (10 pair values)
-constexpr int DICT_PAIR_LANE_K = 256;  // doublet tables up to this many options take the lane-per-option dictionary kernel
+constexpr int DICT_LANE_K = 256;       // option tables up to this width take the lane-per-four-options dictionary kernel
+inline int dict_code_pitch(int n) { return (n + 3) & ~3; }  // bytes between the rows of a code table of n codes per row
 
 constexpr int DENSE_SLOTS = 1024;            // hashed counters of the dense-call statistic
 hipError_t launch_sum_dense(hipStream_t st, unsigned long long *counters);
@@ -133,8 +135,10 @@ hipError_t launch_estep(hipStream_t st, const EstepArgs &a, bool pairs);
 // dictionary form (estep_dict.hip): distinct values and codes of every row of `prob`; stat[0] = most distinct values
 // in a row (DICT_CAP + 1: some row has more)
 hipError_t launch_build_dict(hipStream_t st, const float *prob, long long rows, int G, float *dict, unsigned char *codes, unsigned *stat);
-hipError_t launch_build_pair_codes(hipStream_t st, const unsigned char *codes, const unsigned *opt_pairs, long long rows, int G, int K,
-                                   unsigned char *ocodes);
+// the packed table of the dictionary-form kernel from the two arrays above; `distinct` as found by launch_build_dict
+int dict_table_pitch(int distinct, int K, bool pairs);
+hipError_t launch_pack_rows(hipStream_t st, const float *dict, const unsigned char *codes, const unsigned *opt_pairs, long long rows, int G,
+                            int K, bool pairs, int distinct, unsigned char *table);
 hipError_t launch_estep_dict(hipStream_t st, const EstepArgs &a, bool pairs);
 hipError_t launch_mstep(hipStream_t st, const MstepArgs &a);
 // sums the item partials of variants [v0, v1) and redoes, in the reference's order, the sums whose float32
@@ -143,8 +147,9 @@ hipError_t launch_mstep(hipStream_t st, const MstepArgs &a);
 hipError_t launch_mcombine(hipStream_t st, const MstepArgs &a, const long long *item_ptr, long long v0, long long v1,
                            const int *prow, float *add32, double *add64, unsigned long long *redo, unsigned *n_redo);
 hipError_t launch_store_slice(hipStream_t st, const void *slice, bool f64, long long v_begin, long long n_rows, int G, float *add);
-// set_rows: also CallPair::reserved = the new row (the plain record stream; the tile stream keeps its slot tags there)
-hipError_t launch_remap_row_offsets(hipStream_t st, CallPair *pairs, long long n_pairs, unsigned row_bytes, const int *new_rows, bool set_rows);
+// call_rows (nullable): the compact row array of the same records, rewritten as well
+hipError_t launch_remap_row_offsets(hipStream_t st, CallPair *pairs, long long n_pairs, unsigned row_bytes, const int *new_rows,
+                                    unsigned *call_rows);
 hipError_t launch_f64_to_f32(hipStream_t st, const double *in, float *out, long long n);
 hipError_t launch_f32_to_f64(hipStream_t st, const float *in, double *out, long long n);
 hipError_t launch_prior_betas(hipStream_t st, const float *betas, float *bsum, const unsigned long long *n_mol,

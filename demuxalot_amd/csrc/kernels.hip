@@ -1481,7 +1481,7 @@ __global__ __launch_bounds__(256) void k_store_slice(const T *__restrict__ slice
 // changes from the dense to the padded layout the offsets are rewritten in place (new_rows[v] = padded row of
 // variant v; neutral padding calls point at row 0, which stays row 0).
 __global__ __launch_bounds__(256) void k_remap_row_offsets(CallPair *__restrict__ pairs, long long n_pairs, unsigned row_bytes,
-                                                           const int *__restrict__ new_rows, bool set_rows)
+                                                           const int *__restrict__ new_rows, unsigned *__restrict__ call_rows)
 {
     const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n_pairs) return;
@@ -1489,7 +1489,7 @@ __global__ __launch_bounds__(256) void k_remap_row_offsets(CallPair *__restrict_
     for (int h = 0; h < 2; h++) {
         const unsigned row = (unsigned)new_rows[pairs[i].row_off[h] / row_bytes];
         pairs[i].row_off[h] = row * row_bytes;
-        if (set_rows) pairs[i].reserved[h] = row;  // the plain record stream carries the row as well (estep_dict.hip)
+        if (call_rows) call_rows[2 * i + h] = row;  // the compact row array of the dictionary form (estep_dict.hip)
     }
 }
 
@@ -1824,10 +1824,10 @@ hipError_t launch_store_slice(hipStream_t st, const void *slice, bool f64, long 
 }
 
 hipError_t launch_remap_row_offsets(hipStream_t st, CallPair *pairs, long long n_pairs, unsigned row_bytes, const int *new_rows,
-                                    bool set_rows)
+                                    unsigned *call_rows)
 {
     if (n_pairs == 0) return hipSuccess;
-    hipLaunchKernelGGL(k_remap_row_offsets, dim3(blocks_for(n_pairs, 256)), dim3(256), 0, st, pairs, n_pairs, row_bytes, new_rows, set_rows);
+    hipLaunchKernelGGL(k_remap_row_offsets, dim3(blocks_for(n_pairs, 256)), dim3(256), 0, st, pairs, n_pairs, row_bytes, new_rows, call_rows);
     return hipGetLastError();
 }
 

@@ -101,7 +101,7 @@ __global__ __launch_bounds__(256) void k_build_pairs(const unsigned *__restrict_
                                                      const int *__restrict__ variant, const float *__restrict__ p_wrong,
                                                      const long long *__restrict__ row_start,
                                                      const long long *__restrict__ pair_ptr, long long N, unsigned G,
-                                                     CallPair *__restrict__ pairs)
+                                                     CallPair *__restrict__ pairs, unsigned *__restrict__ call_rows)
 {
     const long long s = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (s >= N) return;
@@ -112,7 +112,7 @@ __global__ __launch_bounds__(256) void k_build_pairs(const unsigned *__restrict_
     CallPair &pr = pairs[pair_ptr[b] + (j >> 1)];
     const int h = (int)(j & 1);
     pr.row_off[h] = (unsigned)variant[i] * G * 4u;   // byte offset of the variant's row in prob[V, G]
-    pr.reserved[h] = (unsigned)variant[i];           // the row itself (dictionary form of the E-step: estep_dict.hip)
+    call_rows[2 * (pair_ptr[b] + (j >> 1)) + h] = (unsigned)variant[i];  // the row itself, compact (estep_dict.hip)
     pr.keep[h] = 1.0f - e;                          // float32, numpy's `1 - e`
     pr.floor[h] = e > 1e-4f ? e : 1e-4f;            // numpy's `e.clip(1e-4)`
 }
@@ -376,11 +376,15 @@ static int repack_core(dmx_ctx *c, Scratch &sc, const int *d_variant, const int 
     c->n_items = n_items;
 
     // barcode-major -> E-step records
-    DMX_TRY(dev_alloc(c, &c->d_call_pairs, (size_t)n_pairs));
-    if (n_pairs) hipLaunchKernelGGL(k_fill_neutral, dim3(grid_for(n_pairs)), dim3(256), 0, st, c->d_call_pairs, n_pairs);
+    // (CALL_PAD_PAIRS neutral records behind the last row: the dictionary form reads whole super-batches)
+    const long long padded_pairs = n_pairs + CALL_PAD_PAIRS;
+    DMX_TRY(dev_alloc(c, &c->d_call_pairs, (size_t)padded_pairs));
+    DMX_TRY(dev_alloc(c, &c->d_call_rows, (size_t)padded_pairs * 2));
+    hipLaunchKernelGGL(k_fill_neutral, dim3(grid_for(padded_pairs)), dim3(256), 0, st, c->d_call_pairs, padded_pairs);
+    HIP_TRY(hipMemsetAsync(c->d_call_rows, 0, sizeof(unsigned) * (size_t)padded_pairs * 2, st));
     if (N)
         hipLaunchKernelGGL(k_build_pairs, dim3(grid_for(N)), dim3(256), 0, st, keys_b, perm_b, d_variant, d_p, row_start,
-                           c->d_pair_ptr, N, (unsigned)G, c->d_call_pairs);
+                           c->d_pair_ptr, N, (unsigned)G, c->d_call_pairs, c->d_call_rows);
     // ---- tile-major E-step schedule, when the shape calls for it ----
     c->n_bins = 0;
     c->n_tiles = 0;

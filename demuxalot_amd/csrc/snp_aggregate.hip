@@ -456,7 +456,7 @@ template <int A, bool SQUARE>
 __global__ __launch_bounds__(256) void k_mstep_f64(const long long *__restrict__ item_ptr, const long long *__restrict__ item_start,
                                                    const int *__restrict__ item_len, const uint2 *__restrict__ calls,
                                                    const double *__restrict__ post, long long V, int G, long long K, double power,
-                                                   float *__restrict__ add)
+                                                   float *__restrict__ add, double *__restrict__ sums)
 {
     const int lane = threadIdx.x & 63;
     const long long v = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -483,7 +483,10 @@ __global__ __launch_bounds__(256) void k_mstep_f64(const long long *__restrict__
 #pragma unroll
     for (int s = 0; s < A; s++) {
         const int g = lane + 64 * s;
-        if (g < G) add[v * G + g] = (float)acc[s];
+        if (g < G) {
+            add[v * G + g] = (float)acc[s];
+            if (sums) sums[v * G + g] = acc[s];  // the unrounded float64 sum (barcode-sharded runs add these over ranks)
+        }
     }
 }
 
@@ -515,15 +518,15 @@ int launch_snp_block(dmx_ctx *c, const SnpArgs &a)
 }
 
 template <int A>
-void launch_m64(dmx_ctx *c, double power)
+void launch_m64(dmx_ctx *c, double power, double *sums)
 {
     const dim3 grid((unsigned)((c->V + 3) / 4)), block(256);
     if (power == 2.0)
         hipLaunchKernelGGL((k_mstep_f64<A, true>), grid, block, 0, c->stream, c->d_item_ptr, c->d_item_start, c->d_item_len, c->d_csc,
-                           c->d_post64, c->V, c->G, (long long)c->K, power, c->d_add);
+                           c->d_post64, c->V, c->G, (long long)c->K, power, c->d_add, sums);
     else
         hipLaunchKernelGGL((k_mstep_f64<A, false>), grid, block, 0, c->stream, c->d_item_ptr, c->d_item_start, c->d_item_len, c->d_csc,
-                           c->d_post64, c->V, c->G, (long long)c->K, power, c->d_add);
+                           c->d_post64, c->V, c->G, (long long)c->K, power, c->d_add, sums);
 }
 
 }  // namespace
@@ -732,24 +735,36 @@ int dmx_estep_snp(dmx_ctx *c, int with_doublets, const double *count_pow, int64_
     return rc;
 }
 
-int dmx_mstep_f64(dmx_ctx *c, double contribution_power, float *addition_out)
+static int mstep_f64(dmx_ctx *c, double contribution_power, float *addition_out, double *sums_out)
 {
     if (!c) return fail(DMX_ERR_INVALID, "null context");
     HIP_TRY(hipSetDevice(c->device));
     if (!c->have_problem || !c->have_post64) return fail(DMX_ERR_INVALID, "call order: dmx_estep_snp before dmx_mstep_f64");
-    if (c->attached()) return fail(DMX_ERR_UNSUPPORTED, "aggregate_on_snps is single-GPU");
+    if (c->attached()) return fail(DMX_ERR_UNSUPPORTED, "the float64 M-step does not run the device-side exchange: barcode-sharded "
+                                                       "aggregate_on_snps runs add dmx_mstep_f64_sums over ranks on the host");
     const int G = c->G;
-    if (G <= 64) launch_m64<1>(c, contribution_power);
-    else if (G <= 128) launch_m64<2>(c, contribution_power);
-    else if (G <= 256) launch_m64<4>(c, contribution_power);
-    else if (G <= 512) launch_m64<8>(c, contribution_power);
-    else launch_m64<16>(c, contribution_power);
+    double *sums = sums_out ? c->d_add64 : nullptr;
+    if (G <= 64) launch_m64<1>(c, contribution_power, sums);
+    else if (G <= 128) launch_m64<2>(c, contribution_power, sums);
+    else if (G <= 256) launch_m64<4>(c, contribution_power, sums);
+    else if (G <= 512) launch_m64<8>(c, contribution_power, sums);
+    else launch_m64<16>(c, contribution_power, sums);
     HIP_TRY(hipGetLastError());
     c->add_partial = false;
     c->add_is_zero = false;
-    if (addition_out && c->V) HIP_TRY(hipMemcpyAsync(addition_out, c->d_add, sizeof(float) * (size_t)c->V * G, hipMemcpyDeviceToHost, c->stream));
+    const size_t vg = (size_t)c->V * G;
+    if (addition_out && vg) HIP_TRY(hipMemcpyAsync(addition_out, c->d_add, sizeof(float) * vg, hipMemcpyDeviceToHost, c->stream));
+    if (sums_out && vg) HIP_TRY(hipMemcpyAsync(sums_out, c->d_add64, sizeof(double) * vg, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
     return 0;
+}
+
+int dmx_mstep_f64(dmx_ctx *c, double contribution_power, float *addition_out) { return mstep_f64(c, contribution_power, addition_out, nullptr); }
+
+int dmx_mstep_f64_sums(dmx_ctx *c, double contribution_power, double *sums_out)
+{
+    if (!sums_out) return fail(DMX_ERR_INVALID, "null output");
+    return mstep_f64(c, contribution_power, nullptr, sums_out);
 }
 
 }  // extern "C"

@@ -275,9 +275,21 @@ class DeviceContext:
         self.K = K
         return logits, probs
 
-    def mstep_f64(self, contribution_power=2.):
+    def mstep_f64(self, contribution_power=2., as_float64=False):
+        """M-step on the float64 posteriors of estep_snp.  as_float64: the unrounded float64 sums (a barcode-sharded run
+        adds them over ranks before the one float32 rounding)."""
+        if as_float64:
+            out = np.empty((self.V, self.G), dtype=np.float64)
+            check(self._lib.dmx_mstep_f64_sums(self._h, float(contribution_power), ptr(out)))
+            return out
         out = np.empty((self.V, self.G), dtype=np.float32)
         check(self._lib.dmx_mstep_f64(self._h, float(contribution_power), ptr(out)))
+        return out
+
+    def get_prior_betas(self):
+        out = np.empty((self.V, self.G), dtype=np.float32)
+        check(self._lib.dmx_get_prior_betas(self._h, ptr(out)))
+        out.flags.writeable = False
         return out
 
     def get_assignments_above(self, threshold):

@@ -13,10 +13,18 @@ libdemux_hip.so over RCCL (include/demux_hip.h: "Multi-GPU").  What is left for 
     regularised prior needs (sum over ranks, demux.py:372-388), and the posterior rows (gather),
   * `learn_genotypes` / `predict_posteriors` with the reference's signatures plus a `plane` argument.
 
-The control plane is any object with the four methods of `SingleProcess`; `TorchControlPlane` runs them over a
-torch.distributed process group (gloo on the host; the data plane never touches it).  A plane that also has a
+The control plane is any object with the four methods of `SingleProcess`.  The one to use is
+`demuxalot_amd.plane.SocketControlPlane` (plain TCP, no torch: a worker that imports torch maps torch's own HIP
+runtime and RCCL next to the ROCm ones, and the library refuses to attach an RCCL communicator in such a process).
+`TorchControlPlane` runs the same methods over an existing torch.distributed (gloo) group for hosts that live in torch
+anyway; there the per-iteration exchange must be host-staged (`host_collectives=True`).  A plane that has a
 `host_collective(op, array)` method carries the per-iteration exchange itself (staged through host memory) in place
-of RCCL: `TorchControlPlane(host_collectives=True)`, or the thread plane of tests/test_gpu_ranks_on_one_gpu.py.
+of RCCL: `SocketControlPlane(host_collectives=True)`, or the thread plane of tests/test_gpu_ranks_on_one_gpu.py.
+
+Where the results go (`results=`): 'all' (default, the reference's contract: every rank gets the DataFrame of ALL
+barcodes), 'root' (rank 0 gets it - raw buffers over the plane, no pickles - the others None), 'device' (every rank
+keeps its rows on its GPU behind a ShardedPosteriors whose assignments / best / option_sums reduce O(B) / O(K)
+numbers across ranks: what users take from the matrix, snp_detection.py:166, notebook cells 14 / 19).
 """
 import numpy as np
 import pandas as pd
@@ -38,6 +46,12 @@ class SingleProcess:
     def gather_rows(self, rows):
         return rows
 
+    def gather_to_root(self, rows):
+        return rows
+
+    def all_ok(self, ok, message=''):
+        return bool(ok), message
+
     def barrier(self):
         pass
 
@@ -58,8 +72,11 @@ class TorchControlPlane:
     def _host_collective(self, op, array):
         import torch
         t = torch.from_numpy(array)  # shares the library's staging buffer
-        if op in ('all_reduce', 'reduce_scatter'):  # gloo has no reduce_scatter: row `rank` of the full sum is it
+        if op == 'all_reduce':
             self._dist.all_reduce(t)
+        elif op == 'reduce_scatter':  # gloo has no reduce_scatter: one reduce per destination, block by block
+            for r in range(self.world):
+                self._dist.reduce(t[r], dst=r)
         else:
             parts = [torch.empty_like(t[0]) for _ in range(self.world)]
             self._dist.all_gather(parts, t[self.rank].clone())
@@ -77,11 +94,34 @@ class TorchControlPlane:
         self._dist.all_reduce(t)
         return t.numpy()
 
+    def _gather(self, rows, everywhere):
+        """Rows of every rank concatenated in rank order (= barcode order) as tensors, not pickles; on every rank or
+        on rank 0 only."""
+        import torch
+        rows = np.ascontiguousarray(rows)
+        counts = torch.zeros(self.world, dtype=torch.int64)
+        counts[self.rank] = rows.shape[0]
+        self._dist.all_reduce(counts)
+        width = int(np.prod(rows.shape[1:], dtype=np.int64))
+        most = int(counts.max())
+        mine = torch.zeros((most, width), dtype=torch.from_numpy(rows.reshape(rows.shape[0], width)).dtype)
+        mine[:rows.shape[0]] = torch.from_numpy(rows.reshape(rows.shape[0], width))
+        if everywhere:
+            parts = [torch.empty_like(mine) for _ in range(self.world)]
+            self._dist.all_gather(parts, mine)
+        else:
+            parts = [torch.empty_like(mine) for _ in range(self.world)] if self.rank == 0 else None
+            self._dist.gather(mine, parts, dst=0)
+            if self.rank != 0:
+                return None
+        whole = np.concatenate([p.numpy()[:int(n)] for p, n in zip(parts, counts)], axis=0)
+        return whole.reshape((whole.shape[0],) + rows.shape[1:])
+
     def gather_rows(self, rows):
-        """Rows of every rank, concatenated in rank order (= barcode order), on every rank."""
-        parts = [None] * self.world
-        self._dist.all_gather_object(parts, np.ascontiguousarray(rows))
-        return np.concatenate(parts, axis=0)
+        return self._gather(rows, True)
+
+    def gather_to_root(self, rows):
+        return self._gather(rows, False)
 
     def barrier(self):
         self._dist.barrier()
@@ -207,78 +247,275 @@ def attach_communicator(ctx, plane, reduce_dtype='f64', force=False):
 # ---------------------------------------------------------------------------------------------------------
 # the Demultiplexer entry points, sharded
 # ---------------------------------------------------------------------------------------------------------
+def _agree(plane, error):
+    """Every rank reports whether its local step worked; a failure anywhere raises on EVERY rank (instead of one rank
+    raising and the others waiting in the next collective for ever)."""
+    all_ok = getattr(plane, 'all_ok', None)
+    if all_ok is None:  # a plane without the status exchange (older duck-typed planes): local behaviour
+        if error is not None:
+            raise error
+        return
+    ok, message = all_ok(error is None, '' if error is None else f'{type(error).__name__}: {error}')
+    if error is not None:
+        raise error
+    if not ok:
+        raise RuntimeError(f'a rank of the sharded run failed: {message}')
+
+
 def _install_shard(chromosome2compressed_snp_calls, genotypes, barcode_handler, plane, add_data_prior, device,
-                   reduce_dtype, context_factory, force_comm):
+                   reduce_dtype, context_factory, force_comm, with_communicator=True, keep_molecule_calls=False):
     """Packs this rank's barcodes on its GPU and installs the regularised prior (whose data term needs the
-    molecule counts of ALL ranks, demux.py:381-384).  Returns (ctx, lo, hi)."""
+    molecule counts of ALL ranks, demux.py:381-384).  Returns (ctx, lo, hi).
+    The ranks agree twice before anybody enters a collective that a failed rank would never join: after the set-up,
+    and after the device pack (where e.g. calls on a chromosome without variants assert, on the one shard that holds
+    them)."""
     from .demux import _pack_on_device
     from .device import DeviceContext, default_device
     n_barcodes = barcode_handler.n_barcodes
     bounds = partition_barcodes(calls_per_barcode(chromosome2compressed_snp_calls, n_barcodes), plane.world)
     lo, hi = int(bounds[plane.rank]), int(bounds[plane.rank + 1])
-    shard = shard_containers(chromosome2compressed_snp_calls, lo, hi) if plane.world > 1 else chromosome2compressed_snp_calls
-    ctx = (context_factory or DeviceContext)(default_device() if device is None else device)
+    ctx, shard, error = None, None, None
     try:
-        attach_communicator(ctx, plane, reduce_dtype, force_comm)
-        _pack_on_device(shard, genotypes, hi - lo, add_data_prior, fetch_betas=False, ctx=ctx,
-                        reduce_molecule_counts=plane.sum_int64 if plane.world > 1 else None)
+        shard = shard_containers(chromosome2compressed_snp_calls, lo, hi) if plane.world > 1 else chromosome2compressed_snp_calls
+        ctx = (context_factory or DeviceContext)(default_device() if device is None else device)
+        if keep_molecule_calls:
+            ctx.set_keep_molecule_calls(True)
+    except Exception as exc:  # noqa: BLE001 - reported to every rank
+        error = exc
+    try:
+        _agree(plane, error)
+        if with_communicator:
+            attach_communicator(ctx, plane, reduce_dtype, force_comm)
+        agreed = []
+
+        def reduce_counts(molecules):  # called by the pack between the device pack and the prior
+            agreed.append(True)
+            _agree(plane, None)
+            return plane.sum_int64(molecules)
+        share_counts = plane.world > 1 and add_data_prior
+        try:
+            _pack_on_device(shard, genotypes, hi - lo, add_data_prior, fetch_betas=False, ctx=ctx,
+                            reduce_molecule_counts=reduce_counts if share_counts else None)
+        except Exception as exc:  # noqa: BLE001
+            if not agreed:
+                _agree(plane, exc)  # tells the others, then raises exc
+            raise
+        if not share_counts:
+            _agree(plane, None)
     except BaseException:
-        ctx.close()
+        if ctx is not None:
+            ctx.close()
         raise
     return ctx, lo, hi
 
 
+class ShardedPosteriors:
+    """This rank's rows of a sharded run's posteriors, on its GPU, plus the plane: the reductions users apply to the
+    [B, K] matrix come back for ALL barcodes while only O(B) / O(K) numbers travel.  Every method is a collective
+    (all ranks call it).  `local` is the rank's own DevicePosteriors (rows [lo, hi) of the experiment)."""
+
+    def __init__(self, local, plane, lo, hi, barcodes):
+        self.local, self.plane, self.lo, self.hi = local, plane, lo, hi
+        self.barcodes = list(barcodes)
+        self.columns = local.columns
+
+    @property
+    def shape(self):
+        return len(self.barcodes), len(self.columns)
+
+    def _index(self, rows=None):
+        index = pd.Index(self.barcodes if rows is None else [self.barcodes[i] for i in rows])
+        index.name = self.local.index_name
+        return index
+
+    def best(self) -> pd.DataFrame:
+        best, prob = self.local._ctx.get_assignments()
+        best = self.plane.gather_rows(best.astype(np.int32))
+        prob = self.plane.gather_rows(prob.astype(np.float32))
+        return pd.DataFrame({'option': np.asarray(self.columns, dtype=object)[best], 'probability': prob}, index=self._index())
+
+    def assignments(self, threshold=0.9) -> pd.Series:
+        """probs[probs.max(axis=1).gt(threshold)].idxmax(axis=1) over all barcodes (snp_detection.py:166)."""
+        best, _prob, _n = self.local._ctx.get_assignments_above(threshold)
+        best = self.plane.gather_rows(best.astype(np.int32))
+        rows = np.flatnonzero(best >= 0)
+        return pd.Series(np.asarray(self.columns, dtype=object)[best[rows]], index=self._index(rows))
+
+    def option_sums(self) -> pd.Series:
+        """probs.sum(axis=0) over all barcodes (float64; rank partial sums added in rank order)."""
+        sums = self.plane.gather_rows(np.asarray(self.local._ctx.get_option_sums(), dtype=np.float64)[None, :])
+        total = sums[0].copy()
+        for part in sums[1:]:
+            total += part
+        return pd.Series(total, index=self.columns)
+
+    def to_dataframe(self, what='probs', root_only=True):
+        """The whole matrix after all: on rank 0 (others None), or on every rank."""
+        block = self.local._ctx.get_probs() if what == 'probs' else self.local._ctx.get_logits()
+        gather = getattr(self.plane, 'gather_to_root', None) if root_only else None
+        whole = gather(block) if gather is not None else self.plane.gather_rows(block)
+        if whole is None:
+            return None
+        return pd.DataFrame(whole, index=self._index(), columns=self.columns)
+
+    def close(self):
+        self.local.close()
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+
+def _collect(plane, block, results):
+    """`block` (this rank's rows) -> all rows on every rank ('all') or on rank 0 ('root': others None)."""
+    assert results in ('all', 'root')
+    if results == 'root' and getattr(plane, 'gather_to_root', None) is not None:
+        return plane.gather_to_root(block)
+    return plane.gather_rows(block)
+
+
 def learn_genotypes(chromosome2compressed_snp_calls, genotypes, barcode_handler, plane, n_iterations=5,
                     p_genotype_clip=0.01, doublet_prior=0., barcode_prior_logits=None, device=None,
-                    reduce_dtype='f64', context_factory=None, force_comm=False):
+                    reduce_dtype='f64', context_factory=None, force_comm=False, results='all'):
     """Demultiplexer.learn_genotypes (demux.py:35-66) over the ranks of `plane`: every rank passes the SAME
-    inputs (whole experiment), works on its barcode range, and gets back the same learnt genotypes and the
-    posterior DataFrame of ALL barcodes."""
-    from .demux import Demultiplexer, _option_names
+    inputs (whole experiment), works on its barcode range, and gets back the same learnt genotypes and - see
+    `results` in the module docstring - the posterior DataFrame of ALL barcodes / None / a ShardedPosteriors.
+    Every rank must pass the same arguments (the calls inside are collectives)."""
+    from .demux import Demultiplexer, DevicePosteriors, _option_names
     assert 0 <= doublet_prior < 1
+    assert results in ('all', 'root', 'device')
     penalties = Demultiplexer._doublet_penalties(genotypes.n_genotypes, doublet_prior)
     if barcode_prior_logits is not None:
         assert barcode_prior_logits.shape == (barcode_handler.n_barcodes, len(penalties)), 'wrong shape of priors'
     assert n_iterations >= 1, 'n_iterations should be positive'
+    columns = _option_names(genotypes.genotype_names, doublet_prior)
+    if Demultiplexer.aggregate_on_snps:  # the staged loop is the implementation (float64 posteriors)
+        assert results != 'device', 'device-resident results are float32; aggregate_on_snps yields float64 posteriors'
+        *_, (probs_df, last) = staged_genotype_learning(
+            chromosome2compressed_snp_calls, genotypes, barcode_handler, plane, n_iterations=n_iterations,
+            p_genotype_clip=p_genotype_clip, doublet_prior=doublet_prior, barcode_prior_logits=barcode_prior_logits,
+            device=device, reduce_dtype=reduce_dtype, context_factory=context_factory, force_comm=force_comm, results=results)
+        return genotypes._with_betas(genotypes.get_betas() + last['genotype_addition']), probs_df
     ctx, lo, hi = _install_shard(chromosome2compressed_snp_calls, genotypes, barcode_handler, plane, True, device,
                                  reduce_dtype, context_factory, force_comm)
+    keep = results == 'device'
     try:
         prior = None if barcode_prior_logits is None else np.ascontiguousarray(barcode_prior_logits[lo:hi])
         _logits, probs, addition = ctx.em(
             n_iterations, p_genotype_clip, penalties, with_doublets=doublet_prior != 0, prior_logits=prior,
-            contribution_power=Demultiplexer.contribution_power, fetch_logits=False)
+            contribution_power=Demultiplexer.contribution_power, fetch_logits=False, fetch_probs=not keep)
+    except BaseException:
+        keep = False
+        raise
+    finally:
+        if not keep:
+            ctx.close()
+    learnt = genotypes._with_betas(genotypes.get_betas() + addition)
+    if results == 'device':
+        local = DevicePosteriors(ctx, barcode_handler.ordered_barcodes[lo:hi], columns)
+        return learnt, ShardedPosteriors(local, plane, lo, hi, barcode_handler.ordered_barcodes)
+    probs = _collect(plane, probs, results)
+    probs_df = None if probs is None else pd.DataFrame(data=probs, index=barcode_handler.ordered_barcodes, columns=columns)
+    return learnt, probs_df
+
+
+def staged_genotype_learning(chromosome2compressed_snp_calls, genotypes, barcode_handler, plane, n_iterations=5,
+                             p_genotype_clip=0.01, doublet_prior=0., barcode_prior_logits=None, device=None,
+                             reduce_dtype='f64', context_factory=None, force_comm=False, results='all'):
+    """Demultiplexer.staged_genotype_learning (demux.py:69-118) over the ranks of `plane`: a generator yielding, per
+    EM iteration, (posterior DataFrame of all barcodes, {'barcode_logits', 'genotype_prior', 'genotype_addition'}),
+    the addition being the one the iteration's E-step used.  Every rank iterates the generator in step (each iteration
+    runs the exchange).  results = 'root': the frames / logits only on rank 0 (None elsewhere).
+    Honours Demultiplexer.aggregate_on_snps (demux.py:204-244): the float64 partial sums of the ranks are added in rank
+    order through the plane (they are [V, G] float64: the wire format of the exchange)."""
+    from .demux import Demultiplexer, _option_names
+    assert 0 <= doublet_prior < 1
+    assert results in ('all', 'root')
+    penalties = Demultiplexer._doublet_penalties(genotypes.n_genotypes, doublet_prior)
+    if barcode_prior_logits is not None:
+        assert barcode_prior_logits.shape == (barcode_handler.n_barcodes, len(penalties)), 'wrong shape of priors'
+    aggregate = bool(Demultiplexer.aggregate_on_snps)
+    columns = _option_names(genotypes.genotype_names, doublet_prior)
+    # aggregate mode: the float64 M-step is single-context; its [V, G] result is summed over ranks on the host
+    ctx, lo, hi = _install_shard(chromosome2compressed_snp_calls, genotypes, barcode_handler, plane, True, device,
+                                 reduce_dtype, context_factory, force_comm, with_communicator=not aggregate,
+                                 keep_molecule_calls=aggregate)
+    try:
+        prior_betas = ctx.get_prior_betas() if hasattr(ctx, 'get_prior_betas') else None
+        addition = None if prior_betas is None else np.zeros_like(prior_betas)
+        ctx.set_addition(None)
+        local_prior = None if barcode_prior_logits is None else np.ascontiguousarray(barcode_prior_logits[lo:hi])
+        for iteration in range(n_iterations):
+            ctx.probs_from_betas(p_genotype_clip, fetch=False)
+            prior = local_prior if iteration == 0 else None
+            if aggregate:
+                logits, probs = ctx.estep_snp(doublet_prior != 0, Demultiplexer.compensation_during_computing_barcode_logits,
+                                              prior_logits=prior)
+            else:
+                logits, probs = ctx.estep(penalties, with_doublets=doublet_prior != 0, prior_logits=prior)
+            all_probs, all_logits = _collect(plane, probs, results), _collect(plane, logits, results)
+            frame = None if all_probs is None else pd.DataFrame(data=all_probs, index=barcode_handler.ordered_barcodes, columns=columns)
+            yield frame, {'barcode_logits': all_logits, 'genotype_prior': prior_betas, 'genotype_addition': addition}
+            if aggregate:
+                partial = ctx.mstep_f64(Demultiplexer.contribution_power, as_float64=True)
+                total = sum_float64(plane, partial)
+                addition = total.astype(np.float32)
+                ctx.set_addition(addition)
+            else:
+                addition = ctx.mstep(Demultiplexer.contribution_power)  # the exchange + the full addition on every rank
     finally:
         ctx.close()
-    probs = plane.gather_rows(probs)
-    probs_df = pd.DataFrame(data=probs, index=barcode_handler.ordered_barcodes,
-                            columns=_option_names(genotypes.genotype_names, doublet_prior))
-    return genotypes._with_betas(genotypes.get_betas() + addition), probs_df
+
+
+def sum_float64(plane, array):
+    """Sum over ranks of a float64 array, added in rank order on every rank (deterministic)."""
+    if plane.world == 1:
+        return np.asarray(array, dtype=np.float64)
+    parts = plane.gather_rows(np.ascontiguousarray(array, dtype=np.float64).reshape(1, -1))
+    total = parts[0].copy()
+    for part in parts[1:]:
+        total += part
+    return total.reshape(np.shape(array))
 
 
 def predict_posteriors(chromosome2compressed_snp_calls, genotypes, barcode_handler, plane, p_genotype_clip=0.01,
-                       doublet_prior=0.35, device=None, context_factory=None):
+                       doublet_prior=0.35, device=None, context_factory=None, results='all'):
     """Demultiplexer.predict_posteriors (demux.py:120-156) over the ranks of `plane`; needs no data-plane
-    collective at all (rows are independent, the P-step is replicated)."""
-    from .demux import Demultiplexer, _option_names
-    from .device import DeviceContext, default_device
-    from .demux import _pack_on_device
+    collective at all (rows are independent, the P-step is replicated).  `results`: module docstring; 'device'
+    returns ONE ShardedPosteriors."""
+    from .demux import Demultiplexer, DevicePosteriors, _option_names
+    assert results in ('all', 'root', 'device')
     penalties = Demultiplexer._doublet_penalties(genotypes.n_genotypes, doublet_prior)
-    n_barcodes = barcode_handler.n_barcodes
-    bounds = partition_barcodes(calls_per_barcode(chromosome2compressed_snp_calls, n_barcodes), plane.world)
-    lo, hi = int(bounds[plane.rank]), int(bounds[plane.rank + 1])
-    shard = shard_containers(chromosome2compressed_snp_calls, lo, hi) if plane.world > 1 else chromosome2compressed_snp_calls
-    ctx = (context_factory or DeviceContext)(default_device() if device is None else device)
+    aggregate = bool(Demultiplexer.aggregate_on_snps)
+    assert not (aggregate and results == 'device'), 'device-resident results are float32; aggregate_on_snps yields float64'
+    ctx, lo, hi = _install_shard(chromosome2compressed_snp_calls, genotypes, barcode_handler, plane, False, device,
+                                 'f64', context_factory, False, with_communicator=False, keep_molecule_calls=aggregate)
+    keep = results == 'device'
     try:
-        _pack_on_device(shard, genotypes, hi - lo, False, fetch_betas=False, ctx=ctx)
         ctx.set_addition(None)
         genotype_prob = ctx.probs_from_betas(p_genotype_clip)
         assert np.isfinite(genotype_prob).all()
-        logits, probs = ctx.estep(penalties, with_doublets=doublet_prior != 0)
+        if aggregate:
+            logits, probs = ctx.estep_snp(doublet_prior != 0, Demultiplexer.compensation_during_computing_barcode_logits)
+        else:
+            logits, probs = ctx.estep(penalties, with_doublets=doublet_prior != 0, fetch_logits=not keep, fetch_probs=not keep)
+    except BaseException:
+        keep = False
+        raise
     finally:
-        ctx.close()
+        if not keep:
+            ctx.close()
     columns = _option_names(genotypes.genotype_names, doublet_prior)
+    if results == 'device':
+        local = DevicePosteriors(ctx, barcode_handler.ordered_barcodes[lo:hi], columns, index_name='BARCODE')
+        return ShardedPosteriors(local, plane, lo, hi, barcode_handler.ordered_barcodes)
     frames = []
-    for block in (plane.gather_rows(logits), plane.gather_rows(probs)):
+    for block in (_collect(plane, logits, results), _collect(plane, probs, results)):
+        if block is None:
+            frames.append(None)
+            continue
         frame = pd.DataFrame(data=block, index=list(barcode_handler.ordered_barcodes), columns=columns)
         frame.index.name = 'BARCODE'
         frames.append(frame)

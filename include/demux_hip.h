@@ -192,6 +192,9 @@ int dmx_get_estep_form(dmx_ctx *ctx, int32_t *form, int32_t *distinct_values);
  * largest problems run, selectable so that it can be exercised at any size.  Results are bit-identical. */
 int dmx_set_mstep_wide_addresses(dmx_ctx *ctx, int wide);
 
+/* The prior betas resident on the device (as set by dmx_set_betas or computed by dmx_set_prior_betas), float32[V*G]. */
+int dmx_get_prior_betas(dmx_ctx *ctx, float *out);
+
 /* genotype_addition float32[V*G]; NULL resets it to zero (demux.py:86). */
 int dmx_set_addition(dmx_ctx *ctx, const float *addition);
 
@@ -300,6 +303,10 @@ int dmx_get_max_pair_count(dmx_ctx *ctx, int64_t *max_count);
 int dmx_estep_snp(dmx_ctx *ctx, int with_doublets, const double *count_pow, int64_t n_count_pow,
                   const void *prior_logits, int prior_dtype, double *logits_out, double *probs_out);
 int dmx_mstep_f64(dmx_ctx *ctx, double contribution_power, float *addition_out);
+/* The same M-step, returning the UNROUNDED float64 sums float64[V*G] (np.bincount's result before the float32 store,
+ * utils.py:35-36): a barcode-sharded aggregate_on_snps run adds the ranks' sums on the host and rounds once
+ * (demuxalot_amd/distributed.py: staged_genotype_learning). */
+int dmx_mstep_f64_sums(dmx_ctx *ctx, double contribution_power, double *sums_out);
 
 /* ------------------------------------------------------------------------- *
  * Multi-GPU: one ctx per rank, barcodes sharded by the caller (every rank holds the calls of its barcodes, all
@@ -317,6 +324,14 @@ int dmx_mstep_f64(dmx_ctx *ctx, double contribution_power, float *addition_out);
  * Collective calls -- every rank must make them, in the same order: dmx_probs_from_betas, dmx_mstep (all ranks
  * pass addition_out or none does), dmx_em, dmx_run_iterations, dmx_get_addition.
  * ------------------------------------------------------------------------- */
+/* Which HIP / RCCL runtime files this process has mapped, one "key=path" per line: hip=... (one line per distinct
+ * libamdhip64 - exactly one in a healthy process), rccl_mapped=..., rccl_loaded=<the file dmx_comm_* bound, if any>.
+ * RCCL is always taken from the directory of the HIP runtime libdemux_hip.so itself resolved, and dmx_comm_unique_id /
+ * dmx_comm_init refuse a process that has two HIP runtimes mapped (e.g. one that imported torch): streams and
+ * buffers of one runtime must not be handed to collectives of another.  Environment: DEMUXALOT_AMD_RCCL=<file>,
+ * DEMUXALOT_AMD_ALLOW_FOREIGN_RCCL=1. */
+int dmx_runtime_info(char *out, int64_t capacity);
+
 /* Host only: the variant slices dmx_comm_init would cut for nranks ranks: cuts int64[nranks + 1] (first variant of
  * every slice, each at the first variant of a SNP), *slice_rows = rows of the longest slice (nullable),
  * *contiguous = 1 when every SNP's variants are contiguous in the numbering (nullable). */

@@ -33,7 +33,9 @@ def random_calls(rng, n_barcodes, n_rows, mean_calls):
 
 
 def run_estep(ctx, table, pen, doublets, mode):
-    ctx.set_estep_dictionary(mode)
+    # 'auto' would pass these small problems to the direct form (the dictionary form pays from a few rounds of
+    # wavefronts on): 'always' tries it for every table
+    ctx.set_estep_dictionary('always' if mode == 'auto' else mode)
     ctx.set_probs(table)
     logits, probs = ctx.estep(pen, with_doublets=doublets)
     return logits, probs, ctx.estep_form()
@@ -41,7 +43,8 @@ def run_estep(ctx, table, pen, doublets, mode):
 
 @pytest.mark.parametrize('n_genotypes,doublet_prior,n_values', [
     (2, 0., 2), (5, 0., 3), (8, 0.35, 3), (8, 0.35, 4), (20, 0., 4), (20, 0.25, 4), (22, 0.25, 2), (33, 0., 8),
-    (64, 0., 4), (64, 0., 8), (64, 0., 1), (70, 0., 5), (130, 0., 4), (130, 0., 7), (300, 0., 3), (600, 0., 8)])
+    (64, 0., 4), (64, 0., 8), (64, 0., 1), (70, 0., 5), (130, 0., 4), (130, 0., 7), (256, 0., 3), (3, 0., 3), (4, 0.3, 2),
+    (16, 0., 8), (17, 0., 2), (32, 0., 4), (129, 0., 8)])
 def test_dictionary_form_equals_direct_form(oracle, n_genotypes, doublet_prior, n_values):
     from demuxalot_amd import Demultiplexer
     from demuxalot_amd.device import DeviceContext
@@ -70,21 +73,23 @@ def test_dictionary_form_equals_direct_form(oracle, n_genotypes, doublet_prior, 
 
 
 @pytest.mark.parametrize('n_genotypes,doublet_prior,n_values,why', [
-    (64, 0., 9, 'nine values in a row'), (12, 0.3, 5, 'five values with doublets'), (64, 0., 64, 'all distinct')])
+    (64, 0., 9, 'nine values in a row'), (12, 0.3, 5, 'five values with doublets'), (64, 0., 64, 'all distinct'),
+    (300, 0., 3, 'more than 256 options'), (30, 0.2, 3, 'more than 256 options (doublets)')])
 def test_rows_with_many_values_take_the_direct_form(n_genotypes, doublet_prior, n_values, why):
     from demuxalot_amd import Demultiplexer
     from demuxalot_amd.device import DeviceContext
     rng = np.random.default_rng(5)
     variant, cb, e = random_calls(rng, 300, 400, 30)
     table = low_cardinality_table(rng, 400, n_genotypes, min(n_values, 8))
-    table[7, :n_values] = np.linspace(0.1, 0.9, n_values, dtype=np.float32)  # ONE row beyond the capacity
+    if 'options' not in why:
+        table[7, :n_values] = np.linspace(0.1, 0.9, n_values, dtype=np.float32)  # ONE row beyond the capacity
     pen = Demultiplexer._doublet_penalties(n_genotypes, doublet_prior)
     ctx = DeviceContext(0)
     try:
         ctx.set_problem(300, 400, n_genotypes, variant, cb, e, np.arange(400, dtype=np.int32))
         l_dir, p_dir, _ = run_estep(ctx, table, pen, doublet_prior != 0, 'never')
         l_try, p_try, form = run_estep(ctx, table, pen, doublet_prior != 0, 'always')
-        assert form[0] == 'direct' and form[1] >= min(n_values, 9), (why, form)
+        assert form[0] == 'direct' and ('options' in why or form[1] >= min(n_values, 9)), (why, form)
         fio.assert_bitwise(l_try, l_dir, why)
         fio.assert_bitwise(p_try, p_dir, why)
     finally:
@@ -93,27 +98,38 @@ def test_rows_with_many_values_take_the_direct_form(n_genotypes, doublet_prior, 
 
 @pytest.mark.parametrize('name,expect', [('f1_synthetic_default.npz', 'dict'), ('f2_synthetic_g4.npz', 'dict'),
                                          ('f6_shipped_example.npz', 'dict'), ('f3_small_4.npz', 'direct')])
-def test_reference_fixtures_take_the_expected_form(name, expect):
-    """predict_posteriors and EM iteration 0 on the reference's own test inputs run the dictionary form (their rows
-    hold 2-3 distinct values), later iterations the direct form; the outputs are the reference's, bit for bit."""
+def test_reference_fixtures_through_the_dictionary_form(name, expect, monkeypatch):
+    """predict_posteriors and EM on the reference's own test inputs with the dictionary form tried for every E-step
+    (DEMUXALOT_AMD_ESTEP_DICT=always; by default problems this small take the direct form): their rows hold 2-3 distinct
+    values, so predict and EM iteration 0 run the form; the outputs are the reference's, bit for bit."""
     from demuxalot_amd import Demultiplexer
     from demuxalot_amd.device import get_context
-    fx = fio.load(name)
-    calls, genotypes, handler = fio.product_inputs(fx)
-    for i in range(int(fx['n_predict'])):
-        dp, clip = float(fx[f'predict{i}_dp']), float(fx[f'predict{i}_clip'])
-        logits_df, probs_df = Demultiplexer.predict_posteriors(calls, genotypes, handler, p_genotype_clip=clip, doublet_prior=dp)
-        form, distinct = get_context().estep_form()
-        assert form == expect, (name, dp, form, distinct)
-        fio.assert_bitwise(logits_df.values, fx[f'predict{i}_logits'], f'{name} predict {i} logits')
-        fio.assert_bitwise(probs_df.values, fx[f'predict{i}_probs'], f'{name} predict {i} probs')
-    stages = Demultiplexer.staged_genotype_learning(calls, genotypes, handler, n_iterations=2)
-    seen = []
-    for it, (probs_df, dbg) in enumerate(stages):
-        # the generator's private context is not reachable from here; the outputs are what is pinned
-        fio.assert_bitwise(probs_df.values, fx[f'em0_it{it}_probs'], f'{name} EM it {it}')
-        seen.append(it)
-    assert seen == [0, 1]
+    monkeypatch.setenv('DEMUXALOT_AMD_ESTEP_DICT', 'always')  # read by every new context (the generator's private one)
+    ctx = get_context()
+    ctx.set_estep_dictionary('always')
+    try:
+        fx = fio.load(name)
+        calls, genotypes, handler = fio.product_inputs(fx)
+        for i in range(int(fx['n_predict'])):
+            dp, clip = float(fx[f'predict{i}_dp']), float(fx[f'predict{i}_clip'])
+            logits_df, probs_df = Demultiplexer.predict_posteriors(calls, genotypes, handler, p_genotype_clip=clip, doublet_prior=dp)
+            form, distinct = ctx.estep_form()
+            wide = logits_df.shape[1] > 256
+            assert form == ('direct' if wide else expect), (name, dp, form, distinct)
+            fio.assert_bitwise(logits_df.values, fx[f'predict{i}_logits'], f'{name} predict {i} logits')
+            fio.assert_bitwise(probs_df.values, fx[f'predict{i}_probs'], f'{name} predict {i} probs')
+        for i in range(int(fx['n_em'])):
+            kwargs = dict(n_iterations=int(fx[f'em{i}_n_iterations']), p_genotype_clip=float(fx[f'em{i}_clip']),
+                          doublet_prior=float(fx[f'em{i}_dp']))
+            prior = fx.get(f'em{i}_prior_logits')
+            stages = Demultiplexer.staged_genotype_learning(
+                calls, genotypes, handler, barcode_prior_logits=None if prior is None else prior.copy(), **kwargs)
+            for it, (probs_df, dbg) in enumerate(stages):
+                fio.assert_bitwise(dbg['barcode_logits'], fx[f'em{i}_it{it}_logits'], f'{name} EM {i} it {it} logits')
+                fio.assert_bitwise(probs_df.values, fx[f'em{i}_it{it}_probs'], f'{name} EM {i} it {it} probs')
+                fio.assert_bitwise(dbg['genotype_addition'], fx[f'em{i}_it{it}_addition'], f'{name} EM {i} it {it} addition')
+    finally:
+        ctx.set_estep_dictionary('auto')
 
 
 def test_em_driver_switches_forms_between_iterations(oracle):
@@ -127,7 +143,7 @@ def test_em_driver_switches_forms_between_iterations(oracle):
     for mode in ('never', 'auto'):
         ctx = DeviceContext(0)
         try:
-            ctx.set_estep_dictionary(mode)
+            ctx.set_estep_dictionary('always' if mode == 'auto' else mode)
             ctx.set_problem(p.n_barcodes, p.n_variants, 16, p.variant_id, p.compressed_cb, p.p_base_wrong, p.v2snp)
             ctx.set_betas(p.prior_betas())
             _, probs1, add1 = ctx.em(1, 0.01, pen, with_doublets=False, fetch_logits=False)
@@ -155,7 +171,7 @@ def test_headline_shape_predict_dictionary_vs_direct():
         ctx.set_problem(p.n_barcodes, p.n_variants, 64, p.variant_id, p.compressed_cb, p.p_base_wrong, p.v2snp)
         ctx.set_betas(p.prior_betas(add_data_prior=False))
         got = {}
-        for mode in ('never', 'auto'):
+        for mode in ('never', 'auto'):  # 200k barcodes: the default mode takes the form by itself
             ctx.set_estep_dictionary(mode)
             ctx.set_addition(None)
             ctx.probs_from_betas(0.01, fetch=False)

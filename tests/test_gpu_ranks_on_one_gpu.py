@@ -89,14 +89,11 @@ def test_sharded_em_equals_the_single_context_run(world, reduce_dtype):
     assert ('reduce_scatter', 'float64' if reduce_dtype == 'f64' else 'float32') in kinds and ('all_gather', 'float32') in kinds
 
 
-def _gloo_rank(rank, world, port, out):
-    import os
-    import torch.distributed as dist
-    from demuxalot_amd import distributed
-    os.environ['MASTER_ADDR'], os.environ['MASTER_PORT'] = '127.0.0.1', str(port)
-    dist.init_process_group('gloo', rank=rank, world_size=world)
+def _socket_rank(rank, world, port, out):
+    from demuxalot_amd import _lib, distributed
+    from demuxalot_amd.plane import SocketControlPlane
+    plane = SocketControlPlane(rank, world, '127.0.0.1', port=port, host_collectives=True)  # the exchange over sockets, no RCCL
     try:
-        plane = distributed.TorchControlPlane(host_collectives=True)  # the exchange over gloo, no RCCL
         report = {}
         for name in ('f2_synthetic_g4.npz', 'f3_small_3.npz'):
             fx = fio.load(name)
@@ -109,27 +106,31 @@ def _gloo_rank(rank, world, port, out):
             report[name] = (bool(np.allclose(learnt.variant_betas, fx['em0_learnt_betas'], rtol=3e-7, atol=0)),
                             bool(np.array_equal(probs_df.values.argmax(1), want.argmax(1))),
                             float(np.abs(probs_df.values - want).max()))
+        report['hip_runtimes'] = _lib.runtime_info()['hip']
         out.put((rank, report))
     finally:
-        dist.destroy_process_group()
+        plane.close()
 
 
-def test_two_processes_one_gpu_exchange_over_gloo():
-    """Two PROCESSES on the one GPU, the per-iteration exchange carried by gloo through the caller-provided-collectives
-    entry (TorchControlPlane(host_collectives=True)): the sharded learn_genotypes against the reference's outputs."""
+def test_two_processes_one_gpu_exchange_over_the_socket_plane():
+    """Two PROCESSES on the one GPU, control plane AND per-iteration exchange carried by the torch-free socket plane
+    (demuxalot_amd/plane.py, through the caller-provided-collectives entry): the sharded learn_genotypes against the
+    reference's outputs, and exactly one HIP runtime mapped in each worker."""
+    import multiprocessing as mp
     import socket
-    import torch.multiprocessing as mp
     with socket.socket() as s:
         s.bind(('127.0.0.1', 0))
         port = s.getsockname()[1]
     ctx = mp.get_context('spawn')
     out = ctx.Queue()
-    procs = [ctx.Process(target=_gloo_rank, args=(r, 2, port, out)) for r in range(2)]
+    procs = [ctx.Process(target=_socket_rank, args=(r, 2, port, out)) for r in range(2)]
     for pr in procs:
         pr.start()
+    reports = [out.get(timeout=600) for _ in range(2)]
     for pr in procs:
-        pr.join(timeout=600)
+        pr.join(timeout=60)
         assert pr.exitcode == 0
-    for _rank, report in (out.get(timeout=10) for _ in range(2)):
+    for _rank, report in reports:
+        assert len(report.pop('hip_runtimes')) == 1
         for name, (betas_close, argmax_same, max_dev) in report.items():
             assert betas_close and argmax_same and max_dev <= 1e-5, (name, betas_close, argmax_same, max_dev)
