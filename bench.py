@@ -144,8 +144,11 @@ def live_traffic(args, kernel):
     import tempfile
     if shutil.which('rocprofv3') is None:
         return None
+    # never nest profilers: a bench run that is itself under rocprofv3 (or any LD_PRELOAD tool) keeps to the committed figures
+    if os.environ.get('LD_PRELOAD') or any(k.startswith(('ROCP_', 'ROCPROF')) for k in os.environ):
+        return None
     out_dir = tempfile.mkdtemp(prefix='bench_pmc_', dir='/tmp')
-    child = ['python3', os.path.join(ROOT, 'bench.py'), '--workload', args.workload, '--steps', '2', '--warmup', '1',
+    child = [sys.executable, os.path.join(ROOT, 'bench.py'), '--workload', args.workload, '--steps', '2', '--warmup', '1',
              '--no-cpu-baseline', '--no-fast-mode', '--no-live-traffic'] + (['--flat-genotypes'] if args.flat_genotypes else [])
     env = dict(os.environ, TMPDIR='/tmp')
     total = 0.0
@@ -159,7 +162,7 @@ def live_traffic(args, kernel):
                 for row in csv.DictReader(open(path)):
                     if kernel in row['Kernel_Name'] and row['Counter_Name'] == counter:
                         values.append(float(row['Counter_Value']))
-            if not values:
+            if not values:  # e.g. another E-step kernel ran (DEMUXALOT_AMD_ESTEP_SCHEDULE=tiled): no figure rather than a wrong one
                 return None
             total += 1024.0 * sum(values) / len(values)
         return total
@@ -193,6 +196,9 @@ def main():
                          'is used); the additions are then equal for all genotypes, so the posteriors stay uniform iteration after iteration')
     ap.add_argument('--force-dist', action='store_true',
                     help='testing aid: run the multi-rank control/collective path even with one rank')
+    ap.add_argument('--host-plane', action='store_true',
+                    help='the per-iteration exchange staged through host memory over the control plane instead of RCCL '
+                         '(dmx_comm_init_host): several ranks on ONE GPU, hosts without a usable RCCL fabric')
     args = ap.parse_args()
 
     # gloo and RCCL print banners on stdout; stdout must carry the one JSON line only, so fd 1 is pointed
@@ -206,15 +212,15 @@ def main():
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
     assert world == args.gpus, f'--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run'
 
-    dist = None
+    # Control plane (rendezvous, RCCL unique id, barrier, max-reduce of the wall time): plain sockets
+    # (demuxalot_amd/plane.py).  torch.distributed.run is only the LAUNCHER: the workers never import torch, whose
+    # ROCm wheels carry their own libamdhip64 / librccl - two HIP runtimes in one process is what the library refuses.
+    # The data-plane collectives are RCCL inside libdemux_hip.so (or, with --host-plane, staged through the plane).
+    plane = None
     use_dist = world > 1 or args.force_dist
     if use_dist:
-        # control plane only (rendezvous, barrier, max-reduce of the wall time) over gloo;
-        # the data-plane collective is RCCL inside libdemux_hip.so
-        import torch.distributed as dist
-        if 'MASTER_ADDR' not in os.environ:  # --force-dist without a launcher
-            os.environ['MASTER_ADDR'], os.environ['MASTER_PORT'] = '127.0.0.1', '29533'
-        dist.init_process_group('gloo', rank=rank, world_size=world)
+        from demuxalot_amd.plane import SocketControlPlane
+        plane = SocketControlPlane(rank, world, os.environ.get('MASTER_ADDR', '127.0.0.1'), host_collectives=args.host_plane)
 
     from demuxalot_amd import Demultiplexer, synth
     from demuxalot_amd.device import DeviceContext
@@ -244,10 +250,17 @@ def main():
     K = len(pen)
 
     ctx = DeviceContext(local_rank % max(1, _lib_device_count()))
+    runtimes = None
+    if use_dist and args.host_plane:
+        ctx.comm_init_host(rank, world, plane.host_collective, reduce_dtype=args.reduce_dtype)
+    elif use_dist:
+        unique_id = plane.broadcast_bytes(DeviceContext.new_unique_id() if rank == 0 else None)
+        ctx.comm_init(rank, world, unique_id, reduce_dtype=args.reduce_dtype)
     if use_dist:
-        ids = [DeviceContext.new_unique_id() if rank == 0 else None]
-        dist.broadcast_object_list(ids, src=0)
-        ctx.comm_init(rank, world, ids[0], reduce_dtype=args.reduce_dtype)
+        from demuxalot_amd import _lib
+        runtimes = _lib.runtime_info()
+        assert len(runtimes['hip']) == 1, f'more than one HIP runtime mapped: {runtimes}'
+        assert 'torch' not in sys.modules
     t_up = time.perf_counter()
     ctx.set_problem(B, V, G, problem.variant_id, problem.compressed_cb, problem.p_base_wrong, problem.v2snp)
     ctx.set_betas(betas)
@@ -259,8 +272,8 @@ def main():
     logits0, probs0 = ctx.estep(pen, with_doublets=dp > 0)
 
     def barrier():
-        if dist is not None:
-            dist.barrier()
+        if plane is not None:
+            plane.barrier()
 
     ctx.run_iterations(args.warmup, 0.01)
     ctx.synchronize()
@@ -272,11 +285,8 @@ def main():
     ctx.synchronize()
     barrier()
     elapsed = time.perf_counter() - t0
-    if dist is not None:
-        import torch
-        t = torch.tensor([elapsed], dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t[0])
+    if plane is not None:
+        elapsed = plane.max_float64(elapsed)
     timers = ctx.timings()
 
     # the tolerance-mode E-step (dmx_set_estep_mode: assignments identical, posteriors within the contract's 1e-5)
@@ -299,11 +309,8 @@ def main():
         ctx.synchronize()
         barrier()
         elapsed_fast = time.perf_counter() - t0f
-        if dist is not None:
-            import torch
-            t = torch.tensor([elapsed_fast], dtype=torch.float64)
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            elapsed_fast = float(t[0])
+        if plane is not None:
+            elapsed_fast = plane.max_float64(elapsed_fast)
         timers_fast = ctx.timings()
         fast = dict(value=B_total * args.steps / elapsed_fast, ms_per_step=1e3 * elapsed_fast / args.steps,
                     em_iterations_per_s=args.steps / elapsed_fast,
@@ -361,7 +368,8 @@ def main():
             'config': {'workload': args.workload, 'barcodes_total': B_total, 'barcodes_per_gpu': B, 'snps': S, 'variants': V, 'genotypes': G,
                        'options': K, 'calls_per_gpu': N, 'doublet_prior': dp,
                        'summation': 'fast (DEMUXALOT_AMD_EXACT_ADDITIONS=0)' if os.environ.get('DEMUXALOT_AMD_EXACT_ADDITIONS', '1') in ('0', '') else 'exact: additions bit-identical to the reference (default)',
-                       'parallelism': f'barcode shards x{world}' + (f', RCCL reduce-scatter {args.reduce_dtype} + all-gather f32 of variant slices' if use_dist else '')},
+                       'parallelism': f'barcode shards x{world}' + (f', {"host-staged" if args.host_plane else "RCCL"} reduce-scatter {args.reduce_dtype} + all-gather f32 of variant slices' if use_dist else ''),
+                       'runtimes': runtimes},
             'em_iterations_per_s': args.steps / elapsed,
             'predict_barcodes_per_s': B_total / predict_s,
             'predict': {'dictionary_form': predict['auto'], 'direct_form': predict['never'],
@@ -378,7 +386,10 @@ def main():
             fast['estep_hbm_frac'] = ab['estep'] / (e_fast * 1e-3) / 1e9 / 8000.0
             fast['delivered_gather_GBps'] = (N * 4 * G) / (e_fast * 1e-3) / 1e9
         out['roofline']['traffic_source'] = 'profiles/pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE + WRITE_SIZE of an earlier run)'
-        if world == 1 and not args.no_live_traffic and not args.no_cpu_baseline:
+        if os.environ.get('DEMUXALOT_AMD_ESTEP_SCHEDULE', 'auto') == 'tiled' and out['roofline']['kernel'] == 'k_estep_direct':
+            out['roofline']['kernel'] = 'k_estep_tiled'
+            out['roofline']['traffic'], out['roofline']['traffic_source'] = None, 'none (no committed figure for this kernel)'
+        if world == 1 and not args.no_live_traffic:
             live = live_traffic(args, out['roofline']['kernel'])
             if live is not None:
                 out['roofline']['traffic'] = live
@@ -397,9 +408,9 @@ def main():
             out['cpu_baseline'] = None
         sys.stdout.flush()
         os.write(json_fd, (json.dumps(out) + '\n').encode())
-    if dist is not None:
-        dist.barrier()
-        dist.destroy_process_group()
+    if plane is not None:
+        plane.barrier()
+        plane.close()
 
 
 if __name__ == '__main__':

@@ -522,7 +522,11 @@ int layout_exchange(dmx_ctx *c)
     bool contiguous = true;
     long long rows = V;
     exchange_slices(c->h_v2snp.data(), V, n, c->cut, rows, contiguous);
-    c->sliced = c->attached() && contiguous && V > 0;
+    // DEMUXALOT_AMD_EXCHANGE=allreduce: the plain exchange (all-reduce of the float64 sums, P-step on every rank) whatever
+    // the SNP layout - the fallback switch for the sliced exchange (reduce-scatter / sliced P-step / all-gather)
+    const char *exchange = std::getenv("DEMUXALOT_AMD_EXCHANGE");
+    const bool force_allreduce = exchange && std::strcmp(exchange, "allreduce") == 0;
+    c->sliced = c->attached() && contiguous && V > 0 && !force_allreduce;
     if (!c->sliced) {
         c->cut.assign((size_t)n + 1, 0);
         c->cut[n] = V;

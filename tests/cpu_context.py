@@ -13,10 +13,71 @@ from demuxalot_amd.distributed import exchange_slices
 from oracle import demux_oracle as oracle
 
 
+class _HostCollectives:
+    """torch.distributed-shaped adapter over a caller-provided collective (include/demux_hip.h: dmx_host_collective
+    semantics, as demuxalot_amd.device hands them to a plane): what OracleContext needs of `dist`."""
+
+    def __init__(self, rank, world, collective):
+        self.rank, self.world, self.collective = rank, world, collective
+
+    def all_reduce(self, t):
+        self.collective('all_reduce', t.numpy().reshape(-1))
+
+    def reduce(self, t, dst):
+        # one slice of a reduce-scatter: stage it as row `dst` of a [world, block] buffer
+        buf = np.zeros((self.world, t.numel()), dtype=t.numpy().dtype)
+        buf[dst] = t.numpy().reshape(-1)
+        self.collective('reduce_scatter', buf)
+        if dst == self.rank:
+            t.numpy().reshape(-1)[...] = buf[dst]
+
+    def all_gather(self, parts, mine):
+        buf = np.zeros((self.world, mine.numel()), dtype=mine.numpy().dtype)
+        buf[self.rank] = mine.numpy().reshape(-1)
+        self.collective('all_gather', buf)
+        for r, part in enumerate(parts):
+            part.numpy().reshape(-1)[...] = buf[r]
+
+
+class _Array:
+    """The two tensor methods the exchange code below uses, on a numpy array (keeps the module torch-free when the
+    collectives are the caller's)."""
+
+    def __init__(self, array):
+        self.array = array
+
+    def numpy(self):
+        return self.array
+
+    def numel(self):
+        return self.array.size
+
+
 class OracleContext:
     def __init__(self, device=0):
         self.rank, self.world, self.dist = 0, 1, None
         self.addition = None
+        self.torch_free = False
+
+    def comm_init_host(self, rank, nranks, collective, reduce_dtype='f64'):
+        """The exchange over the caller's collectives (a plane with host_collective): no torch anywhere."""
+        self.rank, self.world, self.dist = rank, nranks, _HostCollectives(rank, nranks, collective)
+        self.torch_free = True
+
+    def _tensor(self, array):
+        if self.torch_free:
+            return _Array(array)
+        import torch
+        return torch.from_numpy(array)
+
+    def _zeros(self, shape):
+        return self._tensor(np.zeros(shape, dtype=np.float32))
+
+    def get_prior_betas(self):
+        return self.prior
+
+    def set_keep_molecule_calls(self, keep):
+        assert not keep, 'the CPU stand-in has no aggregate_on_snps mode'
 
     @staticmethod
     def new_unique_id():
@@ -83,13 +144,12 @@ class OracleContext:
         if not self.sliced:
             self.prob = oracle.probs_from_betas(self.v2snp, betas, p_genotype_clip)
             return self.prob
-        import torch
         lo, hi = self._slice(self.rank)  # the P-step of the owned slice only (whole SNP groups)
         mine = np.zeros((self.slice_rows, self.G), dtype=np.float32)
         if hi > lo:
             mine[:hi - lo] = oracle.probs_from_betas(self.v2snp[lo:hi] - self.v2snp[lo], betas[lo:hi], p_genotype_clip)
-        parts = [torch.zeros(mine.shape, dtype=torch.float32) for _ in range(self.world)]
-        self.dist.all_gather(parts, torch.from_numpy(mine))
+        parts = [self._zeros(mine.shape) for _ in range(self.world)]
+        self.dist.all_gather(parts, self._tensor(mine))
         self.prob = np.concatenate([parts[r].numpy()[:self._slice(r)[1] - self._slice(r)[0]] for r in range(self.world)])
         return self.prob
 
@@ -118,32 +178,29 @@ class OracleContext:
         if self.dist is None:
             self.addition = part.astype(np.float32)
         elif not self.sliced:
-            import torch
-            t = torch.from_numpy(part)
+            t = self._tensor(part)
             self.dist.all_reduce(t)
             self.addition = t.numpy().astype(np.float32)
         else:
-            import torch
             self.addition = np.full((self.V, self.G), np.nan, dtype=np.float32)  # foreign slices are NOT current
             for r in range(self.world):  # reduce-scatter of the padded slices
                 lo, hi = self._slice(r)
                 padded = np.zeros((self.slice_rows, self.G))
                 padded[:hi - lo] = part[lo:hi]
-                t = torch.from_numpy(padded)
+                t = self._tensor(padded)
                 self.dist.reduce(t, dst=r)
                 if r == self.rank:
                     self.addition[lo:hi] = t.numpy()[:hi - lo].astype(np.float32)
             self.partial = True
-        return self.addition
+        return self._full_addition() if fetch else self.addition
 
     def _full_addition(self):
         if self.dist is not None and self.sliced and getattr(self, 'partial', False):
-            import torch
             lo, hi = self._slice(self.rank)
             mine = np.zeros((self.slice_rows, self.G), dtype=np.float32)
             mine[:hi - lo] = self.addition[lo:hi]
-            parts = [torch.zeros(mine.shape, dtype=torch.float32) for _ in range(self.world)]
-            self.dist.all_gather(parts, torch.from_numpy(mine))
+            parts = [self._zeros(mine.shape) for _ in range(self.world)]
+            self.dist.all_gather(parts, self._tensor(mine))
             self.addition = np.concatenate([parts[r].numpy()[:self._slice(r)[1] - self._slice(r)[0]] for r in range(self.world)])
             self.partial = False
         return self.addition
@@ -156,5 +213,5 @@ class OracleContext:
             self.probs_from_betas(p_genotype_clip)
             self.estep(penalties, with_doublets, prior_logits if it == 0 else None)
             if it + 1 < n_iterations:
-                self.mstep(contribution_power)
+                self.mstep(contribution_power, fetch=False)
         return self.logits, self.post, self._full_addition()

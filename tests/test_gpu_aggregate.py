@@ -114,3 +114,38 @@ def test_aggregate_wide_option_tables_against_the_oracle(oracle, n_genotypes):
     want_probs = shifted / shifted.sum(axis=1, keepdims=True)
     assert np.array_equal(probs.argmax(axis=1), want_probs.argmax(axis=1)) and np.abs(probs - want_probs).max() <= 1e-12
     print(f'G={n_genotypes}: float64 logits within {(np.abs(logits - want) / np.spacing(np.abs(want))).max():.1f} ulp of the oracle')
+
+
+def test_float32_and_float64_e_steps_with_different_option_counts_on_one_context():
+    """Call order through the raw entry points: a float32 E-step with singlets (K = G), then an aggregate E-step with
+    doublets (K = G (G + 1) / 2) on the same context and back.  Results laid out for the other option count must read
+    as absent (an error), never as out-of-bounds device reads."""
+    from demuxalot_amd import Demultiplexer, synth
+    from demuxalot_amd._lib import DemuxHipError
+    from demuxalot_amd.device import DeviceContext
+    p = synth.generate(300, 200, 5, calls_per_barcode=30, seed=9)
+    G = 5
+    ctx = DeviceContext(0)
+    try:
+        ctx.set_problem(p.n_barcodes, p.n_variants, G, p.variant_id, p.compressed_cb, p.p_base_wrong, p.v2snp)
+        ctx.set_molecule_calls(p.variant_id, p.compressed_cb, p.p_base_wrong)
+        ctx.set_betas(p.prior_betas())
+        ctx.set_addition(None)
+        ctx.probs_from_betas(0.01, fetch=False)
+        logits32, probs32 = ctx.estep(Demultiplexer._doublet_penalties(G, 0.), with_doublets=False)
+        assert probs32.shape == (300, 5)
+        logits64, probs64 = ctx.estep_snp(True, 0.5)  # K = 15 now
+        assert probs64.shape == (300, 15)
+        with pytest.raises(DemuxHipError):  # the float32 posteriors belong to K = 5
+            ctx.get_probs()
+        with pytest.raises(DemuxHipError):
+            ctx.mstep(2.)
+        add64 = ctx.mstep_f64(2.)
+        assert add64.shape == (p.n_variants, G) and np.isfinite(add64).all()
+        logits32b, probs32b = ctx.estep(Demultiplexer._doublet_penalties(G, 0.), with_doublets=False)  # K = 5 again
+        fio.assert_bitwise(probs32b, probs32, 'float32 E-step repeated after the aggregate one')
+        with pytest.raises(DemuxHipError):  # the float64 posteriors belong to K = 15
+            ctx.mstep_f64(2.)
+        assert np.isfinite(ctx.mstep(2.)).all()
+    finally:
+        ctx.close()

@@ -134,3 +134,170 @@ def test_two_processes_one_gpu_exchange_over_the_socket_plane():
         assert len(report.pop('hip_runtimes')) == 1
         for name, (betas_close, argmax_same, max_dev) in report.items():
             assert betas_close and argmax_same and max_dev <= 1e-5, (name, betas_close, argmax_same, max_dev)
+
+
+@pytest.mark.parametrize('world', [3])
+def test_device_resident_sharded_results_against_pandas(world):
+    """results='device' (world 3, F1 = the reference's tests/test_synthetic.py inputs): every rank keeps its rows on the
+    GPU; assignments / best / option sums over ALL barcodes equal what pandas makes of the reference's matrix, with only
+    O(B) / O(K) numbers crossing ranks; results='root' hands the frame to rank 0 only."""
+    import pandas as pd
+    from demuxalot_amd import distributed
+    fx = fio.load('f1_synthetic_default.npz')
+    calls, genotypes, handler = fio.product_inputs(fx)
+    i = 1  # a doublet run of the fixture
+    dp, clip = float(fx[f'predict{i}_dp']), float(fx[f'predict{i}_clip'])
+    want = pd.DataFrame(fx[f'predict{i}_probs'], index=[str(b) for b in fx['barcodes']], columns=[str(c) for c in fx[f'predict{i}_columns']])
+    shared = ThreadWorld(world)
+
+    def rank_body(plane):
+        with distributed.predict_posteriors(calls, genotypes, handler, plane, p_genotype_clip=clip, doublet_prior=dp,
+                                            results='device') as sharded:
+            assert sharded.shape == want.shape and sharded.local.shape[0] == sharded.hi - sharded.lo < want.shape[0]
+            got = dict(assign=sharded.assignments(0.9), best=sharded.best(), sums=sharded.option_sums(),
+                       frame=sharded.to_dataframe(root_only=True))
+        logits_root, probs_root = distributed.predict_posteriors(calls, genotypes, handler, plane, p_genotype_clip=clip,
+                                                                 doublet_prior=dp, results='root')
+        assert (probs_root is None) == (plane.rank != 0) and (logits_root is None) == (plane.rank != 0)
+        if plane.rank == 0:
+            fio.assert_bitwise(probs_root.values, want.values, 'results=root')
+        return got
+
+    for rank, got in enumerate(shared.run(rank_body)):
+        expect = want[want.max(axis=1).gt(0.9)].idxmax(axis=1)
+        assert got['assign'].index.tolist() == expect.index.tolist() and got['assign'].tolist() == expect.tolist()
+        assert got['best']['option'].tolist() == want.idxmax(axis=1).tolist()
+        assert np.array_equal(got['best']['probability'].values, want.max(axis=1).values)
+        assert np.allclose(got['sums'].values, want.values.astype(np.float64).sum(axis=0), rtol=1e-12, atol=1e-9)
+        assert (got['frame'] is None) == (rank != 0)
+        if rank == 0:
+            fio.assert_bitwise(got['frame'].values, want.values, 'to_dataframe at the root')
+
+
+@pytest.mark.parametrize('aggregate', [False, True])
+def test_sharded_staged_learning(aggregate):
+    """distributed.staged_genotype_learning at world 2 against the reference's per-iteration captures: the default
+    E-step (float32, the exchange inside the library) and aggregate_on_snps (float64 posteriors; the ranks' float64
+    M-step sums added on the host)."""
+    from demuxalot_amd import Demultiplexer, distributed
+    fx = fio.load('f7_aggregate_synthetic_g4.npz' if aggregate else 'f2_synthetic_g4.npz')
+    inputs = fio.load(str(fx['inputs_of'])) if aggregate else fx
+    calls, genotypes, handler = fio.product_inputs(inputs)
+    n_it = int(fx['em0_n_iterations'])
+    kwargs = dict(n_iterations=n_it, doublet_prior=float(fx['em0_dp']))
+    if not aggregate:
+        kwargs['p_genotype_clip'] = float(fx['em0_clip'])
+    if fx.get('em0_prior_logits') is not None:
+        kwargs['barcode_prior_logits'] = fx['em0_prior_logits']
+    shared = ThreadWorld(2)
+
+    def rank_body(plane):
+        return [(frame.values, dbg['barcode_logits'], dbg['genotype_addition'])
+                for frame, dbg in distributed.staged_genotype_learning(calls, genotypes, handler, plane, **kwargs)]
+
+    Demultiplexer.aggregate_on_snps = aggregate
+    try:
+        per_rank = shared.run(rank_body)
+    finally:
+        Demultiplexer.aggregate_on_snps = False
+    for stages in per_rank:
+        assert len(stages) == n_it
+        for it, (probs, logits, addition) in enumerate(stages):
+            want = fx[f'em0_it{it}_probs']
+            assert probs.dtype == want.dtype and probs.shape == want.shape
+            assert np.array_equal(probs.argmax(1), want.argmax(1)) and np.abs(probs - want).max() <= 1e-5, it
+            assert np.allclose(addition, fx[f'em0_it{it}_addition'], rtol=3e-7, atol=1e-12), it
+    assert all(np.array_equal(a[2], b[2]) for a, b in zip(per_rank[0], per_rank[1]))  # the same additions on every rank
+
+
+def _rccl_rank(rank, world, port, out):
+    from demuxalot_amd import _lib, distributed
+    from demuxalot_amd.plane import SocketControlPlane
+    plane = SocketControlPlane(rank, world, '127.0.0.1', port=port)  # control plane only: the exchange is RCCL
+    try:
+        report = {}
+        for name in ('f2_synthetic_g4.npz', 'f3_small_3.npz', 'f1_synthetic_default.npz'):  # F3: the all-reduce fallback
+            fx = fio.load(name)
+            calls, genotypes, handler = fio.product_inputs(fx)
+            kwargs = dict(n_iterations=int(fx['em0_n_iterations']), p_genotype_clip=float(fx['em0_clip']), doublet_prior=float(fx['em0_dp']))
+            learnt, probs_df = distributed.learn_genotypes(calls, genotypes, handler, plane, device=rank,
+                                                           barcode_prior_logits=fx.get('em0_prior_logits'), **kwargs)
+            want = fx[f'em0_it{kwargs["n_iterations"] - 1}_probs']
+            report[name] = (bool(np.allclose(learnt.variant_betas, fx['em0_learnt_betas'], rtol=3e-7, atol=0)),
+                            bool(np.array_equal(probs_df.values.argmax(1), want.argmax(1))), float(np.abs(probs_df.values - want).max()))
+        info = _lib.runtime_info()
+        report['runtime'] = (len(info['hip']), info['rccl_loaded'])
+        out.put((rank, report))
+    finally:
+        plane.close()
+
+
+def test_two_ranks_over_rccl():
+    """The default multi-GPU exchange (ncclReduceScatter into the owned slice, in-place ncclAllGather of the padded
+    genotype table, the all-reduce fallback) with two ranks on two GPUs, against the reference's outputs.  Skipped on a
+    one-GPU box (the driver's scaling node has eight)."""
+    import multiprocessing as mp
+    import socket
+    from demuxalot_amd import _lib
+    if _lib.device_count() < 2:
+        pytest.skip('needs two GPUs')
+    with socket.socket() as s:
+        s.bind(('127.0.0.1', 0))
+        port = s.getsockname()[1]
+    ctx = mp.get_context('spawn')
+    out = ctx.Queue()
+    procs = [ctx.Process(target=_rccl_rank, args=(r, 2, port, out)) for r in range(2)]
+    for pr in procs:
+        pr.start()
+    reports = [out.get(timeout=900) for _ in range(2)]
+    for pr in procs:
+        pr.join(timeout=60)
+        assert pr.exitcode == 0
+    for _rank, report in reports:
+        n_hip, rccl = report.pop('runtime')
+        assert n_hip == 1 and rccl, (n_hip, rccl)
+        for name, (betas_close, argmax_same, max_dev) in report.items():
+            assert betas_close and argmax_same and max_dev <= 1e-5, (name, betas_close, argmax_same, max_dev)
+
+
+def _bench_rank(rank, world, port, out, scaling):
+    """bench.py as one rank of `world` on GPU 0, launched the way torch.distributed.run does (environment only)."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK='0', MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port),
+               TORCHELASTIC_RUN_ID=f'benchtest{port}')
+    done = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--gpus', str(world), '--steps', '2', '--warmup', '1',
+                           '--workload', 'em_20k_10k_64', '--scaling', scaling, '--host-plane', '--no-cpu-baseline', '--no-fast-mode',
+                           '--no-live-traffic'], env=env, cwd=root, capture_output=True, text=True, timeout=900)
+    out.put((rank, done.returncode, done.stdout.strip(), done.stderr[-2000:]))
+
+
+@pytest.mark.parametrize('scaling', ['strong', 'weak'])
+def test_bench_with_two_ranks_on_one_gpu(scaling):
+    """`bench.py --gpus 2 --scaling strong|weak` end to end (socket control plane, exchange staged over the plane): rank 0
+    prints ONE JSON line for the whole job, the other rank nothing."""
+    import json
+    import multiprocessing as mp
+    import socket
+    with socket.socket() as s:
+        s.bind(('127.0.0.1', 0))
+        port = s.getsockname()[1]
+    ctx = mp.get_context('spawn')
+    out = ctx.Queue()
+    procs = [ctx.Process(target=_bench_rank, args=(r, 2, port, out, scaling)) for r in range(2)]
+    for pr in procs:
+        pr.start()
+    results = sorted(out.get(timeout=900) for _ in range(2))
+    for pr in procs:
+        pr.join(timeout=60)
+    for rank, code, stdout, stderr in results:
+        assert code == 0, (rank, stderr)
+        if rank:
+            assert stdout == ''
+    line = json.loads(results[0][2])
+    assert line['n_gpus'] == 2 and line['scaling'] == scaling and line['value'] > 0
+    assert line['config']['barcodes_total'] == (20_000 if scaling == 'strong' else 40_000)
+    assert len(line['config']['runtimes']['hip']) == 1 and line['exchange_ms_per_step'] > 0

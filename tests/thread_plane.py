@@ -62,6 +62,15 @@ class ThreadPlane:
     def gather_rows(self, rows):
         return np.concatenate(self._exchange(np.ascontiguousarray(rows)), axis=0)
 
+    def gather_to_root(self, rows):
+        whole = self.gather_rows(rows)
+        return whole if self.rank == 0 else None
+
+    def all_ok(self, ok, message=''):
+        reports = self._exchange((bool(ok), message))
+        bad = [(r, m) for r, (good, m) in enumerate(reports) if not good]
+        return (True, '') if not bad else (False, f'rank {bad[0][0]}: {bad[0][1]}')
+
     def barrier(self):
         self.shared.barrier.wait(self.shared.timeout)
 
