@@ -131,45 +131,118 @@ def measured_traffic(workload, kernel):
         return None
 
 
-def live_traffic(args, kernel):
-    """HBM-side bytes per launch of `kernel`, measured now: two child runs of this script under
-    `rocprofv3 --kernel-trace --pmc` (FETCH_SIZE and WRITE_SIZE in separate passes, as MI355X_MICROARCH.md prescribes;
-    both are reported in KiB; the row gathers are 4-byte-per-lane reads, not the 16-byte streams with the documented 2x
-    under-count).  None when the profiler is not available or a pass fails - the caller then falls back to the
-    figures committed under profiles/."""
+def live_counters(args, kernel):
+    """Measured now, by child runs of this script under `rocprofv3 --kernel-trace --pmc` (one counter per pass, as
+    MI355X_MICROARCH.md prescribes): HBM-side bytes per launch of `kernel` (FETCH_SIZE + WRITE_SIZE, both reported in KiB;
+    the row gathers are 4-byte-per-lane reads, not the 16-byte streams with the documented 2x under-count) and the clock
+    the kernel sustains (GRBM_GUI_ACTIVE summed over the 8 XCDs / 8 / the kernel's duration in the same pass).
+    {} when the profiler is not available; a missing key when a pass fails - the caller keeps the figures committed
+    under profiles/ for those."""
     import csv
     import glob
     import shutil
     import subprocess
     import tempfile
     if shutil.which('rocprofv3') is None:
-        return None
+        return {}
     # never nest profilers: a bench run that is itself under rocprofv3 (or any LD_PRELOAD tool) keeps to the committed figures
     if os.environ.get('LD_PRELOAD') or any(k.startswith(('ROCP_', 'ROCPROF')) for k in os.environ):
-        return None
+        return {}
     out_dir = tempfile.mkdtemp(prefix='bench_pmc_', dir='/tmp')
     child = [sys.executable, os.path.join(ROOT, 'bench.py'), '--workload', args.workload, '--steps', '2', '--warmup', '1',
-             '--no-cpu-baseline', '--no-fast-mode', '--no-live-traffic'] + (['--flat-genotypes'] if args.flat_genotypes else [])
+             '--no-cpu-baseline', '--no-fast-mode', '--no-live-traffic', '--no-e2e'] + (['--flat-genotypes'] if args.flat_genotypes else [])
     env = dict(os.environ, TMPDIR='/tmp')
-    total = 0.0
+    found = {}
     try:
-        for counter in ('FETCH_SIZE', 'WRITE_SIZE'):
+        for counter in ('FETCH_SIZE', 'WRITE_SIZE', 'GRBM_GUI_ACTIVE'):
             where = os.path.join(out_dir, counter)
-            subprocess.run(['rocprofv3', '--kernel-trace', '--pmc', counter, '--output-format', 'csv', '-d', where, '--'] + child,
-                           env=env, cwd=ROOT, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=180, check=True)
-            values = []
+            try:
+                subprocess.run(['rocprofv3', '--kernel-trace', '--pmc', counter, '--output-format', 'csv', '-d', where, '--'] + child,
+                               env=env, cwd=ROOT, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=180, check=True)
+            except (OSError, subprocess.SubprocessError):
+                continue
+            values, dispatches = [], set()
             for path in glob.glob(os.path.join(where, '**', '*counter_collection.csv'), recursive=True):
                 for row in csv.DictReader(open(path)):
                     if kernel in row['Kernel_Name'] and row['Counter_Name'] == counter:
                         values.append(float(row['Counter_Value']))
-            if not values:  # e.g. another E-step kernel ran (DEMUXALOT_AMD_ESTEP_SCHEDULE=tiled): no figure rather than a wrong one
-                return None
-            total += 1024.0 * sum(values) / len(values)
-        return total
-    except (OSError, subprocess.SubprocessError, KeyError, ValueError):
-        return None
+                        dispatches.add(row['Dispatch_Id'])
+            if not values:  # e.g. another E-step kernel ran: no figure rather than a wrong one
+                continue
+            found[counter] = sum(values) / len(dispatches)
+            if counter == 'GRBM_GUI_ACTIVE':
+                spans = []
+                for path in glob.glob(os.path.join(where, '**', '*kernel_trace.csv'), recursive=True):
+                    for row in csv.DictReader(open(path)):
+                        if kernel in row['Kernel_Name']:
+                            spans.append(float(row['End_Timestamp']) - float(row['Start_Timestamp']))
+                if spans:
+                    found['clock_ghz'] = found[counter] / 8.0 / (sum(spans) / len(spans))  # cycles per XCD / ns
+        if 'FETCH_SIZE' in found and 'WRITE_SIZE' in found:
+            found['traffic'] = 1024.0 * (found['FETCH_SIZE'] + found['WRITE_SIZE'])
+        return found
+    except (OSError, KeyError, ValueError):
+        return found
     finally:
         shutil.rmtree(out_dir, ignore_errors=True)
+
+
+def e2e_timing(problem, doublet_prior, n_iterations=5):
+    """Wall time of the drop-in calls themselves (demux.py:35-66, 120-156: the reference's containers in, DataFrames out)
+    on this workload, and where it goes.  SURVEY.md 8d asks for barcodes/s with and without the D2H of the [B, K] results:
+    `on_device=True` keeps them on the GPU behind a DevicePosteriors (assignments computed there)."""
+    import pandas as pd
+    from demuxalot_amd import Demultiplexer, synth
+    from demuxalot_amd.demux import _option_names, _pack_on_device
+    from demuxalot_amd.device import DeviceContext
+    t0 = time.perf_counter()
+    calls, genotypes, handler = synth.as_objects(problem)
+    t_objects = time.perf_counter() - t0
+    B = handler.n_barcodes
+    n_molecule_calls = int(sum(c.n_snp_calls for c in calls.values()))
+    Demultiplexer.predict_posteriors(calls, genotypes, handler, doublet_prior=doublet_prior)  # warm-up: context, allocations
+
+    def timed(fn):
+        t = time.perf_counter()
+        out = fn()
+        return time.perf_counter() - t, out
+
+    t_predict, (logits_df, probs_df) = timed(lambda: Demultiplexer.predict_posteriors(calls, genotypes, handler, doublet_prior=doublet_prior))
+    t_predict_dev, dev = timed(lambda: Demultiplexer.predict_posteriors(calls, genotypes, handler, doublet_prior=doublet_prior, on_device=True))
+    t_assign_dev, assigned = timed(lambda: dev.assignments(0.9))
+    t_assign_host, assigned_host = timed(lambda: probs_df[probs_df.max(axis=1).gt(0.9)].idxmax(axis=1))
+    same = bool(assigned.index.equals(assigned_host.index) and (assigned.values == assigned_host.values).all())
+    dev.close()
+    t_learn, (_learnt, last_df) = timed(lambda: Demultiplexer.learn_genotypes(calls, genotypes, handler, n_iterations=n_iterations, doublet_prior=0.))
+    t_learn_dev, (_learnt2, dev2) = timed(lambda: Demultiplexer.learn_genotypes(calls, genotypes, handler, n_iterations=n_iterations, doublet_prior=0., on_device=True))
+    dev2.close()
+    # the same steps by hand, for the split
+    pen = Demultiplexer._doublet_penalties(genotypes.n_genotypes, doublet_prior)
+    ctx = DeviceContext(0)
+    try:
+        t_pack, _ = timed(lambda: (_pack_on_device(calls, genotypes, B, False, fetch_betas=False, ctx=ctx), ctx.synchronize()))
+        ctx.set_addition(None)
+        t_pe, _ = timed(lambda: (ctx.probs_from_betas(0.01, fetch=False), ctx.estep(pen, with_doublets=doublet_prior > 0, fetch_logits=False, fetch_probs=False), ctx.synchronize()))
+        t_d2h, (lg, pr) = timed(lambda: (ctx.get_logits(), ctx.get_probs()))
+        columns = _option_names(genotypes.genotype_names, doublet_prior)
+        t_frames, _ = timed(lambda: (pd.DataFrame(lg, index=list(handler.ordered_barcodes), columns=columns),
+                                     pd.DataFrame(pr, index=list(handler.ordered_barcodes), columns=columns)))
+        pen0 = Demultiplexer._doublet_penalties(genotypes.n_genotypes, 0.)
+        t_em, _ = timed(lambda: (ctx.em(n_iterations, 0.01, pen0, with_doublets=False, fetch_logits=False, fetch_probs=False), ctx.synchronize()))
+    finally:
+        ctx.close()
+    return {
+        'workload_molecule_calls': n_molecule_calls, 'barcodes': B,
+        'predict_posteriors_s': t_predict, 'predict_barcodes_per_s': B / t_predict,
+        'predict_posteriors_on_device_s': t_predict_dev, 'predict_on_device_barcodes_per_s': B / t_predict_dev,
+        'assignments_on_device_s': t_assign_dev, 'assignments_with_pandas_s': t_assign_host, 'assignments_identical': same,
+        f'learn_genotypes_{n_iterations}it_s': t_learn, f'learn_genotypes_{n_iterations}it_on_device_s': t_learn_dev,
+        'split_s': {'flatten_upload_device_pack_prior': t_pack, 'pstep_estep': t_pe, 'd2h_logits_and_posteriors': t_d2h,
+                    'two_dataframes': t_frames, f'em_{n_iterations}_iterations_fused': t_em},
+        'build_objects_s (synthetic generator, not part of a call)': t_objects,
+        'note': 'wall time of the Python entry points on the containers of the whole workload (one molecule per call); the reference '
+                'spends ~3.5-4 us per molecule call in pack_calls alone (SURVEY.md 8a9)',
+    }
 
 
 def _lib_device_count():
@@ -183,13 +256,18 @@ def main():
     ap.add_argument('--steps', type=int, default=10)
     ap.add_argument('--warmup', type=int, default=2)
     ap.add_argument('--workload', default='em_200k_100k_64', choices=sorted(WORKLOADS))
-    ap.add_argument('--reduce-dtype', default='f64', choices=['f64', 'f32'])
+    ap.add_argument('--reduce-dtype', default='auto', choices=['auto', 'f64', 'f32'],
+                    help='wire format of the reduce-scatter of the beta additions: float64 partial sums (results independent of the '
+                         'number of ranks up to float32 rounding ties) or float32 (half the bytes; posteriors stay within the 1e-5 '
+                         'contract: tests/test_gpu_ranks_on_one_gpu.py).  auto = f64 up to 2 ranks, f32 from 4 on, where the exchange '
+                         'is what strong scaling runs into (DESIGN.md 5)')
     ap.add_argument('--scaling', default='weak', choices=['weak', 'strong'],
                     help='weak: the workload per GPU; strong: the workload in total, barcodes sharded over the GPUs')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-fast-mode', action='store_true', help='skip the second timed region (tolerance-mode E-step)')
     ap.add_argument('--no-live-traffic', action='store_true',
                     help='roofline.traffic from profiles/pmc_traffic.json instead of two rocprofv3 --pmc child runs')
+    ap.add_argument('--no-e2e', action='store_true', help='skip the end-to-end timing of the drop-in calls (containers in, DataFrames out)')
     ap.add_argument('--flat-genotypes', action='store_true',
                     help='worst case of the M-step: all-equal betas, so every posterior is 1/G and every call contributes to '
                          'every genotype (the start-from-assignment scenario of tests/test_synthetic.py:200-239 before any label '
@@ -209,6 +287,8 @@ def main():
 
     rank = int(os.environ.get('RANK', '0'))
     world = int(os.environ.get('WORLD_SIZE', '1'))
+    if args.reduce_dtype == 'auto':
+        args.reduce_dtype = 'f32' if world >= 4 else 'f64'
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
     assert world == args.gpus, f'--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run'
 
@@ -372,7 +452,8 @@ def main():
                        'runtimes': runtimes},
             'em_iterations_per_s': args.steps / elapsed,
             'predict_barcodes_per_s': B_total / predict_s,
-            'predict': {'dictionary_form': predict['auto'], 'direct_form': predict['never'],
+            'predict': {'dictionary_form': dict(predict['auto'], estep_hbm_frac=algorithmic_bytes(B, V, G, K, N)['estep'] / (predict['auto']['estep_ms'] * 1e-3) / 8e12),
+                        'direct_form': dict(predict['never'], estep_hbm_frac=algorithmic_bytes(B, V, G, K, N)['estep'] / (predict['never']['estep_ms'] * 1e-3) / 8e12),
                         'note': 'P-step + E-step on the table without beta addition (predict_posteriors, EM iteration 0); '
                                 'estep_ms includes building the dictionary'},
             'kernel_ms': {k: (v['ms'] / max(1, v['launches'])) for k, v in timers.items()},
@@ -390,10 +471,18 @@ def main():
             out['roofline']['kernel'] = 'k_estep_tiled'
             out['roofline']['traffic'], out['roofline']['traffic_source'] = None, 'none (no committed figure for this kernel)'
         if world == 1 and not args.no_live_traffic:
-            live = live_traffic(args, out['roofline']['kernel'])
-            if live is not None:
-                out['roofline']['traffic'] = live
-                out['roofline']['traffic_source'] = 'rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, two child runs of this command (live)'
+            live = live_counters(args, out['roofline']['kernel'])
+            if 'traffic' in live:
+                out['roofline']['traffic'] = live['traffic']
+                out['roofline']['traffic_source'] = 'rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, child runs of this command (live)'
+            if 'clock_ghz' in live:  # the VALU issue fraction at the clock the kernel actually holds
+                valu = out['roofline']['valu']
+                valu['sustained_clock_ghz'] = live['clock_ghz']
+                valu['frac_at_sustained_clock'] = valu['frac'] * PEAK_CLOCK_HZ / (live['clock_ghz'] * 1e9)
+                valu['clock_source'] = 'rocprofv3 --pmc GRBM_GUI_ACTIVE / 8 XCDs / kernel duration, child run of this command (live)'
+        if world == 1 and not args.no_e2e and not args.flat_genotypes:
+            ctx.close()  # the end-to-end calls bring their own contexts; free this one's 4 GB first
+            out['e2e'] = e2e_timing(problem, dp)
         if world == 1 and not args.no_cpu_baseline:
             base, ref_logits, ref_post, n_s = cpu_baseline(problem, betas, dp)
             out['cpu_baseline'] = base

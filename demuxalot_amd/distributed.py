@@ -234,8 +234,12 @@ class ShardedEM:
 
 
 def attach_communicator(ctx, plane, reduce_dtype='f64', force=False):
+    """reduce_dtype: 'f64' (default: float64 partial sums on the wire, results independent of the number of ranks up to
+    float32 rounding ties), 'f32' (half the bytes), 'auto' (f64 up to 2 ranks, f32 from 4 on)."""
     if plane.world == 1 and not force:
         return
+    if reduce_dtype == 'auto':
+        reduce_dtype = 'f32' if plane.world >= 4 else 'f64'
     if getattr(plane, 'host_collective', None) is not None:  # the plane brings its own collectives
         ctx.comm_init_host(plane.rank, plane.world, plane.host_collective, reduce_dtype=reduce_dtype)
         return

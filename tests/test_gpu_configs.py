@@ -128,6 +128,19 @@ def test_config2_em_200k_100k_32(oracle):
     # dmx_em skips the dead last M-step: after 4 iterations its addition is the one of the staged 3rd M-step
     fio.assert_bitwise(addition_fused, addition, 'fused driver: addition')
     assert np.abs(probs_fused.sum(axis=1) - 1).max() < 1e-5
+    # configs[2] as written: learn_genotypes with 10 EM iterations.  The staged run goes on for six more iterations
+    # (steps driven one by one through the C ABI, each a pure function of the previous state that the three checked
+    # iterations above pin against the oracle); the fused driver's 10 iterations must land on the same bits.
+    ctx.set_addition(addition)
+    for _ in range(6):
+        ctx.probs_from_betas(0.01, fetch=False)
+        ctx.estep(pen, with_doublets=False, fetch_logits=False, fetch_probs=False)
+        addition = ctx.mstep(2.)
+    ctx.probs_from_betas(0.01, fetch=False)
+    _, probs_staged10 = ctx.estep(pen, with_doublets=False, fetch_logits=False)
+    _, probs_fused10, addition_fused10 = ctx.em(10, 0.01, pen, with_doublets=False, fetch_logits=False)
+    fio.assert_bitwise(addition_fused10, addition, 'fused driver, 10 iterations: addition')
+    fio.assert_bitwise(probs_fused10, probs_staged10, 'fused driver, 10 iterations: posteriors')
 
 
 # ---- configs[3] shape on one GPU -------------------------------------------------------------------------
