@@ -144,10 +144,11 @@ def live_counters(args, kernel):
     import subprocess
     import tempfile
     if shutil.which('rocprofv3') is None:
-        return {}
-    # never nest profilers: a bench run that is itself under rocprofv3 (or any LD_PRELOAD tool) keeps to the committed figures
-    if os.environ.get('LD_PRELOAD') or any(k.startswith(('ROCP_', 'ROCPROF')) for k in os.environ):
-        return {}
+        return {'skipped': 'rocprofv3 not found'}
+    # never nest profilers: a bench run that is itself under rocprofv3 keeps to the committed figures
+    nested = [k for k in os.environ if k.startswith(('ROCP_TOOL', 'ROCPROFILER_', 'ROCPROFV3_'))]
+    if nested or 'rocprof' in os.environ.get('LD_PRELOAD', ''):
+        return {'skipped': f'this run is itself under a profiler ({nested or "LD_PRELOAD"})'}
     out_dir = tempfile.mkdtemp(prefix='bench_pmc_', dir='/tmp')
     child = [sys.executable, os.path.join(ROOT, 'bench.py'), '--workload', args.workload, '--steps', '2', '--warmup', '1',
              '--no-cpu-baseline', '--no-fast-mode', '--no-live-traffic', '--no-e2e'] + (['--flat-genotypes'] if args.flat_genotypes else [])
@@ -158,8 +159,9 @@ def live_counters(args, kernel):
             where = os.path.join(out_dir, counter)
             try:
                 subprocess.run(['rocprofv3', '--kernel-trace', '--pmc', counter, '--output-format', 'csv', '-d', where, '--'] + child,
-                               env=env, cwd=ROOT, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=180, check=True)
-            except (OSError, subprocess.SubprocessError):
+                               env=env, cwd=ROOT, stdout=subprocess.DEVNULL, stderr=subprocess.PIPE, timeout=180, check=True)
+            except (OSError, subprocess.SubprocessError) as exc:
+                found[f'{counter}_failed'] = (getattr(exc, 'stderr', b'') or b'').decode(errors='replace')[-300:] or str(exc)
                 continue
             values, dispatches = [], set()
             for path in glob.glob(os.path.join(where, '**', '*counter_collection.csv'), recursive=True):
@@ -475,6 +477,8 @@ def main():
             if 'traffic' in live:
                 out['roofline']['traffic'] = live['traffic']
                 out['roofline']['traffic_source'] = 'rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, child runs of this command (live)'
+            if 'traffic' not in live or 'clock_ghz' not in live:
+                out['roofline']['live_counters'] = {k: v for k, v in live.items() if k == 'skipped' or k.endswith('_failed')}
             if 'clock_ghz' in live:  # the VALU issue fraction at the clock the kernel actually holds
                 valu = out['roofline']['valu']
                 valu['sustained_clock_ghz'] = live['clock_ghz']

@@ -646,9 +646,11 @@ int prepare_dictionary(dmx_ctx *c, bool pairs, dmx::EstepArgs &a, int *form)
     if (!wanted || c->estep_mode != DMX_ESTEP_EXACT || c->B == 0 || c->prob_rows == 0) return 0;
     const int G = c->G;
     const long long K = c->K, rows = c->prob_rows;
-    if (K > dmx::DICT_LANE_K || rows >= (1 << 24) || a.pairs_bytes == 0) return 0;  // wider tables: the direct forms; 24-bit row x pitch; 32-bit record offsets
-    if (c->dict_mode == 1) {
-        // Where the form pays (measured): singlet runs with enough barcodes for several rounds of
+    const bool block_form = pairs && K > dmx::DICT_LANE_K;  // wide doublet tables: workgroup per barcode
+    if (!block_form && (K > dmx::DICT_LANE_K || rows >= (1 << 24) || a.pairs_bytes == 0)) return 0;  // singlet tables beyond 256: the direct forms; 24-bit row x pitch; 32-bit record offsets
+    if (block_form && (size_t)G * 72 + 9 * 1024 > 160 * 1024) return 0;  // the code rows of a chunk must fit the LDS
+    if (c->dict_mode == 1 && !block_form) {
+        // Where the lane form pays (measured): singlet runs with enough barcodes for several rounds of
         // wavefronts.  A launch of one round lasts as long as its longest barcode, whose calls this form walks in
         // batches with a memory latency each (20k x 10k x 64: 0.31 ms against 0.25 ms direct), and the 16 entry slots of
         // a doublet run leave two calls per barcode and batch (20k x 20k x 8 with doublets: 0.60 against 0.28 ms).
@@ -671,6 +673,13 @@ int prepare_dictionary(dmx_ctx *c, bool pairs, dmx::EstepArgs &a, int *form)
     HIP_TRY(hipStreamSynchronize(c->stream));
     c->dict_distinct = (int)distinct;
     if (distinct == 0 || (int)distinct > (pairs ? dmx::DICT_PAIR_CAP : dmx::DICT_CAP)) return 0;
+    if (block_form) {
+        a.dict_n = (int)distinct;
+        a.dict = c->d_dict;
+        a.codes = c->d_codes;
+        *form = DMX_FORM_DICT_BLOCK;
+        return 0;
+    }
     const size_t pitch = (size_t)dmx::dict_table_pitch((int)distinct, (int)K, pairs), need_bytes = (size_t)rows * pitch;
     if (need_bytes >= (1ull << 32)) return 0;  // buffer addressing
     if (need_bytes > c->cap_dtab) {
@@ -729,12 +738,16 @@ int run_estep(dmx_ctx *c, int with_doublets, bool with_prior, int prior_dtype, f
     a.dtab = nullptr;
     a.dtab_bytes = 0;
     a.dtab_pitch = 0;
+    a.dict = nullptr;
+    a.codes = nullptr;
     std::pair<hipEvent_t, hipEvent_t> ev;
     timer_begin(c, DMX_T_ESTEP, &ev);
     int form = DMX_FORM_DIRECT;
     DMX_TRY(prepare_dictionary(c, with_doublets != 0, a, &form));  // part of the E-step's time
     if (form == DMX_FORM_DICT)
         HIP_TRY(dmx::launch_estep_dict(c->stream, a, with_doublets != 0));
+    else if (form == DMX_FORM_DICT_BLOCK)
+        HIP_TRY(dmx::launch_estep_dict_block(c->stream, a));
     else
         HIP_TRY(dmx::launch_estep(c->stream, a, with_doublets != 0));
     c->estep_form = form;

@@ -425,6 +425,150 @@ hipError_t launch_build_dict(hipStream_t st, const float *prob, long long rows, 
     return hipGetLastError();
 }
 
+// ------------------------------------------------------------------------------------
+// Wide doublet tables (K > DICT_LANE_K, <= 4 distinct values per row): one 256-thread workgroup per barcode and tile of
+// A * 256 options, like k_estep_block (kernels.hip) - but where that kernel evaluates numpy's log per (call, option),
+// this one evaluates the 16 logs of a call's value pairs (c1, c2) once, by 16 threads, and every option looks its log up:
+//   sh_lp[c][c1 * 4 + c2]   float64 log(((d[c1] + d[c2]) * 0.5) * keep_c + floor_c) of the chunk's call c (demux.py:190, 261)
+//   sh_code[g][c]           byte 8 * (index of genotype g's value in the dictionary of call c's row), 8 calls per 8 bytes
+// An option (g1, g2) adds, call after call, sh_lp[c][code[g1][c] * 4 + code[g2][c]]: per eight calls two ds_read_b64 of
+// codes, two v_lshl_add (the eight byte offsets (c1 * 4 + c2) * 8 at once), and per call one byte extraction, one
+// ds_read_b64, one v_add_f64 - against ~68 VALU issue cycles of log in the direct form.  Same float32 operations on
+// the same operands, same addition order: bit-identical logits.
+// ------------------------------------------------------------------------------------
+constexpr int DB_C = 64;                   // calls per chunk
+constexpr int DB_CODE_STRIDE = DB_C + 8;   // bytes between the code rows of two genotypes: 18 words, so that the 8-byte reads
+                                           // of 32 lanes with consecutive second genotypes hit 32 different bank pairs
+
+template <int A>
+__global__ __launch_bounds__(256) void k_estep_dict_block(EstepArgs a, int k_base)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const long long b = a.order[blockIdx.x];
+    const int K = a.K, G = a.G;
+    // LDS carve: logs [C][16] f64 | rows [C] | keep [C] | floor [C] | codes [G][DB_CODE_STRIDE] bytes
+    double *sh_lp = (double *)smem;
+    unsigned *sh_row = (unsigned *)(sh_lp + DB_C * 16);
+    float *sh_keep = (float *)(sh_row + DB_C);
+    float *sh_floor = sh_keep + DB_C;
+    unsigned char *sh_code = (unsigned char *)(sh_floor + DB_C);
+    const unsigned lp_off = (unsigned)(unsigned long long)(__attribute__((address_space(3))) unsigned char *)smem;
+
+    unsigned a1[A], a2[A];  // LDS byte address of the code rows of this thread's options' genotypes
+#pragma unroll
+    for (int s = 0; s < A; s++) {
+        const int k = k_base + s * 256 + tid;
+        const unsigned pr = a.opt_pairs[k < K ? k : K - 1];
+        a1[s] = (pr & 0xFFFFu) * (unsigned)DB_CODE_STRIDE;
+        a2[s] = (pr >> 16) * (unsigned)DB_CODE_STRIDE;
+    }
+    double acc[A];
+#pragma unroll
+    for (int s = 0; s < A; s++) acc[s] = 0.0;
+
+    const unsigned *__restrict__ words = (const unsigned *)(a.pairs + a.pair_ptr[b]);
+    const unsigned *__restrict__ rows = a.call_rows + 2 * a.pair_ptr[b];
+    const int n_calls = 2 * (int)(a.pair_ptr[b + 1] - a.pair_ptr[b]);  // incl. neutral padding, multiple of 8
+    const int code_pitch = dict_code_pitch(G);
+    const int e = tid & 15, cq = tid >> 4;  // phase A: pair entry and call (cq, cq + 16, cq + 32, cq + 48)
+    const unsigned c1 = (unsigned)e >> 2, c2 = (unsigned)e & 3u;
+    for (int pos = 0; pos < n_calls; pos += DB_C) {
+        const int n = (n_calls - pos) < DB_C ? (n_calls - pos) : DB_C;  // multiple of 8
+        __syncthreads();
+        if (tid < n) {
+            const int ci = pos + tid;
+            const int w = (ci >> 1) * 8 + (ci & 1);
+            sh_row[tid] = rows[ci];
+            sh_keep[tid] = __uint_as_float(words[w + 2]);
+            sh_floor[tid] = __uint_as_float(words[w + 4]);
+        }
+        __syncthreads();
+        // codes: wave w stages calls w, w + 4, ...: one coalesced read of the row's G bytes, transposed byte stores
+        for (int c = wave; c < n; c += 4) {
+            const unsigned char *row = a.codes + (size_t)sh_row[c] * code_pitch;
+            for (int g = lane; g < G; g += 64) sh_code[g * DB_CODE_STRIDE + c] = row[g];
+        }
+        // logs: 16 pair entries of every call, two calls per packed log
+#pragma unroll
+        for (int h = 0; h < 2; h++) {
+            const int cx = cq + 32 * h, cy = cx + 16;
+            if (cx < n) {  // n is a multiple of 8: cy < n need not hold
+                const int cyc = cy < n ? cy : cx;
+                const float *dx = a.dict + (size_t)sh_row[cx] * DICT_CAP, *dy = a.dict + (size_t)sh_row[cyc] * DICT_CAP;
+                npm::f32x2 t;
+                t.x = ((dx[c1] + dx[c2]) * 0.5f) * sh_keep[cx];
+                t.y = ((dy[c1] + dy[c2]) * 0.5f) * sh_keep[cyc];
+                t.x = t.x + sh_floor[cx];
+                t.y = t.y + sh_floor[cyc];
+                const npm::f32x2 l2 = npm::log_f32_hot2(t);
+                sh_lp[cx * 16 + e] = (double)l2.x;
+                if (cy < n) sh_lp[cy * 16 + e] = (double)l2.y;
+            }
+        }
+        __syncthreads();
+        for (int c0 = 0; c0 < n; c0 += 8) {
+#pragma unroll
+            for (int s = 0; s < A; s++) {
+                if (k_base + s * 256 + wave * 64 >= K) continue;  // wave-uniform: this wave's slot lies past the last option
+                const uint2 w1 = *(const uint2 *)(sh_code + a1[s] + c0), w2 = *(const uint2 *)(sh_code + a2[s] + c0);
+                const unsigned lo = (w1.x << 2) + w2.x, hi = (w1.y << 2) + w2.y;  // bytes: (c1 * 4 + c2) * 8 <= 120, no carries
+                double v[8];
+#pragma unroll
+                for (int q = 0; q < 8; q++) {
+                    const unsigned idx = ((q < 4 ? lo : hi) >> (8 * (q & 3))) & 0xFFu;
+                    v[q] = *lds_f64(lp_off + idx + (unsigned)((c0 + q) * 128));
+                }
+#pragma unroll
+                for (int q = 0; q < 8; q++) acc[s] += v[q];  // call order
+            }
+        }
+    }
+    __syncthreads();
+    // logits of this tile of options; the softmax over complete rows is k_softmax_rows' (kernels.hip)
+#pragma unroll
+    for (int s = 0; s < A; s++) {
+        const int k = k_base + s * 256 + tid;
+        if (k < K) {
+            const double t = (double)a.pen[k] + acc[s];
+            float l = (float)t;
+            if (a.prior) {
+                const size_t o = (size_t)b * K + k;
+                if (a.prior_dtype == DMX_F32)
+                    l = l + ((const float *)a.prior)[o];
+                else
+                    l = (float)((double)l + ((const double *)a.prior)[o]);
+            }
+            a.logits[(size_t)b * K + k] = l;
+        }
+    }
+}
+
+template <int A>
+static hipError_t launch_dict_block(hipStream_t st, const EstepArgs &a, int k_base)
+{
+    const size_t bytes = (size_t)DB_C * 16 * 8 + (size_t)DB_C * 12 + (size_t)a.G * DB_CODE_STRIDE;
+    hipError_t e = hipFuncSetAttribute((const void *)k_estep_dict_block<A>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL((k_estep_dict_block<A>), dim3((unsigned)a.B), dim3(256), bytes, st, a, k_base);
+    return hipGetLastError();
+}
+
+// doublet tables of more than DICT_LANE_K options: option tiles, then the softmax over complete rows
+hipError_t launch_estep_dict_block(hipStream_t st, const EstepArgs &a)
+{
+    if (a.B == 0) return hipSuccess;
+    const int K = a.K, need = (K + 255) / 256;
+    const int tile = need <= 2 ? 2 : need <= 4 ? 4 : need <= 8 ? 8 : need <= 12 ? 12 : need <= 17 ? 17 : need <= 24 ? 12 : 17;
+    for (int k_base = 0; k_base < K; k_base += tile * 256) {
+        const hipError_t e = tile == 2 ? launch_dict_block<2>(st, a, k_base) : tile == 4 ? launch_dict_block<4>(st, a, k_base)
+                           : tile == 8 ? launch_dict_block<8>(st, a, k_base) : tile == 12 ? launch_dict_block<12>(st, a, k_base)
+                                                                                            : launch_dict_block<17>(st, a, k_base);
+        if (e != hipSuccess) return e;
+    }
+    return launch_softmax_rows(st, a);
+}
+
 static int dict_lanes(int K, bool pairs)  // lanes per barcode of the E-step kernel
 {
     return K <= 16 && !pairs ? 4 : K <= 32 ? 8 : K <= 64 ? 16 : K <= 128 ? 32 : 64;

@@ -63,13 +63,17 @@ struct EstepArgs {
                                   // (estep_dict.hip: DictRow)
     unsigned dtab_bytes;          // extent of dtab (< 4 GiB: buffer addressing)
     int dtab_pitch;
+    // wide doublet tables (K > DICT_LANE_K): the workgroup-per-barcode dictionary kernel reads the two arrays of
+    // launch_build_dict themselves
+    const float *dict;            // [rows, DICT_CAP]
+    const unsigned char *codes;   // [rows, dict_code_pitch(G)] 8 x index of every genotype's value in its row's dictionary
 };
 
 constexpr int CALL_PAD_PAIRS = 64;     // readable neutral records behind the last barcode's row (pairs and call_rows)
 constexpr int DICT_CAP = 8;            // distinct values per row the dictionary form handles (singlet runs)
 constexpr int DICT_PAIR_CAP = 4;       // ... in doublet runs (10 pair values)
 constexpr int DICT_LANE_K = 256;       // option tables up to this width take the lane-per-four-options dictionary kernel
-inline int dict_code_pitch(int n) { return (n + 3) & ~3; }  // bytes between the rows of a code table of n codes per row
+__host__ __device__ inline int dict_code_pitch(int n) { return (n + 3) & ~3; }  // bytes between the rows of a code table of n codes per row
 
 constexpr int DENSE_SLOTS = 1024;            // hashed counters of the dense-call statistic
 hipError_t launch_sum_dense(hipStream_t st, unsigned long long *counters);
@@ -132,6 +136,7 @@ hipError_t launch_probs_from_betas_f64(hipStream_t st, const double *betas, cons
 // sets flags[0] bit 0 when a value lies outside [0, 1] or is not finite
 hipError_t launch_check_unit_range(hipStream_t st, const float *x, long long n, int *flags);
 hipError_t launch_estep(hipStream_t st, const EstepArgs &a, bool pairs);
+hipError_t launch_softmax_rows(hipStream_t st, const EstepArgs &a);  // rows left as logits by the option-tile launches
 // dictionary form (estep_dict.hip): distinct values and codes of every row of `prob`; stat[0] = most distinct values
 // in a row (DICT_CAP + 1: some row has more)
 hipError_t launch_build_dict(hipStream_t st, const float *prob, long long rows, int G, float *dict, unsigned char *codes, unsigned *stat);
@@ -140,6 +145,7 @@ int dict_table_pitch(int distinct, int K, bool pairs);
 hipError_t launch_pack_rows(hipStream_t st, const float *dict, const unsigned char *codes, const unsigned *opt_pairs, long long rows, int G,
                             int K, bool pairs, int distinct, unsigned char *table);
 hipError_t launch_estep_dict(hipStream_t st, const EstepArgs &a, bool pairs);
+hipError_t launch_estep_dict_block(hipStream_t st, const EstepArgs &a);  // doublet tables of more than DICT_LANE_K options
 hipError_t launch_mstep(hipStream_t st, const MstepArgs &a);
 // sums the item partials of variants [v0, v1) and redoes, in the reference's order, the sums whose float32
 // rounding could depend on the order (redo: queue of capacity (n_items / 2 + 1) * G entries, n_redo: its counter)

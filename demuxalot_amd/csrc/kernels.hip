@@ -1732,7 +1732,14 @@ hipError_t launch_estep(hipStream_t st, const EstepArgs &a, bool pairs)
                            : tile == 12 ? launch_block<12>(st, a, k_base) : launch_block<17>(st, a, k_base);
         if (e != hipSuccess) return e;
     }
-    const size_t row_bytes = ((size_t)K + (size_t)a.sum_plan_values) * 4;  // the row + the values of the sum plan
+    return launch_softmax_rows(st, a);
+}
+
+// softmax, bitmaps and barcode codes of complete logit rows (after the option-tile launches of the workgroup-per-barcode forms)
+hipError_t launch_softmax_rows(hipStream_t st, const EstepArgs &a)
+{
+    if (a.B == 0) return hipSuccess;
+    const size_t row_bytes = ((size_t)a.K + (size_t)a.sum_plan_values) * 4;  // the row + the values of the sum plan
     if (row_bytes <= 150 * 1024 && a.sum_plan) {
         const hipError_t e = hipFuncSetAttribute((const void *)k_softmax_rows<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)row_bytes);
         if (e != hipSuccess) return e;

@@ -44,7 +44,8 @@ def run_estep(ctx, table, pen, doublets, mode):
 @pytest.mark.parametrize('n_genotypes,doublet_prior,n_values', [
     (2, 0., 2), (5, 0., 3), (8, 0.35, 3), (8, 0.35, 4), (20, 0., 4), (20, 0.25, 4), (22, 0.25, 2), (33, 0., 8),
     (64, 0., 4), (64, 0., 8), (64, 0., 1), (70, 0., 5), (130, 0., 4), (130, 0., 7), (256, 0., 3), (3, 0., 3), (4, 0.3, 2),
-    (16, 0., 8), (17, 0., 2), (32, 0., 4), (129, 0., 8)])
+    (16, 0., 8), (17, 0., 2), (32, 0., 4), (129, 0., 8),
+    (23, 0.2, 4), (30, 0.2, 3), (64, 0.25, 4), (100, 0.1, 1), (130, 0.25, 2)])  # the last five: doublet tables of more than 256 options
 def test_dictionary_form_equals_direct_form(oracle, n_genotypes, doublet_prior, n_values):
     from demuxalot_amd import Demultiplexer
     from demuxalot_amd.device import DeviceContext
@@ -59,7 +60,8 @@ def test_dictionary_form_equals_direct_form(oracle, n_genotypes, doublet_prior, 
         l_dir, p_dir, form_dir = run_estep(ctx, table, pen, doublet_prior != 0, 'never')
         l_dic, p_dic, form_dic = run_estep(ctx, table, pen, doublet_prior != 0, 'auto')
         assert form_dir == ('direct', 0)
-        assert form_dic[0] == 'dict' and 1 <= form_dic[1] <= n_values, form_dic
+        n_options = len(pen)
+        assert form_dic[0] == ('dict_block' if doublet_prior and n_options > 256 else 'dict') and 1 <= form_dic[1] <= n_values, form_dic
         fio.assert_bitwise(l_dic, l_dir, 'logits: dictionary vs direct form')
         fio.assert_bitwise(p_dic, p_dir, 'posteriors: dictionary vs direct form')
         want = oracle.barcode_logits(variant, cb, e, table, n_barcodes, doublet_prior, log_impl='npsimd')
@@ -74,7 +76,7 @@ def test_dictionary_form_equals_direct_form(oracle, n_genotypes, doublet_prior, 
 
 @pytest.mark.parametrize('n_genotypes,doublet_prior,n_values,why', [
     (64, 0., 9, 'nine values in a row'), (12, 0.3, 5, 'five values with doublets'), (64, 0., 64, 'all distinct'),
-    (300, 0., 3, 'more than 256 options'), (30, 0.2, 3, 'more than 256 options (doublets)')])
+    (300, 0., 3, 'more than 256 options'), (30, 0.2, 5, 'five values with doublets, more than 256 options')])
 def test_rows_with_many_values_take_the_direct_form(n_genotypes, doublet_prior, n_values, why):
     from demuxalot_amd import Demultiplexer
     from demuxalot_amd.device import DeviceContext
