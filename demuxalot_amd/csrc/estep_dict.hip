@@ -453,7 +453,10 @@ __global__ __launch_bounds__(256) void k_estep_dict_block(EstepArgs a, int k_bas
     float *sh_keep = (float *)(sh_row + DB_C);
     float *sh_floor = sh_keep + DB_C;
     unsigned char *sh_code = (unsigned char *)(sh_floor + DB_C);
-    const unsigned lp_off = (unsigned)(unsigned long long)(__attribute__((address_space(3))) unsigned char *)smem;
+    // The kernel's only LDS is this dynamic array, so the logs start at LDS address 0 and a lookup's address is (code byte) +
+    // an immediate; checked rather than assumed.
+    if ((unsigned)(unsigned long long)(__attribute__((address_space(3))) unsigned char *)smem != 0u) __builtin_trap();
+    constexpr unsigned lp_off = 0u;
 
     unsigned a1[A], a2[A];  // LDS byte address of the code rows of this thread's options' genotypes
 #pragma unroll
@@ -507,16 +510,28 @@ __global__ __launch_bounds__(256) void k_estep_dict_block(EstepArgs a, int k_bas
             }
         }
         __syncthreads();
-        for (int c0 = 0; c0 < n; c0 += 8) {
+        // The chunk's eight groups of eight calls are unrolled so that every LDS address is (extracted byte) + an
+        // immediate: one v_bfe_u32 per lookup.  (With the group offset in a register the compiler spent a v_add_u32_sdwa
+        // per lookup - a slow form on this chip: the kernel sat at 100 % VALU busy with 3.5 instructions per term.)
+#pragma unroll
+        for (int c0 = 0; c0 < DB_C; c0 += 8) {
+            if (c0 >= n) break;  // workgroup-uniform
+            // (slots past the last option - the tail of the last tile - walk option K - 1 and are not stored: a test per
+            // slot would cut the straight-line code into A serial chains of two LDS latencies.)  The codes of slot s + 1
+            // are requested before the lookups of slot s.
+            uint2 w1 = *(const uint2 *)(sh_code + a1[0] + c0), w2 = *(const uint2 *)(sh_code + a2[0] + c0);
 #pragma unroll
             for (int s = 0; s < A; s++) {
-                if (k_base + s * 256 + wave * 64 >= K) continue;  // wave-uniform: this wave's slot lies past the last option
-                const uint2 w1 = *(const uint2 *)(sh_code + a1[s] + c0), w2 = *(const uint2 *)(sh_code + a2[s] + c0);
                 const unsigned lo = (w1.x << 2) + w2.x, hi = (w1.y << 2) + w2.y;  // bytes: (c1 * 4 + c2) * 8 <= 120, no carries
+                if (s + 1 < A) {
+                    w1 = *(const uint2 *)(sh_code + a1[s + 1] + c0);
+                    w2 = *(const uint2 *)(sh_code + a2[s + 1] + c0);
+                }
                 double v[8];
 #pragma unroll
                 for (int q = 0; q < 8; q++) {
-                    const unsigned idx = ((q < 4 ? lo : hi) >> (8 * (q & 3))) & 0xFFu;
+                    unsigned idx;  // (asm: the compiler's own selection is v_add_u32_sdwa / v_mov_b32_sdwa, slow forms here)
+                    asm("v_bfe_u32 %0, %1, %2, 8" : "=v"(idx) : "v"(q < 4 ? lo : hi), "n"(8 * (q & 3)));
                     v[q] = *lds_f64(lp_off + idx + (unsigned)((c0 + q) * 128));
                 }
 #pragma unroll
@@ -559,7 +574,9 @@ hipError_t launch_estep_dict_block(hipStream_t st, const EstepArgs &a)
 {
     if (a.B == 0) return hipSuccess;
     const int K = a.K, need = (K + 255) / 256;
-    const int tile = need <= 2 ? 2 : need <= 4 ? 4 : need <= 8 ? 8 : need <= 12 ? 12 : need <= 17 ? 17 : need <= 24 ? 12 : 17;
+    int tile = need <= 2 ? 2 : need <= 4 ? 4 : need <= 8 ? 8 : need <= 12 ? 12 : need <= 17 ? 17 : need <= 24 ? 12 : 17;
+    static const int forced = std::getenv("DEMUXALOT_AMD_DICT_TILE") ? std::atoi(std::getenv("DEMUXALOT_AMD_DICT_TILE")) : 0;  // tuning aid
+    if (forced == 2 || forced == 4 || forced == 8 || forced == 12 || forced == 17) tile = forced;
     for (int k_base = 0; k_base < K; k_base += tile * 256) {
         const hipError_t e = tile == 2 ? launch_dict_block<2>(st, a, k_base) : tile == 4 ? launch_dict_block<4>(st, a, k_base)
                            : tile == 8 ? launch_dict_block<8>(st, a, k_base) : tile == 12 ? launch_dict_block<12>(st, a, k_base)
