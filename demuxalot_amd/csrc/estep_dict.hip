@@ -207,8 +207,11 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(LB <= 16 ? 4
     constexpr int PC = 64 / NE;
     constexpr int CBB = 2 * PC / NB;
     static_assert(CBB >= 1 && CBB * NB == 2 * PC, "a batch = two 64-lane passes of phase A");
-    constexpr int STRIDE = (CBB * NE * 8 + 127) / 128 * 128;  // LDS bytes per barcode and buffer; multiple of 128 so that
-    constexpr int BUFSZ = NB * STRIDE;                         // base | code (< 128) is base + code
+    // LDS bytes per barcode and buffer: the batch's logs plus one entry row of skew, so that the NB barcodes' regions start
+    // NE * 2 banks apart (a power-of-two stride put them on the same banks: 36 % of the LDS cycles were conflicts); a
+    // multiple of NE * 8, so that base | code (< NE * 8) is base + code
+    constexpr int STRIDE = CBB * NE * 8 + (NB > 1 ? NE * 8 : 0);
+    constexpr int BUFSZ = NB * STRIDE;
     constexpr int NEV = PAIRS ? 10 : NE;                       // entries that exist
     constexpr int LE = 4 * LB < 64 ? 4 * LB : 64;              // epilogue: lanes per barcode,
     constexpr int AE = 4 * LB / LE;                            // register slots per lane,

@@ -5,7 +5,7 @@ OUT=gpurun_out/dict_$WL
 mkdir -p $OUT
 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 scripts/predict_loop.py $WL 6 auto > $OUT/trace.log 2>&1
 cp $OUT/trace/*/*kernel_stats.csv $OUT/kernel_stats.csv 2>/dev/null
-for abl in 1 2 3; do DEMUXALOT_AMD_DICT_ABLATE=$abl timeout 200 python3 scripts/predict_loop.py $WL 6 auto >> $OUT/ablate.log 2>&1; done
+for abl in 1 2 3 4 5; do DEMUXALOT_AMD_DICT_ABLATE=$abl timeout 200 python3 scripts/predict_loop.py $WL 6 auto >> $OUT/ablate.log 2>&1; done
 run() { name=$1; shift; timeout 300 rocprofv3 --kernel-trace --pmc "$@" --output-format csv -d $OUT/pmc_$name -- python3 scripts/predict_loop.py $WL 3 auto > $OUT/pmc_$name.log 2>&1; }
 run sq1 SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY
 run sq2 SQ_INSTS_LDS SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_VMEM_RD SQ_ACTIVE_INST_VMEM SQ_INSTS_SALU SQ_WAIT_INST_LDS
