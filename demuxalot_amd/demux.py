@@ -26,7 +26,8 @@ import numpy as np
 import pandas as pd
 
 from . import _lib
-from .device import DeviceContext, default_device, get_context, shared_context_lock
+from .device import (DeviceContext, acquire_private_context, default_device, get_context, release_private_context,
+                     shared_context_lock)
 
 _MOLECULE_CALL_DTYPE = [('variant_id', 'int32'), ('snp_id', 'int32'), ('compressed_cb', 'int32'),
                         ('molecule_id', 'int32'), ('p_base_wrong', 'float32'), ('p_molecule_aligned_wrong', 'float32')]
@@ -215,8 +216,9 @@ class DevicePosteriors:
     nothing of size [B, K] crosses PCIe unless to_dataframes() / rows() ask for it.
     Owns a private device context; close() (or garbage collection) releases the GPU memory."""
 
-    def __init__(self, ctx, barcodes, column_names, index_name=None):
+    def __init__(self, ctx, barcodes, column_names, index_name=None, pooled=True):
         self._ctx = ctx
+        self._pooled = pooled  # False: a context set up elsewhere (e.g. with a communicator attached): destroyed on close
         self.barcodes = list(barcodes)
         self.columns = list(column_names)
         self.index_name = index_name
@@ -271,7 +273,10 @@ class DevicePosteriors:
 
     def close(self):
         if self._ctx is not None:
-            self._ctx.close()
+            if self._pooled:
+                release_private_context(self._ctx)
+            else:
+                self._ctx.close()
             self._ctx = None
 
     def __enter__(self):
@@ -325,7 +330,7 @@ class Demultiplexer:
                 p_genotype_clip=p_genotype_clip, doublet_prior=doublet_prior, barcode_prior_logits=barcode_prior_logits)
             return genotypes._with_betas(genotypes.get_betas() + last['genotype_addition']), probs_df
         if on_device:
-            ctx = DeviceContext(default_device())
+            ctx = acquire_private_context()
             try:
                 _pack_on_device(chromosome2compressed_snp_calls, genotypes, barcode_handler.n_barcodes, True,
                                 fetch_betas=False, ctx=ctx)
@@ -369,7 +374,7 @@ class Demultiplexer:
             assert barcode_prior_logits.shape == (barcode_handler.n_barcodes, len(penalties)), 'wrong shape of priors'
         aggregate = bool(Demultiplexer.aggregate_on_snps)  # read once, like the other class-level knobs of a run
 
-        ctx = DeviceContext(default_device())
+        ctx = acquire_private_context()
         try:
             ctx.set_keep_molecule_calls(aggregate)
             _ctx, prior_betas = _pack_on_device(chromosome2compressed_snp_calls, genotypes, barcode_handler.n_barcodes,
@@ -401,7 +406,7 @@ class Demultiplexer:
                 }
                 genotype_addition = ctx.mstep(Demultiplexer.contribution_power)
         finally:
-            ctx.close()
+            release_private_context(ctx)
 
     @staticmethod
     def predict_posteriors(chromosome2compressed_snp_calls,
@@ -434,7 +439,7 @@ class Demultiplexer:
             return ctx.estep(penalties, with_doublets=doublet_prior != 0, fetch_logits=fetch, fetch_probs=fetch)
 
         if on_device:
-            ctx = DeviceContext(default_device())
+            ctx = acquire_private_context()
             try:
                 run(ctx, False)
             except BaseException:

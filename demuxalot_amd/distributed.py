@@ -418,7 +418,7 @@ def learn_genotypes(chromosome2compressed_snp_calls, genotypes, barcode_handler,
             ctx.close()
     learnt = genotypes._with_betas(genotypes.get_betas() + addition)
     if results == 'device':
-        local = DevicePosteriors(ctx, barcode_handler.ordered_barcodes[lo:hi], columns)
+        local = DevicePosteriors(ctx, barcode_handler.ordered_barcodes[lo:hi], columns, pooled=False)
         return learnt, ShardedPosteriors(local, plane, lo, hi, barcode_handler.ordered_barcodes)
     probs = _collect(plane, probs, results)
     probs_df = None if probs is None else pd.DataFrame(data=probs, index=barcode_handler.ordered_barcodes, columns=columns)
@@ -513,7 +513,7 @@ def predict_posteriors(chromosome2compressed_snp_calls, genotypes, barcode_handl
             ctx.close()
     columns = _option_names(genotypes.genotype_names, doublet_prior)
     if results == 'device':
-        local = DevicePosteriors(ctx, barcode_handler.ordered_barcodes[lo:hi], columns, index_name='BARCODE')
+        local = DevicePosteriors(ctx, barcode_handler.ordered_barcodes[lo:hi], columns, index_name='BARCODE', pooled=False)
         return ShardedPosteriors(local, plane, lo, hi, barcode_handler.ordered_barcodes)
     frames = []
     for block in (_collect(plane, logits, results), _collect(plane, probs, results)):

@@ -301,3 +301,45 @@ def test_bench_with_two_ranks_on_one_gpu(scaling):
     assert line['n_gpus'] == 2 and line['scaling'] == scaling and line['value'] > 0
     assert line['config']['barcodes_total'] == (20_000 if scaling == 'strong' else 40_000)
     assert len(line['config']['runtimes']['hip']) == 1 and line['exchange_ms_per_step'] > 0
+
+
+@pytest.mark.parametrize('name', ['f2_synthetic_g4.npz', 'f1_synthetic_default.npz'])
+def test_dictionary_form_on_the_padded_multi_rank_table(name, monkeypatch):
+    """With a communicator attached genotype_prob lives in the padded slice layout and the E-step records / call rows
+    are re-based to it; the dictionary form (forced on: these problems are too small for it by default) must walk that
+    layout too - sharded predict bitwise, sharded EM within the contract, at world 3."""
+    from demuxalot_amd import distributed
+    monkeypatch.setenv('DEMUXALOT_AMD_ESTEP_DICT', 'always')  # read by the contexts the ranks create
+    fx = fio.load(name)
+    calls, genotypes, handler = fio.product_inputs(fx)
+    kwargs = dict(n_iterations=int(fx['em0_n_iterations']), p_genotype_clip=float(fx['em0_clip']), doublet_prior=float(fx['em0_dp']))
+    shared = ThreadWorld(3)
+
+    def rank_body(plane):
+        learnt, probs_df = distributed.learn_genotypes(calls, genotypes, handler, plane, barcode_prior_logits=fx.get('em0_prior_logits'),
+                                                       force_comm=True, **kwargs)
+        logits_df, p_df = distributed.predict_posteriors(calls, genotypes, handler, plane, p_genotype_clip=float(fx['predict0_clip']),
+                                                         doublet_prior=float(fx['predict0_dp']))
+        # one explicit look at the form on a padded table: this rank's shard, communicator attached
+        from demuxalot_amd.device import DeviceContext
+        ctx = DeviceContext(0)
+        try:
+            distributed.attach_communicator(ctx, plane)
+            from demuxalot_amd.demux import _pack_on_device
+            lo, hi = [int(x) for x in distributed.partition_barcodes(distributed.calls_per_barcode(calls, handler.n_barcodes), plane.world)[plane.rank:plane.rank + 2]]
+            _pack_on_device(distributed.shard_containers(calls, lo, hi), genotypes, hi - lo, False, fetch_betas=False, ctx=ctx)
+            ctx.set_addition(None)
+            ctx.probs_from_betas(0.01, fetch=False)
+            ctx.estep(np.zeros(genotypes.n_genotypes, dtype=np.float32), with_doublets=False, fetch_logits=False, fetch_probs=False)
+            form = ctx.estep_form()
+        finally:
+            ctx.close()
+        return learnt.variant_betas, probs_df.values, logits_df.values, p_df.values, form
+
+    want = fx[f'em0_it{kwargs["n_iterations"] - 1}_probs']
+    for betas, probs, logits, predicted, form in shared.run(rank_body):
+        assert form[0] == 'dict', form
+        assert np.allclose(betas, fx['em0_learnt_betas'], rtol=3e-7, atol=0)
+        assert np.array_equal(probs.argmax(1), want.argmax(1)) and np.abs(probs - want).max() <= 1e-5
+        fio.assert_bitwise(logits, fx['predict0_logits'], 'sharded predict logits through the dictionary form')
+        fio.assert_bitwise(predicted, fx['predict0_probs'], 'sharded predict posteriors through the dictionary form')
