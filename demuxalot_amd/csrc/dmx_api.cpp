@@ -274,6 +274,13 @@ void release_problem(dmx_ctx *c)
         c->d_recv = nullptr;
         c->recv_bytes = 0;
     }
+    dev_free(c, &c->d_erow, (size_t)c->V);
+    dev_free(c, &c->d_chunk_vars, (size_t)c->V);
+    dev_free(c, &c->d_chunk_items, (size_t)c->n_items);
+    c->n_chunks = 0;
+    c->sub_rows = 0;
+    c->chunk_var_off.clear();
+    c->chunk_item_off.clear();
     c->sliced = c->add_partial = false;
     c->slice_rows = c->prob_rows = 0;
     c->cut.clear();
@@ -465,30 +472,30 @@ int host_stage(dmx_ctx *c, size_t bytes)
 // runs `op` on the caller's collectives: device [src, src + bytes_in) -> host stage at byte offset off_in, callback,
 // host stage [off_out, off_out + bytes_out) -> device dst
 int host_collective(dmx_ctx *c, int op, const void *src, size_t off_in, size_t bytes_in, void *dst, size_t off_out, size_t bytes_out,
-                    size_t total_bytes, int64_t count, int dtype, const char *what)
+                    size_t total_bytes, int64_t count, int dtype, const char *what, hipStream_t st)
 {
     DMX_TRY(host_stage(c, total_bytes));
     char *h = (char *)c->h_stage;
-    if (bytes_in) HIP_TRY(hipMemcpyAsync(h + off_in, src, bytes_in, hipMemcpyDeviceToHost, c->stream));
-    HIP_TRY(hipStreamSynchronize(c->stream));
+    if (bytes_in) HIP_TRY(hipMemcpyAsync(h + off_in, src, bytes_in, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
     const int rc = c->host_coll(c->host_user, op, h, count, dtype);
     if (rc != 0) return fail(DMX_ERR_RCCL, "the caller's collective (%s) failed with %d", what, rc);
-    if (bytes_out) HIP_TRY(hipMemcpyAsync(dst, h + off_out, bytes_out, hipMemcpyHostToDevice, c->stream));
-    HIP_TRY(hipStreamSynchronize(c->stream));  // the stage is reused by the next collective
+    if (bytes_out) HIP_TRY(hipMemcpyAsync(dst, h + off_out, bytes_out, hipMemcpyHostToDevice, st));
+    HIP_TRY(hipStreamSynchronize(st));  // the stage is reused by the next collective
     return 0;
 }
 
 // recv[block] = sum over ranks of their send[rank * block ...]
-int coll_reduce_scatter(dmx_ctx *c, const void *send, void *recv, size_t block, bool f64)
+int coll_reduce_scatter(dmx_ctx *c, const void *send, void *recv, size_t block, bool f64, hipStream_t st)
 {
     const size_t elem = f64 ? 8 : 4;
     if (c->comm) {
-        ncclResult_t r = g_rccl.ReduceScatter(send, recv, block, f64 ? ncclDouble : ncclFloat, ncclSum, c->comm, c->stream);
+        ncclResult_t r = g_rccl.ReduceScatter(send, recv, block, f64 ? ncclDouble : ncclFloat, ncclSum, c->comm, st);
         return r == ncclSuccess ? 0 : fail(DMX_ERR_RCCL, "ncclReduceScatter failed: %s", rccl_error(r));
     }
     const size_t total = block * elem * c->nranks;
     return host_collective(c, DMX_COLL_REDUCE_SCATTER, send, 0, total, recv, block * elem * c->rank, block * elem, total, (int64_t)block,
-                           f64 ? DMX_F64 : DMX_F32, "reduce-scatter");
+                           f64 ? DMX_F64 : DMX_F32, "reduce-scatter", st);
 }
 
 // float32 table of nranks blocks, this rank's block filled: everybody's blocks on return
@@ -499,7 +506,7 @@ int coll_all_gather(dmx_ctx *c, float *table, size_t block, const char *what)
         return r == ncclSuccess ? 0 : fail(DMX_ERR_RCCL, "ncclAllGather (%s) failed: %s", what, rccl_error(r));
     }
     const size_t total = block * 4 * c->nranks, mine = block * 4 * c->rank;
-    return host_collective(c, DMX_COLL_ALL_GATHER, table + c->rank * block, mine, block * 4, table, 0, total, total, (int64_t)block, DMX_F32, what);
+    return host_collective(c, DMX_COLL_ALL_GATHER, table + c->rank * block, mine, block * 4, table, 0, total, total, (int64_t)block, DMX_F32, what, c->stream);
 }
 
 int coll_all_reduce(dmx_ctx *c, void *buf, size_t count, bool f64)
@@ -509,7 +516,7 @@ int coll_all_reduce(dmx_ctx *c, void *buf, size_t count, bool f64)
         return r == ncclSuccess ? 0 : fail(DMX_ERR_RCCL, "ncclAllReduce failed: %s", rccl_error(r));
     }
     const size_t total = count * (f64 ? 8 : 4);
-    return host_collective(c, DMX_COLL_ALL_REDUCE, buf, 0, total, buf, 0, total, total, (int64_t)count, f64 ? DMX_F64 : DMX_F32, "all-reduce");
+    return host_collective(c, DMX_COLL_ALL_REDUCE, buf, 0, total, buf, 0, total, total, (int64_t)count, f64 ? DMX_F64 : DMX_F32, "all-reduce", c->stream);
 }
 
 int layout_exchange(dmx_ctx *c)
@@ -553,8 +560,68 @@ int layout_exchange(dmx_ctx *c)
         HIP_TRY(dmx::launch_remap_row_offsets(st, c->d_call_pairs, c->n_pairs, (unsigned)G * 4u, c->d_prow, c->d_call_rows));
         if (c->d_tile_stream) HIP_TRY(dmx::launch_remap_row_offsets(st, c->d_tile_stream, c->n_pairs, (unsigned)G * 4u, c->d_prow, nullptr));
         const size_t elem = c->reduce_dtype == DMX_F64 ? 8 : 4;
-        c->exch_bytes = (size_t)new_rows * G * 8;  // float64 sums; also the float32 staging of the addition gather
-        c->recv_bytes = (size_t)rows * G * elem;
+        // ---- chunked (pipelined) exchange: opt-in (dmx_set_exchange_chunks, DEMUXALOT_AMD_EXCHANGE=pipelined[:R]) ----
+        int want_chunks = c->exch_chunks;
+        if (exchange && std::strncmp(exchange, "pipelined", 9) == 0) want_chunks = exchange[9] == ':' ? std::atoi(exchange + 10) : 4;
+        c->n_chunks = 0;
+        c->sub_rows = rows;
+        long long send_rows = new_rows;
+        if (want_chunks > 1 && rows >= 4 * want_chunks && c->n_items > 0) {
+            const int R = std::min(want_chunks, 16);
+            const long long sub = (rows + R - 1) / R;
+            c->n_chunks = R;
+            c->sub_rows = sub;
+            send_rows = (long long)R * n * sub;
+            // chunk j = rows [j * sub, (j + 1) * sub) of every rank's slice; in the send buffer chunk-major, rank-major inside
+            std::vector<int> erow((size_t)V), chunk_of((size_t)V), vars;
+            vars.reserve((size_t)V);
+            c->chunk_var_off.assign((size_t)R + 1, 0);
+            for (int j = 0; j < R; j++) {
+                for (int r = 0; r < n; r++) {
+                    const long long lo = c->cut[r] + (long long)j * sub, hi = std::min(c->cut[r + 1], lo + sub);
+                    for (long long v = lo; v < hi; v++) {
+                        erow[v] = (int)(((long long)j * n + r) * sub + (v - lo));
+                        chunk_of[v] = j;
+                        vars.push_back((int)v);
+                    }
+                }
+                c->chunk_var_off[(size_t)j + 1] = (long long)vars.size();
+            }
+            // the work items chunk by chunk, in the order of the global (longest first) work list
+            std::vector<long long> item_ptr((size_t)V + 1);
+            std::vector<int> order((size_t)c->n_items), item_chunk((size_t)c->n_items);
+            HIP_TRY(hipMemcpyAsync(item_ptr.data(), c->d_item_ptr, sizeof(long long) * (V + 1), hipMemcpyDeviceToHost, st));
+            HIP_TRY(hipMemcpyAsync(order.data(), c->d_item_order, sizeof(int) * c->n_items, hipMemcpyDeviceToHost, st));
+            HIP_TRY(hipStreamSynchronize(st));
+            for (long long v = 0; v < V; v++)
+                for (long long it = item_ptr[v]; it < item_ptr[v + 1]; it++) item_chunk[(size_t)it] = chunk_of[v];
+            std::vector<long long> count((size_t)R + 1, 0);
+            for (long long i = 0; i < c->n_items; i++) count[(size_t)item_chunk[(size_t)order[(size_t)i]] + 1]++;
+            for (int j = 0; j < R; j++) count[(size_t)j + 1] += count[(size_t)j];
+            c->chunk_item_off = count;
+            std::vector<int> by_chunk((size_t)c->n_items);
+            std::vector<long long> fill(count.begin(), count.end() - 1);
+            for (long long i = 0; i < c->n_items; i++) {
+                const int it = order[(size_t)i];
+                by_chunk[(size_t)fill[(size_t)item_chunk[(size_t)it]]++] = it;
+            }
+            DMX_TRY(dev_alloc(c, &c->d_erow, (size_t)V));
+            DMX_TRY(dev_alloc(c, &c->d_chunk_vars, (size_t)V));
+            DMX_TRY(dev_alloc(c, &c->d_chunk_items, (size_t)c->n_items));
+            HIP_TRY(hipMemcpyAsync(c->d_erow, erow.data(), sizeof(int) * V, hipMemcpyHostToDevice, st));
+            HIP_TRY(hipMemcpyAsync(c->d_chunk_vars, vars.data(), sizeof(int) * V, hipMemcpyHostToDevice, st));
+            HIP_TRY(hipMemcpyAsync(c->d_chunk_items, by_chunk.data(), sizeof(int) * c->n_items, hipMemcpyHostToDevice, st));
+            HIP_TRY(hipStreamSynchronize(st));  // locals
+            if (!c->stream2) HIP_TRY(hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking));
+            while ((int)c->ev_chunk.size() < R) {
+                hipEvent_t ev;
+                HIP_TRY(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+                c->ev_chunk.push_back(ev);
+            }
+            if (!c->ev_exchanged) HIP_TRY(hipEventCreateWithFlags(&c->ev_exchanged, hipEventDisableTiming));
+        }
+        c->exch_bytes = (size_t)send_rows * G * 8;  // float64 sums; also the float32 staging of the addition gather
+        c->recv_bytes = (size_t)(c->n_chunks ? c->n_chunks * c->sub_rows : rows) * G * elem;
         HIP_TRY(hipMalloc(&c->d_exch, c->exch_bytes));
         c->bytes += (int64_t)c->exch_bytes;
         HIP_TRY(hipMalloc(&c->d_recv, c->recv_bytes));
@@ -757,6 +824,45 @@ int run_estep(dmx_ctx *c, int with_doublets, bool with_prior, int prior_dtype, f
     return 0;
 }
 
+// Chunked exchange (layout_exchange: n_chunks > 1).  The M-step kernels are launched chunk by chunk on the context's
+// stream; the exchange stream takes every chunk as soon as its sums exist - combine (+ exact redo) into the chunk-major
+// send buffer, reduce-scatter, round this rank's rows into d_add - while the chunks after it are still being summed.
+// The P-step and the all-gather of genotype_prob stay where they are (start of the next iteration: the direct E-step
+// needs the whole table anyway).  DMX_T_ALLREDUCE then measures what is EXPOSED: the time the context's stream waits
+// for the last chunk.
+int run_mstep_chunked(dmx_ctx *c, dmx::MstepArgs a, unsigned long long *redo)
+{
+    const int R = c->n_chunks, G = c->G;
+    const bool f64 = c->reduce_dtype == DMX_F64;
+    const size_t elem = f64 ? 8 : 4, block = (size_t)c->sub_rows * G;
+    std::pair<hipEvent_t, hipEvent_t> ev;
+    timer_begin(c, DMX_T_MSTEP, &ev);
+    for (int j = 0; j < R; j++) {
+        dmx::MstepArgs aj = a;
+        aj.order = c->d_chunk_items + c->chunk_item_off[(size_t)j];
+        aj.n_items = c->chunk_item_off[(size_t)j + 1] - c->chunk_item_off[(size_t)j];
+        HIP_TRY(dmx::launch_mstep(c->stream, aj));
+        HIP_TRY(hipEventRecord(c->ev_chunk[(size_t)j], c->stream));
+    }
+    timer_end(c, DMX_T_MSTEP, ev);
+    for (int j = 0; j < R; j++) {
+        HIP_TRY(hipStreamWaitEvent(c->stream2, c->ev_chunk[(size_t)j], 0));
+        const long long v0 = c->chunk_var_off[(size_t)j], v1 = c->chunk_var_off[(size_t)j + 1];
+        HIP_TRY(dmx::launch_mcombine(c->stream2, a, c->d_item_ptr, v0, v1, c->d_erow, f64 ? nullptr : (float *)c->d_exch,
+                                     f64 ? (double *)c->d_exch : nullptr, redo, c->d_n_redo, c->d_chunk_vars));
+        char *send = (char *)c->d_exch + (size_t)j * c->nranks * block * elem, *recv = (char *)c->d_recv + (size_t)j * block * elem;
+        DMX_TRY(coll_reduce_scatter(c, send, recv, block, f64, c->stream2));
+        const long long lo = c->cut[c->rank] + (long long)j * c->sub_rows, hi = std::min(c->cut[c->rank + 1], lo + c->sub_rows);
+        if (hi > lo) HIP_TRY(dmx::launch_store_slice(c->stream2, recv, f64, lo, hi - lo, G, c->d_add));
+    }
+    HIP_TRY(hipEventRecord(c->ev_exchanged, c->stream2));
+    timer_begin(c, DMX_T_ALLREDUCE, &ev);
+    HIP_TRY(hipStreamWaitEvent(c->stream, c->ev_exchanged, 0));
+    timer_end(c, DMX_T_ALLREDUCE, ev);
+    c->add_partial = c->nranks > 1;
+    return 0;
+}
+
 int run_mstep(dmx_ctx *c, float power)
 {
     dmx::MstepArgs a;
@@ -788,6 +894,7 @@ int run_mstep(dmx_ctx *c, float power)
     std::pair<hipEvent_t, hipEvent_t> ev;
     const bool dist = c->attached();  // also with one rank: keeps the collective path testable on one GPU
     unsigned long long *redo = c->exact_additions ? c->d_redo : nullptr;
+    if (dist && c->sliced && c->n_chunks > 1) return run_mstep_chunked(c, a, redo);
     timer_begin(c, DMX_T_MSTEP, &ev);
     HIP_TRY(dmx::launch_mstep(c->stream, a));
     timer_end(c, DMX_T_MSTEP, ev);
@@ -807,7 +914,7 @@ int run_mstep(dmx_ctx *c, float power)
         timer_end(c, DMX_T_MCOMBINE, ev);
         timer_begin(c, DMX_T_ALLREDUCE, &ev);
         const size_t block = (size_t)c->slice_rows * c->G;
-        rc = coll_reduce_scatter(c, c->d_exch, c->d_recv, block, f64);
+        rc = coll_reduce_scatter(c, c->d_exch, c->d_recv, block, f64, c->stream);
         if (rc == 0)
             HIP_TRY(dmx::launch_store_slice(c->stream, c->d_recv, f64, c->cut[c->rank], c->cut[c->rank + 1] - c->cut[c->rank], c->G, c->d_add));
         timer_end(c, DMX_T_ALLREDUCE, ev);
@@ -884,6 +991,12 @@ int dmx_destroy(dmx_ctx *c)
     if (c->comm && g_rccl.CommDestroy) g_rccl.CommDestroy(c->comm);
     if (c->h_stage) (void)hipHostFree(c->h_stage);
     release_problem(c);
+    if (c->stream2) {
+        (void)hipStreamSynchronize(c->stream2);
+        (void)hipStreamDestroy(c->stream2);
+    }
+    for (hipEvent_t e : c->ev_chunk) (void)hipEventDestroy(e);
+    if (c->ev_exchanged) (void)hipEventDestroy(c->ev_exchanged);
     if (c->d_scratch) (void)hipFree(c->d_scratch);
     for (auto &t : c->timers) {
         for (auto &ev : t.pending) {
@@ -1079,6 +1192,14 @@ int dmx_get_estep_form(dmx_ctx *c, int32_t *form, int32_t *distinct_values)
     if (!c) return fail(DMX_ERR_INVALID, "null context");
     if (form) *form = c->estep_form;
     if (distinct_values) *distinct_values = c->dict_distinct;
+    return 0;
+}
+
+int dmx_set_exchange_chunks(dmx_ctx *c, int chunks)
+{
+    if (!c) return fail(DMX_ERR_INVALID, "null context");
+    if (chunks < 0 || chunks > 16) return fail(DMX_ERR_INVALID, "chunks must be 0 .. 16");
+    c->exch_chunks = chunks;
     return 0;
 }
 

@@ -137,6 +137,21 @@ struct dmx_ctx {
     std::vector<long long> cut;     // [nranks + 1] first variant of every slice
     std::vector<int> h_v2snp;       // host copy of v2snp (layout decisions)
     int *d_prow = nullptr;          // [V] padded row of every variant (sliced mode)
+    // Chunked (pipelined) exchange, dmx_set_exchange_chunks / DEMUXALOT_AMD_EXCHANGE=pipelined[:R]: every rank slice is cut
+    // into n_chunks runs of sub_rows rows; chunk j = run j of every slice.  The M-step is launched chunk by chunk on the
+    // context's stream, and a second stream combines, reduce-scatters and stores chunk j while the chunks after it
+    // are being summed.  The send buffer is chunk-major (erow), genotype_prob keeps the rank-major layout (prow).
+    int exch_chunks = 0;            // requested (<= 1: off)
+    int n_chunks = 0;               // active for the resident problem (0: off)
+    long long sub_rows = 0;         // rows per chunk of a slice
+    int *d_erow = nullptr;          // [V] row of every variant in the chunk-major send buffer
+    int *d_chunk_vars = nullptr;    // [V] the variants chunk by chunk (rank-major inside a chunk)
+    std::vector<long long> chunk_var_off;   // [n_chunks + 1] offsets into d_chunk_vars
+    int *d_chunk_items = nullptr;   // [n_items] the work items chunk by chunk, longest first inside a chunk
+    std::vector<long long> chunk_item_off;  // [n_chunks + 1]
+    hipStream_t stream2 = nullptr;  // exchange stream
+    std::vector<hipEvent_t> ev_chunk;  // M-step of chunk j launched (stream) -> exchange of chunk j may start (stream2)
+    hipEvent_t ev_exchanged = nullptr; // exchange of the last chunk done (stream2) -> next step (stream)
     void *d_exch = nullptr;         // padded send buffer of the reduce-scatter (float64 or float32 partial sums)
     void *d_recv = nullptr;         // this rank's reduced slice
     size_t exch_bytes = 0, recv_bytes = 0;

@@ -150,8 +150,10 @@ hipError_t launch_mstep(hipStream_t st, const MstepArgs &a);
 // sums the item partials of variants [v0, v1) and redoes, in the reference's order, the sums whose float32
 // rounding could depend on the order (redo: queue of capacity (n_items / 2 + 1) * G entries, n_redo: its counter)
 // prow (nullable): row of every variant in the output tables (padded multi-GPU exchange buffer)
+// vlist (nullable): the variants are entries [v0, v1) of this list instead of v0 .. v1 - 1 (chunks of the pipelined exchange)
 hipError_t launch_mcombine(hipStream_t st, const MstepArgs &a, const long long *item_ptr, long long v0, long long v1,
-                           const int *prow, float *add32, double *add64, unsigned long long *redo, unsigned *n_redo);
+                           const int *prow, float *add32, double *add64, unsigned long long *redo, unsigned *n_redo,
+                           const int *vlist = nullptr);
 hipError_t launch_store_slice(hipStream_t st, const void *slice, bool f64, long long v_begin, long long n_rows, int G, float *add);
 // call_rows (nullable): the compact row array of the same records, rewritten as well
 hipError_t launch_remap_row_offsets(hipStream_t st, CallPair *pairs, long long n_pairs, unsigned row_bytes, const int *new_rows,

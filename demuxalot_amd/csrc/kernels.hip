@@ -1341,7 +1341,7 @@ __global__ __launch_bounds__(256) void k_mcombine(const double *__restrict__ par
                                                   const int *__restrict__ item_len, long long v0, long long v1, int G,
                                                   const int *__restrict__ prow, float *__restrict__ add32,
                                                   double *__restrict__ add64, unsigned long long *__restrict__ redo,
-                                                  unsigned *__restrict__ n_redo)
+                                                  unsigned *__restrict__ n_redo, const int *__restrict__ vlist)
 {
     const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= (v1 - v0) * G) return;
@@ -1354,7 +1354,7 @@ __global__ __launch_bounds__(256) void k_mcombine(const double *__restrict__ par
         row = i / G;
         g = (int)(i % G);
     }
-    const long long v = v0 + row;
+    const long long v = vlist ? (long long)vlist[v0 + row] : v0 + row;  // vlist: entries [v0, v1) of a list of variants
     const long long it0 = item_ptr[v], it1 = item_ptr[v + 1];
     double s = 0.0;
     for (long long it = it0; it < it1; it++) s += partial[(size_t)it * G + g];
@@ -1801,7 +1801,7 @@ hipError_t launch_mstep(hipStream_t st, const MstepArgs &a)
 }
 
 hipError_t launch_mcombine(hipStream_t st, const MstepArgs &a, const long long *item_ptr, long long v0, long long v1,
-                           const int *prow, float *add32, double *add64, unsigned long long *redo, unsigned *n_redo)
+                           const int *prow, float *add32, double *add64, unsigned long long *redo, unsigned *n_redo, const int *vlist)
 {
     if ((v1 - v0) * a.G <= 0) return hipSuccess;
     if (redo) {
@@ -1809,7 +1809,7 @@ hipError_t launch_mcombine(hipStream_t st, const MstepArgs &a, const long long *
         if (e != hipSuccess) return e;
     }
     hipLaunchKernelGGL(k_mcombine, dim3(blocks_for((v1 - v0) * a.G, 256)), dim3(256), 0, st, a.partial, item_ptr,
-                       a.item_start, a.item_len, v0, v1, a.G, prow, add32, add64, redo, n_redo);
+                       a.item_start, a.item_len, v0, v1, a.G, prow, add32, add64, redo, n_redo, vlist);
     if (!redo) return hipGetLastError();
     // exact mode: the sums that must be redone in the reference's order (see k_mcombine)
     const dim3 grid(512), block(64 * EXACT_WAVES);

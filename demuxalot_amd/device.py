@@ -370,6 +370,11 @@ class DeviceContext:
         check(self._lib.dmx_get_estep_form(self._h, ctypes.byref(form), ctypes.byref(distinct)))
         return {0: None, 1: 'direct', 2: 'dict', 3: 'dict_block'}[form.value], distinct.value
 
+    def set_exchange_chunks(self, chunks):
+        """Chunked (pipelined) multi-GPU exchange: > 1 cuts every rank slice into that many runs reduced while the next are
+        being summed (include/demux_hip.h: dmx_set_exchange_chunks).  Before the problem / communicator."""
+        check(self._lib.dmx_set_exchange_chunks(self._h, int(chunks)))
+
     def set_estep_schedule(self, schedule):
         """'auto' (default: tile-major schedule where it pays), 'tiled' (whenever built), 'direct' (never);
         include/demux_hip.h: dmx_set_estep_schedule."""

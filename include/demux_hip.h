@@ -332,6 +332,14 @@ int dmx_mstep_f64_sums(dmx_ctx *ctx, double contribution_power, double *sums_out
  * DEMUXALOT_AMD_ALLOW_FOREIGN_RCCL=1. */
 int dmx_runtime_info(char *out, int64_t capacity);
 
+/* Chunked (pipelined) exchange, opt-in; call before a problem is installed / a communicator attached.  chunks > 1: every
+ * rank's variant slice is cut into `chunks` runs of rows; the M-step is launched chunk by chunk and a second stream
+ * combines, reduce-scatters and stores a chunk while the following ones are being summed (csrc/dmx_api.cpp:
+ * run_mstep_chunked).  Same sums, same collectives per row - the results equal the unchunked exchange's bit for bit.
+ * Also selected by DEMUXALOT_AMD_EXCHANGE=pipelined[:chunks] (default 4).  Not the default: RCCL on a second stream next
+ * to the compute stream has not been run on a multi-GPU node yet. */
+int dmx_set_exchange_chunks(dmx_ctx *ctx, int chunks);
+
 /* Host only: the variant slices dmx_comm_init would cut for nranks ranks: cuts int64[nranks + 1] (first variant of
  * every slice, each at the first variant of a SNP), *slice_rows = rows of the longest slice (nullable),
  * *contiguous = 1 when every SNP's variants are contiguous in the numbering (nullable). */

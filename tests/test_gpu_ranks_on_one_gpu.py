@@ -260,7 +260,7 @@ def test_two_ranks_over_rccl():
             assert betas_close and argmax_same and max_dev <= 1e-5, (name, betas_close, argmax_same, max_dev)
 
 
-def _bench_rank(rank, world, port, out, scaling):
+def _bench_rank(rank, world, port, out, scaling, exchange=None):
     """bench.py as one rank of `world` on GPU 0, launched the way torch.distributed.run does (environment only)."""
     import json
     import os
@@ -269,14 +269,16 @@ def _bench_rank(rank, world, port, out, scaling):
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = dict(os.environ, RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK='0', MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port),
                TORCHELASTIC_RUN_ID=f'benchtest{port}')
+    if exchange:
+        env['DEMUXALOT_AMD_EXCHANGE'] = exchange
     done = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--gpus', str(world), '--steps', '2', '--warmup', '1',
                            '--workload', 'em_20k_10k_64', '--scaling', scaling, '--host-plane', '--no-cpu-baseline', '--no-fast-mode',
                            '--no-live-traffic'], env=env, cwd=root, capture_output=True, text=True, timeout=900)
     out.put((rank, done.returncode, done.stdout.strip(), done.stderr[-2000:]))
 
 
-@pytest.mark.parametrize('scaling', ['strong', 'weak'])
-def test_bench_with_two_ranks_on_one_gpu(scaling):
+@pytest.mark.parametrize('scaling,exchange', [('strong', None), ('weak', None), ('strong', 'pipelined:4')])
+def test_bench_with_two_ranks_on_one_gpu(scaling, exchange):
     """`bench.py --gpus 2 --scaling strong|weak` end to end (socket control plane, exchange staged over the plane): rank 0
     prints ONE JSON line for the whole job, the other rank nothing."""
     import json
@@ -287,7 +289,7 @@ def test_bench_with_two_ranks_on_one_gpu(scaling):
         port = s.getsockname()[1]
     ctx = mp.get_context('spawn')
     out = ctx.Queue()
-    procs = [ctx.Process(target=_bench_rank, args=(r, 2, port, out, scaling)) for r in range(2)]
+    procs = [ctx.Process(target=_bench_rank, args=(r, 2, port, out, scaling, exchange)) for r in range(2)]
     for pr in procs:
         pr.start()
     results = sorted(out.get(timeout=900) for _ in range(2))
@@ -343,3 +345,38 @@ def test_dictionary_form_on_the_padded_multi_rank_table(name, monkeypatch):
         assert np.array_equal(probs.argmax(1), want.argmax(1)) and np.abs(probs - want).max() <= 1e-5
         fio.assert_bitwise(logits, fx['predict0_logits'], 'sharded predict logits through the dictionary form')
         fio.assert_bitwise(predicted, fx['predict0_probs'], 'sharded predict posteriors through the dictionary form')
+
+
+@pytest.mark.parametrize('world,chunks,reduce_dtype', [(2, 4, 'f64'), (3, 3, 'f64'), (4, 4, 'f32')])
+def test_chunked_exchange_equals_the_plain_one(world, chunks, reduce_dtype, monkeypatch):
+    """DEMUXALOT_AMD_EXCHANGE=pipelined:R - the M-step launched chunk by chunk, a second stream combining / reduce-scattering /
+    storing chunk j while the next ones are being summed (csrc/dmx_api.cpp: run_mstep_chunked) - must give the plain
+    exchange's additions and posteriors BIT FOR BIT (same sums, same collective per row), on the reference's inputs."""
+    from demuxalot_amd import distributed
+    fx = fio.load('f1_synthetic_default.npz')
+    calls, genotypes, handler = fio.product_inputs(fx)
+    kwargs = dict(n_iterations=4, p_genotype_clip=float(fx['em0_clip']), doublet_prior=float(fx['em0_dp']), reduce_dtype=reduce_dtype)
+
+    def run(mode):
+        if mode:
+            monkeypatch.setenv('DEMUXALOT_AMD_EXCHANGE', mode)
+        else:
+            monkeypatch.delenv('DEMUXALOT_AMD_EXCHANGE', raising=False)
+        shared = ThreadWorld(world)
+
+        def rank_body(plane):
+            learnt, probs_df = distributed.learn_genotypes(calls, genotypes, handler, plane, **kwargs)
+            return learnt.variant_betas, probs_df.values
+        return shared.run(rank_body), shared.collectives
+
+    plain, plain_ops = run(None)
+    chunked, chunked_ops = run(f'pipelined:{chunks}')
+    # three M-steps: one reduce-scatter each in the plain exchange, `chunks` each in the chunked one
+    assert sum(op == 'reduce_scatter' for op, _d, _s in plain_ops) == 3
+    assert sum(op == 'reduce_scatter' for op, _d, _s in chunked_ops) == 3 * chunks
+    want = fx['em0_it3_probs'] if int(fx['em0_n_iterations']) > 3 else None
+    for (b0, p0), (b1, p1) in zip(plain, chunked):
+        fio.assert_bitwise(b1, b0, 'learnt betas: chunked vs plain exchange')
+        fio.assert_bitwise(p1, p0, 'posteriors: chunked vs plain exchange')
+        if want is not None:
+            assert np.array_equal(p1.argmax(1), want.argmax(1)) and np.abs(p1 - want).max() <= 1e-5
