@@ -613,6 +613,15 @@ int layout_exchange(dmx_ctx *c)
             HIP_TRY(hipMemcpyAsync(c->d_chunk_items, by_chunk.data(), sizeof(int) * c->n_items, hipMemcpyHostToDevice, st));
             HIP_TRY(hipStreamSynchronize(st));  // locals
             if (!c->stream2) HIP_TRY(hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking));
+            if (!c->ev_estep_done) HIP_TRY(hipEventCreateWithFlags(&c->ev_estep_done, hipEventDisableTiming));
+            int least = 0, greatest = 0;  // numerically: greatest priority <= least priority
+            HIP_TRY(hipDeviceGetStreamPriorityRange(&least, &greatest));
+            while ((int)c->chunk_streams.size() < R) {
+                const int j = (int)c->chunk_streams.size();
+                hipStream_t ms;
+                HIP_TRY(hipStreamCreateWithPriority(&ms, hipStreamNonBlocking, std::min(least, greatest + j)));
+                c->chunk_streams.push_back(ms);
+            }
             while ((int)c->ev_chunk.size() < R) {
                 hipEvent_t ev;
                 HIP_TRY(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
@@ -836,13 +845,20 @@ int run_mstep_chunked(dmx_ctx *c, dmx::MstepArgs a, unsigned long long *redo)
     const bool f64 = c->reduce_dtype == DMX_F64;
     const size_t elem = f64 ? 8 : 4, block = (size_t)c->sub_rows * G;
     std::pair<hipEvent_t, hipEvent_t> ev;
+    // The chunks' kernels go to R streams of decreasing priority, all released by the E-step's end: they are in flight
+    // together - one launch after the other on ONE stream paid the longest work item's tail R times (0.71 -> 1.67 ms at
+    // R = 4) -, the dispatcher serving the earlier chunk first, so that chunk j completes well before chunk j + 1.
+    HIP_TRY(hipEventRecord(c->ev_estep_done, c->stream));
     timer_begin(c, DMX_T_MSTEP, &ev);
     for (int j = 0; j < R; j++) {
         dmx::MstepArgs aj = a;
         aj.order = c->d_chunk_items + c->chunk_item_off[(size_t)j];
         aj.n_items = c->chunk_item_off[(size_t)j + 1] - c->chunk_item_off[(size_t)j];
-        HIP_TRY(dmx::launch_mstep(c->stream, aj));
-        HIP_TRY(hipEventRecord(c->ev_chunk[(size_t)j], c->stream));
+        hipStream_t ms = c->chunk_streams[(size_t)j];
+        HIP_TRY(hipStreamWaitEvent(ms, c->ev_estep_done, 0));
+        HIP_TRY(dmx::launch_mstep(ms, aj));
+        HIP_TRY(hipEventRecord(c->ev_chunk[(size_t)j], ms));
+        HIP_TRY(hipStreamWaitEvent(c->stream, c->ev_chunk[(size_t)j], 0));
     }
     timer_end(c, DMX_T_MSTEP, ev);
     for (int j = 0; j < R; j++) {
@@ -995,6 +1011,8 @@ int dmx_destroy(dmx_ctx *c)
         (void)hipStreamSynchronize(c->stream2);
         (void)hipStreamDestroy(c->stream2);
     }
+    for (hipStream_t ms : c->chunk_streams) (void)hipStreamDestroy(ms);
+    if (c->ev_estep_done) (void)hipEventDestroy(c->ev_estep_done);
     for (hipEvent_t e : c->ev_chunk) (void)hipEventDestroy(e);
     if (c->ev_exchanged) (void)hipEventDestroy(c->ev_exchanged);
     if (c->d_scratch) (void)hipFree(c->d_scratch);

@@ -150,6 +150,9 @@ struct dmx_ctx {
     int *d_chunk_items = nullptr;   // [n_items] the work items chunk by chunk, longest first inside a chunk
     std::vector<long long> chunk_item_off;  // [n_chunks + 1]
     hipStream_t stream2 = nullptr;  // exchange stream
+    std::vector<hipStream_t> chunk_streams;  // one per chunk, of decreasing priority: the chunks' M-step kernels are in flight
+                                             // together, the earlier chunk's wavefronts dispatched first
+    hipEvent_t ev_estep_done = nullptr;
     std::vector<hipEvent_t> ev_chunk;  // M-step of chunk j launched (stream) -> exchange of chunk j may start (stream2)
     hipEvent_t ev_exchanged = nullptr; // exchange of the last chunk done (stream2) -> next step (stream)
     void *d_exch = nullptr;         // padded send buffer of the reduce-scatter (float64 or float32 partial sums)
