@@ -35,6 +35,8 @@ WORKLOADS = {
     'em_200k_100k_64': (200_000, 100_000, 64, 0.0, 1237),   # BASELINE.json metric / configs[3] shape
     'em_200k_100k_32': (200_000, 100_000, 32, 0.0, 1236),   # configs[2]
     'predict_20k_20k_8': (20_000, 20_000, 8, 0.35, 1235),   # configs[1]
+    'predict_200k_20k_8': (200_000, 20_000, 8, 0.35, 1245),  # configs[1]'s option table (K = 36) with enough barcodes for the packed form
+    'predict_200k_20k_12': (200_000, 20_000, 12, 0.35, 1246),  # K = 78: 16 lanes x 5 slots
     'em_20k_10k_64': (20_000, 10_000, 64, 0.0, 77),         # quick check
     'em_200k_4k_64': (200_000, 4_000, 64, 0.0, 78),         # diagnostic: 2 MB genotype table (every row gather hits L2)
     'predict_20k_20k_32_doublets': (20_000, 20_000, 32, 0.25, 1240),   # K = 528: workgroup-per-barcode kernel
@@ -94,7 +96,7 @@ VALU_CYCLES_PER_TERM = (17 * 4.4 + 6 * 2.4 + 2 * 4.4 + 2 * 8.3 + 2 * 4.4 + 2 * 4
 N_SIMD, PEAK_CLOCK_HZ = 1024, 2.4e9
 
 
-def roofline(workload, ab, e_ms, m_ms, timers, N, G, K):
+def roofline(workload, ab, e_ms, m_ms, timers, N, G, K, form='direct'):
     """The contract's HBM figures for the dominant kernel (the E-step) on ALGORITHMIC bytes, plus what actually binds
     it: VALU issue of the N*K numpy-exact float32 log terms."""
     achieved = ab['estep'] / (e_ms * 1e-3) / 1e9
@@ -102,6 +104,8 @@ def roofline(workload, ab, e_ms, m_ms, timers, N, G, K):
     terms_per_s = N * K / (e_ms * 1e-3)
     peak_terms = N_SIMD * PEAK_CLOCK_HZ * 64 / VALU_CYCLES_PER_TERM
     kernel = 'k_estep_block' if K > 1024 or (K > G and K > 512) else 'k_estep_direct'  # kernels.hip: launch_estep
+    if form == 'packed':
+        kernel = 'k_estep_packed'  # estep_packed.hip: narrow doublet tables, several option slots per lane
     return {
         'bound': 'valu-issue',
         'kernel': kernel, 'achieved': achieved, 'peak': 8000.0, 'unit': 'GB/s', 'frac': achieved / 8000.0,
@@ -370,6 +374,7 @@ def main():
     if plane is not None:
         elapsed = plane.max_float64(elapsed)
     timers = ctx.timings()
+    em_form = ctx.estep_form()[0]  # what the E-steps of the timed iterations ran (direct | packed)
 
     # the tolerance-mode E-step (dmx_set_estep_mode: assignments identical, posteriors within the contract's 1e-5)
     # with the fast summation mode, timed the same way on the same resident problem; the default (bit-exact)
@@ -460,7 +465,7 @@ def main():
                                 'estep_ms includes building the dictionary'},
             'kernel_ms': {k: (v['ms'] / max(1, v['launches'])) for k, v in timers.items()},
             'exchange_ms_per_step': timers['allreduce']['ms'] / max(1, args.steps),
-            'roofline': roofline(args.workload, ab, e_ms, m_ms, timers, N, G, K),
+            'roofline': roofline(args.workload, ab, e_ms, m_ms, timers, N, G, K, em_form),
             'setup_s': {'generate': t_gen, 'upload': t_up},
             'fast_mode': fast,
         }

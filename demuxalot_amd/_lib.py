@@ -78,6 +78,7 @@ SIGNATURES = {
     'dmx_set_estep_schedule': (c_int, [_P, c_int]),
     'dmx_set_estep_dictionary': (c_int, [_P, c_int]),
     'dmx_get_estep_form': (c_int, [_P, POINTER(c_int32), POINTER(c_int32)]),
+    'dmx_set_estep_packing': (c_int, [_P, c_int]),
     'dmx_set_mstep_wide_addresses': (c_int, [_P, c_int]),
     'dmx_test_logf': (c_int, [_P, _P, _P, c_int64]),
     'dmx_test_logf_hot': (c_int, [_P, _P, _P, c_int64]),

@@ -824,8 +824,28 @@ int run_estep(dmx_ctx *c, int with_doublets, bool with_prior, int prior_dtype, f
         HIP_TRY(dmx::launch_estep_dict(c->stream, a, with_doublets != 0));
     else if (form == DMX_FORM_DICT_BLOCK)
         HIP_TRY(dmx::launch_estep_dict_block(c->stream, a));
-    else
-        HIP_TRY(dmx::launch_estep(c->stream, a, with_doublets != 0));
+    else {
+        // Several option slots per lane (estep_packed.hip) make a barcode's serial walk `slots` times longer, and a launch
+        // lasts at least as long as its longest barcode: it pays when the work per SIMD is a multiple of that walk
+        // (20k x 20k x 8 with doublets, longest row 3 500 calls: 0.72 ms against 0.29 ms direct).
+        int lanes = 0, slots = 0;
+        bool packed = c->estep_packing && with_doublets && !a.fast && a.pairs_bytes && dmx::estep_packed_shape(a.K, a.G, &lanes, &slots);
+        if (packed && c->estep_packing == 1) {
+            if (!c->n_simd) {
+                int cus = 0;
+                HIP_TRY(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, c->device));
+                c->n_simd = 4 * cus;
+            }
+            const long long per_simd = 2 * c->n_pairs / ((64 / lanes) * (long long)c->n_simd);
+            packed = c->max_row_calls > 0 && per_simd >= 2 * c->max_row_calls;
+        }
+        if (packed) {
+            HIP_TRY(dmx::launch_estep_packed(c->stream, a));
+            form = DMX_FORM_PACKED;
+        } else {
+            HIP_TRY(dmx::launch_estep(c->stream, a, with_doublets != 0));
+        }
+    }
     c->estep_form = form;
     if (a.dense_calls) HIP_TRY(dmx::launch_sum_dense(c->stream, c->d_dense_calls));
     timer_end(c, DMX_T_ESTEP, ev);
@@ -1202,6 +1222,14 @@ int dmx_set_estep_dictionary(dmx_ctx *c, int mode)
     if (!c) return fail(DMX_ERR_INVALID, "null context");
     if (mode < 0 || mode > 2) return fail(DMX_ERR_INVALID, "dictionary mode must be 0, 1 or 2");
     c->dict_mode = mode;
+    return 0;
+}
+
+int dmx_set_estep_packing(dmx_ctx *c, int on)
+{
+    if (!c) return fail(DMX_ERR_INVALID, "null context");
+    if (on < 0 || on > 2) return fail(DMX_ERR_INVALID, "packing mode must be 0, 1 or 2");
+    c->estep_packing = on;
     return 0;
 }
 

@@ -81,6 +81,9 @@ struct dmx_ctx {
     bool add_is_zero = true;      // d_add holds zeros (no M-step / dmx_set_addition since the last reset)
     bool dict_candidate = false;  // the current d_prob was computed without an addition, or set by the caller
     int estep_form = 0;           // form of the last E-step: DMX_FORM_*
+    int estep_packing = 1;        // dmx_set_estep_packing: 0 never, 1 where it pays, 2 wherever the shape exists
+    long long max_row_calls = 0;  // calls of the longest barcode row (device repack)
+    int n_simd = 0;               // SIMDs of the device (4 per CU)
     int dict_distinct = 0;        // most distinct values per row found by the last dictionary build (0: none built)
     float *d_dict = nullptr;             // [prob_rows, DICT_CAP]
     unsigned char *d_codes = nullptr;    // [prob_rows, G]

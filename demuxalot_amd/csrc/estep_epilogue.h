@@ -35,40 +35,48 @@ __device__ __forceinline__ uint2 nz_code(unsigned long long live, float first_po
 }
 
 // ------------------------------------------------------------------------------------
-// helpers for the in-register softmax of the direct kernel: option k of a lane group lives in
-// lane (group base + (k & 63)), register slot (k >> 6).
+// helpers for the in-register softmax of the lane-per-option kernels: option k of a lane group of L lanes lives in
+// lane (group base + k % L), register slot k / L.
 // ------------------------------------------------------------------------------------
-template <int A>
+template <int L>
+constexpr int log2_lanes()
+{
+    static_assert(L == 4 || L == 8 || L == 16 || L == 32 || L == 64, "lane groups are powers of two");
+    return L == 4 ? 2 : L == 8 ? 3 : L == 16 ? 4 : L == 32 ? 5 : 6;
+}
+
+template <int L, int A>
 static __device__ __forceinline__ float reg_elem(const float (&x)[A], int i, int gbase)
 {
     float v = 0.0f;
 #pragma unroll
     for (int a = 0; a < A; a++) {
-        const float t = __shfl(x[a], gbase + (i & 63));
-        v = ((i >> 6) == a) ? t : v;
+        const float t = __shfl(x[a], gbase + (i & (L - 1)));
+        v = ((i >> log2_lanes<L>()) == a) ? t : v;
     }
     return v;
 }
 
 // numpy pairwise block (n <= 128) over elements [start, start+n) held in registers.
-// Lane groups are 8-aligned whenever n >= 8 can occur, so (lane & 7) indexes the 8 partial sums
-// and the xor butterflies stay inside the group.
-template <int A>
+// Lane groups are 8-aligned whenever n >= 8 can occur (several slots per lane only in groups of 8 lanes or more), so
+// (lane & 7) indexes the 8 partial sums and the xor butterflies stay inside the group.
+template <int L, int A>
 static __device__ __forceinline__ float reg_block_sum(const float (&x)[A], int start, int n, int lane, int gbase)
 {
+    static_assert(A == 1 || L >= 8, "the 8 partial sums of numpy's pairwise block need 8 lanes");
     if (n < 8) {
         float res = 0.0f;
-        for (int i = 0; i < n; i++) res += reg_elem<A>(x, start + i, gbase);
+        for (int i = 0; i < n; i++) res += reg_elem<L, A>(x, start + i, gbase);
         return res;
     }
     const int j = lane & 7;
     const int nfull = n - (n & 7);
-    float r = reg_elem<A>(x, start + j, gbase);
-    for (int i = 8; i < nfull; i += 8) r += reg_elem<A>(x, start + i + j, gbase);
+    float r = reg_elem<L, A>(x, start + j, gbase);
+    for (int i = 8; i < nfull; i += 8) r += reg_elem<L, A>(x, start + i + j, gbase);
     r = r + __shfl_xor(r, 1);
     r = r + __shfl_xor(r, 2);
     r = r + __shfl_xor(r, 4);
-    for (int i = nfull; i < n; i++) r += reg_elem<A>(x, start + i, gbase);
+    for (int i = nfull; i < n; i++) r += reg_elem<L, A>(x, start + i, gbase);
     return r;
 }
 
@@ -80,10 +88,10 @@ static __device__ __forceinline__ int pw_half(int n)
 
 // np.sum of K <= 1024 register-resident elements (one 8192-element numpy chunk): the pairwise split
 // tree walked iteratively, leaves (<= 128 elements) summed by reg_block_sum.  Uniform control flow.
-template <int A>
+template <int L, int A>
 static __device__ __forceinline__ float reg_row_sum(const float (&x)[A], int K, int lane, int gbase)
 {
-    if (K <= 128) return reg_block_sum<A>(x, 0, K, lane, gbase);
+    if (K <= 128) return reg_block_sum<L, A>(x, 0, K, lane, gbase);
     // explicit post-order traversal; depth <= 4 for K <= 1024
     int st_start[6], st_len[6], st_state[6];
     float st_left[6];
@@ -95,7 +103,7 @@ static __device__ __forceinline__ float reg_row_sum(const float (&x)[A], int K, 
     while (sp >= 0) {
         const int s0 = st_start[sp], len = st_len[sp];
         if (len <= 128) {
-            ret = reg_block_sum<A>(x, s0, len, lane, gbase);
+            ret = reg_block_sum<L, A>(x, s0, len, lane, gbase);
             sp--;
             continue;
         }
@@ -122,13 +130,45 @@ static __device__ __forceinline__ float reg_row_sum(const float (&x)[A], int K, 
 }
 
 template <int L>
+static __device__ __forceinline__ int group_max_over_wave(int v)
+{
+#pragma unroll
+    for (int off = L; off < 64; off <<= 1) v = max(v, __shfl_xor(v, off));
+    return v;
+}
+
+// Operands are kept PAIR-MAJOR: element [q][s] holds calls 2q (.x) and 2q+1 (.y) of option slot s in
+// one 64-bit register pair, i.e. exactly the packed operand - no register shuffling between the
+// gather and the packed instructions (with call-major arrays the compiler staged them through LDS).
+template <int A, bool PAIRS, int H>
+static __device__ __forceinline__ void estep_terms(const npm::f32x2 (&p1)[H][A], const npm::f32x2 (&p2)[H][A],
+                                                   const npm::f32x2 (&keep)[H], const npm::f32x2 (&flo)[H],
+                                                   double (&acc)[A], int n_slots)
+{
+#pragma unroll
+    for (int q = 0; q < H; q++) {
+#pragma unroll
+        for (int s = 0; s < A; s++) {
+            if (A > 1 && s >= n_slots) continue;  // wave-uniform: slot entirely past the last option
+            npm::f32x2 p = p1[q][s];
+            if (PAIRS) p = (p + p2[q][s]) * 0.5f;
+            npm::f32x2 t = p * keep[q];
+            t = t + flo[q];
+            const npm::f32x2 lp = npm::log_f32_hot2(t);
+            acc[s] += (double)lp.x;  // call order preserved: 2q before 2q+1
+            acc[s] += (double)lp.y;
+        }
+    }
+}
+
+template <int L>
 static __device__ __forceinline__ unsigned long long group_mask()
 {
     return L >= 64 ? ~0ull : (1ull << (L & 63)) - 1ull;
 }
 
-// Epilogue of the direct forms: penalties, optional prior, softmax as scipy evaluates it, the M-step's bitmap.
-// acc[s] = float64 sum of the log terms of option kk[s] of barcode b (one lane group of L lanes per barcode).
+// Epilogue of the lane-per-option forms: penalties, optional prior, softmax as scipy evaluates it, the M-step's bitmap.
+// acc[s] = float64 sum of the log terms of option kk[s] = li + L * s of barcode b (one lane group of L lanes per barcode).
 template <int L, int A>
 static __device__ __forceinline__ void estep_epilogue(const EstepArgs &a, long long b, bool live, const double (&acc)[A],
                                                       const int (&kk)[A], const bool (&valid)[A], int lane, int li, int gbase,
@@ -155,32 +195,39 @@ static __device__ __forceinline__ void estep_epilogue(const EstepArgs &a, long l
     for (int off = 1; off < L; off <<= 1) mx = fmaxf(mx, __shfl_xor(mx, off));
 #pragma unroll
     for (int s = 0; s < A; s++) x[s] = npm::exp_f32(lg[s] - mx);
-    const float tot = reg_row_sum<A>(x, K, lane, gbase);
+    const float tot = reg_row_sum<L, A>(x, K, lane, gbase);
     const int W = (a.G + 63) >> 6;
+    unsigned long long mine = 0ull;  // L < 64: the group's bitmap of live singlet posteriors, over all slots
+    float post[A];
 #pragma unroll
     for (int s = 0; s < A; s++) {
-        const float post = x[s] / tot;
+        post[s] = x[s] / tot;
         if (live && valid[s]) {
             const size_t o = (size_t)b * K + kk[s];
             a.logits[o] = lg[s];
-            a.post[o] = post;
+            a.post[o] = post[s];
         }
         // non-zero bitmap of the singlet columns (the M-step skips exact zeros: (0*keep)^2 = +0)
-        const unsigned long long bal = __ballot(live && valid[s] && (li + 64 * s) < a.G && !(post <= a.nz_floor));
+        const unsigned long long bal = __ballot(live && valid[s] && (li + L * s) < a.G && !(post[s] <= a.nz_floor));
         if (L == 64) {
             if (lane == 0 && s < W) a.nz[(size_t)b * W + s] = bal;
-        } else {
-            if (live && li == 0) a.nz[(size_t)b] = (bal >> gbase) & group_mask<L>();
+            if (s == 0) mine = bal;
+        } else if (L * s < 64) {
+            mine |= ((bal >> gbase) & group_mask<L>()) << ((L * s) & 63);
         }
-        if (s == 0 && a.first) {
-            // what the M-step's call-parallel part needs of this barcode, 8 bytes (nz_code): ONE gather per call there,
-            // from a table small enough to stay in L2
-            const unsigned long long mine = L == 64 ? bal : ((bal >> gbase) & group_mask<L>());
-            if (live && li == (mine ? __builtin_ctzll(mine) : 0)) a.first[b] = nz_code(mine, post);
-            // statistic for the M-step's choice of kernel (G <= 64): calls whose barcode has more than 4 live posteriors
-            if (a.dense_calls && live && li == 0 && __popcll(mine) > 4)
-                atomicAdd(a.dense_calls + 1 + (b & (DENSE_SLOTS - 1)), (unsigned long long)row_calls);
-        }
+    }
+    if (L < 64 && live && li == 0) a.nz[(size_t)b] = mine;
+    if (a.first) {
+        // what the M-step's call-parallel part needs of this barcode, 8 bytes (nz_code): ONE gather per call there,
+        // from a table small enough to stay in L2
+        const int g0 = mine ? __builtin_ctzll(mine) : 0;  // the lowest live genotype: lane g0 % L, slot g0 / L
+        float p0 = post[0];
+#pragma unroll
+        for (int s = 1; s < A; s++) p0 = (g0 >> log2_lanes<L>()) == s ? post[s] : p0;
+        if (live && li == (g0 & (L - 1))) a.first[b] = nz_code(mine, p0);
+        // statistic for the M-step's choice of kernel (G <= 64): calls whose barcode has more than 4 live posteriors
+        if (a.dense_calls && live && li == 0 && __popcll(mine) > 4)
+            atomicAdd(a.dense_calls + 1 + (b & (DENSE_SLOTS - 1)), (unsigned long long)row_calls);
     }
 }
 

@@ -1,0 +1,181 @@
+// estep_packed.hip -- exact E-step for NARROW DOUBLET TABLES: several option slots per lane.
+//
+// Reference: demuxalot/demux.py:246-265 (compute_barcode_logits_using_barcode_calls) over the options of
+// demux.py:175-191 (singlets first, then the pairs g1 < g2 with (p1 + p2) * 0.5).
+//
+// The direct form (kernels.hip: k_estep_direct) gives every option a lane of a power-of-two lane group: K = 36 options
+// (8 genotypes with doublets: BASELINE.json configs[1]) occupy 36 of 64 lanes, and the kernel is bound by VALU issue
+// (SQ_ACTIVE_INST_VALU 88 % of the launch, profiles/r3_pmc_direct_small.txt), so 44 % of what it issues is thrown away.
+// Here a lane group has L = 8 / 16 / 32 lanes and every lane A = 3 or 5 option slots (option k = lane k % L, slot
+// k / L): K = 36 -> 8 lanes x 5 slots, 8 barcodes per wavefront, 36 of 40 slots busy.
+//
+//   * Few wavefronts: 20 000 barcodes at 8 per wavefront are 2 500 wavefronts, two or three per SIMD, and every one
+//     of them is a serial walk over its rows' calls - no other wavefront hides its loads.  So the walk is software-
+//     pipelined by BLOCKS of 8 records (16 calls): the records of block k + 2 and the genotype rows of block k + 1 are
+//     requested before block k is evaluated.  [A first version with records two and rows one 2-call step ahead ran at
+//     0.67 ms on 20k x 20k x 8 against the direct form's 0.27: every step waited for its row.]
+//   * Records: lane i of a group holds record 8 k + i of the block (three 8-byte loads per lane and block), row
+//     offsets, keep and floor reach the group by ds_bpermute (lane addresses fixed at kernel start).
+//   * Genotype rows through the lanes: G <= L in every shape this kernel takes (K = G (G + 1) / 2 <= L A), so lane i of
+//     the group loads p[i] of the call's row once, and the two operands of every option come by ds_bpermute: one v_add
+//     per CALL for the row address instead of two per TERM.
+//   * The float64 sums take the same float32 terms in the same order as the direct form: bit-identical.
+#include <hip/hip_runtime.h>
+
+#include "kernels.h"
+#include "np_math.h"
+#include "estep_epilogue.h"
+
+namespace dmx {
+
+template <int L, int A>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_estep_packed(EstepArgs a)
+{
+    static_assert(L == 8 || L == 16 || L == 32, "lane groups of 8, 16 or 32");
+    static_assert(A >= 2 && A <= 5, "option slots per lane");
+    constexpr int CPW = 64 / L;
+    const int lane = threadIdx.x & 63;
+    const int li = lane & (L - 1);
+    const int gbase = lane - li;
+    const int K = a.K;
+
+    int kk[A], sel1[A], sel2[A];  // ds_bpermute addresses (lane * 4) of the option's two genotypes inside the group
+    bool valid[A];
+#pragma unroll
+    for (int s = 0; s < A; s++) {
+        const int k = li + L * s;
+        valid[s] = k < K;
+        kk[s] = valid[s] ? k : K - 1;
+        const unsigned pr = a.opt_pairs[kk[s]];
+        sel1[s] = (gbase + (int)(pr & 0xFFFFu)) * 4;
+        sel2[s] = (gbase + (int)(pr >> 16)) * 4;
+    }
+    double acc[A];
+#pragma unroll
+    for (int s = 0; s < A; s++) acc[s] = 0.0;
+
+    const long long slot = ((long long)blockIdx.x * 4 + (threadIdx.x >> 6)) * CPW + lane / L;
+    const bool live = slot < a.B;
+    const long long b = a.order[live ? slot : a.B - 1];
+    const long long pbeg = a.pair_ptr[b];
+    const int npairs = live ? (int)(a.pair_ptr[b + 1] - pbeg) : 0;  // multiple of 4
+    const int nmax = group_max_over_wave<L>(npairs);
+
+    // Records: lane i of a group (i mod 8) holds record 8 * block + i of the group's row; a block = 8 records = 16 calls.
+    // Past the end of the row: the neutral record behind the last row (keep 0, floor 1: log(p * 0 + 1) = +0).
+    const unsigned neutral = (unsigned)a.pair_ptr[a.B] * 32u;
+    const unsigned row_begin = (unsigned)pbeg * 32u;
+    const char *__restrict__ recs = (const char *)a.pairs;
+    const char *__restrict__ prob = (const char *)a.prob;
+    const unsigned my_col = (unsigned)(li < a.G ? li : a.G - 1) * 4u;  // the genotype this lane fetches of every row
+    const int l8 = li & 7;
+    int bcast[8];  // ds_bpermute address of the group's lane that holds record r of a block
+#pragma unroll
+    for (int r = 0; r < 8; r++) bcast[r] = (gbase + r) * 4;
+
+    struct Rec {
+        uint2 ro, keep, fl;
+    };
+    auto load_block = [&](int first) {  // records first .. first + 7 of every group, one per lane
+        const int idx = first + l8;
+        const unsigned off = idx < npairs ? row_begin + (unsigned)idx * 32u : neutral;
+        Rec r;
+        r.ro = *(const uint2 *)(recs + off);
+        r.keep = *(const uint2 *)(recs + off + 8);
+        r.fl = *(const uint2 *)(recs + off + 16);
+        return r;
+    };
+    auto load_rows = [&](const Rec &blk, float (&rows)[16]) {  // p[my genotype] of the 16 calls of a block
+#pragma unroll
+        for (int r = 0; r < 8; r++) {
+            const unsigned ro0 = (unsigned)__builtin_amdgcn_ds_bpermute(bcast[r], (int)blk.ro.x);
+            const unsigned ro1 = (unsigned)__builtin_amdgcn_ds_bpermute(bcast[r], (int)blk.ro.y);
+            rows[2 * r] = *(const float *)(prob + (ro0 + my_col));
+            rows[2 * r + 1] = *(const float *)(prob + (ro1 + my_col));
+        }
+    };
+    auto terms = [&](const Rec &blk, const float (&rows)[16], int r) {
+        npm::f32x2 p1[1][A], p2[1][A], keep[1], flo[1];
+        keep[0].x = __int_as_float(__builtin_amdgcn_ds_bpermute(bcast[r], (int)blk.keep.x));
+        keep[0].y = __int_as_float(__builtin_amdgcn_ds_bpermute(bcast[r], (int)blk.keep.y));
+        flo[0].x = __int_as_float(__builtin_amdgcn_ds_bpermute(bcast[r], (int)blk.fl.x));
+        flo[0].y = __int_as_float(__builtin_amdgcn_ds_bpermute(bcast[r], (int)blk.fl.y));
+        const int r0 = __float_as_int(rows[2 * r]), r1 = __float_as_int(rows[2 * r + 1]);
+#pragma unroll
+        for (int s = 0; s < A; s++) {
+            p1[0][s].x = __int_as_float(__builtin_amdgcn_ds_bpermute(sel1[s], r0));
+            p1[0][s].y = __int_as_float(__builtin_amdgcn_ds_bpermute(sel1[s], r1));
+            p2[0][s].x = __int_as_float(__builtin_amdgcn_ds_bpermute(sel2[s], r0));
+            p2[0][s].y = __int_as_float(__builtin_amdgcn_ds_bpermute(sel2[s], r1));
+        }
+        estep_terms<A, true, 1>(p1, p2, keep, flo, acc, A);
+    };
+
+    if (nmax > 0) {
+        // block k of the walk: the records of block k + 2 requested, the rows of block k + 1 requested (their offsets
+        // broadcast from the lanes that hold its records), the 8 x 2 calls of block k evaluated.  What is requested at
+        // the start of a block is first needed one block (8 records x A slots x ~140 cycles) later, which is what
+        // a SIMD with two or three wavefronts of this kernel needs: it cannot count on other wavefronts to hide a load.
+        Rec cur = load_block(0), nxt = load_block(8);
+        float rows[16], rows_nxt[16];
+        load_rows(cur, rows);
+        for (int j = 0; j < nmax; j += 8) {
+            const Rec far = load_block(j + 16);
+            load_rows(nxt, rows_nxt);
+            __builtin_amdgcn_sched_barrier(0);  // the loads are issued here, not where their values are first used
+#pragma unroll
+            for (int r = 0; r < 8; r++) terms(cur, rows, r);
+            __builtin_amdgcn_sched_barrier(0);
+            cur = nxt;
+            nxt = far;
+#pragma unroll
+            for (int i = 0; i < 16; i++) rows[i] = rows_nxt[i];
+        }
+    }
+    estep_epilogue<L, A>(a, b, live, acc, kk, valid, lane, li, gbase, 2 * npairs);
+}
+
+// Lane-group shape for a doublet table of K options over G genotypes; false: the direct form is as good or better.
+bool estep_packed_shape(int K, int G, int *lanes, int *slots)
+{
+    static const int shapes[][2] = {{8, 3}, {8, 5}, {16, 3}, {16, 5}, {32, 3}, {32, 5}};
+    int direct = 4;  // slots the direct form spends on a row: next power of two up to 64, then multiples of 64 x {1, 2, 4, 8, 16}
+    while (direct < K && direct < 64) direct <<= 1;
+    while (direct < K) direct <<= 1;
+    int best = direct, bl = 0, ba = 0;
+    for (const auto &sh : shapes) {
+        const int cap = sh[0] * sh[1];
+        if (cap >= K && G <= sh[0] && cap < best) {
+            best = cap;
+            bl = sh[0];
+            ba = sh[1];
+        }
+    }
+    if (!bl) return false;
+    *lanes = bl;
+    *slots = ba;
+    return true;
+}
+
+template <int L, int A>
+static void launch_packed(hipStream_t st, const EstepArgs &a)
+{
+    const unsigned blocks = (unsigned)((a.B + 4 * (64 / L) - 1) / (4 * (64 / L)));
+    hipLaunchKernelGGL((k_estep_packed<L, A>), dim3(blocks), dim3(256), 0, st, a);
+}
+
+hipError_t launch_estep_packed(hipStream_t st, const EstepArgs &a)
+{
+    if (a.B == 0) return hipSuccess;
+    int L = 0, A = 0;
+    if (a.fast || a.pairs_bytes == 0 || !estep_packed_shape(a.K, a.G, &L, &A)) return hipErrorInvalidValue;
+    if (L == 8 && A == 3) launch_packed<8, 3>(st, a);
+    else if (L == 8) launch_packed<8, 5>(st, a);
+    else if (L == 16 && A == 3) launch_packed<16, 3>(st, a);
+    else if (L == 16) launch_packed<16, 5>(st, a);
+    else if (L == 32 && A == 3) launch_packed<32, 3>(st, a);
+    else launch_packed<32, 5>(st, a);
+    return hipGetLastError();
+}
+
+}  // namespace dmx

@@ -156,6 +156,9 @@ hipError_t launch_mcombine(hipStream_t st, const MstepArgs &a, const long long *
                            const int *vlist = nullptr);
 hipError_t launch_store_slice(hipStream_t st, const void *slice, bool f64, long long v_begin, long long n_rows, int G, float *add);
 // call_rows (nullable): the compact row array of the same records, rewritten as well
+// estep_packed.hip: exact E-step of narrow doublet tables, several option slots per lane (K = 36: 8 lanes x 5 slots)
+bool estep_packed_shape(int K, int G, int *lanes, int *slots);
+hipError_t launch_estep_packed(hipStream_t st, const EstepArgs &a);
 hipError_t launch_remap_row_offsets(hipStream_t st, CallPair *pairs, long long n_pairs, unsigned row_bytes, const int *new_rows,
                                     unsigned *call_rows);
 hipError_t launch_f64_to_f32(hipStream_t st, const double *in, float *out, long long n);

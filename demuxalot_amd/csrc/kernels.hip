@@ -147,14 +147,6 @@ static __device__ __forceinline__ T group_bcast(T v, int i, int gbase)
     return __shfl(v, gbase + i);
 }
 
-template <int L>
-static __device__ __forceinline__ int group_max_over_wave(int v)
-{
-#pragma unroll
-    for (int off = L; off < 64; off <<= 1) v = max(v, __shfl_xor(v, off));
-    return v;
-}
-
 // ------------------------------------------------------------------------------------
 // E-step, direct form (K <= 1024).  A wavefront is cut into 64/L lane groups; every group owns
 // one barcode and walks its calls IN ORDER (so the float64 sum has the reference's bincount
@@ -167,30 +159,6 @@ static __device__ __forceinline__ int group_max_over_wave(int v)
 //            call through ds_bpermute.
 // Per call the group reads G*4 contiguous bytes of the prob table (global_load_dword, SGPR base).
 // ------------------------------------------------------------------------------------
-// Operands are kept PAIR-MAJOR: element [q][s] holds calls 2q (.x) and 2q+1 (.y) of option slot s in
-// one 64-bit register pair, i.e. exactly the packed operand - no register shuffling between the
-// gather and the packed instructions (with call-major arrays the compiler staged them through LDS).
-template <int A, bool PAIRS, int H>
-static __device__ __forceinline__ void estep_terms(const npm::f32x2 (&p1)[H][A], const npm::f32x2 (&p2)[H][A],
-                                                   const npm::f32x2 (&keep)[H], const npm::f32x2 (&flo)[H],
-                                                   double (&acc)[A], int n_slots)
-{
-#pragma unroll
-    for (int q = 0; q < H; q++) {
-#pragma unroll
-        for (int s = 0; s < A; s++) {
-            if (A > 1 && s >= n_slots) continue;  // wave-uniform: slot entirely past the last option
-            npm::f32x2 p = p1[q][s];
-            if (PAIRS) p = (p + p2[q][s]) * 0.5f;
-            npm::f32x2 t = p * keep[q];
-            t = t + flo[q];
-            const npm::f32x2 lp = npm::log_f32_hot2(t);
-            acc[s] += (double)lp.x;  // call order preserved: 2q before 2q+1
-            acc[s] += (double)lp.y;
-        }
-    }
-}
-
 // ------------------------------------------------------------------------------------
 // Tolerance mode of the E-step (dmx_set_estep_mode(ctx, DMX_ESTEP_FAST)).  The contract of the path is
 // "assignments identical, posteriors within 1e-5" (BASELINE.json north_star); the default mode above pays

@@ -368,12 +368,15 @@ static int repack_core(dmx_ctx *c, Scratch &sc, const int *d_variant, const int 
     DMX_TRY(scan_with_total(sc, col_items, c->d_item_ptr, (size_t)V, st));
     DMX_TRY(sort_pairs(sc, inv, inv_sorted, ids, (unsigned *)c->d_bc_order, (size_t)B, 32, st));  // longest rows first
     long long n_pairs = 0, n_items = 0;
+    unsigned longest = ~0u;  // ~calls of the longest row
+    if (B) HIP_TRY(hipMemcpyAsync(&longest, inv_sorted, sizeof(unsigned), hipMemcpyDeviceToHost, st));
     HIP_TRY(hipMemcpyAsync(&n_pairs, c->d_pair_ptr + B, sizeof(long long), hipMemcpyDeviceToHost, st));
     HIP_TRY(hipMemcpyAsync(&n_items, c->d_item_ptr + V, sizeof(long long), hipMemcpyDeviceToHost, st));
     HIP_TRY(hipStreamSynchronize(st));
     if (n_items >= (1LL << 31)) return fail(DMX_ERR_UNSUPPORTED, "too many M-step work items");
     c->n_pairs = n_pairs;
     c->n_items = n_items;
+    c->max_row_calls = (long long)(~longest);
 
     // barcode-major -> E-step records
     // (CALL_PAD_PAIRS neutral records behind the last row: the dictionary form reads whole super-batches)

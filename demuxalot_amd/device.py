@@ -26,11 +26,13 @@ class DeviceContext:
         DEMUXALOT_AMD_EXACT_ADDITIONS=0 trades the bit-identical genotype additions of the hottest variants (several work
         items) for ~4 % per EM iteration (include/demux_hip.h: dmx_set_exact_additions); DEMUXALOT_AMD_ESTEP=fast selects the
         tolerance-mode E-step (dmx_set_estep_mode); DEMUXALOT_AMD_ESTEP_SCHEDULE = direct | auto | tiled
-        (dmx_set_estep_schedule); DEMUXALOT_AMD_ESTEP_DICT = never | auto | always (dmx_set_estep_dictionary)."""
+        (dmx_set_estep_schedule); DEMUXALOT_AMD_ESTEP_DICT = never | auto | always (dmx_set_estep_dictionary);
+        DEMUXALOT_AMD_ESTEP_PACKED = never | auto | always (dmx_set_estep_packing)."""
         self.set_exact_additions(os.environ.get('DEMUXALOT_AMD_EXACT_ADDITIONS', '1') not in ('0', ''))
         self.set_estep_mode('fast' if os.environ.get('DEMUXALOT_AMD_ESTEP', 'exact') == 'fast' else 'exact')
         self.set_estep_schedule(os.environ.get('DEMUXALOT_AMD_ESTEP_SCHEDULE', 'auto'))
         self.set_estep_dictionary(os.environ.get('DEMUXALOT_AMD_ESTEP_DICT', 'auto'))
+        self.set_estep_packing(os.environ.get('DEMUXALOT_AMD_ESTEP_PACKED', 'auto'))
 
     def __enter__(self):
         return self
@@ -363,12 +365,17 @@ class DeviceContext:
         check(self._lib.dmx_set_estep_dictionary(self._h, {'never': 0, 'auto': 1, 'always': 2}[mode]))
 
     def estep_form(self):
-        """(form, distinct) of the last E-step: form 'direct' | 'dict' | 'dict_block' | None, distinct = most distinct
+        """(form, distinct) of the last E-step: form 'direct' | 'packed' | 'dict' | 'dict_block' | None, distinct = most distinct
         values in a row of genotype_prob as counted by the last dictionary build (0: none was tried, 9: too many)."""
         import ctypes
         form, distinct = ctypes.c_int32(0), ctypes.c_int32(0)
         check(self._lib.dmx_get_estep_form(self._h, ctypes.byref(form), ctypes.byref(distinct)))
-        return {0: None, 1: 'direct', 2: 'dict', 3: 'dict_block'}[form.value], distinct.value
+        return {0: None, 1: 'direct', 2: 'dict', 3: 'dict_block', 4: 'packed'}[form.value], distinct.value
+
+    def set_estep_packing(self, mode):
+        """'never' | 'auto' (default: where it pays) | 'always': several option slots per lane for narrow doublet tables
+        (include/demux_hip.h: dmx_set_estep_packing)."""
+        check(self._lib.dmx_set_estep_packing(self._h, {'never': 0, 'auto': 1, 'always': 2}[mode]))
 
     def set_exchange_chunks(self, chunks):
         """Chunked (pipelined) multi-GPU exchange: > 1 cuts every rank slice into that many runs reduced while the next are

@@ -184,8 +184,17 @@ int dmx_set_estep_schedule(dmx_ctx *ctx, int tiled);
 #define DMX_FORM_DIRECT 1   /* one numpy log per (call, option): k_estep_direct / k_estep_tiled / k_estep_block */
 #define DMX_FORM_DICT 2     /* dictionary form, lane-per-option kernel */
 #define DMX_FORM_DICT_BLOCK 3   /* dictionary form, workgroup-per-barcode kernel (wide doublet tables) */
+#define DMX_FORM_PACKED 4   /* one numpy log per (call, option), several option slots per lane (narrow doublet tables:
+                               csrc/estep_packed.hip) */
 int dmx_set_estep_dictionary(dmx_ctx *ctx, int mode);
 int dmx_get_estep_form(dmx_ctx *ctx, int32_t *form, int32_t *distinct_values);
+
+/* Narrow doublet tables in the exact mode (K = G (G + 1) / 2 options that fill a power-of-two lane group badly: K = 36
+ * takes 36 of 64 lanes): lane groups of 8 / 16 / 32 lanes with 3 or 5 option slots per lane (csrc/estep_packed.hip).
+ * mode = 1 (default): used where it wastes fewer slots than the direct form AND the problem is large enough for the
+ * longer serial walk per barcode not to decide the launch (calls per SIMD >= 2 x slots... see dmx_api.cpp: run_estep);
+ * 0: never; 2: wherever the shape exists.  Bit-identical results. */
+int dmx_set_estep_packing(dmx_ctx *ctx, int mode);
 
 /* M-step loads (G <= 64).  wide = 0 (default): 32-bit buffer offsets wherever the tables allow (posterior table below
  * 4 GiB, fewer than 2^24 barcodes), 64-bit addresses otherwise.  wide = 1: always 64-bit addresses - the form the

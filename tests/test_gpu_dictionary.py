@@ -59,7 +59,7 @@ def test_dictionary_form_equals_direct_form(oracle, n_genotypes, doublet_prior, 
         ctx.set_problem(n_barcodes, n_rows, n_genotypes, variant, cb, e, np.arange(n_rows, dtype=np.int32))
         l_dir, p_dir, form_dir = run_estep(ctx, table, pen, doublet_prior != 0, 'never')
         l_dic, p_dic, form_dic = run_estep(ctx, table, pen, doublet_prior != 0, 'auto')
-        assert form_dir == ('direct', 0)
+        assert form_dir in (('direct', 0), ('packed', 0))  # 8 genotypes with doublets: several option slots per lane
         n_options = len(pen)
         assert form_dic[0] == ('dict_block' if doublet_prior and n_options > 256 else 'dict') and 1 <= form_dic[1] <= n_values, form_dic
         fio.assert_bitwise(l_dic, l_dir, 'logits: dictionary vs direct form')
@@ -91,7 +91,7 @@ def test_rows_with_many_values_take_the_direct_form(n_genotypes, doublet_prior, 
         ctx.set_problem(300, 400, n_genotypes, variant, cb, e, np.arange(400, dtype=np.int32))
         l_dir, p_dir, _ = run_estep(ctx, table, pen, doublet_prior != 0, 'never')
         l_try, p_try, form = run_estep(ctx, table, pen, doublet_prior != 0, 'always')
-        assert form[0] == 'direct' and ('options' in why or form[1] >= min(n_values, 9)), (why, form)
+        assert form[0] in ('direct', 'packed') and ('options' in why or form[1] >= min(n_values, 9)), (why, form)
         fio.assert_bitwise(l_try, l_dir, why)
         fio.assert_bitwise(p_try, p_dir, why)
     finally:
