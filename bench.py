@@ -336,12 +336,34 @@ def main():
     K = len(pen)
 
     ctx = DeviceContext(local_rank % max(1, _lib_device_count()))
-    runtimes = None
+    runtimes, rccl_fallback = None, None
     if use_dist and args.host_plane:
         ctx.comm_init_host(rank, world, plane.host_collective, reduce_dtype=args.reduce_dtype)
     elif use_dist:
-        unique_id = plane.broadcast_bytes(DeviceContext.new_unique_id() if rank == 0 else None)
-        ctx.comm_init(rank, world, unique_id, reduce_dtype=args.reduce_dtype)
+        # RCCL communicator; when creating it fails on some rank (no usable fabric, library missing), every rank learns
+        # so over the control plane and the run goes on with the exchange staged through host memory - said in the line
+        unique_id, why = None, ''
+        if rank == 0:
+            try:
+                unique_id = DeviceContext.new_unique_id()
+            except Exception as exc:  # noqa: BLE001
+                unique_id, why = b'', f'{type(exc).__name__}: {exc}'
+        unique_id = plane.broadcast_bytes(unique_id)  # empty: rank 0 has no RCCL
+        try:
+            if not unique_id:
+                raise RuntimeError('rank 0 could not create an RCCL unique id ' + why)
+            ctx.comm_init(rank, world, unique_id, reduce_dtype=args.reduce_dtype)
+            ok = True
+        except Exception as exc:  # noqa: BLE001
+            ok, why = False, f'{type(exc).__name__}: {exc}'
+        ok, why = plane.all_ok(ok, why)
+        if not ok:
+            print(f'[bench] RCCL communicator not created ({why}); exchange staged through host memory', file=sys.stderr, flush=True)
+            ctx.close()
+            ctx = DeviceContext(local_rank % max(1, _lib_device_count()))
+            ctx.comm_init_host(rank, world, plane._host_collective, reduce_dtype=args.reduce_dtype)
+            args.host_plane = True
+            rccl_fallback = why
     if use_dist:
         from demuxalot_amd import _lib
         runtimes = _lib.runtime_info()
@@ -456,7 +478,7 @@ def main():
                        'options': K, 'calls_per_gpu': N, 'doublet_prior': dp,
                        'summation': 'fast (DEMUXALOT_AMD_EXACT_ADDITIONS=0)' if os.environ.get('DEMUXALOT_AMD_EXACT_ADDITIONS', '1') in ('0', '') else 'exact: additions bit-identical to the reference (default)',
                        'parallelism': f'barcode shards x{world}' + (f', {"host-staged" if args.host_plane else "RCCL"} reduce-scatter {args.reduce_dtype} + all-gather f32 of variant slices' if use_dist else ''),
-                       'runtimes': runtimes},
+                       'runtimes': runtimes, **({'rccl_fallback': rccl_fallback} if rccl_fallback else {})},
             'em_iterations_per_s': args.steps / elapsed,
             'predict_barcodes_per_s': B_total / predict_s,
             'predict': {'dictionary_form': dict(predict['auto'], estep_hbm_frac=algorithmic_bytes(B, V, G, K, N)['estep'] / (predict['auto']['estep_ms'] * 1e-3) / 8e12),

@@ -1135,6 +1135,12 @@ __global__ __launch_bounds__(256) void k_mstep_calls(MstepArgs a)
                 dense &= dense - 1ull;
             }
         }
+        // These rows are waited for HERE, on this (rare) path, whatever the lanes' masks: their first use is inside
+        // lane-conditional code, and a load the compiler believes pending on SOME path out of here made it drain the
+        // memory pipeline (s_waitcnt vmcnt(0)) in the middle of every chunk's processing - where the next chunks'
+        // loads have just been issued.
+#pragma unroll
+        for (int j = 0; j < D; j++) asm volatile("" : "+v"(q[j]));
     };
 
 #pragma unroll

@@ -260,7 +260,7 @@ def test_two_ranks_over_rccl():
             assert betas_close and argmax_same and max_dev <= 1e-5, (name, betas_close, argmax_same, max_dev)
 
 
-def _bench_rank(rank, world, port, out, scaling, exchange=None):
+def _bench_rank(rank, world, port, out, scaling, exchange=None, broken_rccl=False):
     """bench.py as one rank of `world` on GPU 0, launched the way torch.distributed.run does (environment only)."""
     import json
     import os
@@ -271,9 +271,12 @@ def _bench_rank(rank, world, port, out, scaling, exchange=None):
                TORCHELASTIC_RUN_ID=f'benchtest{port}')
     if exchange:
         env['DEMUXALOT_AMD_EXCHANGE'] = exchange
+    if broken_rccl:
+        env['DEMUXALOT_AMD_RCCL'] = '/nonexistent/librccl.so'
     done = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--gpus', str(world), '--steps', '2', '--warmup', '1',
-                           '--workload', 'em_20k_10k_64', '--scaling', scaling, '--host-plane', '--no-cpu-baseline', '--no-fast-mode',
-                           '--no-live-traffic'], env=env, cwd=root, capture_output=True, text=True, timeout=900)
+                           '--workload', 'em_20k_10k_64', '--scaling', scaling, '--no-cpu-baseline', '--no-fast-mode',
+                           '--no-live-traffic', '--no-e2e'] + ([] if broken_rccl else ['--host-plane']),
+                          env=env, cwd=root, capture_output=True, text=True, timeout=900)
     out.put((rank, done.returncode, done.stdout.strip(), done.stderr[-2000:]))
 
 
@@ -303,6 +306,30 @@ def test_bench_with_two_ranks_on_one_gpu(scaling, exchange):
     assert line['n_gpus'] == 2 and line['scaling'] == scaling and line['value'] > 0
     assert line['config']['barcodes_total'] == (20_000 if scaling == 'strong' else 40_000)
     assert len(line['config']['runtimes']['hip']) == 1 and line['exchange_ms_per_step'] > 0
+
+
+def test_bench_falls_back_to_the_host_plane_without_rccl():
+    """No RCCL communicator (here: the library path points nowhere) on a multi-rank run: every rank learns so over the
+    control plane and the exchange is staged through host memory; the line says so."""
+    import json
+    import multiprocessing as mp
+    import socket
+    with socket.socket() as s:
+        s.bind(('127.0.0.1', 0))
+        port = s.getsockname()[1]
+    ctx = mp.get_context('spawn')
+    out = ctx.Queue()
+    procs = [ctx.Process(target=_bench_rank, args=(r, 2, port, out, 'weak', None, True)) for r in range(2)]
+    for pr in procs:
+        pr.start()
+    results = sorted(out.get(timeout=900) for _ in range(2))
+    for pr in procs:
+        pr.join(timeout=60)
+    for rank, code, _stdout, stderr in results:
+        assert code == 0, (rank, stderr)
+    line = json.loads(results[0][2])
+    assert line['n_gpus'] == 2 and line['value'] > 0 and line['exchange_ms_per_step'] > 0
+    assert 'rccl_fallback' in line['config'] and 'host-staged' in line['config']['parallelism'], line['config']
 
 
 @pytest.mark.parametrize('name', ['f2_synthetic_g4.npz', 'f1_synthetic_default.npz'])
