@@ -72,6 +72,7 @@ SIGNATURES = {
     'dmx_get_timings': (c_int, [_P, POINTER(c_double), POINTER(c_int64)]),
     'dmx_reset_timings': (c_int, [_P]),
     'dmx_device_bytes': (c_int, [_P, POINTER(c_int64)]),
+    'dmx_trim_cache': (c_int, [_P, POINTER(c_int64)]),
     'dmx_set_exact_additions': (c_int, [_P, c_int]),
     'dmx_get_redo_count': (c_int, [_P, POINTER(c_int64)]),
     'dmx_set_estep_mode': (c_int, [_P, c_int]),

@@ -192,6 +192,68 @@ int ensure_sum_plan(dmx_ctx *c, long long K)
 
 }  // namespace dmx
 
+size_t ctx_cache_limit()
+{
+    static const size_t limit = [] {
+        const char *e = std::getenv("DEMUXALOT_AMD_CACHE_GB");
+        const double gb = e ? atof(e) : 24.0;
+        return gb <= 0 ? (size_t)0 : (size_t)(gb * 1073741824.0);
+    }();
+    return limit;
+}
+
+int ctx_malloc(dmx_ctx *c, void **p, size_t bytes)
+{
+    *p = nullptr;
+    if (bytes == 0) bytes = 1;
+    // an idle block of this size, or up to an eighth (+ 64 KB) larger
+    auto it = c->idle_blocks.lower_bound(bytes);
+    if (it != c->idle_blocks.end() && it->first <= bytes + bytes / 8 + 65536) {
+        *p = it->second;
+        c->idle_bytes -= it->first;
+        c->idle_blocks.erase(it);
+        return 0;
+    }
+    hipError_t e = hipMalloc(p, bytes);
+    if (e != hipSuccess && !c->idle_blocks.empty()) {  // out of memory with blocks parked here: give them back, try again
+        (void)hipGetLastError();
+        ctx_trim(c, 0);
+        e = hipMalloc(p, bytes);
+    }
+    if (e != hipSuccess) {
+        *p = nullptr;
+        return fail(DMX_ERR_HIP, "hipMalloc of %zu bytes failed: %s", bytes, hipGetErrorString(e));
+    }
+    c->block_capacity[*p] = bytes;
+    return 0;
+}
+
+void ctx_free(dmx_ctx *c, void *p)
+{
+    if (!p) return;
+    auto it = c->block_capacity.find(p);
+    if (it == c->block_capacity.end() || ctx_cache_limit() == 0) {
+        if (it != c->block_capacity.end()) c->block_capacity.erase(it);
+        (void)hipFree(p);
+        return;
+    }
+    c->idle_blocks.emplace(it->second, p);
+    c->idle_bytes += it->second;
+    if (c->idle_bytes > ctx_cache_limit()) ctx_trim(c, ctx_cache_limit() / 2);
+}
+
+// hipFree (which waits for the device) of idle blocks, largest first, until at most keep_bytes stay parked
+void ctx_trim(dmx_ctx *c, size_t keep_bytes)
+{
+    while (!c->idle_blocks.empty() && c->idle_bytes > keep_bytes) {
+        auto it = std::prev(c->idle_blocks.end());
+        (void)hipFree(it->second);
+        c->idle_bytes -= it->first;
+        c->block_capacity.erase(it->second);
+        c->idle_blocks.erase(it);
+    }
+}
+
 namespace {
 
 int bind(dmx_ctx *c)
@@ -1036,6 +1098,7 @@ int dmx_destroy(dmx_ctx *c)
     for (hipEvent_t e : c->ev_chunk) (void)hipEventDestroy(e);
     if (c->ev_exchanged) (void)hipEventDestroy(c->ev_exchanged);
     if (c->d_scratch) (void)hipFree(c->d_scratch);
+    ctx_trim(c, 0);
     for (auto &t : c->timers) {
         for (auto &ev : t.pending) {
             (void)hipEventDestroy(ev.first);
@@ -1222,6 +1285,15 @@ int dmx_set_estep_dictionary(dmx_ctx *c, int mode)
     if (!c) return fail(DMX_ERR_INVALID, "null context");
     if (mode < 0 || mode > 2) return fail(DMX_ERR_INVALID, "dictionary mode must be 0, 1 or 2");
     c->dict_mode = mode;
+    return 0;
+}
+
+int dmx_trim_cache(dmx_ctx *c, int64_t *released_bytes)
+{
+    DMX_TRY(bind(c));
+    const size_t before = c->idle_bytes;
+    ctx_trim(c, 0);
+    if (released_bytes) *released_bytes = (int64_t)before;
     return 0;
 }
 

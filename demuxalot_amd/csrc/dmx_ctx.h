@@ -4,7 +4,9 @@
 #include <hip/hip_runtime.h>
 #include <rccl/rccl.h>
 
+#include <map>
 #include <string>
+#include <unordered_map>
 #include <utility>
 #include <vector>
 
@@ -164,16 +166,32 @@ struct dmx_ctx {
 
     int64_t bytes = 0;
     TimerSlot timers[DMX_T_COUNT];
+
+    // Device blocks this context has released, kept for its next allocations (ctx_malloc / ctx_free below).
+    std::multimap<size_t, void *> idle_blocks;          // capacity -> block
+    std::unordered_map<void *, size_t> block_capacity;  // every block handed out through ctx_malloc, idle or not
+    size_t idle_bytes = 0;
 };
+
+// Why the context keeps its device blocks: a second predict / learn call on a context frees the previous problem
+// (gigabytes in ~100 blocks) and allocates the next one, and on this stack ONE hipMalloc after such a round of hipFree
+// took 350 ms (rocprofv3 --hip-trace of scripts/e2e_breakdown.py: 87 ms for the first pack of 78.65 M calls, 430 ms for
+// every later one).  Blocks go back to the context that allocated them and are handed out again to requests of
+// (nearly) their size; everything a context launches is ordered on its stream, so a block can be re-used while the
+// work of its previous life is still queued.  DEMUXALOT_AMD_CACHE_GB caps the idle bytes per context (default 24; 0 =
+// free at once).  dmx_destroy and dmx_trim release them.
+size_t ctx_cache_limit();
+int ctx_malloc(dmx_ctx *c, void **p, size_t bytes);
+void ctx_free(dmx_ctx *c, void *p);
+void ctx_trim(dmx_ctx *c, size_t keep_bytes);
 
 template <typename T>
 inline int dev_alloc(dmx_ctx *c, T **p, size_t count)
 {
     *p = nullptr;
     if (count == 0) count = 1;
-    hipError_t e = hipMalloc((void **)p, count * sizeof(T));
-    if (e != hipSuccess)
-        return fail(DMX_ERR_HIP, "hipMalloc of %zu bytes failed: %s", count * sizeof(T), hipGetErrorString(e));
+    const int rc = ctx_malloc(c, (void **)p, count * sizeof(T));
+    if (rc) return rc;
     c->bytes += (int64_t)(count * sizeof(T));
     return 0;
 }
@@ -182,7 +200,7 @@ template <typename T>
 inline void dev_free(dmx_ctx *c, T **p, size_t count)
 {
     if (*p) {
-        (void)hipFree(*p);
+        ctx_free(c, (void *)*p);
         c->bytes -= (int64_t)((count ? count : 1) * sizeof(T));
         *p = nullptr;
     }

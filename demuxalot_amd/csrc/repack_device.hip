@@ -258,18 +258,25 @@ inline unsigned bits_for(unsigned long long max_value)
 }
 
 // scratch owner: frees everything on scope exit
+// Temporaries of one repack, taken from and returned to the context's block cache (dmx_ctx.h: ctx_malloc).  They go
+// back while the kernels that use them may still be queued: the context's next user of such a block runs behind them
+// on the same stream.
 struct Scratch {
+    dmx_ctx *ctx;
     std::vector<void *> ptrs;
+    explicit Scratch(dmx_ctx *c) : ctx(c) {}
+    Scratch(const Scratch &) = delete;
+    Scratch &operator=(const Scratch &) = delete;
     ~Scratch()
     {
-        for (void *p : ptrs) (void)hipFree(p);
+        for (void *p : ptrs) ctx_free(ctx, p);
     }
     template <typename T>
     int get(T **out, size_t count)
     {
         void *p = nullptr;
-        hipError_t e = hipMalloc(&p, (count ? count : 1) * sizeof(T));
-        if (e != hipSuccess) return fail(DMX_ERR_HIP, "hipMalloc(scratch %zu bytes): %s", count * sizeof(T), hipGetErrorString(e));
+        const int rc = ctx_malloc(ctx, &p, (count ? count : 1) * sizeof(T));
+        if (rc) return rc;
         ptrs.push_back(p);
         *out = (T *)p;
         return 0;
@@ -479,7 +486,7 @@ int repack_on_device(dmx_ctx *c, const int32_t *h_variant, const int32_t *h_cb, 
 {
     const long long N = c->N;
     hipStream_t st = c->stream;
-    Scratch sc;
+    Scratch sc(c);
     int *d_variant = nullptr, *d_cb = nullptr;
     float *d_p = nullptr;
     DMX_TRY(sc.get(&d_variant, (size_t)N));
@@ -711,7 +718,7 @@ int pack_on_device(dmx_ctx *c, long long V, const int *var_chrom, const int *var
                    long long *mol_per_variant)
 {
     hipStream_t st = c->stream;
-    Scratch sc;
+    Scratch sc(c);
     int *d_cchrom, *d_cpos, *d_ccb;
     unsigned char *d_cbase;
     float *d_cp;
@@ -768,7 +775,7 @@ int pack_containers_on_device(dmx_ctx *c, long long V, const int *var_chrom, con
                               long long *n_matched, long long *n_unique, long long *mol_per_variant)
 {
     hipStream_t st = c->stream;
-    Scratch sc;
+    Scratch sc(c);
     long long n_calls = 0;
     for (int k = 0; k < n_parts; k++) n_calls += parts[k].n_snp_calls;
     int *d_cchrom, *d_cpos, *d_ccb, *bad;

@@ -32,6 +32,9 @@ from .device import (DeviceContext, acquire_private_context, default_device, get
 _MOLECULE_CALL_DTYPE = [('variant_id', 'int32'), ('snp_id', 'int32'), ('compressed_cb', 'int32'),
                         ('molecule_id', 'int32'), ('p_base_wrong', 'float32'), ('p_molecule_aligned_wrong', 'float32')]
 _BASES = {'A': 0, 'C': 1, 'G': 2, 'T': 3, 'N': 4}
+_BASE_TABLE = np.full(256, 255, dtype=np.uint8)
+for _letter, _code in _BASES.items():
+    _BASE_TABLE[ord(_letter)] = _code
 
 
 class _Packed:
@@ -40,9 +43,38 @@ class _Packed:
                  'molecule_calls', 'n_molecule_calls')
 
 
-def _variant_keys(genotypes):
-    """var2varid -> per-row key arrays (chromosome index, position, base code) and the chromosome numbering."""
+_UNSET = object()
+
+
+def _variant_keys(genotypes, columns=_UNSET):
+    """var2varid -> per-row key arrays (chromosome index, position, base code) and the chromosome numbering.
+    `columns`: variant_columns(genotypes.var2varid) when the caller has them already."""
+    from .genotypes import variant_columns
     n_variants = genotypes.n_variants
+    if columns is _UNSET:
+        columns = variant_columns(genotypes.var2varid)
+    base_codes = None
+    if columns is not None:
+        rows, chrom_codes, chrom_names, pos, bases = columns
+        try:  # single-letter bases: one join + a 256-entry table instead of a dict lookup per variant
+            letters = np.frombuffer(''.join(bases).encode('ascii'), dtype=np.uint8)
+            if len(letters) == len(rows):
+                base_codes = _BASE_TABLE[letters]
+        except (TypeError, UnicodeEncodeError):
+            base_codes = None
+    if base_codes is not None and (base_codes < 255).all() and (len(pos) == 0 or pos.max() < 2 ** 31):
+        assert len(rows) == n_variants and (len(rows) == 0 or (rows.min() >= 0 and rows.max() < n_variants)), \
+            'var2varid rows must enumerate 0..n_variants-1'
+        seen = np.zeros(n_variants, dtype=bool)
+        seen[rows] = True
+        assert seen.all(), 'var2varid rows must enumerate 0..n_variants-1'  # demux.py:317 (a repeated row leaves a gap)
+        var_chrom = np.zeros(n_variants, dtype=np.int32)
+        var_pos = np.zeros(n_variants, dtype=np.int32)
+        var_base = np.zeros(n_variants, dtype=np.uint8)
+        var_chrom[rows] = chrom_codes
+        var_pos[rows] = pos
+        var_base[rows] = base_codes
+        return (var_chrom, var_pos, var_base), {name: i for i, name in enumerate(chrom_names)}
     chrom_index = {}
     var_chrom = np.zeros(n_variants, dtype=np.int32)
     var_pos = np.zeros(n_variants, dtype=np.int32)
@@ -169,15 +201,19 @@ def _pack_on_device(chromosome2compressed_snp_calls, genotypes, n_barcodes, add_
     context (the caller holds shared_context_lock).  `reduce_molecule_counts` (barcode-sharded runs): maps this
     shard's molecule counts per variant to the counts of the whole experiment, which the data term of the
     prior is made of (demux.py:381-384)."""
+    from .genotypes import ProbabilisticGenotypes, snp_ids_from_columns, variant_columns
     from .snp_counter import MOLECULE_DTYPE, SNP_CALL_DTYPE
-    v2snp = genotypes.get_snp_ids_for_variants()
+    columns = _UNSET
+    if getattr(type(genotypes), 'get_snp_ids_for_variants', None) is ProbabilisticGenotypes.get_snp_ids_for_variants:
+        columns = variant_columns(genotypes.var2varid)  # one walk of var2varid for the SNP numbering and the row keys
+    v2snp = snp_ids_from_columns(columns) if columns is not _UNSET and columns is not None else genotypes.get_snp_ids_for_variants()
     assert np.all(v2snp >= 0)
     if ctx is None:
         ctx = get_context()
     containers = list(chromosome2compressed_snp_calls.values())
     if all(c.snp_calls.dtype == SNP_CALL_DTYPE and c.molecules.dtype == MOLECULE_DTYPE for c in containers):
         # the containers' packed records go to the GPU as they are and are taken apart there
-        (var_chrom, var_pos, var_base), chrom_index = _variant_keys(genotypes)
+        (var_chrom, var_pos, var_base), chrom_index = _variant_keys(genotypes, columns)
         parts = []
         for chrom, container in chromosome2compressed_snp_calls.items():
             if chrom in chrom_index:

@@ -411,6 +411,13 @@ class DeviceContext:
     def reset_timings(self):
         check(self._lib.dmx_reset_timings(self._h))
 
+    def trim_cache(self):
+        """Give the device blocks this context keeps for re-use back to the driver; returns the bytes released
+        (include/demux_hip.h: dmx_trim_cache)."""
+        n = ctypes.c_int64(0)
+        check(self._lib.dmx_trim_cache(self._h, ctypes.byref(n)))
+        return n.value
+
     def device_bytes(self):
         n = ctypes.c_int64(0)
         check(self._lib.dmx_device_bytes(self._h, ctypes.byref(n)))

@@ -20,6 +20,42 @@ import numpy as np
 _INITIAL_ROWS = 32768  # capacity the reference starts with (genotypes.py:33); doubled on demand
 
 
+def variant_columns(var2varid):
+    """The (chrom, pos, base) -> row dict as columns, in the dict's iteration order: (rows int64, chromosome codes int64,
+    chromosome names in order of first appearance, positions int64, bases as a list of str), or None when a position
+    does not fit 32 unsigned bits (callers then walk the dict).  Passes in C (map / fromiter / pandas.factorize) instead
+    of a Python loop body per variant; zip(*keys) is NOT one of them (200k-argument call: slower than the loop)."""
+    import pandas as pd
+    from operator import itemgetter
+    n = len(var2varid)
+    rows = np.fromiter(var2varid.values(), dtype=np.int64, count=n)
+    if n == 0:
+        return rows, np.zeros(0, np.int64), [], np.zeros(0, np.int64), []
+    keys = list(var2varid)
+    try:
+        pos = np.fromiter(map(itemgetter(1), keys), dtype=np.int64, count=n)
+    except (TypeError, ValueError, OverflowError):
+        return None
+    if pos.min() < 0 or pos.max() >= 2 ** 32:
+        return None
+    chroms = np.empty(n, dtype=object)
+    chroms[:] = list(map(itemgetter(0), keys))
+    codes, names = pd.factorize(chroms)  # codes in order of first appearance
+    return rows, codes.astype(np.int64), list(names), pos, list(map(itemgetter(2), keys))
+
+
+def snp_ids_from_columns(columns):
+    """get_snp_ids_for_variants from variant_columns(var2varid): SNPs numbered in the order they first appear."""
+    import pandas as pd
+    rows, chrom_codes, _names, pos, _bases = columns
+    snp_of_key = pd.factorize((chrom_codes << 32) | pos)[0].astype(np.int32)
+    out = np.full(len(rows), -1, dtype=np.int32)
+    assert len(rows) == 0 or (rows.min() >= 0 and rows.max() < len(rows)), 'var2varid rows must enumerate 0..n_variants-1'
+    out[rows] = snp_of_key
+    assert (out >= 0).all(), 'var2varid rows must enumerate 0..n_variants-1'
+    return out
+
+
 class ProbabilisticGenotypes:
     """Dirichlet-beta table float32[capacity, G] + (chrom, pos, base) -> row.  Only the first n_variants rows are
     meaningful; genotype names must come sorted and unique (they are the posterior columns)."""
@@ -56,12 +92,15 @@ class ProbabilisticGenotypes:
         var2varid (genotypes.py:56-66; the E-step never looks at the numbers, the P-step only groups by them)."""
         if not self.var2varid:
             return np.zeros(0, dtype=np.int32)
-        keys = list(self.var2varid)
-        rows = np.fromiter(self.var2varid.values(), dtype=np.int64, count=len(keys))
-        numbering, snp_of_key = {}, np.empty(len(keys), dtype=np.int32)
-        for i, (chrom, pos, _base) in enumerate(keys):
+        columns = variant_columns(self.var2varid)
+        if columns is not None:
+            return snp_ids_from_columns(columns)
+        rows = np.fromiter(self.var2varid.values(), dtype=np.int64, count=len(self.var2varid))
+        numbering, snp_of_key = {}, np.empty(len(rows), dtype=np.int32)
+        for i, (chrom, pos, _base) in enumerate(self.var2varid):
             snp_of_key[i] = numbering.setdefault((chrom, pos), len(numbering))
-        out = np.full(len(keys), -1, dtype=np.int32)
+        out = np.full(len(rows), -1, dtype=np.int32)
+        assert len(rows) == 0 or (rows.min() >= 0 and rows.max() < len(rows)), 'var2varid rows must enumerate 0..n_variants-1'
         out[rows] = snp_of_key
         assert (out >= 0).all(), 'var2varid rows must enumerate 0..n_variants-1'
         return out

@@ -431,6 +431,16 @@ def test_repeated_problems_do_not_leak_device_memory():
         for b, g, n in sizes:
             by_shape.setdefault((b, g), set()).add(n)
         assert all(len(v) == 1 for v in by_shape.values()), sizes
+        # released blocks stay with the context for its next allocations; trim_cache hands them back, and the context
+        # goes on working (results of the same problem unchanged)
+        pen = Demultiplexer._doublet_penalties(p.n_genotypes, 0.2)
+        before = ctx.em(2, 0.01, pen, with_doublets=True)
+        assert ctx.trim_cache() > 0 and ctx.trim_cache() == 0
+        ctx.set_problem(p.n_barcodes, p.n_variants, p.n_genotypes, p.variant_id, p.compressed_cb, p.p_base_wrong, p.v2snp)
+        ctx.set_prior_betas(p.raw_betas, 1.0, True, mol_per_variant=np.bincount(p.variant_id, minlength=p.n_variants))
+        after = ctx.em(2, 0.01, pen, with_doublets=True)
+        for x, y in zip(before, after):
+            assert np.array_equal(x, y)
     finally:
         ctx.close()
 

@@ -192,3 +192,48 @@ def test_genotype_clone_is_independent():
     w = g._with_betas(np.full((2, 2), 7, dtype=np.float32))
     assert (w.variant_betas == 7).all() and (g.variant_betas != 7).all() and w.var2varid == g.var2varid
     assert w.var2varid is not g.var2varid and type(w) is type(g)
+
+
+def test_variant_key_columns_follow_the_dict_walk():
+    """The vectorised readers of var2varid (genotypes.variant_columns: _variant_keys, get_snp_ids_for_variants) against
+    a plain walk of the dict: chromosomes and SNPs numbered in order of first appearance (genotypes.py:56-66), rows
+    in any order, equal positions on different chromosomes."""
+    from demuxalot_amd import ProbabilisticGenotypes
+    from demuxalot_amd.demux import _variant_keys
+    rng = np.random.default_rng(5)
+    n = 3000
+    chroms = rng.choice(['chr2', 'chr10', 'chrX', '7', 'MT'], size=n)
+    positions = rng.integers(1, 400, size=n)  # many (chrom, pos) shared by several bases, positions shared across chromosomes
+    bases = rng.choice(list('ACGTN'), size=n)
+    keys = list(dict.fromkeys(zip(chroms.tolist(), positions.tolist(), bases.tolist())))
+    rows = rng.permutation(len(keys))
+    g = ProbabilisticGenotypes(['a', 'b'])
+    g.var2varid = {k: int(r) for k, r in zip(keys, rows)}
+    g.variant_betas = np.zeros((len(keys), 2), dtype=np.float32)
+    chrom_index, snp_index = {}, {}
+    want_chrom, want_pos, want_base, want_snp = (np.zeros(len(keys), dtype=np.int64) for _ in range(4))
+    for (chrom, pos, base), row in g.var2varid.items():
+        want_chrom[row] = chrom_index.setdefault(chrom, len(chrom_index))
+        want_pos[row] = pos
+        want_base[row] = 'ACGTN'.index(base)
+        want_snp[row] = snp_index.setdefault((chrom, pos), len(snp_index))
+    (var_chrom, var_pos, var_base), got_index = _variant_keys(g)
+    assert got_index == chrom_index and list(got_index) == list(chrom_index)
+    assert np.array_equal(var_chrom, want_chrom) and np.array_equal(var_pos, want_pos) and np.array_equal(var_base, want_base)
+    assert var_chrom.dtype == np.int32 and var_pos.dtype == np.int32 and var_base.dtype == np.uint8
+    assert np.array_equal(g.get_snp_ids_for_variants(), want_snp)
+    # what the fast path cannot represent goes through the dict walk: same answers or the same errors
+    g.var2varid[('chr2', 2 ** 40, 'A')] = len(keys)
+    g.variant_betas = np.zeros((len(keys) + 1, 2), dtype=np.float32)
+    snp = g.get_snp_ids_for_variants()
+    assert snp[len(keys)] == len(snp_index) and np.array_equal(snp[:len(keys)], want_snp)
+    del g.var2varid[('chr2', 2 ** 40, 'A')]
+    g.variant_betas = np.zeros((len(keys), 2), dtype=np.float32)
+    g.var2varid[keys[0]] = int(rows[1])  # a row twice, another one missing
+    with pytest.raises(AssertionError):
+        _variant_keys(g)
+    g.var2varid[keys[0]] = int(rows[0])
+    g.var2varid[('chr2', 5, 'AC')] = len(keys)  # not a single letter
+    g.variant_betas = np.zeros((len(keys) + 1, 2), dtype=np.float32)
+    with pytest.raises(KeyError):
+        _variant_keys(g)
