@@ -1005,7 +1005,7 @@ __global__ __launch_bounds__(256) void k_mstep_dense(MstepArgs a)
 // no request): no EXEC regions, nothing merged after a load (the compiler otherwise parks an s_waitcnt vmcnt(0)
 // behind the first conditional posterior gather of every chunk).  Needs the posterior table below 4 GiB and
 // barcode indices below 2^24 (launcher).
-template <bool SQUARE, int R, int D, bool BUF, bool DEEP = false>
+template <bool SQUARE, int R, int D, bool BUF>
 __global__ __launch_bounds__(256) void k_mstep_calls(MstepArgs a)
 {
     if (dense_regime(a)) return;
@@ -1145,128 +1145,14 @@ __global__ __launch_bounds__(256) void k_mstep_calls(MstepArgs a)
 
 #pragma unroll
     for (int r = 0; r < R; r++) val[r * 64 + lane] = 0.0f;
-    // what a chunk needs once its loads have landed: d0 = records, fc0 = barcode codes, ps0 / bm0 / q0 = the extra
-    // posteriors of its sparse calls, the bitmaps of its dense ones and the rows of the first DP of those
-    uint2 d0, fc0;
-    u64 dense0, bm0;
-    float ps0[NZ_S], q0[DP];
-    auto process = [&]() {
-    const float keep = __uint_as_float(d0.y);
-    const unsigned code = fc0.y;
-    const int nnz = (int)(code & 127u);
-    const int mine_all = nnz <= NZ_S ? nnz : 0;  // queue entries this lane's (sparse) call makes
-    // one dense call: lane g appends its contribution to queue g
-    auto put_dense = [&](int i, float q, u64 &cm) {
-        const float kp = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, keep), i));
-        const bool alive = __builtin_amdgcn_inverse_ballot_w64(lane_u64(bm0, i));
-        const u64 call_bit = 1ull << i;
-        const int pos = __popcll(cm & (call_bit - 1ull));
-        const float c = power_of(q * kp);
-        if (alive) {
-            val[pos * 64 + lane] = c;
-            cm |= call_bit;
-        }
-    };
-    auto transpose = [&](int mine) {
-        colmask[lane] = 0ull;
-#pragma unroll
-        for (int t = 0; t < NZ_S; t++) {
-            if (t > 0 && !__any(t < mine)) break;
-            if (t < mine) atomicOr(&colmask[genotype(code, t)], bit);
-        }
-        return colmask[lane];
-    };
-    auto drain = [&](u64 cm) {
-        static_assert(R % 4 == 0, "the drain reads four queue rows at a time");
-        // every queue entry is zero outside [put, drain): what is read is cleared again, so that the rows past a
-        // lane's count need no select (absent entries add +0.0, which changes nothing)
-        const int cnt = __popcll(cm);
-        for (int r = 0; __any(r < cnt); r += 4) {
-            const float v0 = val[(r + 0) * 64 + lane];
-            const float v1 = val[(r + 1) * 64 + lane];
-            const float v2 = val[(r + 2) * 64 + lane];
-            const float v3 = val[(r + 3) * 64 + lane];
-            val[(r + 0) * 64 + lane] = 0.0f;
-            val[(r + 1) * 64 + lane] = 0.0f;
-            val[(r + 2) * 64 + lane] = 0.0f;
-            val[(r + 3) * 64 + lane] = 0.0f;
-            acc += (double)v0;
-            acc += (double)v1;
-            acc += (double)v2;
-            acc += (double)v3;
-        }
-    };
-    auto put_sparse = [&](int mine) {
-#pragma unroll
-        for (int t = 0; t < NZ_S; t++) {
-            if (t > 0 && !__any(t < mine)) break;
-            if (t < mine) {
-                const int g = genotype(code, t);
-                const int pos = __popcll(colmask[g] & below);
-                val[pos * 64 + g] = power_of(ps0[t] * keep);
-            }
-        }
-    };
-    auto put_dense_calls = [&](u64 todo, u64 &cm, bool prefetched) {
-        if (prefetched) {  // the first DP dense calls of the chunk: their rows are here already
-#pragma unroll
-            for (int j = 0; j < DP; j++) {
-                if (todo) {
-                    put_dense(__builtin_ctzll(todo), q0[j], cm);
-                    todo &= todo - 1ull;
-                }
-            }
-        }
-        while (todo) {  // rows fetched here, D at a time
-            float q[D];
-            load_dense_rows(todo, d0, bm0, q);
-#pragma unroll
-            for (int j = 0; j < D; j++) {
-                if (todo) {
-                    put_dense(__builtin_ctzll(todo), q[j], cm);
-                    todo &= todo - 1ull;
-                }
-            }
-        }
-    };
-
-    u64 cm = transpose(mine_all);
-    if (!__any(__popcll(cm) + __popcll(dense0) > R)) {
-        // ---- the whole chunk fits the queues ----
-        put_dense_calls(dense0, cm, true);
-        colmask[lane] = cm;
-        put_sparse(mine_all);
-        drain(cm);
-    } else {
-        // ---- the queues could overflow: fewer calls at a time (R calls always fit) ----
-        int first_lane = 0, width = 32;
-        while (first_lane < 64) {
-            const u64 range = ((1ull << width) - 1ull) << first_lane;
-            const int mine = (range & bit) ? mine_all : 0;
-            cm = transpose(mine);
-            if (width > R && __any(__popcll(cm) + __popcll(dense0 & range) > R)) {
-                width >>= 1;
-                continue;
-            }
-            put_dense_calls(dense0 & range, cm, false);
-            colmask[lane] = cm;
-            put_sparse(mine);
-            drain(cm);
-            first_lane += width;
-        }
-    }
-    };
-
-    if constexpr (!DEEP) {
     // software pipeline: records three chunks ahead, codes two, the extra posteriors of the sparse calls and the
-    // first rows of the dense ones one.  Every load of an iteration is needed in the next one.
-    d0 = load_records(0);
-    uint2 d1 = load_records(64), d2 = load_records(128);
-    fc0 = load_code(0, d0);
-    uint2 fc1 = load_code(64, d1);
-    dense0 = __ballot((int)(fc0.y & 127u) > NZ_S);
+    // first rows of the dense ones one
+    uint2 d0 = load_records(0), d1 = load_records(64), d2 = load_records(128);
+    uint2 fc0 = load_code(0, d0), fc1 = load_code(64, d1);
+    u64 dense0 = __ballot((int)(fc0.y & 127u) > NZ_S);
+    float ps0[NZ_S], q0[DP];
     load_sparse(fc0, d0, ps0);
-    bm0 = load_dense_bitmap(fc0, d0);
+    u64 bm0 = load_dense_bitmap(fc0, d0);
     prefetch_dense_rows(dense0, d0, q0);
     for (int c0 = 0; c0 < n; c0 += 64) {
         const uint2 d3 = load_records(c0 + 192);
@@ -1276,7 +1162,111 @@ __global__ __launch_bounds__(256) void k_mstep_calls(MstepArgs a)
         load_sparse(fc1, d1, ps1);
         const u64 bm1 = load_dense_bitmap(fc1, d1);
         prefetch_dense_rows(dense1, d1, q1);
-        process();
+
+        const float keep = __uint_as_float(d0.y);
+        const unsigned code = fc0.y;
+        const int nnz = (int)(code & 127u);
+        const int mine_all = nnz <= NZ_S ? nnz : 0;  // queue entries this lane's (sparse) call makes
+        // one dense call: lane g appends its contribution to queue g
+        auto put_dense = [&](int i, float q, u64 &cm) {
+            const float kp = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, keep), i));
+            const bool alive = __builtin_amdgcn_inverse_ballot_w64(lane_u64(bm0, i));
+            const u64 call_bit = 1ull << i;
+            const int pos = __popcll(cm & (call_bit - 1ull));
+            const float c = power_of(q * kp);
+            if (alive) {
+                val[pos * 64 + lane] = c;
+                cm |= call_bit;
+            }
+        };
+        auto transpose = [&](int mine) {
+            colmask[lane] = 0ull;
+#pragma unroll
+            for (int t = 0; t < NZ_S; t++) {
+                if (t > 0 && !__any(t < mine)) break;
+                if (t < mine) atomicOr(&colmask[genotype(code, t)], bit);
+            }
+            return colmask[lane];
+        };
+        auto drain = [&](u64 cm) {
+            static_assert(R % 4 == 0, "the drain reads four queue rows at a time");
+            // every queue entry is zero outside [put, drain): what is read is cleared again, so that the rows past a
+            // lane's count need no select (absent entries add +0.0, which changes nothing)
+            const int cnt = __popcll(cm);
+            for (int r = 0; __any(r < cnt); r += 4) {
+                const float v0 = val[(r + 0) * 64 + lane];
+                const float v1 = val[(r + 1) * 64 + lane];
+                const float v2 = val[(r + 2) * 64 + lane];
+                const float v3 = val[(r + 3) * 64 + lane];
+                val[(r + 0) * 64 + lane] = 0.0f;
+                val[(r + 1) * 64 + lane] = 0.0f;
+                val[(r + 2) * 64 + lane] = 0.0f;
+                val[(r + 3) * 64 + lane] = 0.0f;
+                acc += (double)v0;
+                acc += (double)v1;
+                acc += (double)v2;
+                acc += (double)v3;
+            }
+        };
+        auto put_sparse = [&](int mine) {
+#pragma unroll
+            for (int t = 0; t < NZ_S; t++) {
+                if (t > 0 && !__any(t < mine)) break;
+                if (t < mine) {
+                    const int g = genotype(code, t);
+                    const int pos = __popcll(colmask[g] & below);
+                    val[pos * 64 + g] = power_of(ps0[t] * keep);
+                }
+            }
+        };
+        auto put_dense_calls = [&](u64 todo, u64 &cm, bool prefetched) {
+            if (prefetched) {  // the first DP dense calls of the chunk: their rows are here already
+#pragma unroll
+                for (int j = 0; j < DP; j++) {
+                    if (todo) {
+                        put_dense(__builtin_ctzll(todo), q0[j], cm);
+                        todo &= todo - 1ull;
+                    }
+                }
+            }
+            while (todo) {  // rows fetched here, D at a time
+                float q[D];
+                load_dense_rows(todo, d0, bm0, q);
+#pragma unroll
+                for (int j = 0; j < D; j++) {
+                    if (todo) {
+                        put_dense(__builtin_ctzll(todo), q[j], cm);
+                        todo &= todo - 1ull;
+                    }
+                }
+            }
+        };
+
+        u64 cm = transpose(mine_all);
+        if (!__any(__popcll(cm) + __popcll(dense0) > R)) {
+            // ---- the whole chunk fits the queues ----
+            put_dense_calls(dense0, cm, true);
+            colmask[lane] = cm;
+            put_sparse(mine_all);
+            drain(cm);
+        } else {
+            // ---- the queues could overflow: fewer calls at a time (R calls always fit) ----
+            int first_lane = 0, width = 32;
+            while (first_lane < 64) {
+                const u64 range = ((1ull << width) - 1ull) << first_lane;
+                const int mine = (range & bit) ? mine_all : 0;
+                cm = transpose(mine);
+                if (width > R && __any(__popcll(cm) + __popcll(dense0 & range) > R)) {
+                    width >>= 1;
+                    continue;
+                }
+                put_dense_calls(dense0 & range, cm, false);
+                colmask[lane] = cm;
+                put_sparse(mine);
+                drain(cm);
+                first_lane += width;
+            }
+        }
         d0 = d1; d1 = d2; d2 = d3;
         fc0 = fc1; fc1 = fc2;
         dense0 = dense1;
@@ -1285,58 +1275,6 @@ __global__ __launch_bounds__(256) void k_mstep_calls(MstepArgs a)
         for (int j = 0; j < DP; j++) q0[j] = q1[j];
 #pragma unroll
         for (int t = 0; t < NZ_S; t++) ps0[t] = ps1[t];
-    }
-    } else {
-    // Deeper software pipeline.  The records and the posterior rows come over the fabric (2-3 us), the barcode codes
-    // from L2; the wavefront's loads return in order.  So per iteration the code gather (chunk i + 3) is issued first,
-    // then the extras of chunk i + 2, then the records of chunk i + 5, and the next iteration waits for the code gather
-    // only: records and extras get TWO iterations to arrive.  Loads in flight must not be moved, so they land in fixed
-    // registers (two alternating sets for records and extras, the loop is unrolled twice) and are copied to the
-    // working registers after they have arrived.
-    struct Extras {
-        float ps[NZ_S], q[DP];
-        u64 bm;
-    };
-    uint2 d1, d2, d3, fc1, fc2;   // landed: records of chunks i .. i + 3, codes of i .. i + 2
-    uint2 rec_a, rec_b, code_l;   // in flight: records of chunks i + 3 | i + 4 (by parity), code of chunk i + 2
-    Extras ex_a, ex_b;            // in flight: extras of chunks i | i + 1 (by parity)
-    auto issue_extras = [&](uint2 fc, uint2 d, Extras &x) {
-        load_sparse(fc, d, x.ps);
-        x.bm = load_dense_bitmap(fc, d);
-        prefetch_dense_rows(__ballot((int)(fc.y & 127u) > NZ_S), d, x.q);
-    };
-    auto iteration = [&](int c0, uint2 &rec, Extras &ex) {
-        fc2 = code_l;
-        d3 = rec;
-#pragma unroll
-        for (int t = 0; t < NZ_S; t++) ps0[t] = ex.ps[t];
-#pragma unroll
-        for (int j = 0; j < DP; j++) q0[j] = ex.q[j];
-        bm0 = ex.bm;
-        dense0 = __ballot((int)(fc0.y & 127u) > NZ_S);
-        code_l = load_code(c0 + 192, d3);
-        issue_extras(fc2, d2, ex);
-        rec = load_records(c0 + 320);
-        __builtin_amdgcn_sched_barrier(0);  // the loads are issued here, in this order
-        process();
-        d0 = d1; d1 = d2; d2 = d3;
-        fc0 = fc1; fc1 = fc2;
-    };
-    d0 = load_records(0);
-    d1 = load_records(64);
-    d2 = load_records(128);
-    rec_a = load_records(192);
-    rec_b = load_records(256);
-    fc0 = load_code(0, d0);
-    fc1 = load_code(64, d1);
-    code_l = load_code(128, d2);
-    issue_extras(fc0, d0, ex_a);
-    issue_extras(fc1, d1, ex_b);
-    for (int c0 = 0; c0 < n; c0 += 128) {
-        iteration(c0, rec_a, ex_a);
-        if (c0 + 64 >= n) break;
-        iteration(c0 + 64, rec_b, ex_b);
-    }
     }
     if (lane < G) a.partial[(size_t)item * G + lane] = acc;
 }
@@ -1810,15 +1748,10 @@ hipError_t launch_mstep(hipStream_t st, const MstepArgs &a)
         const dim3 grid(blocks_for(a.n_items, 4));
         // 32-bit offsets: posterior table below 4 GiB, barcode index below 2^24 (v_mul_u32_u24), row below 2^24 bytes
         const bool buf = !a.wide && a.post_bytes < (1ull << 32) && a.first_bytes < (8ull << 24) && a.K < (1 << 22);
-        static const bool deep = [] {
-            const char *e = getenv("DEMUXALOT_AMD_MSTEP_DEEP");
-            return e ? atoi(e) != 0 : false;
-        }();
-#define MSTEP_CALLS(SQ)                                                                                      \
-    do {                                                                                                     \
-        if (buf && deep) hipLaunchKernelGGL((k_mstep_calls<SQ, 16, 4, true, true>), grid, dim3(256), 0, st, a);   \
-        else if (buf) hipLaunchKernelGGL((k_mstep_calls<SQ, 16, 4, true>), grid, dim3(256), 0, st, a);       \
-        else hipLaunchKernelGGL((k_mstep_calls<SQ, 16, 4, false>), grid, dim3(256), 0, st, a);               \
+#define MSTEP_CALLS(SQ)                                                                             \
+    do {                                                                                            \
+        if (buf) hipLaunchKernelGGL((k_mstep_calls<SQ, 16, 4, true>), grid, dim3(256), 0, st, a);   \
+        else hipLaunchKernelGGL((k_mstep_calls<SQ, 16, 4, false>), grid, dim3(256), 0, st, a);      \
     } while (0)
         if (a.square)
             MSTEP_CALLS(true);
