@@ -102,6 +102,9 @@ def load():
             raise DemuxHipError(
                 f'{LIB_PATH} is missing: build it with `python -c "import __graft_entry__ as g; g.build()"` '
                 f'or `make -C demuxalot_amd/csrc`. demuxalot_amd has no CPU fallback.')
+        # multi-process GPU work on hosts whose driver only supports dmabuf IPC (RCCL across ranks fails with
+        # "hipIpcGetMemHandle: invalid argument" otherwise); read by the HSA runtime when it starts, i.e. below
+        os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
         lib = ctypes.CDLL(LIB_PATH)
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(lib, name)
