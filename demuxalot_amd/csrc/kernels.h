@@ -78,7 +78,8 @@ __host__ __device__ inline int dict_code_pitch(int n) { return (n + 3) & ~3; }  
 constexpr int DENSE_SLOTS = 1024;            // hashed counters of the dense-call statistic
 hipError_t launch_sum_dense(hipStream_t st, unsigned long long *counters);
 constexpr int TILE_R_MAX = 9;                // barcodes per bin at most (LDS: 4 waves x 9 x 64 doubles = 18 KB per block)
-constexpr long long TILE_BYTES = 2 << 20;    // genotype-table bytes per variant tile (half of an XCD's 4 MB L2)
+constexpr long long TILE_BYTES = 1 << 20;    // genotype-table bytes per variant tile: a quarter of an XCD's 4 MB L2 (tolerance-mode E-step on
+                                             // 200k x 100k x 64: 1.480 / 1.483 / 1.510 / 1.546 ms with tiles of 0.5 / 1 / 2 / 3 MB; DEMUXALOT_AMD_TILE_KB)
 constexpr long long TILE_MIN_BARCODES = 65536;   // below this there are too few bins to fill the chip
 constexpr long long TILE_MIN_TABLE_BYTES = 8 << 20;  // a table this small is L2 / L1 resident anyway
 

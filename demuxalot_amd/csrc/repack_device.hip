@@ -408,7 +408,11 @@ static int repack_core(dmx_ctx *c, Scratch &sc, const int *d_variant, const int 
         const long long rounds = (B + TILE_R_MAX * wave_slots - 1) / (TILE_R_MAX * wave_slots);
         const long long n_bins = rounds * wave_slots;
         const int R = (int)((B + n_bins - 1) / n_bins);  // <= TILE_R_MAX
-        const unsigned tile_rows = (unsigned)std::max<long long>(1, TILE_BYTES / ((long long)G * 4));
+        static const long long tile_bytes = [] {  // experiment knob: DEMUXALOT_AMD_TILE_KB (default TILE_BYTES)
+            const char *e = std::getenv("DEMUXALOT_AMD_TILE_KB");
+            return e && atoll(e) > 0 ? atoll(e) * 1024 : TILE_BYTES;
+        }();
+        const unsigned tile_rows = (unsigned)std::max<long long>(1, tile_bytes / ((long long)G * 4));
         const int n_tiles = (int)((V + tile_rows - 1) / tile_rows);
         const size_t cells = (size_t)n_bins * n_tiles * R;
         const long long total_groups = n_pairs >> 2;
