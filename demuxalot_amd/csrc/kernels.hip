@@ -472,7 +472,7 @@ __global__ __launch_bounds__(256) void k_estep_direct(EstepArgs a)
 // The direct form gathers one genotype row (K * 4 bytes) per call from a table of V rows that no L2 holds (51 MB at
 // 200k x 64; an XCD's L2 is 4 MB): its 8192 resident wavefronts are at 8192 unrelated places of the variant axis, so
 // more than half of the row reads miss L2 and cross the fabric (measured: 7 GB per launch for 0.8 GB of algorithmic
-// bytes).  Here the variant axis is cut into TILES of ~2 MB of table, and every wavefront owns a BIN of up to
+// bytes).  Here the variant axis is cut into TILES of ~1 MB of table (kernels.h: TILE_BYTES), and every wavefront owns a BIN of up to
 // TILE_R_MAX barcodes which it walks tile by tile: the calls of barcode 0 that fall into tile 0, of barcode 1 in tile
 // 0, ... then tile 1, and so on (rows are variant-sorted, so that is a sequential walk of every row, resumed once per
 // tile).  The bins hold equal numbers of calls and there are (rounds x resident wavefronts) of them, all wavefronts
