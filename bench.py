@@ -37,6 +37,7 @@ WORKLOADS = {
     'predict_20k_20k_8': (20_000, 20_000, 8, 0.35, 1235),   # configs[1]
     'predict_200k_20k_8': (200_000, 20_000, 8, 0.35, 1245),  # configs[1]'s option table (K = 36) with enough barcodes for the packed form
     'predict_200k_20k_12': (200_000, 20_000, 12, 0.35, 1246),  # K = 78: 16 lanes x 5 slots
+    'predict_60k_20k_8': (60_000, 20_000, 8, 0.35, 1247),    # in between: the longest rows on 64 lanes, the rest packed
     'em_20k_10k_64': (20_000, 10_000, 64, 0.0, 77),         # quick check
     'em_200k_4k_64': (200_000, 4_000, 64, 0.0, 78),         # diagnostic: 2 MB genotype table (every row gather hits L2)
     'predict_20k_20k_32_doublets': (20_000, 20_000, 32, 0.25, 1240),   # K = 528: workgroup-per-barcode kernel

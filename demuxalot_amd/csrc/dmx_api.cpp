@@ -872,6 +872,7 @@ int run_estep(dmx_ctx *c, int with_doublets, bool with_prior, int prior_dtype, f
     a.bin_rows = c->d_bin_rows;
     a.bin_ptr = c->d_bin_ptr;
     a.tile_stream = c->d_tile_stream;
+    a.n_long = 0;
     a.dict_n = 0;
     a.dtab = nullptr;
     a.dtab_bytes = 0;
@@ -888,18 +889,21 @@ int run_estep(dmx_ctx *c, int with_doublets, bool with_prior, int prior_dtype, f
         HIP_TRY(dmx::launch_estep_dict_block(c->stream, a));
     else {
         // Several option slots per lane (estep_packed.hip) make a barcode's serial walk `slots` times longer, and a launch
-        // lasts at least as long as its longest barcode: it pays when the work per SIMD is a multiple of that walk
-        // (20k x 20k x 8 with doublets, longest row 3 500 calls: 0.72 ms against 0.29 ms direct).
+        // lasts at least as long as its longest barcode.  So the barcodes with more calls than a third of what a SIMD
+        // gets on average (counted by the repack) walk on 64 lanes inside the same launch; when that is more than an
+        // eighth of them the problem is one of few, long rows and the direct form takes it.  20k x 20k x 8 with
+        // doublets (longest row 3 500 calls): all packed 0.72 ms, split at 1 000 / 2 000 rows 0.32 / 0.30 ms, direct
+        // 0.28 ms - the wavefronts of a launch that fits the chip at once stay where they were placed, the heaviest
+        // 64-lane walks next to the heaviest packed ones; see DESIGN.md 4.1c.  Mode 2: every barcode packed; 3: the split
+        // wherever the shape exists.
         int lanes = 0, slots = 0;
         bool packed = c->estep_packing && with_doublets && !a.fast && a.pairs_bytes && dmx::estep_packed_shape(a.K, a.G, &lanes, &slots);
-        if (packed && c->estep_packing == 1) {
-            if (!c->n_simd) {
-                int cus = 0;
-                HIP_TRY(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, c->device));
-                c->n_simd = 4 * cus;
-            }
-            const long long per_simd = 2 * c->n_pairs / ((64 / lanes) * (long long)c->n_simd);
-            packed = c->max_row_calls > 0 && per_simd >= 2 * c->max_row_calls;
+        if (packed && c->estep_packing != 2) {
+            const int k = lanes == 8 ? 0 : lanes == 16 ? 1 : 2;
+            a.n_long = c->max_row_calls > 0 ? c->n_long_rows[k] : c->B;  // no statistic (host-packed problem): not packed
+            if (const char *e = std::getenv("DEMUXALOT_AMD_PACKED_LONG")) a.n_long = std::min<long long>(c->B, std::max(0ll, atoll(e)));  // experiment knob
+            if (c->estep_packing == 1 && 8 * a.n_long > c->B) packed = false;
+            if (!packed) a.n_long = 0;
         }
         if (packed) {
             HIP_TRY(dmx::launch_estep_packed(c->stream, a));
@@ -1300,7 +1304,7 @@ int dmx_trim_cache(dmx_ctx *c, int64_t *released_bytes)
 int dmx_set_estep_packing(dmx_ctx *c, int on)
 {
     if (!c) return fail(DMX_ERR_INVALID, "null context");
-    if (on < 0 || on > 2) return fail(DMX_ERR_INVALID, "packing mode must be 0, 1 or 2");
+    if (on < 0 || on > 3) return fail(DMX_ERR_INVALID, "packing mode must be 0 .. 3");
     c->estep_packing = on;
     return 0;
 }

@@ -86,6 +86,8 @@ struct dmx_ctx {
     int estep_packing = 1;        // dmx_set_estep_packing: 0 never, 1 where it pays, 2 wherever the shape exists
     long long max_row_calls = 0;  // calls of the longest barcode row (device repack)
     int n_simd = 0;               // SIMDs of the device (4 per CU)
+    long long long_row_calls[3] = {0, 0, 0};  // calls per SIMD at 8 / 4 / 2 barcodes per wavefront (device repack) ...
+    long long n_long_rows[3] = {0, 0, 0};     // ... and how many barcode rows have more
     int dict_distinct = 0;        // most distinct values per row found by the last dictionary build (0: none built)
     float *d_dict = nullptr;             // [prob_rows, DICT_CAP]
     unsigned char *d_codes = nullptr;    // [prob_rows, G]

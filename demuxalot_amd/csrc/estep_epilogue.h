@@ -161,6 +161,37 @@ static __device__ __forceinline__ void estep_terms(const npm::f32x2 (&p1)[H][A],
     }
 }
 
+// One batch of H call pairs (2H calls) of a wave-uniform record stream: keep / floor stay in SGPRs, the genotype
+// rows are gathered with the row offset as the buffer load's scalar offset.
+template <int A, int H, bool PAIRS>
+struct RecBatch {
+    npm::f32x2 p1[H][A], p2[H][A], keep[H], flo[H];
+};
+
+template <int A, int H, bool PAIRS>
+static __device__ __forceinline__ void load_batch(RecBatch<A, H, PAIRS> &x, const CallPair *__restrict__ recs, int j,
+                                                  __amdgpu_buffer_rsrc_t rsrc, const unsigned (&o1)[A], const unsigned (&o2)[A],
+                                                  int n_slots)
+{
+    j = __builtin_amdgcn_readfirstlane(j);  // wave-uniform by construction; says so to the compiler (scalar loads)
+#pragma unroll
+    for (int q = 0; q < H; q++) {
+        const CallPair r = recs[j + q];
+        x.keep[q] = npm::f32x2{r.keep[0], r.keep[1]};
+        x.flo[q] = npm::f32x2{r.floor[0], r.floor[1]};
+#pragma unroll
+        for (int s = 0; s < A; s++) {
+            if (A > 1 && s >= n_slots) continue;
+            x.p1[q][s].x = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, (int)o1[s], (int)r.row_off[0], 0));
+            x.p1[q][s].y = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, (int)o1[s], (int)r.row_off[1], 0));
+            if (PAIRS) {
+                x.p2[q][s].x = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, (int)o2[s], (int)r.row_off[0], 0));
+                x.p2[q][s].y = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, (int)o2[s], (int)r.row_off[1], 0));
+            }
+        }
+    }
+}
+
 template <int L>
 static __device__ __forceinline__ unsigned long long group_mask()
 {

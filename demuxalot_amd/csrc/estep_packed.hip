@@ -28,9 +28,91 @@
 
 namespace dmx {
 
+// One barcode on the whole wavefront, option k on lane k % 64, slot k / 64: the walk of k_estep_direct<64, A64, true>
+// (records through the scalar cache, rows gathered with the row offset as the buffer load's scalar offset).  For the
+// longest barcodes of a launch: a barcode's calls are added in order, so its walk is serial, and with A option slots
+// per lane it is A times longer than here.
+template <int A64>
+static __device__ __forceinline__ void walk_on_64_lanes(const EstepArgs &a, long long slot)
+{
+    const int lane = threadIdx.x & 63;
+    const int K = a.K;
+    unsigned o1[A64], o2[A64];
+    int kk[A64];
+    bool valid[A64];
+#pragma unroll
+    for (int s = 0; s < A64; s++) {
+        const int k = lane + 64 * s;
+        valid[s] = k < K;
+        kk[s] = valid[s] ? k : K - 1;
+        const unsigned pr = a.opt_pairs[kk[s]];
+        o1[s] = (pr & 0xFFFFu) * 4u;
+        o2[s] = (pr >> 16) * 4u;
+    }
+    double acc[A64];
+#pragma unroll
+    for (int s = 0; s < A64; s++) acc[s] = 0.0;
+    // The order list, the row offsets and the call records are read through the CONSTANT address space: with the packed
+    // path in the same kernel the compiler no longer proves these (wave-uniform, never written) loads unclobbered,
+    // fetched the records with vector loads and wrapped every row gather in a v_readfirstlane loop (0.60 ms for 20k x
+    // 20k x 8 against the 0.28 ms of the same walk in k_estep_direct).
+    typedef const __attribute__((address_space(4))) int *const_int_ptr;
+    typedef const __attribute__((address_space(4))) long long *const_i64_ptr;
+    typedef const __attribute__((address_space(4))) CallPair *const_rec_ptr;
+    const long long b = ((const_int_ptr)(uintptr_t)a.order)[slot];
+    const long long pbeg = ((const_i64_ptr)(uintptr_t)a.pair_ptr)[b];
+    const int npairs = (int)(((const_i64_ptr)(uintptr_t)a.pair_ptr)[b + 1] - pbeg);
+    const const_rec_ptr recs = (const_rec_ptr)(uintptr_t)(a.pairs + pbeg);
+    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void *)a.prob, 0, (int)a.prob_bytes, 0x00020000);
+    constexpr int H = A64 == 1 ? 4 : 2;  // rows are padded to 4 pairs
+    const int n_slots = (K + 63) >> 6;
+    auto load = [&](RecBatch<A64, H, true> &x, int j) {
+        j = __builtin_amdgcn_readfirstlane(j);
+#pragma unroll
+        for (int q = 0; q < H; q++) {
+            const unsigned ro0 = recs[j + q].row_off[0], ro1 = recs[j + q].row_off[1];
+            x.keep[q] = npm::f32x2{recs[j + q].keep[0], recs[j + q].keep[1]};
+            x.flo[q] = npm::f32x2{recs[j + q].floor[0], recs[j + q].floor[1]};
+#pragma unroll
+            for (int s = 0; s < A64; s++) {
+                if (A64 > 1 && s >= n_slots) continue;
+                x.p1[q][s].x = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, (int)o1[s], (int)ro0, 0));
+                x.p1[q][s].y = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, (int)o1[s], (int)ro1, 0));
+                x.p2[q][s].x = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, (int)o2[s], (int)ro0, 0));
+                x.p2[q][s].y = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, (int)o2[s], (int)ro1, 0));
+            }
+        }
+    };
+    // Two batches in flight (this kernel holds 4 wavefronts per SIMD, k_estep_direct 8: the gathers of batch i + 1 are
+    // issued before batch i is evaluated); a read past the row's last batch is redirected to it and not evaluated.
+    if (npairs > 0) {
+        RecBatch<A64, H, true> x, y;
+        load(x, 0);
+        for (int j0 = 0; j0 < npairs; j0 += 2 * H) {
+            const int j1 = j0 + H;
+            load(y, min(j1, npairs - H));
+            __builtin_amdgcn_sched_barrier(0);
+            estep_terms<A64, true, H>(x.p1, x.p2, x.keep, x.flo, acc, n_slots);
+            if (j1 >= npairs) break;
+            load(x, min(j1 + H, npairs - H));
+            __builtin_amdgcn_sched_barrier(0);
+            estep_terms<A64, true, H>(y.p1, y.p2, y.keep, y.flo, acc, n_slots);
+        }
+    }
+    estep_epilogue<64, A64>(a, b, true, acc, kk, valid, lane, lane, 0, 2 * npairs);
+}
+
 template <int L, int A>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_estep_packed(EstepArgs a)
 {
+    // the first a.n_long barcodes of the length-sorted list: one per wavefront (blocks 0 .. ceil(n_long / 4) - 1)
+    const long long long_blocks = (a.n_long + 3) >> 2;
+    if ((long long)blockIdx.x < long_blocks) {
+        const long long slot64 = (long long)blockIdx.x * 4 + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+        if (slot64 < a.n_long) walk_on_64_lanes<(L * A + 63) / 64>(a, slot64);
+        return;
+    }
+
     static_assert(L == 8 || L == 16 || L == 32, "lane groups of 8, 16 or 32");
     static_assert(A >= 2 && A <= 5, "option slots per lane");
     constexpr int CPW = 64 / L;
@@ -54,7 +136,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
 #pragma unroll
     for (int s = 0; s < A; s++) acc[s] = 0.0;
 
-    const long long slot = ((long long)blockIdx.x * 4 + (threadIdx.x >> 6)) * CPW + lane / L;
+    const long long slot = a.n_long + (((long long)blockIdx.x - long_blocks) * 4 + (threadIdx.x >> 6)) * CPW + lane / L;
     const bool live = slot < a.B;
     const long long b = a.order[live ? slot : a.B - 1];
     const long long pbeg = a.pair_ptr[b];
@@ -160,7 +242,8 @@ bool estep_packed_shape(int K, int G, int *lanes, int *slots)
 template <int L, int A>
 static void launch_packed(hipStream_t st, const EstepArgs &a)
 {
-    const unsigned blocks = (unsigned)((a.B + 4 * (64 / L) - 1) / (4 * (64 / L)));
+    const long long rest = a.B - a.n_long;
+    const unsigned blocks = (unsigned)((a.n_long + 3) / 4 + (rest + 4 * (64 / L) - 1) / (4 * (64 / L)));
     hipLaunchKernelGGL((k_estep_packed<L, A>), dim3(blocks), dim3(256), 0, st, a);
 }
 
@@ -168,7 +251,7 @@ hipError_t launch_estep_packed(hipStream_t st, const EstepArgs &a)
 {
     if (a.B == 0) return hipSuccess;
     int L = 0, A = 0;
-    if (a.fast || a.pairs_bytes == 0 || !estep_packed_shape(a.K, a.G, &L, &A)) return hipErrorInvalidValue;
+    if (a.fast || a.pairs_bytes == 0 || a.n_long < 0 || a.n_long > a.B || !estep_packed_shape(a.K, a.G, &L, &A)) return hipErrorInvalidValue;
     if (L == 8 && A == 3) launch_packed<8, 3>(st, a);
     else if (L == 8) launch_packed<8, 5>(st, a);
     else if (L == 16 && A == 3) launch_packed<16, 3>(st, a);

@@ -65,6 +65,9 @@ struct EstepArgs {
     int dtab_pitch;
     // wide doublet tables (K > DICT_LANE_K): the workgroup-per-barcode dictionary kernel reads the two arrays of
     // launch_build_dict themselves
+    // packed form (estep_packed.hip): the n_long longest barcodes (the first entries of `order`) take 64-lane
+    // wavefronts inside the same launch
+    long long n_long;
     const float *dict;            // [rows, DICT_CAP]
     const unsigned char *codes;   // [rows, dict_code_pitch(G)] 8 x index of every genotype's value in its row's dictionary
 };

@@ -77,6 +77,21 @@ __global__ __launch_bounds__(256) void k_derive_counts(const long long *__restri
     }
 }
 
+// rows with more calls than each of 3 thresholds: inv_sorted holds ~calls, ascending (longest row first)
+__global__ void k_count_longer(const unsigned *__restrict__ inv_sorted, long long n, unsigned t0, unsigned t1, unsigned t2,
+                               long long *__restrict__ out)
+{
+    const unsigned threshold = threadIdx.x == 0 ? t0 : threadIdx.x == 1 ? t1 : t2;
+    if (threadIdx.x > 2) return;
+    long long lo = 0, hi = n;  // first index whose row has <= threshold calls
+    while (lo < hi) {
+        const long long mid = (lo + hi) >> 1;
+        if (~inv_sorted[mid] > threshold) lo = mid + 1;
+        else hi = mid;
+    }
+    out[threadIdx.x] = lo;
+}
+
 __global__ __launch_bounds__(256) void k_iota(unsigned *__restrict__ out, long long n)
 {
     const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -377,6 +392,21 @@ static int repack_core(dmx_ctx *c, Scratch &sc, const int *d_variant, const int 
     long long n_pairs = 0, n_items = 0;
     unsigned longest = ~0u;  // ~calls of the longest row
     if (B) HIP_TRY(hipMemcpyAsync(&longest, inv_sorted, sizeof(unsigned), hipMemcpyDeviceToHost, st));
+    // how many rows are longer than a third of the calls a SIMD gets at 8 / 4 / 2 barcodes per wavefront (the packed
+    // E-step lets those walk on 64 lanes: dmx_api.cpp, run_estep)
+    long long h_longer[3] = {0, 0, 0}, *d_longer = nullptr;
+    if (!c->n_simd) {
+        int cus = 0;
+        HIP_TRY(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, c->device));
+        c->n_simd = 4 * cus;
+    }
+    for (int k = 0; k < 3; k++) c->long_row_calls[k] = N / (3 * (8 >> k) * (long long)std::max(1, c->n_simd));
+    if (B) {
+        DMX_TRY(sc.get(&d_longer, 3));
+        hipLaunchKernelGGL(k_count_longer, dim3(1), dim3(64), 0, st, inv_sorted, B, (unsigned)std::min<long long>(c->long_row_calls[0], 0xFFFFFFFEll),
+                           (unsigned)std::min<long long>(c->long_row_calls[1], 0xFFFFFFFEll), (unsigned)std::min<long long>(c->long_row_calls[2], 0xFFFFFFFEll), d_longer);
+        HIP_TRY(hipMemcpyAsync(h_longer, d_longer, sizeof(h_longer), hipMemcpyDeviceToHost, st));
+    }
     HIP_TRY(hipMemcpyAsync(&n_pairs, c->d_pair_ptr + B, sizeof(long long), hipMemcpyDeviceToHost, st));
     HIP_TRY(hipMemcpyAsync(&n_items, c->d_item_ptr + V, sizeof(long long), hipMemcpyDeviceToHost, st));
     HIP_TRY(hipStreamSynchronize(st));
@@ -384,6 +414,7 @@ static int repack_core(dmx_ctx *c, Scratch &sc, const int *d_variant, const int 
     c->n_pairs = n_pairs;
     c->n_items = n_items;
     c->max_row_calls = (long long)(~longest);
+    for (int k = 0; k < 3; k++) c->n_long_rows[k] = h_longer[k];
 
     // barcode-major -> E-step records
     // (CALL_PAD_PAIRS neutral records behind the last row: the dictionary form reads whole super-batches)

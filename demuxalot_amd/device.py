@@ -373,9 +373,10 @@ class DeviceContext:
         return {0: None, 1: 'direct', 2: 'dict', 3: 'dict_block', 4: 'packed'}[form.value], distinct.value
 
     def set_estep_packing(self, mode):
-        """'never' | 'auto' (default: where it pays) | 'always': several option slots per lane for narrow doublet tables
-        (include/demux_hip.h: dmx_set_estep_packing)."""
-        check(self._lib.dmx_set_estep_packing(self._h, {'never': 0, 'auto': 1, 'always': 2}[mode]))
+        """'never' | 'auto' (default: where it pays) | 'always' (every barcode on packed lane groups) | 'split' (the
+        longest barcodes on 64 lanes, the rest packed, whatever their number): several option slots per lane for narrow
+        doublet tables (include/demux_hip.h: dmx_set_estep_packing)."""
+        check(self._lib.dmx_set_estep_packing(self._h, {'never': 0, 'auto': 1, 'always': 2, 'split': 3}[mode]))
 
     def set_exchange_chunks(self, chunks):
         """Chunked (pipelined) multi-GPU exchange: > 1 cuts every rank slice into that many runs reduced while the next are

@@ -191,9 +191,11 @@ int dmx_get_estep_form(dmx_ctx *ctx, int32_t *form, int32_t *distinct_values);
 
 /* Narrow doublet tables in the exact mode (K = G (G + 1) / 2 options that fill a power-of-two lane group badly: K = 36
  * takes 36 of 64 lanes): lane groups of 8 / 16 / 32 lanes with 3 or 5 option slots per lane (csrc/estep_packed.hip).
- * mode = 1 (default): used where it wastes fewer slots than the direct form AND the problem is large enough for the
- * longer serial walk per barcode not to decide the launch (calls per SIMD >= 2 x slots... see dmx_api.cpp: run_estep);
- * 0: never; 2: wherever the shape exists.  Bit-identical results. */
+ * A barcode's calls are added in order, so with A slots per lane its walk is A times longer; the barcodes with more
+ * calls than a third of what a SIMD gets on average therefore take 64-lane wavefronts inside the same launch.
+ * mode = 1 (default): used where the shape wastes fewer slots than the direct form and at most an eighth of the
+ * barcodes are such long ones; 0: never; 2: every barcode on packed lane groups; 3: the split wherever the shape exists.
+ * Bit-identical results. */
 int dmx_set_estep_packing(dmx_ctx *ctx, int mode);
 
 /* M-step loads (G <= 64).  wide = 0 (default): 32-bit buffer offsets wherever the tables allow (posterior table below

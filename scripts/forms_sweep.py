@@ -1,7 +1,7 @@
 """Randomised bitwise comparison of the E-step forms (GPU box): python scripts/forms_sweep.py [n_trials] [first_seed]
 Every trial: a random problem (genotypes, doublets or not, barcodes, heavy-tailed and empty rows), its importer-style
 table (few distinct values per row) and the table after one M-step (all distinct); on both the E-step is run as
-direct form, dictionary form (forced) and packed form (forced) - logits and posteriors must be bit-identical across
+direct form, dictionary form (forced), packed form (forced) and packed form with the long rows on 64 lanes - logits and posteriors must be bit-identical across
 forms and equal to the numpy oracle's logits, and so must the M-step that reads what each form's epilogue left."""
 import os
 import sys
@@ -46,14 +46,14 @@ for trial in range(first, first + n_trials):
             table = ctx.probs_from_betas(0.01)
             want = oracle.barcode_logits(variant, cb, e, table, B, dp, log_impl='npsimd')
             results = {}
-            for form, (dmode, pmode) in {'direct': ('never', 'never'), 'dict': ('always', 'never'), 'packed': ('never', 'always')}.items():
+            for form, (dmode, pmode) in {'direct': ('never', 'never'), 'dict': ('always', 'never'), 'packed': ('never', 'always'), 'split': ('never', 'split')}.items():
                 ctx.set_estep_dictionary(dmode)
                 ctx.set_estep_packing(pmode)
                 logits, probs = ctx.estep(pen, with_doublets=doublets)
                 ran = ctx.estep_form()[0]
                 seen[ran] = seen.get(ran, 0) + 1
                 results[form] = (logits, probs, ctx.mstep(2.), ran)
-            for form in ('dict', 'packed'):
+            for form in ('dict', 'packed', 'split'):
                 for i, name in enumerate(('logits', 'posteriors', 'additions')):
                     fio.assert_bitwise(results[form][i], results['direct'][i], f'{what} [{stage}] {name}: {results[form][3]} vs direct')
             fio.assert_bitwise(results['direct'][0], want, f'{what} [{stage}] logits vs oracle')

@@ -48,6 +48,13 @@ def test_packed_form_equals_direct_form(oracle, n_genotypes, with_prior):
             fio.assert_bitwise(l_pk, want, 'logits: packed form vs oracle')
         # the M-step reads what the E-step epilogue left (bitmaps, barcode codes): same additions either way
         fio.assert_bitwise(ctx.mstep(2.), add_dir, 'M-step after either form')
+        # the longest barcodes on 64 lanes inside the packed launch (here: nearly all of them - few calls per SIMD)
+        ctx.set_estep_packing('split')
+        l_sp, p_sp = ctx.estep(pen, with_doublets=True, prior_logits=prior)
+        assert ctx.estep_form()[0] == form
+        fio.assert_bitwise(l_sp, l_dir, 'logits: split launch vs direct form')
+        fio.assert_bitwise(p_sp, p_dir, 'posteriors: split launch vs direct form')
+        fio.assert_bitwise(ctx.mstep(2.), add_dir, 'M-step after the split launch')
     finally:
         ctx.close()
 
@@ -78,6 +85,40 @@ def test_packed_form_rows_of_very_different_lengths(oracle):
         assert ctx.estep_form()[0] == 'packed'
         want = oracle.barcode_logits(variant, cb, e, table, n_barcodes, 0.2, log_impl='npsimd')
         fio.assert_bitwise(logits, want, 'logits: packed form vs oracle, ragged rows')
+
+
+@pytest.mark.parametrize('n_genotypes', [8, 12, 16])
+def test_split_launch_long_rows_on_64_lanes(oracle, n_genotypes):
+    """19 000 short rows and 1 000 long ones: 'auto' lets the long ones (more calls than a SIMD gets on average) walk on
+    64 lanes and packs the rest, in one launch; bit-identical to the direct form and the oracle."""
+    from demuxalot_amd import Demultiplexer
+    from demuxalot_amd.device import DeviceContext
+    rng = np.random.default_rng(21 + n_genotypes)
+    n_barcodes, n_rows = 20000, 400
+    lengths = np.full(n_barcodes, 20)
+    lengths[rng.choice(n_barcodes, size=1000, replace=False)] = 200
+    cb = np.repeat(np.arange(n_barcodes, dtype=np.int32), lengths)
+    variant = np.concatenate([rng.choice(n_rows, size=k, replace=False) for k in lengths]).astype(np.int32)
+    e = rng.uniform(0, 0.2, size=len(cb)).astype(np.float32)
+    order = np.lexsort((cb, variant))
+    variant, cb, e = variant[order], cb[order], e[order]
+    table = rng.uniform(0.01, 0.99, size=(n_rows, n_genotypes)).astype(np.float32)
+    pen = Demultiplexer._doublet_penalties(n_genotypes, 0.2)
+    with DeviceContext(0) as ctx:
+        ctx.set_estep_dictionary('never')
+        ctx.set_problem(n_barcodes, n_rows, n_genotypes, variant, cb, e, np.arange(n_rows, dtype=np.int32))
+        ctx.set_probs(table)
+        logits, probs = ctx.estep(pen, with_doublets=True)
+        assert ctx.estep_form()[0] == 'packed'   # auto: 1 000 of 20 000 rows are long
+        added = ctx.mstep(2.)
+        ctx.set_estep_packing('never')
+        l_dir, p_dir = ctx.estep(pen, with_doublets=True)
+        assert ctx.estep_form()[0] == 'direct'
+        fio.assert_bitwise(logits, l_dir, 'logits: split launch vs direct form')
+        fio.assert_bitwise(probs, p_dir, 'posteriors: split launch vs direct form')
+        fio.assert_bitwise(added, ctx.mstep(2.), 'M-step after either')
+        want = oracle.barcode_logits(variant, cb, e, table, n_barcodes, 0.2, log_impl='npsimd')
+        fio.assert_bitwise(logits, want, 'logits: split launch vs oracle')
 
 
 def test_packed_form_through_the_front_end():
