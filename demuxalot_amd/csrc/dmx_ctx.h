@@ -186,6 +186,7 @@ size_t ctx_cache_limit();
 int ctx_malloc(dmx_ctx *c, void **p, size_t bytes);
 void ctx_free(dmx_ctx *c, void *p);
 void ctx_trim(dmx_ctx *c, size_t keep_bytes);
+void ctx_retire(dmx_ctx *c);  // dmx_destroy: idle blocks to the device's retired list (for contexts created later)
 
 template <typename T>
 inline int dev_alloc(dmx_ctx *c, T **p, size_t count)

@@ -384,8 +384,9 @@ int dmx_device_bytes(dmx_ctx *ctx, int64_t *bytes);
 /* Device blocks a context has released (the previous problem's arrays, the temporaries of a repack) stay with it for its
  * next allocations: on this stack a round of hipFree + hipMalloc of a few gigabytes costs ~350 ms, the whole repack of
  * 78.65 M calls 65 ms (csrc/dmx_ctx.h: ctx_malloc).  DEMUXALOT_AMD_CACHE_GB caps the idle bytes per context (default 24;
- * 0: no caching).  dmx_trim_cache gives the idle blocks back to the driver now and reports how many bytes that were;
- * dmx_destroy does the same. */
+ * 0: no caching).  dmx_destroy passes a context's blocks on to the contexts created later on the same device (same cap).
+ * dmx_trim_cache gives this context's idle blocks and the device's retired ones back to the driver now and reports how
+ * many bytes that were. */
 int dmx_trim_cache(dmx_ctx *ctx, int64_t *released_bytes);
 
 /* ------------------------------------------------------------------------- *
