@@ -32,6 +32,10 @@
 
 namespace dmx {
 
+#ifndef PACKED_BLOCK_RECORDS
+#define PACKED_BLOCK_RECORDS 8  // records (pairs of calls) per block of the software pipeline: 4 or 8 (rows are padded to 4); 4 saves 14 VGPRs and is 1-5 % slower
+#endif
+
 // One barcode on the whole wavefront, option k on lane k % 64, slot k / 64: the walk of k_estep_direct<64, A64, true>
 // (records through the scalar cache, rows gathered with the row offset as the buffer load's scalar offset).  For the
 // longest barcodes of a launch: a barcode's calls are added in order, so its walk is serial, and with A option slots
@@ -147,22 +151,23 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
     const int npairs = live ? (int)(a.pair_ptr[b + 1] - pbeg) : 0;  // multiple of 4
     const int nmax = group_max_over_wave<L>(npairs);
 
-    // Records: lane i of a group (i mod 8) holds record 8 * block + i of the group's row; a block = 8 records = 16 calls.
+    // Records: lane i of a group (i mod BR) holds record BR * block + i of the group's row; a block = BR records.
     // Past the end of the row: the neutral record behind the last row (keep 0, floor 1: log(p * 0 + 1) = +0).
     const unsigned neutral = (unsigned)a.pair_ptr[a.B] * 32u;
     const unsigned row_begin = (unsigned)pbeg * 32u;
     const char *__restrict__ recs = (const char *)a.pairs;
     const char *__restrict__ prob = (const char *)a.prob;
     const unsigned my_col = (unsigned)(li < a.G ? li : a.G - 1) * 4u;  // the genotype this lane fetches of every row
-    const int l8 = li & 7;
-    int bcast[8];  // ds_bpermute address of the group's lane that holds record r of a block
+    constexpr int BR = PACKED_BLOCK_RECORDS;
+    const int l8 = li & (BR - 1);
+    int bcast[BR];  // ds_bpermute address of the group's lane that holds record r of a block
 #pragma unroll
-    for (int r = 0; r < 8; r++) bcast[r] = (gbase + r) * 4;
+    for (int r = 0; r < BR; r++) bcast[r] = (gbase + r) * 4;
 
     struct Rec {
         uint2 ro, keep, fl;
     };
-    auto load_block = [&](int first) {  // records first .. first + 7 of every group, one per lane
+    auto load_block = [&](int first) {  // records first .. first + BR - 1 of every group, one per lane
         const int idx = first + l8;
         const unsigned off = idx < npairs ? row_begin + (unsigned)idx * 32u : neutral;
         Rec r;
@@ -171,16 +176,16 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
         r.fl = *(const uint2 *)(recs + off + 16);
         return r;
     };
-    auto load_rows = [&](const Rec &blk, float (&rows)[16]) {  // p[my genotype] of the 16 calls of a block
+    auto load_rows = [&](const Rec &blk, float (&rows)[2 * BR]) {  // p[my genotype] of the 2 BR calls of a block
 #pragma unroll
-        for (int r = 0; r < 8; r++) {
+        for (int r = 0; r < BR; r++) {
             const unsigned ro0 = (unsigned)__builtin_amdgcn_ds_bpermute(bcast[r], (int)blk.ro.x);
             const unsigned ro1 = (unsigned)__builtin_amdgcn_ds_bpermute(bcast[r], (int)blk.ro.y);
             rows[2 * r] = *(const float *)(prob + (ro0 + my_col));
             rows[2 * r + 1] = *(const float *)(prob + (ro1 + my_col));
         }
     };
-    auto terms = [&](const Rec &blk, const float (&rows)[16], int r) {
+    auto terms = [&](const Rec &blk, const float (&rows)[2 * BR], int r) {
         npm::f32x2 p1[1][A], p2[1][A], keep[1], flo[1];
         keep[0].x = __int_as_float(__builtin_amdgcn_ds_bpermute(bcast[r], (int)blk.keep.x));
         keep[0].y = __int_as_float(__builtin_amdgcn_ds_bpermute(bcast[r], (int)blk.keep.y));
@@ -202,20 +207,20 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
         // broadcast from the lanes that hold its records), the 8 x 2 calls of block k evaluated.  What is requested at
         // the start of a block is first needed one block (8 records x A slots x ~140 cycles) later, which is what
         // a SIMD with two or three wavefronts of this kernel needs: it cannot count on other wavefronts to hide a load.
-        Rec cur = load_block(0), nxt = load_block(8);
-        float rows[16], rows_nxt[16];
+        Rec cur = load_block(0), nxt = load_block(BR);
+        float rows[2 * BR], rows_nxt[2 * BR];
         load_rows(cur, rows);
-        for (int j = 0; j < nmax; j += 8) {
-            const Rec far = load_block(j + 16);
+        for (int j = 0; j < nmax; j += BR) {
+            const Rec far = load_block(j + 2 * BR);
             load_rows(nxt, rows_nxt);
             __builtin_amdgcn_sched_barrier(0);  // the loads are issued here, not where their values are first used
 #pragma unroll
-            for (int r = 0; r < 8; r++) terms(cur, rows, r);
+            for (int r = 0; r < BR; r++) terms(cur, rows, r);
             __builtin_amdgcn_sched_barrier(0);
             cur = nxt;
             nxt = far;
 #pragma unroll
-            for (int i = 0; i < 16; i++) rows[i] = rows_nxt[i];
+            for (int i = 0; i < 2 * BR; i++) rows[i] = rows_nxt[i];
         }
     }
     estep_epilogue<L, A>(a, b, live, acc, kk, valid, lane, li, gbase, 2 * npairs);
