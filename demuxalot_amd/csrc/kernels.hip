@@ -232,7 +232,7 @@ static __device__ __forceinline__ void fast_walk_single(const CallPair *__restri
     const int l32 = lane & 31;
     auto fetch = [&](int k) {  // dword (lane % 32) of batch k; batches past the end re-read the last one
         const int kk = k < n_batches ? k : n_batches - 1;
-        return (int)words[(size_t)kk * 32 + l32];
+        return (int)__builtin_nontemporal_load(&words[(size_t)kk * 32 + l32]);  // read once: keep the table rows in L2
     };
     auto issue = [&](int w, FastBatch &g) {  // row offsets of a batch -> SGPRs -> its 8 gathers in flight
         g.rec = w;
