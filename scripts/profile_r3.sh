@@ -16,7 +16,7 @@ with open(sys.argv[2], 'w') as out:
     w = csv.writer(out)
     w.writerow(['Name', 'Calls', 'TotalDurationNs', 'AverageNs', 'Percentage', 'MinNs', 'MaxNs'])
     for r in rows:
-        name = r['Name'].split('(')[0]
+        name = r['Name'].replace('(anonymous namespace)::', '').split('(')[0]
         if 'rocprim' in name: name = 'rocprim::' + name.split('rocprim::')[-1][:60] + ' (device repack)'
         w.writerow([name, r['Calls'], r['TotalDurationNs'], r['AverageNs'], r['Percentage'], r['MinNs'], r['MaxNs']])
 PY
