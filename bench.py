@@ -225,7 +225,8 @@ def e2e_timing(problem, doublet_prior, n_iterations=5):
     dev2.close()
     # the same steps by hand, for the split
     pen = Demultiplexer._doublet_penalties(genotypes.n_genotypes, doublet_prior)
-    ctx = DeviceContext(0)
+    from demuxalot_amd.device import acquire_private_context, release_private_context
+    ctx = acquire_private_context()  # what the calls themselves take: a pooled context, its device blocks re-used
     try:
         t_pack, _ = timed(lambda: (_pack_on_device(calls, genotypes, B, False, fetch_betas=False, ctx=ctx), ctx.synchronize()))
         ctx.set_addition(None)
@@ -237,7 +238,7 @@ def e2e_timing(problem, doublet_prior, n_iterations=5):
         pen0 = Demultiplexer._doublet_penalties(genotypes.n_genotypes, 0.)
         t_em, _ = timed(lambda: (ctx.em(n_iterations, 0.01, pen0, with_doublets=False, fetch_logits=False, fetch_probs=False), ctx.synchronize()))
     finally:
-        ctx.close()
+        release_private_context(ctx)
     return {
         'workload_molecule_calls': n_molecule_calls, 'barcodes': B,
         'predict_posteriors_s': t_predict, 'predict_barcodes_per_s': B / t_predict,

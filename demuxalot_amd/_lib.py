@@ -37,6 +37,9 @@ SIGNATURES = {
                                          POINTER(c_int64), POINTER(c_int64), _P]),
     'dmx_pack_containers_and_set_problem': (c_int, [_P, c_int64, c_int64, c_int32, _P, _P, _P, _P, _P, c_int32,
                                                     POINTER(c_int64), POINTER(c_int64), _P]),
+    'dmx_stage_containers': (c_int, [_P, _P, c_int32]),
+    'dmx_pack_staged_and_set_problem': (c_int, [_P, c_int64, c_int64, c_int32, _P, _P, _P, _P, _P, c_int32,
+                                                POINTER(c_int64), POINTER(c_int64), _P]),
     'dmx_get_packed_calls': (c_int, [_P, _P, _P, _P, _P]),
     'dmx_set_betas': (c_int, [_P, _P]),
     'dmx_set_prior_betas': (c_int, [_P, _P, c_double, c_int, _P, _P]),

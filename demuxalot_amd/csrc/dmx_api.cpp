@@ -1164,6 +1164,7 @@ int dmx_destroy(dmx_ctx *c)
     for (hipEvent_t e : c->ev_chunk) (void)hipEventDestroy(e);
     if (c->ev_exchanged) (void)hipEventDestroy(c->ev_exchanged);
     if (c->d_scratch) (void)hipFree(c->d_scratch);
+    dmx::release_staged_calls(c);
     (void)hipDeviceSynchronize();  // the second stream and the chunk streams too
     ctx_retire(c);
     for (auto &t : c->timers) {
@@ -1313,6 +1314,38 @@ int dmx_pack_containers_and_set_problem(dmx_ctx *c, int64_t B, int64_t V, int32_
     long long matched = 0, unique = 0;
     DMX_TRY(dmx::pack_containers_on_device(c, V, var_chrom, var_pos, var_base, containers, n_containers, &matched, &unique,
                                            (long long *)mol_per_variant));
+    *n_matched = matched;
+    *n_unique = unique;
+    return finish_problem(c, v2snp, snp_ptr, snp_vars);
+}
+
+int dmx_stage_containers(dmx_ctx *c, const dmx_call_container *containers, int32_t n_containers)
+{
+    DMX_TRY(bind(c));
+    if (n_containers < 0 || (n_containers > 0 && !containers)) return fail(DMX_ERR_INVALID, "bad container list");
+    for (int k = 0; k < n_containers; k++) {
+        const dmx_call_container &p = containers[k];
+        if (p.n_snp_calls < 0 || p.n_molecules < 0) return fail(DMX_ERR_INVALID, "container %d: negative size", k);
+        if (p.n_snp_calls > 0 && (!p.snp_calls || !p.molecules || p.n_molecules == 0))
+            return fail(DMX_ERR_INVALID, "container %d: calls without a molecule table", k);
+    }
+    return dmx::stage_containers_on_device(c, containers, n_containers);
+}
+
+int dmx_pack_staged_and_set_problem(dmx_ctx *c, int64_t B, int64_t V, int32_t G, const int32_t *var_chrom, const int32_t *var_pos,
+                                    const uint8_t *var_base, const int32_t *v2snp, const int32_t *chrom_of_container,
+                                    int32_t n_containers, int64_t *n_matched, int64_t *n_unique, int64_t *mol_per_variant)
+{
+    DMX_TRY(bind(c));
+    if (!n_matched || !n_unique || n_containers < 0) return fail(DMX_ERR_INVALID, "bad sizes or null counters");
+    if (V > 0 && (!var_chrom || !var_pos || !var_base)) return fail(DMX_ERR_INVALID, "null variant arrays");
+    if (c->n_staged < 0) return fail(DMX_ERR_INVALID, "call order: dmx_stage_containers before dmx_pack_staged_and_set_problem");
+    std::vector<int> snp_ptr, snp_vars;
+    long long S = 0;
+    DMX_TRY(begin_problem(c, B, V, G, v2snp, snp_ptr, snp_vars, S));
+    long long matched = 0, unique = 0;
+    DMX_TRY(dmx::pack_staged_on_device(c, V, var_chrom, var_pos, var_base, chrom_of_container, n_containers, &matched, &unique,
+                                       (long long *)mol_per_variant));
     *n_matched = matched;
     *n_unique = unique;
     return finish_problem(c, v2snp, snp_ptr, snp_vars);

@@ -166,6 +166,11 @@ struct dmx_ctx {
     void *d_recv = nullptr;         // this rank's reduced slice
     size_t exch_bytes = 0, recv_bytes = 0;
 
+    // flat call arrays of staged containers (dmx_stage_containers -> dmx_pack_staged_and_set_problem); n_staged < 0: none
+    int *st_chrom = nullptr, *st_pos = nullptr, *st_cb = nullptr;
+    unsigned char *st_base = nullptr;
+    float *st_p = nullptr;
+    long long n_staged = -1;
     int64_t bytes = 0;
     TimerSlot timers[DMX_T_COUNT];
 
@@ -224,6 +229,10 @@ int pack_on_device(dmx_ctx *c, long long V, const int *var_chrom, const int *var
 // matched molecule calls (molecule order) -> the (barcode, SNP)-grouped layout of the aggregate_on_snps E-step
 int ensure_sum_plan(dmx_ctx *c, long long K);  // dmx_api.cpp
 int build_snp_groups(dmx_ctx *c, const unsigned long long *vb_keys, const unsigned *src_idx, const float *src_p, long long m);
+int stage_containers_on_device(dmx_ctx *c, const dmx_call_container *parts, int n_parts);
+int pack_staged_on_device(dmx_ctx *c, long long V, const int *var_chrom, const int *var_pos, const unsigned char *var_base,
+                          const int *chrom_table, int n_table, long long *n_matched, long long *n_unique, long long *mol_per_variant);
+void release_staged_calls(dmx_ctx *c);
 int pack_containers_on_device(dmx_ctx *c, long long V, const int *var_chrom, const int *var_pos,
                               const unsigned char *var_base, const dmx_call_container *parts, int n_parts,
                               long long *n_matched, long long *n_unique, long long *mol_per_variant);

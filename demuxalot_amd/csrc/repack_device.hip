@@ -805,22 +805,47 @@ __global__ __launch_bounds__(256) void k_flatten_container(const unsigned char *
 
 }  // namespace
 
-int pack_containers_on_device(dmx_ctx *c, long long V, const int *var_chrom, const int *var_pos,
-                              const unsigned char *var_base, const dmx_call_container *parts, int n_parts,
-                              long long *n_matched, long long *n_unique, long long *mol_per_variant)
+// chromosome numbers of staged calls: from the caller's provisional numbering (container order) to var_chrom's
+__global__ __launch_bounds__(256) void k_remap_chrom(int *__restrict__ chrom, long long n, const int *__restrict__ table, int n_table,
+                                                     int *__restrict__ bad)
+{
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int k = chrom[i];
+    const int to = k >= 0 && k < n_table ? table[k] : -1;
+    if (to < 0) atomicOr(bad, 1);
+    chrom[i] = to;
+}
+
+void release_staged_calls(dmx_ctx *c)
+{
+    ctx_free(c, c->st_chrom);
+    ctx_free(c, c->st_pos);
+    ctx_free(c, c->st_base);
+    ctx_free(c, c->st_cb);
+    ctx_free(c, c->st_p);
+    c->st_chrom = c->st_pos = c->st_cb = nullptr;
+    c->st_base = nullptr;
+    c->st_p = nullptr;
+    c->n_staged = -1;
+}
+
+// Upload + field extraction of the containers' records (everything of the pack that does not need the variant keys):
+// the flat call arrays stay with the context until pack_staged_on_device (or the next staging) takes them.
+int stage_containers_on_device(dmx_ctx *c, const dmx_call_container *parts, int n_parts)
 {
     hipStream_t st = c->stream;
+    release_staged_calls(c);
     Scratch sc(c);
     long long n_calls = 0;
     for (int k = 0; k < n_parts; k++) n_calls += parts[k].n_snp_calls;
-    int *d_cchrom, *d_cpos, *d_ccb, *bad;
-    unsigned char *d_cbase;
-    float *d_cp;
-    DMX_TRY(sc.get(&d_cchrom, (size_t)n_calls));
-    DMX_TRY(sc.get(&d_cpos, (size_t)n_calls));
-    DMX_TRY(sc.get(&d_cbase, (size_t)n_calls));
-    DMX_TRY(sc.get(&d_ccb, (size_t)n_calls));
-    DMX_TRY(sc.get(&d_cp, (size_t)n_calls));
+    const size_t n = (size_t)(n_calls ? n_calls : 1);
+    DMX_TRY(ctx_malloc(c, (void **)&c->st_chrom, n * sizeof(int)));
+    DMX_TRY(ctx_malloc(c, (void **)&c->st_pos, n * sizeof(int)));
+    DMX_TRY(ctx_malloc(c, (void **)&c->st_base, n));
+    DMX_TRY(ctx_malloc(c, (void **)&c->st_cb, n * sizeof(int)));
+    DMX_TRY(ctx_malloc(c, (void **)&c->st_p, n * sizeof(float)));
+    int *bad;
     DMX_TRY(sc.get(&bad, 1));
     HIP_TRY(hipMemsetAsync(bad, 0, sizeof(int), st));
     long long at = 0;
@@ -831,17 +856,57 @@ int pack_containers_on_device(dmx_ctx *c, long long V, const int *var_chrom, con
         DMX_TRY(upload(sc, &d_calls, (const unsigned char *)part.snp_calls, (size_t)part.n_snp_calls * SNP_CALL_BYTES, st));
         DMX_TRY(upload(sc, &d_molecules, (const unsigned char *)part.molecules, (size_t)part.n_molecules * MOLECULE_BYTES, st));
         hipLaunchKernelGGL(k_flatten_container, dim3(grid_for(part.n_snp_calls)), dim3(256), 0, st, d_calls, part.n_snp_calls,
-                           d_molecules, part.n_molecules, part.chrom, d_cchrom + at, d_cpos + at, d_cbase + at, d_ccb + at,
-                           d_cp + at, bad);
+                           d_molecules, part.n_molecules, part.chrom, c->st_chrom + at, c->st_pos + at, c->st_base + at, c->st_cb + at,
+                           c->st_p + at, bad);
         at += part.n_snp_calls;
     }
     HIP_TRY(hipGetLastError());
     int h_bad = 0;
     HIP_TRY(hipMemcpyAsync(&h_bad, bad, sizeof(int), hipMemcpyDeviceToHost, st));
     HIP_TRY(hipStreamSynchronize(st));  // also: the caller's buffers are free to change from here on
-    if (h_bad) return fail(DMX_ERR_INVALID, "molecule_index outside the molecule table");
-    return pack_core(c, sc, V, var_chrom, var_pos, var_base, n_calls, d_cchrom, d_cpos, d_cbase, d_ccb, d_cp, n_matched,
-                     n_unique, mol_per_variant);
+    if (h_bad) {
+        release_staged_calls(c);
+        return fail(DMX_ERR_INVALID, "molecule_index outside the molecule table");
+    }
+    c->n_staged = n_calls;
+    return 0;
+}
+
+// The rest of the pack on the staged calls.  chrom_table (nullable): var_chrom's number of the chromosome every staged
+// call carries provisionally (-1: no variant on it - calls there are an error, demux.py:339-341, 359).
+int pack_staged_on_device(dmx_ctx *c, long long V, const int *var_chrom, const int *var_pos, const unsigned char *var_base,
+                          const int *chrom_table, int n_table, long long *n_matched, long long *n_unique, long long *mol_per_variant)
+{
+    if (c->n_staged < 0) return fail(DMX_ERR_INVALID, "call order: no staged call containers (dmx_stage_containers first)");
+    hipStream_t st = c->stream;
+    Scratch sc(c);
+    const long long n_calls = c->n_staged;
+    if (chrom_table && n_calls) {
+        int *d_table, *bad;
+        DMX_TRY(upload(sc, &d_table, chrom_table, (size_t)std::max(1, n_table), st));
+        DMX_TRY(sc.get(&bad, 1));
+        HIP_TRY(hipMemsetAsync(bad, 0, sizeof(int), st));
+        hipLaunchKernelGGL(k_remap_chrom, dim3(grid_for(n_calls)), dim3(256), 0, st, c->st_chrom, n_calls, d_table, n_table, bad);
+        int h_bad = 0;
+        HIP_TRY(hipMemcpyAsync(&h_bad, bad, sizeof(int), hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipStreamSynchronize(st));
+        if (h_bad) {
+            release_staged_calls(c);
+            return fail(DMX_ERR_INVALID, "calls on a chromosome without variants");
+        }
+    }
+    const int rc = pack_core(c, sc, V, var_chrom, var_pos, var_base, n_calls, c->st_chrom, c->st_pos, c->st_base, c->st_cb, c->st_p,
+                             n_matched, n_unique, mol_per_variant);
+    release_staged_calls(c);
+    return rc;
+}
+
+int pack_containers_on_device(dmx_ctx *c, long long V, const int *var_chrom, const int *var_pos,
+                              const unsigned char *var_base, const dmx_call_container *parts, int n_parts,
+                              long long *n_matched, long long *n_unique, long long *mol_per_variant)
+{
+    DMX_TRY(stage_containers_on_device(c, parts, n_parts));
+    return pack_staged_on_device(c, V, var_chrom, var_pos, var_base, nullptr, 0, n_matched, n_unique, mol_per_variant);
 }
 
 }  // namespace dmx

@@ -82,32 +82,59 @@ class DeviceContext:
         self.B, self.V, self.G, self.N = int(n_barcodes), int(n_variants), int(n_genotypes), n_unique.value
         return n_matched.value, n_unique.value, mol_per_variant
 
-    def pack_containers_and_set_problem(self, n_barcodes, n_genotypes, var_chrom, var_pos, var_base, v2snp, containers):
-        """pack_and_set_problem fed with the raw record arrays of the call containers:
-        `containers` = [(chromosome index, snp_calls[:n] (SNP_CALL_DTYPE), molecules[:m] (MOLECULE_DTYPE))].
-        The field extraction and the molecule -> barcode lookup happen on the GPU."""
+    def _container_list(self, containers):
         from .snp_counter import MOLECULE_DTYPE, SNP_CALL_DTYPE
 
         class Container(ctypes.Structure):
             _fields_ = [('snp_calls', ctypes.c_void_p), ('n_snp_calls', ctypes.c_int64),
                         ('molecules', ctypes.c_void_p), ('n_molecules', ctypes.c_int64), ('chrom', ctypes.c_int32)]
 
-        var_chrom, var_pos, var_base = as_c(var_chrom, np.int32), as_c(var_pos, np.int32), as_c(var_base, np.uint8)
-        v2snp = as_c(v2snp, np.int32)
-        n_variants = len(var_pos)
-        assert len(v2snp) == n_variants
         keep_alive, parts = [], (Container * max(1, len(containers)))()
         for k, (chrom, snp_calls, molecules) in enumerate(containers):
             assert snp_calls.dtype == SNP_CALL_DTYPE and molecules.dtype == MOLECULE_DTYPE
             snp_calls, molecules = np.ascontiguousarray(snp_calls), np.ascontiguousarray(molecules)
             keep_alive += [snp_calls, molecules]
             parts[k] = Container(snp_calls.ctypes.data, len(snp_calls), molecules.ctypes.data, len(molecules), int(chrom))
+        return parts, keep_alive
+
+    def pack_containers_and_set_problem(self, n_barcodes, n_genotypes, var_chrom, var_pos, var_base, v2snp, containers):
+        """pack_and_set_problem fed with the raw record arrays of the call containers:
+        `containers` = [(chromosome index, snp_calls[:n] (SNP_CALL_DTYPE), molecules[:m] (MOLECULE_DTYPE))].
+        The field extraction and the molecule -> barcode lookup happen on the GPU."""
+        var_chrom, var_pos, var_base = as_c(var_chrom, np.int32), as_c(var_pos, np.int32), as_c(var_base, np.uint8)
+        v2snp = as_c(v2snp, np.int32)
+        n_variants = len(var_pos)
+        assert len(v2snp) == n_variants
+        parts, _keep_alive = self._container_list(containers)
         mol_per_variant = np.zeros(n_variants, dtype=np.int64)
         n_matched, n_unique = ctypes.c_int64(0), ctypes.c_int64(0)
         check(self._lib.dmx_pack_containers_and_set_problem(
             self._h, n_barcodes, n_variants, n_genotypes, ptr(var_chrom), ptr(var_pos), ptr(var_base), ptr(v2snp),
             ctypes.cast(parts, ctypes.c_void_p), len(containers), ctypes.byref(n_matched), ctypes.byref(n_unique),
             ptr(mol_per_variant)))
+        self.B, self.V, self.G, self.N = int(n_barcodes), int(n_variants), int(n_genotypes), n_unique.value
+        return n_matched.value, n_unique.value, mol_per_variant
+
+    def stage_containers(self, containers):
+        """First half of pack_containers_and_set_problem: upload + field extraction of the containers' records, which
+        needs nothing of the genotypes (`containers` as there, the chromosome index provisional: the position in the
+        list).  The resident problem stays as it is.  include/demux_hip.h: dmx_stage_containers."""
+        parts, _keep_alive = self._container_list(containers)
+        check(self._lib.dmx_stage_containers(self._h, ctypes.cast(parts, ctypes.c_void_p), len(containers)))
+
+    def pack_staged_and_set_problem(self, n_barcodes, n_genotypes, var_chrom, var_pos, var_base, v2snp, chrom_of_container):
+        """Second half: variant matching, de-duplication and layouts on the staged calls.  chrom_of_container[k] = the
+        chromosome index (numbering of var_chrom) of the k-th staged container, -1 when no variant lies on it."""
+        var_chrom, var_pos, var_base = as_c(var_chrom, np.int32), as_c(var_pos, np.int32), as_c(var_base, np.uint8)
+        v2snp = as_c(v2snp, np.int32)
+        table = as_c(chrom_of_container, np.int32)
+        n_variants = len(var_pos)
+        assert len(v2snp) == n_variants
+        mol_per_variant = np.zeros(n_variants, dtype=np.int64)
+        n_matched, n_unique = ctypes.c_int64(0), ctypes.c_int64(0)
+        check(self._lib.dmx_pack_staged_and_set_problem(
+            self._h, n_barcodes, n_variants, n_genotypes, ptr(var_chrom), ptr(var_pos), ptr(var_base), ptr(v2snp),
+            ptr(table), len(table), ctypes.byref(n_matched), ctypes.byref(n_unique), ptr(mol_per_variant)))
         self.B, self.V, self.G, self.N = int(n_barcodes), int(n_variants), int(n_genotypes), n_unique.value
         return n_matched.value, n_unique.value, mol_per_variant
 

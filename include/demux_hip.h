@@ -126,6 +126,18 @@ int dmx_pack_containers_and_set_problem(dmx_ctx *ctx, int64_t n_barcodes, int64_
                                         int32_t n_containers, int64_t *n_matched, int64_t *n_unique,
                                         int64_t *mol_per_variant);
 
+/* The same in two steps, so that the upload of the containers (which needs nothing of the genotypes) can run while the
+ * caller is still turning var2varid into the variant key arrays: dmx_stage_containers uploads the records and takes
+ * them apart (`chrom` = any provisional numbering, e.g. the container's position in the list; the resident problem is
+ * not touched), dmx_pack_staged_and_set_problem does the rest; chrom_of_container[k] = var_chrom's number of provisional
+ * chromosome k, or -1 when no variant lies on it (staged calls there are an error: demux.py:339-341, 359), NULL = the
+ * numbers are final already. */
+int dmx_stage_containers(dmx_ctx *ctx, const dmx_call_container *containers, int32_t n_containers);
+int dmx_pack_staged_and_set_problem(dmx_ctx *ctx, int64_t n_barcodes, int64_t n_variants, int32_t n_genotypes,
+                                    const int32_t *var_chrom, const int32_t *var_pos, const uint8_t *var_base,
+                                    const int32_t *v2snp, const int32_t *chrom_of_container, int32_t n_containers,
+                                    int64_t *n_matched, int64_t *n_unique, int64_t *mol_per_variant);
+
 /* Regularised prior betas float32[V*G] (output of pack_calls, demux.py:372-388). */
 int dmx_set_betas(dmx_ctx *ctx, const float *prior_betas);
 

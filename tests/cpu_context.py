@@ -100,6 +100,20 @@ class OracleContext:
         self.cuts, self.slice_rows, self.sliced = exchange_slices(self.v2snp, self.world)
         self.sliced = self.sliced and self.dist is not None
 
+    def stage_containers(self, containers):
+        """Two-step form of the device pack (DeviceContext.stage_containers): the chromosome numbers are provisional."""
+        self._staged = list(containers)
+
+    def pack_staged_and_set_problem(self, n_barcodes, n_genotypes, var_chrom, var_pos, var_base, v2snp, chrom_of_container):
+        staged, self._staged = self._staged, None
+        final = []
+        for k, calls, molecules in staged:
+            chrom = int(chrom_of_container[k])
+            assert chrom >= 0 or len(calls) == 0, 'calls on a chromosome without variants'
+            if chrom >= 0:
+                final.append((chrom, calls, molecules))
+        return self.pack_containers_and_set_problem(n_barcodes, n_genotypes, var_chrom, var_pos, var_base, v2snp, final)
+
     def pack_containers_and_set_problem(self, n_barcodes, n_genotypes, var_chrom, var_pos, var_base, v2snp, containers):
         """The host twin of the device pack (dmx_pack_calls_host: product code that needs no GPU)."""
         import ctypes
