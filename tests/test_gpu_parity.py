@@ -580,3 +580,35 @@ def test_mstep_wide_addresses_are_the_same_sums(G, cpb, power):
         ctx.set_mstep_wide_addresses(False)
     fio.assert_bitwise(wide, narrow, f'wide vs 32-bit M-step loads, G={G}')
     assert np.array_equal(narrow, ctx.mstep(power))
+
+
+def test_containers_on_chromosomes_without_variants():
+    """The front-end stages the containers before it knows which chromosomes carry variants (the upload runs beside the
+    walk of var2varid): an empty container on such a chromosome changes nothing, one with calls trips the same assertion
+    as the reference's (demux.py:339-341, 359), and the raw ABI refuses staged calls without a chromosome."""
+    from demuxalot_amd import CompressedSNPCalls, Demultiplexer, _lib
+    from demuxalot_amd.device import DeviceContext
+    fx = fio.load('f2_synthetic_g4.npz')
+    calls, genotypes, handler = fio.product_inputs(fx)
+    want = Demultiplexer.predict_posteriors(calls, genotypes, handler, doublet_prior=0.)
+    empty = CompressedSNPCalls.from_arrays(np.zeros(0, np.int32), np.zeros(0, np.int32), np.zeros(0, np.int32), np.zeros(0, np.uint8),
+                                           np.zeros(0, np.float32))
+    with_empty = dict([('chrNone', empty)] + list(calls.items()) + [('chrZ', empty)])
+    got = Demultiplexer.predict_posteriors(with_empty, genotypes, handler, doublet_prior=0.)
+    for a, b in zip(got, want):
+        fio.assert_bitwise(a.values, b.values, 'an empty container on a chromosome without variants')
+    stray = CompressedSNPCalls.from_arrays(np.zeros(1, np.int32), np.zeros(1, np.int32), np.full(1, 77, np.int32), np.zeros(1, np.uint8),
+                                           np.full(1, 0.01, np.float32))
+    with pytest.raises(AssertionError):
+        Demultiplexer.predict_posteriors(dict(list(calls.items()) + [('chrZ', stray)]), genotypes, handler, doublet_prior=0.)
+    # and the next call on the shared context works as if nothing had been staged
+    again = Demultiplexer.predict_posteriors(calls, genotypes, handler, doublet_prior=0.)
+    fio.assert_bitwise(again[1].values, want[1].values, 'after the refused call')
+    with DeviceContext(0) as ctx:
+        ctx.stage_containers([(0, stray.snp_calls[:1], stray.molecules[:1])])
+        with pytest.raises(_lib.DemuxHipError, match='chromosome without variants'):
+            ctx.pack_staged_and_set_problem(handler.n_barcodes, 2, np.zeros(1, np.int32), np.full(1, 77, np.int32), np.zeros(1, np.uint8),
+                                            np.zeros(1, np.int32), [-1])
+        with pytest.raises(_lib.DemuxHipError, match='call order'):  # nothing staged any more
+            ctx.pack_staged_and_set_problem(handler.n_barcodes, 2, np.zeros(1, np.int32), np.full(1, 77, np.int32), np.zeros(1, np.uint8),
+                                            np.zeros(1, np.int32), [0])
