@@ -361,6 +361,10 @@ void timer_end(dmx_ctx *c, int slot, const std::pair<hipEvent_t, hipEvent_t> &ev
 
 void release_problem(dmx_ctx *c)
 {
+    // the blocks released here are handed out again at once (ctx_malloc) to work ordered on c->stream: whatever the
+    // other streams of the context still have queued on them must be done first (hipFree used to wait for the device)
+    if (c->stream2) (void)hipStreamSynchronize(c->stream2);
+    for (hipStream_t ms : c->chunk_streams) (void)hipStreamSynchronize(ms);
     dev_free(c, &c->d_pair_ptr, (size_t)c->B + 1);
     dev_free(c, &c->d_call_pairs, (size_t)c->n_pairs + dmx::CALL_PAD_PAIRS);
     dev_free(c, &c->d_call_rows, ((size_t)c->n_pairs + dmx::CALL_PAD_PAIRS) * 2);
