@@ -399,6 +399,7 @@ def main():
         elapsed = plane.max_float64(elapsed)
     timers = ctx.timings()
     em_form = ctx.estep_form()[0]  # what the E-steps of the timed iterations ran (direct | packed)
+    guard_stats = ctx.guard_stats()  # (last, total, rows) of the guarded E-steps of the timed region
 
     # the tolerance-mode E-step (dmx_set_estep_mode: assignments identical, posteriors within the contract's 1e-5)
     # with the fast summation mode, timed the same way on the same resident problem; the default (bit-exact)
@@ -490,6 +491,8 @@ def main():
             'kernel_ms': {k: (v['ms'] / max(1, v['launches'])) for k, v in timers.items()},
             'exchange_ms_per_step': timers['allreduce']['ms'] / max(1, args.steps),
             'roofline': roofline(args.workload, ab, e_ms, m_ms, timers, N, G, K, em_form),
+            'guard': {'barcodes_redone_exactly': guard_stats[1], 'barcode_rows': guard_stats[2],
+                      'fraction': guard_stats[1] / max(1, guard_stats[2])},
             'setup_s': {'generate': t_gen, 'upload': t_up},
             'fast_mode': fast,
         }

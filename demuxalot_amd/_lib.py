@@ -79,6 +79,7 @@ SIGNATURES = {
     'dmx_set_exact_additions': (c_int, [_P, c_int]),
     'dmx_get_redo_count': (c_int, [_P, POINTER(c_int64)]),
     'dmx_set_estep_mode': (c_int, [_P, c_int]),
+    'dmx_get_guard_stats': (c_int, [_P, POINTER(c_int64), POINTER(c_int64), POINTER(c_int64)]),
     'dmx_set_estep_schedule': (c_int, [_P, c_int]),
     'dmx_set_estep_dictionary': (c_int, [_P, c_int]),
     'dmx_get_estep_form': (c_int, [_P, POINTER(c_int32), POINTER(c_int32)]),
@@ -87,6 +88,7 @@ SIGNATURES = {
     'dmx_test_logf': (c_int, [_P, _P, _P, c_int64]),
     'dmx_test_logf_hot': (c_int, [_P, _P, _P, c_int64]),
     'dmx_test_expf': (c_int, [_P, _P, _P, c_int64]),
+    'dmx_test_log2_hw': (c_int, [_P, _P, _P, c_int64]),
     'dmx_test_softmax': (c_int, [_P, _P, _P, c_int64, c_int64]),
 }
 

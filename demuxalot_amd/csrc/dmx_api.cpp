@@ -424,6 +424,10 @@ void release_problem(dmx_ctx *c)
     dev_free(c, &c->d_first, (size_t)c->B);
     dev_free(c, &c->d_dense_calls, (size_t)1 + dmx::DENSE_SLOTS);
     c->dense_stat_valid = false;
+    dev_free(c, &c->d_guard_count, (size_t)2);
+    dev_free(c, &c->d_guard_list, (size_t)c->B);
+    c->guard_rows_total = 0;
+    c->guard_ran = false;
     dev_free(c, &c->d_dict, c->cap_dict_rows * dmx::DICT_CAP);
     dev_free(c, &c->d_codes, c->cap_dict_rows * (size_t)dmx::dict_code_pitch(c->G));
     dev_free(c, &c->d_dtab, c->cap_dtab);
@@ -847,7 +851,7 @@ int prepare_dictionary(dmx_ctx *c, bool pairs, dmx::EstepArgs &a, int *form)
     a.dict_n = 0;
     c->dict_distinct = 0;
     const bool wanted = c->dict_mode == 2 || (c->dict_mode == 1 && c->dict_candidate);
-    if (!wanted || c->estep_mode != DMX_ESTEP_EXACT || c->B == 0 || c->prob_rows == 0) return 0;
+    if (!wanted || c->estep_mode == DMX_ESTEP_FAST || c->B == 0 || c->prob_rows == 0) return 0;  // (guarded: exact and faster)
     const int G = c->G;
     const long long K = c->K, rows = c->prob_rows;
     const bool block_form = pairs && K > dmx::DICT_LANE_K;  // wide doublet tables: workgroup per barcode
@@ -930,7 +934,15 @@ int run_estep(dmx_ctx *c, int with_doublets, bool with_prior, int prior_dtype, f
     a.prob_bytes = (unsigned)((unsigned long long)c->prob_rows * c->G * 4ull);
     a.G = c->G;
     a.K = c->K;
-    a.fast = c->estep_mode == DMX_ESTEP_FAST;
+    // Guarded mode: the tolerance-mode kernels wherever a lane-per-option one exists (estep_epilogue.h: estep_guard), the
+    // exact mode for the workgroup-per-barcode shapes
+    const bool guarded = c->estep_mode == DMX_ESTEP_GUARDED && c->K <= 1024 && !(with_doublets && c->K > 256);
+    a.fast = c->estep_mode == DMX_ESTEP_FAST || guarded;
+    a.guard = 0;
+    a.guard_count = c->d_guard_count;
+    a.guard_list = c->d_guard_list;
+    a.order_count = nullptr;
+    c->guard_ran = false;
     a.tiled = c->tiled_estep;
     a.n_bins = c->tiled_estep ? c->n_bins : 0;
     a.bin_rows_cap = c->bin_rows_cap;
@@ -974,6 +986,22 @@ int run_estep(dmx_ctx *c, int with_doublets, bool with_prior, int prior_dtype, f
         if (packed) {
             HIP_TRY(dmx::launch_estep_packed(c->stream, a));
             form = DMX_FORM_PACKED;
+        } else if (guarded) {
+            // fast kernels with the guard evaluated per barcode, then the exact kernel over the barcodes they queued (their
+            // number is only known on the device: a launch sized for all of them, the wavefronts past the queue's end
+            // return at once); the redo rewrites logits, posteriors, bitmaps and codes of those barcodes
+            HIP_TRY(hipMemsetAsync(c->d_guard_count, 0, sizeof(unsigned), c->stream));
+            a.guard = 1;
+            HIP_TRY(dmx::launch_estep(c->stream, a, with_doublets != 0));
+            dmx::EstepArgs redo = a;
+            redo.fast = 0;
+            redo.guard = 0;
+            redo.n_bins = 0;
+            redo.order = c->d_guard_list;
+            redo.order_count = c->d_guard_count;
+            HIP_TRY(dmx::launch_estep(c->stream, redo, with_doublets != 0));
+            c->guard_rows_total += c->B;
+            c->guard_ran = true;
         } else {
             HIP_TRY(dmx::launch_estep(c->stream, a, with_doublets != 0));
         }
@@ -1245,6 +1273,9 @@ static int finish_problem(dmx_ctx *c, const int32_t *v2snp, const std::vector<in
     DMX_TRY(dev_alloc(c, &c->d_nz, (size_t)B * ((G + 63) / 64)));
     DMX_TRY(dev_alloc(c, &c->d_first, (size_t)B));
     DMX_TRY(dev_alloc(c, &c->d_dense_calls, (size_t)1 + dmx::DENSE_SLOTS));
+    DMX_TRY(dev_alloc(c, &c->d_guard_count, (size_t)2));
+    DMX_TRY(dev_alloc(c, &c->d_guard_list, (size_t)B));
+    HIP_TRY(hipMemsetAsync(c->d_guard_count, 0, 2 * sizeof(unsigned), c->stream));
     DMX_TRY(dev_alloc(c, &c->d_best, (size_t)B));
     DMX_TRY(dev_alloc(c, &c->d_bestp, (size_t)B));
     hipStream_t st = c->stream;
@@ -1379,8 +1410,22 @@ int dmx_set_exact_additions(dmx_ctx *c, int exact)
 int dmx_set_estep_mode(dmx_ctx *c, int mode)
 {
     if (!c) return fail(DMX_ERR_INVALID, "null context");
-    if (mode != DMX_ESTEP_EXACT && mode != DMX_ESTEP_FAST) return fail(DMX_ERR_INVALID, "unknown E-step mode %d", mode);
+    if (mode != DMX_ESTEP_EXACT && mode != DMX_ESTEP_FAST && mode != DMX_ESTEP_GUARDED) return fail(DMX_ERR_INVALID, "unknown E-step mode %d", mode);
     c->estep_mode = mode;
+    return 0;
+}
+
+int dmx_get_guard_stats(dmx_ctx *c, int64_t *redone_last, int64_t *redone_total, int64_t *rows_total)
+{
+    DMX_TRY(bind(c));
+    unsigned n[2] = {0u, 0u};
+    if (c->d_guard_count) {
+        HIP_TRY(hipMemcpyAsync(n, c->d_guard_count, sizeof n, hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(hipStreamSynchronize(c->stream));
+    }
+    if (redone_last) *redone_last = c->guard_ran ? (int64_t)n[0] : 0;
+    if (redone_total) *redone_total = (int64_t)n[1];
+    if (rows_total) *rows_total = (int64_t)c->guard_rows_total;
     return 0;
 }
 
@@ -1827,6 +1872,8 @@ int dmx_reset_timings(dmx_ctx *c)
 {
     DMX_TRY(bind(c));
     HIP_TRY(hipStreamSynchronize(c->stream));
+    if (c->d_guard_count) HIP_TRY(hipMemsetAsync(c->d_guard_count + 1, 0, sizeof(unsigned), c->stream));
+    c->guard_rows_total = 0;
     for (int s = 0; s < DMX_T_COUNT; s++) {
         timer_flush(c, s);
         c->timers[s].ms = 0.0;
@@ -1866,6 +1913,7 @@ static int unary_test(dmx_ctx *c, const float *in, float *out, int64_t n, int wh
     if (which == 0) HIP_TRY(dmx::launch_test_log(c->stream, d_in, d_out, n));
     if (which == 1) HIP_TRY(dmx::launch_test_exp(c->stream, d_in, d_out, n));
     if (which == 3) HIP_TRY(dmx::launch_test_log_hot(c->stream, d_in, d_out, n));
+    if (which == 4) HIP_TRY(dmx::launch_test_log2_hw(c->stream, d_in, d_out, n));
     if (which == 2) HIP_TRY(dmx::launch_test_softmax(c->stream, d_in, d_out, rows, (int)cols));
     HIP_TRY(hipMemcpyAsync(out, d_out, (size_t)n * 4, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
@@ -1875,6 +1923,7 @@ static int unary_test(dmx_ctx *c, const float *in, float *out, int64_t n, int wh
 int dmx_test_logf(dmx_ctx *c, const float *in, float *out, int64_t n) { return unary_test(c, in, out, n, 0, 0, 0); }
 int dmx_test_logf_hot(dmx_ctx *c, const float *in, float *out, int64_t n) { return unary_test(c, in, out, n, 3, 0, 0); }
 int dmx_test_expf(dmx_ctx *c, const float *in, float *out, int64_t n) { return unary_test(c, in, out, n, 1, 0, 0); }
+int dmx_test_log2_hw(dmx_ctx *c, const float *in, float *out, int64_t n) { return unary_test(c, in, out, n, 4, 0, 0); }
 int dmx_test_softmax(dmx_ctx *c, const float *in, float *out, int64_t rows, int64_t cols)
 {
     if (rows < 0 || cols <= 0 || cols > (1 << 24)) return fail(DMX_ERR_INVALID, "bad softmax test shape");

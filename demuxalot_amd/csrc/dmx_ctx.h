@@ -76,6 +76,11 @@ struct dmx_ctx {
     int item_calls = 1024;  // work-item length of the resident problem (kernels.h: item_calls_for)
     bool exact_additions = true;  // dmx_set_exact_additions
     int estep_mode = DMX_ESTEP_EXACT;  // dmx_set_estep_mode
+    // guarded mode: barcodes queued by the epilogues of the fast kernels for the exact redo (kernels.h: EstepArgs::guard)
+    unsigned *d_guard_count = nullptr;  // [2] this E-step | all E-steps since the last reset
+    int *d_guard_list = nullptr;        // [B]
+    long long guard_rows_total = 0;     // barcode rows the guarded kernels have walked since the last reset
+    bool guard_ran = false;             // the last E-step evaluated the guard
     int tiled_estep = 1;               // dmx_set_estep_schedule: 0 never, 1 when it pays, 2 whenever the repack built one
     // dictionary form of the E-step (estep_dict.hip): tried when the genotype table was computed without a beta
     // addition (or supplied by the caller), used when every row has few distinct values

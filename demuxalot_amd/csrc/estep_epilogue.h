@@ -198,26 +198,85 @@ static __device__ __forceinline__ unsigned long long group_mask()
     return L >= 64 ? ~0ull : (1ull << (L & 63)) - 1ull;
 }
 
+// ------------------------------------------------------------------------------------
+// Guarded mode (DMX_ESTEP_GUARDED, include/demux_hip.h).  The tolerance-mode kernels leave, per option k of a barcode
+// with n (padded) calls, S'_k = their float64 sum of log terms.  Against the reference's S_k (float64 sum of numpy's
+// float32 logs of the same float32 terms t_i in [1e-4, 1 + 1.0001e-4]):
+//   |S_true - S_k|  <= RHO sum_i |log t_i| <= RHO (|S_true| + 2.1e-4 n)   numpy's float32 log is within RHO = 2.73e-7
+//                      relative of the true log for every float32 in [1e-4, 2.0002] (exhaustive: tests/test_oracle_npsimd.py);
+//                      terms above 1 are below 1.0001e-4 + 2^-23, hence the second summand
+//   |S'_k - S_true| <= (n / 8) (7 x 2^-24 + 2 ulp(log2) ln 2) <= 6.3e-8 n   one float32 rounding per multiplication of
+//                      the 8-term product (no underflow: P >= 1e-32), v_log_f32 of a mantissa in [0.5, 1) within 2 ulp
+//                      (exhaustive on the device: tests/test_gpu_guarded.py), exponents exact, float64 accumulation
+//   logit: both sides round pen + S to float32 (2^-24 relative each) and, with a prior, the sum with it once more.
+// D_k is the sum of the three with the constants rounded up; D = max_k D_k.  With every logit off by at most D,
+// p'_k / p_k and (1 - p'_k) / (1 - p_k) lie in [e^-2D, e^2D], so |p'_k - p_k| <= min(p_k, 1 - p_k) (e^2D - 1); the
+// float32 evaluation of the softmax (numpy's exp, pairwise sum, division: a few ulp of p on either side) gets the
+// 2e-6 between GUARD_TOL and the contract's 1e-5.  The argmax is the reference's when no other logit is within 2 D
+// of the largest.  Returns true (uniform over the lane group) when the barcode must be redone exactly.
+// ------------------------------------------------------------------------------------
+constexpr float GUARD_RHO = 3.0e-7f;
+constexpr float GUARD_POSITIVE_TERM = 2.1e-4f;
+constexpr float GUARD_PER_CALL = 7.0e-8f;
+constexpr float GUARD_LOGIT_ROUNDING = 1.2e-7f;  // 2 x 2^-24 (reference and here) with the conversions' slack
+constexpr float GUARD_TOL = 8.0e-6f;
+
+template <int L, int A>
+static __device__ __forceinline__ bool estep_guard(const float (&dev)[A], const float (&lg)[A], const float (&post)[A],
+                                                   const bool (&valid)[A], float mx, int gbase)
+{
+    float dmax = 0.0f;
+    bool bad = false;
+#pragma unroll
+    for (int s = 0; s < A; s++) {
+        if (!valid[s]) continue;
+        bad |= !(dev[s] < 0.25f);  // also NaN; keeps e^x - 1 <= x (1 + x) applicable below
+        dmax = fmaxf(dmax, dev[s]);
+    }
+#pragma unroll
+    for (int off = 1; off < L; off <<= 1) dmax = fmaxf(dmax, __shfl_xor(dmax, off));
+    const float x2 = 2.0f * dmax;
+    const float e2 = x2 * (1.0f + x2) * 1.000001f;               // >= e^{2D} - 1
+    const float near = mx - (x2 + 2.4e-7f * fabsf(mx)) * 1.000001f;  // logits at or above this could be the reference's argmax
+    int close = 0;
+#pragma unroll
+    for (int s = 0; s < A; s++) {
+        const float m = fminf(post[s], 1.0f - post[s]);
+        bad |= valid[s] && !(m * e2 <= GUARD_TOL);
+        const unsigned long long bal = __ballot(valid[s] && !(lg[s] < near));
+        close += __popcll(L == 64 ? bal : (bal >> gbase) & group_mask<L>());
+    }
+    const unsigned long long any_bad = __ballot(bad);
+    return close != 1 || (L == 64 ? any_bad : (any_bad >> gbase) & group_mask<L>()) != 0ull;
+}
+
 // Epilogue of the lane-per-option forms: penalties, optional prior, softmax as scipy evaluates it, the M-step's bitmap.
 // acc[s] = float64 sum of the log terms of option kk[s] = li + L * s of barcode b (one lane group of L lanes per barcode).
-template <int L, int A>
+// GUARD: instantiated by the tolerance-mode kernels; evaluates estep_guard when a.guard is set.
+template <int L, int A, bool GUARD = false>
 static __device__ __forceinline__ void estep_epilogue(const EstepArgs &a, long long b, bool live, const double (&acc)[A],
                                                       const int (&kk)[A], const bool (&valid)[A], int lane, int li, int gbase,
                                                       int row_calls)
 {
     const int K = a.K;
     float lg[A], x[A];
+    float dev[A];  // GUARD: bound on |logit - reference logit| per option
     float mx = -__builtin_inff();
 #pragma unroll
     for (int s = 0; s < A; s++) {
         const double t = (double)a.pen[kk[s]] + acc[s];
         float l = (float)t;
+        if (GUARD) {
+            const float n = (float)row_calls;
+            dev[s] = GUARD_RHO * (fabsf((float)acc[s]) + GUARD_POSITIVE_TERM * n) + GUARD_PER_CALL * (n + 8.0f) + GUARD_LOGIT_ROUNDING * fabsf(l);
+        }
         if (a.prior) {
             const size_t o = (size_t)b * K + kk[s];
             if (a.prior_dtype == DMX_F32)
                 l = l + ((const float *)a.prior)[o];
             else
                 l = (float)((double)l + ((const double *)a.prior)[o]);
+            if (GUARD) dev[s] += GUARD_LOGIT_ROUNDING * fabsf(l);
         }
         lg[s] = l;
         mx = valid[s] ? fmaxf(mx, l) : mx;
@@ -248,6 +307,16 @@ static __device__ __forceinline__ void estep_epilogue(const EstepArgs &a, long l
         }
     }
     if (L < 64 && live && li == 0) a.nz[(size_t)b] = mine;
+    bool redo = false;  // GUARD: the exact kernel takes this barcode again (it rewrites everything written here)
+    if constexpr (GUARD) {
+        if (a.guard) {
+            redo = estep_guard<L, A>(dev, lg, post, valid, mx, gbase);
+            if (redo && live && li == 0) {
+                a.guard_list[atomicAdd(a.guard_count, 1u)] = (int)b;
+                atomicAdd(a.guard_count + 1, 1u);
+            }
+        }
+    }
     if (a.first) {
         // what the M-step's call-parallel part needs of this barcode, 8 bytes (nz_code): ONE gather per call there,
         // from a table small enough to stay in L2
@@ -257,7 +326,7 @@ static __device__ __forceinline__ void estep_epilogue(const EstepArgs &a, long l
         for (int s = 1; s < A; s++) p0 = (g0 >> log2_lanes<L>()) == s ? post[s] : p0;
         if (live && li == (g0 & (L - 1))) a.first[b] = nz_code(mine, p0);
         // statistic for the M-step's choice of kernel (G <= 64): calls whose barcode has more than 4 live posteriors
-        if (a.dense_calls && live && li == 0 && __popcll(mine) > 4)
+        if (a.dense_calls && live && !redo && li == 0 && __popcll(mine) > 4)
             atomicAdd(a.dense_calls + 1 + (b & (DENSE_SLOTS - 1)), (unsigned long long)row_calls);
     }
 }

@@ -48,6 +48,13 @@ struct EstepArgs {
     int G;
     int K;
     int fast;                   // DMX_ESTEP_FAST: tolerance mode (products of 8 terms + hardware log2), see kernels.hip
+    // guarded mode (DMX_ESTEP_GUARDED; estep_epilogue.h: guard_flags): the fast kernels bound their deviation from the
+    // reference per barcode and queue the barcodes whose posteriors / argmax are not provably within the contract
+    int guard;                  // the epilogue evaluates the guard and appends to guard_list
+    unsigned *guard_count;      // [2] barcodes queued by this E-step | by all E-steps since the last reset
+    int *guard_list;            // [B] the queued barcodes
+    const unsigned *order_count;  // nullable: `order` holds *order_count entries (<= B), known on the device only (the exact
+                                  // redo of the queued barcodes: k_estep_direct over guard_list)
     // tile-major schedule (k_estep_tiled); n_bins == 0: not built for this problem
     int tiled;                  // dmx_set_estep_schedule: 0 never, 1 when it pays (tolerance mode), 2 whenever built
     long long n_bins;
@@ -177,6 +184,7 @@ hipError_t launch_assign(hipStream_t st, const float *post, long long B, int K, 
 hipError_t launch_test_log(hipStream_t st, const float *in, float *out, long long n);
 hipError_t launch_test_log_hot(hipStream_t st, const float *in, float *out, long long n);
 hipError_t launch_test_exp(hipStream_t st, const float *in, float *out, long long n);
+hipError_t launch_test_log2_hw(hipStream_t st, const float *in, float *out, long long n);
 hipError_t launch_test_softmax(hipStream_t st, const float *in, float *out, long long rows, int cols);
 
 }  // namespace dmx

@@ -334,11 +334,13 @@ __global__ __launch_bounds__(256) void k_estep_direct(EstepArgs a)
     long long b;
     bool live;
     int row_calls = 0;  // calls of this lane group's barcode (incl. padding)
+    // rows of `order` to walk: all B, or as many as the guarded E-step queued (known on the device only)
+    const long long n_rows = a.order_count ? (long long)min((unsigned long long)*a.order_count, (unsigned long long)a.B) : a.B;
     if constexpr (L == 64) {
         // ---- wave-uniform path: everything about the row lives in SGPRs ----
         const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
         const long long slot = (long long)blockIdx.x * 4 + wave;
-        if (slot >= a.B) return;
+        if (slot >= n_rows) return;
         live = true;
         b = a.order[slot];
         const long long pbeg = a.pair_ptr[b];
@@ -376,9 +378,10 @@ __global__ __launch_bounds__(256) void k_estep_direct(EstepArgs a)
             }
         }
     } else {
+        if (((long long)blockIdx.x * 4 + (threadIdx.x >> 6)) * CPW >= n_rows) return;  // the whole wavefront past the list
         const long long slot = ((long long)blockIdx.x * 4 + (threadIdx.x >> 6)) * CPW + lane / L;
-        live = slot < a.B;
-        b = a.order[live ? slot : a.B - 1];
+        live = slot < n_rows;
+        b = a.order[live ? slot : n_rows - 1];
         const long long pbeg = a.pair_ptr[b];
         const int n = live ? 2 * (int)(a.pair_ptr[b + 1] - pbeg) : 0;  // calls incl. padding, multiple of 8
         row_calls = n;
@@ -433,7 +436,7 @@ __global__ __launch_bounds__(256) void k_estep_direct(EstepArgs a)
         for (int s = 0; s < A; s++) acc[s] = (facc[s].mant + (double)facc[s].expo) * LN2;
     }
 
-    estep_epilogue<L, A>(a, b, live, acc, kk, valid, lane, li, gbase, row_calls);
+    estep_epilogue<L, A, FAST>(a, b, live, acc, kk, valid, lane, li, gbase, row_calls);
 }
 
 // ------------------------------------------------------------------------------------
@@ -558,7 +561,7 @@ __global__ __launch_bounds__(256) void k_estep_tiled(EstepArgs a)
             out[s] = sh_acc[wave][r][s][lane];
             if (FAST) out[s] *= 0.693147180559945309417232121458176568;
         }
-        estep_epilogue<64, A>(a, (long long)row, true, out, kk, valid, lane, lane, 0,
+        estep_epilogue<64, A, FAST>(a, (long long)row, true, out, kk, valid, lane, lane, 0,
                               2 * (int)(a.pair_ptr[row + 1] - a.pair_ptr[row]));
     }
 }
@@ -1495,6 +1498,13 @@ __global__ __launch_bounds__(256) void k_test_log_hot(const float *in, float *ou
     if (has2) out[i + 1] = r.y;
 }
 
+// the hardware log2 of the tolerance / guarded modes (v_log_f32), for the exhaustive accuracy check of its mantissa range
+__global__ __launch_bounds__(256) void k_test_log2_hw(const float *in, float *out, long long n)
+{
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = __builtin_amdgcn_logf(in[i]);
+}
+
 __global__ __launch_bounds__(256) void k_test_exp(const float *in, float *out, long long n)
 {
     const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -1833,6 +1843,13 @@ hipError_t launch_test_log_hot(hipStream_t st, const float *in, float *out, long
 {
     if (n == 0) return hipSuccess;
     hipLaunchKernelGGL(k_test_log_hot, dim3(blocks_for(n, 512)), dim3(256), 0, st, in, out, n);
+    return hipGetLastError();
+}
+
+hipError_t launch_test_log2_hw(hipStream_t st, const float *in, float *out, long long n)
+{
+    if (n == 0) return hipSuccess;
+    hipLaunchKernelGGL(k_test_log2_hw, dim3(blocks_for(n, 256)), dim3(256), 0, st, in, out, n);
     return hipGetLastError();
 }
 

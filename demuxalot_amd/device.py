@@ -10,6 +10,10 @@ from . import _lib
 from ._lib import DMX_F32, DMX_F64, as_c, check, ptr
 
 
+# E-step arithmetic of a new context (include/demux_hip.h: dmx_set_estep_mode); DEMUXALOT_AMD_ESTEP overrides
+DEFAULT_ESTEP_MODE = 'exact'
+
+
 class DeviceContext:
     def __init__(self, device=0):
         self._lib = _lib.load()
@@ -23,13 +27,18 @@ class DeviceContext:
 
     def apply_environment(self):
         """The modes the environment selects (also re-applied when a pooled context is handed out again):
-        DEMUXALOT_AMD_EXACT_ADDITIONS=0 trades the bit-identical genotype additions of the hottest variants (several work
-        items) for ~4 % per EM iteration (include/demux_hip.h: dmx_set_exact_additions); DEMUXALOT_AMD_ESTEP=fast selects the
-        tolerance-mode E-step (dmx_set_estep_mode); DEMUXALOT_AMD_ESTEP_SCHEDULE = direct | auto | tiled
+        DEMUXALOT_AMD_ESTEP = exact | guarded | fast (dmx_set_estep_mode); DEMUXALOT_AMD_EXACT_ADDITIONS = 1 | 0: the
+        bit-identical genotype additions of the hottest variants (several work items) cost ~4 % per EM iteration
+        (include/demux_hip.h: dmx_set_exact_additions; default: with the exact E-step); DEMUXALOT_AMD_ESTEP_SCHEDULE = direct | auto | tiled
         (dmx_set_estep_schedule); DEMUXALOT_AMD_ESTEP_DICT = never | auto | always (dmx_set_estep_dictionary);
         DEMUXALOT_AMD_ESTEP_PACKED = never | auto | always (dmx_set_estep_packing)."""
-        self.set_exact_additions(os.environ.get('DEMUXALOT_AMD_EXACT_ADDITIONS', '1') not in ('0', ''))
-        self.set_estep_mode('fast' if os.environ.get('DEMUXALOT_AMD_ESTEP', 'exact') == 'fast' else 'exact')
+        mode = os.environ.get('DEMUXALOT_AMD_ESTEP', '') or DEFAULT_ESTEP_MODE
+        assert mode in ('exact', 'fast', 'guarded'), f'DEMUXALOT_AMD_ESTEP={mode!r}: exact, fast or guarded'
+        self.set_estep_mode(mode)
+        # the M-step's exact summation keeps the additions bit-identical to the reference GIVEN bit-identical posteriors:
+        # it goes with the exact E-step unless asked for
+        exact_additions = os.environ.get('DEMUXALOT_AMD_EXACT_ADDITIONS', '')
+        self.set_exact_additions(mode == 'exact' if exact_additions == '' else exact_additions != '0')
         self.set_estep_schedule(os.environ.get('DEMUXALOT_AMD_ESTEP_SCHEDULE', 'auto'))
         self.set_estep_dictionary(os.environ.get('DEMUXALOT_AMD_ESTEP_DICT', 'auto'))
         self.set_estep_packing(os.environ.get('DEMUXALOT_AMD_ESTEP_PACKED', 'auto'))
@@ -382,9 +391,17 @@ class DeviceContext:
                                            DMX_F64 if reduce_dtype == 'f64' else DMX_F32))
 
     def set_estep_mode(self, mode):
-        """'exact' (default: logits / posteriors bit-identical to the reference) or 'fast' (tolerance mode:
-        assignments identical, posteriors within the contract's 1e-5); include/demux_hip.h: dmx_set_estep_mode."""
-        check(self._lib.dmx_set_estep_mode(self._h, {'exact': 0, 'fast': 1}[mode]))
+        """'exact' (logits / posteriors bit-identical to the reference), 'guarded' (tolerance-mode arithmetic, every
+        barcode whose posteriors are not provably within the contract's 1e-5 of the reference's - or whose argmax could
+        differ - redone exactly) or 'fast' (tolerance mode, unguarded); include/demux_hip.h: dmx_set_estep_mode."""
+        check(self._lib.dmx_set_estep_mode(self._h, {'exact': 0, 'fast': 1, 'guarded': 2}[mode]))
+
+    def guard_stats(self):
+        """(barcodes the last guarded E-step redid exactly, the same over all E-steps since reset_timings, barcode rows
+        those E-steps walked); include/demux_hip.h: dmx_get_guard_stats."""
+        last, total, rows = ctypes.c_int64(0), ctypes.c_int64(0), ctypes.c_int64(0)
+        check(self._lib.dmx_get_guard_stats(self._h, ctypes.byref(last), ctypes.byref(total), ctypes.byref(rows)))
+        return last.value, total.value, rows.value
 
     def set_estep_dictionary(self, mode):
         """'never' | 'auto' (default: tried for genotype tables computed without a beta addition) | 'always' (tried for
@@ -462,6 +479,12 @@ class DeviceContext:
         x = as_c(x, np.float32)
         out = np.empty_like(x)
         check(self._lib.dmx_test_logf_hot(self._h, ptr(x), ptr(out), x.size))
+        return out
+
+    def test_log2_hw(self, x):
+        x = as_c(x, np.float32)
+        out = np.empty_like(x)
+        check(self._lib.dmx_test_log2_hw(self._h, ptr(x), ptr(out), x.size))
         return out
 
     def test_exp(self, x):

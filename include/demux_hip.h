@@ -170,9 +170,26 @@ int dmx_get_redo_count(dmx_ctx *ctx, int64_t *count);
  *   product's mantissa (exponents summed as integers, mantissa logs in float64).  Deviations from the reference
  *   are of the size of one float32 rounding of the logit (the reference's own logits carry that much rounding
  *   noise); roughly 6x less VALU work per term, which leaves the E-step bound by the genotype-row gather. */
+/* DMX_ESTEP_GUARDED: the tolerance-mode arithmetic with the contract GUARANTEED per E-step instead of observed.  The
+ *   epilogue of every barcode bounds |logit_fast - logit_reference| for each option k,
+ *       D_k = RHO |S_k| (numpy's float32 log is within RHO = 2.73e-7 relative of the true log on [1e-4, 2]: exhaustive,
+ *             tests/test_oracle_npsimd.py) + 7e-8 per call (7 float32 roundings of the 8-term product + a 2-ulp hardware
+ *             log2 per 8 calls) + the float32 roundings of the logit itself,
+ *   and keeps the fast result only when, with D = max_k D_k,
+ *       min(p_k, 1 - p_k) (e^{2D} - 1) <= 8e-6 for every option (=> |posterior - reference posterior| <= 1e-5 with
+ *       2e-6 left for the float32 evaluation of the softmax on either side), and
+ *       no second logit lies within 2 D of the largest (=> the same argmax);
+ *   every other barcode is queued on the device and redone by the exact kernel in the same E-step, so its logits and
+ *   posteriors are the reference's bit for bit.  Where the dictionary form applies (exact and faster) it is used
+ *   unchanged.  dmx_get_guard_stats counts the barcodes redone.  Shapes without a guarded kernel (option tables beyond
+ *   1024, doublet tables beyond 256 in this mode) run the exact mode. */
 #define DMX_ESTEP_EXACT 0
 #define DMX_ESTEP_FAST 1
+#define DMX_ESTEP_GUARDED 2
 int dmx_set_estep_mode(dmx_ctx *ctx, int mode);
+/* Barcodes the guarded E-steps redid exactly: in the last E-step, and in all E-steps / out of how many barcode rows
+ * since the context was created or dmx_reset_timings (instrumentation; any pointer may be NULL). */
+int dmx_get_guard_stats(dmx_ctx *ctx, int64_t *redone_last, int64_t *redone_total, int64_t *rows_total);
 
 /* E-step work distribution.  For singlet runs of 33..128 genotypes on at least 65 536 barcodes with a genotype table
  * of 8 MB or more, the problem upload also builds a tile-major schedule (bins of 8 barcodes with equal numbers of
@@ -409,6 +426,8 @@ int dmx_test_logf(dmx_ctx *ctx, const float *in, float *out, int64_t n);
 /* the form the E-step kernels inline: positive finite arguments only, range-restricted division */
 int dmx_test_logf_hot(dmx_ctx *ctx, const float *in, float *out, int64_t n);
 int dmx_test_expf(dmx_ctx *ctx, const float *in, float *out, int64_t n);
+/* the hardware log2 (v_log_f32) the tolerance / guarded E-step modes take of a product's mantissa */
+int dmx_test_log2_hw(dmx_ctx *ctx, const float *in, float *out, int64_t n);
 int dmx_test_softmax(dmx_ctx *ctx, const float *in, float *out, int64_t rows, int64_t cols);
 
 #ifdef __cplusplus

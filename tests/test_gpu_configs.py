@@ -195,6 +195,46 @@ def test_config3_fast_mode_within_contract(oracle, problem64):
     print(f'fast mode at 200k x 100k x 64: logits within {ulps:.1f} ulp of the exact mode, posteriors within {dev:.3g}')
 
 
+@pytest.mark.parametrize('G', [64, 32])
+def test_config3_and_config2_guarded_mode_proves_the_contract(oracle, request, G):
+    """The guarded E-step at the headline size (tile-major schedule) and at configs[2]'s (two barcodes per wavefront), on
+    the table of EM iteration 1 (all-distinct rows: the case every iteration after the first runs): against the exact
+    mode on all 200k barcodes - every posterior within 1e-5, every argmax identical, no exceptions -, sampled rows
+    against the oracle, and two guarded EM iterations against two exact ones."""
+    from demuxalot_amd.device import get_context
+    from tests.test_gpu_guarded import check_contract
+    from demuxalot_amd import synth
+    p = request.getfixturevalue('problem64') if G == 64 else synth.generate(200_000, 100_000, 32, seed=1236)
+    ctx = get_context()
+    ctx.set_problem(p.n_barcodes, p.n_variants, G, p.variant_id, p.compressed_cb, p.p_base_wrong, p.v2snp)
+    ctx.set_betas(p.prior_betas())
+    pen = np.zeros(G, dtype=np.float32)
+    try:
+        ctx.set_estep_mode('exact')
+        ctx.em(2, 0.01, pen, with_doublets=False, fetch_logits=False, fetch_probs=False, fetch_addition=False)  # P E M P E
+        ctx.mstep(2., fetch=False)
+        prob = ctx.probs_from_betas(0.01)
+        logits_exact, probs_exact = ctx.estep(pen, with_doublets=False)
+        addition_exact = ctx.mstep(2.)
+        ctx.set_estep_mode('guarded')
+        ctx.reset_timings()
+        logits_g, probs_g = ctx.estep(pen, with_doublets=False)
+        redone, _total, rows = ctx.guard_stats()
+        addition_g = ctx.mstep(2.)
+    finally:
+        ctx.apply_environment()
+    assert rows == p.n_barcodes
+    dev = check_contract(probs_g, probs_exact, f'guarded vs exact, all {p.n_barcodes} barcodes')
+    assert redone <= 0.05 * p.n_barcodes, redone
+    for lo, hi in ((0, 1500), (120_000, 121_500)):
+        v, cb, e = p.subset_barcodes(lo, hi)
+        table_rows, v = np.unique(v, return_inverse=True)
+        want = oracle.barcode_logits(v, cb, e, prob[table_rows], hi - lo, 0., log_impl='npsimd')
+        check_contract(probs_g[lo:hi], oracle.softmax_rows(want, impl='npsimd'), f'guarded rows [{lo},{hi}) vs oracle')
+    assert np.allclose(addition_g, addition_exact, rtol=1e-3, atol=1e-4)
+    print(f'guarded mode at 200k x 100k x {G}: posteriors within {dev:.3g} of the exact mode, {redone} of {p.n_barcodes} barcodes redone exactly')
+
+
 def test_config3_uninformative_posteriors_mstep(oracle, problem64):
     """M-step worst case: posteriors from a flat genotype table (every donor equally likely at every variant,
     the start-from-assignment scenario of tests/test_synthetic.py:200-239 before any label is used): every call

@@ -1,0 +1,199 @@
+"""The guarded E-step (dmx_set_estep_mode(ctx, DMX_ESTEP_GUARDED) / DEMUXALOT_AMD_ESTEP=guarded) on the GPU.
+
+Contract (BASELINE.json north_star): barcode -> donor assignments identical to the reference, posteriors within 1e-5.
+The guarded mode runs the tolerance-mode arithmetic (products of 8 float32 terms, one hardware log2 per product) and
+PROVES the contract per barcode from a bound on its deviation from the reference (csrc/estep_epilogue.h: estep_guard);
+barcodes it cannot prove are redone by the exact kernel inside the same E-step.  So here, unlike in
+tests/test_gpu_fast_mode.py, the contract is asserted without exceptions: every posterior, every argmax."""
+import numpy as np
+import pytest
+
+from tests import fixture_io as fio
+
+pytestmark = pytest.mark.gpu
+
+TOL_POSTERIOR = 1e-5  # BASELINE.json north_star
+
+
+@pytest.fixture()
+def guarded(monkeypatch):
+    """Guarded mode for the shared context and (through the environment) for the private contexts the front-end
+    creates; restored afterwards."""
+    from demuxalot_amd import device
+    monkeypatch.setenv('DEMUXALOT_AMD_ESTEP', 'guarded')
+    ctx = device.get_context()
+    ctx.apply_environment()
+    yield ctx
+    monkeypatch.delenv('DEMUXALOT_AMD_ESTEP')
+    ctx.apply_environment()
+
+
+def check_contract(got_probs, ref_probs, what):
+    dev = np.abs(got_probs.astype(np.float64) - ref_probs)
+    assert (dev <= TOL_POSTERIOR).all(), f'{what}: posterior deviation {dev.max():.3g}'
+    assert np.array_equal(got_probs.argmax(axis=1), ref_probs.argmax(axis=1)), f'{what}: assignments differ'
+    return float(dev.max())
+
+
+def test_hardware_log2_of_a_mantissa_is_within_two_ulp():
+    """v_log_f32 on EVERY float32 in [0.5, 1) - the only arguments the tolerance / guarded modes give it - against the
+    float64 log2: the guard prices it at 2 ulp of a value below 1 (2 x 2^-24); the ISA documents 1 ulp."""
+    from demuxalot_amd.device import get_context
+    ctx = get_context()
+    lo, hi = np.float32(0.5).view(np.uint32), np.float32(1.0).view(np.uint32)
+    m = np.arange(int(lo), int(hi), dtype=np.uint32).view(np.float32)
+    got = ctx.test_log2_hw(m).astype(np.float64)
+    err = np.abs(got - np.log2(m.astype(np.float64)))
+    assert err.max() <= 2 * 2.0 ** -24, err.max()
+    # and exact on the exponent's side: frexp leaves a mantissa in [0.5, 1), never 1.0
+    assert got.max() < 0.0 and got.min() == -1.0
+    print(f'v_log_f32 on [0.5, 1): max abs error {err.max():.3e} = {err.max() / 2.0 ** -24:.2f} ulp(<1)')
+
+
+@pytest.mark.parametrize('name', fio.SMALL + fio.SYNTH)
+def test_guarded_mode_meets_the_contract_on_reference_outputs(guarded, name):
+    """predict_posteriors and every EM iteration of the golden fixtures (the reference's own outputs).  The first
+    E-step of every run sees the importers' table, i.e. the dictionary form (exact); iterations after the first M-step
+    run the guarded kernels on tables that follow the reference's within the posteriors' tolerance."""
+    from demuxalot_amd import Demultiplexer
+    fx = fio.load(name)
+    calls, genotypes, handler = fio.product_inputs(fx)
+    worst = 0.0
+    for i in range(int(fx['n_predict'])):
+        dp, clip = float(fx[f'predict{i}_dp']), float(fx[f'predict{i}_clip'])
+        _, probs_df = Demultiplexer.predict_posteriors(calls, genotypes, handler, p_genotype_clip=clip, doublet_prior=dp)
+        worst = max(worst, check_contract(probs_df.values, fx[f'predict{i}_probs'], f'{name} predict {i}'))
+    for i in range(int(fx['n_em'])):
+        kwargs = dict(n_iterations=int(fx[f'em{i}_n_iterations']), p_genotype_clip=float(fx[f'em{i}_clip']),
+                      doublet_prior=float(fx[f'em{i}_dp']))
+        prior = fx.get(f'em{i}_prior_logits')
+        stages = list(Demultiplexer.staged_genotype_learning(
+            calls, genotypes, handler, barcode_prior_logits=None if prior is None else prior.copy(), **kwargs))
+        for it, (probs_df, dbg) in enumerate(stages):
+            worst = max(worst, check_contract(probs_df.values, fx[f'em{i}_it{it}_probs'], f'{name} run {i} it {it}'))
+            assert np.allclose(dbg['genotype_addition'], fx[f'em{i}_it{it}_addition'], rtol=1e-3, atol=1e-4)
+        learnt, last = Demultiplexer.learn_genotypes(
+            calls, genotypes, handler, barcode_prior_logits=None if prior is None else prior.copy(), **kwargs)
+        check_contract(last.values, fx[f'em{i}_it{kwargs["n_iterations"] - 1}_probs'], f'{name} learn {i}')
+        assert np.allclose(learnt.variant_betas, fx[f'em{i}_learnt_betas'], rtol=1e-3, atol=1e-4)
+    print(f'{name}: worst posterior deviation {worst:.3g}')
+
+
+def _estep_in_modes(table, problem, dp, modes=('exact', 'guarded'), prior=None):
+    """One E-step on `table` in each mode on a private context: {mode: (logits, probs, guard_stats, form)}."""
+    from demuxalot_amd import Demultiplexer
+    from demuxalot_amd.device import DeviceContext
+    G = problem.n_genotypes
+    pen = Demultiplexer._doublet_penalties(G, dp)
+    out = {}
+    ctx = DeviceContext(0)
+    try:
+        ctx.set_estep_dictionary('never')  # the kernels under test, not the dictionary form
+        ctx.set_problem(problem.n_barcodes, problem.n_variants, G, problem.variant_id, problem.compressed_cb, problem.p_base_wrong, problem.v2snp)
+        ctx.set_probs(table)
+        for mode in modes:
+            ctx.set_estep_mode(mode)
+            ctx.reset_timings()
+            logits, probs = ctx.estep(pen, with_doublets=dp > 0, prior_logits=prior)
+            out[mode] = (logits, probs, ctx.guard_stats(), ctx.estep_form()[0])
+    finally:
+        ctx.close()
+    return out
+
+
+@pytest.mark.parametrize('G,dp', [(2, 0.), (3, 0.3), (8, 0.35), (16, 0.), (20, 0.25), (32, 0.), (33, 0.), (64, 0.), (64, 0.1),
+                                  (100, 0.), (128, 0.), (200, 0.), (22, 0.3), (24, 0.3), (32, 0.25), (45, 0.1), (130, 0.05), (300, 0.), (600, 0.)])
+def test_guarded_mode_every_kernel_shape_against_the_exact_mode_and_the_oracle(oracle, G, dp):
+    """All lane-group widths and slot counts (and the shapes that fall back to the exact mode): posteriors within the
+    contract of the exact mode's = the oracle's, argmax identical, on EVERY barcode; the barcodes the guard queued carry
+    the exact mode's bits."""
+    from demuxalot_amd import synth
+    B = 400
+    p = synth.generate(n_barcodes=B, n_snps=300, n_genotypes=G, calls_per_barcode=60, doublets=dp > 0, seed=G)
+    prob = oracle.probs_from_betas(p.v2snp, p.prior_betas(), 0.01)
+    want = oracle.barcode_logits(p.variant_id, p.compressed_cb, p.p_base_wrong, prob, B, dp, log_impl='npsimd')
+    out = _estep_in_modes(prob, p, dp)
+    exact_logits, exact_probs = out['exact'][:2]
+    fio.assert_bitwise(exact_logits, want, 'exact mode vs oracle')
+    logits, probs, (redone, total, rows), _ = out['guarded']
+    check_contract(probs, exact_probs, f'G={G} dp={dp}')
+    K = exact_logits.shape[1]
+    guarded_shape = K <= 1024 and not (dp > 0 and K > 256)
+    assert rows == (B if guarded_shape else 0) and redone == total
+    same = (logits.view(np.uint32) == exact_logits.view(np.uint32)).all(axis=1) & (probs.view(np.uint32) == exact_probs.view(np.uint32)).all(axis=1)
+    assert same.sum() >= redone  # every queued barcode was rewritten by the exact kernel
+    if not guarded_shape:
+        assert same.all()
+    print(f'G={G} dp={dp}: {redone} of {B} barcodes redone exactly, {int(same.sum())} rows bit-identical')
+
+
+def test_ambiguous_barcodes_are_redone_exactly(oracle):
+    """Genotypes in identical pairs: the best two logits of every barcode tie, nothing can be proven about the argmax,
+    so every barcode must come back with the exact mode's bits; with half of the genotypes duplicated, many do."""
+    from demuxalot_amd import synth
+    for G, dup in ((8, 8), (64, 64), (64, 16), (128, 128)):
+        B = 600
+        p = synth.generate(n_barcodes=B, n_snps=400, n_genotypes=G, calls_per_barcode=80, seed=100 + G + dup)
+        prob = oracle.probs_from_betas(p.v2snp, p.prior_betas(), 0.01).copy()
+        prob[:, 1:dup:2] = prob[:, 0:dup - 1:2]  # genotype 2j+1 = genotype 2j
+        out = _estep_in_modes(prob, p, 0.)
+        logits, probs, (redone, _t, rows), _ = out['guarded']
+        if dup == G:
+            assert redone == B == rows
+            fio.assert_bitwise(logits, out['exact'][0], 'all-ambiguous logits')
+            fio.assert_bitwise(probs, out['exact'][1], 'all-ambiguous posteriors')
+        else:
+            check_contract(probs, out['exact'][1], f'G={G} dup={dup}')
+            best = out['exact'][1].argmax(axis=1)
+            tied = best < dup  # the barcode's best genotype has a twin
+            assert redone >= tied.sum()
+            fio.assert_bitwise(logits[tied], out['exact'][0][tied], 'tied rows')
+
+
+def test_guarded_mode_with_prior_logits_and_degenerate_calls(oracle):
+    """barcode_prior_logits (float32 and float64), p_base_wrong of exactly 0 and 1, an empty barcode."""
+    from demuxalot_amd import synth
+    B, G = 300, 20
+    p = synth.generate(n_barcodes=B, n_snps=200, n_genotypes=G, calls_per_barcode=40, seed=9)
+    p.p_base_wrong[:50] = 0.0
+    p.p_base_wrong[50:100] = 1.0
+    keep = p.compressed_cb != 7  # barcode 7 has no calls
+    p = synth.SyntheticProblem(B, p.n_snps, G, p.v2snp, p.raw_betas, p.variant_id[keep], p.compressed_cb[keep], p.p_base_wrong[keep], p.truth)
+    prob = oracle.probs_from_betas(p.v2snp, p.prior_betas(), 0.01)
+    rng = np.random.default_rng(4)
+    for dtype in (np.float32, np.float64):
+        prior = (rng.normal(size=(B, G)) * 3).astype(dtype)
+        prior[::5, 3] += 100
+        out = _estep_in_modes(prob, p, 0., prior=prior)
+        check_contract(out['guarded'][1], out['exact'][1], f'prior {dtype.__name__}')
+    out = _estep_in_modes(prob, p, 0.)
+    check_contract(out['guarded'][1], out['exact'][1], 'degenerate calls')
+    assert np.array_equal(out['guarded'][1][7], np.full(G, 1 / G, dtype=np.float32))  # the empty barcode: ties -> exact redo
+
+
+def test_guarded_em_follows_the_exact_em(oracle):
+    """20k x 10k x 64, four EM iterations in either mode.  Per E-step the contract is proven against the exact mode ON
+    THE SAME TABLE; across iterations the tables differ by what a 1e-5 change of the posteriors does to the M-step,
+    which stays far below the contract here: asserted with the contract's own tolerance."""
+    from demuxalot_amd import synth
+    from demuxalot_amd.device import DeviceContext
+    p = synth.generate(20000, 10000, 64, calls_per_barcode=200, seed=77)
+    betas = p.prior_betas()
+    pen = np.zeros(64, dtype=np.float32)
+    res = {}
+    for mode in ('exact', 'guarded'):
+        ctx = DeviceContext(0)
+        try:
+            ctx.set_estep_mode(mode)
+            ctx.set_estep_dictionary('never')
+            ctx.set_problem(p.n_barcodes, p.n_variants, 64, p.variant_id, p.compressed_cb, p.p_base_wrong, p.v2snp)
+            ctx.set_betas(betas)
+            ctx.reset_timings()
+            res[mode] = ctx.em(4, 0.01, pen, with_doublets=False) + (ctx.guard_stats(),)
+        finally:
+            ctx.close()
+    dev = check_contract(res['guarded'][1], res['exact'][1], 'guarded EM vs exact EM')
+    assert np.allclose(res['guarded'][2], res['exact'][2], rtol=1e-3, atol=1e-4)
+    _last, total, rows = res['guarded'][3]
+    assert rows == 4 * p.n_barcodes
+    print(f'guarded EM: posteriors within {dev:.3g} of the exact run after 4 iterations, {total} of {rows} barcode rows redone exactly')
