@@ -1,22 +1,28 @@
 #!/usr/bin/env python
 """bench.py -- EM-iteration throughput of the Demultiplexer hot path on MI355X.
 
-    python bench.py --gpus 1 --steps 10 --warmup 2
-    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
-           --master-port P bench.py --gpus N --steps K --warmup W
+    python bench.py                                   # 1 GPU
+    python bench.py --gpus N --steps K --warmup W     # N GPUs of one node: starts its own N rank processes
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+           bench.py --gpus N --steps K --warmup W     # the same under a launcher (RANK / WORLD_SIZE from the environment)
 
-One "step" = one EM iteration of learn_genotypes on device-resident inputs: P-step (beta ->
-probability), E-step + softmax, M-step (+ RCCL all-reduce of the beta addition when N > 1).
-Workload (BASELINE.json metric): 200k barcodes x 100k SNPs x 64 genotypes per GPU, synthetic
-(demuxalot_amd/synth.py).  With N GPUs (--scaling weak, the default) every rank owns its
-own 200k-barcode shard of an N x 200k-barcode experiment; the beta tables are replicated and the per-rank
-beta additions are exchanged every iteration (reduce-scatter over variant slices, P-step on the owned slice,
-all-gather of genotype_prob: include/demux_hip.h "Multi-GPU").  --scaling strong is BASELINE.json configs[3]
-as written: ONE 200k-barcode experiment cut into N barcode ranges with equal numbers of calls.
+One "step" = one EM iteration of learn_genotypes on device-resident inputs: P-step (beta -> probability), E-step +
+softmax, M-step (+ the exchange of the beta additions when N > 1).  Workload (BASELINE.json metric): 200k barcodes x
+100k SNPs x 64 genotypes, synthetic (demuxalot_amd/synth.py).
 
-Prints ONE JSON line on rank 0 (contract in the task statement) with `roofline` (E-step kernel,
-HIP-event timed on the stream it runs on) and `cpu_baseline` (the numpy oracle, one core, on a
-bounded barcode sub-sample; rank 0, N = 1 only).
+N > 1, `scaling`: the headline `value` is BASELINE.json configs[3] AS WRITTEN - the ONE 200k-barcode experiment cut into
+N barcode ranges with equal numbers of calls ("strong"); the `weak` object of the same line is the workload per GPU
+(every rank a 200k-barcode shard of an N x 200k-barcode experiment).  The experiment is generated once (rank 0, handed to
+the other ranks through /dev/shm).  The per-iteration exchange - reduce-scatter of the additions over variant slices,
+P-step on the owned slice, all-gather of genotype_prob - runs inside libdemux_hip.so (include/demux_hip.h "Multi-GPU").
+
+E-step arithmetic: the library's default, the GUARDED mode (contract of the path proven per barcode, the rest redone
+bit-exactly: include/demux_hip.h DMX_ESTEP_GUARDED); `exact_mode` = the same timed region with every logit / posterior
+/ addition bit-identical to the reference.
+
+Prints ONE JSON line on rank 0 (contract in the task statement) with `roofline` (dominant kernel of the timed
+iterations, HIP-event timed on the stream it runs on, live rocprofv3 counters) and `cpu_baseline` (the numpy oracle,
+one core, on a bounded barcode sub-sample; N = 1 only).
 """
 import argparse
 import json
@@ -31,7 +37,7 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 WORKLOADS = {
-    # name: (barcodes per GPU, SNPs, genotypes, doublet_prior, generator seed)
+    # name: (barcodes, SNPs, genotypes, doublet_prior, generator seed)
     'em_200k_100k_64': (200_000, 100_000, 64, 0.0, 1237),   # BASELINE.json metric / configs[3] shape
     'em_200k_100k_32': (200_000, 100_000, 32, 0.0, 1236),   # configs[2]
     'predict_20k_20k_8': (20_000, 20_000, 8, 0.35, 1235),   # configs[1]
@@ -39,12 +45,17 @@ WORKLOADS = {
     'predict_200k_20k_12': (200_000, 20_000, 12, 0.35, 1246),  # K = 78: 16 lanes x 5 slots
     'predict_60k_20k_8': (60_000, 20_000, 8, 0.35, 1247),    # in between: the longest rows on 64 lanes, the rest packed
     'em_20k_10k_64': (20_000, 10_000, 64, 0.0, 77),         # quick check
+    'em_25k_100k_64': (25_000, 100_000, 64, 0.0, 1237),     # the size of one rank's share of configs[3] on 8 GPUs
     'em_200k_4k_64': (200_000, 4_000, 64, 0.0, 78),         # diagnostic: 2 MB genotype table (every row gather hits L2)
     'predict_20k_20k_32_doublets': (20_000, 20_000, 32, 0.25, 1240),   # K = 528: workgroup-per-barcode kernel
     'predict_20k_20k_64_doublets': (20_000, 20_000, 64, 0.25, 1243),   # K = 2080: doublets of 64 genotypes
     'predict_5k_20k_128_doublets': (5_000, 20_000, 128, 0.25, 1241),   # K = 8256 (configs[4] option count)
     'em_130k_650k_128_doublets': (130_000, 650_000, 128, 0.25, 1242),  # one rank's share of configs[4] (1M x 650k x 128 on 8 GPUs)
 }
+
+LOG_ISSUE_PEAK = 19.7e12   # v_log_f32 issue peak of the chip, 256 CUs x 4 SIMDs x 64 lanes / 8 cycles x 2.4 GHz
+L2_GATHER_ALL_HIT_GBPS = 15800.0  # 256-byte rows out of L2 through buffer_load_dword: the same loop on a 2 MB table
+N_SIMD, N_XCD = 1024, 8
 
 
 def algorithmic_bytes(B, V, G, K, N):
@@ -55,6 +66,110 @@ def algorithmic_bytes(B, V, G, K, N):
     return dict(estep=e, mstep=m, pstep=p, iteration=e + m + p)
 
 
+# ---------------------------------------------------------------------------------------------------------
+# self-launch: `python bench.py --gpus N` with no launcher
+# ---------------------------------------------------------------------------------------------------------
+def self_launch(args):
+    """The parent of an N-rank run: it never touches the GPU (no HIP call, no library load) - it starts N fresh rank
+    processes of this script with RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* set, relays rank 0's one JSON line, and
+    exits non-zero when any rank does."""
+    import socket
+    import subprocess
+    with socket.socket() as s:  # a free port NUMBER: the control plane's rendezvous is a file keyed by it
+        s.bind(('127.0.0.1', 0))
+        port = s.getsockname()[1]
+    base = dict(os.environ, WORLD_SIZE=str(args.gpus), MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port),
+                TORCHELASTIC_RUN_ID=f'bench{os.getpid()}', HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get('HSA_ENABLE_IPC_MODE_LEGACY', '0'))
+    procs = []
+    for rank in range(args.gpus):
+        env = dict(base, RANK=str(rank), LOCAL_RANK=str(rank))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env, cwd=ROOT,
+                                      stdout=subprocess.PIPE if rank == 0 else subprocess.DEVNULL))
+    line, _ = procs[0].communicate()
+    codes = [procs[0].returncode]
+    deadline = time.monotonic() + 300
+    for pr in procs[1:]:
+        try:
+            codes.append(pr.wait(timeout=max(1.0, deadline - time.monotonic())))
+        except subprocess.TimeoutExpired:
+            pr.kill()
+            codes.append(-9)
+    sys.stdout.write(line.decode(errors='replace'))
+    sys.stdout.flush()
+    if any(codes):
+        print(f'[bench] rank exit codes {codes}', file=sys.stderr, flush=True)
+        return 1
+    return 0
+
+
+# ---------------------------------------------------------------------------------------------------------
+# the experiment: generated once per job
+# ---------------------------------------------------------------------------------------------------------
+_FIELDS = ('v2snp', 'raw_betas', 'variant_id', 'compressed_cb', 'p_base_wrong', 'truth')
+
+
+def save_problem(directory, problem):
+    os.makedirs(directory, exist_ok=True)
+    for name in _FIELDS:
+        np.save(os.path.join(directory, name + '.npy'), getattr(problem, name))
+    with open(os.path.join(directory, 'shape.json.tmp'), 'w') as f:
+        json.dump([problem.n_barcodes, problem.n_snps, problem.n_genotypes], f)
+    os.replace(os.path.join(directory, 'shape.json.tmp'), os.path.join(directory, 'shape.json'))  # last: marks the set complete
+
+
+def load_problem(directory):
+    from demuxalot_amd import synth
+    B, S, G = json.load(open(os.path.join(directory, 'shape.json')))
+    arrays = {name: np.load(os.path.join(directory, name + '.npy'), mmap_mode='r') for name in _FIELDS}
+    return synth.SyntheticProblem(B, S, G, np.asarray(arrays['v2snp']), np.asarray(arrays['raw_betas']), arrays['variant_id'],
+                                  arrays['compressed_cb'], arrays['p_base_wrong'], np.asarray(arrays['truth']))
+
+
+def shared_directory():
+    """Where rank 0 leaves the generated experiment for the other ranks: memory-backed, named after the job."""
+    root = '/dev/shm' if os.path.isdir('/dev/shm') and os.access('/dev/shm', os.W_OK) else '/tmp'
+    job = f'{os.environ.get("MASTER_PORT", "0")}_{os.environ.get("TORCHELASTIC_RUN_ID", "none")}'
+    return os.path.join(root, 'demuxalot_bench_' + ''.join(ch if ch.isalnum() else '_' for ch in job))
+
+
+def get_problem(args, rank, world, plane):
+    """(problem, seconds, where it came from).  DEMUXALOT_BENCH_PROBLEM=<dir>: a set saved by an earlier run (the profiler
+    child runs of live_counters); otherwise rank 0 generates, and with several ranks shares it through /dev/shm."""
+    from demuxalot_amd import synth
+    B, S, G, dp, seed = WORKLOADS[args.workload]
+    t0 = time.perf_counter()
+    cached = os.environ.get('DEMUXALOT_BENCH_PROBLEM', '')
+    if cached and os.path.exists(os.path.join(cached, 'shape.json')):
+        problem = load_problem(cached)
+        assert (problem.n_barcodes, problem.n_snps, problem.n_genotypes) == (B, S, G), 'cached problem of another workload'
+        return problem, time.perf_counter() - t0, 'cache'
+    if world == 1:
+        return synth.generate(B, S, G, doublets=dp > 0, seed=seed), time.perf_counter() - t0, 'generated'
+    directory = shared_directory()
+    problem = None
+    if rank == 0:
+        problem = synth.generate(B, S, G, doublets=dp > 0, seed=seed)
+        save_problem(directory, problem)
+    plane.barrier()
+    if rank != 0:
+        problem = load_problem(directory)
+    return problem, time.perf_counter() - t0, 'generated on rank 0, shared through ' + directory
+
+
+def shard_of(problem, rank, world):
+    """This rank's barcode range of the experiment (equal numbers of calls), barcode indices re-based."""
+    from demuxalot_amd import synth
+    from demuxalot_amd.distributed import partition_barcodes
+    bounds = partition_barcodes(np.bincount(problem.compressed_cb, minlength=problem.n_barcodes), world)
+    lo, hi = int(bounds[rank]), int(bounds[rank + 1])
+    v, cb, e = problem.subset_barcodes(lo, hi)
+    return synth.SyntheticProblem(hi - lo, problem.n_snps, problem.n_genotypes, problem.v2snp, problem.raw_betas, v, cb, e,
+                                  problem.truth[lo:hi])
+
+
+# ---------------------------------------------------------------------------------------------------------
+# CPU baseline
+# ---------------------------------------------------------------------------------------------------------
 def _oracle_iteration(demux_oracle, problem, betas, doublet_prior, n_sample):
     G = problem.n_genotypes
     v, cb, e = problem.subset_barcodes(0, n_sample)
@@ -88,61 +203,17 @@ def cpu_baseline(problem, betas, doublet_prior, target_seconds=15.0):
                 host_cores=os.cpu_count()), logits, post, n_sample
 
 
-# VALU issue model of the exact-mode E-step term (direct kernels, K <= 1024), from the instruction count of the main
-# loop of k_estep_direct<64,1,false,8,false> per two terms (ISA: 124 VALU per 8 calls = 15.5 per term: 17 packed
-# float32, 6 plain integer, 2 v_cvt_f32_i32, 2 v_rcp_f32, 2 v_cvt_f64_f32, 2 v_add_f64) and the issue costs measured by
-# scripts/valu_issue_bench.hip on this chip with >= 2 waves per SIMD (profiles/r2_valu_issue_bench.txt): plain 2.4
-# cycles, packed float32 / float64 / conversions 4.4, transcendental 8.3.
-VALU_CYCLES_PER_TERM = (17 * 4.4 + 6 * 2.4 + 2 * 4.4 + 2 * 8.3 + 2 * 4.4 + 2 * 4.4) / 2
-N_SIMD, PEAK_CLOCK_HZ = 1024, 2.4e9
-
-
-def roofline(workload, ab, e_ms, m_ms, timers, N, G, K, form='direct'):
-    """The contract's HBM figures for the dominant kernel (the E-step) on ALGORITHMIC bytes, plus what actually binds
-    it: VALU issue of the N*K numpy-exact float32 log terms."""
-    achieved = ab['estep'] / (e_ms * 1e-3) / 1e9
-    per_launch = lambda name: timers[name]['ms'] / max(1, timers[name]['launches'])
-    terms_per_s = N * K / (e_ms * 1e-3)
-    peak_terms = N_SIMD * PEAK_CLOCK_HZ * 64 / VALU_CYCLES_PER_TERM
-    kernel = 'k_estep_block' if K > 1024 or (K > G and K > 512) else 'k_estep_direct'  # kernels.hip: launch_estep
-    if form == 'packed':
-        kernel = 'k_estep_packed'  # estep_packed.hip: narrow doublet tables, several option slots per lane
-    return {
-        'bound': 'valu-issue',
-        'kernel': kernel, 'achieved': achieved, 'peak': 8000.0, 'unit': 'GB/s', 'frac': achieved / 8000.0,
-        'traffic': measured_traffic(workload, kernel),
-        'algorithmic_bytes_per_launch': ab['estep'],
-        'iteration_bytes': ab['iteration'],
-        'iteration_frac': ab['iteration'] / (1e-3 * (e_ms + m_ms + per_launch('pstep') + per_launch('mcombine'))) / 1e9 / 8000.0,
-        'delivered_gather_GBps': (N * 4 * G) / (e_ms * 1e-3) / 1e9,
-        'valu': {'log_terms_per_s': terms_per_s, 'peak_terms_per_s': peak_terms, 'frac': terms_per_s / peak_terms,
-                 'cycles_per_term_model': VALU_CYCLES_PER_TERM,
-                 'note': 'exact-mode term = numpy float32 log repeated operation for operation + float64 accumulate; issue costs '
-                         'from profiles/r2_valu_issue_bench.txt; peak at the nominal 2.4 GHz (the kernel sustains ~2.0-2.1 GHz); '
-                         'K > 1024 (k_estep_block) adds two LDS reads per term pair and option'},
-        'note': 'frac is the HBM fraction the contract asks for (algorithmic bytes / time / 8 TB/s); the kernel is bound by '
-                'VALU issue (valu.frac), not by HBM: see DESIGN.md 4',
-    }
-
-
-def measured_traffic(workload, kernel):
-    """HBM-side bytes per launch from the rocprofv3 PMC passes committed under profiles/ (FETCH_SIZE +
-    WRITE_SIZE, see profiles/README.md); None when no profile of this workload/kernel is recorded."""
-    path = os.path.join(ROOT, 'profiles', 'pmc_traffic.json')
-    try:
-        table = json.load(open(path))
-        return table[workload][kernel]['bytes_per_launch']
-    except (OSError, KeyError, ValueError):
-        return None
-
-
-def live_counters(args, kernel):
+# ---------------------------------------------------------------------------------------------------------
+# roofline of the dominant kernel
+# ---------------------------------------------------------------------------------------------------------
+def live_counters(args, problem_dir):
     """Measured now, by child runs of this script under `rocprofv3 --kernel-trace --pmc` (one counter per pass, as
-    MI355X_MICROARCH.md prescribes): HBM-side bytes per launch of `kernel` (FETCH_SIZE + WRITE_SIZE, both reported in KiB;
-    the row gathers are 4-byte-per-lane reads, not the 16-byte streams with the documented 2x under-count) and the clock
-    the kernel sustains (GRBM_GUI_ACTIVE summed over the 8 XCDs / 8 / the kernel's duration in the same pass).
-    {} when the profiler is not available; a missing key when a pass fails - the caller keeps the figures committed
-    under profiles/ for those."""
+    MI355X_MICROARCH.md prescribes), for the E-step kernel the timed iterations spend most time in: its name and average
+    duration under the tracer, HBM-side bytes per launch (FETCH_SIZE + WRITE_SIZE, both reported in KiB; the row gathers
+    are 4-byte-per-lane reads, not the 16-byte streams with the documented 2x under-count), the clock it sustains
+    (GRBM_GUI_ACTIVE summed over the 8 XCDs / 8 / its duration in the same pass) and how busy the VALUs are
+    (SQ_ACTIVE_INST_VALU, in quad-cycles, x 4 / 1024 SIMDs / the cycles of the launch).  The children load the experiment
+    this run saved instead of generating it again.  {'skipped': why} when the profiler is not available."""
     import csv
     import glob
     import shutil
@@ -155,43 +226,83 @@ def live_counters(args, kernel):
     if nested or 'rocprof' in os.environ.get('LD_PRELOAD', ''):
         return {'skipped': f'this run is itself under a profiler ({nested or "LD_PRELOAD"})'}
     out_dir = tempfile.mkdtemp(prefix='bench_pmc_', dir='/tmp')
-    child = [sys.executable, os.path.join(ROOT, 'bench.py'), '--workload', args.workload, '--steps', '2', '--warmup', '1',
-             '--no-cpu-baseline', '--no-fast-mode', '--no-live-traffic', '--no-e2e'] + (['--flat-genotypes'] if args.flat_genotypes else [])
-    env = dict(os.environ, TMPDIR='/tmp')
+    child = [sys.executable, os.path.join(ROOT, 'bench.py'), '--workload', args.workload, '--steps', '2', '--warmup', '1', '--timed-only']
+    child += ['--flat-genotypes'] if args.flat_genotypes else []
+    env = dict(os.environ, TMPDIR='/tmp', DEMUXALOT_BENCH_PROBLEM=problem_dir)
     found = {}
     try:
-        for counter in ('FETCH_SIZE', 'WRITE_SIZE', 'GRBM_GUI_ACTIVE'):
+        for counter in ('FETCH_SIZE', 'WRITE_SIZE', 'GRBM_GUI_ACTIVE', 'SQ_ACTIVE_INST_VALU'):
             where = os.path.join(out_dir, counter)
             try:
                 subprocess.run(['rocprofv3', '--kernel-trace', '--pmc', counter, '--output-format', 'csv', '-d', where, '--'] + child,
-                               env=env, cwd=ROOT, stdout=subprocess.DEVNULL, stderr=subprocess.PIPE, timeout=180, check=True)
+                               env=env, cwd=ROOT, stdout=subprocess.DEVNULL, stderr=subprocess.PIPE, timeout=240, check=True)
             except (OSError, subprocess.SubprocessError) as exc:
                 found[f'{counter}_failed'] = (getattr(exc, 'stderr', b'') or b'').decode(errors='replace')[-300:] or str(exc)
                 continue
+            spans = {}  # kernel name -> durations; the dominant E-step kernel = largest total among the k_estep_* ones
+            for path in glob.glob(os.path.join(where, '**', '*kernel_trace.csv'), recursive=True):
+                for row in csv.DictReader(open(path)):
+                    if 'k_estep' in row['Kernel_Name']:
+                        spans.setdefault(row['Kernel_Name'], []).append(float(row['End_Timestamp']) - float(row['Start_Timestamp']))
+            if not spans:
+                continue
+            kernel = max(spans, key=lambda k: sum(spans[k]))
+            found.setdefault('kernel', kernel.split('(')[0].replace('void dmx::', ''))
             values, dispatches = [], set()
             for path in glob.glob(os.path.join(where, '**', '*counter_collection.csv'), recursive=True):
                 for row in csv.DictReader(open(path)):
-                    if kernel in row['Kernel_Name'] and row['Counter_Name'] == counter:
+                    if row['Kernel_Name'] == kernel and row['Counter_Name'] == counter:
                         values.append(float(row['Counter_Value']))
                         dispatches.add(row['Dispatch_Id'])
-            if not values:  # e.g. another E-step kernel ran: no figure rather than a wrong one
+            if not values:
                 continue
             found[counter] = sum(values) / len(dispatches)
+            ns = sum(spans[kernel]) / len(spans[kernel])
             if counter == 'GRBM_GUI_ACTIVE':
-                spans = []
-                for path in glob.glob(os.path.join(where, '**', '*kernel_trace.csv'), recursive=True):
-                    for row in csv.DictReader(open(path)):
-                        if kernel in row['Kernel_Name']:
-                            spans.append(float(row['End_Timestamp']) - float(row['Start_Timestamp']))
-                if spans:
-                    found['clock_ghz'] = found[counter] / 8.0 / (sum(spans) / len(spans))  # cycles per XCD / ns
+                found['kernel_ns_under_tracer'] = ns
+                found['cycles_per_launch'] = found[counter] / N_XCD
+                found['clock_ghz'] = found['cycles_per_launch'] / ns
+            if counter == 'SQ_ACTIVE_INST_VALU':
+                found['valu_ns'] = ns
         if 'FETCH_SIZE' in found and 'WRITE_SIZE' in found:
             found['traffic'] = 1024.0 * (found['FETCH_SIZE'] + found['WRITE_SIZE'])
+        if 'SQ_ACTIVE_INST_VALU' in found and 'clock_ghz' in found:
+            found['valu_busy'] = found['SQ_ACTIVE_INST_VALU'] * 4.0 / N_SIMD / (found['clock_ghz'] * found['valu_ns'])
         return found
-    except (OSError, KeyError, ValueError):
+    except (OSError, KeyError, ValueError) as exc:
+        found['error'] = repr(exc)
         return found
     finally:
         shutil.rmtree(out_dir, ignore_errors=True)
+
+
+def roofline(ab, e_ms, N, G, K, live):
+    """The contract's HBM figures for the E-step of the timed iterations on ALGORITHMIC bytes, the ops roofline of
+    SURVEY.md 8d (log terms against the v_log_f32 issue peak), and what the kernel actually runs on: the genotype-row
+    gather out of L2 (guarded / tolerance mode) or VALU issue (exact mode) - `valu.busy` from the live counters."""
+    achieved = ab['estep'] / (e_ms * 1e-3) / 1e9
+    terms_per_s = N * K / (e_ms * 1e-3)
+    delivered = (N * 4 * G) / (e_ms * 1e-3) / 1e9
+    out = {
+        'bound': 'hbm', 'kernel': live.get('kernel'), 'achieved': achieved, 'peak': 8000.0, 'unit': 'GB/s', 'frac': achieved / 8000.0,
+        'traffic': live.get('traffic'),
+        'traffic_source': 'rocprofv3 --pmc FETCH_SIZE + WRITE_SIZE per launch, child runs of this command (live)' if 'traffic' in live else None,
+        'algorithmic_bytes_per_launch': ab['estep'], 'estep_ms': e_ms,
+        'ops': {'terms_per_s': terms_per_s, 'peak': LOG_ISSUE_PEAK, 'frac': terms_per_s / LOG_ISSUE_PEAK,
+                'note': 'SURVEY.md 8d: N x K log terms per E-step against the v_log_f32 issue peak (19.7 T/s); the guarded / '
+                        'tolerance mode takes one hardware log2 per 8 terms, the exact mode repeats numpy\'s float32 log (16 VALU '
+                        'instructions per term)'},
+        'l2_gather': {'delivered_GBps': delivered, 'all_hit_rate_GBps': L2_GATHER_ALL_HIT_GBPS, 'frac': delivered / L2_GATHER_ALL_HIT_GBPS,
+                      'note': 'N x 4G bytes of genotype rows per E-step, gathered out of L2 / Infinity Cache (the table fits no L2); '
+                              'the all-hit rate is the same loop on an L2-resident table (DESIGN.md 4.1)'},
+        'valu': {k: live[k] for k in ('valu_busy', 'clock_ghz', 'cycles_per_launch', 'SQ_ACTIVE_INST_VALU', 'kernel_ns_under_tracer') if k in live},
+        'note': 'frac = algorithmic bytes / E-step time / 8 TB/s as the contract defines it; the E-step re-reads a 256-byte table '
+                'row per call, so it is bounded by the L2 gather rate (l2_gather.frac), not by HBM: DESIGN.md 4',
+    }
+    problems = {k: v for k, v in live.items() if k in ('skipped', 'error') or k.endswith('_failed')}
+    if problems:
+        out['live_counters'] = problems
+    return out
 
 
 def e2e_timing(problem, doublet_prior, n_iterations=5):
@@ -201,7 +312,6 @@ def e2e_timing(problem, doublet_prior, n_iterations=5):
     import pandas as pd
     from demuxalot_amd import Demultiplexer, synth
     from demuxalot_amd.demux import _option_names, _pack_on_device
-    from demuxalot_amd.device import DeviceContext
     t0 = time.perf_counter()
     calls, genotypes, handler = synth.as_objects(problem)
     t_objects = time.perf_counter() - t0
@@ -258,6 +368,32 @@ def _lib_device_count():
     return _lib.device_count()
 
 
+def timed_region(ctx, plane, steps, warmup):
+    """W untimed iterations, then exactly K timed ones bracketed by barrier + device synchronisation on both sides;
+    the MAX over ranks of the wall time."""
+    def barrier():
+        if plane is not None:
+            plane.barrier()
+    ctx.run_iterations(warmup, 0.01)
+    ctx.synchronize()
+    ctx.reset_timings()
+    barrier()
+    ctx.synchronize()
+    t0 = time.perf_counter()
+    ctx.run_iterations(steps, 0.01)
+    ctx.synchronize()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if plane is not None:
+        elapsed = plane.max_float64(elapsed)
+    timers = ctx.timings()
+    _redone, redone_total, rows = ctx.guard_stats()
+    return {'elapsed': elapsed, 'ms_per_step': 1e3 * elapsed / steps, 'em_iterations_per_s': steps / elapsed,
+            'kernel_ms': {k: (v['ms'] / max(1, v['launches'])) for k, v in timers.items()},
+            'exchange_ms_per_step': timers['allreduce']['ms'] / max(1, steps),
+            'guard': {'barcodes_redone_exactly': redone_total, 'barcode_rows': rows, 'fraction': redone_total / max(1, rows)}}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -269,12 +405,15 @@ def main():
                          'number of ranks up to float32 rounding ties) or float32 (half the bytes; posteriors stay within the 1e-5 '
                          'contract: tests/test_gpu_ranks_on_one_gpu.py).  auto = f64 up to 2 ranks, f32 from 4 on, where the exchange '
                          'is what strong scaling runs into (DESIGN.md 5)')
-    ap.add_argument('--scaling', default='weak', choices=['weak', 'strong'],
-                    help='weak: the workload per GPU; strong: the workload in total, barcodes sharded over the GPUs')
+    ap.add_argument('--scaling', default='both', choices=['both', 'weak', 'strong'],
+                    help='N > 1.  strong: the workload in total, barcodes sharded over the GPUs (BASELINE.json configs[3] as written); '
+                         'weak: the workload per GPU; both (default): strong is the headline value, weak a sub-object of the line')
+    ap.add_argument('--timed-only', action='store_true', help='the timed region of the default mode only (profiler child runs)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
-    ap.add_argument('--no-fast-mode', action='store_true', help='skip the second timed region (tolerance-mode E-step)')
-    ap.add_argument('--no-live-traffic', action='store_true',
-                    help='roofline.traffic from profiles/pmc_traffic.json instead of two rocprofv3 --pmc child runs')
+    ap.add_argument('--no-exact-mode', action='store_true', help='skip the second timed region (bit-exact E-step and additions)')
+    ap.add_argument('--fast-mode', action='store_true', help='a third timed region: the tolerance-mode E-step without the guard')
+    ap.add_argument('--no-fast-mode', action='store_true', help=argparse.SUPPRESS)  # older command lines (the region is opt-in now)
+    ap.add_argument('--no-live-traffic', action='store_true', help='no rocprofv3 --pmc child runs (roofline.traffic / valu stay empty)')
     ap.add_argument('--no-e2e', action='store_true', help='skip the end-to-end timing of the drop-in calls (containers in, DataFrames out)')
     ap.add_argument('--flat-genotypes', action='store_true',
                     help='worst case of the M-step: all-equal betas, so every posterior is 1/G and every call contributes to '
@@ -286,6 +425,11 @@ def main():
                     help='the per-iteration exchange staged through host memory over the control plane instead of RCCL '
                          '(dmx_comm_init_host): several ranks on ONE GPU, hosts without a usable RCCL fabric')
     args = ap.parse_args()
+    if args.timed_only:
+        args.no_cpu_baseline = args.no_exact_mode = args.no_live_traffic = args.no_e2e = True
+
+    if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
+        sys.exit(self_launch(args))
 
     # gloo and RCCL print banners on stdout; stdout must carry the one JSON line only, so fd 1 is pointed
     # at stderr for the whole run and the line is written to the saved descriptor at the end
@@ -298,10 +442,10 @@ def main():
     if args.reduce_dtype == 'auto':
         args.reduce_dtype = 'f32' if world >= 4 else 'f64'
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
-    assert world == args.gpus, f'--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run'
+    assert world == args.gpus, f'--gpus {args.gpus} but WORLD_SIZE={world}'
 
     # Control plane (rendezvous, RCCL unique id, barrier, max-reduce of the wall time): plain sockets
-    # (demuxalot_amd/plane.py).  torch.distributed.run is only the LAUNCHER: the workers never import torch, whose
+    # (demuxalot_amd/plane.py).  A launcher only starts the processes: the workers never import torch, whose
     # ROCm wheels carry their own libamdhip64 / librccl - two HIP runtimes in one process is what the library refuses.
     # The data-plane collectives are RCCL inside libdemux_hip.so (or, with --host-plane, staged through the plane).
     plane = None
@@ -310,34 +454,21 @@ def main():
         from demuxalot_amd.plane import SocketControlPlane
         plane = SocketControlPlane(rank, world, os.environ.get('MASTER_ADDR', '127.0.0.1'), host_collectives=args.host_plane)
 
-    from demuxalot_amd import Demultiplexer, synth
+    from demuxalot_amd import Demultiplexer
+    from demuxalot_amd import device as dmx_device
     from demuxalot_amd.device import DeviceContext
 
-    B, S, G, dp, seed = WORKLOADS[args.workload]
-    B_total = B  # barcodes of the whole job: per GPU x GPUs (weak) or the workload's own count (strong)
-    t_gen = time.perf_counter()
-    if args.scaling == 'strong' and world > 1:
-        from demuxalot_amd.distributed import partition_barcodes
-        whole = synth.generate(B, S, G, doublets=dp > 0, seed=seed)  # the same experiment on every rank
-        betas = whole.prior_betas(add_data_prior=False)
-        bounds = partition_barcodes(np.bincount(whole.compressed_cb, minlength=B), world)
-        lo, hi = int(bounds[rank]), int(bounds[rank + 1])
-        v_s, cb_s, e_s = whole.subset_barcodes(lo, hi)
-        problem = synth.SyntheticProblem(hi - lo, S, G, whole.v2snp, whole.raw_betas, v_s, cb_s, e_s, whole.truth[lo:hi])
-        del whole
-        B = hi - lo
-    else:
-        problem = synth.generate(B, S, G, doublets=dp > 0, seed=seed, seed_calls=seed * 1000 + rank)
-        betas = problem.prior_betas(add_data_prior=False)  # identical on every rank
-        B_total = B * world
+    B_workload, S, G, dp, _seed = WORKLOADS[args.workload]
+    whole, t_gen, problem_source = get_problem(args, rank, world, plane)
+    betas = whole.prior_betas(add_data_prior=False)  # identical on every rank
     if args.flat_genotypes:
         betas = np.ones_like(betas)
-    t_gen = time.perf_counter() - t_gen
-    V, N = problem.n_variants, problem.n_calls
+    V = whole.n_variants
     pen = Demultiplexer._doublet_penalties(G, dp)
     K = len(pen)
 
     ctx = DeviceContext(local_rank % max(1, _lib_device_count()))
+    default_mode = os.environ.get('DEMUXALOT_AMD_ESTEP', '') or dmx_device.DEFAULT_ESTEP_MODE
     runtimes, rccl_fallback = None, None
     if use_dist and args.host_plane:
         ctx.comm_init_host(rank, world, plane.host_collective, reduce_dtype=args.reduce_dtype)
@@ -371,159 +502,149 @@ def main():
         runtimes = _lib.runtime_info()
         assert len(runtimes['hip']) == 1, f'more than one HIP runtime mapped: {runtimes}'
         assert 'torch' not in sys.modules
-    t_up = time.perf_counter()
-    ctx.set_problem(B, V, G, problem.variant_id, problem.compressed_cb, problem.p_base_wrong, problem.v2snp)
-    ctx.set_betas(betas)
-    t_up = time.perf_counter() - t_up
 
-    # first pass fixes the options and gives the outputs used for the sanity check below
-    ctx.set_addition(None)
-    ctx.probs_from_betas(0.01, fetch=False)
-    logits0, probs0 = ctx.estep(pen, with_doublets=dp > 0)
-
-    def barrier():
-        if plane is not None:
-            plane.barrier()
-
-    ctx.run_iterations(args.warmup, 0.01)
-    ctx.synchronize()
-    ctx.reset_timings()
-    barrier()
-    ctx.synchronize()
-    t0 = time.perf_counter()
-    ctx.run_iterations(args.steps, 0.01)
-    ctx.synchronize()
-    barrier()
-    elapsed = time.perf_counter() - t0
-    if plane is not None:
-        elapsed = plane.max_float64(elapsed)
-    timers = ctx.timings()
-    em_form = ctx.estep_form()[0]  # what the E-steps of the timed iterations ran (direct | packed)
-    guard_stats = ctx.guard_stats()  # (last, total, rows) of the guarded E-steps of the timed region
-
-    # the tolerance-mode E-step (dmx_set_estep_mode: assignments identical, posteriors within the contract's 1e-5)
-    # with the fast summation mode, timed the same way on the same resident problem; the default (bit-exact)
-    # mode above stays the headline `value`
-    fast = None
-    if not args.no_fast_mode:
-        ctx.set_estep_mode('fast')
-        ctx.set_exact_additions(False)
+    def install(problem):
+        t = time.perf_counter()
+        ctx.set_problem(problem.n_barcodes, V, G, problem.variant_id, problem.compressed_cb, problem.p_base_wrong, problem.v2snp)
+        ctx.set_betas(betas)
         ctx.set_addition(None)
         ctx.probs_from_betas(0.01, fetch=False)
-        _lf, probs_fast = ctx.estep(pen, with_doublets=dp > 0)
-        ctx.run_iterations(args.warmup, 0.01)
-        ctx.synchronize()
-        ctx.reset_timings()
-        barrier()
-        ctx.synchronize()
-        t0f = time.perf_counter()
-        ctx.run_iterations(args.steps, 0.01)
-        ctx.synchronize()
-        barrier()
-        elapsed_fast = time.perf_counter() - t0f
-        if plane is not None:
-            elapsed_fast = plane.max_float64(elapsed_fast)
-        timers_fast = ctx.timings()
-        fast = dict(value=B_total * args.steps / elapsed_fast, ms_per_step=1e3 * elapsed_fast / args.steps,
-                    em_iterations_per_s=args.steps / elapsed_fast,
-                    kernel_ms={k: (v['ms'] / max(1, v['launches'])) for k, v in timers_fast.items()},
-                    vs_exact_first_pass=dict(
-                        argmax_identical=bool(np.array_equal(probs_fast.argmax(1), probs0.argmax(1))),
-                        max_abs_posterior_diff=float(np.abs(probs_fast - probs0).max())))
-        ctx.set_estep_mode('exact')
-        ctx.set_exact_additions(os.environ.get('DEMUXALOT_AMD_EXACT_ADDITIONS', '1') not in ('0', ''))
-        ctx.reset_timings()
+        return time.perf_counter() - t
+
+    # ---- the timed regions: configs[3] as written first (strong: this rank's barcode range), then the workload per GPU ----
+    kinds = ['strong', 'weak'] if args.scaling == 'both' else [args.scaling]
+    if world == 1:
+        kinds = kinds[:1]
+    regions, t_up = {}, 0.0
+    logits0 = probs0 = None
+    problem = whole
+    for kind in kinds:
+        problem = shard_of(whole, rank, world) if (kind == 'strong' and world > 1) else whole
+        t_up += install(problem)
+        keep_first = world == 1 and not args.timed_only
+        first = ctx.estep(pen, with_doublets=dp > 0, fetch_logits=keep_first, fetch_probs=keep_first)  # fixes the options
+        if keep_first:
+            logits0, probs0 = first
+        region = timed_region(ctx, plane, args.steps, args.warmup)
+        barcodes_total = B_workload if (kind == 'strong' or world == 1) else B_workload * world
+        region.update(value=barcodes_total * args.steps / region['elapsed'], barcodes_total=barcodes_total,
+                      barcodes_per_gpu=problem.n_barcodes, calls_per_gpu=problem.n_calls)
+        regions[kind] = region
+    head_kind = kinds[0]
+    head = regions[head_kind]
+    N, B = problem.n_calls, problem.n_barcodes   # of the problem that is resident now (n = 1: the whole workload)
+
+    # ---- the same timed region with the bit-exact E-step and additions (same resident problem) ----
+    extra_modes = {}
+    wanted = ([] if args.no_exact_mode or default_mode == 'exact' else ['exact']) + (['fast'] if args.fast_mode else [])
+    for mode in wanted:
+        ctx.set_estep_mode(mode)
+        ctx.set_exact_additions(mode == 'exact')
+        ctx.set_addition(None)
+        ctx.probs_from_betas(0.01, fetch=False)
+        _l, probs_mode = ctx.estep(pen, with_doublets=dp > 0, fetch_logits=False, fetch_probs=world == 1)
+        region = timed_region(ctx, plane, args.steps, args.warmup)
+        region['value'] = regions[kinds[-1]]['barcodes_total'] * args.steps / region['elapsed']
+        region['scaling'] = kinds[-1]
+        if world == 1 and probs0 is not None:
+            region['first_pass_vs_default_mode'] = dict(
+                argmax_identical=bool(np.array_equal(probs_mode.argmax(1), probs0.argmax(1))),
+                max_abs_posterior_diff=float(np.abs(probs_mode - probs0).max()))
+        extra_modes[mode] = region
+    ctx.apply_environment()
 
     # predict_posteriors throughput on the same resident problem (P + E only, no beta addition: demux.py:120-156),
     # rank-local.  The genotype table is then the importers' (a handful of distinct values per row), which is the
     # case the dictionary form of the exact E-step exists for (csrc/estep_dict.hip); timed with the form on (default)
     # and off, same bits either way.
     predict = {}
-    n_pred = max(3, args.steps // 2)
-    for mode in ('auto', 'never'):
-        ctx.set_estep_dictionary(mode)
-        ctx.set_addition(None)
-        ctx.probs_from_betas(0.01, fetch=False)
-        ctx.estep(pen, with_doublets=dp > 0, fetch_logits=False, fetch_probs=False)  # untimed first pass
-        ctx.synchronize()
-        ctx.reset_timings()
-        t1 = time.perf_counter()
-        for _ in range(n_pred):
+    if not args.timed_only:
+        n_pred = max(3, args.steps // 2)
+        for mode in ('auto', 'never'):
+            ctx.set_estep_dictionary(mode)
+            ctx.set_addition(None)
             ctx.probs_from_betas(0.01, fetch=False)
-            ctx.estep(pen, with_doublets=dp > 0, fetch_logits=False, fetch_probs=False)
-        ctx.synchronize()
-        seconds = (time.perf_counter() - t1) / n_pred
-        t_pred = ctx.timings()
-        form, distinct = ctx.estep_form()
-        predict[mode] = dict(seconds=seconds, form=form, distinct_values_per_row=distinct,
-                             estep_ms=t_pred['estep']['ms'] / max(1, t_pred['estep']['launches']),
-                             pstep_ms=t_pred['pstep']['ms'] / max(1, t_pred['pstep']['launches']))
-    ctx.set_estep_dictionary('auto')
-    predict_s = predict['auto']['seconds']
+            ctx.estep(pen, with_doublets=dp > 0, fetch_logits=False, fetch_probs=False)  # untimed first pass
+            ctx.synchronize()
+            ctx.reset_timings()
+            t1 = time.perf_counter()
+            for _ in range(n_pred):
+                ctx.probs_from_betas(0.01, fetch=False)
+                ctx.estep(pen, with_doublets=dp > 0, fetch_logits=False, fetch_probs=False)
+            ctx.synchronize()
+            seconds = (time.perf_counter() - t1) / n_pred
+            t_pred = ctx.timings()
+            form, distinct = ctx.estep_form()
+            pe_ms = t_pred['estep']['ms'] / max(1, t_pred['estep']['launches'])
+            predict['dictionary_form' if mode == 'auto' else 'direct_form'] = dict(
+                seconds=seconds, form=form, distinct_values_per_row=distinct, estep_ms=pe_ms,
+                pstep_ms=t_pred['pstep']['ms'] / max(1, t_pred['pstep']['launches']),
+                estep_hbm_frac=algorithmic_bytes(B, V, G, K, N)['estep'] / (pe_ms * 1e-3) / 8e12)
+        ctx.set_estep_dictionary('auto')
+        predict['note'] = ('P-step + E-step on the table without beta addition (predict_posteriors, EM iteration 0); estep_ms includes '
+                           'building the dictionary; bit-identical to the reference in every E-step mode but `fast`')
 
     if rank == 0:
         ab = algorithmic_bytes(B, V, G, K, N)
-        e_ms = timers['estep']['ms'] / max(1, timers['estep']['launches'])
-        m_ms = timers['mstep']['ms'] / max(1, timers['mstep']['launches'])
-        achieved = ab['estep'] / (e_ms * 1e-3) / 1e9
+        e_ms = regions[kinds[-1]]['kernel_ms']['estep']
+        mode_notes = {'guarded': ': contract of the path proven per barcode and E-step, the rest redone bit-exactly (include/demux_hip.h '
+                                 'DMX_ESTEP_GUARDED); exact_mode = everything bit-identical to the reference',
+                      'exact': ': logits, posteriors and additions bit-identical to the reference',
+                      'fast': ': tolerance mode without the guard'}
         out = {
-            'metric': f'EM iterations/sec + barcodes demuxed/sec, {WORKLOADS[args.workload][0] // 1000}k bc x {S // 1000}k SNP x {G} gt '
-                      + ('per GPU' if args.scaling == 'weak' else f'in total over {world} GPUs') +
+            'metric': f'EM iterations/sec + barcodes demuxed/sec, {B_workload // 1000}k bc x {S // 1000}k SNP x {G} gt '
+                      + ('in total' + (f', barcodes sharded over {world} GPUs' if world > 1 else '') if head_kind == 'strong' else 'per GPU') +
                       ': value = barcodes/s through full learn_genotypes EM iterations (P-step + E-step + softmax + '
                       'M-step [+ exchange]) = barcodes x em_iterations_per_s; predict-only rate in predict_barcodes_per_s',
-            'value': B_total * args.steps / elapsed,
+            'value': head['value'],
             'unit': 'barcodes/s',
             'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
-            'ms_per_step': 1e3 * elapsed / args.steps,
-            'higher_is_better': True, 'scaling': args.scaling, 'vs_baseline': None,
+            'ms_per_step': head['ms_per_step'],
+            'higher_is_better': True, 'scaling': head_kind, 'vs_baseline': None,
             'dtype': 'f32 terms, f64 accumulate', 'data': 'synthetic',
-            'config': {'workload': args.workload, 'barcodes_total': B_total, 'barcodes_per_gpu': B, 'snps': S, 'variants': V, 'genotypes': G,
-                       'options': K, 'calls_per_gpu': N, 'doublet_prior': dp,
-                       'summation': 'fast (DEMUXALOT_AMD_EXACT_ADDITIONS=0)' if os.environ.get('DEMUXALOT_AMD_EXACT_ADDITIONS', '1') in ('0', '') else 'exact: additions bit-identical to the reference (default)',
+            'config': {'workload': args.workload, 'barcodes_total': head['barcodes_total'], 'barcodes_per_gpu': head['barcodes_per_gpu'],
+                       'snps': S, 'variants': V, 'genotypes': G, 'options': K, 'calls_per_gpu': head['calls_per_gpu'], 'doublet_prior': dp,
+                       'estep_mode': default_mode + mode_notes[default_mode],
                        'parallelism': f'barcode shards x{world}' + (f', {"host-staged" if args.host_plane else "RCCL"} reduce-scatter {args.reduce_dtype} + all-gather f32 of variant slices' if use_dist else ''),
                        'runtimes': runtimes, **({'rccl_fallback': rccl_fallback} if rccl_fallback else {})},
-            'em_iterations_per_s': args.steps / elapsed,
-            'predict_barcodes_per_s': B_total / predict_s,
-            'predict': {'dictionary_form': dict(predict['auto'], estep_hbm_frac=algorithmic_bytes(B, V, G, K, N)['estep'] / (predict['auto']['estep_ms'] * 1e-3) / 8e12),
-                        'direct_form': dict(predict['never'], estep_hbm_frac=algorithmic_bytes(B, V, G, K, N)['estep'] / (predict['never']['estep_ms'] * 1e-3) / 8e12),
-                        'note': 'P-step + E-step on the table without beta addition (predict_posteriors, EM iteration 0); '
-                                'estep_ms includes building the dictionary'},
-            'kernel_ms': {k: (v['ms'] / max(1, v['launches'])) for k, v in timers.items()},
-            'exchange_ms_per_step': timers['allreduce']['ms'] / max(1, args.steps),
-            'roofline': roofline(args.workload, ab, e_ms, m_ms, timers, N, G, K, em_form),
-            'guard': {'barcodes_redone_exactly': guard_stats[1], 'barcode_rows': guard_stats[2],
-                      'fraction': guard_stats[1] / max(1, guard_stats[2])},
-            'setup_s': {'generate': t_gen, 'upload': t_up},
-            'fast_mode': fast,
+            'em_iterations_per_s': head['em_iterations_per_s'],
+            'kernel_ms': head['kernel_ms'],
+            'exchange_ms_per_step': head['exchange_ms_per_step'],
+            'guard': head['guard'],
+            'setup_s': {'problem': t_gen, 'problem_source': problem_source, 'upload': t_up},
         }
-        if fast is not None:
-            e_fast = fast['kernel_ms']['estep']
-            fast['estep_hbm_frac'] = ab['estep'] / (e_fast * 1e-3) / 1e9 / 8000.0
-            fast['delivered_gather_GBps'] = (N * 4 * G) / (e_fast * 1e-3) / 1e9
-        out['roofline']['traffic_source'] = 'profiles/pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE + WRITE_SIZE of an earlier run)'
-        if os.environ.get('DEMUXALOT_AMD_ESTEP_SCHEDULE', 'auto') == 'tiled' and out['roofline']['kernel'] == 'k_estep_direct':
-            out['roofline']['kernel'] = 'k_estep_tiled'
-            out['roofline']['traffic'], out['roofline']['traffic_source'] = None, 'none (no committed figure for this kernel)'
+        if 'weak' in regions and head_kind != 'weak':
+            out['weak'] = {k: regions['weak'][k] for k in ('value', 'ms_per_step', 'em_iterations_per_s', 'barcodes_total', 'barcodes_per_gpu',
+                                                           'calls_per_gpu', 'kernel_ms', 'exchange_ms_per_step', 'guard')}
+            out['weak']['note'] = ('the workload per GPU: every rank holds a 200k-barcode shard (a copy of the generated one) of an '
+                                   'N x 200k-barcode experiment')
+        for mode, region in extra_modes.items():
+            out[f'{mode}_mode'] = {k: v for k, v in region.items() if k != 'elapsed'}
+        if predict:
+            out['predict'] = predict
+            out['predict_barcodes_per_s'] = B / predict['dictionary_form']['seconds']
+        live = {}
         if world == 1 and not args.no_live_traffic:
-            live = live_counters(args, out['roofline']['kernel'])
-            if 'traffic' in live:
-                out['roofline']['traffic'] = live['traffic']
-                out['roofline']['traffic_source'] = 'rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, child runs of this command (live)'
-            if 'traffic' not in live or 'clock_ghz' not in live:
-                out['roofline']['live_counters'] = {k: v for k, v in live.items() if k == 'skipped' or k.endswith('_failed')}
-            if 'clock_ghz' in live:  # the VALU issue fraction at the clock the kernel actually holds
-                valu = out['roofline']['valu']
-                valu['sustained_clock_ghz'] = live['clock_ghz']
-                valu['frac_at_sustained_clock'] = valu['frac'] * PEAK_CLOCK_HZ / (live['clock_ghz'] * 1e9)
-                valu['clock_source'] = 'rocprofv3 --pmc GRBM_GUI_ACTIVE / 8 XCDs / kernel duration, child run of this command (live)'
+            cache = os.environ.get('DEMUXALOT_BENCH_PROBLEM', '')
+            own = not cache
+            if own:
+                cache = shared_directory() + f'_pmc{os.getpid()}'
+                save_problem(cache, whole)
+            try:
+                live = live_counters(args, cache)
+            finally:
+                if own:
+                    import shutil
+                    shutil.rmtree(cache, ignore_errors=True)
+        out['roofline'] = roofline(ab, e_ms, N, G, K, live)
         if world == 1 and not args.no_e2e and not args.flat_genotypes:
             ctx.close()  # the end-to-end calls bring their own contexts; free this one's 4 GB first
-            out['e2e'] = e2e_timing(problem, dp)
+            out['e2e'] = e2e_timing(whole, dp)
         if world == 1 and not args.no_cpu_baseline:
-            base, ref_logits, ref_post, n_s = cpu_baseline(problem, betas, dp)
+            base, ref_logits, ref_post, n_s = cpu_baseline(whole, betas, dp)
             out['cpu_baseline'] = base
             out['cpu_baseline']['speedup_vs_gpu_value'] = out['value'] / base['value']
-            # sanity: the GPU rows of the sampled barcodes equal the oracle's
+            # sanity: the GPU rows of the sampled barcodes against the oracle's (first pass = importers' table: bit-exact in every mode)
             out['parity_on_sample'] = {
                 'argmax_identical': bool(np.array_equal(ref_post.argmax(1), probs0[:n_s].argmax(1))),
                 'max_abs_posterior_diff': float(np.abs(ref_post - probs0[:n_s]).max()),
@@ -535,6 +656,9 @@ def main():
         os.write(json_fd, (json.dumps(out) + '\n').encode())
     if plane is not None:
         plane.barrier()
+        if rank == 0 and world > 1 and not os.environ.get('DEMUXALOT_BENCH_PROBLEM'):
+            import shutil
+            shutil.rmtree(shared_directory(), ignore_errors=True)
         plane.close()
 
 

@@ -76,6 +76,8 @@ SIGNATURES = {
     'dmx_reset_timings': (c_int, [_P]),
     'dmx_device_bytes': (c_int, [_P, POINTER(c_int64)]),
     'dmx_trim_cache': (c_int, [_P, POINTER(c_int64)]),
+    'dmx_release_problem': (c_int, [_P]),
+    'dmx_trim_device_caches': (c_int, [c_int, POINTER(c_int64)]),
     'dmx_set_exact_additions': (c_int, [_P, c_int]),
     'dmx_get_redo_count': (c_int, [_P, POINTER(c_int64)]),
     'dmx_set_estep_mode': (c_int, [_P, c_int]),

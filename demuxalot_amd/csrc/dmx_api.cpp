@@ -113,8 +113,10 @@ int load_rccl()
     g_rccl.CommDestroy = (decltype(g_rccl.CommDestroy))dlsym(h, "ncclCommDestroy");
     g_rccl.GetErrorString = (decltype(g_rccl.GetErrorString))dlsym(h, "ncclGetErrorString");
     if (!g_rccl.GetUniqueId || !g_rccl.CommInitRank || !g_rccl.AllReduce || !g_rccl.ReduceScatter || !g_rccl.AllGather ||
-        !g_rccl.CommDestroy)
+        !g_rccl.CommDestroy) {
+        dlclose(h);
         return fail(DMX_ERR_RCCL, "%s lacks a required symbol", path.c_str());
+    }
     // loading RCCL must not have brought a second runtime along either
     const std::vector<std::string> after = mapped_files("libamdhip64");
     if (after.size() > 1 && !lenient) {
@@ -193,7 +195,7 @@ int ensure_sum_plan(dmx_ctx *c, long long K)
 
 }  // namespace dmx
 
-void retired_trim(int device);
+size_t retired_trim(int device);
 
 size_t ctx_cache_limit()
 {
@@ -208,26 +210,78 @@ size_t ctx_cache_limit()
 // Blocks of destroyed contexts (their streams are idle by then), per device, for the contexts created later: a fresh
 // context's first problem cost 0.45 s more than a re-used one's inside a process that had closed a large context before
 // (bench.py's e2e part after the timed regions: 0.57 s against 0.11 s).
+// Lock order: g_retired.lock (retired lists + registry of live contexts) before any context's cache_lock.
 namespace {
 struct RetiredBlocks {
     std::mutex lock;
     std::multimap<size_t, void *> idle[16];
     size_t bytes[16] = {};
+    std::vector<dmx_ctx *> live[16];
 };
 RetiredBlocks g_retired;
+
+size_t trim_locked(dmx_ctx *c, size_t keep_bytes)  // c->cache_lock held
+{
+    size_t freed = 0;
+    while (!c->idle_blocks.empty() && c->idle_bytes > keep_bytes) {
+        auto it = std::prev(c->idle_blocks.end());
+        (void)hipFree(it->second);  // waits for the device: whatever was queued on the block is done
+        c->idle_bytes -= it->first;
+        freed += it->first;
+        c->block_capacity.erase(it->second);
+        c->idle_blocks.erase(it);
+    }
+    return freed;
+}
 }  // namespace
+
+void ctx_register(dmx_ctx *c)
+{
+    if (c->device < 0 || c->device >= 16) return;
+    std::lock_guard<std::mutex> guard(g_retired.lock);
+    g_retired.live[c->device].push_back(c);
+}
+
+void ctx_unregister(dmx_ctx *c)
+{
+    if (c->device < 0 || c->device >= 16) return;
+    std::lock_guard<std::mutex> guard(g_retired.lock);
+    auto &v = g_retired.live[c->device];
+    v.erase(std::remove(v.begin(), v.end(), c), v.end());
+}
+
+// Everything parked on a device goes back to the driver: the idle blocks of EVERY live context (pooled private contexts
+// are unreachable from the API, and each may hold gigabytes) and the retired list.
+size_t trim_device_caches(int device)
+{
+    if (device < 0 || device >= 16) return 0;
+    std::lock_guard<std::mutex> guard(g_retired.lock);
+    size_t freed = 0;
+    for (dmx_ctx *other : g_retired.live[device]) {
+        std::lock_guard<std::mutex> own(other->cache_lock);
+        freed += trim_locked(other, 0);
+    }
+    for (auto &kv : g_retired.idle[device]) (void)hipFree(kv.second);
+    g_retired.idle[device].clear();
+    freed += g_retired.bytes[device];
+    g_retired.bytes[device] = 0;
+    return freed;
+}
 
 int ctx_malloc(dmx_ctx *c, void **p, size_t bytes)
 {
     *p = nullptr;
     if (bytes == 0) bytes = 1;
-    // an idle block of this size, or up to an eighth (+ 64 KB) larger
-    auto it = c->idle_blocks.lower_bound(bytes);
-    if (it != c->idle_blocks.end() && it->first <= bytes + bytes / 8 + 65536) {
-        *p = it->second;
-        c->idle_bytes -= it->first;
-        c->idle_blocks.erase(it);
-        return 0;
+    {
+        // an idle block of this size, or up to an eighth (+ 64 KB) larger
+        std::lock_guard<std::mutex> own(c->cache_lock);
+        auto it = c->idle_blocks.lower_bound(bytes);
+        if (it != c->idle_blocks.end() && it->first <= bytes + bytes / 8 + 65536) {
+            *p = it->second;
+            c->idle_bytes -= it->first;
+            c->idle_blocks.erase(it);
+            return 0;
+        }
     }
     if (c->device >= 0 && c->device < 16) {
         std::lock_guard<std::mutex> guard(g_retired.lock);
@@ -235,23 +289,27 @@ int ctx_malloc(dmx_ctx *c, void **p, size_t bytes)
         auto jt = pool.lower_bound(bytes);
         if (jt != pool.end() && jt->first <= bytes + bytes / 8 + 65536) {
             *p = jt->second;
-            c->block_capacity[*p] = jt->first;
+            {
+                std::lock_guard<std::mutex> own(c->cache_lock);
+                c->block_capacity[*p] = jt->first;
+            }
             g_retired.bytes[c->device] -= jt->first;
             pool.erase(jt);
             return 0;
         }
     }
     hipError_t e = hipMalloc(p, bytes);
-    if (e != hipSuccess) {  // out of memory with blocks parked here or retired: give them back, try again
+    if (e != hipSuccess) {  // out of memory with blocks parked on this device - here, in sibling contexts, retired: give them back, try again
         (void)hipGetLastError();
         ctx_trim(c, 0);
-        retired_trim(c->device);
+        (void)trim_device_caches(c->device);
         e = hipMalloc(p, bytes);
     }
     if (e != hipSuccess) {
         *p = nullptr;
         return fail(DMX_ERR_HIP, "hipMalloc of %zu bytes failed: %s", bytes, hipGetErrorString(e));
     }
+    std::lock_guard<std::mutex> own(c->cache_lock);
     c->block_capacity[*p] = bytes;
     return 0;
 }
@@ -259,24 +317,31 @@ int ctx_malloc(dmx_ctx *c, void **p, size_t bytes)
 void ctx_free(dmx_ctx *c, void *p)
 {
     if (!p) return;
-    auto it = c->block_capacity.find(p);
-    if (it == c->block_capacity.end() || ctx_cache_limit() == 0) {
-        if (it != c->block_capacity.end()) c->block_capacity.erase(it);
-        (void)hipFree(p);
-        return;
+    bool over = false;
+    {
+        std::lock_guard<std::mutex> own(c->cache_lock);
+        auto it = c->block_capacity.find(p);
+        if (it == c->block_capacity.end() || ctx_cache_limit() == 0) {
+            if (it != c->block_capacity.end()) c->block_capacity.erase(it);
+            (void)hipFree(p);
+            return;
+        }
+        c->idle_blocks.emplace(it->second, p);
+        c->idle_bytes += it->second;
+        over = c->idle_bytes > ctx_cache_limit();
     }
-    c->idle_blocks.emplace(it->second, p);
-    c->idle_bytes += it->second;
-    if (c->idle_bytes > ctx_cache_limit()) ctx_trim(c, ctx_cache_limit() / 2);
+    if (over) ctx_trim(c, ctx_cache_limit() / 2);
 }
 
-void retired_trim(int device)
+size_t retired_trim(int device)  // returns the bytes given back
 {
-    if (device < 0 || device >= 16) return;
+    if (device < 0 || device >= 16) return 0;
     std::lock_guard<std::mutex> guard(g_retired.lock);
     for (auto &kv : g_retired.idle[device]) (void)hipFree(kv.second);
     g_retired.idle[device].clear();
+    const size_t freed = g_retired.bytes[device];
     g_retired.bytes[device] = 0;
+    return freed;
 }
 
 // dmx_destroy: the context's idle blocks (its stream has been waited for) go to the device's retired list, up to the
@@ -289,6 +354,7 @@ void ctx_retire(dmx_ctx *c)
     }
     {
         std::lock_guard<std::mutex> guard(g_retired.lock);
+        std::lock_guard<std::mutex> own(c->cache_lock);
         for (auto it = c->idle_blocks.begin(); it != c->idle_blocks.end();) {
             if (g_retired.bytes[c->device] + it->first > ctx_cache_limit()) {
                 ++it;
@@ -307,13 +373,8 @@ void ctx_retire(dmx_ctx *c)
 // hipFree (which waits for the device) of idle blocks, largest first, until at most keep_bytes stay parked
 void ctx_trim(dmx_ctx *c, size_t keep_bytes)
 {
-    while (!c->idle_blocks.empty() && c->idle_bytes > keep_bytes) {
-        auto it = std::prev(c->idle_blocks.end());
-        (void)hipFree(it->second);
-        c->idle_bytes -= it->first;
-        c->block_capacity.erase(it->second);
-        c->idle_blocks.erase(it);
-    }
+    std::lock_guard<std::mutex> own(c->cache_lock);
+    (void)trim_locked(c, keep_bytes);
 }
 
 namespace {
@@ -857,6 +918,7 @@ int prepare_dictionary(dmx_ctx *c, bool pairs, dmx::EstepArgs &a, int *form)
     const bool block_form = pairs && K > dmx::DICT_LANE_K;  // wide doublet tables: workgroup per barcode
     if (!block_form && (K > dmx::DICT_LANE_K || rows >= (1 << 24) || a.pairs_bytes == 0)) return 0;  // singlet tables beyond 256: the direct forms; 24-bit row x pitch; 32-bit record offsets
     if (block_form && (size_t)G * 72 + 9 * 1024 > 160 * 1024) return 0;  // the code rows of a chunk must fit the LDS
+    if (G > 1024) return 0;  // widest k_build_dict instantiation (ensure_options refuses such runs anyway)
     if (c->dict_mode == 1 && !block_form) {
         // Where the lane form pays (measured): singlet runs with enough barcodes for several rounds of
         // wavefronts.  A launch of one round lasts as long as its longest barcode, whose calls this form walks in
@@ -979,7 +1041,9 @@ int run_estep(dmx_ctx *c, int with_doublets, bool with_prior, int prior_dtype, f
         if (packed && c->estep_packing != 2) {
             const int k = lanes == 8 ? 0 : lanes == 16 ? 1 : 2;
             a.n_long = c->max_row_calls > 0 ? c->n_long_rows[k] : c->B;  // no statistic (host-packed problem): not packed
-            if (const char *e = std::getenv("DEMUXALOT_AMD_PACKED_LONG")) a.n_long = std::min<long long>(c->B, std::max(0ll, atoll(e)));  // experiment knob
+#ifdef DMX_EXPERIMENTS  // experiment builds only (make EXPERIMENTS=1)
+            if (const char *e = std::getenv("DEMUXALOT_AMD_PACKED_LONG")) a.n_long = std::min<long long>(c->B, std::max(0ll, atoll(e)));
+#endif
             if (c->estep_packing == 1 && 8 * a.n_long > c->B) packed = false;
             if (!packed) a.n_long = 0;
         }
@@ -1175,6 +1239,7 @@ int dmx_create(int device, dmx_ctx **out)
         delete c;
         return fail(DMX_ERR_HIP, "hipStreamCreate: %s", hipGetErrorString(e));
     }
+    ctx_register(c);
     *out = c;
     return 0;
 }
@@ -1182,6 +1247,7 @@ int dmx_create(int device, dmx_ctx **out)
 int dmx_destroy(dmx_ctx *c)
 {
     if (!c) return 0;
+    ctx_unregister(c);
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
     if (c->comm && g_rccl.CommDestroy) g_rccl.CommDestroy(c->comm);
@@ -1437,15 +1503,35 @@ int dmx_set_estep_dictionary(dmx_ctx *c, int mode)
     return 0;
 }
 
+int dmx_release_problem(dmx_ctx *c)
+{
+    DMX_TRY(bind(c));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    release_problem(c);
+    dmx::release_staged_calls(c);
+    return 0;
+}
+
+int dmx_trim_device_caches(int device, int64_t *released_bytes)
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || device < 0 || device >= n) return fail(DMX_ERR_INVALID, "device %d out of range", device);
+    HIP_TRY(hipSetDevice(device));
+    const size_t freed = trim_device_caches(device);
+    if (released_bytes) *released_bytes = (int64_t)freed;
+    return 0;
+}
+
 int dmx_trim_cache(dmx_ctx *c, int64_t *released_bytes)
 {
     DMX_TRY(bind(c));
-    size_t before = c->idle_bytes;
-    ctx_trim(c, 0);
-    if (c->device >= 0 && c->device < 16) {
-        before += g_retired.bytes[c->device];
-        retired_trim(c->device);
+    size_t before = 0;
+    {
+        std::lock_guard<std::mutex> own(c->cache_lock);
+        before = c->idle_bytes;
     }
+    ctx_trim(c, 0);
+    before += retired_trim(c->device);
     if (released_bytes) *released_bytes = (int64_t)before;
     return 0;
 }

@@ -5,6 +5,7 @@
 #include <rccl/rccl.h>
 
 #include <map>
+#include <mutex>
 #include <string>
 #include <unordered_map>
 #include <utility>
@@ -183,6 +184,7 @@ struct dmx_ctx {
     std::multimap<size_t, void *> idle_blocks;          // capacity -> block
     std::unordered_map<void *, size_t> block_capacity;  // every block handed out through ctx_malloc, idle or not
     size_t idle_bytes = 0;
+    std::mutex cache_lock;  // the three above: another context's out-of-memory retry may trim this one's idle blocks
 };
 
 // Why the context keeps its device blocks: a second predict / learn call on a context frees the previous problem
@@ -197,6 +199,9 @@ int ctx_malloc(dmx_ctx *c, void **p, size_t bytes);
 void ctx_free(dmx_ctx *c, void *p);
 void ctx_trim(dmx_ctx *c, size_t keep_bytes);
 void ctx_retire(dmx_ctx *c);  // dmx_destroy: idle blocks to the device's retired list (for contexts created later)
+void ctx_register(dmx_ctx *c);    // dmx_create / dmx_destroy: the live contexts of a device, whose idle blocks an
+void ctx_unregister(dmx_ctx *c);  // out-of-memory retry anywhere on that device may give back
+size_t trim_device_caches(int device);  // idle blocks of every live context + the retired list; returns the bytes freed
 
 template <typename T>
 inline int dev_alloc(dmx_ctx *c, T **p, size_t count)

@@ -578,8 +578,10 @@ hipError_t launch_estep_dict_block(hipStream_t st, const EstepArgs &a)
     if (a.B == 0) return hipSuccess;
     const int K = a.K, need = (K + 255) / 256;
     int tile = need <= 2 ? 2 : need <= 4 ? 4 : need <= 8 ? 8 : need <= 12 ? 12 : need <= 17 ? 17 : need <= 24 ? 12 : 17;
-    static const int forced = std::getenv("DEMUXALOT_AMD_DICT_TILE") ? std::atoi(std::getenv("DEMUXALOT_AMD_DICT_TILE")) : 0;  // tuning aid
+#ifdef DMX_EXPERIMENTS  // tuning aid of experiment builds (make EXPERIMENTS=1); never in the library build() ships
+    static const int forced = std::getenv("DEMUXALOT_AMD_DICT_TILE") ? std::atoi(std::getenv("DEMUXALOT_AMD_DICT_TILE")) : 0;
     if (forced == 2 || forced == 4 || forced == 8 || forced == 12 || forced == 17) tile = forced;
+#endif
     for (int k_base = 0; k_base < K; k_base += tile * 256) {
         const hipError_t e = tile == 2 ? launch_dict_block<2>(st, a, k_base) : tile == 4 ? launch_dict_block<4>(st, a, k_base)
                            : tile == 8 ? launch_dict_block<8>(st, a, k_base) : tile == 12 ? launch_dict_block<12>(st, a, k_base)
@@ -619,32 +621,40 @@ hipError_t launch_pack_rows(hipStream_t st, const float *dict, const unsigned ch
 template <int NE, int LB, bool PAIRS>
 static void launch_dictq(hipStream_t st, const EstepArgs &a)
 {
-    static const int ablate = std::getenv("DEMUXALOT_AMD_DICT_ABLATE") ? std::atoi(std::getenv("DEMUXALOT_AMD_DICT_ABLATE")) : 0;
     constexpr int NB = 64 / LB;
-    static const long long max_blocks = std::getenv("DEMUXALOT_AMD_DICT_BLOCKS") ? std::atoll(std::getenv("DEMUXALOT_AMD_DICT_BLOCKS")) : (1LL << 40);
-    const dim3 grid((unsigned)std::min<long long>(max_blocks, (a.B + NB - 1) / NB)), block(64);
+    long long max_blocks = 1LL << 40;
+#ifdef DMX_EXPERIMENTS
+    // Timing ablations and partial launches of experiment builds (make EXPERIMENTS=1; results are meaningless): an
+    // environment variable must never be able to make the shipped library return wrong posteriors, so build() compiles
+    // none of this (profiles/r3_pmc_dictq_em_200k_100k_64.txt was taken with such a build).
+    static const int ablate = std::getenv("DEMUXALOT_AMD_DICT_ABLATE") ? std::atoi(std::getenv("DEMUXALOT_AMD_DICT_ABLATE")) : 0;
+    static const long long forced_blocks = std::getenv("DEMUXALOT_AMD_DICT_BLOCKS") ? std::atoll(std::getenv("DEMUXALOT_AMD_DICT_BLOCKS")) : (1LL << 40);
+    max_blocks = forced_blocks;
     if constexpr (NE == 4 && LB == 16 && !PAIRS) {
+        const dim3 grid_a((unsigned)std::min<long long>(max_blocks, (a.B + NB - 1) / NB)), block_a(64);
         if (ablate == 1) {
-            hipLaunchKernelGGL((k_estep_dictq<4, 16, false, 1>), grid, block, 0, st, a);
+            hipLaunchKernelGGL((k_estep_dictq<4, 16, false, 1>), grid_a, block_a, 0, st, a);
             return;
         }
         if (ablate == 2) {
-            hipLaunchKernelGGL((k_estep_dictq<4, 16, false, 2>), grid, block, 0, st, a);
+            hipLaunchKernelGGL((k_estep_dictq<4, 16, false, 2>), grid_a, block_a, 0, st, a);
             return;
         }
         if (ablate == 3) {
-            hipLaunchKernelGGL((k_estep_dictq<4, 16, false, 3>), grid, block, 0, st, a);
+            hipLaunchKernelGGL((k_estep_dictq<4, 16, false, 3>), grid_a, block_a, 0, st, a);
             return;
         }
         if (ablate == 4) {
-            hipLaunchKernelGGL((k_estep_dictq<4, 16, false, 4>), grid, block, 0, st, a);
+            hipLaunchKernelGGL((k_estep_dictq<4, 16, false, 4>), grid_a, block_a, 0, st, a);
             return;
         }
         if (ablate == 5) {
-            hipLaunchKernelGGL((k_estep_dictq<4, 16, false, 5>), grid, block, 0, st, a);
+            hipLaunchKernelGGL((k_estep_dictq<4, 16, false, 5>), grid_a, block_a, 0, st, a);
             return;
         }
     }
+#endif
+    const dim3 grid((unsigned)std::min<long long>(max_blocks, (a.B + NB - 1) / NB)), block(64);
     hipLaunchKernelGGL((k_estep_dictq<NE, LB, PAIRS, 0>), grid, block, 0, st, a);
 }
 

@@ -332,7 +332,9 @@ static int repack_core(dmx_ctx *c, Scratch &sc, const int *d_variant, const int 
     const int G = c->G;
     hipStream_t st = c->stream;
     c->item_calls = item_calls_for(N);
-    if (const char *forced = std::getenv("DEMUXALOT_AMD_ITEM_CALLS")) c->item_calls = std::max(64, std::atoi(forced));  // experiments
+#ifdef DMX_EXPERIMENTS  // experiment builds only (make EXPERIMENTS=1)
+    if (const char *forced = std::getenv("DEMUXALOT_AMD_ITEM_CALLS")) c->item_calls = std::max(64, std::atoi(forced));
+#endif
 
     // the sorts below carry call indices as 32-bit values
     if (N >= (1LL << 32)) return fail(DMX_ERR_UNSUPPORTED, "%lld calls: one context holds fewer than 2^32 (shard the barcodes)", N);
@@ -439,10 +441,14 @@ static int repack_core(dmx_ctx *c, Scratch &sc, const int *d_variant, const int 
         const long long rounds = (B + TILE_R_MAX * wave_slots - 1) / (TILE_R_MAX * wave_slots);
         const long long n_bins = rounds * wave_slots;
         const int R = (int)((B + n_bins - 1) / n_bins);  // <= TILE_R_MAX
-        static const long long tile_bytes = [] {  // experiment knob: DEMUXALOT_AMD_TILE_KB (default TILE_BYTES)
+#ifdef DMX_EXPERIMENTS  // experiment builds only (make EXPERIMENTS=1): DEMUXALOT_AMD_TILE_KB
+        static const long long tile_bytes = [] {
             const char *e = std::getenv("DEMUXALOT_AMD_TILE_KB");
             return e && atoll(e) > 0 ? atoll(e) * 1024 : TILE_BYTES;
         }();
+#else
+        const long long tile_bytes = TILE_BYTES;
+#endif
         const unsigned tile_rows = (unsigned)std::max<long long>(1, tile_bytes / ((long long)G * 4));
         const int n_tiles = (int)((V + tile_rows - 1) / tile_rows);
         const size_t cells = (size_t)n_bins * n_tiles * R;

@@ -232,8 +232,15 @@ def _pack_on_device(chromosome2compressed_snp_calls, genotypes, n_barcodes, add_
                 v2snp = snp_ids_from_columns(columns) if columns is not _UNSET and columns is not None else genotypes.get_snp_ids_for_variants()
                 assert np.all(v2snp >= 0)
             (var_chrom, var_pos, var_base), chrom_index = _variant_keys(genotypes, columns)
-        finally:
+        except BaseException:
             worker.join()
+            if not failure:  # the worker did stage them (~17 bytes per call on the GPU): give them back before unwinding
+                try:
+                    ctx.release_problem()
+                except Exception:  # noqa: BLE001
+                    pass
+            raise
+        worker.join()
         if failure:
             raise failure[0]
         chrom_of_container = []
@@ -272,7 +279,9 @@ class DevicePosteriors:
     """Posteriors (and logits) of one predict_posteriors / learn_genotypes call, kept on the GPU
     (`on_device=True`), with the reductions users of the reference apply to the DataFrame done there:
     nothing of size [B, K] crosses PCIe unless to_dataframes() / rows() ask for it.
-    Owns a private device context; close() (or garbage collection) releases the GPU memory."""
+    Owns a private device context; close() (or garbage collection) hands it back to a small pool with the problem
+    released into the context's block cache - parked, re-used by the next call, and returned to the driver by
+    demuxalot_amd.device.trim_device_caches() or by any allocation that would otherwise run out of device memory."""
 
     def __init__(self, ctx, barcodes, column_names, index_name=None, pooled=True):
         self._ctx = ctx
@@ -463,7 +472,13 @@ class Demultiplexer:
                     'genotype_addition': genotype_addition,
                 }
                 genotype_addition = ctx.mstep(Demultiplexer.contribution_power)
-        finally:
+        except GeneratorExit:  # the consumer stopped early: nothing wrong with the context
+            release_private_context(ctx)
+            raise
+        except BaseException:
+            release_private_context(ctx, failed=True)
+            raise
+        else:
             release_private_context(ctx)
 
     @staticmethod

@@ -10,8 +10,12 @@ from . import _lib
 from ._lib import DMX_F32, DMX_F64, as_c, check, ptr
 
 
-# E-step arithmetic of a new context (include/demux_hip.h: dmx_set_estep_mode); DEMUXALOT_AMD_ESTEP overrides
-DEFAULT_ESTEP_MODE = 'exact'
+# E-step arithmetic of a new context (include/demux_hip.h: dmx_set_estep_mode); DEMUXALOT_AMD_ESTEP overrides.
+# 'guarded': the contract of the path - assignments identical to the reference, posteriors within 1e-5 - PROVEN per barcode and
+# E-step, every barcode that cannot be proven redone with the bit-exact kernel; E-steps on the importers' genotype tables
+# (predict_posteriors, EM iteration 0) take the dictionary form and stay bit-identical to the reference.  'exact': every
+# logit, posterior and beta addition bit-identical to the reference, at 1.6x the time per EM iteration.
+DEFAULT_ESTEP_MODE = 'guarded'
 
 
 class DeviceContext:
@@ -463,6 +467,12 @@ class DeviceContext:
         check(self._lib.dmx_trim_cache(self._h, ctypes.byref(n)))
         return n.value
 
+    def release_problem(self):
+        """The resident problem (and any staged containers) back into this context's block cache
+        (include/demux_hip.h: dmx_release_problem)."""
+        check(self._lib.dmx_release_problem(self._h))
+        self.B = self.V = self.G = self.N = self.K = 0
+
     def device_bytes(self):
         n = ctypes.c_int64(0)
         check(self._lib.dmx_device_bytes(self._h, ctypes.byref(n)))
@@ -551,13 +561,41 @@ def acquire_private_context(device=None) -> DeviceContext:
     return ctx
 
 
-def release_private_context(ctx):
-    """Back to the pool (its resident problem stays allocated until the context is reused or the pool is full)."""
+def release_private_context(ctx, failed=False):
+    """Back to the pool, its resident problem released into its block cache (the next problem installed on it re-uses the
+    blocks; an allocation that runs out of device memory anywhere in the process gives the parked blocks of every context
+    back first: csrc/dmx_api.cpp ctx_malloc).  `failed`: the holder is unwinding from an exception - the context, which
+    may carry a sticky HIP error, is destroyed instead.  The pool holds two contexts per device; drain_private_contexts()
+    empties it, trim_device_caches() returns every parked block of a device to the driver."""
     if ctx is None or getattr(ctx, '_h', None) is None:
         return
-    with _contexts_lock:
-        idle = _idle_private.setdefault(ctx.device, [])
-        if len(idle) < _PRIVATE_POOL:
-            idle.append(ctx)
-            return
+    if not failed:
+        try:
+            ctx.release_problem()
+        except Exception:  # noqa: BLE001 - a context that cannot even release is not worth keeping
+            failed = True
+    if not failed:
+        with _contexts_lock:
+            idle = _idle_private.setdefault(ctx.device, [])
+            if len(idle) < _PRIVATE_POOL:
+                idle.append(ctx)
+                return
     ctx.close()
+
+
+def drain_private_contexts():
+    """Destroys the pooled private contexts (their blocks go to the device's retired list; trim_device_caches() frees those)."""
+    with _contexts_lock:
+        pooled = [ctx for idle in _idle_private.values() for ctx in idle]
+        _idle_private.clear()
+    for ctx in pooled:
+        ctx.close()
+
+
+def trim_device_caches(device=None):
+    """Every device block this process keeps parked on `device` - idle blocks of all live contexts, blocks of destroyed
+    ones - back to the driver; returns the bytes (include/demux_hip.h: dmx_trim_device_caches)."""
+    device = default_device() if device is None else int(device)
+    n = ctypes.c_int64(0)
+    check(_lib.load().dmx_trim_device_caches(device, ctypes.byref(n)))
+    return n.value

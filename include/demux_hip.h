@@ -417,6 +417,13 @@ int dmx_device_bytes(dmx_ctx *ctx, int64_t *bytes);
  * dmx_trim_cache gives this context's idle blocks and the device's retired ones back to the driver now and reports how
  * many bytes that were. */
 int dmx_trim_cache(dmx_ctx *ctx, int64_t *released_bytes);
+/* The resident problem of a context (call layouts, tables, results, staged containers) released into its block cache: what
+ * a holder does with a context it parks for later (demuxalot_amd/device.py: release_private_context).  The context stays
+ * usable; the next problem re-uses the blocks. */
+int dmx_release_problem(dmx_ctx *ctx);
+/* Everything parked on a device back to the driver: the idle blocks of EVERY live context of this process on it and the
+ * retired list.  An allocation that fails for lack of memory does this by itself before it gives up. */
+int dmx_trim_device_caches(int device, int64_t *released_bytes);
 
 /* ------------------------------------------------------------------------- *
  * Device self-tests of the float32 building blocks (used by tests/ on the GPU box):

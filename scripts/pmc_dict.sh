@@ -5,6 +5,7 @@ OUT=gpurun_out/dict_$WL
 mkdir -p $OUT
 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 scripts/predict_loop.py $WL 6 auto > $OUT/trace.log 2>&1
 cp $OUT/trace/*/*kernel_stats.csv $OUT/kernel_stats.csv 2>/dev/null
+# the ablations need an experiment build of the library: make -C demuxalot_amd/csrc clean all EXPERIMENTS=1
 for abl in 1 2 3 4 5; do DEMUXALOT_AMD_DICT_ABLATE=$abl timeout 200 python3 scripts/predict_loop.py $WL 6 auto >> $OUT/ablate.log 2>&1; done
 run() { name=$1; shift; timeout 300 rocprofv3 --kernel-trace --pmc "$@" --output-format csv -d $OUT/pmc_$name -- python3 scripts/predict_loop.py $WL 3 auto > $OUT/pmc_$name.log 2>&1; }
 run sq1 SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY

@@ -24,9 +24,10 @@ def fast(monkeypatch):
     from demuxalot_amd.device import get_context
     monkeypatch.setenv('DEMUXALOT_AMD_ESTEP', 'fast')
     ctx = get_context()
-    ctx.set_estep_mode('fast')
+    ctx.apply_environment()
     yield ctx
-    ctx.set_estep_mode('exact')
+    monkeypatch.setenv('DEMUXALOT_AMD_ESTEP', 'exact')  # the suite's pin (tests/conftest.py)
+    ctx.apply_environment()
 
 
 def posterior_bound(ref_logits):

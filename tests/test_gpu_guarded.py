@@ -24,7 +24,7 @@ def guarded(monkeypatch):
     ctx = device.get_context()
     ctx.apply_environment()
     yield ctx
-    monkeypatch.delenv('DEMUXALOT_AMD_ESTEP')
+    monkeypatch.setenv('DEMUXALOT_AMD_ESTEP', 'exact')  # the suite's pin (tests/conftest.py)
     ctx.apply_environment()
 
 

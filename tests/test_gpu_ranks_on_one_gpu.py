@@ -269,6 +269,7 @@ def _bench_rank(rank, world, port, out, scaling, exchange=None, broken_rccl=Fals
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = dict(os.environ, RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK='0', MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port),
                TORCHELASTIC_RUN_ID=f'benchtest{port}')
+    env.pop('DEMUXALOT_AMD_ESTEP', None)  # the bench runs the library's default mode, not the suite's pin (tests/conftest.py)
     if exchange:
         env['DEMUXALOT_AMD_EXCHANGE'] = exchange
     if broken_rccl:
@@ -306,6 +307,31 @@ def test_bench_with_two_ranks_on_one_gpu(scaling, exchange):
     assert line['n_gpus'] == 2 and line['scaling'] == scaling and line['value'] > 0
     assert line['config']['barcodes_total'] == (20_000 if scaling == 'strong' else 40_000)
     assert len(line['config']['runtimes']['hip']) == 1 and line['exchange_ms_per_step'] > 0
+
+
+def test_bench_starts_its_own_ranks():
+    """`python bench.py --gpus 2` with NO launcher and a scrubbed environment: the parent starts the two rank processes
+    itself (both on this box's one GPU, exchange staged over the plane), relays rank 0's one JSON line - the headline is
+    BASELINE.json configs[3] as written (one experiment, barcodes sharded: strong), the per-GPU workload rides along as
+    `weak` - and the experiment is generated once."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items()
+           if k not in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK', 'MASTER_ADDR', 'MASTER_PORT', 'TORCHELASTIC_RUN_ID', 'DEMUXALOT_AMD_ESTEP')}
+    done = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--gpus', '2', '--steps', '2', '--warmup', '1',
+                           '--workload', 'em_20k_10k_64', '--host-plane'], env=env, cwd=root, capture_output=True, text=True, timeout=900)
+    assert done.returncode == 0, done.stderr[-2000:]
+    lines = [ln for ln in done.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, done.stdout[-2000:]
+    line = json.loads(lines[0])
+    assert line['n_gpus'] == 2 and line['scaling'] == 'strong' and line['value'] > 0
+    assert line['config']['barcodes_total'] == 20_000 and line['config']['estep_mode'].startswith('guarded')
+    assert line['weak']['barcodes_total'] == 40_000 and line['weak']['value'] > 0
+    assert 'shared through' in line['setup_s']['problem_source'] and line['exchange_ms_per_step'] > 0
+    assert line['exact_mode']['value'] > 0
 
 
 def test_bench_falls_back_to_the_host_plane_without_rccl():
