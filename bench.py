@@ -582,7 +582,7 @@ def main():
                 estep_hbm_frac=algorithmic_bytes(B, V, G, K, N)['estep'] / (pe_ms * 1e-3) / 8e12)
         ctx.set_estep_dictionary('auto')
         predict['note'] = ('P-step + E-step on the table without beta addition (predict_posteriors, EM iteration 0); estep_ms includes '
-                           'building the dictionary; bit-identical to the reference in every E-step mode but `fast`')
+                           'building the dictionary; where the dictionary form runs the pass is bit-identical to the reference in every mode but `fast`')
 
     if rank == 0:
         ab = algorithmic_bytes(B, V, G, K, N)

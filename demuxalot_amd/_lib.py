@@ -72,6 +72,7 @@ SIGNATURES = {
     'dmx_comm_unique_id': (c_int, [_P]),
     'dmx_comm_init': (c_int, [_P, c_int, c_int, _P, c_int]),
     'dmx_comm_init_host': (c_int, [_P, c_int, c_int, _P, _P, c_int]),
+    'dmx_comm_init_emulated': (c_int, [_P, c_int, c_int, c_double, c_double, c_int]),
     'dmx_get_timings': (c_int, [_P, POINTER(c_double), POINTER(c_int64)]),
     'dmx_reset_timings': (c_int, [_P]),
     'dmx_device_bytes': (c_int, [_P, POINTER(c_int64)]),

@@ -678,10 +678,24 @@ int host_collective(dmx_ctx *c, int op, const void *src, size_t off_in, size_t b
     return 0;
 }
 
+// Emulated wire: a direct exchange on a fully connected node moves one block per peer link in either direction, all links
+// at once: latency + block bytes / link rate, whatever the number of ranks (the blocks shrink with it).
+int emulated_wire(dmx_ctx *c, size_t block_bytes, int rounds, hipStream_t st)
+{
+    if (c->nranks <= 1) return 0;
+    const double ns = rounds * (c->emu_latency_us * 1e3 + (double)block_bytes / c->emu_link_gbps);
+    HIP_TRY(dmx::launch_delay(st, (long long)(ns * c->emu_ticks_per_ns)));
+    return 0;
+}
+
 // recv[block] = sum over ranks of their send[rank * block ...]
 int coll_reduce_scatter(dmx_ctx *c, const void *send, void *recv, size_t block, bool f64, hipStream_t st)
 {
     const size_t elem = f64 ? 8 : 4;
+    if (c->emulated) {  // the other ranks "send zeros": this rank's own block is the sum
+        HIP_TRY(hipMemcpyAsync(recv, (const char *)send + (size_t)c->rank * block * elem, block * elem, hipMemcpyDeviceToDevice, st));
+        return emulated_wire(c, block * elem, 1, st);
+    }
     if (c->comm) {
         ncclResult_t r = g_rccl.ReduceScatter(send, recv, block, f64 ? ncclDouble : ncclFloat, ncclSum, c->comm, st);
         return r == ncclSuccess ? 0 : fail(DMX_ERR_RCCL, "ncclReduceScatter failed: %s", rccl_error(r));
@@ -694,6 +708,7 @@ int coll_reduce_scatter(dmx_ctx *c, const void *send, void *recv, size_t block, 
 // float32 table of nranks blocks, this rank's block filled: everybody's blocks on return
 int coll_all_gather(dmx_ctx *c, float *table, size_t block, const char *what)
 {
+    if (c->emulated) return emulated_wire(c, block * 4, 1, c->stream);  // the other slices keep what they hold
     if (c->comm) {
         ncclResult_t r = g_rccl.AllGather(table + c->rank * block, table, block, ncclFloat, c->comm, c->stream);
         return r == ncclSuccess ? 0 : fail(DMX_ERR_RCCL, "ncclAllGather (%s) failed: %s", what, rccl_error(r));
@@ -704,6 +719,7 @@ int coll_all_gather(dmx_ctx *c, float *table, size_t block, const char *what)
 
 int coll_all_reduce(dmx_ctx *c, void *buf, size_t count, bool f64)
 {
+    if (c->emulated) return emulated_wire(c, count * (f64 ? 8 : 4) / (size_t)std::max(1, c->nranks), 2, c->stream);  // = reduce-scatter + all-gather
     if (c->comm) {
         ncclResult_t r = g_rccl.AllReduce(buf, buf, count, f64 ? ncclDouble : ncclFloat, ncclSum, c->comm, c->stream);
         return r == ncclSuccess ? 0 : fail(DMX_ERR_RCCL, "ncclAllReduce failed: %s", rccl_error(r));
@@ -743,6 +759,7 @@ int layout_exchange(dmx_ctx *c)
         DMX_TRY(dev_alloc(c, &c->d_prob, (size_t)new_rows * G));
     }
     c->have_probs = false;
+    c->emu_table_filled = false;
     HIP_TRY(hipMemsetAsync(c->d_prob, 0, sizeof(float) * (size_t)(new_rows ? new_rows * G : 1), st));
     if (c->sliced) {
         std::vector<int> prow((size_t)V);
@@ -888,6 +905,15 @@ int run_pstep(dmx_ctx *c, float lo, float hi, bool with_addition)
     std::pair<hipEvent_t, hipEvent_t> ev;
     timer_begin(c, DMX_T_PSTEP, &ev);
     const long long v0 = c->sliced ? c->cut[c->rank] : 0, v1 = c->sliced ? c->cut[c->rank + 1] : c->V;
+    if (c->emulated && c->sliced && !c->emu_table_filled) {
+        // emulated wire: nobody fills the other ranks' slices of genotype_prob; they hold the table without addition, so
+        // that the E-step's rows are what an E-step sees (the posteriors decide which M-step kernel runs)
+        for (int r = 0; r < c->nranks; r++)
+            if (r != c->rank)
+                HIP_TRY(dmx::launch_probs_from_betas(c->stream, c->d_prior, nullptr, c->d_v2snp, c->d_snp_ptr, c->d_snp_vars, c->cut[r],
+                                                     c->cut[r + 1] - c->cut[r], -1LL, c->G, c->d_prow, lo, hi, c->d_prob));
+        c->emu_table_filled = true;
+    }
     HIP_TRY(dmx::launch_probs_from_betas(c->stream, c->d_prior, with_addition ? c->d_add : nullptr, c->d_v2snp,
                                          c->d_snp_ptr, c->d_snp_vars, v0, v1 - v0, c->sliced ? -1LL : (long long)c->S, c->G, c->d_prow, lo, hi,
                                          c->d_prob));
@@ -1908,6 +1934,7 @@ int dmx_comm_init(dmx_ctx *c, int rank, int nranks, const void *unique_id, int r
         c->comm = nullptr;
     }
     c->host_coll = nullptr;
+    c->emulated = false;
     ncclUniqueId id;
     std::memcpy(&id, unique_id, sizeof id);
     ncclResult_t r = g_rccl.CommInitRank(&c->comm, nranks, id, rank);
@@ -1934,7 +1961,32 @@ int dmx_comm_init_host(dmx_ctx *c, int rank, int nranks, dmx_host_collective col
         c->comm = nullptr;
     }
     c->host_coll = collective;
+    c->emulated = false;
     c->host_user = user;
+    c->rank = rank;
+    c->nranks = nranks;
+    c->reduce_dtype = reduce_dtype;
+    if (c->have_problem) DMX_TRY(layout_exchange(c));
+    return 0;
+}
+
+int dmx_comm_init_emulated(dmx_ctx *c, int rank, int nranks, double link_gbytes_per_s, double latency_us, int reduce_dtype)
+{
+    DMX_TRY(bind(c));
+    if (nranks < 1 || rank < 0 || rank >= nranks || !(link_gbytes_per_s > 0) || !(latency_us >= 0)) return fail(DMX_ERR_INVALID, "bad emulated communicator arguments");
+    if (reduce_dtype != DMX_F32 && reduce_dtype != DMX_F64) return fail(DMX_ERR_INVALID, "reduce_dtype must be DMX_F32 or DMX_F64");
+    if (c->comm) {
+        g_rccl.CommDestroy(c->comm);
+        c->comm = nullptr;
+    }
+    c->host_coll = nullptr;
+    int khz = 0;
+    HIP_TRY(hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, c->device));
+    if (khz <= 0) return fail(DMX_ERR_UNSUPPORTED, "the device reports no wall clock rate");
+    c->emu_ticks_per_ns = khz * 1e-6;
+    c->emulated = true;
+    c->emu_link_gbps = link_gbytes_per_s;
+    c->emu_latency_us = latency_us;
     c->rank = rank;
     c->nranks = nranks;
     c->reduce_dtype = reduce_dtype;

@@ -141,7 +141,14 @@ struct dmx_ctx {
     void *host_user = nullptr;
     void *h_stage = nullptr;                  // pinned staging of the host collectives
     size_t h_stage_bytes = 0;
-    bool attached() const { return comm != nullptr || host_coll != nullptr; }
+    // Emulated wire (dmx_comm_init_emulated): the collectives move nothing between processes - this rank's block is copied
+    // where the collective would leave it, then the stream waits for the modelled wire time.  For measuring what of the
+    // exchange a schedule leaves exposed on a box with one GPU; the results of such a run are not a real EM.
+    bool emulated = false;
+    double emu_link_gbps = 50.0, emu_latency_us = 10.0;
+    bool emu_table_filled = false;            // the other ranks' slices of genotype_prob hold the table without addition
+    double emu_ticks_per_ns = 0.1;            // wall-clock ticks of the delay kernel per nanosecond
+    bool attached() const { return comm != nullptr || host_coll != nullptr || emulated; }
     int rank = 0, nranks = 1, reduce_dtype = DMX_F64;
     bool sliced = false;            // reduce-scatter + sliced P-step + all-gather (else: all-reduce + replicated P-step)
     bool add_partial = false;       // only this rank's slice of d_add is current (sliced mode, after an M-step)

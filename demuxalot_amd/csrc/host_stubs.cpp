@@ -28,6 +28,11 @@ hipError_t hipGetDeviceCount(int *count)
     return hipSuccess;
 }
 hipError_t hipSetDevice(int) { return hipSuccess; }
+hipError_t hipDeviceGetAttribute(int *value, hipDeviceAttribute_t, int)
+{
+    *value = 100000;  // wall clock rate in kHz
+    return hipSuccess;
+}
 hipError_t hipDeviceSynchronize(void) { return hipSuccess; }
 hipError_t hipGetLastError(void) { return hipSuccess; }
 const char *hipGetErrorString(hipError_t e) { return e == hipSuccess ? "hipSuccess" : "hip error (host stub)"; }
@@ -146,6 +151,7 @@ hipError_t launch_remap_row_offsets(hipStream_t, CallPair *pairs, long long n_pa
 }
 hipError_t launch_f64_to_f32(hipStream_t, const double *, float *, long long) { return hipSuccess; }
 hipError_t launch_f32_to_f64(hipStream_t, const float *, double *, long long) { return hipSuccess; }
+hipError_t launch_delay(hipStream_t, long long) { return hipSuccess; }
 hipError_t launch_prior_betas(hipStream_t, const float *, float *, const unsigned long long *, const int *, const int *, const int *,
                               long long, int, double, float *) { return hipSuccess; }
 hipError_t launch_rebuild_nz(hipStream_t, const float *, long long, int, int, float, unsigned long long *, uint2 *) { return hipSuccess; }

@@ -1439,6 +1439,20 @@ __global__ __launch_bounds__(256) void k_remap_row_offsets(CallPair *__restrict_
     }
 }
 
+// Emulated wire: holds the stream for `ticks` of the constant-rate wall clock (one wavefront, asleep most of the time).
+__global__ __launch_bounds__(64) void k_delay(long long ticks)
+{
+    const long long t0 = wall_clock64();
+    while (wall_clock64() - t0 < ticks) __builtin_amdgcn_s_sleep(32);
+}
+
+hipError_t launch_delay(hipStream_t st, long long ticks)
+{
+    if (ticks <= 0) return hipSuccess;
+    hipLaunchKernelGGL(k_delay, dim3(1), dim3(64), 0, st, ticks);
+    return hipGetLastError();
+}
+
 __global__ __launch_bounds__(256) void k_f32_to_f64(const float *__restrict__ in, double *__restrict__ out, long long n)
 {
     const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;

@@ -12,9 +12,9 @@ from ._lib import DMX_F32, DMX_F64, as_c, check, ptr
 
 # E-step arithmetic of a new context (include/demux_hip.h: dmx_set_estep_mode); DEMUXALOT_AMD_ESTEP overrides.
 # 'guarded': the contract of the path - assignments identical to the reference, posteriors within 1e-5 - PROVEN per barcode and
-# E-step, every barcode that cannot be proven redone with the bit-exact kernel; E-steps on the importers' genotype tables
-# (predict_posteriors, EM iteration 0) take the dictionary form and stay bit-identical to the reference.  'exact': every
-# logit, posterior and beta addition bit-identical to the reference, at 1.6x the time per EM iteration.
+# E-step, every barcode that cannot be proven redone with the bit-exact kernel; E-steps that take the dictionary form (large
+# singlet runs on the importers' genotype tables: predict_posteriors, EM iteration 0) stay bit-identical to the reference.
+# 'exact': every logit, posterior and beta addition bit-identical to the reference, at 1.6x the time per EM iteration.
 DEFAULT_ESTEP_MODE = 'guarded'
 
 
@@ -393,6 +393,12 @@ class DeviceContext:
         self._host_collective = _lib.HOST_COLLECTIVE(trampoline)  # kept alive with the context
         check(self._lib.dmx_comm_init_host(self._h, int(rank), int(nranks), self._host_collective, None,
                                            DMX_F64 if reduce_dtype == 'f64' else DMX_F32))
+
+    def comm_init_emulated(self, rank, nranks, link_gbytes_per_s=50.0, latency_us=10.0, reduce_dtype='f64'):
+        """This context as rank `rank` of `nranks` over an EMULATED wire (include/demux_hip.h: dmx_comm_init_emulated): for
+        timing the exchange schedule on one GPU; the results of such a run are not an EM of any experiment."""
+        check(self._lib.dmx_comm_init_emulated(self._h, int(rank), int(nranks), float(link_gbytes_per_s), float(latency_us),
+                                               DMX_F64 if reduce_dtype == 'f64' else DMX_F32))
 
     def set_estep_mode(self, mode):
         """'exact' (logits / posteriors bit-identical to the reference), 'guarded' (tolerance-mode arithmetic, every

@@ -401,6 +401,15 @@ int dmx_comm_init(dmx_ctx *ctx, int rank, int nranks, const void *unique_id, int
 enum { DMX_COLL_ALL_REDUCE = 0, DMX_COLL_REDUCE_SCATTER = 1, DMX_COLL_ALL_GATHER = 2 };
 typedef int (*dmx_host_collective)(void *user, int op, void *buf, int64_t count, int dtype);
 int dmx_comm_init_host(dmx_ctx *ctx, int rank, int nranks, dmx_host_collective collective, void *user, int reduce_dtype);
+/* Emulated wire, for MEASURING what of the exchange a schedule leaves exposed on a box with one GPU: this context behaves
+ * as rank `rank` of `nranks` - variant slices, padded tables, sliced P-step, every kernel and copy of the real exchange -
+ * but the three collectives move nothing between processes: this rank's block is copied to where the collective would leave
+ * it, and the stream is then held by a one-wavefront kernel for the modelled wire time, latency_us + block bytes /
+ * link_gbytes_per_s per collective (a direct exchange on a fully connected xGMI node: one block per peer link and
+ * direction, all links at once).  The other ranks contribute nothing - their slices of genotype_prob keep the table
+ * without addition - so the numbers such a run produces are not an EM of any experiment; its TIMINGS are those of one
+ * rank of an nranks-GPU run whose wire behaves as modelled (scripts/emulated_scaling.py). */
+int dmx_comm_init_emulated(dmx_ctx *ctx, int rank, int nranks, double link_gbytes_per_s, double latency_us, int reduce_dtype);
 
 /* Accumulated kernel time per slot (ms, from HIP events on the ctx stream) and launch
  * counts since the last dmx_reset_timings. Arrays of DMX_T_COUNT entries. */

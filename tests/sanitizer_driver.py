@@ -134,7 +134,10 @@ def run_contexts(rng, rounds):
                 def collective(op, array):  # the other ranks "send zeros": nothing to add, nothing to fill
                     assert array.flags.writeable and array.size >= 0
                 ctx.set_exchange_chunks(int(rng.choice([0, 0, 2, 4, 16])))
-                ctx.comm_init_host(rank, world, collective, reduce_dtype=str(rng.choice(['f64', 'f32'])))
+                if rng.random() < 0.3:
+                    ctx.comm_init_emulated(rank, world, 50., 10., reduce_dtype=str(rng.choice(['f64', 'f32'])))
+                else:
+                    ctx.comm_init_host(rank, world, collective, reduce_dtype=str(rng.choice(['f64', 'f32'])))
             ctx.set_estep_mode(str(rng.choice(['exact', 'guarded', 'fast'])))
             ctx.set_estep_dictionary(str(rng.choice(['never', 'auto', 'always'])))
             ctx.set_problem(B, V, G, variant, cb, p, v2snp)
