@@ -435,6 +435,7 @@ void release_problem(dmx_ctx *c)
     dev_free(c, &c->d_item_start, (size_t)c->n_items);
     dev_free(c, &c->d_item_len, (size_t)c->n_items);
     dev_free(c, &c->d_item_ptr, (size_t)c->V + 1);
+    dev_free(c, &c->d_item_variant, (size_t)c->n_items);
     dev_free(c, &c->d_bc_order, (size_t)c->B);
     dev_free(c, &c->d_bin_rows, (size_t)c->n_bins * c->bin_rows_cap);
     dev_free(c, &c->d_bin_order, (size_t)c->n_bins);
@@ -485,6 +486,11 @@ void release_problem(dmx_ctx *c)
     dev_free(c, &c->d_first, (size_t)c->B);
     dev_free(c, &c->d_dense_calls, (size_t)1 + dmx::DENSE_SLOTS);
     c->dense_stat_valid = false;
+    dev_free(c, &c->d_segs, (size_t)c->n_segs);
+    dev_free(c, &c->d_split_first, (size_t)c->n_split + 1);
+    dev_free(c, &c->d_seg_sums, c->cap_seg_sums);
+    c->cap_seg_sums = 0;
+    c->n_segs = c->n_split = 0;
     dev_free(c, &c->d_guard_count, (size_t)2);
     dev_free(c, &c->d_guard_list, (size_t)c->B);
     c->guard_rows_total = 0;
@@ -533,6 +539,54 @@ void release_problem(dmx_ctx *c)
     c->n_items = 0;
 }
 
+// Split rows of the tolerance / guarded E-step (kernels.h: EstepArgs::segs).  A wavefront walks its barcode's calls as a
+// chain of memory latencies, so the longest row bounds a launch from below; rows with more CallPairs than half of what a
+// wavefront slot of the chip gets on average (and at least 128) are cut into equal segments of whole 8-call groups.
+// On the 200k-barcode bench workload nothing is cut (4 800 pairs per slot against rows of at most 2 000); on one rank's
+// share of it on 8 GPUs (25k barcodes, 600 pairs per slot) the rows beyond 600 calls are.
+int build_row_segments(dmx_ctx *c)
+{
+    c->n_segs = c->n_split = 0;
+    const long long B = c->B;
+    if (B == 0 || c->n_pairs == 0) return 0;
+    if (!c->n_simd) {
+        int cus = 0;
+        HIP_TRY(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, c->device));
+        c->n_simd = 4 * cus;
+    }
+    const long long slots = 8ll * std::max(1, c->n_simd);
+    long long cap = std::max<long long>(128, c->n_pairs / (2 * slots));
+    cap = (cap + 3) & ~3ll;
+    std::vector<long long> pair_ptr((size_t)B + 1);
+    std::vector<int> order((size_t)B);
+    HIP_TRY(hipMemcpyAsync(pair_ptr.data(), c->d_pair_ptr, sizeof(long long) * (B + 1), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipMemcpyAsync(order.data(), c->d_bc_order, sizeof(int) * B, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    std::vector<dmx::EstepSegment> segs;
+    std::vector<int> first(1, 0);
+    for (long long j = 0; j < B; j++) {  // `order` is sorted by decreasing length: the split rows are its first entries
+        const int b = order[(size_t)j];
+        const long long pairs = pair_ptr[(size_t)b + 1] - pair_ptr[(size_t)b];
+        if (pairs <= cap) break;
+        const long long pieces = (pairs + cap - 1) / cap;
+        const long long groups = pairs / 4, per = (groups + pieces - 1) / pieces;  // whole 8-call groups per segment
+        for (long long g0 = 0; g0 < groups; g0 += per)
+            segs.push_back({b, (int)(4 * g0), (int)(4 * std::min(per, groups - g0)), 0});
+        first.push_back((int)segs.size());
+    }
+    if (segs.empty()) return 0;
+    // (the segments of one barcode stay adjacent and in order - split_first indexes them - and are of nearly equal length;
+    // the barcodes come longest first, so the work list is roughly longest-first too)
+    c->n_segs = (long long)segs.size();
+    c->n_split = (long long)first.size() - 1;
+    DMX_TRY(dev_alloc(c, &c->d_segs, segs.size()));
+    DMX_TRY(dev_alloc(c, &c->d_split_first, first.size()));
+    HIP_TRY(hipMemcpyAsync(c->d_segs, segs.data(), sizeof(dmx::EstepSegment) * segs.size(), hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipMemcpyAsync(c->d_split_first, first.data(), sizeof(int) * first.size(), hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));  // locals
+    return 0;
+}
+
 int ensure_options(dmx_ctx *c, int with_doublets, const float *penalties)
 {
     const int G = c->G;
@@ -567,6 +621,12 @@ int ensure_options(dmx_ctx *c, int with_doublets, const float *penalties)
     HIP_TRY(hipMemcpyAsync(c->d_pairs, pairs.data(), sizeof(unsigned) * K, hipMemcpyHostToDevice, c->stream));
     HIP_TRY(hipMemcpyAsync(c->d_pen, penalties, sizeof(float) * K, hipMemcpyHostToDevice, c->stream));
     DMX_TRY(dmx::ensure_sum_plan(c, K));
+    if ((size_t)c->n_segs * (size_t)K > c->cap_seg_sums) {
+        dev_free(c, &c->d_seg_sums, c->cap_seg_sums);
+        c->cap_seg_sums = 0;
+        DMX_TRY(dev_alloc(c, &c->d_seg_sums, (size_t)c->n_segs * (size_t)K));
+        c->cap_seg_sums = (size_t)c->n_segs * (size_t)K;
+    }
     HIP_TRY(hipStreamSynchronize(c->stream));  // `pairs` is a local
     if ((int)K != c->K) c->have_post64 = false;  // the float64 results of dmx_estep_snp were laid out for another K
     c->K = (int)K;
@@ -1030,6 +1090,11 @@ int run_estep(dmx_ctx *c, int with_doublets, bool with_prior, int prior_dtype, f
     a.guard_count = c->d_guard_count;
     a.guard_list = c->d_guard_list;
     a.order_count = nullptr;
+    a.segs = c->n_segs > 0 && c->K <= 1024 ? c->d_segs : nullptr;
+    a.n_segs = c->n_segs;
+    a.n_split = c->n_split;
+    a.split_first = c->d_split_first;
+    a.seg_sums = c->d_seg_sums;
     c->guard_ran = false;
     a.tiled = c->tiled_estep;
     a.n_bins = c->tiled_estep ? c->n_bins : 0;
@@ -1180,23 +1245,40 @@ int run_mstep(dmx_ctx *c, float power)
     std::pair<hipEvent_t, hipEvent_t> ev;
     const bool dist = c->attached();  // also with one rank: keeps the collective path testable on one GPU
     unsigned long long *redo = c->exact_additions ? c->d_redo : nullptr;
+    a.item_variant = nullptr;
+    a.item_ptr = c->d_item_ptr;
+    a.prow = nullptr;
+    a.out32 = nullptr;
+    a.out64 = nullptr;
     if (dist && c->sliced && c->n_chunks > 1) return run_mstep_chunked(c, a, redo);
+    const bool f64 = c->reduce_dtype == DMX_F64;
+    // where k_mcombine writes: the variants of one work item are written there by the M-step kernels themselves
+    a.item_variant = c->d_item_variant;
+    if (!dist) {
+        a.out32 = c->d_add;
+    } else if (c->sliced) {
+        a.prow = c->d_prow;
+        if (f64) a.out64 = (double *)c->d_exch;
+        else a.out32 = (float *)c->d_exch;
+    } else {
+        if (f64) a.out64 = c->d_add64;
+        else a.out32 = c->d_add;
+    }
     timer_begin(c, DMX_T_MSTEP, &ev);
     HIP_TRY(dmx::launch_mstep(c->stream, a));
     timer_end(c, DMX_T_MSTEP, ev);
     if (!dist) {
         timer_begin(c, DMX_T_MCOMBINE, &ev);
-        HIP_TRY(dmx::launch_mcombine(c->stream, a, c->d_item_ptr, 0, c->V, nullptr, c->d_add, nullptr, redo, c->d_n_redo));
+        HIP_TRY(dmx::launch_mcombine(c->stream, a, c->d_item_ptr, 0, c->V, nullptr, c->d_add, nullptr, redo, c->d_n_redo, nullptr, true));
         timer_end(c, DMX_T_MCOMBINE, ev);
         return 0;
     }
-    const bool f64 = c->reduce_dtype == DMX_F64;
     int rc = 0;
     if (c->sliced) {
         // partial sums straight into the padded exchange buffer, reduce-scatter, this rank's slice rounded into d_add
         timer_begin(c, DMX_T_MCOMBINE, &ev);
         HIP_TRY(dmx::launch_mcombine(c->stream, a, c->d_item_ptr, 0, c->V, c->d_prow, f64 ? nullptr : (float *)c->d_exch,
-                                     f64 ? (double *)c->d_exch : nullptr, redo, c->d_n_redo));
+                                     f64 ? (double *)c->d_exch : nullptr, redo, c->d_n_redo, nullptr, true));
         timer_end(c, DMX_T_MCOMBINE, ev);
         timer_begin(c, DMX_T_ALLREDUCE, &ev);
         const size_t block = (size_t)c->slice_rows * c->G;
@@ -1211,7 +1293,7 @@ int run_mstep(dmx_ctx *c, float power)
     // SNPs with scattered variants: all-reduce of the dense sums, P-step on every rank
     timer_begin(c, DMX_T_MCOMBINE, &ev);
     HIP_TRY(dmx::launch_mcombine(c->stream, a, c->d_item_ptr, 0, c->V, nullptr, f64 ? nullptr : c->d_add, f64 ? c->d_add64 : nullptr, redo,
-                                 c->d_n_redo));
+                                 c->d_n_redo, nullptr, true));
     timer_end(c, DMX_T_MCOMBINE, ev);
     timer_begin(c, DMX_T_ALLREDUCE, &ev);
     const size_t cnt = (size_t)c->V * c->G;
@@ -1380,6 +1462,7 @@ static int finish_problem(dmx_ctx *c, const int32_t *v2snp, const std::vector<in
     if (B) HIP_TRY(hipMemsetAsync(c->d_nz, 0, sizeof(unsigned long long) * (size_t)B * ((G + 63) / 64), st));
     if (B) HIP_TRY(hipMemsetAsync(c->d_first, 0, sizeof(uint2) * (size_t)B, st));
     HIP_TRY(hipStreamSynchronize(st));  // host staging vectors die in the caller
+    DMX_TRY(build_row_segments(c));
     DMX_TRY(layout_exchange(c));        // genotype_prob table (padded when a communicator is attached)
     c->have_problem = true;
     return 0;

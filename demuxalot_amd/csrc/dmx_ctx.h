@@ -53,6 +53,7 @@ struct dmx_ctx {
     long long *d_item_start = nullptr;
     int *d_item_len = nullptr;
     long long *d_item_ptr = nullptr;
+    int *d_item_variant = nullptr;  // [n_items] variant of every work item (MstepArgs::item_variant)
     int *d_bc_order = nullptr, *d_item_order = nullptr;
     long long n_items = 0;
     // tile-major E-step schedule (repack_device.hip; n_bins == 0: not built)
@@ -100,6 +101,12 @@ struct dmx_ctx {
     unsigned char *d_dtab = nullptr;     // the packed table the kernel reads (estep_dict.hip: DictRow)
     unsigned *d_dict_stat = nullptr;     // [1]
     size_t cap_dict_rows = 0, cap_dtab = 0;
+    // split rows of the tolerance / guarded E-step (kernels.h: EstepArgs::segs; dmx_api.cpp: build_row_segments)
+    dmx::EstepSegment *d_segs = nullptr;
+    int *d_split_first = nullptr;
+    double *d_seg_sums = nullptr;
+    size_t cap_seg_sums = 0;
+    long long n_segs = 0, n_split = 0;
     float nz_floor = 0.0f;     // threshold the current d_nz / d_first were built with
     uint2 *d_first = nullptr;  // [B] {posterior of the lowest live singlet column, count | first live columns} (G <= 64): EstepArgs::first
     unsigned long long *d_dense_calls = nullptr;  // [1] E-step statistic read by the M-step kernels (kernels.h)

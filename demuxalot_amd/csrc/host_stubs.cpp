@@ -134,7 +134,7 @@ hipError_t launch_estep_dict(hipStream_t, const EstepArgs &, bool) { return hipS
 hipError_t launch_estep_dict_block(hipStream_t, const EstepArgs &) { return hipSuccess; }
 hipError_t launch_mstep(hipStream_t, const MstepArgs &) { return hipSuccess; }
 hipError_t launch_mcombine(hipStream_t, const MstepArgs &, const long long *, long long, long long, const int *, float *, double *,
-                           unsigned long long *, unsigned *, const int *) { return hipSuccess; }
+                           unsigned long long *, unsigned *, const int *, bool) { return hipSuccess; }
 hipError_t launch_store_slice(hipStream_t, const void *, bool, long long, long long, int, float *) { return hipSuccess; }
 bool estep_packed_shape(int, int, int *, int *) { return false; }
 hipError_t launch_estep_packed(hipStream_t, const EstepArgs &) { return hipSuccess; }
@@ -241,9 +241,11 @@ int repack_on_device(dmx_ctx *c, const int32_t *variant, const int32_t *cb, cons
     DMX_TRY(dev_alloc(c, &c->d_item_start, (size_t)c->n_items));
     DMX_TRY(dev_alloc(c, &c->d_item_len, (size_t)c->n_items));
     DMX_TRY(dev_alloc(c, &c->d_item_order, (size_t)c->n_items));
+    DMX_TRY(dev_alloc(c, &c->d_item_variant, (size_t)c->n_items));
     for (long long v = 0; v < V; v++) {
         long long it = item_ptr[(size_t)v];
         for (long long s = col_ptr[(size_t)v]; s < col_ptr[(size_t)v + 1]; s += c->item_calls, it++) {
+            c->d_item_variant[it] = (int)v;
             c->d_item_start[it] = s;
             c->d_item_len[it] = (int)std::min<long long>(c->item_calls, col_ptr[(size_t)v + 1] - s);
         }

@@ -21,6 +21,13 @@ struct alignas(32) CallPair {
 };
 static_assert(sizeof(CallPair) == 32, "CallPair layout");
 
+struct EstepSegment {
+    int barcode;     // row
+    int first_pair;  // first CallPair of the segment inside the row (a multiple of 4: whole 8-call groups)
+    int n_pairs;
+    int pad;
+};
+
 struct EstepArgs {
     const long long *pair_ptr;  // [B+1] offsets into `pairs` (barcode-major, rows padded to 4 pairs)
     const int *order;           // [B] barcodes by decreasing row length (work distribution)
@@ -55,6 +62,17 @@ struct EstepArgs {
     int *guard_list;            // [B] the queued barcodes
     const unsigned *order_count;  // nullable: `order` holds *order_count entries (<= B), known on the device only (the exact
                                   // redo of the queued barcodes: k_estep_direct over guard_list)
+    // Split rows (tolerance / guarded mode, 64-lane form; dmx_api.cpp: build_row_segments): a launch cannot end before its
+    // longest barcode does, and a barcode's walk is a chain of memory latencies (~0.7 us per 8 calls) - 0.35 ms for a
+    // 4 000-call row, which is the whole E-step of a 25k-barcode shard.  The n_split longest barcodes (the first entries
+    // of `order`) are therefore cut into segments walked by separate wavefronts; k_estep_join adds a barcode's
+    // segment sums in order and runs the epilogue.  Any fixed association of the float64 sum is inside the guard's bound;
+    // the exact kernels never split (their order is the reference's).
+    const EstepSegment *segs;     // nullable [n_segs] segments of the split barcodes, longest first
+    long long n_segs;
+    long long n_split;            // barcodes cut into segments: order[0 .. n_split)
+    const int *split_first;       // [n_split + 1] first segment of every split barcode
+    double *seg_sums;             // [n_segs, K] float64 sums of the segments, in log2 units
     // tile-major schedule (k_estep_tiled); n_bins == 0: not built for this problem
     int tiled;                  // dmx_set_estep_schedule: 0 never, 1 when it pays (tolerance mode), 2 whenever built
     long long n_bins;
@@ -104,6 +122,15 @@ struct MstepArgs {
     unsigned long long first_bytes; // 8 B
     const uint2 *first;             // [B] bitmap + posterior of the lowest non-zero singlet column (G <= 64), as the E-step wrote them
     double *partial;                // [n_items, G]
+    // Variants of ONE work item (all but the hottest few hundred) need no combining pass: the item's wavefront rounds its
+    // sums straight into the output table (out32 / out64: what k_mcombine would write; row prow[v] or v), and k_mcombine
+    // only visits the variants of several items and those without calls.  item_variant == nullptr: every item leaves
+    // its partial sums (the chunked exchange, whose output rows differ per chunk).
+    const int *item_variant;        // nullable [n_items] variant of every item
+    const long long *item_ptr;      // [V + 1] first item of every variant
+    const int *prow;                // nullable [V] row of every variant in the output table
+    float *out32;                   // exactly one of the two (or none: item_variant == nullptr)
+    double *out64;
     long long n_items;
     long long K;
     unsigned long long post_bytes;  // B * K * 4
@@ -162,9 +189,10 @@ hipError_t launch_mstep(hipStream_t st, const MstepArgs &a);
 // rounding could depend on the order (redo: queue of capacity (n_items / 2 + 1) * G entries, n_redo: its counter)
 // prow (nullable): row of every variant in the output tables (padded multi-GPU exchange buffer)
 // vlist (nullable): the variants are entries [v0, v1) of this list instead of v0 .. v1 - 1 (chunks of the pipelined exchange)
+// skip_single: the variants of one item were written by the M-step kernels themselves (MstepArgs::item_variant)
 hipError_t launch_mcombine(hipStream_t st, const MstepArgs &a, const long long *item_ptr, long long v0, long long v1,
                            const int *prow, float *add32, double *add64, unsigned long long *redo, unsigned *n_redo,
-                           const int *vlist = nullptr);
+                           const int *vlist = nullptr, bool skip_single = false);
 hipError_t launch_store_slice(hipStream_t st, const void *slice, bool f64, long long v_begin, long long n_rows, int G, float *add);
 // call_rows (nullable): the compact row array of the same records, rewritten as well
 // estep_packed.hip: exact E-step of narrow doublet tables, several option slots per lane (K = 36: 8 lanes x 5 slots)

@@ -336,16 +336,38 @@ __global__ __launch_bounds__(256) void k_estep_direct(EstepArgs a)
     int row_calls = 0;  // calls of this lane group's barcode (incl. padding)
     // rows of `order` to walk: all B, or as many as the guarded E-step queued (known on the device only)
     const long long n_rows = a.order_count ? (long long)min((unsigned long long)*a.order_count, (unsigned long long)a.B) : a.B;
+    long long seg_of_wave = -1;  // split rows (FAST, 64 lanes): the segment this wavefront walks
     if constexpr (L == 64) {
         // ---- wave-uniform path: everything about the row lives in SGPRs ----
         const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-        const long long slot = (long long)blockIdx.x * 4 + wave;
-        if (slot >= n_rows) return;
+        long long slot = (long long)blockIdx.x * 4 + wave;
         live = true;
-        b = a.order[slot];
-        const long long pbeg = a.pair_ptr[b];
-        const int npairs = (int)(a.pair_ptr[b + 1] - pbeg);
+        long long pbeg;
+        int npairs;
+        long long seg = -1;  // >= 0: this wavefront walks one segment of a split barcode and leaves its sums
+        if (FAST && a.segs != nullptr) {
+            // work list: the segments of the n_split longest barcodes, then the other barcodes whole
+            if (slot < a.n_segs) {
+                seg = slot;
+                const EstepSegment sg = a.segs[slot];
+                b = sg.barcode;
+                pbeg = a.pair_ptr[b] + sg.first_pair;
+                npairs = sg.n_pairs;
+            } else {
+                slot = slot - a.n_segs + a.n_split;
+                if (slot >= n_rows) return;
+                b = a.order[slot];
+                pbeg = a.pair_ptr[b];
+                npairs = (int)(a.pair_ptr[b + 1] - pbeg);
+            }
+        } else {
+            if (slot >= n_rows) return;
+            b = a.order[slot];
+            pbeg = a.pair_ptr[b];
+            npairs = (int)(a.pair_ptr[b + 1] - pbeg);
+        }
         row_calls = 2 * npairs;
+        seg_of_wave = seg;
         const CallPair *__restrict__ recs = a.pairs + pbeg;
         // buffer addressing: descriptor base = prob table, voffset = this lane's genotype (VGPR, fixed),
         // soffset = the call's row offset straight from the scalar load -> no VALU work per load
@@ -431,12 +453,48 @@ __global__ __launch_bounds__(256) void k_estep_direct(EstepArgs a)
         }
     }
     if constexpr (FAST) {
+        if constexpr (L == 64) {
+            if (seg_of_wave >= 0) {  // a segment of a split barcode: its sums, for k_estep_join
+#pragma unroll
+                for (int s = 0; s < A; s++)
+                    if (valid[s]) a.seg_sums[(size_t)seg_of_wave * K + kk[s]] = facc[s].mant + (double)facc[s].expo;
+                return;
+            }
+        }
         const double LN2 = 0.693147180559945309417232121458176568;
 #pragma unroll
         for (int s = 0; s < A; s++) acc[s] = (facc[s].mant + (double)facc[s].expo) * LN2;
     }
 
     estep_epilogue<L, A, FAST>(a, b, live, acc, kk, valid, lane, li, gbase, row_calls);
+}
+
+// Tolerance / guarded mode, split rows: one wavefront per split barcode adds the sums its segments left (in segment
+// order: a fixed association) and runs the epilogue of the lane-per-option forms.
+template <int A>
+__global__ __launch_bounds__(256) void k_estep_join(EstepArgs a)
+{
+    const int lane = threadIdx.x & 63;
+    const long long j = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (j >= a.n_split) return;
+    const long long b = a.order[j];
+    const int K = a.K;
+    int kk[A];
+    bool valid[A];
+    double acc[A];
+#pragma unroll
+    for (int s = 0; s < A; s++) {
+        const int k = lane + 64 * s;
+        valid[s] = k < K;
+        kk[s] = valid[s] ? k : K - 1;
+        acc[s] = 0.0;
+    }
+    for (int sg = a.split_first[j]; sg < a.split_first[j + 1]; sg++)
+#pragma unroll
+        for (int s = 0; s < A; s++) acc[s] += a.seg_sums[(size_t)sg * K + kk[s]];
+#pragma unroll
+    for (int s = 0; s < A; s++) acc[s] *= 0.693147180559945309417232121458176568;
+    estep_epilogue<64, A, true>(a, b, true, acc, kk, valid, lane, lane, 0, 2 * (int)(a.pair_ptr[b + 1] - a.pair_ptr[b]));
 }
 
 // ------------------------------------------------------------------------------------
@@ -784,6 +842,22 @@ static __device__ __forceinline__ void mstep_terms(const npm::f32x2 (&p)[H][A], 
     }
 }
 
+// Where the sums of work item `item` go: straight into the output table when its variant has no other item (the value
+// k_mcombine would form is 0.0 + acc = acc), else into the item's partial row.
+static __device__ __forceinline__ void mstep_store(const MstepArgs &a, long long item, int g, double acc)
+{
+    if (a.item_variant != nullptr) {
+        const long long v = a.item_variant[item];
+        if (a.item_ptr[v + 1] - a.item_ptr[v] == 1) {
+            const size_t o = (size_t)(a.prow ? (long long)a.prow[v] : v) * a.G + g;
+            if (a.out32) a.out32[o] = (float)acc;
+            else a.out64[o] = acc;
+            return;
+        }
+    }
+    a.partial[(size_t)item * a.G + g] = acc;
+}
+
 template <int A, int U, bool SQUARE, bool SMALL>
 __global__ __launch_bounds__(256) void k_mstep(MstepArgs a)
 {
@@ -866,7 +940,7 @@ __global__ __launch_bounds__(256) void k_mstep(MstepArgs a)
 #pragma unroll
     for (int s = 0; s < A; s++) {
         const int g = lane + 64 * s;
-        if (g < G) a.partial[(size_t)item * G + g] = acc[s];
+        if (g < G) mstep_store(a, item, g, acc[s]);
     }
 }
 
@@ -969,7 +1043,7 @@ __global__ __launch_bounds__(256) void k_mstep_dense(MstepArgs a)
         }
         d_cur = d_nxt;
     }
-    if (lane < a.G) a.partial[(size_t)item * a.G + lane] = acc;
+    if (lane < a.G) mstep_store(a, item, lane, acc);
 }
 
 // BUF: the three per-lane loads of the call-parallel part (records, barcode code, extra posteriors) as raw buffer
@@ -1248,7 +1322,7 @@ __global__ __launch_bounds__(256) void k_mstep_calls(MstepArgs a)
 #pragma unroll
         for (int t = 0; t < NZ_S; t++) ps0[t] = ps1[t];
     }
-    if (lane < G) a.partial[(size_t)item * G + lane] = acc;
+    if (lane < G) mstep_store(a, item, lane, acc);
 }
 
 // one wavefront per (barcode, 64 genotypes): the bitmap and first-posterior table as the E-step writes them
@@ -1287,7 +1361,7 @@ __global__ __launch_bounds__(256) void k_mcombine(const double *__restrict__ par
                                                   const int *__restrict__ item_len, long long v0, long long v1, int G,
                                                   const int *__restrict__ prow, float *__restrict__ add32,
                                                   double *__restrict__ add64, unsigned long long *__restrict__ redo,
-                                                  unsigned *__restrict__ n_redo, const int *__restrict__ vlist)
+                                                  unsigned *__restrict__ n_redo, const int *__restrict__ vlist, bool skip_single)
 {
     const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= (v1 - v0) * G) return;
@@ -1302,6 +1376,7 @@ __global__ __launch_bounds__(256) void k_mcombine(const double *__restrict__ par
     }
     const long long v = vlist ? (long long)vlist[v0 + row] : v0 + row;  // vlist: entries [v0, v1) of a list of variants
     const long long it0 = item_ptr[v], it1 = item_ptr[v + 1];
+    if (skip_single && it1 - it0 == 1) return;  // written by the item's own wavefront (mstep_store)
     double s = 0.0;
     for (long long it = it0; it < it1; it++) s += partial[(size_t)it * G + g];
     const long long o = (prow ? (long long)prow[v] : v) * G + g;  // prow: padded rows of the multi-GPU exchange buffer
@@ -1599,14 +1674,20 @@ hipError_t launch_check_unit_range(hipStream_t st, const float *x, long long n, 
 }
 
 template <int L, int A, int U>
-static void launch_direct(hipStream_t st, const EstepArgs &a, bool pairs)
+static void launch_direct(hipStream_t st, const EstepArgs &a_in, bool pairs)
 {
-    const dim3 grid(blocks_for(a.B, 4 * (64 / L))), block(256);
+    EstepArgs a = a_in;
+    const bool split = L == 64 && a.fast && a.segs != nullptr && a.n_segs > 0 && a.order_count == nullptr;
+    if (!split) a.segs = nullptr;
+    const dim3 grid(blocks_for(split ? a.n_segs + (a.B - a.n_split) : a.B, 4 * (64 / L))), block(256);
     if (a.fast) {
         if (pairs)
             hipLaunchKernelGGL((k_estep_direct<L, A, true, U, true>), grid, block, 0, st, a);
         else
             hipLaunchKernelGGL((k_estep_direct<L, A, false, U, true>), grid, block, 0, st, a);
+        if constexpr (L == 64) {
+            if (split) hipLaunchKernelGGL((k_estep_join<A>), dim3(blocks_for(a.n_split, 4)), block, 0, st, a);
+        }
     } else {
         if (pairs)
             hipLaunchKernelGGL((k_estep_direct<L, A, true, U, false>), grid, block, 0, st, a);
@@ -1768,7 +1849,8 @@ hipError_t launch_mstep(hipStream_t st, const MstepArgs &a)
 }
 
 hipError_t launch_mcombine(hipStream_t st, const MstepArgs &a, const long long *item_ptr, long long v0, long long v1,
-                           const int *prow, float *add32, double *add64, unsigned long long *redo, unsigned *n_redo, const int *vlist)
+                           const int *prow, float *add32, double *add64, unsigned long long *redo, unsigned *n_redo, const int *vlist,
+                           bool skip_single)
 {
     if ((v1 - v0) * a.G <= 0) return hipSuccess;
     if (redo) {
@@ -1776,7 +1858,7 @@ hipError_t launch_mcombine(hipStream_t st, const MstepArgs &a, const long long *
         if (e != hipSuccess) return e;
     }
     hipLaunchKernelGGL(k_mcombine, dim3(blocks_for((v1 - v0) * a.G, 256)), dim3(256), 0, st, a.partial, item_ptr,
-                       a.item_start, a.item_len, v0, v1, a.G, prow, add32, add64, redo, n_redo, vlist);
+                       a.item_start, a.item_len, v0, v1, a.G, prow, add32, add64, redo, n_redo, vlist, skip_single);
     if (!redo) return hipGetLastError();
     // exact mode: the sums that must be redone in the reference's order (see k_mcombine)
     const dim3 grid(512), block(64 * EXACT_WAVES);

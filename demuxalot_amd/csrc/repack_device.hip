@@ -146,7 +146,7 @@ __global__ __launch_bounds__(256) void k_build_csc(const unsigned *__restrict__ 
 __global__ __launch_bounds__(256) void k_build_items(const long long *__restrict__ col_ptr,
                                                      const long long *__restrict__ item_ptr, long long V,
                                                      int item_calls, long long *__restrict__ item_start, int *__restrict__ item_len,
-                                                     unsigned *__restrict__ inv_len, unsigned *__restrict__ ids)
+                                                     unsigned *__restrict__ inv_len, unsigned *__restrict__ ids, int *__restrict__ item_variant)
 {
     const long long v = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (v >= V) return;
@@ -155,6 +155,7 @@ __global__ __launch_bounds__(256) void k_build_items(const long long *__restrict
         const long long len = (col_ptr[v + 1] - s) < item_calls ? (col_ptr[v + 1] - s) : item_calls;
         item_start[it] = s;
         item_len[it] = (int)len;
+        item_variant[it] = (int)v;
         inv_len[it] = ~(unsigned)len;  // ascending sort = longest first
         ids[it] = (unsigned)it;
     }
@@ -509,13 +510,14 @@ static int repack_core(dmx_ctx *c, Scratch &sc, const int *d_variant, const int 
     DMX_TRY(dev_alloc(c, &c->d_item_start, (size_t)n_items));
     DMX_TRY(dev_alloc(c, &c->d_item_len, (size_t)n_items));
     DMX_TRY(dev_alloc(c, &c->d_item_order, (size_t)n_items));
+    DMX_TRY(dev_alloc(c, &c->d_item_variant, (size_t)n_items));
     unsigned *inv_i = nullptr, *ids_i = nullptr, *keys_out = nullptr;
     DMX_TRY(sc.get(&inv_i, (size_t)n_items));
     DMX_TRY(sc.get(&ids_i, (size_t)n_items));
     DMX_TRY(sc.get(&keys_out, (size_t)n_items));
     if (V)
         hipLaunchKernelGGL(k_build_items, dim3(grid_for(V)), dim3(256), 0, st, col_ptr, c->d_item_ptr, V, c->item_calls,
-                           c->d_item_start, c->d_item_len, inv_i, ids_i);
+                           c->d_item_start, c->d_item_len, inv_i, ids_i, c->d_item_variant);
     DMX_TRY(sort_pairs(sc, inv_i, keys_out, ids_i, (unsigned *)c->d_item_order, (size_t)n_items, 32, st));
 
     HIP_TRY(hipGetLastError());

@@ -127,6 +127,29 @@ def test_guarded_mode_every_kernel_shape_against_the_exact_mode_and_the_oracle(o
     print(f'G={G} dp={dp}: {redone} of {B} barcodes redone exactly, {int(same.sum())} rows bit-identical')
 
 
+@pytest.mark.parametrize('G,dp', [(64, 0.), (40, 0.), (100, 0.), (200, 0.), (8, 0.35), (20, 0.2), (32, 0.)])
+def test_guarded_mode_with_split_rows(oracle, G, dp):
+    """Few barcodes with long rows: the 64-lane tolerance kernels cut rows beyond 256 calls into segments walked by separate
+    wavefronts (csrc/dmx_api.cpp: build_row_segments, k_estep_join adds the segment sums in a fixed order).  Same
+    contract against the exact mode on every barcode; the same bits run after run."""
+    from demuxalot_amd import synth
+    B = 300
+    p = synth.generate(n_barcodes=B, n_snps=3000, n_genotypes=G, calls_per_barcode=700, doublets=dp > 0, seed=50 + G)
+    assert np.bincount(p.compressed_cb).max() > 600  # rows beyond 256 calls are cut here (128 CallPairs: the floor of the segment length)
+    prob = oracle.probs_from_betas(p.v2snp, p.prior_betas(), 0.01)
+    out = _estep_in_modes(prob, p, dp, modes=('exact', 'guarded', 'fast'))
+    again = _estep_in_modes(prob, p, dp, modes=('guarded',))
+    fio.assert_bitwise(again['guarded'][0], out['guarded'][0], 'guarded logits, second run')
+    fio.assert_bitwise(again['guarded'][1], out['guarded'][1], 'guarded posteriors, second run')
+    check_contract(out['guarded'][1], out['exact'][1], f'split rows, G={G} dp={dp}')
+    redone = out['guarded'][2][0]
+    same = (out['guarded'][0].view(np.uint32) == out['exact'][0].view(np.uint32)).all(axis=1)
+    assert same.sum() >= redone
+    # the unguarded tolerance mode runs the same split walk: its logits are the guarded ones wherever nothing was redone
+    differs = (out['fast'][0].view(np.uint32) != out['guarded'][0].view(np.uint32)).any(axis=1)
+    assert differs.sum() <= redone
+
+
 def test_ambiguous_barcodes_are_redone_exactly(oracle):
     """Genotypes in identical pairs: the best two logits of every barcode tie, nothing can be proven about the argmax,
     so every barcode must come back with the exact mode's bits; with half of the genotypes duplicated, many do."""
