@@ -1084,7 +1084,10 @@ int run_estep(dmx_ctx *c, int with_doublets, bool with_prior, int prior_dtype, f
     a.K = c->K;
     // Guarded mode: the tolerance-mode kernels wherever a lane-per-option one exists (estep_epilogue.h: estep_guard), the
     // exact mode for the workgroup-per-barcode shapes
-    const bool guarded = c->estep_mode == DMX_ESTEP_GUARDED && c->K <= 1024 && !(with_doublets && c->K > 256);
+    // (the workgroup-per-barcode forms - option tables beyond 1024, doublet tables beyond 256 - evaluate the guard in
+    // k_softmax_rows from the logits alone, which does not cover prior logits: with a prior they run the exact mode)
+    const bool block_shape = c->K > 1024 || (with_doublets && c->K > 256);
+    const bool guarded = c->estep_mode == DMX_ESTEP_GUARDED && !(block_shape && with_prior);
     a.fast = c->estep_mode == DMX_ESTEP_FAST || guarded;
     a.guard = 0;
     a.guard_count = c->d_guard_count;

@@ -640,6 +640,7 @@ __global__ __launch_bounds__(256) void k_estep_block(EstepArgs a, int C, int k_b
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (a.order_count != nullptr && blockIdx.x >= *a.order_count) return;  // the exact redo of a guarded E-step: the queued barcodes only
     const long long b = a.order[blockIdx.x];
     const int K = a.K, G = a.G;
     const int CS = C + 2;
@@ -748,8 +749,11 @@ __global__ __launch_bounds__(256) void k_softmax_rows(EstepArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) float sh_row[];
     __shared__ float sh_red[8];
+    __shared__ float sh_guard[12];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const long long b = blockIdx.x;
+    // rows: all B, or the barcodes the guarded pass queued (their number is known on the device only)
+    if (a.order_count != nullptr && blockIdx.x >= *a.order_count) return;
+    const long long b = a.order_count != nullptr ? (long long)a.order[blockIdx.x] : (long long)blockIdx.x;
     const int K = a.K, G = a.G;
     const float *__restrict__ lg = a.logits + (size_t)b * K;
     float *post = a.post + (size_t)b * K;
@@ -789,6 +793,48 @@ __global__ __launch_bounds__(256) void k_softmax_rows(EstepArgs a)
     __syncthreads();
     const float tot = sh_red[4];
     const int W = (G + 63) >> 6;
+    // Guarded mode after the tolerance-mode option tiles (estep_epilogue.h: estep_guard, same bound): the sums themselves
+    // are gone, |S_k| <= |logit_k| + |pen_k| stands in (no prior logits in this mode: run_estep).
+    bool redo = false;
+    if (a.guard) {
+        const float n = (float)(2 * (a.pair_ptr[b + 1] - a.pair_ptr[b]));
+        float dmax = 0.0f;
+        bool bad = false;
+        for (int k = tid; k < K; k += 256) {
+            const float l = lg[k];
+            const float d = GUARD_RHO * (fabsf(l) + fabsf(a.pen[k]) + GUARD_POSITIVE_TERM * n) + GUARD_PER_CALL * (n + 8.0f) + GUARD_LOGIT_ROUNDING * fabsf(l);
+            bad |= !(d < 0.25f);
+            dmax = fmaxf(dmax, d);
+        }
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) dmax = fmaxf(dmax, __shfl_xor(dmax, off));
+        if (lane == 0) sh_guard[wave] = dmax;
+        __syncthreads();
+        dmax = fmaxf(fmaxf(sh_guard[0], sh_guard[1]), fmaxf(sh_guard[2], sh_guard[3]));
+        const float x2 = 2.0f * dmax;
+        const float e2 = x2 * (1.0f + x2) * 1.000001f;
+        const float near = mx - (x2 + 2.4e-7f * fabsf(mx)) * 1.000001f;
+        int close = 0;
+        for (int k = tid; k < K; k += 256) {
+            const float p = x[k] / tot;
+            bad |= !(fminf(p, 1.0f - p) * e2 <= GUARD_TOL);
+            close += !(lg[k] < near) ? 1 : 0;
+        }
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) close += __shfl_xor(close, off);
+        const bool any_bad = __ballot(bad) != 0ull;
+        if (lane == 0) {
+            sh_guard[4 + wave] = (float)close;
+            sh_guard[8 + wave] = any_bad ? 1.0f : 0.0f;
+        }
+        __syncthreads();
+        const float total_close = sh_guard[4] + sh_guard[5] + sh_guard[6] + sh_guard[7];
+        redo = total_close != 1.0f || (sh_guard[8] + sh_guard[9] + sh_guard[10] + sh_guard[11]) != 0.0f;
+        if (redo && tid == 0) {
+            a.guard_list[atomicAdd(a.guard_count, 1u)] = (int)b;
+            atomicAdd(a.guard_count + 1, 1u);
+        }
+    }
     for (int k0 = 0; k0 < K; k0 += 256) {  // uniform trip count: the ballots below need whole waves
         const int k = k0 + tid;
         float p = 0.0f;
@@ -802,7 +848,7 @@ __global__ __launch_bounds__(256) void k_softmax_rows(EstepArgs a)
             if (lane == 0 && word < W) a.nz[(size_t)b * W + word] = bal;
             if (a.first && word == 0 && lane == (bal ? __builtin_ctzll(bal) : 0)) {
                 a.first[b] = nz_code(bal, p);
-                if (a.dense_calls && __popcll(bal) > 4)
+                if (a.dense_calls && !redo && __popcll(bal) > 4)
                     atomicAdd(a.dense_calls + 1 + (b & (DENSE_SLOTS - 1)), (unsigned long long)(2 * (a.pair_ptr[b + 1] - a.pair_ptr[b])));
             }
         }

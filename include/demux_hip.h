@@ -181,8 +181,8 @@ int dmx_get_redo_count(dmx_ctx *ctx, int64_t *count);
  *       no second logit lies within 2 D of the largest (=> the same argmax);
  *   every other barcode is queued on the device and redone by the exact kernel in the same E-step, so its logits and
  *   posteriors are the reference's bit for bit.  Where the dictionary form applies (exact and faster) it is used
- *   unchanged.  dmx_get_guard_stats counts the barcodes redone.  Shapes without a guarded kernel (option tables beyond
- *   1024, doublet tables beyond 256 in this mode) run the exact mode. */
+ *   unchanged.  dmx_get_guard_stats counts the barcodes redone.  The workgroup-per-barcode forms (option tables beyond
+ *   1024, doublet tables beyond 256) bound |S_k| by |logit_k| + |penalty_k|; with prior logits they run the exact mode. */
 #define DMX_ESTEP_EXACT 0
 #define DMX_ESTEP_FAST 1
 #define DMX_ESTEP_GUARDED 2

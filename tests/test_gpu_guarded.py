@@ -104,7 +104,7 @@ def _estep_in_modes(table, problem, dp, modes=('exact', 'guarded'), prior=None):
 @pytest.mark.parametrize('G,dp', [(2, 0.), (3, 0.3), (8, 0.35), (16, 0.), (20, 0.25), (32, 0.), (33, 0.), (64, 0.), (64, 0.1),
                                   (100, 0.), (128, 0.), (200, 0.), (22, 0.3), (24, 0.3), (32, 0.25), (45, 0.1), (130, 0.05), (300, 0.), (600, 0.)])
 def test_guarded_mode_every_kernel_shape_against_the_exact_mode_and_the_oracle(oracle, G, dp):
-    """All lane-group widths and slot counts (and the shapes that fall back to the exact mode): posteriors within the
+    """All lane-group widths and slot counts, and the workgroup-per-barcode forms (K > 1024, doublet tables > 256): posteriors within the
     contract of the exact mode's = the oracle's, argmax identical, on EVERY barcode; the barcodes the guard queued carry
     the exact mode's bits."""
     from demuxalot_amd import synth
@@ -117,13 +117,9 @@ def test_guarded_mode_every_kernel_shape_against_the_exact_mode_and_the_oracle(o
     fio.assert_bitwise(exact_logits, want, 'exact mode vs oracle')
     logits, probs, (redone, total, rows), _ = out['guarded']
     check_contract(probs, exact_probs, f'G={G} dp={dp}')
-    K = exact_logits.shape[1]
-    guarded_shape = K <= 1024 and not (dp > 0 and K > 256)
-    assert rows == (B if guarded_shape else 0) and redone == total
+    assert rows == B and redone == total  # every shape has a guarded kernel (lane-per-option forms and workgroup-per-barcode forms)
     same = (logits.view(np.uint32) == exact_logits.view(np.uint32)).all(axis=1) & (probs.view(np.uint32) == exact_probs.view(np.uint32)).all(axis=1)
     assert same.sum() >= redone  # every queued barcode was rewritten by the exact kernel
-    if not guarded_shape:
-        assert same.all()
     print(f'G={G} dp={dp}: {redone} of {B} barcodes redone exactly, {int(same.sum())} rows bit-identical')
 
 
@@ -192,6 +188,13 @@ def test_guarded_mode_with_prior_logits_and_degenerate_calls(oracle):
     out = _estep_in_modes(prob, p, 0.)
     check_contract(out['guarded'][1], out['exact'][1], 'degenerate calls')
     assert np.array_equal(out['guarded'][1][7], np.full(G, 1 / G, dtype=np.float32))  # the empty barcode: ties -> exact redo
+    # workgroup-per-barcode form (K = 300 doublet options) with prior logits: no guard for that combination, the exact mode runs
+    p24 = synth.generate(n_barcodes=100, n_snps=200, n_genotypes=24, calls_per_barcode=40, doublets=True, seed=10)
+    prob24 = oracle.probs_from_betas(p24.v2snp, p24.prior_betas(), 0.01)
+    prior24 = (rng.normal(size=(100, 300)) * 3).astype(np.float32)
+    out = _estep_in_modes(prob24, p24, 0.3, prior=prior24)
+    fio.assert_bitwise(out['guarded'][0], out['exact'][0], 'block form with prior logits: exact')
+    assert out['guarded'][2][2] == 0
 
 
 def test_guarded_em_follows_the_exact_em(oracle):
