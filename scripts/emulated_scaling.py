@@ -50,20 +50,21 @@ def main():
     ap.add_argument('--modes', default='guarded')
     ap.add_argument('--kinds', default='strong,weak')
     ap.add_argument('--chunks', type=int, default=0, help='dmx_set_exchange_chunks (0: plain exchange)')
+    ap.add_argument('--workload', default='em_200k_100k_64', help='a workload of bench.py; with --kinds weak the whole workload is one rank\'s '
+                    'share (em_130k_650k_128_doublets = one rank of BASELINE.json configs[4] on 8 GPUs)')
     args = ap.parse_args()
-    B, S, G = 200_000, 100_000, 64
-    whole = synth.generate(B, S, G, seed=1237)
+    import bench
+    B, S, G, dp, seed = bench.WORKLOADS[args.workload]
+    whole = synth.generate(B, S, G, doublets=dp > 0, seed=seed)
     betas = whole.prior_betas(add_data_prior=False)
-    pen = Demultiplexer._doublet_penalties(G, 0.)
+    pen = Demultiplexer._doublet_penalties(G, dp)
     counts = np.bincount(whole.compressed_cb, minlength=B)
-    out = {'workload': 'em_200k_100k_64', 'link_gbytes_per_s': args.link_gbps, 'latency_us': args.latency_us, 'steps': args.steps,
+    out = {'workload': args.workload, 'link_gbytes_per_s': args.link_gbps, 'latency_us': args.latency_us, 'steps': args.steps,
            'chunks': args.chunks, 'runs': []}
     base = {}
     for mode in args.modes.split(','):
         for kind in args.kinds.split(','):
             for n in (int(x) for x in args.ranks.split(',')):
-                if kind == 'weak' and n > 1 and 'strong' in args.kinds.split(',') and False:
-                    continue
                 wire = 'f32' if n >= 4 else 'f64'
                 if kind == 'strong' and n > 1:
                     bounds = partition_barcodes(counts, n)
@@ -84,7 +85,7 @@ def main():
                     ctx.set_betas(betas)
                     ctx.set_addition(None)
                     ctx.probs_from_betas(0.01, fetch=False)
-                    ctx.estep(pen, with_doublets=False, fetch_logits=False, fetch_probs=False)
+                    ctx.estep(pen, with_doublets=dp > 0, fetch_logits=False, fetch_probs=False)
                     r = region(ctx, args.steps, args.warmup)
                 finally:
                     ctx.close()
