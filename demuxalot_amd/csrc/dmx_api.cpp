@@ -425,7 +425,6 @@ void release_problem(dmx_ctx *c)
     // the blocks released here are handed out again at once (ctx_malloc) to work ordered on c->stream: whatever the
     // other streams of the context still have queued on them must be done first (hipFree used to wait for the device)
     if (c->stream2) (void)hipStreamSynchronize(c->stream2);
-    for (hipStream_t ms : c->chunk_streams) (void)hipStreamSynchronize(ms);
     dev_free(c, &c->d_pair_ptr, (size_t)c->B + 1);
     dev_free(c, &c->d_call_pairs, (size_t)c->n_pairs + dmx::CALL_PAD_PAIRS);
     dev_free(c, &c->d_call_rows, ((size_t)c->n_pairs + dmx::CALL_PAD_PAIRS) * 2);
@@ -467,6 +466,7 @@ void release_problem(dmx_ctx *c)
     dev_free(c, &c->d_erow, (size_t)c->V);
     dev_free(c, &c->d_chunk_vars, (size_t)c->V);
     dev_free(c, &c->d_chunk_items, (size_t)c->n_items);
+    dev_free(c, &c->d_chunk_done, (size_t)16 * dmx::CHUNK_SLOTS);
     c->n_chunks = 0;
     c->sub_rows = 0;
     c->chunk_var_off.clear();
@@ -884,19 +884,6 @@ int layout_exchange(dmx_ctx *c)
             HIP_TRY(hipStreamSynchronize(st));  // locals
             if (!c->stream2) HIP_TRY(hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking));
             if (!c->ev_estep_done) HIP_TRY(hipEventCreateWithFlags(&c->ev_estep_done, hipEventDisableTiming));
-            int least = 0, greatest = 0;  // numerically: greatest priority <= least priority
-            HIP_TRY(hipDeviceGetStreamPriorityRange(&least, &greatest));
-            while ((int)c->chunk_streams.size() < R) {
-                const int j = (int)c->chunk_streams.size();
-                hipStream_t ms;
-                HIP_TRY(hipStreamCreateWithPriority(&ms, hipStreamNonBlocking, std::min(least, greatest + j)));
-                c->chunk_streams.push_back(ms);
-            }
-            while ((int)c->ev_chunk.size() < R) {
-                hipEvent_t ev;
-                HIP_TRY(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
-                c->ev_chunk.push_back(ev);
-            }
             if (!c->ev_exchanged) HIP_TRY(hipEventCreateWithFlags(&c->ev_exchanged, hipEventDisableTiming));
         }
         c->exch_bytes = (size_t)send_rows * G * 8;  // float64 sums; also the float32 staging of the addition gather
@@ -1171,39 +1158,44 @@ int run_estep(dmx_ctx *c, int with_doublets, bool with_prior, int prior_dtype, f
     return 0;
 }
 
-// Chunked exchange (layout_exchange: n_chunks > 1).  The M-step kernels are launched chunk by chunk on the context's
-// stream; the exchange stream takes every chunk as soon as its sums exist - combine (+ exact redo) into the chunk-major
-// send buffer, reduce-scatter, round this rank's rows into d_add - while the chunks after it are still being summed.
-// The P-step and the all-gather of genotype_prob stay where they are (start of the next iteration: the direct E-step
-// needs the whole table anyway).  DMX_T_ALLREDUCE then measures what is EXPOSED: the time the context's stream waits
-// for the last chunk.
+// Chunked exchange (layout_exchange: n_chunks > 1; dmx_set_exchange_chunks).  ONE M-step launch on the context's stream
+// walks the work items chunk by chunk (chunk j = run j of every rank's slice); the wavefront that finishes an item bumps
+// its chunk's counter (kernels.hip: mstep_item_done).  The exchange stream holds, per chunk, a one-wavefront kernel that
+// waits for the counter to reach the chunk's item count, then combines (+ exact redo) the chunk into the chunk-major
+// send buffer, reduce-scatters it and rounds this rank's rows into d_add - while the launch is still summing the chunks
+// behind it.  Two cross-stream events per iteration (exchange stream after the counters' reset; context stream after
+// the last chunk), no host involvement in between.  [Round 3 launched the chunks on R streams of decreasing priority
+// with an event per chunk: +0.6 ms per iteration in event waits, more than the exchange it could hide.]
+// The P-step and the all-gather of genotype_prob stay where they are (start of the next iteration: the E-step needs the
+// whole table).  DMX_T_ALLREDUCE then measures what is EXPOSED: the time the context's stream waits for the last chunk.
 int run_mstep_chunked(dmx_ctx *c, dmx::MstepArgs a, unsigned long long *redo)
 {
     const int R = c->n_chunks, G = c->G;
     const bool f64 = c->reduce_dtype == DMX_F64;
     const size_t elem = f64 ? 8 : 4, block = (size_t)c->sub_rows * G;
     std::pair<hipEvent_t, hipEvent_t> ev;
-    // The chunks' kernels go to R streams of decreasing priority, all released by the E-step's end: they are in flight
-    // together - one launch after the other on ONE stream paid the longest work item's tail R times (0.71 -> 1.67 ms at
-    // R = 4) -, the dispatcher serving the earlier chunk first, so that chunk j completes well before chunk j + 1.
-    HIP_TRY(hipEventRecord(c->ev_estep_done, c->stream));
+    if (!c->d_chunk_done) DMX_TRY(dev_alloc(c, &c->d_chunk_done, (size_t)16 * dmx::CHUNK_SLOTS));
+    HIP_TRY(hipMemsetAsync(c->d_chunk_done, 0, 16 * dmx::CHUNK_SLOTS * sizeof(unsigned), c->stream));
+    HIP_TRY(hipEventRecord(c->ev_estep_done, c->stream));  // counters reset (and the E-step's posteriors final)
+    a.order = c->d_chunk_items;
+    a.chunk_done = c->d_chunk_done;
+    a.n_chunks = R;
+    for (int j = 0; j < 16; j++) a.chunk_end[j] = c->chunk_item_off[(size_t)std::min(j + 1, R)];
+    // single-item variants go straight into the chunk-major send buffer
+    a.item_variant = c->d_item_variant;
+    a.prow = c->d_erow;
+    a.out32 = f64 ? nullptr : (float *)c->d_exch;
+    a.out64 = f64 ? (double *)c->d_exch : nullptr;
     timer_begin(c, DMX_T_MSTEP, &ev);
-    for (int j = 0; j < R; j++) {
-        dmx::MstepArgs aj = a;
-        aj.order = c->d_chunk_items + c->chunk_item_off[(size_t)j];
-        aj.n_items = c->chunk_item_off[(size_t)j + 1] - c->chunk_item_off[(size_t)j];
-        hipStream_t ms = c->chunk_streams[(size_t)j];
-        HIP_TRY(hipStreamWaitEvent(ms, c->ev_estep_done, 0));
-        HIP_TRY(dmx::launch_mstep(ms, aj));
-        HIP_TRY(hipEventRecord(c->ev_chunk[(size_t)j], ms));
-        HIP_TRY(hipStreamWaitEvent(c->stream, c->ev_chunk[(size_t)j], 0));
-    }
+    HIP_TRY(dmx::launch_mstep(c->stream, a));
     timer_end(c, DMX_T_MSTEP, ev);
+    HIP_TRY(hipStreamWaitEvent(c->stream2, c->ev_estep_done, 0));
     for (int j = 0; j < R; j++) {
-        HIP_TRY(hipStreamWaitEvent(c->stream2, c->ev_chunk[(size_t)j], 0));
+        const long long items = c->chunk_item_off[(size_t)j + 1] - c->chunk_item_off[(size_t)j];
+        HIP_TRY(dmx::launch_wait_count(c->stream2, c->d_chunk_done + (size_t)j * dmx::CHUNK_SLOTS, (unsigned)items));
         const long long v0 = c->chunk_var_off[(size_t)j], v1 = c->chunk_var_off[(size_t)j + 1];
         HIP_TRY(dmx::launch_mcombine(c->stream2, a, c->d_item_ptr, v0, v1, c->d_erow, f64 ? nullptr : (float *)c->d_exch,
-                                     f64 ? (double *)c->d_exch : nullptr, redo, c->d_n_redo, c->d_chunk_vars));
+                                     f64 ? (double *)c->d_exch : nullptr, redo, c->d_n_redo, c->d_chunk_vars, true));
         char *send = (char *)c->d_exch + (size_t)j * c->nranks * block * elem, *recv = (char *)c->d_recv + (size_t)j * block * elem;
         DMX_TRY(coll_reduce_scatter(c, send, recv, block, f64, c->stream2));
         const long long lo = c->cut[c->rank] + (long long)j * c->sub_rows, hi = std::min(c->cut[c->rank + 1], lo + c->sub_rows);
@@ -1253,6 +1245,9 @@ int run_mstep(dmx_ctx *c, float power)
     a.prow = nullptr;
     a.out32 = nullptr;
     a.out64 = nullptr;
+    a.chunk_done = nullptr;
+    a.n_chunks = 0;
+    for (long long &e : a.chunk_end) e = 0;
     if (dist && c->sliced && c->n_chunks > 1) return run_mstep_chunked(c, a, redo);
     const bool f64 = c->reduce_dtype == DMX_F64;
     // where k_mcombine writes: the variants of one work item are written there by the M-step kernels themselves
@@ -1368,13 +1363,11 @@ int dmx_destroy(dmx_ctx *c)
         (void)hipStreamSynchronize(c->stream2);
         (void)hipStreamDestroy(c->stream2);
     }
-    for (hipStream_t ms : c->chunk_streams) (void)hipStreamDestroy(ms);
     if (c->ev_estep_done) (void)hipEventDestroy(c->ev_estep_done);
-    for (hipEvent_t e : c->ev_chunk) (void)hipEventDestroy(e);
     if (c->ev_exchanged) (void)hipEventDestroy(c->ev_exchanged);
     if (c->d_scratch) (void)hipFree(c->d_scratch);
     dmx::release_staged_calls(c);
-    (void)hipDeviceSynchronize();  // the second stream and the chunk streams too
+    (void)hipDeviceSynchronize();  // the exchange stream too
     ctx_retire(c);
     for (auto &t : c->timers) {
         for (auto &ev : t.pending) {

@@ -165,9 +165,10 @@ struct dmx_ctx {
     std::vector<int> h_v2snp;       // host copy of v2snp (layout decisions)
     int *d_prow = nullptr;          // [V] padded row of every variant (sliced mode)
     // Chunked (pipelined) exchange, dmx_set_exchange_chunks / DEMUXALOT_AMD_EXCHANGE=pipelined[:R]: every rank slice is cut
-    // into n_chunks runs of sub_rows rows; chunk j = run j of every slice.  The M-step is launched chunk by chunk on the
-    // context's stream, and a second stream combines, reduce-scatters and stores chunk j while the chunks after it
-    // are being summed.  The send buffer is chunk-major (erow), genotype_prob keeps the rank-major layout (prow).
+    // into n_chunks runs of sub_rows rows; chunk j = run j of every slice.  One M-step launch walks the items chunk by
+    // chunk and counts the finished items per chunk; a second stream combines, reduce-scatters and stores chunk j as soon
+    // as its count is complete, while the chunks after it are being summed (dmx_api.cpp: run_mstep_chunked).  The send
+    // buffer is chunk-major (erow), genotype_prob keeps the rank-major layout (prow).
     int exch_chunks = 0;            // requested (<= 1: off)
     int n_chunks = 0;               // active for the resident problem (0: off)
     long long sub_rows = 0;         // rows per chunk of a slice
@@ -175,13 +176,11 @@ struct dmx_ctx {
     int *d_chunk_vars = nullptr;    // [V] the variants chunk by chunk (rank-major inside a chunk)
     std::vector<long long> chunk_var_off;   // [n_chunks + 1] offsets into d_chunk_vars
     int *d_chunk_items = nullptr;   // [n_items] the work items chunk by chunk, longest first inside a chunk
+    unsigned *d_chunk_done = nullptr;  // [16][CHUNK_SLOTS] items finished per chunk (MstepArgs::chunk_done)
     std::vector<long long> chunk_item_off;  // [n_chunks + 1]
     hipStream_t stream2 = nullptr;  // exchange stream
-    std::vector<hipStream_t> chunk_streams;  // one per chunk, of decreasing priority: the chunks' M-step kernels are in flight
-                                             // together, the earlier chunk's wavefronts dispatched first
-    hipEvent_t ev_estep_done = nullptr;
-    std::vector<hipEvent_t> ev_chunk;  // M-step of chunk j launched (stream) -> exchange of chunk j may start (stream2)
-    hipEvent_t ev_exchanged = nullptr; // exchange of the last chunk done (stream2) -> next step (stream)
+    hipEvent_t ev_estep_done = nullptr;  // chunk counters reset, posteriors final (stream) -> the exchange stream may start waiting
+    hipEvent_t ev_exchanged = nullptr;   // exchange of the last chunk done (stream2) -> next step (stream)
     void *d_exch = nullptr;         // padded send buffer of the reduce-scatter (float64 or float32 partial sums)
     void *d_recv = nullptr;         // this rank's reduced slice
     size_t exch_bytes = 0, recv_bytes = 0;

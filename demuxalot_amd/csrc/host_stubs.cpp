@@ -152,6 +152,7 @@ hipError_t launch_remap_row_offsets(hipStream_t, CallPair *pairs, long long n_pa
 hipError_t launch_f64_to_f32(hipStream_t, const double *, float *, long long) { return hipSuccess; }
 hipError_t launch_f32_to_f64(hipStream_t, const float *, double *, long long) { return hipSuccess; }
 hipError_t launch_delay(hipStream_t, long long) { return hipSuccess; }
+hipError_t launch_wait_count(hipStream_t, const unsigned *, unsigned) { return hipSuccess; }
 hipError_t launch_prior_betas(hipStream_t, const float *, float *, const unsigned long long *, const int *, const int *, const int *,
                               long long, int, double, float *) { return hipSuccess; }
 hipError_t launch_rebuild_nz(hipStream_t, const float *, long long, int, int, float, unsigned long long *, uint2 *) { return hipSuccess; }
