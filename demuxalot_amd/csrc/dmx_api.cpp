@@ -424,13 +424,13 @@ void release_problem(dmx_ctx *c)
 {
     // the blocks released here are handed out again at once (ctx_malloc) to work ordered on c->stream: whatever the
     // other streams of the context still have queued on them must be done first (hipFree used to wait for the device)
-    if (c->stream2) (void)hipStreamSynchronize(c->stream2);
     dev_free(c, &c->d_pair_ptr, (size_t)c->B + 1);
     dev_free(c, &c->d_call_pairs, (size_t)c->n_pairs + dmx::CALL_PAD_PAIRS);
     dev_free(c, &c->d_call_rows, ((size_t)c->n_pairs + dmx::CALL_PAD_PAIRS) * 2);
     dev_free(c, &c->d_tile_stream, (size_t)c->n_pairs);
     c->n_pairs = 0;
-    dev_free(c, &c->d_csc, (size_t)c->N);
+    dev_free(c, &c->d_csc, (size_t)c->n_csc);
+    c->n_csc = 0;
     dev_free(c, &c->d_item_start, (size_t)c->n_items);
     dev_free(c, &c->d_item_len, (size_t)c->n_items);
     dev_free(c, &c->d_item_ptr, (size_t)c->V + 1);
@@ -463,14 +463,11 @@ void release_problem(dmx_ctx *c)
         c->d_recv = nullptr;
         c->recv_bytes = 0;
     }
-    dev_free(c, &c->d_erow, (size_t)c->V);
-    dev_free(c, &c->d_chunk_vars, (size_t)c->V);
-    dev_free(c, &c->d_chunk_items, (size_t)c->n_items);
-    dev_free(c, &c->d_chunk_done, (size_t)16 * dmx::CHUNK_SLOTS);
-    c->n_chunks = 0;
-    c->sub_rows = 0;
-    c->chunk_var_off.clear();
-    c->chunk_item_off.clear();
+    dev_free(c, &c->d_first_g, (size_t)c->rows_total);
+    dev_free(c, &c->d_nz_g, (size_t)c->rows_total * ((c->G + 63) / 64));
+    dev_free(c, &c->d_post_g, (size_t)c->rows_total * c->G);
+    c->mshard = c->post_gathered = c->emu_post_filled = false;
+    c->rows_pad = c->rows_total = 0;
     c->sliced = c->add_partial = false;
     c->slice_rows = c->prob_rows = 0;
     c->cut.clear();
@@ -788,6 +785,91 @@ int coll_all_reduce(dmx_ctx *c, void *buf, size_t count, bool f64)
     return host_collective(c, DMX_COLL_ALL_REDUCE, buf, 0, total, buf, 0, total, total, (int64_t)count, f64 ? DMX_F64 : DMX_F32, "all-reduce", c->stream);
 }
 
+// small host numbers of every rank, through the data-plane collective: out[r * count + i] = rank r's values[i] (each < 2^48)
+int gather_numbers(dmx_ctx *c, const long long *values, int count, std::vector<long long> &out)
+{
+    const int n = c->nranks;
+    std::vector<float> host((size_t)n * count * 3, 0.0f);  // three 16-bit digits per number: exact in float32
+    for (int i = 0; i < count; i++)
+        for (int d = 0; d < 3; d++) host[((size_t)c->rank * count + i) * 3 + d] = (float)((values[i] >> (16 * d)) & 0xFFFF);
+    float *dev = nullptr;
+    HIP_TRY(hipMalloc((void **)&dev, host.size() * sizeof(float)));
+    int rc = 0;
+    if (hipMemcpyAsync(dev, host.data(), host.size() * sizeof(float), hipMemcpyHostToDevice, c->stream) != hipSuccess) rc = fail(DMX_ERR_HIP, "upload failed");
+    if (rc == 0) rc = coll_all_gather(c, dev, (size_t)count * 3, "sizes");
+    if (rc == 0 && hipMemcpyAsync(host.data(), dev, host.size() * sizeof(float), hipMemcpyDeviceToHost, c->stream) != hipSuccess) rc = fail(DMX_ERR_HIP, "download failed");
+    if (rc == 0 && hipStreamSynchronize(c->stream) != hipSuccess) rc = fail(DMX_ERR_HIP, "synchronisation failed");
+    (void)hipStreamSynchronize(c->stream);
+    (void)hipFree(dev);
+    if (rc) return rc;
+    out.assign((size_t)n * count, 0);
+    for (int r = 0; r < n; r++)
+        for (int i = 0; i < count; i++) {
+            long long v = 0;
+            for (int d = 0; d < 3; d++) v |= (long long)host[((size_t)r * count + i) * 3 + d] << (16 * d);
+            out[(size_t)r * count + i] = c->emulated ? values[i] : v;  // emulated wire: every rank is a copy of this one
+        }
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------
+// Multi-GPU, what is exchanged.  The E-step shards on barcodes.  Reducing the M-step's partial [V, G] sums over the ranks
+// (round 3: reduce-scatter over variant slices) puts a DENSE table on the wire - 51 MB at 200k variants x 64 - although
+// what the ranks really have to tell each other is sparse: the posteriors, ~1.05 live genotypes per barcode.  And it makes
+// every rank walk all V variants with 1 / n of the calls each: items of ~50 calls at 8 ranks, where the M-step kernels run
+// at half their rate, plus an unsharded combine pass.  So the M-step shards on VARIANTS instead:
+//     set-up   every rank's variant-major call records travel once (all-gather); rank r keeps the calls of ITS variant
+//              slice from the barcodes of ALL ranks (global barcode row = owner * rows_pad + barcode)
+//     E-step   writes its barcodes' posterior codes / bitmaps / singlet posteriors into its block of three global tables
+//     exchange all-gather of those three tables (8 + 8 W + 4 G bytes per barcode)
+//     M-step   rank r sums slice r over all barcodes in the reference's order - float64, one rounding: the additions
+//              are BIT-IDENTICAL to a single-GPU run whatever the number of ranks, nothing is added across ranks
+//     P-step   of slice r, then the all-gather of genotype_prob as before
+// ------------------------------------------------------------------------------------
+int shard_mstep_by_variant(dmx_ctx *c)
+{
+    const int n = c->nranks, G = c->G, W = (G + 63) / 64;
+    hipStream_t st = c->stream;
+    const long long mine[2] = {c->B, c->n_csc};
+    std::vector<long long> all;
+    DMX_TRY(gather_numbers(c, mine, 2, all));
+    long long rows_pad = 1, calls_pad = 1;
+    for (int r = 0; r < n; r++) {
+        rows_pad = std::max(rows_pad, all[(size_t)2 * r]);
+        calls_pad = std::max(calls_pad, all[(size_t)2 * r + 1]);
+    }
+    if (rows_pad * n >= (1LL << 31)) return fail(DMX_ERR_UNSUPPORTED, "%lld barcode rows over all ranks exceed int32", rows_pad * n);
+    // the call records of every rank
+    uint4 *wire = nullptr;
+    const size_t wire_bytes = sizeof(uint4) * (size_t)calls_pad * n;
+    hipError_t e = hipMalloc((void **)&wire, wire_bytes);
+    if (e != hipSuccess) return fail(DMX_ERR_HIP, "hipMalloc of %zu bytes for the call records of all ranks failed: %s", wire_bytes, hipGetErrorString(e));
+    int rc = 0;
+    if (c->emulated) {  // emulated wire: the other ranks hold copies of this rank's calls (their barcodes other rows)
+        for (int r = 0; r < n && rc == 0; r++) rc = dmx::wire_records_of(c, r * rows_pad, wire + (size_t)r * calls_pad, calls_pad);
+        if (rc == 0) rc = emulated_wire(c, sizeof(uint4) * (size_t)calls_pad, 1, st);
+    } else {
+        rc = dmx::wire_records_of(c, c->rank * rows_pad, wire + (size_t)c->rank * calls_pad, calls_pad);
+        if (rc == 0) rc = coll_all_gather(c, (float *)wire, (size_t)calls_pad * 4, "call records");
+    }
+    if (rc == 0) rc = dmx::install_mstep_records(c, wire, calls_pad * n, c->cut[c->rank], c->cut[c->rank + 1]);
+    (void)hipStreamSynchronize(st);
+    (void)hipFree(wire);
+    if (rc) return rc;
+    c->rows_pad = rows_pad;
+    c->rows_total = rows_pad * n;
+    DMX_TRY(dev_alloc(c, &c->d_first_g, (size_t)c->rows_total));
+    DMX_TRY(dev_alloc(c, &c->d_nz_g, (size_t)c->rows_total * W));
+    DMX_TRY(dev_alloc(c, &c->d_post_g, (size_t)c->rows_total * G));
+    HIP_TRY(hipMemsetAsync(c->d_first_g, 0, sizeof(uint2) * (size_t)c->rows_total, st));
+    HIP_TRY(hipMemsetAsync(c->d_nz_g, 0, sizeof(unsigned long long) * (size_t)c->rows_total * W, st));
+    HIP_TRY(hipMemsetAsync(c->d_post_g, 0, sizeof(float) * (size_t)c->rows_total * G, st));
+    c->mshard = true;
+    c->post_gathered = false;
+    c->emu_post_filled = false;
+    return 0;
+}
+
 int layout_exchange(dmx_ctx *c)
 {
     const long long V = c->V;
@@ -830,70 +912,17 @@ int layout_exchange(dmx_ctx *c)
         HIP_TRY(dmx::launch_remap_row_offsets(st, c->d_call_pairs, c->n_pairs, (unsigned)G * 4u, c->d_prow, c->d_call_rows));
         if (c->d_tile_stream) HIP_TRY(dmx::launch_remap_row_offsets(st, c->d_tile_stream, c->n_pairs, (unsigned)G * 4u, c->d_prow, nullptr));
         const size_t elem = c->reduce_dtype == DMX_F64 ? 8 : 4;
-        // ---- chunked (pipelined) exchange: opt-in (dmx_set_exchange_chunks, DEMUXALOT_AMD_EXCHANGE=pipelined[:R]) ----
-        int want_chunks = c->exch_chunks;
-        if (exchange && std::strncmp(exchange, "pipelined", 9) == 0) want_chunks = exchange[9] == ':' ? std::atoi(exchange + 10) : 4;
-        c->n_chunks = 0;
-        c->sub_rows = rows;
-        long long send_rows = new_rows;
-        if (want_chunks > 1 && rows >= 4 * want_chunks && c->n_items > 0) {
-            const int R = std::min(want_chunks, 16);
-            const long long sub = (rows + R - 1) / R;
-            c->n_chunks = R;
-            c->sub_rows = sub;
-            send_rows = (long long)R * n * sub;
-            // chunk j = rows [j * sub, (j + 1) * sub) of every rank's slice; in the send buffer chunk-major, rank-major inside
-            std::vector<int> erow((size_t)V), chunk_of((size_t)V), vars;
-            vars.reserve((size_t)V);
-            c->chunk_var_off.assign((size_t)R + 1, 0);
-            for (int j = 0; j < R; j++) {
-                for (int r = 0; r < n; r++) {
-                    const long long lo = c->cut[r] + (long long)j * sub, hi = std::min(c->cut[r + 1], lo + sub);
-                    for (long long v = lo; v < hi; v++) {
-                        erow[v] = (int)(((long long)j * n + r) * sub + (v - lo));
-                        chunk_of[v] = j;
-                        vars.push_back((int)v);
-                    }
-                }
-                c->chunk_var_off[(size_t)j + 1] = (long long)vars.size();
-            }
-            // the work items chunk by chunk, in the order of the global (longest first) work list
-            std::vector<long long> item_ptr((size_t)V + 1);
-            std::vector<int> order((size_t)c->n_items), item_chunk((size_t)c->n_items);
-            HIP_TRY(hipMemcpyAsync(item_ptr.data(), c->d_item_ptr, sizeof(long long) * (V + 1), hipMemcpyDeviceToHost, st));
-            HIP_TRY(hipMemcpyAsync(order.data(), c->d_item_order, sizeof(int) * c->n_items, hipMemcpyDeviceToHost, st));
-            HIP_TRY(hipStreamSynchronize(st));
-            for (long long v = 0; v < V; v++)
-                for (long long it = item_ptr[v]; it < item_ptr[v + 1]; it++) item_chunk[(size_t)it] = chunk_of[v];
-            std::vector<long long> count((size_t)R + 1, 0);
-            for (long long i = 0; i < c->n_items; i++) count[(size_t)item_chunk[(size_t)order[(size_t)i]] + 1]++;
-            for (int j = 0; j < R; j++) count[(size_t)j + 1] += count[(size_t)j];
-            c->chunk_item_off = count;
-            std::vector<int> by_chunk((size_t)c->n_items);
-            std::vector<long long> fill(count.begin(), count.end() - 1);
-            for (long long i = 0; i < c->n_items; i++) {
-                const int it = order[(size_t)i];
-                by_chunk[(size_t)fill[(size_t)item_chunk[(size_t)it]]++] = it;
-            }
-            DMX_TRY(dev_alloc(c, &c->d_erow, (size_t)V));
-            DMX_TRY(dev_alloc(c, &c->d_chunk_vars, (size_t)V));
-            DMX_TRY(dev_alloc(c, &c->d_chunk_items, (size_t)c->n_items));
-            HIP_TRY(hipMemcpyAsync(c->d_erow, erow.data(), sizeof(int) * V, hipMemcpyHostToDevice, st));
-            HIP_TRY(hipMemcpyAsync(c->d_chunk_vars, vars.data(), sizeof(int) * V, hipMemcpyHostToDevice, st));
-            HIP_TRY(hipMemcpyAsync(c->d_chunk_items, by_chunk.data(), sizeof(int) * c->n_items, hipMemcpyHostToDevice, st));
-            HIP_TRY(hipStreamSynchronize(st));  // locals
-            if (!c->stream2) HIP_TRY(hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking));
-            if (!c->ev_estep_done) HIP_TRY(hipEventCreateWithFlags(&c->ev_estep_done, hipEventDisableTiming));
-            if (!c->ev_exchanged) HIP_TRY(hipEventCreateWithFlags(&c->ev_exchanged, hipEventDisableTiming));
-        }
-        c->exch_bytes = (size_t)send_rows * G * 8;  // float64 sums; also the float32 staging of the addition gather
-        c->recv_bytes = (size_t)(c->n_chunks ? c->n_chunks * c->sub_rows : rows) * G * elem;
+        c->exch_bytes = (size_t)new_rows * G * 8;  // float64 sums of the reduce-scatter exchange; also the float32 staging of the addition gather
+        c->recv_bytes = (size_t)rows * G * elem;
         HIP_TRY(hipMalloc(&c->d_exch, c->exch_bytes));
         c->bytes += (int64_t)c->exch_bytes;
         HIP_TRY(hipMalloc(&c->d_recv, c->recv_bytes));
         c->bytes += (int64_t)c->recv_bytes;
         HIP_TRY(hipMemsetAsync(c->d_exch, 0, c->exch_bytes, st));  // padding rows stay zero
         HIP_TRY(hipStreamSynchronize(st));                          // `prow` is a local
+        // DEMUXALOT_AMD_EXCHANGE=reduce_scatter keeps the M-step on every rank's own barcodes and reduce-scatters the sums
+        const bool by_sums = exchange && std::strcmp(exchange, "reduce_scatter") == 0;
+        if (n > 1 && !by_sums) DMX_TRY(shard_mstep_by_variant(c));
     }
     c->add_partial = false;
     return 0;
@@ -1058,8 +1087,12 @@ int run_estep(dmx_ctx *c, int with_doublets, bool with_prior, int prior_dtype, f
     a.prior_dtype = prior_dtype;
     a.logits = c->d_logits;
     a.post = c->d_post;
-    a.nz = c->d_nz;
-    a.first = c->G <= 64 ? c->d_first : nullptr;
+    // variant-sharded M-step: the posteriors' codes / bitmaps / singlet columns go into this rank's block of the global tables
+    const size_t row_base = c->mshard ? (size_t)c->rank * (size_t)c->rows_pad : 0;
+    a.nz = c->mshard ? c->d_nz_g + row_base * ((c->G + 63) / 64) : c->d_nz;
+    a.first = c->G <= 64 ? (c->mshard ? c->d_first_g + row_base : c->d_first) : nullptr;
+    a.post_singlets = c->mshard ? c->d_post_g + row_base * c->G : nullptr;
+    c->post_gathered = false;
     a.dense_calls = c->G <= 64 ? c->d_dense_calls : nullptr;
     if (a.dense_calls) HIP_TRY(hipMemsetAsync(c->d_dense_calls, 0, sizeof(unsigned long long) * (1 + dmx::DENSE_SLOTS), c->stream));
     c->dense_stat_valid = a.dense_calls != nullptr;
@@ -1158,73 +1191,56 @@ int run_estep(dmx_ctx *c, int with_doublets, bool with_prior, int prior_dtype, f
     return 0;
 }
 
-// Chunked exchange (layout_exchange: n_chunks > 1; dmx_set_exchange_chunks).  ONE M-step launch on the context's stream
-// walks the work items chunk by chunk (chunk j = run j of every rank's slice); the wavefront that finishes an item bumps
-// its chunk's counter (kernels.hip: mstep_item_done).  The exchange stream holds, per chunk, a one-wavefront kernel that
-// waits for the counter to reach the chunk's item count, then combines (+ exact redo) the chunk into the chunk-major
-// send buffer, reduce-scatters it and rounds this rank's rows into d_add - while the launch is still summing the chunks
-// behind it.  Two cross-stream events per iteration (exchange stream after the counters' reset; context stream after
-// the last chunk), no host involvement in between.  [Round 3 launched the chunks on R streams of decreasing priority
-// with an event per chunk: +0.6 ms per iteration in event waits, more than the exchange it could hide.]
-// The P-step and the all-gather of genotype_prob stay where they are (start of the next iteration: the E-step needs the
-// whole table).  DMX_T_ALLREDUCE then measures what is EXPOSED: the time the context's stream waits for the last chunk.
-int run_mstep_chunked(dmx_ctx *c, dmx::MstepArgs a, unsigned long long *redo)
+// Variant-sharded M-step (shard_mstep_by_variant): everybody's posterior codes, bitmaps and singlet posteriors, gathered
+// once per E-step.  Emulated wire: the other ranks' blocks hold a copy of this rank's first ones (what the M-step reads
+// of them decides its work), never refreshed.
+int gather_posteriors(dmx_ctx *c)
 {
-    const int R = c->n_chunks, G = c->G;
-    const bool f64 = c->reduce_dtype == DMX_F64;
-    const size_t elem = f64 ? 8 : 4, block = (size_t)c->sub_rows * G;
+    if (!c->mshard || c->post_gathered) return 0;
+    const int G = c->G, W = (G + 63) / 64;
+    const size_t rows = (size_t)c->rows_pad;
     std::pair<hipEvent_t, hipEvent_t> ev;
-    if (!c->d_chunk_done) DMX_TRY(dev_alloc(c, &c->d_chunk_done, (size_t)16 * dmx::CHUNK_SLOTS));
-    HIP_TRY(hipMemsetAsync(c->d_chunk_done, 0, 16 * dmx::CHUNK_SLOTS * sizeof(unsigned), c->stream));
-    HIP_TRY(hipEventRecord(c->ev_estep_done, c->stream));  // counters reset (and the E-step's posteriors final)
-    a.order = c->d_chunk_items;
-    a.chunk_done = c->d_chunk_done;
-    a.n_chunks = R;
-    for (int j = 0; j < 16; j++) a.chunk_end[j] = c->chunk_item_off[(size_t)std::min(j + 1, R)];
-    // single-item variants go straight into the chunk-major send buffer
-    a.item_variant = c->d_item_variant;
-    a.prow = c->d_erow;
-    a.out32 = f64 ? nullptr : (float *)c->d_exch;
-    a.out64 = f64 ? (double *)c->d_exch : nullptr;
-    timer_begin(c, DMX_T_MSTEP, &ev);
-    HIP_TRY(dmx::launch_mstep(c->stream, a));
-    timer_end(c, DMX_T_MSTEP, ev);
-    HIP_TRY(hipStreamWaitEvent(c->stream2, c->ev_estep_done, 0));
-    for (int j = 0; j < R; j++) {
-        const long long items = c->chunk_item_off[(size_t)j + 1] - c->chunk_item_off[(size_t)j];
-        HIP_TRY(dmx::launch_wait_count(c->stream2, c->d_chunk_done + (size_t)j * dmx::CHUNK_SLOTS, (unsigned)items));
-        const long long v0 = c->chunk_var_off[(size_t)j], v1 = c->chunk_var_off[(size_t)j + 1];
-        HIP_TRY(dmx::launch_mcombine(c->stream2, a, c->d_item_ptr, v0, v1, c->d_erow, f64 ? nullptr : (float *)c->d_exch,
-                                     f64 ? (double *)c->d_exch : nullptr, redo, c->d_n_redo, c->d_chunk_vars, true));
-        char *send = (char *)c->d_exch + (size_t)j * c->nranks * block * elem, *recv = (char *)c->d_recv + (size_t)j * block * elem;
-        DMX_TRY(coll_reduce_scatter(c, send, recv, block, f64, c->stream2));
-        const long long lo = c->cut[c->rank] + (long long)j * c->sub_rows, hi = std::min(c->cut[c->rank + 1], lo + c->sub_rows);
-        if (hi > lo) HIP_TRY(dmx::launch_store_slice(c->stream2, recv, f64, lo, hi - lo, G, c->d_add));
-    }
-    HIP_TRY(hipEventRecord(c->ev_exchanged, c->stream2));
     timer_begin(c, DMX_T_ALLREDUCE, &ev);
-    HIP_TRY(hipStreamWaitEvent(c->stream, c->ev_exchanged, 0));
+    int rc = 0;
+    if (c->emulated && !c->emu_post_filled) {
+        for (int r = 0; r < c->nranks; r++) {
+            if (r == c->rank) continue;
+            HIP_TRY(hipMemcpyAsync(c->d_first_g + r * rows, c->d_first_g + c->rank * rows, sizeof(uint2) * rows, hipMemcpyDeviceToDevice, c->stream));
+            HIP_TRY(hipMemcpyAsync(c->d_nz_g + r * rows * W, c->d_nz_g + c->rank * rows * W, sizeof(unsigned long long) * rows * W, hipMemcpyDeviceToDevice, c->stream));
+            HIP_TRY(hipMemcpyAsync(c->d_post_g + r * rows * G, c->d_post_g + c->rank * rows * G, sizeof(float) * rows * G, hipMemcpyDeviceToDevice, c->stream));
+        }
+        c->emu_post_filled = true;
+    }
+    rc = coll_all_gather(c, (float *)c->d_first_g, rows * 2, "posterior codes");
+    if (rc == 0) rc = coll_all_gather(c, (float *)c->d_nz_g, rows * W * 2, "posterior bitmaps");
+    if (rc == 0) rc = coll_all_gather(c, c->d_post_g, rows * G, "singlet posteriors");
     timer_end(c, DMX_T_ALLREDUCE, ev);
-    c->add_partial = c->nranks > 1;
+    if (rc) return rc;
+    c->post_gathered = true;
     return 0;
 }
 
 int run_mstep(dmx_ctx *c, float power)
 {
+    const bool mshard = c->mshard;
+    const size_t row_base = mshard ? (size_t)c->rank * (size_t)c->rows_pad : 0;
+    const int Wn = (c->G + 63) / 64;
     dmx::MstepArgs a;
     a.order = c->d_item_order;
     a.item_start = c->d_item_start;
     a.item_len = c->d_item_len;
     a.calls = c->d_csc;
-    a.post = c->d_post;
-    a.nz = c->d_nz;
-    a.first = c->d_first;
-    a.first_bytes = 8ull * (unsigned long long)c->B;
+    // variant-sharded: the barcodes of all ranks (global rows), singlet posteriors only (row stride G)
+    a.post = mshard ? c->d_post_g : c->d_post;
+    a.nz = mshard ? c->d_nz_g : c->d_nz;
+    a.first = mshard ? c->d_first_g : c->d_first;
+    const unsigned long long rows = mshard ? (unsigned long long)c->rows_total : (unsigned long long)c->B;
+    a.K = mshard ? c->G : c->K;
+    a.first_bytes = 8ull * rows;
     a.wide = c->mstep_wide;
-    a.post_bytes = (unsigned long long)c->B * (unsigned long long)c->K * 4ull;
+    a.post_bytes = rows * (unsigned long long)a.K * 4ull;
     a.partial = c->d_partial;
     a.n_items = c->n_items;
-    a.K = c->K;
     a.G = c->G;
     a.square = (power == 2.0f);
     a.power = power;
@@ -1232,10 +1248,12 @@ int run_mstep(dmx_ctx *c, float power)
     a.total_calls = 2ull * (unsigned long long)c->n_pairs;
     if (!a.square && c->nz_floor != 0.0f) {
         // the E-step assumed a squaring M-step: rebuild the bitmap with the exact `!= 0` rule
-        HIP_TRY(dmx::launch_rebuild_nz(c->stream, c->d_post, c->B, c->K, c->G, 0.0f, c->d_nz,
-                                       c->G <= 64 ? c->d_first : nullptr));
+        HIP_TRY(dmx::launch_rebuild_nz(c->stream, c->d_post, c->B, c->K, c->G, 0.0f, (mshard ? c->d_nz_g : c->d_nz) + row_base * Wn,
+                                       c->G <= 64 ? (mshard ? c->d_first_g : c->d_first) + row_base : nullptr));
         c->nz_floor = 0.0f;
+        c->post_gathered = false;
     }
+    DMX_TRY(gather_posteriors(c));
     c->add_is_zero = false;
     std::pair<hipEvent_t, hipEvent_t> ev;
     const bool dist = c->attached();  // also with one rank: keeps the collective path testable on one GPU
@@ -1245,14 +1263,10 @@ int run_mstep(dmx_ctx *c, float power)
     a.prow = nullptr;
     a.out32 = nullptr;
     a.out64 = nullptr;
-    a.chunk_done = nullptr;
-    a.n_chunks = 0;
-    for (long long &e : a.chunk_end) e = 0;
-    if (dist && c->sliced && c->n_chunks > 1) return run_mstep_chunked(c, a, redo);
     const bool f64 = c->reduce_dtype == DMX_F64;
     // where k_mcombine writes: the variants of one work item are written there by the M-step kernels themselves
     a.item_variant = c->d_item_variant;
-    if (!dist) {
+    if (!dist || mshard) {
         a.out32 = c->d_add;
     } else if (c->sliced) {
         a.prow = c->d_prow;
@@ -1269,6 +1283,15 @@ int run_mstep(dmx_ctx *c, float power)
         timer_begin(c, DMX_T_MCOMBINE, &ev);
         HIP_TRY(dmx::launch_mcombine(c->stream, a, c->d_item_ptr, 0, c->V, nullptr, c->d_add, nullptr, redo, c->d_n_redo, nullptr, true));
         timer_end(c, DMX_T_MCOMBINE, ev);
+        return 0;
+    }
+    if (mshard) {
+        // this rank's variant slice, summed over the barcodes of all ranks: final, exact, nothing to reduce
+        timer_begin(c, DMX_T_MCOMBINE, &ev);
+        HIP_TRY(dmx::launch_mcombine(c->stream, a, c->d_item_ptr, c->cut[c->rank], c->cut[c->rank + 1], nullptr, c->d_add, nullptr, redo,
+                                     c->d_n_redo, nullptr, true));
+        timer_end(c, DMX_T_MCOMBINE, ev);
+        c->add_partial = c->nranks > 1;
         return 0;
     }
     int rc = 0;
@@ -1359,12 +1382,6 @@ int dmx_destroy(dmx_ctx *c)
     if (c->comm && g_rccl.CommDestroy) g_rccl.CommDestroy(c->comm);
     if (c->h_stage) (void)hipHostFree(c->h_stage);
     release_problem(c);
-    if (c->stream2) {
-        (void)hipStreamSynchronize(c->stream2);
-        (void)hipStreamDestroy(c->stream2);
-    }
-    if (c->ev_estep_done) (void)hipEventDestroy(c->ev_estep_done);
-    if (c->ev_exchanged) (void)hipEventDestroy(c->ev_exchanged);
     if (c->d_scratch) (void)hipFree(c->d_scratch);
     dmx::release_staged_calls(c);
     (void)hipDeviceSynchronize();  // the exchange stream too
@@ -1654,14 +1671,6 @@ int dmx_get_estep_form(dmx_ctx *c, int32_t *form, int32_t *distinct_values)
     if (!c) return fail(DMX_ERR_INVALID, "null context");
     if (form) *form = c->estep_form;
     if (distinct_values) *distinct_values = c->dict_distinct;
-    return 0;
-}
-
-int dmx_set_exchange_chunks(dmx_ctx *c, int chunks)
-{
-    if (!c) return fail(DMX_ERR_INVALID, "null context");
-    if (chunks < 0 || chunks > 16) return fail(DMX_ERR_INVALID, "chunks must be 0 .. 16");
-    c->exch_chunks = chunks;
     return 0;
 }
 

@@ -50,6 +50,7 @@ struct dmx_ctx {
     unsigned *d_call_rows = nullptr;  // table row of every call of d_call_pairs (EstepArgs::call_rows)
     long long n_pairs = 0;
     uint2 *d_csc = nullptr;
+    long long n_csc = 0;  // M-step records held: N, or the calls of this rank's variant slice over the barcodes of all ranks
     long long *d_item_start = nullptr;
     int *d_item_len = nullptr;
     long long *d_item_ptr = nullptr;
@@ -164,23 +165,16 @@ struct dmx_ctx {
     std::vector<long long> cut;     // [nranks + 1] first variant of every slice
     std::vector<int> h_v2snp;       // host copy of v2snp (layout decisions)
     int *d_prow = nullptr;          // [V] padded row of every variant (sliced mode)
-    // Chunked (pipelined) exchange, dmx_set_exchange_chunks / DEMUXALOT_AMD_EXCHANGE=pipelined[:R]: every rank slice is cut
-    // into n_chunks runs of sub_rows rows; chunk j = run j of every slice.  One M-step launch walks the items chunk by
-    // chunk and counts the finished items per chunk; a second stream combines, reduce-scatters and stores chunk j as soon
-    // as its count is complete, while the chunks after it are being summed (dmx_api.cpp: run_mstep_chunked).  The send
-    // buffer is chunk-major (erow), genotype_prob keeps the rank-major layout (prow).
-    int exch_chunks = 0;            // requested (<= 1: off)
-    int n_chunks = 0;               // active for the resident problem (0: off)
-    long long sub_rows = 0;         // rows per chunk of a slice
-    int *d_erow = nullptr;          // [V] row of every variant in the chunk-major send buffer
-    int *d_chunk_vars = nullptr;    // [V] the variants chunk by chunk (rank-major inside a chunk)
-    std::vector<long long> chunk_var_off;   // [n_chunks + 1] offsets into d_chunk_vars
-    int *d_chunk_items = nullptr;   // [n_items] the work items chunk by chunk, longest first inside a chunk
-    unsigned *d_chunk_done = nullptr;  // [16][CHUNK_SLOTS] items finished per chunk (MstepArgs::chunk_done)
-    std::vector<long long> chunk_item_off;  // [n_chunks + 1]
-    hipStream_t stream2 = nullptr;  // exchange stream
-    hipEvent_t ev_estep_done = nullptr;  // chunk counters reset, posteriors final (stream) -> the exchange stream may start waiting
-    hipEvent_t ev_exchanged = nullptr;   // exchange of the last chunk done (stream2) -> next step (stream)
+    // M-step sharded on variants (dmx_api.cpp: shard_mstep_by_variant): d_csc and the work items hold the calls of this rank's
+    // variant slice from the barcodes of ALL ranks; the three tables the M-step reads of a barcode are global
+    // (row = owner rank * rows_pad + barcode), filled block by block by the ranks' E-steps and all-gathered
+    bool mshard = false;
+    long long rows_pad = 0, rows_total = 0;  // barcode rows per rank block / of all ranks
+    uint2 *d_first_g = nullptr;              // [rows_total] EstepArgs::first of every barcode
+    unsigned long long *d_nz_g = nullptr;    // [rows_total, ceil(G / 64)]
+    float *d_post_g = nullptr;               // [rows_total, G] singlet posteriors
+    bool post_gathered = false;              // the tables hold the last E-step of every rank
+    bool emu_post_filled = false;            // emulated wire: the other ranks' blocks were filled once
     void *d_exch = nullptr;         // padded send buffer of the reduce-scatter (float64 or float32 partial sums)
     void *d_recv = nullptr;         // this rank's reduced slice
     size_t exch_bytes = 0, recv_bytes = 0;
@@ -251,6 +245,9 @@ int pack_on_device(dmx_ctx *c, long long V, const int *var_chrom, const int *var
                    long long *mol_per_variant);
 // matched molecule calls (molecule order) -> the (barcode, SNP)-grouped layout of the aggregate_on_snps E-step
 int ensure_sum_plan(dmx_ctx *c, long long K);  // dmx_api.cpp
+// multi-GPU, M-step records by variant slice (repack_device.hip)
+int wire_records_of(dmx_ctx *c, long long row_base, uint4 *d_out, long long capacity);
+int install_mstep_records(dmx_ctx *c, const uint4 *d_rec, long long n, long long v_lo, long long v_hi);
 int build_snp_groups(dmx_ctx *c, const unsigned long long *vb_keys, const unsigned *src_idx, const float *src_p, long long m);
 int stage_containers_on_device(dmx_ctx *c, const dmx_call_container *parts, int n_parts);
 int pack_staged_on_device(dmx_ctx *c, long long V, const int *var_chrom, const int *var_pos, const unsigned char *var_base,

@@ -296,6 +296,7 @@ static __device__ __forceinline__ void estep_epilogue(const EstepArgs &a, long l
             const size_t o = (size_t)b * K + kk[s];
             a.logits[o] = lg[s];
             a.post[o] = post[s];
+            if (a.post_singlets != nullptr && kk[s] < a.G) a.post_singlets[(size_t)b * a.G + kk[s]] = post[s];
         }
         // non-zero bitmap of the singlet columns (the M-step skips exact zeros: (0*keep)^2 = +0)
         const unsigned long long bal = __ballot(live && valid[s] && (li + L * s) < a.G && !(post[s] <= a.nz_floor));

@@ -152,7 +152,6 @@ hipError_t launch_remap_row_offsets(hipStream_t, CallPair *pairs, long long n_pa
 hipError_t launch_f64_to_f32(hipStream_t, const double *, float *, long long) { return hipSuccess; }
 hipError_t launch_f32_to_f64(hipStream_t, const float *, double *, long long) { return hipSuccess; }
 hipError_t launch_delay(hipStream_t, long long) { return hipSuccess; }
-hipError_t launch_wait_count(hipStream_t, const unsigned *, unsigned) { return hipSuccess; }
 hipError_t launch_prior_betas(hipStream_t, const float *, float *, const unsigned long long *, const int *, const int *, const int *,
                               long long, int, double, float *) { return hipSuccess; }
 hipError_t launch_rebuild_nz(hipStream_t, const float *, long long, int, int, float, unsigned long long *, uint2 *) { return hipSuccess; }
@@ -232,6 +231,7 @@ int repack_on_device(dmx_ctx *c, const int32_t *variant, const int32_t *cb, cons
     c->n_bins = 0;
     c->n_tiles = c->bin_rows_cap = 0;
     DMX_TRY(dev_alloc(c, &c->d_csc, (size_t)N));
+    c->n_csc = N;
     for (long long s = 0; s < N; s++) {
         const long long i = perm_v[(size_t)s];
         const float keep = 1.0f - p[i];
@@ -243,6 +243,66 @@ int repack_on_device(dmx_ctx *c, const int32_t *variant, const int32_t *cb, cons
     DMX_TRY(dev_alloc(c, &c->d_item_len, (size_t)c->n_items));
     DMX_TRY(dev_alloc(c, &c->d_item_order, (size_t)c->n_items));
     DMX_TRY(dev_alloc(c, &c->d_item_variant, (size_t)c->n_items));
+    for (long long v = 0; v < V; v++) {
+        long long it = item_ptr[(size_t)v];
+        for (long long s = col_ptr[(size_t)v]; s < col_ptr[(size_t)v + 1]; s += c->item_calls, it++) {
+            c->d_item_variant[it] = (int)v;
+            c->d_item_start[it] = s;
+            c->d_item_len[it] = (int)std::min<long long>(c->item_calls, col_ptr[(size_t)v + 1] - s);
+        }
+    }
+    std::vector<int> order((size_t)c->n_items);
+    std::iota(order.begin(), order.end(), 0);
+    std::stable_sort(order.begin(), order.end(), [&](int x, int y) { return c->d_item_len[x] > c->d_item_len[y]; });
+    if (c->n_items) std::memcpy(c->d_item_order, order.data(), sizeof(int) * (size_t)c->n_items);
+    return 0;
+}
+
+// multi-GPU, M-step records by variant slice: the same derivation as repack_device.hip's, on the host
+int wire_records_of(dmx_ctx *c, long long row_base, uint4 *out, long long capacity)
+{
+    std::memset(out, 0, sizeof(uint4) * (size_t)capacity);
+    for (long long it = 0; it < c->n_items; it++)
+        for (int i = 0; i < c->d_item_len[it]; i++) {
+            const long long s = c->d_item_start[it] + i;
+            out[s] = make_uint4((unsigned)c->d_item_variant[it], c->d_csc[s].x + (unsigned)row_base, c->d_csc[s].y, 1u);
+        }
+    return 0;
+}
+
+int install_mstep_records(dmx_ctx *c, const uint4 *rec, long long n, long long v_lo, long long v_hi)
+{
+    const long long V = c->V;
+    std::vector<long long> keep;
+    for (long long i = 0; i < n; i++)
+        if (rec[i].w != 0u && rec[i].x >= (unsigned)v_lo && rec[i].x < (unsigned)v_hi) keep.push_back(i);
+    std::stable_sort(keep.begin(), keep.end(), [&](long long x, long long y) { return rec[x].x < rec[y].x; });
+    const long long m = (long long)keep.size();
+    dev_free(c, &c->d_csc, (size_t)c->n_csc);
+    dev_free(c, &c->d_item_start, (size_t)c->n_items);
+    dev_free(c, &c->d_item_len, (size_t)c->n_items);
+    dev_free(c, &c->d_item_order, (size_t)c->n_items);
+    dev_free(c, &c->d_item_variant, (size_t)c->n_items);
+    dev_free(c, &c->d_partial, (size_t)c->n_items * c->G);
+    dev_free(c, &c->d_redo, c->cap_redo);
+    c->item_calls = item_calls_for(m);
+    std::vector<long long> col_ptr((size_t)V + 1, 0), item_ptr((size_t)V + 1, 0);
+    for (long long i : keep) col_ptr[(size_t)rec[i].x + 1]++;
+    for (long long v = 0; v < V; v++) col_ptr[(size_t)v + 1] += col_ptr[(size_t)v];
+    for (long long v = 0; v < V; v++)
+        item_ptr[(size_t)v + 1] = item_ptr[(size_t)v] + (col_ptr[(size_t)v + 1] - col_ptr[(size_t)v] + c->item_calls - 1) / c->item_calls;
+    c->n_items = item_ptr[(size_t)V];
+    c->n_csc = m;
+    std::memcpy(c->d_item_ptr, item_ptr.data(), sizeof(long long) * ((size_t)V + 1));
+    DMX_TRY(dev_alloc(c, &c->d_csc, (size_t)m));
+    for (long long s = 0; s < m; s++) c->d_csc[s] = make_uint2(rec[keep[(size_t)s]].y, rec[keep[(size_t)s]].z);
+    DMX_TRY(dev_alloc(c, &c->d_item_start, (size_t)c->n_items));
+    DMX_TRY(dev_alloc(c, &c->d_item_len, (size_t)c->n_items));
+    DMX_TRY(dev_alloc(c, &c->d_item_order, (size_t)c->n_items));
+    DMX_TRY(dev_alloc(c, &c->d_item_variant, (size_t)c->n_items));
+    DMX_TRY(dev_alloc(c, &c->d_partial, (size_t)c->n_items * c->G));
+    c->cap_redo = ((size_t)c->n_items / 2 + 1) * (size_t)c->G;
+    DMX_TRY(dev_alloc(c, &c->d_redo, c->cap_redo));
     for (long long v = 0; v < V; v++) {
         long long it = item_ptr[(size_t)v];
         for (long long s = col_ptr[(size_t)v]; s < col_ptr[(size_t)v + 1]; s += c->item_calls, it++) {

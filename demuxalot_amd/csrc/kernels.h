@@ -44,6 +44,8 @@ struct EstepArgs {
     int prior_dtype;            // DMX_F32 / DMX_F64
     float *logits;              // [B, K]
     float *post;                // [B, K]
+    float *post_singlets;       // nullable [B, G]: the singlet columns once more, row stride G (multi-GPU: this rank's block of the
+                                // table the variant-sharded M-step reads, dmx_api.cpp: shard_mstep_by_variant)
     unsigned long long *nz;     // [B, ceil(G/64)] bit g set <=> !(post[b, g] <= nz_floor) (singlet columns; read by the M-step)
     uint2 *first;               // nullable [B] (G <= 64): {bits of post[b, lowest live genotype], count | first four live
                                 // genotypes} (kernels.hip: nz_code): the M-step's one gather per call
@@ -131,14 +133,6 @@ struct MstepArgs {
     const int *prow;                // nullable [V] row of every variant in the output table
     float *out32;                   // exactly one of the two (or none: item_variant == nullptr)
     double *out64;
-    // Chunked exchange (dmx_api.cpp: run_mstep_chunked): `order` lists the items chunk by chunk (chunk j = entries
-    // [chunk_end[j - 1], chunk_end[j])); the wavefront that finishes an item bumps its chunk's counter, and a one-wavefront
-    // kernel on the exchange stream (launch_wait_count) holds that stream until the chunk's items are all done - chunk j is
-    // combined and reduce-scattered while the launch is still summing the chunks behind it, with no host or event in between.
-    unsigned *chunk_done;           // nullable [n_chunks][CHUNK_SLOTS] items finished per chunk, over hashed counters (one address
-                                    // would serialise 200k atomics: +2 ms measured)
-    int n_chunks;
-    long long chunk_end[16];
     long long n_items;
     long long K;
     unsigned long long post_bytes;  // B * K * 4
@@ -211,10 +205,6 @@ hipError_t launch_remap_row_offsets(hipStream_t st, CallPair *pairs, long long n
 hipError_t launch_f64_to_f32(hipStream_t st, const double *in, float *out, long long n);
 // one wavefront that keeps the stream busy for `ticks` of the constant-rate wall clock (emulated wire: dmx_comm_init_emulated)
 hipError_t launch_delay(hipStream_t st, long long ticks);
-constexpr int CHUNK_SLOTS = 256;
-// one wavefront that holds the stream until the CHUNK_SLOTS counters at `counters` add up to `target` (the counters the
-// M-step's wavefronts bump: MstepArgs::chunk_done)
-hipError_t launch_wait_count(hipStream_t st, const unsigned *counters, unsigned target);
 hipError_t launch_f32_to_f64(hipStream_t st, const float *in, double *out, long long n);
 hipError_t launch_prior_betas(hipStream_t st, const float *betas, float *bsum, const unsigned long long *n_mol,
                               const int *v2snp, const int *snp_ptr, const int *snp_vars, long long V, int G,

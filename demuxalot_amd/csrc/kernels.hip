@@ -841,6 +841,7 @@ __global__ __launch_bounds__(256) void k_softmax_rows(EstepArgs a)
         if (k < K) {
             p = x[k] / tot;
             post[k] = p;
+            if (a.post_singlets != nullptr && k < G) a.post_singlets[(size_t)b * G + k] = p;
         }
         if (k0 < G) {
             const unsigned long long bal = __ballot(k < G && !(p <= a.nz_floor));
@@ -892,62 +893,16 @@ static __device__ __forceinline__ void mstep_terms(const npm::f32x2 (&p)[H][A], 
 // k_mcombine would form is 0.0 + acc = acc), else into the item's partial row.
 static __device__ __forceinline__ void mstep_store(const MstepArgs &a, long long item, int g, double acc)
 {
-    // Chunked exchange (a.chunk_done): the sums are read by the exchange stream's kernels while this launch is still
-    // running, possibly on another XCD, whose L2 is a different one: they are stored with agent scope (written through
-    // this XCD's L2), so that the per-item release below needs no L2 write-back (a __threadfence() per item - a
-    // buffer_wbl2 each - took the M-step from 0.68 to 6.2 ms).
-    const bool through = a.chunk_done != nullptr;
     if (a.item_variant != nullptr) {
         const long long v = a.item_variant[item];
         if (a.item_ptr[v + 1] - a.item_ptr[v] == 1) {
             const size_t o = (size_t)(a.prow ? (long long)a.prow[v] : v) * a.G + g;
-            if (a.out32) {
-                if (through) __hip_atomic_store(a.out32 + o, (float)acc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                else a.out32[o] = (float)acc;
-            } else {
-                if (through) __hip_atomic_store(a.out64 + o, acc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                else a.out64[o] = acc;
-            }
+            if (a.out32) a.out32[o] = (float)acc;
+            else a.out64[o] = acc;
             return;
         }
     }
-    if (through) __hip_atomic_store(a.partial + (size_t)item * a.G + g, acc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    else a.partial[(size_t)item * a.G + g] = acc;
-}
-
-// Chunked exchange: the item at position `slot` of the work list is done (its sums are stored): make them visible and
-// count it for its chunk.  Wave-uniform call after the last store of the wavefront.
-static __device__ __forceinline__ void mstep_item_done(const MstepArgs &a, long long slot)
-{
-    if (a.chunk_done == nullptr) return;
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");  // the wavefront's (write-through) stores are complete before the count
-    if ((threadIdx.x & 63) == 0) {
-        int j = 0;
-        while (j + 1 < a.n_chunks && slot >= a.chunk_end[j]) j++;
-        atomicAdd(a.chunk_done + (size_t)j * CHUNK_SLOTS + (size_t)(slot & (CHUNK_SLOTS - 1)), 1u);
-    }
-}
-
-__global__ __launch_bounds__(64) void k_wait_count(const unsigned *counters, unsigned target)
-{
-    static_assert(CHUNK_SLOTS == 256, "four counters per lane");
-    const int lane = threadIdx.x;
-    for (;;) {
-        unsigned n = 0;
-#pragma unroll
-        for (int q = 0; q < 4; q++) n += __hip_atomic_load(counters + lane + 64 * q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-#pragma unroll
-        for (int off = 1; off < 64; off <<= 1) n += __shfl_xor(n, off);
-        if (n >= target) break;
-        __builtin_amdgcn_s_sleep(16);
-    }
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-}
-
-hipError_t launch_wait_count(hipStream_t st, const unsigned *counters, unsigned target)
-{
-    hipLaunchKernelGGL(k_wait_count, dim3(1), dim3(64), 0, st, counters, target);
-    return hipGetLastError();
+    a.partial[(size_t)item * a.G + g] = acc;
 }
 
 template <int A, int U, bool SQUARE, bool SMALL>
@@ -1034,7 +989,6 @@ __global__ __launch_bounds__(256) void k_mstep(MstepArgs a)
         const int g = lane + 64 * s;
         if (g < G) mstep_store(a, item, g, acc[s]);
     }
-    mstep_item_done(a, slot);
 }
 
 // ------------------------------------------------------------------------------------
@@ -1137,7 +1091,6 @@ __global__ __launch_bounds__(256) void k_mstep_dense(MstepArgs a)
         d_cur = d_nxt;
     }
     if (lane < a.G) mstep_store(a, item, lane, acc);
-    mstep_item_done(a, slot);
 }
 
 // BUF: the three per-lane loads of the call-parallel part (records, barcode code, extra posteriors) as raw buffer
@@ -1417,7 +1370,6 @@ __global__ __launch_bounds__(256) void k_mstep_calls(MstepArgs a)
         for (int t = 0; t < NZ_S; t++) ps0[t] = ps1[t];
     }
     if (lane < G) mstep_store(a, item, lane, acc);
-    mstep_item_done(a, slot);
 }
 
 // one wavefront per (barcode, 64 genotypes): the bitmap and first-posterior table as the E-step writes them

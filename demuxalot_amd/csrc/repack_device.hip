@@ -504,6 +504,7 @@ static int repack_core(dmx_ctx *c, Scratch &sc, const int *d_variant, const int 
 
     // variant-major -> M-step records
     DMX_TRY(dev_alloc(c, &c->d_csc, (size_t)N));
+    c->n_csc = N;
     if (N) hipLaunchKernelGGL(k_build_csc, dim3(grid_for(N)), dim3(256), 0, st, perm_v, d_cb, d_p, N, c->d_csc);
 
     // ---- work items and their length-sorted list ----
@@ -522,6 +523,144 @@ static int repack_core(dmx_ctx *c, Scratch &sc, const int *d_variant, const int 
 
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipStreamSynchronize(st));  // scratch is released by the caller's Scratch
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------
+// Multi-GPU: M-step records by VARIANT SLICE (dmx_api.cpp: shard_mstep_by_variant).  Every rank's variant-major call
+// records travel once, at set-up; each rank keeps the calls of ITS variant slice - from the barcodes of all ranks, the
+// barcode a global row r * rows_per_rank + b - and derives from them what repack_core derives for the M-step: the
+// variant-major records, the work items and their length-sorted list.  The gathered buffer is rank-major and a rank's
+// records are variant-major with ascending barcodes, so the stable sort by variant leaves every variant's calls in
+// ascending GLOBAL barcode order: the reference's np.bincount order (demux.py:113-118) over the whole experiment.
+// ------------------------------------------------------------------------------------
+namespace {
+// record of one call on the wire: {variant, global barcode row, bits of 1 - p_base_wrong, 1 (0: padding)}
+__global__ __launch_bounds__(256) void k_wire_records(const uint2 *__restrict__ csc, const long long *__restrict__ item_start,
+                                                      const int *__restrict__ item_len, const int *__restrict__ item_variant,
+                                                      long long n_items, unsigned row_base, uint4 *__restrict__ out)
+{
+    // one wavefront per work item: its calls are consecutive in csc and belong to one variant
+    const int lane = threadIdx.x & 63;
+    const long long it = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (it >= n_items) return;
+    const long long s0 = item_start[it];
+    const unsigned v = (unsigned)item_variant[it];
+    for (int i = lane; i < item_len[it]; i += 64) {
+        const uint2 r = csc[s0 + i];
+        out[s0 + i] = make_uint4(v, r.x + row_base, r.y, 1u);
+    }
+}
+
+__global__ __launch_bounds__(256) void k_flag_slice(const uint4 *__restrict__ rec, long long n, unsigned v_lo, unsigned v_hi,
+                                                    long long *__restrict__ flag)
+{
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) flag[i] = (rec[i].w != 0u && rec[i].x >= v_lo && rec[i].x < v_hi) ? 1 : 0;
+}
+
+__global__ __launch_bounds__(256) void k_compact_slice(const uint4 *__restrict__ rec, long long n, unsigned v_lo, unsigned v_hi,
+                                                       const long long *__restrict__ pos, unsigned *__restrict__ variant,
+                                                       uint2 *__restrict__ row_keep)
+{
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint4 r = rec[i];
+    if (r.w != 0u && r.x >= v_lo && r.x < v_hi) {
+        variant[pos[i]] = r.x;
+        row_keep[pos[i]] = make_uint2(r.y, r.z);
+    }
+}
+
+__global__ __launch_bounds__(256) void k_permute_records(const unsigned *__restrict__ perm, const uint2 *__restrict__ in, long long n,
+                                                         uint2 *__restrict__ out)
+{
+    const long long s = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (s < n) out[s] = in[perm[s]];
+}
+}  // namespace
+
+// this rank's variant-major records in wire form (16 bytes per call), `capacity` entries, the tail zero (padding)
+int wire_records_of(dmx_ctx *c, long long row_base, uint4 *d_out, long long capacity)
+{
+    hipStream_t st = c->stream;
+    HIP_TRY(hipMemsetAsync(d_out, 0, sizeof(uint4) * (size_t)capacity, st));
+    if (c->n_items)
+        hipLaunchKernelGGL(k_wire_records, dim3(grid_for(c->n_items * 64)), dim3(256), 0, st, c->d_csc, c->d_item_start, c->d_item_len,
+                           c->d_item_variant, c->n_items, (unsigned)row_base, d_out);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+// the records of variants [v_lo, v_hi) among `n` gathered wire records become the context's M-step records
+int install_mstep_records(dmx_ctx *c, const uint4 *d_rec, long long n, long long v_lo, long long v_hi)
+{
+    hipStream_t st = c->stream;
+    const long long V = c->V;
+    Scratch sc(c);
+    long long *flag = nullptr, *pos = nullptr;
+    DMX_TRY(sc.get(&flag, (size_t)n + 1));
+    DMX_TRY(sc.get(&pos, (size_t)n + 1));
+    if (n) hipLaunchKernelGGL(k_flag_slice, dim3(grid_for(n)), dim3(256), 0, st, d_rec, n, (unsigned)v_lo, (unsigned)v_hi, flag);
+    DMX_TRY(scan_with_total(sc, flag, pos, (size_t)n, st));
+    long long m = 0;
+    HIP_TRY(hipMemcpyAsync(&m, pos + n, sizeof(long long), hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    if (m >= (1LL << 32)) return fail(DMX_ERR_UNSUPPORTED, "%lld calls in one variant slice: one context holds fewer than 2^32", m);
+    unsigned *variant = nullptr, *keys_v = nullptr, *iota = nullptr, *perm = nullptr;
+    uint2 *row_keep = nullptr;
+    DMX_TRY(sc.get(&variant, (size_t)m));
+    DMX_TRY(sc.get(&keys_v, (size_t)m));
+    DMX_TRY(sc.get(&iota, (size_t)m));
+    DMX_TRY(sc.get(&perm, (size_t)m));
+    DMX_TRY(sc.get(&row_keep, (size_t)m));
+    if (n) hipLaunchKernelGGL(k_compact_slice, dim3(grid_for(n)), dim3(256), 0, st, d_rec, n, (unsigned)v_lo, (unsigned)v_hi, pos, variant, row_keep);
+    if (m) hipLaunchKernelGGL(k_iota, dim3(grid_for(m)), dim3(256), 0, st, iota, m);
+    DMX_TRY(sort_pairs(sc, variant, keys_v, iota, perm, (size_t)m, bits_for(V ? V - 1 : 0), st));
+    // the old records and items go, the slice's come
+    dev_free(c, &c->d_csc, (size_t)c->n_csc);
+    dev_free(c, &c->d_item_start, (size_t)c->n_items);
+    dev_free(c, &c->d_item_len, (size_t)c->n_items);
+    dev_free(c, &c->d_item_order, (size_t)c->n_items);
+    dev_free(c, &c->d_item_variant, (size_t)c->n_items);
+    dev_free(c, &c->d_partial, (size_t)c->n_items * c->G);
+    dev_free(c, &c->d_redo, c->cap_redo);
+    c->n_items = 0;
+    c->n_csc = 0;
+    c->item_calls = item_calls_for(m);
+    long long *col_ptr = nullptr, *col_items = nullptr;
+    DMX_TRY(sc.get(&col_ptr, (size_t)V + 1));
+    DMX_TRY(sc.get(&col_items, (size_t)V));
+    hipLaunchKernelGGL(k_boundaries, dim3(grid_for(V + 1)), dim3(256), 0, st, keys_v, m, V, col_ptr);
+    if (V)
+        hipLaunchKernelGGL(k_derive_counts, dim3(grid_for(V)), dim3(256), 0, st, col_ptr, V, 1, c->item_calls, col_items, (unsigned *)nullptr,
+                           (unsigned *)nullptr);
+    DMX_TRY(scan_with_total(sc, col_items, c->d_item_ptr, (size_t)V, st));
+    long long n_items = 0;
+    HIP_TRY(hipMemcpyAsync(&n_items, c->d_item_ptr + V, sizeof(long long), hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    if (n_items >= (1LL << 31)) return fail(DMX_ERR_UNSUPPORTED, "too many M-step work items");
+    DMX_TRY(dev_alloc(c, &c->d_csc, (size_t)m));
+    c->n_csc = m;
+    if (m) hipLaunchKernelGGL(k_permute_records, dim3(grid_for(m)), dim3(256), 0, st, perm, row_keep, m, c->d_csc);
+    c->n_items = n_items;
+    DMX_TRY(dev_alloc(c, &c->d_item_start, (size_t)n_items));
+    DMX_TRY(dev_alloc(c, &c->d_item_len, (size_t)n_items));
+    DMX_TRY(dev_alloc(c, &c->d_item_order, (size_t)n_items));
+    DMX_TRY(dev_alloc(c, &c->d_item_variant, (size_t)n_items));
+    DMX_TRY(dev_alloc(c, &c->d_partial, (size_t)n_items * c->G));
+    c->cap_redo = ((size_t)n_items / 2 + 1) * (size_t)c->G;
+    DMX_TRY(dev_alloc(c, &c->d_redo, c->cap_redo));
+    unsigned *inv_i = nullptr, *ids_i = nullptr, *keys_out = nullptr;
+    DMX_TRY(sc.get(&inv_i, (size_t)n_items));
+    DMX_TRY(sc.get(&ids_i, (size_t)n_items));
+    DMX_TRY(sc.get(&keys_out, (size_t)n_items));
+    if (V)
+        hipLaunchKernelGGL(k_build_items, dim3(grid_for(V)), dim3(256), 0, st, col_ptr, c->d_item_ptr, V, c->item_calls, c->d_item_start,
+                           c->d_item_len, inv_i, ids_i, c->d_item_variant);
+    DMX_TRY(sort_pairs(sc, inv_i, keys_out, ids_i, (unsigned *)c->d_item_order, (size_t)n_items, 32, st));
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipStreamSynchronize(st));
     return 0;
 }
 

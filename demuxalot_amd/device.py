@@ -432,11 +432,6 @@ class DeviceContext:
         doublet tables (include/demux_hip.h: dmx_set_estep_packing)."""
         check(self._lib.dmx_set_estep_packing(self._h, {'never': 0, 'auto': 1, 'always': 2, 'split': 3}[mode]))
 
-    def set_exchange_chunks(self, chunks):
-        """Chunked (pipelined) multi-GPU exchange: > 1 cuts every rank slice into that many runs reduced while the next are
-        being summed (include/demux_hip.h: dmx_set_exchange_chunks).  Before the problem / communicator."""
-        check(self._lib.dmx_set_exchange_chunks(self._h, int(chunks)))
-
     def set_estep_schedule(self, schedule):
         """'auto' (default: tile-major schedule where it pays), 'tiled' (whenever built), 'direct' (never);
         include/demux_hip.h: dmx_set_estep_schedule."""

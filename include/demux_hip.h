@@ -349,20 +349,28 @@ int dmx_mstep_f64(dmx_ctx *ctx, double contribution_power, float *addition_out);
 int dmx_mstep_f64_sums(dmx_ctx *ctx, double contribution_power, double *sums_out);
 
 /* ------------------------------------------------------------------------- *
- * Multi-GPU: one ctx per rank, barcodes sharded by the caller (every rank holds the calls of its barcodes, all
- * variants, the whole beta table).  E-step rows need nothing from other ranks; the M-step sums over barcodes, so
- * the per-rank sums are exchanged once per EM iteration, inside dmx_mstep / dmx_probs_from_betas / dmx_em:
- *   reduce-scatter of the partial sums (variant slices cut at SNP boundaries, one per rank)
- *   -> the owner rounds its slice to float32 and runs the P-step (demux.py:267-274) on it
- *   -> all-gather of the float32 genotype_prob slices.
- * When some SNP's variants are not contiguous in the variant numbering the slices cannot be cut and the exchange
- * falls back to an all-reduce of the sums with the P-step on every rank.  Results are the same either way.
+ * Multi-GPU: one ctx per rank, barcodes sharded by the caller (every rank installs the calls of ITS barcodes, all
+ * variants, the whole beta table).  E-step rows need nothing from other ranks.  The M-step (demux.py:113-118) sums over
+ * the calls of a variant, i.e. over the barcodes of all ranks; it is sharded on VARIANTS (slices cut at SNP boundaries,
+ * one per rank):
+ *   set-up (dmx_comm_init* with a problem resident, or installing a problem with a communicator attached): the ranks'
+ *     variant-major call records are all-gathered once; rank r keeps the calls of its variant slice from the barcodes of
+ *     all ranks;
+ *   per EM iteration, inside dmx_mstep / dmx_probs_from_betas / dmx_em / dmx_run_iterations:
+ *     all-gather of what the M-step reads of a barcode (8-byte posterior code, bitmap, singlet posteriors)
+ *     -> rank r sums slice r over ALL barcodes in the reference's order, float64, one rounding: the additions are
+ *        bit-identical to a single-GPU run for any number of ranks - nothing is added across ranks -
+ *     -> P-step (demux.py:267-274) of slice r -> all-gather of the float32 genotype_prob slices.
+ * DEMUXALOT_AMD_EXCHANGE=reduce_scatter selects round 3's exchange instead (M-step on every rank's own barcodes over all
+ * variants, reduce-scatter of the float64 / float32 partial sums over the slices, then as above); =allreduce, or SNPs
+ * whose variants are not contiguous in the variant numbering (no slices can be cut), the all-reduce of the sums with the
+ * P-step on every rank.  reduce_dtype matters for those two only: DMX_F64 exchanges float64 partial sums and rounds once,
+ * DMX_F32 halves the bytes.
  * dmx_comm_unique_id fills 128 bytes on rank 0 (ncclGetUniqueId); the caller broadcasts them and every rank calls
  * dmx_comm_init (before or after installing the problem; once per installed problem).
- * reduce_dtype: DMX_F64 exchanges the float64 partial sums and rounds once (rank-count independent up to float64
- * re-association); DMX_F32 halves the reduce-scatter bytes.
- * Collective calls -- every rank must make them, in the same order: dmx_probs_from_betas, dmx_mstep (all ranks
- * pass addition_out or none does), dmx_em, dmx_run_iterations, dmx_get_addition.
+ * Collective calls -- every rank must make them, in the same order: dmx_set_problem / dmx_pack_*_and_set_problem with a
+ * communicator attached (or dmx_comm_init* with a problem resident), dmx_probs_from_betas, dmx_mstep (all ranks pass
+ * addition_out or none does), dmx_em, dmx_run_iterations, dmx_get_addition.
  * ------------------------------------------------------------------------- */
 /* Which HIP / RCCL runtime files this process has mapped, one "key=path" per line: hip=... (one line per distinct
  * libamdhip64 - exactly one in a healthy process), rccl_mapped=..., rccl_loaded=<the file dmx_comm_* bound, if any>.
@@ -371,14 +379,6 @@ int dmx_mstep_f64_sums(dmx_ctx *ctx, double contribution_power, double *sums_out
  * buffers of one runtime must not be handed to collectives of another.  Environment: DEMUXALOT_AMD_RCCL=<file>,
  * DEMUXALOT_AMD_ALLOW_FOREIGN_RCCL=1. */
 int dmx_runtime_info(char *out, int64_t capacity);
-
-/* Chunked (pipelined) exchange, opt-in; call before a problem is installed / a communicator attached.  chunks > 1: every
- * rank's variant slice is cut into `chunks` runs of rows; the M-step is launched chunk by chunk and a second stream
- * combines, reduce-scatters and stores a chunk while the following ones are being summed (csrc/dmx_api.cpp:
- * run_mstep_chunked).  Same sums, same collectives per row - the results equal the unchunked exchange's bit for bit.
- * Also selected by DEMUXALOT_AMD_EXCHANGE=pipelined[:chunks] (default 4).  Not the default: RCCL on a second stream next
- * to the compute stream has not been run on a multi-GPU node yet. */
-int dmx_set_exchange_chunks(dmx_ctx *ctx, int chunks);
 
 /* Host only: the variant slices dmx_comm_init would cut for nranks ranks: cuts int64[nranks + 1] (first variant of
  * every slice, each at the first variant of a SNP), *slice_rows = rows of the longest slice (nullable),

@@ -49,7 +49,7 @@ def main():
     ap.add_argument('--ranks', default='1,2,4,8')
     ap.add_argument('--modes', default='guarded')
     ap.add_argument('--kinds', default='strong,weak')
-    ap.add_argument('--chunks', type=int, default=0, help='dmx_set_exchange_chunks (0: plain exchange)')
+    ap.add_argument('--exchange', default='', help="DEMUXALOT_AMD_EXCHANGE: '' (default: variant-sharded M-step) | reduce_scatter | allreduce")
     ap.add_argument('--workload', default='em_200k_100k_64', help='a workload of bench.py; with --kinds weak the whole workload is one rank\'s '
                     'share (em_130k_650k_128_doublets = one rank of BASELINE.json configs[4] on 8 GPUs)')
     args = ap.parse_args()
@@ -60,7 +60,9 @@ def main():
     pen = Demultiplexer._doublet_penalties(G, dp)
     counts = np.bincount(whole.compressed_cb, minlength=B)
     out = {'workload': args.workload, 'link_gbytes_per_s': args.link_gbps, 'latency_us': args.latency_us, 'steps': args.steps,
-           'chunks': args.chunks, 'runs': []}
+           'exchange': args.exchange or 'variant-sharded M-step (default)', 'runs': []}
+    if args.exchange:
+        os.environ['DEMUXALOT_AMD_EXCHANGE'] = args.exchange
     base = {}
     for mode in args.modes.split(','):
         for kind in args.kinds.split(','):
@@ -78,8 +80,6 @@ def main():
                     ctx.set_estep_mode(mode)
                     ctx.set_exact_additions(mode == 'exact')
                     if n > 1:
-                        if args.chunks:
-                            ctx.set_exchange_chunks(args.chunks)
                         ctx.comm_init_emulated(0, n, args.link_gbps, args.latency_us, reduce_dtype=wire)
                     ctx.set_problem(problem.n_barcodes, problem.n_variants, G, problem.variant_id, problem.compressed_cb, problem.p_base_wrong, problem.v2snp)
                     ctx.set_betas(betas)

@@ -5,7 +5,8 @@ stubbed at link time (csrc/host_stubs.cpp: device memory is malloc memory, the k
   1. a fuzz of dmx_pack_calls_host against the oracle's match + de-duplication (bit-exact),
   2. a fuzz of dmx_exchange_slices against its definition,
   3. whole "runs" of the context API (problem, betas, P / E / M steps, fused EM, results, timers, cache) on random
-     problems, single and with host-staged collectives of 2 .. 5 ranks, plain and chunked exchange,
+     problems, single and with host-staged collectives of 2 .. 5 ranks (variant-sharded M-step, reduce-scatter and
+     all-reduce exchange),
   4. the error contract: bad sizes, null pointers, calls out of order.
 
 Results of (3) are meaningless (no kernel runs); what counts is that AddressSanitizer / UBSan stay silent - any report
@@ -130,10 +131,10 @@ def run_contexts(rng, rounds):
         rank = int(rng.integers(0, world))
         ctx = DeviceContext(0)
         try:
+            os.environ['DEMUXALOT_AMD_EXCHANGE'] = str(rng.choice(['variant', 'variant', 'reduce_scatter', 'allreduce']))
             if world > 1 or rng.random() < 0.3:
                 def collective(op, array):  # the other ranks "send zeros": nothing to add, nothing to fill
                     assert array.flags.writeable and array.size >= 0
-                ctx.set_exchange_chunks(int(rng.choice([0, 0, 2, 4, 16])))
                 if rng.random() < 0.3:
                     ctx.comm_init_emulated(rank, world, 50., 10., reduce_dtype=str(rng.choice(['f64', 'f32'])))
                 else:
@@ -198,7 +199,7 @@ def error_contract(lib):
                        ('dmx_get_block', (ctx._h, 7, 0, 0, 0, 0, None)), ('dmx_set_estep_mode', (ctx._h, 9)),
                        ('dmx_set_estep_mode', (None, 0)), ('dmx_comm_init_host', (ctx._h, 3, 2, None, None, 1)),
                        ('dmx_exchange_slices', (-1, None, 1, None, None, None)), ('dmx_trim_device_caches', (99, None)),
-                       ('dmx_set_exchange_chunks', (ctx._h, 99)), ('dmx_runtime_info', (None, 0))):
+                       ('dmx_runtime_info', (None, 0))):
         assert getattr(lib, name)(*args) != 0, name
         assert lib.dmx_last_error()
     ctx.set_problem(3, 2, 2, np.array([0, 1, 1], dtype=np.int32), np.array([0, 1, 2], dtype=np.int32), np.array([.1, .2, .3], dtype=np.float32),
