@@ -13,8 +13,10 @@ softmax, M-step (+ the exchange of the beta additions when N > 1).  Workload (BA
 N > 1, `scaling`: the headline `value` is BASELINE.json configs[3] AS WRITTEN - the ONE 200k-barcode experiment cut into
 N barcode ranges with equal numbers of calls ("strong"); the `weak` object of the same line is the workload per GPU
 (every rank a 200k-barcode shard of an N x 200k-barcode experiment).  The experiment is generated once (rank 0, handed to
-the other ranks through /dev/shm).  The per-iteration exchange - reduce-scatter of the additions over variant slices,
-P-step on the owned slice, all-gather of genotype_prob - runs inside libdemux_hip.so (include/demux_hip.h "Multi-GPU").
+the other ranks through /dev/shm).  The per-iteration exchange runs inside libdemux_hip.so (include/demux_hip.h
+"Multi-GPU"): the M-step sharded on variants (all-gather of what it reads of every barcode; additions bit-identical to one
+GPU) or, where that would move more bytes (weak scaling), the reduce-scatter of the per-rank sums; then the P-step on the
+owned variant slice and the all-gather of genotype_prob.
 
 E-step arithmetic: the library's default, the GUARDED mode (contract of the path proven per barcode, the rest redone
 bit-exactly: include/demux_hip.h DMX_ESTEP_GUARDED); `exact_mode` = the same timed region with every logit / posterior
@@ -528,7 +530,7 @@ def main():
         region = timed_region(ctx, plane, args.steps, args.warmup)
         barcodes_total = B_workload if (kind == 'strong' or world == 1) else B_workload * world
         region.update(value=barcodes_total * args.steps / region['elapsed'], barcodes_total=barcodes_total,
-                      barcodes_per_gpu=problem.n_barcodes, calls_per_gpu=problem.n_calls)
+                      barcodes_per_gpu=problem.n_barcodes, calls_per_gpu=problem.n_calls, exchange=ctx.exchange_mode())
         regions[kind] = region
     head_kind = kinds[0]
     head = regions[head_kind]
@@ -605,7 +607,11 @@ def main():
             'config': {'workload': args.workload, 'barcodes_total': head['barcodes_total'], 'barcodes_per_gpu': head['barcodes_per_gpu'],
                        'snps': S, 'variants': V, 'genotypes': G, 'options': K, 'calls_per_gpu': head['calls_per_gpu'], 'doublet_prior': dp,
                        'estep_mode': default_mode + mode_notes[default_mode],
-                       'parallelism': f'barcode shards x{world}' + (f', {"host-staged" if args.host_plane else "RCCL"} reduce-scatter {args.reduce_dtype} + all-gather f32 of variant slices' if use_dist else ''),
+                       'parallelism': f'barcode shards x{world}' + (
+                           {'variant': ', M-step sharded on variants: all-gather of posterior codes / bitmaps / singlet posteriors, all-gather f32 of genotype_prob slices',
+                            'reduce_scatter': f', reduce-scatter {args.reduce_dtype} of the partial sums + all-gather f32 of genotype_prob slices',
+                            'allreduce': f', all-reduce {args.reduce_dtype} of the partial sums'}.get(head.get('exchange'), '')
+                           + (' (host-staged)' if args.host_plane else ' (RCCL)') if use_dist else ''),
                        'runtimes': runtimes, **({'rccl_fallback': rccl_fallback} if rccl_fallback else {})},
             'em_iterations_per_s': head['em_iterations_per_s'],
             'kernel_ms': head['kernel_ms'],
@@ -615,7 +621,7 @@ def main():
         }
         if 'weak' in regions and head_kind != 'weak':
             out['weak'] = {k: regions['weak'][k] for k in ('value', 'ms_per_step', 'em_iterations_per_s', 'barcodes_total', 'barcodes_per_gpu',
-                                                           'calls_per_gpu', 'kernel_ms', 'exchange_ms_per_step', 'guard')}
+                                                           'calls_per_gpu', 'kernel_ms', 'exchange_ms_per_step', 'guard', 'exchange')}
             out['weak']['note'] = ('the workload per GPU: every rank holds a 200k-barcode shard (a copy of the generated one) of an '
                                    'N x 200k-barcode experiment')
         for mode, region in extra_modes.items():

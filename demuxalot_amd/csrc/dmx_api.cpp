@@ -826,7 +826,12 @@ int gather_numbers(dmx_ctx *c, const long long *values, int count, std::vector<l
 //              are BIT-IDENTICAL to a single-GPU run whatever the number of ranks, nothing is added across ranks
 //     P-step   of slice r, then the all-gather of genotype_prob as before
 // ------------------------------------------------------------------------------------
-int shard_mstep_by_variant(dmx_ctx *c)
+// force: DEMUXALOT_AMD_EXCHANGE=variant.  Otherwise the exchange with fewer bytes on the wire per iteration is taken: what
+// the M-step reads of ALL barcodes (4 G + 8 + 8 W bytes each: grows with the barcodes of the whole job) against the
+// [V, G] partial sums of the reduce-scatter (fixed).  One 200k-barcode experiment over n GPUs: the posteriors (54 MB
+// against 51 / 102 MB of float32 / float64 sums) - and the M-step then walks whole variants instead of 1 / n of each;
+// n x 200k barcodes (weak scaling): the sums.  Every rank sees the same sizes and decides alike.
+int shard_mstep_by_variant(dmx_ctx *c, bool force)
 {
     const int n = c->nranks, G = c->G, W = (G + 63) / 64;
     hipStream_t st = c->stream;
@@ -839,6 +844,9 @@ int shard_mstep_by_variant(dmx_ctx *c)
         calls_pad = std::max(calls_pad, all[(size_t)2 * r + 1]);
     }
     if (rows_pad * n >= (1LL << 31)) return fail(DMX_ERR_UNSUPPORTED, "%lld barcode rows over all ranks exceed int32", rows_pad * n);
+    const double posterior_bytes = (double)rows_pad * n * (4.0 * G + 8.0 + 8.0 * W);
+    const double sum_bytes = (double)c->V * G * (c->reduce_dtype == DMX_F64 ? 8.0 : 4.0);
+    if (!force && posterior_bytes > 1.1 * sum_bytes) return 0;  // the reduce-scatter of the sums moves less
     // the call records of every rank
     uint4 *wire = nullptr;
     const size_t wire_bytes = sizeof(uint4) * (size_t)calls_pad * n;
@@ -920,9 +928,10 @@ int layout_exchange(dmx_ctx *c)
         c->bytes += (int64_t)c->recv_bytes;
         HIP_TRY(hipMemsetAsync(c->d_exch, 0, c->exch_bytes, st));  // padding rows stay zero
         HIP_TRY(hipStreamSynchronize(st));                          // `prow` is a local
-        // DEMUXALOT_AMD_EXCHANGE=reduce_scatter keeps the M-step on every rank's own barcodes and reduce-scatters the sums
+        // DEMUXALOT_AMD_EXCHANGE=reduce_scatter keeps the M-step on every rank's own barcodes and reduce-scatters the sums;
+        // =variant shards the M-step on variants whatever the sizes; default: whichever moves fewer bytes per iteration
         const bool by_sums = exchange && std::strcmp(exchange, "reduce_scatter") == 0;
-        if (n > 1 && !by_sums) DMX_TRY(shard_mstep_by_variant(c));
+        if (n > 1 && !by_sums) DMX_TRY(shard_mstep_by_variant(c, exchange && std::strcmp(exchange, "variant") == 0));
     }
     c->add_partial = false;
     return 0;
@@ -2079,6 +2088,13 @@ int dmx_comm_init_emulated(dmx_ctx *c, int rank, int nranks, double link_gbytes_
     c->nranks = nranks;
     c->reduce_dtype = reduce_dtype;
     if (c->have_problem) DMX_TRY(layout_exchange(c));
+    return 0;
+}
+
+int dmx_get_exchange_mode(dmx_ctx *c, int32_t *mode)
+{
+    if (!c || !mode) return fail(DMX_ERR_INVALID, "null argument");
+    *mode = !c->attached() ? DMX_EXCHANGE_NONE : c->mshard ? DMX_EXCHANGE_VARIANT : c->sliced ? DMX_EXCHANGE_REDUCE_SCATTER : DMX_EXCHANGE_ALLREDUCE;
     return 0;
 }
 

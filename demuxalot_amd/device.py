@@ -400,6 +400,13 @@ class DeviceContext:
         check(self._lib.dmx_comm_init_emulated(self._h, int(rank), int(nranks), float(link_gbytes_per_s), float(latency_us),
                                                DMX_F64 if reduce_dtype == 'f64' else DMX_F32))
 
+    def exchange_mode(self):
+        """None (no communicator) | 'variant' (M-step sharded on variants, posteriors all-gathered) | 'reduce_scatter' |
+        'allreduce' (exchanges of the per-rank sums); include/demux_hip.h: dmx_get_exchange_mode."""
+        mode = ctypes.c_int32(0)
+        check(self._lib.dmx_get_exchange_mode(self._h, ctypes.byref(mode)))
+        return {0: None, 1: 'variant', 2: 'reduce_scatter', 3: 'allreduce'}[mode.value]
+
     def set_estep_mode(self, mode):
         """'exact' (logits / posteriors bit-identical to the reference), 'guarded' (tolerance-mode arithmetic, every
         barcode whose posteriors are not provably within the contract's 1e-5 of the reference's - or whose argmax could

@@ -361,17 +361,29 @@ int dmx_mstep_f64_sums(dmx_ctx *ctx, double contribution_power, double *sums_out
  *     -> rank r sums slice r over ALL barcodes in the reference's order, float64, one rounding: the additions are
  *        bit-identical to a single-GPU run for any number of ranks - nothing is added across ranks -
  *     -> P-step (demux.py:267-274) of slice r -> all-gather of the float32 genotype_prob slices.
- * DEMUXALOT_AMD_EXCHANGE=reduce_scatter selects round 3's exchange instead (M-step on every rank's own barcodes over all
- * variants, reduce-scatter of the float64 / float32 partial sums over the slices, then as above); =allreduce, or SNPs
- * whose variants are not contiguous in the variant numbering (no slices can be cut), the all-reduce of the sums with the
- * P-step on every rank.  reduce_dtype matters for those two only: DMX_F64 exchanges float64 partial sums and rounds once,
- * DMX_F32 halves the bytes.
+ * That exchange moves 4 G + 8 + 8 ceil(G / 64) bytes per barcode OF THE WHOLE JOB.  When that is more than 1.1 x the
+ * [V, G] partial sums (many more barcodes than variants: n x 200k-barcode weak scaling), the exchange of the sums is
+ * taken instead: M-step on every rank's own barcodes over all variants, reduce-scatter of the float64 / float32 partial
+ * sums over the slices, then P-step and all-gather as above (per-rank sums are added: results within a float32 ulp of
+ * the single-GPU ones, not bit-identical).  Every rank sees the same sizes and decides alike.
+ * DEMUXALOT_AMD_EXCHANGE = variant | reduce_scatter forces either; = allreduce, or SNPs whose variants are not
+ * contiguous in the variant numbering (no slices can be cut): all-reduce of the sums, P-step on every rank.
+ * reduce_dtype matters for the exchanges of sums only: DMX_F64 exchanges float64 partial sums and rounds once, DMX_F32
+ * halves the bytes.
  * dmx_comm_unique_id fills 128 bytes on rank 0 (ncclGetUniqueId); the caller broadcasts them and every rank calls
  * dmx_comm_init (before or after installing the problem; once per installed problem).
  * Collective calls -- every rank must make them, in the same order: dmx_set_problem / dmx_pack_*_and_set_problem with a
  * communicator attached (or dmx_comm_init* with a problem resident), dmx_probs_from_betas, dmx_mstep (all ranks pass
  * addition_out or none does), dmx_em, dmx_run_iterations, dmx_get_addition.
  * ------------------------------------------------------------------------- */
+/* The exchange the resident problem runs (see above): no communicator, or with one attached the M-step sharded on
+ * variants / the reduce-scatter of the sums / the all-reduce of the sums (with one rank nothing travels either way). */
+#define DMX_EXCHANGE_NONE 0
+#define DMX_EXCHANGE_VARIANT 1
+#define DMX_EXCHANGE_REDUCE_SCATTER 2
+#define DMX_EXCHANGE_ALLREDUCE 3
+int dmx_get_exchange_mode(dmx_ctx *ctx, int32_t *mode);
+
 /* Which HIP / RCCL runtime files this process has mapped, one "key=path" per line: hip=... (one line per distinct
  * libamdhip64 - exactly one in a healthy process), rccl_mapped=..., rccl_loaded=<the file dmx_comm_* bound, if any>.
  * RCCL is always taken from the directory of the HIP runtime libdemux_hip.so itself resolved, and dmx_comm_unique_id /
