@@ -49,6 +49,8 @@ struct RcclApi {
     ncclResult_t (*ReduceScatter)(const void *, void *, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
     ncclResult_t (*AllGather)(const void *, void *, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
     ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+    ncclResult_t (*GroupStart)() = nullptr;
+    ncclResult_t (*GroupEnd)() = nullptr;
     const char *(*GetErrorString)(ncclResult_t) = nullptr;
     std::string path;
 };
@@ -112,6 +114,8 @@ int load_rccl()
     g_rccl.AllGather = (decltype(g_rccl.AllGather))dlsym(h, "ncclAllGather");
     g_rccl.CommDestroy = (decltype(g_rccl.CommDestroy))dlsym(h, "ncclCommDestroy");
     g_rccl.GetErrorString = (decltype(g_rccl.GetErrorString))dlsym(h, "ncclGetErrorString");
+    g_rccl.GroupStart = (decltype(g_rccl.GroupStart))dlsym(h, "ncclGroupStart");
+    g_rccl.GroupEnd = (decltype(g_rccl.GroupEnd))dlsym(h, "ncclGroupEnd");
     if (!g_rccl.GetUniqueId || !g_rccl.CommInitRank || !g_rccl.AllReduce || !g_rccl.ReduceScatter || !g_rccl.AllGather ||
         !g_rccl.CommDestroy) {
         dlclose(h);
@@ -740,8 +744,30 @@ int host_collective(dmx_ctx *c, int op, const void *src, size_t off_in, size_t b
 int emulated_wire(dmx_ctx *c, size_t block_bytes, int rounds, hipStream_t st)
 {
     if (c->nranks <= 1) return 0;
-    const double ns = rounds * (c->emu_latency_us * 1e3 + (double)block_bytes / c->emu_link_gbps);
+    // inside a group (coll_group_begin) the collectives are one launch: the latency is paid by the first only
+    const double latency = c->in_group && c->group_paid ? 0.0 : c->emu_latency_us * 1e3;
+    c->group_paid = true;
+    const double ns = rounds * (latency + (double)block_bytes / c->emu_link_gbps);
     HIP_TRY(dmx::launch_delay(st, (long long)(ns * c->emu_ticks_per_ns)));
+    return 0;
+}
+
+// Several collectives as one launch (ncclGroupStart / ncclGroupEnd); the host-staged and emulated backends run them one
+// after the other.
+void coll_group_begin(dmx_ctx *c)
+{
+    c->in_group = true;
+    c->group_paid = false;
+    if (c->comm && g_rccl.GroupStart) (void)g_rccl.GroupStart();
+}
+
+int coll_group_end(dmx_ctx *c)
+{
+    c->in_group = false;
+    if (c->comm && g_rccl.GroupEnd) {
+        ncclResult_t r = g_rccl.GroupEnd();
+        if (r != ncclSuccess) return fail(DMX_ERR_RCCL, "ncclGroupEnd failed: %s", rccl_error(r));
+    }
     return 0;
 }
 
@@ -1220,9 +1246,12 @@ int gather_posteriors(dmx_ctx *c)
         }
         c->emu_post_filled = true;
     }
+    coll_group_begin(c);  // one launch for the three tables
     rc = coll_all_gather(c, (float *)c->d_first_g, rows * 2, "posterior codes");
     if (rc == 0) rc = coll_all_gather(c, (float *)c->d_nz_g, rows * W * 2, "posterior bitmaps");
     if (rc == 0) rc = coll_all_gather(c, c->d_post_g, rows * G, "singlet posteriors");
+    const int rc_end = coll_group_end(c);
+    if (rc == 0) rc = rc_end;
     timer_end(c, DMX_T_ALLREDUCE, ev);
     if (rc) return rc;
     c->post_gathered = true;

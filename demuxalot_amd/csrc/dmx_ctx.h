@@ -154,6 +154,7 @@ struct dmx_ctx {
     // exchange a schedule leaves exposed on a box with one GPU; the results of such a run are not a real EM.
     bool emulated = false;
     double emu_link_gbps = 50.0, emu_latency_us = 10.0;
+    bool in_group = false, group_paid = false;  // coll_group_begin .. coll_group_end: several collectives, one launch
     bool emu_table_filled = false;            // the other ranks' slices of genotype_prob hold the table without addition
     double emu_ticks_per_ns = 0.1;            // wall-clock ticks of the delay kernel per nanosecond
     bool attached() const { return comm != nullptr || host_coll != nullptr || emulated; }

@@ -5,6 +5,7 @@ import os
 import sys
 import time
 import numpy as np
+os.environ.setdefault('DEMUXALOT_AMD_ESTEP', 'exact')  # bitwise comparisons: the exact mode (the library's default is the guarded one)
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, root)
 sys.path.insert(0, os.path.join(root, 'tests'))

@@ -6,7 +6,7 @@ R=${GRAFT_REPO_ROOT:-/root/repo}
 OUT=$R/gpurun_out/r4_prof
 mkdir -p $OUT
 for WL in "$@"; do
-  rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/$WL -- python3 $R/bench.py --workload $WL --steps 10 --warmup 2 --no-cpu-baseline --no-e2e --no-live-traffic > $OUT/bench_line_$WL.json 2> $OUT/bench_$WL.err
+  rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/$WL -- python3 $R/bench.py --workload $WL --steps ${STEPS:-10} --warmup 2 --no-cpu-baseline --no-e2e --no-live-traffic > $OUT/bench_line_$WL.json 2> $OUT/bench_$WL.err
   f=$(find $OUT/$WL -name '*kernel_stats.csv' | head -1)
   [ -n "$f" ] && python3 - "$f" > $OUT/kernel_stats_$WL.csv <<'PY'
 import csv, sys
@@ -14,6 +14,9 @@ rows = list(csv.DictReader(open(sys.argv[1])))
 w = csv.writer(sys.stdout)
 w.writerow(['Name', 'Calls', 'TotalDurationNs', 'AverageNs', 'Percentage', 'MinNs', 'MaxNs'])
 for r in rows:
-    w.writerow([r['Name'].split('(')[0], r['Calls'], r['TotalDurationNs'], r['AverageNs'], r['Percentage'], r['MinNs'], r['MaxNs']])
+    name = r['Name'].replace('(anonymous namespace)::', '').split('(')[0]
+    if 'rocprim' in name:
+        name = 'rocprim::' + name.split('rocprim::')[-1][:60] + ' (device repack)'
+    w.writerow([name, r['Calls'], r['TotalDurationNs'], r['AverageNs'], r['Percentage'], r['MinNs'], r['MaxNs']])
 PY
 done
