@@ -219,14 +219,23 @@ static __device__ __forceinline__ void estep_flush(float (&prod)[A], FastAcc (&a
 // ------------------------------------------------------------------------------------
 struct FastBatch {
     npm::f32x2 p[4];  // gathered genotype probabilities of the batch's 8 calls (call 2q in .x, 2q+1 in .y)
-    int rec;          // the batch's records: lane l holds dword l of its 4 CallPairs
 };
 
-template <typename OnGroup>
+// HALF (tables of 17 .. 32 genotypes): a 256-byte gather holds the rows of TWO calls - lanes 0 .. 31 take the even call of
+// a pair, lanes 32 .. 63 the odd one (the row offset, keep and floor of a lane's call selected per half with v_cndmask) -,
+// so a batch of 8 calls is 4 gathers and every lane multiplies the 4 terms of its half; the two halves' sums are added
+// when the barcode is finished.  Half the gathers per call of the one-call-per-gather form.
+template <bool HALF, typename OnGroup>
 static __device__ __forceinline__ void fast_walk_single(const CallPair *__restrict__ recs, int n_batches,
                                                         __amdgpu_buffer_rsrc_t rsrc, unsigned lane_off, int lane, float &prod,
-                                                        FastAcc &facc, OnGroup on_group)
+                                                        FastAcc &facc, unsigned *ring, OnGroup on_group)
 {
+    // The records of a batch reach every lane through LDS: the batch's 32 dwords (one per lane, loaded batches ahead)
+    // are written to one of four 128-byte slots of the wavefront and read back as broadcast reads - row offsets when the
+    // gathers are issued, keep / floor when the batch is consumed.  [Until round 4 the fields were moved to SGPRs with 24
+    // v_readlane per 8 calls, ~9 issue cycles each: 0.9 ms of the kernel's 1.45 - it was bound by those, not by the
+    // gathers: a variant with HALF the gathers per call (below) took just as long.]
+    const bool hi = lane >= 32;
     if (n_batches <= 0) return;
     const unsigned *__restrict__ words = (const unsigned *)recs;
     const int l32 = lane & 31;
@@ -234,27 +243,36 @@ static __device__ __forceinline__ void fast_walk_single(const CallPair *__restri
         const int kk = k < n_batches ? k : n_batches - 1;
         return (int)__builtin_nontemporal_load(&words[(size_t)kk * 32 + l32]);  // read once: keep the table rows in L2
     };
-    auto issue = [&](int w, FastBatch &g) {  // row offsets of a batch -> SGPRs -> its 8 gathers in flight
-        g.rec = w;
+    auto issue = [&](int w, FastBatch &g, int slot) {  // records -> LDS slot; row offsets back -> the batch's gathers in flight
+        unsigned *rec = ring + slot * 32;
+        rec[l32] = (unsigned)w;
 #pragma unroll
         for (int q = 0; q < 4; q++) {
-            const int r0 = __builtin_amdgcn_readlane(w, 8 * q), r1 = __builtin_amdgcn_readlane(w, 8 * q + 1);
-            g.p[q].x = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, (int)lane_off, r0, 0));
-            g.p[q].y = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, (int)lane_off, r1, 0));
+            const uint2 ro = *(const uint2 *)(rec + 8 * q);
+            if constexpr (HALF) {
+                g.p[q].x = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, (int)(lane_off + (hi ? ro.y : ro.x)), 0, 0));
+            } else {
+                g.p[q].x = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, (int)(lane_off + ro.x), 0, 0));
+                g.p[q].y = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, (int)(lane_off + ro.y), 0, 0));
+            }
         }
     };
-    auto consume = [&](int k, const FastBatch &g) {
-        on_group(k, __builtin_amdgcn_readlane(g.rec, 6));
+    auto consume = [&](int k, const FastBatch &g, int slot) {
+        const unsigned *rec = ring + slot * 32;
+        on_group(k, __builtin_amdgcn_readfirstlane((int)rec[6]));
 #pragma unroll
         for (int q = 0; q < 4; q++) {
-            npm::f32x2 keep, flo;
-            keep.x = __builtin_bit_cast(float, __builtin_amdgcn_readlane(g.rec, 8 * q + 2));
-            keep.y = __builtin_bit_cast(float, __builtin_amdgcn_readlane(g.rec, 8 * q + 3));
-            flo.x = __builtin_bit_cast(float, __builtin_amdgcn_readlane(g.rec, 8 * q + 4));
-            flo.y = __builtin_bit_cast(float, __builtin_amdgcn_readlane(g.rec, 8 * q + 5));
-            npm::f32x2 t = g.p[q] * keep;
-            t = t + flo;
-            prod = (prod * t.x) * t.y;
+            const npm::f32x2 keep = *(const npm::f32x2 *)(rec + 8 * q + 2);
+            const npm::f32x2 flo = *(const npm::f32x2 *)(rec + 8 * q + 4);
+            if constexpr (HALF) {
+                float t = g.p[q].x * (hi ? keep.y : keep.x);
+                t = t + (hi ? flo.y : flo.x);
+                prod = prod * t;
+            } else {
+                npm::f32x2 t = g.p[q] * keep;
+                t = t + flo;
+                prod = (prod * t.x) * t.y;
+            }
         }
         const float m = __builtin_amdgcn_frexp_mantf(prod);
         facc.expo += __builtin_amdgcn_frexp_expf(prod);
@@ -262,31 +280,31 @@ static __device__ __forceinline__ void fast_walk_single(const CallPair *__restri
         prod = 1.0f;
     };
     // records of batches k+4 .. k+7 on their way, gathers of batches k+1 .. k+3 in flight while batch k is consumed;
-    // the loop is unrolled by 4 so that every ring slot is a fixed register
+    // the loop is unrolled by 4 so that every ring slot is a fixed register (and a fixed LDS slot)
     int w0 = fetch(0), w1 = fetch(1), w2 = fetch(2), w3 = fetch(3);
     FastBatch g0, g1, g2, g3;
-    issue(w0, g0);
+    issue(w0, g0, 0);
     w0 = fetch(4);
-    issue(w1, g1);
+    issue(w1, g1, 1);
     w1 = fetch(5);
-    issue(w2, g2);
+    issue(w2, g2, 2);
     w2 = fetch(6);
     for (int k = 0; k < n_batches; k += 4) {
-        issue(w3, g3);
+        issue(w3, g3, 3);
         w3 = fetch(k + 7);
-        consume(k, g0);
+        consume(k, g0, 0);
         if (k + 1 >= n_batches) break;
-        issue(w0, g0);
+        issue(w0, g0, 0);
         w0 = fetch(k + 8);
-        consume(k + 1, g1);
+        consume(k + 1, g1, 1);
         if (k + 2 >= n_batches) break;
-        issue(w1, g1);
+        issue(w1, g1, 1);
         w1 = fetch(k + 9);
-        consume(k + 2, g2);
+        consume(k + 2, g2, 2);
         if (k + 3 >= n_batches) break;
-        issue(w2, g2);
+        issue(w2, g2, 2);
         w2 = fetch(k + 10);
-        consume(k + 3, g3);
+        consume(k + 3, g3, 3);
     }
 }
 
@@ -409,6 +427,74 @@ __global__ __launch_bounds__(256) void k_estep_direct(EstepArgs a)
         row_calls = n;
         const unsigned *__restrict__ words = (const unsigned *)(a.pairs + pbeg);
         const int nmax = group_max_over_wave<L>(n);
+        if constexpr (FAST) {
+            // Tolerance arithmetic: a few instructions per term, so what the loop waits for is memory.  Two stages in
+            // flight: the record fields of the NEXT chunk of L calls (one call per lane), and the row gathers of the NEXT
+            // batch of U calls, both requested before the current batch is consumed (200k x 100k x 32: 1.30 -> see
+            // DESIGN.md 4.1).  Batches alternate between two fixed register sets (compile-time unrolled).
+            constexpr int H = U / 2;
+            struct Batch {
+                npm::f32x2 p1[H][A], p2[H][A], keep[H], flo[H];
+            };
+            auto load_fields = [&](int c0, unsigned &ro, float &kp, float &fl) {
+                const int ci = c0 + li;
+                const bool mine = ci < n;
+                const int w = mine ? (ci >> 1) * 8 + (ci & 1) : 0;
+                ro = 0u;
+                kp = 0.0f;
+                fl = 1.0f;
+                if (mine) {
+                    ro = words[w];
+                    kp = __uint_as_float(words[w + 2]);
+                    fl = __uint_as_float(words[w + 4]);
+                }
+            };
+            auto issue = [&](Batch &x, unsigned ro_v, float keep_v, float floor_v, int i0) {
+#pragma unroll
+                for (int q = 0; q < H; q++) {
+                    const unsigned ro0 = group_bcast<L>(ro_v, i0 + 2 * q, gbase);
+                    const unsigned ro1 = group_bcast<L>(ro_v, i0 + 2 * q + 1, gbase);
+                    x.keep[q].x = group_bcast<L>(keep_v, i0 + 2 * q, gbase);
+                    x.keep[q].y = group_bcast<L>(keep_v, i0 + 2 * q + 1, gbase);
+                    x.flo[q].x = group_bcast<L>(floor_v, i0 + 2 * q, gbase);
+                    x.flo[q].y = group_bcast<L>(floor_v, i0 + 2 * q + 1, gbase);
+#pragma unroll
+                    for (int s = 0; s < A; s++) {
+                        x.p1[q][s].x = *(const float *)(prob + (ro0 + o1[s]));
+                        x.p1[q][s].y = *(const float *)(prob + (ro1 + o1[s]));
+                        if (PAIRS) {
+                            x.p2[q][s].x = *(const float *)(prob + (ro0 + o2[s]));
+                            x.p2[q][s].y = *(const float *)(prob + (ro1 + o2[s]));
+                        }
+                    }
+                }
+            };
+            auto consume = [&](const Batch &x, int pos) {
+                estep_products<A, PAIRS, H>(x.p1, x.p2, x.keep, x.flo, prod, n_slots);
+                if (((pos + U) & 7) == 0) estep_flush<A>(prod, facc, n_slots);
+            };
+            unsigned ro_c, ro_n = 0u;
+            float keep_c, keep_n = 0.0f, floor_c, floor_n = 1.0f;
+            load_fields(0, ro_c, keep_c, floor_c);
+            for (int c0 = 0; c0 < nmax; c0 += L) {
+                if (c0 + L < nmax) load_fields(c0 + L, ro_n, keep_n, floor_n);
+                const int cnt = (nmax - c0) < L ? (nmax - c0) : L;  // a multiple of U (rows are padded to 8 calls)
+                Batch x, y;
+                issue(x, ro_c, keep_c, floor_c, 0);
+#pragma unroll
+                for (int i0 = 0; i0 < L; i0 += 2 * U) {
+                    if (i0 >= cnt) break;
+                    if (i0 + U < cnt) issue(y, ro_c, keep_c, floor_c, i0 + U);
+                    consume(x, c0 + i0);
+                    if (i0 + U >= cnt) break;
+                    if (i0 + 2 * U < cnt) issue(x, ro_c, keep_c, floor_c, i0 + 2 * U);
+                    consume(y, c0 + i0 + U);
+                }
+                ro_c = ro_n;
+                keep_c = keep_n;
+                floor_c = floor_n;
+            }
+        } else
         for (int c0 = 0; c0 < nmax; c0 += L) {
             // fields of call c0 + li of this group's row; groups that are done feed neutral calls
             const int ci = c0 + li;
@@ -515,10 +601,12 @@ __global__ __launch_bounds__(256) void k_estep_join(EstepArgs a)
 // change it is swapped with the slot's copy in LDS.  Every barcode's calls are still added strictly in order, so
 // the sums are bit-identical to the direct form's.
 // ------------------------------------------------------------------------------------
-template <int A, bool FAST>
+template <int A, bool FAST, bool HALF = false>
 __global__ __launch_bounds__(256) void k_estep_tiled(EstepArgs a)
 {
+    static_assert(!HALF || (A == 1 && FAST), "two calls per gather: tolerance arithmetic, tables of at most 32 genotypes");
     __shared__ double sh_acc[4][TILE_R_MAX][A][64];
+    __shared__ unsigned sh_rec[4][4 * 32];  // fast_walk_single: four batches of records per wavefront
     const int lane = threadIdx.x & 63;
     const int K = a.K;
     const int R = a.bin_rows_cap;
@@ -536,6 +624,7 @@ __global__ __launch_bounds__(256) void k_estep_tiled(EstepArgs a)
         valid[s] = k < K;
         kk[s] = valid[s] ? k : K - 1;
         o1[s] = (unsigned)kk[s] * 4u;
+        if (HALF) o1[s] = (unsigned)min(lane & 31, K - 1) * 4u;  // both halves of the wavefront: genotype lane % 32
     }
     const int n_slots = (K + 63) >> 6;
     for (int r = 0; r < R; r++)
@@ -574,7 +663,7 @@ __global__ __launch_bounds__(256) void k_estep_tiled(EstepArgs a)
         cur = tag;
     };
     if constexpr (FAST && A == 1) {
-        fast_walk_single(recs, n_pairs >> 2, rsrc, o1[0], lane, prod[0], facc[0], [&](int, int tag) { enter(0, tag); });
+        fast_walk_single<HALF>(recs, n_pairs >> 2, rsrc, o1[0], lane, prod[0], facc[0], sh_rec[wave], [&](int, int tag) { enter(0, tag); });
     } else if constexpr (FAST) {
         // two batches in flight (see k_estep_direct); reads past the bin's last batch are redirected to it
         if (n_pairs > 0) {
@@ -617,6 +706,7 @@ __global__ __launch_bounds__(256) void k_estep_tiled(EstepArgs a)
 #pragma unroll
         for (int s = 0; s < A; s++) {
             out[s] = sh_acc[wave][r][s][lane];
+            if (HALF) out[s] = out[s] + shfl_xor_f64(out[s], 32);  // even calls (lanes 0 .. 31) + odd calls (lanes 32 .. 63)
             if (FAST) out[s] *= 0.693147180559945309417232121458176568;
         }
         estep_epilogue<64, A, FAST>(a, (long long)row, true, out, kk, valid, lane, lane, 0,
@@ -1767,6 +1857,12 @@ template <int A>
 static void launch_tiled(hipStream_t st, const EstepArgs &a)
 {
     const dim3 grid(blocks_for(a.n_bins, 4)), block(256);
+    if constexpr (A == 1) {
+        if (a.fast && a.K <= 32) {  // two calls per gather
+            hipLaunchKernelGGL((k_estep_tiled<1, true, true>), grid, block, 0, st, a);
+            return;
+        }
+    }
     if (a.fast)
         hipLaunchKernelGGL((k_estep_tiled<A, true>), grid, block, 0, st, a);
     else
@@ -1781,7 +1877,7 @@ hipError_t launch_estep(hipStream_t st, const EstepArgs &a, bool pairs)
     // time is the row gathers (1.50 ms against 1.72 ms on 200k x 100k x 64: L2 hit rate 44 % -> 68 %); the exact mode
     // is bound by its arithmetic and only pays the schedule's overhead (2.94 against 2.70 ms), so it keeps one
     // barcode per wavefront unless the schedule is forced (a.tiled == 2: tests).
-    if (a.n_bins > 0 && !pairs && K > 32 && K <= 128 && (a.fast || a.tiled == 2)) {
+    if (a.n_bins > 0 && !pairs && K <= 128 && ((a.fast && K > 16) || (a.tiled == 2 && K > 32))) {
         if (K <= 64) launch_tiled<1>(st, a);
         else launch_tiled<2>(st, a);
         return hipGetLastError();

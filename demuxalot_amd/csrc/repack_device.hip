@@ -433,7 +433,7 @@ static int repack_core(dmx_ctx *c, Scratch &sc, const int *d_variant, const int 
     c->n_bins = 0;
     c->n_tiles = 0;
     c->bin_rows_cap = 0;
-    if (G > 32 && G <= 128 && B >= TILE_MIN_BARCODES && V * (long long)G * 4 >= TILE_MIN_TABLE_BYTES) {
+    if (G > 16 && G <= 128 && B >= TILE_MIN_BARCODES && V * (long long)G * 4 >= TILE_MIN_TABLE_BYTES) {
         // as many bins as wavefronts the chip holds, times a whole number of rounds: bins have equal work, so a
         // launch is that many rounds long, and a partly filled last round would cost a whole one
         hipDeviceProp_t prop;
