@@ -3,12 +3,14 @@
 The EM path shards on barcodes: E-step rows are independent; the M-step is a sum over calls, hence over barcode
 shards; the P-step is a pure function of [V, G] tables.  One process per GPU holds one contiguous barcode range
 (balanced by number of calls, not by number of barcodes), the calls of those barcodes with barcode indices re-based
-to the range, and a full copy of the beta tables.  The per-iteration exchange -- reduce-scatter of the partial beta
-additions over variant slices, P-step on the owned slice, all-gather of genotype_prob -- happens inside
-libdemux_hip.so over RCCL (include/demux_hip.h: "Multi-GPU").  What is left for Python:
+to the range, and a full copy of the beta tables.  The per-iteration exchange happens inside libdemux_hip.so over RCCL
+(include/demux_hip.h: "Multi-GPU"): the M-step sharded on variants - all-gather of what it reads of every barcode, every
+rank summing its variant slice over all barcodes (additions bit-identical to one GPU) - or, where that would move more
+bytes, the reduce-scatter of the per-rank sums; then the P-step on the owned slice and the all-gather of genotype_prob.
+What is left for Python:
 
   * cutting the barcode ranges and filtering the reference's call containers to a range (every rank packs only
-    its own barcodes on its GPU),
+    its own barcodes on its GPU; the communicator is attached afterwards, once all ranks agree that their packs worked),
   * three small control-plane exchanges: the RCCL unique id (broadcast), the molecule counts per variant that the
     regularised prior needs (sum over ranks, demux.py:372-388), and the posterior rows (gather),
   * `learn_genotypes` / `predict_posteriors` with the reference's signatures plus a `plane` argument.
@@ -288,8 +290,6 @@ def _install_shard(chromosome2compressed_snp_calls, genotypes, barcode_handler, 
         error = exc
     try:
         _agree(plane, error)
-        if with_communicator:
-            attach_communicator(ctx, plane, reduce_dtype, force_comm)
         agreed = []
 
         def reduce_counts(molecules):  # called by the pack between the device pack and the prior
@@ -306,6 +306,11 @@ def _install_shard(chromosome2compressed_snp_calls, genotypes, barcode_handler, 
             raise
         if not share_counts:
             _agree(plane, None)
+        # The communicator is attached to the RESIDENT problem, after every rank has agreed that its pack worked: attaching
+        # lays the problem out for the exchange, which is itself collective (the ranks' call records are all-gathered for
+        # the variant-sharded M-step) - a rank that failed in its pack would never join it.
+        if with_communicator:
+            attach_communicator(ctx, plane, reduce_dtype, force_comm)
     except BaseException:
         if ctx is not None:
             ctx.close()

@@ -1,11 +1,15 @@
 """TEST INFRASTRUCTURE: a CPU stand-in for demuxalot_amd.device.DeviceContext, used to drive the multi-rank host
 code (demuxalot_amd/distributed.py) over a gloo process group on a box without GPUs.
 
-The arithmetic is the oracle's.  The multi-rank exchange repeats, step for step and over torch.distributed, the
-sequence libdemux_hip.so runs over RCCL (csrc/dmx_api.cpp "Multi-GPU exchange"): per-rank float64 partial sums in
-the PADDED slice layout (slices from the library's own dmx_exchange_slices) -> reduce-scatter -> float32 slice ->
-P-step on the owned slice -> all-gather of genotype_prob.  gloo has no reduce_scatter; it is spelled as one
-dist.reduce per slice."""
+The arithmetic is the oracle's.  The multi-rank exchange repeats, step for step and over torch.distributed (or the
+caller's collectives), the sequences libdemux_hip.so runs over RCCL (csrc/dmx_api.cpp "Multi-GPU"):
+  * default, the M-step sharded on variants (shard_mstep_by_variant): at set-up every rank's calls are all-gathered and
+    each rank keeps those of its variant slice (slices from the library's own dmx_exchange_slices) with global barcode
+    rows; per iteration the singlet posteriors are all-gathered and every rank sums its slice over all barcodes - one
+    float64 sum per entry in the reference's order, so the results equal a single-rank run's bit for bit;
+  * `exchange='reduce_scatter'`: per-rank float64 partial sums in the PADDED slice layout -> reduce-scatter (gloo has
+    none; it is spelled as one dist.reduce per slice) -> float32 slice;
+then in both the P-step on the owned slice -> all-gather of genotype_prob."""
 import numpy as np
 
 from demuxalot_amd import _lib
@@ -54,15 +58,28 @@ class _Array:
 
 
 class OracleContext:
+    exchange = 'variant'  # or 'reduce_scatter' (module docstring)
+
     def __init__(self, device=0):
         self.rank, self.world, self.dist = 0, 1, None
         self.addition = None
         self.torch_free = False
+        self.mcalls = None  # variant-sharded M-step: (variant, global barcode row, p_base_wrong) of this rank's slice
+
+    def _gather_padded(self, array, rows):
+        """Every rank's `array` (first axis padded to `rows`), as float64 (exact for the integers that travel here)."""
+        mine = np.zeros((rows,) + array.shape[1:], dtype=np.float64)
+        mine[:len(array)] = array
+        parts = [self._tensor(np.zeros_like(mine)) for _ in range(self.world)]
+        self.dist.all_gather(parts, self._tensor(mine))
+        return [part.numpy() for part in parts]
 
     def comm_init_host(self, rank, nranks, collective, reduce_dtype='f64'):
         """The exchange over the caller's collectives (a plane with host_collective): no torch anywhere."""
         self.rank, self.world, self.dist = rank, nranks, _HostCollectives(rank, nranks, collective)
         self.torch_free = True
+        if getattr(self, 'calls', None) is not None:
+            self._layout_exchange()
 
     def _tensor(self, array):
         if self.torch_free:
@@ -87,6 +104,8 @@ class OracleContext:
         import torch.distributed as dist
         assert len(unique_id) == _lib.UNIQUE_ID_BYTES and unique_id.startswith(b'cpu-stand-in')  # rank 0's bytes arrived
         self.rank, self.world, self.dist = rank, nranks, dist
+        if getattr(self, 'calls', None) is not None:
+            self._layout_exchange()
 
     def close(self):
         pass
@@ -97,8 +116,32 @@ class OracleContext:
         order = np.lexsort((compressed_cb, variant_id))  # the reference's barcode_calls order
         self.calls = (np.asarray(variant_id)[order], np.asarray(compressed_cb)[order], np.asarray(p_base_wrong, dtype=np.float32)[order])
         self.v2snp = np.asarray(v2snp, dtype=np.int32)
+        self._layout_exchange()
+
+    def _layout_exchange(self):
+        """Slices and (variant-sharded M-step) the calls of this rank's slice: when a problem is installed with a communicator
+        attached, or a communicator is attached to the resident problem (include/demux_hip.h: collective either way)."""
         self.cuts, self.slice_rows, self.sliced = exchange_slices(self.v2snp, self.world)
         self.sliced = self.sliced and self.dist is not None
+        self.mcalls = None
+        if self.sliced and self.world > 1 and self.exchange == 'variant':
+            # set-up of the variant-sharded M-step: sizes, then everybody's calls; this rank keeps its variant slice
+            sizes = self._gather_padded(np.array([[self.B, len(self.calls[0])]], dtype=np.float64), 1)
+            self.rows_pad = max(1, int(max(part[0, 0] for part in sizes)))
+            n_pad = max(1, int(max(part[0, 1] for part in sizes)))
+            v, cb, e = self.calls
+            wire = np.stack([v.astype(np.float64), cb.astype(np.float64) + self.rank * self.rows_pad, e.astype(np.float64),
+                             np.ones(len(v))], axis=1) if len(v) else np.zeros((0, 4))
+            lo, hi = self._slice(self.rank)
+            keep_v, keep_row, keep_e = [], [], []
+            for part in self._gather_padded(wire, n_pad):  # rank-major: ascending global barcode rows inside a variant
+                sel = (part[:, 3] == 1) & (part[:, 0] >= lo) & (part[:, 0] < hi)
+                keep_v.append(part[sel, 0].astype(np.int64))
+                keep_row.append(part[sel, 1].astype(np.int64))
+                keep_e.append(part[sel, 2].astype(np.float32))
+            mv, mrow, me = np.concatenate(keep_v), np.concatenate(keep_row), np.concatenate(keep_e)
+            order = np.argsort(mv, kind='stable')
+            self.mcalls = (mv[order], mrow[order], me[order])
 
     def stage_containers(self, containers):
         """Two-step form of the device pack (DeviceContext.stage_containers): the chromosome numbers are provisional."""
@@ -184,11 +227,26 @@ class OracleContext:
     def mstep(self, contribution_power=2., fetch=True):
         v, cb, e = self.calls
         keep = 1 - e
-        part = np.zeros((self.V, self.G))
-        for g in range(self.G):
-            w = self.post[cb, g] * keep
-            w **= contribution_power
-            part[:, g] = np.bincount(v, weights=w, minlength=self.V)
+        if self.mcalls is None:
+            part = np.zeros((self.V, self.G))
+            for g in range(self.G):
+                w = self.post[cb, g] * keep
+                w **= contribution_power
+                part[:, g] = np.bincount(v, weights=w, minlength=self.V)
+        if self.mcalls is not None:
+            # variant-sharded: everybody's singlet posteriors, then this rank's slice summed over all barcodes
+            posts = self._gather_padded(self.post[:, :self.G].astype(np.float64), self.rows_pad)
+            post_all = np.concatenate(posts).astype(np.float32)
+            mv, mrow, me = self.mcalls
+            lo, hi = self._slice(self.rank)
+            self.addition = np.full((self.V, self.G), np.nan, dtype=np.float32)  # foreign slices are NOT current
+            keep_m = 1 - me
+            for g in range(self.G):
+                w = post_all[mrow, g] * keep_m
+                w **= contribution_power
+                self.addition[lo:hi, g] = np.bincount(mv - lo, weights=w, minlength=hi - lo)
+            self.partial = True
+            return self._full_addition() if fetch else self.addition
         if self.dist is None:
             self.addition = part.astype(np.float32)
         elif not self.sliced:
