@@ -13,7 +13,9 @@ Topology: a star.  Rank 0 listens, every other rank holds one connection to it; 
 Rendezvous: under torchrun MASTER_PORT belongs to the launcher's own store, so rank 0 binds an ephemeral port
 and publishes it (with a random token) in a file named after (MASTER_ADDR, MASTER_PORT, TORCHELASTIC_RUN_ID) in the
 temporary directory - one node, as the benchmark contract has it; the others poll the file and present the token,
-so that a stale file of an earlier run is recognised and waited out.  With an explicit `port` the file is skipped.
+so that a stale file of an earlier run is recognised and waited out.  With an explicit `port` the file is skipped and
+the token is derived from DEMUXALOT_AMD_PLANE_TOKEN / the port.  Message lengths come from the peer and are bounded
+before anything is allocated; the HELLO of an unauthenticated peer is read with a 12-byte limit.
 """
 import os
 import socket
@@ -46,12 +48,25 @@ def _recv_exact(sock, n):
     return buf
 
 
-def _recv(sock, expect_op):
+_MAX_PAYLOAD = 1 << 36  # 64 GiB: no legitimate message (result rows, staged exchange buffers) comes near
+
+
+def _recv(sock, expect_op, limit=_MAX_PAYLOAD):
     magic, op, n = _HDR.unpack(bytes(_recv_exact(sock, _HDR.size)))
     if magic != _MAGIC or op != expect_op:
         raise ConnectionError(f'control plane: out-of-step message (op {op}, expected {expect_op}): the ranks did not call '
                               f'the same operations in the same order')
+    if not 0 <= n <= limit:  # the length comes from the peer: never allocate what it says unchecked
+        raise ConnectionError(f'control plane: message of {n} bytes (op {op}) exceeds the {limit} allowed here')
     return _recv_exact(sock, n)
+
+
+def _explicit_port_token(port):
+    """Token of a rendezvous on an explicit port: DEMUXALOT_AMD_PLANE_TOKEN (shared by the ranks' environments) when set,
+    else derived from the port - enough to tell the ranks of one test apart from a stray connection, not a secret."""
+    import hashlib
+    secret = os.environ.get('DEMUXALOT_AMD_PLANE_TOKEN', '')
+    return hashlib.sha256(f'demuxalot_amd plane {secret} {int(port)}'.encode()).digest()[:8]
 
 
 class SocketControlPlane:
@@ -92,10 +107,14 @@ class SocketControlPlane:
         server.setsockopt(socket.SOL_SOCKET, socket.SO_REUSEADDR, 1)
         server.bind((addr, 0 if port is None else int(port)))
         server.listen(self.world)
-        token = os.urandom(8)
+        # The token every peer must present: random and published in the rendezvous file; with an explicit port (tests) the
+        # ranks derive it from DEMUXALOT_AMD_PLANE_TOKEN, or - absent that - from the port itself (same-host test harnesses)
+        token = os.urandom(8) if port is None else _explicit_port_token(port)
         if port is None:
-            tmp = self._file + f'.{os.getpid()}'
-            with open(tmp, 'wb') as f:
+            tmp = self._file + f'.{os.getpid()}.{token.hex()}'
+            # O_EXCL | O_NOFOLLOW, owner-only: a file or symlink planted under the predictable name is not written through
+            fd = os.open(tmp, os.O_WRONLY | os.O_CREAT | os.O_EXCL | getattr(os, 'O_NOFOLLOW', 0), 0o600)
+            with os.fdopen(fd, 'wb') as f:
                 f.write(struct.pack('<I', server.getsockname()[1]) + token)
             os.replace(tmp, self._file)
         server.settimeout(self._timeout)
@@ -105,12 +124,15 @@ class SocketControlPlane:
             conn.setsockopt(socket.IPPROTO_TCP, socket.TCP_NODELAY, 1)
             conn.settimeout(self._timeout)
             try:
-                hello = bytes(_recv(conn, OP_HELLO))
-            except (ConnectionError, socket.timeout):
+                hello = bytes(_recv(conn, OP_HELLO, limit=12))  # rank + token: nothing larger is read from a stranger
+            except (ConnectionError, socket.timeout, OSError):
+                conn.close()
+                continue
+            if len(hello) != 12:
                 conn.close()
                 continue
             rank, = struct.unpack('<I', hello[:4])
-            if (port is None and hello[4:12] != token) or not 0 < rank < self.world or rank in peers:
+            if hello[4:12] != token or not 0 < rank < self.world or rank in peers:
                 conn.close()  # a stranger, or a rank of an earlier run that read a stale file
                 continue
             _send(conn, OP_HELLO, struct.pack('<I', self.world))
@@ -134,7 +156,7 @@ class SocketControlPlane:
                         raise FileNotFoundError
                     target, token = struct.unpack('<I', blob[:4])[0], blob[4:]
                 else:
-                    target, token = int(port), b'\0' * 8
+                    target, token = int(port), _explicit_port_token(port)
                 sock = socket.create_connection((addr, target), timeout=5.0)
                 sock.setsockopt(socket.IPPROTO_TCP, socket.TCP_NODELAY, 1)
                 sock.settimeout(self._timeout)
