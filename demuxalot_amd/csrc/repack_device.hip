@@ -17,16 +17,11 @@
 #include <cstdlib>
 #include <algorithm>
 #include <hip/hip_runtime.h>
-
-#include <atomic>
-#include <mutex>
-#include <thread>
 #include <rocprim/rocprim.hpp>
 
 #include "dmx_ctx.h"
 
 namespace dmx {
-int upload_bytes(dmx_ctx *c, void *d_dst, const void *h_src, size_t bytes, hipStream_t st);
 namespace {
 
 // range check without atomics in the good case: a wave only touches memory when it saw a bad index
@@ -680,9 +675,9 @@ int repack_on_device(dmx_ctx *c, const int32_t *h_variant, const int32_t *h_cb, 
     DMX_TRY(sc.get(&d_cb, (size_t)N));
     DMX_TRY(sc.get(&d_p, (size_t)N));
     if (N) {
-        DMX_TRY(upload_bytes(c, d_variant, h_variant, sizeof(int) * (size_t)N, st));
-        DMX_TRY(upload_bytes(c, d_cb, h_cb, sizeof(int) * (size_t)N, st));
-        DMX_TRY(upload_bytes(c, d_p, h_p, sizeof(float) * (size_t)N, st));
+        HIP_TRY(hipMemcpyAsync(d_variant, h_variant, sizeof(int) * N, hipMemcpyHostToDevice, st));
+        HIP_TRY(hipMemcpyAsync(d_cb, h_cb, sizeof(int) * N, hipMemcpyHostToDevice, st));
+        HIP_TRY(hipMemcpyAsync(d_p, h_p, sizeof(float) * N, hipMemcpyHostToDevice, st));
     }
     return repack_core(c, sc, d_variant, d_cb, d_p);
 }
@@ -772,86 +767,6 @@ __global__ __launch_bounds__(256) void k_products(const unsigned long long *keys
     u_count[u] = t - s;
 }
 
-}  // namespace
-
-// ------------------------------------------------------------------------------------
-// Large host -> device copies from the caller's PAGEABLE arrays (the containers' records: 1.97 GB at 78.65 M calls).
-// hipMemcpyAsync from pageable memory goes through the runtime's own staging at ~33 GB/s, and copies issued from several
-// threads serialise there; the copy engines themselves run at ~56 GB/s.  So: own pinned staging.  UP_THREADS host threads
-// each own two 32 MB pinned buffers and a stream; a thread memcpy's a chunk into one buffer while the DMA of its previous
-// chunk drains the other.  The staging is one per process and device (pinning 256 MB costs tens of milliseconds, once).
-// ------------------------------------------------------------------------------------
-constexpr int UP_THREADS = 4;
-constexpr size_t UP_CHUNK = size_t(32) << 20;
-constexpr size_t UP_MIN_BYTES = size_t(128) << 20;  // below this the plain copy is as fast
-
-struct PinnedUploader {
-    std::mutex lock;  // one upload at a time per device
-    bool ready = false, broken = false;
-    void *buf[UP_THREADS][2] = {};
-    hipEvent_t ev[UP_THREADS][2] = {};
-    hipEvent_t done[UP_THREADS] = {};
-    hipEvent_t start = nullptr;  // the destination may be a recycled block with work of its previous life queued on the caller's stream
-    hipStream_t stream[UP_THREADS] = {};
-};
-PinnedUploader g_uploaders[16];
-
-int upload_bytes(dmx_ctx *c, void *d_dst, const void *h_src, size_t bytes, hipStream_t st)
-{
-    if (bytes == 0) return 0;
-    PinnedUploader *up = c->device >= 0 && c->device < 16 ? &g_uploaders[c->device] : nullptr;
-    if (up == nullptr || bytes < UP_MIN_BYTES || up->broken) {
-        HIP_TRY(hipMemcpyAsync(d_dst, h_src, bytes, hipMemcpyHostToDevice, st));
-        return 0;
-    }
-    std::lock_guard<std::mutex> guard(up->lock);
-    if (!up->ready) {
-        bool ok = hipEventCreateWithFlags(&up->start, hipEventDisableTiming) == hipSuccess;
-        for (int t = 0; t < UP_THREADS && ok; t++) {
-            ok = ok && hipStreamCreateWithFlags(&up->stream[t], hipStreamNonBlocking) == hipSuccess;
-            ok = ok && hipEventCreateWithFlags(&up->done[t], hipEventDisableTiming) == hipSuccess;
-            for (int h = 0; h < 2 && ok; h++) {
-                ok = ok && hipHostMalloc(&up->buf[t][h], UP_CHUNK, hipHostMallocDefault) == hipSuccess;
-                ok = ok && hipEventCreateWithFlags(&up->ev[t][h], hipEventDisableTiming) == hipSuccess;
-            }
-        }
-        if (!ok) {  // no pinned memory to be had: the plain path from now on
-            (void)hipGetLastError();
-            up->broken = true;
-            HIP_TRY(hipMemcpyAsync(d_dst, h_src, bytes, hipMemcpyHostToDevice, st));
-            return 0;
-        }
-        up->ready = true;
-    }
-    const size_t n_chunks = (bytes + UP_CHUNK - 1) / UP_CHUNK;
-    std::atomic<int> failed{0};
-    HIP_TRY(hipEventRecord(up->start, st));
-    auto worker = [&](int t) {
-        if (hipSetDevice(c->device) != hipSuccess || hipStreamWaitEvent(up->stream[t], up->start, 0) != hipSuccess) {
-            failed = 1;
-            return;
-        }
-        int turn = 0;
-        bool used[2] = {false, false};
-        for (size_t j = (size_t)t; j < n_chunks; j += UP_THREADS, turn ^= 1) {
-            const size_t off = j * UP_CHUNK, len = std::min(UP_CHUNK, bytes - off);
-            if (used[turn] && hipEventSynchronize(up->ev[t][turn]) != hipSuccess) failed = 1;  // the DMA that last read this buffer
-            std::memcpy(up->buf[t][turn], (const char *)h_src + off, len);
-            if (hipMemcpyAsync((char *)d_dst + off, up->buf[t][turn], len, hipMemcpyHostToDevice, up->stream[t]) != hipSuccess) failed = 1;
-            if (hipEventRecord(up->ev[t][turn], up->stream[t]) != hipSuccess) failed = 1;
-            used[turn] = true;
-        }
-        if (hipEventRecord(up->done[t], up->stream[t]) != hipSuccess) failed = 1;
-    };
-    std::thread threads[UP_THREADS];
-    for (int t = 0; t < UP_THREADS; t++) threads[t] = std::thread(worker, t);
-    for (int t = 0; t < UP_THREADS; t++) threads[t].join();
-    if (failed) return fail(DMX_ERR_HIP, "staged upload of %zu bytes failed", bytes);
-    for (int t = 0; t < UP_THREADS; t++) HIP_TRY(hipStreamWaitEvent(st, up->done[t], 0));  // what follows on `st` sees the data
-    return 0;
-}
-
-namespace {
 template <typename T>
 int upload(Scratch &sc, T **dst, const T *src, size_t n, hipStream_t st)
 {
@@ -1085,10 +1000,8 @@ int stage_containers_on_device(dmx_ctx *c, const dmx_call_container *parts, int 
         const dmx_call_container &part = parts[k];
         if (part.n_snp_calls == 0) continue;
         unsigned char *d_calls, *d_molecules;
-        DMX_TRY(sc.get(&d_calls, (size_t)part.n_snp_calls * SNP_CALL_BYTES));
-        DMX_TRY(sc.get(&d_molecules, (size_t)part.n_molecules * MOLECULE_BYTES));
-        DMX_TRY(upload_bytes(c, d_calls, part.snp_calls, (size_t)part.n_snp_calls * SNP_CALL_BYTES, st));
-        DMX_TRY(upload_bytes(c, d_molecules, part.molecules, (size_t)part.n_molecules * MOLECULE_BYTES, st));
+        DMX_TRY(upload(sc, &d_calls, (const unsigned char *)part.snp_calls, (size_t)part.n_snp_calls * SNP_CALL_BYTES, st));
+        DMX_TRY(upload(sc, &d_molecules, (const unsigned char *)part.molecules, (size_t)part.n_molecules * MOLECULE_BYTES, st));
         hipLaunchKernelGGL(k_flatten_container, dim3(grid_for(part.n_snp_calls)), dim3(256), 0, st, d_calls, part.n_snp_calls,
                            d_molecules, part.n_molecules, part.chrom, c->st_chrom + at, c->st_pos + at, c->st_base + at, c->st_cb + at,
                            c->st_p + at, bad);
