@@ -907,7 +907,7 @@ __global__ __launch_bounds__(256) void k_softmax_rows(EstepArgs a)
         int close = 0;
         for (int k = tid; k < K; k += 256) {
             const float p = x[k] / tot;
-            bad |= !(fminf(p, 1.0f - p) * e2 <= GUARD_TOL);
+            bad |= !(fminf(p, 1.0f - p) * e2 <= (K > 1024 ? GUARD_TOL_WIDE : GUARD_TOL));
             close += !(lg[k] < near) ? 1 : 0;
         }
 #pragma unroll

@@ -177,7 +177,8 @@ int dmx_get_redo_count(dmx_ctx *ctx, int64_t *count);
  *             log2 per 8 calls) + the float32 roundings of the logit itself,
  *   and keeps the fast result only when, with D = max_k D_k,
  *       min(p_k, 1 - p_k) (e^{2D} - 1) <= 8e-6 for every option (=> |posterior - reference posterior| <= 1e-5 with
- *       2e-6 left for the float32 evaluation of the softmax on either side), and
+ *       2e-6 left for the float32 evaluation of the softmax on either side; 6e-6 / 4e-6 for rows of more than 1024
+ *       options), and
  *       no second logit lies within 2 D of the largest (=> the same argmax);
  *   every other barcode is queued on the device and redone by the exact kernel in the same E-step, so its logits and
  *   posteriors are the reference's bit for bit.  Where the dictionary form applies (exact and faster) it is used
