@@ -362,7 +362,7 @@ int dmx_mstep_f64_sums(dmx_ctx *ctx, double contribution_power, double *sums_out
  *     -> rank r sums slice r over ALL barcodes in the reference's order, float64, one rounding: the additions are
  *        bit-identical to a single-GPU run for any number of ranks - nothing is added across ranks -
  *     -> P-step (demux.py:267-274) of slice r -> all-gather of the float32 genotype_prob slices.
- * That exchange moves 4 G + 8 + 8 ceil(G / 64) bytes per barcode OF THE WHOLE JOB.  When that is more than 1.1 x the
+ * That exchange moves 4 G + 8 + 8 ceil(G / 64) bytes per barcode OF THE WHOLE JOB.  When that is more than 1.25 x the
  * [V, G] partial sums (many more barcodes than variants: n x 200k-barcode weak scaling), the exchange of the sums is
  * taken instead: M-step on every rank's own barcodes over all variants, reduce-scatter of the float64 / float32 partial
  * sums over the slices, then P-step and all-gather as above (per-rank sums are added: results within a float32 ulp of
