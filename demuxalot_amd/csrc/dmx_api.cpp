@@ -959,7 +959,9 @@ int layout_exchange(dmx_ctx *c)
         // DEMUXALOT_AMD_EXCHANGE=reduce_scatter keeps the M-step on every rank's own barcodes and reduce-scatters the sums;
         // =variant shards the M-step on variants whatever the sizes; default: whichever moves fewer bytes per iteration
         const bool by_sums = exchange && std::strcmp(exchange, "reduce_scatter") == 0;
-        if (n > 1 && !by_sums) DMX_TRY(shard_mstep_by_variant(c, exchange && std::strcmp(exchange, "variant") == 0));
+        const bool by_variant = exchange && std::strcmp(exchange, "variant") == 0;
+        // (forced, it also runs with ONE rank: its collectives through a real one-rank RCCL communicator on a one-GPU test box)
+        if ((n > 1 && !by_sums) || by_variant) DMX_TRY(shard_mstep_by_variant(c, by_variant));
     }
     c->add_partial = false;
     return 0;

@@ -367,7 +367,7 @@ int dmx_mstep_f64_sums(dmx_ctx *ctx, double contribution_power, double *sums_out
  * taken instead: M-step on every rank's own barcodes over all variants, reduce-scatter of the float64 / float32 partial
  * sums over the slices, then P-step and all-gather as above (per-rank sums are added: results within a float32 ulp of
  * the single-GPU ones, not bit-identical).  Every rank sees the same sizes and decides alike.
- * DEMUXALOT_AMD_EXCHANGE = variant | reduce_scatter forces either; = allreduce, or SNPs whose variants are not
+ * DEMUXALOT_AMD_EXCHANGE = variant | reduce_scatter forces either (variant also with a one-rank communicator: tests); = allreduce, or SNPs whose variants are not
  * contiguous in the variant numbering (no slices can be cut): all-reduce of the sums, P-step on every rank.
  * reduce_dtype matters for the exchanges of sums only: DMX_F64 exchanges float64 partial sums and rounds once, DMX_F32
  * halves the bytes.

@@ -512,6 +512,48 @@ def test_rccl_communicator_single_rank(reduce_dtype):
         assert np.allclose(add_coll, add_plain, rtol=3e-7, atol=0)
 
 
+def test_variant_sharded_exchange_through_a_one_rank_rccl_communicator(monkeypatch):
+    """The variant-sharded M-step forced onto ONE rank: its set-up all-gather of the call records, the per-iteration grouped
+    all-gathers of the posterior tables (ncclGroupStart / ncclGroupEnd) and the genotype_prob all-gather run through a real
+    RCCL communicator on the one GPU a test box has.  With one rank the collectives are copies: everything stays
+    bit-identical to the plain context, in the exact and (same kernels, same order) the guarded mode."""
+    from demuxalot_amd import synth
+    from demuxalot_amd.device import DeviceContext, get_context
+    p = synth.generate(30000, 3000, 48, calls_per_barcode=40, seed=1717)
+    prior = p.prior_betas()
+    pen = np.zeros(48, dtype=np.float32)
+    for mode in ('exact', 'guarded'):
+        plain = get_context()
+        plain.set_estep_mode(mode)
+        plain.set_exact_additions(mode == 'exact')
+        try:
+            plain.set_problem(p.n_barcodes, p.n_variants, 48, p.variant_id, p.compressed_cb, p.p_base_wrong, p.v2snp)
+            plain.set_betas(prior)
+            _, probs_plain, add_plain = plain.em(3, 0.01, pen, with_doublets=False)
+        finally:
+            plain.apply_environment()
+        monkeypatch.setenv('DEMUXALOT_AMD_EXCHANGE', 'variant')
+        ctx = DeviceContext(0)
+        try:
+            ctx.set_estep_mode(mode)
+            ctx.set_exact_additions(mode == 'exact')
+            ctx.comm_init(0, 1, DeviceContext.new_unique_id(), reduce_dtype='f64')
+            ctx.set_problem(p.n_barcodes, p.n_variants, 48, p.variant_id, p.compressed_cb, p.p_base_wrong, p.v2snp)
+            assert ctx.exchange_mode() == 'variant'
+            ctx.set_betas(prior)
+            _, probs_coll, add_coll = ctx.em(3, 0.01, pen, with_doublets=False)
+            assert ctx.timings()['allreduce']['launches'] >= 2
+        finally:
+            ctx.close()
+            monkeypatch.delenv('DEMUXALOT_AMD_EXCHANGE')
+        if mode == 'exact':
+            fio.assert_bitwise(add_coll, add_plain, 'variant-sharded M-step through RCCL: additions')
+            fio.assert_bitwise(probs_coll, probs_plain, 'variant-sharded M-step through RCCL: posteriors')
+        else:  # sums of float64 in another order: a float32 rounding tie at most
+            assert np.allclose(add_coll, add_plain, rtol=3e-7, atol=0)
+            assert np.array_equal(probs_coll.argmax(1), probs_plain.argmax(1)) and np.abs(probs_coll - probs_plain).max() <= 1e-5
+
+
 # ---- mid/large sizes ------------------------------------------------------------------------------
 def test_midsize_em_matches_oracle(oracle):
     """20k barcodes x 10k SNPs x 64 genotypes (N ~ 3.6M): three EM iterations against the numpy oracle."""
