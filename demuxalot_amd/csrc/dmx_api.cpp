@@ -478,7 +478,7 @@ void release_problem(dmx_ctx *c)
     c->h_v2snp.clear();
     dev_free(c, &c->d_partial, (size_t)c->n_items * c->G);
     dev_free(c, &c->d_redo, c->cap_redo);
-    dev_free(c, &c->d_n_redo, (size_t)1);
+    dev_free(c, &c->d_n_redo, (size_t)2);
     c->cap_redo = 0;
     dev_free(c, &c->d_logits, (size_t)c->cap_bk);
     dev_free(c, &c->d_post, (size_t)c->cap_bk);
@@ -1311,6 +1311,7 @@ int run_mstep(dmx_ctx *c, float power)
     const bool f64 = c->reduce_dtype == DMX_F64;
     // where k_mcombine writes: the variants of one work item are written there by the M-step kernels themselves
     a.item_variant = c->d_item_variant;
+    a.redo_cap = c->cap_redo;
     if (!dist || mshard) {
         a.out32 = c->d_add;
     } else if (c->sliced) {
@@ -1501,7 +1502,7 @@ static int finish_problem(dmx_ctx *c, const int32_t *v2snp, const std::vector<in
     DMX_TRY(dev_alloc(c, &c->d_partial, (size_t)c->n_items * G));
     c->cap_redo = ((size_t)c->n_items / 2 + 1) * (size_t)G;  // a variant queues at most G sums and only with >= 2 items
     DMX_TRY(dev_alloc(c, &c->d_redo, c->cap_redo));
-    DMX_TRY(dev_alloc(c, &c->d_n_redo, (size_t)1));
+    DMX_TRY(dev_alloc(c, &c->d_n_redo, (size_t)2));  // long variants, the others
     DMX_TRY(dev_alloc(c, &c->d_nz, (size_t)B * ((G + 63) / 64)));
     DMX_TRY(dev_alloc(c, &c->d_first, (size_t)B));
     DMX_TRY(dev_alloc(c, &c->d_dense_calls, (size_t)1 + dmx::DENSE_SLOTS));
@@ -1731,12 +1732,12 @@ int dmx_get_redo_count(dmx_ctx *c, int64_t *count)
 {
     DMX_TRY(bind(c));
     if (!count) return fail(DMX_ERR_INVALID, "null argument");
-    unsigned n = 0;
+    unsigned n[2] = {0, 0};
     if (c->d_n_redo) {
-        HIP_TRY(hipMemcpyAsync(&n, c->d_n_redo, sizeof(unsigned), hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(hipMemcpyAsync(n, c->d_n_redo, 2 * sizeof(unsigned), hipMemcpyDeviceToHost, c->stream));
         HIP_TRY(hipStreamSynchronize(c->stream));
     }
-    *count = (int64_t)n;
+    *count = (int64_t)n[0] + (int64_t)n[1];
     return 0;
 }
 

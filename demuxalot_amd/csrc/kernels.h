@@ -129,6 +129,7 @@ struct MstepArgs {
     // only visits the variants of several items and those without calls.  item_variant == nullptr: every item leaves
     // its partial sums (the chunked exchange, whose output rows differ per chunk).
     const int *item_variant;        // nullable [n_items] variant of every item
+    unsigned long long redo_cap;    // capacity of the redo queue (launch_mcombine: long variants from the front, the others from the back)
     const long long *item_ptr;      // [V + 1] first item of every variant
     const int *prow;                // nullable [V] row of every variant in the output table
     float *out32;                   // exactly one of the two (or none: item_variant == nullptr)
@@ -188,7 +189,8 @@ hipError_t launch_estep_dict(hipStream_t st, const EstepArgs &a, bool pairs);
 hipError_t launch_estep_dict_block(hipStream_t st, const EstepArgs &a);  // doublet tables of more than DICT_LANE_K options
 hipError_t launch_mstep(hipStream_t st, const MstepArgs &a);
 // sums the item partials of variants [v0, v1) and redoes, in the reference's order, the sums whose float32
-// rounding could depend on the order (redo: queue of capacity (n_items / 2 + 1) * G entries, n_redo: its counter)
+// rounding could depend on the order (redo: queue of a.redo_cap = (n_items / 2 + 1) * G entries, n_redo: its TWO counters -
+// variants of more than EXACT_LONG calls are queued from the front, the others from the back)
 // prow (nullable): row of every variant in the output tables (padded multi-GPU exchange buffer)
 // vlist (nullable): the variants are entries [v0, v1) of this list instead of v0 .. v1 - 1 (chunks of the pipelined exchange)
 // skip_single: the variants of one item were written by the M-step kernels themselves (MstepArgs::item_variant)

@@ -1492,13 +1492,20 @@ __global__ __launch_bounds__(256) void k_rebuild_nz(const float *__restrict__ po
 // either summation order
 //     |S_seq - S_comb| <= 2 n u S   (non-negative addends, n calls, u = 2^-53; 4 n u S is used),
 // and the (variant, genotype) pair is otherwise queued for k_mstep_exact, which redoes that one sum in order.
+constexpr int EXACT_WAVES = 16;
+constexpr int EXACT_SPAN = 1024;  // calls per wavefront and segment (LDS: EXACT_WAVES * EXACT_SPAN floats = 64 KB)
+// Variants of more calls than this are redone by a whole workgroup (k_mstep_exact), the others by one wavefront each: a rank
+// of a variant-sharded run holds 1 / n of the variants in work items 1 / n as long, so that thousands of medium-sized
+// variants - not a few dozen hot ones - have sums at a float32 tie (7 289 per M-step at 8 ranks of 200k x 100k x 64).
+constexpr long long EXACT_LONG = 8 * EXACT_SPAN;
 __global__ __launch_bounds__(256) void k_mcombine(const double *__restrict__ partial,
                                                   const long long *__restrict__ item_ptr,
                                                   const long long *__restrict__ item_start,
                                                   const int *__restrict__ item_len, long long v0, long long v1, int G,
                                                   const int *__restrict__ prow, float *__restrict__ add32,
                                                   double *__restrict__ add64, unsigned long long *__restrict__ redo,
-                                                  unsigned *__restrict__ n_redo, const int *__restrict__ vlist, bool skip_single)
+                                                  unsigned *__restrict__ n_redo, unsigned long long redo_cap,
+                                                  const int *__restrict__ vlist, bool skip_single)
 {
     const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= (v1 - v0) * G) return;
@@ -1525,8 +1532,11 @@ __global__ __launch_bounds__(256) void k_mcombine(const double *__restrict__ par
         const float f = (float)s;
         const double lo = 0.5 * ((double)f + (double)nextafterf(f, 0.0f));  // rounding boundary towards zero
         const double hi = 0.5 * ((double)f + (double)nextafterf(f, __builtin_inff()));
-        if (!(s - bound > lo && s + bound < hi))
-            redo[atomicAdd(n_redo, 1u)] = ((unsigned long long)v << 16) | (unsigned long long)g;
+        if (!(s - bound > lo && s + bound < hi)) {
+            const unsigned long long entry = ((unsigned long long)v << 16) | (unsigned long long)g;
+            if (n > EXACT_LONG) redo[atomicAdd(&n_redo[0], 1u)] = entry;       // a workgroup per sum
+            else redo[redo_cap - 1ull - atomicAdd(&n_redo[1], 1u)] = entry;    // a wavefront per sum
+        }
     }
 }
 
@@ -1536,8 +1546,6 @@ __global__ __launch_bounds__(256) void k_mcombine(const double *__restrict__ par
 // wavefront collects the non-zero contributions of its EXACT_SPAN calls to the genotype in LDS (call order), then
 // wavefront 0 adds the lists in order.  The gathers -- the expensive part -- run in parallel; only the additions
 // are serial.
-constexpr int EXACT_WAVES = 16;
-constexpr int EXACT_SPAN = 1024;  // calls per wavefront and segment (LDS: EXACT_WAVES * EXACT_SPAN floats = 64 KB)
 template <bool SQUARE>
 __global__ __launch_bounds__(64 * EXACT_WAVES) void k_mstep_exact(MstepArgs a, const long long *__restrict__ item_ptr,
                                                                   const unsigned long long *__restrict__ redo,
@@ -1550,72 +1558,106 @@ __global__ __launch_bounds__(64 * EXACT_WAVES) void k_mstep_exact(MstepArgs a, c
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     float *mine = sh_c[wave];
-    const unsigned count = *n_redo;
     const int W = (a.G + 63) >> 6;
-    for (unsigned e = blockIdx.x; e < count; e += gridDim.x) {
-        const unsigned long long entry = redo[e];
-        const long long v = (long long)(entry >> 16);
-        const int g = (int)(entry & 0xFFFFull);
-        const long long it0 = item_ptr[v], it1 = item_ptr[v + 1];
+    // calls [lo, hi) of a variant (at most EXACT_SPAN): this wavefront's list of the non-zero contributions to genotype g,
+    // in call order; returns their number.
+    // The calls as three rounds of independent loads - all records, then all bitmap words, then all posteriors - instead
+    // of a chunk-by-chunk chain (the kernel is a chain of load latencies: 0.11 ms -> 0.04 ms on 200k x 100k x 64).
+    auto collect = [&](const uint2 *__restrict__ calls, long long lo, long long hi, int g) {
+        int cnt = 0;
+        constexpr int CH = EXACT_SPAN / 64;
+        uint2 d[CH];
+        unsigned long long word[CH];
+        float p[CH];
+#pragma unroll
+        for (int j = 0; j < CH; j++) {
+            d[j] = make_uint2(0u, 0u);
+            if (lo + 64 * j + lane < hi) d[j] = calls[lo + 64 * j + lane];
+        }
+#pragma unroll
+        for (int j = 0; j < CH; j++) {
+            word[j] = 0ull;
+            if (lo + 64 * j + lane < hi) word[j] = a.nz[(size_t)d[j].x * W + (g >> 6)];
+        }
+#pragma unroll
+        for (int j = 0; j < CH; j++) {
+            p[j] = 0.0f;
+            if ((word[j] >> (g & 63)) & 1ull) p[j] = a.post[(size_t)d[j].x * a.K + g];
+        }
+#pragma unroll
+        for (int j = 0; j < CH; j++) {
+            const bool live = (word[j] >> (g & 63)) & 1ull;
+            float c = p[j] * __uint_as_float(d[j].y);
+            c = SQUARE ? c * c : powf(c, a.power);
+            const unsigned long long bal = __ballot(live);
+            if (live) mine[cnt + __popcll(bal & ((1ull << lane) - 1ull))] = c;
+            cnt += __popcll(bal);
+        }
+        return cnt;
+    };
+    // the list of one wavefront added to ONE accumulator in order (every lane carries the same sum)
+    auto add_list = [&](const float *list, int cw, double acc) {
+        for (int base = 0; base < cw; base += 64) {
+            const float x = base + lane < cw ? list[base + lane] : 0.0f;
+            const int m = (cw - base) < 64 ? (cw - base) : 64;
+            for (int i = 0; i < m; i++)
+                acc += (double)__builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, x), i));
+        }
+        return acc;
+    };
+    struct Entry {
+        long long v, n;
+        int g;
+        const uint2 *calls;
+    };
+    auto entry_of = [&](unsigned long long entry) {
+        Entry e;
+        e.v = (long long)(entry >> 16);
+        e.g = (int)(entry & 0xFFFFull);
+        const long long it0 = item_ptr[e.v], it1 = item_ptr[e.v + 1];
         const long long first = a.item_start[it0];
-        const long long n = a.item_start[it1 - 1] + a.item_len[it1 - 1] - first;
-        const uint2 *__restrict__ calls = a.calls + first;
+        e.n = a.item_start[it1 - 1] + a.item_len[it1 - 1] - first;
+        e.calls = a.calls + first;
+        return e;
+    };
+    auto store = [&](const Entry &e, double acc) {
+        const long long o = (prow ? (long long)prow[e.v] : e.v) * a.G + e.g;
+        if (add32) add32[o] = (float)acc;
+        if (add64) add64[o] = acc;
+    };
+
+    // ---- long variants (front of the queue): a workgroup per sum, segments of EXACT_WAVES x EXACT_SPAN calls ----
+    const unsigned count_long = n_redo[0];
+    for (unsigned q = blockIdx.x; q < count_long; q += gridDim.x) {
+        const Entry e = entry_of(redo[q]);
         double acc = 0.0;  // meaningful in wavefront 0
-        for (long long seg = 0; seg < n; seg += (long long)EXACT_WAVES * EXACT_SPAN) {
+        for (long long seg = 0; seg < e.n; seg += (long long)EXACT_WAVES * EXACT_SPAN) {
             const long long lo = seg + (long long)wave * EXACT_SPAN;
-            const long long hi = lo + EXACT_SPAN < n ? lo + EXACT_SPAN : n;
-            int cnt = 0;
-            // The wavefront's EXACT_SPAN calls as three rounds of independent loads - all records, then all bitmap
-            // words, then all posteriors - instead of a chunk-by-chunk chain (the kernel is a chain of load latencies:
-            // 0.11 ms -> 0.04 ms on the 200k x 100k x 64 workload).
-            constexpr int CH = EXACT_SPAN / 64;
-            uint2 d[CH];
-            unsigned long long word[CH];
-            float p[CH];
-#pragma unroll
-            for (int j = 0; j < CH; j++) {
-                d[j] = make_uint2(0u, 0u);
-                if (lo + 64 * j + lane < hi) d[j] = calls[lo + 64 * j + lane];
-            }
-#pragma unroll
-            for (int j = 0; j < CH; j++) {
-                word[j] = 0ull;
-                if (lo + 64 * j + lane < hi) word[j] = a.nz[(size_t)d[j].x * W + (g >> 6)];
-            }
-#pragma unroll
-            for (int j = 0; j < CH; j++) {
-                p[j] = 0.0f;
-                if ((word[j] >> (g & 63)) & 1ull) p[j] = a.post[(size_t)d[j].x * a.K + g];
-            }
-#pragma unroll
-            for (int j = 0; j < CH; j++) {
-                const bool live = (word[j] >> (g & 63)) & 1ull;
-                float c = p[j] * __uint_as_float(d[j].y);
-                c = SQUARE ? c * c : powf(c, a.power);
-                const unsigned long long bal = __ballot(live);
-                if (live) mine[cnt + __popcll(bal & ((1ull << lane) - 1ull))] = c;
-                cnt += __popcll(bal);
-            }
+            const long long hi = lo + EXACT_SPAN < e.n ? lo + EXACT_SPAN : e.n;
+            const int cnt = collect(e.calls, lo, hi, e.g);
             if (lane == 0) sh_cnt[wave] = cnt;
             __syncthreads();
-            if (wave == 0) {
-                for (int w = 0; w < EXACT_WAVES; w++) {
-                    const int cw = sh_cnt[w];
-                    for (int base = 0; base < cw; base += 64) {
-                        const float x = base + lane < cw ? sh_c[w][base + lane] : 0.0f;
-                        const int m = (cw - base) < 64 ? (cw - base) : 64;
-                        for (int i = 0; i < m; i++)
-                            acc += (double)__builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, x), i));
-                    }
-                }
-            }
+            if (wave == 0)
+                for (int w = 0; w < EXACT_WAVES; w++) acc = add_list(sh_c[w], sh_cnt[w], acc);
             __syncthreads();
         }
-        if (threadIdx.x == 0) {
-            const long long o = (prow ? (long long)prow[v] : v) * a.G + g;
-            if (add32) add32[o] = (float)acc;
-            if (add64) add64[o] = acc;
+        if (threadIdx.x == 0) store(e, acc);
+    }
+    // ---- the others (back of the queue): a wavefront per sum, its own list in LDS, no workgroup barrier ----
+    const unsigned count_short = n_redo[1];
+    for (unsigned q = blockIdx.x * EXACT_WAVES + wave; q < count_short; q += gridDim.x * EXACT_WAVES) {
+        const Entry e = entry_of(redo[a.redo_cap - 1ull - q]);
+        double acc = 0.0;
+        for (long long lo = 0; lo < e.n; lo += EXACT_SPAN) {
+            const int cnt = collect(e.calls, lo, lo + EXACT_SPAN < e.n ? lo + EXACT_SPAN : e.n, e.g);
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");  // the list was written by other lanes of this wavefront
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            acc = add_list(mine, cnt, acc);
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");  // read before the next segment overwrites it
+            __builtin_amdgcn_wave_barrier();
         }
+        if (lane == 0) store(e, acc);
     }
 }
 
@@ -1997,11 +2039,11 @@ hipError_t launch_mcombine(hipStream_t st, const MstepArgs &a, const long long *
 {
     if ((v1 - v0) * a.G <= 0) return hipSuccess;
     if (redo) {
-        const hipError_t e = hipMemsetAsync(n_redo, 0, sizeof(unsigned), st);
+        const hipError_t e = hipMemsetAsync(n_redo, 0, 2 * sizeof(unsigned), st);
         if (e != hipSuccess) return e;
     }
     hipLaunchKernelGGL(k_mcombine, dim3(blocks_for((v1 - v0) * a.G, 256)), dim3(256), 0, st, a.partial, item_ptr,
-                       a.item_start, a.item_len, v0, v1, a.G, prow, add32, add64, redo, n_redo, vlist, skip_single);
+                       a.item_start, a.item_len, v0, v1, a.G, prow, add32, add64, redo, n_redo, a.redo_cap, vlist, skip_single);
     if (!redo) return hipGetLastError();
     // exact mode: the sums that must be redone in the reference's order (see k_mcombine)
     const dim3 grid(512), block(64 * EXACT_WAVES);
