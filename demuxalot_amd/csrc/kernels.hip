@@ -207,6 +207,78 @@ static __device__ __forceinline__ void estep_flush(float (&prod)[A], FastAcc (&a
 }
 
 // ------------------------------------------------------------------------------------
+// Tolerance mode with doublets, 64 lanes per barcode: an option (g1, g2) needs p[g1] and p[g2] of every call, and as two
+// per-lane gathers per call and option slot it was the address unit, not arithmetic, that the kernel ran on (20k x 20k x 8
+// with doublets, K = 36: 16 gathers per 8 calls).  The G <= GPAD probabilities of a call's row are contiguous, so ONE
+// load fetches the rows of RPL = 64 / GPAD calls - lane l: call l / GPAD of the load, genotype l % GPAD - and every
+// lane picks its two values out of the wavefront with ds_bpermute (the LDS crossbar, no memory involved).  Same values,
+// same arithmetic as the gather form: bit-identical sums.
+//   A = 1 (K <= 64: G <= 10), A = 2 (K <= 128: G <= 15): GPAD 16;  A <= 8 (K <= 512: G <= 31): GPAD 32
+// ------------------------------------------------------------------------------------
+template <int A>
+struct PairRowShape {
+    static constexpr int GPAD = A <= 2 ? 16 : A <= 8 ? 32 : 64;
+    static constexpr int RPL = 64 / GPAD;  // calls per row load
+};
+
+template <int H, int NL>
+struct PairRowBatch {
+    float raw[NL];  // load i: the rows of calls i * RPL .. of the batch
+    npm::f32x2 keep[H], flo[H];
+};
+
+template <int A, int H, int NL>
+static __device__ __forceinline__ void load_pair_rows(PairRowBatch<H, NL> &x, const CallPair *__restrict__ recs, int j,
+                                                      __amdgpu_buffer_rsrc_t rsrc, int lane)
+{
+    constexpr int GPAD = PairRowShape<A>::GPAD, RPL = PairRowShape<A>::RPL;
+    static_assert(NL * RPL == 2 * H, "whole row loads per batch");
+    j = __builtin_amdgcn_readfirstlane(j);
+    unsigned ro[2 * H];
+#pragma unroll
+    for (int q = 0; q < H; q++) {
+        const CallPair r = recs[j + q];
+        x.keep[q] = npm::f32x2{r.keep[0], r.keep[1]};
+        x.flo[q] = npm::f32x2{r.floor[0], r.floor[1]};
+        ro[2 * q] = r.row_off[0];
+        ro[2 * q + 1] = r.row_off[1];
+    }
+    const unsigned goff = (unsigned)(lane % GPAD) * 4u;  // (genotypes past G: bytes of the next row or past the table, never used)
+#pragma unroll
+    for (int i = 0; i < NL; i++) {
+        unsigned sel = ro[i * RPL + RPL - 1];
+#pragma unroll
+        for (int c = RPL - 2; c >= 0; c--) sel = lane < (c + 1) * GPAD ? ro[i * RPL + c] : sel;
+        x.raw[i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, (int)(sel + goff), 0, 0));
+    }
+}
+
+// o1 / o2: byte offsets of the option's two genotypes inside a row = 4 x their lane inside a call's GPAD lanes
+template <int A, int H, int NL>
+static __device__ __forceinline__ void pair_row_products(const PairRowBatch<H, NL> &x, const unsigned (&o1)[A], const unsigned (&o2)[A],
+                                                         float (&prod)[A], int n_slots)
+{
+    constexpr int GPAD = PairRowShape<A>::GPAD, RPL = PairRowShape<A>::RPL;
+    auto pick = [&](unsigned off, int call) {
+        return __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute((int)(off + (unsigned)((call % RPL) * GPAD * 4)),
+                                                                      __builtin_bit_cast(int, x.raw[call / RPL])));
+    };
+#pragma unroll
+    for (int q = 0; q < H; q++) {
+#pragma unroll
+        for (int s = 0; s < A; s++) {
+            if (A > 1 && s >= n_slots) continue;
+            const npm::f32x2 p1{pick(o1[s], 2 * q), pick(o1[s], 2 * q + 1)};
+            const npm::f32x2 p2{pick(o2[s], 2 * q), pick(o2[s], 2 * q + 1)};
+            const npm::f32x2 p = (p1 + p2) * 0.5f;
+            npm::f32x2 t = p * x.keep[q];
+            t = t + x.flo[q];
+            prod[s] = (prod[s] * t.x) * t.y;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------
 // Tolerance mode, K <= 64 singlets (one accumulator per lane): the software pipeline of the record stream.
 // With ~10 VALU cycles per term there is nothing to hide latency behind, and the chain
 //     scalar load of the call records (misses the scalar cache: the 1.3 GB stream is read once, from HBM)
@@ -396,6 +468,27 @@ __global__ __launch_bounds__(256) void k_estep_direct(EstepArgs a)
             // The tolerance mode has little arithmetic per call, so the row gathers' latency is what it waits for:
             // two batches in flight (ping-pong), the gathers of batch i+1 issued before batch i is consumed.  Reads past
             // the row's last batch are redirected to it (valid records, results unused).
+            if constexpr (PAIRS && A <= 8) {
+                // rows loaded whole, the options' two genotypes picked out of the wavefront (load_pair_rows)
+                constexpr int NL = 2 * H / PairRowShape<A>::RPL;
+                // two batches in flight, as below.  (Tried: four batches in flight - no change; the records through the
+                // vector path, six batches ahead, so that no wait for a pick also waits for scalar loads - slower, 0.196
+                // against 0.175 ms on 20k x 20k x 8 with doublets: what the loop runs on now is the rate of the picks.)
+                if (npairs > 0) {
+                    PairRowBatch<H, NL> x, y;
+                    load_pair_rows<A, H, NL>(x, recs, 0, rsrc, lane);
+                    for (int j0 = 0; j0 < npairs; j0 += 2 * H) {
+                        const int j1 = j0 + H;
+                        load_pair_rows<A, H, NL>(y, recs, min(j1, npairs - H), rsrc, lane);
+                        pair_row_products<A, H, NL>(x, o1, o2, prod, n_slots);
+                        if (((j0 + H) & 3) == 0) estep_flush<A>(prod, facc, n_slots);  // every 8 calls (rows are padded to 8)
+                        if (j1 >= npairs) break;
+                        load_pair_rows<A, H, NL>(x, recs, min(j1 + H, npairs - H), rsrc, lane);
+                        pair_row_products<A, H, NL>(y, o1, o2, prod, n_slots);
+                        if (((j1 + H) & 3) == 0) estep_flush<A>(prod, facc, n_slots);
+                    }
+                }
+            } else
             if (npairs > 0) {
                 RecBatch<A, H, PAIRS> x, y;
                 load_batch<A, H, PAIRS>(x, recs, 0, rsrc, o1, o2, n_slots);
