@@ -405,8 +405,8 @@ def main():
     ap.add_argument('--reduce-dtype', default='auto', choices=['auto', 'f64', 'f32'],
                     help='wire format of the reduce-scatter of the beta additions: float64 partial sums (results independent of the '
                          'number of ranks up to float32 rounding ties) or float32 (half the bytes; posteriors stay within the 1e-5 '
-                         'contract: tests/test_gpu_ranks_on_one_gpu.py).  auto = f64 up to 2 ranks, f32 from 4 on, where the exchange '
-                         'is what strong scaling runs into (DESIGN.md 5)')
+                         'contract: tests/test_gpu_ranks_on_one_gpu.py).  auto = f32 (two GPUs share ONE link, so the bytes matter most '
+                         'there: DESIGN.md 5); f64 when DEMUXALOT_AMD_ESTEP=exact.  The variant-sharded M-step exchanges no sums at all')
     ap.add_argument('--scaling', default='both', choices=['both', 'weak', 'strong'],
                     help='N > 1.  strong: the workload in total, barcodes sharded over the GPUs (BASELINE.json configs[3] as written); '
                          'weak: the workload per GPU; both (default): strong is the headline value, weak a sub-object of the line')
@@ -442,7 +442,7 @@ def main():
     rank = int(os.environ.get('RANK', '0'))
     world = int(os.environ.get('WORLD_SIZE', '1'))
     if args.reduce_dtype == 'auto':
-        args.reduce_dtype = 'f32' if world >= 4 else 'f64'
+        args.reduce_dtype = 'f64' if os.environ.get('DEMUXALOT_AMD_ESTEP', '') == 'exact' else 'f32'
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
     assert world == args.gpus, f'--gpus {args.gpus} but WORLD_SIZE={world}'
 

@@ -67,7 +67,7 @@ def main():
     for mode in args.modes.split(','):
         for kind in args.kinds.split(','):
             for n in (int(x) for x in args.ranks.split(',')):
-                wire = 'f32' if n >= 4 else 'f64'
+                wire = 'f64' if mode == 'exact' else 'f32'  # as bench.py chooses
                 if kind == 'strong' and n > 1:
                     bounds = partition_barcodes(counts, n)
                     lo, hi = int(bounds[0]), int(bounds[1])
