@@ -1949,10 +1949,13 @@ template <int L, int A, int U>
 static void launch_direct(hipStream_t st, const EstepArgs &a_in, bool pairs)
 {
     EstepArgs a = a_in;
-    const bool split = L == 64 && a.fast && a.segs != nullptr && a.n_segs > 0 && a.order_count == nullptr;
+    // the doublet tolerance kernel loads a call's row whole into PairRowShape<A>::GPAD lanes: every table of G (G + 1) / 2
+    // options that reaches this A has G <= GPAD; any other option table takes the exact kernel (always admissible)
+    const bool fast = a.fast && (!(pairs && L == 64 && A <= 8) || a.G <= PairRowShape<A>::GPAD);
+    const bool split = L == 64 && fast && a.segs != nullptr && a.n_segs > 0 && a.order_count == nullptr;
     if (!split) a.segs = nullptr;
     const dim3 grid(blocks_for(split ? a.n_segs + (a.B - a.n_split) : a.B, 4 * (64 / L))), block(256);
-    if (a.fast) {
+    if (fast) {
         if (pairs)
             hipLaunchKernelGGL((k_estep_direct<L, A, true, U, true>), grid, block, 0, st, a);
         else
