@@ -183,3 +183,31 @@ def test_headline_shape_predict_dictionary_vs_direct():
         fio.assert_bitwise(got['auto'][1], got['never'][1], 'posteriors')
     finally:
         ctx.close()
+
+
+@pytest.mark.parametrize('doublets', [False, True])
+def test_more_than_1024_genotypes_is_refused_with_a_message(doublets):
+    """1025 genotypes (singlets, and doublets whose dictionary gate once let them through to a kernel that does not exist):
+    the E-step refuses loudly instead of failing inside a launch; 1024 genotypes run."""
+    from demuxalot_amd import Demultiplexer, synth
+    from demuxalot_amd._lib import DemuxHipError
+    from demuxalot_amd.device import DeviceContext
+    for G, fails in ((1024, False), (1025, True)):
+        if doublets and not fails:
+            continue  # K = 524 800 options: covered at smaller G by the wide-table tests
+        p = synth.generate(40, 30, G, calls_per_barcode=10, doublets=doublets, seed=5 + G)
+        pen = Demultiplexer._doublet_penalties(G, 0.3 if doublets else 0.0)
+        ctx = DeviceContext(0)
+        try:
+            ctx.set_problem(p.n_barcodes, p.n_variants, G, p.variant_id, p.compressed_cb, p.p_base_wrong, p.v2snp)
+            ctx.set_betas(p.prior_betas(add_data_prior=False))
+            ctx.set_addition(None)
+            ctx.probs_from_betas(0.01, fetch=False)
+            if fails:
+                with pytest.raises(DemuxHipError, match='more than 1024 genotypes'):
+                    ctx.estep(pen, with_doublets=doublets, fetch_logits=False, fetch_probs=True)
+            else:
+                _, probs = ctx.estep(pen, with_doublets=doublets, fetch_logits=False, fetch_probs=True)
+                assert np.isfinite(probs).all() and np.allclose(probs.sum(1), 1.0, atol=1e-4)
+        finally:
+            ctx.close()
