@@ -471,9 +471,12 @@ __global__ __launch_bounds__(256) void k_estep_direct(EstepArgs a)
             if constexpr (PAIRS && A <= 8) {
                 // rows loaded whole, the options' two genotypes picked out of the wavefront (load_pair_rows)
                 constexpr int NL = 2 * H / PairRowShape<A>::RPL;
-                // two batches in flight, as below.  (Tried: four batches in flight - no change; the records through the
-                // vector path, six batches ahead, so that no wait for a pick also waits for scalar loads - slower, 0.196
-                // against 0.175 ms on 20k x 20k x 8 with doublets: what the loop runs on now is the rate of the picks.)
+                // two batches in flight, as below.  PMC (scripts/pmc_doublet_rows.sh, 20k x 20k x 8 with doublets, 0.175 ms):
+                // VALU 50 % busy, LDS array 65 % (4 cycles per pick), 6.6 wavefronts per SIMD.  Tried: four batches in flight -
+                // no change; no scalar memory in the loop (picks and scalar loads share lgkmcnt, and scalar loads return out
+                // of order): records as one dword per lane, keep / floor out of it by v_readlane, stages spread over four
+                // iterations with the picks of the next batch issued before the arithmetic of this one - 0.196 ms, the 16
+                // v_readlane per 8 calls cost more than the waits they remove.
                 if (npairs > 0) {
                     PairRowBatch<H, NL> x, y;
                     load_pair_rows<A, H, NL>(x, recs, 0, rsrc, lane);
