@@ -91,6 +91,43 @@ def test_sharded_em_equals_the_single_context_run(world, reduce_dtype, monkeypat
     assert kinds == {('all_gather', 'float32')}, kinds
 
 
+@pytest.mark.parametrize('exchange', ['variant', 'reduce_scatter'])
+@pytest.mark.parametrize('n_barcodes,n_snps,world', [(3, 40, 4), (50, 2, 4), (7, 3, 3)])
+def test_sharded_em_with_empty_ranks_and_empty_slices(n_barcodes, n_snps, world, exchange, monkeypatch):
+    """Fewer barcodes than ranks (ranks without a barcode or a call) and fewer SNPs than ranks (variant slices without a
+    variant): the sharded run still equals the single context."""
+    monkeypatch.setenv('DEMUXALOT_AMD_EXCHANGE', exchange)
+    from demuxalot_amd import distributed, synth
+    from demuxalot_amd.device import DeviceContext
+    G = 5
+    p = synth.generate(n_barcodes, n_snps, G, calls_per_barcode=12, seed=31 + n_barcodes)
+    betas = p.prior_betas()
+    pen = np.zeros(G, dtype=np.float32)
+    with DeviceContext(0) as ctx:
+        ctx.set_problem(p.n_barcodes, p.n_variants, G, p.variant_id, p.compressed_cb, p.p_base_wrong, p.v2snp)
+        ctx.set_betas(betas)
+        _l, want_probs, want_add = ctx.em(3, 0.01, pen, False, fetch_logits=False)
+    shared = ThreadWorld(world)
+
+    def rank_body(plane):
+        em = distributed.ShardedEM(plane, p.n_barcodes, p.v2snp, betas, p.variant_id, p.compressed_cb, p.p_base_wrong, reduce_dtype='f64')
+        try:
+            probs, addition = em.learn(3, 0.01, pen, False)
+            return em.lo, em.hi, probs, addition
+        finally:
+            em.ctx.close()
+
+    results = shared.run(rank_body)
+    assert results[0][0] == 0 and results[-1][1] == p.n_barcodes
+    for lo, hi, probs, addition in results:
+        assert probs.shape == (hi - lo, G)
+        if exchange == 'variant':
+            fio.assert_bitwise(probs, want_probs[lo:hi], f'posterior rows [{lo}, {hi})')
+            fio.assert_bitwise(addition, want_add, 'addition')
+        else:
+            assert np.allclose(addition, want_add, rtol=3e-7, atol=0) and np.allclose(probs, want_probs[lo:hi], rtol=0, atol=1e-5)
+
+
 def _socket_rank(rank, world, port, out):
     from demuxalot_amd import _lib, distributed
     from demuxalot_amd.plane import SocketControlPlane
