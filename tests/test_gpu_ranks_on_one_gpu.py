@@ -128,6 +128,37 @@ def test_sharded_em_with_empty_ranks_and_empty_slices(n_barcodes, n_snps, world,
             assert np.allclose(addition, want_add, rtol=3e-7, atol=0) and np.allclose(probs, want_probs[lo:hi], rtol=0, atol=1e-5)
 
 
+@pytest.mark.parametrize('n_genotypes,doublets', [(100, False), (130, False), (70, True)])
+def test_variant_sharded_mstep_beyond_64_genotypes(n_genotypes, doublets, monkeypatch):
+    """Bitmaps of two and three words per barcode (and the wide M-step kernel) through the variant-sharded exchange: three
+    ranks against one context, bit for bit."""
+    monkeypatch.setenv('DEMUXALOT_AMD_EXCHANGE', 'variant')
+    from demuxalot_amd import Demultiplexer, distributed, synth
+    from demuxalot_amd.device import DeviceContext
+    G = n_genotypes
+    p = synth.generate(900, 400, G, calls_per_barcode=60, doublets=doublets, seed=77 + G)
+    betas = p.prior_betas()
+    pen = Demultiplexer._doublet_penalties(G, 0.2 if doublets else 0.0)
+    with DeviceContext(0) as ctx:
+        ctx.set_problem(p.n_barcodes, p.n_variants, G, p.variant_id, p.compressed_cb, p.p_base_wrong, p.v2snp)
+        ctx.set_betas(betas)
+        _l, want_probs, want_add = ctx.em(3, 0.01, pen, doublets, fetch_logits=False)
+    shared = ThreadWorld(3)
+
+    def rank_body(plane):
+        em = distributed.ShardedEM(plane, p.n_barcodes, p.v2snp, betas, p.variant_id, p.compressed_cb, p.p_base_wrong, reduce_dtype='f64')
+        try:
+            assert em.ctx.exchange_mode() == 'variant'
+            probs, addition = em.learn(3, 0.01, pen, doublets)
+            return em.lo, em.hi, probs, addition
+        finally:
+            em.ctx.close()
+
+    for lo, hi, probs, addition in shared.run(rank_body):
+        fio.assert_bitwise(probs, want_probs[lo:hi], f'posterior rows [{lo}, {hi})')
+        fio.assert_bitwise(addition, want_add, 'addition')
+
+
 def _socket_rank(rank, world, port, out):
     from demuxalot_amd import _lib, distributed
     from demuxalot_amd.plane import SocketControlPlane
