@@ -410,6 +410,9 @@ def main():
     ap.add_argument('--scaling', default='both', choices=['both', 'weak', 'strong'],
                     help='N > 1.  strong: the workload in total, barcodes sharded over the GPUs (BASELINE.json configs[3] as written); '
                          'weak: the workload per GPU; both (default): strong is the headline value, weak a sub-object of the line')
+    ap.add_argument('--mstep', default='tiles', choices=['tiles', 'items', 'auto'],
+                    help='M-step form of the timed regions: tiles (steady state of a long run; records built during the warm-up), '
+                         'items (what runs of fewer than 16 iterations take), auto (the library decides per call)')
     ap.add_argument('--timed-only', action='store_true', help='the timed region of the default mode only (profiler child runs)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-exact-mode', action='store_true', help='skip the second timed region (bit-exact E-step and additions)')
@@ -513,6 +516,15 @@ def main():
         ctx.probs_from_betas(0.01, fetch=False)
         return time.perf_counter() - t
 
+    # The timed region is the steady state of a long EM run.  The library takes the tile-major M-step by itself once a call
+    # has 16 M-steps ahead of it (building its records costs ~4 ms, a sort of the calls: include/demux_hip.h
+    # dmx_set_mstep_tiles); here the records are built during the warm-up, whatever --steps says, and the line carries the
+    # work-item form's figure next to it (`work_item_mstep`: what a 5-iteration learn_genotypes call runs).
+    if args.mstep == 'tiles':
+        ctx.set_mstep_tiles('always')
+    elif args.mstep == 'items':
+        ctx.set_mstep_tiles('never')
+
     # ---- the timed regions: configs[3] as written first (strong: this rank's barcode range), then the workload per GPU ----
     kinds = ['strong', 'weak'] if args.scaling == 'both' else [args.scaling]
     if world == 1:
@@ -532,6 +544,7 @@ def main():
         region.update(value=barcodes_total * args.steps / region['elapsed'], barcodes_total=barcodes_total,
                       barcodes_per_gpu=problem.n_barcodes, calls_per_gpu=problem.n_calls, exchange=ctx.exchange_mode())
         regions[kind] = region
+    ctx_mstep_form = ctx.mstep_form()
     head_kind = kinds[0]
     head = regions[head_kind]
     N, B = problem.n_calls, problem.n_barcodes   # of the problem that is resident now (n = 1: the whole workload)
@@ -554,6 +567,16 @@ def main():
                 max_abs_posterior_diff=float(np.abs(probs_mode - probs0).max()))
         extra_modes[mode] = region
     ctx.apply_environment()
+    work_item_region = None
+    if args.mstep == 'tiles' and not args.timed_only and ctx_mstep_form == 'tiles':
+        ctx.set_mstep_tiles('never')
+        ctx.set_addition(None)
+        ctx.probs_from_betas(0.01, fetch=False)
+        ctx.estep(pen, with_doublets=dp > 0, fetch_logits=False, fetch_probs=False)
+        work_item_region = timed_region(ctx, plane, args.steps, args.warmup)
+        work_item_region['value'] = regions[kinds[-1]]['barcodes_total'] * args.steps / work_item_region['elapsed']
+        work_item_region['scaling'] = kinds[-1]
+        ctx.set_mstep_tiles('always')
 
     # predict_posteriors throughput on the same resident problem (P + E only, no beta addition: demux.py:120-156),
     # rank-local.  The genotype table is then the importers' (a handful of distinct values per row), which is the
@@ -607,6 +630,7 @@ def main():
             'config': {'workload': args.workload, 'barcodes_total': head['barcodes_total'], 'barcodes_per_gpu': head['barcodes_per_gpu'],
                        'snps': S, 'variants': V, 'genotypes': G, 'options': K, 'calls_per_gpu': head['calls_per_gpu'], 'doublet_prior': dp,
                        'estep_mode': default_mode + mode_notes[default_mode],
+                       'mstep_form': ctx_mstep_form,
                        'parallelism': f'barcode shards x{world}' + (
                            {'variant': ', M-step sharded on variants: all-gather of posterior codes / bitmaps / singlet posteriors, all-gather f32 of genotype_prob slices',
                             'reduce_scatter': f', reduce-scatter {args.reduce_dtype} of the partial sums + all-gather f32 of genotype_prob slices',
@@ -626,6 +650,10 @@ def main():
                                    'N x 200k-barcode experiment')
         for mode, region in extra_modes.items():
             out[f'{mode}_mode'] = {k: v for k, v in region.items() if k != 'elapsed'}
+        if work_item_region:
+            out['work_item_mstep'] = {k: v for k, v in work_item_region.items() if k != 'elapsed'}
+            out['work_item_mstep']['note'] = ('the same timed region with the work-item M-step, the form of runs with fewer than 16 M-steps '
+                                              'ahead (the tile-major records cost a 4 ms sort of the calls to build)')
         if predict:
             out['predict'] = predict
             out['predict_barcodes_per_s'] = B / predict['dictionary_form']['seconds']

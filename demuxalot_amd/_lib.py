@@ -88,6 +88,8 @@ SIGNATURES = {
     'dmx_get_estep_form': (c_int, [_P, POINTER(c_int32), POINTER(c_int32)]),
     'dmx_set_estep_packing': (c_int, [_P, c_int]),
     'dmx_set_mstep_wide_addresses': (c_int, [_P, c_int]),
+    'dmx_set_mstep_tiles': (c_int, [_P, c_int]),
+    'dmx_get_mstep_form': (c_int, [_P, POINTER(c_int32)]),
     'dmx_test_logf': (c_int, [_P, _P, _P, c_int64]),
     'dmx_test_logf_hot': (c_int, [_P, _P, _P, c_int64]),
     'dmx_test_expf': (c_int, [_P, _P, _P, c_int64]),

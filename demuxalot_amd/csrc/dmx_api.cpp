@@ -476,6 +476,7 @@ void release_problem(dmx_ctx *c)
     c->slice_rows = c->prob_rows = 0;
     c->cut.clear();
     c->h_v2snp.clear();
+    dmx::release_mstep_tiles(c);
     dev_free(c, &c->d_partial, (size_t)c->n_items * c->G);
     dev_free(c, &c->d_redo, c->cap_redo);
     dev_free(c, &c->d_n_redo, (size_t)2);
@@ -1312,6 +1313,28 @@ int run_mstep(dmx_ctx *c, float power)
     // where k_mcombine writes: the variants of one work item are written there by the M-step kernels themselves
     a.item_variant = c->d_item_variant;
     a.redo_cap = c->cap_redo;
+    // tile-major form (kernels.h: MTileArgs): sums in any order, so not with the exact additions; built on first use
+    a.tiles_done = false;
+    dmx::MTileArgs tiles{};
+    // Building the records (a sort of the calls: 4.1 ms on 200k x 100k x 64, where an M-step then takes 0.46 instead of
+    // 0.69 ms) pays from MSTEP_TILES_PAY M-steps on: taken when the running call still has that many to do, or the
+    // problem has seen that many already (somebody iterates call by call), or always (dmx_set_mstep_tiles(ctx, 2)).
+    constexpr int MSTEP_TILES_PAY = 16;
+    const bool tiles_wanted = c->mstep_tiles == 2 || (c->mstep_tiles == 1 && (c->n_mt > 0 || c->msteps_ahead >= MSTEP_TILES_PAY ||
+                                                                             c->msteps_done >= MSTEP_TILES_PAY));
+    c->msteps_done++;
+    if (!c->exact_additions && tiles_wanted && c->G <= 64 && c->n_csc > 0) {
+        if (!c->mt_tried) DMX_TRY(dmx::build_mstep_tiles(c, mshard ? c->cut[c->rank] : 0, mshard ? c->cut[c->rank + 1] : c->V));
+        if (c->n_mt > 0) {
+            tiles.stream = c->d_mt_stream;
+            tiles.ptr = c->d_mt_ptr;
+            tiles.first = c->d_mt_first;
+            tiles.order = c->d_mt_order;
+            tiles.n_tiles = c->n_mt;
+            tiles.tv = c->mt_tv;
+            a.tiles_done = true;
+        }
+    }
     if (!dist || mshard) {
         a.out32 = c->d_add;
     } else if (c->sliced) {
@@ -1323,7 +1346,9 @@ int run_mstep(dmx_ctx *c, float power)
         else a.out32 = c->d_add;
     }
     timer_begin(c, DMX_T_MSTEP, &ev);
-    HIP_TRY(dmx::launch_mstep(c->stream, a));
+    if (a.tiles_done) HIP_TRY(dmx::launch_mstep_tiles(c->stream, a, tiles));
+    else HIP_TRY(dmx::launch_mstep(c->stream, a));
+    c->mstep_form = a.tiles_done ? 2 : 1;
     timer_end(c, DMX_T_MSTEP, ev);
     if (!dist) {
         timer_begin(c, DMX_T_MCOMBINE, &ev);
@@ -1523,6 +1548,7 @@ static int finish_problem(dmx_ctx *c, const int32_t *v2snp, const std::vector<in
     HIP_TRY(hipStreamSynchronize(st));  // host staging vectors die in the caller
     DMX_TRY(build_row_segments(c));
     DMX_TRY(layout_exchange(c));        // genotype_prob table (padded when a communicator is attached)
+    c->msteps_done = 0;
     c->have_problem = true;
     return 0;
 }
@@ -1741,6 +1767,21 @@ int dmx_get_redo_count(dmx_ctx *c, int64_t *count)
     return 0;
 }
 
+int dmx_set_mstep_tiles(dmx_ctx *c, int enable)
+{
+    if (!c) return fail(DMX_ERR_INVALID, "null context");
+    if (enable < 0 || enable > 2) return fail(DMX_ERR_INVALID, "dmx_set_mstep_tiles: 0 never, 1 when it pays, 2 always");
+    c->mstep_tiles = enable;
+    return 0;
+}
+
+int dmx_get_mstep_form(dmx_ctx *c, int32_t *form)
+{
+    if (!c || !form) return fail(DMX_ERR_INVALID, "null argument");
+    *form = c->mstep_form;
+    return 0;
+}
+
 int dmx_set_mstep_wide_addresses(dmx_ctx *c, int wide)
 {
     if (!c) return fail(DMX_ERR_INVALID, "null context");
@@ -1936,7 +1977,12 @@ int dmx_em(dmx_ctx *c, int n_iterations, float lo, float hi, int with_doublets, 
     for (int it = 0; it < n_iterations; it++) {
         DMX_TRY(run_pstep(c, lo, hi, true));
         DMX_TRY(run_estep(c, with_doublets, it == 0 && prior_logits != nullptr, prior_dtype, power));
-        if (it + 1 < n_iterations) DMX_TRY(run_mstep(c, power));  // the M-step after the last yield is dead
+        if (it + 1 < n_iterations) {  // the M-step after the last yield is dead
+            c->msteps_ahead = n_iterations - 1 - it;
+            const int rc_m = run_mstep(c, power);
+            c->msteps_ahead = 0;
+            if (rc_m) return rc_m;
+        }
     }
     const size_t bk = (size_t)c->B * c->K;
     DMX_TRY(copy_out(c, logits_out, c->d_logits, bk));
@@ -1957,7 +2003,10 @@ int dmx_run_iterations(dmx_ctx *c, int n_iterations, float lo, float hi, float p
     for (int it = 0; it < n_iterations; it++) {
         DMX_TRY(run_pstep(c, lo, hi, true));
         DMX_TRY(run_estep(c, with_doublets, false, DMX_F32, power));
-        DMX_TRY(run_mstep(c, power));
+        c->msteps_ahead = n_iterations - it;
+        const int rc_m = run_mstep(c, power);
+        c->msteps_ahead = 0;
+        if (rc_m) return rc_m;
     }
     return 0;
 }

@@ -72,6 +72,18 @@ struct dmx_ctx {
     unsigned *d_n_redo = nullptr;
     size_t cap_redo = 0;
     bool mstep_wide = false;  // dmx_set_mstep_wide_addresses
+    // tile-major M-step (kernels.hip: k_mstep_tiles; built on first use by build_mstep_tiles, n_mt == 0: not built / not eligible)
+    uint2 *d_mt_stream = nullptr;   // [n_csc] the M-step records once more, sorted by (variant tile, barcode row): x = row | variant in tile << 24
+    long long *d_mt_ptr = nullptr;  // [n_mt + 1] first record of every tile
+    int *d_mt_first = nullptr;      // [n_mt + 1] first variant of every tile
+    int *d_mt_order = nullptr;      // [n_mt] tiles by decreasing number of calls
+    long long n_mt = 0;
+    int mt_tv = 0;                  // variants per tile at most
+    bool mt_tried = false;          // a build was attempted for the resident M-step records
+    int mstep_tiles = 1;            // dmx_set_mstep_tiles: 0 never, 1 when building the records pays, 2 always
+    long long msteps_done = 0;      // M-steps run on the resident problem
+    int msteps_ahead = 0;           // M-steps the running dmx_em / dmx_run_iterations call still has to do (0 outside)
+    int mstep_form = 0;             // form of the last M-step launch: 0 none, 1 work items, 2 tiles (dmx_get_mstep_form)
     int *d_sum_plan = nullptr;  // np.sum over a row of K values as a leaf / level plan (dmx_api.cpp: ensure_options)
     size_t cap_sum_plan = 0;
     long long sum_plan_k = -1;
@@ -249,6 +261,10 @@ int ensure_sum_plan(dmx_ctx *c, long long K);  // dmx_api.cpp
 // multi-GPU, M-step records by variant slice (repack_device.hip)
 int wire_records_of(dmx_ctx *c, long long row_base, uint4 *d_out, long long capacity);
 int install_mstep_records(dmx_ctx *c, const uint4 *d_rec, long long n, long long v_lo, long long v_hi);
+// tile-major M-step records of variants [v_lo, v_hi) (the ctx's M-step records must cover exactly those); leaves n_mt == 0
+// when the problem does not fit the form
+int build_mstep_tiles(dmx_ctx *c, long long v_lo, long long v_hi);
+void release_mstep_tiles(dmx_ctx *c);
 int build_snp_groups(dmx_ctx *c, const unsigned long long *vb_keys, const unsigned *src_idx, const float *src_p, long long m);
 int stage_containers_on_device(dmx_ctx *c, const dmx_call_container *parts, int n_parts);
 int pack_staged_on_device(dmx_ctx *c, long long V, const int *var_chrom, const int *var_pos, const unsigned char *var_base,

@@ -133,6 +133,7 @@ hipError_t launch_pack_rows(hipStream_t, const float *, const unsigned char *, c
 hipError_t launch_estep_dict(hipStream_t, const EstepArgs &, bool) { return hipSuccess; }
 hipError_t launch_estep_dict_block(hipStream_t, const EstepArgs &) { return hipSuccess; }
 hipError_t launch_mstep(hipStream_t, const MstepArgs &) { return hipSuccess; }
+hipError_t launch_mstep_tiles(hipStream_t, const MstepArgs &, const MTileArgs &) { return hipSuccess; }
 hipError_t launch_mcombine(hipStream_t, const MstepArgs &, const long long *, long long, long long, const int *, float *, double *,
                            unsigned long long *, unsigned *, const int *, bool) { return hipSuccess; }
 hipError_t launch_store_slice(hipStream_t, const void *, bool, long long, long long, int, float *) { return hipSuccess; }
@@ -268,6 +269,18 @@ int wire_records_of(dmx_ctx *c, long long row_base, uint4 *out, long long capaci
             out[s] = make_uint4((unsigned)c->d_item_variant[it], c->d_csc[s].x + (unsigned)row_base, c->d_csc[s].y, 1u);
         }
     return 0;
+}
+
+// the tile-major M-step records are a device-side layout: the host build stays with the work-item form
+int build_mstep_tiles(dmx_ctx *c, long long, long long)
+{
+    c->mt_tried = true;
+    return 0;
+}
+void release_mstep_tiles(dmx_ctx *c)
+{
+    c->n_mt = 0;
+    c->mt_tried = false;
 }
 
 int install_mstep_records(dmx_ctx *c, const uint4 *rec, long long n, long long v_lo, long long v_hi)

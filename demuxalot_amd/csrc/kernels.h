@@ -130,6 +130,7 @@ struct MstepArgs {
     // its partial sums (the chunked exchange, whose output rows differ per chunk).
     const int *item_variant;        // nullable [n_items] variant of every item
     unsigned long long redo_cap;    // capacity of the redo queue (launch_mcombine: long variants from the front, the others from the back)
+    bool tiles_done;                // the sums were written by k_mstep_tiles unless the dense regime's kernel ran (k_mcombine then only acts in that regime)
     const long long *item_ptr;      // [V + 1] first item of every variant
     const int *prow;                // nullable [V] row of every variant in the output table
     float *out32;                   // exactly one of the two (or none: item_variant == nullptr)
@@ -194,6 +195,22 @@ hipError_t launch_mstep(hipStream_t st, const MstepArgs &a);
 // prow (nullable): row of every variant in the output tables (padded multi-GPU exchange buffer)
 // vlist (nullable): the variants are entries [v0, v1) of this list instead of v0 .. v1 - 1 (chunks of the pipelined exchange)
 // skip_single: the variants of one item were written by the M-step kernels themselves (MstepArgs::item_variant)
+// Tile-major M-step (sums in any order: not for dmx_set_exact_additions), G <= 64.  The variant axis is cut into tiles of at most
+// `tv` variants; the M-step records are kept once more sorted by (tile, barcode row), so that a tile's calls read the barcode
+// codes in ascending order (the item form's one gather per call out of a 1.6 MB table, 112 G requests/s to the L2s, was
+// what bounded it).  One workgroup per tile: float64 accumulators [variants of the tile][G] in LDS, ds_add_f64.
+struct MTileArgs {
+    const uint2 *stream;   // x = barcode row | variant in tile << 24, y = bits of 1 - p_base_wrong
+    const long long *ptr;  // [n_tiles + 1]
+    const int *first;      // [n_tiles + 1] first variant of every tile
+    const int *order;      // [n_tiles] tiles by decreasing number of calls
+    long long n_tiles;
+    int tv;
+};
+constexpr int MTILE_LDS_BYTES = 64 * 1024;  // accumulators of a tile: with the 12 KB of dense-call queues, two workgroups per CU
+constexpr int MTILE_MAX_VARIANTS = 128;     // 7 bits of the record
+hipError_t launch_mstep_tiles(hipStream_t st, const MstepArgs &a, const MTileArgs &t);
+
 hipError_t launch_mcombine(hipStream_t st, const MstepArgs &a, const long long *item_ptr, long long v0, long long v1,
                            const int *prow, float *add32, double *add64, unsigned long long *redo, unsigned *n_redo,
                            const int *vlist = nullptr, bool skip_single = false);

@@ -1558,6 +1558,127 @@ __global__ __launch_bounds__(256) void k_mstep_calls(MstepArgs a)
     if (lane < G) mstep_store(a, item, lane, acc);
 }
 
+// ------------------------------------------------------------------------------------
+// M-step, tile-major form (kernels.h: MTileArgs; G <= 64; sums in any order - not for the exact additions).
+// The item form above walks one variant's calls at a time, and a variant's calls belong to barcodes ~500 apart: one 8-byte
+// gather of the barcode's code per call, 64 different cache lines per wavefront load - 78.7 M requests to the L2s on
+// 200k x 100k x 64, which is what it ran on (0.68 ms whatever was done to its arithmetic).  Here the records of a TILE of
+// up to 128 variants are sorted by barcode, so that the 64 calls of a wavefront load belong to ~64 barcodes out of a
+// window of ~130 consecutive ones: the code gather touches 8-16 lines instead of 64.  What the order costs - the
+// contributions of a variant no longer arrive together - is paid in LDS: the workgroup keeps float64 accumulators
+// [variants of the tile][G] there and every lane adds its call's contribution(s) with ds_add_f64 (any order; the sums are
+// exact in float64 for all but the longest variants, and rounded to float32 once).
+//   sparse calls (<= NZ_CODE live posteriors: the code holds the genotypes and the first posterior) one per lane,
+//   dense calls one at a time by the whole wavefront, lane g taking post[row, g].
+// The workgroup of a tile writes its rows of the output itself: no partial sums, no combining pass.
+// ------------------------------------------------------------------------------------
+constexpr int MTILE_QUEUE = 128;  // dense calls a wavefront parks before it takes their rows (>= 64 + the flush threshold)
+template <bool SQUARE>
+__global__ __launch_bounds__(512) void k_mstep_tiles(MstepArgs a, MTileArgs t)
+{
+    if (dense_regime(a)) return;
+    extern __shared__ __attribute__((aligned(16))) double mt_acc[];
+    __shared__ unsigned mt_queue[8][3][MTILE_QUEUE];  // per wavefront: barcode row, accumulator base, keep bits of its parked dense calls
+    const int tile = t.order[blockIdx.x];
+    const int v0 = t.first[tile], nv = t.first[tile + 1] - v0;
+    const long long beg = t.ptr[tile], end = t.ptr[tile + 1];
+    const int G = a.G;
+    const long long K = a.K;
+    for (int i = threadIdx.x; i < nv * G; i += 512) mt_acc[i] = 0.0;
+    __syncthreads();
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    unsigned *q_row = mt_queue[wave][0], *q_base = mt_queue[wave][1], *q_keep = mt_queue[wave][2];
+    int queued = 0;  // (uniform)
+    auto power_of = [&](float c) { return SQUARE ? c * c : powf(c, a.power); };
+    auto add = [&](int index, float c) {
+        __hip_atomic_fetch_add(&mt_acc[index], (double)c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    };
+    // The parked dense calls, 16 at a time: lane g takes post[row, g] of every one of them (16 row loads in flight: they come
+    // from the posterior table, i.e. over the fabric, and one at a time their latency was the whole kernel), then adds.  A
+    // posterior at or below the contribution floor contributes exactly +0 (as in k_mstep_dense): no bitmap is read.
+    auto flush = [&]() {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        constexpr int DB = 16;
+        for (int q0 = 0; q0 < queued; q0 += DB) {
+            float p[DB];
+#pragma unroll
+            for (int i = 0; i < DB; i++) {
+                p[i] = 0.0f;
+                if (q0 + i < queued && lane < G) p[i] = a.post[(size_t)q_row[q0 + i] * K + lane];
+            }
+#pragma unroll
+            for (int i = 0; i < DB; i++)
+                if (q0 + i < queued && lane < G) add((int)q_base[q0 + i] + lane, power_of(p[i] * __uint_as_float(q_keep[q0 + i])));
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        queued = 0;
+    };
+    constexpr int UN = 4;  // chunks of 64 calls in flight per wavefront: records, then codes, then the rare extra posteriors
+    for (long long c0 = beg + (long long)wave * (64 * UN); c0 < end; c0 += 8ll * 64 * UN) {
+        uint2 rec[UN], code[UN];
+#pragma unroll
+        for (int u = 0; u < UN; u++) {
+            const long long i = c0 + 64 * u + lane;
+            rec[u] = make_uint2(0u, 0u);
+            if (i < end) rec[u] = t.stream[i];
+        }
+#pragma unroll
+        for (int u = 0; u < UN; u++) {
+            const long long i = c0 + 64 * u + lane;
+            code[u] = make_uint2(0u, 0u);  // no live genotype
+            if (i < end) code[u] = a.first[rec[u].x & 0xFFFFFFu];
+        }
+        float extra[UN][NZ_CODE - 1];  // the second .. fourth live posterior of the sparse calls (5 % of them have any)
+#pragma unroll
+        for (int u = 0; u < UN; u++) {
+            const int nnz = (int)(code[u].y & 127u);
+            const float *__restrict__ post_row = a.post + (size_t)(rec[u].x & 0xFFFFFFu) * K;
+#pragma unroll
+            for (int j = 1; j < NZ_CODE; j++) {
+                extra[u][j - 1] = 0.0f;
+                if (nnz <= NZ_CODE && j < nnz) extra[u][j - 1] = post_row[(code[u].y >> (7 + 6 * j)) & 63u];
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < UN; u++) {
+            const unsigned row = rec[u].x & 0xFFFFFFu;
+            const int base = (int)(rec[u].x >> 24) * G;
+            const float keep = __uint_as_float(rec[u].y);
+            const int nnz = (int)(code[u].y & 127u);
+            if (nnz >= 1 && nnz <= NZ_CODE) {
+                add(base + (int)((code[u].y >> 7) & 63u), power_of(__uint_as_float(code[u].x) * keep));
+#pragma unroll
+                for (int j = 1; j < NZ_CODE; j++)
+                    if (j < nnz) add(base + (int)((code[u].y >> (7 + 6 * j)) & 63u), power_of(extra[u][j - 1] * keep));
+            }
+            const unsigned long long dense = __ballot(nnz > NZ_CODE);
+            if (dense) {  // (uniform)
+                if (queued > MTILE_QUEUE - 64) flush();
+                if (nnz > NZ_CODE) {
+                    const int at = queued + __popcll(dense & ((1ull << lane) - 1ull));
+                    q_row[at] = row;
+                    q_base[at] = (unsigned)base;
+                    q_keep[at] = rec[u].y;
+                }
+                queued += __popcll(dense);
+            }
+        }
+    }
+    if (queued) flush();
+    __syncthreads();
+    for (int i = threadIdx.x; i < nv * G; i += 512) {
+        const int r = (int)((unsigned)i / (unsigned)G), g = i - r * G;
+        const long long v = v0 + r;
+        const size_t o = (size_t)(a.prow ? (long long)a.prow[v] : v) * G + g;
+        if (a.out32) a.out32[o] = (float)mt_acc[i];
+        else a.out64[o] = mt_acc[i];
+    }
+}
+
 // one wavefront per (barcode, 64 genotypes): the bitmap and first-posterior table as the E-step writes them
 __global__ __launch_bounds__(256) void k_rebuild_nz(const float *__restrict__ post, long long B, int K, int G,
                                                     float nz_floor, unsigned long long *__restrict__ nz,
@@ -1601,37 +1722,41 @@ __global__ __launch_bounds__(256) void k_mcombine(const double *__restrict__ par
                                                   const int *__restrict__ prow, float *__restrict__ add32,
                                                   double *__restrict__ add64, unsigned long long *__restrict__ redo,
                                                   unsigned *__restrict__ n_redo, unsigned long long redo_cap,
-                                                  const int *__restrict__ vlist, bool skip_single)
+                                                  const int *__restrict__ vlist, bool skip_single,
+                                                  const unsigned long long *__restrict__ dense_calls, unsigned long long total_calls,
+                                                  bool only_dense)
 {
-    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= (v1 - v0) * G) return;
-    long long row;
-    int g;
-    if ((v1 - v0) * G < (1ll << 31)) {  // (uniform) the 64-bit division is a hundred instructions
-        row = (unsigned)i / (unsigned)G;
-        g = (int)((unsigned)i - (unsigned)row * (unsigned)G);
-    } else {
-        row = i / G;
-        g = (int)(i % G);
-    }
-    const long long v = vlist ? (long long)vlist[v0 + row] : v0 + row;  // vlist: entries [v0, v1) of a list of variants
-    const long long it0 = item_ptr[v], it1 = item_ptr[v + 1];
-    if (skip_single && it1 - it0 == 1) return;  // written by the item's own wavefront (mstep_store)
-    double s = 0.0;
-    for (long long it = it0; it < it1; it++) s += partial[(size_t)it * G + g];
-    const long long o = (prow ? (long long)prow[v] : v) * G + g;  // prow: padded rows of the multi-GPU exchange buffer
-    if (add64) add64[o] = s;
-    if (add32) add32[o] = (float)s;
-    if (redo && it1 - it0 > 1 && s > 0.0) {
-        const long long n = item_start[it1 - 1] + item_len[it1 - 1] - item_start[it0];
-        const double bound = 4.0 * (double)n * 1.1102230246251565e-16 * s;
-        const float f = (float)s;
-        const double lo = 0.5 * ((double)f + (double)nextafterf(f, 0.0f));  // rounding boundary towards zero
-        const double hi = 0.5 * ((double)f + (double)nextafterf(f, __builtin_inff()));
-        if (!(s - bound > lo && s + bound < hi)) {
-            const unsigned long long entry = ((unsigned long long)v << 16) | (unsigned long long)g;
-            if (n > EXACT_LONG) redo[atomicAdd(&n_redo[0], 1u)] = entry;       // a workgroup per sum
-            else redo[redo_cap - 1ull - atomicAdd(&n_redo[1], 1u)] = entry;    // a wavefront per sum
+    // only_dense: k_mstep_tiles has written the sums, unless the dense regime's kernel (partial sums per item) took the launch
+    if (only_dense && !(dense_calls != nullptr && 4ull * *dense_calls > total_calls)) return;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < (v1 - v0) * G; i += (long long)gridDim.x * blockDim.x) {
+        long long row;
+        int g;
+        if ((v1 - v0) * G < (1ll << 31)) {  // (uniform) the 64-bit division is a hundred instructions
+            row = (unsigned)i / (unsigned)G;
+            g = (int)((unsigned)i - (unsigned)row * (unsigned)G);
+        } else {
+            row = i / G;
+            g = (int)(i % G);
+        }
+        const long long v = vlist ? (long long)vlist[v0 + row] : v0 + row;  // vlist: entries [v0, v1) of a list of variants
+        const long long it0 = item_ptr[v], it1 = item_ptr[v + 1];
+        if (skip_single && it1 - it0 == 1) continue;  // written by the item's own wavefront (mstep_store)
+        double s = 0.0;
+        for (long long it = it0; it < it1; it++) s += partial[(size_t)it * G + g];
+        const long long o = (prow ? (long long)prow[v] : v) * G + g;  // prow: padded rows of the multi-GPU exchange buffer
+        if (add64) add64[o] = s;
+        if (add32) add32[o] = (float)s;
+        if (redo && it1 - it0 > 1 && s > 0.0) {
+            const long long n = item_start[it1 - 1] + item_len[it1 - 1] - item_start[it0];
+            const double bound = 4.0 * (double)n * 1.1102230246251565e-16 * s;
+            const float f = (float)s;
+            const double lo = 0.5 * ((double)f + (double)nextafterf(f, 0.0f));  // rounding boundary towards zero
+            const double hi = 0.5 * ((double)f + (double)nextafterf(f, __builtin_inff()));
+            if (!(s - bound > lo && s + bound < hi)) {
+                const unsigned long long entry = ((unsigned long long)v << 16) | (unsigned long long)g;
+                if (n > EXACT_LONG) redo[atomicAdd(&n_redo[0], 1u)] = entry;       // a workgroup per sum
+                else redo[redo_cap - 1ull - atomicAdd(&n_redo[1], 1u)] = entry;    // a wavefront per sum
+            }
         }
     }
 }
@@ -2132,6 +2257,24 @@ hipError_t launch_mstep(hipStream_t st, const MstepArgs &a)
     return hipGetLastError();
 }
 
+hipError_t launch_mstep_tiles(hipStream_t st, const MstepArgs &a, const MTileArgs &t)
+{
+    if (t.n_tiles == 0) return hipSuccess;
+    const size_t lds = (size_t)t.tv * a.G * sizeof(double);
+    if (a.square)
+        hipLaunchKernelGGL((k_mstep_tiles<true>), dim3((unsigned)t.n_tiles), dim3(512), lds, st, a, t);
+    else
+        hipLaunchKernelGGL((k_mstep_tiles<false>), dim3((unsigned)t.n_tiles), dim3(512), lds, st, a, t);
+    if (a.dense_calls && a.n_items) {  // the dense regime's kernel; exactly one of the two does the work (dense_regime)
+        const dim3 grid(blocks_for(a.n_items, 4));
+        if (a.square)
+            hipLaunchKernelGGL((k_mstep_dense<true>), grid, dim3(256), 0, st, a);
+        else
+            hipLaunchKernelGGL((k_mstep_dense<false>), grid, dim3(256), 0, st, a);
+    }
+    return hipGetLastError();
+}
+
 hipError_t launch_mcombine(hipStream_t st, const MstepArgs &a, const long long *item_ptr, long long v0, long long v1,
                            const int *prow, float *add32, double *add64, unsigned long long *redo, unsigned *n_redo, const int *vlist,
                            bool skip_single)
@@ -2141,8 +2284,11 @@ hipError_t launch_mcombine(hipStream_t st, const MstepArgs &a, const long long *
         const hipError_t e = hipMemsetAsync(n_redo, 0, 2 * sizeof(unsigned), st);
         if (e != hipSuccess) return e;
     }
-    hipLaunchKernelGGL(k_mcombine, dim3(blocks_for((v1 - v0) * a.G, 256)), dim3(256), 0, st, a.partial, item_ptr,
-                       a.item_start, a.item_len, v0, v1, a.G, prow, add32, add64, redo, n_redo, a.redo_cap, vlist, skip_single);
+    // (after k_mstep_tiles the pass only acts in the dense regime: a small grid that strides, so that standing back costs nothing)
+    const unsigned full_grid = blocks_for((v1 - v0) * a.G, 256);
+    hipLaunchKernelGGL(k_mcombine, dim3(a.tiles_done ? std::min(full_grid, 1024u) : full_grid), dim3(256), 0, st, a.partial, item_ptr,
+                       a.item_start, a.item_len, v0, v1, a.G, prow, add32, add64, redo, n_redo, a.redo_cap, vlist, skip_single,
+                       a.dense_calls, a.total_calls, a.tiles_done);
     if (!redo) return hipGetLastError();
     // exact mode: the sums that must be redone in the reference's order (see k_mcombine)
     const dim3 grid(512), block(64 * EXACT_WAVES);

@@ -618,6 +618,7 @@ int install_mstep_records(dmx_ctx *c, const uint4 *d_rec, long long n, long long
     if (m) hipLaunchKernelGGL(k_iota, dim3(grid_for(m)), dim3(256), 0, st, iota, m);
     DMX_TRY(sort_pairs(sc, variant, keys_v, iota, perm, (size_t)m, bits_for(V ? V - 1 : 0), st));
     // the old records and items go, the slice's come
+    release_mstep_tiles(c);
     dev_free(c, &c->d_csc, (size_t)c->n_csc);
     dev_free(c, &c->d_item_start, (size_t)c->n_items);
     dev_free(c, &c->d_item_len, (size_t)c->n_items);
@@ -661,6 +662,141 @@ int install_mstep_records(dmx_ctx *c, const uint4 *d_rec, long long n, long long
     DMX_TRY(sort_pairs(sc, inv_i, keys_out, ids_i, (unsigned *)c->d_item_order, (size_t)n_items, 32, st));
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipStreamSynchronize(st));
+    return 0;
+}
+
+namespace {
+// one workgroup per work item: sort key (tile, barcode row) and the tile-major record of every call of the item
+__global__ __launch_bounds__(256) void k_mtile_keys(const uint2 *__restrict__ csc, const long long *__restrict__ item_start,
+                                                    const int *__restrict__ item_len, const int *__restrict__ item_variant,
+                                                    const unsigned *__restrict__ tile_of, const unsigned *__restrict__ vin_of,
+                                                    unsigned row_bits, unsigned *__restrict__ keys, uint2 *__restrict__ rec)
+{
+    const long long item = blockIdx.x;
+    const long long s0 = item_start[item];
+    const int n = item_len[item];
+    const int v = item_variant[item];
+    const unsigned tile = tile_of[v], vin = vin_of[v];
+    for (int i = threadIdx.x; i < n; i += 256) {
+        const uint2 d = csc[s0 + i];
+        keys[s0 + i] = (tile << row_bits) | d.x;
+        rec[s0 + i] = make_uint2(d.x | (vin << 24), d.y);
+    }
+}
+}  // namespace
+
+void release_mstep_tiles(dmx_ctx *c)
+{
+    dev_free(c, &c->d_mt_stream, (size_t)c->n_csc);
+    dev_free(c, &c->d_mt_ptr, (size_t)c->n_mt + 1);
+    dev_free(c, &c->d_mt_first, (size_t)c->n_mt + 1);
+    dev_free(c, &c->d_mt_order, (size_t)c->n_mt);
+    c->n_mt = 0;
+    c->mt_tv = 0;
+    c->mt_tried = false;
+}
+
+// Tiles of the tile-major M-step (kernels.h: MTileArgs): runs of at most tv variants and (where a run of variants allows) about
+// cap calls, cut on the host from the work items' offsets; then the M-step records once more, sorted by (tile, barcode row).
+int build_mstep_tiles(dmx_ctx *c, long long v_lo, long long v_hi)
+{
+    release_mstep_tiles(c);
+    c->mt_tried = true;
+    const int G = c->G;
+    const long long rows = c->mshard ? c->rows_total : c->B, m = c->n_csc, n_items = c->n_items;
+    if (G < 1 || G > 64 || rows >= (1LL << 24) || m == 0 || m >= (1LL << 32) || v_hi <= v_lo) return 0;
+    hipStream_t st = c->stream;
+    const long long V = c->V;
+    std::vector<long long> item_ptr((size_t)V + 1), item_start((size_t)n_items);
+    std::vector<int> item_len((size_t)n_items);
+    HIP_TRY(hipMemcpyAsync(item_ptr.data(), c->d_item_ptr, sizeof(long long) * (V + 1), hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipMemcpyAsync(item_start.data(), c->d_item_start, sizeof(long long) * n_items, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipMemcpyAsync(item_len.data(), c->d_item_len, sizeof(int) * n_items, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    // the records are variant-major: first record and number of calls of every variant
+    std::vector<long long> first_call((size_t)V + 1, 0);
+    {
+        long long at = 0;
+        for (long long v = 0; v < V; v++) {
+            first_call[(size_t)v] = at;
+            for (long long it = item_ptr[(size_t)v]; it < item_ptr[(size_t)v + 1]; it++) {
+                if (item_start[(size_t)it] != at) return fail(DMX_ERR_INVALID, "M-step work items are not contiguous in variant order");
+                at += item_len[(size_t)it];
+            }
+        }
+        first_call[(size_t)V] = at;
+        if (at != m) return fail(DMX_ERR_INVALID, "M-step work items cover %lld of %lld records", at, m);
+        if (first_call[(size_t)v_lo] != 0 || first_call[(size_t)v_hi] != m) return 0;  // records outside the range: stay with the item form
+    }
+    if (!c->n_simd) {
+        int cus = 0;
+        HIP_TRY(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, c->device));
+        c->n_simd = 4 * cus;
+    }
+    const int tv = std::max(1, std::min<int>(dmx::MTILE_MAX_VARIANTS, dmx::MTILE_LDS_BYTES / (G * 8)));
+    const unsigned row_bits = bits_for(rows ? (unsigned long long)rows - 1 : 0);
+    std::vector<int> tile_first;
+    std::vector<long long> tile_ptr;
+    std::vector<unsigned> tile_of((size_t)V, 0u), vin_of((size_t)V, 0u);
+    // about twelve tiles per CU (two workgroups per CU at a time), as long as the sort key (tile, row) fits 32 bits
+    long long cap = std::max<long long>(4096, m / (3ll * std::max(1, c->n_simd)));
+    for (int attempt = 0;; attempt++) {
+        tile_first.clear();
+        tile_ptr.clear();
+        long long v = v_lo;
+        while (v < v_hi) {
+            tile_first.push_back((int)v);
+            tile_ptr.push_back(first_call[(size_t)v]);
+            long long w = v + 1;  // a tile takes at least one variant, however many calls it has
+            while (w < v_hi && w - v < tv && first_call[(size_t)w + 1] - first_call[(size_t)v] <= cap) w++;
+            for (long long x = v; x < w; x++) {
+                tile_of[(size_t)x] = (unsigned)(tile_first.size() - 1);
+                vin_of[(size_t)x] = (unsigned)(x - v);
+            }
+            v = w;
+        }
+        const unsigned tile_bits = bits_for(tile_first.empty() ? 0 : (unsigned long long)tile_first.size() - 1);
+        if (tile_bits + row_bits <= 32) break;
+        if (cap >= m || attempt > 40) return 0;  // even the widest tiles are too many for a 32-bit key: item form
+        cap *= 2;
+    }
+    const long long n_mt = (long long)tile_first.size();
+    tile_first.push_back((int)v_hi);
+    tile_ptr.push_back(m);
+    std::vector<int> order((size_t)n_mt);
+    for (long long i = 0; i < n_mt; i++) order[(size_t)i] = (int)i;
+    std::stable_sort(order.begin(), order.end(), [&](int x, int y) {
+        return tile_ptr[(size_t)x + 1] - tile_ptr[(size_t)x] > tile_ptr[(size_t)y + 1] - tile_ptr[(size_t)y];
+    });
+    Scratch sc(c);
+    unsigned *d_tile_of = nullptr, *d_vin_of = nullptr, *keys = nullptr, *keys_out = nullptr, *iota = nullptr, *perm = nullptr;
+    uint2 *rec = nullptr;
+    DMX_TRY(sc.get(&d_tile_of, (size_t)V));
+    DMX_TRY(sc.get(&d_vin_of, (size_t)V));
+    DMX_TRY(sc.get(&keys, (size_t)m));
+    DMX_TRY(sc.get(&keys_out, (size_t)m));
+    DMX_TRY(sc.get(&iota, (size_t)m));
+    DMX_TRY(sc.get(&perm, (size_t)m));
+    DMX_TRY(sc.get(&rec, (size_t)m));
+    HIP_TRY(hipMemcpyAsync(d_tile_of, tile_of.data(), sizeof(unsigned) * V, hipMemcpyHostToDevice, st));
+    HIP_TRY(hipMemcpyAsync(d_vin_of, vin_of.data(), sizeof(unsigned) * V, hipMemcpyHostToDevice, st));
+    hipLaunchKernelGGL(k_mtile_keys, dim3((unsigned)n_items), dim3(256), 0, st, c->d_csc, c->d_item_start, c->d_item_len, c->d_item_variant,
+                       d_tile_of, d_vin_of, row_bits, keys, rec);
+    hipLaunchKernelGGL(k_iota, dim3(grid_for(m)), dim3(256), 0, st, iota, m);
+    const unsigned tile_bits = bits_for(n_mt > 1 ? (unsigned long long)n_mt - 1 : 0);
+    DMX_TRY(sort_pairs(sc, keys, keys_out, iota, perm, (size_t)m, std::max(1u, tile_bits + row_bits), st));
+    DMX_TRY(dev_alloc(c, &c->d_mt_stream, (size_t)m));
+    hipLaunchKernelGGL(k_permute_records, dim3(grid_for(m)), dim3(256), 0, st, perm, rec, m, c->d_mt_stream);
+    DMX_TRY(dev_alloc(c, &c->d_mt_ptr, (size_t)n_mt + 1));
+    DMX_TRY(dev_alloc(c, &c->d_mt_first, (size_t)n_mt + 1));
+    DMX_TRY(dev_alloc(c, &c->d_mt_order, (size_t)n_mt));
+    HIP_TRY(hipMemcpyAsync(c->d_mt_ptr, tile_ptr.data(), sizeof(long long) * (n_mt + 1), hipMemcpyHostToDevice, st));
+    HIP_TRY(hipMemcpyAsync(c->d_mt_first, tile_first.data(), sizeof(int) * (n_mt + 1), hipMemcpyHostToDevice, st));
+    HIP_TRY(hipMemcpyAsync(c->d_mt_order, order.data(), sizeof(int) * n_mt, hipMemcpyHostToDevice, st));
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipStreamSynchronize(st));  // host vectors, scratch
+    c->n_mt = n_mt;
+    c->mt_tv = tv;
     return 0;
 }
 

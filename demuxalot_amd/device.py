@@ -448,6 +448,19 @@ class DeviceContext:
         """include/demux_hip.h: dmx_set_mstep_wide_addresses (the M-step form of the largest problems, at any size)."""
         check(self._lib.dmx_set_mstep_wide_addresses(self._h, int(bool(wide))))
 
+    def set_mstep_tiles(self, mode):
+        """Tile-major form of the M-step: 'never' | 'auto' (default: when building its records pays, i.e. from 16 M-steps on) |
+        'always' (at the first M-step); needs the exact additions off and G <= 64.  include/demux_hip.h: dmx_set_mstep_tiles."""
+        if isinstance(mode, str):
+            mode = {'never': 0, 'auto': 1, 'always': 2}[mode]
+        check(self._lib.dmx_set_mstep_tiles(self._h, int(mode) if not isinstance(mode, bool) else (2 if mode else 0)))
+
+    def mstep_form(self):
+        """None | 'items' | 'tiles': the form of the last M-step launch (include/demux_hip.h: dmx_get_mstep_form)."""
+        form = ctypes.c_int32(0)
+        check(self._lib.dmx_get_mstep_form(self._h, ctypes.byref(form)))
+        return {0: None, 1: 'items', 2: 'tiles'}[form.value]
+
     def redo_count(self):
         """Sums the last exact-mode M-step redid in the reference's order (include/demux_hip.h: dmx_get_redo_count)."""
         n = ctypes.c_int64(0)

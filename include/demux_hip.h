@@ -161,6 +161,17 @@ int dmx_set_exact_additions(dmx_ctx *ctx, int exact);
 /* Number of (variant, genotype) sums the last exact-mode M-step redid in the reference's order (instrumentation). */
 int dmx_get_redo_count(dmx_ctx *ctx, int64_t *count);
 
+/* Tile-major form of the M-step (kernels.h: MTileArgs).  Possible when the exact additions are off (the sums are formed
+ * in any order - float64, one rounding: a float32 rounding tie at most against the reference's order, and not
+ * necessarily the same tie from run to run) and G <= 64: the M-step records are kept once more, sorted by (tile of <= 128
+ * variants, barcode), +8 bytes per call.  Building them is a sort of the calls (4.1 ms on 200k x 100k x 64, where an
+ * M-step then takes 0.46 instead of 0.69 ms), so
+ *   1 (default) builds them when the running dmx_em / dmx_run_iterations call still has 16 M-steps to do, or the
+ *     resident problem has seen 16;  2 at the first M-step;  0 never (the work-item form). */
+int dmx_set_mstep_tiles(dmx_ctx *ctx, int enable);
+/* form of the last M-step launch: 0 none yet, 1 work items, 2 tiles (the dense regime's kernel may still have taken either) */
+int dmx_get_mstep_form(dmx_ctx *ctx, int32_t *form);
+
 /* E-step arithmetic.
  * DMX_ESTEP_EXACT (default): every term log(p (1 - e) + max(e, 1e-4)) is evaluated with numpy's float32 log
  *   operation for operation and accumulated in float64 in the reference's order: logits and posteriors are
