@@ -207,7 +207,7 @@ struct MTileArgs {
     long long n_tiles;
     int tv;
 };
-constexpr int MTILE_LDS_BYTES = 64 * 1024;  // accumulators of a tile: with the 12 KB of dense-call queues, two workgroups per CU
+constexpr int MTILE_LDS_BYTES = 64 * 1024;  // accumulators of a tile: with the 12 KB of dense-call queues, two workgroups of 1024 threads per CU
 constexpr int MTILE_MAX_VARIANTS = 128;     // 7 bits of the record
 hipError_t launch_mstep_tiles(hipStream_t st, const MstepArgs &a, const MTileArgs &t);
 

@@ -1572,23 +1572,27 @@ __global__ __launch_bounds__(256) void k_mstep_calls(MstepArgs a)
 //   dense calls one at a time by the whole wavefront, lane g taking post[row, g].
 // The workgroup of a tile writes its rows of the output itself: no partial sums, no combining pass.
 // ------------------------------------------------------------------------------------
-constexpr int MTILE_QUEUE = 128;  // dense calls a wavefront parks before it takes their rows (>= 64 + the flush threshold)
+// 1024 threads and 64 + 12 KB of LDS per workgroup: two workgroups = 32 wavefronts per CU (56 VGPRs).  Measured on 200k x 100k x
+// 64: 512 threads 0.46 ms, 1024 threads 0.34; 2 / 3 / 4 / 6 / 8 chunks in flight per wavefront 0.50 / 0.35 / 0.34 / 0.45 / 0.44
+// (beyond 64 VGPRs half the wavefronts); dense rows 8 / 16 / 32 at a time 0.36 / 0.34 / 0.47; non-temporal record loads: no change.
+constexpr int MTILE_THREADS = 1024;
+constexpr int MTILE_QUEUE = 96;  // dense calls a wavefront parks before it takes their rows (64 + the flush threshold)
 template <bool SQUARE>
-__global__ __launch_bounds__(512) void k_mstep_tiles(MstepArgs a, MTileArgs t)
+__global__ __launch_bounds__(MTILE_THREADS) void k_mstep_tiles(MstepArgs a, MTileArgs t)
 {
     if (dense_regime(a)) return;
     extern __shared__ __attribute__((aligned(16))) double mt_acc[];
-    __shared__ unsigned mt_queue[8][3][MTILE_QUEUE];  // per wavefront: barcode row, accumulator base, keep bits of its parked dense calls
+    __shared__ unsigned mt_queue[MTILE_THREADS / 64][2][MTILE_QUEUE];  // per wavefront: barcode row | variant in tile << 24, keep bits of its parked dense calls
     const int tile = t.order[blockIdx.x];
     const int v0 = t.first[tile], nv = t.first[tile + 1] - v0;
     const long long beg = t.ptr[tile], end = t.ptr[tile + 1];
     const int G = a.G;
     const long long K = a.K;
-    for (int i = threadIdx.x; i < nv * G; i += 512) mt_acc[i] = 0.0;
+    for (int i = threadIdx.x; i < nv * G; i += MTILE_THREADS) mt_acc[i] = 0.0;
     __syncthreads();
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    unsigned *q_row = mt_queue[wave][0], *q_base = mt_queue[wave][1], *q_keep = mt_queue[wave][2];
+    unsigned *q_rec = mt_queue[wave][0], *q_keep = mt_queue[wave][1];
     int queued = 0;  // (uniform)
     auto power_of = [&](float c) { return SQUARE ? c * c : powf(c, a.power); };
     auto add = [&](int index, float c) {
@@ -1607,18 +1611,18 @@ __global__ __launch_bounds__(512) void k_mstep_tiles(MstepArgs a, MTileArgs t)
 #pragma unroll
             for (int i = 0; i < DB; i++) {
                 p[i] = 0.0f;
-                if (q0 + i < queued && lane < G) p[i] = a.post[(size_t)q_row[q0 + i] * K + lane];
+                if (q0 + i < queued && lane < G) p[i] = a.post[(size_t)(q_rec[q0 + i] & 0xFFFFFFu) * K + lane];
             }
 #pragma unroll
             for (int i = 0; i < DB; i++)
-                if (q0 + i < queued && lane < G) add((int)q_base[q0 + i] + lane, power_of(p[i] * __uint_as_float(q_keep[q0 + i])));
+                if (q0 + i < queued && lane < G) add((int)(q_rec[q0 + i] >> 24) * G + lane, power_of(p[i] * __uint_as_float(q_keep[q0 + i])));
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         queued = 0;
     };
     constexpr int UN = 4;  // chunks of 64 calls in flight per wavefront: records, then codes, then the rare extra posteriors
-    for (long long c0 = beg + (long long)wave * (64 * UN); c0 < end; c0 += 8ll * 64 * UN) {
+    for (long long c0 = beg + (long long)wave * (64 * UN); c0 < end; c0 += (long long)(MTILE_THREADS / 64) * 64 * UN) {
         uint2 rec[UN], code[UN];
 #pragma unroll
         for (int u = 0; u < UN; u++) {
@@ -1660,8 +1664,7 @@ __global__ __launch_bounds__(512) void k_mstep_tiles(MstepArgs a, MTileArgs t)
                 if (queued > MTILE_QUEUE - 64) flush();
                 if (nnz > NZ_CODE) {
                     const int at = queued + __popcll(dense & ((1ull << lane) - 1ull));
-                    q_row[at] = row;
-                    q_base[at] = (unsigned)base;
+                    q_rec[at] = rec[u].x;
                     q_keep[at] = rec[u].y;
                 }
                 queued += __popcll(dense);
@@ -1670,7 +1673,7 @@ __global__ __launch_bounds__(512) void k_mstep_tiles(MstepArgs a, MTileArgs t)
     }
     if (queued) flush();
     __syncthreads();
-    for (int i = threadIdx.x; i < nv * G; i += 512) {
+    for (int i = threadIdx.x; i < nv * G; i += MTILE_THREADS) {
         const int r = (int)((unsigned)i / (unsigned)G), g = i - r * G;
         const long long v = v0 + r;
         const size_t o = (size_t)(a.prow ? (long long)a.prow[v] : v) * G + g;
@@ -2262,9 +2265,9 @@ hipError_t launch_mstep_tiles(hipStream_t st, const MstepArgs &a, const MTileArg
     if (t.n_tiles == 0) return hipSuccess;
     const size_t lds = (size_t)t.tv * a.G * sizeof(double);
     if (a.square)
-        hipLaunchKernelGGL((k_mstep_tiles<true>), dim3((unsigned)t.n_tiles), dim3(512), lds, st, a, t);
+        hipLaunchKernelGGL((k_mstep_tiles<true>), dim3((unsigned)t.n_tiles), dim3(MTILE_THREADS), lds, st, a, t);
     else
-        hipLaunchKernelGGL((k_mstep_tiles<false>), dim3((unsigned)t.n_tiles), dim3(512), lds, st, a, t);
+        hipLaunchKernelGGL((k_mstep_tiles<false>), dim3((unsigned)t.n_tiles), dim3(MTILE_THREADS), lds, st, a, t);
     if (a.dense_calls && a.n_items) {  // the dense regime's kernel; exactly one of the two does the work (dense_regime)
         const dim3 grid(blocks_for(a.n_items, 4));
         if (a.square)

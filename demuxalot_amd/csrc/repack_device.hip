@@ -738,8 +738,10 @@ int build_mstep_tiles(dmx_ctx *c, long long v_lo, long long v_hi)
     std::vector<int> tile_first;
     std::vector<long long> tile_ptr;
     std::vector<unsigned> tile_of((size_t)V, 0u), vin_of((size_t)V, 0u);
-    // about twelve tiles per CU (two workgroups per CU at a time), as long as the sort key (tile, row) fits 32 bits
-    long long cap = std::max<long long>(4096, m / (3ll * std::max(1, c->n_simd)));
+    // at most a 1024th of the calls per tile (four tiles per CU and more: most tiles end at their 128 variants first; a tile costs
+    // its 64 KB of accumulators zeroed and written back - 0.34 / 0.36 / 0.46 / 0.54 ms with caps of 1 / 2 / 3 / 6 per SIMD on
+    // 200k x 100k x 64), as long as the sort key (tile, row) fits 32 bits
+    long long cap = std::max<long long>(4096, m / std::max(1, c->n_simd));
     for (int attempt = 0;; attempt++) {
         tile_first.clear();
         tile_ptr.clear();

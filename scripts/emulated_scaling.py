@@ -79,6 +79,7 @@ def main():
                 try:
                     ctx.set_estep_mode(mode)
                     ctx.set_exact_additions(mode == 'exact')
+                    ctx.set_mstep_tiles('always')  # as bench.py: the tile-major records are built during the warm-up
                     if n > 1:
                         ctx.comm_init_emulated(0, n, args.link_gbps, args.latency_us, reduce_dtype=wire)
                     ctx.set_problem(problem.n_barcodes, problem.n_variants, G, problem.variant_id, problem.compressed_cb, problem.p_base_wrong, problem.v2snp)
