@@ -1575,6 +1575,7 @@ __global__ __launch_bounds__(256) void k_mstep_calls(MstepArgs a)
 // 1024 threads and 64 + 12 KB of LDS per workgroup: two workgroups = 32 wavefronts per CU (56 VGPRs).  Measured on 200k x 100k x
 // 64: 512 threads 0.46 ms, 1024 threads 0.34; 2 / 3 / 4 / 6 / 8 chunks in flight per wavefront 0.50 / 0.35 / 0.34 / 0.45 / 0.44
 // (beyond 64 VGPRs half the wavefronts); dense rows 8 / 16 / 32 at a time 0.36 / 0.34 / 0.47; non-temporal record loads: no change.
+// Requesting the next round's records before working on this one's: 70 VGPRs, or 64 with spills - 0.40 ms.
 constexpr int MTILE_THREADS = 1024;
 constexpr int MTILE_QUEUE = 96;  // dense calls a wavefront parks before it takes their rows (64 + the flush threshold)
 template <bool SQUARE>
