@@ -720,12 +720,12 @@ int build_mstep_tiles(dmx_ctx *c, long long v_lo, long long v_hi)
         for (long long v = 0; v < V; v++) {
             first_call[(size_t)v] = at;
             for (long long it = item_ptr[(size_t)v]; it < item_ptr[(size_t)v + 1]; it++) {
-                if (item_start[(size_t)it] != at) return fail(DMX_ERR_INVALID, "M-step work items are not contiguous in variant order");
+                if (item_start[(size_t)it] != at) return 0;  // (never with the items the repack builds) stay with the work-item form
                 at += item_len[(size_t)it];
             }
         }
         first_call[(size_t)V] = at;
-        if (at != m) return fail(DMX_ERR_INVALID, "M-step work items cover %lld of %lld records", at, m);
+        if (at != m) return 0;
         if (first_call[(size_t)v_lo] != 0 || first_call[(size_t)v_hi] != m) return 0;  // records outside the range: stay with the item form
     }
     if (!c->n_simd) {
