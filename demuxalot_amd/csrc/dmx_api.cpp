@@ -1323,7 +1323,7 @@ int run_mstep(dmx_ctx *c, float power)
     const bool tiles_wanted = c->mstep_tiles == 2 || (c->mstep_tiles == 1 && (c->n_mt > 0 || c->msteps_ahead >= MSTEP_TILES_PAY ||
                                                                              c->msteps_done >= MSTEP_TILES_PAY));
     c->msteps_done++;
-    if (!c->exact_additions && tiles_wanted && c->G <= 64 && c->n_csc > 0 && a.post_bytes < (1ull << 32) && a.first_bytes < (1ull << 32)) {  // (32-bit offsets)
+    if (!c->exact_additions && tiles_wanted && c->G <= 64 && c->n_csc > 0) {
         if (!c->mt_tried) DMX_TRY(dmx::build_mstep_tiles(c, mshard ? c->cut[c->rank] : 0, mshard ? c->cut[c->rank + 1] : c->V));
         if (c->n_mt > 0) {
             tiles.stream = c->d_mt_stream;

@@ -1576,6 +1576,8 @@ __global__ __launch_bounds__(256) void k_mstep_calls(MstepArgs a)
 // 64: 512 threads 0.46 ms, 1024 threads 0.34; 2 / 3 / 4 / 6 / 8 chunks in flight per wavefront 0.50 / 0.35 / 0.34 / 0.45 / 0.44
 // (beyond 64 VGPRs half the wavefronts); dense rows 8 / 16 / 32 at a time 0.36 / 0.34 / 0.47; non-temporal record loads: no change.
 // Requesting the next round's records before working on this one's: 70 VGPRs, or 64 with spills - 0.40 ms.
+// All loads as raw buffer loads with out-of-range masking (no EXEC regions, no 64-bit address arithmetic: 52 VGPRs, a tenth
+// fewer instructions): 0.34 ms as well (0.32 against 0.30 at 32 genotypes) - PMC: VALU 64 %, address unit 69 %, LDS 49 % busy.
 constexpr int MTILE_THREADS = 1024;
 constexpr int MTILE_QUEUE = 96;  // dense calls a wavefront parks before it takes their rows (64 + the flush threshold)
 template <bool SQUARE>
@@ -1599,15 +1601,6 @@ __global__ __launch_bounds__(MTILE_THREADS) void k_mstep_tiles(MstepArgs a, MTil
     auto add = [&](int index, float c) {
         __hip_atomic_fetch_add(&mt_acc[index], (double)c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     };
-    // Loads as raw buffer loads with 32-bit offsets, inactive lanes pointed out of range (such a load returns 0 and makes no
-    // request): no EXEC regions around them, no 64-bit address arithmetic (the first version spent a third of its
-    // instructions on both).  The launcher guarantees tables below 4 GiB.
-    constexpr unsigned OOB = 0xFFFFFFFFu;
-    const unsigned n_tile = (unsigned)(end - beg);
-    const __amdgpu_buffer_rsrc_t r_stream = __builtin_amdgcn_make_buffer_rsrc((void *)(t.stream + beg), 0, (int)(n_tile * 8u), 0x00020000);
-    const __amdgpu_buffer_rsrc_t r_first = __builtin_amdgcn_make_buffer_rsrc((void *)a.first, 0, (int)a.first_bytes, 0x00020000);
-    const __amdgpu_buffer_rsrc_t r_post = __builtin_amdgcn_make_buffer_rsrc((void *)a.post, 0, (int)a.post_bytes, 0x00020000);
-    const unsigned row_bytes = (unsigned)K * 4u;
     // The parked dense calls, 16 at a time: lane g takes post[row, g] of every one of them (16 row loads in flight: they come
     // from the posterior table, i.e. over the fabric, and one at a time their latency was the whole kernel), then adds.  A
     // posterior at or below the contribution floor contributes exactly +0 (as in k_mstep_dense): no bitmap is read.
@@ -1616,13 +1609,12 @@ __global__ __launch_bounds__(MTILE_THREADS) void k_mstep_tiles(MstepArgs a, MTil
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         constexpr int DB = 16;
-        const unsigned lane_off = (unsigned)lane * 4u;
         for (int q0 = 0; q0 < queued; q0 += DB) {
             float p[DB];
 #pragma unroll
             for (int i = 0; i < DB; i++) {
-                const unsigned off = q0 + i < queued && lane < G ? __umul24(q_rec[q0 + i] & 0xFFFFFFu, row_bytes) + lane_off : OOB;
-                p[i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r_post, (int)off, 0, 0));
+                p[i] = 0.0f;
+                if (q0 + i < queued && lane < G) p[i] = a.post[(size_t)(q_rec[q0 + i] & 0xFFFFFFu) * K + lane];
             }
 #pragma unroll
             for (int i = 0; i < DB; i++)
@@ -1633,35 +1625,34 @@ __global__ __launch_bounds__(MTILE_THREADS) void k_mstep_tiles(MstepArgs a, MTil
         queued = 0;
     };
     constexpr int UN = 4;  // chunks of 64 calls in flight per wavefront: records, then codes, then the rare extra posteriors
-    for (unsigned c0 = (unsigned)wave * (64u * UN); c0 < n_tile; c0 += (unsigned)(MTILE_THREADS / 64) * 64u * UN) {
+    for (long long c0 = beg + (long long)wave * (64 * UN); c0 < end; c0 += (long long)(MTILE_THREADS / 64) * 64 * UN) {
         uint2 rec[UN], code[UN];
 #pragma unroll
-        for (int u = 0; u < UN; u++) {  // past the tile's end: zeros (out of the descriptor's range)
-            const auto r = __builtin_amdgcn_raw_buffer_load_b64(r_stream, (int)((c0 + 64u * u + (unsigned)lane) * 8u), 0, 0);
-            rec[u] = make_uint2(r[0], r[1]);
+        for (int u = 0; u < UN; u++) {
+            const long long i = c0 + 64 * u + lane;
+            rec[u] = make_uint2(0u, 0u);
+            if (i < end) rec[u] = t.stream[i];
         }
 #pragma unroll
         for (int u = 0; u < UN; u++) {
-            const bool active = c0 + 64u * u + (unsigned)lane < n_tile;
-            const auto q = __builtin_amdgcn_raw_buffer_load_b64(r_first, (int)(active ? (rec[u].x & 0xFFFFFFu) * 8u : OOB), 0, 0);
-            code[u] = make_uint2(q[0], q[1]);  // inactive: no live genotype
+            const long long i = c0 + 64 * u + lane;
+            code[u] = make_uint2(0u, 0u);  // no live genotype
+            if (i < end) code[u] = a.first[rec[u].x & 0xFFFFFFu];
         }
         float extra[UN][NZ_CODE - 1];  // the second .. fourth live posterior of the sparse calls (5 % of them have any)
 #pragma unroll
         for (int u = 0; u < UN; u++) {
             const int nnz = (int)(code[u].y & 127u);
-            const unsigned base_off = __umul24(rec[u].x & 0xFFFFFFu, row_bytes);
+            const float *__restrict__ post_row = a.post + (size_t)(rec[u].x & 0xFFFFFFu) * K;
 #pragma unroll
             for (int j = 1; j < NZ_CODE; j++) {
-                const bool need = nnz <= NZ_CODE && j < nnz;
                 extra[u][j - 1] = 0.0f;
-                if (__ballot(need) == 0ull) continue;  // (uniform) most chunks have no call with a third or fourth live posterior
-                const unsigned off = need ? base_off + 4u * ((code[u].y >> (7 + 6 * j)) & 63u) : OOB;
-                extra[u][j - 1] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r_post, (int)off, 0, 0));
+                if (nnz <= NZ_CODE && j < nnz) extra[u][j - 1] = post_row[(code[u].y >> (7 + 6 * j)) & 63u];
             }
         }
 #pragma unroll
         for (int u = 0; u < UN; u++) {
+            const unsigned row = rec[u].x & 0xFFFFFFu;
             const int base = (int)(rec[u].x >> 24) * G;
             const float keep = __uint_as_float(rec[u].y);
             const int nnz = (int)(code[u].y & 127u);
