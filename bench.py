@@ -568,7 +568,10 @@ def main():
         extra_modes[mode] = region
     ctx.apply_environment()
     work_item_region = None
-    if args.mstep == 'tiles' and not args.timed_only and ctx_mstep_form == 'tiles':
+    took_tiles = ctx_mstep_form == 'tiles'
+    if plane is not None:  # every rank or none (the region has barriers)
+        took_tiles = plane.all_ok(took_tiles, 'work-item M-step on this rank')[0]
+    if args.mstep == 'tiles' and not args.timed_only and took_tiles:
         ctx.set_mstep_tiles('never')
         ctx.set_addition(None)
         ctx.probs_from_betas(0.01, fetch=False)
