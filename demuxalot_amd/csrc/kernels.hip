@@ -863,7 +863,9 @@ __global__ __launch_bounds__(256) void k_estep_block(EstepArgs a, int C, int k_b
             const int ci = pos + tid;
             const int w = (ci >> 1) * 8 + (ci & 1);
             sh_off[tid] = words[w];  // byte offset of the prob row
-            sh_keep[tid] = __uint_as_float(words[w + 2]);
+            // HALF the keep factor: ((p1 + p2) * 0.5) * keep and (p1 + p2) * (0.5 * keep) round the same real number once (the
+            // halvings are exact: p1 + p2 >= 2 clip, keep = 1 - e is 0 or >= 2^-24), so one multiplication per term less
+            sh_keep[tid] = 0.5f * __uint_as_float(words[w + 2]);
             sh_floor[tid] = __uint_as_float(words[w + 4]);
         }
         __syncthreads();
@@ -881,7 +883,7 @@ __global__ __launch_bounds__(256) void k_estep_block(EstepArgs a, int C, int k_b
                 if (k_base + s * 256 + wave * 64 >= K) continue;  // wave-uniform: this wave's slot lies past the last option
                 const npm::f32x2 pa = *(const npm::f32x2 *)(sh_t + a1[s] + c);
                 const npm::f32x2 pb = *(const npm::f32x2 *)(sh_t + a2[s] + c);
-                npm::f32x2 t = ((pa + pb) * 0.5f) * keep2;
+                npm::f32x2 t = (pa + pb) * keep2;  // keep2 = half the keep factors
                 t = t + flo2;
                 if constexpr (FAST) {  // see estep_products / estep_flush: one log2 per 8 calls
                     prod[s] = (prod[s] * t.x) * t.y;
