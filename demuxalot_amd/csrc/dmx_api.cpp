@@ -508,6 +508,8 @@ void release_problem(dmx_ctx *c)
     c->dict_distinct = 0;
     dev_free(c, &c->d_pen, (size_t)c->cap_k);
     dev_free(c, &c->d_pairs, (size_t)c->cap_k);
+    dev_free(c, &c->d_pair_blocks, (size_t)c->cap_pair_blocks);
+    c->cap_pair_blocks = c->n_pair_blocks = 0;
     dev_free(c, &c->d_sum_plan, c->cap_sum_plan);
     c->cap_sum_plan = 0;
     c->sum_plan_k = -1;
@@ -621,6 +623,22 @@ int ensure_options(dmx_ctx *c, int with_doublets, const float *penalties)
             for (int g2 = g1 + 1; g2 < G; g2++) pairs[k++] = (unsigned)g1 | ((unsigned)g2 << 16);
     }
     HIP_TRY(hipMemcpyAsync(c->d_pairs, pairs.data(), sizeof(unsigned) * K, hipMemcpyHostToDevice, c->stream));
+    // 2 x 3 blocks of the (g1, g2) triangle for the tolerance mode's workgroup-per-barcode kernel (kernels.hip: k_estep_pairblocks)
+    std::vector<unsigned> blocks;
+    if (with_doublets && K > 256) {
+        constexpr int R1 = dmx::PAIRBLOCK_R1, R2 = dmx::PAIRBLOCK_R2;
+        for (int i = 0; R1 * i < G; i++)
+            for (int j = 0; R2 * j < G; j++)
+                if (R2 * j + R2 - 1 >= R1 * i) blocks.push_back((unsigned)i | ((unsigned)j << 16));  // some g2 of the block is >= its smallest g1
+    }
+    c->n_pair_blocks = (int)blocks.size();
+    if (c->n_pair_blocks > c->cap_pair_blocks) {
+        dev_free(c, &c->d_pair_blocks, (size_t)c->cap_pair_blocks);
+        c->cap_pair_blocks = 0;
+        DMX_TRY(dev_alloc(c, &c->d_pair_blocks, blocks.size()));
+        c->cap_pair_blocks = c->n_pair_blocks;
+    }
+    if (c->n_pair_blocks) HIP_TRY(hipMemcpyAsync(c->d_pair_blocks, blocks.data(), sizeof(unsigned) * blocks.size(), hipMemcpyHostToDevice, c->stream));
     HIP_TRY(hipMemcpyAsync(c->d_pen, penalties, sizeof(float) * K, hipMemcpyHostToDevice, c->stream));
     DMX_TRY(dmx::ensure_sum_plan(c, K));
     if ((size_t)c->n_segs * (size_t)K > c->cap_seg_sums) {
@@ -1120,6 +1138,8 @@ int run_estep(dmx_ctx *c, int with_doublets, bool with_prior, int prior_dtype, f
     a.pairs_bytes = rec_bytes < (1ull << 32) ? (unsigned)rec_bytes : 0u;
     a.prob = c->d_prob;
     a.opt_pairs = c->d_pairs;
+    a.pair_blocks = with_doublets ? c->d_pair_blocks : nullptr;
+    a.n_pair_blocks = with_doublets ? c->n_pair_blocks : 0;
     a.sum_plan = c->d_sum_plan;
     a.sum_plan_values = c->sum_plan_values;
     a.pen = c->d_pen;

@@ -127,6 +127,8 @@ struct dmx_ctx {
     long long cap_bk = 0;
     float *d_pen = nullptr;
     unsigned *d_pairs = nullptr;
+    unsigned *d_pair_blocks = nullptr;  // EstepArgs::pair_blocks (doublet runs whose options go to the workgroup-per-barcode forms)
+    int n_pair_blocks = 0, cap_pair_blocks = 0;
     int cap_k = 0;
     void *d_prior_logits = nullptr;
     size_t cap_prior = 0;

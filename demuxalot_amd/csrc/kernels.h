@@ -21,6 +21,11 @@ struct alignas(32) CallPair {
 };
 static_assert(sizeof(CallPair) == 32, "CallPair layout");
 
+// block of the option triangle one thread of k_estep_pairblocks takes: g1 in R1 consecutive genotypes x g2 in R2.  E-step of
+// 130k x 650k x 128 / 20k x 20k x 64 / 20k x 20k x 32, all with doublets (K = 8256 / 2080 / 528), in ms: 2 x 3: 74.8 / 2.97 / 1.23,
+// 3 x 3: 75.3 / 2.61 / 1.82, 2 x 4: 77.4 / 3.56 / 1.56, 3 x 4: 77.1 / 3.08 / 2.18, 4 x 4: 86.0 / 3.67 / 2.57 (k_estep_block<6,true>: 88.2 / 3.45 / 1.2)
+constexpr int PAIRBLOCK_R1 = 2, PAIRBLOCK_R2 = 3;
+
 struct EstepSegment {
     int barcode;     // row
     int first_pair;  // first CallPair of the segment inside the row (a multiple of 4: whole 8-call groups)
@@ -39,6 +44,8 @@ struct EstepArgs {
                                 // leaves (start, length), inner nodes (left value, right value) level by level, roots}
     int sum_plan_values;        // leaves + inner nodes
     const unsigned *opt_pairs;  // [K] g1 | g2 << 16 (doublet runs only)
+    const unsigned *pair_blocks;  // [n_pair_blocks] i | j << 16: 2 x 3 blocks (g1 in {2i, 2i+1}, g2 in {3j .. 3j+2}) that hold an option g1 <= g2 (k_estep_pairblocks)
+    int n_pair_blocks;
     const float *pen;           // [K] doublet penalties
     const void *prior;          // nullable [B, K] prior logits (device)
     int prior_dtype;            // DMX_F32 / DMX_F64

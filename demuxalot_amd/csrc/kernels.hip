@@ -932,6 +932,114 @@ __global__ __launch_bounds__(256) void k_estep_block(EstepArgs a, int C, int k_b
 // STAGED: the row goes to LDS (K floats) once, the workgroup forms numpy's pairwise sum of the exponentials there, and
 // the posteriors are written once.  (Through global memory - the form kept for rows that do not fit, K > 37 000 - the
 // sum is a chain of dependent 4-byte loads by one wavefront: 44 ms on 130k barcodes x 8256 options.)
+// ------------------------------------------------------------------------------------
+// Tolerance / guarded mode, wide doublet tables: the option triangle in 2 x 3 BLOCKS.  k_estep_block gives every thread a
+// run of consecutive options, i.e. per pair of calls two LDS reads (the rows of g1 and of g2) for every option - the LDS
+// array, not arithmetic, is what the tolerance arithmetic then runs on (configs[4]: 88 ms where the multiplications are
+// worth 35).  Here a thread takes the options (g1, g2) of g1 in {2i, 2i+1} x g2 in {3j, 3j+1, 3j+2}: five row reads for six
+// options.  Blocks on the diagonal carry the singlets (g, g) - ((p + p) * 0.5 = p exactly) - and options with g1 > g2 that
+// are computed and dropped.  Same staging, same terms, same products of 8 as k_estep_block<., true>; the rows' softmax and
+// the guard are k_softmax_rows'.
+// ------------------------------------------------------------------------------------
+template <int R1, int R2>
+__global__ __launch_bounds__(256) void k_estep_pairblocks(EstepArgs a, int C, int blk_base)
+{
+    constexpr int NO = R1 * R2;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const long long b = a.order[blockIdx.x];
+    const int K = a.K, G = a.G;
+    const int CS = C + 2;
+    float *sh_t = (float *)smem;  // [G][CS] transposed rows of the chunk's calls
+    float *sh_keep = sh_t + (size_t)G * CS;
+    float *sh_floor = sh_keep + C;
+    unsigned *sh_off = (unsigned *)(sh_floor + C);
+
+    const int blk = blk_base + tid;
+    const bool mine = blk < a.n_pair_blocks;
+    const bool wave_active = blk_base + wave * 64 < a.n_pair_blocks;  // (uniform)
+    const unsigned ij = a.pair_blocks[mine ? blk : a.n_pair_blocks - 1];
+    const int g1_0 = R1 * (int)(ij & 0xFFFFu), g2_0 = R2 * (int)(ij >> 16);
+    unsigned r1[R1], r2[R2];  // LDS dword index of the rows (clamped: options past G are dropped at the end)
+#pragma unroll
+    for (int x = 0; x < R1; x++) r1[x] = (unsigned)min(g1_0 + x, G - 1) * (unsigned)CS;
+#pragma unroll
+    for (int y = 0; y < R2; y++) r2[y] = (unsigned)min(g2_0 + y, G - 1) * (unsigned)CS;
+    double acc[NO];
+    int acc_e[NO];
+    float prod[NO];
+#pragma unroll
+    for (int o = 0; o < NO; o++) {
+        acc[o] = 0.0;
+        acc_e[o] = 0;
+        prod[o] = 1.0f;
+    }
+    const unsigned *__restrict__ words = (const unsigned *)(a.pairs + a.pair_ptr[b]);
+    const int n_calls = 2 * (int)(a.pair_ptr[b + 1] - a.pair_ptr[b]);  // incl. neutral padding, multiple of 8
+    for (int pos = 0; pos < n_calls; pos += C) {
+        const int n = (n_calls - pos) < C ? (n_calls - pos) : C;  // multiple of 8
+        __syncthreads();
+        if (tid < n) {
+            const int ci = pos + tid;
+            const int w = (ci >> 1) * 8 + (ci & 1);
+            sh_off[tid] = words[w];
+            sh_keep[tid] = 0.5f * __uint_as_float(words[w + 2]);  // half the keep factor: see k_estep_block
+            sh_floor[tid] = __uint_as_float(words[w + 4]);
+        }
+        __syncthreads();
+        for (int c = wave; c < n; c += 4) {
+            const char *row = (const char *)a.prob + sh_off[c];
+            for (int g = lane; g < G; g += 64) sh_t[g * CS + c] = *(const float *)(row + (unsigned)g * 4u);
+        }
+        __syncthreads();
+        if (!wave_active) continue;
+        for (int c = 0; c < n; c += 2) {
+            const npm::f32x2 keep2 = *(const npm::f32x2 *)(sh_keep + c);
+            const npm::f32x2 flo2 = *(const npm::f32x2 *)(sh_floor + c);
+            npm::f32x2 pa[R1], pb[R2];
+#pragma unroll
+            for (int x = 0; x < R1; x++) pa[x] = *(const npm::f32x2 *)(sh_t + r1[x] + c);
+#pragma unroll
+            for (int y = 0; y < R2; y++) pb[y] = *(const npm::f32x2 *)(sh_t + r2[y] + c);
+#pragma unroll
+            for (int x = 0; x < R1; x++)
+#pragma unroll
+                for (int y = 0; y < R2; y++) {
+                    npm::f32x2 t = (pa[x] + pb[y]) * keep2;
+                    t = t + flo2;
+                    const int o = R2 * x + y;
+                    prod[o] = (prod[o] * t.x) * t.y;
+                    if ((c & 7) == 6) {
+                        acc_e[o] += __builtin_amdgcn_frexp_expf(prod[o]);
+                        acc[o] += (double)__builtin_amdgcn_logf(__builtin_amdgcn_frexp_mantf(prod[o]));
+                        prod[o] = 1.0f;
+                    }
+                }
+        }
+    }
+    if (!mine) return;
+    const double LN2 = 0.693147180559945309417232121458176568;
+#pragma unroll
+    for (int x = 0; x < R1; x++)
+#pragma unroll
+        for (int y = 0; y < R2; y++) {
+            const int g1 = g1_0 + x, g2 = g2_0 + y;
+            if (g1 > g2 || g2 >= G) continue;
+            // option index: singlets (g, g) first, then g1 < g2 row-major (dmx_api.cpp: ensure_options)
+            const int k = g1 == g2 ? g1 : G + g1 * (2 * G - g1 - 1) / 2 + (g2 - g1 - 1);
+            const double t = (double)a.pen[k] + (acc[R2 * x + y] + (double)acc_e[R2 * x + y]) * LN2;
+            float l = (float)t;
+            if (a.prior) {
+                const size_t o = (size_t)b * K + k;
+                if (a.prior_dtype == DMX_F32)
+                    l = l + ((const float *)a.prior)[o];
+                else
+                    l = (float)((double)l + ((const double *)a.prior)[o]);
+            }
+            a.logits[(size_t)b * K + k] = l;
+        }
+}
+
 template <bool STAGED>
 __global__ __launch_bounds__(256) void k_softmax_rows(EstepArgs a)
 {
@@ -2186,6 +2294,18 @@ hipError_t launch_estep(hipStream_t st, const EstepArgs &a, bool pairs)
     //     again; three of 12: 264 ms.
     // (Tiles of 65 accumulators per thread -- 385 VGPRs plus SGPR spills -- ended in GPU memory faults that narrower
     // tiles of the same source do not show: profiles/r2_block_tile65_experiment.txt.)
+    if (a.fast && pairs && a.pair_blocks != nullptr && a.n_pair_blocks > 0 && a.order_count == nullptr) {
+        // tolerance arithmetic: 2 x 3 blocks of the option triangle, 256 blocks per launch (k_estep_pairblocks)
+        int C = (16384 / (4 * a.G)) & ~7;  // calls staged per chunk, as launch_block
+        C = C < 8 ? 8 : (C > 128 ? 128 : C);
+        size_t bytes = (size_t)(C + 2) * a.G * 4 + (size_t)C * 12;
+        bytes = (bytes + 15) & ~size_t(15);
+        const hipError_t e = hipFuncSetAttribute((const void *)k_estep_pairblocks<PAIRBLOCK_R1, PAIRBLOCK_R2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+        if (e != hipSuccess) return e;
+        for (int blk_base = 0; blk_base < a.n_pair_blocks; blk_base += 256)
+            hipLaunchKernelGGL((k_estep_pairblocks<PAIRBLOCK_R1, PAIRBLOCK_R2>), dim3((unsigned)a.B), dim3(256), bytes, st, a, C, blk_base);
+        return launch_softmax_rows(st, a);
+    }
     const int need = (K + 255) / 256;
     int tile = need <= 2 ? 2 : need <= 4 ? 4 : need <= 6 ? 6 : need <= 8 ? 8 : need <= 12 ? 12 : need <= 17 ? 17 : need <= 24 ? 12 : 17;
     // the tolerance mode carries a running product and an exponent per option besides the accumulator: tiles of 6
