@@ -941,8 +941,8 @@ __global__ __launch_bounds__(256) void k_estep_block(EstepArgs a, int C, int k_b
 // are computed and dropped.  Same staging, same terms, same products of 8 as k_estep_block<., true>; the rows' softmax and
 // the guard are k_softmax_rows'.
 // ------------------------------------------------------------------------------------
-template <int R1, int R2>
-__global__ __launch_bounds__(256) void k_estep_pairblocks(EstepArgs a, int C, int blk_base)
+template <int R1, int R2, int THREADS>
+__global__ __launch_bounds__(THREADS) void k_estep_pairblocks(EstepArgs a, int C, int blk_base)
 {
     constexpr int NO = R1 * R2;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -987,7 +987,7 @@ __global__ __launch_bounds__(256) void k_estep_pairblocks(EstepArgs a, int C, in
             sh_floor[tid] = __uint_as_float(words[w + 4]);
         }
         __syncthreads();
-        for (int c = wave; c < n; c += 4) {
+        for (int c = wave; c < n; c += THREADS / 64) {
             const char *row = (const char *)a.prob + sh_off[c];
             for (int g = lane; g < G; g += 64) sh_t[g * CS + c] = *(const float *)(row + (unsigned)g * 4u);
         }
@@ -2296,14 +2296,23 @@ hipError_t launch_estep(hipStream_t st, const EstepArgs &a, bool pairs)
     // tiles of the same source do not show: profiles/r2_block_tile65_experiment.txt.)
     if (a.fast && pairs && a.pair_blocks != nullptr && a.n_pair_blocks > 0 && a.order_count == nullptr) {
         // tolerance arithmetic: 2 x 3 blocks of the option triangle, 256 blocks per launch (k_estep_pairblocks)
-        int C = (16384 / (4 * a.G)) & ~7;  // calls staged per chunk, as launch_block
+        const bool big = a.n_pair_blocks >= 1024;         // enough blocks for 512 threads to share the staging of a chunk
+        int C = ((big ? 32768 : 16384) / (4 * a.G)) & ~7;  // calls staged per chunk (twice as many for 512 threads: 69.3 -> 67.9 ms at K = 8256)
         C = C < 8 ? 8 : (C > 128 ? 128 : C);
         size_t bytes = (size_t)(C + 2) * a.G * 4 + (size_t)C * 12;
         bytes = (bytes + 15) & ~size_t(15);
-        const hipError_t e = hipFuncSetAttribute((const void *)k_estep_pairblocks<PAIRBLOCK_R1, PAIRBLOCK_R2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+        // 512 threads share the staging of a chunk where there are blocks for them (K = 8256: 1 450 blocks, 74.7 -> 69.7 ms;
+        // K = 528: 121 blocks, 1.24 ms with 256 threads against 1.84); 1024 threads: 103 ms
+        auto launch = [&](auto kernel, int threads) {
+            const hipError_t e = hipFuncSetAttribute((const void *)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+            if (e != hipSuccess) return e;
+            for (int blk_base = 0; blk_base < a.n_pair_blocks; blk_base += threads)
+                hipLaunchKernelGGL(kernel, dim3((unsigned)a.B), dim3(threads), bytes, st, a, C, blk_base);
+            return hipSuccess;
+        };
+        const hipError_t e = big ? launch(k_estep_pairblocks<PAIRBLOCK_R1, PAIRBLOCK_R2, 512>, 512)
+                                                     : launch(k_estep_pairblocks<PAIRBLOCK_R1, PAIRBLOCK_R2, 256>, 256);
         if (e != hipSuccess) return e;
-        for (int blk_base = 0; blk_base < a.n_pair_blocks; blk_base += 256)
-            hipLaunchKernelGGL((k_estep_pairblocks<PAIRBLOCK_R1, PAIRBLOCK_R2>), dim3((unsigned)a.B), dim3(256), bytes, st, a, C, blk_base);
         return launch_softmax_rows(st, a);
     }
     const int need = (K + 255) / 256;
