@@ -1348,45 +1348,47 @@ __global__ __launch_bounds__(256) void k_mstep_dense(MstepArgs a)
     if (!dense_regime(a)) return;
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    const long long slot = (long long)blockIdx.x * 4 + wave;
-    if (slot >= a.n_items) return;
-    const long long item = a.order[slot];
-    const int n = a.item_len[item];
-    const uint2 *__restrict__ calls = a.calls + a.item_start[item];
-    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void *)a.post, 0, (int)a.post_bytes, 0x00020000);
-    const unsigned row_bytes = (unsigned)a.K * 4u;
-    const unsigned voff = (unsigned)(lane < a.G ? lane : 0) * 4u;
-    double acc = 0.0;
-    auto records = [&](int c0) {
-        uint2 d = make_uint2(0u, 0u);  // padding: keep bits 0 -> (p * 0)^power = +0
-        if (c0 + lane < n) d = calls[c0 + lane];
-        return d;
-    };
-    // row gathers in flight per wavefront: 8 -> 2.52 ms, 16 -> 2.42 ms, 32 -> 2.43 ms on 200k x 100k x 64 with uniform
-    // posteriors (the fabric-side gather rate is the limit, not their latency)
-    constexpr int DENSE_ROWS = 16;
-    uint2 d_cur = records(0);
-    for (int c0 = 0; c0 < n; c0 += 64) {
-        const uint2 d_nxt = records(c0 + 64);
-        const int cnt = (n - c0) < 64 ? (n - c0) : 64;
-        for (int i0 = 0; i0 < cnt; i0 += DENSE_ROWS) {
-            float p[DENSE_ROWS];
-#pragma unroll
-            for (int u = 0; u < DENSE_ROWS; u++) {
-                const unsigned cb = (unsigned)__builtin_amdgcn_readlane((int)d_cur.x, (i0 + u) & 63);
-                p[u] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, (int)voff, (int)(cb * row_bytes), 0));
+    // (a grid that strides over the items: most launches find the regime sparse and return - with one block per four items
+    // that alone took 12 us of every EM iteration)
+    for (long long slot = (long long)blockIdx.x * 4 + wave; slot < a.n_items; slot += (long long)gridDim.x * 4) {
+        const long long item = a.order[slot];
+        const int n = a.item_len[item];
+        const uint2 *__restrict__ calls = a.calls + a.item_start[item];
+        const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void *)a.post, 0, (int)a.post_bytes, 0x00020000);
+        const unsigned row_bytes = (unsigned)a.K * 4u;
+        const unsigned voff = (unsigned)(lane < a.G ? lane : 0) * 4u;
+        double acc = 0.0;
+        auto records = [&](int c0) {
+            uint2 d = make_uint2(0u, 0u);  // padding: keep bits 0 -> (p * 0)^power = +0
+            if (c0 + lane < n) d = calls[c0 + lane];
+            return d;
+        };
+        // row gathers in flight per wavefront: 8 -> 2.52 ms, 16 -> 2.42 ms, 32 -> 2.43 ms on 200k x 100k x 64 with uniform
+        // posteriors (the fabric-side gather rate is the limit, not their latency)
+        constexpr int DENSE_ROWS = 16;
+        uint2 d_cur = records(0);
+        for (int c0 = 0; c0 < n; c0 += 64) {
+            const uint2 d_nxt = records(c0 + 64);
+            const int cnt = (n - c0) < 64 ? (n - c0) : 64;
+            for (int i0 = 0; i0 < cnt; i0 += DENSE_ROWS) {
+                float p[DENSE_ROWS];
+    #pragma unroll
+                for (int u = 0; u < DENSE_ROWS; u++) {
+                    const unsigned cb = (unsigned)__builtin_amdgcn_readlane((int)d_cur.x, (i0 + u) & 63);
+                    p[u] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, (int)voff, (int)(cb * row_bytes), 0));
+                }
+    #pragma unroll
+                for (int u = 0; u < DENSE_ROWS; u++) {
+                    const float keep = __builtin_bit_cast(float, __builtin_amdgcn_readlane((int)d_cur.y, (i0 + u) & 63));
+                    float c = p[u] * keep;
+                    c = SQUARE ? c * c : powf(c, a.power);
+                    acc += (double)c;
+                }
             }
-#pragma unroll
-            for (int u = 0; u < DENSE_ROWS; u++) {
-                const float keep = __builtin_bit_cast(float, __builtin_amdgcn_readlane((int)d_cur.y, (i0 + u) & 63));
-                float c = p[u] * keep;
-                c = SQUARE ? c * c : powf(c, a.power);
-                acc += (double)c;
-            }
+            d_cur = d_nxt;
         }
-        d_cur = d_nxt;
+        if (lane < a.G) mstep_store(a, item, lane, acc);
     }
-    if (lane < a.G) mstep_store(a, item, lane, acc);
 }
 
 // BUF: the three per-lane loads of the call-parallel part (records, barcode code, extra posteriors) as raw buffer
@@ -2379,10 +2381,11 @@ hipError_t launch_mstep(hipStream_t st, const MstepArgs &a)
             MSTEP_CALLS(false);
 #undef MSTEP_CALLS
         if (a.dense_calls) {  // the dense regime's kernel; exactly one of the two does the work (dense_regime)
+            const dim3 dense_grid(std::min(blocks_for(a.n_items, 4), 2048u));
             if (a.square)
-                hipLaunchKernelGGL((k_mstep_dense<true>), grid, dim3(256), 0, st, a);
+                hipLaunchKernelGGL((k_mstep_dense<true>), dense_grid, dim3(256), 0, st, a);
             else
-                hipLaunchKernelGGL((k_mstep_dense<false>), grid, dim3(256), 0, st, a);
+                hipLaunchKernelGGL((k_mstep_dense<false>), dense_grid, dim3(256), 0, st, a);
         }
         return hipGetLastError();
     }
@@ -2403,7 +2406,7 @@ hipError_t launch_mstep_tiles(hipStream_t st, const MstepArgs &a, const MTileArg
     else
         hipLaunchKernelGGL((k_mstep_tiles<false>), dim3((unsigned)t.n_tiles), dim3(MTILE_THREADS), lds, st, a, t);
     if (a.dense_calls && a.n_items) {  // the dense regime's kernel; exactly one of the two does the work (dense_regime)
-        const dim3 grid(blocks_for(a.n_items, 4));
+        const dim3 grid(std::min(blocks_for(a.n_items, 4), 2048u));
         if (a.square)
             hipLaunchKernelGGL((k_mstep_dense<true>), grid, dim3(256), 0, st, a);
         else
