@@ -1154,7 +1154,7 @@ int run_estep(dmx_ctx *c, int with_doublets, bool with_prior, int prior_dtype, f
     a.post_singlets = c->mshard ? c->d_post_g + row_base * c->G : nullptr;
     c->post_gathered = false;
     a.dense_calls = c->G <= 64 ? c->d_dense_calls : nullptr;
-    if (a.dense_calls) HIP_TRY(hipMemsetAsync(c->d_dense_calls, 0, sizeof(unsigned long long) * (1 + dmx::DENSE_SLOTS), c->stream));
+    // (the slots are zero: set at the install, left so by k_sum_dense at the end of every E-step that used them)
     c->dense_stat_valid = a.dense_calls != nullptr;
     a.nz_floor = power == 2.0f ? dmx::NZ_FLOOR_SQUARE : 0.0f;
     c->nz_floor = a.nz_floor;
@@ -1554,6 +1554,7 @@ static int finish_problem(dmx_ctx *c, const int32_t *v2snp, const std::vector<in
     DMX_TRY(dev_alloc(c, &c->d_guard_count, (size_t)2));
     DMX_TRY(dev_alloc(c, &c->d_guard_list, (size_t)B));
     HIP_TRY(hipMemsetAsync(c->d_guard_count, 0, 2 * sizeof(unsigned), c->stream));
+    HIP_TRY(hipMemsetAsync(c->d_dense_calls, 0, sizeof(unsigned long long) * (1 + dmx::DENSE_SLOTS), c->stream));
     DMX_TRY(dev_alloc(c, &c->d_best, (size_t)B));
     DMX_TRY(dev_alloc(c, &c->d_bestp, (size_t)B));
     hipStream_t st = c->stream;
