@@ -1343,13 +1343,14 @@ int run_mstep(dmx_ctx *c, float power)
     const bool tiles_wanted = c->mstep_tiles == 2 || (c->mstep_tiles == 1 && (c->n_mt > 0 || c->msteps_ahead >= MSTEP_TILES_PAY ||
                                                                              c->msteps_done >= MSTEP_TILES_PAY));
     c->msteps_done++;
-    if (!c->exact_additions && tiles_wanted && c->G <= 64 && c->n_csc > 0) {
+    if (!c->exact_additions && tiles_wanted && c->G <= 64 && c->n_csc > 0 && power > 0.0f) {  // (power > 0: contributions in [0, 1])
         if (!c->mt_tried) DMX_TRY(dmx::build_mstep_tiles(c, mshard ? c->cut[c->rank] : 0, mshard ? c->cut[c->rank + 1] : c->V));
         if (c->n_mt > 0) {
             tiles.stream = c->d_mt_stream;
             tiles.ptr = c->d_mt_ptr;
             tiles.first = c->d_mt_first;
             tiles.order = c->d_mt_order;
+            tiles.shift = c->d_mt_shift;
             tiles.n_tiles = c->n_mt;
             tiles.tv = c->mt_tv;
             a.tiles_done = true;

@@ -77,6 +77,7 @@ struct dmx_ctx {
     long long *d_mt_ptr = nullptr;  // [n_mt + 1] first record of every tile
     int *d_mt_first = nullptr;      // [n_mt + 1] first variant of every tile
     int *d_mt_order = nullptr;      // [n_mt] tiles by decreasing number of calls
+    int *d_mt_shift = nullptr;      // [n_mt] fixed-point exponent of every tile (MTileArgs::shift)
     long long n_mt = 0;
     int mt_tv = 0;                  // variants per tile at most
     bool mt_tried = false;          // a build was attempted for the resident M-step records

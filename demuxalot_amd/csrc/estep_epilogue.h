@@ -252,9 +252,25 @@ static __device__ __forceinline__ bool estep_guard(const float (&dev)[A], const 
     return close != 1 || (L == 64 ? any_bad : (any_bad >> gbase) & group_mask<L>()) != 0ull;
 }
 
+// The guard's bookkeeping for one barcode (lane `writer` of its lane group acts): queued for the exact redo (a.guard == 1), or -
+// in the exact kernels of an E-step that runs direct (a.guard == 2) - only counted, on hashed counters (200k atomics on one
+// address took 0.65 ms; k_guard_begin adds the slots up).
+constexpr int GUARD_SLOTS = 256;
+static __device__ __forceinline__ void guard_note(const EstepArgs &a, long long b, bool counting)
+{
+    if (counting) atomicAdd(a.guard_count + GS_WORDS + (int)(b & (GUARD_SLOTS - 1)), 1u);
+    else a.guard_list[atomicAdd(a.guard_count + GS_COUNT, 1u)] = (int)b;
+}
+// whether this launch evaluates the guard: the fast kernels of a guarded E-step always, its exact kernels when the E-step runs direct
+static __device__ __forceinline__ bool guard_active(const EstepArgs &a)
+{
+    return a.guard == 1 || (a.guard == 2 && a.direct != nullptr && *a.direct != 0u);
+}
+
 // Epilogue of the lane-per-option forms: penalties, optional prior, softmax as scipy evaluates it, the M-step's bitmap.
 // acc[s] = float64 sum of the log terms of option kk[s] = li + L * s of barcode b (one lane group of L lanes per barcode).
-// GUARD: instantiated by the tolerance-mode kernels; evaluates estep_guard when a.guard is set.
+// The guard (a.guard; estep_guard above) is evaluated by the tolerance-mode kernels of a guarded E-step and, for the count
+// alone, by its exact kernels when the E-step runs direct (kernels.h: EstepArgs::direct).
 template <int L, int A, bool GUARD = false>
 static __device__ __forceinline__ void estep_epilogue(const EstepArgs &a, long long b, bool live, const double (&acc)[A],
                                                       const int (&kk)[A], const bool (&valid)[A], int lane, int li, int gbase,
@@ -262,23 +278,17 @@ static __device__ __forceinline__ void estep_epilogue(const EstepArgs &a, long l
 {
     const int K = a.K;
     float lg[A], x[A];
-    float dev[A];  // GUARD: bound on |logit - reference logit| per option
     float mx = -__builtin_inff();
 #pragma unroll
     for (int s = 0; s < A; s++) {
         const double t = (double)a.pen[kk[s]] + acc[s];
         float l = (float)t;
-        if (GUARD) {
-            const float n = (float)row_calls;
-            dev[s] = GUARD_RHO * (fabsf((float)acc[s]) + GUARD_POSITIVE_TERM * n) + GUARD_PER_CALL * (n + 8.0f) + GUARD_LOGIT_ROUNDING * fabsf(l);
-        }
         if (a.prior) {
             const size_t o = (size_t)b * K + kk[s];
             if (a.prior_dtype == DMX_F32)
                 l = l + ((const float *)a.prior)[o];
             else
                 l = (float)((double)l + ((const double *)a.prior)[o]);
-            if (GUARD) dev[s] += GUARD_LOGIT_ROUNDING * fabsf(l);
         }
         lg[s] = l;
         mx = valid[s] ? fmaxf(mx, l) : mx;
@@ -310,15 +320,20 @@ static __device__ __forceinline__ void estep_epilogue(const EstepArgs &a, long l
         }
     }
     if (L < 64 && live && li == 0) a.nz[(size_t)b] = mine;
-    bool redo = false;  // GUARD: the exact kernel takes this barcode again (it rewrites everything written here)
-    if constexpr (GUARD) {
-        if (a.guard) {
-            redo = estep_guard<L, A>(dev, lg, post, valid, mx, gbase);
-            if (redo && live && li == 0) {
-                a.guard_list[atomicAdd(a.guard_count, 1u)] = (int)b;
-                atomicAdd(a.guard_count + 1, 1u);
-            }
+    bool redo = false;  // the exact kernel takes this barcode again (it rewrites everything written here)
+    if (a.guard && guard_active(a)) {  // (uniform)
+        const bool counting = a.guard == 2;
+        float dev[A];  // bound on |logit - reference logit| per option
+        const float n = (float)row_calls;
+#pragma unroll
+        for (int s = 0; s < A; s++) {
+            const float l0 = (float)((double)a.pen[kk[s]] + acc[s]);
+            dev[s] = GUARD_RHO * (fabsf((float)acc[s]) + GUARD_POSITIVE_TERM * n) + GUARD_PER_CALL * (n + 8.0f) + GUARD_LOGIT_ROUNDING * fabsf(l0);
+            if (a.prior) dev[s] += GUARD_LOGIT_ROUNDING * fabsf(lg[s]);
         }
+        const bool flagged = estep_guard<L, A>(dev, lg, post, valid, mx, gbase);
+        if (flagged && live && li == 0) guard_note(a, b, counting);
+        redo = flagged && !counting;
     }
     if (a.first) {
         // what the M-step's call-parallel part needs of this barcode, 8 bytes (nz_code): ONE gather per call there,

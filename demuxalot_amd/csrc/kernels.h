@@ -66,11 +66,22 @@ struct EstepArgs {
     int fast;                   // DMX_ESTEP_FAST: tolerance mode (products of 8 terms + hardware log2), see kernels.hip
     // guarded mode (DMX_ESTEP_GUARDED; estep_epilogue.h: guard_flags): the fast kernels bound their deviation from the
     // reference per barcode and queue the barcodes whose posteriors / argmax are not provably within the contract
-    int guard;                  // the epilogue evaluates the guard and appends to guard_list
-    unsigned *guard_count;      // [2] barcodes queued by this E-step | by all E-steps since the last reset
+    int guard;                  // 1: the epilogue evaluates the guard and appends to guard_list (the fast kernels of a guarded E-step);
+                                // 2: the exact kernels of a guarded E-step: when the E-step runs DIRECT (below) the guard is evaluated on
+                                //    their own results and the barcodes that would have been queued are only counted
+    unsigned *guard_count;      // the guard's device state (GuardState below): [GS_COUNT] barcodes queued (direct: that would have been) by this E-step
     int *guard_list;            // [B] the queued barcodes
     const unsigned *order_count;  // nullable: `order` holds *order_count entries (<= B), known on the device only (the exact
                                   // redo of the queued barcodes: k_estep_direct over guard_list)
+    // Adaptive guarded mode.  The fast pass costs F, the exact kernel E per barcode (F / E = 0.56 at 200k x 100k x 64, 0.34 at
+    // K = 8256); with a fraction f of the barcodes queued a guarded E-step costs F + f E - more than the exact mode's E once
+    // f > 1 - F / E, and 1.56 E on a workload where nothing can be proven (few calls per barcode, related donors).  So the
+    // E-step that follows one which queued more than 40 % of the barcodes runs DIRECT: the fast kernels stand back (they read
+    // *direct and return), the exact launch walks `order_direct` - every barcode - instead of the queue and counts the
+    // barcodes the guard would have queued, so that the E-step after one with fewer than 30 % goes back to the fast pass.
+    // The decision is taken on the device (k_guard_begin, between two E-steps on the stream): no host synchronisation.
+    const unsigned *direct;       // nullable: &state[GS_DIRECT]
+    const int *order_direct;      // [B] what the exact launch walks when the E-step runs direct (barcodes by decreasing row length)
     // Split rows (tolerance / guarded mode, 64-lane form; dmx_api.cpp: build_row_segments): a launch cannot end before its
     // longest barcode does, and a barcode's walk is a chain of memory latencies (~0.7 us per 8 calls) - 0.35 ms for a
     // 4 000-call row, which is the whole E-step of a 25k-barcode shard.  The n_split longest barcodes (the first entries
@@ -105,6 +116,17 @@ struct EstepArgs {
     const float *dict;            // [rows, DICT_CAP]
     const unsigned char *codes;   // [rows, dict_code_pitch(G)] 8 x index of every genotype's value in its row's dictionary
 };
+
+// device state of the guarded mode (dmx_ctx::d_guard_count, 8 x unsigned)
+enum { GS_COUNT = 0,         // barcodes queued by the current E-step (a direct one: that the guard would have queued)
+       GS_DIRECT = 1,        // the current E-step runs the exact kernel on every barcode
+       GS_VALID = 2,         // GS_COUNT / GS_DIRECT / GS_ROWS describe a finished E-step of the resident problem
+       GS_ROWS = 3,          // its barcode rows
+       GS_PENDING = 4,       // ... and it is not yet part of the totals
+       GS_DIRECT_STEPS = 5,  // E-steps run direct since the last reset
+       GS_TOTAL = 6,         // (64 bit, two words) barcodes computed by the exact kernel since the last reset
+       GS_WORDS = 8 };
+hipError_t launch_guard_begin(hipStream_t st, unsigned *state, long long B, int adaptive);
 
 constexpr int CALL_PAD_PAIRS = 64;     // readable neutral records behind the last barcode's row (pairs and call_rows)
 constexpr int DICT_CAP = 8;            // distinct values per row the dictionary form handles (singlet runs)
@@ -202,7 +224,8 @@ hipError_t launch_mstep(hipStream_t st, const MstepArgs &a);
 // prow (nullable): row of every variant in the output tables (padded multi-GPU exchange buffer)
 // vlist (nullable): the variants are entries [v0, v1) of this list instead of v0 .. v1 - 1 (chunks of the pipelined exchange)
 // skip_single: the variants of one item were written by the M-step kernels themselves (MstepArgs::item_variant)
-// Tile-major M-step (sums in any order: not for dmx_set_exact_additions), G <= 64.  The variant axis is cut into tiles of at most
+// Tile-major M-step (fixed-point sums, order-independent and bit-reproducible, but not the reference's float64 sum bit for bit:
+// not for dmx_set_exact_additions), G <= 64, contribution_power > 0.  The variant axis is cut into tiles of at most
 // `tv` variants; the M-step records are kept once more sorted by (tile, barcode row), so that a tile's calls read the barcode
 // codes in ascending order (the item form's one gather per call out of a 1.6 MB table, 112 G requests/s to the L2s, was
 // what bounded it).  One workgroup per tile: float64 accumulators [variants of the tile][G] in LDS, ds_add_f64.
@@ -211,6 +234,7 @@ struct MTileArgs {
     const long long *ptr;  // [n_tiles + 1]
     const int *first;      // [n_tiles + 1] first variant of every tile
     const int *order;      // [n_tiles] tiles by decreasing number of calls
+    const int *shift;      // [n_tiles] binary exponent of the tile's fixed-point grid (k_mstep_tiles: contributions are added as rint(c 2^shift))
     long long n_tiles;
     int tv;
 };

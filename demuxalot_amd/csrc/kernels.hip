@@ -424,8 +424,14 @@ __global__ __launch_bounds__(256) void k_estep_direct(EstepArgs a)
     long long b;
     bool live;
     int row_calls = 0;  // calls of this lane group's barcode (incl. padding)
+    // Guarded E-step that runs direct (kernels.h: EstepArgs::direct): the fast kernels stand back, the exact launch walks
+    // every barcode instead of the queue
+    const bool direct = a.direct != nullptr && *a.direct != 0u;  // (uniform)
+    if (FAST && a.guard && direct) return;
+    const bool all_rows = !FAST && a.order_count != nullptr && direct;
+    const int *__restrict__ order = all_rows ? a.order_direct : a.order;
     // rows of `order` to walk: all B, or as many as the guarded E-step queued (known on the device only)
-    const long long n_rows = a.order_count ? (long long)min((unsigned long long)*a.order_count, (unsigned long long)a.B) : a.B;
+    const long long n_rows = a.order_count && !all_rows ? (long long)min((unsigned long long)*a.order_count, (unsigned long long)a.B) : a.B;
     long long seg_of_wave = -1;  // split rows (FAST, 64 lanes): the segment this wavefront walks
     if constexpr (L == 64) {
         // ---- wave-uniform path: everything about the row lives in SGPRs ----
@@ -446,13 +452,13 @@ __global__ __launch_bounds__(256) void k_estep_direct(EstepArgs a)
             } else {
                 slot = slot - a.n_segs + a.n_split;
                 if (slot >= n_rows) return;
-                b = a.order[slot];
+                b = order[slot];
                 pbeg = a.pair_ptr[b];
                 npairs = (int)(a.pair_ptr[b + 1] - pbeg);
             }
         } else {
             if (slot >= n_rows) return;
-            b = a.order[slot];
+            b = order[slot];
             pbeg = a.pair_ptr[b];
             npairs = (int)(a.pair_ptr[b + 1] - pbeg);
         }
@@ -517,7 +523,7 @@ __global__ __launch_bounds__(256) void k_estep_direct(EstepArgs a)
         if (((long long)blockIdx.x * 4 + (threadIdx.x >> 6)) * CPW >= n_rows) return;  // the whole wavefront past the list
         const long long slot = ((long long)blockIdx.x * 4 + (threadIdx.x >> 6)) * CPW + lane / L;
         live = slot < n_rows;
-        b = a.order[live ? slot : n_rows - 1];
+        b = order[live ? slot : n_rows - 1];
         const long long pbeg = a.pair_ptr[b];
         const int n = live ? 2 * (int)(a.pair_ptr[b + 1] - pbeg) : 0;  // calls incl. padding, multiple of 8
         row_calls = n;
@@ -659,6 +665,7 @@ __global__ __launch_bounds__(256) void k_estep_join(EstepArgs a)
     const int lane = threadIdx.x & 63;
     const long long j = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (j >= a.n_split) return;
+    if (a.guard && a.direct != nullptr && *a.direct != 0u) return;  // the E-step runs direct: the exact launch does every barcode
     const long long b = a.order[j];
     const int K = a.K;
     int kk[A];
@@ -709,6 +716,7 @@ __global__ __launch_bounds__(256) void k_estep_tiled(EstepArgs a)
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const long long slot_id = (long long)blockIdx.x * 4 + wave;
     if (slot_id >= a.n_bins) return;
+    if (FAST && a.guard && a.direct != nullptr && *a.direct != 0u) return;  // the E-step runs direct (EstepArgs::direct)
     const long long bin = a.bin_order[slot_id];
 
     unsigned o1[A];
@@ -826,8 +834,11 @@ __global__ __launch_bounds__(256) void k_estep_block(EstepArgs a, int C, int k_b
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    if (a.order_count != nullptr && blockIdx.x >= *a.order_count) return;  // the exact redo of a guarded E-step: the queued barcodes only
-    const long long b = a.order[blockIdx.x];
+    const bool direct = a.direct != nullptr && *a.direct != 0u;  // (uniform) the guarded E-step runs direct: EstepArgs::direct
+    if (FAST && a.guard && direct) return;
+    const bool all_rows = !FAST && a.order_count != nullptr && direct;
+    if (a.order_count != nullptr && !all_rows && blockIdx.x >= *a.order_count) return;  // the exact redo of a guarded E-step: the queued barcodes only
+    const long long b = all_rows ? a.order_direct[blockIdx.x] : a.order[blockIdx.x];
     const int K = a.K, G = a.G;
     const int CS = C + 2;
     // LDS carve: sh_t [G*CS] f32 | keep [C] | floor [C] | row offsets [C]
@@ -947,6 +958,7 @@ __global__ __launch_bounds__(THREADS) void k_estep_pairblocks(EstepArgs a, int C
     constexpr int NO = R1 * R2;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (a.guard && a.direct != nullptr && *a.direct != 0u) return;  // the guarded E-step runs direct (EstepArgs::direct)
     const long long b = a.order[blockIdx.x];
     const int K = a.K, G = a.G;
     const int CS = C + 2;
@@ -1047,9 +1059,13 @@ __global__ __launch_bounds__(256) void k_softmax_rows(EstepArgs a)
     __shared__ float sh_red[8];
     __shared__ float sh_guard[12];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    // rows: all B, or the barcodes the guarded pass queued (their number is known on the device only)
-    if (a.order_count != nullptr && blockIdx.x >= *a.order_count) return;
-    const long long b = a.order_count != nullptr ? (long long)a.order[blockIdx.x] : (long long)blockIdx.x;
+    // rows: all B, or the barcodes the guarded pass queued (their number is known on the device only); a guarded E-step that
+    // runs direct (EstepArgs::direct): the pass after the fast option tiles stands back, the one after the exact tiles takes all rows
+    const bool direct = a.direct != nullptr && *a.direct != 0u;
+    if (a.guard == 1 && direct) return;
+    const bool all_rows = a.order_count != nullptr && direct;
+    if (a.order_count != nullptr && !all_rows && blockIdx.x >= *a.order_count) return;
+    const long long b = a.order_count != nullptr && !all_rows ? (long long)a.order[blockIdx.x] : (long long)blockIdx.x;
     const int K = a.K, G = a.G;
     const float *__restrict__ lg = a.logits + (size_t)b * K;
     float *post = a.post + (size_t)b * K;
@@ -1092,7 +1108,8 @@ __global__ __launch_bounds__(256) void k_softmax_rows(EstepArgs a)
     // Guarded mode after the tolerance-mode option tiles (estep_epilogue.h: estep_guard, same bound): the sums themselves
     // are gone, |S_k| <= |logit_k| + |pen_k| stands in (no prior logits in this mode: run_estep).
     bool redo = false;
-    if (a.guard) {
+    if (a.guard && guard_active(a)) {
+        const bool counting = a.guard == 2;  // the exact tiles of a direct E-step: what the guard would have queued is only counted
         const float n = (float)(2 * (a.pair_ptr[b + 1] - a.pair_ptr[b]));
         float dmax = 0.0f;
         bool bad = false;
@@ -1125,11 +1142,9 @@ __global__ __launch_bounds__(256) void k_softmax_rows(EstepArgs a)
         }
         __syncthreads();
         const float total_close = sh_guard[4] + sh_guard[5] + sh_guard[6] + sh_guard[7];
-        redo = total_close != 1.0f || (sh_guard[8] + sh_guard[9] + sh_guard[10] + sh_guard[11]) != 0.0f;
-        if (redo && tid == 0) {
-            a.guard_list[atomicAdd(a.guard_count, 1u)] = (int)b;
-            atomicAdd(a.guard_count + 1, 1u);
-        }
+        const bool flagged = total_close != 1.0f || (sh_guard[8] + sh_guard[9] + sh_guard[10] + sh_guard[11]) != 0.0f;
+        if (flagged && tid == 0) guard_note(a, b, counting);
+        redo = flagged && !counting;
     }
     for (int k0 = 0; k0 < K; k0 += 256) {  // uniform trip count: the ballots below need whole waves
         const int k = k0 + tid;
@@ -1323,6 +1338,45 @@ __global__ __launch_bounds__(256) void k_sum_dense(unsigned long long *counters)
     if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = s;
     __syncthreads();
     if (threadIdx.x == 0) counters[0] = part[0] + part[1] + part[2] + part[3];
+}
+
+// Between two E-steps of the guarded mode: books the E-step that has finished (its queue length, or - run direct - what the
+// guard would have queued, summed from the hashed counters), and decides how the next one runs: direct after an E-step of
+// the same problem that queued more than 40 % of its barcodes, back to the fast pass after one below 30 % (kernels.h:
+// EstepArgs::direct).  One workgroup; replaces the memset of the queue length.
+__global__ __launch_bounds__(GUARD_SLOTS) void k_guard_begin(unsigned *st, unsigned B, int adaptive)
+{
+    __shared__ unsigned part[GUARD_SLOTS / 64];
+    unsigned v = st[GS_WORDS + threadIdx.x];
+    st[GS_WORDS + threadIdx.x] = 0u;
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off);
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = v;
+    __syncthreads();
+    if (threadIdx.x != 0) return;
+    unsigned count = st[GS_COUNT];
+    for (int i = 0; i < GUARD_SLOTS / 64; i++) count += part[i];
+    const unsigned was_direct = st[GS_DIRECT], rows = st[GS_ROWS];
+    if (st[GS_PENDING]) {
+        unsigned long long total = ((unsigned long long)st[GS_TOTAL + 1] << 32) | st[GS_TOTAL];
+        total += was_direct ? rows : count;
+        st[GS_TOTAL] = (unsigned)total;
+        st[GS_TOTAL + 1] = (unsigned)(total >> 32);
+    }
+    unsigned direct = 0u;
+    if (adaptive && st[GS_VALID] && rows == B)
+        direct = was_direct ? (10ull * count > 3ull * B) : (10ull * count > 4ull * B);
+    st[GS_DIRECT] = direct;
+    st[GS_DIRECT_STEPS] += direct;
+    st[GS_COUNT] = 0u;
+    st[GS_ROWS] = B;
+    st[GS_VALID] = 1u;
+    st[GS_PENDING] = 1u;
+}
+
+hipError_t launch_guard_begin(hipStream_t st, unsigned *state, long long B, int adaptive)
+{
+    hipLaunchKernelGGL(k_guard_begin, dim3(1), dim3(GUARD_SLOTS), 0, st, state, (unsigned)B, adaptive);
+    return hipGetLastError();
 }
 
 hipError_t launch_sum_dense(hipStream_t st, unsigned long long *counters)
@@ -1675,15 +1729,24 @@ __global__ __launch_bounds__(256) void k_mstep_calls(MstepArgs a)
 }
 
 // ------------------------------------------------------------------------------------
-// M-step, tile-major form (kernels.h: MTileArgs; G <= 64; sums in any order - not for the exact additions).
+// M-step, tile-major form (kernels.h: MTileArgs; G <= 64; not for the exact additions).
 // The item form above walks one variant's calls at a time, and a variant's calls belong to barcodes ~500 apart: one 8-byte
 // gather of the barcode's code per call, 64 different cache lines per wavefront load - 78.7 M requests to the L2s on
 // 200k x 100k x 64, which is what it ran on (0.68 ms whatever was done to its arithmetic).  Here the records of a TILE of
 // up to 128 variants are sorted by barcode, so that the 64 calls of a wavefront load belong to ~64 barcodes out of a
 // window of ~130 consecutive ones: the code gather touches 8-16 lines instead of 64.  What the order costs - the
-// contributions of a variant no longer arrive together - is paid in LDS: the workgroup keeps float64 accumulators
-// [variants of the tile][G] there and every lane adds its call's contribution(s) with ds_add_f64 (any order; the sums are
-// exact in float64 for all but the longest variants, and rounded to float32 once).
+// contributions of a variant no longer arrive together - is paid in LDS: the workgroup keeps accumulators
+// [variants of the tile][G] there and every lane adds its call's contribution(s) with an LDS atomic.
+// FIXED-POINT accumulators: the reference's np.bincount is a fixed sequential float64 sum and bit-reproducible; float64
+// atomics arriving in any order are not (a sum next to a float32 rounding tie could round either way from run to run: what
+// this kernel did until round 5).  Every contribution c = (posterior x keep)^power is a float32 in [0, 1]; it is added as the
+// 64-bit INTEGER rint(c x 2^s), s = the tile's shift = min(50, 62 - ceil(log2(calls of its longest variant + 1))) (no overflow:
+// a variant has at most one call per barcode), so the sum does not depend on the order of the additions at all: the same bits
+// on every run, on any number of wavefronts.  Contributions of 2^(23 - s) and more (2^-27 = 7.5e-9 at s = 50: every live
+// posterior above 1e-4) are on that grid EXACTLY, so for all but the sums of nothing but dead posteriors the integer sum is
+// the exact real sum, rounded once to float64 and once to float32 - the reference's sequential float64 sum carries its own
+// 1e-16 relative rounding noise, so the two differ at a float32 rounding tie at most; in general
+//     |addition - reference| <= one float32 ulp  +  n 2^-(s + 1)   (n calls of the variant; 1.8e-13 for 400 calls).
 //   sparse calls (<= NZ_CODE live posteriors: the code holds the genotypes and the first posterior) one per lane,
 //   dense calls one at a time by the whole wavefront, lane g taking post[row, g].
 // The workgroup of a tile writes its rows of the output itself: no partial sums, no combining pass.
@@ -1700,22 +1763,28 @@ template <bool SQUARE>
 __global__ __launch_bounds__(MTILE_THREADS) void k_mstep_tiles(MstepArgs a, MTileArgs t)
 {
     if (dense_regime(a)) return;
-    extern __shared__ __attribute__((aligned(16))) double mt_acc[];
+    extern __shared__ __attribute__((aligned(16))) unsigned long long mt_acc[];
     __shared__ unsigned mt_queue[MTILE_THREADS / 64][2][MTILE_QUEUE];  // per wavefront: barcode row | variant in tile << 24, keep bits of its parked dense calls
     const int tile = t.order[blockIdx.x];
     const int v0 = t.first[tile], nv = t.first[tile + 1] - v0;
     const long long beg = t.ptr[tile], end = t.ptr[tile + 1];
     const int G = a.G;
     const long long K = a.K;
-    for (int i = threadIdx.x; i < nv * G; i += MTILE_THREADS) mt_acc[i] = 0.0;
+    for (int i = threadIdx.x; i < nv * G; i += MTILE_THREADS) mt_acc[i] = 0ull;
     __syncthreads();
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int shift = __builtin_amdgcn_readfirstlane(t.shift[tile]);
     unsigned *q_rec = mt_queue[wave][0], *q_keep = mt_queue[wave][1];
     int queued = 0;  // (uniform)
     auto power_of = [&](float c) { return SQUARE ? c * c : powf(c, a.power); };
+    // c in [0, 1] -> rint(c 2^shift) as an integer: adding 1.5 x 2^52 leaves the rounded value (ties to even) in the low bits
+    // of the sum's mantissa (c 2^shift < 2^51)
+    constexpr double MAGIC = 6755399441055744.0;
     auto add = [&](int index, float c) {
-        __hip_atomic_fetch_add(&mt_acc[index], (double)c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        const double d = __builtin_ldexp((double)c, shift) + MAGIC;
+        const unsigned long long q = (unsigned long long)(__double_as_longlong(d) - __double_as_longlong(MAGIC));
+        __hip_atomic_fetch_add(&mt_acc[index], q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     };
     // The parked dense calls, 16 at a time: lane g takes post[row, g] of every one of them (16 row loads in flight: they come
     // from the posterior table, i.e. over the fabric, and one at a time their latency was the whole kernel), then adds.  A
@@ -1796,8 +1865,9 @@ __global__ __launch_bounds__(MTILE_THREADS) void k_mstep_tiles(MstepArgs a, MTil
         const int r = (int)((unsigned)i / (unsigned)G), g = i - r * G;
         const long long v = v0 + r;
         const size_t o = (size_t)(a.prow ? (long long)a.prow[v] : v) * G + g;
-        if (a.out32) a.out32[o] = (float)mt_acc[i];
-        else a.out64[o] = mt_acc[i];
+        const double sum = __builtin_ldexp((double)(long long)mt_acc[i], -shift);  // one rounding to float64 (sums beyond 2^53 grid units)
+        if (a.out32) a.out32[o] = (float)sum;
+        else a.out64[o] = sum;
     }
 }
 
@@ -2404,7 +2474,7 @@ hipError_t launch_mstep(hipStream_t st, const MstepArgs &a)
 hipError_t launch_mstep_tiles(hipStream_t st, const MstepArgs &a, const MTileArgs &t)
 {
     if (t.n_tiles == 0) return hipSuccess;
-    const size_t lds = (size_t)t.tv * a.G * sizeof(double);
+    const size_t lds = (size_t)t.tv * a.G * sizeof(unsigned long long);
     if (a.square)
         hipLaunchKernelGGL((k_mstep_tiles<true>), dim3((unsigned)t.n_tiles), dim3(MTILE_THREADS), lds, st, a, t);
     else

@@ -691,6 +691,7 @@ void release_mstep_tiles(dmx_ctx *c)
     dev_free(c, &c->d_mt_ptr, (size_t)c->n_mt + 1);
     dev_free(c, &c->d_mt_first, (size_t)c->n_mt + 1);
     dev_free(c, &c->d_mt_order, (size_t)c->n_mt);
+    dev_free(c, &c->d_mt_shift, (size_t)c->n_mt);
     c->n_mt = 0;
     c->mt_tv = 0;
     c->mt_tried = false;
@@ -765,6 +766,15 @@ int build_mstep_tiles(dmx_ctx *c, long long v_lo, long long v_hi)
     const long long n_mt = (long long)tile_first.size();
     tile_first.push_back((int)v_hi);
     tile_ptr.push_back(m);
+    // fixed-point exponent of every tile (k_mstep_tiles): contributions in [0, 1] are added as rint(c 2^shift); the sum of the
+    // longest variant's n contributions stays below 2^63, and c 2^shift below 2^51 (the conversion's range)
+    std::vector<int> tile_shift((size_t)n_mt);
+    for (long long i = 0; i < n_mt; i++) {
+        long long longest = 1;
+        for (long long v = tile_first[(size_t)i]; v < tile_first[(size_t)i + 1]; v++)
+            longest = std::max(longest, first_call[(size_t)v + 1] - first_call[(size_t)v]);
+        tile_shift[(size_t)i] = std::min(50, 62 - (int)bits_for((unsigned long long)longest));
+    }
     std::vector<int> order((size_t)n_mt);
     for (long long i = 0; i < n_mt; i++) order[(size_t)i] = (int)i;
     std::stable_sort(order.begin(), order.end(), [&](int x, int y) {
@@ -792,6 +802,8 @@ int build_mstep_tiles(dmx_ctx *c, long long v_lo, long long v_hi)
     DMX_TRY(dev_alloc(c, &c->d_mt_ptr, (size_t)n_mt + 1));
     DMX_TRY(dev_alloc(c, &c->d_mt_first, (size_t)n_mt + 1));
     DMX_TRY(dev_alloc(c, &c->d_mt_order, (size_t)n_mt));
+    DMX_TRY(dev_alloc(c, &c->d_mt_shift, (size_t)n_mt));
+    HIP_TRY(hipMemcpyAsync(c->d_mt_shift, tile_shift.data(), sizeof(int) * n_mt, hipMemcpyHostToDevice, st));
     HIP_TRY(hipMemcpyAsync(c->d_mt_ptr, tile_ptr.data(), sizeof(long long) * (n_mt + 1), hipMemcpyHostToDevice, st));
     HIP_TRY(hipMemcpyAsync(c->d_mt_first, tile_first.data(), sizeof(int) * (n_mt + 1), hipMemcpyHostToDevice, st));
     HIP_TRY(hipMemcpyAsync(c->d_mt_order, order.data(), sizeof(int) * n_mt, hipMemcpyHostToDevice, st));

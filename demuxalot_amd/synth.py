@@ -83,19 +83,10 @@ def make_genotype_betas(rng, n_snps, n_genotypes):
     return betas, dosage
 
 
-def generate(n_barcodes, n_snps, n_genotypes, calls_per_barcode=400, doublets=False, seed=1234,
-             variant_major=True, seed_calls=None) -> SyntheticProblem:
-    """`seed` fixes the genotype table and SNP popularity; `seed_calls` (default: seed) fixes the
-    barcodes and their calls, so that several shards can share one genotype table."""
-    rng = np.random.Generator(np.random.PCG64(seed))
-    B, S, G = int(n_barcodes), int(n_snps), int(n_genotypes)
+def _generate_calls(rng, B, S, G, dosage, weights, calls_per_barcode, doublets, variant_major):
+    """Barcodes and their calls for a given genotype table: (truth int32[B, 2], variant, cb, p_base_wrong), the unique
+    (barcode, variant) calls variant-major (barcodes ascending inside a variant) or barcode-major."""
     V = 2 * S
-    betas, dosage = make_genotype_betas(rng, S, G)
-    weights = rng.lognormal(0.0, 1.5, size=S)
-    if seed_calls is not None and seed_calls != seed:
-        rng = np.random.Generator(np.random.PCG64(seed_calls))
-    v2snp = (np.arange(V, dtype=np.int32) // 2).astype(np.int32)
-
     truth = np.empty((B, 2), dtype=np.int32)
     truth[:, 0] = rng.integers(0, G, size=B)
     truth[:, 1] = truth[:, 0]
@@ -139,8 +130,63 @@ def generate(n_barcodes, n_snps, n_genotypes, calls_per_barcode=400, doublets=Fa
     if variant_major:
         order = np.argsort(u_variant, kind='stable')  # barcodes stay ascending inside a variant
         u_variant, u_cb, p = u_variant[order], u_cb[order], p[order]
-    return SyntheticProblem(B, S, G, v2snp, betas, np.ascontiguousarray(u_variant), np.ascontiguousarray(u_cb),
-                            np.ascontiguousarray(p), truth)
+    return truth, np.ascontiguousarray(u_variant), np.ascontiguousarray(u_cb), np.ascontiguousarray(p)
+
+
+def generate(n_barcodes, n_snps, n_genotypes, calls_per_barcode=400, doublets=False, seed=1234,
+             variant_major=True, seed_calls=None) -> SyntheticProblem:
+    """`seed` fixes the genotype table and SNP popularity; `seed_calls` (default: seed) fixes the
+    barcodes and their calls, so that several shards can share one genotype table."""
+    rng = np.random.Generator(np.random.PCG64(seed))
+    B, S, G = int(n_barcodes), int(n_snps), int(n_genotypes)
+    V = 2 * S
+    betas, dosage = make_genotype_betas(rng, S, G)
+    weights = rng.lognormal(0.0, 1.5, size=S)
+    if seed_calls is not None and seed_calls != seed:
+        rng = np.random.Generator(np.random.PCG64(seed_calls))
+    v2snp = (np.arange(V, dtype=np.int32) // 2).astype(np.int32)
+    truth, u_variant, u_cb, p = _generate_calls(rng, B, S, G, dosage, weights, calls_per_barcode, doublets, variant_major)
+    return SyntheticProblem(B, S, G, v2snp, betas, u_variant, u_cb, p, truth)
+
+
+def generate_sharded(n_barcodes, n_snps, n_genotypes, n_shards=8, calls_per_barcode=400, doublets=False, seed=1234,
+                     threads=None) -> SyntheticProblem:
+    """The same experiment model at sizes where one pass of generate() takes minutes and tens of gigabytes
+    (BASELINE.json configs[4]: 1M barcodes x 650k SNPs x 128 genotypes, ~4e8 calls): ONE genotype table (seed), the
+    barcodes cut into n_shards consecutive ranges whose calls are drawn independently (generator seed x 1000 + shard) by
+    a pool of threads (numpy's generators, sorts and searches release the interpreter lock).  Deterministic for a given
+    (seed, n_shards), whatever the number of threads.  The calls come shard after shard, variant-major inside a shard
+    with ascending barcodes: for every variant the barcodes ascend over the whole array (the reference's bincount order,
+    demux.py:113-118), for every barcode the variants ascend (demux.py:261) - as in generate()'s output."""
+    import os
+    from concurrent.futures import ThreadPoolExecutor
+    rng = np.random.Generator(np.random.PCG64(seed))
+    B, S, G = int(n_barcodes), int(n_snps), int(n_genotypes)
+    V = 2 * S
+    betas, dosage = make_genotype_betas(rng, S, G)
+    weights = rng.lognormal(0.0, 1.5, size=S)
+    v2snp = (np.arange(V, dtype=np.int32) // 2).astype(np.int32)
+    bounds = [B * k // n_shards for k in range(n_shards + 1)]
+
+    def shard(k):
+        rng_k = np.random.Generator(np.random.PCG64(seed * 1000 + k))
+        truth, v, cb, p = _generate_calls(rng_k, bounds[k + 1] - bounds[k], S, G, dosage, weights, calls_per_barcode, doublets, True)
+        cb += np.int32(bounds[k])
+        return truth, v, cb, p
+
+    workers = max(1, min(n_shards, threads if threads else (os.cpu_count() or 1)))
+    with ThreadPoolExecutor(max_workers=workers) as pool:
+        parts = list(pool.map(shard, range(n_shards)))
+    truth = np.concatenate([t for t, _, _, _ in parts])
+    sizes = [len(v) for _, v, _, _ in parts]
+    variant, cb, p = np.empty(sum(sizes), np.int32), np.empty(sum(sizes), np.int32), np.empty(sum(sizes), np.float32)
+    at = 0
+    for k in range(n_shards):  # shard by shard, each freed as soon as it is copied
+        _t, v_k, cb_k, p_k = parts[k]
+        parts[k] = None
+        variant[at:at + len(v_k)], cb[at:at + len(v_k)], p[at:at + len(v_k)] = v_k, cb_k, p_k
+        at += len(v_k)
+    return SyntheticProblem(B, S, G, v2snp, betas, variant, cb, p, truth)
 
 
 def as_objects(problem: SyntheticProblem, n_chromosomes=3):

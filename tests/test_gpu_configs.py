@@ -311,6 +311,129 @@ def test_config4_rank_share_130k_650k_128_doublets(oracle):
     assert singlets.shape == (130_000, 128) and (addition >= 0).all()
 
 
+# ---- configs[4] as written: the whole experiment on one GPU -----------------------------------------------
+def test_config4_as_written_1M_650k_128_doublets_on_one_gpu(oracle):
+    """BASELINE.json configs[4] at its full size on ONE MI355X: 1M barcodes x 650k SNPs (V = 1.3 M) x 128 genotypes,
+    doublet_prior .25 (K = 8256), ~4e8 calls.  B x K = 8.26e9 ELEMENTS (> 2^32: 33 GB of logits, 33 GB of posteriors)
+    and N > 2^28 are exactly where a 32-bit offset would hide, so the checks sit on both sides of those boundaries:
+      P-step   slices of the [V, G] table from both ends, bitwise (exact mode and default mode: the P-step is the same)
+      E-step   exact mode: sampled barcode rows from the first rows, the last rows and the rows whose element offset
+               crosses 2^32 (row 520 223), bitwise against the oracle (8256 column passes each);
+               default (guarded) mode: the same rows within the contract, the singlet posteriors of ALL 1M barcodes
+               within 1e-5 of the exact mode's and the arg-max of all 1M rows (device reduction) identical
+      M-step   rows of multi-item variants (the 16 384-call work items and the in-order redo), the hottest variants
+               and random ones against np.bincount on the GPU's own singlet posteriors, bitwise
+      results  dmx_get_block / dmx_get_assignments / dmx_get_top_options at row indices beyond the 2^32-element offset
+    then two fused EM iterations (dmx_em) in the default mode."""
+    import time
+    import psutil
+    from demuxalot_amd import Demultiplexer, synth
+    from demuxalot_amd.device import get_context
+    from tests.test_gpu_guarded import check_contract
+    if psutil.virtual_memory().available < 56e9:
+        pytest.skip(f'needs ~50 GB of host memory for the 4e8-call experiment ({psutil.virtual_memory().available / 1e9:.0f} GB free)')
+    B, S, G, dp = 1_000_000, 650_000, 128, 0.25
+    t0 = time.perf_counter()
+    p = synth.generate_sharded(B, S, G, n_shards=16, doublets=True, seed=1242)
+    t_gen = time.perf_counter() - t0
+    K = G * (G + 1) // 2
+    assert B * K > 2 ** 32 and p.n_calls > 2 ** 28, (B * K, p.n_calls)
+    rng = np.random.default_rng(41)
+    prior = p.prior_betas()
+    pen = Demultiplexer._doublet_penalties(G, dp)
+    cross = 2 ** 32 // K  # the row whose elements straddle the 2^32-element offset
+    samples = [(0, 24), (cross - 10, cross + 14), (B - 24, B)]
+    ctx = get_context()
+    try:
+        t0 = time.perf_counter()
+        ctx.set_problem(B, p.n_variants, G, p.variant_id, p.compressed_cb, p.p_base_wrong, p.v2snp)
+        ctx.set_betas(prior)
+        ctx.set_addition(None)
+        t_install = time.perf_counter() - t0
+        prob = ctx.probs_from_betas(0.01)
+        for v0, v1 in ((0, 100_000), (p.n_variants - 100_000, p.n_variants)):  # whole SNP groups (variants 2s, 2s + 1)
+            want = oracle.probs_from_betas(p.v2snp[v0:v1] - p.v2snp[v0], prior[v0:v1], 0.01)
+            fio.assert_bitwise(prob[v0:v1], want, f'P-step rows [{v0},{v1})')
+        # ---- iteration 0, exact mode: the importers' table (a handful of distinct values per row: the dictionary form) ----
+        ctx.set_estep_mode('exact')
+        ctx.set_exact_additions(True)
+        ctx.estep(pen, with_doublets=True, fetch_logits=False, fetch_probs=False)
+        form0 = ctx.estep_form()[0]
+        for lo, hi in samples[1:]:
+            check_e_rows(ctx, oracle, p, prob, lo, hi, dp, f'it 0 exact E rows [{lo},{hi})')
+        singlets = ctx.get_block('probs', 0, B, 0, G)
+        addition = ctx.mstep(2.)
+        counts = np.bincount(p.variant_id, minlength=p.n_variants)
+        multi = np.flatnonzero(counts > item_calls_for(p.n_calls))
+        assert len(multi) >= 20, len(multi)
+        variants = np.unique(np.concatenate([rng.choice(multi, size=40, replace=False), np.argsort(counts)[-8:],
+                                             rng.choice(p.n_variants, size=300, replace=False)]))
+        fio.assert_bitwise(addition[variants], addition_rows(p, singlets, variants), 'it 0 M-step rows (exact mode)')
+        assert (addition >= 0).all() and np.isfinite(addition).all()
+        # ---- iteration 1, exact mode: the table of prior + addition (all-distinct rows: the one-log-per-term kernels) ----
+        prob = ctx.probs_from_betas(0.01)
+        for v0, v1 in ((0, 100_000), (p.n_variants - 100_000, p.n_variants)):
+            want = oracle.probs_from_betas(p.v2snp[v0:v1] - p.v2snp[v0], (prior + addition)[v0:v1], 0.01)
+            fio.assert_bitwise(prob[v0:v1], want, f'it 1 P-step rows [{v0},{v1})')
+        t0 = time.perf_counter()
+        ctx.estep(pen, with_doublets=True, fetch_logits=False, fetch_probs=False)
+        ctx.synchronize()
+        t_exact = time.perf_counter() - t0
+        form1 = ctx.estep_form()[0]
+        assert form1 == 'direct', form1
+        device_bytes = ctx.device_bytes()
+        exact_rows = {}
+        for lo, hi in samples:
+            check_e_rows(ctx, oracle, p, prob, lo, hi, dp, f'it 1 exact E rows [{lo},{hi})')
+            exact_rows[lo] = ctx.get_block('probs', lo, hi)
+        singlets = ctx.get_block('probs', 0, B, 0, G)
+        best_exact, best_p_exact = ctx.get_assignments()
+        for lo, hi in samples:  # device reductions at rows beyond the 2^32-element offset against numpy on the fetched block
+            block = exact_rows[lo]
+            assert np.array_equal(best_exact[lo:hi], block.argmax(axis=1)) and np.array_equal(best_p_exact[lo:hi], block.max(axis=1))
+        top, top_p = ctx.get_top_options(2)
+        block = exact_rows[samples[-1][0]]
+        order = np.argsort(-block, axis=1, kind='stable')[:, :2]
+        assert np.array_equal(top[B - 24:], order) and np.array_equal(top_p[B - 24:], np.take_along_axis(block, order, axis=1))
+        assert abs(float(ctx.get_option_sums().sum()) - B) < 1e-3 * B
+        addition1 = ctx.mstep(2.)
+        fio.assert_bitwise(addition1[variants], addition_rows(p, singlets, variants), 'it 1 M-step rows (exact mode)')
+        # ---- the library's default mode on the same table ----
+        ctx.set_estep_mode('guarded')
+        ctx.set_exact_additions(False)
+        ctx.reset_timings()
+        t0 = time.perf_counter()
+        ctx.estep(pen, with_doublets=True, fetch_logits=False, fetch_probs=False)
+        ctx.synchronize()
+        t_guarded = time.perf_counter() - t0
+        redone, _total, rows = ctx.guard_stats()
+        assert rows == B and ctx.estep_form()[0] == 'direct'
+        for lo, hi in samples:
+            check_contract(ctx.get_block('probs', lo, hi), exact_rows[lo], f'guarded E rows [{lo},{hi})')
+        singlets_g = ctx.get_block('probs', 0, B, 0, G)
+        assert np.abs(singlets_g.astype(np.float64) - singlets).max() <= 1e-5
+        best_g, _ = ctx.get_assignments()
+        assert np.array_equal(best_g, best_exact), 'default mode: assignments of all 1M barcodes'
+        singlet = p.truth[:, 0] == p.truth[:, 1]
+        hit = (best_g[singlet] == p.truth[singlet, 0]).mean()
+        assert hit > 0.9, hit
+        addition_g = ctx.mstep(2.)
+        assert np.abs(addition_g[variants].astype(np.float64) - addition1[variants]).max() <= 2e-5 * counts[variants].max()
+        # ---- two fused EM iterations, default mode ----
+        t0 = time.perf_counter()
+        ctx.em(2, 0.01, pen, with_doublets=True, fetch_logits=False, fetch_probs=False, fetch_addition=False)
+        t_em = time.perf_counter() - t0
+        best_em, best_p_em = ctx.get_assignments()
+        assert np.isfinite(best_p_em).all() and (best_p_em > 0).all() and (best_em == best_g).mean() > 0.98
+    finally:
+        ctx.apply_environment()
+        ctx.release_problem()
+        ctx.trim_cache()
+    print(f'configs[4] as written on one GPU: {p.n_calls} calls generated in {t_gen:.0f} s, installed in {t_install:.1f} s, '
+          f'{device_bytes / 1e9:.1f} GB on the device ({device_bytes / p.n_calls:.0f} B per call incl. the [B, K] results); iteration 0 took the {form0} form; '
+          f'E-step of iteration 1: exact {t_exact:.2f} s, default {t_guarded:.2f} s ({redone} barcodes redone exactly); 2 fused EM iterations {t_em:.2f} s')
+
+
 # ---- the tile-major schedule with two accumulators per lane (65..128 genotypes, singlets) ------------------
 def test_tiled_schedule_two_slots_per_lane(oracle):
     """70k barcodes x 20k SNPs x 128 genotypes (K = 128 singlets: two options per lane; 20 MB genotype table, so the
