@@ -83,6 +83,8 @@ SIGNATURES = {
     'dmx_get_redo_count': (c_int, [_P, POINTER(c_int64)]),
     'dmx_set_estep_mode': (c_int, [_P, c_int]),
     'dmx_get_guard_stats': (c_int, [_P, POINTER(c_int64), POINTER(c_int64), POINTER(c_int64)]),
+    'dmx_set_guard_adaptive': (c_int, [_P, c_int]),
+    'dmx_get_guard_direct': (c_int, [_P, POINTER(c_int32), POINTER(c_int64), POINTER(c_int64), POINTER(c_double), POINTER(c_double)]),
     'dmx_set_estep_schedule': (c_int, [_P, c_int]),
     'dmx_set_estep_dictionary': (c_int, [_P, c_int]),
     'dmx_get_estep_form': (c_int, [_P, POINTER(c_int32), POINTER(c_int32)]),
@@ -90,6 +92,8 @@ SIGNATURES = {
     'dmx_set_mstep_wide_addresses': (c_int, [_P, c_int]),
     'dmx_set_mstep_tiles': (c_int, [_P, c_int]),
     'dmx_get_mstep_form': (c_int, [_P, POINTER(c_int32)]),
+    'dmx_set_msteps_expected': (c_int, [_P, c_int64]),
+    'dmx_get_mstep_tiles_info': (c_int, [_P, POINTER(c_int32), POINTER(c_double)]),
     'dmx_test_logf': (c_int, [_P, _P, _P, c_int64]),
     'dmx_test_logf_hot': (c_int, [_P, _P, _P, c_int64]),
     'dmx_test_expf': (c_int, [_P, _P, _P, c_int64]),

@@ -5,6 +5,7 @@
 #include <rccl/rccl.h>
 
 #include <array>
+#include <chrono>
 #include <functional>
 
 #include <algorithm>
@@ -433,6 +434,7 @@ void release_problem(dmx_ctx *c)
     dev_free(c, &c->d_call_rows, ((size_t)c->n_pairs + dmx::CALL_PAD_PAIRS) * 2);
     dev_free(c, &c->d_tile_stream, (size_t)c->n_pairs);
     c->n_pairs = 0;
+    dmx::release_mstep_tiles(c);  // (its record stream is sized by n_csc)
     dev_free(c, &c->d_csc, (size_t)c->n_csc);
     c->n_csc = 0;
     dev_free(c, &c->d_item_start, (size_t)c->n_items);
@@ -476,7 +478,6 @@ void release_problem(dmx_ctx *c)
     c->slice_rows = c->prob_rows = 0;
     c->cut.clear();
     c->h_v2snp.clear();
-    dmx::release_mstep_tiles(c);
     dev_free(c, &c->d_partial, (size_t)c->n_items * c->G);
     dev_free(c, &c->d_redo, c->cap_redo);
     dev_free(c, &c->d_n_redo, (size_t)2);
@@ -493,7 +494,7 @@ void release_problem(dmx_ctx *c)
     dev_free(c, &c->d_seg_sums, c->cap_seg_sums);
     c->cap_seg_sums = 0;
     c->n_segs = c->n_split = 0;
-    dev_free(c, &c->d_guard_count, (size_t)2);
+    dev_free(c, &c->d_guard_count, (size_t)dmx::GS_WORDS + dmx::GUARD_SLOTS);
     dev_free(c, &c->d_guard_list, (size_t)c->B);
     c->guard_rows_total = 0;
     c->guard_ran = false;
@@ -1173,6 +1174,8 @@ int run_estep(dmx_ctx *c, int with_doublets, bool with_prior, int prior_dtype, f
     a.guard_count = c->d_guard_count;
     a.guard_list = c->d_guard_list;
     a.order_count = nullptr;
+    a.direct = nullptr;
+    a.order_direct = nullptr;
     a.segs = c->n_segs > 0 && c->K <= 1024 ? c->d_segs : nullptr;
     a.n_segs = c->n_segs;
     a.n_split = c->n_split;
@@ -1230,16 +1233,21 @@ int run_estep(dmx_ctx *c, int with_doublets, bool with_prior, int prior_dtype, f
         } else if (guarded) {
             // fast kernels with the guard evaluated per barcode, then the exact kernel over the barcodes they queued (their
             // number is only known on the device: a launch sized for all of them, the wavefronts past the queue's end
-            // return at once); the redo rewrites logits, posteriors, bitmaps and codes of those barcodes
-            HIP_TRY(hipMemsetAsync(c->d_guard_count, 0, sizeof(unsigned), c->stream));
+            // return at once); the redo rewrites logits, posteriors, bitmaps and codes of those barcodes.  Adaptive
+            // (kernels.h: EstepArgs::direct): after an E-step that queued more than 40 % of the barcodes the fast kernels
+            // stand back and the exact launch walks every barcode - decided on the device by k_guard_begin.
+            HIP_TRY(dmx::launch_guard_begin(c->stream, c->d_guard_count, c->B, c->K, c->guard_adaptive));
             a.guard = 1;
+            a.direct = c->d_guard_count + dmx::GS_DIRECT;
+            a.order_direct = c->d_bc_order;
             HIP_TRY(dmx::launch_estep(c->stream, a, with_doublets != 0));
+            HIP_TRY(dmx::launch_guard_stamp(c->stream, c->d_guard_count, dmx::GS_T_REDO));
             dmx::EstepArgs redo = a;
             redo.fast = 0;
-            redo.guard = 0;
+            redo.guard = 2;
             redo.n_bins = 0;
             redo.order = c->d_guard_list;
-            redo.order_count = c->d_guard_count;
+            redo.order_count = c->d_guard_count + dmx::GS_COUNT;
             HIP_TRY(dmx::launch_estep(c->stream, redo, with_doublets != 0));
             c->guard_rows_total += c->B;
             c->guard_ran = true;
@@ -1248,7 +1256,8 @@ int run_estep(dmx_ctx *c, int with_doublets, bool with_prior, int prior_dtype, f
         }
     }
     c->estep_form = form;
-    if (a.dense_calls) HIP_TRY(dmx::launch_sum_dense(c->stream, c->d_dense_calls));
+    if (a.dense_calls) HIP_TRY(dmx::launch_sum_dense(c->stream, c->d_dense_calls, c->guard_ran ? c->d_guard_count : nullptr));
+    else if (c->guard_ran) HIP_TRY(dmx::launch_guard_stamp(c->stream, c->d_guard_count, dmx::GS_T_END));
     timer_end(c, DMX_T_ESTEP, ev);
     c->have_post = true;
     return 0;
@@ -1336,15 +1345,23 @@ int run_mstep(dmx_ctx *c, float power)
     // tile-major form (kernels.h: MTileArgs): sums in any order, so not with the exact additions; built on first use
     a.tiles_done = false;
     dmx::MTileArgs tiles{};
-    // Building the records (a sort of the calls: 4.1 ms on 200k x 100k x 64, where an M-step then takes 0.46 instead of
-    // 0.69 ms) pays from MSTEP_TILES_PAY M-steps on: taken when the running call still has that many to do, or the
-    // problem has seen that many already (somebody iterates call by call), or always (dmx_set_mstep_tiles(ctx, 2)).
-    constexpr int MSTEP_TILES_PAY = 16;
-    const bool tiles_wanted = c->mstep_tiles == 2 || (c->mstep_tiles == 1 && (c->n_mt > 0 || c->msteps_ahead >= MSTEP_TILES_PAY ||
+    // Building the records (a sort of the calls: 4.1 ms on 200k x 100k x 64, where an M-step then takes 0.34 instead of
+    // 0.69 ms) pays from MSTEP_TILES_PAY M-steps on: taken when that many are still to come - in the running dmx_em /
+    // dmx_run_iterations call, or as the caller announced (dmx_set_msteps_expected) -, or the problem has seen that many
+    // already (somebody iterates call by call), or always (dmx_set_mstep_tiles(ctx, 2)).
+    constexpr int MSTEP_TILES_PAY = 12;
+    const long long ahead = std::max<long long>(c->msteps_ahead, c->msteps_expected);
+    const bool tiles_wanted = c->mstep_tiles == 2 || (c->mstep_tiles == 1 && (c->n_mt > 0 || ahead >= MSTEP_TILES_PAY ||
                                                                              c->msteps_done >= MSTEP_TILES_PAY));
+    if (c->msteps_expected > 0) c->msteps_expected--;
     c->msteps_done++;
     if (!c->exact_additions && tiles_wanted && c->G <= 64 && c->n_csc > 0 && power > 0.0f) {  // (power > 0: contributions in [0, 1])
-        if (!c->mt_tried) DMX_TRY(dmx::build_mstep_tiles(c, mshard ? c->cut[c->rank] : 0, mshard ? c->cut[c->rank + 1] : c->V));
+        if (!c->mt_tried) {
+            HIP_TRY(hipStreamSynchronize(c->stream));  // (the build synchronises anyway; this makes its wall time its own)
+            const auto t0 = std::chrono::steady_clock::now();
+            DMX_TRY(dmx::build_mstep_tiles(c, mshard ? c->cut[c->rank] : 0, mshard ? c->cut[c->rank + 1] : c->V));
+            c->mt_build_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+        }
         if (c->n_mt > 0) {
             tiles.stream = c->d_mt_stream;
             tiles.ptr = c->d_mt_ptr;
@@ -1552,9 +1569,9 @@ static int finish_problem(dmx_ctx *c, const int32_t *v2snp, const std::vector<in
     DMX_TRY(dev_alloc(c, &c->d_nz, (size_t)B * ((G + 63) / 64)));
     DMX_TRY(dev_alloc(c, &c->d_first, (size_t)B));
     DMX_TRY(dev_alloc(c, &c->d_dense_calls, (size_t)1 + dmx::DENSE_SLOTS));
-    DMX_TRY(dev_alloc(c, &c->d_guard_count, (size_t)2));
+    DMX_TRY(dev_alloc(c, &c->d_guard_count, (size_t)dmx::GS_WORDS + dmx::GUARD_SLOTS));
     DMX_TRY(dev_alloc(c, &c->d_guard_list, (size_t)B));
-    HIP_TRY(hipMemsetAsync(c->d_guard_count, 0, 2 * sizeof(unsigned), c->stream));
+    HIP_TRY(hipMemsetAsync(c->d_guard_count, 0, (dmx::GS_WORDS + dmx::GUARD_SLOTS) * sizeof(unsigned), c->stream));
     HIP_TRY(hipMemsetAsync(c->d_dense_calls, 0, sizeof(unsigned long long) * (1 + dmx::DENSE_SLOTS), c->stream));
     DMX_TRY(dev_alloc(c, &c->d_best, (size_t)B));
     DMX_TRY(dev_alloc(c, &c->d_bestp, (size_t)B));
@@ -1697,17 +1714,56 @@ int dmx_set_estep_mode(dmx_ctx *c, int mode)
     return 0;
 }
 
+static int read_guard_state(dmx_ctx *c, unsigned (&st)[dmx::GS_WORDS], long long *count)
+{
+    std::vector<unsigned> all((size_t)dmx::GS_WORDS + dmx::GUARD_SLOTS, 0u);
+    if (c->d_guard_count) {
+        HIP_TRY(hipMemcpyAsync(all.data(), c->d_guard_count, all.size() * sizeof(unsigned), hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(hipStreamSynchronize(c->stream));
+    }
+    for (int i = 0; i < dmx::GS_WORDS; i++) st[i] = all[(size_t)i];
+    *count = st[dmx::GS_DIRECT] ? 0 : st[dmx::GS_COUNT];  // (a direct E-step's queue holds every barcode; it counts on the hashed slots)
+    for (int i = 0; i < dmx::GUARD_SLOTS; i++) *count += all[(size_t)dmx::GS_WORDS + i];
+    return 0;
+}
+
 int dmx_get_guard_stats(dmx_ctx *c, int64_t *redone_last, int64_t *redone_total, int64_t *rows_total)
 {
     DMX_TRY(bind(c));
-    unsigned n[2] = {0u, 0u};
-    if (c->d_guard_count) {
-        HIP_TRY(hipMemcpyAsync(n, c->d_guard_count, sizeof n, hipMemcpyDeviceToHost, c->stream));
-        HIP_TRY(hipStreamSynchronize(c->stream));
-    }
-    if (redone_last) *redone_last = c->guard_ran ? (int64_t)n[0] : 0;
-    if (redone_total) *redone_total = (int64_t)n[1];
+    unsigned st[dmx::GS_WORDS];
+    long long count = 0;
+    DMX_TRY(read_guard_state(c, st, &count));
+    // barcodes the last guarded E-step computed with the exact kernel: its queue, or all of them when it ran direct
+    const long long last = st[dmx::GS_DIRECT] ? (long long)st[dmx::GS_ROWS] : count;
+    const long long total = (long long)(((unsigned long long)st[dmx::GS_TOTAL + 1] << 32) | st[dmx::GS_TOTAL]) + (st[dmx::GS_PENDING] ? last : 0);
+    if (redone_last) *redone_last = c->guard_ran ? (int64_t)last : 0;
+    if (redone_total) *redone_total = (int64_t)total;
     if (rows_total) *rows_total = (int64_t)c->guard_rows_total;
+    return 0;
+}
+
+int dmx_set_guard_adaptive(dmx_ctx *c, int adaptive)
+{
+    if (!c) return fail(DMX_ERR_INVALID, "null context");
+    c->guard_adaptive = adaptive != 0;
+    return 0;
+}
+
+int dmx_get_guard_direct(dmx_ctx *c, int32_t *last_ran_direct, int64_t *direct_steps, int64_t *would_queue_last, double *fast_pass_ms,
+                         double *exact_pass_ms)
+{
+    DMX_TRY(bind(c));
+    unsigned st[dmx::GS_WORDS];
+    long long count = 0;
+    DMX_TRY(read_guard_state(c, st, &count));
+    if (last_ran_direct) *last_ran_direct = c->guard_ran && st[dmx::GS_DIRECT] ? 1 : 0;
+    if (direct_steps) *direct_steps = (int64_t)st[dmx::GS_DIRECT_STEPS];
+    if (would_queue_last) *would_queue_last = c->guard_ran ? (int64_t)count : 0;
+    int khz = 0;
+    HIP_TRY(hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, c->device));
+    const double ms_per_tick = khz > 0 ? 1.0 / (double)khz : 0.0;
+    if (fast_pass_ms) *fast_pass_ms = st[dmx::GS_F_TICKS] * ms_per_tick;
+    if (exact_pass_ms) *exact_pass_ms = (st[dmx::GS_E_MEASURED] ? 1.0 : -1.0) * st[dmx::GS_E_TICKS] * ms_per_tick;
     return 0;
 }
 
@@ -1794,6 +1850,21 @@ int dmx_set_mstep_tiles(dmx_ctx *c, int enable)
     if (!c) return fail(DMX_ERR_INVALID, "null context");
     if (enable < 0 || enable > 2) return fail(DMX_ERR_INVALID, "dmx_set_mstep_tiles: 0 never, 1 when it pays, 2 always");
     c->mstep_tiles = enable;
+    return 0;
+}
+
+int dmx_set_msteps_expected(dmx_ctx *c, int64_t n)
+{
+    if (!c) return fail(DMX_ERR_INVALID, "null context");
+    c->msteps_expected = n > 0 ? (long long)n : 0;
+    return 0;
+}
+
+int dmx_get_mstep_tiles_info(dmx_ctx *c, int32_t *built, double *build_ms)
+{
+    if (!c) return fail(DMX_ERR_INVALID, "null context");
+    if (built) *built = c->n_mt > 0 ? 1 : 0;
+    if (build_ms) *build_ms = c->n_mt > 0 ? c->mt_build_ms : 0.0;
     return 0;
 }
 
@@ -2222,7 +2293,8 @@ int dmx_reset_timings(dmx_ctx *c)
 {
     DMX_TRY(bind(c));
     HIP_TRY(hipStreamSynchronize(c->stream));
-    if (c->d_guard_count) HIP_TRY(hipMemsetAsync(c->d_guard_count + 1, 0, sizeof(unsigned), c->stream));
+    // the totals; the last E-step's own numbers stay (they decide how the next one runs: kernels.hip k_guard_begin)
+    if (c->d_guard_count) HIP_TRY(hipMemsetAsync(c->d_guard_count + dmx::GS_PENDING, 0, 4 * sizeof(unsigned), c->stream));  // GS_PENDING, GS_DIRECT_STEPS, GS_TOTAL
     c->guard_rows_total = 0;
     for (int s = 0; s < DMX_T_COUNT; s++) {
         timer_flush(c, s);

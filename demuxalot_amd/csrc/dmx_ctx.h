@@ -84,6 +84,8 @@ struct dmx_ctx {
     int mstep_tiles = 1;            // dmx_set_mstep_tiles: 0 never, 1 when building the records pays, 2 always
     long long msteps_done = 0;      // M-steps run on the resident problem
     int msteps_ahead = 0;           // M-steps the running dmx_em / dmx_run_iterations call still has to do (0 outside)
+    long long msteps_expected = 0;  // dmx_set_msteps_expected: M-steps the caller says it will still run (counted down as they run)
+    double mt_build_ms = 0.0;       // host wall time of the last build of the tile-major records
     int mstep_form = 0;             // form of the last M-step launch: 0 none, 1 work items, 2 tiles (dmx_get_mstep_form)
     int *d_sum_plan = nullptr;  // np.sum over a row of K values as a leaf / level plan (dmx_api.cpp: ensure_options)
     size_t cap_sum_plan = 0;
@@ -93,7 +95,8 @@ struct dmx_ctx {
     bool exact_additions = true;  // dmx_set_exact_additions
     int estep_mode = DMX_ESTEP_EXACT;  // dmx_set_estep_mode
     // guarded mode: barcodes queued by the epilogues of the fast kernels for the exact redo (kernels.h: EstepArgs::guard)
-    unsigned *d_guard_count = nullptr;  // [2] this E-step | all E-steps since the last reset
+    unsigned *d_guard_count = nullptr;  // [GS_WORDS + GUARD_SLOTS] device state of the guarded mode (kernels.h: GS_*)
+    int guard_adaptive = 1;             // dmx_set_guard_adaptive: E-steps after one that queued > 40 % of the barcodes run the exact kernel directly
     int *d_guard_list = nullptr;        // [B]
     long long guard_rows_total = 0;     // barcode rows the guarded kernels have walked since the last reset
     bool guard_ran = false;             // the last E-step evaluated the guard

@@ -2,7 +2,7 @@
 // (make asan -> ../libdemux_host_asan.so: dmx_api.cpp + pack_host.cpp + this file, g++ -fsanitize=address,undefined).
 // Never part of the shipped library and never a fallback: the kernels' launchers do NOTHING here, so every result is
 // meaningless.  What the build is for: running the 2 000 lines of host logic that carry the C ABI's error contract -
-// argument validation, call order, the block cache, np.sum plans, variant slices and the padded / chunk-major layouts
+// argument validation, call order, the block cache, np.sum plans, variant slices and the padded layouts
 // of the multi-GPU exchange, host-staged collectives - under AddressSanitizer and UBSan on the CPU
 // (tests/test_host_sanitizers.py; the contract replaces the reference's asserts at
 // demux.py:78,81,98,135,160,317,359,374).  "Device memory" is plain malloc memory, so that every copy the shim makes
@@ -114,7 +114,7 @@ hipError_t hipEventElapsedTime(float *ms, hipEvent_t, hipEvent_t)
 // ------------------------------------------------------------------------------------
 namespace dmx {
 
-hipError_t launch_sum_dense(hipStream_t, unsigned long long *) { return hipSuccess; }
+hipError_t launch_sum_dense(hipStream_t, unsigned long long *, unsigned *) { return hipSuccess; }
 hipError_t launch_probs_from_betas(hipStream_t, const float *, const float *, const int *, const int *, const int *, long long, long long,
                                    long long, int, const int *, float, float, float *) { return hipSuccess; }
 hipError_t launch_probs_from_betas_f64(hipStream_t, const double *, const int *, const int *, const int *, long long, long long, int,
@@ -134,6 +134,8 @@ hipError_t launch_estep_dict(hipStream_t, const EstepArgs &, bool) { return hipS
 hipError_t launch_estep_dict_block(hipStream_t, const EstepArgs &) { return hipSuccess; }
 hipError_t launch_mstep(hipStream_t, const MstepArgs &) { return hipSuccess; }
 hipError_t launch_mstep_tiles(hipStream_t, const MstepArgs &, const MTileArgs &) { return hipSuccess; }
+hipError_t launch_guard_begin(hipStream_t, unsigned *, long long, int, int) { return hipSuccess; }
+hipError_t launch_guard_stamp(hipStream_t, unsigned *, int) { return hipSuccess; }
 hipError_t launch_mcombine(hipStream_t, const MstepArgs &, const long long *, long long, long long, const int *, float *, double *,
                            unsigned long long *, unsigned *, const int *, bool) { return hipSuccess; }
 hipError_t launch_store_slice(hipStream_t, const void *, bool, long long, long long, int, float *) { return hipSuccess; }
@@ -165,7 +167,7 @@ hipError_t launch_test_softmax(hipStream_t, const float *, float *, long long, i
 
 // ------------------------------------------------------------------------------------
 // The layouts repack_device.hip derives on the GPU, derived here with the same definitions (csrc/kernels.h, the
-// kernels of repack_device.hip) so that what dmx_api.cpp does with them - sizes, the chunk lists of the pipelined
+// kernels of repack_device.hip) so that what dmx_api.cpp does with them - sizes, the variant slices of the
 // exchange, the row remap - walks real structures.
 // ------------------------------------------------------------------------------------
 int repack_on_device(dmx_ctx *c, const int32_t *variant, const int32_t *cb, const float *p)

@@ -73,15 +73,19 @@ struct EstepArgs {
     int *guard_list;            // [B] the queued barcodes
     const unsigned *order_count;  // nullable: `order` holds *order_count entries (<= B), known on the device only (the exact
                                   // redo of the queued barcodes: k_estep_direct over guard_list)
-    // Adaptive guarded mode.  The fast pass costs F, the exact kernel E per barcode (F / E = 0.56 at 200k x 100k x 64, 0.34 at
-    // K = 8256); with a fraction f of the barcodes queued a guarded E-step costs F + f E - more than the exact mode's E once
-    // f > 1 - F / E, and 1.56 E on a workload where nothing can be proven (few calls per barcode, related donors).  So the
-    // E-step that follows one which queued more than 40 % of the barcodes runs DIRECT: the fast kernels stand back (they read
-    // *direct and return), the exact launch walks `order_direct` - every barcode - instead of the queue and counts the
-    // barcodes the guard would have queued, so that the E-step after one with fewer than 30 % goes back to the fast pass.
-    // The decision is taken on the device (k_guard_begin, between two E-steps on the stream): no host synchronisation.
+    // Adaptive guarded mode.  With the fast pass taking F, the exact kernel over every barcode E and a fraction f of the
+    // barcodes queued, a guarded E-step costs F + f E against the exact mode's E: more once f > 1 - F / E.  F / E is 0.56 at
+    // 200k x 100k x 64 and 0.34 at K = 8256, but above 1 on short rows (50 calls per barcode: the per-barcode epilogue is
+    // most of either kernel), so no fixed threshold on f is right.  The E-step is therefore TIMED on the device: the wall
+    // clock is stored before the fast launches (k_guard_begin), between them and the exact launch (k_guard_stamp) and behind
+    // it; k_guard_begin (between two E-steps on the stream) turns the stamps of the finished E-step into F and E (E from the redo's time over
+    // its share of the barcodes until an E-step has run direct and measured it) and lets the next E-step run DIRECT when
+    // F + f E > E: the fast kernels stand back (they read *direct, copy `order_direct` - every barcode - into the queue and
+    // return), so that the exact launch behind them walks every barcode; it counts the barcodes the guard would have
+    // queued, so that f stays known and the fast pass returns when it pays again (3 % of hysteresis).  No host
+    // synchronisation anywhere.
     const unsigned *direct;       // nullable: &state[GS_DIRECT]
-    const int *order_direct;      // [B] what the exact launch walks when the E-step runs direct (barcodes by decreasing row length)
+    const int *order_direct;      // [B] what the queue is filled with when the E-step runs direct (barcodes by decreasing row length)
     // Split rows (tolerance / guarded mode, 64-lane form; dmx_api.cpp: build_row_segments): a launch cannot end before its
     // longest barcode does, and a barcode's walk is a chain of memory latencies (~0.7 us per 8 calls) - 0.35 ms for a
     // 4 000-call row, which is the whole E-step of a 25k-barcode shard.  The n_split longest barcodes (the first entries
@@ -117,16 +121,26 @@ struct EstepArgs {
     const unsigned char *codes;   // [rows, dict_code_pitch(G)] 8 x index of every genotype's value in its row's dictionary
 };
 
-// device state of the guarded mode (dmx_ctx::d_guard_count, 8 x unsigned)
+// device state of the guarded mode (dmx_ctx::d_guard_count: GS_WORDS + GUARD_SLOTS x unsigned)
 enum { GS_COUNT = 0,         // barcodes queued by the current E-step (a direct one: that the guard would have queued)
        GS_DIRECT = 1,        // the current E-step runs the exact kernel on every barcode
-       GS_VALID = 2,         // GS_COUNT / GS_DIRECT / GS_ROWS describe a finished E-step of the resident problem
+       GS_VALID = 2,         // the words below describe a finished E-step of the resident problem
        GS_ROWS = 3,          // its barcode rows
        GS_PENDING = 4,       // ... and it is not yet part of the totals
        GS_DIRECT_STEPS = 5,  // E-steps run direct since the last reset
        GS_TOTAL = 6,         // (64 bit, two words) barcodes computed by the exact kernel since the last reset
-       GS_WORDS = 8 };
-hipError_t launch_guard_begin(hipStream_t st, unsigned *state, long long B, int adaptive);
+       GS_T_FAST = 8,        // wall clock (low 32 bits) before the fast launches / between them and the exact launch / behind it
+       GS_T_REDO = 9,
+       GS_T_END = 10,
+       GS_F_TICKS = 11,      // duration of the fast pass over all barcodes (0: not measured yet)
+       GS_E_TICKS = 12,      // duration of the exact kernel over all barcodes: measured by a direct E-step, estimated before
+       GS_E_MEASURED = 13,
+       GS_O_TICKS = 14,      // duration of the exact launch on an empty queue
+       GS_K = 15,            // option count of the finished E-step (another K: F and E start over)
+       GS_WORDS = 16 };
+constexpr int GUARD_SLOTS = 256;  // hashed counters behind the state words (counts of a direct E-step)
+hipError_t launch_guard_begin(hipStream_t st, unsigned *state, long long B, int K, int adaptive);
+hipError_t launch_guard_stamp(hipStream_t st, unsigned *state, int which);  // state[which] = the device's wall clock (GS_T_REDO, GS_T_END)
 
 constexpr int CALL_PAD_PAIRS = 64;     // readable neutral records behind the last barcode's row (pairs and call_rows)
 constexpr int DICT_CAP = 8;            // distinct values per row the dictionary form handles (singlet runs)
@@ -135,7 +149,7 @@ constexpr int DICT_LANE_K = 256;       // option tables up to this width take th
 __host__ __device__ inline int dict_code_pitch(int n) { return (n + 3) & ~3; }  // bytes between the rows of a code table of n codes per row
 
 constexpr int DENSE_SLOTS = 1024;            // hashed counters of the dense-call statistic
-hipError_t launch_sum_dense(hipStream_t st, unsigned long long *counters);
+hipError_t launch_sum_dense(hipStream_t st, unsigned long long *counters, unsigned *guard_state = nullptr);  // (also stamps GS_T_END)
 constexpr int TILE_R_MAX = 9;                // barcodes per bin at most (LDS: 4 waves x 9 x 64 doubles = 18 KB per block)
 constexpr long long TILE_BYTES = 1 << 20;    // genotype-table bytes per variant tile: a quarter of an XCD's 4 MB L2 (tolerance-mode E-step on
                                              // 200k x 100k x 64: 1.480 / 1.483 / 1.510 / 1.546 ms with tiles of 0.5 / 1 / 2 / 3 MB; DEMUXALOT_AMD_TILE_KB)

@@ -426,12 +426,9 @@ __global__ __launch_bounds__(256) void k_estep_direct(EstepArgs a)
     int row_calls = 0;  // calls of this lane group's barcode (incl. padding)
     // Guarded E-step that runs direct (kernels.h: EstepArgs::direct): the fast kernels stand back, the exact launch walks
     // every barcode instead of the queue
-    const bool direct = a.direct != nullptr && *a.direct != 0u;  // (uniform)
-    if (FAST && a.guard && direct) return;
-    const bool all_rows = !FAST && a.order_count != nullptr && direct;
-    const int *__restrict__ order = all_rows ? a.order_direct : a.order;
+    if (FAST && guard_stand_back(a, true)) return;
     // rows of `order` to walk: all B, or as many as the guarded E-step queued (known on the device only)
-    const long long n_rows = a.order_count && !all_rows ? (long long)min((unsigned long long)*a.order_count, (unsigned long long)a.B) : a.B;
+    const long long n_rows = a.order_count ? (long long)min((unsigned long long)*a.order_count, (unsigned long long)a.B) : a.B;
     long long seg_of_wave = -1;  // split rows (FAST, 64 lanes): the segment this wavefront walks
     if constexpr (L == 64) {
         // ---- wave-uniform path: everything about the row lives in SGPRs ----
@@ -452,13 +449,13 @@ __global__ __launch_bounds__(256) void k_estep_direct(EstepArgs a)
             } else {
                 slot = slot - a.n_segs + a.n_split;
                 if (slot >= n_rows) return;
-                b = order[slot];
+                b = a.order[slot];
                 pbeg = a.pair_ptr[b];
                 npairs = (int)(a.pair_ptr[b + 1] - pbeg);
             }
         } else {
             if (slot >= n_rows) return;
-            b = order[slot];
+            b = a.order[slot];
             pbeg = a.pair_ptr[b];
             npairs = (int)(a.pair_ptr[b + 1] - pbeg);
         }
@@ -523,7 +520,7 @@ __global__ __launch_bounds__(256) void k_estep_direct(EstepArgs a)
         if (((long long)blockIdx.x * 4 + (threadIdx.x >> 6)) * CPW >= n_rows) return;  // the whole wavefront past the list
         const long long slot = ((long long)blockIdx.x * 4 + (threadIdx.x >> 6)) * CPW + lane / L;
         live = slot < n_rows;
-        b = order[live ? slot : n_rows - 1];
+        b = a.order[live ? slot : n_rows - 1];
         const long long pbeg = a.pair_ptr[b];
         const int n = live ? 2 * (int)(a.pair_ptr[b + 1] - pbeg) : 0;  // calls incl. padding, multiple of 8
         row_calls = n;
@@ -715,8 +712,8 @@ __global__ __launch_bounds__(256) void k_estep_tiled(EstepArgs a)
     const int R = a.bin_rows_cap;
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const long long slot_id = (long long)blockIdx.x * 4 + wave;
+    if (FAST && guard_stand_back(a, true)) return;  // the E-step runs direct (EstepArgs::direct)
     if (slot_id >= a.n_bins) return;
-    if (FAST && a.guard && a.direct != nullptr && *a.direct != 0u) return;  // the E-step runs direct (EstepArgs::direct)
     const long long bin = a.bin_order[slot_id];
 
     unsigned o1[A];
@@ -834,11 +831,9 @@ __global__ __launch_bounds__(256) void k_estep_block(EstepArgs a, int C, int k_b
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const bool direct = a.direct != nullptr && *a.direct != 0u;  // (uniform) the guarded E-step runs direct: EstepArgs::direct
-    if (FAST && a.guard && direct) return;
-    const bool all_rows = !FAST && a.order_count != nullptr && direct;
-    if (a.order_count != nullptr && !all_rows && blockIdx.x >= *a.order_count) return;  // the exact redo of a guarded E-step: the queued barcodes only
-    const long long b = all_rows ? a.order_direct[blockIdx.x] : a.order[blockIdx.x];
+    if (FAST && guard_stand_back(a, k_base == 0)) return;  // the guarded E-step runs direct: EstepArgs::direct
+    if (a.order_count != nullptr && blockIdx.x >= *a.order_count) return;  // the exact redo of a guarded E-step: the queued barcodes only
+    const long long b = a.order[blockIdx.x];
     const int K = a.K, G = a.G;
     const int CS = C + 2;
     // LDS carve: sh_t [G*CS] f32 | keep [C] | floor [C] | row offsets [C]
@@ -958,7 +953,7 @@ __global__ __launch_bounds__(THREADS) void k_estep_pairblocks(EstepArgs a, int C
     constexpr int NO = R1 * R2;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    if (a.guard && a.direct != nullptr && *a.direct != 0u) return;  // the guarded E-step runs direct (EstepArgs::direct)
+    if (guard_stand_back(a, blk_base == 0)) return;  // the guarded E-step runs direct (EstepArgs::direct)
     const long long b = a.order[blockIdx.x];
     const int K = a.K, G = a.G;
     const int CS = C + 2;
@@ -1060,12 +1055,10 @@ __global__ __launch_bounds__(256) void k_softmax_rows(EstepArgs a)
     __shared__ float sh_guard[12];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     // rows: all B, or the barcodes the guarded pass queued (their number is known on the device only); a guarded E-step that
-    // runs direct (EstepArgs::direct): the pass after the fast option tiles stands back, the one after the exact tiles takes all rows
-    const bool direct = a.direct != nullptr && *a.direct != 0u;
-    if (a.guard == 1 && direct) return;
-    const bool all_rows = a.order_count != nullptr && direct;
-    if (a.order_count != nullptr && !all_rows && blockIdx.x >= *a.order_count) return;
-    const long long b = a.order_count != nullptr && !all_rows ? (long long)a.order[blockIdx.x] : (long long)blockIdx.x;
+    // runs direct (EstepArgs::direct): the pass after the fast option tiles stands back (the queue then holds every barcode)
+    if (a.guard == 1 && a.direct != nullptr && *a.direct != 0u) return;
+    if (a.order_count != nullptr && blockIdx.x >= *a.order_count) return;
+    const long long b = a.order_count != nullptr ? (long long)a.order[blockIdx.x] : (long long)blockIdx.x;
     const int K = a.K, G = a.G;
     const float *__restrict__ lg = a.logits + (size_t)b * K;
     float *post = a.post + (size_t)b * K;
@@ -1323,9 +1316,10 @@ __global__ __launch_bounds__(256) void k_mstep(MstepArgs a)
 // counters[0] = sum of the DENSE_SLOTS hashed counters the E-step epilogues add to (one address would serialise
 // 200k atomics: +0.65 ms measured); the slots are left at zero for the next E-step (a memset per E-step was two more
 // launches: 15 us of every EM iteration)
-__global__ __launch_bounds__(256) void k_sum_dense(unsigned long long *counters)
+__global__ __launch_bounds__(256) void k_sum_dense(unsigned long long *counters, unsigned *guard_state)
 {
     __shared__ unsigned long long part[4];
+    if (guard_state != nullptr && threadIdx.x == 0) guard_state[GS_T_END] = (unsigned)wall_clock64();  // the E-step's kernels are done
     unsigned long long s = 0;
     for (int i = threadIdx.x; i < DENSE_SLOTS; i += 256) {
         s += counters[1 + i];
@@ -1341,10 +1335,10 @@ __global__ __launch_bounds__(256) void k_sum_dense(unsigned long long *counters)
 }
 
 // Between two E-steps of the guarded mode: books the E-step that has finished (its queue length, or - run direct - what the
-// guard would have queued, summed from the hashed counters), and decides how the next one runs: direct after an E-step of
-// the same problem that queued more than 40 % of its barcodes, back to the fast pass after one below 30 % (kernels.h:
-// EstepArgs::direct).  One workgroup; replaces the memset of the queue length.
-__global__ __launch_bounds__(GUARD_SLOTS) void k_guard_begin(unsigned *st, unsigned B, int adaptive)
+// guard would have queued, summed from the hashed counters; the durations of its two passes from the stamps their kernels
+// left), and decides how the next one runs: direct when the fast pass + the exact redo of the queued share costs more than
+// the exact kernel over every barcode (kernels.h: EstepArgs::direct).  One workgroup; replaces the memset of the queue length.
+__global__ __launch_bounds__(GUARD_SLOTS) void k_guard_begin(unsigned *st, unsigned B, unsigned K, int adaptive)
 {
     __shared__ unsigned part[GUARD_SLOTS / 64];
     unsigned v = st[GS_WORDS + threadIdx.x];
@@ -1353,35 +1347,72 @@ __global__ __launch_bounds__(GUARD_SLOTS) void k_guard_begin(unsigned *st, unsig
     if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = v;
     __syncthreads();
     if (threadIdx.x != 0) return;
-    unsigned count = st[GS_COUNT];
-    for (int i = 0; i < GUARD_SLOTS / 64; i++) count += part[i];
     const unsigned was_direct = st[GS_DIRECT], rows = st[GS_ROWS];
+    unsigned count = was_direct ? 0u : st[GS_COUNT];  // (a direct E-step's queue holds every barcode; its count is on the slots)
+    for (int i = 0; i < GUARD_SLOTS / 64; i++) count += part[i];
     if (st[GS_PENDING]) {
         unsigned long long total = ((unsigned long long)st[GS_TOTAL + 1] << 32) | st[GS_TOTAL];
         total += was_direct ? rows : count;
         st[GS_TOTAL] = (unsigned)total;
         st[GS_TOTAL + 1] = (unsigned)(total >> 32);
     }
+    const bool same = st[GS_VALID] && rows == B && st[GS_K] == K;
+    if (!same) st[GS_F_TICKS] = st[GS_E_TICKS] = st[GS_E_MEASURED] = st[GS_O_TICKS] = 0u;
     unsigned direct = 0u;
-    if (adaptive && st[GS_VALID] && rows == B)
-        direct = was_direct ? (10ull * count > 3ull * B) : (10ull * count > 4ull * B);
+    if (same) {
+        // durations of the finished E-step's passes (32-bit wall clock differences: modular, intervals far below the wrap)
+        const unsigned d_fast = st[GS_T_REDO] - st[GS_T_FAST], d_redo = st[GS_T_END] - st[GS_T_REDO];
+        if (d_fast < (1u << 30) && d_redo < (1u << 30)) {
+            if (was_direct) {
+                st[GS_E_TICKS] = d_redo > 0u ? d_redo : 1u;
+                st[GS_E_MEASURED] = 1u;
+            } else {
+                st[GS_F_TICKS] = d_fast > 0u ? d_fast : 1u;
+                if (1000ull * count < rows) st[GS_O_TICKS] = d_redo;  // an (almost) empty queue: what the exact launch costs by itself
+                if (!st[GS_E_MEASURED] && 20ull * count >= rows) {  // the redo's time over its share of the barcodes
+                    const unsigned own = st[GS_O_TICKS];
+                    const double e = (double)(d_redo > own ? d_redo - own : 1u) * (double)rows / (double)count;
+                    st[GS_E_TICKS] = e < 1.0e9 ? (unsigned)e + 1u : 1000000000u;
+                }
+            }
+        }
+        const double F = (double)st[GS_F_TICKS], E = (double)st[GS_E_TICKS];
+        if (adaptive && F > 0.0 && E > 0.0) {
+            const double guarded = F + (double)count / (double)rows * E;  // against E for the direct run; 3 % of hysteresis
+            direct = was_direct ? (guarded > 0.97 * E) : (guarded > 1.03 * E);
+        }
+    }
     st[GS_DIRECT] = direct;
     st[GS_DIRECT_STEPS] += direct;
     st[GS_COUNT] = 0u;
     st[GS_ROWS] = B;
+    st[GS_K] = K;
     st[GS_VALID] = 1u;
     st[GS_PENDING] = 1u;
+    st[GS_T_FAST] = st[GS_T_REDO] = st[GS_T_END] = (unsigned)wall_clock64();
 }
 
-hipError_t launch_guard_begin(hipStream_t st, unsigned *state, long long B, int adaptive)
+hipError_t launch_guard_begin(hipStream_t st, unsigned *state, long long B, int K, int adaptive)
 {
-    hipLaunchKernelGGL(k_guard_begin, dim3(1), dim3(GUARD_SLOTS), 0, st, state, (unsigned)B, adaptive);
+    hipLaunchKernelGGL(k_guard_begin, dim3(1), dim3(GUARD_SLOTS), 0, st, state, (unsigned)B, (unsigned)K, adaptive);
     return hipGetLastError();
 }
 
-hipError_t launch_sum_dense(hipStream_t st, unsigned long long *counters)
+// The wall clock between two launches of a guarded E-step (GS_T_REDO between its fast and its exact pass, GS_T_END behind
+// them), as a kernel of its own: a store at the top of the E-step kernels themselves - thread 0 of block 0 stamping its
+// start - makes every load behind it "possibly clobbered", and the exact kernel's uniform loads (records, offsets) turned
+// from scalar into vector loads: +40 % on its time.
+__global__ void k_guard_stamp(unsigned *st, int which) { st[which] = (unsigned)wall_clock64(); }
+
+hipError_t launch_guard_stamp(hipStream_t st, unsigned *state, int which)
 {
-    hipLaunchKernelGGL(k_sum_dense, dim3(1), dim3(256), 0, st, counters);
+    hipLaunchKernelGGL(k_guard_stamp, dim3(1), dim3(1), 0, st, state, which);
+    return hipGetLastError();
+}
+
+hipError_t launch_sum_dense(hipStream_t st, unsigned long long *counters, unsigned *guard_state)
+{
+    hipLaunchKernelGGL(k_sum_dense, dim3(1), dim3(256), 0, st, counters, guard_state);
     return hipGetLastError();
 }
 

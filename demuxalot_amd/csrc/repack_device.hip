@@ -530,9 +530,13 @@ static int repack_core(dmx_ctx *c, Scratch &sc, const int *d_variant, const int 
 // Multi-GPU: M-step records by VARIANT SLICE (dmx_api.cpp: shard_mstep_by_variant).  Every rank's variant-major call
 // records travel once, at set-up; each rank keeps the calls of ITS variant slice - from the barcodes of all ranks, the
 // barcode a global row r * rows_per_rank + b - and derives from them what repack_core derives for the M-step: the
-// variant-major records, the work items and their length-sorted list.  The gathered buffer is rank-major and a rank's
-// records are variant-major with ascending barcodes, so the stable sort by variant leaves every variant's calls in
-// ascending GLOBAL barcode order: the reference's np.bincount order (demux.py:113-118) over the whole experiment.
+// variant-major records, the work items and their length-sorted list.  The gathered buffer is rank-major and the ranks hold
+// consecutive barcode ranges, so the stable sort by variant leaves every variant's calls rank after rank, each rank's in
+// its own input order.  PRECONDITION of the bit-identity with one GPU: inside a variant the caller's calls ascend by barcode -
+// what the reference's molecule_calls2barcode_calls (np.unique: demux.py:278-300), this library's packs and synth.py all
+// produce; the order is then the ascending GLOBAL barcode order, i.e. np.bincount's (demux.py:113-118) over the whole
+// experiment.  For calls handed to dmx_set_problem in another order one GPU sums a variant in the given order and n ranks
+// rank after rank: the same float64 terms in another order, a float32 rounding tie at most.
 // ------------------------------------------------------------------------------------
 namespace {
 // record of one call on the wire: {variant, global barcode row, bits of 1 - p_base_wrong, 1 (0: padding)}

@@ -737,10 +737,10 @@ int dmx_estep_snp(dmx_ctx *c, int with_doublets, const double *count_pow, int64_
 
 static int mstep_f64(dmx_ctx *c, double contribution_power, float *addition_out, double *sums_out)
 {
+    if (!c) return fail(DMX_ERR_INVALID, "null context");
     if (c->mshard)
         return fail(DMX_ERR_UNSUPPORTED, "the float64 M-step of aggregate_on_snps runs on a context without a communicator (its sums are added "
                                          "over the ranks by the caller: dmx_mstep_f64_sums)");
-    if (!c) return fail(DMX_ERR_INVALID, "null context");
     HIP_TRY(hipSetDevice(c->device));
     if (!c->have_problem || !c->have_post64) return fail(DMX_ERR_INVALID, "call order: dmx_estep_snp before dmx_mstep_f64");
     if (c->attached()) return fail(DMX_ERR_UNSUPPORTED, "the float64 M-step does not run the device-side exchange: barcode-sharded "

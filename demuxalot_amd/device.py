@@ -420,6 +420,25 @@ class DeviceContext:
         check(self._lib.dmx_get_guard_stats(self._h, ctypes.byref(last), ctypes.byref(total), ctypes.byref(rows)))
         return last.value, total.value, rows.value
 
+    def set_guard_adaptive(self, adaptive):
+        """Guarded mode: E-steps that follow one which queued more than 40 % of the barcodes run the exact kernel on every
+        barcode (default on; include/demux_hip.h: dmx_set_guard_adaptive)."""
+        check(self._lib.dmx_set_guard_adaptive(self._h, int(bool(adaptive))))
+
+    def guard_direct(self):
+        """(the last guarded E-step ran direct, E-steps run direct since reset_timings, barcodes the last one queued or -
+        direct - would have queued); include/demux_hip.h: dmx_get_guard_direct."""
+        return self.guard_state()[:3]
+
+    def guard_state(self):
+        """guard_direct() + the device's own timings of the two passes: (..., fast pass over all barcodes in ms, exact kernel
+        over all barcodes in ms; 0 = not known yet, negative = estimated from the redo's share, not yet measured)."""
+        last, steps, would = ctypes.c_int32(0), ctypes.c_int64(0), ctypes.c_int64(0)
+        fast_ms, exact_ms = ctypes.c_double(0), ctypes.c_double(0)
+        check(self._lib.dmx_get_guard_direct(self._h, ctypes.byref(last), ctypes.byref(steps), ctypes.byref(would),
+                                             ctypes.byref(fast_ms), ctypes.byref(exact_ms)))
+        return bool(last.value), steps.value, would.value, fast_ms.value, exact_ms.value
+
     def set_estep_dictionary(self, mode):
         """'never' | 'auto' (default: tried for genotype tables computed without a beta addition) | 'always' (tried for
         every E-step).  Bit-identical results in every mode; include/demux_hip.h: dmx_set_estep_dictionary."""
@@ -449,11 +468,21 @@ class DeviceContext:
         check(self._lib.dmx_set_mstep_wide_addresses(self._h, int(bool(wide))))
 
     def set_mstep_tiles(self, mode):
-        """Tile-major form of the M-step: 'never' | 'auto' (default: when building its records pays, i.e. from 16 M-steps on) |
+        """Tile-major form of the M-step: 'never' | 'auto' (default: when building its records pays, i.e. from 12 M-steps on) |
         'always' (at the first M-step); needs the exact additions off and G <= 64.  include/demux_hip.h: dmx_set_mstep_tiles."""
         if isinstance(mode, str):
             mode = {'never': 0, 'auto': 1, 'always': 2}[mode]
         check(self._lib.dmx_set_mstep_tiles(self._h, int(mode) if not isinstance(mode, bool) else (2 if mode else 0)))
+
+    def set_msteps_expected(self, n):
+        """Hint: about n more M-steps will run on the resident problem (include/demux_hip.h: dmx_set_msteps_expected)."""
+        check(self._lib.dmx_set_msteps_expected(self._h, int(n)))
+
+    def mstep_tiles_info(self):
+        """(the tile-major M-step records exist, host wall time of their build in ms)."""
+        built, ms = ctypes.c_int32(0), ctypes.c_double(0)
+        check(self._lib.dmx_get_mstep_tiles_info(self._h, ctypes.byref(built), ctypes.byref(ms)))
+        return bool(built.value), ms.value
 
     def mstep_form(self):
         """None | 'items' | 'tiles': the form of the last M-step launch (include/demux_hip.h: dmx_get_mstep_form)."""

@@ -66,9 +66,13 @@ class SyntheticProblem:
         return self.variant_id[keep], (self.compressed_cb[keep] - lo).astype(np.int32), self.p_base_wrong[keep]
 
 
-def make_genotype_betas(rng, n_snps, n_genotypes):
+def make_genotype_betas(rng, n_snps, n_genotypes, sibling_pairs=False):
     f = np.clip(rng.beta(0.5, 0.5, size=n_snps), 0.02, 0.98)
     dosage = rng.binomial(2, f[:, None], size=(n_snps, n_genotypes)).astype(np.int8)
+    if sibling_pairs:  # donors 2j and 2j + 1 carry the same genotype at half of the SNPs (related donors: hard to tell apart)
+        same = rng.random((n_snps, n_genotypes // 2)) < 0.5
+        odd = dosage[:, 1:2 * (n_genotypes // 2):2]
+        odd[same] = dosage[:, 0:2 * (n_genotypes // 2):2][same]
     betas = np.empty((2 * n_snps, n_genotypes), dtype=np.float32)
     betas[0::2] = 50.0 * (2 - dosage)
     betas[1::2] = 50.0 * dosage
@@ -134,13 +138,14 @@ def _generate_calls(rng, B, S, G, dosage, weights, calls_per_barcode, doublets, 
 
 
 def generate(n_barcodes, n_snps, n_genotypes, calls_per_barcode=400, doublets=False, seed=1234,
-             variant_major=True, seed_calls=None) -> SyntheticProblem:
+             variant_major=True, seed_calls=None, sibling_pairs=False) -> SyntheticProblem:
     """`seed` fixes the genotype table and SNP popularity; `seed_calls` (default: seed) fixes the
-    barcodes and their calls, so that several shards can share one genotype table."""
+    barcodes and their calls, so that several shards can share one genotype table.  `sibling_pairs`: donors 2j / 2j + 1
+    share their genotype at half of the SNPs (with few calls per barcode: the workload the guarded E-step can prove least of)."""
     rng = np.random.Generator(np.random.PCG64(seed))
     B, S, G = int(n_barcodes), int(n_snps), int(n_genotypes)
     V = 2 * S
-    betas, dosage = make_genotype_betas(rng, S, G)
+    betas, dosage = make_genotype_betas(rng, S, G, sibling_pairs)
     weights = rng.lognormal(0.0, 1.5, size=S)
     if seed_calls is not None and seed_calls != seed:
         rng = np.random.Generator(np.random.PCG64(seed_calls))

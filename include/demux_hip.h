@@ -161,14 +161,22 @@ int dmx_set_exact_additions(dmx_ctx *ctx, int exact);
 /* Number of (variant, genotype) sums the last exact-mode M-step redid in the reference's order (instrumentation). */
 int dmx_get_redo_count(dmx_ctx *ctx, int64_t *count);
 
-/* Tile-major form of the M-step (kernels.h: MTileArgs).  Possible when the exact additions are off (the sums are formed
- * in any order - float64, one rounding: a float32 rounding tie at most against the reference's order, and not
- * necessarily the same tie from run to run) and G <= 64: the M-step records are kept once more, sorted by (tile of <= 128
- * variants, barcode), +8 bytes per call.  Building them is a sort of the calls (4.1 ms on 200k x 100k x 64, where an
- * M-step then takes 0.46 instead of 0.69 ms), so
- *   1 (default) builds them when the running dmx_em / dmx_run_iterations call still has 16 M-steps to do, or the
- *     resident problem has seen 16;  2 at the first M-step;  0 never (the work-item form). */
+/* Tile-major form of the M-step (kernels.h: MTileArgs).  Possible when the exact additions are off, G <= 64 and
+ * contribution_power > 0: the M-step records are kept once more, sorted by (tile of <= 128 variants, barcode), +8 bytes per
+ * call, and the sums are formed in 64-bit FIXED POINT (every contribution, a float32 in [0, 1], added as the integer
+ * rint(c 2^s), s = 50 for all but the hottest tiles): independent of the order of the additions, so bit-reproducible from run
+ * to run like the reference's np.bincount (utils.py:35-36), exact for contributions of 2^-27 and more, and within one float32
+ * ulp + n 2^-(s + 1) (n calls of the variant) of the reference's float64 sum in general.  Building the records is a sort of
+ * the calls (4.1 ms on 200k x 100k x 64, where an M-step then takes 0.34 instead of 0.69 ms), so
+ *   1 (default) builds them at the first M-step that has 12 or more M-steps still to come - in the running dmx_em /
+ *     dmx_run_iterations call, or announced with dmx_set_msteps_expected -, or when the resident problem has seen 12;
+ *   2 at the first M-step;  0 never (the work-item form).
+ * dmx_set_msteps_expected: a hint - the caller will run about n more M-steps on the resident problem (a front-end that drives
+ * the iterations call by call, a benchmark that warms up first); counted down as M-steps run.
+ * dmx_get_mstep_tiles_info: whether the records exist and the host wall time their build took. */
 int dmx_set_mstep_tiles(dmx_ctx *ctx, int enable);
+int dmx_set_msteps_expected(dmx_ctx *ctx, int64_t n);
+int dmx_get_mstep_tiles_info(dmx_ctx *ctx, int32_t *built, double *build_ms);
 /* form of the last M-step launch: 0 none yet, 1 work items, 2 tiles (the dense regime's kernel may still have taken either) */
 int dmx_get_mstep_form(dmx_ctx *ctx, int32_t *form);
 
@@ -199,9 +207,29 @@ int dmx_get_mstep_form(dmx_ctx *ctx, int32_t *form);
 #define DMX_ESTEP_FAST 1
 #define DMX_ESTEP_GUARDED 2
 int dmx_set_estep_mode(dmx_ctx *ctx, int mode);
-/* Barcodes the guarded E-steps redid exactly: in the last E-step, and in all E-steps / out of how many barcode rows
- * since the context was created or dmx_reset_timings (instrumentation; any pointer may be NULL). */
+/* Barcodes the guarded E-steps computed with the exact kernel (the queued ones, or all of them in an E-step that ran direct:
+ * below): in the last E-step, and in all E-steps / out of how many barcode rows since the context was created or
+ * dmx_reset_timings (instrumentation; any pointer may be NULL). */
 int dmx_get_guard_stats(dmx_ctx *ctx, int64_t *redone_last, int64_t *redone_total, int64_t *rows_total);
+/* Worst case of the guarded mode.  With the fast pass taking F, the exact kernel over every barcode E, and a fraction f of the
+ * barcodes queued, a guarded E-step costs F + f E: more than the exact mode's E once f > 1 - F / E, and (F + E) / E on a
+ * workload where nothing can be proven.  F / E depends on the workload (0.56 at 200k x 100k x 64, 0.34 at 1M x 650k x 128 with
+ * doublets, above 1 on small problems), so the two passes are TIMED on the device (wall-clock stamps between the launches)
+ * and - adaptive = 1, the default - the E-step that follows one of the same resident problem and option
+ * table for which F + f E > E runs DIRECT: the fast kernels stand back and the exact kernel walks every barcode (results then
+ * bit-identical to the reference's on all of them), counting what the guard would have queued, so that the fast pass
+ * returns when it pays again (3 % of hysteresis).  Decided on the device between two E-steps, no host synchronisation.  E is
+ * first estimated from the redo's time over its share of the barcodes (only when that share is at least 5 %), then measured
+ * by the first direct E-step.  An iterated run is then never slower than the exact mode by more than one mispredicted
+ * E-step plus the fast kernels' launches standing back (~10 us per E-step); a single E-step (predict_posteriors) has no
+ * history and runs the fast pass + redo.  adaptive = 0: always the fast pass + redo.
+ * dmx_get_guard_direct: whether the last guarded E-step ran direct, how many did since dmx_reset_timings, the number of
+ * barcodes the last one queued (direct: would have queued), and the device's own timings: the fast pass over all barcodes
+ * and the exact kernel over all barcodes in ms (0: not known yet; negative: the estimate, not yet measured by a direct
+ * E-step); any pointer may be NULL. */
+int dmx_set_guard_adaptive(dmx_ctx *ctx, int adaptive);
+int dmx_get_guard_direct(dmx_ctx *ctx, int32_t *last_ran_direct, int64_t *direct_steps, int64_t *would_queue_last, double *fast_pass_ms,
+                         double *exact_pass_ms);
 
 /* E-step work distribution.  For singlet runs of 33..128 genotypes on at least 65 536 barcodes with a genotype table
  * of 8 MB or more, the problem upload also builds a tile-major schedule (bins of 8 barcodes with equal numbers of
@@ -371,7 +399,10 @@ int dmx_mstep_f64_sums(dmx_ctx *ctx, double contribution_power, double *sums_out
  *   per EM iteration, inside dmx_mstep / dmx_probs_from_betas / dmx_em / dmx_run_iterations:
  *     all-gather of what the M-step reads of a barcode (8-byte posterior code, bitmap, singlet posteriors)
  *     -> rank r sums slice r over ALL barcodes in the reference's order, float64, one rounding: the additions are
- *        bit-identical to a single-GPU run for any number of ranks - nothing is added across ranks -
+ *        bit-identical to a single-GPU run for any number of ranks - nothing is added across ranks - PROVIDED the calls of
+ *        every variant ascend by barcode in the caller's arrays (what the reference's np.unique, dmx_pack_* and pack_calls
+ *        produce); for calls in another order the n-rank sum takes a variant's calls rank after rank instead of in the
+ *        given order: the same float64 terms, a float32 rounding tie at most -
  *     -> P-step (demux.py:267-274) of slice r -> all-gather of the float32 genotype_prob slices.
  * That exchange moves 4 G + 8 + 8 ceil(G / 64) bytes per barcode OF THE WHOLE JOB.  When that is more than 1.25 x the
  * [V, G] partial sums (many more barcodes than variants: n x 200k-barcode weak scaling), the exchange of the sums is

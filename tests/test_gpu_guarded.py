@@ -223,3 +223,75 @@ def test_guarded_em_follows_the_exact_em(oracle):
     _last, total, rows = res['guarded'][3]
     assert rows == 4 * p.n_barcodes
     print(f'guarded EM: posteriors within {dev:.3g} of the exact run after 4 iterations, {total} of {rows} barcode rows redone exactly')
+
+
+@pytest.mark.parametrize('G,dp,B,cpb', [(64, 0., 30000, 300), (12, 0.3, 20000, 200), (24, 0.2, 4000, 60), (128, 0.25, 600, 40)])
+def test_guarded_mode_adapts_to_a_workload_it_cannot_prove(G, dp, B, cpb):
+    """Worst case of the default mode (include/demux_hip.h: dmx_set_guard_adaptive).  Genotypes in identical pairs: the two
+    best logits of every barcode tie, the guard can prove nothing, and the fast pass is wasted on every barcode.  The kernels
+    time their two passes on the device; after the first such E-step the next ones run DIRECT - the exact kernel on every
+    barcode, bit-identical to the exact mode - and keep counting what the guard would have queued.  Prior logits that settle
+    every barcode empty the queue again, and the fast pass returns when - by the device's own timings - it is the cheaper
+    way: every decision is checked against the rule F + f E > E (3 % of hysteresis) on the numbers the device reports.
+    The lane-per-option kernels (K = 64, and K = 78 with doublets) and the workgroup-per-barcode forms (K = 300, K = 8256)
+    all carry the switch.  Without the adaptation nothing ever runs direct."""
+    from demuxalot_amd import Demultiplexer, synth
+    from demuxalot_amd.device import DeviceContext
+    p = synth.generate(B, 2000, G, calls_per_barcode=cpb, doublets=dp > 0, seed=300 + G)
+    pen = Demultiplexer._doublet_penalties(G, dp)
+    K = len(pen)
+    block_shape = K > 1024 or (dp > 0 and K > 256)  # no guard with prior logits there: the exact mode runs
+    ctx = DeviceContext(0)
+    try:
+        ctx.set_estep_dictionary('never')
+        ctx.set_estep_packing('never')  # (the packed form is exact and runs unguarded)
+        ctx.set_problem(p.n_barcodes, p.n_variants, G, p.variant_id, p.compressed_cb, p.p_base_wrong, p.v2snp)
+        ctx.set_betas(p.prior_betas())
+        ctx.set_addition(None)
+        table = ctx.probs_from_betas(0.01).copy()
+        table[:, 1::2] = table[:, 0:2 * (G // 2):2]  # genotype 2j + 1 = genotype 2j
+        ctx.set_probs(table)
+        ctx.set_estep_mode('exact')
+        logits_e, probs_e = ctx.estep(pen, with_doublets=dp > 0)
+        rng = np.random.default_rng(5)
+        sharp = np.zeros((B, K), dtype=np.float32)
+        sharp[np.arange(B), rng.integers(0, G, size=B)] = 200.0  # prior logits that settle every barcode
+        if not block_shape:
+            logits_es, probs_es = ctx.estep(pen, with_doublets=dp > 0, prior_logits=sharp)
+        ctx.set_estep_mode('guarded')
+        ctx.reset_timings()
+        history = []
+        with_prior = (False, False, False) + ((True,) * 4 + (False, False) if not block_shape else (False,))
+        for step, prior in enumerate(with_prior):
+            logits_g, probs_g = ctx.estep(pen, with_doublets=dp > 0, prior_logits=sharp if prior else None)
+            direct, _steps, would, fast_ms, exact_ms = ctx.guard_state()
+            history.append((direct, would, fast_ms, exact_ms))
+            want_l, want_p = (logits_es, probs_es) if prior else (logits_e, probs_e)
+            check_contract(probs_g, want_p, f'step {step}')
+            if direct or not prior:  # (every barcode of the tied table is redone by the exact kernel either way)
+                fio.assert_bitwise(logits_g, want_l, f'step {step}: logits')
+                fio.assert_bitwise(probs_g, want_p, f'step {step}: posteriors')
+        assert history[0][0] is False and history[0][1] == B, history  # nothing could be proven
+        assert history[1][0] and history[2][0] and history[1][1] == B, history  # so the next E-steps ran direct, still counting
+        assert history[2][3] > 0, history  # ... and measured the exact kernel over all barcodes
+        for step in range(1, len(history)):  # every decision against the rule, on the device's own numbers
+            was_direct, queued = history[step - 1][0], history[step - 1][1]
+            fast_ms, exact_ms = history[step][2], abs(history[step][3])
+            if fast_ms > 0 and exact_ms > 0:
+                guarded_cost = fast_ms + queued / B * exact_ms
+                margin = 0.97 if was_direct else 1.03
+                if abs(guarded_cost / (margin * exact_ms) - 1) > 1e-3:
+                    assert history[step][0] == (guarded_cost > margin * exact_ms), (step, history)
+        if not block_shape:
+            assert history[3][1] < 0.05 * B, history  # the sharp prior leaves (almost) nothing to queue
+        last, total, rows = ctx.guard_stats()
+        assert rows == len(with_prior) * B and total == sum(B if d else w for d, w, _f, _e in history)
+        # adaptation off: the fast pass + redo every time
+        ctx.set_guard_adaptive(False)
+        for _ in range(3):
+            _l, probs_g = ctx.estep(pen, with_doublets=dp > 0)
+            assert ctx.guard_direct()[0] is False
+            check_contract(probs_g, probs_e, 'adaptation off')
+    finally:
+        ctx.close()
+    print(f'G={G} dp={dp}: (direct, queued or would-queue, fast pass ms, exact pass ms) per E-step {history}')

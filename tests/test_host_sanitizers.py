@@ -4,7 +4,7 @@
 GPU-side symbol replaced at link time by csrc/host_stubs.cpp (device memory is malloc memory, the kernels' launchers do
 nothing).  tests/sanitizer_driver.py then runs, in a subprocess that preloads the sanitizer runtime, a fuzz of
 dmx_pack_calls_host against the oracle, a fuzz of dmx_exchange_slices against its definition, whole runs of the context
-API on random problems (single, and with host-staged collectives of 2 .. 5 ranks, plain and chunked exchange) and the
+API on random problems (single, and with host-staged collectives of 2 .. 5 ranks, in every exchange mode) and the
 error contract that replaces the reference's asserts (demux.py:78,81,98,135,160,317,359,374).  Any sanitizer report
 aborts the subprocess.  Never runs on the GPU box (not a `gpu` test) and is never loaded by the product."""
 import os
