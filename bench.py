@@ -73,37 +73,85 @@ def algorithmic_bytes(B, V, G, K, N):
 # ---------------------------------------------------------------------------------------------------------
 # self-launch: `python bench.py --gpus N` with no launcher
 # ---------------------------------------------------------------------------------------------------------
+def phase(name):
+    """Where this rank is, for the watchdog of self_launch (one small file per rank; a no-op outside a self-launched run)."""
+    directory = os.environ.get('DEMUXALOT_BENCH_STATUS_DIR')
+    if not directory:
+        return
+    try:
+        with open(os.path.join(directory, f'rank{os.environ.get("RANK", "0")}'), 'w') as f:
+            f.write(f'{name} (since {time.strftime("%H:%M:%S")})')
+    except OSError:
+        pass
+    # test hook (tests/test_bench_watchdog_cpu.py): this rank stops here for good, as a rank hung in a collective would
+    if os.environ.get('DEMUXALOT_BENCH_STALL') == f'{os.environ.get("RANK", "0")}:{name}':
+        while True:
+            time.sleep(3600)
+
+
 def self_launch(args):
     """The parent of an N-rank run: it never touches the GPU (no HIP call, no library load) - it starts N fresh rank
     processes of this script with RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* set, relays rank 0's one JSON line, and
-    exits non-zero when any rank does."""
+    exits non-zero when any rank does.  WATCHDOG: the ranks report their phase in small files; when the deadline
+    (--deadline seconds for the whole run) passes, or a rank has died and the others do not follow within 30 s (they sit in a
+    rendezvous or a collective that will never complete), the parent kills the rank processes it started - those PIDs, nothing
+    else -, prints every rank's last phase and exits non-zero: the first real multi-rank RCCL run that hangs costs its
+    deadline, not the driver's."""
+    import shutil
     import socket
     import subprocess
+    import tempfile
     with socket.socket() as s:  # a free port NUMBER: the control plane's rendezvous is a file keyed by it
         s.bind(('127.0.0.1', 0))
         port = s.getsockname()[1]
+    status_dir = tempfile.mkdtemp(prefix='demuxalot_bench_status_')
     base = dict(os.environ, WORLD_SIZE=str(args.gpus), MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port),
-                TORCHELASTIC_RUN_ID=f'bench{os.getpid()}', HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get('HSA_ENABLE_IPC_MODE_LEGACY', '0'))
+                TORCHELASTIC_RUN_ID=f'bench{os.getpid()}', HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get('HSA_ENABLE_IPC_MODE_LEGACY', '0'),
+                DEMUXALOT_BENCH_STATUS_DIR=status_dir)
     procs = []
-    for rank in range(args.gpus):
-        env = dict(base, RANK=str(rank), LOCAL_RANK=str(rank))
-        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env, cwd=ROOT,
-                                      stdout=subprocess.PIPE if rank == 0 else subprocess.DEVNULL))
-    line, _ = procs[0].communicate()
-    codes = [procs[0].returncode]
-    deadline = time.monotonic() + 300
-    for pr in procs[1:]:
+    out_path = os.path.join(status_dir, 'rank0.stdout')
+    with open(out_path, 'wb') as rank0_out:
+        for rank in range(args.gpus):
+            env = dict(base, RANK=str(rank), LOCAL_RANK=str(rank))
+            procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env, cwd=ROOT,
+                                          stdout=rank0_out if rank == 0 else subprocess.DEVNULL))
+    deadline = time.monotonic() + args.deadline
+    first_death, verdict = None, None
+    while True:
+        codes = [pr.poll() for pr in procs]
+        if all(code is not None for code in codes):
+            break
+        now = time.monotonic()
+        if any(code not in (None, 0) for code in codes) and first_death is None:
+            first_death = now
+        if now > deadline:
+            verdict = f'deadline of {args.deadline:.0f} s passed'
+        elif first_death is not None and now > first_death + 30:
+            verdict = 'a rank failed and the others did not finish within 30 s'
+        if verdict:
+            break
+        time.sleep(0.2)
+    if verdict:
+        for pr in procs:  # exactly the processes started above
+            if pr.poll() is None:
+                pr.kill()
+        codes = [pr.wait() for pr in procs]
+
+    def last_phase(rank):
         try:
-            codes.append(pr.wait(timeout=max(1.0, deadline - time.monotonic())))
-        except subprocess.TimeoutExpired:
-            pr.kill()
-            codes.append(-9)
-    sys.stdout.write(line.decode(errors='replace'))
+            return open(os.path.join(status_dir, f'rank{rank}')).read()
+        except OSError:
+            return 'no phase reported (died before main, or never started)'
+    sys.stdout.write(open(out_path, 'rb').read().decode(errors='replace'))
     sys.stdout.flush()
-    if any(codes):
-        print(f'[bench] rank exit codes {codes}', file=sys.stderr, flush=True)
-        return 1
-    return 0
+    failed = verdict is not None or any(codes)
+    if failed:
+        print(f'[bench] {verdict or "a rank exited non-zero"}; exit codes {codes}', file=sys.stderr)
+        for rank in range(args.gpus):
+            print(f'[bench]   rank {rank}: exit code {codes[rank]}, last phase: {last_phase(rank)}', file=sys.stderr)
+        sys.stderr.flush()
+    shutil.rmtree(status_dir, ignore_errors=True)
+    return 1 if failed else 0
 
 
 # ---------------------------------------------------------------------------------------------------------
@@ -333,12 +381,23 @@ def e2e_timing(problem, doublet_prior, n_iterations=5):
         out = fn()
         return time.perf_counter() - t, out
 
+    def forget():  # what the front-end keeps between calls on the same inputs (demux.py: _pack_on_device): as for inputs never seen
+        from demuxalot_amd.device import get_context
+        get_context()._resident_key = None
+        genotypes._amd_variant_keys = None
+        handler._amd_index = None
+
+    forget()
     t_predict, (logits_df, probs_df) = timed(lambda: Demultiplexer.predict_posteriors(calls, genotypes, handler, doublet_prior=doublet_prior))
+    t_predict_again, _ = timed(lambda: Demultiplexer.predict_posteriors(calls, genotypes, handler, doublet_prior=doublet_prior))
+    t_learn_after, _ = timed(lambda: Demultiplexer.learn_genotypes(calls, genotypes, handler, n_iterations=n_iterations, doublet_prior=0.))
+    forget()
     t_predict_dev, dev = timed(lambda: Demultiplexer.predict_posteriors(calls, genotypes, handler, doublet_prior=doublet_prior, on_device=True))
     t_assign_dev, assigned = timed(lambda: dev.assignments(0.9))
     t_assign_host, assigned_host = timed(lambda: probs_df[probs_df.max(axis=1).gt(0.9)].idxmax(axis=1))
     same = bool(assigned.index.equals(assigned_host.index) and (assigned.values == assigned_host.values).all())
     dev.close()
+    forget()
     t_learn, (_learnt, last_df) = timed(lambda: Demultiplexer.learn_genotypes(calls, genotypes, handler, n_iterations=n_iterations, doublet_prior=0.))
     t_learn_dev, (_learnt2, dev2) = timed(lambda: Demultiplexer.learn_genotypes(calls, genotypes, handler, n_iterations=n_iterations, doublet_prior=0., on_device=True))
     dev2.close()
@@ -361,6 +420,7 @@ def e2e_timing(problem, doublet_prior, n_iterations=5):
     return {
         'workload_molecule_calls': n_molecule_calls, 'barcodes': B,
         'predict_posteriors_s': t_predict, 'predict_barcodes_per_s': B / t_predict,
+        'predict_posteriors_same_inputs_again_s': t_predict_again, f'learn_genotypes_{n_iterations}it_after_predict_s': t_learn_after,
         'predict_posteriors_on_device_s': t_predict_dev, 'predict_on_device_barcodes_per_s': B / t_predict_dev,
         'assignments_on_device_s': t_assign_dev, 'assignments_with_pandas_s': t_assign_host, 'assignments_identical': same,
         f'learn_genotypes_{n_iterations}it_s': t_learn, f'learn_genotypes_{n_iterations}it_on_device_s': t_learn_dev,
@@ -368,50 +428,62 @@ def e2e_timing(problem, doublet_prior, n_iterations=5):
                     'two_dataframes': t_frames, f'em_{n_iterations}_iterations_fused': t_em},
         'build_objects_s (synthetic generator, not part of a call)': t_objects,
         'note': 'wall time of the Python entry points on the containers of the whole workload (one molecule per call); the reference '
-                'spends ~3.5-4 us per molecule call in pack_calls alone (SURVEY.md 8a9)',
+                'spends ~3.5-4 us per molecule call in pack_calls alone (SURVEY.md 8a9).  predict_posteriors_s / learn_genotypes_*_s: inputs '
+                'the front-end has not seen (warm context); *_again / *_after_predict: the same containers and genotypes again - the packed '
+                'problem is still resident, the key arrays of var2varid are kept on the genotypes object',
     }
 
 
-def hard_workload(args, ctx, install_problem, pen, dp):
-    """The default mode's worst case next to the exact mode on the SAME shape (include/demux_hip.h: dmx_set_guard_adaptive):
-    50 calls per barcode instead of 400 and donors in sibling pairs, so that most barcodes keep some posterior between 0.03
-    and 0.97 and the guarded E-step can prove little.  Three timed regions on the resident hard problem: the default mode
-    (adaptive: after the first E-step the exact kernel runs on every barcode), the same with the adaptation off (fast pass
-    + exact redo of the queued barcodes every time), and the exact mode."""
+def hard_workload(args, ctx, whole, betas, pen, dp):
+    """The default mode's worst cases next to the exact mode on the SAME shape (include/demux_hip.h: dmx_set_guard_adaptive).
+    `siblings_50_calls`: 50 calls per barcode instead of 400 and donors in sibling pairs (half of the SNPs identical), so
+    that a fifth of the barcodes keep some posterior between 0.03 and 0.97.  `identical_twins`: the workload's own calls
+    on a genotype table whose donors 2j and 2j + 1 are identical - the two best logits of EVERY barcode tie, the guard can
+    prove nothing, the fast pass is wasted on all of them: the worst case there is.  Three timed regions each: the default
+    mode (adaptive: E-steps for which fast pass + redo costs more than the exact kernel run it on every barcode), the
+    same with the adaptation off (fast pass + exact redo of the queued barcodes every time), and the exact mode."""
     from demuxalot_amd import synth
     B, S, G, _dp, seed = WORKLOADS[args.workload]
     t0 = time.perf_counter()
-    problem = synth.generate(B, S, G, calls_per_barcode=50, doublets=dp > 0, seed=seed + 5000, sibling_pairs=True)
+    siblings = synth.generate(B, S, G, calls_per_barcode=50, doublets=dp > 0, seed=seed + 5000, sibling_pairs=True)
     t_gen = time.perf_counter() - t0
-    install_problem(problem)
-    out = {'calls': problem.n_calls, 'calls_per_barcode': 50, 'sibling_pairs': True, 'generated_s': t_gen}
-    for name, mode, adaptive in (('default', None, True), ('default_without_adaptation', None, False), ('exact', 'exact', True)):
-        ctx.apply_environment()
-        if mode:
-            ctx.set_estep_mode(mode)
-            ctx.set_exact_additions(True)
-        ctx.set_guard_adaptive(adaptive)
-        ctx.set_addition(None)
-        ctx.probs_from_betas(0.01, fetch=False)
-        ctx.set_estep_dictionary('never')  # (the first pass of an EM run takes the dictionary form: exact in every mode)
-        ctx.estep(pen, with_doublets=dp > 0, fetch_logits=False, fetch_probs=False)
-        first_queued = ctx.guard_state()[2]
-        if args.mstep == 'auto':
-            ctx.set_msteps_expected(args.warmup + args.steps)
-        region = timed_region(ctx, None, args.steps, args.warmup)
-        _direct, direct_steps, would, fast_ms, exact_ms = ctx.guard_state()
-        out[name] = {'ms_per_step': region['ms_per_step'], 'kernel_ms': region['kernel_ms'], 'guard': region['guard'],
-                     'first_estep_queued_fraction': first_queued / B, 'esteps_run_direct': direct_steps, 'steps': args.steps,
-                     'last_estep_would_queue_fraction': would / B,
-                     'device_timed_ms': {'fast_pass_all_barcodes': fast_ms, 'exact_kernel_all_barcodes': abs(exact_ms),
-                                         'exact_kernel_measured_by_a_direct_estep': exact_ms > 0}}
+    twins = betas.copy()
+    twins[:, 1:2 * (G // 2):2] = twins[:, 0:2 * (G // 2):2]
+    out = {}
+    for variant, problem, table in (('siblings_50_calls', siblings, siblings.prior_betas(add_data_prior=False)), ('identical_twins', whole, twins)):
+        ctx.set_problem(problem.n_barcodes, problem.n_variants, G, problem.variant_id, problem.compressed_cb, problem.p_base_wrong, problem.v2snp)
+        ctx.set_betas(table)
+        res = {'calls': problem.n_calls}
+        for name, mode, adaptive in (('default', None, True), ('default_without_adaptation', None, False), ('exact', 'exact', True)):
+            ctx.apply_environment()
+            if mode:
+                ctx.set_estep_mode(mode)
+                ctx.set_exact_additions(True)
+            ctx.set_guard_adaptive(adaptive)
+            ctx.set_addition(None)
+            ctx.probs_from_betas(0.01, fetch=False)
+            ctx.set_estep_dictionary('never')  # (the first pass of an EM run takes the dictionary form: exact in every mode)
+            ctx.estep(pen, with_doublets=dp > 0, fetch_logits=False, fetch_probs=False)
+            first_queued = ctx.guard_state()[2]
+            if args.mstep == 'auto':
+                ctx.set_msteps_expected(args.warmup + args.steps)
+            region = timed_region(ctx, None, args.steps, args.warmup)
+            _direct, direct_steps, would, fast_ms, exact_ms = ctx.guard_state()
+            res[name] = {'ms_per_step': region['ms_per_step'], 'kernel_ms': region['kernel_ms'], 'guard': region['guard'],
+                         'first_estep_queued_fraction': first_queued / problem.n_barcodes, 'esteps_run_direct': direct_steps, 'steps': args.steps,
+                         'last_estep_would_queue_fraction': would / problem.n_barcodes,
+                         'device_timed_ms': {'fast_pass_all_barcodes': fast_ms, 'exact_kernel_all_barcodes': abs(exact_ms),
+                                             'exact_kernel_measured_by_a_direct_estep': exact_ms > 0}}
+        res['default_over_exact'] = res['default']['ms_per_step'] / res['exact']['ms_per_step']
+        res['estep_default_over_exact'] = res['default']['kernel_ms']['estep'] / res['exact']['kernel_ms']['estep']
+        out[variant] = res
+    out['siblings_50_calls'].update(calls_per_barcode=50, sibling_pairs=True, generated_s=t_gen)
     ctx.set_estep_dictionary('auto')
     ctx.set_guard_adaptive(True)
     ctx.apply_environment()
-    out['default_over_exact'] = out['default']['ms_per_step'] / out['exact']['ms_per_step']
-    out['note'] = ('guarded E-step = fast pass F + exact redo of the queued fraction f = F + f E against the exact kernel\'s E; the kernels time both '
-                   'passes on the device and E-steps for which F + f E > E run the exact kernel on every barcode (bit-identical to the '
-                   'reference there): include/demux_hip.h dmx_set_guard_adaptive')
+    out['note'] = ('guarded E-step = fast pass F + exact redo of the queued fraction f = F + f E against the exact kernel\'s E; both passes are timed '
+                   'on the device and E-steps for which F + f E > E run the exact kernel on every barcode (bit-identical to the reference '
+                   'there): include/demux_hip.h dmx_set_guard_adaptive')
     return out
 
 
@@ -466,6 +538,9 @@ def main():
                          'iterations knows) and builds the tile-major records at the first M-step when 12 or more are to come; the build then '
                          'falls into the warm-up and the line reports it (mstep_records_build_ms, ms_per_step_incl_record_build).  tiles / '
                          'items: the form forced')
+    ap.add_argument('--deadline', type=float, default=1500.0,
+                    help='N > 1 without a launcher: seconds after which the parent kills the rank processes it started, reports every '
+                         'rank\'s last phase and exits non-zero (a rank hung in a collective must not cost the caller its own limit)')
     ap.add_argument('--timed-only', action='store_true', help='the timed region of the default mode only (profiler child runs)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-exact-mode', action='store_true', help='skip the second timed region (bit-exact E-step and additions)')
@@ -498,6 +573,7 @@ def main():
 
     rank = int(os.environ.get('RANK', '0'))
     world = int(os.environ.get('WORLD_SIZE', '1'))
+    phase('start')
     if args.reduce_dtype == 'auto':
         args.reduce_dtype = 'f64' if os.environ.get('DEMUXALOT_AMD_ESTEP', '') == 'exact' else 'f32'
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
@@ -511,6 +587,7 @@ def main():
     use_dist = world > 1 or args.force_dist
     if use_dist:
         from demuxalot_amd.plane import SocketControlPlane
+        phase('control plane rendezvous')
         plane = SocketControlPlane(rank, world, os.environ.get('MASTER_ADDR', '127.0.0.1'), host_collectives=args.host_plane)
 
     from demuxalot_amd import Demultiplexer
@@ -518,6 +595,7 @@ def main():
     from demuxalot_amd.device import DeviceContext
 
     B_workload, S, G, dp, _seed = WORKLOADS[args.workload]
+    phase('generating / loading the experiment')
     whole, t_gen, problem_source = get_problem(args, rank, world, plane)
     betas = whole.prior_betas(add_data_prior=False)  # identical on every rank
     if args.flat_genotypes:
@@ -526,6 +604,7 @@ def main():
     pen = Demultiplexer._doublet_penalties(G, dp)
     K = len(pen)
 
+    phase('creating the device context')
     ctx = DeviceContext(local_rank % max(1, _lib_device_count()))
     default_mode = os.environ.get('DEMUXALOT_AMD_ESTEP', '') or dmx_device.DEFAULT_ESTEP_MODE
     runtimes, rccl_fallback = None, None
@@ -534,6 +613,7 @@ def main():
     elif use_dist:
         # RCCL communicator; when creating it fails on some rank (no usable fabric, library missing), every rank learns
         # so over the control plane and the run goes on with the exchange staged through host memory - said in the line
+        phase('RCCL communicator (ncclCommInitRank)')
         unique_id, why = None, ''
         if rank == 0:
             try:
@@ -589,6 +669,7 @@ def main():
     problem = whole
     for kind in kinds:
         problem = shard_of(whole, rank, world) if (kind == 'strong' and world > 1) else whole
+        phase(f'{kind}: installing the problem (set-up collectives)')
         t_up += install(problem)
         keep_first = world == 1 and not args.timed_only
         ctx.estep(pen, with_doublets=dp > 0, fetch_logits=False, fetch_probs=False)  # fixes the options
@@ -598,6 +679,7 @@ def main():
             best0 = ctx.get_assignments()[0]
         if args.mstep == 'auto':
             ctx.set_msteps_expected(args.warmup + args.steps)
+        phase(f'{kind}: warm-up + timed region (per-iteration collectives)')
         region = timed_region(ctx, plane, args.steps, args.warmup)
         built, build_ms = ctx.mstep_tiles_info()
         region['mstep_records_build_ms'] = build_ms if built else 0.0
@@ -614,6 +696,7 @@ def main():
     extra_modes = {}
     wanted = ([] if args.no_exact_mode or default_mode == 'exact' else ['exact']) + (['fast'] if args.fast_mode else [])
     for mode in wanted:
+        phase(f'{mode} mode: timed region')
         ctx.set_estep_mode(mode)
         ctx.set_exact_additions(mode == 'exact')
         ctx.set_addition(None)
@@ -676,12 +759,9 @@ def main():
                            'building the dictionary; where the dictionary form runs the pass is bit-identical to the reference in every mode but `fast`')
 
     hard = None
-    if world == 1 and not args.no_hard_workload and not args.flat_genotypes:
-        def install_hard(hard_problem):
-            ctx.set_problem(hard_problem.n_barcodes, hard_problem.n_variants, G, hard_problem.variant_id, hard_problem.compressed_cb,
-                            hard_problem.p_base_wrong, hard_problem.v2snp)
-            ctx.set_betas(hard_problem.prior_betas(add_data_prior=False))
-        hard = hard_workload(args, ctx, install_hard, pen, dp)
+    if world == 1 and not args.no_hard_workload and not args.flat_genotypes and N <= 200_000_000:
+        phase('hard workloads')
+        hard = hard_workload(args, ctx, whole, betas, pen, dp)
 
     if rank == 0:
         ab = algorithmic_bytes(B, V, G, K, N)
@@ -771,12 +851,14 @@ def main():
             out['cpu_baseline'] = None
         sys.stdout.flush()
         os.write(json_fd, (json.dumps(out) + '\n').encode())
+    phase('final barrier')
     if plane is not None:
         plane.barrier()
         if rank == 0 and world > 1 and not os.environ.get('DEMUXALOT_BENCH_PROBLEM'):
             import shutil
             shutil.rmtree(shared_directory(), ignore_errors=True)
         plane.close()
+    phase('done')
 
 
 if __name__ == '__main__':

@@ -494,8 +494,10 @@ void release_problem(dmx_ctx *c)
     dev_free(c, &c->d_seg_sums, c->cap_seg_sums);
     c->cap_seg_sums = 0;
     c->n_segs = c->n_split = 0;
-    dev_free(c, &c->d_guard_count, (size_t)dmx::GS_WORDS + dmx::GUARD_SLOTS);
+    dev_free(c, &c->d_guard_count, (size_t)dmx::GUARD_STATE_WORDS);
     dev_free(c, &c->d_guard_list, (size_t)c->B);
+    dev_free(c, &c->d_guard_sub, (size_t)dmx::GUARD_QUEUES * c->guard_sub_cap);
+    c->guard_sub_cap = 0;
     c->guard_rows_total = 0;
     c->guard_ran = false;
     dev_free(c, &c->d_dict, c->cap_dict_rows * dmx::DICT_CAP);
@@ -1173,6 +1175,8 @@ int run_estep(dmx_ctx *c, int with_doublets, bool with_prior, int prior_dtype, f
     a.guard = 0;
     a.guard_count = c->d_guard_count;
     a.guard_list = c->d_guard_list;
+    a.guard_sub = c->d_guard_sub;
+    a.guard_sub_cap = c->guard_sub_cap;
     a.order_count = nullptr;
     a.direct = nullptr;
     a.order_direct = nullptr;
@@ -1241,7 +1245,7 @@ int run_estep(dmx_ctx *c, int with_doublets, bool with_prior, int prior_dtype, f
             a.direct = c->d_guard_count + dmx::GS_DIRECT;
             a.order_direct = c->d_bc_order;
             HIP_TRY(dmx::launch_estep(c->stream, a, with_doublets != 0));
-            HIP_TRY(dmx::launch_guard_stamp(c->stream, c->d_guard_count, dmx::GS_T_REDO));
+            HIP_TRY(dmx::launch_guard_compact(c->stream, c->d_guard_count, c->d_guard_sub, c->guard_sub_cap, c->d_guard_list));
             dmx::EstepArgs redo = a;
             redo.fast = 0;
             redo.guard = 2;
@@ -1569,9 +1573,11 @@ static int finish_problem(dmx_ctx *c, const int32_t *v2snp, const std::vector<in
     DMX_TRY(dev_alloc(c, &c->d_nz, (size_t)B * ((G + 63) / 64)));
     DMX_TRY(dev_alloc(c, &c->d_first, (size_t)B));
     DMX_TRY(dev_alloc(c, &c->d_dense_calls, (size_t)1 + dmx::DENSE_SLOTS));
-    DMX_TRY(dev_alloc(c, &c->d_guard_count, (size_t)dmx::GS_WORDS + dmx::GUARD_SLOTS));
+    DMX_TRY(dev_alloc(c, &c->d_guard_count, (size_t)dmx::GUARD_STATE_WORDS));
     DMX_TRY(dev_alloc(c, &c->d_guard_list, (size_t)B));
-    HIP_TRY(hipMemsetAsync(c->d_guard_count, 0, (dmx::GS_WORDS + dmx::GUARD_SLOTS) * sizeof(unsigned), c->stream));
+    c->guard_sub_cap = (unsigned)((B + dmx::GUARD_QUEUES - 1) / dmx::GUARD_QUEUES);
+    DMX_TRY(dev_alloc(c, &c->d_guard_sub, (size_t)dmx::GUARD_QUEUES * c->guard_sub_cap));
+    HIP_TRY(hipMemsetAsync(c->d_guard_count, 0, dmx::GUARD_STATE_WORDS * sizeof(unsigned), c->stream));
     HIP_TRY(hipMemsetAsync(c->d_dense_calls, 0, sizeof(unsigned long long) * (1 + dmx::DENSE_SLOTS), c->stream));
     DMX_TRY(dev_alloc(c, &c->d_best, (size_t)B));
     DMX_TRY(dev_alloc(c, &c->d_bestp, (size_t)B));
@@ -1716,7 +1722,7 @@ int dmx_set_estep_mode(dmx_ctx *c, int mode)
 
 static int read_guard_state(dmx_ctx *c, unsigned (&st)[dmx::GS_WORDS], long long *count)
 {
-    std::vector<unsigned> all((size_t)dmx::GS_WORDS + dmx::GUARD_SLOTS, 0u);
+    std::vector<unsigned> all((size_t)dmx::GUARD_STATE_WORDS, 0u);
     if (c->d_guard_count) {
         HIP_TRY(hipMemcpyAsync(all.data(), c->d_guard_count, all.size() * sizeof(unsigned), hipMemcpyDeviceToHost, c->stream));
         HIP_TRY(hipStreamSynchronize(c->stream));

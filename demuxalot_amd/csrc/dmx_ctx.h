@@ -73,12 +73,13 @@ struct dmx_ctx {
     size_t cap_redo = 0;
     bool mstep_wide = false;  // dmx_set_mstep_wide_addresses
     // tile-major M-step (kernels.hip: k_mstep_tiles; built on first use by build_mstep_tiles, n_mt == 0: not built / not eligible)
-    uint2 *d_mt_stream = nullptr;   // [n_csc] the M-step records once more, sorted by (variant tile, barcode row): x = row | variant in tile << 24
+    uint2 *d_mt_stream = nullptr;   // [n_mt_stream] the M-step records once more, sorted by (variant tile, barcode row): x = row | variant in tile << 24
     long long *d_mt_ptr = nullptr;  // [n_mt + 1] first record of every tile
     int *d_mt_first = nullptr;      // [n_mt + 1] first variant of every tile
     int *d_mt_order = nullptr;      // [n_mt] tiles by decreasing number of calls
     int *d_mt_shift = nullptr;      // [n_mt] fixed-point exponent of every tile (MTileArgs::shift)
     long long n_mt = 0;
+    long long n_mt_stream = 0;      // records d_mt_stream holds room for (the calls; with the padding calls' slots when built from the barcode-major records)
     int mt_tv = 0;                  // variants per tile at most
     bool mt_tried = false;          // a build was attempted for the resident M-step records
     int mstep_tiles = 1;            // dmx_set_mstep_tiles: 0 never, 1 when building the records pays, 2 always
@@ -95,9 +96,11 @@ struct dmx_ctx {
     bool exact_additions = true;  // dmx_set_exact_additions
     int estep_mode = DMX_ESTEP_EXACT;  // dmx_set_estep_mode
     // guarded mode: barcodes queued by the epilogues of the fast kernels for the exact redo (kernels.h: EstepArgs::guard)
-    unsigned *d_guard_count = nullptr;  // [GS_WORDS + GUARD_SLOTS] device state of the guarded mode (kernels.h: GS_*)
+    unsigned *d_guard_count = nullptr;  // [GUARD_STATE_WORDS] device state of the guarded mode (kernels.h: GS_*)
     int guard_adaptive = 1;             // dmx_set_guard_adaptive: E-steps after one that queued > 40 % of the barcodes run the exact kernel directly
-    int *d_guard_list = nullptr;        // [B]
+    int *d_guard_list = nullptr;        // [B] EstepArgs::guard_list
+    int *d_guard_sub = nullptr;         // [GUARD_QUEUES x guard_sub_cap] EstepArgs::guard_sub
+    unsigned guard_sub_cap = 0;
     long long guard_rows_total = 0;     // barcode rows the guarded kernels have walked since the last reset
     bool guard_ran = false;             // the last E-step evaluated the guard
     int tiled_estep = 1;               // dmx_set_estep_schedule: 0 never, 1 when it pays, 2 whenever the repack built one

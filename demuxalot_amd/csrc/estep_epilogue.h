@@ -252,13 +252,18 @@ static __device__ __forceinline__ bool estep_guard(const float (&dev)[A], const 
     return close != 1 || (L == 64 ? any_bad : (any_bad >> gbase) & group_mask<L>()) != 0ull;
 }
 
-// The guard's bookkeeping for one barcode (lane `writer` of its lane group acts): queued for the exact redo (a.guard == 1), or -
-// in the exact kernels of an E-step that runs direct (a.guard == 2) - only counted, on hashed counters (200k atomics on one
-// address took 0.65 ms; k_guard_begin adds the slots up).
+// The guard's bookkeeping for one barcode (one lane of its lane group acts): queued for the exact redo (a.guard == 1: appended to
+// the sub-queue of its residue class, k_guard_compact makes the dense list of them), or - in the exact kernels of an E-step
+// that runs direct (a.guard == 2) - only counted, on hashed counters (200k atomics on one address took 0.65 ms;
+// k_guard_begin adds the slots up).
 static __device__ __forceinline__ void guard_note(const EstepArgs &a, long long b, bool counting)
 {
-    if (counting) atomicAdd(a.guard_count + GS_WORDS + (int)(b & (GUARD_SLOTS - 1)), 1u);
-    else a.guard_list[atomicAdd(a.guard_count + GS_COUNT, 1u)] = (int)b;
+    if (counting) {
+        atomicAdd(a.guard_count + GS_WORDS + (int)(b & (GUARD_SLOTS - 1)), 1u);
+    } else {
+        const unsigned q = (unsigned)(b & (GUARD_QUEUES - 1));  // (at most ceil(B / GUARD_QUEUES) barcodes share a queue)
+        a.guard_sub[(size_t)q * a.guard_sub_cap + atomicAdd(a.guard_count + GS_WORDS + GUARD_SLOTS + q, 1u)] = (int)b;
+    }
 }
 // A fast kernel of a guarded E-step that runs direct (kernels.h: EstepArgs::direct) stands back - and, on its way out, its
 // first launch turns the queue into the list of ALL barcodes (longest rows first), so that the exact launch behind it walks

@@ -70,7 +70,9 @@ struct EstepArgs {
                                 // 2: the exact kernels of a guarded E-step: when the E-step runs DIRECT (below) the guard is evaluated on
                                 //    their own results and the barcodes that would have been queued are only counted
     unsigned *guard_count;      // the guard's device state (GuardState below): [GS_COUNT] barcodes queued (direct: that would have been) by this E-step
-    int *guard_list;            // [B] the queued barcodes
+    int *guard_list;            // [B] the queued barcodes, dense (what the exact launch walks): written by k_guard_compact
+    int *guard_sub;             // [GUARD_QUEUES x guard_sub_cap] the sub-queues the guard appends to: barcode b -> queue b % GUARD_QUEUES (one
+    unsigned guard_sub_cap;     //   queue counter took ~5 ns per append - 0.2 ms of a 0.5 ms fast pass that queued 19 % of 200k barcodes)
     const unsigned *order_count;  // nullable: `order` holds *order_count entries (<= B), known on the device only (the exact
                                   // redo of the queued barcodes: k_estep_direct over guard_list)
     // Adaptive guarded mode.  With the fast pass taking F, the exact kernel over every barcode E and a fraction f of the
@@ -138,7 +140,12 @@ enum { GS_COUNT = 0,         // barcodes queued by the current E-step (a direct 
        GS_O_TICKS = 14,      // duration of the exact launch on an empty queue
        GS_K = 15,            // option count of the finished E-step (another K: F and E start over)
        GS_WORDS = 16 };
-constexpr int GUARD_SLOTS = 256;  // hashed counters behind the state words (counts of a direct E-step)
+constexpr int GUARD_SLOTS = 256;   // hashed counters behind the state words (counts of a direct E-step)
+constexpr int GUARD_QUEUES = 256;  // ... and behind those the lengths of the sub-queues (EstepArgs::guard_sub)
+constexpr int GUARD_STATE_WORDS = GS_WORDS + GUARD_SLOTS + GUARD_QUEUES;
+// between the fast launches and the exact launch of a guarded E-step: the sub-queues become the dense list, GS_COUNT their total
+// length, GS_T_REDO the wall clock (a direct E-step: the clock alone - the fast kernels have listed every barcode)
+hipError_t launch_guard_compact(hipStream_t st, unsigned *state, const int *sub, unsigned sub_cap, int *list);
 hipError_t launch_guard_begin(hipStream_t st, unsigned *state, long long B, int K, int adaptive);
 hipError_t launch_guard_stamp(hipStream_t st, unsigned *state, int which);  // state[which] = the device's wall clock (GS_T_REDO, GS_T_END)
 

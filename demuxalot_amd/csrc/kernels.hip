@@ -292,6 +292,18 @@ static __device__ __forceinline__ void pair_row_products(const PairRowBatch<H, N
 struct FastBatch {
     npm::f32x2 p[4];  // gathered genotype probabilities of the batch's 8 calls (call 2q in .x, 2q+1 in .y)
 };
+// Experiment knobs of the row gathers (make EXPERIMENTS=1 CXXEXTRA="-DDMX_ROW_AUX=2"; profiles/r5_estep_gather_experiments.txt):
+//   DMX_ROW_AUX       cache-policy bits of the gathers' buffer loads: 0 default, 2 nt, 16 sc1, 17 sc0 sc1 (the last three bypass the L1)
+//   DMX_GATHER_DEPTH  batches of 8 gathers a wavefront keeps in flight + 1 (4: the shipped pipeline)
+#ifndef DMX_ROW_AUX
+#define DMX_ROW_AUX 0
+#endif
+#ifndef DMX_GATHER_DEPTH
+#define DMX_GATHER_DEPTH 4
+#endif
+#ifndef DMX_PAIRBLOCK_SERIAL_PRODUCT
+#define DMX_PAIRBLOCK_SERIAL_PRODUCT 0  // 1: k_estep_pairblocks multiplies the two terms of a pair of calls one after the other (until round 5)
+#endif
 
 // HALF (tables of 17 .. 32 genotypes): a 256-byte gather holds the rows of TWO calls - lanes 0 .. 31 take the even call of
 // a pair, lanes 32 .. 63 the odd one (the row offset, keep and floor of a lane's call selected per half with v_cndmask) -,
@@ -322,10 +334,10 @@ static __device__ __forceinline__ void fast_walk_single(const CallPair *__restri
         for (int q = 0; q < 4; q++) {
             const uint2 ro = *(const uint2 *)(rec + 8 * q);
             if constexpr (HALF) {
-                g.p[q].x = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, (int)(lane_off + (hi ? ro.y : ro.x)), 0, 0));
+                g.p[q].x = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, (int)(lane_off + (hi ? ro.y : ro.x)), 0, DMX_ROW_AUX));
             } else {
-                g.p[q].x = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, (int)(lane_off + ro.x), 0, 0));
-                g.p[q].y = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, (int)(lane_off + ro.y), 0, 0));
+                g.p[q].x = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, (int)(lane_off + ro.x), 0, DMX_ROW_AUX));
+                g.p[q].y = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, (int)(lane_off + ro.y), 0, DMX_ROW_AUX));
             }
         }
     };
@@ -351,6 +363,35 @@ static __device__ __forceinline__ void fast_walk_single(const CallPair *__restri
         facc.mant += (double)__builtin_amdgcn_logf(m);
         prod = 1.0f;
     };
+#if DMX_GATHER_DEPTH != 4
+    {   // the same pipeline with a ring of DMX_GATHER_DEPTH batches (experiment builds; `ring` holds that many record slots)
+        constexpr int D = DMX_GATHER_DEPTH;
+        int w[D];
+        FastBatch g[D];
+#pragma unroll
+        for (int j = 0; j < D; j++) w[j] = fetch(j);
+#pragma unroll
+        for (int j = 0; j < D - 1; j++) {
+            issue(w[j], g[j], j);
+            w[j] = fetch(D + j);
+        }
+        for (int k = 0; k < n_batches; k += D) {
+            bool done = false;
+#pragma unroll
+            for (int u = 0; u < D; u++) {
+                if (done) continue;
+                constexpr int dummy = 0;
+                (void)dummy;
+                const int slot = (u + D - 1) % D;
+                issue(w[slot], g[slot], slot);
+                w[slot] = fetch(k + u + 2 * D - 1);
+                consume(k + u, g[u], u);
+                done = k + u + 1 >= n_batches;
+            }
+        }
+        return;
+    }
+#endif
     // records of batches k+4 .. k+7 on their way, gathers of batches k+1 .. k+3 in flight while batch k is consumed;
     // the loop is unrolled by 4 so that every ring slot is a fixed register (and a fixed LDS slot)
     int w0 = fetch(0), w1 = fetch(1), w2 = fetch(2), w3 = fetch(3);
@@ -706,7 +747,7 @@ __global__ __launch_bounds__(256) void k_estep_tiled(EstepArgs a)
 {
     static_assert(!HALF || (A == 1 && FAST), "two calls per gather: tolerance arithmetic, tables of at most 32 genotypes");
     __shared__ double sh_acc[4][TILE_R_MAX][A][64];
-    __shared__ unsigned sh_rec[4][4 * 32];  // fast_walk_single: four batches of records per wavefront
+    __shared__ unsigned sh_rec[4][DMX_GATHER_DEPTH * 32];  // fast_walk_single: four batches of records per wavefront
     const int lane = threadIdx.x & 63;
     const int K = a.K;
     const int R = a.bin_rows_cap;
@@ -974,12 +1015,15 @@ __global__ __launch_bounds__(THREADS) void k_estep_pairblocks(EstepArgs a, int C
     for (int y = 0; y < R2; y++) r2[y] = (unsigned)min(g2_0 + y, G - 1) * (unsigned)CS;
     double acc[NO];
     int acc_e[NO];
-    float prod[NO];
+    // running product of the terms since the last flush, the even calls in .x and the odd ones in .y: ONE packed multiplication
+    // per pair of calls (v_pk_mul_f32) instead of two dependent ones; the halves are multiplied when the 8 terms are flushed -
+    // the same seven roundings per 8 terms in another association (the guard's bound counts roundings, not their order)
+    npm::f32x2 prod[NO];
 #pragma unroll
     for (int o = 0; o < NO; o++) {
         acc[o] = 0.0;
         acc_e[o] = 0;
-        prod[o] = 1.0f;
+        prod[o] = npm::f32x2{1.0f, 1.0f};
     }
     const unsigned *__restrict__ words = (const unsigned *)(a.pairs + a.pair_ptr[b]);
     const int n_calls = 2 * (int)(a.pair_ptr[b + 1] - a.pair_ptr[b]);  // incl. neutral padding, multiple of 8
@@ -1015,11 +1059,16 @@ __global__ __launch_bounds__(THREADS) void k_estep_pairblocks(EstepArgs a, int C
                     npm::f32x2 t = (pa[x] + pb[y]) * keep2;
                     t = t + flo2;
                     const int o = R2 * x + y;
-                    prod[o] = (prod[o] * t.x) * t.y;
+#if DMX_PAIRBLOCK_SERIAL_PRODUCT
+                    prod[o].x = (prod[o].x * t.x) * t.y;
+#else
+                    prod[o] = prod[o] * t;
+#endif
                     if ((c & 7) == 6) {
-                        acc_e[o] += __builtin_amdgcn_frexp_expf(prod[o]);
-                        acc[o] += (double)__builtin_amdgcn_logf(__builtin_amdgcn_frexp_mantf(prod[o]));
-                        prod[o] = 1.0f;
+                        const float whole = prod[o].x * prod[o].y;
+                        acc_e[o] += __builtin_amdgcn_frexp_expf(whole);
+                        acc[o] += (double)__builtin_amdgcn_logf(__builtin_amdgcn_frexp_mantf(whole));
+                        prod[o] = npm::f32x2{1.0f, 1.0f};
                     }
                 }
         }
@@ -1340,9 +1389,11 @@ __global__ __launch_bounds__(256) void k_sum_dense(unsigned long long *counters,
 // the exact kernel over every barcode (kernels.h: EstepArgs::direct).  One workgroup; replaces the memset of the queue length.
 __global__ __launch_bounds__(GUARD_SLOTS) void k_guard_begin(unsigned *st, unsigned B, unsigned K, int adaptive)
 {
+    static_assert(GUARD_QUEUES == GUARD_SLOTS, "one thread per slot and per sub-queue");
     __shared__ unsigned part[GUARD_SLOTS / 64];
     unsigned v = st[GS_WORDS + threadIdx.x];
     st[GS_WORDS + threadIdx.x] = 0u;
+    st[GS_WORDS + GUARD_SLOTS + threadIdx.x] = 0u;  // the sub-queues of the coming E-step are empty
     for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off);
     if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = v;
     __syncthreads();
@@ -1395,6 +1446,42 @@ __global__ __launch_bounds__(GUARD_SLOTS) void k_guard_begin(unsigned *st, unsig
 hipError_t launch_guard_begin(hipStream_t st, unsigned *state, long long B, int K, int adaptive)
 {
     hipLaunchKernelGGL(k_guard_begin, dim3(1), dim3(GUARD_SLOTS), 0, st, state, (unsigned)B, (unsigned)K, adaptive);
+    return hipGetLastError();
+}
+
+// Between the fast launches and the exact launch of a guarded E-step: block q copies sub-queue q behind the sub-queues before
+// it (their lengths added up by every block for itself: 256 words), block 0 leaves the total and the wall clock.
+__global__ __launch_bounds__(256) void k_guard_compact(unsigned *st, const int *__restrict__ sub, unsigned cap, int *__restrict__ list)
+{
+    __shared__ unsigned before[4], all[4];
+    const unsigned q = blockIdx.x;
+    if (st[GS_DIRECT] != 0u) {  // (uniform) the fast kernels stood back and listed every barcode
+        if (q == 0 && threadIdx.x == 0) st[GS_T_REDO] = (unsigned)wall_clock64();
+        return;
+    }
+    const unsigned len = st[GS_WORDS + GUARD_SLOTS + threadIdx.x];  // GUARD_QUEUES == 256 threads
+    unsigned lo = threadIdx.x < q ? len : 0u, total = len;
+    for (int off = 32; off > 0; off >>= 1) {
+        lo += __shfl_down(lo, off);
+        total += __shfl_down(total, off);
+    }
+    if ((threadIdx.x & 63) == 0) {
+        before[threadIdx.x >> 6] = lo;
+        all[threadIdx.x >> 6] = total;
+    }
+    __syncthreads();
+    const unsigned offset = before[0] + before[1] + before[2] + before[3];
+    const unsigned mine = st[GS_WORDS + GUARD_SLOTS + q];
+    for (unsigned i = threadIdx.x; i < mine; i += 256) list[offset + i] = sub[(size_t)q * cap + i];
+    if (q == 0 && threadIdx.x == 0) {
+        st[GS_COUNT] = all[0] + all[1] + all[2] + all[3];
+        st[GS_T_REDO] = (unsigned)wall_clock64();
+    }
+}
+
+hipError_t launch_guard_compact(hipStream_t st, unsigned *state, const int *sub, unsigned sub_cap, int *list)
+{
+    hipLaunchKernelGGL(k_guard_compact, dim3(GUARD_QUEUES), dim3(256), 0, st, state, sub, sub_cap, list);
     return hipGetLastError();
 }
 

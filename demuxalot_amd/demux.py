@@ -90,6 +90,56 @@ def _variant_keys(genotypes, columns=_UNSET):
     return (var_chrom, var_pos, var_base), chrom_index
 
 
+def _var2varid_fingerprint(var2varid):
+    """Identity of a (chrom, pos, base) -> row dict cheap enough to take on every call: the object, its length, its first
+    and last entries (dicts keep insertion order and the importers only ever append: genotypes.py extend_variants)."""
+    n = len(var2varid)
+    if n == 0:
+        return id(var2varid), 0
+    return id(var2varid), n, next(iter(var2varid.items())), next(reversed(var2varid.items()))
+
+
+def _cached_variant_keys(genotypes):
+    """(fingerprint, v2snp, (var_chrom, var_pos, var_base), chromosome -> index) of a genotypes object.  Walking var2varid is
+    30 ms for 200k variants - a third of a predict_posteriors call on 78 M calls - and predict -> learn -> predict on the
+    same genotypes (examples/2-with-detection-of-new-SNPs.ipynb cells 12 / 16-18, tests/test_synthetic.py:184-190) walked it
+    every time: the arrays are kept on the object, keyed by the fingerprint of its var2varid (assigning another dict, or
+    adding variants, invalidates them).  A mapping edited in place at unchanged length, first and last entry is not
+    detected: set `genotypes._amd_variant_keys = None` after such surgery."""
+    from .genotypes import ProbabilisticGenotypes, snp_ids_from_columns, variant_columns
+    own_numbering = getattr(type(genotypes), 'get_snp_ids_for_variants', None) is ProbabilisticGenotypes.get_snp_ids_for_variants
+    fingerprint = (_var2varid_fingerprint(genotypes.var2varid), genotypes.n_variants, own_numbering)
+    cached = getattr(genotypes, '_amd_variant_keys', None)
+    if cached is not None and cached[0] == fingerprint:
+        return cached
+    columns = variant_columns(genotypes.var2varid)  # one walk of var2varid for the SNP numbering and the row keys
+    if own_numbering and columns is not None:
+        v2snp = snp_ids_from_columns(columns)
+    else:
+        v2snp = genotypes.get_snp_ids_for_variants()
+    assert np.all(v2snp >= 0)
+    keys, chrom_index = _variant_keys(genotypes, columns)
+    cached = (fingerprint, v2snp, keys, chrom_index)
+    try:
+        genotypes._amd_variant_keys = cached
+    except AttributeError:  # an object that takes no attributes: nothing is kept
+        pass
+    return cached
+
+
+def _sampled_checksum(records):
+    """crc32 of the head, the tail and ~512 strided records of a record array: what tells an array edited in place from
+    the one a device problem was packed from, at a cost of microseconds."""
+    import zlib
+    n = len(records)
+    if n == 0:
+        return 0
+    flat = np.ascontiguousarray(records).view(np.uint8).reshape(-1)
+    crc = zlib.crc32(flat[:4096].tobytes())
+    crc = zlib.crc32(flat[-4096:].tobytes(), crc)
+    return zlib.crc32(np.ascontiguousarray(records[::max(1, n // 512)]).view(np.uint8).tobytes(), crc)
+
+
 def _flatten_inputs(chromosome2compressed_snp_calls, genotypes, want_molecule_table):
     """var2varid -> per-row key arrays; per-chromosome call containers -> flat call arrays."""
     (var_chrom, var_pos, var_base), chrom_index = _variant_keys(genotypes)
@@ -201,13 +251,25 @@ def _pack_on_device(chromosome2compressed_snp_calls, genotypes, n_barcodes, add_
     context (the caller holds shared_context_lock).  `reduce_molecule_counts` (barcode-sharded runs): maps this
     shard's molecule counts per variant to the counts of the whole experiment, which the data term of the
     prior is made of (demux.py:381-384)."""
-    from .genotypes import ProbabilisticGenotypes, snp_ids_from_columns, variant_columns
     from .snp_counter import MOLECULE_DTYPE, SNP_CALL_DTYPE
-    columns, v2snp = _UNSET, None
     if ctx is None:
         ctx = get_context()
+    shared = bool(getattr(ctx, '_is_shared', False))  # the process-wide context (its users hold shared_context_lock)
     containers = list(chromosome2compressed_snp_calls.values())
-    if all(c.snp_calls.dtype == SNP_CALL_DTYPE and c.molecules.dtype == MOLECULE_DTYPE for c in containers):
+    raw = all(c.snp_calls.dtype == SNP_CALL_DTYPE and c.molecules.dtype == MOLECULE_DTYPE for c in containers)
+    # The packed problem stays resident on the shared context: predict_posteriors followed by learn_genotypes on the same
+    # containers and genotypes (the reference's own usage pattern, see _cached_variant_keys) packs once.  Key: identity +
+    # length counters + a sampled checksum of every container's arrays, the fingerprint of var2varid, the shape.
+    key = None
+    if shared and raw and reduce_molecule_counts is None:
+        key = (tuple((chrom, id(c.snp_calls), id(c.molecules), int(c.n_snp_calls), int(c.n_molecules),
+                      _sampled_checksum(c.snp_calls[:c.n_snp_calls]), _sampled_checksum(c.molecules[:c.n_molecules]))
+                     for chrom, c in chromosome2compressed_snp_calls.items()),
+               _var2varid_fingerprint(genotypes.var2varid), genotypes.n_variants, genotypes.n_genotypes, int(n_barcodes),
+               bool(getattr(ctx, '_keep_molecule_calls', False)))
+    if key is not None and getattr(ctx, '_resident_key', None) == key:
+        molecules = None  # (the counts per variant are on the device: dmx_set_prior_betas takes them from there)
+    elif raw:
         # The containers' packed records go to the GPU as they are and are taken apart there - and they go FIRST, in a
         # second thread (the upload is one foreign call, which releases the interpreter), while this one walks
         # var2varid: 45 ms of upload next to 30 ms of walk for 78.65 M calls and 200 k variants.
@@ -226,12 +288,7 @@ def _pack_on_device(chromosome2compressed_snp_calls, genotypes, n_barcodes, add_
         worker = threading.Thread(target=stage)
         worker.start()
         try:
-            if columns is _UNSET and getattr(type(genotypes), 'get_snp_ids_for_variants', None) is ProbabilisticGenotypes.get_snp_ids_for_variants:
-                columns = variant_columns(genotypes.var2varid)  # one walk of var2varid for the SNP numbering and the row keys
-            if v2snp is None:
-                v2snp = snp_ids_from_columns(columns) if columns is not _UNSET and columns is not None else genotypes.get_snp_ids_for_variants()
-                assert np.all(v2snp >= 0)
-            (var_chrom, var_pos, var_base), chrom_index = _variant_keys(genotypes, columns)
+            _fp, v2snp, (var_chrom, var_pos, var_base), chrom_index = _cached_variant_keys(genotypes)
         except BaseException:
             worker.join()
             if not failure:  # the worker did stage them (~17 bytes per call on the GPU): give them back before unwinding
@@ -250,6 +307,7 @@ def _pack_on_device(chromosome2compressed_snp_calls, genotypes, n_barcodes, add_
             chrom_of_container.append(chrom_index.get(chrom, -1))
         _m, _u, molecules = ctx.pack_staged_and_set_problem(n_barcodes, genotypes.n_genotypes, var_chrom, var_pos, var_base, v2snp,
                                                             chrom_of_container)
+        ctx._resident_key = key
     else:
         v2snp = genotypes.get_snp_ids_for_variants()
         assert np.all(v2snp >= 0)
@@ -264,6 +322,23 @@ def _pack_on_device(chromosome2compressed_snp_calls, genotypes, n_barcodes, add_
     betas = ctx.set_prior_betas(genotypes.get_betas(), genotypes.default_prior, add_data_prior,
                                 mol_per_variant=molecules, fetch=fetch_betas)
     return ctx, betas
+
+
+def _barcode_index(barcode_handler, name=None):
+    """pd.Index of barcode_handler.ordered_barcodes (200k strings: ~4 ms to build, per frame), kept on the handler and
+    shared by the frames of later calls (an Index is immutable; every frame gets its own shallow copy with its name)."""
+    barcodes = barcode_handler.ordered_barcodes
+    fingerprint = (id(barcodes), len(barcodes), barcodes[0] if len(barcodes) else None, barcodes[-1] if len(barcodes) else None)
+    cached = getattr(barcode_handler, '_amd_index', None)
+    if cached is None or cached[0] != fingerprint:
+        cached = (fingerprint, pd.Index(list(barcodes)))
+        try:
+            barcode_handler._amd_index = cached
+        except AttributeError:
+            pass
+    index = cached[1].copy()
+    index.name = name
+    return index
 
 
 def _option_names(genotype_names, doublet_prior):
@@ -417,7 +492,7 @@ class Demultiplexer:
                 n_iterations, p_genotype_clip, penalties, with_doublets=doublet_prior != 0,
                 prior_logits=barcode_prior_logits, contribution_power=Demultiplexer.contribution_power,
                 fetch_logits=False)
-        probs_df = pd.DataFrame(data=probs, index=barcode_handler.ordered_barcodes, columns=column_names)
+        probs_df = pd.DataFrame(data=probs, index=_barcode_index(barcode_handler), columns=column_names)
         learnt_genotypes = genotypes._with_betas(genotypes.get_betas() + addition)
         return learnt_genotypes, probs_df
 
@@ -522,9 +597,8 @@ class Demultiplexer:
         with shared_context_lock:
             logits, probs = run(get_context(), True)
 
-        index = pd.Index(list(barcode_handler.ordered_barcodes), name='BARCODE')  # built once: 200k strings take ~4 ms
-        logits_df = pd.DataFrame(data=logits, index=index, columns=column_names)
-        probs_df = pd.DataFrame(data=probs, index=index.copy(), columns=column_names)  # own Index object, shared labels
+        logits_df = pd.DataFrame(data=logits, index=_barcode_index(barcode_handler, 'BARCODE'), columns=column_names)
+        probs_df = pd.DataFrame(data=probs, index=_barcode_index(barcode_handler, 'BARCODE'), columns=column_names)  # own Index object, shared labels
         return logits_df, probs_df
 
     # ------------------------------------------------------------------------------------

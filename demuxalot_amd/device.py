@@ -27,6 +27,8 @@ class DeviceContext:
         self.device = int(device)
         self.B = self.V = self.G = self.N = 0
         self.K = 0
+        self._resident_key = None
+        self._keep_molecule_calls = False
         self.apply_environment()
 
     def apply_environment(self):
@@ -66,6 +68,7 @@ class DeviceContext:
 
     # ---- problem ----------------------------------------------------------------------
     def set_problem(self, n_barcodes, n_variants, n_genotypes, variant_id, compressed_cb, p_base_wrong, v2snp):
+        self._resident_key = None  # (demux.py: _pack_on_device keeps the packed problem of the shared context across calls)
         variant_id = as_c(variant_id, np.int32)
         compressed_cb = as_c(compressed_cb, np.int32)
         p_base_wrong = as_c(p_base_wrong, np.float32)
@@ -80,6 +83,7 @@ class DeviceContext:
                              call_chrom, call_pos, call_base, call_cb, call_p):
         """Device pack (variant matching + de-duplication, demux.py:276-300, 332-365) installed directly as
         the resident problem. Returns (n_matched, n_unique, molecules per variant)."""
+        self._resident_key = None  # (demux.py: _pack_on_device keeps the packed problem of the shared context across calls)
         var_chrom, var_pos, var_base = as_c(var_chrom, np.int32), as_c(var_pos, np.int32), as_c(var_base, np.uint8)
         v2snp = as_c(v2snp, np.int32)
         call_chrom, call_pos = as_c(call_chrom, np.int32), as_c(call_pos, np.int32)
@@ -114,6 +118,7 @@ class DeviceContext:
         """pack_and_set_problem fed with the raw record arrays of the call containers:
         `containers` = [(chromosome index, snp_calls[:n] (SNP_CALL_DTYPE), molecules[:m] (MOLECULE_DTYPE))].
         The field extraction and the molecule -> barcode lookup happen on the GPU."""
+        self._resident_key = None  # (demux.py: _pack_on_device keeps the packed problem of the shared context across calls)
         var_chrom, var_pos, var_base = as_c(var_chrom, np.int32), as_c(var_pos, np.int32), as_c(var_base, np.uint8)
         v2snp = as_c(v2snp, np.int32)
         n_variants = len(var_pos)
@@ -132,12 +137,14 @@ class DeviceContext:
         """First half of pack_containers_and_set_problem: upload + field extraction of the containers' records, which
         needs nothing of the genotypes (`containers` as there, the chromosome index provisional: the position in the
         list).  The resident problem stays as it is.  include/demux_hip.h: dmx_stage_containers."""
+        self._resident_key = None  # (demux.py: _pack_on_device keeps the packed problem of the shared context across calls)
         parts, _keep_alive = self._container_list(containers)
         check(self._lib.dmx_stage_containers(self._h, ctypes.cast(parts, ctypes.c_void_p), len(containers)))
 
     def pack_staged_and_set_problem(self, n_barcodes, n_genotypes, var_chrom, var_pos, var_base, v2snp, chrom_of_container):
         """Second half: variant matching, de-duplication and layouts on the staged calls.  chrom_of_container[k] = the
         chromosome index (numbering of var_chrom) of the k-th staged container, -1 when no variant lies on it."""
+        self._resident_key = None  # (demux.py: _pack_on_device keeps the packed problem of the shared context across calls)
         var_chrom, var_pos, var_base = as_c(var_chrom, np.int32), as_c(var_pos, np.int32), as_c(var_base, np.uint8)
         v2snp = as_c(v2snp, np.int32)
         table = as_c(chrom_of_container, np.int32)
@@ -293,9 +300,11 @@ class DeviceContext:
 
     # ---- aggregate_on_snps (demux.py:204-244) --------------------------------------------------------
     def set_keep_molecule_calls(self, keep):
+        self._keep_molecule_calls = bool(keep)
         check(self._lib.dmx_set_keep_molecule_calls(self._h, int(bool(keep))))
 
     def set_molecule_calls(self, variant_id, compressed_cb, p_base_wrong):
+        self._resident_key = None  # (demux.py: _pack_on_device keeps the packed problem of the shared context across calls)
         variant_id, compressed_cb = as_c(variant_id, np.int32), as_c(compressed_cb, np.int32)
         p_base_wrong = as_c(p_base_wrong, np.float32)
         assert len(variant_id) == len(compressed_cb) == len(p_base_wrong)
@@ -520,6 +529,7 @@ class DeviceContext:
     def release_problem(self):
         """The resident problem (and any staged containers) back into this context's block cache
         (include/demux_hip.h: dmx_release_problem)."""
+        self._resident_key = None  # (demux.py: _pack_on_device keeps the packed problem of the shared context across calls)
         check(self._lib.dmx_release_problem(self._h))
         self.B = self.V = self.G = self.N = self.K = 0
 
@@ -586,6 +596,7 @@ def get_context(device=None) -> DeviceContext:
     with _contexts_lock:
         if device not in _contexts:
             _contexts[device] = DeviceContext(device)
+            _contexts[device]._is_shared = True  # (demux.py: _pack_on_device keeps its packed problem across calls)
         return _contexts[device]
 
 

@@ -239,8 +239,17 @@ class ProbabilisticGenotypes:
                 out.var2varid = dict(value)
             elif name == 'variant_betas':
                 out.variant_betas = value.copy() if with_betas else None
+            elif name == '_amd_variant_keys':
+                continue  # (below)
             else:
                 setattr(out, name, deepcopy(value))
+        # the key arrays the front-end keeps on the object (demux.py: _cached_variant_keys) describe the copy's mapping as
+        # well - same entries, same order -: handed over under the copy's fingerprint, so that predict_posteriors on learnt
+        # genotypes does not walk var2varid again
+        cached = self.__dict__.get('_amd_variant_keys')
+        if cached is not None and cached[0][0][0] == id(self.var2varid) and cached[0][0][1] == len(self.var2varid):
+            fingerprint = ((id(out.var2varid),) + tuple(cached[0][0][1:]),) + tuple(cached[0][1:])
+            out._amd_variant_keys = (fingerprint,) + tuple(cached[1:])
         return out
 
     # ---- checkpoint format of learnt genotypes (parquet) ---------------------------------

@@ -1,7 +1,9 @@
-# Doublet tolerance E-step with whole-row loads (configs[1]): PMC passes of the timed iterations; GPU box: bash scripts/pmc_doublet_rows.sh
+# Tile-major tolerance E-step (and tile-major M-step): PMC passes of the timed iterations; GPU box: bash scripts/pmc_estep_tiled.sh [workload] [variant]
 cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
 WL=${1:-em_200k_100k_64}
-OUT=gpurun_out/estep_tiled_$WL
+VARIANT=${2:-base}   # base | aux16 | depth6 ...: build/variants/libdemux_hip_<variant>.so (scripts/gather_experiments.sh)
+[ $VARIANT != base ] && export DEMUXALOT_AMD_LIB=$GRAFT_REPO_ROOT/build/variants/libdemux_hip_$VARIANT.so
+OUT=gpurun_out/estep_tiled_${WL}_$VARIANT
 mkdir -p $OUT
 run() { name=$1; shift; timeout 300 rocprofv3 --kernel-trace --pmc "$@" --output-format csv -d $OUT/pmc_$name -- python3 bench.py --workload $WL --steps 10 --warmup 2 --timed-only > $OUT/pmc_$name.log 2>&1; }
 run sq1 SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY

@@ -231,7 +231,9 @@ def test_config3_and_config2_guarded_mode_proves_the_contract(oracle, request, G
         table_rows, v = np.unique(v, return_inverse=True)
         want = oracle.barcode_logits(v, cb, e, prob[table_rows], hi - lo, 0., log_impl='npsimd')
         check_contract(probs_g[lo:hi], oracle.softmax_rows(want, impl='npsimd'), f'guarded rows [{lo},{hi}) vs oracle')
-    assert np.allclose(addition_g, addition_exact, rtol=1e-3, atol=1e-4)
+    # same table, posteriors within 1e-5: an addition entry may differ by 1e-5 (2 + 1e-5) per call of the variant (+ float32 roundings)
+    n_calls = np.bincount(p.variant_id, minlength=p.n_variants).astype(np.float64)[:, None]
+    assert (np.abs(addition_g.astype(np.float64) - addition_exact) <= n_calls * 2.00001e-5 + 2.0 ** -22 * addition_exact).all()
     print(f'guarded mode at 200k x 100k x {G}: posteriors within {dev:.3g} of the exact mode, {redone} of {p.n_barcodes} barcodes redone exactly')
 
 
