@@ -478,6 +478,7 @@ void release_problem(dmx_ctx *c)
     c->slice_rows = c->prob_rows = 0;
     c->cut.clear();
     c->h_v2snp.clear();
+    c->h_col_ptr.clear();
     dev_free(c, &c->d_partial, (size_t)c->n_items * c->G);
     dev_free(c, &c->d_redo, c->cap_redo);
     dev_free(c, &c->d_n_redo, (size_t)2);
@@ -1173,6 +1174,7 @@ int run_estep(dmx_ctx *c, int with_doublets, bool with_prior, int prior_dtype, f
     const bool guarded = c->estep_mode == DMX_ESTEP_GUARDED && !(block_shape && with_prior);
     a.fast = c->estep_mode == DMX_ESTEP_FAST || guarded;
     a.guard = 0;
+    a.guard_per_call = 7.0e-8f;  // estep_epilogue.h: GUARD_PER_CALL (launch_estep raises it for the form with pre-scaled rows)
     a.guard_count = c->d_guard_count;
     a.guard_list = c->d_guard_list;
     a.guard_sub = c->d_guard_sub;
@@ -1349,11 +1351,11 @@ int run_mstep(dmx_ctx *c, float power)
     // tile-major form (kernels.h: MTileArgs): sums in any order, so not with the exact additions; built on first use
     a.tiles_done = false;
     dmx::MTileArgs tiles{};
-    // Building the records (a sort of the calls: 4.1 ms on 200k x 100k x 64, where an M-step then takes 0.34 instead of
-    // 0.69 ms) pays from MSTEP_TILES_PAY M-steps on: taken when that many are still to come - in the running dmx_em /
+    // Building the records (a sort of the calls: 3.0 ms on 200k x 100k x 64, where an M-step + combine then takes 0.34 instead of
+    // 0.70 ms) pays from MSTEP_TILES_PAY M-steps on: taken when that many are still to come - in the running dmx_em /
     // dmx_run_iterations call, or as the caller announced (dmx_set_msteps_expected) -, or the problem has seen that many
     // already (somebody iterates call by call), or always (dmx_set_mstep_tiles(ctx, 2)).
-    constexpr int MSTEP_TILES_PAY = 12;
+    constexpr int MSTEP_TILES_PAY = 9;
     const long long ahead = std::max<long long>(c->msteps_ahead, c->msteps_expected);
     const bool tiles_wanted = c->mstep_tiles == 2 || (c->mstep_tiles == 1 && (c->n_mt > 0 || ahead >= MSTEP_TILES_PAY ||
                                                                              c->msteps_done >= MSTEP_TILES_PAY));

@@ -79,6 +79,7 @@ struct dmx_ctx {
     int *d_mt_order = nullptr;      // [n_mt] tiles by decreasing number of calls
     int *d_mt_shift = nullptr;      // [n_mt] fixed-point exponent of every tile (MTileArgs::shift)
     long long n_mt = 0;
+    std::vector<long long> h_col_ptr;  // [V + 1] first M-step record of every variant (host copy made by the repack: the tiles are cut from it)
     long long n_mt_stream = 0;      // records d_mt_stream holds room for (the calls; with the padding calls' slots when built from the barcode-major records)
     int mt_tv = 0;                  // variants per tile at most
     bool mt_tried = false;          // a build was attempted for the resident M-step records

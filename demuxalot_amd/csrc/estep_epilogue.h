@@ -218,6 +218,13 @@ static __device__ __forceinline__ unsigned long long group_mask()
 constexpr float GUARD_RHO = 3.0e-7f;
 constexpr float GUARD_POSITIVE_TERM = 2.1e-4f;
 constexpr float GUARD_PER_CALL = 7.0e-8f;
+// k_estep_pairblocks stages the rows PRE-SCALED, u_g = p_g (keep / 2), and forms a term as (u_g1 + u_g2) + floor: two packed
+// additions where (p_g1 + p_g2) (keep / 2) + floor takes an addition, a multiplication and an addition (the kernel is VALU-bound:
+// 85 % busy, profiles/r5_pmc_pairblocks.txt).  That is no longer the reference's own float32 term: u_g1, u_g2 and their sum carry
+// one rounding each where the reference's (p_g1 + p_g2) and its product with keep / 2 carry two, so the part of the term that
+// depends on p differs by at most 3 x 2^-24 relative, the term (>= that part) by at most that plus one more rounding of the sum
+// with the floor: 4 x 2^-24 = 2.4e-7 relative per term = 2.4e-7 in its log, on top of GUARD_PER_CALL.
+constexpr float GUARD_PER_CALL_PRESCALED = 3.1e-7f;
 constexpr float GUARD_LOGIT_ROUNDING = 1.2e-7f;  // 2 x 2^-24 (reference and here) with the conversions' slack
 constexpr float GUARD_TOL = 8.0e-6f;
 constexpr float GUARD_TOL_WIDE = 6.0e-6f;  // rows of more than 1024 options (k_softmax_rows): numpy's pairwise sum has three more
@@ -346,7 +353,7 @@ static __device__ __forceinline__ void estep_epilogue(const EstepArgs &a, long l
 #pragma unroll
         for (int s = 0; s < A; s++) {
             const float l0 = (float)((double)a.pen[kk[s]] + acc[s]);
-            dev[s] = GUARD_RHO * (fabsf((float)acc[s]) + GUARD_POSITIVE_TERM * n) + GUARD_PER_CALL * (n + 8.0f) + GUARD_LOGIT_ROUNDING * fabsf(l0);
+            dev[s] = GUARD_RHO * (fabsf((float)acc[s]) + GUARD_POSITIVE_TERM * n) + a.guard_per_call * (n + 8.0f) + GUARD_LOGIT_ROUNDING * fabsf(l0);
             if (a.prior) dev[s] += GUARD_LOGIT_ROUNDING * fabsf(lg[s]);
         }
         const bool flagged = estep_guard<L, A>(dev, lg, post, valid, mx, gbase);

@@ -66,6 +66,8 @@ struct EstepArgs {
     int fast;                   // DMX_ESTEP_FAST: tolerance mode (products of 8 terms + hardware log2), see kernels.hip
     // guarded mode (DMX_ESTEP_GUARDED; estep_epilogue.h: guard_flags): the fast kernels bound their deviation from the
     // reference per barcode and queue the barcodes whose posteriors / argmax are not provably within the contract
+    float guard_per_call;       // the guard's allowance per call for the fast arithmetic of the launching form (estep_epilogue.h: GUARD_PER_CALL,
+                                // GUARD_PER_CALL_PRESCALED for k_estep_pairblocks' pre-scaled rows)
     int guard;                  // 1: the epilogue evaluates the guard and appends to guard_list (the fast kernels of a guarded E-step);
                                 // 2: the exact kernels of a guarded E-step: when the E-step runs DIRECT (below) the guard is evaluated on
                                 //    their own results and the barcodes that would have been queued are only counted

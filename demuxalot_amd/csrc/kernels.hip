@@ -985,8 +985,9 @@ __global__ __launch_bounds__(256) void k_estep_block(EstepArgs a, int C, int k_b
 // array, not arithmetic, is what the tolerance arithmetic then runs on (configs[4]: 88 ms where the multiplications are
 // worth 35).  Here a thread takes the options (g1, g2) of g1 in {2i, 2i+1} x g2 in {3j, 3j+1, 3j+2}: five row reads for six
 // options.  Blocks on the diagonal carry the singlets (g, g) - ((p + p) * 0.5 = p exactly) - and options with g1 > g2 that
-// are computed and dropped.  Same staging, same terms, same products of 8 as k_estep_block<., true>; the rows' softmax and
-// the guard are k_softmax_rows'.
+// are computed and dropped.  Same staging and products of 8 as k_estep_block<., true> - but the rows are staged pre-scaled by
+// keep / 2, a term is two additions (estep_epilogue.h: GUARD_PER_CALL_PRESCALED); the rows' softmax and the guard are
+// k_softmax_rows'.
 // ------------------------------------------------------------------------------------
 template <int R1, int R2, int THREADS>
 __global__ __launch_bounds__(THREADS) void k_estep_pairblocks(EstepArgs a, int C, int blk_base)
@@ -1038,14 +1039,14 @@ __global__ __launch_bounds__(THREADS) void k_estep_pairblocks(EstepArgs a, int C
             sh_floor[tid] = __uint_as_float(words[w + 4]);
         }
         __syncthreads();
-        for (int c = wave; c < n; c += THREADS / 64) {
+        for (int c = wave; c < n; c += THREADS / 64) {  // rows staged pre-scaled: u_g = p_g (keep / 2)  (GUARD_PER_CALL_PRESCALED)
             const char *row = (const char *)a.prob + sh_off[c];
-            for (int g = lane; g < G; g += 64) sh_t[g * CS + c] = *(const float *)(row + (unsigned)g * 4u);
+            const float half_keep = sh_keep[c];
+            for (int g = lane; g < G; g += 64) sh_t[g * CS + c] = *(const float *)(row + (unsigned)g * 4u) * half_keep;
         }
         __syncthreads();
         if (!wave_active) continue;
         for (int c = 0; c < n; c += 2) {
-            const npm::f32x2 keep2 = *(const npm::f32x2 *)(sh_keep + c);
             const npm::f32x2 flo2 = *(const npm::f32x2 *)(sh_floor + c);
             npm::f32x2 pa[R1], pb[R2];
 #pragma unroll
@@ -1056,8 +1057,7 @@ __global__ __launch_bounds__(THREADS) void k_estep_pairblocks(EstepArgs a, int C
             for (int x = 0; x < R1; x++)
 #pragma unroll
                 for (int y = 0; y < R2; y++) {
-                    npm::f32x2 t = (pa[x] + pb[y]) * keep2;
-                    t = t + flo2;
+                    const npm::f32x2 t = (pa[x] + pb[y]) + flo2;
                     const int o = R2 * x + y;
 #if DMX_PAIRBLOCK_SERIAL_PRODUCT
                     prod[o].x = (prod[o].x * t.x) * t.y;
@@ -1157,7 +1157,7 @@ __global__ __launch_bounds__(256) void k_softmax_rows(EstepArgs a)
         bool bad = false;
         for (int k = tid; k < K; k += 256) {
             const float l = lg[k];
-            const float d = GUARD_RHO * (fabsf(l) + fabsf(a.pen[k]) + GUARD_POSITIVE_TERM * n) + GUARD_PER_CALL * (n + 8.0f) + GUARD_LOGIT_ROUNDING * fabsf(l);
+            const float d = GUARD_RHO * (fabsf(l) + fabsf(a.pen[k]) + GUARD_POSITIVE_TERM * n) + a.guard_per_call * (n + 8.0f) + GUARD_LOGIT_ROUNDING * fabsf(l);
             bad |= !(d < 0.25f);
             dmax = fmaxf(dmax, d);
         }
@@ -2489,6 +2489,8 @@ hipError_t launch_estep(hipStream_t st, const EstepArgs &a, bool pairs)
     // (Tiles of 65 accumulators per thread -- 385 VGPRs plus SGPR spills -- ended in GPU memory faults that narrower
     // tiles of the same source do not show: profiles/r2_block_tile65_experiment.txt.)
     if (a.fast && pairs && a.pair_blocks != nullptr && a.n_pair_blocks > 0 && a.order_count == nullptr) {
+        EstepArgs prescaled = a;
+        prescaled.guard_per_call = GUARD_PER_CALL_PRESCALED;
         // tolerance arithmetic: 2 x 3 blocks of the option triangle, 256 blocks per launch (k_estep_pairblocks)
         const bool big = a.n_pair_blocks >= 1024;         // enough blocks for 512 threads to share the staging of a chunk
         int C = ((big ? 32768 : 16384) / (4 * a.G)) & ~7;  // calls staged per chunk (twice as many for 512 threads: 69.3 -> 67.9 ms at K = 8256)
@@ -2501,13 +2503,13 @@ hipError_t launch_estep(hipStream_t st, const EstepArgs &a, bool pairs)
             const hipError_t e = hipFuncSetAttribute((const void *)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
             if (e != hipSuccess) return e;
             for (int blk_base = 0; blk_base < a.n_pair_blocks; blk_base += threads)
-                hipLaunchKernelGGL(kernel, dim3((unsigned)a.B), dim3(threads), bytes, st, a, C, blk_base);
+                hipLaunchKernelGGL(kernel, dim3((unsigned)a.B), dim3(threads), bytes, st, prescaled, C, blk_base);
             return hipSuccess;
         };
         const hipError_t e = big ? launch(k_estep_pairblocks<PAIRBLOCK_R1, PAIRBLOCK_R2, 512>, 512)
                                                      : launch(k_estep_pairblocks<PAIRBLOCK_R1, PAIRBLOCK_R2, 256>, 256);
         if (e != hipSuccess) return e;
-        return launch_softmax_rows(st, a);
+        return launch_softmax_rows(st, prescaled);
     }
     const int need = (K + 255) / 256;
     int tile = need <= 2 ? 2 : need <= 4 ? 4 : need <= 6 ? 6 : need <= 8 ? 8 : need <= 12 ? 12 : need <= 17 ? 17 : need <= 24 ? 12 : 17;

@@ -520,6 +520,9 @@ static int repack_core(dmx_ctx *c, Scratch &sc, const int *d_variant, const int 
         hipLaunchKernelGGL(k_build_items, dim3(grid_for(V)), dim3(256), 0, st, col_ptr, c->d_item_ptr, V, c->item_calls,
                            c->d_item_start, c->d_item_len, inv_i, ids_i, c->d_item_variant);
     DMX_TRY(sort_pairs(sc, inv_i, keys_out, ids_i, (unsigned *)c->d_item_order, (size_t)n_items, 32, st));
+    // the variant-major offsets stay on the host: what cuts the tiles of the tile-major M-step (build_mstep_tiles)
+    c->h_col_ptr.resize((size_t)V + 1);
+    HIP_TRY(hipMemcpyAsync(c->h_col_ptr.data(), col_ptr, sizeof(long long) * (V + 1), hipMemcpyDeviceToHost, st));
 
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipStreamSynchronize(st));  // scratch is released by the caller's Scratch
@@ -664,6 +667,8 @@ int install_mstep_records(dmx_ctx *c, const uint4 *d_rec, long long n, long long
         hipLaunchKernelGGL(k_build_items, dim3(grid_for(V)), dim3(256), 0, st, col_ptr, c->d_item_ptr, V, c->item_calls, c->d_item_start,
                            c->d_item_len, inv_i, ids_i, c->d_item_variant);
     DMX_TRY(sort_pairs(sc, inv_i, keys_out, ids_i, (unsigned *)c->d_item_order, (size_t)n_items, 32, st));
+    c->h_col_ptr.resize((size_t)V + 1);
+    HIP_TRY(hipMemcpyAsync(c->h_col_ptr.data(), col_ptr, sizeof(long long) * (V + 1), hipMemcpyDeviceToHost, st));
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipStreamSynchronize(st));
     return 0;
@@ -702,17 +707,24 @@ __global__ __launch_bounds__(256) void k_mtile_from_rows(const CallPair *__restr
     const long long b = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (b >= B) return;
     const long long p0 = pair_ptr[b];
-    const long long n = 2 * (pair_ptr[b + 1] - p0);
-    const unsigned *__restrict__ words = (const unsigned *)(pairs + p0);
-    for (long long i = lane; i < n; i += 64) {
-        const long long w = (i >> 1) * 8 + (i & 1);
-        const unsigned row_off = words[w], keep = words[w + 2], floor_bits = words[w + 4];
-        // the neutral calls that pad a row to 8 (keep 0, floor 1, row 0); a real call with p_base_wrong == 1 looks the same and
-        // is dropped with them: it contributes (posterior x 0)^power = +0 to every sum
-        const bool padding = keep == 0u && floor_bits == 0x3F800000u && row_off == 0u;
-        const unsigned v = row_off / row_bytes;
-        keys[2 * p0 + i] = padding ? sentinel : tile_of[v];
-        rec[2 * p0 + i] = (unsigned long long)((unsigned)b | (vin_of[v] << 24)) | ((unsigned long long)keep << 32);
+    const long long n_pairs = pair_ptr[b + 1] - p0;
+    for (long long j = lane; j < n_pairs; j += 64) {  // a lane takes a whole 32-byte record (two calls): coalesced in, coalesced out
+        const uint4 lo = ((const uint4 *)(pairs + p0 + j))[0];  // row_off[2], keep[2]
+        const uint4 hi = ((const uint4 *)(pairs + p0 + j))[1];  // floor[2], reserved[2]
+        const unsigned row_off[2] = {lo.x, lo.y}, keep[2] = {lo.z, lo.w}, floor_bits[2] = {hi.x, hi.y};
+        unsigned key[2];
+        unsigned long long r[2];
+#pragma unroll
+        for (int h = 0; h < 2; h++) {
+            // the neutral calls that pad a row to 8 (keep 0, floor 1, row 0); a real call with p_base_wrong == 1 looks the same and
+            // is dropped with them: it contributes (posterior x 0)^power = +0 to every sum
+            const bool padding = keep[h] == 0u && floor_bits[h] == 0x3F800000u && row_off[h] == 0u;
+            const unsigned v = row_off[h] / row_bytes;
+            key[h] = padding ? sentinel : tile_of[v];
+            r[h] = (unsigned long long)((unsigned)b | (vin_of[v] << 24)) | ((unsigned long long)keep[h] << 32);
+        }
+        *(uint2 *)(keys + 2 * (p0 + j)) = make_uint2(key[0], key[1]);
+        *(ulonglong2 *)(rec + 2 * (p0 + j)) = make_ulonglong2(r[0], r[1]);
     }
 }
 
@@ -762,31 +774,14 @@ int build_mstep_tiles(dmx_ctx *c, long long v_lo, long long v_hi)
     release_mstep_tiles(c);
     c->mt_tried = true;
     const int G = c->G;
-    const long long rows = c->mshard ? c->rows_total : c->B, m = c->n_csc, n_items = c->n_items;
+    const long long rows = c->mshard ? c->rows_total : c->B, m = c->n_csc;
     if (G < 1 || G > 64 || rows >= (1LL << 24) || m == 0 || m >= (1LL << 32) || v_hi <= v_lo) return 0;
     hipStream_t st = c->stream;
     const long long V = c->V;
-    std::vector<long long> item_ptr((size_t)V + 1), item_start((size_t)n_items);
-    std::vector<int> item_len((size_t)n_items);
-    HIP_TRY(hipMemcpyAsync(item_ptr.data(), c->d_item_ptr, sizeof(long long) * (V + 1), hipMemcpyDeviceToHost, st));
-    HIP_TRY(hipMemcpyAsync(item_start.data(), c->d_item_start, sizeof(long long) * n_items, hipMemcpyDeviceToHost, st));
-    HIP_TRY(hipMemcpyAsync(item_len.data(), c->d_item_len, sizeof(int) * n_items, hipMemcpyDeviceToHost, st));
-    HIP_TRY(hipStreamSynchronize(st));
-    // the records are variant-major: first record and number of calls of every variant
-    std::vector<long long> first_call((size_t)V + 1, 0);
-    {
-        long long at = 0;
-        for (long long v = 0; v < V; v++) {
-            first_call[(size_t)v] = at;
-            for (long long it = item_ptr[(size_t)v]; it < item_ptr[(size_t)v + 1]; it++) {
-                if (item_start[(size_t)it] != at) return 0;  // (never with the items the repack builds) stay with the work-item form
-                at += item_len[(size_t)it];
-            }
-        }
-        first_call[(size_t)V] = at;
-        if (at != m) return 0;
-        if (first_call[(size_t)v_lo] != 0 || first_call[(size_t)v_hi] != m) return 0;  // records outside the range: stay with the item form
-    }
+    // first record of every variant: the repack left the variant-major offsets on the host (dmx_ctx::h_col_ptr)
+    if ((long long)c->h_col_ptr.size() != V + 1 || c->h_col_ptr[(size_t)V] != m) return 0;  // (not the resident records') stay with the item form
+    const std::vector<long long> &first_call = c->h_col_ptr;
+    if (first_call[(size_t)v_lo] != 0 || first_call[(size_t)v_hi] != m) return 0;  // records outside the range: stay with the item form
     if (!c->n_simd) {
         int cus = 0;
         HIP_TRY(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, c->device));
@@ -882,7 +877,7 @@ int build_mstep_tiles(dmx_ctx *c, long long v_lo, long long v_hi)
     DMX_TRY(sc.get(&rec, (size_t)m));
     HIP_TRY(hipMemcpyAsync(d_tile_of, tile_of.data(), sizeof(unsigned) * V, hipMemcpyHostToDevice, st));
     HIP_TRY(hipMemcpyAsync(d_vin_of, vin_of.data(), sizeof(unsigned) * V, hipMemcpyHostToDevice, st));
-    hipLaunchKernelGGL(k_mtile_keys, dim3((unsigned)n_items), dim3(256), 0, st, c->d_csc, c->d_item_start, c->d_item_len, c->d_item_variant,
+    hipLaunchKernelGGL(k_mtile_keys, dim3((unsigned)c->n_items), dim3(256), 0, st, c->d_csc, c->d_item_start, c->d_item_len, c->d_item_variant,
                        d_tile_of, d_vin_of, row_bits, keys, rec);
     hipLaunchKernelGGL(k_iota, dim3(grid_for(m)), dim3(256), 0, st, iota, m);
     const unsigned tile_bits = bits_for(n_mt > 1 ? (unsigned long long)n_mt - 1 : 0);
@@ -926,8 +921,8 @@ int repack_on_device(dmx_ctx *c, const int32_t *h_variant, const int32_t *h_cb, 
 // ------------------------------------------------------------------------------------
 // Device pack: Demultiplexer.pack_calls' variant matching + molecule_calls2barcode_calls
 // (demuxalot/demux.py:276-300, 332-365) on the GPU, feeding repack_core without a round trip:
-//   1. 64-bit keys (chromosome, position, base) of the variants, sorted (rocPRIM) -> binary search
-//      of every molecule call -> variant row or "no match";
+//   1. 64-bit keys (chromosome, position, base) of the variants in a hash table -> one or two probes
+//      per molecule call -> variant row or "no match";
 //   2. order-preserving compaction of the matched calls (prefix sum of the match flags);
 //   3. stable radix sort of (variant << 32 | barcode, input index);
 //   4. one thread per run of equal keys multiplies the members' p_base_wrong in input order,
@@ -940,36 +935,66 @@ __host__ __device__ inline unsigned long long variant_key(int chrom, int pos, un
     return ((unsigned long long)(unsigned)chrom << 35) | ((unsigned long long)(unsigned)pos << 3) | (unsigned long long)(base & 7);
 }
 
-__global__ __launch_bounds__(256) void k_variant_keys(const int *chrom, const int *pos, const unsigned char *base, long long n,
-                                                      unsigned long long *keys, unsigned *rows)
+// Variant matching through an open-addressing hash table of the variants' 64-bit keys (capacity a power of two >= 2 V, linear
+// probing): one or two 16-byte probes per molecule call instead of an 18-step binary search through the sorted keys (k_match
+// took 11.5 ms of the 25 ms device pack of 78 M calls, most of it the search's dependent loads and one atomic per call on the
+// molecule counters of the variants - 72 000 of them on the hottest variant's; the counts now come from the sorted calls).
+constexpr unsigned long long EMPTY_SLOT = ~0ull;
+
+__device__ __forceinline__ unsigned long long slot_of(unsigned long long key, unsigned bits)
 {
-    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    keys[i] = variant_key(chrom[i], pos[i], base[i]);
-    rows[i] = (unsigned)i;
+    return (key * 0x9E3779B97F4A7C15ull) >> (64u - bits);
+}
+
+__global__ __launch_bounds__(256) void k_table_insert(const int *chrom, const int *pos, const unsigned char *base, long long V,
+                                                      unsigned bits, unsigned long long *tkeys, unsigned *trows)
+{
+    const long long v = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (v >= V) return;
+    const unsigned long long key = variant_key(chrom[v], pos[v], base[v]), mask = (1ull << bits) - 1ull;
+    for (unsigned long long h = slot_of(key, bits);; h = (h + 1ull) & mask) {
+        const unsigned long long seen = atomicCAS(&tkeys[h], EMPTY_SLOT, key);
+        if (seen == EMPTY_SLOT || seen == key) {
+            atomicMin(&trows[h], (unsigned)v);  // rows that share a key (only a caller's own arrays could): the lowest, as the sorted search chose
+            return;
+        }
+    }
 }
 
 __global__ __launch_bounds__(256) void k_match(const int *chrom, const int *pos, const unsigned char *base, const int *cb,
-                                               long long n, const unsigned long long *vkeys, const unsigned *vrows,
-                                               long long V, int *call_variant, unsigned *flag,
-                                               unsigned long long *mol_per_variant, int *bad)
+                                               long long n, const unsigned long long *tkeys, const unsigned *trows,
+                                               unsigned bits, int *call_variant, unsigned *flag, int *bad)
 {
     const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
-    const unsigned long long q = variant_key(chrom[i], pos[i], base[i]);
-    long long lo = 0, hi = V;  // lower_bound
-    while (lo < hi) {
-        const long long mid = (lo + hi) >> 1;
-        if (vkeys[mid] < q) lo = mid + 1; else hi = mid;
+    const unsigned long long q = variant_key(chrom[i], pos[i], base[i]), mask = (1ull << bits) - 1ull;
+    int v = -1;
+    for (unsigned long long h = slot_of(q, bits);; h = (h + 1ull) & mask) {
+        const unsigned long long k = tkeys[h];
+        if (k == q) v = (int)trows[h];
+        if (k == q || k == EMPTY_SLOT) break;
     }
-    const bool hit = lo < V && vkeys[lo] == q;
-    const int v = hit ? (int)vrows[lo] : -1;
     call_variant[i] = v;
-    flag[i] = hit ? 1u : 0u;
-    if (hit) {
-        if (cb[i] < 0) atomicMax(bad, 1);
-        atomicAdd(&mol_per_variant[v], 1ull);
-    }
+    flag[i] = v >= 0 ? 1u : 0u;
+    if (v >= 0 && cb[i] < 0) atomicMax(bad, 1);
+}
+
+// matched molecule calls per variant (np.bincount(molecule_calls['variant_id']) of demux.py:381) from the calls sorted by
+// (variant << 32 | barcode): one thread per variant, two binary searches
+__global__ __launch_bounds__(256) void k_variant_counts(const unsigned long long *sorted_keys, long long m, long long V,
+                                                        unsigned long long *counts)
+{
+    const long long v = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (v >= V) return;
+    auto lower = [&](unsigned long long key) {
+        long long lo = 0, hi = m;
+        while (lo < hi) {
+            const long long mid = (lo + hi) >> 1;
+            if (sorted_keys[mid] < key) lo = mid + 1; else hi = mid;
+        }
+        return lo;
+    };
+    counts[v] = (unsigned long long)(lower((unsigned long long)(v + 1) << 32) - lower((unsigned long long)v << 32));
 }
 
 __global__ __launch_bounds__(256) void k_compact_keys(const int *call_variant, const int *cb, const unsigned *flag,
@@ -1026,26 +1051,21 @@ static int pack_core(dmx_ctx *c, Scratch &sc, long long V, const int *var_chrom,
 {
     hipStream_t st = c->stream;
     if (n_calls >= (1LL << 32)) return fail(DMX_ERR_UNSUPPORTED, "more than 2^32 molecule calls in one batch");
-    // 1. sorted variant keys
+    // 1. hash table of the variant keys
     int *d_vchrom, *d_vpos;
     unsigned char *d_vbase;
     DMX_TRY(upload(sc, &d_vchrom, var_chrom, (size_t)V, st));
     DMX_TRY(upload(sc, &d_vpos, var_pos, (size_t)V, st));
     DMX_TRY(upload(sc, &d_vbase, var_base, (size_t)V, st));
-    unsigned long long *vkeys, *vkeys_sorted;
-    unsigned *vrows, *vrows_sorted;
-    DMX_TRY(sc.get(&vkeys, (size_t)V));
-    DMX_TRY(sc.get(&vkeys_sorted, (size_t)V));
-    DMX_TRY(sc.get(&vrows, (size_t)V));
-    DMX_TRY(sc.get(&vrows_sorted, (size_t)V));
-    if (V) {
-        hipLaunchKernelGGL(k_variant_keys, dim3(grid_for(V)), dim3(256), 0, st, d_vchrom, d_vpos, d_vbase, V, vkeys, vrows);
-        size_t bytes = 0;
-        HIP_TRY(rocprim::radix_sort_pairs(nullptr, bytes, vkeys, vkeys_sorted, vrows, vrows_sorted, (size_t)V, 0u, 64u, st));
-        char *tmp;
-        DMX_TRY(sc.get(&tmp, bytes));
-        HIP_TRY(rocprim::radix_sort_pairs(tmp, bytes, vkeys, vkeys_sorted, vrows, vrows_sorted, (size_t)V, 0u, 64u, st));
-    }
+    const unsigned table_bits = std::max(6u, bits_for((unsigned long long)(2 * V)));
+    const size_t table_slots = (size_t)1 << table_bits;
+    unsigned long long *tkeys;
+    unsigned *trows;
+    DMX_TRY(sc.get(&tkeys, table_slots));
+    DMX_TRY(sc.get(&trows, table_slots));
+    HIP_TRY(hipMemsetAsync(tkeys, 0xFF, sizeof(unsigned long long) * table_slots, st));
+    HIP_TRY(hipMemsetAsync(trows, 0xFF, sizeof(unsigned) * table_slots, st));
+    if (V) hipLaunchKernelGGL(k_table_insert, dim3(grid_for(V)), dim3(256), 0, st, d_vchrom, d_vpos, d_vbase, V, table_bits, tkeys, trows);
     // 2. match + order-preserving compaction
     int *call_variant, *bad;
     unsigned *flag, *pos_excl;
@@ -1056,12 +1076,11 @@ static int pack_core(dmx_ctx *c, Scratch &sc, long long V, const int *var_chrom,
     DMX_TRY(sc.get(&flag, (size_t)n_calls + 1));
     DMX_TRY(sc.get(&pos_excl, (size_t)n_calls + 1));
     DMX_TRY(sc.get(&bad, 1));
-    HIP_TRY(hipMemsetAsync(d_mol, 0, sizeof(unsigned long long) * (V ? V : 1), st));
     HIP_TRY(hipMemsetAsync(bad, 0, sizeof(int), st));
-    HIP_TRY(hipMemsetAsync(flag, 0, sizeof(unsigned) * ((size_t)n_calls + 1), st));
+    HIP_TRY(hipMemsetAsync(flag + n_calls, 0, sizeof(unsigned), st));
     if (n_calls)
         hipLaunchKernelGGL(k_match, dim3(grid_for(n_calls)), dim3(256), 0, st, d_cchrom, d_cpos, d_cbase, d_ccb, n_calls,
-                           vkeys_sorted, vrows_sorted, V, call_variant, flag, d_mol, bad);
+                           tkeys, trows, table_bits, call_variant, flag, bad);
     {
         size_t bytes = 0;
         HIP_TRY(rocprim::exclusive_scan(nullptr, bytes, flag, pos_excl, 0u, (size_t)n_calls + 1, rocprim::plus<unsigned>(), st));
@@ -1073,8 +1092,6 @@ static int pack_core(dmx_ctx *c, Scratch &sc, long long V, const int *var_chrom,
     int h_bad = 0;
     HIP_TRY(hipMemcpyAsync(&h_matched, pos_excl + n_calls, sizeof(unsigned), hipMemcpyDeviceToHost, st));
     HIP_TRY(hipMemcpyAsync(&h_bad, bad, sizeof(int), hipMemcpyDeviceToHost, st));
-    if (mol_per_variant && V)
-        HIP_TRY(hipMemcpyAsync(mol_per_variant, d_mol, sizeof(long long) * V, hipMemcpyDeviceToHost, st));
     HIP_TRY(hipStreamSynchronize(st));
     if (h_bad) return fail(DMX_ERR_INVALID, "negative barcode index among the matched calls");
     const long long m = h_matched;
@@ -1099,6 +1116,9 @@ static int pack_core(dmx_ctx *c, Scratch &sc, long long V, const int *var_chrom,
         DMX_TRY(sc.get(&tmp, bytes));
         HIP_TRY(rocprim::radix_sort_pairs(tmp, bytes, keys, keys_sorted, idx, perm, (size_t)m, 0u, end_bit, st));
     }
+    // matched molecule calls per variant, from the sorted keys
+    if (V) hipLaunchKernelGGL(k_variant_counts, dim3(grid_for(V)), dim3(256), 0, st, m ? keys_sorted : keys, m, V, d_mol);
+    if (mol_per_variant && V) HIP_TRY(hipMemcpyAsync(mol_per_variant, d_mol, sizeof(long long) * V, hipMemcpyDeviceToHost, st));
     // 4. runs of equal keys -> products in input order
     unsigned *head, *seg_incl;
     DMX_TRY(sc.get(&head, (size_t)m));

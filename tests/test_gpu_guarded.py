@@ -313,3 +313,31 @@ def test_guarded_mode_adapts_to_a_workload_it_cannot_prove(G, dp, B, cpb):
     finally:
         ctx.close()
     print(f'G={G} dp={dp}: (direct, queued or would-queue, fast pass ms, exact pass ms) per E-step {history}')
+
+
+@pytest.mark.parametrize('name', ['f1_synthetic_default.npz', 'f2_synthetic_g4.npz'])
+def test_default_mode_through_the_tile_major_mstep_on_reference_outputs_and_twice_the_same_bits(guarded, name):
+    """learn_genotypes in the library's default mode with the M-step form of long runs (tile-major records, fixed-point sums)
+    on the reference's own fixtures: every yielded iteration within the contract (posteriors 1e-5, assignments identical),
+    the learnt betas within what such posteriors allow - and the whole call twice: the same bits (the reference is
+    bit-reproducible run to run; so is the default mode since its M-step sums in fixed point)."""
+    from demuxalot_amd import Demultiplexer
+    fx = fio.load(name)
+    calls, genotypes, handler = fio.product_inputs(fx)
+    guarded.set_mstep_tiles('always')
+    try:
+        for i in range(int(fx['n_em'])):
+            kwargs = dict(n_iterations=int(fx[f'em{i}_n_iterations']), p_genotype_clip=float(fx[f'em{i}_clip']), doublet_prior=float(fx[f'em{i}_dp']))
+            prior = fx.get(f'em{i}_prior_logits')
+            runs = []
+            for _ in range(2):
+                learnt, last = Demultiplexer.learn_genotypes(calls, genotypes, handler,
+                                                             barcode_prior_logits=None if prior is None else prior.copy(), **kwargs)
+                assert guarded.mstep_form() == ('tiles' if len(genotypes.genotype_names) <= 64 and kwargs['n_iterations'] > 1 else guarded.mstep_form())
+                check_contract(last.values, fx[f'em{i}_it{kwargs["n_iterations"] - 1}_probs'], f'{name} learn {i} through the tile-major M-step')
+                assert_addition_within_bound(learnt.variant_betas, fx[f'em{i}_learnt_betas'], fx, f'{name} learnt betas {i} (tiles)')
+                runs.append((last.values.copy(), learnt.variant_betas.copy()))
+            fio.assert_bitwise(runs[1][0], runs[0][0], f'{name} run {i}: posteriors of a second call')
+            fio.assert_bitwise(runs[1][1], runs[0][1], f'{name} run {i}: learnt betas of a second call')
+    finally:
+        guarded.set_mstep_tiles('auto')
