@@ -24,7 +24,11 @@ static_assert(sizeof(CallPair) == 32, "CallPair layout");
 // block of the option triangle one thread of k_estep_pairblocks takes: g1 in R1 consecutive genotypes x g2 in R2.  E-step of
 // 130k x 650k x 128 / 20k x 20k x 64 / 20k x 20k x 32, all with doublets (K = 8256 / 2080 / 528), in ms: 2 x 3: 74.8 / 2.97 / 1.23,
 // 3 x 3: 75.3 / 2.61 / 1.82, 2 x 4: 77.4 / 3.56 / 1.56, 3 x 4: 77.1 / 3.08 / 2.18, 4 x 4: 86.0 / 3.67 / 2.57 (k_estep_block<6,true>: 88.2 / 3.45 / 1.2)
-constexpr int PAIRBLOCK_R1 = 2, PAIRBLOCK_R2 = 3;
+#ifndef DMX_PAIRBLOCK_R1
+#define DMX_PAIRBLOCK_R1 2
+#define DMX_PAIRBLOCK_R2 3
+#endif
+constexpr int PAIRBLOCK_R1 = DMX_PAIRBLOCK_R1, PAIRBLOCK_R2 = DMX_PAIRBLOCK_R2;
 
 struct EstepSegment {
     int barcode;     // row

@@ -985,12 +985,26 @@ __global__ __launch_bounds__(256) void k_estep_block(EstepArgs a, int C, int k_b
 // array, not arithmetic, is what the tolerance arithmetic then runs on (configs[4]: 88 ms where the multiplications are
 // worth 35).  Here a thread takes the options (g1, g2) of g1 in {2i, 2i+1} x g2 in {3j, 3j+1, 3j+2}: five row reads for six
 // options.  Blocks on the diagonal carry the singlets (g, g) - ((p + p) * 0.5 = p exactly) - and options with g1 > g2 that
-// are computed and dropped.  Same staging and products of 8 as k_estep_block<., true> - but the rows are staged pre-scaled by
+// are computed and dropped.  Round 5 (profiles/r5_pmc_pairblocks.txt: VALU 85 % busy, LDS 31 %; the packed float32 operations occupy the
+// VALU twice, so packing more of them saved instructions and no time): (1) rows staged pre-scaled - a term is two packed
+// additions, not add / multiply / add; (2) 8 calls per trip, unrolled: no flush test and branch per option and pair of calls, the
+// LDS reads of a whole group in flight; (3) the register allocation held to 64 VGPRs = 8 wavefronts per SIMD (amdgpu_waves_per_eu;
+// 76 bytes of scratch per lane): unrolled at the compiler's own 106 VGPRs (4 wavefronts) the E-step of 130k x 650k x 128 took 72.4 ms,
+// at 84 (5) 72.0, at 80 (6) 56.4, at 72 (7) 58.5, at 64 (8) 54.7 - against 65.4 not unrolled and 68.4 in round 4; blocks of 2 x 4 /
+// 3 x 3 / 3 x 4 options at 8 wavefronts: 105 / 166 / 248 ms (144 - 248 bytes of scratch).
+// Same staging and products of 8 as k_estep_block<., true> - but the rows are staged pre-scaled by
 // keep / 2, a term is two additions (estep_epilogue.h: GUARD_PER_CALL_PRESCALED); the rows' softmax and the guard are
 // k_softmax_rows'.
 // ------------------------------------------------------------------------------------
+#ifndef DMX_PAIRBLOCK_WAVES
+#define DMX_PAIRBLOCK_WAVES 8  // wavefronts per SIMD the register allocation of k_estep_pairblocks aims at (0: the compiler's choice); see below
+#endif
 template <int R1, int R2, int THREADS>
-__global__ __launch_bounds__(THREADS) void k_estep_pairblocks(EstepArgs a, int C, int blk_base)
+__global__ __launch_bounds__(THREADS)
+#if DMX_PAIRBLOCK_WAVES
+__attribute__((amdgpu_waves_per_eu(DMX_PAIRBLOCK_WAVES, DMX_PAIRBLOCK_WAVES)))
+#endif
+void k_estep_pairblocks(EstepArgs a, int C, int blk_base)
 {
     constexpr int NO = R1 * R2;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -1046,31 +1060,37 @@ __global__ __launch_bounds__(THREADS) void k_estep_pairblocks(EstepArgs a, int C
         }
         __syncthreads();
         if (!wave_active) continue;
-        for (int c = 0; c < n; c += 2) {
-            const npm::f32x2 flo2 = *(const npm::f32x2 *)(sh_floor + c);
-            npm::f32x2 pa[R1], pb[R2];
+        // 8 calls per trip (rows are padded to 8 calls, the chunks hold whole groups): four pairs of calls unrolled - no flush
+        // test and no branch per option and pair, the LDS reads of a whole group in flight -, then one flush per option
+        for (int c = 0; c < n; c += 8) {
 #pragma unroll
-            for (int x = 0; x < R1; x++) pa[x] = *(const npm::f32x2 *)(sh_t + r1[x] + c);
+            for (int q = 0; q < 8; q += 2) {
+                const npm::f32x2 flo2 = *(const npm::f32x2 *)(sh_floor + c + q);
+                npm::f32x2 pa[R1], pb[R2];
 #pragma unroll
-            for (int y = 0; y < R2; y++) pb[y] = *(const npm::f32x2 *)(sh_t + r2[y] + c);
+                for (int x = 0; x < R1; x++) pa[x] = *(const npm::f32x2 *)(sh_t + r1[x] + c + q);
 #pragma unroll
-            for (int x = 0; x < R1; x++)
+                for (int y = 0; y < R2; y++) pb[y] = *(const npm::f32x2 *)(sh_t + r2[y] + c + q);
 #pragma unroll
-                for (int y = 0; y < R2; y++) {
-                    const npm::f32x2 t = (pa[x] + pb[y]) + flo2;
-                    const int o = R2 * x + y;
+                for (int x = 0; x < R1; x++)
+#pragma unroll
+                    for (int y = 0; y < R2; y++) {
+                        const npm::f32x2 t = (pa[x] + pb[y]) + flo2;
+                        const int o = R2 * x + y;
 #if DMX_PAIRBLOCK_SERIAL_PRODUCT
-                    prod[o].x = (prod[o].x * t.x) * t.y;
+                        prod[o].x = (prod[o].x * t.x) * t.y;
 #else
-                    prod[o] = prod[o] * t;
+                        prod[o] = prod[o] * t;
 #endif
-                    if ((c & 7) == 6) {
-                        const float whole = prod[o].x * prod[o].y;
-                        acc_e[o] += __builtin_amdgcn_frexp_expf(whole);
-                        acc[o] += (double)__builtin_amdgcn_logf(__builtin_amdgcn_frexp_mantf(whole));
-                        prod[o] = npm::f32x2{1.0f, 1.0f};
                     }
-                }
+            }
+#pragma unroll
+            for (int o = 0; o < NO; o++) {
+                const float whole = prod[o].x * prod[o].y;
+                acc_e[o] += __builtin_amdgcn_frexp_expf(whole);
+                acc[o] += (double)__builtin_amdgcn_logf(__builtin_amdgcn_frexp_mantf(whole));
+                prod[o] = npm::f32x2{1.0f, 1.0f};
+            }
         }
     }
     if (!mine) return;
