@@ -1247,7 +1247,7 @@ int run_estep(dmx_ctx *c, int with_doublets, bool with_prior, int prior_dtype, f
             a.direct = c->d_guard_count + dmx::GS_DIRECT;
             a.order_direct = c->d_bc_order;
             HIP_TRY(dmx::launch_estep(c->stream, a, with_doublets != 0));
-            HIP_TRY(dmx::launch_guard_compact(c->stream, c->d_guard_count, c->d_guard_sub, c->guard_sub_cap, c->d_guard_list));
+            HIP_TRY(dmx::launch_guard_compact(c->stream, c->d_guard_count, c->d_guard_sub, c->guard_sub_cap, c->d_guard_list, c->d_bc_order, c->B));
             dmx::EstepArgs redo = a;
             redo.fast = 0;
             redo.guard = 2;

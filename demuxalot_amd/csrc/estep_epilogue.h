@@ -272,19 +272,14 @@ static __device__ __forceinline__ void guard_note(const EstepArgs &a, long long 
         a.guard_sub[(size_t)q * a.guard_sub_cap + atomicAdd(a.guard_count + GS_WORDS + GUARD_SLOTS + q, 1u)] = (int)b;
     }
 }
-// A fast kernel of a guarded E-step that runs direct (kernels.h: EstepArgs::direct) stands back - and, on its way out, its
-// first launch turns the queue into the list of ALL barcodes (longest rows first), so that the exact launch behind it walks
-// every barcode with the very code that walks the queue (a pointer chosen at run time in the exact kernels made their
-// uniform loads vector loads: +40 % on their time).  Returns true when the caller has to return.
-static __device__ __forceinline__ bool guard_stand_back(const EstepArgs &a, bool first_launch)
+// A fast kernel of a guarded E-step that runs direct (kernels.h: EstepArgs::direct) stands back: k_guard_compact, between it
+// and the exact launch, then lists ALL barcodes (longest rows first) in the queue, so that the exact launch walks every barcode
+// with the very code that walks the queue.  Nothing is stored here, and the exact kernels choose no pointer at run time: a
+// store ahead of the kernels' uniform loads (records, offsets), or a selected base pointer, turned those scalar loads into
+// vector loads - +40 % on the exact kernel's time, 2 x on the 64-lane fast kernel's.  Returns true when the caller has to return.
+static __device__ __forceinline__ bool guard_stand_back(const EstepArgs &a)
 {
-    if (a.guard != 1 || a.direct == nullptr || *a.direct == 0u) return false;
-    if (first_launch) {
-        const long long stride = (long long)gridDim.x * blockDim.x;
-        for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < a.B; i += stride) a.guard_list[i] = a.order_direct[i];
-        if (blockIdx.x == 0 && threadIdx.x == 0) a.guard_count[GS_COUNT] = (unsigned)a.B;
-    }
-    return true;
+    return a.guard == 1 && a.direct != nullptr && *a.direct != 0u;
 }
 // whether this launch evaluates the guard: the fast kernels of a guarded E-step always, its exact kernels when the E-step runs direct
 static __device__ __forceinline__ bool guard_active(const EstepArgs &a)

@@ -136,7 +136,7 @@ hipError_t launch_mstep(hipStream_t, const MstepArgs &) { return hipSuccess; }
 hipError_t launch_mstep_tiles(hipStream_t, const MstepArgs &, const MTileArgs &) { return hipSuccess; }
 hipError_t launch_guard_begin(hipStream_t, unsigned *, long long, int, int) { return hipSuccess; }
 hipError_t launch_guard_stamp(hipStream_t, unsigned *, int) { return hipSuccess; }
-hipError_t launch_guard_compact(hipStream_t, unsigned *, const int *, unsigned, int *) { return hipSuccess; }
+hipError_t launch_guard_compact(hipStream_t, unsigned *, const int *, unsigned, int *, const int *, long long) { return hipSuccess; }
 hipError_t launch_mcombine(hipStream_t, const MstepArgs &, const long long *, long long, long long, const int *, float *, double *,
                            unsigned long long *, unsigned *, const int *, bool) { return hipSuccess; }
 hipError_t launch_store_slice(hipStream_t, const void *, bool, long long, long long, int, float *) { return hipSuccess; }

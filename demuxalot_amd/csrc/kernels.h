@@ -88,8 +88,8 @@ struct EstepArgs {
     // clock is stored before the fast launches (k_guard_begin), between them and the exact launch (k_guard_stamp) and behind
     // it; k_guard_begin (between two E-steps on the stream) turns the stamps of the finished E-step into F and E (E from the redo's time over
     // its share of the barcodes until an E-step has run direct and measured it) and lets the next E-step run DIRECT when
-    // F + f E > E: the fast kernels stand back (they read *direct, copy `order_direct` - every barcode - into the queue and
-    // return), so that the exact launch behind them walks every barcode; it counts the barcodes the guard would have
+    // F + f E > E: the fast kernels stand back (they read *direct and return), k_guard_compact lists `order_direct` - every
+    // barcode - in the queue, so that the exact launch behind them walks every barcode; it counts the barcodes the guard would have
     // queued, so that f stays known and the fast pass returns when it pays again (3 % of hysteresis).  No host
     // synchronisation anywhere.
     const unsigned *direct;       // nullable: &state[GS_DIRECT]
@@ -150,8 +150,8 @@ constexpr int GUARD_SLOTS = 256;   // hashed counters behind the state words (co
 constexpr int GUARD_QUEUES = 256;  // ... and behind those the lengths of the sub-queues (EstepArgs::guard_sub)
 constexpr int GUARD_STATE_WORDS = GS_WORDS + GUARD_SLOTS + GUARD_QUEUES;
 // between the fast launches and the exact launch of a guarded E-step: the sub-queues become the dense list, GS_COUNT their total
-// length, GS_T_REDO the wall clock (a direct E-step: the clock alone - the fast kernels have listed every barcode)
-hipError_t launch_guard_compact(hipStream_t st, unsigned *state, const int *sub, unsigned sub_cap, int *list);
+// length, GS_T_REDO the wall clock (a direct E-step: the list becomes every barcode, order_direct)
+hipError_t launch_guard_compact(hipStream_t st, unsigned *state, const int *sub, unsigned sub_cap, int *list, const int *order_direct, long long B);
 hipError_t launch_guard_begin(hipStream_t st, unsigned *state, long long B, int K, int adaptive);
 hipError_t launch_guard_stamp(hipStream_t st, unsigned *state, int which);  // state[which] = the device's wall clock (GS_T_REDO, GS_T_END)
 

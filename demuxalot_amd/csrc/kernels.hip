@@ -467,7 +467,7 @@ __global__ __launch_bounds__(256) void k_estep_direct(EstepArgs a)
     int row_calls = 0;  // calls of this lane group's barcode (incl. padding)
     // Guarded E-step that runs direct (kernels.h: EstepArgs::direct): the fast kernels stand back, the exact launch walks
     // every barcode instead of the queue
-    if (FAST && guard_stand_back(a, true)) return;
+    if (FAST && guard_stand_back(a)) return;
     // rows of `order` to walk: all B, or as many as the guarded E-step queued (known on the device only)
     const long long n_rows = a.order_count ? (long long)min((unsigned long long)*a.order_count, (unsigned long long)a.B) : a.B;
     long long seg_of_wave = -1;  // split rows (FAST, 64 lanes): the segment this wavefront walks
@@ -742,8 +742,15 @@ __global__ __launch_bounds__(256) void k_estep_join(EstepArgs a)
 // change it is swapped with the slot's copy in LDS.  Every barcode's calls are still added strictly in order, so
 // the sums are bit-identical to the direct form's.
 // ------------------------------------------------------------------------------------
+#ifndef DMX_TILED_WAVES
+#define DMX_TILED_WAVES 0  // experiment builds: wavefronts per SIMD the register allocation of k_estep_tiled aims at (0: the compiler's choice, 67 VGPRs = 7)
+#endif
 template <int A, bool FAST, bool HALF = false>
-__global__ __launch_bounds__(256) void k_estep_tiled(EstepArgs a)
+__global__ __launch_bounds__(256)
+#if DMX_TILED_WAVES
+__attribute__((amdgpu_waves_per_eu(DMX_TILED_WAVES, DMX_TILED_WAVES)))
+#endif
+void k_estep_tiled(EstepArgs a)
 {
     static_assert(!HALF || (A == 1 && FAST), "two calls per gather: tolerance arithmetic, tables of at most 32 genotypes");
     __shared__ double sh_acc[4][TILE_R_MAX][A][64];
@@ -753,7 +760,7 @@ __global__ __launch_bounds__(256) void k_estep_tiled(EstepArgs a)
     const int R = a.bin_rows_cap;
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const long long slot_id = (long long)blockIdx.x * 4 + wave;
-    if (FAST && guard_stand_back(a, true)) return;  // the E-step runs direct (EstepArgs::direct)
+    if (FAST && guard_stand_back(a)) return;  // the E-step runs direct (EstepArgs::direct)
     if (slot_id >= a.n_bins) return;
     const long long bin = a.bin_order[slot_id];
 
@@ -872,7 +879,7 @@ __global__ __launch_bounds__(256) void k_estep_block(EstepArgs a, int C, int k_b
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    if (FAST && guard_stand_back(a, k_base == 0)) return;  // the guarded E-step runs direct: EstepArgs::direct
+    if (FAST && guard_stand_back(a)) return;  // the guarded E-step runs direct: EstepArgs::direct
     if (a.order_count != nullptr && blockIdx.x >= *a.order_count) return;  // the exact redo of a guarded E-step: the queued barcodes only
     const long long b = a.order[blockIdx.x];
     const int K = a.K, G = a.G;
@@ -1009,7 +1016,7 @@ void k_estep_pairblocks(EstepArgs a, int C, int blk_base)
     constexpr int NO = R1 * R2;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    if (guard_stand_back(a, blk_base == 0)) return;  // the guarded E-step runs direct (EstepArgs::direct)
+    if (guard_stand_back(a)) return;  // the guarded E-step runs direct (EstepArgs::direct)
     const long long b = a.order[blockIdx.x];
     const int K = a.K, G = a.G;
     const int CS = C + 2;
@@ -1470,13 +1477,19 @@ hipError_t launch_guard_begin(hipStream_t st, unsigned *state, long long B, int 
 }
 
 // Between the fast launches and the exact launch of a guarded E-step: block q copies sub-queue q behind the sub-queues before
-// it (their lengths added up by every block for itself: 256 words), block 0 leaves the total and the wall clock.
-__global__ __launch_bounds__(256) void k_guard_compact(unsigned *st, const int *__restrict__ sub, unsigned cap, int *__restrict__ list)
+// it (their lengths added up by every block for itself: 256 words), block 0 leaves the total and the wall clock.  An E-step
+// that runs direct: the list becomes every barcode (EstepArgs::order_direct).
+__global__ __launch_bounds__(256) void k_guard_compact(unsigned *st, const int *__restrict__ sub, unsigned cap, int *__restrict__ list,
+                                                       const int *__restrict__ order_direct, unsigned B)
 {
     __shared__ unsigned before[4], all[4];
     const unsigned q = blockIdx.x;
-    if (st[GS_DIRECT] != 0u) {  // (uniform) the fast kernels stood back and listed every barcode
-        if (q == 0 && threadIdx.x == 0) st[GS_T_REDO] = (unsigned)wall_clock64();
+    if (st[GS_DIRECT] != 0u) {  // (uniform) the fast kernels stood back: the exact launch gets every barcode, longest rows first
+        for (unsigned i = q * 256u + threadIdx.x; i < B; i += GUARD_QUEUES * 256u) list[i] = order_direct[i];
+        if (q == 0 && threadIdx.x == 0) {
+            st[GS_COUNT] = B;
+            st[GS_T_REDO] = (unsigned)wall_clock64();
+        }
         return;
     }
     const unsigned len = st[GS_WORDS + GUARD_SLOTS + threadIdx.x];  // GUARD_QUEUES == 256 threads
@@ -1499,9 +1512,9 @@ __global__ __launch_bounds__(256) void k_guard_compact(unsigned *st, const int *
     }
 }
 
-hipError_t launch_guard_compact(hipStream_t st, unsigned *state, const int *sub, unsigned sub_cap, int *list)
+hipError_t launch_guard_compact(hipStream_t st, unsigned *state, const int *sub, unsigned sub_cap, int *list, const int *order_direct, long long B)
 {
-    hipLaunchKernelGGL(k_guard_compact, dim3(GUARD_QUEUES), dim3(256), 0, st, state, sub, sub_cap, list);
+    hipLaunchKernelGGL(k_guard_compact, dim3(GUARD_QUEUES), dim3(256), 0, st, state, sub, sub_cap, list, order_direct, (unsigned)B);
     return hipGetLastError();
 }
 
