@@ -698,10 +698,11 @@ namespace {
 // One wavefront per barcode: sort key (tile; `sentinel` for the padding calls) and tile-major record of every call of the row,
 // taken from the barcode-major E-step records (row offset -> variant, keep).  Written at the call's position in the
 // barcode-major order, so that a STABLE sort by the key alone leaves every tile's records in ascending barcode order.
+// tile_vin[v] = tile of variant v << 7 | its index inside the tile: ONE gather per call (the two tables took two: 157 M L2 requests,
+// which is what the kernel ran on)
 __global__ __launch_bounds__(256) void k_mtile_from_rows(const CallPair *__restrict__ pairs, const long long *__restrict__ pair_ptr,
-                                                         long long B, unsigned row_bytes, const unsigned *__restrict__ tile_of,
-                                                         const unsigned *__restrict__ vin_of, unsigned sentinel,
-                                                         unsigned *__restrict__ keys, unsigned long long *__restrict__ rec)
+                                                         long long B, unsigned row_bytes, const unsigned *__restrict__ tile_vin,
+                                                         unsigned sentinel, unsigned *__restrict__ keys, unsigned long long *__restrict__ rec)
 {
     const int lane = threadIdx.x & 63;
     const long long b = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -719,9 +720,9 @@ __global__ __launch_bounds__(256) void k_mtile_from_rows(const CallPair *__restr
             // the neutral calls that pad a row to 8 (keep 0, floor 1, row 0); a real call with p_base_wrong == 1 looks the same and
             // is dropped with them: it contributes (posterior x 0)^power = +0 to every sum
             const bool padding = keep[h] == 0u && floor_bits[h] == 0x3F800000u && row_off[h] == 0u;
-            const unsigned v = row_off[h] / row_bytes;
-            key[h] = padding ? sentinel : tile_of[v];
-            r[h] = (unsigned long long)((unsigned)b | (vin_of[v] << 24)) | ((unsigned long long)keep[h] << 32);
+            const unsigned tv = tile_vin[row_off[h] / row_bytes];
+            key[h] = padding ? sentinel : tv >> 7;
+            r[h] = (unsigned long long)((unsigned)b | ((tv & 127u) << 24)) | ((unsigned long long)keep[h] << 32);
         }
         *(uint2 *)(keys + 2 * (p0 + j)) = make_uint2(key[0], key[1]);
         *(ulonglong2 *)(rec + 2 * (p0 + j)) = make_ulonglong2(r[0], r[1]);
@@ -848,13 +849,13 @@ int build_mstep_tiles(dmx_ctx *c, long long v_lo, long long v_hi)
         DMX_TRY(sc.get(&keys, n));
         DMX_TRY(sc.get(&keys_out, n));
         DMX_TRY(sc.get(&vals, n));
+        for (long long v = 0; v < V; v++) tile_of[(size_t)v] = (tile_of[(size_t)v] << 7) | vin_of[(size_t)v];  // (vin < 128 = MTILE_MAX_VARIANTS)
         HIP_TRY(hipMemcpyAsync(d_tile_of, tile_of.data(), sizeof(unsigned) * V, hipMemcpyHostToDevice, st));
-        HIP_TRY(hipMemcpyAsync(d_vin_of, vin_of.data(), sizeof(unsigned) * V, hipMemcpyHostToDevice, st));
         DMX_TRY(dev_alloc(c, &vals_out, n));
         c->d_mt_stream = (uint2 *)vals_out;
         c->n_mt_stream = (long long)n;
         hipLaunchKernelGGL(k_mtile_from_rows, dim3((unsigned)((c->B + 3) / 4)), dim3(256), 0, st, c->d_call_pairs, c->d_pair_ptr, c->B,
-                           (unsigned)G * 4u, d_tile_of, d_vin_of, (unsigned)n_mt, keys, vals);
+                           (unsigned)G * 4u, d_tile_of, (unsigned)n_mt, keys, vals);
         DMX_TRY(sort_pairs64(sc, keys, keys_out, vals, vals_out, n, bits_for((unsigned long long)n_mt), st));
         DMX_TRY(dev_alloc(c, &c->d_mt_ptr, (size_t)n_mt + 1));
         hipLaunchKernelGGL(k_tile_ptr, dim3(grid_for(n_mt + 1)), dim3(256), 0, st, keys_out, (long long)n, n_mt, c->d_mt_ptr);
