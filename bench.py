@@ -535,7 +535,7 @@ def main():
     ap.add_argument('--mstep', default='auto', choices=['auto', 'tiles', 'items'],
                     help='M-step form of the timed regions.  auto (default): the LIBRARY decides, as it does for a learn_genotypes call - it is '
                          'told how many iterations this run makes (warm-up + steps: dmx_set_msteps_expected, what a front-end looping over EM '
-                         'iterations knows) and builds the tile-major records at the first M-step when 9 or more are to come; the build then '
+                         'iterations knows) and builds the tile-major records at the first M-step when 8 or more are to come; the build then '
                          'falls into the warm-up and the line reports it (mstep_records_build_ms, ms_per_step_incl_record_build).  tiles / '
                          'items: the form forced')
     ap.add_argument('--deadline', type=float, default=1500.0,
@@ -651,10 +651,10 @@ def main():
         return time.perf_counter() - t
 
     # The M-step form is the library's own choice (include/demux_hip.h: dmx_set_mstep_tiles): it builds the tile-major records
-    # (a 3 ms sort of the calls; an M-step then takes 0.34 instead of 0.70 ms) at the first M-step that has 9 or more still to
+    # (a 2.6 ms sort of the calls; an M-step then takes 0.34 instead of 0.70 ms) at the first M-step that has 8 or more still to
     # come.  This run tells it how many it will make - warm-up + steps, as learn_genotypes(n_iterations=...) does through
     # dmx_em - so the build falls into the warm-up; its cost is reported next to the steady-state figure, and the line
-    # carries the work-item form's figure too (`work_item_mstep`: what runs of fewer than 9 M-steps take).
+    # carries the work-item form's figure too (`work_item_mstep`: what runs of fewer than 8 M-steps take).
     if args.mstep == 'tiles':
         ctx.set_mstep_tiles('always')
     elif args.mstep == 'items':
@@ -812,8 +812,8 @@ def main():
             out[f'{mode}_mode'] = {k: v for k, v in region.items() if k != 'elapsed'}
         if work_item_region:
             out['work_item_mstep'] = {k: v for k, v in work_item_region.items() if k != 'elapsed'}
-            out['work_item_mstep']['note'] = ('the same timed region with the work-item M-step, the form of runs with fewer than 9 M-steps '
-                                              'ahead (the tile-major records cost a 3 ms sort of the calls to build)')
+            out['work_item_mstep']['note'] = ('the same timed region with the work-item M-step, the form of runs with fewer than 8 M-steps '
+                                              'ahead (the tile-major records cost a 2.6 ms sort of the calls to build)')
         if hard:
             out['hard_workload'] = hard
         if predict:

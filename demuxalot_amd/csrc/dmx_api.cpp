@@ -1351,11 +1351,11 @@ int run_mstep(dmx_ctx *c, float power)
     // tile-major form (kernels.h: MTileArgs): sums in any order, so not with the exact additions; built on first use
     a.tiles_done = false;
     dmx::MTileArgs tiles{};
-    // Building the records (a sort of the calls: 3.0 ms on 200k x 100k x 64, where an M-step + combine then takes 0.34 instead of
+    // Building the records (a sort of the calls: 2.6 ms on 200k x 100k x 64, where an M-step + combine then takes 0.34 instead of
     // 0.70 ms) pays from MSTEP_TILES_PAY M-steps on: taken when that many are still to come - in the running dmx_em /
     // dmx_run_iterations call, or as the caller announced (dmx_set_msteps_expected) -, or the problem has seen that many
     // already (somebody iterates call by call), or always (dmx_set_mstep_tiles(ctx, 2)).
-    constexpr int MSTEP_TILES_PAY = 9;
+    constexpr int MSTEP_TILES_PAY = 8;
     const long long ahead = std::max<long long>(c->msteps_ahead, c->msteps_expected);
     const bool tiles_wanted = c->mstep_tiles == 2 || (c->mstep_tiles == 1 && (c->n_mt > 0 || ahead >= MSTEP_TILES_PAY ||
                                                                              c->msteps_done >= MSTEP_TILES_PAY));

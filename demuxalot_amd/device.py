@@ -477,7 +477,7 @@ class DeviceContext:
         check(self._lib.dmx_set_mstep_wide_addresses(self._h, int(bool(wide))))
 
     def set_mstep_tiles(self, mode):
-        """Tile-major form of the M-step: 'never' | 'auto' (default: when building its records pays, i.e. from 9 M-steps on) |
+        """Tile-major form of the M-step: 'never' | 'auto' (default: when building its records pays, i.e. from 8 M-steps on) |
         'always' (at the first M-step); needs the exact additions off and G <= 64.  include/demux_hip.h: dmx_set_mstep_tiles."""
         if isinstance(mode, str):
             mode = {'never': 0, 'auto': 1, 'always': 2}[mode]

@@ -167,9 +167,9 @@ int dmx_get_redo_count(dmx_ctx *ctx, int64_t *count);
  * rint(c 2^s), s = 50 for all but the hottest tiles): independent of the order of the additions, so bit-reproducible from run
  * to run like the reference's np.bincount (utils.py:35-36), exact for contributions of 2^-27 and more, and within one float32
  * ulp + n 2^-(s + 1) (n calls of the variant) of the reference's float64 sum in general.  Building the records is a sort of
- * the calls (3.0 ms on 200k x 100k x 64, where an M-step then takes 0.34 instead of 0.70 ms), so
- *   1 (default) builds them at the first M-step that has 9 or more M-steps still to come - in the running dmx_em /
- *     dmx_run_iterations call, or announced with dmx_set_msteps_expected -, or when the resident problem has seen 9;
+ * the calls (2.6 ms on 200k x 100k x 64, where an M-step then takes 0.34 instead of 0.70 ms), so
+ *   1 (default) builds them at the first M-step that has 8 or more M-steps still to come - in the running dmx_em /
+ *     dmx_run_iterations call, or announced with dmx_set_msteps_expected -, or when the resident problem has seen 8;
  *   2 at the first M-step;  0 never (the work-item form).
  * dmx_set_msteps_expected: a hint - the caller will run about n more M-steps on the resident problem (a front-end that drives
  * the iterations call by call, a benchmark that warms up first); counted down as M-steps run.
