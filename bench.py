@@ -283,7 +283,8 @@ def live_counters(args, problem_dir):
     if nested or 'rocprof' in os.environ.get('LD_PRELOAD', ''):
         return {'skipped': f'this run is itself under a profiler ({nested or "LD_PRELOAD"})'}
     out_dir = tempfile.mkdtemp(prefix='bench_pmc_', dir='/tmp')
-    child = [sys.executable, os.path.join(ROOT, 'bench.py'), '--workload', args.workload, '--steps', '2', '--warmup', '1', '--timed-only']
+    # (6 + 2 iterations: calls whose E-steps but the last may take the coarse pass - the dominant kernel of the timed region is the child's too)
+    child = [sys.executable, os.path.join(ROOT, 'bench.py'), '--workload', args.workload, '--steps', '6', '--warmup', '2', '--timed-only']
     child += ['--flat-genotypes'] if args.flat_genotypes else []
     env = dict(os.environ, TMPDIR='/tmp', DEMUXALOT_BENCH_PROBLEM=problem_dir)
     found = {}
@@ -333,13 +334,13 @@ def live_counters(args, problem_dir):
         shutil.rmtree(out_dir, ignore_errors=True)
 
 
-def roofline(ab, e_ms, N, G, K, live):
+def roofline(ab, e_ms, N, G, K, live, coarse_share=0.0):
     """The contract's HBM figures for the E-step of the timed iterations on ALGORITHMIC bytes, the ops roofline of
     SURVEY.md 8d (log terms against the v_log_f32 issue peak), and what the kernel actually runs on: the genotype-row
     gather out of L2 (guarded / tolerance mode) or VALU issue (exact mode) - `valu.busy` from the live counters."""
     achieved = ab['estep'] / (e_ms * 1e-3) / 1e9
     terms_per_s = N * K / (e_ms * 1e-3)
-    delivered = (N * 4 * G) / (e_ms * 1e-3) / 1e9
+    delivered = (N * (4 - 2 * coarse_share) * G) / (e_ms * 1e-3) / 1e9   # (the coarse pass gathers binary16 rows)
     out = {
         'bound': 'hbm', 'kernel': live.get('kernel'), 'achieved': achieved, 'peak': 8000.0, 'unit': 'GB/s', 'frac': achieved / 8000.0,
         'traffic': live.get('traffic'),
@@ -350,7 +351,8 @@ def roofline(ab, e_ms, N, G, K, live):
                         'tolerance mode takes one hardware log2 per 8 terms, the exact mode repeats numpy\'s float32 log (16 VALU '
                         'instructions per term)'},
         'l2_gather': {'delivered_GBps': delivered, 'all_hit_rate_GBps': L2_GATHER_ALL_HIT_GBPS, 'frac': delivered / L2_GATHER_ALL_HIT_GBPS,
-                      'note': 'N x 4G bytes of genotype rows per E-step, gathered out of L2 / Infinity Cache (the table fits no L2); '
+                      'coarse_pass_share_of_the_esteps': coarse_share,
+                      'note': 'N x 4G bytes (coarse pass: N x 2G) of genotype rows per E-step, gathered out of L2 / Infinity Cache (the table fits no L2); '
                               'the all-hit rate is the same loop on an L2-resident table (DESIGN.md 4.1)'},
         'valu': {k: live[k] for k in ('valu_busy', 'clock_ghz', 'cycles_per_launch', 'SQ_ACTIVE_INST_VALU', 'kernel_ns_under_tracer') if k in live},
         'note': 'frac = algorithmic bytes / E-step time / 8 TB/s as the contract defines it; the E-step re-reads a 256-byte table '
@@ -469,7 +471,7 @@ def hard_workload(args, ctx, whole, betas, pen, dp):
                 ctx.set_msteps_expected(args.warmup + args.steps)
             region = timed_region(ctx, None, args.steps, args.warmup)
             _direct, direct_steps, would, fast_ms, exact_ms = ctx.guard_state()
-            res[name] = {'ms_per_step': region['ms_per_step'], 'kernel_ms': region['kernel_ms'], 'guard': region['guard'],
+            res[name] = {'ms_per_step': region['ms_per_step'], 'kernel_ms': region['kernel_ms'], 'guard': region['guard'], 'estep_passes': region['estep_passes'],
                          'first_estep_queued_fraction': first_queued / problem.n_barcodes, 'esteps_run_direct': direct_steps, 'steps': args.steps,
                          'last_estep_would_queue_fraction': would / problem.n_barcodes,
                          'device_timed_ms': {'fast_pass_all_barcodes': fast_ms, 'exact_kernel_all_barcodes': abs(exact_ms),
@@ -512,7 +514,11 @@ def timed_region(ctx, plane, steps, warmup):
         elapsed = plane.max_float64(elapsed)
     timers = ctx.timings()
     _redone, redone_total, rows = ctx.guard_stats()
+    levels = ctx.guard_levels()
     return {'elapsed': elapsed, 'ms_per_step': 1e3 * elapsed / steps, 'em_iterations_per_s': steps / elapsed,
+            'estep_passes': {'coarse': levels['coarse_steps'], 'of': steps, 'last': {0: 'coarse', 1: 'fine', 2: 'direct'}.get(levels['level'], 'not guarded'),
+                             'device_timed_ms': {'coarse_pass': levels['coarse_pass_ms'], 'fine_pass': levels['fine_pass_ms'], 'exact_kernel': abs(levels['exact_pass_ms'])},
+                             'last_estep_flagged': {'fine_guard': levels['flagged_fine'], 'coarse_guard': levels['flagged_coarse']}},
             'kernel_ms': {k: (v['ms'] / max(1, v['launches'])) for k, v in timers.items()},
             'exchange_ms_per_step': timers['allreduce']['ms'] / max(1, steps),
             'guard': {'barcodes_redone_exactly': redone_total, 'barcode_rows': rows, 'fraction': redone_total / max(1, rows)}}
@@ -728,6 +734,18 @@ def main():
         work_item_region['scaling'] = kinds[-1]
         ctx.set_mstep_tiles('always' if args.mstep == 'tiles' else 'auto')
 
+    fine_only_region = None
+    if not args.timed_only and default_mode == 'guarded' and regions[kinds[-1]]['estep_passes']['coarse'] > 0:
+        phase('default mode without the coarse pass: timed region')
+        ctx.set_coarse_pass(False)
+        ctx.set_addition(None)
+        ctx.probs_from_betas(0.01, fetch=False)
+        ctx.estep(pen, with_doublets=dp > 0, fetch_logits=False, fetch_probs=False)
+        fine_only_region = timed_region(ctx, plane, args.steps, args.warmup)
+        fine_only_region['value'] = regions[kinds[-1]]['barcodes_total'] * args.steps / fine_only_region['elapsed']
+        fine_only_region['scaling'] = kinds[-1]
+        ctx.set_coarse_pass(True)
+
     # predict_posteriors throughput on the same resident problem (P + E only, no beta addition: demux.py:120-156),
     # rank-local.  The genotype table is then the importers' (a handful of distinct values per row), which is the
     # case the dictionary form of the exact E-step exists for (csrc/estep_dict.hip); timed with the form on (default)
@@ -768,7 +786,9 @@ def main():
         ab = algorithmic_bytes(B, V, G, K, N)
         e_ms = regions[kinds[-1]]['kernel_ms']['estep']
         mode_notes = {'guarded': ': contract of the path proven per barcode and E-step, the rest redone bit-exactly (include/demux_hip.h '
-                                 'DMX_ESTEP_GUARDED); exact_mode = everything bit-identical to the reference',
+                                 'DMX_ESTEP_GUARDED); E-steps whose logits nobody can read - all but the last of a call: estep_passes - may take the '
+                                 'coarse pass (genotype table as binary16, dmx_set_coarse_pass), the timed region is ONE dmx_run_iterations call of '
+                                 '`steps` iterations; exact_mode = everything bit-identical to the reference',
                       'exact': ': logits, posteriors and additions bit-identical to the reference',
                       'fast': ': tolerance mode without the guard'}
         out = {
@@ -801,6 +821,7 @@ def main():
             'kernel_ms': head['kernel_ms'],
             'exchange_ms_per_step': head['exchange_ms_per_step'],
             'guard': head['guard'],
+            'estep_passes': head['estep_passes'],
             'setup_s': {'problem': t_gen, 'problem_source': problem_source, 'upload': t_up},
         }
         if 'weak' in regions and head_kind != 'weak':
@@ -814,6 +835,10 @@ def main():
             out['work_item_mstep'] = {k: v for k, v in work_item_region.items() if k != 'elapsed'}
             out['work_item_mstep']['note'] = ('the same timed region with the work-item M-step, the form of runs with fewer than 8 M-steps '
                                               'ahead (the tile-major records cost a 2.6 ms sort of the calls to build)')
+        if fine_only_region:
+            out['without_coarse_pass'] = {k: v for k, v in fine_only_region.items() if k != 'elapsed'}
+            out['without_coarse_pass']['note'] = ('the same timed region with dmx_set_coarse_pass(0): every E-step the fine pass on the float32 table (the default mode of round 4; '
+                                                  'what the LAST E-step of every call runs in any case - its logits are the ones a caller can read)')
         if hard:
             out['hard_workload'] = hard
         if predict:
@@ -832,7 +857,8 @@ def main():
                 if own:
                     import shutil
                     shutil.rmtree(cache, ignore_errors=True)
-        out['roofline'] = roofline(ab, e_ms, N, G, K, live)
+        passes = regions[kinds[-1]].get('estep_passes', {})
+        out['roofline'] = roofline(ab, e_ms, N, G, K, live, coarse_share=passes.get('coarse', 0) / max(1, passes.get('of', 1)))
         if world == 1 and not args.no_e2e and not args.flat_genotypes and N > 200_000_000:
             out['e2e'] = {'skipped': 'the object form of an experiment of this size (1.3 M dictionary entries, 1 M barcode strings, 4e8 container records) is '
                                      'minutes of Python before any call is made'}

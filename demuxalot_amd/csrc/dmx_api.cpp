@@ -455,6 +455,9 @@ void release_problem(dmx_ctx *c)
     dev_free(c, &c->d_prior, vg);
     dev_free(c, &c->d_add, vg);
     dev_free(c, &c->d_prob, (size_t)c->prob_rows * c->G);
+    dev_free(c, &c->d_prob16, c->cap_prob16);
+    c->cap_prob16 = 0;
+    c->prob16_valid = false;
     dev_free(c, &c->d_add64, vg);
     dev_free(c, &c->d_prow, (size_t)c->V);
     if (c->d_exch) {
@@ -1064,6 +1067,7 @@ int run_pstep(dmx_ctx *c, float lo, float hi, bool with_addition)
         if (rc) return rc;
     }
     c->have_probs = true;
+    c->p_clip_lo = lo;
     c->dict_candidate = !with_addition || c->add_is_zero;
     return 0;
 }
@@ -1131,7 +1135,9 @@ int prepare_dictionary(dmx_ctx *c, bool pairs, dmx::EstepArgs &a, int *form)
     return 0;
 }
 
-int run_estep(dmx_ctx *c, int with_doublets, bool with_prior, int prior_dtype, float power)
+// logits_kept: somebody can read this E-step's logits (it is the last one of the call); else the next E-step of the same call
+// overwrites them, and the guarded mode may take the coarse pass (kernels.hip: k_estep_tiled_coarse)
+int run_estep(dmx_ctx *c, int with_doublets, bool with_prior, int prior_dtype, float power, bool logits_kept = true)
 {
     dmx::EstepArgs a;
     a.pair_ptr = c->d_pair_ptr;
@@ -1141,6 +1147,11 @@ int run_estep(dmx_ctx *c, int with_doublets, bool with_prior, int prior_dtype, f
     const unsigned long long rec_bytes = ((unsigned long long)c->n_pairs + dmx::CALL_PAD_PAIRS) * sizeof(dmx::CallPair);
     a.pairs_bytes = rec_bytes < (1ull << 32) ? (unsigned)rec_bytes : 0u;
     a.prob = c->d_prob;
+    a.prob16 = nullptr;
+    a.guard_accum = 0.0f;
+    a.guard_alt_per_call = 0.0f;
+    a.guard_alt_accum = 0.0f;
+    a.guard_main_coarse = 0;
     a.opt_pairs = c->d_pairs;
     a.pair_blocks = with_doublets ? c->d_pair_blocks : nullptr;
     a.n_pair_blocks = with_doublets ? c->n_pair_blocks : 0;
@@ -1242,13 +1253,43 @@ int run_estep(dmx_ctx *c, int with_doublets, bool with_prior, int prior_dtype, f
             // return at once); the redo rewrites logits, posteriors, bitmaps and codes of those barcodes.  Adaptive
             // (kernels.h: EstepArgs::direct): after an E-step that queued more than 40 % of the barcodes the fast kernels
             // stand back and the exact launch walks every barcode - decided on the device by k_guard_begin.
-            HIP_TRY(dmx::launch_guard_begin(c->stream, c->d_guard_count, c->B, c->K, c->guard_adaptive));
+            // The coarse pass (kernels.hip: k_estep_tiled_coarse; singlets, 33 .. 64 genotypes, the tile-major schedule, a P-step's
+            // table whose clip keeps binary16 normal) is admissible when nobody can read this E-step's logits.  Which of coarse pass,
+            // fine pass and the direct form runs is the device's choice (k_guard_begin): both fast launches are issued, the one
+            // that is not taken stands back.
+            const bool capable = c->coarse_pass && !with_doublets && c->K > 32 && c->K <= 64 && a.n_bins > 0 && c->p_clip_lo >= 6.2e-5f;
+            const bool allow_coarse = capable && (!logits_kept || c->coarse_pass == 2);
+            HIP_TRY(dmx::launch_guard_begin(c->stream, c->d_guard_count, c->B, c->K, c->guard_adaptive, capable, allow_coarse));
             a.guard = 1;
-            a.direct = c->d_guard_count + dmx::GS_DIRECT;
             a.order_direct = c->d_bc_order;
+            a.guard_main_coarse = 0;
+            a.guard_alt_per_call = capable ? dmx::GUARD_PER_CALL_COARSE : 0.0f;
+            a.guard_alt_accum = capable ? dmx::GUARD_ACCUM_F32 : 0.0f;
+            if (allow_coarse) {
+                const size_t need = (size_t)c->prob_rows * c->G * 2;
+                if (need > c->cap_prob16) {
+                    dev_free(c, &c->d_prob16, c->cap_prob16);
+                    c->cap_prob16 = 0;
+                    DMX_TRY(dev_alloc(c, &c->d_prob16, need));
+                    c->cap_prob16 = need;
+                    HIP_TRY(hipMemsetAsync(c->d_prob16, 0, need * sizeof(unsigned short), c->stream));
+                }
+                HIP_TRY(dmx::launch_prob_to_half(c->stream, c->d_prob, c->prob_rows, c->G, c->d_prob16, c->d_guard_count + dmx::GS_SKIP_COARSE));
+                dmx::EstepArgs coarse = a;
+                coarse.prob16 = c->d_prob16;
+                coarse.guard_per_call = dmx::GUARD_PER_CALL_COARSE;
+                coarse.guard_accum = dmx::GUARD_ACCUM_F32;
+                coarse.guard_main_coarse = 1;
+                coarse.guard_alt_per_call = a.guard_per_call;
+                coarse.guard_alt_accum = 0.0f;
+                coarse.direct = c->d_guard_count + dmx::GS_SKIP_COARSE;
+                HIP_TRY(dmx::launch_estep(c->stream, coarse, false));
+            }
+            a.direct = c->d_guard_count + dmx::GS_SKIP_FINE;
             HIP_TRY(dmx::launch_estep(c->stream, a, with_doublets != 0));
             HIP_TRY(dmx::launch_guard_compact(c->stream, c->d_guard_count, c->d_guard_sub, c->guard_sub_cap, c->d_guard_list, c->d_bc_order, c->B));
             dmx::EstepArgs redo = a;
+            redo.direct = c->d_guard_count + dmx::GS_DIRECT;
             redo.fast = 0;
             redo.guard = 2;
             redo.n_bins = 0;
@@ -1722,7 +1763,7 @@ int dmx_set_estep_mode(dmx_ctx *c, int mode)
     return 0;
 }
 
-static int read_guard_state(dmx_ctx *c, unsigned (&st)[dmx::GS_WORDS], long long *count)
+static int read_guard_state(dmx_ctx *c, unsigned (&st)[dmx::GS_WORDS], long long *count, long long *count_fine = nullptr, long long *count_coarse = nullptr)
 {
     std::vector<unsigned> all((size_t)dmx::GUARD_STATE_WORDS, 0u);
     if (c->d_guard_count) {
@@ -1730,8 +1771,19 @@ static int read_guard_state(dmx_ctx *c, unsigned (&st)[dmx::GS_WORDS], long long
         HIP_TRY(hipStreamSynchronize(c->stream));
     }
     for (int i = 0; i < dmx::GS_WORDS; i++) st[i] = all[(size_t)i];
-    *count = st[dmx::GS_DIRECT] ? 0 : st[dmx::GS_COUNT];  // (a direct E-step's queue holds every barcode; it counts on the hashed slots)
-    for (int i = 0; i < dmx::GUARD_SLOTS; i++) *count += all[(size_t)dmx::GS_WORDS + i];
+    // the last E-step's flags: the guard of the pass that ran filled the queue, the other guard (a direct E-step: both) counted on its
+    // hashed slots (k_guard_begin of the next E-step adds them up and clears them)
+    long long hashed_fine = 0, hashed_coarse = 0;
+    for (int i = 0; i < dmx::GUARD_SLOTS; i++) {
+        hashed_fine += all[(size_t)dmx::GS_SLOTS_FINE + i];
+        hashed_coarse += all[(size_t)dmx::GS_SLOTS_COARSE + i];
+    }
+    const unsigned level = st[dmx::GS_LEVEL];
+    const long long fine = level == 1u ? (long long)st[dmx::GS_COUNT] : hashed_fine;
+    const long long coarse = level == 0u ? (long long)st[dmx::GS_COUNT] : (st[dmx::GS_CAPABLE] ? hashed_coarse : -1);
+    *count = level == 0u ? coarse : fine;  // of the pass that ran (direct: what the fine pass would have queued)
+    if (count_fine) *count_fine = fine;
+    if (count_coarse) *count_coarse = coarse;
     return 0;
 }
 
@@ -1747,6 +1799,14 @@ int dmx_get_guard_stats(dmx_ctx *c, int64_t *redone_last, int64_t *redone_total,
     if (redone_last) *redone_last = c->guard_ran ? (int64_t)last : 0;
     if (redone_total) *redone_total = (int64_t)total;
     if (rows_total) *rows_total = (int64_t)c->guard_rows_total;
+    return 0;
+}
+
+int dmx_set_coarse_pass(dmx_ctx *c, int coarse)
+{
+    if (!c) return fail(DMX_ERR_INVALID, "null context");
+    if (coarse < 0 || coarse > 2) return fail(DMX_ERR_INVALID, "coarse pass: 0 never, 1 where the logits are not read, 2 wherever the shape allows");
+    c->coarse_pass = coarse;
     return 0;
 }
 
@@ -1771,6 +1831,26 @@ int dmx_get_guard_direct(dmx_ctx *c, int32_t *last_ran_direct, int64_t *direct_s
     HIP_TRY(hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, c->device));
     const double ms_per_tick = khz > 0 ? 1.0 / (double)khz : 0.0;
     if (fast_pass_ms) *fast_pass_ms = st[dmx::GS_F_TICKS] * ms_per_tick;
+    if (exact_pass_ms) *exact_pass_ms = (st[dmx::GS_E_MEASURED] ? 1.0 : -1.0) * st[dmx::GS_E_TICKS] * ms_per_tick;
+    return 0;
+}
+
+int dmx_get_guard_levels(dmx_ctx *c, int32_t *level_last, int64_t *coarse_steps, int64_t *flagged_fine_last, int64_t *flagged_coarse_last,
+                         double *coarse_pass_ms, double *fine_pass_ms, double *exact_pass_ms)
+{
+    DMX_TRY(bind(c));
+    unsigned st[dmx::GS_WORDS];
+    long long count = 0, fine = 0, coarse = 0;
+    DMX_TRY(read_guard_state(c, st, &count, &fine, &coarse));
+    if (level_last) *level_last = c->guard_ran ? (int32_t)st[dmx::GS_LEVEL] : -1;
+    if (coarse_steps) *coarse_steps = (int64_t)st[dmx::GS_COARSE_STEPS];
+    if (flagged_fine_last) *flagged_fine_last = c->guard_ran ? (int64_t)fine : 0;
+    if (flagged_coarse_last) *flagged_coarse_last = c->guard_ran ? (int64_t)coarse : -1;
+    int khz = 0;
+    HIP_TRY(hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, c->device));
+    const double ms_per_tick = khz > 0 ? 1.0 / (double)khz : 0.0;
+    if (coarse_pass_ms) *coarse_pass_ms = st[dmx::GS_C_TICKS] * ms_per_tick;
+    if (fine_pass_ms) *fine_pass_ms = st[dmx::GS_F_TICKS] * ms_per_tick;
     if (exact_pass_ms) *exact_pass_ms = (st[dmx::GS_E_MEASURED] ? 1.0 : -1.0) * st[dmx::GS_E_TICKS] * ms_per_tick;
     return 0;
 }
@@ -2007,6 +2087,7 @@ int dmx_set_probs(dmx_ctx *c, const float *prob)
     HIP_TRY(hipStreamSynchronize(c->stream));
     if (flag) return fail(DMX_ERR_INVALID, "genotype_prob has entries outside [0, 1] (or NaN)");
     c->have_probs = true;
+    c->p_clip_lo = 0.0f;  // (a caller's table: entries may lie below binary16's normal range - no coarse pass)
     c->dict_candidate = true;
     return 0;
 }
@@ -2030,6 +2111,7 @@ int dmx_probs_from_betas_f64(dmx_ctx *c, const double *betas, float lo, float hi
     if (e != hipSuccess) return fail(DMX_ERR_HIP, "P-step from float64 betas: %s", hipGetErrorString(e));
     if (rc_copy) return rc_copy;
     c->have_probs = true;
+    c->p_clip_lo = lo;
     c->dict_candidate = true;
     return 0;
 }
@@ -2077,7 +2159,7 @@ int dmx_em(dmx_ctx *c, int n_iterations, float lo, float hi, int with_doublets, 
     c->add_partial = false;
     for (int it = 0; it < n_iterations; it++) {
         DMX_TRY(run_pstep(c, lo, hi, true));
-        DMX_TRY(run_estep(c, with_doublets, it == 0 && prior_logits != nullptr, prior_dtype, power));
+        DMX_TRY(run_estep(c, with_doublets, it == 0 && prior_logits != nullptr, prior_dtype, power, it + 1 == n_iterations));
         if (it + 1 < n_iterations) {  // the M-step after the last yield is dead
             c->msteps_ahead = n_iterations - 1 - it;
             const int rc_m = run_mstep(c, power);
@@ -2103,7 +2185,7 @@ int dmx_run_iterations(dmx_ctx *c, int n_iterations, float lo, float hi, float p
     const int with_doublets = c->K != c->G;
     for (int it = 0; it < n_iterations; it++) {
         DMX_TRY(run_pstep(c, lo, hi, true));
-        DMX_TRY(run_estep(c, with_doublets, false, DMX_F32, power));
+        DMX_TRY(run_estep(c, with_doublets, false, DMX_F32, power, it + 1 == n_iterations));
         c->msteps_ahead = n_iterations - it;
         const int rc_m = run_mstep(c, power);
         c->msteps_ahead = 0;
@@ -2303,6 +2385,7 @@ int dmx_reset_timings(dmx_ctx *c)
     HIP_TRY(hipStreamSynchronize(c->stream));
     // the totals; the last E-step's own numbers stay (they decide how the next one runs: kernels.hip k_guard_begin)
     if (c->d_guard_count) HIP_TRY(hipMemsetAsync(c->d_guard_count + dmx::GS_PENDING, 0, 4 * sizeof(unsigned), c->stream));  // GS_PENDING, GS_DIRECT_STEPS, GS_TOTAL
+    if (c->d_guard_count) HIP_TRY(hipMemsetAsync(c->d_guard_count + dmx::GS_COARSE_STEPS, 0, sizeof(unsigned), c->stream));
     c->guard_rows_total = 0;
     for (int s = 0; s < DMX_T_COUNT; s++) {
         timer_flush(c, s);

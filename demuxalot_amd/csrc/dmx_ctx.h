@@ -65,6 +65,11 @@ struct dmx_ctx {
     dmx::CallPair *d_tile_stream = nullptr;  // the E-step records once more, in the order the bins consume them
     int *d_v2snp = nullptr, *d_snp_ptr = nullptr, *d_snp_vars = nullptr;
     float *d_prior = nullptr, *d_add = nullptr, *d_prob = nullptr;
+    unsigned short *d_prob16 = nullptr;  // d_prob as binary16 at the same row offsets (the coarse pass of the guarded E-step), cap_prob16 values
+    size_t cap_prob16 = 0;
+    bool prob16_valid = false;           // ... and it holds the current d_prob
+    int coarse_pass = 1;                 // dmx_set_coarse_pass
+    float p_clip_lo = 0.0f;              // lower clip of the P-step that produced d_prob (0: a caller's table, dmx_set_probs)
     double *d_add64 = nullptr, *d_partial = nullptr;
     float *d_logits = nullptr, *d_post = nullptr;
     unsigned long long *d_nz = nullptr;

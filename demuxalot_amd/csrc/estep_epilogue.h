@@ -239,13 +239,15 @@ static __device__ __forceinline__ bool estep_guard(const float (&dev)[A], const 
 #pragma unroll
     for (int s = 0; s < A; s++) {
         if (!valid[s]) continue;
-        bad |= !(dev[s] < 0.25f);  // also NaN; keeps e^x - 1 <= x (1 + x) applicable below
+        bad |= !(dev[s] < 40.0f);  // also NaN; e^{2D} stays finite below
         dmax = fmaxf(dmax, dev[s]);
     }
 #pragma unroll
     for (int off = 1; off < L; off <<= 1) dmax = fmaxf(dmax, __shfl_xor(dmax, off));
     const float x2 = 2.0f * dmax;
-    const float e2 = x2 * (1.0f + x2) * 1.000001f;               // >= e^{2D} - 1
+    // >= e^{2D} - 1: x (1 + x) while 2 D < 0.5 (every form but the coarse pass, whose D grows by 2^-9 per call: k_estep_tiled_coarse),
+    // else the hardware's 2^x (within 1 ulp) of an exponent rounded up, with a margin of 2e-5 relative
+    const float e2 = dmax < 0.25f ? x2 * (1.0f + x2) * 1.000001f : __builtin_amdgcn_exp2f(x2 * 1.4426953f) * 1.00002f - 1.0f;
     const float near = mx - (x2 + 2.4e-7f * fabsf(mx)) * 1.000001f;  // logits at or above this could be the reference's argmax
     int close = 0;
 #pragma unroll
@@ -263,13 +265,13 @@ static __device__ __forceinline__ bool estep_guard(const float (&dev)[A], const 
 // the sub-queue of its residue class, k_guard_compact makes the dense list of them), or - in the exact kernels of an E-step
 // that runs direct (a.guard == 2) - only counted, on hashed counters (200k atomics on one address took 0.65 ms;
 // k_guard_begin adds the slots up).
-static __device__ __forceinline__ void guard_note(const EstepArgs &a, long long b, bool counting)
+static __device__ __forceinline__ void guard_note(const EstepArgs &a, long long b, bool counting, bool coarse_set = false)
 {
     if (counting) {
-        atomicAdd(a.guard_count + GS_WORDS + (int)(b & (GUARD_SLOTS - 1)), 1u);
+        atomicAdd(a.guard_count + (coarse_set ? GS_SLOTS_COARSE : GS_SLOTS_FINE) + (int)(b & (GUARD_SLOTS - 1)), 1u);
     } else {
         const unsigned q = (unsigned)(b & (GUARD_QUEUES - 1));  // (at most ceil(B / GUARD_QUEUES) barcodes share a queue)
-        a.guard_sub[(size_t)q * a.guard_sub_cap + atomicAdd(a.guard_count + GS_WORDS + GUARD_SLOTS + q, 1u)] = (int)b;
+        a.guard_sub[(size_t)q * a.guard_sub_cap + atomicAdd(a.guard_count + GS_QUEUE_LEN + q, 1u)] = (int)b;
     }
 }
 // A fast kernel of a guarded E-step that runs direct (kernels.h: EstepArgs::direct) stands back: k_guard_compact, between it
@@ -345,15 +347,26 @@ static __device__ __forceinline__ void estep_epilogue(const EstepArgs &a, long l
         const bool counting = a.guard == 2;
         float dev[A];  // bound on |logit - reference logit| per option
         const float n = (float)row_calls;
+        auto bound = [&](float per_call, float accum) {
 #pragma unroll
-        for (int s = 0; s < A; s++) {
-            const float l0 = (float)((double)a.pen[kk[s]] + acc[s]);
-            dev[s] = GUARD_RHO * (fabsf((float)acc[s]) + GUARD_POSITIVE_TERM * n) + a.guard_per_call * (n + 8.0f) + GUARD_LOGIT_ROUNDING * fabsf(l0);
-            if (a.prior) dev[s] += GUARD_LOGIT_ROUNDING * fabsf(lg[s]);
-        }
+            for (int s = 0; s < A; s++) {
+                const float l0 = (float)((double)a.pen[kk[s]] + acc[s]);
+                dev[s] = GUARD_RHO * (fabsf((float)acc[s]) + GUARD_POSITIVE_TERM * n) + per_call * (n + 8.0f) + GUARD_LOGIT_ROUNDING * fabsf(l0);
+                // a sum of n / 8 log2 values accumulated in float32: every addition rounds to 2^-24 of a partial sum, and the partial
+                // sums stay below |sum| + 2 x (the positive terms: < 1.5e-4 log2 units per call) - here in natural-log units
+                if (accum != 0.0f) dev[s] += accum * (0.125f * n + 2.0f) * (fabsf((float)acc[s]) + 3.0e-4f * n);
+                if (a.prior) dev[s] += GUARD_LOGIT_ROUNDING * fabsf(lg[s]);
+            }
+        };
+        bound(a.guard_per_call, a.guard_accum);
         const bool flagged = estep_guard<L, A>(dev, lg, post, valid, mx, gbase);
-        if (flagged && live && li == 0) guard_note(a, b, counting);
+        if (flagged && live && li == 0) guard_note(a, b, counting, a.guard_main_coarse != 0);
         redo = flagged && !counting;
+        if (a.guard_alt_per_call != 0.0f) {  // (uniform) what the other pass's guard would say of this barcode: counted only
+            bound(a.guard_alt_per_call, a.guard_alt_accum);
+            const bool flagged_alt = estep_guard<L, A>(dev, lg, post, valid, mx, gbase);
+            if (flagged_alt && live && li == 0) guard_note(a, b, true, a.guard_main_coarse == 0);
+        }
     }
     if (a.first) {
         // what the M-step's call-parallel part needs of this barcode, 8 bytes (nz_code): ONE gather per call there,

@@ -44,6 +44,8 @@ struct EstepArgs {
     const unsigned *call_rows;  // [2 * (n_pairs + CALL_PAD_PAIRS)] table row of every call of `pairs` (dictionary form)
     unsigned pairs_bytes;       // extent of `pairs` incl. the padding records when below 4 GiB (dictionary form: buffer addressing), else 0
     const float *prob;          // [V, G] genotype_prob, row-major
+    const unsigned short *prob16;  // nullable: the same table rounded to bfloat16 (round to nearest even), entry (row, g) at BYTE row * G * 4 + g * 2 -
+                                   // the float32 table's row offsets address it, half of every row's bytes are used (k_estep_tiled_coarse)
     const int *sum_plan;        // np.sum over a row of K values: {n_leaves, n_levels, n_roots, level offsets [n_levels + 1],
                                 // leaves (start, length), inner nodes (left value, right value) level by level, roots}
     int sum_plan_values;        // leaves + inner nodes
@@ -70,6 +72,11 @@ struct EstepArgs {
     int fast;                   // DMX_ESTEP_FAST: tolerance mode (products of 8 terms + hardware log2), see kernels.hip
     // guarded mode (DMX_ESTEP_GUARDED; estep_epilogue.h: guard_flags): the fast kernels bound their deviation from the
     // reference per barcode and queue the barcodes whose posteriors / argmax are not provably within the contract
+    float guard_accum;          // the guard's allowance for sums of log2 accumulated in float32 (k_estep_tiled_coarse), else 0: per addition
+                                // 2^-24 of the running sum (estep_epilogue.h)
+    float guard_alt_per_call;   // != 0: the OTHER pass's allowances (the fine pass: the coarse one's and vice versa; the exact kernels of a
+    float guard_alt_accum;      //   direct E-step: the coarse one's): that guard is evaluated too and its flags are counted (GS_SLOTS_*)
+    int guard_main_coarse;      // guard_per_call / guard_accum are the coarse pass's (the alternative is then the fine pass's)
     float guard_per_call;       // the guard's allowance per call for the fast arithmetic of the launching form (estep_epilogue.h: GUARD_PER_CALL,
                                 // GUARD_PER_CALL_PRESCALED for k_estep_pairblocks' pre-scaled rows)
     int guard;                  // 1: the epilogue evaluates the guard and appends to guard_list (the fast kernels of a guarded E-step);
@@ -145,14 +152,36 @@ enum { GS_COUNT = 0,         // barcodes queued by the current E-step (a direct 
        GS_E_MEASURED = 13,
        GS_O_TICKS = 14,      // duration of the exact launch on an empty queue
        GS_K = 15,            // option count of the finished E-step (another K: F and E start over)
-       GS_WORDS = 16 };
-constexpr int GUARD_SLOTS = 256;   // hashed counters behind the state words (counts of a direct E-step)
+       // Three levels (estep_epilogue.h; kernels.hip: k_guard_begin): 0 the COARSE pass (binary16 table: k_estep_tiled_coarse) + redo,
+       // 1 the FINE pass (the tolerance arithmetic on the float32 table) + redo, 2 DIRECT.  Whichever kernels run evaluate BOTH guards,
+       // so the queued fraction of either pass is known after every E-step, and both passes are timed when they run.
+       GS_LEVEL = 16,        // level of the current E-step
+       GS_SKIP_COARSE = 17,  // != 0: the coarse launch of the current E-step stands back (what its EstepArgs::direct points at)
+       GS_SKIP_FINE = 18,    // ... the fine launch
+       GS_C_TICKS = 19,      // duration of the coarse pass over all barcodes (0: not measured yet)
+       GS_COUNT_FINE = 20,   // barcodes the fine / the coarse guard flagged in the finished E-step (GS_UNKNOWN: not evaluated)
+       GS_COUNT_COARSE = 21,
+       GS_CAPABLE = 22,      // the current E-step evaluates the coarse guard too (the problem has a coarse pass)
+       GS_COARSE_STEPS = 23, // E-steps that took the coarse pass since the last reset
+       GS_WORDS = 24 };
+constexpr unsigned GS_UNKNOWN = 0xFFFFFFFFu;
+// The coarse pass (kernels.hip: k_estep_tiled_coarse) reads the genotype table as binary16, rounded to nearest: p' = p (1 + d), |d| <= 2^-11
+// for every p >= 2^-14 (normal range; run_estep checks the clip).  Its term fl(fl(p' keep) + floor) is the reference's operation sequence
+// on p', so it differs from the reference's term by at most 2^-11 (1 + 2^-23) + 2 x 2^-24 relative (the floor is >= 0 and exact), its log
+// by at most d / (1 - d): 4.8852e-4; then per call 7/8 float32 roundings of the 8-term product (5.3e-8) and 1/8 of v_log_f32's error on
+// a product in [1e-32, 256] - within 2 ulp of a result below 128 in magnitude (tests/test_gpu_guarded.py), 1.53e-5 log2 units = 1.06e-5: 1.33e-6.
+constexpr float GUARD_PER_CALL_COARSE = 4.905e-4f;
+constexpr float GUARD_ACCUM_F32 = 6.0e-8f;  // 2^-24, rounded up: per float32 addition of the running sum (estep_epilogue.h)
+constexpr int GUARD_SLOTS = 256;   // hashed counters behind the state words: barcodes flagged by a guard whose pass does not run (a direct
+                                   // E-step: both; a fine one: the coarse guard's; a coarse one: the fine guard's) - a set per guard
 constexpr int GUARD_QUEUES = 256;  // ... and behind those the lengths of the sub-queues (EstepArgs::guard_sub)
-constexpr int GUARD_STATE_WORDS = GS_WORDS + GUARD_SLOTS + GUARD_QUEUES;
+constexpr int GS_SLOTS_FINE = GS_WORDS, GS_SLOTS_COARSE = GS_WORDS + GUARD_SLOTS, GS_QUEUE_LEN = GS_WORDS + 2 * GUARD_SLOTS;
+constexpr int GUARD_STATE_WORDS = GS_WORDS + 2 * GUARD_SLOTS + GUARD_QUEUES;
 // between the fast launches and the exact launch of a guarded E-step: the sub-queues become the dense list, GS_COUNT their total
 // length, GS_T_REDO the wall clock (a direct E-step: the list becomes every barcode, order_direct)
 hipError_t launch_guard_compact(hipStream_t st, unsigned *state, const int *sub, unsigned sub_cap, int *list, const int *order_direct, long long B);
-hipError_t launch_guard_begin(hipStream_t st, unsigned *state, long long B, int K, int adaptive);
+// capable: the coming E-step evaluates the coarse guard too; allow_coarse: ... and may take the coarse pass (nobody reads its logits)
+hipError_t launch_guard_begin(hipStream_t st, unsigned *state, long long B, int K, int adaptive, int capable, int allow_coarse);
 hipError_t launch_guard_stamp(hipStream_t st, unsigned *state, int which);  // state[which] = the device's wall clock (GS_T_REDO, GS_T_END)
 
 constexpr int CALL_PAD_PAIRS = 64;     // readable neutral records behind the last barcode's row (pairs and call_rows)
@@ -234,6 +263,7 @@ hipError_t launch_probs_from_betas_f64(hipStream_t st, const double *betas, cons
 // sets flags[0] bit 0 when a value lies outside [0, 1] or is not finite
 hipError_t launch_check_unit_range(hipStream_t st, const float *x, long long n, int *flags);
 hipError_t launch_estep(hipStream_t st, const EstepArgs &a, bool pairs);
+hipError_t launch_prob_to_half(hipStream_t st, const float *prob, long long rows, int G, unsigned short *out, const unsigned *skip);  // EstepArgs::prob16; *skip != 0: nothing
 hipError_t launch_softmax_rows(hipStream_t st, const EstepArgs &a);  // rows left as logits by the option-tile launches
 // dictionary form (estep_dict.hip): distinct values and codes of every row of `prob`; stat[0] = most distinct values
 // in a row (DICT_CAP + 1: some row has more)

@@ -21,6 +21,7 @@
 #include <cstdlib>
 #include <cstring>
 
+#include <type_traits>
 #include "kernels.h"
 #include "np_math.h"
 #include "estep_epilogue.h"
@@ -402,22 +403,31 @@ static __device__ __forceinline__ void fast_walk_single(const CallPair *__restri
     w1 = fetch(5);
     issue(w2, g2, 2);
     w2 = fetch(6);
-    for (int k = 0; k < n_batches; k += 4) {
+    // ONE exit, the remainder peeled: with a `break` after every step the compiler unifies the exits into a block that also carries the
+    // back edge, the wait-count analysis sees the loop's head reached from states in which a register's load was the last one issued,
+    // and puts s_waitcnt vmcnt(0) there - the pipeline drained once per trip of 4 batches (until round 5).
+    int k = 0;
+    for (; k + 4 <= n_batches; k += 4) {
         issue(w3, g3, 3);
         w3 = fetch(k + 7);
         consume(k, g0, 0);
-        if (k + 1 >= n_batches) break;
         issue(w0, g0, 0);
         w0 = fetch(k + 8);
         consume(k + 1, g1, 1);
-        if (k + 2 >= n_batches) break;
         issue(w1, g1, 1);
         w1 = fetch(k + 9);
         consume(k + 2, g2, 2);
-        if (k + 3 >= n_batches) break;
         issue(w2, g2, 2);
         w2 = fetch(k + 10);
         consume(k + 3, g3, 3);
+    }
+    const int rem = n_batches - k;
+    if (rem > 0) {  // (the gathers of the last three batches are in flight)
+        consume(k, g0, 0);
+        if (rem > 1) {
+            consume(k + 1, g1, 1);
+            if (rem > 2) consume(k + 2, g2, 2);
+        }
     }
 }
 
@@ -862,6 +872,198 @@ void k_estep_tiled(EstepArgs a)
                               2 * (int)(a.pair_ptr[row + 1] - a.pair_ptr[row]));
     }
 }
+
+// ------------------------------------------------------------------------------------
+// E-step, COARSE pass of the tile-major form (guarded mode, singlets, 33 .. 64 genotypes; EM iterations whose logits nobody reads).
+// k_estep_tiled<1, true> sits on the L1's data path: every call gathers a 256-byte row that misses the L1 (8 clocks of fill + read per
+// call, 6.9 measured: DESIGN.md 4.1), with the LDS (its records' broadcast reads, 6.5 clocks per call) and the VALU (4.6) close behind.
+// What the guard needs of a fast pass is only a PROVABLE bound D on the logits' deviation: a barcode whose second posterior is below
+// 1e-6 keeps its result under D = 0.2 just as under D = 1.5e-4, and on a workload of separable donors that is 99.6 % of the barcodes.
+// So this pass reads the genotype table as binary16 - 128-byte rows, one L1 line per call, relative error 2^-11 per term, priced per
+// call by the guard (estep_epilogue.h; EstepArgs::guard_per_call) - and takes everything else off the paths that were next in line:
+//   records   a batch's 32 dwords are loaded as 8 bytes per lane by EACH row of 16 lanes (lane i of a row: dwords 2i, 2i + 1) and reach
+//             the arithmetic as DPP row broadcasts inside the consuming instructions (v_mul_f32_dpp .. row_newbcast) - no LDS, no readlane;
+//   sums      the log2 of a batch's 8-term product (v_log_f32 of the product itself: its exponent is part of the result) is added in
+//             float32 (EstepArgs::guard_accum), parked in LDS as float32.
+// The barcodes it cannot prove go to the exact redo like those of every guarded pass.
+// ------------------------------------------------------------------------------------
+typedef unsigned u32x2_t __attribute__((ext_vector_type(2)));
+
+static __device__ __forceinline__ unsigned row_bcast(unsigned v, int n)  // lane n of the caller's row of 16 lanes (n: compile-time after unrolling)
+{
+#define DMX_BC(N) case N: return (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x150 + N, 0xf, 0xf, false);
+    switch (n) {
+        DMX_BC(0) DMX_BC(1) DMX_BC(2) DMX_BC(3) DMX_BC(4) DMX_BC(5) DMX_BC(6) DMX_BC(7)
+        DMX_BC(8) DMX_BC(9) DMX_BC(10) DMX_BC(11) DMX_BC(12) DMX_BC(13) DMX_BC(14) DMX_BC(15)
+    }
+#undef DMX_BC
+    return v;
+}
+
+struct CoarseBatch {
+    unsigned h[4];  // gather q: binary16 probabilities of genotypes 2 (lane % 32), + 1 of call 2 q (lanes 0 .. 31) / 2 q + 1 (lanes 32 .. 63)
+};
+
+// a VOP2 instruction whose first source is lane N of the caller's row of 16 lanes (written out: the vectoriser pairs the builtin's
+// multiplications into packed ones, which cannot take a DPP operand - two v_mov_b32_dpp and a v_mov per operand instead of none)
+#define DMX_DPP_OP(NAME, OPCODE)                                                                                          \
+    template <int N>                                                                                                      \
+    static __device__ __forceinline__ float NAME(unsigned w, float x)                                                     \
+    {                                                                                                                     \
+        float r;                                                                                                          \
+        asm(OPCODE " %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "=v"(r) : "v"(w), "v"(x), "n"(N));          \
+        return r;                                                                                                         \
+    }
+DMX_DPP_OP(mul_row_bcast, "v_mul_f32_dpp")
+DMX_DPP_OP(add_row_bcast, "v_add_f32_dpp")
+#undef DMX_DPP_OP
+
+struct CoarseSum {
+    float lo, hi;  // sums of log2 for genotypes 2 (lane % 32) and + 1 over the calls of this lane's half
+};
+
+template <typename OnGroup>
+static __device__ __forceinline__ void coarse_walk(const CallPair *__restrict__ recs, int n_batches, __amdgpu_buffer_rsrc_t rsrc,
+                                                   unsigned lane_off, int lane, CoarseSum &lacc, OnGroup on_group)
+{
+    if (n_batches <= 0) return;
+    constexpr int DG = 4;  // gathers of batches k+1 .. k+3 in flight while batch k is consumed
+    constexpr int DR = 8;  // records: fetched 7 batches ahead of their consumption, 4 ahead of their gathers
+    const unsigned *__restrict__ words = (const unsigned *)recs + (2 * (lane & 15) + (lane >> 5));
+    // Dword 8 q + f of a batch sits in lane 4 q + f / 2 of every row of 16 lanes, component f % 2; a lane keeps the component of
+    // ITS call of every pair (even: lanes 0 .. 31, odd: 32 .. 63): row offset of its call of pair q in lane 4 q, keep in 4 q + 1,
+    // floor in 4 q + 2; the group's slot tag in lane 3 of the lower half.  Batches past the end re-read the last one.
+    auto fetch = [&](int k) {
+        const int kc = k < n_batches ? k : n_batches - 1;
+        return __builtin_nontemporal_load(&words[(size_t)kc * 32]);
+    };
+    auto issue = [&](unsigned w, CoarseBatch &g) {
+#pragma unroll
+        for (int q = 0; q < 4; q++)
+            g.h[q] = __builtin_amdgcn_raw_buffer_load_b32(rsrc, (int)(row_bcast(w, 4 * q) + lane_off), 0, 0);
+    };
+    auto consume = [&](int k, unsigned w, const CoarseBatch &g) {
+        on_group(k, __builtin_amdgcn_readlane((int)w, 3));
+        float prod_lo = 1.0f, prod_hi = 1.0f;
+        auto pair = [&](unsigned h, auto q) {  // the terms fl(fl(p' keep) + floor) of this lane's two genotypes for its call of pair q
+            constexpr int Q = decltype(q)::value;
+            const float p_lo = (float)__builtin_bit_cast(_Float16, (unsigned short)(h & 0xFFFFu));
+            const float p_hi = (float)__builtin_bit_cast(_Float16, (unsigned short)(h >> 16));
+            prod_lo = prod_lo * add_row_bcast<4 * Q + 2>(w, mul_row_bcast<4 * Q + 1>(w, p_lo));
+            prod_hi = prod_hi * add_row_bcast<4 * Q + 2>(w, mul_row_bcast<4 * Q + 1>(w, p_hi));
+        };
+        pair(g.h[0], std::integral_constant<int, 0>{});
+        pair(g.h[1], std::integral_constant<int, 1>{});
+        pair(g.h[2], std::integral_constant<int, 2>{});
+        pair(g.h[3], std::integral_constant<int, 3>{});
+        lacc.lo += __builtin_amdgcn_logf(prod_lo);  // v_log_f32 = log2; a product of 4 terms lies in [1e-16, 16]
+        lacc.hi += __builtin_amdgcn_logf(prod_hi);
+    };
+    unsigned w[DR];
+    CoarseBatch g[DG];
+#pragma unroll
+    for (int j = 0; j < DR - 1; j++) w[j] = fetch(j);
+#pragma unroll
+    for (int j = 0; j < DG - 1; j++) issue(w[j], g[j]);
+    // Unrolled by DR, so that every ring slot is a fixed register.  The loop has ONE exit and the remainder is peeled: with a `break` after
+    // every step the compiler unifies the exits into one block that also carries the back edge, the wait-count analysis then sees the
+    // header reached from states in which a register's load was the last one issued, and puts s_waitcnt vmcnt(0) at the loop's head -
+    // the pipeline drained once per trip.
+#define DMX_COARSE_STEP(U)                                       \
+    issue(w[(U + DG - 1) % DR], g[(U + DG - 1) % DG]);           \
+    w[(U + DR - 1) % DR] = fetch(k + U + DR - 1);                \
+    consume(k + U, w[U], g[U % DG]);
+    int k = 0;
+    for (; k + DR <= n_batches; k += DR) {
+        DMX_COARSE_STEP(0)
+        DMX_COARSE_STEP(1)
+        DMX_COARSE_STEP(2)
+        DMX_COARSE_STEP(3)
+        DMX_COARSE_STEP(4)
+        DMX_COARSE_STEP(5)
+        DMX_COARSE_STEP(6)
+        DMX_COARSE_STEP(7)
+    }
+    const int rem = n_batches - k;
+    if (rem > 0) {
+        DMX_COARSE_STEP(0)
+        if (rem > 1) {
+            DMX_COARSE_STEP(1)
+            if (rem > 2) {
+                DMX_COARSE_STEP(2)
+                if (rem > 3) {
+                    DMX_COARSE_STEP(3)
+                    if (rem > 4) {
+                        DMX_COARSE_STEP(4)
+                        if (rem > 5) {
+                            DMX_COARSE_STEP(5)
+                            if (rem > 6) {
+                                DMX_COARSE_STEP(6)
+                            }
+                        }
+                    }
+                }
+            }
+        }
+    }
+#undef DMX_COARSE_STEP
+}
+
+__global__ __launch_bounds__(256) void k_estep_tiled_coarse(EstepArgs a)
+{
+    __shared__ CoarseSum sh_acc[4][TILE_R_MAX][64];
+    const int lane = threadIdx.x & 63;
+    const int K = a.K;
+    const int R = a.bin_rows_cap;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const long long slot_id = (long long)blockIdx.x * 4 + wave;
+    if (guard_stand_back(a)) return;  // the E-step runs direct (EstepArgs::direct)
+    if (slot_id >= a.n_bins) return;
+    const long long bin = a.bin_order[slot_id];
+    int kk[1];
+    bool valid[1];
+    valid[0] = lane < K;
+    kk[0] = valid[0] ? lane : K - 1;
+    for (int r = 0; r < R; r++) sh_acc[wave][r][lane] = CoarseSum{0.0f, 0.0f};
+    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void *)a.prob16, 0, (int)a.prob_bytes, 0x00020000);
+    const long long g0 = a.bin_ptr[bin];
+    const int n_batches = (int)(a.bin_ptr[bin + 1] - g0);
+    const CallPair *__restrict__ recs = a.tile_stream + g0 * 4;
+    CoarseSum lacc{0.0f, 0.0f};
+    int cur = 0;  // slot whose sums are in registers
+    // genotypes 2 l, 2 l + 1 of the lane's half: one dword of the binary16 row (a pair past G reads into the unused half of the row)
+    coarse_walk(recs, n_batches, rsrc, (unsigned)(lane & 31) * 4u, lane, lacc, [&](int, int tag) {
+        if (tag == cur) return;  // (wave-uniform)
+        sh_acc[wave][cur][lane] = lacc;
+        lacc = sh_acc[wave][tag][lane];
+        cur = tag;
+    });
+    sh_acc[wave][cur][lane] = lacc;
+    for (int r = 0; r < R; r++) {
+        const int row = a.bin_rows[bin * R + r];
+        if (row < 0) continue;
+        CoarseSum v = sh_acc[wave][r][lane];
+        v.lo += __shfl_xor(v.lo, 32);  // even calls (lanes 0 .. 31) + odd calls (lanes 32 .. 63)
+        v.hi += __shfl_xor(v.hi, 32);
+        const float lo = __shfl(v.lo, lane >> 1), hi = __shfl(v.hi, lane >> 1);  // option k = lane: genotype k of lane k / 2
+        double out[1];
+        out[0] = (double)((lane & 1) ? hi : lo) * 0.693147180559945309417232121458176568;
+        estep_epilogue<64, 1, true>(a, (long long)row, true, out, kk, valid, lane, lane, 0, 2 * (int)(a.pair_ptr[row + 1] - a.pair_ptr[row]));
+    }
+}
+
+// float32 genotype table -> binary16, round to nearest even, at the float32 table's row offsets (EstepArgs::prob16)
+__global__ __launch_bounds__(256) void k_prob_to_half(const float *__restrict__ prob, long long n, unsigned short *__restrict__ out, int G,
+                                                      const unsigned *__restrict__ skip)
+{
+    if (skip != nullptr && *skip != 0u) return;  // the coarse pass stands back (GS_SKIP_COARSE)
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const long long row = i / G;
+    const int g = (int)(i - row * G);
+    out[row * (2 * G) + g] = __builtin_bit_cast(unsigned short, (_Float16)prob[i]);
+}
+
 
 // ------------------------------------------------------------------------------------
 // E-step, block form (K > 1024).  One 256-thread workgroup per barcode, option k = s*256 + tid.
@@ -1414,20 +1616,37 @@ __global__ __launch_bounds__(256) void k_sum_dense(unsigned long long *counters,
 // guard would have queued, summed from the hashed counters; the durations of its two passes from the stamps their kernels
 // left), and decides how the next one runs: direct when the fast pass + the exact redo of the queued share costs more than
 // the exact kernel over every barcode (kernels.h: EstepArgs::direct).  One workgroup; replaces the memset of the queue length.
-__global__ __launch_bounds__(GUARD_SLOTS) void k_guard_begin(unsigned *st, unsigned B, unsigned K, int adaptive)
+__global__ __launch_bounds__(GUARD_SLOTS) void k_guard_begin(unsigned *st, unsigned B, unsigned K, int adaptive, int capable, int allow_coarse)
 {
     static_assert(GUARD_QUEUES == GUARD_SLOTS, "one thread per slot and per sub-queue");
-    __shared__ unsigned part[GUARD_SLOTS / 64];
-    unsigned v = st[GS_WORDS + threadIdx.x];
-    st[GS_WORDS + threadIdx.x] = 0u;
-    st[GS_WORDS + GUARD_SLOTS + threadIdx.x] = 0u;  // the sub-queues of the coming E-step are empty
-    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off);
-    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = v;
+    __shared__ unsigned part[2][GUARD_SLOTS / 64];
+    unsigned v = st[GS_SLOTS_FINE + threadIdx.x], vc = st[GS_SLOTS_COARSE + threadIdx.x];
+    st[GS_SLOTS_FINE + threadIdx.x] = 0u;
+    st[GS_SLOTS_COARSE + threadIdx.x] = 0u;
+    st[GS_QUEUE_LEN + threadIdx.x] = 0u;  // the sub-queues of the coming E-step are empty
+    for (int off = 32; off > 0; off >>= 1) {
+        v += __shfl_down(v, off);
+        vc += __shfl_down(vc, off);
+    }
+    if ((threadIdx.x & 63) == 0) {
+        part[0][threadIdx.x >> 6] = v;
+        part[1][threadIdx.x >> 6] = vc;
+    }
     __syncthreads();
     if (threadIdx.x != 0) return;
-    const unsigned was_direct = st[GS_DIRECT], rows = st[GS_ROWS];
-    unsigned count = was_direct ? 0u : st[GS_COUNT];  // (a direct E-step's queue holds every barcode; its count is on the slots)
-    for (int i = 0; i < GUARD_SLOTS / 64; i++) count += part[i];
+    const unsigned was = st[GS_LEVEL], rows = st[GS_ROWS], was_capable = st[GS_CAPABLE];
+    const bool was_direct = was == 2u;
+    unsigned hashed_fine = 0u, hashed_coarse = 0u;
+    for (int i = 0; i < GUARD_SLOTS / 64; i++) {
+        hashed_fine += part[0][i];
+        hashed_coarse += part[1][i];
+    }
+    // what the two guards flagged in the finished E-step: the guard of the pass that ran filled the queue, the other one (a direct
+    // E-step: both) counted on its hashed slots
+    const unsigned queued = was_direct ? 0u : st[GS_COUNT];
+    const unsigned count_fine = was == 1u ? queued : hashed_fine;
+    const unsigned count_coarse = was == 0u ? queued : (was_capable ? hashed_coarse : GS_UNKNOWN);
+    const unsigned count = was == 0u ? count_coarse : count_fine;  // of the pass that ran (direct: what the fine pass would have queued)
     if (st[GS_PENDING]) {
         unsigned long long total = ((unsigned long long)st[GS_TOTAL + 1] << 32) | st[GS_TOTAL];
         total += was_direct ? rows : count;
@@ -1435,8 +1654,8 @@ __global__ __launch_bounds__(GUARD_SLOTS) void k_guard_begin(unsigned *st, unsig
         st[GS_TOTAL + 1] = (unsigned)(total >> 32);
     }
     const bool same = st[GS_VALID] && rows == B && st[GS_K] == K;
-    if (!same) st[GS_F_TICKS] = st[GS_E_TICKS] = st[GS_E_MEASURED] = st[GS_O_TICKS] = 0u;
-    unsigned direct = 0u;
+    if (!same) st[GS_F_TICKS] = st[GS_C_TICKS] = st[GS_E_TICKS] = st[GS_E_MEASURED] = st[GS_O_TICKS] = 0u;
+    unsigned level = allow_coarse ? 0u : 1u;
     if (same) {
         // durations of the finished E-step's passes (32-bit wall clock differences: modular, intervals far below the wrap)
         const unsigned d_fast = st[GS_T_REDO] - st[GS_T_FAST], d_redo = st[GS_T_END] - st[GS_T_REDO];
@@ -1445,7 +1664,7 @@ __global__ __launch_bounds__(GUARD_SLOTS) void k_guard_begin(unsigned *st, unsig
                 st[GS_E_TICKS] = d_redo > 0u ? d_redo : 1u;
                 st[GS_E_MEASURED] = 1u;
             } else {
-                st[GS_F_TICKS] = d_fast > 0u ? d_fast : 1u;
+                st[was == 0u ? GS_C_TICKS : GS_F_TICKS] = d_fast > 0u ? d_fast : 1u;
                 if (1000ull * count < rows) st[GS_O_TICKS] = d_redo;  // an (almost) empty queue: what the exact launch costs by itself
                 if (!st[GS_E_MEASURED] && 20ull * count >= rows) {  // the redo's time over its share of the barcodes
                     const unsigned own = st[GS_O_TICKS];
@@ -1454,14 +1673,38 @@ __global__ __launch_bounds__(GUARD_SLOTS) void k_guard_begin(unsigned *st, unsig
                 }
             }
         }
-        const double F = (double)st[GS_F_TICKS], E = (double)st[GS_E_TICKS];
-        if (adaptive && F > 0.0 && E > 0.0) {
-            const double guarded = F + (double)count / (double)rows * E;  // against E for the direct run; 3 % of hysteresis
-            direct = was_direct ? (guarded > 0.97 * E) : (guarded > 1.03 * E);
+        st[GS_COUNT_FINE] = count_fine;
+        st[GS_COUNT_COARSE] = count_coarse;
+        // The coming E-step: the cheapest of  C + f_coarse E  (if admissible),  F + f_fine E  and  E, each pass's time as the device
+        // measured it.  A pass that has not run yet is priced from the other one - the coarse pass at 0.63 F (what it takes at
+        // 200k x 100k x 64), the fine pass at C (optimistic: it gets its turn and is measured) -; without any E (no E-step has
+        // queued 5 % of its barcodes) the redo is priced at 1.8 F for the choice between the two passes only - the direct form
+        // needs a measured or estimated E.  3 % of hysteresis.
+        double F = (double)st[GS_F_TICKS], C = (double)st[GS_C_TICKS];
+        const double E = (double)st[GS_E_TICKS];
+        if (adaptive && (F > 0.0 || C > 0.0)) {
+            if (F == 0.0) F = C;
+            if (C == 0.0) C = 0.63 * F;
+            const double e_redo = E > 0.0 ? E : 1.8 * F;
+            const double f_fine = (double)count_fine / (double)rows;
+            double cost[3];
+            cost[0] = allow_coarse && count_coarse != GS_UNKNOWN ? C + (double)count_coarse / (double)rows * e_redo : 1.0e300;
+            cost[1] = F + f_fine * e_redo;
+            cost[2] = E > 0.0 ? E : 1.0e300;
+            if (was <= 2u) cost[was] *= 0.97;  // (the level that ran stays unless another one is 3 % cheaper)
+            level = cost[0] <= cost[1] ? 0u : 1u;
+            if (cost[2] < cost[level]) level = 2u;
         }
+    } else {
+        st[GS_COUNT_FINE] = st[GS_COUNT_COARSE] = GS_UNKNOWN;
     }
-    st[GS_DIRECT] = direct;
-    st[GS_DIRECT_STEPS] += direct;
+    st[GS_LEVEL] = level;
+    st[GS_DIRECT] = level == 2u;
+    st[GS_SKIP_COARSE] = level != 0u;
+    st[GS_SKIP_FINE] = level != 1u;
+    st[GS_DIRECT_STEPS] += level == 2u;
+    st[GS_COARSE_STEPS] += level == 0u;
+    st[GS_CAPABLE] = capable != 0;
     st[GS_COUNT] = 0u;
     st[GS_ROWS] = B;
     st[GS_K] = K;
@@ -1470,9 +1713,9 @@ __global__ __launch_bounds__(GUARD_SLOTS) void k_guard_begin(unsigned *st, unsig
     st[GS_T_FAST] = st[GS_T_REDO] = st[GS_T_END] = (unsigned)wall_clock64();
 }
 
-hipError_t launch_guard_begin(hipStream_t st, unsigned *state, long long B, int K, int adaptive)
+hipError_t launch_guard_begin(hipStream_t st, unsigned *state, long long B, int K, int adaptive, int capable, int allow_coarse)
 {
-    hipLaunchKernelGGL(k_guard_begin, dim3(1), dim3(GUARD_SLOTS), 0, st, state, (unsigned)B, (unsigned)K, adaptive);
+    hipLaunchKernelGGL(k_guard_begin, dim3(1), dim3(GUARD_SLOTS), 0, st, state, (unsigned)B, (unsigned)K, adaptive, capable, allow_coarse);
     return hipGetLastError();
 }
 
@@ -1492,7 +1735,7 @@ __global__ __launch_bounds__(256) void k_guard_compact(unsigned *st, const int *
         }
         return;
     }
-    const unsigned len = st[GS_WORDS + GUARD_SLOTS + threadIdx.x];  // GUARD_QUEUES == 256 threads
+    const unsigned len = st[GS_QUEUE_LEN + threadIdx.x];  // GUARD_QUEUES == 256 threads
     unsigned lo = threadIdx.x < q ? len : 0u, total = len;
     for (int off = 32; off > 0; off >>= 1) {
         lo += __shfl_down(lo, off);
@@ -1504,7 +1747,7 @@ __global__ __launch_bounds__(256) void k_guard_compact(unsigned *st, const int *
     }
     __syncthreads();
     const unsigned offset = before[0] + before[1] + before[2] + before[3];
-    const unsigned mine = st[GS_WORDS + GUARD_SLOTS + q];
+    const unsigned mine = st[GS_QUEUE_LEN + q];
     for (unsigned i = threadIdx.x; i < mine; i += 256) list[offset + i] = sub[(size_t)q * cap + i];
     if (q == 0 && threadIdx.x == 0) {
         st[GS_COUNT] = all[0] + all[1] + all[2] + all[3];
@@ -2409,6 +2652,14 @@ __global__ __launch_bounds__(256) void k_check_unit_range(const float *__restric
     if (__ballot(bad) != 0ull && (threadIdx.x & 63) == 0) atomicOr(flags, 1);
 }
 
+hipError_t launch_prob_to_half(hipStream_t st, const float *prob, long long rows, int G, unsigned short *out, const unsigned *skip)
+{
+    const long long n = rows * G;
+    if (n == 0) return hipSuccess;
+    hipLaunchKernelGGL(k_prob_to_half, dim3(blocks_for(n, 256)), dim3(256), 0, st, prob, n, out, G, skip);
+    return hipGetLastError();
+}
+
 hipError_t launch_check_unit_range(hipStream_t st, const float *x, long long n, int *flags)
 {
     if (n == 0) return hipSuccess;
@@ -2467,6 +2718,10 @@ static void launch_tiled(hipStream_t st, const EstepArgs &a)
 {
     const dim3 grid(blocks_for(a.n_bins, 4)), block(256);
     if constexpr (A == 1) {
+        if (a.fast && a.prob16 != nullptr && a.K > 32) {  // the coarse pass (guarded mode only: dmx_api.cpp: run_estep)
+            hipLaunchKernelGGL(k_estep_tiled_coarse, grid, block, 0, st, a);
+            return;
+        }
         if (a.fast && a.K <= 32) {  // two calls per gather
             hipLaunchKernelGGL((k_estep_tiled<1, true, true>), grid, block, 0, st, a);
             return;

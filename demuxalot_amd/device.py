@@ -48,6 +48,7 @@ class DeviceContext:
         self.set_estep_schedule(os.environ.get('DEMUXALOT_AMD_ESTEP_SCHEDULE', 'auto'))
         self.set_estep_dictionary(os.environ.get('DEMUXALOT_AMD_ESTEP_DICT', 'auto'))
         self.set_estep_packing(os.environ.get('DEMUXALOT_AMD_ESTEP_PACKED', 'auto'))
+        self.set_coarse_pass(True)
 
     def __enter__(self):
         return self
@@ -433,6 +434,22 @@ class DeviceContext:
         """Guarded mode: E-steps that follow one which queued more than 40 % of the barcodes run the exact kernel on every
         barcode (default on; include/demux_hip.h: dmx_set_guard_adaptive)."""
         check(self._lib.dmx_set_guard_adaptive(self._h, int(bool(adaptive))))
+
+    def set_coarse_pass(self, coarse):
+        """Guarded mode: E-steps whose logits nobody reads may take the coarse pass (binary16 genotype table; default on;
+        'always': every E-step, single ones included - their logits then carry the coarse bound; include/demux_hip.h: dmx_set_coarse_pass)."""
+        check(self._lib.dmx_set_coarse_pass(self._h, 2 if coarse == 'always' else int(bool(coarse))))
+
+    def guard_levels(self):
+        """dict: level of the last guarded E-step (0 coarse, 1 fine, 2 direct, -1 none), coarse E-steps since reset_timings, barcodes
+        flagged by the fine / coarse guard in the last one, the device's timings of the passes in ms (dmx_get_guard_levels)."""
+        level = ctypes.c_int32()
+        steps, fine, coarse = ctypes.c_int64(), ctypes.c_int64(), ctypes.c_int64()
+        c_ms, f_ms, e_ms = ctypes.c_double(), ctypes.c_double(), ctypes.c_double()
+        check(self._lib.dmx_get_guard_levels(self._h, ctypes.byref(level), ctypes.byref(steps), ctypes.byref(fine), ctypes.byref(coarse),
+                                             ctypes.byref(c_ms), ctypes.byref(f_ms), ctypes.byref(e_ms)))
+        return {'level': level.value, 'coarse_steps': steps.value, 'flagged_fine': fine.value, 'flagged_coarse': coarse.value,
+                'coarse_pass_ms': c_ms.value, 'fine_pass_ms': f_ms.value, 'exact_pass_ms': e_ms.value}
 
     def guard_direct(self):
         """(the last guarded E-step ran direct, E-steps run direct since reset_timings, barcodes the last one queued or -

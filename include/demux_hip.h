@@ -228,6 +228,22 @@ int dmx_get_guard_stats(dmx_ctx *ctx, int64_t *redone_last, int64_t *redone_tota
  * and the exact kernel over all barcodes in ms (0: not known yet; negative: the estimate, not yet measured by a direct
  * E-step); any pointer may be NULL. */
 int dmx_set_guard_adaptive(dmx_ctx *ctx, int adaptive);
+/* The COARSE pass of the guarded mode (csrc/kernels.hip: k_estep_tiled_coarse).  For singlet runs of 33..64 genotypes under the
+ * tile-major schedule, an E-step whose logits nobody can read - every E-step of a dmx_em / dmx_run_iterations call but the
+ * last - may read the genotype table as binary16 (half the bytes of every row gather; relative error 2^-11 per term, priced
+ * per call by the guard): posteriors of the barcodes it keeps are proven within the contract exactly as in the fine pass,
+ * the others are redone by the exact kernel; the LOGITS of such an E-step are only within the guard's bound D (0.2 at 400
+ * calls per barcode) of the reference's, which is why the last E-step of a call - the one whose logits dmx_get_logits /
+ * dmx_get_block / dmx_em return - never takes it.  Coarse pass, fine pass or the direct form: chosen per E-step on the
+ * device from the measured times of the passes and the fractions both guards flag (both are evaluated whichever pass runs).
+ * coarse = 0: never (the guarded mode of round 4).  Default 1.  coarse = 2: admissible for EVERY E-step, the last one of a call and
+ * dmx_estep included - their logits then carry the bound D (tests and measurements).  dmx_get_guard_levels: level of the last guarded E-step
+ * (0 coarse, 1 fine, 2 direct; -1: none), E-steps that took the coarse pass since dmx_reset_timings, barcodes the fine / the
+ * coarse guard flagged in the last one (-1: not evaluated), and the device's timings of the three passes over all barcodes
+ * in ms (0: not run yet; exact: negative while it is an estimate).  Any pointer may be NULL. */
+int dmx_set_coarse_pass(dmx_ctx *ctx, int coarse);
+int dmx_get_guard_levels(dmx_ctx *ctx, int32_t *level_last, int64_t *coarse_steps, int64_t *flagged_fine_last, int64_t *flagged_coarse_last,
+                         double *coarse_pass_ms, double *fine_pass_ms, double *exact_pass_ms);
 int dmx_get_guard_direct(dmx_ctx *ctx, int32_t *last_ran_direct, int64_t *direct_steps, int64_t *would_queue_last, double *fast_pass_ms,
                          double *exact_pass_ms);
 

@@ -1,0 +1,111 @@
+"""The coarse pass of the default (guarded) mode - k_estep_tiled_coarse, include/demux_hip.h: dmx_set_coarse_pass - inside the calls
+that take it: dmx_em / dmx_run_iterations on problems large enough for the tile-major schedule (>= 65 536 barcodes, a genotype
+table of >= 8 MB, 33 .. 64 genotypes, no doublets).  Same-table checks at the headline size: tests/test_gpu_configs.py."""
+import numpy as np
+import pytest
+
+from tests.test_gpu_guarded import check_contract
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope='module')
+def separable():
+    from demuxalot_amd import synth
+    return synth.generate(70_000, 40_000, 64, calls_per_barcode=200, seed=4100)
+
+
+@pytest.fixture(scope='module')
+def siblings():
+    from demuxalot_amd import synth
+    return synth.generate(70_000, 40_000, 64, calls_per_barcode=50, seed=4101, sibling_pairs=True)
+
+
+def _install(ctx, p):
+    ctx.set_problem(p.n_barcodes, p.n_variants, p.n_genotypes, p.variant_id, p.compressed_cb, p.p_base_wrong, p.v2snp)
+    ctx.set_betas(p.prior_betas())
+
+
+def test_em_call_takes_the_coarse_pass_for_all_but_its_last_estep(separable):
+    """dmx_em with 6 iterations: E-step 0 runs the dictionary form (exact), 1 .. 4 may take the coarse pass - on separable donors they
+    do -, the last one, whose logits the call returns, the fine pass.  Against the exact mode's call: posteriors of every barcode
+    within 1e-5 with the same arg-max, additions within what such posteriors allow, returned logits as close as the fine pass
+    leaves them; and the guarded mode of round 4 (coarse pass off) for comparison."""
+    from demuxalot_amd.device import DeviceContext
+    p = separable
+    pen = np.zeros(p.n_genotypes, dtype=np.float32)
+    out = {}
+    for name, mode, coarse in (('exact', 'exact', True), ('default', 'guarded', True), ('fine only', 'guarded', False)):
+        ctx = DeviceContext(0)
+        try:
+            ctx.set_estep_mode(mode)
+            ctx.set_exact_additions(mode == 'exact')
+            ctx.set_coarse_pass(coarse)
+            _install(ctx, p)
+            ctx.reset_timings()
+            logits, probs, addition = ctx.em(6, 0.01, pen, with_doublets=False)
+            out[name] = (logits, probs, addition, ctx.guard_levels(), ctx.guard_stats())
+        finally:
+            ctx.close()
+    lv = out['default'][3]
+    assert lv['level'] == 1, lv                      # the last E-step: the fine pass
+    assert lv['coarse_steps'] == 4, lv               # E-steps 1 .. 4
+    assert lv['coarse_pass_ms'] > 0, lv              # (the last E-step's own time is folded in when the next one begins)
+    assert out['fine only'][3]['coarse_steps'] == 0 and out['fine only'][3]['flagged_coarse'] == -1
+    n_calls_v = np.bincount(p.variant_id, minlength=p.n_variants).astype(np.float64)[:, None]
+    for name in ('default', 'fine only'):
+        dev = check_contract(out[name][1], out['exact'][1], f'{name} vs exact after 6 iterations')
+        d_add = np.abs(out[name][2].astype(np.float64) - out['exact'][2])
+        assert (d_add <= n_calls_v * 2.00001e-5 + 2.0 ** -22 * out['exact'][2]).all()
+        d_logit = np.abs(out[name][0] - out['exact'][0]).max()
+        assert d_logit <= 2e-3, (name, d_logit)   # the fine pass's arithmetic + what 1e-5 posteriors do to the tables over 5 M-steps
+        print(f'{name}: posteriors within {dev:.3g}, logits within {d_logit:.3g} of the exact call; levels {out[name][3]}; guard {out[name][4]}')
+
+
+def test_coarse_pass_gives_way_where_it_proves_too_little(siblings):
+    """Sibling donors, 50 calls per barcode: the coarse guard (D ~ 0.03) flags most barcodes, the fine one a fifth.  The first
+    admissible E-step takes the coarse pass and finds that out; the device then prices  C + f_coarse E  against  F + f_fine E  and E
+    on its own timings and leaves the coarse pass.  Results stay within the contract of the exact mode's whichever level ran."""
+    from demuxalot_amd.device import DeviceContext
+    p = siblings
+    pen = np.zeros(p.n_genotypes, dtype=np.float32)
+    ref = DeviceContext(0)
+    try:
+        ref.set_estep_mode('exact')
+        _install(ref, p)
+        _l, probs_exact, _a = ref.em(2, 0.01, pen, with_doublets=False, fetch_logits=False)
+    finally:
+        ref.close()
+    ctx = DeviceContext(0)
+    try:
+        ctx.set_estep_mode('guarded')
+        _install(ctx, p)
+        ctx.set_coarse_pass('always')   # (single E-steps below: admissible every time, so that every decision can be read back)
+        ctx.reset_timings()
+        ctx.em(2, 0.01, pen, with_doublets=False, fetch_logits=False, fetch_probs=False, fetch_addition=False)  # P E M P E: the second E-step is guarded
+        history = [ctx.guard_levels()]
+        for step in range(6):
+            _l, probs = ctx.estep(pen, with_doublets=False)
+            history.append(ctx.guard_levels())
+            check_contract(probs, probs_exact, f'E-step {step} at level {history[-1]["level"]}')
+    finally:
+        ctx.close()
+    B = p.n_barcodes
+    assert history[0]['level'] == 0 and history[0]['coarse_steps'] == 1, history   # it had its turn (nothing was known before it)
+    assert history[-1]['coarse_steps'] <= 2 and history[-1]['level'] != 0 and history[-2]['level'] != 0, history  # ... and was left
+    assert max(h['flagged_coarse'] for h in history) > 0.4 * B, history
+    assert all(0 < h['flagged_fine'] < 0.4 * B for h in history), history
+    for prev, cur in zip(history[:-1], history[1:]):   # every decision against the rule, on the numbers the device reports
+        C, F, E = cur['coarse_pass_ms'], cur['fine_pass_ms'], abs(cur['exact_pass_ms'])
+        if not (C > 0 or F > 0):
+            continue
+        F_ = F if F > 0 else C
+        C_ = C if C > 0 else 0.63 * F_
+        e_redo = E if E > 0 else 1.8 * F_
+        cost = [C_ + prev['flagged_coarse'] / B * e_redo, F_ + prev['flagged_fine'] / B * e_redo, E if E > 0 else float('inf')]
+        cost[prev['level']] *= 0.97
+        best = min(range(3), key=lambda i: cost[i])
+        ranked = sorted(cost)
+        if ranked[1] / ranked[0] > 1.002:   # (not a tie within the clock's resolution)
+            assert cur['level'] == best, (prev, cur, cost)
+    print('levels', [(h['level'], h['flagged_coarse'], h['flagged_fine'], round(h['coarse_pass_ms'], 3), round(h['fine_pass_ms'], 3), round(h['exact_pass_ms'], 3)) for h in history])
