@@ -425,6 +425,16 @@ void timer_end(dmx_ctx *c, int slot, const std::pair<hipEvent_t, hipEvent_t> &ev
     if (t.pending.size() >= 4096) timer_flush(c, slot);
 }
 
+// the coarse pass's records and constants (run_estep builds them at the problem's first admissible E-step)
+static void release_coarse_stream(dmx_ctx *c)
+{
+    dev_free(c, &c->d_coarse_stream, c->cap_coarse_stream);
+    c->cap_coarse_stream = 0;
+    dev_free(c, &c->d_coarse_bin_ptr, (size_t)c->n_bins + 1);
+    dev_free(c, &c->d_log2_keep, (size_t)c->B);
+    c->coarse_ready = false;
+}
+
 void release_problem(dmx_ctx *c)
 {
     // the blocks released here are handed out again at once (ctx_malloc) to work ordered on c->stream: whatever the
@@ -433,6 +443,7 @@ void release_problem(dmx_ctx *c)
     dev_free(c, &c->d_call_pairs, (size_t)c->n_pairs + dmx::CALL_PAD_PAIRS);
     dev_free(c, &c->d_call_rows, ((size_t)c->n_pairs + dmx::CALL_PAD_PAIRS) * 2);
     dev_free(c, &c->d_tile_stream, (size_t)c->n_pairs);
+    release_coarse_stream(c);
     c->n_pairs = 0;
     dmx::release_mstep_tiles(c);  // (its record stream is sized by n_csc)
     dev_free(c, &c->d_csc, (size_t)c->n_csc);
@@ -973,6 +984,7 @@ int layout_exchange(dmx_ctx *c)
         HIP_TRY(hipMemcpyAsync(c->d_prow, prow.data(), sizeof(int) * V, hipMemcpyHostToDevice, st));
         HIP_TRY(dmx::launch_remap_row_offsets(st, c->d_call_pairs, c->n_pairs, (unsigned)G * 4u, c->d_prow, c->d_call_rows));
         if (c->d_tile_stream) HIP_TRY(dmx::launch_remap_row_offsets(st, c->d_tile_stream, c->n_pairs, (unsigned)G * 4u, c->d_prow, nullptr));
+        release_coarse_stream(c);  // (its row offsets are the tile-major stream's: rebuilt at the next admissible E-step)
         const size_t elem = c->reduce_dtype == DMX_F64 ? 8 : 4;
         c->exch_bytes = (size_t)new_rows * G * 8;  // float64 sums of the reduce-scatter exchange; also the float32 staging of the addition gather
         c->recv_bytes = (size_t)rows * G * elem;
@@ -1206,6 +1218,9 @@ int run_estep(dmx_ctx *c, int with_doublets, bool with_prior, int prior_dtype, f
     a.bin_rows = c->d_bin_rows;
     a.bin_ptr = c->d_bin_ptr;
     a.tile_stream = c->d_tile_stream;
+    a.coarse_stream = nullptr;
+    a.coarse_bin_ptr = nullptr;
+    a.log2_keep = nullptr;
     a.n_long = 0;
     a.dict_n = 0;
     a.dtab = nullptr;
@@ -1257,8 +1272,30 @@ int run_estep(dmx_ctx *c, int with_doublets, bool with_prior, int prior_dtype, f
             // table whose clip keeps binary16 normal) is admissible when nobody can read this E-step's logits.  Which of coarse pass,
             // fine pass and the direct form runs is the device's choice (k_guard_begin): both fast launches are issued, the one
             // that is not taken stands back.
-            const bool capable = c->coarse_pass && !with_doublets && c->K > 32 && c->K <= 64 && a.n_bins > 0 && c->p_clip_lo >= 6.2e-5f;
+            const bool capable = c->coarse_pass && !with_doublets && c->K > 32 && c->K <= 64 && a.n_bins > 0 && c->p_clip_lo >= 6.2e-5f &&
+                                 (unsigned long long)a.prob_bytes + (unsigned long long)c->G * 4ull < (1ull << 32);
             const bool allow_coarse = capable && (!logits_kept || c->coarse_pass == 2);
+            if (allow_coarse && !c->coarse_ready) {
+                // once per problem, ahead of k_guard_begin's time stamp (not part of the pass the device times): the coarse pass's
+                // records - 8 bytes per call where the tile-major stream has 16 - and the log2 of the keep factors per barcode
+                const size_t words = (((size_t)c->n_pairs / 4 + (size_t)c->n_bins) / 2 + 1) * 32;
+                DMX_TRY(dev_alloc(c, &c->d_coarse_stream, words));
+                c->cap_coarse_stream = words;
+                DMX_TRY(dev_alloc(c, &c->d_coarse_bin_ptr, (size_t)c->n_bins + 1));
+                DMX_TRY(dev_alloc(c, &c->d_log2_keep, (size_t)c->B));
+                HIP_TRY(dmx::launch_coarse_bin_ptr(c->stream, c->d_bin_ptr, c->n_bins, c->d_coarse_bin_ptr));
+                HIP_TRY(dmx::launch_build_coarse_stream(c->stream, c->d_tile_stream, c->d_bin_ptr, c->n_bins, a.prob_bytes, c->d_coarse_bin_ptr, c->d_coarse_stream));
+                HIP_TRY(dmx::launch_barcode_log2_keep(c->stream, c->d_call_pairs, c->d_pair_ptr, c->B, c->d_log2_keep));
+                c->coarse_ready = true;
+            }
+            const size_t need16 = ((size_t)c->prob_rows + 1) * c->G * 2;  // the table as binary16 + the all-zero row the padding calls gather
+            if (allow_coarse && need16 > c->cap_prob16) {
+                dev_free(c, &c->d_prob16, c->cap_prob16);
+                c->cap_prob16 = 0;
+                DMX_TRY(dev_alloc(c, &c->d_prob16, need16));
+                c->cap_prob16 = need16;
+                HIP_TRY(hipMemsetAsync(c->d_prob16, 0, need16 * sizeof(unsigned short), c->stream));
+            }
             HIP_TRY(dmx::launch_guard_begin(c->stream, c->d_guard_count, c->B, c->K, c->guard_adaptive, capable, allow_coarse));
             a.guard = 1;
             a.order_direct = c->d_bc_order;
@@ -1266,17 +1303,12 @@ int run_estep(dmx_ctx *c, int with_doublets, bool with_prior, int prior_dtype, f
             a.guard_alt_per_call = capable ? dmx::GUARD_PER_CALL_COARSE : 0.0f;
             a.guard_alt_accum = capable ? dmx::GUARD_ACCUM_F32 : 0.0f;
             if (allow_coarse) {
-                const size_t need = (size_t)c->prob_rows * c->G * 2;
-                if (need > c->cap_prob16) {
-                    dev_free(c, &c->d_prob16, c->cap_prob16);
-                    c->cap_prob16 = 0;
-                    DMX_TRY(dev_alloc(c, &c->d_prob16, need));
-                    c->cap_prob16 = need;
-                    HIP_TRY(hipMemsetAsync(c->d_prob16, 0, need * sizeof(unsigned short), c->stream));
-                }
                 HIP_TRY(dmx::launch_prob_to_half(c->stream, c->d_prob, c->prob_rows, c->G, c->d_prob16, c->d_guard_count + dmx::GS_SKIP_COARSE));
                 dmx::EstepArgs coarse = a;
                 coarse.prob16 = c->d_prob16;
+                coarse.coarse_stream = c->d_coarse_stream;
+                coarse.coarse_bin_ptr = c->d_coarse_bin_ptr;
+                coarse.log2_keep = c->d_log2_keep;
                 coarse.guard_per_call = dmx::GUARD_PER_CALL_COARSE;
                 coarse.guard_accum = dmx::GUARD_ACCUM_F32;
                 coarse.guard_main_coarse = 1;

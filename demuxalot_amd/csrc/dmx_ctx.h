@@ -67,6 +67,11 @@ struct dmx_ctx {
     float *d_prior = nullptr, *d_add = nullptr, *d_prob = nullptr;
     unsigned short *d_prob16 = nullptr;  // d_prob as binary16 at the same row offsets (the coarse pass of the guarded E-step), cap_prob16 values
     size_t cap_prob16 = 0;
+    unsigned *d_coarse_stream = nullptr;      // the coarse pass's records (kernels.hip: coarse_walk), cap_coarse_stream dwords; built at the first
+    long long *d_coarse_bin_ptr = nullptr;    //   admissible E-step of a problem from the tile-major stream; [n_bins + 1]
+    double *d_log2_keep = nullptr;            // [B]
+    size_t cap_coarse_stream = 0;
+    bool coarse_ready = false;
     bool prob16_valid = false;           // ... and it holds the current d_prob
     int coarse_pass = 1;                 // dmx_set_coarse_pass
     float p_clip_lo = 0.0f;              // lower clip of the P-step that produced d_prob (0: a caller's table, dmx_set_probs)

@@ -226,6 +226,7 @@ constexpr float GUARD_PER_CALL = 7.0e-8f;
 // with the floor: 4 x 2^-24 = 2.4e-7 relative per term = 2.4e-7 in its log, on top of GUARD_PER_CALL.
 constexpr float GUARD_PER_CALL_PRESCALED = 3.1e-7f;
 constexpr float GUARD_LOGIT_ROUNDING = 1.2e-7f;  // 2 x 2^-24 (reference and here) with the conversions' slack
+constexpr int GUARD_ALT_SAMPLE = 8;  // one barcode in 8 is shown to the guard of the pass that does not run (estep_epilogue)
 constexpr float GUARD_TOL = 8.0e-6f;
 constexpr float GUARD_TOL_WIDE = 6.0e-6f;  // rows of more than 1024 options (k_softmax_rows): numpy's pairwise sum has three more
                                            // levels there, so the float32 evaluation of the softmax gets 4e-6 instead of 2e-6
@@ -296,7 +297,7 @@ static __device__ __forceinline__ bool guard_active(const EstepArgs &a)
 template <int L, int A, bool GUARD = false>
 static __device__ __forceinline__ void estep_epilogue(const EstepArgs &a, long long b, bool live, const double (&acc)[A],
                                                       const int (&kk)[A], const bool (&valid)[A], int lane, int li, int gbase,
-                                                      int row_calls)
+                                                      int row_calls, float accum_extra = 0.0f)
 {
     const int K = a.K;
     float lg[A], x[A];
@@ -354,7 +355,8 @@ static __device__ __forceinline__ void estep_epilogue(const EstepArgs &a, long l
                 dev[s] = GUARD_RHO * (fabsf((float)acc[s]) + GUARD_POSITIVE_TERM * n) + per_call * (n + 8.0f) + GUARD_LOGIT_ROUNDING * fabsf(l0);
                 // a sum of n / 8 log2 values accumulated in float32: every addition rounds to 2^-24 of a partial sum, and the partial
                 // sums stay below |sum| + 2 x (the positive terms: < 1.5e-4 log2 units per call) - here in natural-log units
-                if (accum != 0.0f) dev[s] += accum * (0.125f * n + 2.0f) * (fabsf((float)acc[s]) + 3.0e-4f * n);
+                // (accum_extra: what the caller's partial sums may exceed the total by, beyond that)
+                if (accum != 0.0f) dev[s] += accum * (0.125f * n + 2.0f) * (fabsf((float)acc[s]) + 3.0e-4f * n + accum_extra);
                 if (a.prior) dev[s] += GUARD_LOGIT_ROUNDING * fabsf(lg[s]);
             }
         };
@@ -362,10 +364,15 @@ static __device__ __forceinline__ void estep_epilogue(const EstepArgs &a, long l
         const bool flagged = estep_guard<L, A>(dev, lg, post, valid, mx, gbase);
         if (flagged && live && li == 0) guard_note(a, b, counting, a.guard_main_coarse != 0);
         redo = flagged && !counting;
-        if (a.guard_alt_per_call != 0.0f) {  // (uniform) what the other pass's guard would say of this barcode: counted only
+        // What the OTHER pass's guard would say, so that the device can price that pass (k_guard_begin): a SAMPLE - the barcodes
+        // b % 8 == 0 of a lane group's row, each counted 8 times - since the second evaluation costs a short row's kernel 13 %
+        // (200k x 50 calls: fine pass 0.351 -> 0.398 ms with every barcode evaluated twice).  L < 64: the groups of a wavefront
+        // hold different barcodes, so the evaluation stays uniform there and only the count is sampled.
+        if (a.guard_alt_per_call != 0.0f && (L < 64 || (b & (GUARD_ALT_SAMPLE - 1)) == 0)) {
             bound(a.guard_alt_per_call, a.guard_alt_accum);
             const bool flagged_alt = estep_guard<L, A>(dev, lg, post, valid, mx, gbase);
-            if (flagged_alt && live && li == 0) guard_note(a, b, true, a.guard_main_coarse == 0);
+            if (flagged_alt && live && li == 0 && (b & (GUARD_ALT_SAMPLE - 1)) == 0)
+                atomicAdd(a.guard_count + (a.guard_main_coarse == 0 ? GS_SLOTS_COARSE : GS_SLOTS_FINE) + (int)((b / GUARD_ALT_SAMPLE) & (GUARD_SLOTS - 1)), (unsigned)GUARD_ALT_SAMPLE);
         }
     }
     if (a.first) {

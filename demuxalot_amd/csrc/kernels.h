@@ -119,6 +119,9 @@ struct EstepArgs {
     const int *bin_order;       // [n_bins] bins by decreasing number of calls
     const int *bin_rows;        // [n_bins][R] barcodes of the bin (-1: empty slot)
     const long long *bin_ptr;   // [n_bins + 1] first group (4 CallPairs = 8 calls) of every bin in tile_stream
+    const unsigned *coarse_stream;    // nullable: the coarse pass's records (kernels.hip: coarse_walk), 32 dwords per double batch of 16 calls
+    const long long *coarse_bin_ptr;  // [n_bins + 1] first double batch of every bin in coarse_stream
+    const double *log2_keep;          // [B] sum of log2(keep) over the barcode's calls: the coarse pass's terms are (p + floor / keep)
     const CallPair *tile_stream;  // the call records in bin-major, tile-major, slot-minor order; reserved[0] of a
                                   // group's first pair = the slot (accumulator) the group belongs to
     // dictionary form (estep_dict.hip); dict_n == 0: not used by this launch
@@ -159,18 +162,22 @@ enum { GS_COUNT = 0,         // barcodes queued by the current E-step (a direct 
        GS_SKIP_COARSE = 17,  // != 0: the coarse launch of the current E-step stands back (what its EstepArgs::direct points at)
        GS_SKIP_FINE = 18,    // ... the fine launch
        GS_C_TICKS = 19,      // duration of the coarse pass over all barcodes (0: not measured yet)
-       GS_COUNT_FINE = 20,   // barcodes the fine / the coarse guard flagged in the finished E-step (GS_UNKNOWN: not evaluated)
+       GS_COUNT_FINE = 20,   // barcodes the fine / the coarse guard flagged in the finished E-step (GS_UNKNOWN: not evaluated); the guard of the pass
+                             // that did not run sees one barcode in 8 (estep_epilogue.h: GUARD_ALT_SAMPLE): its count is that estimate
        GS_COUNT_COARSE = 21,
        GS_CAPABLE = 22,      // the current E-step evaluates the coarse guard too (the problem has a coarse pass)
        GS_COARSE_STEPS = 23, // E-steps that took the coarse pass since the last reset
        GS_WORDS = 24 };
 constexpr unsigned GS_UNKNOWN = 0xFFFFFFFFu;
 // The coarse pass (kernels.hip: k_estep_tiled_coarse) reads the genotype table as binary16, rounded to nearest: p' = p (1 + d), |d| <= 2^-11
-// for every p >= 2^-14 (normal range; run_estep checks the clip).  Its term fl(fl(p' keep) + floor) is the reference's operation sequence
-// on p', so it differs from the reference's term by at most 2^-11 (1 + 2^-23) + 2 x 2^-24 relative (the floor is >= 0 and exact), its log
-// by at most d / (1 - d): 4.8852e-4; then per call 7/8 float32 roundings of the 8-term product (5.3e-8) and 1/8 of v_log_f32's error on
-// a product in [1e-32, 256] - within 2 ulp of a result below 128 in magnitude (tests/test_gpu_guarded.py), 1.53e-5 log2 units = 1.06e-5: 1.33e-6.
-constexpr float GUARD_PER_CALL_COARSE = 4.905e-4f;
+// for every p >= 2^-14 (normal range; run_estep checks the clip), and forms a term as keep (p' + r), r = fl(floor / keep) with the slot tag in
+// its low 4 bits: against the true term keep (p + floor / keep) the sum p' + r is off by at most 2^-11 (p') + 2^-24 + 2^-19 (r) + 2^-24 (its own
+// rounding) relative - p, r >= 0 -, the reference's float32 term by 2 x 2^-24, so the logs differ by at most d / (1 - d) with
+// d = 4.8828e-4 + 1.91e-6 + 4 x 6e-8: 4.9068e-4.  Then per call 3/4 of a float32 rounding of the 4-term product (4.5e-8) and 1/4 of v_log_f32's
+// error on a product in [1e-16, 2^80) - within 2 ulp of a result below 128 in magnitude (tests/test_gpu_guarded.py): 1.53e-5 log2 units =
+// 1.06e-5, a quarter of it per call: 2.7e-6.  (A product beyond float32 - calls with keep below 1e-9 - becomes inf / NaN: the guard flags NaN.)
+// log2_keep is a float64 sum of float64 logs: 1e-16 relative.
+constexpr float GUARD_PER_CALL_COARSE = 4.94e-4f;
 constexpr float GUARD_ACCUM_F32 = 6.0e-8f;  // 2^-24, rounded up: per float32 addition of the running sum (estep_epilogue.h)
 constexpr int GUARD_SLOTS = 256;   // hashed counters behind the state words: barcodes flagged by a guard whose pass does not run (a direct
                                    // E-step: both; a fine one: the coarse guard's; a coarse one: the fine guard's) - a set per guard
@@ -263,6 +270,11 @@ hipError_t launch_probs_from_betas_f64(hipStream_t st, const double *betas, cons
 // sets flags[0] bit 0 when a value lies outside [0, 1] or is not finite
 hipError_t launch_check_unit_range(hipStream_t st, const float *x, long long n, int *flags);
 hipError_t launch_estep(hipStream_t st, const EstepArgs &a, bool pairs);
+// the coarse pass's records from the tile-major stream: coarse_bin_ptr first (one block), then the stream; zero_off = byte offset of the all-zero row
+hipError_t launch_coarse_bin_ptr(hipStream_t st, const long long *bin_ptr, long long n_bins, long long *coarse_bin_ptr);
+hipError_t launch_build_coarse_stream(hipStream_t st, const CallPair *stream, const long long *bin_ptr, long long n_bins, unsigned zero_off,
+                                      long long *coarse_bin_ptr, unsigned *out);
+hipError_t launch_barcode_log2_keep(hipStream_t st, const CallPair *pairs, const long long *pair_ptr, long long B, double *out);
 hipError_t launch_prob_to_half(hipStream_t st, const float *prob, long long rows, int G, unsigned short *out, const unsigned *skip);  // EstepArgs::prob16; *skip != 0: nothing
 hipError_t launch_softmax_rows(hipStream_t st, const EstepArgs &a);  // rows left as logits by the option-tile launches
 // dictionary form (estep_dict.hip): distinct values and codes of every row of `prob`; stat[0] = most distinct values

@@ -904,77 +904,83 @@ struct CoarseBatch {
     unsigned h[4];  // gather q: binary16 probabilities of genotypes 2 (lane % 32), + 1 of call 2 q (lanes 0 .. 31) / 2 q + 1 (lanes 32 .. 63)
 };
 
-// a VOP2 instruction whose first source is lane N of the caller's row of 16 lanes (written out: the vectoriser pairs the builtin's
-// multiplications into packed ones, which cannot take a DPP operand - two v_mov_b32_dpp and a v_mov per operand instead of none)
-#define DMX_DPP_OP(NAME, OPCODE)                                                                                          \
-    template <int N>                                                                                                      \
-    static __device__ __forceinline__ float NAME(unsigned w, float x)                                                     \
-    {                                                                                                                     \
-        float r;                                                                                                          \
-        asm(OPCODE " %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "=v"(r) : "v"(w), "v"(x), "n"(N));          \
-        return r;                                                                                                         \
-    }
-DMX_DPP_OP(mul_row_bcast, "v_mul_f32_dpp")
-DMX_DPP_OP(add_row_bcast, "v_add_f32_dpp")
-#undef DMX_DPP_OP
+// v_add_f32 whose first source is lane N of the caller's row of 16 lanes (written out: the vectoriser pairs the builtin's additions
+// into packed ones, which cannot take a DPP operand - two v_mov_b32_dpp and a v_mov per operand instead of none)
+template <int N>
+static __device__ __forceinline__ float add_row_bcast(unsigned w, float x)
+{
+    float r;
+    asm("v_add_f32_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "=v"(r) : "v"(w), "v"(x), "n"(N));
+    return r;
+}
 
 struct CoarseSum {
     float lo, hi;  // sums of log2 for genotypes 2 (lane % 32) and + 1 over the calls of this lane's half
 };
 
+// The coarse pass's own record stream (launch_build_coarse_stream): per call a row offset and r = floor / keep -
+//     term = p keep + floor = keep (p + r):   log2 of a barcode's product = sum_c log2(p_c + r_c) + sum_c log2 keep_c,
+// the second sum the same for every option (EstepArgs::log2_keep, added in the epilogue): ONE addition per term instead of a
+// multiplication and an addition, 8 bytes per call instead of 16.  A DOUBLE BATCH (16 calls) is 32 dwords:
+//     [ even calls:  A: off0 off2 off4 off6  r0 r2 r4 r6 | B: the same of the second batch ][ odd calls: A: off1 .. r7 | B: ... ]
+// lane i of the two lower rows of 16 lanes loads dword i, of the two upper rows dword 16 + i: one dword per lane and TWO batches; the
+// slot tag of a batch sits in the low 4 bits of its r0 (2^-19 of r: priced).  Padding calls - and calls with keep = 0 - gather the
+// all-zero row behind the table with r = floor: p + r = floor exactly.  Every bin starts at a double batch (coarse_bin_ptr).
 template <typename OnGroup>
-static __device__ __forceinline__ void coarse_walk(const CallPair *__restrict__ recs, int n_batches, __amdgpu_buffer_rsrc_t rsrc,
+static __device__ __forceinline__ void coarse_walk(const unsigned *__restrict__ stream, int n_batches, __amdgpu_buffer_rsrc_t rsrc,
                                                    unsigned lane_off, int lane, CoarseSum &lacc, OnGroup on_group)
 {
     if (n_batches <= 0) return;
     constexpr int DG = 4;  // gathers of batches k+1 .. k+3 in flight while batch k is consumed
-    constexpr int DR = 8;  // records: fetched 7 batches ahead of their consumption, 4 ahead of their gathers
-    const unsigned *__restrict__ words = (const unsigned *)recs + (2 * (lane & 15) + (lane >> 5));
-    // Dword 8 q + f of a batch sits in lane 4 q + f / 2 of every row of 16 lanes, component f % 2; a lane keeps the component of
-    // ITS call of every pair (even: lanes 0 .. 31, odd: 32 .. 63): row offset of its call of pair q in lane 4 q, keep in 4 q + 1,
-    // floor in 4 q + 2; the group's slot tag in lane 3 of the lower half.  Batches past the end re-read the last one.
-    auto fetch = [&](int k) {
-        const int kc = k < n_batches ? k : n_batches - 1;
-        return __builtin_nontemporal_load(&words[(size_t)kc * 32]);
+    constexpr int DD = 4;  // double batches of records in registers: fetched 8 batches ahead of their consumption
+    const int n_double = (n_batches + 1) >> 1;
+    const unsigned *__restrict__ words = stream + ((lane >> 5) * 16 + (lane & 15));
+    auto fetch = [&](int d) {  // (double batches past the end re-read the last one)
+        const int dc = d < n_double ? d : n_double - 1;
+        return __builtin_nontemporal_load(&words[(size_t)dc * 32]);
     };
-    auto issue = [&](unsigned w, CoarseBatch &g) {
+    auto issue = [&](unsigned w, auto second, CoarseBatch &g) {
+        constexpr int S = decltype(second)::value;
 #pragma unroll
-        for (int q = 0; q < 4; q++)
-            g.h[q] = __builtin_amdgcn_raw_buffer_load_b32(rsrc, (int)(row_bcast(w, 4 * q) + lane_off), 0, 0);
+        for (int q = 0; q < 4; q++) g.h[q] = __builtin_amdgcn_raw_buffer_load_b32(rsrc, (int)(row_bcast(w, 8 * S + q) + lane_off), 0, 0);
     };
-    auto consume = [&](int k, unsigned w, const CoarseBatch &g) {
-        on_group(k, __builtin_amdgcn_readlane((int)w, 3));
-        float prod_lo = 1.0f, prod_hi = 1.0f;
-        auto pair = [&](unsigned h, auto q) {  // the terms fl(fl(p' keep) + floor) of this lane's two genotypes for its call of pair q
-            constexpr int Q = decltype(q)::value;
-            const float p_lo = (float)__builtin_bit_cast(_Float16, (unsigned short)(h & 0xFFFFu));
-            const float p_hi = (float)__builtin_bit_cast(_Float16, (unsigned short)(h >> 16));
-            prod_lo = prod_lo * add_row_bcast<4 * Q + 2>(w, mul_row_bcast<4 * Q + 1>(w, p_lo));
-            prod_hi = prod_hi * add_row_bcast<4 * Q + 2>(w, mul_row_bcast<4 * Q + 1>(w, p_hi));
-        };
-        pair(g.h[0], std::integral_constant<int, 0>{});
-        pair(g.h[1], std::integral_constant<int, 1>{});
-        pair(g.h[2], std::integral_constant<int, 2>{});
-        pair(g.h[3], std::integral_constant<int, 3>{});
-        lacc.lo += __builtin_amdgcn_logf(prod_lo);  // v_log_f32 = log2; a product of 4 terms lies in [1e-16, 16]
+    auto consume = [&](int k, unsigned w, auto second, const CoarseBatch &g) {
+        constexpr int S = decltype(second)::value;
+        on_group(k, __builtin_amdgcn_readlane((int)w, 8 * S + 4) & 15);
+        auto lo = [](unsigned h) { return (float)__builtin_bit_cast(_Float16, (unsigned short)(h & 0xFFFFu)); };
+        auto hi = [](unsigned h) { return (float)__builtin_bit_cast(_Float16, (unsigned short)(h >> 16)); };
+        float prod_lo = add_row_bcast<8 * S + 4>(w, lo(g.h[0])), prod_hi = add_row_bcast<8 * S + 4>(w, hi(g.h[0]));
+        prod_lo = prod_lo * add_row_bcast<8 * S + 5>(w, lo(g.h[1]));
+        prod_hi = prod_hi * add_row_bcast<8 * S + 5>(w, hi(g.h[1]));
+        prod_lo = prod_lo * add_row_bcast<8 * S + 6>(w, lo(g.h[2]));
+        prod_hi = prod_hi * add_row_bcast<8 * S + 6>(w, hi(g.h[2]));
+        prod_lo = prod_lo * add_row_bcast<8 * S + 7>(w, lo(g.h[3]));
+        prod_hi = prod_hi * add_row_bcast<8 * S + 7>(w, hi(g.h[3]));
+        lacc.lo += __builtin_amdgcn_logf(prod_lo);  // v_log_f32 = log2 of a product of 4 sums p + r
         lacc.hi += __builtin_amdgcn_logf(prod_hi);
     };
-    unsigned w[DR];
+    using First = std::integral_constant<int, 0>;
+    using Second = std::integral_constant<int, 1>;
+    unsigned w[DD];
     CoarseBatch g[DG];
 #pragma unroll
-    for (int j = 0; j < DR - 1; j++) w[j] = fetch(j);
-#pragma unroll
-    for (int j = 0; j < DG - 1; j++) issue(w[j], g[j]);
-    // Unrolled by DR, so that every ring slot is a fixed register.  The loop has ONE exit and the remainder is peeled: with a `break` after
-    // every step the compiler unifies the exits into one block that also carries the back edge, the wait-count analysis then sees the
-    // header reached from states in which a register's load was the last one issued, and puts s_waitcnt vmcnt(0) at the loop's head -
-    // the pipeline drained once per trip.
-#define DMX_COARSE_STEP(U)                                       \
-    issue(w[(U + DG - 1) % DR], g[(U + DG - 1) % DG]);           \
-    w[(U + DR - 1) % DR] = fetch(k + U + DR - 1);                \
-    consume(k + U, w[U], g[U % DG]);
+    for (int j = 0; j < DD; j++) w[j] = fetch(j);
+    issue(w[0], First{}, g[0]);
+    issue(w[0], Second{}, g[1]);
+    issue(w[1], First{}, g[2]);
+    // Unrolled by 8 batches, so that every ring slot is a fixed register.  ONE exit and the remainder peeled: with a `break` after every
+    // step the compiler unifies the exits into a block that also carries the back edge, the wait-count analysis then sees the loop's
+    // head reached from states in which a register's load was the last one issued, and puts s_waitcnt vmcnt(0) there.
+    // step U of a trip starting at batch k: gathers of batch k + U + 3 issued, batch k + U consumed; behind an odd step its double
+    // batch's register takes the records of the double batch 4 ahead
+#define DMX_COARSE_ISSUE(U) issue(w[(((U) + 3) >> 1) & 3], std::integral_constant<int, ((U) + 3) & 1>{}, g[((U) + 3) & 3]);
+#define DMX_COARSE_CONSUME(U) consume(k + (U), w[((U) >> 1) & 3], std::integral_constant<int, (U) & 1>{}, g[(U) & 3]);
+#define DMX_COARSE_STEP(U)                                                    \
+    DMX_COARSE_ISSUE(U)                                                       \
+    DMX_COARSE_CONSUME(U)                                                     \
+    if (((U) & 1) != 0) w[((U) >> 1) & 3] = fetch(((k + (U)) >> 1) + DD);
     int k = 0;
-    for (; k + DR <= n_batches; k += DR) {
+    for (; k + 8 <= n_batches; k += 8) {
         DMX_COARSE_STEP(0)
         DMX_COARSE_STEP(1)
         DMX_COARSE_STEP(2)
@@ -984,7 +990,7 @@ static __device__ __forceinline__ void coarse_walk(const CallPair *__restrict__ 
         DMX_COARSE_STEP(6)
         DMX_COARSE_STEP(7)
     }
-    const int rem = n_batches - k;
+    const int rem = n_batches - k;  // (k is a multiple of 8: the registers hold what a trip's start expects)
     if (rem > 0) {
         DMX_COARSE_STEP(0)
         if (rem > 1) {
@@ -1007,6 +1013,8 @@ static __device__ __forceinline__ void coarse_walk(const CallPair *__restrict__ 
         }
     }
 #undef DMX_COARSE_STEP
+#undef DMX_COARSE_CONSUME
+#undef DMX_COARSE_ISSUE
 }
 
 __global__ __launch_bounds__(256) void k_estep_tiled_coarse(EstepArgs a)
@@ -1017,7 +1025,7 @@ __global__ __launch_bounds__(256) void k_estep_tiled_coarse(EstepArgs a)
     const int R = a.bin_rows_cap;
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const long long slot_id = (long long)blockIdx.x * 4 + wave;
-    if (guard_stand_back(a)) return;  // the E-step runs direct (EstepArgs::direct)
+    if (guard_stand_back(a)) return;  // another level runs (EstepArgs::direct)
     if (slot_id >= a.n_bins) return;
     const long long bin = a.bin_order[slot_id];
     int kk[1];
@@ -1025,14 +1033,14 @@ __global__ __launch_bounds__(256) void k_estep_tiled_coarse(EstepArgs a)
     valid[0] = lane < K;
     kk[0] = valid[0] ? lane : K - 1;
     for (int r = 0; r < R; r++) sh_acc[wave][r][lane] = CoarseSum{0.0f, 0.0f};
-    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void *)a.prob16, 0, (int)a.prob_bytes, 0x00020000);
-    const long long g0 = a.bin_ptr[bin];
-    const int n_batches = (int)(a.bin_ptr[bin + 1] - g0);
-    const CallPair *__restrict__ recs = a.tile_stream + g0 * 4;
+    // (the table's extent + the all-zero row behind it)
+    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void *)a.prob16, 0, (int)(a.prob_bytes + (unsigned)a.G * 4u), 0x00020000);
+    const int n_batches = (int)(a.bin_ptr[bin + 1] - a.bin_ptr[bin]);
+    const unsigned *__restrict__ stream = a.coarse_stream + a.coarse_bin_ptr[bin] * 32;
     CoarseSum lacc{0.0f, 0.0f};
     int cur = 0;  // slot whose sums are in registers
     // genotypes 2 l, 2 l + 1 of the lane's half: one dword of the binary16 row (a pair past G reads into the unused half of the row)
-    coarse_walk(recs, n_batches, rsrc, (unsigned)(lane & 31) * 4u, lane, lacc, [&](int, int tag) {
+    coarse_walk(stream, n_batches, rsrc, (unsigned)(lane & 31) * 4u, lane, lacc, [&](int, int tag) {
         if (tag == cur) return;  // (wave-uniform)
         sh_acc[wave][cur][lane] = lacc;
         lacc = sh_acc[wave][tag][lane];
@@ -1047,9 +1055,94 @@ __global__ __launch_bounds__(256) void k_estep_tiled_coarse(EstepArgs a)
         v.hi += __shfl_xor(v.hi, 32);
         const float lo = __shfl(v.lo, lane >> 1), hi = __shfl(v.hi, lane >> 1);  // option k = lane: genotype k of lane k / 2
         double out[1];
-        out[0] = (double)((lane & 1) ? hi : lo) * 0.693147180559945309417232121458176568;
-        estep_epilogue<64, 1, true>(a, (long long)row, true, out, kk, valid, lane, lane, 0, 2 * (int)(a.pair_ptr[row + 1] - a.pair_ptr[row]));
+        const double lk = a.log2_keep[row];
+        out[0] = ((double)((lane & 1) ? hi : lo) + lk) * 0.693147180559945309417232121458176568;
+        // (the float32 partial sums are those of log2(p + r) <= -log2 keep + 1.5e-4: up to 3 |log2_keep| beyond the total's magnitude)
+        estep_epilogue<64, 1, true>(a, (long long)row, true, out, kk, valid, lane, lane, 0, 2 * (int)(a.pair_ptr[row + 1] - a.pair_ptr[row]),
+                                    3.0f * 0.6931472f * fabsf((float)lk) * 1.000001f);
     }
+}
+
+// ---- the coarse pass's record stream and per-barcode constants (built once per problem, at its first admissible E-step) ----
+// first double batch of every bin: bins hold whole double batches
+__global__ __launch_bounds__(1024) void k_coarse_bin_ptr(const long long *__restrict__ bin_ptr, long long n_bins, long long *__restrict__ out)
+{
+    __shared__ long long part[1024];
+    const long long per = (n_bins + 1023) / 1024, b0 = (long long)threadIdx.x * per, b1 = b0 + per < n_bins ? b0 + per : n_bins;
+    long long mine = 0;
+    for (long long b = b0; b < b1; b++) mine += (bin_ptr[b + 1] - bin_ptr[b] + 1) >> 1;
+    part[threadIdx.x] = mine;
+    __syncthreads();
+    for (int off = 1; off < 1024; off <<= 1) {
+        const long long add = (int)threadIdx.x >= off ? part[threadIdx.x - off] : 0;
+        __syncthreads();
+        part[threadIdx.x] += add;
+        __syncthreads();
+    }
+    long long at = part[threadIdx.x] - mine;
+    for (long long b = b0; b < b1; b++) {
+        out[b] = at;
+        at += (bin_ptr[b + 1] - bin_ptr[b] + 1) >> 1;
+    }
+    if (threadIdx.x == 1023) out[n_bins] = part[1023];
+}
+
+// one wavefront per bin: the bin's groups of the tile-major stream (4 CallPairs = 8 calls each) -> its double batches
+__global__ __launch_bounds__(256) void k_build_coarse_stream(const CallPair *__restrict__ stream, const long long *__restrict__ bin_ptr,
+                                                             const long long *__restrict__ coarse_bin_ptr, long long n_bins, unsigned zero_off,
+                                                             unsigned *__restrict__ out)
+{
+    const long long bin = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (bin >= n_bins) return;
+    const int lane = threadIdx.x & 63;
+    const long long g0 = bin_ptr[bin];
+    const int n_groups = (int)(bin_ptr[bin + 1] - g0), n_double = (n_groups + 1) >> 1;
+    unsigned *dst = out + coarse_bin_ptr[bin] * 32;
+    for (int i = lane; i < n_double * 32; i += 64) {
+        const int d = i >> 5, w = i & 31, half = w >> 4, batch = 2 * d + ((w >> 3) & 1), f = w & 7, q = f & 3;
+        unsigned off = zero_off;
+        float r = 1.0f;
+        unsigned tag = 0u;
+        if (batch < n_groups) {
+            const CallPair *grp = stream + (g0 + batch) * 4;
+            const CallPair p = grp[q];
+            tag = grp[0].reserved[0];
+            const float keep = p.keep[half], flo = p.floor[half];
+            if (keep > 0.0f) {
+                off = p.row_off[half];
+                r = flo / keep;  // keep = fl(1 - e) >= 2^-24, floor <= 1: r < 2^25, a product of 4 sums below 2^100
+            } else if (keep == 0.0f) {
+                r = flo;  // p keep + floor = floor: the all-zero row
+            } else {
+                r = __builtin_nanf("");  // a negative or NaN keep factor (p_base_wrong beyond 1): NaN sums, the guard queues the barcode
+            }
+        } else if (n_groups > 0) {
+            tag = stream[(g0 + n_groups - 1) * 4].reserved[0];  // the padding batch stays in the last group's slot
+        }
+        unsigned word = off;
+        if (f >= 4) {
+            word = __float_as_uint(r);
+            if (f == 4) word = (word & ~15u) | (tag & 15u);  // r0: the batch's slot tag in its low 4 bits (both halves carry it, the lower one's is read)
+        }
+        dst[i] = word;
+    }
+}
+
+// sum over a barcode's calls of log2(keep), keep > 0 (one wavefront per barcode; float64)
+__global__ __launch_bounds__(256) void k_barcode_log2_keep(const CallPair *__restrict__ pairs, const long long *__restrict__ pair_ptr, long long B,
+                                                           double *__restrict__ out)
+{
+    const long long b = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (b >= B) return;
+    const int lane = threadIdx.x & 63;
+    double s = 0.0;
+    for (long long i = pair_ptr[b] + lane; i < pair_ptr[b + 1]; i += 64) {
+        const CallPair p = pairs[i];
+        if (p.keep[0] > 0.0f) s += log2((double)p.keep[0]);
+        if (p.keep[1] > 0.0f) s += log2((double)p.keep[1]);
+    }
+    for (int off = 32; off > 0; off >>= 1) s += shfl_xor_f64(s, off);
+    if (lane == 0) out[b] = s;
 }
 
 // float32 genotype table -> binary16, round to nearest even, at the float32 table's row offsets (EstepArgs::prob16)
@@ -2650,6 +2743,27 @@ __global__ __launch_bounds__(256) void k_check_unit_range(const float *__restric
     const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     const bool bad = i < n && !(x[i < n ? i : 0] >= 0.0f && x[i < n ? i : 0] <= 1.0f);
     if (__ballot(bad) != 0ull && (threadIdx.x & 63) == 0) atomicOr(flags, 1);
+}
+
+hipError_t launch_build_coarse_stream(hipStream_t st, const CallPair *stream, const long long *bin_ptr, long long n_bins, unsigned zero_off,
+                                      long long *coarse_bin_ptr, unsigned *out)
+{
+    if (n_bins == 0) return hipSuccess;
+    hipLaunchKernelGGL(k_build_coarse_stream, dim3(blocks_for(n_bins, 4)), dim3(256), 0, st, stream, bin_ptr, coarse_bin_ptr, n_bins, zero_off, out);
+    return hipGetLastError();
+}
+
+hipError_t launch_coarse_bin_ptr(hipStream_t st, const long long *bin_ptr, long long n_bins, long long *coarse_bin_ptr)
+{
+    hipLaunchKernelGGL(k_coarse_bin_ptr, dim3(1), dim3(1024), 0, st, bin_ptr, n_bins, coarse_bin_ptr);
+    return hipGetLastError();
+}
+
+hipError_t launch_barcode_log2_keep(hipStream_t st, const CallPair *pairs, const long long *pair_ptr, long long B, double *out)
+{
+    if (B == 0) return hipSuccess;
+    hipLaunchKernelGGL(k_barcode_log2_keep, dim3(blocks_for(B, 4)), dim3(256), 0, st, pairs, pair_ptr, B, out);
+    return hipGetLastError();
 }
 
 hipError_t launch_prob_to_half(hipStream_t st, const float *prob, long long rows, int G, unsigned short *out, const unsigned *skip)

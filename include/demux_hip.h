@@ -239,7 +239,8 @@ int dmx_set_guard_adaptive(dmx_ctx *ctx, int adaptive);
  * coarse = 0: never (the guarded mode of round 4).  Default 1.  coarse = 2: admissible for EVERY E-step, the last one of a call and
  * dmx_estep included - their logits then carry the bound D (tests and measurements).  dmx_get_guard_levels: level of the last guarded E-step
  * (0 coarse, 1 fine, 2 direct; -1: none), E-steps that took the coarse pass since dmx_reset_timings, barcodes the fine / the
- * coarse guard flagged in the last one (-1: not evaluated), and the device's timings of the three passes over all barcodes
+ * coarse guard flagged in the last one (-1: not evaluated; the guard of a pass that did not run is shown one barcode in 8: an
+ * estimate), and the device's timings of the three passes over all barcodes
  * in ms (0: not run yet; exact: negative while it is an estimate).  Any pointer may be NULL. */
 int dmx_set_coarse_pass(dmx_ctx *ctx, int coarse);
 int dmx_get_guard_levels(dmx_ctx *ctx, int32_t *level_last, int64_t *coarse_steps, int64_t *flagged_fine_last, int64_t *flagged_coarse_last,

@@ -49,7 +49,7 @@ def test_em_call_takes_the_coarse_pass_for_all_but_its_last_estep(separable):
             ctx.close()
     lv = out['default'][3]
     assert lv['level'] == 1, lv                      # the last E-step: the fine pass
-    assert lv['coarse_steps'] == 4, lv               # E-steps 1 .. 4
+    assert lv['coarse_steps'] in (3, 4), lv          # E-steps 1 .. 4 (the fine pass, never timed on this problem, may be given one of them: k_guard_begin)
     assert lv['coarse_pass_ms'] > 0, lv              # (the last E-step's own time is folded in when the next one begins)
     assert out['fine only'][3]['coarse_steps'] == 0 and out['fine only'][3]['flagged_coarse'] == -1
     n_calls_v = np.bincount(p.variant_id, minlength=p.n_variants).astype(np.float64)[:, None]
