@@ -1272,19 +1272,19 @@ int run_estep(dmx_ctx *c, int with_doublets, bool with_prior, int prior_dtype, f
             // table whose clip keeps binary16 normal) is admissible when nobody can read this E-step's logits.  Which of coarse pass,
             // fine pass and the direct form runs is the device's choice (k_guard_begin): both fast launches are issued, the one
             // that is not taken stands back.
-            const bool capable = c->coarse_pass && !with_doublets && c->K > 32 && c->K <= 64 && a.n_bins > 0 && c->p_clip_lo >= 6.2e-5f &&
+            const bool capable = c->coarse_pass && !with_doublets && c->K > 16 && c->K <= 64 && a.n_bins > 0 && c->p_clip_lo >= 6.2e-5f &&
                                  (unsigned long long)a.prob_bytes + (unsigned long long)c->G * 4ull < (1ull << 32);
             const bool allow_coarse = capable && (!logits_kept || c->coarse_pass == 2);
             if (allow_coarse && !c->coarse_ready) {
                 // once per problem, ahead of k_guard_begin's time stamp (not part of the pass the device times): the coarse pass's
                 // records - 8 bytes per call where the tile-major stream has 16 - and the log2 of the keep factors per barcode
-                const size_t words = (((size_t)c->n_pairs / 4 + (size_t)c->n_bins) / 2 + 1) * 32;
+                const int cpg = dmx::coarse_calls_per_gather((int)c->K), bpr = dmx::coarse_batches_per_record(cpg);
+                const size_t words = (((size_t)c->n_pairs / 4 + (size_t)c->n_bins * (bpr - 1)) / bpr + 1) * (size_t)(cpg * 16);
                 DMX_TRY(dev_alloc(c, &c->d_coarse_stream, words));
                 c->cap_coarse_stream = words;
                 DMX_TRY(dev_alloc(c, &c->d_coarse_bin_ptr, (size_t)c->n_bins + 1));
                 DMX_TRY(dev_alloc(c, &c->d_log2_keep, (size_t)c->B));
-                HIP_TRY(dmx::launch_coarse_bin_ptr(c->stream, c->d_bin_ptr, c->n_bins, c->d_coarse_bin_ptr));
-                HIP_TRY(dmx::launch_build_coarse_stream(c->stream, c->d_tile_stream, c->d_bin_ptr, c->n_bins, a.prob_bytes, c->d_coarse_bin_ptr, c->d_coarse_stream));
+                HIP_TRY(dmx::launch_build_coarse_stream(c->stream, c->d_tile_stream, c->d_bin_ptr, c->n_bins, a.prob_bytes, cpg, c->d_coarse_bin_ptr, c->d_coarse_stream));
                 HIP_TRY(dmx::launch_barcode_log2_keep(c->stream, c->d_call_pairs, c->d_pair_ptr, c->B, c->d_log2_keep));
                 c->coarse_ready = true;
             }

@@ -136,8 +136,7 @@ hipError_t launch_mstep(hipStream_t, const MstepArgs &) { return hipSuccess; }
 hipError_t launch_mstep_tiles(hipStream_t, const MstepArgs &, const MTileArgs &) { return hipSuccess; }
 hipError_t launch_guard_begin(hipStream_t, unsigned *, long long, int, int, int, int) { return hipSuccess; }
 hipError_t launch_prob_to_half(hipStream_t, const float *, long long, int, unsigned short *, const unsigned *) { return hipSuccess; }
-hipError_t launch_coarse_bin_ptr(hipStream_t, const long long *, long long, long long *) { return hipSuccess; }
-hipError_t launch_build_coarse_stream(hipStream_t, const CallPair *, const long long *, long long, unsigned, long long *, unsigned *) { return hipSuccess; }
+hipError_t launch_build_coarse_stream(hipStream_t, const CallPair *, const long long *, long long, unsigned, int, long long *, unsigned *) { return hipSuccess; }
 hipError_t launch_barcode_log2_keep(hipStream_t, const CallPair *, const long long *, long long, double *) { return hipSuccess; }
 hipError_t launch_guard_stamp(hipStream_t, unsigned *, int) { return hipSuccess; }
 hipError_t launch_guard_compact(hipStream_t, unsigned *, const int *, unsigned, int *, const int *, long long) { return hipSuccess; }

@@ -119,8 +119,8 @@ struct EstepArgs {
     const int *bin_order;       // [n_bins] bins by decreasing number of calls
     const int *bin_rows;        // [n_bins][R] barcodes of the bin (-1: empty slot)
     const long long *bin_ptr;   // [n_bins + 1] first group (4 CallPairs = 8 calls) of every bin in tile_stream
-    const unsigned *coarse_stream;    // nullable: the coarse pass's records (kernels.hip: coarse_walk), 32 dwords per double batch of 16 calls
-    const long long *coarse_bin_ptr;  // [n_bins + 1] first double batch of every bin in coarse_stream
+    const unsigned *coarse_stream;    // nullable: the coarse pass's records (kernels.hip: coarse_walk), 16 dwords per block and record
+    const long long *coarse_bin_ptr;  // [n_bins + 1] first record of every bin in coarse_stream
     const double *log2_keep;          // [B] sum of log2(keep) over the barcode's calls: the coarse pass's terms are (p + floor / keep)
     const CallPair *tile_stream;  // the call records in bin-major, tile-major, slot-minor order; reserved[0] of a
                                   // group's first pair = the slot (accumulator) the group belongs to
@@ -270,10 +270,12 @@ hipError_t launch_probs_from_betas_f64(hipStream_t st, const double *betas, cons
 // sets flags[0] bit 0 when a value lies outside [0, 1] or is not finite
 hipError_t launch_check_unit_range(hipStream_t st, const float *x, long long n, int *flags);
 hipError_t launch_estep(hipStream_t st, const EstepArgs &a, bool pairs);
-// the coarse pass's records from the tile-major stream: coarse_bin_ptr first (one block), then the stream; zero_off = byte offset of the all-zero row
-hipError_t launch_coarse_bin_ptr(hipStream_t st, const long long *bin_ptr, long long n_bins, long long *coarse_bin_ptr);
+// the coarse pass's records from the tile-major stream (coarse_bin_ptr first, one block; then the stream); cpg = calls per gather: 2 for
+// 33 .. 64 genotypes, 4 for 17 .. 32; zero_off = byte offset of the all-zero row behind the table
+constexpr int coarse_calls_per_gather(int K) { return K > 32 ? 2 : 4; }
+constexpr int coarse_batches_per_record(int cpg) { return cpg; }  // (kernels.hip: CoarseShape<CPG>::BPR)
 hipError_t launch_build_coarse_stream(hipStream_t st, const CallPair *stream, const long long *bin_ptr, long long n_bins, unsigned zero_off,
-                                      long long *coarse_bin_ptr, unsigned *out);
+                                      int cpg, long long *coarse_bin_ptr, unsigned *out);
 hipError_t launch_barcode_log2_keep(hipStream_t st, const CallPair *pairs, const long long *pair_ptr, long long B, double *out);
 hipError_t launch_prob_to_half(hipStream_t st, const float *prob, long long rows, int G, unsigned short *out, const unsigned *skip);  // EstepArgs::prob16; *skip != 0: nothing
 hipError_t launch_softmax_rows(hipStream_t st, const EstepArgs &a);  // rows left as logits by the option-tile launches

@@ -22,6 +22,7 @@
 #include <cstring>
 
 #include <type_traits>
+#include <utility>
 #include "kernels.h"
 #include "np_math.h"
 #include "estep_epilogue.h"
@@ -900,10 +901,6 @@ static __device__ __forceinline__ unsigned row_bcast(unsigned v, int n)  // lane
     return v;
 }
 
-struct CoarseBatch {
-    unsigned h[4];  // gather q: binary16 probabilities of genotypes 2 (lane % 32), + 1 of call 2 q (lanes 0 .. 31) / 2 q + 1 (lanes 32 .. 63)
-};
-
 // v_add_f32 whose first source is lane N of the caller's row of 16 lanes (written out: the vectoriser pairs the builtin's additions
 // into packed ones, which cannot take a DPP operand - two v_mov_b32_dpp and a v_mov per operand instead of none)
 template <int N>
@@ -915,108 +912,110 @@ static __device__ __forceinline__ float add_row_bcast(unsigned w, float x)
 }
 
 struct CoarseSum {
-    float lo, hi;  // sums of log2 for genotypes 2 (lane % 32) and + 1 over the calls of this lane's half
+    float lo, hi;  // sums of log2 for genotypes 2 i and 2 i + 1 (i = lane % lanes per call) over the calls of this lane's block
+};
+
+template <typename F, int... I>
+static __device__ __forceinline__ void for_each_int(std::integer_sequence<int, I...>, F f)  // f(integral_constant<int, 0>) ... in order
+{
+    (f(std::integral_constant<int, I>{}), ...);
+}
+
+// Shape of the coarse pass for CPG calls per 256-byte gather: 2 (33 .. 64 genotypes: a call's binary16 row is 128 bytes, 32 lanes) or
+// 4 (17 .. 32 genotypes: 64 bytes, 16 lanes).  Lanes of BLOCK j = lane / (64 / CPG) take call q CPG + j of a group's gather q.
+template <int CPG>
+struct CoarseShape {
+    static constexpr int LPC = 64 / CPG;  // lanes per call
+    static constexpr int GPB = 8 / CPG;   // gathers per batch (= one group of 8 calls of one barcode)
+    static constexpr int BPR = 8 / GPB;   // batches per record: a block's record is 16 dwords = BPR x (GPB offsets, GPB r)
+    static constexpr int DD = 4;          // records in registers
+    static constexpr int T = DD * BPR;    // batches per trip of the unrolled loop
+    static constexpr int GA = CPG == 2 ? 3 : 7;  // batches whose gathers are in flight while one is consumed (12 / 14 gathers)
+    static constexpr int DG = GA + 1;
+    static_assert(T % DG == 0, "ring slots must be fixed registers");
 };
 
 // The coarse pass's own record stream (launch_build_coarse_stream): per call a row offset and r = floor / keep -
 //     term = p keep + floor = keep (p + r):   log2 of a barcode's product = sum_c log2(p_c + r_c) + sum_c log2 keep_c,
 // the second sum the same for every option (EstepArgs::log2_keep, added in the epilogue): ONE addition per term instead of a
-// multiplication and an addition, 8 bytes per call instead of 16.  A DOUBLE BATCH (16 calls) is 32 dwords:
-//     [ even calls:  A: off0 off2 off4 off6  r0 r2 r4 r6 | B: the same of the second batch ][ odd calls: A: off1 .. r7 | B: ... ]
-// lane i of the two lower rows of 16 lanes loads dword i, of the two upper rows dword 16 + i: one dword per lane and TWO batches; the
-// slot tag of a batch sits in the low 4 bits of its r0 (2^-19 of r: priced).  Padding calls - and calls with keep = 0 - gather the
-// all-zero row behind the table with r = floor: p + r = floor exactly.  Every bin starts at a double batch (coarse_bin_ptr).
-template <typename OnGroup>
+// multiplication and an addition, 8 bytes per call instead of 16.  A RECORD is CPG blocks of 16 dwords and covers BPR batches; block j,
+// batch s of the record:  dwords s 2 GPB + q: row offset of call q CPG + j,  s 2 GPB + GPB + q: its r  (CPG = 2: the even calls' block
+// [A: off0 off2 off4 off6 r0 r2 r4 r6 | B: ...] and the odd calls').  Lane i of a row of 16 lanes loads dword i of its block: one
+// dword per lane for BPR batches, and every field reaches the arithmetic as a DPP row broadcast.  The slot tag of a batch sits in the
+// low 4 bits of its r0 (2^-19 of r: priced).  Padding calls - and calls with keep = 0 - gather the all-zero row behind the table with
+// r = floor: p + r = floor exactly.  Every bin starts at a record (coarse_bin_ptr).
+template <int CPG, typename OnGroup>
 static __device__ __forceinline__ void coarse_walk(const unsigned *__restrict__ stream, int n_batches, __amdgpu_buffer_rsrc_t rsrc,
                                                    unsigned lane_off, int lane, CoarseSum &lacc, OnGroup on_group)
 {
+    using S = CoarseShape<CPG>;
+    constexpr int GPB = S::GPB, BPR = S::BPR, DD = S::DD, T = S::T, GA = S::GA, DG = S::DG;
     if (n_batches <= 0) return;
-    constexpr int DG = 4;  // gathers of batches k+1 .. k+3 in flight while batch k is consumed
-    constexpr int DD = 4;  // double batches of records in registers: fetched 8 batches ahead of their consumption
-    const int n_double = (n_batches + 1) >> 1;
-    const unsigned *__restrict__ words = stream + ((lane >> 5) * 16 + (lane & 15));
-    auto fetch = [&](int d) {  // (double batches past the end re-read the last one)
-        const int dc = d < n_double ? d : n_double - 1;
-        return __builtin_nontemporal_load(&words[(size_t)dc * 32]);
+    const int n_rec = (n_batches + BPR - 1) / BPR;
+    const unsigned *__restrict__ words = stream + ((lane / S::LPC) * 16 + (lane & 15));
+    auto fetch = [&](int d) {  // (records past the end re-read the last one)
+        const int dc = d < n_rec ? d : n_rec - 1;
+        return __builtin_nontemporal_load(&words[(size_t)dc * (CPG * 16)]);
     };
-    auto issue = [&](unsigned w, auto second, CoarseBatch &g) {
-        constexpr int S = decltype(second)::value;
+    struct Gathers {
+        unsigned h[GPB];  // gather q: binary16 probabilities of genotypes 2 i, 2 i + 1 of this block's call of gather q
+    };
+    auto issue = [&](unsigned w, auto sel, Gathers &g) {
+        constexpr int B0 = decltype(sel)::value * 2 * GPB;
 #pragma unroll
-        for (int q = 0; q < 4; q++) g.h[q] = __builtin_amdgcn_raw_buffer_load_b32(rsrc, (int)(row_bcast(w, 8 * S + q) + lane_off), 0, 0);
+        for (int q = 0; q < GPB; q++) g.h[q] = __builtin_amdgcn_raw_buffer_load_b32(rsrc, (int)(row_bcast(w, B0 + q) + lane_off), 0, 0);
     };
-    auto consume = [&](int k, unsigned w, auto second, const CoarseBatch &g) {
-        constexpr int S = decltype(second)::value;
-        on_group(k, __builtin_amdgcn_readlane((int)w, 8 * S + 4) & 15);
+    auto consume = [&](int k, unsigned w, auto sel, const Gathers &g) {
+        constexpr int R0 = decltype(sel)::value * 2 * GPB + GPB;
+        on_group(k, __builtin_amdgcn_readlane((int)w, R0) & 15);
         auto lo = [](unsigned h) { return (float)__builtin_bit_cast(_Float16, (unsigned short)(h & 0xFFFFu)); };
         auto hi = [](unsigned h) { return (float)__builtin_bit_cast(_Float16, (unsigned short)(h >> 16)); };
-        float prod_lo = add_row_bcast<8 * S + 4>(w, lo(g.h[0])), prod_hi = add_row_bcast<8 * S + 4>(w, hi(g.h[0]));
-        prod_lo = prod_lo * add_row_bcast<8 * S + 5>(w, lo(g.h[1]));
-        prod_hi = prod_hi * add_row_bcast<8 * S + 5>(w, hi(g.h[1]));
-        prod_lo = prod_lo * add_row_bcast<8 * S + 6>(w, lo(g.h[2]));
-        prod_hi = prod_hi * add_row_bcast<8 * S + 6>(w, hi(g.h[2]));
-        prod_lo = prod_lo * add_row_bcast<8 * S + 7>(w, lo(g.h[3]));
-        prod_hi = prod_hi * add_row_bcast<8 * S + 7>(w, hi(g.h[3]));
-        lacc.lo += __builtin_amdgcn_logf(prod_lo);  // v_log_f32 = log2 of a product of 4 sums p + r
+        float prod_lo = add_row_bcast<R0>(w, lo(g.h[0])), prod_hi = add_row_bcast<R0>(w, hi(g.h[0]));
+        prod_lo = prod_lo * add_row_bcast<R0 + 1>(w, lo(g.h[1]));
+        prod_hi = prod_hi * add_row_bcast<R0 + 1>(w, hi(g.h[1]));
+        if constexpr (GPB == 4) {
+            prod_lo = prod_lo * add_row_bcast<R0 + 2>(w, lo(g.h[2]));
+            prod_hi = prod_hi * add_row_bcast<R0 + 2>(w, hi(g.h[2]));
+            prod_lo = prod_lo * add_row_bcast<R0 + 3>(w, lo(g.h[3]));
+            prod_hi = prod_hi * add_row_bcast<R0 + 3>(w, hi(g.h[3]));
+        }
+        lacc.lo += __builtin_amdgcn_logf(prod_lo);  // v_log_f32 = log2 of a product of GPB sums p + r
         lacc.hi += __builtin_amdgcn_logf(prod_hi);
     };
-    using First = std::integral_constant<int, 0>;
-    using Second = std::integral_constant<int, 1>;
     unsigned w[DD];
-    CoarseBatch g[DG];
+    Gathers g[DG];
 #pragma unroll
     for (int j = 0; j < DD; j++) w[j] = fetch(j);
-    issue(w[0], First{}, g[0]);
-    issue(w[0], Second{}, g[1]);
-    issue(w[1], First{}, g[2]);
-    // Unrolled by 8 batches, so that every ring slot is a fixed register.  ONE exit and the remainder peeled: with a `break` after every
-    // step the compiler unifies the exits into a block that also carries the back edge, the wait-count analysis then sees the loop's
-    // head reached from states in which a register's load was the last one issued, and puts s_waitcnt vmcnt(0) there.
-    // step U of a trip starting at batch k: gathers of batch k + U + 3 issued, batch k + U consumed; behind an odd step its double
-    // batch's register takes the records of the double batch 4 ahead
-#define DMX_COARSE_ISSUE(U) issue(w[(((U) + 3) >> 1) & 3], std::integral_constant<int, ((U) + 3) & 1>{}, g[((U) + 3) & 3]);
-#define DMX_COARSE_CONSUME(U) consume(k + (U), w[((U) >> 1) & 3], std::integral_constant<int, (U) & 1>{}, g[(U) & 3]);
-#define DMX_COARSE_STEP(U)                                                    \
-    DMX_COARSE_ISSUE(U)                                                       \
-    DMX_COARSE_CONSUME(U)                                                     \
-    if (((U) & 1) != 0) w[((U) >> 1) & 3] = fetch(((k + (U)) >> 1) + DD);
+    auto prologue = [&](auto u) { issue(w[(decltype(u)::value / BPR) % DD], std::integral_constant<int, decltype(u)::value % BPR>{}, g[decltype(u)::value % DG]); };
+    // step U of a trip starting at batch k: the gathers of batch k + U + GA issued, batch k + U consumed; behind the last batch of a record
+    // its register takes the record DD ahead
+    auto step = [&](int k, auto u) {
+        constexpr int U = decltype(u)::value;
+        issue(w[((U + GA) / BPR) % DD], std::integral_constant<int, (U + GA) % BPR>{}, g[(U + GA) % DG]);
+        consume(k + U, w[(U / BPR) % DD], std::integral_constant<int, U % BPR>{}, g[U % DG]);
+        if constexpr (U % BPR == BPR - 1) w[(U / BPR) % DD] = fetch((k + U) / BPR + DD);
+    };
+    for_each_int(std::make_integer_sequence<int, GA>{}, prologue);
+    // ONE exit and the remainder peeled: with a `break` after every step the compiler unifies the exits into a block that also carries
+    // the back edge, the wait-count analysis then sees the loop's head reached from states in which a register's load was the last
+    // one issued, and puts s_waitcnt vmcnt(0) there - the pipeline drained once per trip.
     int k = 0;
-    for (; k + 8 <= n_batches; k += 8) {
-        DMX_COARSE_STEP(0)
-        DMX_COARSE_STEP(1)
-        DMX_COARSE_STEP(2)
-        DMX_COARSE_STEP(3)
-        DMX_COARSE_STEP(4)
-        DMX_COARSE_STEP(5)
-        DMX_COARSE_STEP(6)
-        DMX_COARSE_STEP(7)
-    }
-    const int rem = n_batches - k;  // (k is a multiple of 8: the registers hold what a trip's start expects)
-    if (rem > 0) {
-        DMX_COARSE_STEP(0)
-        if (rem > 1) {
-            DMX_COARSE_STEP(1)
-            if (rem > 2) {
-                DMX_COARSE_STEP(2)
-                if (rem > 3) {
-                    DMX_COARSE_STEP(3)
-                    if (rem > 4) {
-                        DMX_COARSE_STEP(4)
-                        if (rem > 5) {
-                            DMX_COARSE_STEP(5)
-                            if (rem > 6) {
-                                DMX_COARSE_STEP(6)
-                            }
-                        }
-                    }
-                }
+    for (; k + T <= n_batches; k += T)
+        for_each_int(std::make_integer_sequence<int, T>{}, [&](auto u) { step(k, u); });
+    const int rem = n_batches - k;  // (k is a multiple of T: the registers hold what a trip's start expects)
+    auto tail = [&](auto self, auto u) -> void {
+        constexpr int U = decltype(u)::value;
+        if constexpr (U < T - 1) {
+            if (rem > U) {
+                step(k, u);
+                self(self, std::integral_constant<int, U + 1>{});
             }
         }
-    }
-#undef DMX_COARSE_STEP
-#undef DMX_COARSE_CONSUME
-#undef DMX_COARSE_ISSUE
+    };
+    tail(tail, std::integral_constant<int, 0>{});
 }
 
+template <int CPG>
 __global__ __launch_bounds__(256) void k_estep_tiled_coarse(EstepArgs a)
 {
     __shared__ CoarseSum sh_acc[4][TILE_R_MAX][64];
@@ -1036,11 +1035,11 @@ __global__ __launch_bounds__(256) void k_estep_tiled_coarse(EstepArgs a)
     // (the table's extent + the all-zero row behind it)
     const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void *)a.prob16, 0, (int)(a.prob_bytes + (unsigned)a.G * 4u), 0x00020000);
     const int n_batches = (int)(a.bin_ptr[bin + 1] - a.bin_ptr[bin]);
-    const unsigned *__restrict__ stream = a.coarse_stream + a.coarse_bin_ptr[bin] * 32;
+    const unsigned *__restrict__ stream = a.coarse_stream + a.coarse_bin_ptr[bin] * (CPG * 16);
     CoarseSum lacc{0.0f, 0.0f};
     int cur = 0;  // slot whose sums are in registers
-    // genotypes 2 l, 2 l + 1 of the lane's half: one dword of the binary16 row (a pair past G reads into the unused half of the row)
-    coarse_walk(stream, n_batches, rsrc, (unsigned)(lane & 31) * 4u, lane, lacc, [&](int, int tag) {
+    // genotypes 2 i, 2 i + 1 of the lane's call: one dword of the binary16 row (a pair past G reads into the unused half of the row)
+    coarse_walk<CPG>(stream, n_batches, rsrc, (unsigned)(lane & (CoarseShape<CPG>::LPC - 1)) * 4u, lane, lacc, [&](int, int tag) {
         if (tag == cur) return;  // (wave-uniform)
         sh_acc[wave][cur][lane] = lacc;
         lacc = sh_acc[wave][tag][lane];
@@ -1051,8 +1050,11 @@ __global__ __launch_bounds__(256) void k_estep_tiled_coarse(EstepArgs a)
         const int row = a.bin_rows[bin * R + r];
         if (row < 0) continue;
         CoarseSum v = sh_acc[wave][r][lane];
-        v.lo += __shfl_xor(v.lo, 32);  // even calls (lanes 0 .. 31) + odd calls (lanes 32 .. 63)
-        v.hi += __shfl_xor(v.hi, 32);
+#pragma unroll
+        for (int off = 32; off >= CoarseShape<CPG>::LPC; off >>= 1) {  // the blocks' shares of the barcode's calls
+            v.lo += __shfl_xor(v.lo, off);
+            v.hi += __shfl_xor(v.hi, off);
+        }
         const float lo = __shfl(v.lo, lane >> 1), hi = __shfl(v.hi, lane >> 1);  // option k = lane: genotype k of lane k / 2
         double out[1];
         const double lk = a.log2_keep[row];
@@ -1064,13 +1066,13 @@ __global__ __launch_bounds__(256) void k_estep_tiled_coarse(EstepArgs a)
 }
 
 // ---- the coarse pass's record stream and per-barcode constants (built once per problem, at its first admissible E-step) ----
-// first double batch of every bin: bins hold whole double batches
-__global__ __launch_bounds__(1024) void k_coarse_bin_ptr(const long long *__restrict__ bin_ptr, long long n_bins, long long *__restrict__ out)
+// first record of every bin: bins hold whole records of bpr batches
+__global__ __launch_bounds__(1024) void k_coarse_bin_ptr(const long long *__restrict__ bin_ptr, long long n_bins, int bpr, long long *__restrict__ out)
 {
     __shared__ long long part[1024];
     const long long per = (n_bins + 1023) / 1024, b0 = (long long)threadIdx.x * per, b1 = b0 + per < n_bins ? b0 + per : n_bins;
     long long mine = 0;
-    for (long long b = b0; b < b1; b++) mine += (bin_ptr[b + 1] - bin_ptr[b] + 1) >> 1;
+    for (long long b = b0; b < b1; b++) mine += (bin_ptr[b + 1] - bin_ptr[b] + bpr - 1) / bpr;
     part[threadIdx.x] = mine;
     __syncthreads();
     for (int off = 1; off < 1024; off <<= 1) {
@@ -1082,30 +1084,34 @@ __global__ __launch_bounds__(1024) void k_coarse_bin_ptr(const long long *__rest
     long long at = part[threadIdx.x] - mine;
     for (long long b = b0; b < b1; b++) {
         out[b] = at;
-        at += (bin_ptr[b + 1] - bin_ptr[b] + 1) >> 1;
+        at += (bin_ptr[b + 1] - bin_ptr[b] + bpr - 1) / bpr;
     }
     if (threadIdx.x == 1023) out[n_bins] = part[1023];
 }
 
-// one wavefront per bin: the bin's groups of the tile-major stream (4 CallPairs = 8 calls each) -> its double batches
+// one wavefront per bin: the bin's groups of the tile-major stream (4 CallPairs = 8 calls each) -> its records (coarse_walk)
+template <int CPG>
 __global__ __launch_bounds__(256) void k_build_coarse_stream(const CallPair *__restrict__ stream, const long long *__restrict__ bin_ptr,
                                                              const long long *__restrict__ coarse_bin_ptr, long long n_bins, unsigned zero_off,
                                                              unsigned *__restrict__ out)
 {
+    using S = CoarseShape<CPG>;
     const long long bin = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (bin >= n_bins) return;
     const int lane = threadIdx.x & 63;
     const long long g0 = bin_ptr[bin];
-    const int n_groups = (int)(bin_ptr[bin + 1] - g0), n_double = (n_groups + 1) >> 1;
-    unsigned *dst = out + coarse_bin_ptr[bin] * 32;
-    for (int i = lane; i < n_double * 32; i += 64) {
-        const int d = i >> 5, w = i & 31, half = w >> 4, batch = 2 * d + ((w >> 3) & 1), f = w & 7, q = f & 3;
+    const int n_groups = (int)(bin_ptr[bin + 1] - g0), n_rec = (n_groups + S::BPR - 1) / S::BPR;
+    unsigned *dst = out + coarse_bin_ptr[bin] * (CPG * 16);
+    for (int i = lane; i < n_rec * CPG * 16; i += 64) {
+        const int rec = i / (CPG * 16), w = i % (CPG * 16), blk = w >> 4, d = w & 15;
+        const int batch = rec * S::BPR + d / (2 * S::GPB), f = d % (2 * S::GPB), q = f % S::GPB, call = q * CPG + blk;
         unsigned off = zero_off;
         float r = 1.0f;
         unsigned tag = 0u;
         if (batch < n_groups) {
             const CallPair *grp = stream + (g0 + batch) * 4;
-            const CallPair p = grp[q];
+            const CallPair p = grp[call >> 1];
+            const int half = call & 1;
             tag = grp[0].reserved[0];
             const float keep = p.keep[half], flo = p.floor[half];
             if (keep > 0.0f) {
@@ -1117,12 +1123,12 @@ __global__ __launch_bounds__(256) void k_build_coarse_stream(const CallPair *__r
                 r = __builtin_nanf("");  // a negative or NaN keep factor (p_base_wrong beyond 1): NaN sums, the guard queues the barcode
             }
         } else if (n_groups > 0) {
-            tag = stream[(g0 + n_groups - 1) * 4].reserved[0];  // the padding batch stays in the last group's slot
+            tag = stream[(g0 + n_groups - 1) * 4].reserved[0];  // the padding batches stay in the last group's slot
         }
         unsigned word = off;
-        if (f >= 4) {
+        if (f >= S::GPB) {
             word = __float_as_uint(r);
-            if (f == 4) word = (word & ~15u) | (tag & 15u);  // r0: the batch's slot tag in its low 4 bits (both halves carry it, the lower one's is read)
+            if (f == S::GPB) word = (word & ~15u) | (tag & 15u);  // r0: the batch's slot tag in its low 4 bits (every block carries it, block 0's is read)
         }
         dst[i] = word;
     }
@@ -2746,16 +2752,14 @@ __global__ __launch_bounds__(256) void k_check_unit_range(const float *__restric
 }
 
 hipError_t launch_build_coarse_stream(hipStream_t st, const CallPair *stream, const long long *bin_ptr, long long n_bins, unsigned zero_off,
-                                      long long *coarse_bin_ptr, unsigned *out)
+                                      int cpg, long long *coarse_bin_ptr, unsigned *out)
 {
     if (n_bins == 0) return hipSuccess;
-    hipLaunchKernelGGL(k_build_coarse_stream, dim3(blocks_for(n_bins, 4)), dim3(256), 0, st, stream, bin_ptr, coarse_bin_ptr, n_bins, zero_off, out);
-    return hipGetLastError();
-}
-
-hipError_t launch_coarse_bin_ptr(hipStream_t st, const long long *bin_ptr, long long n_bins, long long *coarse_bin_ptr)
-{
-    hipLaunchKernelGGL(k_coarse_bin_ptr, dim3(1), dim3(1024), 0, st, bin_ptr, n_bins, coarse_bin_ptr);
+    hipLaunchKernelGGL(k_coarse_bin_ptr, dim3(1), dim3(1024), 0, st, bin_ptr, n_bins, cpg == 2 ? CoarseShape<2>::BPR : CoarseShape<4>::BPR, coarse_bin_ptr);
+    if (cpg == 2)
+        hipLaunchKernelGGL(k_build_coarse_stream<2>, dim3(blocks_for(n_bins, 4)), dim3(256), 0, st, stream, bin_ptr, coarse_bin_ptr, n_bins, zero_off, out);
+    else
+        hipLaunchKernelGGL(k_build_coarse_stream<4>, dim3(blocks_for(n_bins, 4)), dim3(256), 0, st, stream, bin_ptr, coarse_bin_ptr, n_bins, zero_off, out);
     return hipGetLastError();
 }
 
@@ -2832,8 +2836,11 @@ static void launch_tiled(hipStream_t st, const EstepArgs &a)
 {
     const dim3 grid(blocks_for(a.n_bins, 4)), block(256);
     if constexpr (A == 1) {
-        if (a.fast && a.prob16 != nullptr && a.K > 32) {  // the coarse pass (guarded mode only: dmx_api.cpp: run_estep)
-            hipLaunchKernelGGL(k_estep_tiled_coarse, grid, block, 0, st, a);
+        if (a.fast && a.prob16 != nullptr) {  // the coarse pass (guarded mode only: dmx_api.cpp: run_estep)
+            if (a.K > 32)
+                hipLaunchKernelGGL(k_estep_tiled_coarse<2>, grid, block, 0, st, a);
+            else
+                hipLaunchKernelGGL(k_estep_tiled_coarse<4>, grid, block, 0, st, a);
             return;
         }
         if (a.fast && a.K <= 32) {  // two calls per gather

@@ -231,21 +231,18 @@ def test_config3_and_config2_guarded_mode_proves_the_contract(oracle, request, G
         ctx.apply_environment()
     assert rows == p.n_barcodes
     n_calls_b = 8 * ((np.bincount(p.compressed_cb, minlength=p.n_barcodes) + 7) // 8).astype(np.float64)[:, None]  # rows are padded to 8 calls
-    if G == 64:
-        assert levels['level'] == 0 and levels['flagged_coarse'] == redone_c and 0 <= levels['flagged_fine'] <= 2 * redone_c + 100, levels
-        dev_c = check_contract(probs_c, probs_exact, f'coarse pass vs exact, all {p.n_barcodes} barcodes')
-        assert redone_c <= 0.05 * p.n_barcodes, redone_c
-        # its logits: within the bound the guard itself priced them with (estep_epilogue.h) - barcodes it queued are the exact kernel's
-        mag = np.abs(logits_exact.astype(np.float64))
-        bound = 4.94e-4 * (n_calls_b + 8) + 6.0e-8 * (0.125 * n_calls_b + 2) * (mag + 3e-4 * n_calls_b) + 3.0e-7 * (mag + 2.1e-4 * n_calls_b) + 2.4e-7 * mag
-        worst = np.abs(logits_c.astype(np.float64) - logits_exact) / bound
-        assert worst.max() <= 1.0, (worst.max(), np.unravel_index(worst.argmax(), worst.shape))
-        n_calls_v = np.bincount(p.variant_id, minlength=p.n_variants).astype(np.float64)[:, None]
-        assert (np.abs(addition_c.astype(np.float64) - addition_exact) <= n_calls_v * 2.00001e-5 + 2.0 ** -22 * addition_exact).all()
-        print(f'coarse pass at 200k x 100k x 64: posteriors within {dev_c:.3g} of the exact mode, {redone_c} barcodes redone exactly, '
-              f'logits at most {worst.max():.3f} of their bound (largest deviation {np.abs(logits_c - logits_exact).max():.3g})')
-    else:
-        assert levels['level'] == 1 and levels['flagged_coarse'] == -1, levels  # (no coarse pass for tables of 32 genotypes)
+    assert levels['level'] == 0 and levels['flagged_coarse'] == redone_c and 0 <= levels['flagged_fine'] <= 2 * redone_c + 100, levels
+    dev_c = check_contract(probs_c, probs_exact, f'coarse pass vs exact, all {p.n_barcodes} barcodes')
+    assert redone_c <= 0.05 * p.n_barcodes, redone_c
+    # its logits: within the bound the guard itself priced them with (estep_epilogue.h) - barcodes it queued are the exact kernel's
+    mag = np.abs(logits_exact.astype(np.float64))
+    bound = 4.94e-4 * (n_calls_b + 8) + 6.0e-8 * (0.125 * n_calls_b + 2) * (mag + 3e-4 * n_calls_b) + 3.0e-7 * (mag + 2.1e-4 * n_calls_b) + 2.4e-7 * mag
+    worst = np.abs(logits_c.astype(np.float64) - logits_exact) / bound
+    assert worst.max() <= 1.0, (worst.max(), np.unravel_index(worst.argmax(), worst.shape))
+    n_calls_v = np.bincount(p.variant_id, minlength=p.n_variants).astype(np.float64)[:, None]
+    assert (np.abs(addition_c.astype(np.float64) - addition_exact) <= n_calls_v * 2.00001e-5 + 2.0 ** -22 * addition_exact).all()
+    print(f'coarse pass at 200k x 100k x {G}: posteriors within {dev_c:.3g} of the exact mode, {redone_c} barcodes redone exactly, '
+          f'logits at most {worst.max():.3f} of their bound (largest deviation {np.abs(logits_c - logits_exact).max():.3g})')
     dev = check_contract(probs_g, probs_exact, f'guarded vs exact, all {p.n_barcodes} barcodes')
     assert redone <= 0.05 * p.n_barcodes, redone
     for lo, hi in ((0, 1500), (120_000, 121_500)):
