@@ -892,7 +892,7 @@ typedef unsigned u32x2_t __attribute__((ext_vector_type(2)));
 
 static __device__ __forceinline__ unsigned row_bcast(unsigned v, int n)  // lane n of the caller's row of 16 lanes (n: compile-time after unrolling)
 {
-#define DMX_BC(N) case N: return (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x150 + N, 0xf, 0xf, false);
+#define DMX_BC(N) case N: return (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x150 + N, 0xf, 0xf, true);  // (bound_ctrl: no `old` value to prepare)
     switch (n) {
         DMX_BC(0) DMX_BC(1) DMX_BC(2) DMX_BC(3) DMX_BC(4) DMX_BC(5) DMX_BC(6) DMX_BC(7)
         DMX_BC(8) DMX_BC(9) DMX_BC(10) DMX_BC(11) DMX_BC(12) DMX_BC(13) DMX_BC(14) DMX_BC(15)
@@ -1037,15 +1037,17 @@ __global__ __launch_bounds__(256) void k_estep_tiled_coarse(EstepArgs a)
     const int n_batches = (int)(a.bin_ptr[bin + 1] - a.bin_ptr[bin]);
     const unsigned *__restrict__ stream = a.coarse_stream + a.coarse_bin_ptr[bin] * (CPG * 16);
     CoarseSum lacc{0.0f, 0.0f};
-    int cur = 0;  // slot whose sums are in registers
+    int cur = 0;  // slot whose sums are in registers, and where it parks them (kept as an address: one v_lshl_add per change of slot, not two)
+    CoarseSum *cur_at = &sh_acc[wave][0][lane];
     // genotypes 2 i, 2 i + 1 of the lane's call: one dword of the binary16 row (a pair past G reads into the unused half of the row)
     coarse_walk<CPG>(stream, n_batches, rsrc, (unsigned)(lane & (CoarseShape<CPG>::LPC - 1)) * 4u, lane, lacc, [&](int, int tag) {
         if (tag == cur) return;  // (wave-uniform)
-        sh_acc[wave][cur][lane] = lacc;
-        lacc = sh_acc[wave][tag][lane];
+        *cur_at = lacc;
+        cur_at = &sh_acc[wave][tag][lane];
+        lacc = *cur_at;
         cur = tag;
     });
-    sh_acc[wave][cur][lane] = lacc;
+    *cur_at = lacc;
     for (int r = 0; r < R; r++) {
         const int row = a.bin_rows[bin * R + r];
         if (row < 0) continue;
