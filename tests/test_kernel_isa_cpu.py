@@ -27,11 +27,7 @@ KERNELS = {
 
 @pytest.mark.skipif(shutil.which(HIPCC) is None and not os.path.exists(HIPCC), reason='hipcc not installed')
 def test_scalar_fed_kernels_keep_their_scalar_loads(tmp_path):
-    asm = tmp_path / 'kernels.s'
-    subprocess.check_call([HIPCC, '-O3', '-std=c++17', '-ffp-contract=off', '-fno-fast-math', '-I' + os.path.join(ROOT, 'include'),
-                           '-I/opt/rocm/include', '--offload-arch=gfx950', '-fhip-fp32-correctly-rounded-divide-sqrt', '-fno-gpu-rdc',
-                           '-S', '--cuda-device-only', os.path.join(CSRC, 'kernels.hip'), '-o', str(asm)], stderr=subprocess.DEVNULL)
-    text = asm.read_text()
+    text = _compile(tmp_path)
     for name, (min_scalar, max_vector, max_readlane) in KERNELS.items():
         start = text.index(name + ':')
         body = text[start:text.index('.Lfunc_end', start)]
@@ -43,3 +39,59 @@ def test_scalar_fed_kernels_keep_their_scalar_loads(tmp_path):
         assert scalar >= min_scalar and vector <= max_vector and readlane <= max_readlane, \
             f'{name}: {scalar} scalar loads (>= {min_scalar}), {vector} vector global loads (<= {max_vector}), {readlane} lane reads (<= {max_readlane}): ' \
             'the record stream is no longer fetched through the scalar cache (a store or a selected pointer ahead of the loads?)'
+
+
+def _compile(tmp_path):
+    asm = tmp_path / 'kernels.s'
+    if not asm.exists():
+        subprocess.check_call([HIPCC, '-O3', '-std=c++17', '-ffp-contract=off', '-fno-fast-math', '-I' + os.path.join(ROOT, 'include'),
+                               '-I/opt/rocm/include', '--offload-arch=gfx950', '-fhip-fp32-correctly-rounded-divide-sqrt', '-fno-gpu-rdc',
+                               '-S', '--cuda-device-only', os.path.join(CSRC, 'kernels.hip'), '-o', str(asm)], stderr=subprocess.DEVNULL)
+    return asm.read_text()
+
+
+def _main_loop(text, name):
+    """The longest innermost loop of a kernel: (its lines, the lines between its label and its first vector memory instruction)."""
+    start = text.index(name + ':')
+    body = text[start:text.index('.Lfunc_end', start)].splitlines()
+    best = None
+    for i, line in enumerate(body):
+        if 'Inner Loop Header' not in line:
+            continue
+        label = line.split(':')[0].strip()
+        back = [j for j, other in enumerate(body) if re.search(r's_c?branch\w*\s+' + re.escape(label) + r'\b', other)]
+        if back and (best is None or back[-1] - i > len(best)):
+            best = body[i:back[-1] + 1]
+    assert best is not None, f'{name}: no loop found'
+    head = []
+    for line in best[1:]:
+        if re.match(r'\s+(buffer_load|global_load)', line):
+            break
+        head.append(line)
+    return best, head
+
+
+# Software-pipelined walks of the tile-major E-step: gathers of several batches in flight across the loop's back edge.
+#   kernel -> (fewest `row_newbcast` DPP operands in the loop, most LDS reads in it per trip)
+PIPELINED = {
+    '_ZN3dmx20k_estep_tiled_coarseILi2EEEvNS_9EstepArgsE': (96, 8),   # coarse pass, 33 .. 64 genotypes: records through DPP only (LDS: the slot's sums)
+    '_ZN3dmx20k_estep_tiled_coarseILi4EEEvNS_9EstepArgsE': (96, 16),  # ... 17 .. 32 genotypes
+    '_ZN3dmx13k_estep_tiledILi1ELb1ELb0EEEvNS_9EstepArgsE': (0, 64),  # fine pass (records through LDS)
+}
+
+
+@pytest.mark.skipif(shutil.which(HIPCC) is None and not os.path.exists(HIPCC), reason='hipcc not installed')
+def test_pipelined_walks_do_not_drain_at_the_loop_head(tmp_path):
+    """A `break` after every step of an unrolled pipeline loop makes the compiler unify the exits into a block that also carries the
+    back edge; the wait-count analysis then sees the loop's head reached from states in which a register's load was the last one
+    issued and puts `s_waitcnt vmcnt(0)` there: the pipeline drained once per trip, same results.  The walks have ONE exit and a
+    peeled remainder; this test keeps them that way, and the coarse pass's records on the DPP path (no LDS, no lane reads per field)."""
+    text = _compile(tmp_path)
+    for name, (min_dpp, max_lds_reads) in PIPELINED.items():
+        loop, head = _main_loop(text, name)
+        assert not any('vmcnt(0)' in line for line in head), f'{name}: the loop waits for every load at its head:\n' + '\n'.join(head[:6])
+        drains = sum('vmcnt(0)' in line for line in loop)
+        assert drains == 0, f'{name}: {drains} x s_waitcnt vmcnt(0) inside the pipelined loop'
+        dpp = sum('row_newbcast' in line for line in loop)
+        lds_reads = sum(bool(re.match(r'\s+ds_read', line)) for line in loop)
+        assert dpp >= min_dpp and lds_reads <= max_lds_reads, f'{name}: {dpp} DPP row broadcasts (>= {min_dpp}), {lds_reads} LDS reads (<= {max_lds_reads}) per trip'
