@@ -16,7 +16,7 @@ for rep in 1 2; do
     lib=$GRAFT_REPO_ROOT/build/variants/libdemux_hip_$v.so
     [ $v = shipped ] && lib=$GRAFT_REPO_ROOT/demuxalot_amd/libdemux_hip.so
     DEMUXALOT_AMD_LIB=$lib timeout 300 python3 bench.py --timed-only --steps 30 --warmup 5 2>/dev/null | python3 -c "
-import json,sys; d=json.loads(sys.stdin.read()); print('$v', 'ms_per_step', round(d['ms_per_step'],4), 'estep', round(d['kernel_ms']['estep'],4), 'coarse pass (device)', d['estep_passes']['device_timed_ms']['coarse_pass'], 'guard', d['guard']['fraction'])" >> $OUT
+import json,sys; d=json.loads(sys.stdin.read()); print('$v', 'ms_per_step', round(d['ms_per_step'],4), 'estep', round(d['kernel_ms']['estep'],4), 'mstep', round(d['kernel_ms']['mstep'],4), 'coarse pass (device)', d['estep_passes']['device_timed_ms']['coarse_pass'], 'guard', d['guard']['fraction'])" >> $OUT
   done
 done
 cat $OUT
