@@ -2246,21 +2246,14 @@ __global__ __launch_bounds__(256) void k_mstep_calls(MstepArgs a)
 //   dense calls one at a time by the whole wavefront, lane g taking post[row, g].
 // The workgroup of a tile writes its rows of the output itself: no partial sums, no combining pass.
 // ------------------------------------------------------------------------------------
-// 1024 threads and 64 + 10 + 4 KB of LDS per workgroup: two workgroups = 32 wavefronts per CU (56 VGPRs).  Measured on 200k x 100k x
+// 1024 threads and 64 + 12 KB of LDS per workgroup: two workgroups = 32 wavefronts per CU (56 VGPRs).  Measured on 200k x 100k x
 // 64: 512 threads 0.46 ms, 1024 threads 0.34; 2 / 3 / 4 / 6 / 8 chunks in flight per wavefront 0.50 / 0.35 / 0.34 / 0.45 / 0.44
 // (beyond 64 VGPRs half the wavefronts); dense rows 8 / 16 / 32 at a time 0.36 / 0.34 / 0.47; non-temporal record loads: no change.
 // Requesting the next round's records before working on this one's: 70 VGPRs, or 64 with spills - 0.40 ms.
 // All loads as raw buffer loads with out-of-range masking (no EXEC regions, no 64-bit address arithmetic: 52 VGPRs, a tenth
 // fewer instructions): 0.34 ms as well (0.32 against 0.30 at 32 genotypes) - PMC: VALU 64 %, address unit 69 %, LDS 49 % busy.
 constexpr int MTILE_THREADS = 1024;
-constexpr int MTILE_QUEUE = 80;  // dense calls a wavefront parks before it takes their rows (64 + the flush threshold)
-// Sparse calls with a second .. fourth live posterior (5 % of the calls on the benchmark workload - but one in nearly every chunk of 64, so that
-// three predicated gathers and three predicated contributions ran for every chunk): parked like the dense calls and taken a lane each when
-// MTILE_EXTRA_FLUSH have gathered.  A chunk with more of them than that is handled in line as before (a workload of ambiguous barcodes).
-constexpr int MTILE_EXTRA_QUEUE = 32, MTILE_EXTRA_FLUSH = 16;
-#ifndef DMX_MTILE_EXTRAS_INLINE
-#define DMX_MTILE_EXTRAS_INLINE 0  // experiment builds: 1 = the form until round 5 (every chunk in line)
-#endif
+constexpr int MTILE_QUEUE = 96;  // dense calls a wavefront parks before it takes their rows (64 + the flush threshold)
 template <bool SQUARE>
 __global__ __launch_bounds__(MTILE_THREADS) void k_mstep_tiles(MstepArgs a, MTileArgs t)
 {
@@ -2277,10 +2270,8 @@ __global__ __launch_bounds__(MTILE_THREADS) void k_mstep_tiles(MstepArgs a, MTil
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int shift = __builtin_amdgcn_readfirstlane(t.shift[tile]);
-    __shared__ unsigned mt_extra[MTILE_THREADS / 64][2][MTILE_EXTRA_QUEUE];  // per wavefront: the same two words of its parked sparse calls with several live posteriors
     unsigned *q_rec = mt_queue[wave][0], *q_keep = mt_queue[wave][1];
-    unsigned *x_rec = mt_extra[wave][0], *x_keep = mt_extra[wave][1];
-    int queued = 0, extras = 0;  // (uniform)
+    int queued = 0;  // (uniform)
     auto power_of = [&](float c) { return SQUARE ? c * c : powf(c, a.power); };
     // c in [0, 1] -> rint(c 2^shift) as an integer: adding 1.5 x 2^52 leaves the rounded value (ties to even) in the low bits
     // of the sum's mantissa (c 2^shift < 2^51)
@@ -2313,29 +2304,6 @@ __global__ __launch_bounds__(MTILE_THREADS) void k_mstep_tiles(MstepArgs a, MTil
         __builtin_amdgcn_wave_barrier();
         queued = 0;
     };
-    // the parked sparse calls, a lane each: the barcode's code again (L2), its second .. fourth live posterior, their contributions
-    auto flush_extras = [&]() {
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        if (lane < extras) {
-            const unsigned rx = x_rec[lane], row = rx & 0xFFFFFFu;
-            const float keep = __uint_as_float(x_keep[lane]);
-            const int base = (int)(rx >> 24) * G;
-            const unsigned cy = a.first[row].y;
-            const int nnz = (int)(cy & 127u);
-            const float *__restrict__ post_row = a.post + (size_t)row * K;
-            float p[NZ_CODE - 1];
-#pragma unroll
-            for (int j = 1; j < NZ_CODE; j++) p[j - 1] = j < nnz ? post_row[(cy >> (7 + 6 * j)) & 63u] : 0.0f;
-#pragma unroll
-            for (int j = 1; j < NZ_CODE; j++)
-                if (j < nnz) add(base + (int)((cy >> (7 + 6 * j)) & 63u), power_of(p[j - 1] * keep));
-        }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        extras = 0;
-    };
     constexpr int UN = 4;  // chunks of 64 calls in flight per wavefront: records, then codes, then the rare extra posteriors
     for (long long c0 = beg + (long long)wave * (64 * UN); c0 < end; c0 += (long long)(MTILE_THREADS / 64) * 64 * UN) {
         uint2 rec[UN], code[UN];
@@ -2351,35 +2319,28 @@ __global__ __launch_bounds__(MTILE_THREADS) void k_mstep_tiles(MstepArgs a, MTil
             code[u] = make_uint2(0u, 0u);  // no live genotype
             if (i < end) code[u] = a.first[rec[u].x & 0xFFFFFFu];
         }
+        float extra[UN][NZ_CODE - 1];  // the second .. fourth live posterior of the sparse calls (5 % of them have any)
 #pragma unroll
         for (int u = 0; u < UN; u++) {
+            const int nnz = (int)(code[u].y & 127u);
+            const float *__restrict__ post_row = a.post + (size_t)(rec[u].x & 0xFFFFFFu) * K;
+#pragma unroll
+            for (int j = 1; j < NZ_CODE; j++) {
+                extra[u][j - 1] = 0.0f;
+                if (nnz <= NZ_CODE && j < nnz) extra[u][j - 1] = post_row[(code[u].y >> (7 + 6 * j)) & 63u];
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < UN; u++) {
+            const unsigned row = rec[u].x & 0xFFFFFFu;
             const int base = (int)(rec[u].x >> 24) * G;
             const float keep = __uint_as_float(rec[u].y);
             const int nnz = (int)(code[u].y & 127u);
-            if (nnz >= 1 && nnz <= NZ_CODE) add(base + (int)((code[u].y >> 7) & 63u), power_of(__uint_as_float(code[u].x) * keep));
-            // the second .. fourth live posterior of the sparse calls (5 % of them have any)
-            const bool several = nnz >= 2 && nnz <= NZ_CODE;
-            const unsigned long long more = __ballot(several);
-            if (more) {  // (uniform)
-                const int n_more = __popcll(more);
-                if (!DMX_MTILE_EXTRAS_INLINE && n_more <= MTILE_EXTRA_FLUSH) {
-                    if (extras + n_more > MTILE_EXTRA_QUEUE) flush_extras();
-                    if (several) {
-                        const int at = extras + __popcll(more & ((1ull << lane) - 1ull));
-                        x_rec[at] = rec[u].x;
-                        x_keep[at] = rec[u].y;
-                    }
-                    extras += n_more;
-                    if (extras >= MTILE_EXTRA_FLUSH) flush_extras();
-                } else {  // a chunk of ambiguous barcodes: in line
-                    const float *__restrict__ post_row = a.post + (size_t)(rec[u].x & 0xFFFFFFu) * K;
-                    float p[NZ_CODE - 1];
+            if (nnz >= 1 && nnz <= NZ_CODE) {
+                add(base + (int)((code[u].y >> 7) & 63u), power_of(__uint_as_float(code[u].x) * keep));
 #pragma unroll
-                    for (int j = 1; j < NZ_CODE; j++) p[j - 1] = (several && j < nnz) ? post_row[(code[u].y >> (7 + 6 * j)) & 63u] : 0.0f;
-#pragma unroll
-                    for (int j = 1; j < NZ_CODE; j++)
-                        if (several && j < nnz) add(base + (int)((code[u].y >> (7 + 6 * j)) & 63u), power_of(p[j - 1] * keep));
-                }
+                for (int j = 1; j < NZ_CODE; j++)
+                    if (j < nnz) add(base + (int)((code[u].y >> (7 + 6 * j)) & 63u), power_of(extra[u][j - 1] * keep));
             }
             const unsigned long long dense = __ballot(nnz > NZ_CODE);
             if (dense) {  // (uniform)
@@ -2394,7 +2355,6 @@ __global__ __launch_bounds__(MTILE_THREADS) void k_mstep_tiles(MstepArgs a, MTil
         }
     }
     if (queued) flush();
-    if (extras) flush_extras();
     __syncthreads();
     for (int i = threadIdx.x; i < nv * G; i += MTILE_THREADS) {
         const int r = (int)((unsigned)i / (unsigned)G), g = i - r * G;
