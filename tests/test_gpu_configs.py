@@ -256,6 +256,39 @@ def test_config3_and_config2_guarded_mode_proves_the_contract(oracle, request, G
     print(f'guarded mode at 200k x 100k x {G}: posteriors within {dev:.3g} of the exact mode, {redone} of {p.n_barcodes} barcodes redone exactly')
 
 
+def test_config3_twenty_iterations_in_the_default_mode_follow_the_exact_mode(problem64):
+    """The headline configuration as the bench runs it: ONE call of 20 EM iterations in the default mode - E-step 0 in the
+    dictionary form, 1 .. 18 on the coarse pass (binary16 table), the last one on the fine pass, the tile-major fixed-point
+    M-step from the first M-step on - against the same call in the exact mode: after 20 iterations every posterior of all
+    200 000 barcodes within 1e-5, every arg-max identical, the returned logits as close as the fine pass leaves them, the
+    additions within what such posteriors allow."""
+    from demuxalot_amd.device import DeviceContext
+    from tests.test_gpu_guarded import check_contract
+    p = problem64
+    pen = np.zeros(64, dtype=np.float32)
+    out = {}
+    for mode in ('exact', 'guarded'):
+        ctx = DeviceContext(0)
+        try:
+            ctx.set_estep_mode(mode)
+            ctx.set_exact_additions(mode == 'exact')
+            ctx.set_problem(p.n_barcodes, p.n_variants, 64, p.variant_id, p.compressed_cb, p.p_base_wrong, p.v2snp)
+            ctx.set_betas(p.prior_betas())
+            ctx.reset_timings()
+            logits, probs, addition = ctx.em(20, 0.01, pen, with_doublets=False)
+            out[mode] = (logits, probs, addition, ctx.guard_levels(), ctx.mstep_form())
+        finally:
+            ctx.close()
+    levels, form = out['guarded'][3], out['guarded'][4]
+    assert levels['level'] == 1 and levels['coarse_steps'] >= 17 and form == 'tiles', (levels, form)
+    dev = check_contract(out['guarded'][1], out['exact'][1], 'default vs exact after 20 iterations, all 200 000 barcodes')
+    d_logit = float(np.abs(out['guarded'][0] - out['exact'][0]).max())
+    assert d_logit <= 5e-3, d_logit
+    n_calls_v = np.bincount(p.variant_id, minlength=p.n_variants).astype(np.float64)[:, None]
+    assert (np.abs(out['guarded'][2].astype(np.float64) - out['exact'][2]) <= n_calls_v * 2.00001e-5 + 2.0 ** -22 * out['exact'][2]).all()
+    print(f'20 iterations at 200k x 100k x 64: {levels["coarse_steps"]} coarse E-steps; posteriors within {dev:.3g} of the exact run, logits within {d_logit:.3g}')
+
+
 def test_config3_uninformative_posteriors_mstep(oracle, problem64):
     """M-step worst case: posteriors from a flat genotype table (every donor equally likely at every variant,
     the start-from-assignment scenario of tests/test_synthetic.py:200-239 before any label is used): every call

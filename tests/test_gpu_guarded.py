@@ -67,6 +67,29 @@ def test_hardware_log2_of_a_mantissa_is_within_two_ulp():
     print(f'v_log_f32 on [0.5, 1): max abs error {err.max():.3e} = {err.max() / 2.0 ** -24:.2f} ulp(<1)')
 
 
+def test_hardware_log2_of_a_whole_product_is_within_two_ulp_of_its_result():
+    """The coarse pass (kernels.hip: coarse_walk) takes v_log_f32 of a 4-term product itself - anything in [1e-16, 2^100) - and prices
+    it at 2 ulp of a result below 128 in magnitude (1.53e-5 log2 units; kernels.h: GUARD_PER_CALL_COARSE).  Every binade of that range:
+    all 2^23 mantissas of 12 of them, 2^16 mantissas of every other one; the error against float64 log2 stays within 2 ulp OF THE
+    RESULT (and therefore below the priced 1.53e-5 everywhere)."""
+    from demuxalot_amd.device import get_context
+    ctx = get_context()
+    worst_abs, worst_ulp = 0.0, 0.0
+    dense = {-56, -40, -24, -8, -2, -1, 0, 1, 7, 33, 64, 99}
+    for e in range(-56, 100):
+        step = 1 if e in dense else 128
+        bits = (np.uint32(e + 127) << np.uint32(23)) + np.arange(0, 1 << 23, step, dtype=np.uint32)
+        x = bits.view(np.float32)
+        got = ctx.test_log2_hw(x).astype(np.float64)
+        want = np.log2(x.astype(np.float64))
+        err = np.abs(got - want)
+        ulp = np.spacing(np.abs(want).astype(np.float32)).astype(np.float64)
+        worst_abs = max(worst_abs, float(err.max()))
+        worst_ulp = max(worst_ulp, float((err / np.maximum(ulp, 2.0 ** -149)).max()))
+    assert worst_abs <= 1.53e-5 and worst_ulp <= 2.0, (worst_abs, worst_ulp)
+    print(f'v_log_f32 on [2^-56, 2^100): max abs error {worst_abs:.3e}, {worst_ulp:.2f} ulp of the result')
+
+
 @pytest.mark.parametrize('name', fio.SMALL + fio.SYNTH)
 def test_guarded_mode_meets_the_contract_on_reference_outputs(guarded, name):
     """predict_posteriors and every EM iteration of the golden fixtures (the reference's own outputs).  The first
