@@ -1777,14 +1777,15 @@ __global__ __launch_bounds__(GUARD_SLOTS) void k_guard_begin(unsigned *st, unsig
         st[GS_COUNT_FINE] = count_fine;
         st[GS_COUNT_COARSE] = count_coarse;
         // The coming E-step: the cheapest of  C + f_coarse E  (if admissible),  F + f_fine E  and  E, each pass's time as the device
-        // measured it.  A pass that has not run yet is priced from the other one - the coarse pass at 0.63 F (what it takes at
-        // 200k x 100k x 64), the fine pass at C (optimistic: it gets its turn and is measured) -; without any E (no E-step has
-        // queued 5 % of its barcodes) the redo is priced at 1.8 F for the choice between the two passes only - the direct form
-        // needs a measured or estimated E.  3 % of hysteresis.
+        // measured it.  A pass that has not run yet is priced from the other one at the ratio they have at 200k x 100k x 64 (C =
+        // 0.63 F) - no E-step is spent on finding out: the last E-step of every call takes the fine pass anyway (its logits are
+        // read) and measures F, the first admissible one the coarse pass -; without any E (no E-step has queued 5 % of its
+        // barcodes) the redo is priced at 1.8 F for the choice between the two passes only - the direct form needs a measured or
+        // estimated E.  3 % of hysteresis.
         double F = (double)st[GS_F_TICKS], C = (double)st[GS_C_TICKS];
         const double E = (double)st[GS_E_TICKS];
         if (adaptive && (F > 0.0 || C > 0.0)) {
-            if (F == 0.0) F = C;
+            if (F == 0.0) F = C / 0.63;
             if (C == 0.0) C = 0.63 * F;
             const double e_redo = E > 0.0 ? E : 1.8 * F;
             const double f_fine = (double)count_fine / (double)rows;
