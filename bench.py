@@ -735,7 +735,7 @@ def main():
         ctx.set_mstep_tiles('always' if args.mstep == 'tiles' else 'auto')
 
     fine_only_region = None
-    if not args.timed_only and default_mode == 'guarded' and regions[kinds[-1]]['estep_passes']['coarse'] > 0:
+    if world == 1 and not args.timed_only and default_mode == 'guarded' and regions[kinds[-1]]['estep_passes']['coarse'] > 0:  # (one rank: the region has barriers)
         phase('default mode without the coarse pass: timed region')
         ctx.set_coarse_pass(False)
         ctx.set_addition(None)

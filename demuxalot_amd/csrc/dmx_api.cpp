@@ -1053,8 +1053,36 @@ int ensure_full_addition(dmx_ctx *c)
     return 0;
 }
 
-int run_pstep(dmx_ctx *c, float lo, float hi, bool with_addition)
+// Whether the E-step behind a P-step with clip `lo` can take the coarse pass (kernels.hip: k_estep_tiled_coarse) - what run_estep asks
+// again, of the table it finds.
+static bool coarse_capable(const dmx_ctx *c, int with_doublets, float lo)
 {
+    return c->coarse_pass && c->estep_mode == DMX_ESTEP_GUARDED && !with_doublets && c->K > 16 && c->K <= 64 && c->tiled_estep && c->n_bins > 0 &&
+           lo >= 6.2e-5f && ((unsigned long long)c->prob_rows + 1ull) * (unsigned long long)c->G * 4ull < (1ull << 32);
+}
+
+// the table as binary16 + the all-zero row the padding calls gather (EstepArgs::prob16)
+static int ensure_prob16(dmx_ctx *c)
+{
+    const size_t need16 = ((size_t)c->prob_rows + 1) * c->G * 2;
+    if (need16 > c->cap_prob16) {
+        dev_free(c, &c->d_prob16, c->cap_prob16);
+        c->cap_prob16 = 0;
+        DMX_TRY(dev_alloc(c, &c->d_prob16, need16));
+        c->cap_prob16 = need16;
+        c->prob16_valid = false;
+        HIP_TRY(hipMemsetAsync(c->d_prob16, 0, need16 * sizeof(unsigned short), c->stream));
+    }
+    return 0;
+}
+
+// with_half: the E-step behind this P-step may take the coarse pass - the kernel writes the table as binary16 too (one rank, whole
+// table; a sliced run converts behind the all-gather of the slices: run_estep)
+int run_pstep(dmx_ctx *c, float lo, float hi, bool with_addition, bool with_half = false)
+{
+    with_half = with_half && !c->sliced;
+    if (with_half) DMX_TRY(ensure_prob16(c));
+    c->prob16_valid = false;
     std::pair<hipEvent_t, hipEvent_t> ev;
     timer_begin(c, DMX_T_PSTEP, &ev);
     const long long v0 = c->sliced ? c->cut[c->rank] : 0, v1 = c->sliced ? c->cut[c->rank + 1] : c->V;
@@ -1069,7 +1097,8 @@ int run_pstep(dmx_ctx *c, float lo, float hi, bool with_addition)
     }
     HIP_TRY(dmx::launch_probs_from_betas(c->stream, c->d_prior, with_addition ? c->d_add : nullptr, c->d_v2snp,
                                          c->d_snp_ptr, c->d_snp_vars, v0, v1 - v0, c->sliced ? -1LL : (long long)c->S, c->G, c->d_prow, lo, hi,
-                                         c->d_prob));
+                                         c->d_prob, with_half ? c->d_prob16 : nullptr));
+    c->prob16_valid = with_half;
     timer_end(c, DMX_T_PSTEP, ev);
     if (c->sliced) {  // everybody gets everybody's slice of genotype_prob
         timer_begin(c, DMX_T_ALLREDUCE, &ev);
@@ -1272,8 +1301,7 @@ int run_estep(dmx_ctx *c, int with_doublets, bool with_prior, int prior_dtype, f
             // table whose clip keeps binary16 normal) is admissible when nobody can read this E-step's logits.  Which of coarse pass,
             // fine pass and the direct form runs is the device's choice (k_guard_begin): both fast launches are issued, the one
             // that is not taken stands back.
-            const bool capable = c->coarse_pass && !with_doublets && c->K > 16 && c->K <= 64 && a.n_bins > 0 && c->p_clip_lo >= 6.2e-5f &&
-                                 (unsigned long long)a.prob_bytes + (unsigned long long)c->G * 4ull < (1ull << 32);
+            const bool capable = coarse_capable(c, with_doublets, c->p_clip_lo) && a.n_bins > 0;
             const bool allow_coarse = capable && (!logits_kept || c->coarse_pass == 2);
             if (allow_coarse && !c->coarse_ready) {
                 // once per problem, ahead of k_guard_begin's time stamp (not part of the pass the device times): the coarse pass's
@@ -1288,14 +1316,7 @@ int run_estep(dmx_ctx *c, int with_doublets, bool with_prior, int prior_dtype, f
                 HIP_TRY(dmx::launch_barcode_log2_keep(c->stream, c->d_call_pairs, c->d_pair_ptr, c->B, c->d_log2_keep));
                 c->coarse_ready = true;
             }
-            const size_t need16 = ((size_t)c->prob_rows + 1) * c->G * 2;  // the table as binary16 + the all-zero row the padding calls gather
-            if (allow_coarse && need16 > c->cap_prob16) {
-                dev_free(c, &c->d_prob16, c->cap_prob16);
-                c->cap_prob16 = 0;
-                DMX_TRY(dev_alloc(c, &c->d_prob16, need16));
-                c->cap_prob16 = need16;
-                HIP_TRY(hipMemsetAsync(c->d_prob16, 0, need16 * sizeof(unsigned short), c->stream));
-            }
+            if (allow_coarse) DMX_TRY(ensure_prob16(c));
             HIP_TRY(dmx::launch_guard_begin(c->stream, c->d_guard_count, c->B, c->K, c->guard_adaptive, capable, allow_coarse));
             a.guard = 1;
             a.order_direct = c->d_bc_order;
@@ -1303,7 +1324,8 @@ int run_estep(dmx_ctx *c, int with_doublets, bool with_prior, int prior_dtype, f
             a.guard_alt_per_call = capable ? dmx::GUARD_PER_CALL_COARSE : 0.0f;
             a.guard_alt_accum = capable ? dmx::GUARD_ACCUM_F32 : 0.0f;
             if (allow_coarse) {
-                HIP_TRY(dmx::launch_prob_to_half(c->stream, c->d_prob, c->prob_rows, c->G, c->d_prob16, c->d_guard_count + dmx::GS_SKIP_COARSE));
+                if (!c->prob16_valid)  // (the P-step of a dmx_em / dmx_run_iterations call has written it already)
+                    HIP_TRY(dmx::launch_prob_to_half(c->stream, c->d_prob, c->prob_rows, c->G, c->d_prob16, c->d_guard_count + dmx::GS_SKIP_COARSE));
                 dmx::EstepArgs coarse = a;
                 coarse.prob16 = c->d_prob16;
                 coarse.coarse_stream = c->d_coarse_stream;
@@ -2120,6 +2142,7 @@ int dmx_set_probs(dmx_ctx *c, const float *prob)
     if (flag) return fail(DMX_ERR_INVALID, "genotype_prob has entries outside [0, 1] (or NaN)");
     c->have_probs = true;
     c->p_clip_lo = 0.0f;  // (a caller's table: entries may lie below binary16's normal range - no coarse pass)
+    c->prob16_valid = false;
     c->dict_candidate = true;
     return 0;
 }
@@ -2144,6 +2167,7 @@ int dmx_probs_from_betas_f64(dmx_ctx *c, const double *betas, float lo, float hi
     if (rc_copy) return rc_copy;
     c->have_probs = true;
     c->p_clip_lo = lo;
+    c->prob16_valid = false;
     c->dict_candidate = true;
     return 0;
 }
@@ -2190,7 +2214,7 @@ int dmx_em(dmx_ctx *c, int n_iterations, float lo, float hi, int with_doublets, 
     c->add_is_zero = true;
     c->add_partial = false;
     for (int it = 0; it < n_iterations; it++) {
-        DMX_TRY(run_pstep(c, lo, hi, true));
+        DMX_TRY(run_pstep(c, lo, hi, true, it + 1 < n_iterations && it > 0 && coarse_capable(c, with_doublets, lo)));  // (iteration 0: the dictionary form)
         DMX_TRY(run_estep(c, with_doublets, it == 0 && prior_logits != nullptr, prior_dtype, power, it + 1 == n_iterations));
         if (it + 1 < n_iterations) {  // the M-step after the last yield is dead
             c->msteps_ahead = n_iterations - 1 - it;
@@ -2216,7 +2240,7 @@ int dmx_run_iterations(dmx_ctx *c, int n_iterations, float lo, float hi, float p
     if (n_iterations < 0) return fail(DMX_ERR_INVALID, "negative n_iterations");
     const int with_doublets = c->K != c->G;
     for (int it = 0; it < n_iterations; it++) {
-        DMX_TRY(run_pstep(c, lo, hi, true));
+        DMX_TRY(run_pstep(c, lo, hi, true, it + 1 < n_iterations && coarse_capable(c, with_doublets, lo)));
         DMX_TRY(run_estep(c, with_doublets, false, DMX_F32, power, it + 1 == n_iterations));
         c->msteps_ahead = n_iterations - it;
         const int rc_m = run_mstep(c, power);

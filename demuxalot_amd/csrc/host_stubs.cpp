@@ -116,7 +116,7 @@ namespace dmx {
 
 hipError_t launch_sum_dense(hipStream_t, unsigned long long *, unsigned *) { return hipSuccess; }
 hipError_t launch_probs_from_betas(hipStream_t, const float *, const float *, const int *, const int *, const int *, long long, long long,
-                                   long long, int, const int *, float, float, float *) { return hipSuccess; }
+                                   long long, int, const int *, float, float, float *, unsigned short *) { return hipSuccess; }
 hipError_t launch_probs_from_betas_f64(hipStream_t, const double *, const int *, const int *, const int *, long long, long long, int,
                                        const int *, float, float, float *) { return hipSuccess; }
 hipError_t launch_check_unit_range(hipStream_t, const float *, long long, int *) { return hipSuccess; }

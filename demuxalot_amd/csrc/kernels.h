@@ -262,7 +262,7 @@ inline int item_calls_for(long long n_calls)
 // (padded multi-GPU layout) or row v when prow is null
 hipError_t launch_probs_from_betas(hipStream_t st, const float *prior, const float *addition, const int *v2snp,
                                    const int *snp_ptr, const int *snp_vars, long long v_begin, long long n_rows, long long n_snps,
-                                   int G, const int *prow, float lo, float hi, float *prob);
+                                   int G, const int *prow, float lo, float hi, float *prob, unsigned short *prob16 = nullptr);
 // the same from caller-supplied float64 betas (no addition): numpy divides float64 / float64 and rounds once
 hipError_t launch_probs_from_betas_f64(hipStream_t st, const double *betas, const int *v2snp, const int *snp_ptr,
                                        const int *snp_vars, long long V, long long n_snps, int G, const int *prow, float lo,

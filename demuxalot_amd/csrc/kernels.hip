@@ -45,8 +45,10 @@ __global__ __launch_bounds__(256) void k_probs_from_betas(const T *__restrict__ 
                                                           const int *__restrict__ snp_vars, long long v_begin,
                                                           long long n_rows, long long n_snps, int G,
                                                           const int *__restrict__ prow, float clip_lo, float clip_hi,
-                                                          float *__restrict__ prob)
+                                                          float *__restrict__ prob, unsigned short *__restrict__ prob16)
 {
+    // prob16 (nullable): the table once more, rounded to binary16 at the float32 table's row offsets (EstepArgs::prob16: the coarse
+    // pass of the E-step that follows; as k_prob_to_half writes it).
     // n_snps >= 0: the whole table, one lane group per SNP 0 .. n_snps - 1.  Otherwise variants [v_begin, v_begin +
     // n_rows) (whole SNP groups: a rank's slice), one lane group per variant, the SNP's first variant working.
     // prob row of variant v = prow[v] (padded multi-GPU layout) or v.
@@ -84,7 +86,9 @@ __global__ __launch_bounds__(256) void k_probs_from_betas(const T *__restrict__ 
             if (w[q] < 0) continue;
             float p = (float)((double)held[q] / den);
             p = fminf(fmaxf(p, clip_lo), clip_hi);  // ndarray.clip(lo, hi) = minimum(maximum(x, lo), hi)
-            prob[(prow ? (long long)prow[w[q]] : w[q]) * G + g] = p;
+            const long long row = prow ? (long long)prow[w[q]] : w[q];
+            prob[row * G + g] = p;
+            if (prob16) prob16[row * (2 * G) + g] = __builtin_bit_cast(unsigned short, (_Float16)p);
         }
         for (int j = j0 + HELD; j < j1; j++) {
             const long long v_j = snp_vars[j];
@@ -92,7 +96,9 @@ __global__ __launch_bounds__(256) void k_probs_from_betas(const T *__restrict__ 
             const T beta = addition ? prior[o] + addition[o] : prior[o];
             float p = (float)((double)beta / den);
             p = fminf(fmaxf(p, clip_lo), clip_hi);
-            prob[(prow ? (long long)prow[v_j] : v_j) * G + g] = p;
+            const long long row = prow ? (long long)prow[v_j] : v_j;
+            prob[row * G + g] = p;
+            if (prob16) prob16[row * (2 * G) + g] = __builtin_bit_cast(unsigned short, (_Float16)p);
         }
     }
 }
@@ -2715,13 +2721,13 @@ static inline unsigned blocks_for(long long n, int per_block) { return (unsigned
 template <typename T>
 static hipError_t launch_pstep(hipStream_t st, const T *prior, const T *addition, const int *v2snp, const int *snp_ptr,
                                const int *snp_vars, long long v_begin, long long n_rows, long long n_snps, int G, const int *prow,
-                               float lo, float hi, float *prob)
+                               float lo, float hi, float *prob, unsigned short *prob16 = nullptr)
 {
     if (n_rows * G == 0) return hipSuccess;
     const long long groups = n_snps >= 0 ? n_snps : n_rows;
 #define PSTEP(L)                                                                                                          \
     hipLaunchKernelGGL((k_probs_from_betas<T, L>), dim3(blocks_for(groups, 4 * (64 / L))), dim3(256), 0, st, prior, addition, \
-                       v2snp, snp_ptr, snp_vars, v_begin, n_rows, n_snps, G, prow, lo, hi, prob)
+                       v2snp, snp_ptr, snp_vars, v_begin, n_rows, n_snps, G, prow, lo, hi, prob, prob16)
     if (G <= 4) PSTEP(4);
     else if (G <= 8) PSTEP(8);
     else if (G <= 16) PSTEP(16);
@@ -2734,9 +2740,9 @@ static hipError_t launch_pstep(hipStream_t st, const T *prior, const T *addition
 // n_snps >= 0: [v_begin, v_begin + n_rows) is the whole table and the SNPs are numbered 0 .. n_snps - 1
 hipError_t launch_probs_from_betas(hipStream_t st, const float *prior, const float *addition, const int *v2snp,
                                    const int *snp_ptr, const int *snp_vars, long long v_begin, long long n_rows, long long n_snps,
-                                   int G, const int *prow, float lo, float hi, float *prob)
+                                   int G, const int *prow, float lo, float hi, float *prob, unsigned short *prob16)
 {
-    return launch_pstep<float>(st, prior, addition, v2snp, snp_ptr, snp_vars, v_begin, n_rows, n_snps, G, prow, lo, hi, prob);
+    return launch_pstep<float>(st, prior, addition, v2snp, snp_ptr, snp_vars, v_begin, n_rows, n_snps, G, prow, lo, hi, prob, prob16);
 }
 
 hipError_t launch_probs_from_betas_f64(hipStream_t st, const double *betas, const int *v2snp, const int *snp_ptr,
