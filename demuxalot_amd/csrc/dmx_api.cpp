@@ -1057,7 +1057,7 @@ int ensure_full_addition(dmx_ctx *c)
 // again, of the table it finds.
 static bool coarse_capable(const dmx_ctx *c, int with_doublets, float lo)
 {
-    return c->coarse_pass && c->estep_mode == DMX_ESTEP_GUARDED && !with_doublets && c->K > 16 && c->K <= 64 && c->tiled_estep && c->n_bins > 0 &&
+    return c->coarse_pass && c->estep_mode == DMX_ESTEP_GUARDED && !with_doublets && c->K > 16 && c->K <= 128 && c->tiled_estep && c->n_bins > 0 &&
            lo >= 6.2e-5f && ((unsigned long long)c->prob_rows + 1ull) * (unsigned long long)c->G * 4ull < (1ull << 32);
 }
 
@@ -1295,9 +1295,9 @@ int run_estep(dmx_ctx *c, int with_doublets, bool with_prior, int prior_dtype, f
             // fast kernels with the guard evaluated per barcode, then the exact kernel over the barcodes they queued (their
             // number is only known on the device: a launch sized for all of them, the wavefronts past the queue's end
             // return at once); the redo rewrites logits, posteriors, bitmaps and codes of those barcodes.  Adaptive
-            // (kernels.h: EstepArgs::direct): after an E-step that queued more than 40 % of the barcodes the fast kernels
-            // stand back and the exact launch walks every barcode - decided on the device by k_guard_begin.
-            // The coarse pass (kernels.hip: k_estep_tiled_coarse; singlets, 33 .. 64 genotypes, the tile-major schedule, a P-step's
+            // (kernels.hip: k_guard_begin): the passes are timed on the device, and an E-step for which pass + redo would cost
+            // more than the exact kernel over every barcode runs that kernel directly - the fast kernels stand back.
+            // The coarse pass (kernels.hip: k_estep_tiled_coarse; singlets, 17 .. 128 genotypes, the tile-major schedule, a P-step's
             // table whose clip keeps binary16 normal) is admissible when nobody can read this E-step's logits.  Which of coarse pass,
             // fine pass and the direct form runs is the device's choice (k_guard_begin): both fast launches are issued, the one
             // that is not taken stands back.

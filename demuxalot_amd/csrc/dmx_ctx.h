@@ -108,7 +108,7 @@ struct dmx_ctx {
     int estep_mode = DMX_ESTEP_EXACT;  // dmx_set_estep_mode
     // guarded mode: barcodes queued by the epilogues of the fast kernels for the exact redo (kernels.h: EstepArgs::guard)
     unsigned *d_guard_count = nullptr;  // [GUARD_STATE_WORDS] device state of the guarded mode (kernels.h: GS_*)
-    int guard_adaptive = 1;             // dmx_set_guard_adaptive: E-steps after one that queued > 40 % of the barcodes run the exact kernel directly
+    int guard_adaptive = 1;             // dmx_set_guard_adaptive: the device picks coarse pass / fine pass / the exact kernel on every barcode per E-step from its own timings
     int *d_guard_list = nullptr;        // [B] EstepArgs::guard_list
     int *d_guard_sub = nullptr;         // [GUARD_QUEUES x guard_sub_cap] EstepArgs::guard_sub
     unsigned guard_sub_cap = 0;

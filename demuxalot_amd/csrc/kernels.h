@@ -270,9 +270,9 @@ hipError_t launch_probs_from_betas_f64(hipStream_t st, const double *betas, cons
 // sets flags[0] bit 0 when a value lies outside [0, 1] or is not finite
 hipError_t launch_check_unit_range(hipStream_t st, const float *x, long long n, int *flags);
 hipError_t launch_estep(hipStream_t st, const EstepArgs &a, bool pairs);
-// the coarse pass's records from the tile-major stream (coarse_bin_ptr first, one block; then the stream); cpg = calls per gather: 2 for
-// 33 .. 64 genotypes, 4 for 17 .. 32; zero_off = byte offset of the all-zero row behind the table
-constexpr int coarse_calls_per_gather(int K) { return K > 32 ? 2 : 4; }
+// the coarse pass's records from the tile-major stream (coarse_bin_ptr first, one block; then the stream); cpg = calls per gather: 1 for
+// 65 .. 128 genotypes, 2 for 33 .. 64, 4 for 17 .. 32; zero_off = byte offset of the all-zero row behind the table
+constexpr int coarse_calls_per_gather(int K) { return K > 64 ? 1 : K > 32 ? 2 : 4; }
 constexpr int coarse_batches_per_record(int cpg) { return cpg; }  // (kernels.hip: CoarseShape<CPG>::BPR)
 hipError_t launch_build_coarse_stream(hipStream_t st, const CallPair *stream, const long long *bin_ptr, long long n_bins, unsigned zero_off,
                                       int cpg, long long *coarse_bin_ptr, unsigned *out);

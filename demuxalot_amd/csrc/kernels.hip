@@ -927,8 +927,9 @@ static __device__ __forceinline__ void for_each_int(std::integer_sequence<int, I
     (f(std::integral_constant<int, I>{}), ...);
 }
 
-// Shape of the coarse pass for CPG calls per 256-byte gather: 2 (33 .. 64 genotypes: a call's binary16 row is 128 bytes, 32 lanes) or
-// 4 (17 .. 32 genotypes: 64 bytes, 16 lanes).  Lanes of BLOCK j = lane / (64 / CPG) take call q CPG + j of a group's gather q.
+// Shape of the coarse pass for CPG calls per 256-byte gather: 1 (65 .. 128 genotypes: a call's binary16 row is the whole gather), 2 (33 ..
+// 64 genotypes: 128 bytes, 32 lanes) or 4 (17 .. 32 genotypes: 64 bytes, 16 lanes).  Lanes of BLOCK j = lane / (64 / CPG) take call
+// q CPG + j of a group's gather q.
 template <int CPG>
 struct CoarseShape {
     static constexpr int LPC = 64 / CPG;  // lanes per call
@@ -936,7 +937,7 @@ struct CoarseShape {
     static constexpr int BPR = 8 / GPB;   // batches per record: a block's record is 16 dwords = BPR x (GPB offsets, GPB r)
     static constexpr int DD = 4;          // records in registers
     static constexpr int T = DD * BPR;    // batches per trip of the unrolled loop
-    static constexpr int GA = CPG == 2 ? 3 : 7;  // batches whose gathers are in flight while one is consumed (12 / 14 gathers)
+    static constexpr int GA = CPG == 4 ? 7 : 3;  // batches whose gathers are in flight while one is consumed (24 / 12 / 14 gathers)
     static constexpr int DG = GA + 1;
     static_assert(T % DG == 0, "ring slots must be fixed registers");
 };
@@ -979,11 +980,21 @@ static __device__ __forceinline__ void coarse_walk(const unsigned *__restrict__ 
         float prod_lo = add_row_bcast<R0>(w, lo(g.h[0])), prod_hi = add_row_bcast<R0>(w, hi(g.h[0]));
         prod_lo = prod_lo * add_row_bcast<R0 + 1>(w, lo(g.h[1]));
         prod_hi = prod_hi * add_row_bcast<R0 + 1>(w, hi(g.h[1]));
-        if constexpr (GPB == 4) {
+        if constexpr (GPB >= 4) {
             prod_lo = prod_lo * add_row_bcast<R0 + 2>(w, lo(g.h[2]));
             prod_hi = prod_hi * add_row_bcast<R0 + 2>(w, hi(g.h[2]));
             prod_lo = prod_lo * add_row_bcast<R0 + 3>(w, lo(g.h[3]));
             prod_hi = prod_hi * add_row_bcast<R0 + 3>(w, hi(g.h[3]));
+        }
+        if constexpr (GPB == 8) {  // (a product of 8 sums: at least 1e-32; beyond float32 only with several keep factors near 2^-24 - NaN, queued)
+            prod_lo = prod_lo * add_row_bcast<R0 + 4>(w, lo(g.h[4]));
+            prod_hi = prod_hi * add_row_bcast<R0 + 4>(w, hi(g.h[4]));
+            prod_lo = prod_lo * add_row_bcast<R0 + 5>(w, lo(g.h[5]));
+            prod_hi = prod_hi * add_row_bcast<R0 + 5>(w, hi(g.h[5]));
+            prod_lo = prod_lo * add_row_bcast<R0 + 6>(w, lo(g.h[6]));
+            prod_hi = prod_hi * add_row_bcast<R0 + 6>(w, hi(g.h[6]));
+            prod_lo = prod_lo * add_row_bcast<R0 + 7>(w, lo(g.h[7]));
+            prod_hi = prod_hi * add_row_bcast<R0 + 7>(w, hi(g.h[7]));
         }
         lacc.lo += __builtin_amdgcn_logf(prod_lo);  // v_log_f32 = log2 of a product of GPB sums p + r
         lacc.hi += __builtin_amdgcn_logf(prod_hi);
@@ -1033,10 +1044,14 @@ __global__ __launch_bounds__(256) void k_estep_tiled_coarse(EstepArgs a)
     if (guard_stand_back(a)) return;  // another level runs (EstepArgs::direct)
     if (slot_id >= a.n_bins) return;
     const long long bin = a.bin_order[slot_id];
-    int kk[1];
-    bool valid[1];
-    valid[0] = lane < K;
-    kk[0] = valid[0] ? lane : K - 1;
+    constexpr int A = CPG == 1 ? 2 : 1;  // option slots per lane of the epilogue: option k = lane + 64 s
+    int kk[A];
+    bool valid[A];
+#pragma unroll
+    for (int s = 0; s < A; s++) {
+        valid[s] = lane + 64 * s < K;
+        kk[s] = valid[s] ? lane + 64 * s : K - 1;
+    }
     for (int r = 0; r < R; r++) sh_acc[wave][r][lane] = CoarseSum{0.0f, 0.0f};
     // (the table's extent + the all-zero row behind it)
     const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void *)a.prob16, 0, (int)(a.prob_bytes + (unsigned)a.G * 4u), 0x00020000);
@@ -1063,12 +1078,15 @@ __global__ __launch_bounds__(256) void k_estep_tiled_coarse(EstepArgs a)
             v.lo += __shfl_xor(v.lo, off);
             v.hi += __shfl_xor(v.hi, off);
         }
-        const float lo = __shfl(v.lo, lane >> 1), hi = __shfl(v.hi, lane >> 1);  // option k = lane: genotype k of lane k / 2
-        double out[1];
+        double out[A];
         const double lk = a.log2_keep[row];
-        out[0] = ((double)((lane & 1) ? hi : lo) + lk) * 0.693147180559945309417232121458176568;
+#pragma unroll
+        for (int s = 0; s < A; s++) {  // option k = lane + 64 s: genotype k of lane k / 2
+            const float lo = __shfl(v.lo, (lane >> 1) + 32 * s), hi = __shfl(v.hi, (lane >> 1) + 32 * s);
+            out[s] = ((double)((lane & 1) ? hi : lo) + lk) * 0.693147180559945309417232121458176568;
+        }
         // (the float32 partial sums are those of log2(p + r) <= -log2 keep + 1.5e-4: up to 3 |log2_keep| beyond the total's magnitude)
-        estep_epilogue<64, 1, true>(a, (long long)row, true, out, kk, valid, lane, lane, 0, 2 * (int)(a.pair_ptr[row + 1] - a.pair_ptr[row]),
+        estep_epilogue<64, A, true>(a, (long long)row, true, out, kk, valid, lane, lane, 0, 2 * (int)(a.pair_ptr[row + 1] - a.pair_ptr[row]),
                                     3.0f * 0.6931472f * fabsf((float)lk) * 1.000001f);
     }
 }
@@ -2764,8 +2782,11 @@ hipError_t launch_build_coarse_stream(hipStream_t st, const CallPair *stream, co
                                       int cpg, long long *coarse_bin_ptr, unsigned *out)
 {
     if (n_bins == 0) return hipSuccess;
-    hipLaunchKernelGGL(k_coarse_bin_ptr, dim3(1), dim3(1024), 0, st, bin_ptr, n_bins, cpg == 2 ? CoarseShape<2>::BPR : CoarseShape<4>::BPR, coarse_bin_ptr);
-    if (cpg == 2)
+    hipLaunchKernelGGL(k_coarse_bin_ptr, dim3(1), dim3(1024), 0, st, bin_ptr, n_bins, cpg, coarse_bin_ptr);  // (CoarseShape<CPG>::BPR == CPG)
+    static_assert(CoarseShape<1>::BPR == 1 && CoarseShape<2>::BPR == 2 && CoarseShape<4>::BPR == 4, "coarse_batches_per_record");
+    if (cpg == 1)
+        hipLaunchKernelGGL(k_build_coarse_stream<1>, dim3(blocks_for(n_bins, 4)), dim3(256), 0, st, stream, bin_ptr, coarse_bin_ptr, n_bins, zero_off, out);
+    else if (cpg == 2)
         hipLaunchKernelGGL(k_build_coarse_stream<2>, dim3(blocks_for(n_bins, 4)), dim3(256), 0, st, stream, bin_ptr, coarse_bin_ptr, n_bins, zero_off, out);
     else
         hipLaunchKernelGGL(k_build_coarse_stream<4>, dim3(blocks_for(n_bins, 4)), dim3(256), 0, st, stream, bin_ptr, coarse_bin_ptr, n_bins, zero_off, out);
@@ -2854,6 +2875,12 @@ static void launch_tiled(hipStream_t st, const EstepArgs &a)
         }
         if (a.fast && a.K <= 32) {  // two calls per gather
             hipLaunchKernelGGL((k_estep_tiled<1, true, true>), grid, block, 0, st, a);
+            return;
+        }
+    }
+    if constexpr (A == 2) {
+        if (a.fast && a.prob16 != nullptr) {  // the coarse pass for 65 .. 128 genotypes: one call per gather
+            hipLaunchKernelGGL(k_estep_tiled_coarse<1>, grid, block, 0, st, a);
             return;
         }
     }

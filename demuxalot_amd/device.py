@@ -431,8 +431,8 @@ class DeviceContext:
         return last.value, total.value, rows.value
 
     def set_guard_adaptive(self, adaptive):
-        """Guarded mode: E-steps that follow one which queued more than 40 % of the barcodes run the exact kernel on every
-        barcode (default on; include/demux_hip.h: dmx_set_guard_adaptive)."""
+        """Guarded mode: the passes are timed on the device and every E-step takes the cheapest of coarse pass + redo, fine pass + redo
+        and the exact kernel on every barcode (default on; off: never the last one; include/demux_hip.h: dmx_set_guard_adaptive)."""
         check(self._lib.dmx_set_guard_adaptive(self._h, int(bool(adaptive))))
 
     def set_coarse_pass(self, coarse):

@@ -1,5 +1,5 @@
-"""Randomised check of the coarse pass (k_estep_tiled_coarse<2|4>) on problems large enough for the tile-major
-schedule: random genotype counts 17 .. 64 (odd ones included), calls per barcode, P-step clips down to binary16's normal range,
+"""Randomised check of the coarse pass (k_estep_tiled_coarse<1|2|4>) on problems large enough for the tile-major
+schedule: random genotype counts 17 .. 128 (odd ones included: one, two or four calls per gather), calls per barcode, P-step clips down to binary16's normal range,
 sibling donors, degenerate error probabilities.  Per problem: one EM iteration in the exact mode, then on the same table the exact
 E-step and the coarse pass forced for a single E-step (dmx_set_coarse_pass 2): every posterior within 1e-5, every arg-max identical,
 every logit within the bound the guard priced it with.  GPU box: python3 scripts/coarse_sweep.py [n_problems] [seed]"""
@@ -17,7 +17,7 @@ n_problems = int(sys.argv[1]) if len(sys.argv) > 1 else 24
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 2026)
 worst_ratio, worst_dev, t0 = 0.0, 0.0, time.time()
 for trial in range(n_problems):
-    G = int(rng.integers(17, 65))
+    G = int(rng.integers(17, 129))
     cpb = int(rng.choice([24, 60, 150, 400]))
     clip = float(rng.choice([0.01, 0.01, 0.002, 1e-4]))
     siblings = bool(rng.random() < 0.3)

@@ -149,3 +149,39 @@ def test_coarse_pass_on_the_padded_multi_rank_table(monkeypatch):
         check_contract(probs, want_probs[lo:hi], f'posterior rows [{lo}, {hi}) of the sharded run')
         assert (np.abs(addition.astype(np.float64) - want_add) <= n_calls_v * 2.00001e-5 + 2.0 ** -22 * want_add).all()
     print('levels per rank', [r[4] for r in results])
+
+
+@pytest.mark.parametrize('G', [17, 32, 33, 64, 65, 100, 128])
+def test_coarse_pass_shapes_on_one_table(G):
+    """Every shape of the coarse pass - four calls per gather (17 .. 32 genotypes), two (33 .. 64), one (65 .. 128), at both ends of
+    each range - forced for a single E-step on the table of EM iteration 1: against the exact mode every posterior within 1e-5, every
+    arg-max identical, every logit within the bound the guard priced it with (kernels.h: GUARD_PER_CALL_COARSE, GUARD_ACCUM_F32)."""
+    from demuxalot_amd import synth
+    from demuxalot_amd.device import DeviceContext
+    S = max(30_000, (9 << 20) // (8 * G) + 1000)   # a genotype table of at least 8 MB: the tile-major schedule
+    p = synth.generate(66_000, S, G, calls_per_barcode=240, seed=4200 + G)
+    pen = np.zeros(G, dtype=np.float32)
+    ctx = DeviceContext(0)
+    try:
+        ctx.set_estep_mode('exact')
+        ctx.set_problem(p.n_barcodes, p.n_variants, G, p.variant_id, p.compressed_cb, p.p_base_wrong, p.v2snp)
+        ctx.set_betas(p.prior_betas())
+        ctx.em(2, 0.01, pen, with_doublets=False, fetch_logits=False, fetch_probs=False, fetch_addition=False)
+        ctx.mstep(2., fetch=False)
+        ctx.probs_from_betas(0.01, fetch=False)
+        logits_e, probs_e = ctx.estep(pen, with_doublets=False)
+        ctx.set_estep_mode('guarded')
+        ctx.set_coarse_pass('always')
+        logits_c, probs_c = ctx.estep(pen, with_doublets=False)
+        levels, redone = ctx.guard_levels(), ctx.guard_stats()[0]
+    finally:
+        ctx.close()
+    assert levels['level'] == 0 and levels['flagged_coarse'] == redone, levels
+    dev = check_contract(probs_c, probs_e, f'coarse pass, {G} genotypes')
+    n = 8 * ((np.bincount(p.compressed_cb, minlength=p.n_barcodes) + 7) // 8).astype(np.float64)[:, None]
+    mag = np.abs(logits_e.astype(np.float64))
+    lk = np.bincount(p.compressed_cb, weights=-np.log(1.0 - p.p_base_wrong.astype(np.float64)), minlength=p.n_barcodes)[:, None]
+    bound = 4.94e-4 * (n + 8) + 6.0e-8 * (0.125 * n + 2) * (mag + 3e-4 * n + 3 * lk) + 3.0e-7 * (mag + 2.1e-4 * n) + 2.4e-7 * mag
+    worst = float((np.abs(logits_c.astype(np.float64) - logits_e) / bound).max())
+    assert worst <= 1.0, worst
+    print(f'G={G}: {redone} of {p.n_barcodes} barcodes redone, posteriors within {dev:.3g}, logits at most {worst:.3f} of their bound')
