@@ -36,6 +36,7 @@ for trial in range(first, first + n_trials):
     ctx = DeviceContext(0)
     try:
         ctx.set_estep_dictionary('never')
+        ctx.set_guard_adaptive(False)  # (two E-steps of one table must run the same form for the bit comparison below: fast pass + redo both times)
         ctx.set_problem(B, p.n_variants, G, variant, cb, e, p.v2snp)
         ctx.set_betas(p.prior_betas(add_data_prior=False))
         ctx.set_addition(None)
