@@ -515,7 +515,9 @@ def timed_region(ctx, plane, steps, warmup):
     timers = ctx.timings()
     _redone, redone_total, rows = ctx.guard_stats()
     levels = ctx.guard_levels()
-    return {'elapsed': elapsed, 'ms_per_step': 1e3 * elapsed / steps, 'em_iterations_per_s': steps / elapsed,
+    m_full, m_delta, m_changed = ctx.mstep_incremental()
+    return {'elapsed': elapsed,
+            'mstep_passes': {'full': m_full, 'delta': m_delta, 'of': steps, 'barcodes_changed_in_the_last_mstep': m_changed}, 'ms_per_step': 1e3 * elapsed / steps, 'em_iterations_per_s': steps / elapsed,
             'estep_passes': {'coarse': levels['coarse_steps'], 'of': steps, 'last': {0: 'coarse', 1: 'fine', 2: 'direct'}.get(levels['level'], 'not guarded'),
                              'device_timed_ms': {'coarse_pass': levels['coarse_pass_ms'], 'fine_pass': levels['fine_pass_ms'], 'exact_kernel': abs(levels['exact_pass_ms'])},
                              'last_estep_flagged': {'fine_guard': levels['flagged_fine'], 'coarse_guard': levels['flagged_coarse']}},
@@ -734,6 +736,18 @@ def main():
         work_item_region['scaling'] = kinds[-1]
         ctx.set_mstep_tiles('always' if args.mstep == 'tiles' else 'auto')
 
+    full_mstep_region = None
+    if world == 1 and not args.timed_only and regions[kinds[-1]]['mstep_passes']['delta'] > 0:  # (one rank: the region has barriers)
+        phase('default mode with every M-step the full pass: timed region')
+        ctx.set_mstep_incremental(False)
+        ctx.set_addition(None)
+        ctx.probs_from_betas(0.01, fetch=False)
+        ctx.estep(pen, with_doublets=dp > 0, fetch_logits=False, fetch_probs=False)
+        full_mstep_region = timed_region(ctx, plane, args.steps, args.warmup)
+        full_mstep_region['value'] = regions[kinds[-1]]['barcodes_total'] * args.steps / full_mstep_region['elapsed']
+        full_mstep_region['scaling'] = kinds[-1]
+        ctx.set_mstep_incremental(True)
+
     fine_only_region = None
     if world == 1 and not args.timed_only and default_mode == 'guarded' and regions[kinds[-1]]['estep_passes']['coarse'] > 0:  # (one rank: the region has barriers)
         phase('default mode without the coarse pass: timed region')
@@ -822,6 +836,7 @@ def main():
             'exchange_ms_per_step': head['exchange_ms_per_step'],
             'guard': head['guard'],
             'estep_passes': head['estep_passes'],
+            'mstep_passes': head['mstep_passes'],
             'setup_s': {'problem': t_gen, 'problem_source': problem_source, 'upload': t_up},
         }
         if 'weak' in regions and head_kind != 'weak':
@@ -835,6 +850,11 @@ def main():
             out['work_item_mstep'] = {k: v for k, v in work_item_region.items() if k != 'elapsed'}
             out['work_item_mstep']['note'] = ('the same timed region with the work-item M-step, the form of runs with fewer than 8 M-steps '
                                               'ahead (the tile-major records cost a 2.6 ms sort of the calls to build)')
+        if full_mstep_region:
+            out['without_incremental_mstep'] = {k: v for k, v in full_mstep_region.items() if k != 'elapsed'}
+            out['without_incremental_mstep']['note'] = ('the same timed region with dmx_set_mstep_incremental(0): every M-step sums every call again (the tile-major full pass; same bits). '
+                                                        'Default: after one full pass the integer sums stay on the device and an M-step only visits the barcodes whose posteriors changed '
+                                                        'where it matters - mstep_passes says how many did what in the timed call')
         if fine_only_region:
             out['without_coarse_pass'] = {k: v for k, v in fine_only_region.items() if k != 'elapsed'}
             out['without_coarse_pass']['note'] = ('the same timed region with dmx_set_coarse_pass(0): every E-step the fine pass on the float32 table (the default mode of round 4; '

@@ -85,6 +85,8 @@ SIGNATURES = {
     'dmx_get_guard_stats': (c_int, [_P, POINTER(c_int64), POINTER(c_int64), POINTER(c_int64)]),
     'dmx_set_guard_adaptive': (c_int, [_P, c_int]),
     'dmx_set_coarse_pass': (c_int, [_P, c_int]),
+    'dmx_set_mstep_incremental': (c_int, [_P, c_int]),
+    'dmx_get_mstep_incremental': (c_int, [_P, POINTER(c_int64), POINTER(c_int64), POINTER(c_int64)]),
     'dmx_get_guard_levels': (c_int, [_P, POINTER(c_int32), POINTER(c_int64), POINTER(c_int64), POINTER(c_int64), POINTER(c_double), POINTER(c_double), POINTER(c_double)]),
     'dmx_get_guard_direct': (c_int, [_P, POINTER(c_int32), POINTER(c_int64), POINTER(c_int64), POINTER(c_double), POINTER(c_double)]),
     'dmx_set_estep_schedule': (c_int, [_P, c_int]),

@@ -425,6 +425,19 @@ void timer_end(dmx_ctx *c, int slot, const std::pair<hipEvent_t, hipEvent_t> &ev
     if (t.pending.size() >= 4096) timer_flush(c, slot);
 }
 
+// incremental M-step: the sums, the posteriors they were formed from, the work lists (run_mstep allocates them at first use)
+static void release_incremental(dmx_ctx *c)
+{
+    const size_t vg = (size_t)c->V * c->G;
+    dev_free(c, &c->d_acc64, vg);
+    dev_free(c, &c->d_prev_post, (size_t)c->B * c->G);
+    dev_free(c, &c->d_prev_first, (size_t)c->B);
+    dev_free(c, &c->d_incr_list, (size_t)c->B);
+    dev_free(c, &c->d_incr_touched, (size_t)c->V);
+    dev_free(c, &c->d_incr_state, (size_t)(3 * dmx::IS_WORDS));
+    c->incr_valid = false;
+}
+
 // the coarse pass's records and constants (run_estep builds them at the problem's first admissible E-step)
 static void release_coarse_stream(dmx_ctx *c)
 {
@@ -444,6 +457,7 @@ void release_problem(dmx_ctx *c)
     dev_free(c, &c->d_call_rows, ((size_t)c->n_pairs + dmx::CALL_PAD_PAIRS) * 2);
     dev_free(c, &c->d_tile_stream, (size_t)c->n_pairs);
     release_coarse_stream(c);
+    release_incremental(c);
     c->n_pairs = 0;
     dmx::release_mstep_tiles(c);  // (its record stream is sized by n_csc)
     dev_free(c, &c->d_csc, (size_t)c->n_csc);
@@ -1484,8 +1498,53 @@ int run_mstep(dmx_ctx *c, float power)
         if (f64) a.out64 = c->d_add64;
         else a.out32 = c->d_add;
     }
+    // Incremental form (kernels.h: MIncrArgs): one context with all calls of its barcodes, the tiles' per-variant exponents at hand.
+    const bool incremental = a.tiles_done && c->mstep_incremental && !dist && !c->sliced && c->d_mt_shift_v != nullptr && a.out32 == c->d_add &&
+                             c->d_call_rows != nullptr;
+    dmx::MIncrArgs incr{};
+    if (incremental) {
+        if (!c->d_acc64) {
+            DMX_TRY(dev_alloc(c, &c->d_acc64, (size_t)c->V * c->G));
+            DMX_TRY(dev_alloc(c, &c->d_prev_post, (size_t)c->B * c->G));
+            DMX_TRY(dev_alloc(c, &c->d_prev_first, (size_t)c->B));
+            DMX_TRY(dev_alloc(c, &c->d_incr_list, (size_t)c->B));
+            DMX_TRY(dev_alloc(c, &c->d_incr_touched, (size_t)c->V));
+            DMX_TRY(dev_alloc(c, &c->d_incr_state, (size_t)(3 * dmx::IS_WORDS)));  // two alternating sets + the counters
+            HIP_TRY(hipMemsetAsync(c->d_incr_state, 0, sizeof(unsigned) * 3 * dmx::IS_WORDS, c->stream));
+            HIP_TRY(hipMemsetAsync(c->d_incr_touched, 0, (size_t)c->V, c->stream));
+            c->incr_valid = false;
+        }
+        if (!c->incr_valid || c->incr_power != power) {  // (nothing to build on: zeroed state words ask for the full pass)
+            HIP_TRY(hipMemsetAsync(c->d_incr_state, 0, sizeof(unsigned) * 2 * dmx::IS_WORDS, c->stream));
+            c->incr_parity = 0;
+            c->incr_valid = true;
+            c->incr_power = power;
+        }
+        incr.state = c->d_incr_state + c->incr_parity * dmx::IS_WORDS;
+        incr.next = c->d_incr_state + (c->incr_parity ^ 1) * dmx::IS_WORDS;
+        c->incr_parity ^= 1;
+        incr.counters = c->d_incr_state + 2 * dmx::IS_WORDS;
+        incr.acc64 = c->d_acc64;
+        incr.prev = c->d_prev_post;
+        incr.prev_first = c->d_prev_first;
+        incr.list = c->d_incr_list;
+        incr.touched = c->d_incr_touched;
+        incr.shift_v = c->d_mt_shift_v;
+        incr.pairs = c->d_call_pairs;
+        incr.call_rows = c->d_call_rows;
+        incr.pair_ptr = c->d_pair_ptr;
+        incr.B = c->B;
+        incr.V = c->V;
+        incr.floor = dmx::mincr_floor(power);
+        tiles.acc64 = c->d_acc64;
+        tiles.incr_state = incr.state;
+        c->mstep_incr_launches++;
+    } else {
+        c->incr_valid = false;  // (another form writes the addition: the kept sums no longer describe it)
+    }
     timer_begin(c, DMX_T_MSTEP, &ev);
-    if (a.tiles_done) HIP_TRY(dmx::launch_mstep_tiles(c->stream, a, tiles));
+    if (incremental) HIP_TRY(dmx::launch_mstep_incremental(c->stream, a, tiles, incr));
+    else if (a.tiles_done) HIP_TRY(dmx::launch_mstep_tiles(c->stream, a, tiles));
     else HIP_TRY(dmx::launch_mstep(c->stream, a));
     c->mstep_form = a.tiles_done ? 2 : 1;
     timer_end(c, DMX_T_MSTEP, ev);
@@ -1856,6 +1915,27 @@ int dmx_get_guard_stats(dmx_ctx *c, int64_t *redone_last, int64_t *redone_total,
     return 0;
 }
 
+int dmx_set_mstep_incremental(dmx_ctx *c, int incremental)
+{
+    if (!c) return fail(DMX_ERR_INVALID, "null context");
+    c->mstep_incremental = incremental != 0;
+    return 0;
+}
+
+int dmx_get_mstep_incremental(dmx_ctx *c, int64_t *full_passes, int64_t *delta_passes, int64_t *barcodes_last_delta)
+{
+    DMX_TRY(bind(c));
+    unsigned st[3 * dmx::IS_WORDS] = {};
+    if (c->d_incr_state) {
+        HIP_TRY(hipMemcpyAsync(st, c->d_incr_state, sizeof(st), hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(hipStreamSynchronize(c->stream));
+    }
+    if (full_passes) *full_passes = (int64_t)st[2 * dmx::IS_WORDS];
+    if (delta_passes) *delta_passes = (int64_t)st[2 * dmx::IS_WORDS + 1];
+    if (barcodes_last_delta) *barcodes_last_delta = st[2 * dmx::IS_WORDS + 2] == 0xFFFFFFFFu ? -1 : (int64_t)st[2 * dmx::IS_WORDS + 2];
+    return 0;
+}
+
 int dmx_set_coarse_pass(dmx_ctx *c, int coarse)
 {
     if (!c) return fail(DMX_ERR_INVALID, "null context");
@@ -2105,6 +2185,7 @@ int dmx_set_addition(dmx_ctx *c, const float *addition)
     DMX_TRY(bind(c));
     DMX_TRY(need(c, c->have_problem, "dmx_set_problem before dmx_set_addition"));
     const size_t vg = (size_t)c->V * c->G;
+    c->incr_valid = false;  // (the addition is no longer the last M-step's: the incremental M-step starts over)
     if (addition) {
         HIP_TRY(hipMemcpyAsync(c->d_add, addition, sizeof(float) * vg, hipMemcpyHostToDevice, c->stream));
         HIP_TRY(hipStreamSynchronize(c->stream));
@@ -2211,6 +2292,7 @@ int dmx_em(dmx_ctx *c, int n_iterations, float lo, float hi, int with_doublets, 
     DMX_TRY(upload_prior_logits(c, prior_logits, prior_dtype));
     const size_t vg = (size_t)c->V * c->G;
     HIP_TRY(hipMemsetAsync(c->d_add, 0, sizeof(float) * (vg ? vg : 1), c->stream));  // demux.py:86
+    c->incr_valid = false;
     c->add_is_zero = true;
     c->add_partial = false;
     for (int it = 0; it < n_iterations; it++) {
@@ -2442,6 +2524,7 @@ int dmx_reset_timings(dmx_ctx *c)
     // the totals; the last E-step's own numbers stay (they decide how the next one runs: kernels.hip k_guard_begin)
     if (c->d_guard_count) HIP_TRY(hipMemsetAsync(c->d_guard_count + dmx::GS_PENDING, 0, 4 * sizeof(unsigned), c->stream));  // GS_PENDING, GS_DIRECT_STEPS, GS_TOTAL
     if (c->d_guard_count) HIP_TRY(hipMemsetAsync(c->d_guard_count + dmx::GS_COARSE_STEPS, 0, sizeof(unsigned), c->stream));
+    if (c->d_incr_state) HIP_TRY(hipMemsetAsync(c->d_incr_state + 2 * dmx::IS_WORDS, 0, sizeof(unsigned) * dmx::IS_WORDS, c->stream));
     c->guard_rows_total = 0;
     for (int s = 0; s < DMX_T_COUNT; s++) {
         timer_flush(c, s);

@@ -88,6 +88,19 @@ struct dmx_ctx {
     int *d_mt_first = nullptr;      // [n_mt + 1] first variant of every tile
     int *d_mt_order = nullptr;      // [n_mt] tiles by decreasing number of calls
     int *d_mt_shift = nullptr;      // [n_mt] fixed-point exponent of every tile (MTileArgs::shift)
+    unsigned char *d_mt_shift_v = nullptr;  // [V] the same per variant (incremental M-step; only when the tiles were built from one context's own records)
+    // incremental M-step (kernels.h: MIncrArgs): the tiles' integer sums and the posteriors they were formed from, kept between M-steps
+    unsigned long long *d_acc64 = nullptr;  // [V, G]
+    float *d_prev_post = nullptr;           // [B, G]
+    uint2 *d_prev_first = nullptr;          // [B]
+    int *d_incr_list = nullptr;             // [B]
+    unsigned char *d_incr_touched = nullptr;  // [V]
+    unsigned *d_incr_state = nullptr;       // [2 x IS_WORDS] the state words of this and of the next M-step, alternating
+    int incr_parity = 0;
+    bool incr_valid = false;                // the device state may be trusted (else the state words are zeroed: a full pass)
+    float incr_power = 0.0f;                // contribution power of the sums in d_acc64
+    int mstep_incremental = 1;              // dmx_set_mstep_incremental
+    long long mstep_incr_launches = 0;      // M-steps that went through the incremental launch sequence
     long long n_mt = 0;
     std::vector<long long> h_col_ptr;  // [V + 1] first M-step record of every variant (host copy made by the repack: the tiles are cut from it)
     long long n_mt_stream = 0;      // records d_mt_stream holds room for (the calls; with the padding calls' slots when built from the barcode-major records)

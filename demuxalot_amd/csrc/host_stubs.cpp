@@ -133,6 +133,7 @@ hipError_t launch_pack_rows(hipStream_t, const float *, const unsigned char *, c
 hipError_t launch_estep_dict(hipStream_t, const EstepArgs &, bool) { return hipSuccess; }
 hipError_t launch_estep_dict_block(hipStream_t, const EstepArgs &) { return hipSuccess; }
 hipError_t launch_mstep(hipStream_t, const MstepArgs &) { return hipSuccess; }
+hipError_t launch_mstep_incremental(hipStream_t, const MstepArgs &, const MTileArgs &, const MIncrArgs &) { return hipSuccess; }
 hipError_t launch_mstep_tiles(hipStream_t, const MstepArgs &, const MTileArgs &) { return hipSuccess; }
 hipError_t launch_guard_begin(hipStream_t, unsigned *, long long, int, int, int, int) { return hipSuccess; }
 hipError_t launch_prob_to_half(hipStream_t, const float *, long long, int, unsigned short *, const unsigned *) { return hipSuccess; }

@@ -308,7 +308,42 @@ struct MTileArgs {
     const int *shift;      // [n_tiles] binary exponent of the tile's fixed-point grid (k_mstep_tiles: contributions are added as rint(c 2^shift))
     long long n_tiles;
     int tv;
+    // incremental M-step (MIncrArgs below; both null: every M-step the full pass)
+    unsigned long long *acc64;   // [V, G] the tiles' fixed-point sums, kept between M-steps
+    const unsigned *incr_state;  // the current M-step's state words: the launch stands back unless they ask for the full pass
 };
+// Incremental M-step (kernels.hip: k_mincr_*).  The tile-major M-step adds INTEGERS - rint(c 2^shift) of every contribution
+// c = (posterior x keep)^power -, so its sums can be UPDATED exactly: after a full pass has left them in acc64, an M-step only has
+// to visit the barcodes whose posteriors changed where it matters - a posterior below 2^-26 contributes c 2^shift < 2^-2, i.e.
+// exactly 0, so a change between two such values changes nothing - and add, per call and genotype, the difference of the new and the
+// old integer.  On converged iterations that is a fraction of a percent of the calls (99 % of the barcodes sit at a posterior of
+// exactly 1.0).  The result is the full pass's, bit for bit.  All decisions on the device: k_mincr_changes lists the changed barcodes
+// and counts their calls; when the sums are not valid, the changed barcodes hold more than an eighth of the calls, or the posteriors
+// are dense (dense_regime), the delta pass stands back and the full pass (k_mstep_tiles) runs instead.
+struct MIncrArgs {
+    unsigned *state;        // this M-step's state words (IS_*); `next`: the other set, prepared by k_mincr_finish for the next M-step
+    unsigned *next;
+    unsigned *counters;     // [0] full passes, [1] delta passes, [2] barcodes the last M-step found changed (since dmx_reset_timings)
+    unsigned long long *acc64;     // [V, G]
+    float *prev;                   // [B, G] singlet posteriors the sums in acc64 were formed from
+    uint2 *prev_first;             // [B] ... and their codes (MstepArgs::first)
+    int *list;                     // [B] changed barcodes
+    unsigned char *touched;        // [V] variants whose sums the delta pass changed (their rows of the addition are converted again)
+    const unsigned char *shift_v;  // [V] fixed-point exponent of the variant's tile (MTileArgs::shift)
+    const CallPair *pairs;         // barcode-major call records + the table row (= variant) of every call
+    const unsigned *call_rows;
+    const long long *pair_ptr;
+    long long B, V;
+    float floor;            // mincr_floor(power)
+};
+enum { IS_N = 0,        // changed barcodes of this M-step
+       IS_CALLS = 2,    // (64 bit, words 2 and 3) their (padded) calls
+       IS_VALID = 4,    // acc64 / prev hold the previous M-step's sums and posteriors
+       IS_WORDS = 8 };
+// posteriors below this contribute exactly 0 on every tile's grid (shift <= 50): p^power 2^50 <= 2^-2 for p <= 2^(-52 / power) - 2^-26 for the
+// reference's power of 2; powers for which that is not a normal float32: 0 (every bit counts)
+inline float mincr_floor(float power) { return power * 126.0f > 52.0f ? exp2f(-52.0f / power) : 0.0f; }
+hipError_t launch_mstep_incremental(hipStream_t st, const MstepArgs &a, const MTileArgs &t, const MIncrArgs &x);
 constexpr int MTILE_LDS_BYTES = 64 * 1024;  // accumulators of a tile: with the 12 KB of dense-call queues, two workgroups of 1024 threads per CU
 constexpr int MTILE_MAX_VARIANTS = 128;     // 7 bits of the record
 hipError_t launch_mstep_tiles(hipStream_t st, const MstepArgs &a, const MTileArgs &t);

@@ -2279,10 +2279,18 @@ __global__ __launch_bounds__(256) void k_mstep_calls(MstepArgs a)
 // fewer instructions): 0.34 ms as well (0.32 against 0.30 at 32 genotypes) - PMC: VALU 64 %, address unit 69 %, LDS 49 % busy.
 constexpr int MTILE_THREADS = 1024;
 constexpr int MTILE_QUEUE = 96;  // dense calls a wavefront parks before it takes their rows (64 + the flush threshold)
+// whether this M-step runs the full pass (k_mstep_tiles) instead of the delta pass: see MIncrArgs
+static __device__ __forceinline__ bool incr_full(const unsigned *state, const MstepArgs &a)
+{
+    const unsigned long long calls = ((unsigned long long)state[IS_CALLS + 1] << 32) | state[IS_CALLS];
+    return state[IS_VALID] == 0u || 8ull * calls > a.total_calls || dense_regime(a);
+}
+
 template <bool SQUARE>
 __global__ __launch_bounds__(MTILE_THREADS) void k_mstep_tiles(MstepArgs a, MTileArgs t)
 {
     if (dense_regime(a)) return;
+    if (t.incr_state != nullptr && !incr_full(t.incr_state, a)) return;  // the delta pass updates the sums (k_mincr_delta)
     extern __shared__ __attribute__((aligned(16))) unsigned long long mt_acc[];
     __shared__ unsigned mt_queue[MTILE_THREADS / 64][2][MTILE_QUEUE];  // per wavefront: barcode row | variant in tile << 24, keep bits of its parked dense calls
     const int tile = t.order[blockIdx.x];
@@ -2388,6 +2396,135 @@ __global__ __launch_bounds__(MTILE_THREADS) void k_mstep_tiles(MstepArgs a, MTil
         const double sum = __builtin_ldexp((double)(long long)mt_acc[i], -shift);  // one rounding to float64 (sums beyond 2^53 grid units)
         if (a.out32) a.out32[o] = (float)sum;
         else a.out64[o] = sum;
+        if (t.acc64) t.acc64[(size_t)v * G + g] = mt_acc[i];  // (incremental M-step: the sums themselves, for the delta passes to come)
+    }
+}
+
+// ---- incremental M-step (kernels.h: MIncrArgs) ----
+// a posterior pair that makes a difference to the sums: other bits, and not both below the grid's floor (NaN: a difference)
+static __device__ __forceinline__ bool mincr_differs(float now, float before, float floor)
+{
+    return __float_as_uint(now) != __float_as_uint(before) && !(fmaxf(now, before) < floor);
+}
+
+// A lane per barcode: its 8-byte code (nz_code: first live posterior, count, first live genotypes) against the code the sums were
+// formed with - a barcode with ONE live posterior then and now and the same code has not changed where it matters (99 % of them on
+// converged iterations: 16 bytes per barcode instead of two 256-byte rows).  The others' rows are compared by the whole wavefront, a
+// barcode at a time (lane = genotype).
+__global__ __launch_bounds__(256) void k_mincr_changes(MstepArgs a, MIncrArgs x)
+{
+    if (x.state[IS_VALID] == 0u || dense_regime(a)) return;  // the full pass is coming
+    // (16 barcodes per wavefront: the row comparisons of a wavefront are one after the other, so more wavefronts = more of them in flight)
+    const int lane = threadIdx.x & 63;
+    const long long b = ((long long)blockIdx.x * 4 + (threadIdx.x >> 6)) * 16 + lane;
+    bool look = false;
+    if (lane < 16 && b < x.B) {
+        const uint2 now = a.first[b], before = x.prev_first[b];
+        look = !((now.y & 127u) == 1u && now.x == before.x && now.y == before.y);
+    }
+    for (unsigned long long m = __ballot(look); m != 0ull; m &= m - 1ull) {  // (uniform)
+        const long long bb = b - lane + __builtin_ctzll(m);
+        bool differs = false;
+        if (lane < a.G) differs = mincr_differs(a.post[(size_t)bb * a.K + lane], x.prev[(size_t)bb * a.G + lane], x.floor);
+        const bool changed = __ballot(differs) != 0ull;
+        if (lane == 0) {
+            if (changed) {
+                x.list[atomicAdd(x.state + IS_N, 1u)] = (int)bb;
+                atomicAdd((unsigned long long *)(x.state + IS_CALLS), 2ull * (unsigned long long)(x.pair_ptr[bb + 1] - x.pair_ptr[bb]));
+            } else {
+                x.prev_first[bb] = a.first[bb];  // (nothing that matters changed: the next M-step need not look at its rows again)
+            }
+        }
+    }
+}
+
+// the changed barcodes, a wavefront each (the wavefronts stride over the list): lane = call, per genotype that differs the difference of
+// the new and the old integer contribution, added to the sums with device-scope atomics
+template <bool SQUARE>
+__global__ __launch_bounds__(256) void k_mincr_delta(MstepArgs a, MIncrArgs x)
+{
+    if (incr_full(x.state, a)) return;
+    const int lane = threadIdx.x & 63;
+    const unsigned n = x.state[IS_N];
+    const int G = a.G;
+    constexpr double MAGIC = 6755399441055744.0;  // (k_mstep_tiles: the same conversion)
+    auto quant = [&](float c, int shift) {
+        const double d = __builtin_ldexp((double)(SQUARE ? c * c : powf(c, a.power)), shift) + MAGIC;
+        return (unsigned long long)(__double_as_longlong(d) - __double_as_longlong(MAGIC));
+    };
+    // a workgroup per changed barcode (the workgroups stride over the list), its four wavefronts taking the chunks of 64 calls in turn:
+    // a launch lasts as long as its longest barcode
+    const int wave = threadIdx.x >> 6;
+    for (unsigned i = blockIdx.x; i < n; i += gridDim.x) {
+        const long long b = x.list[i];
+        float now = 0.0f, before = 0.0f;
+        if (lane < G) {
+            now = a.post[(size_t)b * a.K + lane];
+            before = x.prev[(size_t)b * G + lane];
+        }
+        const unsigned long long mask = __ballot(lane < G && mincr_differs(now, before, x.floor));
+        const long long p0 = x.pair_ptr[b];
+        const int n_calls = 2 * (int)(x.pair_ptr[b + 1] - p0);
+        for (int c0 = 64 * wave; c0 < n_calls; c0 += 256) {
+            const int ci = c0 + lane;
+            const bool mine = ci < n_calls;
+            float keep = 0.0f;
+            unsigned row = 0u;
+            if (mine) {
+                keep = x.pairs[p0 + (ci >> 1)].keep[ci & 1];
+                row = x.call_rows[2 * p0 + ci];
+            }
+            const int shift = mine ? (int)x.shift_v[row] : 0;
+            for (unsigned long long m = mask; m != 0ull; m &= m - 1ull) {  // (uniform)
+                const int g = __builtin_ctzll(m);
+                const float pn = __shfl(now, g), po = __shfl(before, g);
+                const unsigned long long qn = quant(pn * keep, shift), qo = quant(po * keep, shift);
+                if (mine && qn != qo) {
+                    __hip_atomic_fetch_add(&x.acc64[(size_t)row * G + g], qn - qo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    x.touched[row] = 1;
+                }
+            }
+        }
+        __syncthreads();  // (every wavefront has read the old row)
+        if (wave == 0) {
+            if (lane < G) x.prev[(size_t)b * G + lane] = now;
+            if (lane == 0) x.prev_first[b] = a.first[b];
+        }
+    }
+}
+
+// behind the delta pass: the rows of the addition whose sums changed (a thread per variant); behind a full pass: the posteriors and
+// codes it summed, for the next M-step to compare with.  Prepares the next M-step's state words.
+__global__ __launch_bounds__(256) void k_mincr_finish(MstepArgs a, MIncrArgs x)
+{
+    const bool full = incr_full(x.state, a);
+    const int G = a.G;
+    const long long tid = (long long)blockIdx.x * blockDim.x + threadIdx.x, stride = (long long)gridDim.x * blockDim.x;
+    if (full) {
+        for (long long i = tid; i < x.B * G; i += stride) {
+            const long long b = i / G;
+            x.prev[i] = a.post[(size_t)b * a.K + (i - b * G)];
+        }
+        for (long long b = tid; b < x.B; b += stride) x.prev_first[b] = a.first[b];
+    } else {
+        const int lane = threadIdx.x & 63;
+        for (long long v0 = (tid - lane); v0 < x.V; v0 += stride) {  // a wavefront per 64 variants: their flags, then the touched rows, lane = genotype
+            const long long v = v0 + lane;
+            const bool hit = v < x.V && x.touched[v] != 0;
+            if (hit) x.touched[v] = 0;
+            for (unsigned long long m = __ballot(hit); m != 0ull; m &= m - 1ull) {
+                const long long vv = v0 + __builtin_ctzll(m);
+                const int shift = (int)x.shift_v[vv];
+                if (lane < G) a.out32[(size_t)vv * G + lane] = (float)__builtin_ldexp((double)(long long)x.acc64[(size_t)vv * G + lane], -shift);
+            }
+        }
+    }
+    if (tid == 0) {
+        x.counters[full ? 0 : 1] += 1u;
+        x.counters[2] = x.state[IS_VALID] ? x.state[IS_N] : 0xFFFFFFFFu;  // barcodes this M-step found changed (no valid sums: not looked for)
+        x.next[IS_N] = 0u;
+        x.next[IS_CALLS] = x.next[IS_CALLS + 1] = 0u;
+        x.next[IS_VALID] = full ? (dense_regime(a) ? 0u : 1u) : 1u;  // (dense regime: k_mstep_dense did the work, the sums are not the tiles')
     }
 }
 
@@ -3033,6 +3170,21 @@ hipError_t launch_mstep(hipStream_t st, const MstepArgs &a)
     else if (G <= 512) launch_m<8, 2>(st, a);
     else if (G <= 1024) launch_m<16, 2>(st, a);
     else return hipErrorInvalidValue;
+    return hipGetLastError();
+}
+
+// changes -> delta pass | full pass (exactly one of them works) -> conversion / snapshot; the dense regime's kernel as in launch_mstep_tiles
+hipError_t launch_mstep_incremental(hipStream_t st, const MstepArgs &a, const MTileArgs &t, const MIncrArgs &x)
+{
+    if (t.n_tiles == 0 || x.B == 0) return hipSuccess;
+    hipLaunchKernelGGL(k_mincr_changes, dim3(blocks_for(x.B, 64)), dim3(256), 0, st, a, x);
+    if (a.square)
+        hipLaunchKernelGGL((k_mincr_delta<true>), dim3(4096), dim3(256), 0, st, a, x);
+    else
+        hipLaunchKernelGGL((k_mincr_delta<false>), dim3(4096), dim3(256), 0, st, a, x);
+    const hipError_t e = launch_mstep_tiles(st, a, t);  // (stands back unless the full pass is due; + the dense regime's kernel)
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(k_mincr_finish, dim3(2048), dim3(256), 0, st, a, x);
     return hipGetLastError();
 }
 

@@ -763,6 +763,8 @@ void release_mstep_tiles(dmx_ctx *c)
     dev_free(c, &c->d_mt_first, (size_t)c->n_mt + 1);
     dev_free(c, &c->d_mt_order, (size_t)c->n_mt);
     dev_free(c, &c->d_mt_shift, (size_t)c->n_mt);
+    dev_free(c, &c->d_mt_shift_v, (size_t)c->V);
+    c->incr_valid = false;
     c->n_mt = 0;
     c->mt_tv = 0;
     c->mt_tried = false;
@@ -849,6 +851,10 @@ int build_mstep_tiles(dmx_ctx *c, long long v_lo, long long v_hi)
         DMX_TRY(sc.get(&keys, n));
         DMX_TRY(sc.get(&keys_out, n));
         DMX_TRY(sc.get(&vals, n));
+        std::vector<unsigned char> shift_v((size_t)V);
+        for (long long v = 0; v < V; v++) shift_v[(size_t)v] = (unsigned char)tile_shift[(size_t)tile_of[(size_t)v]];
+        DMX_TRY(dev_alloc(c, &c->d_mt_shift_v, (size_t)V));
+        HIP_TRY(hipMemcpyAsync(c->d_mt_shift_v, shift_v.data(), (size_t)V, hipMemcpyHostToDevice, st));
         for (long long v = 0; v < V; v++) tile_of[(size_t)v] = (tile_of[(size_t)v] << 7) | vin_of[(size_t)v];  // (vin < 128 = MTILE_MAX_VARIANTS)
         HIP_TRY(hipMemcpyAsync(d_tile_of, tile_of.data(), sizeof(unsigned) * V, hipMemcpyHostToDevice, st));
         DMX_TRY(dev_alloc(c, &vals_out, n));

@@ -49,6 +49,7 @@ class DeviceContext:
         self.set_estep_dictionary(os.environ.get('DEMUXALOT_AMD_ESTEP_DICT', 'auto'))
         self.set_estep_packing(os.environ.get('DEMUXALOT_AMD_ESTEP_PACKED', 'auto'))
         self.set_coarse_pass(True)
+        self.set_mstep_incremental(True)
 
     def __enter__(self):
         return self
@@ -439,6 +440,17 @@ class DeviceContext:
         """Guarded mode: E-steps whose logits nobody reads may take the coarse pass (binary16 genotype table; default on;
         'always': every E-step, single ones included - their logits then carry the coarse bound; include/demux_hip.h: dmx_set_coarse_pass)."""
         check(self._lib.dmx_set_coarse_pass(self._h, 2 if coarse == 'always' else int(bool(coarse))))
+
+    def set_mstep_incremental(self, incremental):
+        """Default mode, tile-major M-step: update the kept integer sums for the barcodes whose posteriors changed instead of summing every
+        call again (same bits; default on; include/demux_hip.h: dmx_set_mstep_incremental)."""
+        check(self._lib.dmx_set_mstep_incremental(self._h, int(bool(incremental))))
+
+    def mstep_incremental(self):
+        """(full passes, delta passes since reset_timings, barcodes the last delta pass visited)"""
+        full, delta, last = ctypes.c_int64(), ctypes.c_int64(), ctypes.c_int64()
+        check(self._lib.dmx_get_mstep_incremental(self._h, ctypes.byref(full), ctypes.byref(delta), ctypes.byref(last)))
+        return full.value, delta.value, last.value
 
     def guard_levels(self):
         """dict: level of the last guarded E-step (0 coarse, 1 fine, 2 direct, -1 none), coarse E-steps since reset_timings, barcodes

@@ -243,6 +243,17 @@ int dmx_set_guard_adaptive(dmx_ctx *ctx, int adaptive);
  * estimate), and the device's timings of the three passes over all barcodes
  * in ms (0: not run yet; exact: negative while it is an estimate).  Any pointer may be NULL. */
 int dmx_set_coarse_pass(dmx_ctx *ctx, int coarse);
+/* Incremental M-step (csrc/kernels.h: MIncrArgs).  The tile-major M-step adds integers, so its sums can be updated exactly: once a
+ * full pass has left them on the device, an M-step visits only the barcodes whose posteriors changed where it matters (a posterior
+ * below 2^-26 contributes exactly 0 on the sums' grid) and adds the differences of their new and old contributions - a fraction of a
+ * percent of the calls on converged iterations.  The additions are the full pass's, bit for bit; the device falls back to the full
+ * pass whenever the changed barcodes hold more than an eighth of the calls, the kept sums are not valid (a new problem, dmx_set_addition,
+ * the first M-step of a dmx_em call, another M-step form in between) or the posteriors are dense.  Taken where the tile-major form is
+ * (dmx_set_mstep_tiles) on one context that holds all calls of its barcodes.  incremental = 0: every M-step the full pass.  Default 1.
+ * dmx_get_mstep_incremental: full and delta passes since dmx_reset_timings, barcodes the last M-step found changed (-1: it had no
+ * valid sums to compare with). */
+int dmx_set_mstep_incremental(dmx_ctx *ctx, int incremental);
+int dmx_get_mstep_incremental(dmx_ctx *ctx, int64_t *full_passes, int64_t *delta_passes, int64_t *barcodes_changed_last);
 int dmx_get_guard_levels(dmx_ctx *ctx, int32_t *level_last, int64_t *coarse_steps, int64_t *flagged_fine_last, int64_t *flagged_coarse_last,
                          double *coarse_pass_ms, double *fine_pass_ms, double *exact_pass_ms);
 int dmx_get_guard_direct(dmx_ctx *ctx, int32_t *last_ran_direct, int64_t *direct_steps, int64_t *would_queue_last, double *fast_pass_ms,

@@ -186,3 +186,64 @@ def test_tile_major_mstep_is_bit_reproducible(G, B, S, cpb):
     for other in runs[1:]:
         for x, y in zip(runs[0], other):
             assert np.array_equal(x.view(np.uint32), y.view(np.uint32))
+
+
+@pytest.mark.parametrize('power', [2.0, 1.5])
+@pytest.mark.parametrize('G,doublets,B,S,cpb,hard', [(8, True, 6000, 3000, 400, False), (33, False, 6000, 3000, 500, False),
+                                                    (64, False, 12000, 6000, 400, False), (64, False, 12000, 4000, 400, True),
+                                                    (24, True, 5000, 2000, 60, True)])
+def test_incremental_mstep_is_the_full_pass_bit_for_bit(G, doublets, B, S, cpb, hard, power):
+    """The incremental M-step (include/demux_hip.h: dmx_set_mstep_incremental; kernels.h: MIncrArgs): after one full pass of the
+    tile-major kernel the integer sums stay on the device, and an M-step only adds, for the barcodes whose posteriors changed where
+    it matters, the differences of their new and old integer contributions.  Eight EM iterations with it and without it (every M-step
+    the full pass): the additions equal BIT FOR BIT after every one of them, and the delta pass did run (sibling donors / few calls per barcode: the
+    device falls back to the full pass by itself wherever the changed barcodes hold an eighth of the calls or the posteriors are dense)."""
+    from demuxalot_amd import Demultiplexer, synth
+    p = synth.generate(B, S, G, calls_per_barcode=cpb, doublets=doublets, seed=1700 + G + B, sibling_pairs=hard)
+    pen = Demultiplexer._doublet_penalties(G, 0.2 if doublets else 0.0)
+    runs = {}
+    for incremental in (True, False):
+        ctx = _context(p, G, False, True)
+        try:
+            ctx.set_mstep_incremental(incremental)
+            ctx.reset_timings()
+            runs[incremental] = (_additions(ctx, pen, doublets, power, n_iterations=8), ctx.mstep_incremental())
+            assert ctx.mstep_form() == 'tiles'
+        finally:
+            ctx.close()
+    for it, (got, want) in enumerate(zip(runs[True][0], runs[False][0])):
+        assert np.array_equal(got.view(np.uint32), want.view(np.uint32)), (it, int((got != want).sum()), float(np.abs(got - want).max()))
+    full, delta, last = runs[True][1]
+    assert full + delta == 8 and full >= 1 and runs[False][1] == (0, 0, 0), (runs[True][1], runs[False][1])
+    if not hard:
+        assert delta >= 5 and 0 <= last < 0.2 * B, (full, delta, last)   # separable donors with 400 calls per barcode: the later iterations change little
+    print(f'G={G} doublets={doublets} hard={hard} power={power}: {full} full + {delta} delta passes, the last delta pass visited {last} of {B} barcodes')
+
+
+def test_incremental_mstep_starts_over_when_the_addition_is_replaced():
+    """dmx_set_addition, a dmx_em call (which zeroes the addition first) and a switch of the M-step form make the kept sums useless:
+    the next M-step is a full pass, and the results stay those of a context that never kept anything."""
+    from demuxalot_amd import synth
+    p = synth.generate(8000, 2000, 16, calls_per_barcode=400, seed=1790)
+    pen = np.zeros(16, dtype=np.float32)
+    out = {}
+    for incremental in (True, False):
+        ctx = _context(p, 16, False, True)
+        try:
+            ctx.set_mstep_incremental(incremental)
+            ctx.reset_timings()
+            a = _additions(ctx, pen, False, 2.0, n_iterations=3)
+            ctx.set_addition(a[0] * np.float32(0.5))                       # somebody else's addition
+            b = _additions(ctx, pen, False, 2.0, n_iterations=2)
+            _l, _p, c_add = ctx.em(4, 0.01, pen, with_doublets=False, fetch_logits=False, fetch_probs=False)
+            ctx.set_mstep_tiles(False)                                     # the work-item form in between
+            d = _additions(ctx, pen, False, 2.0, n_iterations=1)
+            ctx.set_mstep_tiles(True)
+            e = _additions(ctx, pen, False, 2.0, n_iterations=2)
+            out[incremental] = (a + b + [c_add] + e, ctx.mstep_incremental())
+        finally:
+            ctx.close()
+    for i, (got, want) in enumerate(zip(out[True][0], out[False][0])):
+        assert np.array_equal(got.view(np.uint32), want.view(np.uint32)), i
+    full, delta, _last = out[True][1]
+    assert full >= 4 and delta >= 4, (full, delta)   # a full pass after each of the four breaks, delta passes behind them
