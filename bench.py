@@ -471,7 +471,7 @@ def hard_workload(args, ctx, whole, betas, pen, dp):
                 ctx.set_msteps_expected(args.warmup + args.steps)
             region = timed_region(ctx, None, args.steps, args.warmup)
             _direct, direct_steps, would, fast_ms, exact_ms = ctx.guard_state()
-            res[name] = {'ms_per_step': region['ms_per_step'], 'kernel_ms': region['kernel_ms'], 'guard': region['guard'], 'estep_passes': region['estep_passes'],
+            res[name] = {'ms_per_step': region['ms_per_step'], 'kernel_ms': region['kernel_ms'], 'guard': region['guard'], 'estep_passes': region['estep_passes'], 'mstep_passes': region['mstep_passes'],
                          'first_estep_queued_fraction': first_queued / problem.n_barcodes, 'esteps_run_direct': direct_steps, 'steps': args.steps,
                          'last_estep_would_queue_fraction': would / problem.n_barcodes,
                          'device_timed_ms': {'fast_pass_all_barcodes': fast_ms, 'exact_kernel_all_barcodes': abs(exact_ms),

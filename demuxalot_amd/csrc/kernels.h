@@ -339,6 +339,8 @@ struct MIncrArgs {
 enum { IS_N = 0,        // changed barcodes of this M-step
        IS_CALLS = 2,    // (64 bit, words 2 and 3) their (padded) calls
        IS_VALID = 4,    // acc64 / prev hold the previous M-step's sums and posteriors
+       IS_STREAK = 5,   // full passes in a row that the changes asked for
+       IS_SITOUT = 6,   // M-steps still to go without looking for changes (k_mincr_finish)
        IS_WORDS = 8 };
 // posteriors below this contribute exactly 0 on every tile's grid (shift <= 50): p^power 2^50 <= 2^-2 for p <= 2^(-52 / power) - 2^-26 for the
 // reference's power of 2; powers for which that is not a normal float32: 0 (every bit counts)

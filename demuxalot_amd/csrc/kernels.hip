@@ -2401,6 +2401,7 @@ __global__ __launch_bounds__(MTILE_THREADS) void k_mstep_tiles(MstepArgs a, MTil
 }
 
 // ---- incremental M-step (kernels.h: MIncrArgs) ----
+constexpr unsigned MINCR_COOLDOWN = 8;  // M-steps that do not look for changes after two full passes the changes asked for (k_mincr_finish)
 // a posterior pair that makes a difference to the sums: other bits, and not both below the grid's floor (NaN: a difference)
 static __device__ __forceinline__ bool mincr_differs(float now, float before, float floor)
 {
@@ -2500,13 +2501,20 @@ __global__ __launch_bounds__(256) void k_mincr_finish(MstepArgs a, MIncrArgs x)
     const bool full = incr_full(x.state, a);
     const int G = a.G;
     const long long tid = (long long)blockIdx.x * blockDim.x + threadIdx.x, stride = (long long)gridDim.x * blockDim.x;
-    if (full) {
+    // A workload whose posteriors keep changing (sibling donors, few calls per barcode) pays for the comparison and gets the full pass
+    // anyway: after two full passes in a row that the CHANGES asked for, the next MINCR_COOLDOWN M-steps do not look (no valid sums: the
+    // full pass, no snapshot behind it), then the sums are kept again (IS_STREAK, IS_SITOUT of the state words).
+    const bool too_many = full && x.state[IS_VALID] != 0u && !dense_regime(a);
+    const unsigned streak = too_many ? x.state[IS_STREAK] + 1u : 0u;
+    const unsigned sitting_out = x.state[IS_SITOUT];
+    const bool keep_next = full ? (!dense_regime(a) && streak < 2u && sitting_out <= 1u) : true;  // whether the next M-step finds valid sums
+    if (full && keep_next) {
         for (long long i = tid; i < x.B * G; i += stride) {
             const long long b = i / G;
             x.prev[i] = a.post[(size_t)b * a.K + (i - b * G)];
         }
         for (long long b = tid; b < x.B; b += stride) x.prev_first[b] = a.first[b];
-    } else {
+    } else if (!full) {
         const int lane = threadIdx.x & 63;
         for (long long v0 = (tid - lane); v0 < x.V; v0 += stride) {  // a wavefront per 64 variants: their flags, then the touched rows, lane = genotype
             const long long v = v0 + lane;
@@ -2524,7 +2532,9 @@ __global__ __launch_bounds__(256) void k_mincr_finish(MstepArgs a, MIncrArgs x)
         x.counters[2] = x.state[IS_VALID] ? x.state[IS_N] : 0xFFFFFFFFu;  // barcodes this M-step found changed (no valid sums: not looked for)
         x.next[IS_N] = 0u;
         x.next[IS_CALLS] = x.next[IS_CALLS + 1] = 0u;
-        x.next[IS_VALID] = full ? (dense_regime(a) ? 0u : 1u) : 1u;  // (dense regime: k_mstep_dense did the work, the sums are not the tiles')
+        x.next[IS_VALID] = keep_next ? 1u : 0u;  // (dense regime: k_mstep_dense did the work, the sums are not the tiles')
+        x.next[IS_STREAK] = streak >= 2u ? 0u : streak;
+        x.next[IS_SITOUT] = streak >= 2u ? MINCR_COOLDOWN : (sitting_out > 0u ? sitting_out - 1u : 0u);
     }
 }
 
