@@ -1516,6 +1516,16 @@ int run_mstep(dmx_ctx *c, float power)
         }
         if (!c->incr_valid || c->incr_power != power) {  // (nothing to build on: zeroed state words ask for the full pass)
             HIP_TRY(hipMemsetAsync(c->d_incr_state, 0, sizeof(unsigned) * 2 * dmx::IS_WORDS, c->stream));
+            if (c->mstep_incremental == 2) {  // (measurement: the sums built from nothing by the delta pass instead of the full pass)
+                const unsigned on[2] = {1u, 1u};
+                HIP_TRY(hipMemsetAsync(c->d_acc64, 0, sizeof(unsigned long long) * (size_t)c->V * c->G, c->stream));
+                HIP_TRY(hipMemsetAsync(c->d_prev_post, 0, sizeof(float) * (size_t)c->B * c->G, c->stream));
+                HIP_TRY(hipMemsetAsync(c->d_prev_first, 0xFF, sizeof(uint2) * (size_t)c->B, c->stream));
+                HIP_TRY(hipMemsetAsync(c->d_add, 0, sizeof(float) * (size_t)c->V * c->G, c->stream));
+                HIP_TRY(hipMemcpyAsync(c->d_incr_state + dmx::IS_VALID, &on[0], sizeof(unsigned), hipMemcpyHostToDevice, c->stream));
+                HIP_TRY(hipMemcpyAsync(c->d_incr_state + dmx::IS_FORCE, &on[1], sizeof(unsigned), hipMemcpyHostToDevice, c->stream));
+                HIP_TRY(hipStreamSynchronize(c->stream));
+            }
             c->incr_parity = 0;
             c->incr_valid = true;
             c->incr_power = power;
@@ -1918,7 +1928,9 @@ int dmx_get_guard_stats(dmx_ctx *c, int64_t *redone_last, int64_t *redone_total,
 int dmx_set_mstep_incremental(dmx_ctx *c, int incremental)
 {
     if (!c) return fail(DMX_ERR_INVALID, "null context");
-    c->mstep_incremental = incremental != 0;
+    if (incremental < 0 || incremental > 2) return fail(DMX_ERR_INVALID, "incremental M-step: 0 off, 1 on, 2 on with the first sums built by the delta pass");
+    if (incremental != c->mstep_incremental) c->incr_valid = false;
+    c->mstep_incremental = incremental;
     return 0;
 }
 

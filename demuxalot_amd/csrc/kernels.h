@@ -341,6 +341,7 @@ enum { IS_N = 0,        // changed barcodes of this M-step
        IS_VALID = 4,    // acc64 / prev hold the previous M-step's sums and posteriors
        IS_STREAK = 5,   // full passes in a row that the changes asked for
        IS_SITOUT = 6,   // M-steps still to go without looking for changes (k_mincr_finish)
+       IS_FORCE = 7,    // this M-step's delta pass builds the sums from nothing (acc64, prev and the addition zeroed by the host): never the full pass
        IS_WORDS = 8 };
 // posteriors below this contribute exactly 0 on every tile's grid (shift <= 50): p^power 2^50 <= 2^-2 for p <= 2^(-52 / power) - 2^-26 for the
 // reference's power of 2; powers for which that is not a normal float32: 0 (every bit counts)

@@ -2283,6 +2283,7 @@ constexpr int MTILE_QUEUE = 96;  // dense calls a wavefront parks before it take
 static __device__ __forceinline__ bool incr_full(const unsigned *state, const MstepArgs &a)
 {
     const unsigned long long calls = ((unsigned long long)state[IS_CALLS + 1] << 32) | state[IS_CALLS];
+    if (state[IS_FORCE] != 0u) return dense_regime(a);
     return state[IS_VALID] == 0u || 8ull * calls > a.total_calls || dense_regime(a);
 }
 
@@ -2532,6 +2533,7 @@ __global__ __launch_bounds__(256) void k_mincr_finish(MstepArgs a, MIncrArgs x)
         x.counters[2] = x.state[IS_VALID] ? x.state[IS_N] : 0xFFFFFFFFu;  // barcodes this M-step found changed (no valid sums: not looked for)
         x.next[IS_N] = 0u;
         x.next[IS_CALLS] = x.next[IS_CALLS + 1] = 0u;
+        x.next[IS_FORCE] = 0u;
         x.next[IS_VALID] = keep_next ? 1u : 0u;  // (dense regime: k_mstep_dense did the work, the sums are not the tiles')
         x.next[IS_STREAK] = streak >= 2u ? 0u : streak;
         x.next[IS_SITOUT] = streak >= 2u ? MINCR_COOLDOWN : (sitting_out > 0u ? sitting_out - 1u : 0u);

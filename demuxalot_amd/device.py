@@ -444,7 +444,7 @@ class DeviceContext:
     def set_mstep_incremental(self, incremental):
         """Default mode, tile-major M-step: update the kept integer sums for the barcodes whose posteriors changed instead of summing every
         call again (same bits; default on; include/demux_hip.h: dmx_set_mstep_incremental)."""
-        check(self._lib.dmx_set_mstep_incremental(self._h, int(bool(incremental))))
+        check(self._lib.dmx_set_mstep_incremental(self._h, 2 if incremental == 'bootstrap' else int(bool(incremental))))
 
     def mstep_incremental(self):
         """(full passes, delta passes since reset_timings, barcodes the last delta pass visited)"""

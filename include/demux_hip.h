@@ -250,6 +250,8 @@ int dmx_set_coarse_pass(dmx_ctx *ctx, int coarse);
  * pass whenever the changed barcodes hold more than an eighth of the calls, the kept sums are not valid (a new problem, dmx_set_addition,
  * the first M-step of a dmx_em call, another M-step form in between) or the posteriors are dense.  Taken where the tile-major form is
  * (dmx_set_mstep_tiles) on one context that holds all calls of its barcodes.  incremental = 0: every M-step the full pass.  Default 1.
+ * incremental = 2 (tests, measurements): the first sums too are built by the delta pass, every barcode against an all-zero row - the
+ * full pass's bits from another kernel and another walk of the calls, at 20 x its time.
  * dmx_get_mstep_incremental: full and delta passes since dmx_reset_timings, barcodes the last M-step found changed (-1: it had no
  * valid sums to compare with). */
 int dmx_set_mstep_incremental(dmx_ctx *ctx, int incremental);

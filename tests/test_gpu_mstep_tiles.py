@@ -247,3 +247,24 @@ def test_incremental_mstep_starts_over_when_the_addition_is_replaced():
         assert np.array_equal(got.view(np.uint32), want.view(np.uint32)), i
     full, delta, _last = out[True][1]
     assert full >= 4 and delta >= 4, (full, delta)   # a full pass after each of the four breaks, delta passes behind them
+
+
+def test_the_delta_pass_builds_the_full_pass_sums_from_nothing():
+    """dmx_set_mstep_incremental(ctx, 2): the first M-step's sums are built by the DELTA pass - every barcode against an all-zero
+    posterior row, every contribution a difference from 0 - instead of the tile-major full pass.  Two different kernels, two different
+    walks of the calls (barcode-major with device-scope atomics / tile-major in LDS): the same integers, hence the same bits."""
+    from demuxalot_amd import synth
+    p = synth.generate(9000, 3000, 32, calls_per_barcode=400, seed=1811)
+    pen = np.zeros(32, dtype=np.float32)
+    out = {}
+    for mode in (True, 'bootstrap'):
+        ctx = _context(p, 32, False, True)
+        try:
+            ctx.set_mstep_incremental(mode)
+            ctx.reset_timings()
+            out[mode] = (_additions(ctx, pen, False, 2.0, n_iterations=3), ctx.mstep_incremental())
+        finally:
+            ctx.close()
+    for it in range(3):
+        assert np.array_equal(out[True][0][it].view(np.uint32), out['bootstrap'][0][it].view(np.uint32)), it
+    assert out[True][1][0] == 1 and out['bootstrap'][1][:2] == (0, 3), (out[True][1], out['bootstrap'][1])
