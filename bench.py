@@ -517,7 +517,8 @@ def timed_region(ctx, plane, steps, warmup):
     levels = ctx.guard_levels()
     m_full, m_delta, m_changed = ctx.mstep_incremental()
     return {'elapsed': elapsed,
-            'mstep_passes': {'full': m_full, 'delta': m_delta, 'of': steps, 'barcodes_changed_in_the_last_mstep': m_changed}, 'ms_per_step': 1e3 * elapsed / steps, 'em_iterations_per_s': steps / elapsed,
+            'mstep_passes': ({'incremental_mstep': True, 'full': m_full, 'delta': m_delta, 'of': steps, 'barcodes_changed_in_the_last_mstep': m_changed}
+                             if m_full + m_delta > 0 else {'incremental_mstep': False, 'note': 'every M-step recomputes every sum'}), 'ms_per_step': 1e3 * elapsed / steps, 'em_iterations_per_s': steps / elapsed,
             'estep_passes': {'coarse': levels['coarse_steps'], 'of': steps, 'last': {0: 'coarse', 1: 'fine', 2: 'direct'}.get(levels['level'], 'not guarded'),
                              'device_timed_ms': {'coarse_pass': levels['coarse_pass_ms'], 'fine_pass': levels['fine_pass_ms'], 'exact_kernel': abs(levels['exact_pass_ms'])},
                              'last_estep_flagged': {'fine_guard': levels['flagged_fine'], 'coarse_guard': levels['flagged_coarse']}},
@@ -546,6 +547,8 @@ def main():
                          'iterations knows) and builds the tile-major records at the first M-step when 8 or more are to come; the build then '
                          'falls into the warm-up and the line reports it (mstep_records_build_ms, ms_per_step_incl_record_build).  tiles / '
                          'items: the form forced')
+    ap.add_argument('--incremental-mstep', action='store_true',
+                    help='the headline regions with the library\'s default M-step (incremental: dmx_set_mstep_incremental(1)) instead of a full pass per iteration')
     ap.add_argument('--deadline', type=float, default=1500.0,
                     help='N > 1 without a launcher: seconds after which the parent kills the rank processes it started, reports every '
                          'rank\'s last phase and exits non-zero (a rank hung in a collective must not cost the caller its own limit)')
@@ -667,6 +670,17 @@ def main():
         ctx.set_mstep_tiles('always')
     elif args.mstep == 'items':
         ctx.set_mstep_tiles('never')
+    # The headline regions recompute EVERY sum in EVERY iteration (dmx_set_mstep_incremental(0)): the library's default - the incremental
+    # M-step, which keeps the integer sums of the previous iteration and only adds the differences for the barcodes whose posteriors changed
+    # (same bits) - is timed right behind them and reported as `with_incremental_mstep`, not as `value`: on this synthetic experiment the EM
+    # has converged by the timed iterations, so that an incremental step has next to nothing left to do.
+    ctx.set_mstep_incremental(args.incremental_mstep)
+    _apply_environment = ctx.apply_environment
+
+    def apply_environment_for_the_bench():  # (the extra regions reset the modes in between: the M-step stays as chosen here)
+        _apply_environment()
+        ctx.set_mstep_incremental(args.incremental_mstep)
+    ctx.apply_environment = apply_environment_for_the_bench
 
     # ---- the timed regions: configs[3] as written first (strong: this rank's barcode range), then the workload per GPU ----
     kinds = ['strong', 'weak'] if args.scaling == 'both' else [args.scaling]
@@ -736,17 +750,17 @@ def main():
         work_item_region['scaling'] = kinds[-1]
         ctx.set_mstep_tiles('always' if args.mstep == 'tiles' else 'auto')
 
-    full_mstep_region = None
-    if world == 1 and not args.timed_only and regions[kinds[-1]]['mstep_passes']['delta'] > 0:  # (one rank: the region has barriers)
-        phase('default mode with every M-step the full pass: timed region')
-        ctx.set_mstep_incremental(False)
+    incr_mstep_region = None
+    if world == 1 and not args.timed_only and not args.incremental_mstep and ctx_mstep_form == 'tiles' and default_mode != 'exact':  # (one rank: the region has barriers)
+        phase('default mode with the incremental M-step (the library default): timed region')
+        ctx.set_mstep_incremental(True)
         ctx.set_addition(None)
         ctx.probs_from_betas(0.01, fetch=False)
         ctx.estep(pen, with_doublets=dp > 0, fetch_logits=False, fetch_probs=False)
-        full_mstep_region = timed_region(ctx, plane, args.steps, args.warmup)
-        full_mstep_region['value'] = regions[kinds[-1]]['barcodes_total'] * args.steps / full_mstep_region['elapsed']
-        full_mstep_region['scaling'] = kinds[-1]
-        ctx.set_mstep_incremental(True)
+        incr_mstep_region = timed_region(ctx, plane, args.steps, args.warmup)
+        incr_mstep_region['value'] = regions[kinds[-1]]['barcodes_total'] * args.steps / incr_mstep_region['elapsed']
+        incr_mstep_region['scaling'] = kinds[-1]
+        ctx.set_mstep_incremental(False)
 
     fine_only_region = None
     if world == 1 and not args.timed_only and default_mode == 'guarded' and regions[kinds[-1]]['estep_passes']['coarse'] > 0:  # (one rank: the region has barriers)
@@ -815,7 +829,8 @@ def main():
             'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
             'ms_per_step': head['ms_per_step'],
             'higher_is_better': True, 'scaling': head_kind, 'vs_baseline': None,
-            'dtype': 'f32 terms, f64 accumulate', 'data': 'synthetic',
+            'dtype': 'f32 terms, f64 accumulate (coarse pass of the guarded mode: genotype table read as binary16, f32 terms and sums - proven per barcode within the '
+                     'contract, the rest redone in the exact arithmetic)', 'data': 'synthetic',
             'config': {'workload': args.workload, 'barcodes_total': head['barcodes_total'], 'barcodes_per_gpu': head['barcodes_per_gpu'],
                        'snps': S, 'variants': V, 'genotypes': G, 'options': K, 'calls_per_gpu': head['calls_per_gpu'], 'doublet_prior': dp,
                        'estep_mode': default_mode + mode_notes[default_mode],
@@ -850,11 +865,13 @@ def main():
             out['work_item_mstep'] = {k: v for k, v in work_item_region.items() if k != 'elapsed'}
             out['work_item_mstep']['note'] = ('the same timed region with the work-item M-step, the form of runs with fewer than 8 M-steps '
                                               'ahead (the tile-major records cost a 2.6 ms sort of the calls to build)')
-        if full_mstep_region:
-            out['without_incremental_mstep'] = {k: v for k, v in full_mstep_region.items() if k != 'elapsed'}
-            out['without_incremental_mstep']['note'] = ('the same timed region with dmx_set_mstep_incremental(0): every M-step sums every call again (the tile-major full pass; same bits). '
-                                                        'Default: after one full pass the integer sums stay on the device and an M-step only visits the barcodes whose posteriors changed '
-                                                        'where it matters - mstep_passes says how many did what in the timed call')
+        if incr_mstep_region:
+            out['with_incremental_mstep'] = {k: v for k, v in incr_mstep_region.items() if k != 'elapsed'}
+            out['with_incremental_mstep']['note'] = ('the same timed region as a DEFAULT call of the library runs it (dmx_set_mstep_incremental(1)): after one full pass the tile-major '
+                                                     'M-step\'s integer sums stay on the device and an M-step only adds the differences for the barcodes whose posteriors changed where it '
+                                                     'matters - the full pass\'s bits (tests/test_gpu_mstep_tiles.py); mstep_passes says how many M-steps did what.  Not the headline: the '
+                                                     'synthetic experiment has converged by the timed iterations (the 6th to 25th of the run), so the incremental step has next to nothing '
+                                                     'left to do; `value` recomputes every sum in every iteration')
         if fine_only_region:
             out['without_coarse_pass'] = {k: v for k, v in fine_only_region.items() if k != 'elapsed'}
             out['without_coarse_pass']['note'] = ('the same timed region with dmx_set_coarse_pass(0): every E-step the fine pass on the float32 table (the default mode of round 4; '
