@@ -48,6 +48,8 @@ WORKLOADS = {
     'predict_60k_20k_8': (60_000, 20_000, 8, 0.35, 1247),    # in between: the longest rows on 64 lanes, the rest packed
     'em_20k_10k_64': (20_000, 10_000, 64, 0.0, 77),         # quick check
     'em_25k_100k_64': (25_000, 100_000, 64, 0.0, 1237),     # the size of one rank's share of configs[3] on 8 GPUs
+    'em_10k_100k_64': (10_000, 100_000, 64, 0.0, 1237),     # a single-sample experiment: the tile-major schedule's smallest sizes
+    'em_50k_100k_64': (50_000, 100_000, 64, 0.0, 1237),
     'em_200k_4k_64': (200_000, 4_000, 64, 0.0, 78),         # diagnostic: 2 MB genotype table (every row gather hits L2)
     'predict_20k_20k_32_doublets': (20_000, 20_000, 32, 0.25, 1240),   # K = 528: workgroup-per-barcode kernel
     'predict_20k_20k_64_doublets': (20_000, 20_000, 64, 0.25, 1243),   # K = 2080: doublets of 64 genotypes

@@ -202,7 +202,13 @@ hipError_t launch_sum_dense(hipStream_t st, unsigned long long *counters, unsign
 constexpr int TILE_R_MAX = 9;                // barcodes per bin at most (LDS: 4 waves x 9 x 64 doubles = 18 KB per block)
 constexpr long long TILE_BYTES = 1 << 20;    // genotype-table bytes per variant tile: a quarter of an XCD's 4 MB L2 (tolerance-mode E-step on
                                              // 200k x 100k x 64: 1.480 / 1.483 / 1.510 / 1.546 ms with tiles of 0.5 / 1 / 2 / 3 MB; DEMUXALOT_AMD_TILE_KB)
-constexpr long long TILE_MIN_BARCODES = 65536;   // below this there are too few bins to fill the chip
+#ifndef DMX_TILE_MIN_BARCODES
+#define DMX_TILE_MIN_BARCODES 8192
+#endif
+// below this there are fewer bins than wavefront slots.  (65 536 until the coarse pass: the FINE pass gains nothing from the schedule on smaller
+// problems - 25k barcodes 0.221 against 0.234 ms, 10k 0.134 against 0.115 -, the coarse pass, which only exists on it, does: E-step of 10k / 25k /
+// 50k barcodes x 100k SNPs x 64 genotypes 0.115 -> 0.091 / 0.234 -> 0.141 / 0.451 -> 0.251 ms; scripts/small_shard_variants.sh)
+constexpr long long TILE_MIN_BARCODES = DMX_TILE_MIN_BARCODES;
 constexpr long long TILE_MIN_TABLE_BYTES = 8 << 20;  // a table this small is L2 / L1 resident anyway
 
 struct MstepArgs {
