@@ -209,7 +209,12 @@ constexpr long long TILE_BYTES = 1 << 20;    // genotype-table bytes per variant
 // problems - 25k barcodes 0.221 against 0.234 ms, 10k 0.134 against 0.115 -, the coarse pass, which only exists on it, does: E-step of 10k / 25k /
 // 50k barcodes x 100k SNPs x 64 genotypes 0.115 -> 0.091 / 0.234 -> 0.141 / 0.451 -> 0.251 ms; scripts/small_shard_variants.sh)
 constexpr long long TILE_MIN_BARCODES = DMX_TILE_MIN_BARCODES;
-constexpr long long TILE_MIN_TABLE_BYTES = 8 << 20;  // a table this small is L2 / L1 resident anyway
+#ifndef DMX_TILE_MIN_TABLE_BYTES
+#define DMX_TILE_MIN_TABLE_BYTES (1 << 20)
+#endif
+// (8 MB until the coarse pass: a smaller table is L2-resident and the fine pass gains nothing from the schedule; the coarse pass, which only
+// exists on it, does - every row still misses the 32 KB L1: 20k barcodes x 10k SNPs x 64 genotypes, a 5 MB table: E-step 0.141 -> 0.107 ms)
+constexpr long long TILE_MIN_TABLE_BYTES = DMX_TILE_MIN_TABLE_BYTES;
 
 struct MstepArgs {
     const int *order;               // [n_items] items by decreasing length (work distribution)

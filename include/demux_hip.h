@@ -262,7 +262,7 @@ int dmx_get_guard_direct(dmx_ctx *ctx, int32_t *last_ran_direct, int64_t *direct
                          double *exact_pass_ms);
 
 /* E-step work distribution.  For singlet runs of 17..128 genotypes on at least 8 192 barcodes with a genotype table
- * of 8 MB or more, the problem upload also builds a tile-major schedule (bins of 8 barcodes with equal numbers of
+ * of 1 MB or more, the problem upload also builds a tile-major schedule (bins of 8 barcodes with equal numbers of
  * calls, walked variant tile by variant tile, so that the wavefronts of an XCD gather genotype rows from the same
  * ~2 MB of the table at any time: csrc/kernels.hip, k_estep_tiled).  tiled = 1 (default): used where it pays, i.e.
  * in the tolerance mode (DMX_ESTEP_FAST), whose time is the row gathers; the exact mode is bound by its arithmetic

@@ -2,7 +2,7 @@
 schedule: random genotype counts 17 .. 128 (odd ones included: one, two or four calls per gather), calls per barcode, P-step clips down to binary16's normal range,
 sibling donors, degenerate error probabilities.  Per problem: one EM iteration in the exact mode, then on the same table the exact
 E-step and the coarse pass forced for a single E-step (dmx_set_coarse_pass 2): every posterior within 1e-5, every arg-max identical,
-every logit within the bound the guard priced it with.  GPU box: python3 scripts/coarse_sweep.py [n_problems] [seed]"""
+every logit within the bound the guard priced it with.  GPU box: [SWEEP_SMALL=1] python3 scripts/coarse_sweep.py [n_problems] [seed]"""
 import os
 import sys
 import time
@@ -21,8 +21,12 @@ for trial in range(n_problems):
     cpb = int(rng.choice([24, 60, 150, 400]))
     clip = float(rng.choice([0.01, 0.01, 0.002, 1e-4]))
     siblings = bool(rng.random() < 0.3)
-    B = int(rng.integers(66_000, 90_000))
-    S = int(max(40_000, (9 << 20) // (8 * G) + 1000))       # genotype table of at least 8 MB
+    if os.environ.get('SWEEP_SMALL'):                       # the schedule's smallest sizes: 8 192 barcodes, a table of 1 MB
+        B = int(rng.integers(8_200, 40_000))
+        S = int(rng.integers((1 << 20) // (8 * G) + 50, (6 << 20) // (8 * G) + 100))
+    else:
+        B = int(rng.integers(66_000, 90_000))
+        S = int(max(40_000, (9 << 20) // (8 * G) + 1000))   # a genotype table of 9 MB and more
     p = synth.generate(B, S, G, calls_per_barcode=cpb, seed=int(rng.integers(1, 1 << 30)), sibling_pairs=siblings)
     e = p.p_base_wrong.copy()
     odd = rng.random(len(e)) < 0.002                         # degenerate error probabilities: 0, ~1, exactly 1

@@ -1,6 +1,6 @@
 """The coarse pass of the default (guarded) mode - k_estep_tiled_coarse, include/demux_hip.h: dmx_set_coarse_pass - inside the calls
 that take it: dmx_em / dmx_run_iterations on problems large enough for the tile-major schedule (>= 8 192 barcodes, a genotype
-table of >= 8 MB, 33 .. 64 genotypes, no doublets).  Same-table checks at the headline size: tests/test_gpu_configs.py."""
+table of >= 1 MB, 33 .. 64 genotypes, no doublets).  Same-table checks at the headline size: tests/test_gpu_configs.py."""
 import numpy as np
 import pytest
 
