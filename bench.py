@@ -348,6 +348,8 @@ def roofline(ab, e_ms, N, G, K, live, coarse_share=0.0):
         'traffic': live.get('traffic'),
         'traffic_source': 'rocprofv3 --pmc FETCH_SIZE + WRITE_SIZE per launch, child runs of this command (live)' if 'traffic' in live else None,
         'algorithmic_bytes_per_launch': ab['estep'], 'estep_ms': e_ms,
+        'estep_ms_source': 'HIP events on the library\'s stream around the E-step phase (dmx_set_phase_timers), average over the `steps` E-steps of the timed call '
+                           'made once more behind the timed window with the events on (ms_per_step_with_phase_timers); the timed window itself runs without them, as a default call does',
         'ops': {'terms_per_s': terms_per_s, 'peak': LOG_ISSUE_PEAK, 'frac': terms_per_s / LOG_ISSUE_PEAK,
                 'note': 'SURVEY.md 8d: N x K log terms per E-step against the v_log_f32 issue peak (19.7 T/s); the guarded / '
                         'tolerance mode takes one hardware log2 per 8 terms, the exact mode repeats numpy\'s float32 log (16 VALU '
@@ -471,7 +473,7 @@ def hard_workload(args, ctx, whole, betas, pen, dp):
             first_queued = ctx.guard_state()[2]
             if args.mstep == 'auto':
                 ctx.set_msteps_expected(args.warmup + args.steps)
-            region = timed_region(ctx, None, args.steps, args.warmup)
+            region = timed_region(ctx, None, args.steps, args.warmup, spin=lambda: ctx.estep(pen, with_doublets=dp > 0, fetch_logits=False, fetch_probs=False))
             _direct, direct_steps, would, fast_ms, exact_ms = ctx.guard_state()
             res[name] = {'ms_per_step': region['ms_per_step'], 'kernel_ms': region['kernel_ms'], 'guard': region['guard'], 'estep_passes': region['estep_passes'], 'mstep_passes': region['mstep_passes'],
                          'first_estep_queued_fraction': first_queued / problem.n_barcodes, 'esteps_run_direct': direct_steps, 'steps': args.steps,
@@ -496,15 +498,46 @@ def _lib_device_count():
     return _lib.device_count()
 
 
-def timed_region(ctx, plane, steps, warmup):
-    """W untimed iterations, then exactly K timed ones bracketed by barrier + device synchronisation on both sides;
-    the MAX over ranks of the wall time."""
+CLOCK_WARMUP_MS = 60.0
+
+
+def clock_warmup(ctx, spin, ms=CLOCK_WARMUP_MS):
+    """Device work for `ms` milliseconds that leaves the EM where it is (`spin` enqueues the E-step on the current table once more:
+    the same posteriors again).  The device lowers its clocks within 10 ms of idling and takes about 30 ms of work to raise them
+    again (scripts/phase_timer_cost.py: E-step 1.03 -> 0.90 ms, M-step 0.37 -> 0.33 ms over the first 30 ms after an idle): behind
+    the host-side pauses between this script's regions, W = 5 warm-up iterations (6 ms) end inside that ramp, and a timed region
+    of 23 ms would report the ramp instead of the rate the device sustains.  The figure after an idle is measured too
+    (`after_idle` of the line)."""
+    if spin is None or ms <= 0:
+        return 0
+    t0, n = time.perf_counter(), 0
+    while (time.perf_counter() - t0) * 1e3 < ms:
+        for _ in range(8):
+            spin()
+        ctx.synchronize()
+        n += 8
+    return n
+
+
+def timed_region(ctx, plane, steps, warmup, spin=None, idle_s=0.0):
+    """(`spin`: clock_warmup ahead of the warm-up iterations; `idle_s`: the device left idle that long ahead of them instead.)
+    W untimed iterations, then exactly K timed ones bracketed by barrier + device synchronisation on both sides;
+    the MAX over ranks of the wall time.  The timed call runs as a default call does, without the phase timers (an event record
+    is a barrier packet of its own: 6 us at each of the iteration's four phase boundaries); kernel_ms comes from the SAME call made
+    once more behind the timed window with the timers on, and its wall time is reported beside (ms_per_step_with_phase_timers)."""
     def barrier():
         if plane is not None:
             plane.barrier()
+    n_spin = 0
+    if idle_s > 0:
+        ctx.synchronize()
+        time.sleep(idle_s)
+    else:
+        n_spin = clock_warmup(ctx, spin)
     ctx.run_iterations(warmup, 0.01)
     ctx.synchronize()
     ctx.reset_timings()
+    ctx.set_phase_timers(False)
     barrier()
     ctx.synchronize()
     t0 = time.perf_counter()
@@ -514,11 +547,22 @@ def timed_region(ctx, plane, steps, warmup):
     elapsed = time.perf_counter() - t0
     if plane is not None:
         elapsed = plane.max_float64(elapsed)
+    stats = (ctx.guard_stats(), ctx.guard_levels(), ctx.mstep_incremental())
+    ctx.set_phase_timers(True)
+    ctx.reset_timings()
+    barrier()
+    ctx.synchronize()
+    t0 = time.perf_counter()
+    ctx.run_iterations(steps, 0.01)
+    ctx.synchronize()
+    barrier()
+    elapsed_timers = time.perf_counter() - t0
+    if plane is not None:
+        elapsed_timers = plane.max_float64(elapsed_timers)
     timers = ctx.timings()
-    _redone, redone_total, rows = ctx.guard_stats()
-    levels = ctx.guard_levels()
-    m_full, m_delta, m_changed = ctx.mstep_incremental()
-    return {'elapsed': elapsed,
+    ctx.set_phase_timers(False)
+    (_redone, redone_total, rows), levels, (m_full, m_delta, m_changed) = stats
+    return {'elapsed': elapsed, 'ms_per_step_with_phase_timers': 1e3 * elapsed_timers / steps, 'clock_warmup_esteps': n_spin,
             'mstep_passes': ({'incremental_mstep': True, 'full': m_full, 'delta': m_delta, 'of': steps, 'barcodes_changed_in_the_last_mstep': m_changed}
                              if m_full + m_delta > 0 else {'incremental_mstep': False, 'note': 'every M-step recomputes every sum'}), 'ms_per_step': 1e3 * elapsed / steps, 'em_iterations_per_s': steps / elapsed,
             'estep_passes': {'coarse': levels['coarse_steps'], 'of': steps, 'last': {0: 'coarse', 1: 'fine', 2: 'direct'}.get(levels['level'], 'not guarded'),
@@ -684,6 +728,9 @@ def main():
         ctx.set_mstep_incremental(args.incremental_mstep)
     ctx.apply_environment = apply_environment_for_the_bench
 
+    def estep_again():  # (clock_warmup: the E-step on the table as it stands - the EM does not move)
+        ctx.estep(pen, with_doublets=dp > 0, fetch_logits=False, fetch_probs=False)
+
     # ---- the timed regions: configs[3] as written first (strong: this rank's barcode range), then the workload per GPU ----
     kinds = ['strong', 'weak'] if args.scaling == 'both' else [args.scaling]
     if world == 1:
@@ -704,7 +751,7 @@ def main():
         if args.mstep == 'auto':
             ctx.set_msteps_expected(args.warmup + args.steps)
         phase(f'{kind}: warm-up + timed region (per-iteration collectives)')
-        region = timed_region(ctx, plane, args.steps, args.warmup)
+        region = timed_region(ctx, plane, args.steps, args.warmup, spin=estep_again)
         built, build_ms = ctx.mstep_tiles_info()
         region['mstep_records_build_ms'] = build_ms if built else 0.0
         region['device_bytes'] = ctx.device_bytes()
@@ -729,7 +776,7 @@ def main():
         ctx.estep(pen, with_doublets=dp > 0, fetch_logits=False, fetch_probs=False)
         probs_mode = ctx.get_block('probs', 0, len(probs0)) if (world == 1 and probs0 is not None) else None
         best_mode = ctx.get_assignments()[0] if probs_mode is not None else None
-        region = timed_region(ctx, plane, args.steps, args.warmup)
+        region = timed_region(ctx, plane, args.steps, args.warmup, spin=estep_again)
         region['value'] = regions[kinds[-1]]['barcodes_total'] * args.steps / region['elapsed']
         region['scaling'] = kinds[-1]
         if probs_mode is not None:
@@ -747,7 +794,7 @@ def main():
         ctx.set_addition(None)
         ctx.probs_from_betas(0.01, fetch=False)
         ctx.estep(pen, with_doublets=dp > 0, fetch_logits=False, fetch_probs=False)
-        work_item_region = timed_region(ctx, plane, args.steps, args.warmup)
+        work_item_region = timed_region(ctx, plane, args.steps, args.warmup, spin=estep_again)
         work_item_region['value'] = regions[kinds[-1]]['barcodes_total'] * args.steps / work_item_region['elapsed']
         work_item_region['scaling'] = kinds[-1]
         ctx.set_mstep_tiles('always' if args.mstep == 'tiles' else 'auto')
@@ -759,7 +806,7 @@ def main():
         ctx.set_addition(None)
         ctx.probs_from_betas(0.01, fetch=False)
         ctx.estep(pen, with_doublets=dp > 0, fetch_logits=False, fetch_probs=False)
-        incr_mstep_region = timed_region(ctx, plane, args.steps, args.warmup)
+        incr_mstep_region = timed_region(ctx, plane, args.steps, args.warmup, spin=estep_again)
         incr_mstep_region['value'] = regions[kinds[-1]]['barcodes_total'] * args.steps / incr_mstep_region['elapsed']
         incr_mstep_region['scaling'] = kinds[-1]
         ctx.set_mstep_incremental(False)
@@ -771,10 +818,19 @@ def main():
         ctx.set_addition(None)
         ctx.probs_from_betas(0.01, fetch=False)
         ctx.estep(pen, with_doublets=dp > 0, fetch_logits=False, fetch_probs=False)
-        fine_only_region = timed_region(ctx, plane, args.steps, args.warmup)
+        fine_only_region = timed_region(ctx, plane, args.steps, args.warmup, spin=estep_again)
         fine_only_region['value'] = regions[kinds[-1]]['barcodes_total'] * args.steps / fine_only_region['elapsed']
         fine_only_region['scaling'] = kinds[-1]
         ctx.set_coarse_pass(True)
+
+    after_idle_region = None
+    if world == 1 and not args.timed_only:
+        phase('default mode on a device that has idled: timed region')
+        ctx.set_addition(None)
+        ctx.probs_from_betas(0.01, fetch=False)
+        ctx.estep(pen, with_doublets=dp > 0, fetch_logits=False, fetch_probs=False)
+        after_idle_region = timed_region(ctx, plane, args.steps, args.warmup, idle_s=0.5)
+        after_idle_region['value'] = regions[kinds[-1]]['barcodes_total'] * args.steps / after_idle_region['elapsed']
 
     # predict_posteriors throughput on the same resident problem (P + E only, no beta addition: demux.py:120-156),
     # rank-local.  The genotype table is then the importers' (a handful of distinct values per row), which is the
@@ -789,6 +845,7 @@ def main():
             ctx.probs_from_betas(0.01, fetch=False)
             ctx.estep(pen, with_doublets=dp > 0, fetch_logits=False, fetch_probs=False)  # untimed first pass
             ctx.synchronize()
+            ctx.set_phase_timers(True)
             ctx.reset_timings()
             t1 = time.perf_counter()
             for _ in range(n_pred):
@@ -797,6 +854,7 @@ def main():
             ctx.synchronize()
             seconds = (time.perf_counter() - t1) / n_pred
             t_pred = ctx.timings()
+            ctx.set_phase_timers(False)
             form, distinct = ctx.estep_form()
             pe_ms = t_pred['estep']['ms'] / max(1, t_pred['estep']['launches'])
             predict['dictionary_form' if mode == 'auto' else 'direct_form'] = dict(
@@ -850,6 +908,9 @@ def main():
             'mstep_records_build_ms': head['mstep_records_build_ms'],
             'ms_per_step_incl_record_build': head['ms_per_step'] + head['mstep_records_build_ms'] / max(1, args.warmup + args.steps),
             'kernel_ms': head['kernel_ms'],
+            'ms_per_step_with_phase_timers': head['ms_per_step_with_phase_timers'],
+            'kernel_ms_note': 'per phase, HIP events on the library\'s stream (dmx_set_phase_timers): the timed call made once more behind the timed window with the events on - an event '
+                              'record is a barrier packet of its own, 6 us at each of the four phase boundaries, which a default call does not pay and `value` does not contain',
             'exchange_ms_per_step': head['exchange_ms_per_step'],
             'guard': head['guard'],
             'estep_passes': head['estep_passes'],
@@ -874,6 +935,11 @@ def main():
                                                      'matters - the full pass\'s bits (tests/test_gpu_mstep_tiles.py); mstep_passes says how many M-steps did what.  Not the headline: the '
                                                      'synthetic experiment has converged by the timed iterations (the 6th to 25th of the run), so the incremental step has next to nothing '
                                                      'left to do; `value` recomputes every sum in every iteration')
+        out['clock_warmup'] = {'ms': CLOCK_WARMUP_MS, 'esteps_ahead_of_the_headline_region': head['clock_warmup_esteps'], 'note': clock_warmup.__doc__.split('\n\n')[0].replace('\n    ', ' ')}
+        if after_idle_region:
+            out['after_idle'] = {k: after_idle_region[k] for k in ('value', 'ms_per_step', 'em_iterations_per_s', 'ms_per_step_with_phase_timers', 'kernel_ms')}
+            out['after_idle']['note'] = ('the same timed region - W warm-up iterations, K timed ones - begun 0.5 s after the device was last busy, without the clock warm-up: what the first '
+                                         'short call on an idle device sees (the clocks come up over its first 30 ms)')
         if fine_only_region:
             out['without_coarse_pass'] = {k: v for k, v in fine_only_region.items() if k != 'elapsed'}
             out['without_coarse_pass']['note'] = ('the same timed region with dmx_set_coarse_pass(0): every E-step the fine pass on the float32 table (the default mode of round 4; '

@@ -388,38 +388,65 @@ int bind(dmx_ctx *c)
 {
     if (!c) return fail(DMX_ERR_INVALID, "null ctx");
     HIP_TRY(hipSetDevice(c->device));
+    c->boundary = nullptr;  // whatever this call enqueues first sits behind the last phase's stamp
     return 0;
 }
 
-void timer_begin(dmx_ctx *c, int slot, std::pair<hipEvent_t, hipEvent_t> *ev)
+TimerStamp *stamp_now(dmx_ctx *c)
 {
-    TimerSlot &t = c->timers[slot];
-    if (!t.free_list.empty()) {
-        *ev = t.free_list.back();
-        t.free_list.pop_back();
+    TimerStamp *s;
+    if (!c->idle_stamps.empty()) {
+        s = c->idle_stamps.back();
+        c->idle_stamps.pop_back();
     } else {
-        (void)hipEventCreate(&ev->first);
-        (void)hipEventCreate(&ev->second);
+        s = new TimerStamp;
+        (void)hipEventCreateWithFlags(&s->ev, hipEventReleaseToDevice);
     }
-    (void)hipEventRecord(ev->first, c->stream);
+    s->refs = 0;
+    (void)hipEventRecord(s->ev, c->stream);
+    return s;
+}
+
+void stamp_release(dmx_ctx *c, TimerStamp *s)
+{
+    if (--s->refs > 0) return;
+    if (c->boundary == s) c->boundary = nullptr;
+    c->idle_stamps.push_back(s);
+}
+
+void timer_begin(dmx_ctx *c, int slot, TimerSpan *ev)
+{
+    (void)slot;
+    ev->first = ev->second = nullptr;
+    if (!c->phase_timers) return;
+    ev->first = c->boundary ? c->boundary : stamp_now(c);  // the phase before this one ended here: one barrier packet, not two
+    ev->first->refs++;
+    c->boundary = nullptr;
 }
 
 void timer_flush(dmx_ctx *c, int slot)
 {
     TimerSlot &t = c->timers[slot];
     for (auto &ev : t.pending) {
-        (void)hipEventSynchronize(ev.second);
+        (void)hipEventSynchronize(ev.second->ev);
         float ms = 0.f;
-        if (hipEventElapsedTime(&ms, ev.first, ev.second) == hipSuccess) t.ms += ms;
-        t.free_list.push_back(ev);
+        if (hipEventElapsedTime(&ms, ev.first->ev, ev.second->ev) == hipSuccess) t.ms += ms;
+        stamp_release(c, ev.first);
+        stamp_release(c, ev.second);
     }
     t.pending.clear();
 }
 
-void timer_end(dmx_ctx *c, int slot, const std::pair<hipEvent_t, hipEvent_t> &ev)
+void timer_end(dmx_ctx *c, int slot, TimerSpan ev)
 {
     TimerSlot &t = c->timers[slot];
-    (void)hipEventRecord(ev.second, c->stream);
+    if (ev.first == nullptr) {  // (the timers were off when the phase began)
+        t.launches++;
+        return;
+    }
+    ev.second = stamp_now(c);
+    ev.second->refs++;
+    c->boundary = ev.second;
     t.pending.push_back(ev);
     t.launches++;
     if (t.pending.size() >= 4096) timer_flush(c, slot);
@@ -1097,7 +1124,7 @@ int run_pstep(dmx_ctx *c, float lo, float hi, bool with_addition, bool with_half
     with_half = with_half && !c->sliced;
     if (with_half) DMX_TRY(ensure_prob16(c));
     c->prob16_valid = false;
-    std::pair<hipEvent_t, hipEvent_t> ev;
+    TimerSpan ev;
     timer_begin(c, DMX_T_PSTEP, &ev);
     const long long v0 = c->sliced ? c->cut[c->rank] : 0, v1 = c->sliced ? c->cut[c->rank + 1] : c->V;
     if (c->emulated && c->sliced && !c->emu_table_filled) {
@@ -1271,7 +1298,7 @@ int run_estep(dmx_ctx *c, int with_doublets, bool with_prior, int prior_dtype, f
     a.dtab_pitch = 0;
     a.dict = nullptr;
     a.codes = nullptr;
-    std::pair<hipEvent_t, hipEvent_t> ev;
+    TimerSpan ev;
     timer_begin(c, DMX_T_ESTEP, &ev);
     int form = DMX_FORM_DIRECT;
     DMX_TRY(prepare_dictionary(c, with_doublets != 0, a, &form));  // part of the E-step's time
@@ -1386,7 +1413,7 @@ int gather_posteriors(dmx_ctx *c)
     if (!c->mshard || c->post_gathered) return 0;
     const int G = c->G, W = (G + 63) / 64;
     const size_t rows = (size_t)c->rows_pad;
-    std::pair<hipEvent_t, hipEvent_t> ev;
+    TimerSpan ev;
     timer_begin(c, DMX_T_ALLREDUCE, &ev);
     int rc = 0;
     if (c->emulated && !c->emu_post_filled) {
@@ -1445,7 +1472,7 @@ int run_mstep(dmx_ctx *c, float power)
     }
     DMX_TRY(gather_posteriors(c));
     c->add_is_zero = false;
-    std::pair<hipEvent_t, hipEvent_t> ev;
+    TimerSpan ev;
     const bool dist = c->attached();  // also with one rank: keeps the collective path testable on one GPU
     unsigned long long *redo = c->exact_additions ? c->d_redo : nullptr;
     a.item_variant = nullptr;
@@ -1665,15 +1692,11 @@ int dmx_destroy(dmx_ctx *c)
     dmx::release_staged_calls(c);
     (void)hipDeviceSynchronize();  // the exchange stream too
     ctx_retire(c);
-    for (auto &t : c->timers) {
-        for (auto &ev : t.pending) {
-            (void)hipEventDestroy(ev.first);
-            (void)hipEventDestroy(ev.second);
-        }
-        for (auto &ev : t.free_list) {
-            (void)hipEventDestroy(ev.first);
-            (void)hipEventDestroy(ev.second);
-        }
+    c->boundary = nullptr;
+    for (int slot = 0; slot < DMX_T_COUNT; slot++) timer_flush(c, slot);
+    for (TimerStamp *s : c->idle_stamps) {
+        (void)hipEventDestroy(s->ev);
+        delete s;
     }
     (void)hipStreamDestroy(c->stream);
     delete c;
@@ -1998,6 +2021,38 @@ int dmx_get_guard_levels(dmx_ctx *c, int32_t *level_last, int64_t *coarse_steps,
     if (coarse_pass_ms) *coarse_pass_ms = st[dmx::GS_C_TICKS] * ms_per_tick;
     if (fine_pass_ms) *fine_pass_ms = st[dmx::GS_F_TICKS] * ms_per_tick;
     if (exact_pass_ms) *exact_pass_ms = (st[dmx::GS_E_MEASURED] ? 1.0 : -1.0) * st[dmx::GS_E_TICKS] * ms_per_tick;
+    return 0;
+}
+
+int dmx_get_guard_probes(dmx_ctx *c, int64_t *probes, int64_t *streak)
+{
+    DMX_TRY(bind(c));
+    unsigned st[dmx::GS_WORDS];
+    long long count = 0, fine = 0, coarse = 0;
+    DMX_TRY(read_guard_state(c, st, &count, &fine, &coarse));
+    if (probes) *probes = (int64_t)st[dmx::GS_PROBES];
+    if (streak) *streak = (int64_t)st[dmx::GS_STREAK];
+    return 0;
+}
+
+int dmx_debug_set_pass_ms(dmx_ctx *c, double coarse_pass_ms, double fine_pass_ms, double exact_pass_ms)
+{
+    DMX_TRY(bind(c));
+    if (!c->d_guard_count) return fail(DMX_ERR_INVALID, "call order: a guarded E-step before dmx_debug_set_pass_ms");
+    int khz = 0;
+    HIP_TRY(hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, c->device));
+    const double ms[3] = {coarse_pass_ms, fine_pass_ms, exact_pass_ms};
+    const int word[3] = {dmx::GS_C_TICKS, dmx::GS_F_TICKS, dmx::GS_E_TICKS};
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    for (int i = 0; i < 3; i++) {
+        if (ms[i] < 0.0) continue;
+        const unsigned ticks = (unsigned)std::min(ms[i] * (double)khz, 1.0e9);
+        HIP_TRY(hipMemcpy(c->d_guard_count + word[i], &ticks, sizeof(unsigned), hipMemcpyHostToDevice));
+        if (i == 2) {
+            const unsigned measured = ticks != 0u;
+            HIP_TRY(hipMemcpy(c->d_guard_count + dmx::GS_E_MEASURED, &measured, sizeof(unsigned), hipMemcpyHostToDevice));
+        }
+    }
     return 0;
 }
 
@@ -2517,6 +2572,14 @@ int dmx_get_exchange_mode(dmx_ctx *c, int32_t *mode)
     return 0;
 }
 
+int dmx_set_phase_timers(dmx_ctx *c, int on)
+{
+    if (!c) return fail(DMX_ERR_INVALID, "null ctx");
+    c->phase_timers = on != 0;
+    c->boundary = nullptr;
+    return 0;
+}
+
 int dmx_get_timings(dmx_ctx *c, double *ms, int64_t *launches)
 {
     DMX_TRY(bind(c));
@@ -2535,7 +2598,7 @@ int dmx_reset_timings(dmx_ctx *c)
     HIP_TRY(hipStreamSynchronize(c->stream));
     // the totals; the last E-step's own numbers stay (they decide how the next one runs: kernels.hip k_guard_begin)
     if (c->d_guard_count) HIP_TRY(hipMemsetAsync(c->d_guard_count + dmx::GS_PENDING, 0, 4 * sizeof(unsigned), c->stream));  // GS_PENDING, GS_DIRECT_STEPS, GS_TOTAL
-    if (c->d_guard_count) HIP_TRY(hipMemsetAsync(c->d_guard_count + dmx::GS_COARSE_STEPS, 0, sizeof(unsigned), c->stream));
+    if (c->d_guard_count) HIP_TRY(hipMemsetAsync(c->d_guard_count + dmx::GS_COARSE_STEPS, 0, 2 * sizeof(unsigned), c->stream));  // + GS_PROBES
     if (c->d_incr_state) HIP_TRY(hipMemsetAsync(c->d_incr_state + 2 * dmx::IS_WORDS, 0, sizeof(unsigned) * dmx::IS_WORDS, c->stream));
     c->guard_rows_total = 0;
     for (int s = 0; s < DMX_T_COUNT; s++) {

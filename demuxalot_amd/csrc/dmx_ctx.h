@@ -31,9 +31,19 @@ using dmx::fail;
 // ------------------------------------------------------------------------------------
 // context
 // ------------------------------------------------------------------------------------
+// Phase timers (dmx_get_timings).  A stamp is one recorded event; a span is two of them.  Two phases that follow each other
+// inside one API call share the stamp between them: an event record is a barrier packet of its own on the queue, and two of them
+// back to back at each of an EM iteration's four phase boundaries were 10 us each - 40 us of a 1.14 ms iteration (round 5,
+// scripts/iteration_timeline.sh).  Events release to the device only (hipEventReleaseToDevice): nothing on the host reads what the
+// kernels wrote at a phase boundary.
+struct TimerStamp {
+    hipEvent_t ev = nullptr;
+    int refs = 0;
+};
+typedef std::pair<TimerStamp *, TimerStamp *> TimerSpan;
+
 struct TimerSlot {
-    std::vector<std::pair<hipEvent_t, hipEvent_t>> pending;
-    std::vector<std::pair<hipEvent_t, hipEvent_t>> free_list;
+    std::vector<TimerSpan> pending;
     double ms = 0.0;
     int64_t launches = 0;
 };
@@ -232,6 +242,9 @@ struct dmx_ctx {
     long long n_staged = -1;
     int64_t bytes = 0;
     TimerSlot timers[DMX_T_COUNT];
+    bool phase_timers = false;  // dmx_set_phase_timers: events around the phases (off: the launch counts only)
+    std::vector<TimerStamp *> idle_stamps;
+    TimerStamp *boundary = nullptr;  // the stamp the last phase ended on, while nothing else has been enqueued behind it (bind() clears it)
 
     // Device blocks this context has released, kept for its next allocations (ctx_malloc / ctx_free below).
     std::multimap<size_t, void *> idle_blocks;          // capacity -> block

@@ -167,7 +167,16 @@ enum { GS_COUNT = 0,         // barcodes queued by the current E-step (a direct 
        GS_COUNT_COARSE = 21,
        GS_CAPABLE = 22,      // the current E-step evaluates the coarse guard too (the problem has a coarse pass)
        GS_COARSE_STEPS = 23, // E-steps that took the coarse pass since the last reset
-       GS_WORDS = 24 };
+       GS_PROBES = 24,       // E-steps that ran another level than the cheapest one to have it timed again, since the last reset
+       GS_STREAK = 25,       // E-steps in a row on the current level without such a re-probe (k_guard_begin: GUARD_PROBE_STREAK)
+       GS_WORDS = 26 };
+// A pass is timed only when it runs.  A time taken once under other conditions - the first E-step of a call on a device that had idled
+// runs at a fraction of its clocks - would stand for as long as the pass is not chosen, and it is not chosen because of that time: a
+// 250-iteration call begun 0.5 s after the last one took the fine pass throughout, 1.88 instead of 1.10 ms per iteration (round 5,
+// scripts/phase_timer_cost.py).  After GUARD_PROBE_STREAK E-steps in a row on one level the cheapest OTHER admissible level runs once if
+// its standing price is below twice the running level's: at most 1.6 % of E-step time, nothing where the levels are further apart
+// (coarse against fine at 200k x 100k x 64: 0.69 against 1.47 ms).
+constexpr unsigned GUARD_PROBE_STREAK = 64;
 constexpr unsigned GS_UNKNOWN = 0xFFFFFFFFu;
 // The coarse pass (kernels.hip: k_estep_tiled_coarse) reads the genotype table as binary16, rounded to nearest: p' = p (1 + d), |d| <= 2^-11
 // for every p >= 2^-14 (normal range; run_estep checks the clip), and forms a term as keep (p' + r), r = fl(floor / keep) with the slot tag in

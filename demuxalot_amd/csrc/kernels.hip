@@ -1780,7 +1780,7 @@ __global__ __launch_bounds__(GUARD_SLOTS) void k_guard_begin(unsigned *st, unsig
     }
     const bool same = st[GS_VALID] && rows == B && st[GS_K] == K;
     if (!same) st[GS_F_TICKS] = st[GS_C_TICKS] = st[GS_E_TICKS] = st[GS_E_MEASURED] = st[GS_O_TICKS] = 0u;
-    unsigned level = allow_coarse ? 0u : 1u;
+    unsigned level = allow_coarse ? 0u : 1u, streak = 0u;
     if (same) {
         // durations of the finished E-step's passes (32-bit wall clock differences: modular, intervals far below the wrap)
         const unsigned d_fast = st[GS_T_REDO] - st[GS_T_FAST], d_redo = st[GS_T_END] - st[GS_T_REDO];
@@ -1820,6 +1820,22 @@ __global__ __launch_bounds__(GUARD_SLOTS) void k_guard_begin(unsigned *st, unsig
             if (was <= 2u) cost[was] *= 0.97;  // (the level that ran stays unless another one is 3 % cheaper)
             level = cost[0] <= cost[1] ? 0u : 1u;
             if (cost[2] < cost[level]) level = 2u;
+            // times of the passes that do not run go stale (kernels.h: GUARD_PROBE_STREAK)
+            streak = level == was ? st[GS_STREAK] + 1u : 0u;
+            if (streak >= GUARD_PROBE_STREAK) {
+                unsigned other = 3u;
+                double best = 2.0 * cost[level];
+                for (unsigned l = 0; l < 3u; l++)
+                    if (l != level && cost[l] < best) {
+                        best = cost[l];
+                        other = l;
+                    }
+                if (other < 3u) {
+                    level = other;
+                    st[GS_PROBES] += 1u;
+                }
+                streak = 0u;
+            }
         }
     } else {
         st[GS_COUNT_FINE] = st[GS_COUNT_COARSE] = GS_UNKNOWN;
@@ -1830,6 +1846,7 @@ __global__ __launch_bounds__(GUARD_SLOTS) void k_guard_begin(unsigned *st, unsig
     st[GS_SKIP_FINE] = level != 1u;
     st[GS_DIRECT_STEPS] += level == 2u;
     st[GS_COARSE_STEPS] += level == 0u;
+    st[GS_STREAK] = streak;
     st[GS_CAPABLE] = capable != 0;
     st[GS_COUNT] = 0u;
     st[GS_ROWS] = B;

@@ -50,6 +50,7 @@ class DeviceContext:
         self.set_estep_packing(os.environ.get('DEMUXALOT_AMD_ESTEP_PACKED', 'auto'))
         self.set_coarse_pass(True)
         self.set_mstep_incremental(True)
+        self.set_phase_timers(False)
 
     def __enter__(self):
         return self
@@ -463,6 +464,17 @@ class DeviceContext:
         return {'level': level.value, 'coarse_steps': steps.value, 'flagged_fine': fine.value, 'flagged_coarse': coarse.value,
                 'coarse_pass_ms': c_ms.value, 'fine_pass_ms': f_ms.value, 'exact_pass_ms': e_ms.value}
 
+    def guard_probes(self):
+        """(E-steps that ran another level than the cheapest to have it timed again since reset_timings, E-steps in a row on the
+        current level); include/demux_hip.h: dmx_get_guard_probes."""
+        probes, streak = ctypes.c_int64(), ctypes.c_int64()
+        check(self._lib.dmx_get_guard_probes(self._h, ctypes.byref(probes), ctypes.byref(streak)))
+        return probes.value, streak.value
+
+    def debug_set_pass_ms(self, coarse=-1.0, fine=-1.0, exact=-1.0):
+        """Testing aid: overwrite the device's own times of the passes (include/demux_hip.h: dmx_debug_set_pass_ms)."""
+        check(self._lib.dmx_debug_set_pass_ms(self._h, float(coarse), float(fine), float(exact)))
+
     def guard_direct(self):
         """(the last guarded E-step ran direct, E-steps run direct since reset_timings, barcodes the last one queued or -
         direct - would have queued); include/demux_hip.h: dmx_get_guard_direct."""
@@ -539,7 +551,13 @@ class DeviceContext:
         check(self._lib.dmx_set_exact_additions(self._h, int(bool(exact))))
 
     # ---- instrumentation ----------------------------------------------------------------
+    def set_phase_timers(self, on):
+        """HIP events around the phases of the calls that follow, read by timings() (default off - an event record is a barrier
+        packet of its own, 6 us per phase boundary; the launch counts are kept either way: include/demux_hip.h dmx_set_phase_timers)."""
+        check(self._lib.dmx_set_phase_timers(self._h, int(bool(on))))
+
     def timings(self):
+        """{phase: {ms, launches}} since reset_timings(); ms only of the phases that ran with set_phase_timers(True)."""
         ms = (ctypes.c_double * _lib.T_COUNT)()
         n = (ctypes.c_int64 * _lib.T_COUNT)()
         check(self._lib.dmx_get_timings(self._h, ms, n))

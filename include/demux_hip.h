@@ -258,6 +258,14 @@ int dmx_set_mstep_incremental(dmx_ctx *ctx, int incremental);
 int dmx_get_mstep_incremental(dmx_ctx *ctx, int64_t *full_passes, int64_t *delta_passes, int64_t *barcodes_changed_last);
 int dmx_get_guard_levels(dmx_ctx *ctx, int32_t *level_last, int64_t *coarse_steps, int64_t *flagged_fine_last, int64_t *flagged_coarse_last,
                          double *coarse_pass_ms, double *fine_pass_ms, double *exact_pass_ms);
+/* The device times a pass only when it runs, so the time of a pass that is not chosen goes stale - and a pass timed once under other
+ * conditions (the first E-step on a device that had idled runs at a fraction of its clocks) would not be chosen again because of that
+ * time.  After 64 E-steps in a row on one level the cheapest other admissible level runs once, if its standing price is below twice the
+ * running one's (csrc/kernels.h: GUARD_PROBE_STREAK).  dmx_get_guard_probes: such E-steps since dmx_reset_timings, the current streak.
+ * dmx_debug_set_pass_ms (testing aid): overwrite the device's times of the coarse / fine / exact pass (ms over all barcodes; negative:
+ * leave; exact 0: back to "not measured"). */
+int dmx_get_guard_probes(dmx_ctx *ctx, int64_t *probes, int64_t *streak);
+int dmx_debug_set_pass_ms(dmx_ctx *ctx, double coarse_pass_ms, double fine_pass_ms, double exact_pass_ms);
 int dmx_get_guard_direct(dmx_ctx *ctx, int32_t *last_ran_direct, int64_t *direct_steps, int64_t *would_queue_last, double *fast_pass_ms,
                          double *exact_pass_ms);
 
@@ -497,7 +505,12 @@ int dmx_comm_init_host(dmx_ctx *ctx, int rank, int nranks, dmx_host_collective c
 int dmx_comm_init_emulated(dmx_ctx *ctx, int rank, int nranks, double link_gbytes_per_s, double latency_us, int reduce_dtype);
 
 /* Accumulated kernel time per slot (ms, from HIP events on the ctx stream) and launch
- * counts since the last dmx_reset_timings. Arrays of DMX_T_COUNT entries. */
+ * counts since the last dmx_reset_timings. Arrays of DMX_T_COUNT entries.
+ * The events are recorded only while the phase timers are on (dmx_set_phase_timers(ctx, 1); default off, the launch counts are
+ * kept either way): an event record is a barrier packet of its own on the queue, 6 us at each of an EM iteration's four phase
+ * boundaries - 2 % of a 1.14 ms iteration that nobody reading no timings should pay (two per boundary, as shipped until round 5:
+ * 40 us; consecutive phases share the event between them now). */
+int dmx_set_phase_timers(dmx_ctx *ctx, int on);
 int dmx_get_timings(dmx_ctx *ctx, double *ms, int64_t *launches);
 int dmx_reset_timings(dmx_ctx *ctx);
 

@@ -20,7 +20,7 @@ for B in (25_000, 50_000, 100_000):
         ctx.estep(pen, with_doublets=False, fetch_logits=False, fetch_probs=False)
         hist = []
         for it in range(8):
-            ctx.reset_timings()
+            ctx.set_phase_timers(True); ctx.reset_timings()
             ctx.run_iterations(1, 0.01)
             ctx.synchronize()
             t = ctx.timings()

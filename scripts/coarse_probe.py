@@ -43,7 +43,7 @@ def run(mode, coarse):
     ctx.set_msteps_expected(iters + 12)
     ctx.run_iterations(iters, 0.01)
     ctx.synchronize()
-    ctx.reset_timings()
+    ctx.set_phase_timers(True); ctx.reset_timings()
     ctx.run_iterations(10, 0.01)
     ctx.synchronize()
     t = ctx.timings()

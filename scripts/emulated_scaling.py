@@ -30,7 +30,7 @@ from demuxalot_amd.distributed import partition_barcodes  # noqa: E402
 def region(ctx, steps, warmup):
     ctx.run_iterations(warmup, 0.01)
     ctx.synchronize()
-    ctx.reset_timings()
+    ctx.set_phase_timers(True); ctx.reset_timings()
     t0 = time.perf_counter()
     ctx.run_iterations(steps, 0.01)
     ctx.synchronize()

@@ -37,7 +37,7 @@ def run(name, install, G, dp, n_calls_per_variant):
             ctx.set_exact_additions(mode == 'exact')
             ctx.set_mstep_tiles(tiles)
             install(ctx)
-            ctx.reset_timings()
+            ctx.set_phase_timers(True); ctx.reset_timings()
             results[(mode, tiles)] = (staged(ctx, pen, dp > 0), ctx.guard_stats())
         finally:
             ctx.close()

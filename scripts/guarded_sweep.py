@@ -47,7 +47,7 @@ for trial in range(first, first + n_trials):
             le, pe = ctx.estep(pen, with_doublets=doublets)
             addition = ctx.mstep(2.)
             ctx.set_estep_mode('guarded')
-            ctx.reset_timings()
+            ctx.set_phase_timers(True); ctx.reset_timings()
             lg, pg = ctx.estep(pen, with_doublets=doublets)
             redone, _t, n_rows = ctx.guard_stats()
             lg2, pg2 = ctx.estep(pen, with_doublets=doublets)

@@ -13,7 +13,7 @@ for mode in (True, 'bootstrap'):
     out = []
     for it in range(3):
         ctx.probs_from_betas(0.01, fetch=False); ctx.estep(pen, with_doublets=False, fetch_logits=False, fetch_probs=False)
-        ctx.synchronize(); ctx.reset_timings(); a = ctx.mstep(2.); t = ctx.timings()
+        ctx.synchronize(); ctx.set_phase_timers(True); ctx.reset_timings(); a = ctx.mstep(2.); t = ctx.timings()
         out.append((a, t['mstep']['ms'], ctx.mstep_incremental()))
     res[mode] = out; ctx.close()
 for it in range(3):

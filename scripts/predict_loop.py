@@ -22,7 +22,7 @@ ctx.set_addition(None)
 ctx.probs_from_betas(0.01, fetch=False)
 ctx.estep(pen, with_doublets=dp > 0, fetch_logits=False, fetch_probs=False)
 ctx.synchronize()
-ctx.reset_timings()
+ctx.set_phase_timers(True); ctx.reset_timings()
 t0 = time.perf_counter()
 for _ in range(passes):
     ctx.probs_from_betas(0.01, fetch=False)

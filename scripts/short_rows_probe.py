@@ -22,7 +22,7 @@ for cpb in (25, 50, 100, 200, 400):
         ctx.set_estep_mode(mode)
         ctx.set_estep_schedule(schedule)
         ctx.estep(pen, with_doublets=False, fetch_logits=False, fetch_probs=False)
-        ctx.reset_timings()
+        ctx.set_phase_timers(True); ctx.reset_timings()
         for _ in range(10):
             ctx.estep(pen, with_doublets=False, fetch_logits=False, fetch_probs=False)
         t = ctx.timings()['estep']

@@ -14,7 +14,7 @@ for G, dp in [(4, 0.), (8, 0.), (8, .35), (16, 0.), (16, .3), (24, 0.), (32, 0.)
     pen = Demultiplexer._doublet_penalties(G, dp)
     ctx.set_addition(None); ctx.probs_from_betas(0.01, fetch=False)
     ctx.estep(pen, with_doublets=dp > 0, fetch_logits=False, fetch_probs=False)
-    ctx.run_iterations(2, 0.01); ctx.synchronize(); ctx.reset_timings()
+    ctx.run_iterations(2, 0.01); ctx.synchronize(); ctx.set_phase_timers(True); ctx.reset_timings()
     ctx.run_iterations(5, 0.01); ctx.synchronize()
     t = ctx.timings()
     e = t['estep']['ms'] / t['estep']['launches']; m = t['mstep']['ms'] / t['mstep']['launches']

@@ -185,3 +185,41 @@ def test_coarse_pass_shapes_on_one_table(G):
     worst = float((np.abs(logits_c.astype(np.float64) - logits_e) / bound).max())
     assert worst <= 1.0, worst
     print(f'G={G}: {redone} of {p.n_barcodes} barcodes redone, posteriors within {dev:.3g}, logits at most {worst:.3f} of their bound')
+
+
+def test_a_stale_time_of_a_pass_that_does_not_run_is_taken_again(separable):
+    """The device times a pass only when it runs.  A coarse pass timed once at 10 ms (planted here; in the field: the first E-step on
+    a device that had idled) loses against the fine pass - and would lose for ever, since it never runs again to be timed.  After 64
+    E-steps in a row on the fine pass the coarse pass runs once (its standing price is below twice the fine pass's only if it is
+    planted there: 1.8 x), is timed, and takes over; the posteriors stay those of a run that never left the coarse pass, within the
+    contract of either pass."""
+    from demuxalot_amd.device import DeviceContext
+    p = separable
+    pen = np.zeros(p.n_genotypes, dtype=np.float32)
+    ctx = DeviceContext(0)
+    try:
+        ctx.set_estep_mode('guarded')
+        ctx.set_exact_additions(False)
+        _install(ctx, p)
+        ctx.em(6, 0.01, pen, with_doublets=False, fetch_logits=False, fetch_probs=False, fetch_addition=False)
+        ctx.reset_timings()
+        ctx.run_iterations(10, 0.01)
+        lv = ctx.guard_levels()   # (an E-step's own time is folded in when the next one begins: the fine pass's is that of dmx_em's last)
+        assert lv['coarse_steps'] == 9 and ctx.guard_probes()[0] == 0, lv
+        assert lv['coarse_pass_ms'] > 0 and lv['fine_pass_ms'] > lv['coarse_pass_ms'], lv
+        ctx.debug_set_pass_ms(coarse=1.8 * lv['fine_pass_ms'])   # stale and wrong
+        ctx.reset_timings()
+        ctx.run_iterations(60, 0.01)
+        assert ctx.guard_levels()['coarse_steps'] == 0 and ctx.guard_probes()[0] == 0, (ctx.guard_levels(), ctx.guard_probes())
+        ctx.run_iterations(40, 0.01)     # the 64th E-step on the fine pass falls into this call
+        lv2, (probes, _streak) = ctx.guard_levels(), ctx.guard_probes()
+        assert probes == 1, (lv2, probes)
+        assert lv2['coarse_steps'] >= 30, lv2            # the probe and every admissible E-step behind it
+        assert lv2['coarse_pass_ms'] < lv2['fine_pass_ms'], lv2
+        # a time too far off to be worth an E-step (beyond twice the running level's price) stays: no probe
+        ctx.debug_set_pass_ms(coarse=5.0 * lv['fine_pass_ms'])
+        ctx.reset_timings()
+        ctx.run_iterations(150, 0.01)
+        assert ctx.guard_probes()[0] == 0 and ctx.guard_levels()['coarse_steps'] == 0
+    finally:
+        ctx.close()
