@@ -721,11 +721,16 @@ def main():
     # (same bits) - is timed right behind them and reported as `with_incremental_mstep`, not as `value`: on this synthetic experiment the EM
     # has converged by the timed iterations, so that an incremental step has next to nothing left to do.
     ctx.set_mstep_incremental(args.incremental_mstep)
+    # The timed call is what learn_genotypes makes: it returns the last iteration's posteriors, no logits (demux.py:65-66), and says so
+    # (dmx_set_logits_needed(0)) - the last E-step of the call is then one whose logits nobody reads, like the 19 before it.  The same region
+    # with the last E-step's logits kept (what a caller of the C ABI gets by default): `with_logits_of_the_last_estep`.
+    ctx.set_logits_needed(False)
     _apply_environment = ctx.apply_environment
 
     def apply_environment_for_the_bench():  # (the extra regions reset the modes in between: the M-step stays as chosen here)
         _apply_environment()
         ctx.set_mstep_incremental(args.incremental_mstep)
+        ctx.set_logits_needed(False)
     ctx.apply_environment = apply_environment_for_the_bench
 
     def estep_again():  # (clock_warmup: the E-step on the table as it stands - the EM does not move)
@@ -823,6 +828,17 @@ def main():
         fine_only_region['scaling'] = kinds[-1]
         ctx.set_coarse_pass(True)
 
+    logits_kept_region = None
+    if world == 1 and not args.timed_only and default_mode == 'guarded':
+        phase('default mode, logits of the last E-step kept: timed region')
+        ctx.set_logits_needed(True)
+        ctx.set_addition(None)
+        ctx.probs_from_betas(0.01, fetch=False)
+        ctx.estep(pen, with_doublets=dp > 0, fetch_logits=False, fetch_probs=False)
+        logits_kept_region = timed_region(ctx, plane, args.steps, args.warmup, spin=estep_again)
+        logits_kept_region['value'] = regions[kinds[-1]]['barcodes_total'] * args.steps / logits_kept_region['elapsed']
+        ctx.set_logits_needed(False)
+
     after_idle_region = None
     if world == 1 and not args.timed_only:
         phase('default mode on a device that has idled: timed region')
@@ -876,7 +892,8 @@ def main():
         mode_notes = {'guarded': ': contract of the path proven per barcode and E-step, the rest redone bit-exactly (include/demux_hip.h '
                                  'DMX_ESTEP_GUARDED); E-steps whose logits nobody can read - all but the last of a call: estep_passes - may take the '
                                  'coarse pass (genotype table as binary16, dmx_set_coarse_pass), the timed region is ONE dmx_run_iterations call of '
-                                 '`steps` iterations; exact_mode = everything bit-identical to the reference',
+                                 '`steps` iterations made as learn_genotypes makes its call: no logits returned (dmx_set_logits_needed(0)), so the last E-step '
+                                 'is such an E-step too; exact_mode = everything bit-identical to the reference',
                       'exact': ': logits, posteriors and additions bit-identical to the reference',
                       'fast': ': tolerance mode without the guard'}
         out = {
@@ -935,6 +952,10 @@ def main():
                                                      'matters - the full pass\'s bits (tests/test_gpu_mstep_tiles.py); mstep_passes says how many M-steps did what.  Not the headline: the '
                                                      'synthetic experiment has converged by the timed iterations (the 6th to 25th of the run), so the incremental step has next to nothing '
                                                      'left to do; `value` recomputes every sum in every iteration')
+        if logits_kept_region:
+            out['with_logits_of_the_last_estep'] = {k: v for k, v in logits_kept_region.items() if k != 'elapsed'}
+            out['with_logits_of_the_last_estep']['note'] = ('the same timed region with dmx_set_logits_needed(1), the C ABI\'s default: the last E-step of the call takes the fine pass '
+                                                            '(float32 table), so that its logits are the ones the contract describes; `value` is the call learn_genotypes makes, which returns posteriors only')
         out['clock_warmup'] = {'ms': CLOCK_WARMUP_MS, 'esteps_ahead_of_the_headline_region': head['clock_warmup_esteps'], 'note': clock_warmup.__doc__.split('\n\n')[0].replace('\n    ', ' ')}
         if after_idle_region:
             out['after_idle'] = {k: after_idle_region[k] for k in ('value', 'ms_per_step', 'em_iterations_per_s', 'ms_per_step_with_phase_timers', 'kernel_ms')}

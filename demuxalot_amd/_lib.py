@@ -76,6 +76,7 @@ SIGNATURES = {
     'dmx_get_timings': (c_int, [_P, POINTER(c_double), POINTER(c_int64)]),
     'dmx_reset_timings': (c_int, [_P]),
     'dmx_set_phase_timers': (c_int, [_P, c_int]),
+    'dmx_set_logits_needed': (c_int, [_P, c_int]),
     'dmx_get_guard_probes': (c_int, [_P, POINTER(c_int64), POINTER(c_int64)]),
     'dmx_debug_set_pass_ms': (c_int, [_P, c_double, c_double, c_double]),
     'dmx_device_bytes': (c_int, [_P, POINTER(c_int64)]),

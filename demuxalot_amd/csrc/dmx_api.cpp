@@ -1402,6 +1402,7 @@ int run_estep(dmx_ctx *c, int with_doublets, bool with_prior, int prior_dtype, f
     else if (c->guard_ran) HIP_TRY(dmx::launch_guard_stamp(c->stream, c->d_guard_count, dmx::GS_T_END));
     timer_end(c, DMX_T_ESTEP, ev);
     c->have_post = true;
+    c->logits_readable = logits_kept;  // (an E-step nobody was to read the logits of may have taken the coarse pass: the device's choice)
     return 0;
 }
 
@@ -2024,6 +2025,13 @@ int dmx_get_guard_levels(dmx_ctx *c, int32_t *level_last, int64_t *coarse_steps,
     return 0;
 }
 
+int dmx_set_logits_needed(dmx_ctx *c, int needed)
+{
+    if (!c) return fail(DMX_ERR_INVALID, "null context");
+    c->logits_needed = needed != 0;
+    return 0;
+}
+
 int dmx_get_guard_probes(dmx_ctx *c, int64_t *probes, int64_t *streak)
 {
     DMX_TRY(bind(c));
@@ -2362,9 +2370,11 @@ int dmx_em(dmx_ctx *c, int n_iterations, float lo, float hi, int with_doublets, 
     c->incr_valid = false;
     c->add_is_zero = true;
     c->add_partial = false;
+    const bool keep_last = c->logits_needed || logits_out != nullptr;  // (dmx_set_logits_needed)
     for (int it = 0; it < n_iterations; it++) {
-        DMX_TRY(run_pstep(c, lo, hi, true, it + 1 < n_iterations && it > 0 && coarse_capable(c, with_doublets, lo)));  // (iteration 0: the dictionary form)
-        DMX_TRY(run_estep(c, with_doublets, it == 0 && prior_logits != nullptr, prior_dtype, power, it + 1 == n_iterations));
+        const bool kept = it + 1 == n_iterations && keep_last;  // somebody can read this E-step's logits
+        DMX_TRY(run_pstep(c, lo, hi, true, !kept && it > 0 && coarse_capable(c, with_doublets, lo)));  // (iteration 0: the dictionary form)
+        DMX_TRY(run_estep(c, with_doublets, it == 0 && prior_logits != nullptr, prior_dtype, power, kept));
         if (it + 1 < n_iterations) {  // the M-step after the last yield is dead
             c->msteps_ahead = n_iterations - 1 - it;
             const int rc_m = run_mstep(c, power);
@@ -2389,8 +2399,9 @@ int dmx_run_iterations(dmx_ctx *c, int n_iterations, float lo, float hi, float p
     if (n_iterations < 0) return fail(DMX_ERR_INVALID, "negative n_iterations");
     const int with_doublets = c->K != c->G;
     for (int it = 0; it < n_iterations; it++) {
-        DMX_TRY(run_pstep(c, lo, hi, true, it + 1 < n_iterations && coarse_capable(c, with_doublets, lo)));
-        DMX_TRY(run_estep(c, with_doublets, false, DMX_F32, power, it + 1 == n_iterations));
+        const bool kept = it + 1 == n_iterations && c->logits_needed;  // somebody can read this E-step's logits
+        DMX_TRY(run_pstep(c, lo, hi, true, !kept && coarse_capable(c, with_doublets, lo)));
+        DMX_TRY(run_estep(c, with_doublets, false, DMX_F32, power, kept));
         c->msteps_ahead = n_iterations - it;
         const int rc_m = run_mstep(c, power);
         c->msteps_ahead = 0;
@@ -2403,6 +2414,7 @@ int dmx_get_logits(dmx_ctx *c, float *out)
 {
     DMX_TRY(bind(c));
     DMX_TRY(need(c, c->have_post, "dmx_estep before dmx_get_logits"));
+    DMX_TRY(need(c, c->logits_readable, "the last E-step ran with dmx_set_logits_needed(ctx, 0): its logits were not kept (dmx_estep computes them)"));
     DMX_TRY(copy_out(c, out, c->d_logits, (size_t)c->B * c->K));
     HIP_TRY(hipStreamSynchronize(c->stream));
     return 0;
@@ -2432,6 +2444,8 @@ int dmx_get_block(dmx_ctx *c, int what, int64_t b0, int64_t b1, int64_t k0, int6
     DMX_TRY(bind(c));
     DMX_TRY(need(c, c->have_post, "dmx_estep before dmx_get_block"));
     if (what != DMX_LOGITS && what != DMX_PROBS) return fail(DMX_ERR_INVALID, "what must be DMX_LOGITS or DMX_PROBS");
+    if (what == DMX_LOGITS)
+        DMX_TRY(need(c, c->logits_readable, "the last E-step ran with dmx_set_logits_needed(ctx, 0): its logits were not kept (dmx_estep computes them)"));
     if (b0 < 0 || b1 < b0 || b1 > c->B || k0 < 0 || k1 < k0 || k1 > c->K)
         return fail(DMX_ERR_INVALID, "block [%lld,%lld) x [%lld,%lld) outside [0,%lld) x [0,%d)", (long long)b0, (long long)b1,
                     (long long)k0, (long long)k1, c->B, c->K);

@@ -488,10 +488,15 @@ class Demultiplexer:
         with shared_context_lock:
             ctx, _betas = _pack_on_device(chromosome2compressed_snp_calls, genotypes, barcode_handler.n_barcodes, True,
                                           fetch_betas=False)
-            _logits, probs, addition = ctx.em(
-                n_iterations, p_genotype_clip, penalties, with_doublets=doublet_prior != 0,
-                prior_logits=barcode_prior_logits, contribution_power=Demultiplexer.contribution_power,
-                fetch_logits=False)
+            # only the last iteration's posteriors go back to the caller (demux.py:65-66): nobody reads its logits
+            ctx.set_logits_needed(False)
+            try:
+                _logits, probs, addition = ctx.em(
+                    n_iterations, p_genotype_clip, penalties, with_doublets=doublet_prior != 0,
+                    prior_logits=barcode_prior_logits, contribution_power=Demultiplexer.contribution_power,
+                    fetch_logits=False)
+            finally:
+                ctx.set_logits_needed(True)
         probs_df = pd.DataFrame(data=probs, index=_barcode_index(barcode_handler), columns=column_names)
         learnt_genotypes = genotypes._with_betas(genotypes.get_betas() + addition)
         return learnt_genotypes, probs_df

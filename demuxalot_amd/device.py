@@ -51,6 +51,7 @@ class DeviceContext:
         self.set_coarse_pass(True)
         self.set_mstep_incremental(True)
         self.set_phase_timers(False)
+        self.set_logits_needed(True)
 
     def __enter__(self):
         return self
@@ -463,6 +464,12 @@ class DeviceContext:
                                              ctypes.byref(c_ms), ctypes.byref(f_ms), ctypes.byref(e_ms)))
         return {'level': level.value, 'coarse_steps': steps.value, 'flagged_fine': fine.value, 'flagged_coarse': coarse.value,
                 'coarse_pass_ms': c_ms.value, 'fine_pass_ms': f_ms.value, 'exact_pass_ms': e_ms.value}
+
+    def set_logits_needed(self, needed):
+        """False: nobody will read the logits of the last E-step of the em / run_iterations calls that follow (learn_genotypes returns
+        posteriors only), so that E-step too may take the coarse pass; get_logits / get_block('logits') then raise until an E-step
+        keeps its logits again (include/demux_hip.h: dmx_set_logits_needed).  Default True."""
+        check(self._lib.dmx_set_logits_needed(self._h, int(bool(needed))))
 
     def guard_probes(self):
         """(E-steps that ran another level than the cheapest to have it timed again since reset_timings, E-steps in a row on the

@@ -243,6 +243,13 @@ int dmx_set_guard_adaptive(dmx_ctx *ctx, int adaptive);
  * estimate), and the device's timings of the three passes over all barcodes
  * in ms (0: not run yet; exact: negative while it is an estimate).  Any pointer may be NULL. */
 int dmx_set_coarse_pass(dmx_ctx *ctx, int coarse);
+/* The reference's learn_genotypes returns the learnt genotypes and the LAST iteration's posteriors - no logits (demux.py:55-66).  A
+ * caller that will not read the logits of the last E-step of its dmx_em / dmx_run_iterations calls says so with needed = 0: that E-step
+ * is then one "whose logits nobody reads" like the ones before it and may take the coarse pass - its posteriors proven within the
+ * contract per barcode like every coarse E-step's.  dmx_em with a logits output pointer keeps them regardless.  After such a call
+ * dmx_get_logits / dmx_get_block(DMX_LOGITS) fail (DMX_ERR_INVALID) until an E-step has kept its logits again (dmx_estep, or a call
+ * with needed = 1); posteriors, assignments and the reductions are available as ever.  Default 1. */
+int dmx_set_logits_needed(dmx_ctx *ctx, int needed);
 /* Incremental M-step (csrc/kernels.h: MIncrArgs).  The tile-major M-step adds integers, so its sums can be updated exactly: once a
  * full pass has left them on the device, an M-step visits only the barcodes whose posteriors changed where it matters (a posterior
  * below 2^-26 contributes exactly 0 on the sums' grid) and adds the differences of their new and old contributions - a fraction of a

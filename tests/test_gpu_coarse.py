@@ -223,3 +223,58 @@ def test_a_stale_time_of_a_pass_that_does_not_run_is_taken_again(separable):
         assert ctx.guard_probes()[0] == 0 and ctx.guard_levels()['coarse_steps'] == 0
     finally:
         ctx.close()
+
+
+def test_a_call_that_returns_no_logits_may_take_the_coarse_pass_for_its_last_estep(separable):
+    """learn_genotypes returns the learnt genotypes and the last iteration's posteriors, no logits (demux.py:55-66): its dmx_em call says
+    so (dmx_set_logits_needed(0)) and the last E-step becomes one whose logits nobody reads, like the ones before it.  Posteriors of
+    every barcode within the contract of the exact mode's call; the logits are then not served (loudly), everything else is; a logits
+    output pointer, or an E-step of its own, keeps them as before."""
+    from demuxalot_amd._lib import DemuxHipError
+    from demuxalot_amd.device import DeviceContext
+    p = separable
+    pen = np.zeros(p.n_genotypes, dtype=np.float32)
+    ctx = DeviceContext(0)
+    try:
+        ctx.set_estep_mode('exact')
+        ctx.set_exact_additions(True)
+        _install(ctx, p)
+        _l, probs_exact, add_exact = ctx.em(6, 0.01, pen, with_doublets=False, fetch_logits=False)
+        ctx.set_estep_mode('guarded')
+        ctx.set_exact_additions(False)
+        ctx.set_logits_needed(False)
+        ctx.reset_timings()
+        _l, probs, addition = ctx.em(6, 0.01, pen, with_doublets=False, fetch_logits=False)
+        lv = ctx.guard_levels()
+        assert lv['level'] == 0 and lv['coarse_steps'] == 5, lv      # E-step 0: dictionary form; 1 .. 5: coarse, the last one too
+        check_contract(probs, probs_exact, 'no logits needed: 6 iterations vs exact')
+        assert np.array_equal(ctx.get_block('probs', 0, 100), probs[:100])
+        assert np.array_equal(ctx.get_assignments()[0], probs.argmax(axis=1))
+        with pytest.raises(DemuxHipError, match='logits were not kept'):
+            ctx.get_logits()
+        with pytest.raises(DemuxHipError, match='logits were not kept'):
+            ctx.get_block('logits', 0, 10)
+        # the same call asked for its logits: kept, the last E-step on the fine pass
+        ctx.reset_timings()
+        logits, probs2, _a = ctx.em(6, 0.01, pen, with_doublets=False)
+        lv = ctx.guard_levels()
+        assert lv['level'] == 1 and lv['coarse_steps'] == 4, lv
+        assert np.array_equal(ctx.get_logits(), logits)
+        check_contract(probs2, probs_exact, 'logits asked for: 6 iterations vs exact')
+        # dmx_run_iterations has no output pointers: the setting alone decides
+        ctx.reset_timings()
+        ctx.run_iterations(5, 0.01)
+        lv = ctx.guard_levels()
+        assert lv['level'] == 0 and lv['coarse_steps'] == 5, lv
+        with pytest.raises(DemuxHipError, match='logits were not kept'):
+            ctx.get_logits()
+        ctx.estep(pen, with_doublets=False, fetch_logits=False, fetch_probs=False)   # an E-step of its own keeps them
+        assert np.isfinite(ctx.get_block('logits', 0, 10)).all()
+        ctx.set_logits_needed(True)
+        ctx.reset_timings()
+        ctx.run_iterations(5, 0.01)
+        lv = ctx.guard_levels()
+        assert lv['level'] == 1 and lv['coarse_steps'] == 4, lv
+        assert np.isfinite(ctx.get_logits()).all()
+    finally:
+        ctx.close()
