@@ -2912,11 +2912,15 @@ static hipError_t launch_pstep(hipStream_t st, const T *prior, const T *addition
 #define PSTEP(L)                                                                                                          \
     hipLaunchKernelGGL((k_probs_from_betas<T, L>), dim3(blocks_for(groups, 4 * (64 / L))), dim3(256), 0, st, prior, addition, \
                        v2snp, snp_ptr, snp_vars, v_begin, n_rows, n_snps, G, prow, lo, hi, prob, prob16)
+    // Lanes per variant row: a lane group walks the chain SNP -> its variants -> their rows -> stores, and what the kernel waits on is
+    // that chain (58 VGPRs: 8 wavefronts per SIMD as it is), so wide tables take HALF a row per pass of a lane group's loop - two SNPs in
+    // flight per wavefront: 64 genotypes 0.054 -> 0.045 ms on 200 000 variants (a quarter of a row: 0.048), 32 genotypes 0.032 -> 0.028
+    // (scripts/pstep_lanes.sh)
     if (G <= 4) PSTEP(4);
     else if (G <= 8) PSTEP(8);
     else if (G <= 16) PSTEP(16);
-    else if (G <= 32) PSTEP(32);
-    else PSTEP(64);
+    else if (G <= 32) PSTEP(16);
+    else PSTEP(32);
 #undef PSTEP
     return hipGetLastError();
 }
