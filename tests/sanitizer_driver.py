@@ -121,6 +121,7 @@ def random_problem(rng, B, V, G, n):
 
 
 def run_contexts(rng, rounds):
+    from demuxalot_amd._lib import DemuxHipError
     from demuxalot_amd.device import DeviceContext
     for r in range(rounds):
         B, V, G = int(rng.integers(1, 300)), int(rng.integers(1, 120)), int(rng.choice([1, 2, 5, 8, 31, 64, 65, 130]))
@@ -149,9 +150,23 @@ def run_contexts(rng, rounds):
             prior = None if rng.random() < 0.6 else rng.random((B, K)).astype(rng.choice([np.float32, np.float64]))
             ctx.estep(pen, with_doublets=doublets, prior_logits=prior)
             ctx.mstep(2. if rng.random() < 0.7 else 1.5)
+            ctx.set_phase_timers(bool(rng.random() < 0.5))
             ctx.em(int(rng.integers(1, 4)), 0.01, pen, with_doublets=doublets, prior_logits=prior)
             ctx.run_iterations(2, 0.01)
             ctx.get_logits(), ctx.get_probs(), ctx.get_addition(), ctx.get_assignments()
+            ctx.set_logits_needed(False)  # a call that returns no logits: they are refused afterwards, loudly, until an E-step keeps them
+            ctx.run_iterations(1, 0.01)
+            try:
+                ctx.get_logits()
+                raise AssertionError('logits served although dmx_set_logits_needed(0) was in force')
+            except DemuxHipError as exc:
+                assert 'logits were not kept' in str(exc), exc
+            ctx.get_probs()
+            ctx.set_logits_needed(True)
+            ctx.run_iterations(1, 0.01)
+            ctx.get_logits(), ctx.guard_probes()
+            if ctx.guard_stats()[2] > 0:  # (a guarded E-step has run: there are pass times to overwrite)
+                ctx.debug_set_pass_ms(coarse=0.5, fine=1.0, exact=2.0)
             ctx.get_block('probs', 0, B, 0, min(K, 3))
             ctx.set_probs(rng.random((V, G)).astype(np.float32))
             ctx.probs_from_betas_f64(rng.random((V, G)), 0.01)
