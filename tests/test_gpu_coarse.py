@@ -190,8 +190,8 @@ def test_coarse_pass_shapes_on_one_table(G):
 def test_a_stale_time_of_a_pass_that_does_not_run_is_taken_again(separable):
     """The device times a pass only when it runs.  A coarse pass timed once at 10 ms (planted here; in the field: the first E-step on
     a device that had idled) loses against the fine pass - and would lose for ever, since it never runs again to be timed.  After 64
-    E-steps in a row on the fine pass the coarse pass runs once (its standing price is below twice the fine pass's only if it is
-    planted there: 1.8 x), is timed, and takes over; the posteriors stay those of a run that never left the coarse pass, within the
+    E-steps in a row on the fine pass the coarse pass runs once (its standing price, planted at 1.5 x the fine pass's, is below twice
+    the running level's), is timed, and takes over; the posteriors stay those of a run that never left the coarse pass, within the
     contract of either pass."""
     from demuxalot_amd.device import DeviceContext
     p = separable
@@ -207,7 +207,9 @@ def test_a_stale_time_of_a_pass_that_does_not_run_is_taken_again(separable):
         lv = ctx.guard_levels()   # (an E-step's own time is folded in when the next one begins: the fine pass's is that of dmx_em's last)
         assert lv['coarse_steps'] == 9 and ctx.guard_probes()[0] == 0, lv
         assert lv['coarse_pass_ms'] > 0 and lv['fine_pass_ms'] > lv['coarse_pass_ms'], lv
-        ctx.debug_set_pass_ms(coarse=1.8 * lv['fine_pass_ms'])   # stale and wrong
+        ctx.run_iterations(10, 0.01)                             # (the device at its clocks: the times the factors below multiply are the warm ones)
+        lv = ctx.guard_levels()
+        ctx.debug_set_pass_ms(coarse=1.5 * lv['fine_pass_ms'])   # stale and wrong
         ctx.reset_timings()
         ctx.run_iterations(60, 0.01)
         assert ctx.guard_levels()['coarse_steps'] == 0 and ctx.guard_probes()[0] == 0, (ctx.guard_levels(), ctx.guard_probes())
