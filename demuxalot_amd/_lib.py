@@ -66,6 +66,7 @@ SIGNATURES = {
     'dmx_mstep_f64': (c_int, [_P, c_double, _P]),
     'dmx_mstep_f64_sums': (c_int, [_P, c_double, _P]),
     'dmx_get_prior_betas': (c_int, [_P, _P]),
+    'dmx_get_learnt_betas': (c_int, [_P, _P]),
     'dmx_exchange_slices': (c_int, [c_int64, _P, c_int32, _P, POINTER(c_int64), POINTER(c_int32)]),
     'dmx_runtime_info': (c_int, [c_char_p, c_int64]),
     'dmx_get_exchange_mode': (c_int, [_P, POINTER(c_int32)]),

@@ -505,6 +505,8 @@ void release_problem(dmx_ctx *c)
     dev_free(c, &c->d_snp_vars, (size_t)c->V);
     const size_t vg = (size_t)c->V * c->G;
     dev_free(c, &c->d_prior, vg);
+    dev_free(c, &c->d_raw, vg);
+    c->have_raw = false;
     dev_free(c, &c->d_add, vg);
     dev_free(c, &c->d_prob, (size_t)c->prob_rows * c->G);
     dev_free(c, &c->d_prob16, c->cap_prob16);
@@ -2187,6 +2189,7 @@ int dmx_set_betas(dmx_ctx *c, const float *prior)
     HIP_TRY(hipMemcpyAsync(c->d_prior, prior, sizeof(float) * c->V * c->G, hipMemcpyHostToDevice, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
     c->have_betas = true;
+    c->have_raw = false;  // (a prior table given as such: no raw betas behind it)
     return 0;
 }
 
@@ -2199,13 +2202,11 @@ int dmx_set_prior_betas(dmx_ctx *c, const float *raw_betas, double default_prior
     const int G = c->G;
     if (V > 0 && !raw_betas) return fail(DMX_ERR_INVALID, "null betas");
     const size_t vg = (size_t)V * G;
-    float *d_raw = nullptr, *d_bsum = nullptr;
-    HIP_TRY(hipMalloc((void **)&d_raw, (vg ? vg : 1) * sizeof(float)));
-    hipError_t e = hipMalloc((void **)&d_bsum, (size_t)(V ? V : 1) * sizeof(float));
-    if (e != hipSuccess) {
-        (void)hipFree(d_raw);
-        return fail(DMX_ERR_HIP, "hipMalloc: %s", hipGetErrorString(e));
-    }
+    // the raw betas stay on the device: dmx_get_learnt_betas forms raw + addition there (demux.py:65)
+    c->have_raw = false;
+    if (!c->d_raw) DMX_TRY(dev_alloc(c, &c->d_raw, vg));
+    float *d_raw = c->d_raw, *d_bsum = nullptr;
+    HIP_TRY(hipMalloc((void **)&d_bsum, (size_t)(V ? V : 1) * sizeof(float)));
     int rc = 0;
     do {
         if (vg && hipMemcpyAsync(d_raw, raw_betas, vg * sizeof(float), hipMemcpyHostToDevice, c->stream) != hipSuccess) {
@@ -2227,7 +2228,7 @@ int dmx_set_prior_betas(dmx_ctx *c, const float *raw_betas, double default_prior
             }
             n_mol = c->d_mol;
         }
-        e = dmx::launch_prior_betas(c->stream, d_raw, d_bsum, n_mol, c->d_v2snp, c->d_snp_ptr, c->d_snp_vars, V, G,
+        const hipError_t e = dmx::launch_prior_betas(c->stream, d_raw, d_bsum, n_mol, c->d_v2snp, c->d_snp_ptr, c->d_snp_vars, V, G,
                                     default_prior, c->d_prior);
         if (e != hipSuccess) {
             rc = fail(DMX_ERR_HIP, "prior betas kernel: %s", hipGetErrorString(e));
@@ -2240,9 +2241,8 @@ int dmx_set_prior_betas(dmx_ctx *c, const float *raw_betas, double default_prior
         if (hipStreamSynchronize(c->stream) != hipSuccess) rc = fail(DMX_ERR_HIP, "synchronisation failed");
     } while (false);
     (void)hipStreamSynchronize(c->stream);
-    (void)hipFree(d_raw);
     (void)hipFree(d_bsum);
-    if (rc == 0) c->have_betas = true;
+    if (rc == 0) c->have_betas = c->have_raw = true;
     return rc;
 }
 
@@ -2252,6 +2252,25 @@ int dmx_get_prior_betas(dmx_ctx *c, float *out)
     DMX_TRY(need(c, c->have_problem && c->have_betas, "prior betas (dmx_set_betas / dmx_set_prior_betas) before dmx_get_prior_betas"));
     DMX_TRY(copy_out(c, out, c->d_prior, (size_t)c->V * c->G));
     HIP_TRY(hipStreamSynchronize(c->stream));
+    return 0;
+}
+
+int dmx_get_learnt_betas(dmx_ctx *c, float *out)
+{
+    DMX_TRY(bind(c));
+    DMX_TRY(need(c, c->have_problem && c->have_betas && c->have_raw, "dmx_set_prior_betas (the raw betas) before dmx_get_learnt_betas"));
+    if (!out && c->V > 0) return fail(DMX_ERR_INVALID, "null output");
+    DMX_TRY(ensure_full_addition(c));  // collective when sliced
+    const size_t vg = (size_t)c->V * c->G;
+    if (vg == 0) return 0;
+    float *d_sum = nullptr;
+    DMX_TRY(dev_alloc(c, &d_sum, vg));
+    hipError_t e = dmx::launch_add_f32(c->stream, c->d_raw, c->d_add, d_sum, (long long)vg);
+    if (e == hipSuccess) e = hipMemcpyAsync(out, d_sum, vg * sizeof(float), hipMemcpyDeviceToHost, c->stream);
+    const hipError_t e2 = hipStreamSynchronize(c->stream);
+    dev_free(c, &d_sum, vg);
+    if (e != hipSuccess) return fail(DMX_ERR_HIP, "learnt betas: %s", hipGetErrorString(e));
+    if (e2 != hipSuccess) return fail(DMX_ERR_HIP, "learnt betas: %s", hipGetErrorString(e2));
     return 0;
 }
 

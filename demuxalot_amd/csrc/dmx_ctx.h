@@ -75,6 +75,8 @@ struct dmx_ctx {
     dmx::CallPair *d_tile_stream = nullptr;  // the E-step records once more, in the order the bins consume them
     int *d_v2snp = nullptr, *d_snp_ptr = nullptr, *d_snp_vars = nullptr;
     float *d_prior = nullptr, *d_add = nullptr, *d_prob = nullptr;
+    float *d_raw = nullptr;  // the raw betas dmx_set_prior_betas was given (dmx_get_learnt_betas: raw + addition); have_raw
+    bool have_raw = false;
     unsigned short *d_prob16 = nullptr;  // d_prob as binary16 at the same row offsets (the coarse pass of the guarded E-step), cap_prob16 values
     size_t cap_prob16 = 0;
     unsigned *d_coarse_stream = nullptr;      // the coarse pass's records (kernels.hip: coarse_walk), cap_coarse_stream dwords; built at the first

@@ -158,6 +158,7 @@ hipError_t launch_remap_row_offsets(hipStream_t, CallPair *pairs, long long n_pa
     return hipSuccess;
 }
 hipError_t launch_f64_to_f32(hipStream_t, const double *, float *, long long) { return hipSuccess; }
+hipError_t launch_add_f32(hipStream_t, const float *, const float *, float *, long long) { return hipSuccess; }
 hipError_t launch_f32_to_f64(hipStream_t, const float *, double *, long long) { return hipSuccess; }
 hipError_t launch_delay(hipStream_t, long long) { return hipSuccess; }
 hipError_t launch_prior_betas(hipStream_t, const float *, float *, const unsigned long long *, const int *, const int *, const int *,

@@ -382,6 +382,7 @@ hipError_t launch_estep_packed(hipStream_t st, const EstepArgs &a);
 hipError_t launch_remap_row_offsets(hipStream_t st, CallPair *pairs, long long n_pairs, unsigned row_bytes, const int *new_rows,
                                     unsigned *call_rows);
 hipError_t launch_f64_to_f32(hipStream_t st, const double *in, float *out, long long n);
+hipError_t launch_add_f32(hipStream_t st, const float *a, const float *b, float *out, long long n);  // out = a + b, one float32 rounding (numpy's)
 // one wavefront that keeps the stream busy for `ticks` of the constant-rate wall clock (emulated wire: dmx_comm_init_emulated)
 hipError_t launch_delay(hipStream_t st, long long ticks);
 hipError_t launch_f32_to_f64(hipStream_t st, const float *in, double *out, long long n);

@@ -3281,6 +3281,19 @@ hipError_t launch_remap_row_offsets(hipStream_t st, CallPair *pairs, long long n
     return hipGetLastError();
 }
 
+__global__ __launch_bounds__(256) void k_add_f32(const float *__restrict__ a, const float *__restrict__ b, float *__restrict__ out, long long n)
+{
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) out[i] = a[i] + b[i];
+}
+
+hipError_t launch_add_f32(hipStream_t st, const float *a, const float *b, float *out, long long n)
+{
+    if (n == 0) return hipSuccess;
+    hipLaunchKernelGGL(k_add_f32, dim3(blocks_for(n, 256)), dim3(256), 0, st, a, b, out, n);
+    return hipGetLastError();
+}
+
 hipError_t launch_f64_to_f32(hipStream_t st, const double *in, float *out, long long n)
 {
     if (n == 0) return hipSuccess;

@@ -476,14 +476,14 @@ class Demultiplexer:
             try:
                 _pack_on_device(chromosome2compressed_snp_calls, genotypes, barcode_handler.n_barcodes, True,
                                 fetch_betas=False, ctx=ctx)
-                _l, _p, addition = ctx.em(
-                    n_iterations, p_genotype_clip, penalties, with_doublets=doublet_prior != 0,
-                    prior_logits=barcode_prior_logits, contribution_power=Demultiplexer.contribution_power,
-                    fetch_logits=False, fetch_probs=False)
+                ctx.em(n_iterations, p_genotype_clip, penalties, with_doublets=doublet_prior != 0,
+                       prior_logits=barcode_prior_logits, contribution_power=Demultiplexer.contribution_power,
+                       fetch_logits=False, fetch_probs=False, fetch_addition=False)
+                learnt_betas = ctx.get_learnt_betas()  # genotypes.get_betas() + addition (demux.py:65), added on the device
             except BaseException:
                 ctx.close()
                 raise
-            learnt_genotypes = genotypes._with_betas(genotypes.get_betas() + addition)
+            learnt_genotypes = genotypes._with_betas(learnt_betas, _take=True)
             return learnt_genotypes, DevicePosteriors(ctx, barcode_handler.ordered_barcodes, column_names)
         with shared_context_lock:
             ctx, _betas = _pack_on_device(chromosome2compressed_snp_calls, genotypes, barcode_handler.n_barcodes, True,
@@ -491,14 +491,15 @@ class Demultiplexer:
             # only the last iteration's posteriors go back to the caller (demux.py:65-66): nobody reads its logits
             ctx.set_logits_needed(False)
             try:
-                _logits, probs, addition = ctx.em(
+                _logits, probs, _addition = ctx.em(
                     n_iterations, p_genotype_clip, penalties, with_doublets=doublet_prior != 0,
                     prior_logits=barcode_prior_logits, contribution_power=Demultiplexer.contribution_power,
-                    fetch_logits=False)
+                    fetch_logits=False, fetch_addition=False)
+                learnt_betas = ctx.get_learnt_betas()  # genotypes.get_betas() + addition (demux.py:65), added on the device
             finally:
                 ctx.set_logits_needed(True)
         probs_df = pd.DataFrame(data=probs, index=_barcode_index(barcode_handler), columns=column_names)
-        learnt_genotypes = genotypes._with_betas(genotypes.get_betas() + addition)
+        learnt_genotypes = genotypes._with_betas(learnt_betas, _take=True)
         return learnt_genotypes, probs_df
 
     @staticmethod

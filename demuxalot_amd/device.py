@@ -347,6 +347,13 @@ class DeviceContext:
         out.flags.writeable = False
         return out
 
+    def get_learnt_betas(self):
+        """raw betas (as given to set_prior_betas) + the last M-step's addition, float32 [V, G], added on the device
+        (include/demux_hip.h: dmx_get_learnt_betas; demux.py:65)."""
+        out = np.empty((self.V, self.G), dtype=np.float32)
+        check(self._lib.dmx_get_learnt_betas(self._h, ptr(out)))
+        return out
+
     def get_assignments_above(self, threshold):
         """(best option or -1 where the row maximum is not > threshold, row maximum, number assigned)."""
         best = np.empty(self.B, dtype=np.int32)

@@ -216,14 +216,19 @@ class ProbabilisticGenotypes:
     def get_snp_positions_set(self) -> set:
         return {key[:2] for key in self.var2varid}
 
-    def _with_betas(self, external_betas: np.ndarray) -> 'ProbabilisticGenotypes':
+    def _with_betas(self, external_betas: np.ndarray, _take=False) -> 'ProbabilisticGenotypes':
         """A copy of this object whose table is exactly `external_betas` ([n_variants, G] float32, non-negative):
-        how learn_genotypes hands back the learnt genotypes (genotypes.py:327-334)."""
+        how learn_genotypes hands back the learnt genotypes (genotypes.py:327-334).  `_take` (the front-end's own freshly
+        downloaded table: nobody else holds it): the array itself becomes the table instead of a copy of it."""
         assert external_betas.shape == (self.n_variants, self.n_genotypes)
         assert external_betas.dtype == self.variant_betas.dtype
         assert external_betas.size == 0 or external_betas.min() >= 0
         out = self._clone(with_betas=False)
-        out.variant_betas = np.array(external_betas, copy=True)
+        if _take and external_betas.flags.c_contiguous and external_betas.flags.owndata:
+            external_betas.flags.writeable = True
+            out.variant_betas = external_betas
+        else:
+            out.variant_betas = np.array(external_betas, copy=True)
         return out
 
     def clone(self):

@@ -319,6 +319,11 @@ int dmx_set_mstep_wide_addresses(dmx_ctx *ctx, int wide);
 
 /* The prior betas resident on the device (as set by dmx_set_betas or computed by dmx_set_prior_betas), float32[V*G]. */
 int dmx_get_prior_betas(dmx_ctx *ctx, float *out);
+/* The learnt genotypes of demux.py:65: `genotypes.get_betas() + genotype_addition`, float32[V*G] - the raw betas dmx_set_prior_betas was
+ * given (they stay on the device) plus the addition of the last M-step, one float32 addition per element as numpy's, formed on the
+ * device: the host neither downloads the addition nor adds 4 V G bytes to it (10 of learn_genotypes' 36 ms at 200k x 100k x 64).
+ * DMX_ERR_INVALID after dmx_set_betas (a prior table given as such has no raw betas behind it). */
+int dmx_get_learnt_betas(dmx_ctx *ctx, float *out);
 
 /* genotype_addition float32[V*G]; NULL resets it to zero (demux.py:86). */
 int dmx_set_addition(dmx_ctx *ctx, const float *addition);

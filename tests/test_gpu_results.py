@@ -190,3 +190,31 @@ def test_sharded_entry_points_with_one_rank_communicator(name, reduce_dtype):
                                                      doublet_prior=float(fx['predict0_dp']))
     fio.assert_bitwise(logits_df.values, fx['predict0_logits'], 'predict logits')
     fio.assert_bitwise(p_df.values, fx['predict0_probs'], 'predict probs')
+
+
+def test_learnt_betas_formed_on_the_device():
+    """dmx_get_learnt_betas: raw betas (as dmx_set_prior_betas was given them) + the last M-step's addition, one float32 addition per
+    element - numpy's `genotypes.get_betas() + genotype_addition` (demux.py:65), bit for bit; refused when the prior table was set as
+    such (no raw betas behind it); the front-end hands the downloaded table itself to the learnt genotypes, writeable, no copy."""
+    from demuxalot_amd import _lib, synth
+    from demuxalot_amd.device import DeviceContext
+    p = synth.generate(3000, 2500, 12, seed=77)
+    rng = np.random.default_rng(5)
+    raw = (rng.gamma(2.0, 3.0, size=(p.n_variants, p.n_genotypes)) * (rng.random((p.n_variants, p.n_genotypes)) > 0.1)).astype(np.float32)
+    pen = np.zeros(p.n_genotypes, dtype=np.float32)
+    ctx = DeviceContext(0)
+    try:
+        ctx.set_problem(p.n_barcodes, p.n_variants, p.n_genotypes, p.variant_id, p.compressed_cb, p.p_base_wrong, p.v2snp)
+        mol = np.bincount(p.variant_id, minlength=p.n_variants).astype(np.int64)
+        ctx.set_prior_betas(raw, 1.0, True, mol_per_variant=mol, fetch=False)
+        _l, _p, addition = ctx.em(3, 0.01, pen, with_doublets=False)
+        learnt = ctx.get_learnt_betas()
+        fio.assert_bitwise(learnt, raw + addition, 'raw + addition')
+        assert learnt.flags.writeable and learnt.flags.owndata
+        ctx.set_addition(None)
+        fio.assert_bitwise(ctx.get_learnt_betas(), raw, 'addition reset')
+        ctx.set_betas(raw)
+        with pytest.raises(_lib.DemuxHipError, match='raw betas'):
+            ctx.get_learnt_betas()
+    finally:
+        ctx.close()
