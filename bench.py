@@ -257,8 +257,8 @@ def cpu_baseline(problem, betas, doublet_prior, target_seconds=15.0):
     n_sample = int(max(n_probe, min(problem.n_barcodes, (target_seconds - t_fixed) / per_barcode)))
     dt, n_calls, logits, post = _oracle_iteration(demux_oracle, problem, betas, doublet_prior, n_sample)
     return dict(value=n_sample / dt, unit='barcodes/s', cores=1, kind='port',
-                sample=f'first {n_sample} barcodes ({n_calls} calls) of the workload, full V and G, '
-                       f'one EM iteration in {dt:.1f} s, numpy single-threaded like the reference',
+                sample=f'first {n_sample} barcodes ({n_calls} calls), one EM iteration, {dt:.1f} s',
+                sample_note='the first barcodes of the workload with the full V and G; numpy single-threaded like the reference',
                 host_cores=os.cpu_count()), logits, post, n_sample
 
 
@@ -285,8 +285,10 @@ def live_counters(args, problem_dir):
     if nested or 'rocprof' in os.environ.get('LD_PRELOAD', ''):
         return {'skipped': f'this run is itself under a profiler ({nested or "LD_PRELOAD"})'}
     out_dir = tempfile.mkdtemp(prefix='bench_pmc_', dir='/tmp')
-    # (6 + 2 iterations: calls whose E-steps but the last may take the coarse pass - the dominant kernel of the timed region is the child's too)
-    child = [sys.executable, os.path.join(ROOT, 'bench.py'), '--workload', args.workload, '--steps', '6', '--warmup', '2', '--timed-only']
+    # The child makes the timed call and nothing around it (--timed-only: no clock warm-up spins, no other region): install, the first
+    # E-step (dictionary form, ONE launch), 2 + 12 + 12 iterations - so the k_estep_* kernel with the largest total IS the timed
+    # iterations' (round 5 picked the warm-up's k_estep_dictq: 56 spin E-steps ahead of every region)
+    child = [sys.executable, os.path.join(ROOT, 'bench.py'), '--workload', args.workload, '--steps', '12', '--warmup', '2', '--timed-only']
     child += ['--flat-genotypes'] if args.flat_genotypes else []
     env = dict(os.environ, TMPDIR='/tmp', DEMUXALOT_BENCH_PROBLEM=problem_dir)
     found = {}
@@ -308,6 +310,7 @@ def live_counters(args, problem_dir):
                 continue
             kernel = max(spans, key=lambda k: sum(spans[k]))
             found.setdefault('kernel', kernel.split('(')[0].replace('void dmx::', ''))
+            found.setdefault('kernel_launches_in_the_child', len(spans[kernel]))
             values, dispatches = [], set()
             for path in glob.glob(os.path.join(where, '**', '*counter_collection.csv'), recursive=True):
                 for row in csv.DictReader(open(path)):
@@ -336,7 +339,7 @@ def live_counters(args, problem_dir):
         shutil.rmtree(out_dir, ignore_errors=True)
 
 
-def roofline(ab, e_ms, N, G, K, live, coarse_share=0.0):
+def roofline(ab, e_ms, N, G, K, live, coarse_share=0.0, passes=None, ms_per_step=None):
     """The contract's HBM figures for the E-step of the timed iterations on ALGORITHMIC bytes, the ops roofline of
     SURVEY.md 8d (log terms against the v_log_f32 issue peak), and what the kernel actually runs on: the genotype-row
     gather out of L2 (guarded / tolerance mode) or VALU issue (exact mode) - `valu.busy` from the live counters."""
@@ -362,6 +365,23 @@ def roofline(ab, e_ms, N, G, K, live, coarse_share=0.0):
         'note': 'frac = algorithmic bytes / E-step time / 8 TB/s as the contract defines it; the E-step re-reads a 256-byte table '
                 'row per call, so it is bounded by the L2 gather rate (l2_gather.frac), not by HBM: DESIGN.md 4',
     }
+    out['kernel_ns_under_tracer'] = live.get('kernel_ns_under_tracer')
+    out['valu_busy'] = live.get('valu_busy')
+    if ms_per_step:
+        out['iteration_frac'] = ab['iteration'] / (ms_per_step * 1e-3) / 8e12   # all three phases' algorithmic bytes / the whole step / 8 TB/s
+    # the kernel the counters describe must be the one the timed E-steps ran (estep_passes of the timed region)
+    passes = passes or {}
+    expected = ('k_estep_tiled_coarse' if 2 * passes.get('coarse', 0) > passes.get('of', 1) else
+                {'fine': 'k_estep_tiled<', 'direct': 'k_estep_direct'}.get(passes.get('last')))
+    out['kernel_expected'] = expected
+    if expected and live.get('kernel'):
+        out['kernel_is_the_timed_one'] = expected in live['kernel']
+        if not out['kernel_is_the_timed_one']:
+            print(f'[bench] live counters describe {live["kernel"]}, the timed E-steps ran {expected}*: traffic / valu dropped from the line', file=sys.stderr)
+            out['traffic'] = out['kernel_ns_under_tracer'] = out['valu_busy'] = None
+            out['live_counters'] = {'error': f'counters of {live["kernel"]}, timed kernel {expected}'}
+    elif expected and not out['kernel']:
+        out['kernel'] = expected + ' (by estep_passes; no live trace)'
     problems = {k: v for k, v in live.items() if k in ('skipped', 'error') or k.endswith('_failed')}
     if problems:
         out['live_counters'] = problems
@@ -519,8 +539,10 @@ def clock_warmup(ctx, spin, ms=CLOCK_WARMUP_MS):
     return n
 
 
-def timed_region(ctx, plane, steps, warmup, spin=None, idle_s=0.0):
-    """(`spin`: clock_warmup ahead of the warm-up iterations; `idle_s`: the device left idle that long ahead of them instead.)
+def timed_region(ctx, plane, steps, warmup, spin=None, idle_s=0.0, snapshot=False):
+    """(`spin`: clock_warmup ahead of the warm-up iterations - NOT used by the headline region, which is the contract's W warm-up
+    iterations and nothing else; `idle_s`: the device left idle that long ahead of them instead; `snapshot`: the end state of the
+    region - best option and its posterior of every barcode, all singlet posteriors - fetched behind both windows for parity_timed.)
     W untimed iterations, then exactly K timed ones bracketed by barrier + device synchronisation on both sides;
     the MAX over ranks of the wall time.  The timed call runs as a default call does, without the phase timers (an event record
     is a barrier packet of its own: 6 us at each of the iteration's four phase boundaries); kernel_ms comes from the SAME call made
@@ -561,8 +583,11 @@ def timed_region(ctx, plane, steps, warmup, spin=None, idle_s=0.0):
         elapsed_timers = plane.max_float64(elapsed_timers)
     timers = ctx.timings()
     ctx.set_phase_timers(False)
+    end_state = None
+    if snapshot:
+        end_state = dict(best=ctx.get_assignments()[0], probs=ctx.get_block('probs', 0, ctx.B, 0, min(ctx.K, 128)), iterations=warmup + 2 * steps)
     (_redone, redone_total, rows), levels, (m_full, m_delta, m_changed) = stats
-    return {'elapsed': elapsed, 'ms_per_step_with_phase_timers': 1e3 * elapsed_timers / steps, 'clock_warmup_esteps': n_spin,
+    return {'elapsed': elapsed, 'end_state': end_state, 'ms_per_step_with_phase_timers': 1e3 * elapsed_timers / steps, 'clock_warmup_esteps': n_spin,
             'mstep_passes': ({'incremental_mstep': True, 'full': m_full, 'delta': m_delta, 'of': steps, 'barcodes_changed_in_the_last_mstep': m_changed}
                              if m_full + m_delta > 0 else {'incremental_mstep': False, 'note': 'every M-step recomputes every sum'}), 'ms_per_step': 1e3 * elapsed / steps, 'em_iterations_per_s': steps / elapsed,
             'estep_passes': {'coarse': levels['coarse_steps'], 'of': steps, 'last': {0: 'coarse', 1: 'fine', 2: 'direct'}.get(levels['level'], 'not guarded'),
@@ -571,6 +596,86 @@ def timed_region(ctx, plane, steps, warmup, spin=None, idle_s=0.0):
             'kernel_ms': {k: (v['ms'] / max(1, v['launches'])) for k, v in timers.items()},
             'exchange_ms_per_step': timers['allreduce']['ms'] / max(1, steps),
             'guard': {'barcodes_redone_exactly': redone_total, 'barcode_rows': rows, 'fraction': redone_total / max(1, rows)}}
+
+# ---------------------------------------------------------------------------------------------------------
+# the ONE line on stdout: compact, bounded; everything else goes to a sidecar file
+# ---------------------------------------------------------------------------------------------------------
+LINE_LIMIT = 4000   # bytes; the driver keeps the last 8 000 characters of stdout (round 5's 20 kB line was cut and never parsed)
+LINE_KEYS = ('metric', 'value', 'unit', 'n_gpus', 'steps', 'warmup', 'ms_per_step', 'higher_is_better', 'scaling', 'vs_baseline', 'dtype', 'data',
+             'config', 'roofline', 'cpu_baseline')
+
+
+def _sig(x, digits=6):
+    """Floats to `digits` significant figures (the line is for reading and parsing, the sidecar keeps everything)."""
+    if isinstance(x, float):
+        return float(f'{x:.{digits}g}')
+    if isinstance(x, dict):
+        return {k: _sig(v, digits) for k, v in x.items()}
+    if isinstance(x, (list, tuple)):
+        return [_sig(v, digits) for v in x]
+    return x
+
+
+def compact_line(full, details_path=None):
+    """The contract's JSON line out of the full result: the contract's keys, `roofline` and `cpu_baseline` as the task statement
+    defines them, the three scalars the round-5 verdict asks for beside them and the parity checks of this very run.  Regions, hard
+    workloads, end-to-end splits and notes stay in the sidecar (`details`).  Raises when the line would not fit LINE_LIMIT: a line
+    the driver cannot parse is a round without a measurement."""
+    roof, base = full.get('roofline') or {}, full.get('cpu_baseline')
+    cfg = full['config']
+    line = {
+        'metric': full['metric'], 'value': full['value'], 'unit': full['unit'], 'n_gpus': full['n_gpus'], 'steps': full['steps'], 'warmup': full['warmup'],
+        'ms_per_step': full['ms_per_step'], 'higher_is_better': True, 'scaling': full['scaling'], 'vs_baseline': None,
+        'dtype': full['dtype'], 'data': full['data'],
+        'config': {k: cfg[k] for k in ('workload', 'barcodes_total', 'barcodes_per_gpu', 'snps', 'variants', 'genotypes', 'options', 'calls_per_gpu',
+                                       'doublet_prior', 'estep_mode', 'mstep_form', 'parallelism') if k in cfg},
+        'em_iterations_per_s': full.get('em_iterations_per_s'),
+        'kernel_ms': full.get('kernel_ms'),
+        'estep_passes': {k: v for k, v in (full.get('estep_passes') or {}).items() if k in ('coarse', 'of', 'last')},
+        'guard_redone_fraction': (full.get('guard') or {}).get('fraction'),
+        'roofline': {k: roof.get(k) for k in ('bound', 'kernel', 'achieved', 'peak', 'unit', 'frac', 'traffic', 'algorithmic_bytes_per_launch', 'estep_ms',
+                                              'kernel_ns_under_tracer', 'valu_busy', 'iteration_frac')},
+        'cpu_baseline': ({k: base.get(k) for k in ('value', 'unit', 'cores', 'host_cores', 'kind', 'sample', 'speedup_vs_gpu_value')} if base else None),
+        'exact_mode_ms_per_step': (full.get('exact_mode') or {}).get('ms_per_step'),
+        'after_idle_ms_per_step': (full.get('after_idle') or {}).get('ms_per_step'),
+        'clocks_warm_ms_per_step': (full.get('clocks_warm') or {}).get('ms_per_step'),
+        'default_call_5it_ms_per_iteration': full.get('default_call_5it_ms_per_iteration'),
+        'cold_start_5it_ms_per_iteration': (full.get('cold_start_5it') or {}).get('ms_per_step'),
+        'predict_barcodes_per_s': full.get('predict_barcodes_per_s'),
+        'device_bytes_per_call': (full.get('device_bytes') or {}).get('per_call_without_the_results'),
+        'parity_timed': full.get('parity_timed'),
+        'parity_on_sample': full.get('parity_on_sample'),
+    }
+    if full.get('weak'):
+        line['weak'] = {k: full['weak'].get(k) for k in ('value', 'ms_per_step', 'barcodes_total', 'exchange_ms_per_step')}
+    if full.get('exchange_ms_per_step'):
+        line['exchange_ms_per_step'] = full['exchange_ms_per_step']
+    if 'live_counters' in roof:
+        line['roofline']['live_counters'] = {k: str(v)[:80] for k, v in roof['live_counters'].items()}
+    if details_path:
+        line['details'] = details_path
+    line = {k: v for k, v in _sig(line).items() if v is not None or k in LINE_KEYS}
+    text = json.dumps(line, separators=(', ', ': '))
+    missing = [k for k in LINE_KEYS if k not in line]
+    if missing or len(text) >= LINE_LIMIT:
+        raise AssertionError(f'bench line unusable: {len(text)} bytes (limit {LINE_LIMIT}), missing keys {missing}')
+    return text
+
+
+def write_details(full, workload, world):
+    """The full result (every region, the hard workloads, the end-to-end split, the notes) as a sidecar file: gpurun_out/ of the
+    repository when it can be written (it travels back from the GPU box), the temporary directory otherwise."""
+    name = f'bench_details_{workload}_n{world}.json'
+    for directory in (os.path.join(ROOT, 'gpurun_out'), os.environ.get('TMPDIR', '/tmp')):
+        try:
+            os.makedirs(directory, exist_ok=True)
+            path = os.path.join(directory, name)
+            with open(path, 'w') as f:
+                json.dump(full, f, indent=1)
+            return os.path.relpath(path, ROOT) if path.startswith(ROOT) else path
+        except OSError:
+            continue
+    return None
 
 
 def main():
@@ -756,7 +861,7 @@ def main():
         if args.mstep == 'auto':
             ctx.set_msteps_expected(args.warmup + args.steps)
         phase(f'{kind}: warm-up + timed region (per-iteration collectives)')
-        region = timed_region(ctx, plane, args.steps, args.warmup, spin=estep_again)
+        region = timed_region(ctx, plane, args.steps, args.warmup, snapshot=world == 1 and not args.timed_only)
         built, build_ms = ctx.mstep_tiles_info()
         region['mstep_records_build_ms'] = build_ms if built else 0.0
         region['device_bytes'] = ctx.device_bytes()
@@ -781,7 +886,7 @@ def main():
         ctx.estep(pen, with_doublets=dp > 0, fetch_logits=False, fetch_probs=False)
         probs_mode = ctx.get_block('probs', 0, len(probs0)) if (world == 1 and probs0 is not None) else None
         best_mode = ctx.get_assignments()[0] if probs_mode is not None else None
-        region = timed_region(ctx, plane, args.steps, args.warmup, spin=estep_again)
+        region = timed_region(ctx, plane, args.steps, args.warmup, snapshot=world == 1 and mode == 'exact')
         region['value'] = regions[kinds[-1]]['barcodes_total'] * args.steps / region['elapsed']
         region['scaling'] = kinds[-1]
         if probs_mode is not None:
@@ -789,6 +894,17 @@ def main():
                 argmax_identical_all_barcodes=bool(np.array_equal(best_mode, best0)),
                 max_abs_posterior_diff_first_rows=float(np.abs(probs_mode - probs0).max()), rows_compared=len(probs0))
         extra_modes[mode] = region
+    # What the bench times, checked: the end state of the default-mode region (best option and posteriors of EVERY barcode after
+    # W + 2K iterations from the prior: warm-up, timed window, the window again with the phase timers) against the end state of the
+    # exact-mode region after the same iterations from the same start - north_star's contract on the outputs of the EM loop.
+    parity_timed = None
+    end_default, end_exact = regions[kinds[-1]].get('end_state'), (extra_modes.get('exact') or {}).get('end_state')
+    if end_default is not None and end_exact is not None:
+        diff = np.abs(end_default['probs'] - end_exact['probs'])
+        parity_timed = {'argmax_identical': bool(np.array_equal(end_default['best'], end_exact['best'])),
+                        'assignments_differing': int((end_default['best'] != end_exact['best']).sum()),
+                        'max_abs_posterior_diff': float(diff.max()), 'within_1e-5': bool(diff.max() <= 1e-5),
+                        'barcodes': int(len(end_default['best'])), 'em_iterations': int(end_default['iterations']), 'against': 'exact_mode region, same start'}
     ctx.apply_environment()
     work_item_region = None
     took_tiles = ctx_mstep_form == 'tiles'
@@ -799,7 +915,7 @@ def main():
         ctx.set_addition(None)
         ctx.probs_from_betas(0.01, fetch=False)
         ctx.estep(pen, with_doublets=dp > 0, fetch_logits=False, fetch_probs=False)
-        work_item_region = timed_region(ctx, plane, args.steps, args.warmup, spin=estep_again)
+        work_item_region = timed_region(ctx, plane, args.steps, args.warmup)
         work_item_region['value'] = regions[kinds[-1]]['barcodes_total'] * args.steps / work_item_region['elapsed']
         work_item_region['scaling'] = kinds[-1]
         ctx.set_mstep_tiles('always' if args.mstep == 'tiles' else 'auto')
@@ -811,7 +927,7 @@ def main():
         ctx.set_addition(None)
         ctx.probs_from_betas(0.01, fetch=False)
         ctx.estep(pen, with_doublets=dp > 0, fetch_logits=False, fetch_probs=False)
-        incr_mstep_region = timed_region(ctx, plane, args.steps, args.warmup, spin=estep_again)
+        incr_mstep_region = timed_region(ctx, plane, args.steps, args.warmup)
         incr_mstep_region['value'] = regions[kinds[-1]]['barcodes_total'] * args.steps / incr_mstep_region['elapsed']
         incr_mstep_region['scaling'] = kinds[-1]
         ctx.set_mstep_incremental(False)
@@ -823,7 +939,7 @@ def main():
         ctx.set_addition(None)
         ctx.probs_from_betas(0.01, fetch=False)
         ctx.estep(pen, with_doublets=dp > 0, fetch_logits=False, fetch_probs=False)
-        fine_only_region = timed_region(ctx, plane, args.steps, args.warmup, spin=estep_again)
+        fine_only_region = timed_region(ctx, plane, args.steps, args.warmup)
         fine_only_region['value'] = regions[kinds[-1]]['barcodes_total'] * args.steps / fine_only_region['elapsed']
         fine_only_region['scaling'] = kinds[-1]
         ctx.set_coarse_pass(True)
@@ -835,9 +951,40 @@ def main():
         ctx.set_addition(None)
         ctx.probs_from_betas(0.01, fetch=False)
         ctx.estep(pen, with_doublets=dp > 0, fetch_logits=False, fetch_probs=False)
-        logits_kept_region = timed_region(ctx, plane, args.steps, args.warmup, spin=estep_again)
+        logits_kept_region = timed_region(ctx, plane, args.steps, args.warmup)
         logits_kept_region['value'] = regions[kinds[-1]]['barcodes_total'] * args.steps / logits_kept_region['elapsed']
         ctx.set_logits_needed(False)
+
+    clocks_warm_region = None
+    if world == 1 and not args.timed_only:
+        phase('default mode behind a clock warm-up: timed region')
+        ctx.set_addition(None)
+        ctx.probs_from_betas(0.01, fetch=False)
+        ctx.estep(pen, with_doublets=dp > 0, fetch_logits=False, fetch_probs=False)
+        clocks_warm_region = timed_region(ctx, plane, args.steps, args.warmup, spin=estep_again)
+        clocks_warm_region['value'] = regions[kinds[-1]]['barcodes_total'] * args.steps / clocks_warm_region['elapsed']
+
+    # What a learn_genotypes(n_iterations=5) call (the reference's default, demux.py:38) costs per iteration when it starts from the
+    # prior: the dictionary-form first E-step, the stream / record builds, the first guard decisions - none of which the steady-state
+    # `value` contains.  One dmx_em call exactly as demuxalot_amd/demux.py makes it, three times, the median.
+    cold_region = None
+    if world == 1 and not args.timed_only:
+        phase('cold start: 5-iteration calls from the prior')
+        _apply_environment()   # the library's own defaults: incremental M-step, form chosen for a 5-iteration call
+        ctx.set_logits_needed(False)
+        times = []
+        for _ in range(3):
+            install(problem)   # a fresh problem: no records, streams or pass prices of an earlier call
+            ctx.synchronize()
+            t0 = time.perf_counter()
+            ctx.em(5, 0.01, pen, with_doublets=dp > 0, fetch_logits=False, fetch_probs=False, fetch_addition=False)
+            ctx.synchronize()
+            times.append(time.perf_counter() - t0)
+        levels = ctx.guard_levels()
+        cold_region = {'ms_per_step': 1e3 * sorted(times)[1] / 5, 'calls_ms': [1e3 * t for t in times], 'mstep_form': ctx.mstep_form(),
+                       'coarse_steps_of_the_last_call': levels['coarse_steps'],
+                       'note': 'dmx_em(5 iterations) from the prior on a freshly installed problem (every record / stream build inside the call), results left on the device: median of three calls / 5'}
+        ctx.apply_environment()
 
     after_idle_region = None
     if world == 1 and not args.timed_only:
@@ -896,26 +1043,28 @@ def main():
                                  'is such an E-step too; exact_mode = everything bit-identical to the reference',
                       'exact': ': logits, posteriors and additions bit-identical to the reference',
                       'fast': ': tolerance mode without the guard'}
+        mode_short = {'guarded': 'guarded (1e-5 / arg-max contract proven per barcode, else exact redo; coarse f16-table pass where no logits are read)',
+                      'exact': 'exact (bit-identical to the reference)', 'fast': 'fast (tolerance mode, no guard)'}
         out = {
-            'metric': f'EM iterations/sec + barcodes demuxed/sec, {B_workload // 1000}k bc x {S // 1000}k SNP x {G} gt '
-                      + ('in total' + (f', barcodes sharded over {world} GPUs' if world > 1 else '') if head_kind == 'strong' else 'per GPU') +
-                      ': value = barcodes/s through full learn_genotypes EM iterations (P-step + E-step + softmax + '
-                      'M-step [+ exchange]) = barcodes x em_iterations_per_s; predict-only rate in predict_barcodes_per_s',
+            'metric': f'EM iterations/sec + barcodes demuxed/sec, {B_workload // 1000}k bc x {S // 1000}k SNP x {G} gt',
+            'metric_note': ('in total' + (f', barcodes sharded over {world} GPUs' if world > 1 else '') if head_kind == 'strong' else 'per GPU') +
+                           ': value = barcodes/s through full learn_genotypes EM iterations (P-step + E-step + softmax + '
+                           'M-step [+ exchange]) = barcodes x em_iterations_per_s; predict-only rate in predict_barcodes_per_s',
             'value': head['value'],
             'unit': 'barcodes/s',
             'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
             'ms_per_step': head['ms_per_step'],
             'higher_is_better': True, 'scaling': head_kind, 'vs_baseline': None,
-            'dtype': 'f32 terms, f64 accumulate (coarse pass of the guarded mode: genotype table read as binary16, f32 terms and sums - proven per barcode within the '
-                     'contract, the rest redone in the exact arithmetic)', 'data': 'synthetic',
+            'dtype': 'f32 terms, f64 sums' + (' (guarded mode: coarse pass reads the table as f16 and sums in f32; exact redo where the contract is not proven)'
+                                              if default_mode == 'guarded' else ''), 'data': 'synthetic',
             'config': {'workload': args.workload, 'barcodes_total': head['barcodes_total'], 'barcodes_per_gpu': head['barcodes_per_gpu'],
                        'snps': S, 'variants': V, 'genotypes': G, 'options': K, 'calls_per_gpu': head['calls_per_gpu'], 'doublet_prior': dp,
-                       'estep_mode': default_mode + mode_notes[default_mode],
-                       'mstep_form': f'{ctx_mstep_form} (--mstep {args.mstep}' + (': chosen by the library for a run of warm-up + steps iterations)' if args.mstep == 'auto' else ': forced)'),
+                       'estep_mode': mode_short[default_mode], 'estep_mode_note': default_mode + mode_notes[default_mode],
+                       'mstep_form': f'{ctx_mstep_form} (--mstep {args.mstep})',
                        'parallelism': f'barcode shards x{world}' + (
-                           {'variant': ', M-step sharded on variants: all-gather of posterior codes / bitmaps / singlet posteriors, all-gather f32 of genotype_prob slices',
-                            'reduce_scatter': f', reduce-scatter {args.reduce_dtype} of the partial sums + all-gather f32 of genotype_prob slices',
-                            'allreduce': f', all-reduce {args.reduce_dtype} of the partial sums'}.get(head.get('exchange'), '')
+                           {'variant': ', variant-sharded M-step: all-gather of posteriors + genotype_prob slices',
+                            'reduce_scatter': f', reduce-scatter {args.reduce_dtype} of partial sums + all-gather of genotype_prob slices',
+                            'allreduce': f', all-reduce {args.reduce_dtype} of partial sums'}.get(head.get('exchange'), '')
                            + (' (host-staged)' if args.host_plane else ' (RCCL)') if use_dist else ''),
                        'runtimes': runtimes, **({'rccl_fallback': rccl_fallback} if rccl_fallback else {})},
             'em_iterations_per_s': head['em_iterations_per_s'],
@@ -940,31 +1089,38 @@ def main():
             out['weak']['note'] = ('the workload per GPU: every rank holds a 200k-barcode shard (a copy of the generated one) of an '
                                    'N x 200k-barcode experiment')
         for mode, region in extra_modes.items():
-            out[f'{mode}_mode'] = {k: v for k, v in region.items() if k != 'elapsed'}
+            out[f'{mode}_mode'] = {k: v for k, v in region.items() if k not in ('elapsed', 'end_state')}
         if work_item_region:
-            out['work_item_mstep'] = {k: v for k, v in work_item_region.items() if k != 'elapsed'}
+            out['work_item_mstep'] = {k: v for k, v in work_item_region.items() if k not in ('elapsed', 'end_state')}
             out['work_item_mstep']['note'] = ('the same timed region with the work-item M-step, the form of runs with fewer than 8 M-steps '
                                               'ahead (the tile-major records cost a 2.6 ms sort of the calls to build)')
         if incr_mstep_region:
-            out['with_incremental_mstep'] = {k: v for k, v in incr_mstep_region.items() if k != 'elapsed'}
+            out['with_incremental_mstep'] = {k: v for k, v in incr_mstep_region.items() if k not in ('elapsed', 'end_state')}
             out['with_incremental_mstep']['note'] = ('the same timed region as a DEFAULT call of the library runs it (dmx_set_mstep_incremental(1)): after one full pass the tile-major '
                                                      'M-step\'s integer sums stay on the device and an M-step only adds the differences for the barcodes whose posteriors changed where it '
                                                      'matters - the full pass\'s bits (tests/test_gpu_mstep_tiles.py); mstep_passes says how many M-steps did what.  Not the headline: the '
                                                      'synthetic experiment has converged by the timed iterations (the 6th to 25th of the run), so the incremental step has next to nothing '
                                                      'left to do; `value` recomputes every sum in every iteration')
         if logits_kept_region:
-            out['with_logits_of_the_last_estep'] = {k: v for k, v in logits_kept_region.items() if k != 'elapsed'}
+            out['with_logits_of_the_last_estep'] = {k: v for k, v in logits_kept_region.items() if k not in ('elapsed', 'end_state')}
             out['with_logits_of_the_last_estep']['note'] = ('the same timed region with dmx_set_logits_needed(1), the C ABI\'s default: the last E-step of the call takes the fine pass '
                                                             '(float32 table), so that its logits are the ones the contract describes; `value` is the call learn_genotypes makes, which returns posteriors only')
-        out['clock_warmup'] = {'ms': CLOCK_WARMUP_MS, 'esteps_ahead_of_the_headline_region': head['clock_warmup_esteps'], 'note': clock_warmup.__doc__.split('\n\n')[0].replace('\n    ', ' ')}
+        if clocks_warm_region:
+            out['clocks_warm'] = {k: clocks_warm_region[k] for k in ('value', 'ms_per_step', 'em_iterations_per_s', 'ms_per_step_with_phase_timers', 'kernel_ms', 'clock_warmup_esteps')}
+            out['clocks_warm']['note'] = ('the same timed region behind %g ms of E-steps on the standing table (no EM progress): ' % CLOCK_WARMUP_MS
+                                          + clock_warmup.__doc__.split('\n\n')[0].replace('\n    ', ' ') + '  NOT the headline: `value` is W warm-up iterations + K timed ones, nothing else')
+        if cold_region:
+            out['cold_start_5it'] = cold_region
         if after_idle_region:
             out['after_idle'] = {k: after_idle_region[k] for k in ('value', 'ms_per_step', 'em_iterations_per_s', 'ms_per_step_with_phase_timers', 'kernel_ms')}
             out['after_idle']['note'] = ('the same timed region - W warm-up iterations, K timed ones - begun 0.5 s after the device was last busy, without the clock warm-up: what the first '
                                          'short call on an idle device sees (the clocks come up over its first 30 ms)')
         if fine_only_region:
-            out['without_coarse_pass'] = {k: v for k, v in fine_only_region.items() if k != 'elapsed'}
+            out['without_coarse_pass'] = {k: v for k, v in fine_only_region.items() if k not in ('elapsed', 'end_state')}
             out['without_coarse_pass']['note'] = ('the same timed region with dmx_set_coarse_pass(0): every E-step the fine pass on the float32 table (the default mode of round 4; '
                                                   'what the LAST E-step of every call runs in any case - its logits are the ones a caller can read)')
+        if parity_timed:
+            out['parity_timed'] = parity_timed
         if hard:
             out['hard_workload'] = hard
         if predict:
@@ -984,7 +1140,7 @@ def main():
                     import shutil
                     shutil.rmtree(cache, ignore_errors=True)
         passes = regions[kinds[-1]].get('estep_passes', {})
-        out['roofline'] = roofline(ab, e_ms, N, G, K, live, coarse_share=passes.get('coarse', 0) / max(1, passes.get('of', 1)))
+        out['roofline'] = roofline(ab, e_ms, N, G, K, live, coarse_share=passes.get('coarse', 0) / max(1, passes.get('of', 1)), passes=passes, ms_per_step=head['ms_per_step'])
         if world == 1 and not args.no_e2e and not args.flat_genotypes and N > 200_000_000:
             out['e2e'] = {'skipped': 'the object form of an experiment of this size (1.3 M dictionary entries, 1 M barcode strings, 4e8 container records) is '
                                      'minutes of Python before any call is made'}
@@ -1005,8 +1161,13 @@ def main():
             }
         else:
             out['cpu_baseline'] = None
+        if isinstance(out.get('e2e'), dict) and 'split_s' in out['e2e']:
+            out['default_call_5it_ms_per_iteration'] = 1e3 * out['e2e']['split_s']['em_5_iterations_fused'] / 5
+        details = write_details(out, args.workload, world)
+        print(json.dumps(out), file=sys.stderr)   # (the whole result for a reader of the log; stdout carries the compact line only)
         sys.stdout.flush()
-        os.write(json_fd, (json.dumps(out) + '\n').encode())
+        sys.stderr.flush()
+        os.write(json_fd, (compact_line(out, details) + '\n').encode())
     phase('final barrier')
     if plane is not None:
         plane.barrier()

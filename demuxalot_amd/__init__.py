@@ -7,6 +7,6 @@ __version__ = '0.1.0'
 from .utils import BarcodeHandler
 from .snp_counter import CompressedSNPCalls
 from .genotypes import ProbabilisticGenotypes
-from .demux import Demultiplexer, DevicePosteriors
+from .demux import Demultiplexer, DevicePosteriors, invalidate_resident
 
-__all__ = ['BarcodeHandler', 'CompressedSNPCalls', 'ProbabilisticGenotypes', 'Demultiplexer', 'DevicePosteriors']
+__all__ = ['BarcodeHandler', 'CompressedSNPCalls', 'ProbabilisticGenotypes', 'Demultiplexer', 'DevicePosteriors', 'invalidate_resident']

@@ -32,6 +32,7 @@ SIGNATURES = {
     'dmx_synchronize': (c_int, [_P]),
     'dmx_pack_calls_host': (c_int, [c_int64, _P, _P, _P, c_int64, _P, _P, _P, _P, _P, _P,
                                     POINTER(c_int64), POINTER(c_int64), _P, _P, _P, _P, _P]),
+    'dmx_hash_host': (c_int, [_P, c_int64, c_int32, POINTER(ctypes.c_uint64)]),
     'dmx_set_problem': (c_int, [_P, c_int64, c_int64, c_int32, c_int64, _P, _P, _P, _P]),
     'dmx_pack_and_set_problem': (c_int, [_P, c_int64, c_int64, c_int32, _P, _P, _P, _P, c_int64, _P, _P, _P, _P, _P,
                                          POINTER(c_int64), POINTER(c_int64), _P]),

@@ -20,6 +20,7 @@ What runs where
               calls and the float64 M-step that follows it                   -> demux.py:204-244
 There is no CPU fallback for the GPU steps.
 """
+import os
 from typing import Dict, Tuple
 
 import numpy as np
@@ -92,11 +93,14 @@ def _variant_keys(genotypes, columns=_UNSET):
 
 def _var2varid_fingerprint(var2varid):
     """Identity of a (chrom, pos, base) -> row dict cheap enough to take on every call: the object, its length, its first
-    and last entries (dicts keep insertion order and the importers only ever append: genotypes.py extend_variants)."""
+    and last entries and ~61 entries at a stride (dicts keep insertion order and the importers only ever append:
+    genotypes.py extend_variants; the mutators of demuxalot_amd.ProbabilisticGenotypes drop the kept arrays themselves)."""
     n = len(var2varid)
     if n == 0:
         return id(var2varid), 0
-    return id(var2varid), n, next(iter(var2varid.items())), next(reversed(var2varid.items()))
+    import itertools
+    sample = tuple(itertools.islice(var2varid.items(), 0, None, max(1, n // 61)))  # (a walk at C speed: ~1 ms for 200k entries)
+    return id(var2varid), n, next(reversed(var2varid.items())), hash(sample)
 
 
 def _cached_variant_keys(genotypes):
@@ -128,8 +132,9 @@ def _cached_variant_keys(genotypes):
 
 
 def _sampled_checksum(records):
-    """crc32 of the head, the tail and ~512 strided records of a record array: what tells an array edited in place from
-    the one a device problem was packed from, at a cost of microseconds."""
+    """crc32 of the head, the tail and ~512 strided records of a record array.  NOT what the resident problem is keyed by any more
+    (a sparse in-place edit slips through): kept for DEMUXALOT_AMD_RESIDENT=sampled, the opt-in of callers who never edit their
+    containers in place and want the last 15 ms of a repeated call."""
     import zlib
     n = len(records)
     if n == 0:
@@ -138,6 +143,46 @@ def _sampled_checksum(records):
     crc = zlib.crc32(flat[:4096].tobytes())
     crc = zlib.crc32(flat[-4096:].tobytes(), crc)
     return zlib.crc32(np.ascontiguousarray(records[::max(1, n // 512)]).view(np.uint8).tobytes(), crc)
+
+
+def _content_hash(records):
+    """64-bit hash of EVERY byte of a record array (dmx_hash_host: several host threads, memory bandwidth - 2 GB in ~15 ms).
+    The reference packs its inputs anew on every call (demux.py:303); a packed problem of an earlier call stands in for that
+    only when every record of every container hashes as it did then, whatever object the records live in."""
+    import ctypes
+    records = np.ascontiguousarray(records)
+    out = ctypes.c_uint64(0)
+    _lib.check(_lib.load().dmx_hash_host(records.ctypes.data if records.size else None, int(records.nbytes), 0, ctypes.byref(out)))
+    return int(out.value)
+
+
+def resident_policy():
+    """DEMUXALOT_AMD_RESIDENT = full (default: reuse keyed by the content hash of every record) | sampled (identity + a
+    sampled checksum, round 5's key: in-place edits of single records are NOT seen) | 0 (never reuse: every call packs)."""
+    policy = os.environ.get('DEMUXALOT_AMD_RESIDENT', 'full').lower()
+    policy = {'1': 'full', 'on': 'full', 'off': '0', 'never': '0', 'none': '0'}.get(policy, policy)
+    assert policy in ('full', 'sampled', '0'), f'DEMUXALOT_AMD_RESIDENT={policy!r}: full, sampled or 0'
+    return policy
+
+
+def invalidate_resident(genotypes=None, barcode_handler=None):
+    """Forget what the front-end keeps between calls: the packed problem resident on the shared device context(s) and, when
+    given, the key arrays kept on a genotypes object and the Index kept on a barcode handler.  The next call packs anew, as
+    every call of the reference does."""
+    from . import device
+    with device.shared_context_lock:
+        for ctx in device.shared_contexts():
+            ctx._resident_key = None
+    if genotypes is not None:
+        try:
+            genotypes._amd_variant_keys = None
+        except AttributeError:
+            pass
+    if barcode_handler is not None:
+        try:
+            barcode_handler._amd_index = None
+        except AttributeError:
+            pass
 
 
 def _flatten_inputs(chromosome2compressed_snp_calls, genotypes, want_molecule_table):
@@ -258,13 +303,20 @@ def _pack_on_device(chromosome2compressed_snp_calls, genotypes, n_barcodes, add_
     containers = list(chromosome2compressed_snp_calls.values())
     raw = all(c.snp_calls.dtype == SNP_CALL_DTYPE and c.molecules.dtype == MOLECULE_DTYPE for c in containers)
     # The packed problem stays resident on the shared context: predict_posteriors followed by learn_genotypes on the same
-    # containers and genotypes (the reference's own usage pattern, see _cached_variant_keys) packs once.  Key: identity +
-    # length counters + a sampled checksum of every container's arrays, the fingerprint of var2varid, the shape.
+    # containers and genotypes (the reference's own usage pattern, see _cached_variant_keys) packs once.  Key: the content
+    # hash of EVERY record of every container (no object identities: an array edited in place hashes differently, a freed
+    # id() that comes back means nothing), the fingerprint of var2varid, the shape.  resident_policy(): the switch.
     key = None
-    if shared and raw and reduce_molecule_counts is None:
-        key = (tuple((chrom, id(c.snp_calls), id(c.molecules), int(c.n_snp_calls), int(c.n_molecules),
-                      _sampled_checksum(c.snp_calls[:c.n_snp_calls]), _sampled_checksum(c.molecules[:c.n_molecules]))
-                     for chrom, c in chromosome2compressed_snp_calls.items()),
+    policy = resident_policy() if (shared and raw and reduce_molecule_counts is None) else '0'
+    if policy == 'full':
+        key = ('full', tuple((chrom, int(c.n_snp_calls), int(c.n_molecules), _content_hash(c.snp_calls[:c.n_snp_calls]),
+                              _content_hash(c.molecules[:c.n_molecules])) for chrom, c in chromosome2compressed_snp_calls.items()),
+               _var2varid_fingerprint(genotypes.var2varid), genotypes.n_variants, genotypes.n_genotypes, int(n_barcodes),
+               bool(getattr(ctx, '_keep_molecule_calls', False)))
+    elif policy == 'sampled':
+        key = ('sampled', tuple((chrom, id(c.snp_calls), id(c.molecules), int(c.n_snp_calls), int(c.n_molecules),
+                                 _sampled_checksum(c.snp_calls[:c.n_snp_calls]), _sampled_checksum(c.molecules[:c.n_molecules]))
+                                for chrom, c in chromosome2compressed_snp_calls.items()),
                _var2varid_fingerprint(genotypes.var2varid), genotypes.n_variants, genotypes.n_genotypes, int(n_barcodes),
                bool(getattr(ctx, '_keep_molecule_calls', False)))
     if key is not None and getattr(ctx, '_resident_key', None) == key:

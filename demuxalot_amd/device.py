@@ -37,7 +37,9 @@ class DeviceContext:
         bit-identical genotype additions of the hottest variants (several work items) cost ~4 % per EM iteration
         (include/demux_hip.h: dmx_set_exact_additions; default: with the exact E-step); DEMUXALOT_AMD_ESTEP_SCHEDULE = direct | auto | tiled
         (dmx_set_estep_schedule); DEMUXALOT_AMD_ESTEP_DICT = never | auto | always (dmx_set_estep_dictionary);
-        DEMUXALOT_AMD_ESTEP_PACKED = never | auto | always (dmx_set_estep_packing)."""
+        DEMUXALOT_AMD_ESTEP_PACKED = never | auto | always (dmx_set_estep_packing); DEMUXALOT_AMD_COARSE_PASS = 1 | 0: the guarded
+        mode's binary16 pass for E-steps whose logits nobody reads (dmx_set_coarse_pass; default on); DEMUXALOT_AMD_MSTEP_INCREMENTAL
+        = 1 | 0: the tile-major M-step keeps its integer sums and adds differences (dmx_set_mstep_incremental; default on)."""
         mode = os.environ.get('DEMUXALOT_AMD_ESTEP', '') or DEFAULT_ESTEP_MODE
         assert mode in ('exact', 'fast', 'guarded'), f'DEMUXALOT_AMD_ESTEP={mode!r}: exact, fast or guarded'
         self.set_estep_mode(mode)
@@ -48,8 +50,8 @@ class DeviceContext:
         self.set_estep_schedule(os.environ.get('DEMUXALOT_AMD_ESTEP_SCHEDULE', 'auto'))
         self.set_estep_dictionary(os.environ.get('DEMUXALOT_AMD_ESTEP_DICT', 'auto'))
         self.set_estep_packing(os.environ.get('DEMUXALOT_AMD_ESTEP_PACKED', 'auto'))
-        self.set_coarse_pass(True)
-        self.set_mstep_incremental(True)
+        self.set_coarse_pass(os.environ.get('DEMUXALOT_AMD_COARSE_PASS', '1') != '0')
+        self.set_mstep_incremental(os.environ.get('DEMUXALOT_AMD_MSTEP_INCREMENTAL', '1') != '0')
         self.set_phase_timers(False)
         self.set_logits_needed(True)
 
@@ -662,6 +664,12 @@ def get_context(device=None) -> DeviceContext:
 
 
 shared_context_lock = threading.RLock()
+
+
+def shared_contexts():
+    """The process-wide contexts created so far, one per device (demux.py: invalidate_resident)."""
+    with _contexts_lock:
+        return list(_contexts.values())
 
 # Private contexts (a DevicePosteriors, a staged_genotype_learning generator) come from a small pool: a context that
 # has been used keeps its stream and, through the runtime's allocator, the address ranges of its buffers, and

@@ -112,7 +112,13 @@ class ProbabilisticGenotypes:
             row = len(self.var2varid)
             self.var2varid[(chrom, pos, base)] = row
             self.extend_variants(0)
+            self.invalidate()
         return row
+
+    def invalidate(self):
+        """Drops the key arrays the front-end keeps on this object between calls (demux.py: _cached_variant_keys).  Every method
+        here that changes var2varid calls it; call it yourself after editing var2varid by hand."""
+        self.__dict__.pop('_amd_variant_keys', None)
 
     def extend_variants(self, n_samples=1):
         """Makes room for n_samples more rows than are registered (the table doubles, as the reference's does)."""
@@ -282,6 +288,7 @@ class ProbabilisticGenotypes:
             if key not in self.var2varid:
                 self.extend_variants(1)
                 self.var2varid[key] = self.n_variants
+                self.invalidate()
             rows.append(self.var2varid[key])
         for g, name in enumerate(self.genotype_names):
             if name in prior.columns:

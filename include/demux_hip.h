@@ -80,6 +80,11 @@ int dmx_pack_calls_host(int64_t n_variants, const int32_t *var_chrom, const int3
                         int64_t *n_unique, int32_t *out_variant, int32_t *out_cb, float *out_p, int64_t *out_count,
                         int64_t *mol_per_variant);
 
+/* 64-bit content hash of a host buffer, computed on `threads` host threads (0: up to 16) at memory bandwidth.  What the
+ * Python front-end keys the resident packed problem with: the reference re-packs on every call (demux.py:303), so the
+ * problem of an earlier call is reused only when EVERY record of every container hashes as it did. */
+int dmx_hash_host(const void *data, int64_t bytes, int32_t threads, uint64_t *hash_out);
+
 /* ------------------------------------------------------------------------- *
  * Problem upload.  The calls come as the reference's `barcode_calls` columns
  * (variant_id, compressed_cb, p_base_wrong; demux.py:290-300), in any order; the
