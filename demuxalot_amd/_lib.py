@@ -1,4 +1,4 @@
-"""ctypes binding of libdemux_hip.so (C ABI: include/demux_hip.h).
+"""ctypes binding of libdemux_hip.so (C ABI: include/demux_hip.h; test / tuning surface: include/demux_hip_debug.h).
 
 There is no CPU fallback: if the shared library is missing, or no MI355X is visible when a
 device context is requested, the calls raise.  Host-only entry points (dmx_pack_calls_host)
@@ -74,21 +74,25 @@ SIGNATURES = {
     'dmx_comm_unique_id': (c_int, [_P]),
     'dmx_comm_init': (c_int, [_P, c_int, c_int, _P, c_int]),
     'dmx_comm_init_host': (c_int, [_P, c_int, c_int, _P, _P, c_int]),
-    'dmx_comm_init_emulated': (c_int, [_P, c_int, c_int, c_double, c_double, c_int]),
     'dmx_get_timings': (c_int, [_P, POINTER(c_double), POINTER(c_int64)]),
     'dmx_reset_timings': (c_int, [_P]),
     'dmx_set_phase_timers': (c_int, [_P, c_int]),
     'dmx_set_logits_needed': (c_int, [_P, c_int]),
-    'dmx_get_guard_probes': (c_int, [_P, POINTER(c_int64), POINTER(c_int64)]),
-    'dmx_debug_set_pass_ms': (c_int, [_P, c_double, c_double, c_double]),
     'dmx_device_bytes': (c_int, [_P, POINTER(c_int64)]),
     'dmx_trim_cache': (c_int, [_P, POINTER(c_int64)]),
     'dmx_release_problem': (c_int, [_P]),
     'dmx_trim_device_caches': (c_int, [c_int, POINTER(c_int64)]),
     'dmx_set_exact_additions': (c_int, [_P, c_int]),
-    'dmx_get_redo_count': (c_int, [_P, POINTER(c_int64)]),
     'dmx_set_estep_mode': (c_int, [_P, c_int]),
     'dmx_get_guard_stats': (c_int, [_P, POINTER(c_int64), POINTER(c_int64), POINTER(c_int64)]),
+    'dmx_set_msteps_expected': (c_int, [_P, c_int64]),
+}
+# every symbol include/demux_hip_debug.h declares (tests, bench.py, scripts: switches, controller read-outs, self-tests)
+DEBUG_SIGNATURES = {
+    'dmx_comm_init_emulated': (c_int, [_P, c_int, c_int, c_double, c_double, c_int]),
+    'dmx_get_guard_probes': (c_int, [_P, POINTER(c_int64), POINTER(c_int64)]),
+    'dmx_debug_set_pass_ms': (c_int, [_P, c_double, c_double, c_double]),
+    'dmx_get_redo_count': (c_int, [_P, POINTER(c_int64)]),
     'dmx_set_guard_adaptive': (c_int, [_P, c_int]),
     'dmx_set_coarse_pass': (c_int, [_P, c_int]),
     'dmx_set_mstep_incremental': (c_int, [_P, c_int]),
@@ -102,7 +106,6 @@ SIGNATURES = {
     'dmx_set_mstep_wide_addresses': (c_int, [_P, c_int]),
     'dmx_set_mstep_tiles': (c_int, [_P, c_int]),
     'dmx_get_mstep_form': (c_int, [_P, POINTER(c_int32)]),
-    'dmx_set_msteps_expected': (c_int, [_P, c_int64]),
     'dmx_get_mstep_tiles_info': (c_int, [_P, POINTER(c_int32), POINTER(c_double)]),
     'dmx_test_logf': (c_int, [_P, _P, _P, c_int64]),
     'dmx_test_logf_hot': (c_int, [_P, _P, _P, c_int64]),
@@ -130,7 +133,7 @@ def load():
         # "hipIpcGetMemHandle: invalid argument" otherwise); read by the HSA runtime when it starts, i.e. below
         os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
         lib = ctypes.CDLL(LIB_PATH)
-        for name, (res, args) in SIGNATURES.items():
+        for name, (res, args) in {**SIGNATURES, **DEBUG_SIGNATURES}.items():
             fn = getattr(lib, name)
             fn.restype = res
             fn.argtypes = args

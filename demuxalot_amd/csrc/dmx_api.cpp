@@ -437,7 +437,7 @@ void timer_flush(dmx_ctx *c, int slot)
     t.pending.clear();
 }
 
-void timer_end(dmx_ctx *c, int slot, TimerSpan ev)
+void timer_end(dmx_ctx *c, int slot, TimerSpan &ev)
 {
     TimerSlot &t = c->timers[slot];
     if (ev.first == nullptr) {  // (the timers were off when the phase began)
@@ -449,8 +449,24 @@ void timer_end(dmx_ctx *c, int slot, TimerSpan ev)
     c->boundary = ev.second;
     t.pending.push_back(ev);
     t.launches++;
+    t.timed++;
+    ev.first = ev.second = nullptr;  // (handed to the slot: SpanGuard has nothing to give back)
     if (t.pending.size() >= 4096) timer_flush(c, slot);
 }
+
+// A phase that leaves through an error return between timer_begin and timer_end (HIP_TRY / DMX_TRY) still holds a reference to
+// its opening stamp: without this the stamp never returned to idle_stamps and its event was never destroyed.
+struct SpanGuard {
+    dmx_ctx *c;
+    TimerSpan *ev;
+    ~SpanGuard()
+    {
+        if (ev->first != nullptr) {
+            stamp_release(c, ev->first);
+            ev->first = nullptr;
+        }
+    }
+};
 
 // incremental M-step: the sums, the posteriors they were formed from, the work lists (run_mstep allocates them at first use)
 static void release_incremental(dmx_ctx *c)
@@ -1126,7 +1142,8 @@ int run_pstep(dmx_ctx *c, float lo, float hi, bool with_addition, bool with_half
     with_half = with_half && !c->sliced;
     if (with_half) DMX_TRY(ensure_prob16(c));
     c->prob16_valid = false;
-    TimerSpan ev;
+    TimerSpan ev{nullptr, nullptr};
+    SpanGuard ev_guard{c, &ev};
     timer_begin(c, DMX_T_PSTEP, &ev);
     const long long v0 = c->sliced ? c->cut[c->rank] : 0, v1 = c->sliced ? c->cut[c->rank + 1] : c->V;
     if (c->emulated && c->sliced && !c->emu_table_filled) {
@@ -1300,7 +1317,8 @@ int run_estep(dmx_ctx *c, int with_doublets, bool with_prior, int prior_dtype, f
     a.dtab_pitch = 0;
     a.dict = nullptr;
     a.codes = nullptr;
-    TimerSpan ev;
+    TimerSpan ev{nullptr, nullptr};
+    SpanGuard ev_guard{c, &ev};
     timer_begin(c, DMX_T_ESTEP, &ev);
     int form = DMX_FORM_DIRECT;
     DMX_TRY(prepare_dictionary(c, with_doublets != 0, a, &form));  // part of the E-step's time
@@ -1416,7 +1434,8 @@ int gather_posteriors(dmx_ctx *c)
     if (!c->mshard || c->post_gathered) return 0;
     const int G = c->G, W = (G + 63) / 64;
     const size_t rows = (size_t)c->rows_pad;
-    TimerSpan ev;
+    TimerSpan ev{nullptr, nullptr};
+    SpanGuard ev_guard{c, &ev};
     timer_begin(c, DMX_T_ALLREDUCE, &ev);
     int rc = 0;
     if (c->emulated && !c->emu_post_filled) {
@@ -1475,7 +1494,8 @@ int run_mstep(dmx_ctx *c, float power)
     }
     DMX_TRY(gather_posteriors(c));
     c->add_is_zero = false;
-    TimerSpan ev;
+    TimerSpan ev{nullptr, nullptr};
+    SpanGuard ev_guard{c, &ev};
     const bool dist = c->attached();  // also with one rank: keeps the collective path testable on one GPU
     unsigned long long *redo = c->exact_additions ? c->d_redo : nullptr;
     a.item_variant = nullptr;
@@ -2619,7 +2639,8 @@ int dmx_get_timings(dmx_ctx *c, double *ms, int64_t *launches)
     HIP_TRY(hipStreamSynchronize(c->stream));
     for (int s = 0; s < DMX_T_COUNT; s++) {
         timer_flush(c, s);
-        if (ms) ms[s] = c->timers[s].ms;
+        // -1: launches ran in this slot, none of them between events (the phase timers were off: dmx_set_phase_timers)
+        if (ms) ms[s] = (c->timers[s].launches > 0 && c->timers[s].timed == 0) ? -1.0 : c->timers[s].ms;
         if (launches) launches[s] = c->timers[s].launches;
     }
     return 0;
@@ -2638,6 +2659,7 @@ int dmx_reset_timings(dmx_ctx *c)
         timer_flush(c, s);
         c->timers[s].ms = 0.0;
         c->timers[s].launches = 0;
+        c->timers[s].timed = 0;
     }
     return 0;
 }

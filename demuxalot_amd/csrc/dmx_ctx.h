@@ -46,6 +46,7 @@ struct TimerSlot {
     std::vector<TimerSpan> pending;
     double ms = 0.0;
     int64_t launches = 0;
+    int64_t timed = 0;  // launches that were bracketed by events (phase timers on)
 };
 
 struct dmx_ctx {

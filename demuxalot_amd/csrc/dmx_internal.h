@@ -5,6 +5,7 @@
 #include <cstdio>
 
 #include "demux_hip.h"
+#include "demux_hip_debug.h"
 
 namespace dmx {
 

@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 
 #include "demux_hip.h"
+#include "demux_hip_debug.h"
 
 namespace dmx {
 

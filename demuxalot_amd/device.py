@@ -573,7 +573,8 @@ class DeviceContext:
         check(self._lib.dmx_set_phase_timers(self._h, int(bool(on))))
 
     def timings(self):
-        """{phase: {ms, launches}} since reset_timings(); ms only of the phases that ran with set_phase_timers(True)."""
+        """{phase: {ms, launches}} since reset_timings(); ms only of the phases that ran with set_phase_timers(True), -1 when
+        the phase ran but never with the timers on (dmx_get_timings)."""
         ms = (ctypes.c_double * _lib.T_COUNT)()
         n = (ctypes.c_int64 * _lib.T_COUNT)()
         check(self._lib.dmx_get_timings(self._h, ms, n))

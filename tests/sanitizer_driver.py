@@ -27,7 +27,7 @@ LIB = os.path.join(ROOT, 'demuxalot_amd', 'libdemux_host_asan.so')
 
 def load():
     lib = ctypes.CDLL(LIB)
-    for name, (res, args) in _lib.SIGNATURES.items():
+    for name, (res, args) in {**_lib.SIGNATURES, **_lib.DEBUG_SIGNATURES}.items():
         if hasattr(lib, name):  # the .hip translation units' entry points (results, aggregate_on_snps) are not in this build
             fn = getattr(lib, name)
             fn.restype, fn.argtypes = res, args

@@ -56,6 +56,42 @@ def test_predict_learn_predict_packs_once_and_every_change_of_the_inputs_repacks
     calls[name].snp_calls['p_base_wrong'][:calls[name].n_snp_calls] = saved
     predict()
     assert len(packs) == 4
+    # ONE record in the middle of a container edited in place (advisor, round 5: a sampled checksum does not see it): the key is
+    # the content hash of every record
+    n_calls = calls[name].n_snp_calls
+    middle = n_calls // 2 + 1
+    kept = calls[name].snp_calls['p_base_wrong'][middle]
+    calls[name].snp_calls['p_base_wrong'][middle] = np.float32(0.25) if kept != np.float32(0.25) else np.float32(0.125)
+    Demultiplexer.predict_posteriors(calls, genotypes, handler, p_genotype_clip=clip, doublet_prior=dp)
+    assert len(packs) == 5, 'a single edited record went unnoticed'
+    calls[name].snp_calls['p_base_wrong'][middle] = kept
+    kept_cb = calls[name].molecules['compressed_cb'][calls[name].n_molecules // 2]
+    calls[name].molecules['compressed_cb'][calls[name].n_molecules // 2] = (kept_cb + 1) % handler.n_barcodes
+    Demultiplexer.predict_posteriors(calls, genotypes, handler, p_genotype_clip=clip, doublet_prior=dp)
+    assert len(packs) == 6, 'a single edited molecule record went unnoticed'
+    calls[name].molecules['compressed_cb'][calls[name].n_molecules // 2] = kept_cb
+    predict()
+    assert len(packs) == 7
+    # the same records in OTHER arrays (copies): content-addressed, no identity in the key - not packed again
+    import copy
+    copies = {chrom: copy.deepcopy(c) for chrom, c in calls.items()}
+    logits_c, probs_c = Demultiplexer.predict_posteriors(copies, genotypes, handler, p_genotype_clip=clip, doublet_prior=dp)
+    fio.assert_bitwise(probs_c.values, fx['predict0_probs'], 'posteriors on copies of the containers')
+    assert len(packs) == 7
+    # the switches: invalidate_resident(), DEMUXALOT_AMD_RESIDENT=0
+    from demuxalot_amd import invalidate_resident
+    invalidate_resident()
+    predict()
+    assert len(packs) == 8
+    monkeypatch.setenv('DEMUXALOT_AMD_RESIDENT', '0')
+    predict()
+    predict()
+    assert len(packs) == 10
+    monkeypatch.delenv('DEMUXALOT_AMD_RESIDENT')
+    predict()   # (the calls above left no key behind)
+    predict()
+    assert len(packs) == 11
+    packs[:] = packs[:4]
     # another var2varid object with the same content: the keys are derived again, the result is the same
     genotypes.var2varid = dict(genotypes.var2varid)
     predict()

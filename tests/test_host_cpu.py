@@ -14,15 +14,28 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def test_library_exports_every_declared_symbol():
+    """Per header: demux_hip.h is what a front-end binds, demux_hip_debug.h the test / tuning surface.  Every
+    declared symbol is exported and bound with a signature, nothing is bound that no header declares, no test or debug name sits
+    in the public header, and the library exports no dmx_* symbol that neither header declares."""
+    import subprocess
     from demuxalot_amd import _lib
-    header = open(os.path.join(ROOT, 'include', 'demux_hip.h')).read()
-    declared = set(re.findall(r'\b(dmx_[a-z0-9_]+)\s*\(', header))
-    declared -= {'dmx_ctx', 'dmx_status'}
-    assert len(declared) >= 25
     lib = _lib.load()
-    for name in sorted(declared):
-        assert hasattr(lib, name), f'{name} is declared in include/demux_hip.h but not exported'
-    assert declared == set(_lib.SIGNATURES), declared ^ set(_lib.SIGNATURES)
+    both = set()
+    for header_name, signatures, at_least in (('demux_hip.h', _lib.SIGNATURES, 25), ('demux_hip_debug.h', _lib.DEBUG_SIGNATURES, 10)):
+        header = open(os.path.join(ROOT, 'include', header_name)).read()
+        declared = set(re.findall(r'^(?:int|const char \*)\s*(dmx_[a-z0-9_]+)\s*\(', header, flags=re.M))
+        assert len(declared) >= at_least
+        for name in sorted(declared):
+            assert hasattr(lib, name), f'{name} is declared in include/{header_name} but not exported'
+        assert declared == set(signatures), (header_name, declared ^ set(signatures))
+        assert not (declared & both), declared & both
+        both |= declared
+    public = set(_lib.SIGNATURES)
+    assert not [n for n in public if n.startswith(('dmx_test_', 'dmx_debug_')) or 'emulated' in n], 'test / debug names in the public header'
+    assert len(public) <= 64, len(public)
+    nm = subprocess.run(['nm', '-D', '--defined-only', _lib.LIB_PATH], capture_output=True, text=True, check=True).stdout
+    exported = set(re.findall(r'\bT (dmx_[a-z0-9_]+)$', nm, flags=re.M))
+    assert exported == both, exported ^ both
     assert lib.dmx_version().decode().startswith('demux_hip')
 
 
@@ -237,3 +250,55 @@ def test_variant_key_columns_follow_the_dict_walk():
     g.variant_betas = np.zeros((len(keys) + 1, 2), dtype=np.float32)
     with pytest.raises(KeyError):
         _variant_keys(g)
+
+
+def test_content_hash_sees_every_byte_and_does_not_depend_on_the_thread_count():
+    """dmx_hash_host keys the resident packed problem (demuxalot_amd/demux.py: _pack_on_device): any single edited byte must
+    change it, the same bytes in another array must not, and the number of hashing threads must not matter."""
+    import ctypes
+    from demuxalot_amd import _lib
+    from demuxalot_amd.demux import _content_hash
+    lib = _lib.load()
+    rng = np.random.default_rng(5)
+    data = rng.integers(0, 256, size=9_000_001, dtype=np.uint8)   # several 1 MiB chunks and a ragged tail
+    want = _content_hash(data)
+    assert _content_hash(data.copy()) == want
+    for threads in (1, 2, 3, 7, 16):
+        out = ctypes.c_uint64(0)
+        _lib.check(lib.dmx_hash_host(data.ctypes.data, data.nbytes, threads, ctypes.byref(out)))
+        assert out.value == want, threads
+    for position in (0, 1, 31, 32, 33, 4_500_000, (1 << 20) - 1, 1 << 20, len(data) - 2, len(data) - 1):
+        edited = data.copy()
+        edited[position] ^= 1
+        assert _content_hash(edited) != want, position
+    assert _content_hash(data[:-1]) != want and _content_hash(np.concatenate([data, np.zeros(1, np.uint8)])) != want
+    assert _content_hash(data[:0]) == _content_hash(np.zeros(0, np.float32))
+    records = np.zeros(1000, dtype=[('a', 'i4'), ('b', 'f4'), ('c', 'u1')])   # a record array with padding-free odd item size
+    h0 = _content_hash(records)
+    records['c'][517] = 1
+    assert _content_hash(records) != h0
+    out = ctypes.c_uint64(0)
+    assert lib.dmx_hash_host(None, 8, 0, ctypes.byref(out)) != 0 and lib.dmx_hash_host(data.ctypes.data, -1, 0, ctypes.byref(out)) != 0
+
+
+def test_variant_key_cache_is_dropped_by_the_mutators_and_sees_an_edit_in_the_middle():
+    from demuxalot_amd import ProbabilisticGenotypes
+    from demuxalot_amd.demux import _var2varid_fingerprint
+    genotypes = ProbabilisticGenotypes(['a', 'b', 'c'])
+    for pos in range(5000):
+        genotypes.get_variant_id('chr1', pos, 'ACGT'[pos % 4])
+    genotypes._amd_variant_keys = ('stale',)
+    genotypes.get_variant_id('chr1', 17, 'A' if 17 % 4 else 'C')      # a new variant: the kept arrays go
+    assert getattr(genotypes, '_amd_variant_keys', None) is None
+    genotypes._amd_variant_keys = ('stale',)
+    genotypes.get_variant_id('chr1', 0, 'A')                          # an existing one: nothing changed, nothing dropped
+    assert genotypes._amd_variant_keys == ('stale',)
+    genotypes.invalidate()
+    assert getattr(genotypes, '_amd_variant_keys', None) is None
+    # entries re-pointed in the middle of the mapping at unchanged length and ends: a strided sample of the items is in the fingerprint
+    before = _var2varid_fingerprint(genotypes.var2varid)
+    keys = list(genotypes.var2varid)
+    stride = max(1, len(keys) // 61)
+    a, b = keys[stride * 30], keys[stride * 31]
+    genotypes.var2varid[a], genotypes.var2varid[b] = genotypes.var2varid[b], genotypes.var2varid[a]
+    assert _var2varid_fingerprint(genotypes.var2varid) != before
