@@ -440,7 +440,11 @@ def e2e_timing(problem, doublet_prior, n_iterations=5):
         t_frames, _ = timed(lambda: (pd.DataFrame(lg, index=list(handler.ordered_barcodes), columns=columns),
                                      pd.DataFrame(pr, index=list(handler.ordered_barcodes), columns=columns)))
         pen0 = Demultiplexer._doublet_penalties(genotypes.n_genotypes, 0.)
-        t_em, _ = timed(lambda: (ctx.em(n_iterations, 0.01, pen0, with_doublets=False, fetch_logits=False, fetch_probs=False), ctx.synchronize()))
+        # the EM call exactly as learn_genotypes makes it (demuxalot_amd/demux.py): no logits wanted, posteriors and addition left on the
+        # device (the learnt table is formed there: dmx_get_learnt_betas); round 5 timed it with the 51 MB addition downloaded
+        ctx.set_logits_needed(False)
+        t_em, _ = timed(lambda: (ctx.em(n_iterations, 0.01, pen0, with_doublets=False, fetch_logits=False, fetch_probs=False, fetch_addition=False), ctx.synchronize()))
+        ctx.set_logits_needed(True)
     finally:
         release_private_context(ctx)
     return {
@@ -646,6 +650,8 @@ def compact_line(full, details_path=None):
         'parity_timed': full.get('parity_timed'),
         'parity_on_sample': full.get('parity_on_sample'),
     }
+    if cfg.get('rccl_fallback'):
+        line['config']['rccl_fallback'] = str(cfg['rccl_fallback'])[:120]
     if full.get('weak'):
         line['weak'] = {k: full['weak'].get(k) for k in ('value', 'ms_per_step', 'barcodes_total', 'exchange_ms_per_step')}
     if full.get('exchange_ms_per_step'):

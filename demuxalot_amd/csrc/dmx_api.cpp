@@ -1321,7 +1321,12 @@ int run_estep(dmx_ctx *c, int with_doublets, bool with_prior, int prior_dtype, f
     SpanGuard ev_guard{c, &ev};
     timer_begin(c, DMX_T_ESTEP, &ev);
     int form = DMX_FORM_DIRECT;
-    DMX_TRY(prepare_dictionary(c, with_doublets != 0, a, &form));  // part of the E-step's time
+    // The dictionary form is exact and faster than the fine pass, but not than the COARSE pass (200k x 100k x 64: 1.1 ms with its
+    // dictionary build against 0.75): an E-step whose logits nobody reads - the first of a dmx_em call of several iterations - takes
+    // the coarse pass like the ones behind it (its records are built here instead of one E-step later).
+    const bool coarse_first = c->estep_mode == DMX_ESTEP_GUARDED && !logits_kept && c->guard_adaptive && coarse_capable(c, with_doublets, c->p_clip_lo) &&
+                              a.n_bins > 0 && c->dict_mode == 1;
+    if (!coarse_first) DMX_TRY(prepare_dictionary(c, with_doublets != 0, a, &form));  // part of the E-step's time
     if (form == DMX_FORM_DICT)
         HIP_TRY(dmx::launch_estep_dict(c->stream, a, with_doublets != 0));
     else if (form == DMX_FORM_DICT_BLOCK)
@@ -1373,8 +1378,9 @@ int run_estep(dmx_ctx *c, int with_doublets, bool with_prior, int prior_dtype, f
                 c->cap_coarse_stream = words;
                 DMX_TRY(dev_alloc(c, &c->d_coarse_bin_ptr, (size_t)c->n_bins + 1));
                 DMX_TRY(dev_alloc(c, &c->d_log2_keep, (size_t)c->B));
-                HIP_TRY(dmx::launch_build_coarse_stream(c->stream, c->d_tile_stream, c->d_bin_ptr, c->n_bins, a.prob_bytes, cpg, c->d_coarse_bin_ptr, c->d_coarse_stream));
-                HIP_TRY(dmx::launch_barcode_log2_keep(c->stream, c->d_call_pairs, c->d_pair_ptr, c->B, c->d_log2_keep));
+                // (the barcodes' sums of log2 keep come out of the same pass: every call's keep factor is read there once)
+                HIP_TRY(dmx::launch_build_coarse_stream(c->stream, c->d_tile_stream, c->d_bin_ptr, c->n_bins, a.prob_bytes, cpg, c->d_coarse_bin_ptr, c->d_coarse_stream,
+                                                        c->d_bin_rows, c->bin_rows_cap, c->d_log2_keep));
                 c->coarse_ready = true;
             }
             if (allow_coarse) DMX_TRY(ensure_prob16(c));
@@ -1507,6 +1513,9 @@ int run_mstep(dmx_ctx *c, float power)
     // where k_mcombine writes: the variants of one work item are written there by the M-step kernels themselves
     a.item_variant = c->d_item_variant;
     a.redo_cap = c->cap_redo;
+    a.fixed_shift_v = nullptr;
+    a.fixed_acc64 = nullptr;
+    a.fixed_state = nullptr;
     // tile-major form (kernels.h: MTileArgs): sums in any order, so not with the exact additions; built on first use
     a.tiles_done = false;
     dmx::MTileArgs tiles{};
@@ -1548,9 +1557,20 @@ int run_mstep(dmx_ctx *c, float power)
         if (f64) a.out64 = c->d_add64;
         else a.out32 = c->d_add;
     }
+    // Fixed-point WORK-ITEM form (kernels.h: MstepArgs::fixed_shift_v): where the tile-major records are not there - a call too short
+    // to pay for their sort, learn_genotypes' default of 5 iterations among them - the work items add the tile-major form's integers
+    // with the tile cut's exponents (plan_mstep_shifts: the host's cut, no sort), so that their sums are the tile-major form's bit for
+    // bit and the incremental M-step builds on them: one full pass of 0.7 ms, then delta passes, instead of 0.7 ms per M-step.
+    // (dmx_set_mstep_tiles(ctx, 0) or dmx_set_mstep_incremental(ctx, 0): the float64 work-item form, as before.)
+    bool fixed_items = !a.tiles_done && c->mstep_tiles != 0 && c->mstep_incremental && !c->exact_additions && c->G <= 64 && c->n_csc > 0 &&
+                       power > 0.0f && !dist && !mshard && !c->sliced && a.out32 == c->d_add && c->d_call_rows != nullptr && c->d_item_variant != nullptr;
+    if (fixed_items) {
+        DMX_TRY(dmx::plan_mstep_shifts(c));
+        fixed_items = c->d_mt_shift_v != nullptr;
+    }
     // Incremental form (kernels.h: MIncrArgs): one context with all calls of its barcodes, the tiles' per-variant exponents at hand.
-    const bool incremental = a.tiles_done && c->mstep_incremental && !dist && !c->sliced && c->d_mt_shift_v != nullptr && a.out32 == c->d_add &&
-                             c->d_call_rows != nullptr;
+    const bool incremental = (a.tiles_done || fixed_items) && c->mstep_incremental && !dist && !c->sliced && c->d_mt_shift_v != nullptr &&
+                             a.out32 == c->d_add && c->d_call_rows != nullptr;
     dmx::MIncrArgs incr{};
     if (incremental) {
         if (!c->d_acc64) {
@@ -1598,15 +1618,21 @@ int run_mstep(dmx_ctx *c, float power)
         incr.floor = dmx::mincr_floor(power);
         tiles.acc64 = c->d_acc64;
         tiles.incr_state = incr.state;
+        if (fixed_items) {
+            a.fixed_shift_v = c->d_mt_shift_v;
+            a.fixed_acc64 = c->d_acc64;
+            a.fixed_state = incr.state;
+        }
         c->mstep_incr_launches++;
     } else {
         c->incr_valid = false;  // (another form writes the addition: the kept sums no longer describe it)
     }
     timer_begin(c, DMX_T_MSTEP, &ev);
-    if (incremental) HIP_TRY(dmx::launch_mstep_incremental(c->stream, a, tiles, incr));
+    if (incremental && fixed_items) HIP_TRY(dmx::launch_mstep_items_incremental(c->stream, a, incr));
+    else if (incremental) HIP_TRY(dmx::launch_mstep_incremental(c->stream, a, tiles, incr));
     else if (a.tiles_done) HIP_TRY(dmx::launch_mstep_tiles(c->stream, a, tiles));
     else HIP_TRY(dmx::launch_mstep(c->stream, a));
-    c->mstep_form = a.tiles_done ? 2 : 1;
+    c->mstep_form = a.tiles_done ? 2 : (incremental && fixed_items ? 3 : 1);
     timer_end(c, DMX_T_MSTEP, ev);
     if (!dist) {
         timer_begin(c, DMX_T_MCOMBINE, &ev);

@@ -103,7 +103,7 @@ struct dmx_ctx {
     int *d_mt_first = nullptr;      // [n_mt + 1] first variant of every tile
     int *d_mt_order = nullptr;      // [n_mt] tiles by decreasing number of calls
     int *d_mt_shift = nullptr;      // [n_mt] fixed-point exponent of every tile (MTileArgs::shift)
-    unsigned char *d_mt_shift_v = nullptr;  // [V] the same per variant (incremental M-step; only when the tiles were built from one context's own records)
+    unsigned char *d_mt_shift_v = nullptr;  // [V] the same per variant (incremental M-step, fixed-point work-item form; one context's own records only)
     // incremental M-step (kernels.h: MIncrArgs): the tiles' integer sums and the posteriors they were formed from, kept between M-steps
     unsigned long long *d_acc64 = nullptr;  // [V, G]
     float *d_prev_post = nullptr;           // [B, G]
@@ -121,6 +121,7 @@ struct dmx_ctx {
     long long n_mt_stream = 0;      // records d_mt_stream holds room for (the calls; with the padding calls' slots when built from the barcode-major records)
     int mt_tv = 0;                  // variants per tile at most
     bool mt_tried = false;          // a build was attempted for the resident M-step records
+    bool mt_shift_tried = false;    // ... the tile cut for the exponents alone (plan_mstep_shifts)
     int mstep_tiles = 1;            // dmx_set_mstep_tiles: 0 never, 1 when building the records pays, 2 always
     long long msteps_done = 0;      // M-steps run on the resident problem
     int msteps_ahead = 0;           // M-steps the running dmx_em / dmx_run_iterations call still has to do (0 outside)
@@ -315,6 +316,7 @@ int install_mstep_records(dmx_ctx *c, const uint4 *d_rec, long long n, long long
 // tile-major M-step records of variants [v_lo, v_hi) (the ctx's M-step records must cover exactly those); leaves n_mt == 0
 // when the problem does not fit the form
 int build_mstep_tiles(dmx_ctx *c, long long v_lo, long long v_hi);
+int plan_mstep_shifts(dmx_ctx *c);  // the tiles' fixed-point exponents per variant without the tile-major records (fixed-point work-item M-step)
 void release_mstep_tiles(dmx_ctx *c);
 int build_snp_groups(dmx_ctx *c, const unsigned long long *vb_keys, const unsigned *src_idx, const float *src_p, long long m);
 int stage_containers_on_device(dmx_ctx *c, const dmx_call_container *parts, int n_parts);

@@ -134,10 +134,11 @@ hipError_t launch_estep_dict(hipStream_t, const EstepArgs &, bool) { return hipS
 hipError_t launch_estep_dict_block(hipStream_t, const EstepArgs &) { return hipSuccess; }
 hipError_t launch_mstep(hipStream_t, const MstepArgs &) { return hipSuccess; }
 hipError_t launch_mstep_incremental(hipStream_t, const MstepArgs &, const MTileArgs &, const MIncrArgs &) { return hipSuccess; }
+hipError_t launch_mstep_items_incremental(hipStream_t, const MstepArgs &, const MIncrArgs &) { return hipSuccess; }
 hipError_t launch_mstep_tiles(hipStream_t, const MstepArgs &, const MTileArgs &) { return hipSuccess; }
 hipError_t launch_guard_begin(hipStream_t, unsigned *, long long, int, int, int, int) { return hipSuccess; }
 hipError_t launch_prob_to_half(hipStream_t, const float *, long long, int, unsigned short *, const unsigned *) { return hipSuccess; }
-hipError_t launch_build_coarse_stream(hipStream_t, const CallPair *, const long long *, long long, unsigned, int, long long *, unsigned *) { return hipSuccess; }
+hipError_t launch_build_coarse_stream(hipStream_t, const CallPair *, const long long *, long long, unsigned, int, long long *, unsigned *, const int *, int, double *) { return hipSuccess; }
 hipError_t launch_barcode_log2_keep(hipStream_t, const CallPair *, const long long *, long long, double *) { return hipSuccess; }
 hipError_t launch_guard_stamp(hipStream_t, unsigned *, int) { return hipSuccess; }
 hipError_t launch_guard_compact(hipStream_t, unsigned *, const int *, unsigned, int *, const int *, long long) { return hipSuccess; }
@@ -285,10 +286,16 @@ int build_mstep_tiles(dmx_ctx *c, long long, long long)
     c->mt_tried = true;
     return 0;
 }
+int plan_mstep_shifts(dmx_ctx *c)
+{
+    c->mt_shift_tried = true;  // (no exponents: the float64 work-item form)
+    return 0;
+}
 void release_mstep_tiles(dmx_ctx *c)
 {
     c->n_mt = 0;
     c->mt_tried = false;
+    c->mt_shift_tried = false;
 }
 
 int install_mstep_records(dmx_ctx *c, const uint4 *rec, long long n, long long v_lo, long long v_hi)

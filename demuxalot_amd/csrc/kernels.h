@@ -259,6 +259,15 @@ struct MstepArgs {
     // posterior table beyond 4 GiB): always the call-parallel kernel.
     const unsigned long long *dense_calls;
     unsigned long long total_calls;
+    // FIXED-POINT work-item form (fixed_shift_v != nullptr; G <= 64, no exact additions): the items add the integers rint(c 2^shift)
+    // the tile-major kernel adds - shift = the variant's (MIncrArgs::shift_v) -, so their sums ARE the tile-major form's, bit for bit
+    // (integer addition does not care who adds in which order), without the tile-major records: what a call too short to pay for
+    // their sort runs, and what the incremental M-step (MIncrArgs) builds on there.  partial[] then holds 64-bit integers;
+    // k_mcombine adds them, converts once and leaves the sums in fixed_acc64.  fixed_state (nullable): the incremental M-step's
+    // state words - the launch stands back unless they ask for the full pass.
+    const unsigned char *fixed_shift_v;
+    unsigned long long *fixed_acc64;
+    const unsigned *fixed_state;
 };
 
 // A posterior p <= 2^-80 contributes (p * keep)^2 = +0 exactly for |keep| <= 32 (|p * keep| <= 2^-75, and a
@@ -296,7 +305,7 @@ hipError_t launch_estep(hipStream_t st, const EstepArgs &a, bool pairs);
 constexpr int coarse_calls_per_gather(int K) { return K > 64 ? 1 : K > 32 ? 2 : 4; }
 constexpr int coarse_batches_per_record(int cpg) { return cpg; }  // (kernels.hip: CoarseShape<CPG>::BPR)
 hipError_t launch_build_coarse_stream(hipStream_t st, const CallPair *stream, const long long *bin_ptr, long long n_bins, unsigned zero_off,
-                                      int cpg, long long *coarse_bin_ptr, unsigned *out);
+                                      int cpg, long long *coarse_bin_ptr, unsigned *out, const int *bin_rows, int R, double *log2_keep);
 hipError_t launch_barcode_log2_keep(hipStream_t st, const CallPair *pairs, const long long *pair_ptr, long long B, double *out);
 hipError_t launch_prob_to_half(hipStream_t st, const float *prob, long long rows, int G, unsigned short *out, const unsigned *skip);  // EstepArgs::prob16; *skip != 0: nothing
 hipError_t launch_softmax_rows(hipStream_t st, const EstepArgs &a);  // rows left as logits by the option-tile launches
@@ -368,6 +377,8 @@ enum { IS_N = 0,        // changed barcodes of this M-step
 // reference's power of 2; powers for which that is not a normal float32: 0 (every bit counts)
 inline float mincr_floor(float power) { return power * 126.0f > 52.0f ? exp2f(-52.0f / power) : 0.0f; }
 hipError_t launch_mstep_incremental(hipStream_t st, const MstepArgs &a, const MTileArgs &t, const MIncrArgs &x);
+// the same with the fixed-point work-item form as the full pass (MstepArgs::fixed_shift_v): no tile-major records needed
+hipError_t launch_mstep_items_incremental(hipStream_t st, const MstepArgs &a, const MIncrArgs &x);
 constexpr int MTILE_LDS_BYTES = 64 * 1024;  // accumulators of a tile: with the 12 KB of dense-call queues, two workgroups of 1024 threads per CU
 constexpr int MTILE_MAX_VARIANTS = 128;     // 7 bits of the record
 hipError_t launch_mstep_tiles(hipStream_t st, const MstepArgs &a, const MTileArgs &t);

@@ -1115,16 +1115,24 @@ __global__ __launch_bounds__(1024) void k_coarse_bin_ptr(const long long *__rest
     if (threadIdx.x == 1023) out[n_bins] = part[1023];
 }
 
-// one wavefront per bin: the bin's groups of the tile-major stream (4 CallPairs = 8 calls each) -> its records (coarse_walk)
+// one wavefront per bin: the bin's groups of the tile-major stream (4 CallPairs = 8 calls each) -> its records (coarse_walk), and -
+// every call's keep factor passes through exactly one lane here - the bin's barcodes' sums of log2 keep (EstepArgs::log2_keep;
+// a pass of its own over the barcode-major records until round 6: 0.3 ms of a cold 5-iteration call).  The logarithm is the
+// hardware's (v_log_f32: keep in [2^-24, 1]), summed in float64: the constant is the same for every option of a barcode, so it
+// cancels in the posteriors; the logits of a coarse E-step carry it, within 1e-7 per call of the float64 logarithm's.
 template <int CPG>
 __global__ __launch_bounds__(256) void k_build_coarse_stream(const CallPair *__restrict__ stream, const long long *__restrict__ bin_ptr,
                                                              const long long *__restrict__ coarse_bin_ptr, long long n_bins, unsigned zero_off,
-                                                             unsigned *__restrict__ out)
+                                                             unsigned *__restrict__ out, const int *__restrict__ bin_rows, int R,
+                                                             double *__restrict__ log2_keep)
 {
     using S = CoarseShape<CPG>;
+    __shared__ double sh_lk[4][TILE_R_MAX][64];
     const long long bin = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (bin >= n_bins) return;
     const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    for (int r = 0; r < R; r++) sh_lk[wave][r][lane] = 0.0;
     const long long g0 = bin_ptr[bin];
     const int n_groups = (int)(bin_ptr[bin + 1] - g0), n_rec = (n_groups + S::BPR - 1) / S::BPR;
     unsigned *dst = out + coarse_bin_ptr[bin] * (CPG * 16);
@@ -1143,6 +1151,7 @@ __global__ __launch_bounds__(256) void k_build_coarse_stream(const CallPair *__r
             if (keep > 0.0f) {
                 off = p.row_off[half];
                 r = flo / keep;  // keep = fl(1 - e) >= 2^-24, floor <= 1: r < 2^25, a product of 4 sums below 2^100
+                if (f >= S::GPB && (int)(tag & 15u) < R) sh_lk[wave][tag & 15u][lane] += (double)__builtin_amdgcn_logf(keep);  // (the lane that writes this call's r)
             } else if (keep == 0.0f) {
                 r = flo;  // p keep + floor = floor: the all-zero row
             } else {
@@ -1157,6 +1166,12 @@ __global__ __launch_bounds__(256) void k_build_coarse_stream(const CallPair *__r
             if (f == S::GPB) word = (word & ~15u) | (tag & 15u);  // r0: the batch's slot tag in its low 4 bits (every block carries it, block 0's is read)
         }
         dst[i] = word;
+    }
+    for (int r = 0; r < R; r++) {
+        double v = sh_lk[wave][r][lane];
+        for (int off = 32; off > 0; off >>= 1) v += shfl_xor_f64(v, off);
+        const int row = bin_rows[bin * R + r];
+        if (lane == 0 && row >= 0) log2_keep[row] = v;
     }
 }
 
@@ -1930,6 +1945,38 @@ static __device__ __forceinline__ bool dense_regime(const MstepArgs &a)
     return a.dense_calls != nullptr && 4ull * *a.dense_calls > a.total_calls;
 }
 
+// whether this M-step runs the full pass (k_mstep_tiles, or the fixed-point work-item form) instead of the delta pass: see MIncrArgs
+static __device__ __forceinline__ bool incr_full(const unsigned *state, const MstepArgs &a)
+{
+    const unsigned long long calls = ((unsigned long long)state[IS_CALLS + 1] << 32) | state[IS_CALLS];
+    if (state[IS_FORCE] != 0u) return dense_regime(a);
+    return state[IS_VALID] == 0u || 8ull * calls > a.total_calls || dense_regime(a);
+}
+
+// c in [0, 1] -> rint(c 2^shift) as an integer (k_mstep_tiles, k_mincr_delta and the fixed-point work-item form add the same
+// integers): adding 1.5 x 2^52 leaves the rounded value (ties to even) in the low bits of the sum's mantissa (c 2^shift < 2^51)
+static __device__ __forceinline__ unsigned long long fixed_of(float c, int shift)
+{
+    constexpr double MAGIC = 6755399441055744.0;
+    const double d = __builtin_ldexp((double)c, shift) + MAGIC;
+    return (unsigned long long)(__double_as_longlong(d) - __double_as_longlong(MAGIC));
+}
+
+// Where the integer sums of work item `item` go (fixed-point work-item form, MstepArgs::fixed_shift_v): a variant of ONE item is
+// finished here - its sums into fixed_acc64, converted once into the addition, as k_mstep_tiles writes them -, the others leave
+// their integers in the item's partial row for k_mcombine.
+static __device__ __forceinline__ void mstep_store_fixed(const MstepArgs &a, long long item, int g, unsigned long long acc, int shift)
+{
+    const long long v = a.item_variant[item];
+    if (a.item_ptr[v + 1] - a.item_ptr[v] == 1) {
+        const size_t o = (size_t)v * a.G + g;
+        a.out32[o] = (float)__builtin_ldexp((double)(long long)acc, -shift);
+        a.fixed_acc64[o] = acc;
+        return;
+    }
+    a.partial[(size_t)item * a.G + g] = __longlong_as_double((long long)acc);
+}
+
 // ------------------------------------------------------------------------------------
 // M-step, dense form (G <= 64, most posteriors alive): the call-parallel form below handles a call with more than 4
 // live posteriors one at a time through its queues (4.2 ms on 200k x 100k x 64 with uniform posteriors); here a
@@ -1991,10 +2038,11 @@ __global__ __launch_bounds__(256) void k_mstep_dense(MstepArgs a)
 // no request): no EXEC regions, nothing merged after a load (the compiler otherwise parks an s_waitcnt vmcnt(0)
 // behind the first conditional posterior gather of every chunk).  Needs the posterior table below 4 GiB and
 // barcode indices below 2^24 (launcher).
-template <bool SQUARE, int R, int D, bool BUF>
+template <bool SQUARE, int R, int D, bool BUF, bool FIXED = false>
 __global__ __launch_bounds__(256) void k_mstep_calls(MstepArgs a)
 {
     if (dense_regime(a)) return;
+    if (FIXED && a.fixed_state != nullptr && !incr_full(a.fixed_state, a)) return;  // the delta pass updates the sums (k_mincr_delta)
     constexpr int NZ_S = NZ_CODE;  // "sparse" call: at most this many non-zero posteriors
     typedef unsigned long long u64;
     __shared__ float sh_val[4][R * 64];
@@ -2013,6 +2061,12 @@ __global__ __launch_bounds__(256) void k_mstep_calls(MstepArgs a)
     const u64 bit = 1ull << lane;
     const u64 below = bit - 1ull;
     double acc = 0.0;
+    u64 acc_fixed = 0ull;  // FIXED: the sum of rint(c 2^shift), shift = the variant's (uniform: an item belongs to one variant)
+    const int shift = FIXED ? __builtin_amdgcn_readfirstlane((int)a.fixed_shift_v[a.item_variant[item]]) : 0;
+    auto accumulate = [&](float v) {
+        if constexpr (FIXED) acc_fixed += fixed_of(v, shift);
+        else acc += (double)v;
+    };
 
     auto power_of = [&](float c) { return SQUARE ? c * c : powf(c, a.power); };
     auto genotype = [](unsigned code, int t) { return (int)((code >> (7 + 6 * t)) & 63u); };
@@ -2188,10 +2242,10 @@ __global__ __launch_bounds__(256) void k_mstep_calls(MstepArgs a)
                 val[(r + 1) * 64 + lane] = 0.0f;
                 val[(r + 2) * 64 + lane] = 0.0f;
                 val[(r + 3) * 64 + lane] = 0.0f;
-                acc += (double)v0;
-                acc += (double)v1;
-                acc += (double)v2;
-                acc += (double)v3;
+                accumulate(v0);
+                accumulate(v1);
+                accumulate(v2);
+                accumulate(v3);
             }
         };
         auto put_sparse = [&](int mine) {
@@ -2262,7 +2316,10 @@ __global__ __launch_bounds__(256) void k_mstep_calls(MstepArgs a)
 #pragma unroll
         for (int t = 0; t < NZ_S; t++) ps0[t] = ps1[t];
     }
-    if (lane < G) mstep_store(a, item, lane, acc);
+    if (lane < G) {
+        if constexpr (FIXED) mstep_store_fixed(a, item, lane, acc_fixed, shift);
+        else mstep_store(a, item, lane, acc);
+    }
 }
 
 // ------------------------------------------------------------------------------------
@@ -2296,13 +2353,6 @@ __global__ __launch_bounds__(256) void k_mstep_calls(MstepArgs a)
 // fewer instructions): 0.34 ms as well (0.32 against 0.30 at 32 genotypes) - PMC: VALU 64 %, address unit 69 %, LDS 49 % busy.
 constexpr int MTILE_THREADS = 1024;
 constexpr int MTILE_QUEUE = 96;  // dense calls a wavefront parks before it takes their rows (64 + the flush threshold)
-// whether this M-step runs the full pass (k_mstep_tiles) instead of the delta pass: see MIncrArgs
-static __device__ __forceinline__ bool incr_full(const unsigned *state, const MstepArgs &a)
-{
-    const unsigned long long calls = ((unsigned long long)state[IS_CALLS + 1] << 32) | state[IS_CALLS];
-    if (state[IS_FORCE] != 0u) return dense_regime(a);
-    return state[IS_VALID] == 0u || 8ull * calls > a.total_calls || dense_regime(a);
-}
 
 template <bool SQUARE>
 __global__ __launch_bounds__(MTILE_THREADS) void k_mstep_tiles(MstepArgs a, MTileArgs t)
@@ -2602,10 +2652,20 @@ __global__ __launch_bounds__(256) void k_mcombine(const double *__restrict__ par
                                                   unsigned *__restrict__ n_redo, unsigned long long redo_cap,
                                                   const int *__restrict__ vlist, bool skip_single,
                                                   const unsigned long long *__restrict__ dense_calls, unsigned long long total_calls,
-                                                  bool only_dense)
+                                                  bool only_dense, const unsigned char *__restrict__ fixed_shift_v,
+                                                  unsigned long long *__restrict__ fixed_acc64, const unsigned *__restrict__ fixed_state)
 {
     // only_dense: k_mstep_tiles has written the sums, unless the dense regime's kernel (partial sums per item) took the launch
-    if (only_dense && !(dense_calls != nullptr && 4ull * *dense_calls > total_calls)) return;
+    const bool dense = dense_calls != nullptr && 4ull * *dense_calls > total_calls;
+    if (only_dense && !dense) return;
+    // fixed-point work-item form (MstepArgs::fixed_shift_v): the partials are 64-bit integers, unless the dense regime's kernel left
+    // float64 ones; when the incremental M-step's delta pass updated the sums (fixed_state) the partials are stale: nothing to combine
+    const bool fixed = fixed_shift_v != nullptr && !dense;
+    if (fixed && fixed_state != nullptr) {
+        const unsigned long long calls = ((unsigned long long)fixed_state[IS_CALLS + 1] << 32) | fixed_state[IS_CALLS];
+        const bool full = fixed_state[IS_FORCE] != 0u ? false : (fixed_state[IS_VALID] == 0u || 8ull * calls > total_calls);
+        if (!full) return;
+    }
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < (v1 - v0) * G; i += (long long)gridDim.x * blockDim.x) {
         long long row;
         int g;
@@ -2619,6 +2679,13 @@ __global__ __launch_bounds__(256) void k_mcombine(const double *__restrict__ par
         const long long v = vlist ? (long long)vlist[v0 + row] : v0 + row;  // vlist: entries [v0, v1) of a list of variants
         const long long it0 = item_ptr[v], it1 = item_ptr[v + 1];
         if (skip_single && it1 - it0 == 1) continue;  // written by the item's own wavefront (mstep_store)
+        if (fixed) {  // integer partial sums: any order, one conversion (as k_mstep_tiles writes a tile's rows); a variant without calls: 0
+            unsigned long long q = 0ull;
+            for (long long it = it0; it < it1; it++) q += (unsigned long long)__double_as_longlong(partial[(size_t)it * G + g]);
+            add32[v * G + g] = (float)__builtin_ldexp((double)(long long)q, -(int)fixed_shift_v[v]);
+            fixed_acc64[v * G + g] = q;
+            continue;
+        }
         double s = 0.0;
         for (long long it = it0; it < it1; it++) s += partial[(size_t)it * G + g];
         const long long o = (prow ? (long long)prow[v] : v) * G + g;  // prow: padded rows of the multi-GPU exchange buffer
@@ -2949,17 +3016,17 @@ __global__ __launch_bounds__(256) void k_check_unit_range(const float *__restric
 }
 
 hipError_t launch_build_coarse_stream(hipStream_t st, const CallPair *stream, const long long *bin_ptr, long long n_bins, unsigned zero_off,
-                                      int cpg, long long *coarse_bin_ptr, unsigned *out)
+                                      int cpg, long long *coarse_bin_ptr, unsigned *out, const int *bin_rows, int R, double *log2_keep)
 {
     if (n_bins == 0) return hipSuccess;
     hipLaunchKernelGGL(k_coarse_bin_ptr, dim3(1), dim3(1024), 0, st, bin_ptr, n_bins, cpg, coarse_bin_ptr);  // (CoarseShape<CPG>::BPR == CPG)
     static_assert(CoarseShape<1>::BPR == 1 && CoarseShape<2>::BPR == 2 && CoarseShape<4>::BPR == 4, "coarse_batches_per_record");
     if (cpg == 1)
-        hipLaunchKernelGGL(k_build_coarse_stream<1>, dim3(blocks_for(n_bins, 4)), dim3(256), 0, st, stream, bin_ptr, coarse_bin_ptr, n_bins, zero_off, out);
+        hipLaunchKernelGGL(k_build_coarse_stream<1>, dim3(blocks_for(n_bins, 4)), dim3(256), 0, st, stream, bin_ptr, coarse_bin_ptr, n_bins, zero_off, out, bin_rows, R, log2_keep);
     else if (cpg == 2)
-        hipLaunchKernelGGL(k_build_coarse_stream<2>, dim3(blocks_for(n_bins, 4)), dim3(256), 0, st, stream, bin_ptr, coarse_bin_ptr, n_bins, zero_off, out);
+        hipLaunchKernelGGL(k_build_coarse_stream<2>, dim3(blocks_for(n_bins, 4)), dim3(256), 0, st, stream, bin_ptr, coarse_bin_ptr, n_bins, zero_off, out, bin_rows, R, log2_keep);
     else
-        hipLaunchKernelGGL(k_build_coarse_stream<4>, dim3(blocks_for(n_bins, 4)), dim3(256), 0, st, stream, bin_ptr, coarse_bin_ptr, n_bins, zero_off, out);
+        hipLaunchKernelGGL(k_build_coarse_stream<4>, dim3(blocks_for(n_bins, 4)), dim3(256), 0, st, stream, bin_ptr, coarse_bin_ptr, n_bins, zero_off, out, bin_rows, R, log2_keep);
     return hipGetLastError();
 }
 
@@ -3179,10 +3246,13 @@ hipError_t launch_mstep(hipStream_t st, const MstepArgs &a)
         const dim3 grid(blocks_for(a.n_items, 4));
         // 32-bit offsets: posterior table below 4 GiB, barcode index below 2^24 (v_mul_u32_u24), row below 2^24 bytes
         const bool buf = !a.wide && a.post_bytes < (1ull << 32) && a.first_bytes < (8ull << 24) && a.K < (1 << 22);
-#define MSTEP_CALLS(SQ)                                                                             \
-    do {                                                                                            \
-        if (buf) hipLaunchKernelGGL((k_mstep_calls<SQ, 16, 4, true>), grid, dim3(256), 0, st, a);   \
-        else hipLaunchKernelGGL((k_mstep_calls<SQ, 16, 4, false>), grid, dim3(256), 0, st, a);      \
+#define MSTEP_CALLS(SQ)                                                                                            \
+    do {                                                                                                           \
+        if (a.fixed_shift_v != nullptr) {                                                                          \
+            if (buf) hipLaunchKernelGGL((k_mstep_calls<SQ, 16, 4, true, true>), grid, dim3(256), 0, st, a);        \
+            else hipLaunchKernelGGL((k_mstep_calls<SQ, 16, 4, false, true>), grid, dim3(256), 0, st, a);           \
+        } else if (buf) hipLaunchKernelGGL((k_mstep_calls<SQ, 16, 4, true>), grid, dim3(256), 0, st, a);           \
+        else hipLaunchKernelGGL((k_mstep_calls<SQ, 16, 4, false>), grid, dim3(256), 0, st, a);                     \
     } while (0)
         if (a.square)
             MSTEP_CALLS(true);
@@ -3221,6 +3291,22 @@ hipError_t launch_mstep_incremental(hipStream_t st, const MstepArgs &a, const MT
     return hipGetLastError();
 }
 
+// the same sequence with the fixed-point work-item form as the full pass (no tile-major records): changes -> delta pass | the items'
+// full pass (exactly one of them works; k_mcombine, launched by the caller behind this, stands back with it) -> conversion / snapshot
+hipError_t launch_mstep_items_incremental(hipStream_t st, const MstepArgs &a, const MIncrArgs &x)
+{
+    if (a.n_items == 0 || x.B == 0 || a.fixed_shift_v == nullptr) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(k_mincr_changes, dim3(blocks_for(x.B, 64)), dim3(256), 0, st, a, x);
+    if (a.square)
+        hipLaunchKernelGGL((k_mincr_delta<true>), dim3(4096), dim3(256), 0, st, a, x);
+    else
+        hipLaunchKernelGGL((k_mincr_delta<false>), dim3(4096), dim3(256), 0, st, a, x);
+    const hipError_t e = launch_mstep(st, a);  // (stands back unless the full pass is due; + the dense regime's kernel)
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(k_mincr_finish, dim3(2048), dim3(256), 0, st, a, x);
+    return hipGetLastError();
+}
+
 hipError_t launch_mstep_tiles(hipStream_t st, const MstepArgs &a, const MTileArgs &t)
 {
     if (t.n_tiles == 0) return hipSuccess;
@@ -3252,7 +3338,7 @@ hipError_t launch_mcombine(hipStream_t st, const MstepArgs &a, const long long *
     const unsigned full_grid = blocks_for((v1 - v0) * a.G, 256);
     hipLaunchKernelGGL(k_mcombine, dim3(a.tiles_done ? std::min(full_grid, 1024u) : full_grid), dim3(256), 0, st, a.partial, item_ptr,
                        a.item_start, a.item_len, v0, v1, a.G, prow, add32, add64, redo, n_redo, a.redo_cap, vlist, skip_single,
-                       a.dense_calls, a.total_calls, a.tiles_done);
+                       a.dense_calls, a.total_calls, a.tiles_done, a.fixed_shift_v, a.fixed_acc64, a.fixed_state);
     if (!redo) return hipGetLastError();
     // exact mode: the sums that must be redone in the reference's order (see k_mcombine)
     const dim3 grid(512), block(64 * EXACT_WAVES);

@@ -768,69 +768,123 @@ void release_mstep_tiles(dmx_ctx *c)
     c->n_mt = 0;
     c->mt_tv = 0;
     c->mt_tried = false;
+    c->mt_shift_tried = false;
 }
 
 // Tiles of the tile-major M-step (kernels.h: MTileArgs): runs of at most tv variants and (where a run of variants allows) about
-// cap calls, cut on the host from the work items' offsets; then the M-step records once more, sorted by (tile, barcode row).
-int build_mstep_tiles(dmx_ctx *c, long long v_lo, long long v_hi)
+// cap calls, cut on the host from the work items' offsets - and with them the fixed-point exponent of every tile (k_mstep_tiles:
+// contributions in [0, 1] are added as rint(c 2^shift); the sum of the longest variant's n contributions stays below 2^63, and
+// c 2^shift below 2^51, the conversion's range).  false: the problem does not take the tile form (stay with the item form).
+namespace {
+struct TileCut {
+    std::vector<int> tile_first;        // [n_mt + 1]
+    std::vector<long long> tile_ptr;    // [n_mt + 1]
+    std::vector<unsigned> tile_of, vin_of;  // [V]
+    std::vector<int> tile_shift;        // [n_mt]
+    int tv = 0;
+    unsigned row_bits = 0;
+    long long n_mt = 0;
+};
+
+bool cut_mstep_tiles(dmx_ctx *c, long long v_lo, long long v_hi, TileCut &t)
 {
-    release_mstep_tiles(c);
-    c->mt_tried = true;
     const int G = c->G;
     const long long rows = c->mshard ? c->rows_total : c->B, m = c->n_csc;
-    if (G < 1 || G > 64 || rows >= (1LL << 24) || m == 0 || m >= (1LL << 32) || v_hi <= v_lo) return 0;
-    hipStream_t st = c->stream;
+    if (G < 1 || G > 64 || rows >= (1LL << 24) || m == 0 || m >= (1LL << 32) || v_hi <= v_lo) return false;
     const long long V = c->V;
     // first record of every variant: the repack left the variant-major offsets on the host (dmx_ctx::h_col_ptr)
-    if ((long long)c->h_col_ptr.size() != V + 1 || c->h_col_ptr[(size_t)V] != m) return 0;  // (not the resident records') stay with the item form
+    if ((long long)c->h_col_ptr.size() != V + 1 || c->h_col_ptr[(size_t)V] != m) return false;  // (not the resident records') stay with the item form
     const std::vector<long long> &first_call = c->h_col_ptr;
-    if (first_call[(size_t)v_lo] != 0 || first_call[(size_t)v_hi] != m) return 0;  // records outside the range: stay with the item form
+    if (first_call[(size_t)v_lo] != 0 || first_call[(size_t)v_hi] != m) return false;  // records outside the range: stay with the item form
     if (!c->n_simd) {
         int cus = 0;
-        HIP_TRY(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, c->device));
+        if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, c->device) != hipSuccess) return false;
         c->n_simd = 4 * cus;
     }
-    const int tv = std::max(1, std::min<int>(dmx::MTILE_MAX_VARIANTS, dmx::MTILE_LDS_BYTES / (G * 8)));
-    const unsigned row_bits = bits_for(rows ? (unsigned long long)rows - 1 : 0);
-    std::vector<int> tile_first;
-    std::vector<long long> tile_ptr;
-    std::vector<unsigned> tile_of((size_t)V, 0u), vin_of((size_t)V, 0u);
+    t.tv = std::max(1, std::min<int>(dmx::MTILE_MAX_VARIANTS, dmx::MTILE_LDS_BYTES / (G * 8)));
+    t.row_bits = bits_for(rows ? (unsigned long long)rows - 1 : 0);
+    t.tile_of.assign((size_t)V, 0u);
+    t.vin_of.assign((size_t)V, 0u);
     // at most a 1024th of the calls per tile (four tiles per CU and more: most tiles end at their 128 variants first; a tile costs
     // its 64 KB of accumulators zeroed and written back - 0.34 / 0.36 / 0.46 / 0.54 ms with caps of 1 / 2 / 3 / 6 per SIMD on
     // 200k x 100k x 64), as long as the sort key (tile, row) fits 32 bits
     long long cap = std::max<long long>(4096, m / std::max(1, c->n_simd));
     for (int attempt = 0;; attempt++) {
-        tile_first.clear();
-        tile_ptr.clear();
+        t.tile_first.clear();
+        t.tile_ptr.clear();
         long long v = v_lo;
         while (v < v_hi) {
-            tile_first.push_back((int)v);
-            tile_ptr.push_back(first_call[(size_t)v]);
+            t.tile_first.push_back((int)v);
+            t.tile_ptr.push_back(first_call[(size_t)v]);
             long long w = v + 1;  // a tile takes at least one variant, however many calls it has
-            while (w < v_hi && w - v < tv && first_call[(size_t)w + 1] - first_call[(size_t)v] <= cap) w++;
+            while (w < v_hi && w - v < t.tv && first_call[(size_t)w + 1] - first_call[(size_t)v] <= cap) w++;
             for (long long x = v; x < w; x++) {
-                tile_of[(size_t)x] = (unsigned)(tile_first.size() - 1);
-                vin_of[(size_t)x] = (unsigned)(x - v);
+                t.tile_of[(size_t)x] = (unsigned)(t.tile_first.size() - 1);
+                t.vin_of[(size_t)x] = (unsigned)(x - v);
             }
             v = w;
         }
-        const unsigned tile_bits = bits_for(tile_first.empty() ? 0 : (unsigned long long)tile_first.size() - 1);
-        if (tile_bits + row_bits <= 32) break;
-        if (cap >= m || attempt > 40) return 0;  // even the widest tiles are too many for a 32-bit key: item form
+        const unsigned tile_bits = bits_for(t.tile_first.empty() ? 0 : (unsigned long long)t.tile_first.size() - 1);
+        if (tile_bits + t.row_bits <= 32) break;
+        if (cap >= m || attempt > 40) return false;  // even the widest tiles are too many for a 32-bit key: item form
         cap *= 2;
     }
-    const long long n_mt = (long long)tile_first.size();
-    tile_first.push_back((int)v_hi);
-    tile_ptr.push_back(m);
-    // fixed-point exponent of every tile (k_mstep_tiles): contributions in [0, 1] are added as rint(c 2^shift); the sum of the
-    // longest variant's n contributions stays below 2^63, and c 2^shift below 2^51 (the conversion's range)
-    std::vector<int> tile_shift((size_t)n_mt);
-    for (long long i = 0; i < n_mt; i++) {
+    t.n_mt = (long long)t.tile_first.size();
+    t.tile_first.push_back((int)v_hi);
+    t.tile_ptr.push_back(m);
+    t.tile_shift.resize((size_t)t.n_mt);
+    for (long long i = 0; i < t.n_mt; i++) {
         long long longest = 1;
-        for (long long v = tile_first[(size_t)i]; v < tile_first[(size_t)i + 1]; v++)
+        for (long long v = t.tile_first[(size_t)i]; v < t.tile_first[(size_t)i + 1]; v++)
             longest = std::max(longest, first_call[(size_t)v + 1] - first_call[(size_t)v]);
-        tile_shift[(size_t)i] = std::min(50, 62 - (int)bits_for((unsigned long long)longest));
+        t.tile_shift[(size_t)i] = std::min(50, 62 - (int)bits_for((unsigned long long)longest));
     }
+    return true;
+}
+
+// [V] exponent of every variant's tile, on the device (MIncrArgs::shift_v, MstepArgs::fixed_shift_v)
+int upload_variant_shifts(dmx_ctx *c, const TileCut &t)
+{
+    const long long V = c->V;
+    std::vector<unsigned char> shift_v((size_t)V);
+    for (long long v = 0; v < V; v++) shift_v[(size_t)v] = (unsigned char)t.tile_shift[(size_t)t.tile_of[(size_t)v]];
+    if (!c->d_mt_shift_v) DMX_TRY(dev_alloc(c, &c->d_mt_shift_v, (size_t)V));
+    HIP_TRY(hipMemcpyAsync(c->d_mt_shift_v, shift_v.data(), (size_t)V, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));  // (the host vector)
+    return 0;
+}
+}  // namespace
+
+// The exponents alone, without the tile-major records (their sort): what the fixed-point WORK-ITEM form adds with (MstepArgs::
+// fixed_shift_v) - the same cut, so the same exponents the tile-major form uses should the records be built later.  Leaves
+// d_mt_shift_v null when the problem does not take the tile cut (the caller then stays with the float64 item form).
+int plan_mstep_shifts(dmx_ctx *c)
+{
+    if (c->d_mt_shift_v != nullptr || c->mt_shift_tried) return 0;
+    c->mt_shift_tried = true;
+    if (c->mshard || c->sliced) return 0;
+    TileCut t;
+    if (!cut_mstep_tiles(c, 0, c->V, t)) return 0;
+    return upload_variant_shifts(c, t);
+}
+
+int build_mstep_tiles(dmx_ctx *c, long long v_lo, long long v_hi)
+{
+    release_mstep_tiles(c);
+    c->mt_tried = true;
+    TileCut cut;
+    if (!cut_mstep_tiles(c, v_lo, v_hi, cut)) return 0;
+    const int G = c->G;
+    const long long m = c->n_csc;
+    hipStream_t st = c->stream;
+    const long long V = c->V;
+    const int tv = cut.tv;
+    const unsigned row_bits = cut.row_bits;
+    std::vector<int> &tile_first = cut.tile_first;
+    std::vector<long long> &tile_ptr = cut.tile_ptr;
+    std::vector<unsigned> &tile_of = cut.tile_of, &vin_of = cut.vin_of;
+    std::vector<int> &tile_shift = cut.tile_shift;
+    const long long n_mt = cut.n_mt;
     std::vector<int> order((size_t)n_mt);
     for (long long i = 0; i < n_mt; i++) order[(size_t)i] = (int)i;
     std::stable_sort(order.begin(), order.end(), [&](int x, int y) {
@@ -851,10 +905,7 @@ int build_mstep_tiles(dmx_ctx *c, long long v_lo, long long v_hi)
         DMX_TRY(sc.get(&keys, n));
         DMX_TRY(sc.get(&keys_out, n));
         DMX_TRY(sc.get(&vals, n));
-        std::vector<unsigned char> shift_v((size_t)V);
-        for (long long v = 0; v < V; v++) shift_v[(size_t)v] = (unsigned char)tile_shift[(size_t)tile_of[(size_t)v]];
-        DMX_TRY(dev_alloc(c, &c->d_mt_shift_v, (size_t)V));
-        HIP_TRY(hipMemcpyAsync(c->d_mt_shift_v, shift_v.data(), (size_t)V, hipMemcpyHostToDevice, st));
+        DMX_TRY(upload_variant_shifts(c, cut));
         for (long long v = 0; v < V; v++) tile_of[(size_t)v] = (tile_of[(size_t)v] << 7) | vin_of[(size_t)v];  // (vin < 128 = MTILE_MAX_VARIANTS)
         HIP_TRY(hipMemcpyAsync(d_tile_of, tile_of.data(), sizeof(unsigned) * V, hipMemcpyHostToDevice, st));
         DMX_TRY(dev_alloc(c, &vals_out, n));

@@ -551,10 +551,11 @@ class DeviceContext:
         return bool(built.value), ms.value
 
     def mstep_form(self):
-        """None | 'items' | 'tiles': the form of the last M-step launch (include/demux_hip.h: dmx_get_mstep_form)."""
+        """None | 'items' | 'tiles' | 'items_fixed' (the work items adding the tile-major form's integers, under the incremental
+        M-step: calls too short to pay for the tile-major records): the form of the last M-step launch (dmx_get_mstep_form)."""
         form = ctypes.c_int32(0)
         check(self._lib.dmx_get_mstep_form(self._h, ctypes.byref(form)))
-        return {0: None, 1: 'items', 2: 'tiles'}[form.value]
+        return {0: None, 1: 'items', 2: 'tiles', 3: 'items_fixed'}[form.value]
 
     def redo_count(self):
         """Sums the last exact-mode M-step redid in the reference's order (include/demux_hip.h: dmx_get_redo_count)."""

@@ -33,7 +33,8 @@ int dmx_get_redo_count(dmx_ctx *ctx, int64_t *count);
  * dmx_get_mstep_tiles_info: whether the records exist and the host wall time their build took. */
 int dmx_set_mstep_tiles(dmx_ctx *ctx, int enable);
 int dmx_get_mstep_tiles_info(dmx_ctx *ctx, int32_t *built, double *build_ms);
-/* form of the last M-step launch: 0 none yet, 1 work items, 2 tiles (the dense regime's kernel may still have taken either) */
+/* form of the last M-step launch: 0 none yet, 1 work items (float64 partial sums), 2 tiles, 3 work items adding the tile-major form's
+ * integers under the incremental M-step (the dense regime's kernel may still have taken any of them) */
 int dmx_get_mstep_form(dmx_ctx *ctx, int32_t *form);
 
 /* Worst case of the guarded mode.  With the fast pass taking F, the exact kernel over every barcode E, and a fraction f of the

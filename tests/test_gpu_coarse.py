@@ -27,8 +27,9 @@ def _install(ctx, p):
 
 
 def test_em_call_takes_the_coarse_pass_for_all_but_its_last_estep(separable):
-    """dmx_em with 6 iterations: E-step 0 runs the dictionary form (exact), 1 .. 4 may take the coarse pass - on separable donors they
-    do -, the last one, whose logits the call returns, the fine pass.  Against the exact mode's call: posteriors of every barcode
+    """dmx_em with 6 iterations: E-steps 0 .. 4 may take the coarse pass - on separable donors they do (E-step 0 took the exact
+    dictionary form until round 6: faster than the fine pass, slower than the coarse one) -, the last one, whose logits the call
+    returns, the fine pass.  Against the exact mode's call: posteriors of every barcode
     within 1e-5 with the same arg-max, additions within what such posteriors allow, returned logits as close as the fine pass
     leaves them; and the guarded mode of round 4 (coarse pass off) for comparison."""
     from demuxalot_amd.device import DeviceContext
@@ -49,7 +50,7 @@ def test_em_call_takes_the_coarse_pass_for_all_but_its_last_estep(separable):
             ctx.close()
     lv = out['default'][3]
     assert lv['level'] == 1, lv                      # the last E-step: the fine pass
-    assert lv['coarse_steps'] == 4, lv               # E-steps 1 .. 4
+    assert lv['coarse_steps'] == 5, lv               # E-steps 0 .. 4
     assert lv['coarse_pass_ms'] > 0, lv              # (the last E-step's own time is folded in when the next one begins)
     assert out['fine only'][3]['coarse_steps'] == 0 and out['fine only'][3]['flagged_coarse'] == -1
     n_calls_v = np.bincount(p.variant_id, minlength=p.n_variants).astype(np.float64)[:, None]
@@ -82,7 +83,7 @@ def test_coarse_pass_gives_way_where_it_proves_too_little(siblings):
         _install(ctx, p)
         ctx.set_coarse_pass('always')   # (single E-steps below: admissible every time, so that every decision can be read back)
         ctx.reset_timings()
-        ctx.em(2, 0.01, pen, with_doublets=False, fetch_logits=False, fetch_probs=False, fetch_addition=False)  # P E M P E: the second E-step is guarded
+        ctx.em(2, 0.01, pen, with_doublets=False, fetch_logits=False, fetch_probs=False, fetch_addition=False)  # P E M P E: both E-steps guarded, the first one's logits nobody reads
         history = [ctx.guard_levels()]
         for step in range(6):
             _l, probs = ctx.estep(pen, with_doublets=False)
@@ -91,8 +92,8 @@ def test_coarse_pass_gives_way_where_it_proves_too_little(siblings):
     finally:
         ctx.close()
     B = p.n_barcodes
-    assert history[0]['level'] == 0 and history[0]['coarse_steps'] == 1, history   # it had its turn (nothing was known before it)
-    assert history[-1]['coarse_steps'] <= 2 and history[-1]['level'] != 0 and history[-2]['level'] != 0, history  # ... and was left
+    assert history[0]['coarse_steps'] >= 1, history   # it had its turn (nothing was known before the call's first E-step)
+    assert history[-1]['coarse_steps'] <= 3 and history[-1]['level'] != 0 and history[-2]['level'] != 0, history  # ... and was left
     assert max(h['flagged_coarse'] for h in history) > 0.4 * B, history
     assert all(0 < h['flagged_fine'] < 0.4 * B for h in history), history
     for prev, cur in zip(history[:-1], history[1:]):   # every decision against the rule, on the numbers the device reports
@@ -222,7 +223,9 @@ def test_a_stale_time_of_a_pass_that_does_not_run_is_taken_again(separable):
         ctx.debug_set_pass_ms(coarse=5.0 * lv['fine_pass_ms'])
         ctx.reset_timings()
         ctx.run_iterations(150, 0.01)
-        assert ctx.guard_probes()[0] == 0 and ctx.guard_levels()['coarse_steps'] == 0
+        # (the exact kernel's time is an estimate here since round 6 - the call's first E-step is a guarded one on the prior table and
+        # queues enough barcodes to price it -, and an estimate below twice the fine pass's price earns the DIRECT level a probe)
+        assert ctx.guard_levels()['coarse_steps'] == 0 and ctx.guard_probes()[0] <= 3, (ctx.guard_levels(), ctx.guard_probes())
     finally:
         ctx.close()
 
@@ -248,7 +251,7 @@ def test_a_call_that_returns_no_logits_may_take_the_coarse_pass_for_its_last_est
         ctx.reset_timings()
         _l, probs, addition = ctx.em(6, 0.01, pen, with_doublets=False, fetch_logits=False)
         lv = ctx.guard_levels()
-        assert lv['level'] == 0 and lv['coarse_steps'] == 5, lv      # E-step 0: dictionary form; 1 .. 5: coarse, the last one too
+        assert lv['level'] == 0 and lv['coarse_steps'] == 6, lv      # E-steps 0 .. 5: coarse, the last one too
         check_contract(probs, probs_exact, 'no logits needed: 6 iterations vs exact')
         assert np.array_equal(ctx.get_block('probs', 0, 100), probs[:100])
         assert np.array_equal(ctx.get_assignments()[0], probs.argmax(axis=1))

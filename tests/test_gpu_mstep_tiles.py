@@ -268,3 +268,72 @@ def test_the_delta_pass_builds_the_full_pass_sums_from_nothing():
     for it in range(3):
         assert np.array_equal(out[True][0][it].view(np.uint32), out['bootstrap'][0][it].view(np.uint32)), it
     assert out[True][1][0] == 1 and out['bootstrap'][1][:2] == (0, 3), (out[True][1], out['bootstrap'][1])
+
+
+@pytest.mark.parametrize('power', [2.0, 1.5])
+@pytest.mark.parametrize('G,doublets,B,S,cpb,hard', [(8, True, 6000, 3000, 400, False), (33, False, 6000, 3000, 500, False),
+                                                    (64, False, 30000, 6000, 150, False), (64, False, 12000, 4000, 400, True),
+                                                    (2, False, 3000, 500, 30, False), (16, False, 5000, 40, 200, False)])
+def test_fixed_point_work_items_are_the_tile_form_bit_for_bit(G, doublets, B, S, cpb, hard, power):
+    """A call too short to pay for the tile-major records (learn_genotypes' default of 5 iterations) runs the WORK-ITEM kernel with the
+    tile-major form's arithmetic - every contribution added as the integer rint(c 2^shift), shift from the same tile cut - and the
+    incremental M-step on top of its sums (kernels.h: MstepArgs::fixed_shift_v).  Integer sums do not depend on who adds in which
+    order: the additions equal the tile-major full pass's BIT FOR BIT in every iteration, no tile-major records are ever built, the
+    delta pass runs, and two runs give the same bits."""
+    from demuxalot_amd import Demultiplexer, synth
+    p = synth.generate(B, S, G, calls_per_barcode=cpb, doublets=doublets, seed=2100 + G + B, sibling_pairs=hard)
+    pen = Demultiplexer._doublet_penalties(G, 0.2 if doublets else 0.0)
+    n_it = 5
+    want_ctx = _context(p, G, False, True)          # tile-major records at the first M-step, every M-step the full pass
+    try:
+        want_ctx.set_mstep_incremental(False)
+        want = _additions(want_ctx, pen, doublets, power, n_iterations=n_it)
+        assert want_ctx.mstep_form() == 'tiles'
+    finally:
+        want_ctx.close()
+    runs = []
+    for _ in range(2):
+        ctx = _context(p, G, False, 'auto')         # the library's defaults: records only when 8 M-steps are to come
+        try:
+            ctx.set_mstep_incremental(True)
+            ctx.reset_timings()
+            got = _additions(ctx, pen, doublets, power, n_iterations=n_it)
+            assert ctx.mstep_form() == 'items_fixed' and ctx.mstep_tiles_info()[0] is False
+            full, delta, last = ctx.mstep_incremental()
+            runs.append(got)
+        finally:
+            ctx.close()
+        for it in range(n_it):
+            assert np.array_equal(got[it].view(np.uint32), want[it].view(np.uint32)), (it, int((got[it] != want[it]).sum()), float(np.abs(got[it] - want[it]).max()))
+        assert full + delta == n_it and full >= 1, (full, delta, last)
+        if not hard and cpb >= 400:   # (few calls per barcode: dense posteriors in the first iterations - the dense regime's kernel, no kept sums)
+            assert delta >= 2, (full, delta, last)
+    for x, y in zip(*runs):
+        assert np.array_equal(x.view(np.uint32), y.view(np.uint32))
+    print(f'G={G} doublets={doublets} hard={hard} power={power}: {full} full + {delta} delta passes on the work items\' sums')
+
+
+def test_fixed_point_work_items_in_the_dense_regime_and_through_the_switches():
+    """All-equal betas (every posterior 1 / G): the dense regime's kernel takes the launches - float64 sums, as in every other form -
+    and the combining pass must read its partial sums as float64, not as the fixed-point form's integers.  dmx_set_mstep_tiles(0) and
+    dmx_set_mstep_incremental(0) both mean the float64 work-item form of before."""
+    from demuxalot_amd import synth
+    G = 64
+    p = synth.generate(6000, 1500, G, calls_per_barcode=100, seed=4243)
+    pen = np.zeros(G, dtype=np.float32)
+    flat = np.ones_like(p.prior_betas())
+    out = {}
+    for name, tiles, incremental in (('items', False, True), ('auto', 'auto', True), ('auto_full', 'auto', False)):
+        ctx = _context(p, G, False, tiles)
+        try:
+            ctx.set_mstep_incremental(incremental)
+            ctx.set_betas(flat)
+            ctx.set_addition(None)
+            out[name] = (_additions(ctx, pen, False, 2.0, n_iterations=3), ctx.mstep_form())
+        finally:
+            ctx.close()
+    assert out['items'][1] == 'items' and out['auto_full'][1] == 'items' and out['auto'][1] == 'items_fixed'
+    for it in range(3):
+        assert np.array_equal(out['auto'][0][it].view(np.uint32), out['items'][0][it].view(np.uint32)), it
+        assert np.array_equal(out['auto_full'][0][it].view(np.uint32), out['items'][0][it].view(np.uint32)), it
+        assert np.isfinite(out['auto'][0][it]).all() and out['auto'][0][it].max() > 0

@@ -4,6 +4,8 @@ except the RCCL calls themselves is what an N-GPU run executes: the padded varia
 straight into the exchange buffer (prow), reduce-scatter -> rounded slice -> sliced P-step -> all-gather of
 genotype_prob, the re-based E-step records, the all-reduce fallback for scattered SNP groups, and the Python
 sharding (distributed.py) on top.  (RCCL itself is exercised with one rank in tests/test_gpu_parity.py.)"""
+import os
+
 import numpy as np
 import pytest
 
@@ -351,6 +353,16 @@ def _bench_rank(rank, world, port, out, scaling, exchange=None, broken_rccl=Fals
     out.put((rank, done.returncode, done.stdout.strip(), done.stderr[-2000:]))
 
 
+def _bench_details(line):
+    """The sidecar of a bench line (bench.py: write_details): everything the compact line leaves out."""
+    import json
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    path = line['details'] if os.path.isabs(line['details']) else os.path.join(root, line['details'])
+    full = json.load(open(path))
+    assert full['value'] == pytest.approx(line['value'], rel=1e-5) and full['n_gpus'] == line['n_gpus']   # the same run's
+    return full
+
+
 @pytest.mark.parametrize('scaling,exchange', [('strong', None), ('weak', None), ('strong', 'reduce_scatter')])
 def test_bench_with_two_ranks_on_one_gpu(scaling, exchange):
     """`bench.py --gpus 2 --scaling strong|weak` end to end (socket control plane, exchange staged over the plane): rank 0
@@ -376,7 +388,8 @@ def test_bench_with_two_ranks_on_one_gpu(scaling, exchange):
     line = json.loads(results[0][2])
     assert line['n_gpus'] == 2 and line['scaling'] == scaling and line['value'] > 0
     assert line['config']['barcodes_total'] == (20_000 if scaling == 'strong' else 40_000)
-    assert len(line['config']['runtimes']['hip']) == 1 and line['exchange_ms_per_step'] > 0
+    assert len(results[0][2]) < 4000   # (bench.LINE_LIMIT: the driver's reader)
+    assert len(_bench_details(line)['config']['runtimes']['hip']) == 1 and line['exchange_ms_per_step'] > 0
 
 
 def test_bench_starts_its_own_ranks():
@@ -400,8 +413,9 @@ def test_bench_starts_its_own_ranks():
     assert line['n_gpus'] == 2 and line['scaling'] == 'strong' and line['value'] > 0
     assert line['config']['barcodes_total'] == 20_000 and line['config']['estep_mode'].startswith('guarded')
     assert line['weak']['barcodes_total'] == 40_000 and line['weak']['value'] > 0
-    assert 'shared through' in line['setup_s']['problem_source'] and line['exchange_ms_per_step'] > 0
-    assert line['exact_mode']['value'] > 0
+    full = _bench_details(line)
+    assert 'shared through' in full['setup_s']['problem_source'] and line['exchange_ms_per_step'] > 0
+    assert full['exact_mode']['value'] > 0 and line['exact_mode_ms_per_step'] > 0
 
 
 def test_bench_falls_back_to_the_host_plane_without_rccl():
@@ -425,7 +439,7 @@ def test_bench_falls_back_to_the_host_plane_without_rccl():
         assert code == 0, (rank, stderr)
     line = json.loads(results[0][2])
     assert line['n_gpus'] == 2 and line['value'] > 0 and line['exchange_ms_per_step'] > 0
-    assert 'rccl_fallback' in line['config'] and '(host-staged)' in line['config']['parallelism'], line['config']
+    assert 'rccl_fallback' in _bench_details(line)['config'] and 'rccl_fallback' in line['config'] and '(host-staged)' in line['config']['parallelism'], line['config']
 
 
 @pytest.mark.parametrize('name', ['f2_synthetic_g4.npz', 'f1_synthetic_default.npz'])
