@@ -263,7 +263,7 @@ def test_a_call_that_returns_no_logits_may_take_the_coarse_pass_for_its_last_est
         ctx.reset_timings()
         logits, probs2, _a = ctx.em(6, 0.01, pen, with_doublets=False)
         lv = ctx.guard_levels()
-        assert lv['level'] == 1 and lv['coarse_steps'] == 4, lv
+        assert lv['level'] == 1 and lv['coarse_steps'] == 5, lv
         assert np.array_equal(ctx.get_logits(), logits)
         check_contract(probs2, probs_exact, 'logits asked for: 6 iterations vs exact')
         # dmx_run_iterations has no output pointers: the setting alone decides
