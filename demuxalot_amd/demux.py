@@ -306,20 +306,36 @@ def _pack_on_device(chromosome2compressed_snp_calls, genotypes, n_barcodes, add_
     # containers and genotypes (the reference's own usage pattern, see _cached_variant_keys) packs once.  Key: the content
     # hash of EVERY record of every container (no object identities: an array edited in place hashes differently, a freed
     # id() that comes back means nothing), the fingerprint of var2varid, the shape.  resident_policy(): the switch.
+    # The full hashes cost 16 ms for 2 GB of records: on a call whose inputs CANNOT be the resident ones (other shapes, or a sampled
+    # checksum that already differs) they are taken in a second thread next to the upload; only a call that looks like a repeat
+    # pays for them up front - and saves the 45 ms upload and the 13 ms device pack when they confirm it.
     key = None
+    hashes_later = None   # thread computing the full hashes of a call that packs (policy 'full')
     policy = resident_policy() if (shared and raw and reduce_molecule_counts is None) else '0'
+    resident = getattr(ctx, '_resident_key', None)
+    named = list(chromosome2compressed_snp_calls.items())
+
+    def full_hashes():
+        return tuple((_content_hash(c.snp_calls[:c.n_snp_calls]), _content_hash(c.molecules[:c.n_molecules])) for _chrom, c in named)
+
     if policy == 'full':
-        key = ('full', tuple((chrom, int(c.n_snp_calls), int(c.n_molecules), _content_hash(c.snp_calls[:c.n_snp_calls]),
-                              _content_hash(c.molecules[:c.n_molecules])) for chrom, c in chromosome2compressed_snp_calls.items()),
-               _var2varid_fingerprint(genotypes.var2varid), genotypes.n_variants, genotypes.n_genotypes, int(n_barcodes),
-               bool(getattr(ctx, '_keep_molecule_calls', False)))
+        meta = (tuple((chrom, int(c.n_snp_calls), int(c.n_molecules)) for chrom, c in named),
+                _var2varid_fingerprint(genotypes.var2varid), genotypes.n_variants, genotypes.n_genotypes, int(n_barcodes),
+                bool(getattr(ctx, '_keep_molecule_calls', False)))
+        sampled = tuple((_sampled_checksum(c.snp_calls[:c.n_snp_calls]), _sampled_checksum(c.molecules[:c.n_molecules])) for _chrom, c in named)
+        if resident is not None and resident[:3] == ('full', meta, sampled):
+            key = ('full', meta, sampled, full_hashes())   # looks like a repeat: every record decides
+        else:
+            import threading
+            box = []
+            hashes_later = (threading.Thread(target=lambda: box.append(full_hashes())), box, meta, sampled)
     elif policy == 'sampled':
         key = ('sampled', tuple((chrom, id(c.snp_calls), id(c.molecules), int(c.n_snp_calls), int(c.n_molecules),
                                  _sampled_checksum(c.snp_calls[:c.n_snp_calls]), _sampled_checksum(c.molecules[:c.n_molecules]))
-                                for chrom, c in chromosome2compressed_snp_calls.items()),
+                                for chrom, c in named),
                _var2varid_fingerprint(genotypes.var2varid), genotypes.n_variants, genotypes.n_genotypes, int(n_barcodes),
                bool(getattr(ctx, '_keep_molecule_calls', False)))
-    if key is not None and getattr(ctx, '_resident_key', None) == key:
+    if key is not None and resident == key:
         molecules = None  # (the counts per variant are on the device: dmx_set_prior_betas takes them from there)
     elif raw:
         # The containers' packed records go to the GPU as they are and are taken apart there - and they go FIRST, in a
@@ -339,10 +355,14 @@ def _pack_on_device(chromosome2compressed_snp_calls, genotypes, n_barcodes, add_
 
         worker = threading.Thread(target=stage)
         worker.start()
+        if hashes_later is not None:
+            hashes_later[0].start()
         try:
             _fp, v2snp, (var_chrom, var_pos, var_base), chrom_index = _cached_variant_keys(genotypes)
         except BaseException:
             worker.join()
+            if hashes_later is not None:
+                hashes_later[0].join()
             if not failure:  # the worker did stage them (~17 bytes per call on the GPU): give them back before unwinding
                 try:
                     ctx.release_problem()
@@ -359,6 +379,10 @@ def _pack_on_device(chromosome2compressed_snp_calls, genotypes, n_barcodes, add_
             chrom_of_container.append(chrom_index.get(chrom, -1))
         _m, _u, molecules = ctx.pack_staged_and_set_problem(n_barcodes, genotypes.n_genotypes, var_chrom, var_pos, var_base, v2snp,
                                                             chrom_of_container)
+        if hashes_later is not None:
+            thread, box, meta, sampled = hashes_later
+            thread.join()
+            key = ('full', meta, sampled, box[0]) if box else None   # (a hash that failed: nothing is kept)
         ctx._resident_key = key
     else:
         v2snp = genotypes.get_snp_ids_for_variants()
