@@ -975,27 +975,24 @@ static __device__ __forceinline__ void coarse_walk(const unsigned *__restrict__ 
     auto consume = [&](int k, unsigned w, auto sel, const Gathers &g) {
         constexpr int R0 = decltype(sel)::value * 2 * GPB + GPB;
         on_group(k, __builtin_amdgcn_readlane((int)w, R0) & 15);
-        auto lo = [](unsigned h) { return (float)__builtin_bit_cast(_Float16, (unsigned short)(h & 0xFFFFu)); };
-        auto hi = [](unsigned h) { return (float)__builtin_bit_cast(_Float16, (unsigned short)(h >> 16)); };
-        float prod_lo = add_row_bcast<R0>(w, lo(g.h[0])), prod_hi = add_row_bcast<R0>(w, hi(g.h[0]));
-        prod_lo = prod_lo * add_row_bcast<R0 + 1>(w, lo(g.h[1]));
-        prod_hi = prod_hi * add_row_bcast<R0 + 1>(w, hi(g.h[1]));
-        if constexpr (GPB >= 4) {
-            prod_lo = prod_lo * add_row_bcast<R0 + 2>(w, lo(g.h[2]));
-            prod_hi = prod_hi * add_row_bcast<R0 + 2>(w, hi(g.h[2]));
-            prod_lo = prod_lo * add_row_bcast<R0 + 3>(w, lo(g.h[3]));
-            prod_hi = prod_hi * add_row_bcast<R0 + 3>(w, hi(g.h[3]));
-        }
-        if constexpr (GPB == 8) {  // (a product of 8 sums: at least 1e-32; beyond float32 only with several keep factors near 2^-24 - NaN, queued)
-            prod_lo = prod_lo * add_row_bcast<R0 + 4>(w, lo(g.h[4]));
-            prod_hi = prod_hi * add_row_bcast<R0 + 4>(w, hi(g.h[4]));
-            prod_lo = prod_lo * add_row_bcast<R0 + 5>(w, lo(g.h[5]));
-            prod_hi = prod_hi * add_row_bcast<R0 + 5>(w, hi(g.h[5]));
-            prod_lo = prod_lo * add_row_bcast<R0 + 6>(w, lo(g.h[6]));
-            prod_hi = prod_hi * add_row_bcast<R0 + 6>(w, hi(g.h[6]));
-            prod_lo = prod_lo * add_row_bcast<R0 + 7>(w, lo(g.h[7]));
-            prod_hi = prod_hi * add_row_bcast<R0 + 7>(w, hi(g.h[7]));
-        }
+        // p + r of the lane's two genotypes: the binary16 probability goes into ONE v_fma_mix_f32 each (p x 1.0 + r, p converted inside
+        // the instruction: the float32 rounding of v_cvt_f32_f16 + v_add_f32, bit for bit), r as one DPP row broadcast per call - three
+        // instructions per call and lane where conversion, conversion, addition, addition were four (round 6: the pass is VALU-bound)
+        auto sums = [&](auto q, float &s_lo, float &s_hi) {
+            constexpr int Q = decltype(q)::value;
+            const float r = __uint_as_float(row_bcast(w, R0 + Q));
+            const unsigned h = g.h[Q];  // (named here: an asm operand does not capture for the lambda)
+            asm("v_fma_mix_f32 %0, %1, 1.0, %2 op_sel_hi:[1,0,0]" : "=v"(s_lo) : "v"(h), "v"(r));
+            asm("v_fma_mix_f32 %0, %1, 1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(s_hi) : "v"(h), "v"(r));
+        };
+        float prod_lo, prod_hi;
+        sums(std::integral_constant<int, 0>{}, prod_lo, prod_hi);
+        for_each_int(std::make_integer_sequence<int, GPB - 1>{}, [&](auto qm1) {  // (a product of GPB sums: at least 1e-32 for GPB = 8; beyond
+            float s_lo, s_hi;                                                       // float32 only with several keep factors near 2^-24 - NaN, queued)
+            sums(std::integral_constant<int, decltype(qm1)::value + 1>{}, s_lo, s_hi);
+            prod_lo = prod_lo * s_lo;
+            prod_hi = prod_hi * s_hi;
+        });
         lacc.lo += __builtin_amdgcn_logf(prod_lo);  // v_log_f32 = log2 of a product of GPB sums p + r
         lacc.hi += __builtin_amdgcn_logf(prod_hi);
     };

@@ -74,8 +74,9 @@ def _main_loop(text, name):
 # Software-pipelined walks of the tile-major E-step: gathers of several batches in flight across the loop's back edge.
 #   kernel -> (fewest `row_newbcast` DPP operands in the loop, most LDS reads in it per trip)
 PIPELINED = {
-    '_ZN3dmx20k_estep_tiled_coarseILi2EEEvNS_9EstepArgsE': (96, 8),   # coarse pass, 33 .. 64 genotypes: records through DPP only (LDS: the slot's sums)
-    '_ZN3dmx20k_estep_tiled_coarseILi4EEEvNS_9EstepArgsE': (96, 16),  # ... 17 .. 32 genotypes
+    # (round 6: one broadcast of r per call feeding two v_fma_mix_f32 instead of a DPP operand in each of two additions: 64 per trip, was 96)
+    '_ZN3dmx20k_estep_tiled_coarseILi2EEEvNS_9EstepArgsE': (64, 8),   # coarse pass, 33 .. 64 genotypes: records through DPP only (LDS: the slot's sums)
+    '_ZN3dmx20k_estep_tiled_coarseILi4EEEvNS_9EstepArgsE': (64, 16),  # ... 17 .. 32 genotypes
     '_ZN3dmx13k_estep_tiledILi1ELb1ELb0EEEvNS_9EstepArgsE': (0, 64),  # fine pass (records through LDS)
 }
 
@@ -93,5 +94,8 @@ def test_pipelined_walks_do_not_drain_at_the_loop_head(tmp_path):
         drains = sum('vmcnt(0)' in line for line in loop)
         assert drains == 0, f'{name}: {drains} x s_waitcnt vmcnt(0) inside the pipelined loop'
         dpp = sum('row_newbcast' in line for line in loop)
+        if 'tiled_coarse' in name:   # the binary16 operands are converted inside the additions (v_fma_mix_f32): no conversion instruction of its own
+            assert not any('v_cvt_f32_f16' in line for line in loop), f'{name}: v_cvt_f32_f16 in the pipelined loop'
+            assert sum('v_fma_mix_f32' in line for line in loop) >= 64, name
         lds_reads = sum(bool(re.match(r'\s+ds_read', line)) for line in loop)
         assert dpp >= min_dpp and lds_reads <= max_lds_reads, f'{name}: {dpp} DPP row broadcasts (>= {min_dpp}), {lds_reads} LDS reads (<= {max_lds_reads}) per trip'
