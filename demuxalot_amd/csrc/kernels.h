@@ -186,8 +186,10 @@ constexpr unsigned GS_UNKNOWN = 0xFFFFFFFFu;
 // d = 4.8828e-4 + 1.91e-6 + 4 x 6e-8: 4.9068e-4.  Then per call 3/4 of a float32 rounding of the 4-term product (4.5e-8) and 1/4 of v_log_f32's
 // error on a product in [1e-16, 2^80) - within 2 ulp of a result below 128 in magnitude (tests/test_gpu_guarded.py): 1.53e-5 log2 units =
 // 1.06e-5, a quarter of it per call: 2.7e-6.  (A product beyond float32 - calls with keep below 1e-9 - becomes inf / NaN: the guard flags NaN.)
-// log2_keep is a float64 sum of float64 logs: 1e-16 relative.
-constexpr float GUARD_PER_CALL_COARSE = 4.94e-4f;
+// log2_keep (launch_build_coarse_stream) is a float64 sum of v_log_f32 results since round 6: the same constant for every option of a barcode,
+// so its error cancels in the posteriors and in every difference of two logits; in a logit served by a coarse E-step (dmx_set_coarse_pass(2)) it
+// is one more v_log_f32 error per call, 1.06e-5.  4.934e-4 + 1.06e-5 = 5.04e-4, rounded up (round 5: 4.94e-4, 0.1 % of headroom).
+constexpr float GUARD_PER_CALL_COARSE = 5.1e-4f;
 constexpr float GUARD_ACCUM_F32 = 6.0e-8f;  // 2^-24, rounded up: per float32 addition of the running sum (estep_epilogue.h)
 constexpr int GUARD_SLOTS = 256;   // hashed counters behind the state words: barcodes flagged by a guard whose pass does not run (a direct
                                    // E-step: both; a fine one: the coarse guard's; a coarse one: the fine guard's) - a set per guard

@@ -55,7 +55,7 @@ for trial in range(n_problems):
     mag = np.abs(logits_e.astype(np.float64))
     keep = 1.0 - e.astype(np.float32)
     lk = np.bincount(p.compressed_cb, weights=np.where(keep > 0, -np.log(np.maximum(keep, 1e-30)), 0.0), minlength=B)[:, None]
-    bound = 4.94e-4 * (n + 8) + 6.0e-8 * (0.125 * n + 2) * (mag + 3e-4 * n + 3 * lk) + 3.0e-7 * (mag + 2.1e-4 * n) + 2.4e-7 * mag
+    bound = 5.1e-4 * (n + 8) + 6.0e-8 * (0.125 * n + 2) * (mag + 3e-4 * n + 3 * lk) + 3.0e-7 * (mag + 2.1e-4 * n) + 2.4e-7 * mag
     ratio = (np.abs(logits_c.astype(np.float64) - logits_e) / bound).max()
     worst_ratio, worst_dev = max(worst_ratio, ratio), max(worst_dev, dev)
     print(f'{trial:3d} G={G:2d} B={B} S={S} calls/barcode={cpb:3d} clip={clip:g} siblings={int(siblings)}: redone {redone} ({100 * redone / B:.2f} %), '
