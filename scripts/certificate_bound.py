@@ -11,7 +11,10 @@ The chain (X: exact run, Y: guarded run; delta_b: bound on |Y - X| of barcode b'
   E-step   |dlogit[b,k]| <= sum_{c in b} keep_c |dp[v_c,k]| / (p[v_c,k] keep_c + floor_c - keep_c |dp|) =: D_table[b,k]      (demux.py:246-265)
   softmax  certified iff, with D = max_k D_table + the guard's own D_arith (0.2 taken for the coarse pass at 400 calls):
            min(x_k, 1 - x_k)(e^{2D} - 1) <= 1e-5 for every k and no second logit within 2 D of the best  -> delta_b = 1e-5, else delta_b = 1.
-Three variants: `optimistic` (NOT a bound: the barcodes the chain cannot certify are given delta = 1e-5 all the same - what the chain
+Four variants: `refined` (rigorous: a barcode the chain cannot certify is still computed EXACTLY on either side - by the redo here, by
+the exact run there -, only on different tables, so its posteriors differ by at most max_k min(x_k, 1 - x_k)(e^{2 D_table} - 1): that
+delta instead of 1, per option; what it would cost at run time: the per-option D_table is a second E-step on a table of bounds, the
+per-entry |dadd| a second M-step), `optimistic` (NOT a bound: the barcodes the chain cannot certify are given delta = 1e-5 all the same - what the chain
 would do if nothing poisoned it), `per option` (D_table per barcode AND option, as above - what an implementation would need one more genotype-row gather
 per call for: a second E-step) and `scalar` (one eps = max |dp| per iteration times a per-barcode constant W_b = sum_c keep_c / (clip keep_c + floor_c):
 free at run time).
@@ -61,7 +64,7 @@ def analyse(name, p, d_arith):
     prior = p.prior_betas().astype(np.float64)
     W = np.bincount(b, weights=keep / (CLIP * keep + floor), minlength=B)
     print(f'## {name}: {B} barcodes x {V} variants x {G} genotypes, {len(v)} calls; W_b = sum_c keep / (clip keep + floor): median {np.median(W):.0f}, max {W.max():.0f}')
-    for variant in ('optimistic', 'per option', 'scalar'):
+    for variant in ('refined', 'optimistic', 'per option', 'scalar'):
         delta = np.zeros(B)   # iteration 0: the same table on both sides; the guard's 1e-5 (kept) or 0 (redone exactly)
         delta[:] = 1e-5
         print(f'# bound: {variant}')
@@ -85,7 +88,7 @@ def analyse(name, p, d_arith):
                 np.add.at(dden, snp, dadd)
                 room = den[snp] - dden[snp]
                 dp = np.where(room > 0, np.minimum((dadd + prob_x * dden[snp]) / np.maximum(room, 1e-300), 1.0), 1.0)   # (a probability moves by 1 at most)
-                if variant == 'scalar':
+                if variant == 'scalar':  # noqa: E721
                     D_table = (min(dp.max(), 1.0) * W)[:, None] * np.ones((1, G))
                 else:
                     t = prob_x[v] * keep[:, None] + floor[:, None]
@@ -100,11 +103,16 @@ def analyse(name, p, d_arith):
             margin_ok = (top2[:, 1] - top2[:, 0]) > 2.0 * D
             worst = (np.minimum(x, 1.0 - x).max(axis=1)) * np.expm1(np.minimum(2.0 * D, 700.0))
             certified = margin_ok & (worst <= 8e-6)
-            delta = np.where(certified, 1e-5, 1e-5 if variant == 'optimistic' else 1.0)
+            if variant == 'refined':
+                d_table = D - d_arith
+                same_arithmetic = np.minimum(x, 1.0 - x).max(axis=1) * np.expm1(np.minimum(2.0 * d_table, 700.0)) + (1e-7 if it > 0 else 0.0)   # + the float32 softmax on either side
+                delta = np.where(certified, 1e-5, np.minimum(1.0, same_arithmetic))
+            else:
+                delta = np.where(certified, 1e-5, 1e-5 if variant == 'optimistic' else 1.0)
             print(f'iteration {it}: max |dp| bound {dp.max():.3g}, D (median / max over barcodes) {np.median(D):.3g} / {D.max():.3g}; certified {certified.mean() * 100:.2f} % of the barcodes; '
                   f'ACTUAL: max |guarded - exact| posterior {actual.max():.2e}, assignments that differ {flips}, barcodes beyond 1e-5: {int((actual > 1e-5).sum())}'
                   f'{"" if (actual[certified] <= 1e-5).all() else "  !! a certified barcode differs"}', flush=True)
-            if certified.mean() == 0.0 and variant != 'optimistic':
+            if certified.mean() == 0.0 and variant not in ('optimistic', 'refined'):
                 print('  (nothing left to certify: every later iteration is uncertified too)')
                 break
 
