@@ -307,8 +307,10 @@ def _pack_on_device(chromosome2compressed_snp_calls, genotypes, n_barcodes, add_
     # hash of EVERY record of every container (no object identities: an array edited in place hashes differently, a freed
     # id() that comes back means nothing), the fingerprint of var2varid, the shape.  resident_policy(): the switch.
     # The full hashes cost 16 ms for 2 GB of records: on a call whose inputs CANNOT be the resident ones (other shapes, or a sampled
-    # checksum that already differs) they are taken in a second thread next to the upload; only a call that looks like a repeat
-    # pays for them up front - and saves the 45 ms upload and the 13 ms device pack when they confirm it.
+    # checksum that already differs) they are taken in a second thread BEHIND the upload - next to it they competed with the runtime's
+    # own host copies for memory bandwidth: 91 instead of 77 ms - while the device packs (13 ms) and computes the prior, and are joined
+    # before this function returns (the caller may edit its arrays after that); only a call that looks like a repeat pays for them
+    # up front - and saves the 45 ms upload and the 13 ms device pack when they confirm it.
     key = None
     hashes_later = None   # thread computing the full hashes of a call that packs (policy 'full')
     policy = resident_policy() if (shared and raw and reduce_molecule_counts is None) else '0'
@@ -355,14 +357,10 @@ def _pack_on_device(chromosome2compressed_snp_calls, genotypes, n_barcodes, add_
 
         worker = threading.Thread(target=stage)
         worker.start()
-        if hashes_later is not None:
-            hashes_later[0].start()
         try:
             _fp, v2snp, (var_chrom, var_pos, var_base), chrom_index = _cached_variant_keys(genotypes)
         except BaseException:
             worker.join()
-            if hashes_later is not None:
-                hashes_later[0].join()
             if not failure:  # the worker did stage them (~17 bytes per call on the GPU): give them back before unwinding
                 try:
                     ctx.release_problem()
@@ -372,18 +370,21 @@ def _pack_on_device(chromosome2compressed_snp_calls, genotypes, n_barcodes, add_
         worker.join()
         if failure:
             raise failure[0]
+        if hashes_later is not None:
+            hashes_later[0].start()   # (the records are on the device: the host's memory system is free for the hashes)
         chrom_of_container = []
         for chrom, container in items:
             if chrom not in chrom_index:  # demux.py:339-341, 359: calls on a chromosome without variants trip the reference's final assert
                 assert container.n_snp_calls == 0
             chrom_of_container.append(chrom_index.get(chrom, -1))
-        _m, _u, molecules = ctx.pack_staged_and_set_problem(n_barcodes, genotypes.n_genotypes, var_chrom, var_pos, var_base, v2snp,
-                                                            chrom_of_container)
-        if hashes_later is not None:
-            thread, box, meta, sampled = hashes_later
-            thread.join()
-            key = ('full', meta, sampled, box[0]) if box else None   # (a hash that failed: nothing is kept)
-        ctx._resident_key = key
+        try:
+            _m, _u, molecules = ctx.pack_staged_and_set_problem(n_barcodes, genotypes.n_genotypes, var_chrom, var_pos, var_base, v2snp,
+                                                                chrom_of_container)
+        except BaseException:
+            if hashes_later is not None:
+                hashes_later[0].join()
+            raise
+        ctx._resident_key = key   # (policy 'full': set below, once the hashes are in)
     else:
         v2snp = genotypes.get_snp_ids_for_variants()
         assert np.all(v2snp >= 0)
@@ -395,8 +396,14 @@ def _pack_on_device(chromosome2compressed_snp_calls, genotypes, n_barcodes, add_
         molecules = reduce_molecule_counts(molecules)
     else:
         molecules = None
-    betas = ctx.set_prior_betas(genotypes.get_betas(), genotypes.default_prior, add_data_prior,
-                                mol_per_variant=molecules, fetch=fetch_betas)
+    try:
+        betas = ctx.set_prior_betas(genotypes.get_betas(), genotypes.default_prior, add_data_prior,
+                                    mol_per_variant=molecules, fetch=fetch_betas)
+    finally:
+        if hashes_later is not None and hashes_later[0].ident is not None:   # (started: the records went to the device)
+            thread, box, meta, sampled = hashes_later
+            thread.join()
+            ctx._resident_key = ('full', meta, sampled, box[0]) if box else None   # (a hash that failed: nothing is kept)
     return ctx, betas
 
 
