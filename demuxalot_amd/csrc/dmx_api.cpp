@@ -98,6 +98,7 @@ static int finish_problem(dmx_ctx *c, const int32_t *v2snp, const std::vector<in
     DMX_TRY(build_row_segments(c));
     DMX_TRY(layout_exchange(c));        // genotype_prob table (padded when a communicator is attached)
     c->msteps_done = 0;
+    c->incr_heavy = false;
     c->have_problem = true;
     return 0;
 }

@@ -668,7 +668,7 @@ int dmx_reset_timings(dmx_ctx *c)
     // the totals; the last E-step's own numbers stay (they decide how the next one runs: kernels.hip k_guard_begin)
     if (c->d_guard_count) HIP_TRY(hipMemsetAsync(c->d_guard_count + dmx::GS_PENDING, 0, 4 * sizeof(unsigned), c->stream));  // GS_PENDING, GS_DIRECT_STEPS, GS_TOTAL
     if (c->d_guard_count) HIP_TRY(hipMemsetAsync(c->d_guard_count + dmx::GS_COARSE_STEPS, 0, 2 * sizeof(unsigned), c->stream));  // + GS_PROBES
-    if (c->d_incr_state) HIP_TRY(hipMemsetAsync(c->d_incr_state + 2 * dmx::IS_WORDS, 0, sizeof(unsigned) * dmx::IS_WORDS, c->stream));
+    if (c->d_incr_state) HIP_TRY(hipMemsetAsync(c->d_incr_state + 2 * dmx::IS_WORDS, 0, sizeof(unsigned) * 3, c->stream));  // (word 3: full passes since the install, kept)
     c->guard_rows_total = 0;
     for (int s = 0; s < DMX_T_COUNT; s++) {
         timer_flush(c, s);

@@ -2594,6 +2594,9 @@ __global__ __launch_bounds__(256) void k_mincr_finish(MstepArgs a, MIncrArgs x)
     }
     if (tid == 0) {
         x.counters[full ? 0 : 1] += 1u;
+        // full passes of the sparse regime's kernels since the state was allocated (not reset by dmx_reset_timings: run_mstep's policy reads
+        // it - the tile-major records do nothing for the dense regime's kernel)
+        if (full && !dense_regime(a)) x.counters[3] += 1u;
         x.counters[2] = x.state[IS_VALID] ? x.state[IS_N] : 0xFFFFFFFFu;  // barcodes this M-step found changed (no valid sums: not looked for)
         x.next[IS_N] = 0u;
         x.next[IS_CALLS] = x.next[IS_CALLS + 1] = 0u;

@@ -168,7 +168,9 @@ int dmx_set_exact_additions(dmx_ctx *ctx, int exact);
 /* The tile-major M-step (csrc/kernels.h: MTileArgs; switches and the long description in demux_hip_debug.h) keeps the M-step
  * records once more, sorted by (tile of <= 128 variants, barcode), and sums in 64-bit fixed point: order-independent, bit-
  * reproducible, within one float32 ulp + n 2^-51 of the reference's float64 sum.  The library builds the records when enough M-steps
- * are to come to pay for the sort: in the running dmx_em / dmx_run_iterations call, or as announced here.
+ * are to come to pay for the sort - in the running dmx_em / dmx_run_iterations call, or as announced here - and, where the incremental
+ * M-step applies (whose full passes the work items make with the same fixed-point arithmetic, no records needed), only once full
+ * passes keep coming.
  * dmx_set_msteps_expected: a hint - the caller will run about n more M-steps on the resident problem (a front-end that drives the
  * iterations call by call, a benchmark that warms up first); counted down as M-steps run. */
 int dmx_set_msteps_expected(dmx_ctx *ctx, int64_t n);

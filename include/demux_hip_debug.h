@@ -26,8 +26,11 @@ int dmx_get_redo_count(dmx_ctx *ctx, int64_t *count);
  * ulp + n 2^-(s + 1) (n calls of the variant) of the reference's float64 sum in general.  Building the records is a sort of
  * the calls (2.6 ms on 200k x 100k x 64, where an M-step then takes 0.34 instead of 0.70 ms), so
  *   1 (default) builds them at the first M-step that has 8 or more M-steps still to come - in the running dmx_em /
- *     dmx_run_iterations call, or announced with dmx_set_msteps_expected -, or when the resident problem has seen 8;
- *   2 at the first M-step;  0 never (the work-item form).
+ *     dmx_run_iterations call, or announced with dmx_set_msteps_expected -, or when the resident problem has seen 8; where the
+ *     incremental M-step applies (dmx_set_mstep_incremental: its full passes are made by the work items with the same fixed-point
+ *     arithmetic, dmx_get_mstep_form = 3) only once the device's count of full passes, read at the 4th / 16th / 64th M-step,
+ *     says that they keep coming;
+ *   2 at the first M-step;  0 never (the float64 work-item form).
  * dmx_set_msteps_expected: a hint - the caller will run about n more M-steps on the resident problem (a front-end that drives
  * the iterations call by call, a benchmark that warms up first); counted down as M-steps run.
  * dmx_get_mstep_tiles_info: whether the records exist and the host wall time their build took. */

@@ -280,7 +280,7 @@ def test_config3_twenty_iterations_in_the_default_mode_follow_the_exact_mode(pro
         finally:
             ctx.close()
     levels, form = out['guarded'][3], out['guarded'][4]
-    assert levels['level'] == 1 and levels['coarse_steps'] >= 17 and form == 'tiles', (levels, form)
+    assert levels['level'] == 1 and levels['coarse_steps'] >= 17 and form in ('tiles', 'items_fixed'), (levels, form)   # (round 6: a converging call never builds the tile records)
     dev = check_contract(out['guarded'][1], out['exact'][1], 'default vs exact after 20 iterations, all 200 000 barcodes')
     d_logit = float(np.abs(out['guarded'][0] - out['exact'][0]).max())
     assert d_logit <= 5e-3, d_logit

@@ -337,3 +337,49 @@ def test_fixed_point_work_items_in_the_dense_regime_and_through_the_switches():
         assert np.array_equal(out['auto'][0][it].view(np.uint32), out['items'][0][it].view(np.uint32)), it
         assert np.array_equal(out['auto_full'][0][it].view(np.uint32), out['items'][0][it].view(np.uint32)), it
         assert np.isfinite(out['auto'][0][it]).all() and out['auto'][0][it].max() > 0
+
+
+def test_tile_records_are_built_only_where_full_passes_keep_coming():
+    """Under the incremental M-step only full passes cost anything, and the work items make them without the tile-major records (0.71
+    against 0.33 ms at 200k x 100k x 64, no 2.6 ms sort): a context that can go incremental starts on the work items and looks at the
+    device's count of (sparse-regime) full passes at its 4th, 16th and 64th M-step.  Separable donors - the delta pass takes over -: a
+    12-iteration call never builds the records.  A run whose every M-step is a full pass (here: the addition is replaced behind each,
+    which makes the kept sums useless) with 8 or more M-steps still announced at the 5th: the records are built there.  Either way the additions
+    are those of a context that had the records from the start, bit for bit."""
+    from demuxalot_amd import synth
+    G = 32
+    pen = np.zeros(G, dtype=np.float32)
+    p = synth.generate(12000, 4000, G, calls_per_barcode=400, seed=2700)
+    out = {}
+    for tiles in ('auto', True):
+        ctx = _context(p, G, False, tiles)
+        try:
+            ctx.set_mstep_incremental(True)
+            ctx.reset_timings()
+            _l, _p, addition = ctx.em(12, 0.01, pen, with_doublets=False, fetch_logits=False, fetch_probs=False)
+            converging = (addition, ctx.mstep_form(), ctx.mstep_tiles_info()[0], ctx.mstep_incremental())
+        finally:
+            ctx.close()
+        ctx = _context(p, G, False, tiles)   # the same problem on a fresh context, every M-step a full pass
+        try:
+            ctx.set_mstep_incremental(True)
+            ctx.set_msteps_expected(16)   # (8 or more still to come when the device's count is read at the 5th)
+            forms, additions = [], []
+            for _ in range(10):
+                ctx.probs_from_betas(0.01, fetch=False)
+                ctx.estep(pen, with_doublets=False, fetch_logits=False, fetch_probs=False)
+                additions.append(ctx.mstep(2.0))
+                forms.append((ctx.mstep_form(), ctx.mstep_tiles_info()[0]))
+                ctx.set_addition(additions[-1])   # (somebody else's addition, as far as the kept sums are concerned)
+            out[tiles] = (converging, forms, additions)
+        finally:
+            ctx.close()
+    (add_auto, form_auto, built_auto, (full, delta, _last)), forms_auto, additions_auto = out['auto']
+    assert np.array_equal(add_auto.view(np.uint32), out[True][0][0].view(np.uint32))
+    assert built_auto is False and form_auto == 'items_fixed' and full == 1 and delta == 10, out['auto'][0][1:]
+    for it, (x, y) in enumerate(zip(additions_auto, out[True][2])):
+        assert np.array_equal(x.view(np.uint32), y.view(np.uint32)), it
+    # the first four M-steps run on the work items (full passes each); the fifth looks at the device's count and builds the records
+    assert [f for f, _b in forms_auto[:4]] == ['items_fixed'] * 4 and forms_auto[3][1] is False, forms_auto
+    assert forms_auto[-1] == ('tiles', True) and ('tiles', True) in forms_auto[4:6], forms_auto
+    print('forms of the ten full-pass M-steps:', forms_auto)
