@@ -238,6 +238,11 @@ struct dmx_ctx {
     float *d_post_g = nullptr;               // [rows_total, G] singlet posteriors
     bool post_gathered = false;              // the tables hold the last E-step of every rank
     bool emu_post_filled = false;            // emulated wire: the other ranks' blocks were filled once
+    // compact exchange of the posterior rows (gather_posteriors; G <= 64): per rank a block of {rows listed, 3 pad, cap x (row, G floats)}
+    unsigned *d_post_compact = nullptr;      // [nranks * post_compact_words]
+    size_t post_compact_words = 0;           // words per rank block (0: the whole table travels, as until round 6)
+    unsigned post_compact_cap = 0;           // rows a block can list
+    long long post_compact_taken = 0, post_compact_overflows = 0;  // E-steps exchanged compactly / that fell back to the whole table
     void *d_exch = nullptr;         // padded send buffer of the reduce-scatter (float64 or float32 partial sums)
     void *d_recv = nullptr;         // this rank's reduced slice
     size_t exch_bytes = 0, recv_bytes = 0;

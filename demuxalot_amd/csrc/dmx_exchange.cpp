@@ -358,6 +358,20 @@ int shard_mstep_by_variant(dmx_ctx *c, bool force)
     HIP_TRY(hipMemsetAsync(c->d_first_g, 0, sizeof(uint2) * (size_t)c->rows_total, st));
     HIP_TRY(hipMemsetAsync(c->d_nz_g, 0, sizeof(unsigned long long) * (size_t)c->rows_total * W, st));
     HIP_TRY(hipMemsetAsync(c->d_post_g, 0, sizeof(float) * (size_t)c->rows_total * G, st));
+    // Compact exchange of the posterior rows (gather_posteriors): a barcode with ONE live posterior - 85 % of them after the first
+    // E-step of a separable experiment, 99 % once it has converged - is described by its 8-byte code; only the rows of the others
+    // travel, in a list of at most rows_pad / 4 per rank (beyond that: the whole table, as until round 6).  G <= 64 (the codes exist).
+    // DEMUXALOT_AMD_EXCHANGE_COMPACT=0 switches it off, =<n> sets the capacity to n rows (tests: the overflow path).
+    c->post_compact_words = 0;
+    c->post_compact_cap = 0;
+    const char *compact = std::getenv("DEMUXALOT_AMD_EXCHANGE_COMPACT");
+    const long long asked = compact ? atoll(compact) : -1;
+    if (G <= 64 && asked != 0 && n > 1) {
+        c->post_compact_cap = (unsigned)(asked > 0 ? std::min<long long>(asked, rows_pad) : std::max<long long>(64, rows_pad / 4));
+        c->post_compact_words = 4 + (size_t)c->post_compact_cap * (size_t)(1 + G);
+        DMX_TRY(dev_alloc(c, &c->d_post_compact, c->post_compact_words * (size_t)n));
+        HIP_TRY(hipMemsetAsync(c->d_post_compact, 0, sizeof(unsigned) * c->post_compact_words * (size_t)n, st));
+    }
     c->mshard = true;
     c->post_gathered = false;
     c->emu_post_filled = false;
@@ -447,12 +461,34 @@ int gather_posteriors(dmx_ctx *c)
         }
         c->emu_post_filled = true;
     }
-    coll_group_begin(c);  // one launch for the three tables
+    const bool compact = c->post_compact_words != 0;
+    if (compact)  // this rank's rows with several live posteriors, listed (the count may run beyond the capacity: overflow)
+        HIP_TRY(dmx::launch_post_compact_build(c->stream, c->d_first_g + c->rank * rows, c->d_post_g + c->rank * rows * G, c->B, G, c->post_compact_cap,
+                                               c->d_post_compact + (size_t)c->rank * c->post_compact_words));
+    coll_group_begin(c);  // one launch for the tables
     rc = coll_all_gather(c, (float *)c->d_first_g, rows * 2, "posterior codes");
     if (rc == 0) rc = coll_all_gather(c, (float *)c->d_nz_g, rows * W * 2, "posterior bitmaps");
-    if (rc == 0) rc = coll_all_gather(c, c->d_post_g, rows * G, "singlet posteriors");
-    const int rc_end = coll_group_end(c);
+    if (rc == 0 && compact) rc = coll_all_gather(c, (float *)c->d_post_compact, c->post_compact_words, "listed posterior rows");
+    if (rc == 0 && !compact) rc = coll_all_gather(c, c->d_post_g, rows * G, "singlet posteriors");
+    int rc_end = coll_group_end(c);
     if (rc == 0) rc = rc_end;
+    if (rc == 0 && compact) {
+        // every rank reads every rank's count: the same decision everywhere (the one host synchronisation of the exchange)
+        std::vector<unsigned> counts((size_t)c->nranks, 0u);
+        for (int r = 0; r < c->nranks; r++)
+            HIP_TRY(hipMemcpyAsync(&counts[(size_t)r], c->d_post_compact + (size_t)r * c->post_compact_words, sizeof(unsigned), hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(hipStreamSynchronize(c->stream));
+        bool overflow = false;
+        for (int r = 0; r < c->nranks; r++) overflow = overflow || counts[(size_t)r] > c->post_compact_cap;
+        if (overflow) {  // (dense posteriors: the first E-steps of a run that starts from uninformative genotypes)
+            c->post_compact_overflows++;
+            rc = coll_all_gather(c, c->d_post_g, rows * G, "singlet posteriors (the lists overflowed)");
+        } else {
+            c->post_compact_taken++;
+            HIP_TRY(dmx::launch_post_reconstruct(c->stream, c->d_first_g, c->d_post_g, c->d_post_compact, (unsigned long long)c->post_compact_words,
+                                                 (long long)rows, G, c->nranks, c->rank, c->post_compact_cap));
+        }
+    }
     timer_end(c, DMX_T_ALLREDUCE, ev);
     if (rc) return rc;
     c->post_gathered = true;
@@ -571,6 +607,15 @@ int dmx_comm_init_emulated(dmx_ctx *c, int rank, int nranks, double link_gbytes_
     c->nranks = nranks;
     c->reduce_dtype = reduce_dtype;
     if (c->have_problem) DMX_TRY(layout_exchange(c));
+    return 0;
+}
+
+int dmx_get_exchange_compact(dmx_ctx *c, int64_t *taken, int64_t *overflows, int64_t *capacity_rows)
+{
+    if (!c) return fail(DMX_ERR_INVALID, "null ctx");
+    if (taken) *taken = c->post_compact_taken;
+    if (overflows) *overflows = c->post_compact_overflows;
+    if (capacity_rows) *capacity_rows = c->post_compact_words ? (int64_t)c->post_compact_cap : 0;
     return 0;
 }
 

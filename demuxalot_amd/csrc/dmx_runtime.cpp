@@ -444,6 +444,9 @@ void release_problem(dmx_ctx *c)
     dev_free(c, &c->d_first_g, (size_t)c->rows_total);
     dev_free(c, &c->d_nz_g, (size_t)c->rows_total * ((c->G + 63) / 64));
     dev_free(c, &c->d_post_g, (size_t)c->rows_total * c->G);
+    dev_free(c, &c->d_post_compact, c->post_compact_words * (size_t)std::max(1, c->nranks));
+    c->post_compact_words = 0;
+    c->post_compact_cap = 0;
     c->mshard = c->post_gathered = c->emu_post_filled = false;
     c->rows_pad = c->rows_total = 0;
     c->sliced = c->add_partial = false;

@@ -162,6 +162,12 @@ hipError_t launch_f64_to_f32(hipStream_t, const double *, float *, long long) { 
 hipError_t launch_add_f32(hipStream_t, const float *, const float *, float *, long long) { return hipSuccess; }
 hipError_t launch_f32_to_f64(hipStream_t, const float *, double *, long long) { return hipSuccess; }
 hipError_t launch_delay(hipStream_t, long long) { return hipSuccess; }
+hipError_t launch_post_compact_build(hipStream_t, const uint2 *, const float *, long long, int, unsigned cap, unsigned *block)
+{
+    block[0] = cap + 1;  // (no kernels here: "overflow", so that the host logic takes the whole-table path it can execute)
+    return hipSuccess;
+}
+hipError_t launch_post_reconstruct(hipStream_t, const uint2 *, float *, const unsigned *, unsigned long long, long long, int, int, int, unsigned) { return hipSuccess; }
 hipError_t launch_prior_betas(hipStream_t, const float *, float *, const unsigned long long *, const int *, const int *, const int *,
                               long long, int, double, float *) { return hipSuccess; }
 hipError_t launch_rebuild_nz(hipStream_t, const float *, long long, int, int, float, unsigned long long *, uint2 *) { return hipSuccess; }

@@ -399,6 +399,10 @@ hipError_t launch_f64_to_f32(hipStream_t st, const double *in, float *out, long 
 hipError_t launch_add_f32(hipStream_t st, const float *a, const float *b, float *out, long long n);  // out = a + b, one float32 rounding (numpy's)
 // one wavefront that keeps the stream busy for `ticks` of the constant-rate wall clock (emulated wire: dmx_comm_init_emulated)
 hipError_t launch_delay(hipStream_t st, long long ticks);
+// compact exchange of the posterior rows (kernels.hip: k_post_compact_build / k_post_reconstruct; dmx_exchange.cpp: gather_posteriors)
+hipError_t launch_post_compact_build(hipStream_t st, const uint2 *first, const float *post, long long B, int G, unsigned cap, unsigned *block);
+hipError_t launch_post_reconstruct(hipStream_t st, const uint2 *first_g, float *post_g, const unsigned *blocks, unsigned long long block_words,
+                                   long long rows_pad, int G, int nranks, int own, unsigned cap);
 hipError_t launch_f32_to_f64(hipStream_t st, const float *in, double *out, long long n);
 hipError_t launch_prior_betas(hipStream_t st, const float *betas, float *bsum, const unsigned long long *n_mol,
                               const int *v2snp, const int *snp_ptr, const int *snp_vars, long long V, int G,

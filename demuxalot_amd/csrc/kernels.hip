@@ -3349,6 +3349,78 @@ hipError_t launch_mcombine(hipStream_t st, const MstepArgs &a, const long long *
     return hipGetLastError();
 }
 
+// ---- compact exchange of the posterior rows (variant-sharded M-step, G <= 64; dmx_exchange.cpp: gather_posteriors) ----
+// What the M-step reads of a barcode with ONE live posterior is in its 8-byte code (nz_code); its 256-byte row need not travel: the
+// receivers rebuild it - the code's posterior at the code's genotype, zeros elsewhere; a posterior that is not live contributes
+// exactly +0 to every sum (NZ_FLOOR_SQUARE; with another contribution_power "live" means non-zero), so the additions keep their bits.
+// Rows with several live posteriors (1 - 15 % of the barcodes) travel in a list: block = {rows listed (beyond `cap`: overflow - the
+// caller falls back to the all-gather of the whole table), 3 words of padding, cap entries of (row, G floats)}.
+__global__ __launch_bounds__(256) void k_post_compact_build(const uint2 *__restrict__ first, const float *__restrict__ post, long long B, int G,
+                                                            unsigned cap, unsigned *__restrict__ block)
+{
+    const int lane = threadIdx.x & 63;
+    const long long b0 = ((long long)blockIdx.x * 4 + (threadIdx.x >> 6)) * 64;
+    const long long b = b0 + lane;
+    const bool multi = b < B && (first[b < B ? b : 0].y & 127u) != 1u;
+    unsigned long long m = __ballot(multi);
+    if (!m) return;
+    unsigned base = 0;
+    if (lane == 0) base = atomicAdd(&block[0], (unsigned)__popcll(m));
+    base = (unsigned)__shfl((int)base, 0);
+    for (unsigned i = 0; m != 0ull; m &= m - 1ull, i++) {  // (uniform)
+        const long long row = b0 + __builtin_ctzll(m);
+        const unsigned at = base + i;
+        if (at >= cap) break;
+        unsigned *e = block + 4 + (size_t)at * (size_t)(1 + G);
+        if (lane == 0) e[0] = (unsigned)row;
+        if (lane < G) e[1 + lane] = __float_as_uint(post[(size_t)row * G + lane]);
+    }
+}
+
+// the other ranks' rows: a wavefront per row with at most one live posterior (from its code), then a wavefront per listed row
+__global__ __launch_bounds__(256) void k_post_reconstruct(const uint2 *__restrict__ first_g, float *__restrict__ post_g, const unsigned *__restrict__ blocks,
+                                                          unsigned long long block_words, long long rows_pad, int G, int nranks, int own, unsigned cap)
+{
+    const int lane = threadIdx.x & 63;
+    const long long wave = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const long long n_rows = rows_pad * nranks;
+    if (wave < n_rows) {
+        const long long r = wave / rows_pad;
+        if (r == own) return;
+        const uint2 code = first_g[wave];
+        const unsigned nnz = code.y & 127u;
+        if (nnz <= 1u && lane < G)
+            post_g[(size_t)wave * G + lane] = (nnz == 1u && lane == (int)((code.y >> 7) & 63u)) ? __uint_as_float(code.x) : 0.0f;
+        return;
+    }
+    const long long e_id = wave - n_rows;
+    const long long r = e_id / cap;
+    const unsigned at = (unsigned)(e_id - r * cap);
+    if (r >= nranks || r == own) return;
+    const unsigned *block = blocks + (size_t)r * block_words;
+    if (at >= block[0]) return;
+    const unsigned *e = block + 4 + (size_t)at * (size_t)(1 + G);
+    const long long row = (long long)e[0];
+    if (row < rows_pad && lane < G) post_g[((size_t)r * rows_pad + row) * G + lane] = __uint_as_float(e[1 + lane]);
+}
+
+hipError_t launch_post_compact_build(hipStream_t st, const uint2 *first, const float *post, long long B, int G, unsigned cap, unsigned *block)
+{
+    hipError_t e = hipMemsetAsync(block, 0, 4 * sizeof(unsigned), st);
+    if (e != hipSuccess || B == 0) return e;
+    hipLaunchKernelGGL(k_post_compact_build, dim3(blocks_for(B, 256)), dim3(256), 0, st, first, post, B, G, cap, block);
+    return hipGetLastError();
+}
+
+hipError_t launch_post_reconstruct(hipStream_t st, const uint2 *first_g, float *post_g, const unsigned *blocks, unsigned long long block_words,
+                                   long long rows_pad, int G, int nranks, int own, unsigned cap)
+{
+    const long long waves = rows_pad * nranks + (long long)cap * nranks;
+    if (waves == 0) return hipSuccess;
+    hipLaunchKernelGGL(k_post_reconstruct, dim3(blocks_for(waves, 4)), dim3(256), 0, st, first_g, post_g, blocks, block_words, rows_pad, G, nranks, own, cap);
+    return hipGetLastError();
+}
+
 hipError_t launch_store_slice(hipStream_t st, const void *slice, bool f64, long long v_begin, long long n_rows, int G, float *add)
 {
     if (n_rows * G == 0) return hipSuccess;

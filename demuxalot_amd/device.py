@@ -422,6 +422,13 @@ class DeviceContext:
         check(self._lib.dmx_comm_init_emulated(self._h, int(rank), int(nranks), float(link_gbytes_per_s), float(latency_us),
                                                DMX_F64 if reduce_dtype == 'f64' else DMX_F32))
 
+    def exchange_compact(self):
+        """(E-steps whose posterior rows travelled as a list, E-steps that fell back to the whole table, rows a list can hold; 0: the
+        compact form is off) - include/demux_hip_debug.h: dmx_get_exchange_compact."""
+        taken, overflows, cap = ctypes.c_int64(0), ctypes.c_int64(0), ctypes.c_int64(0)
+        check(self._lib.dmx_get_exchange_compact(self._h, ctypes.byref(taken), ctypes.byref(overflows), ctypes.byref(cap)))
+        return int(taken.value), int(overflows.value), int(cap.value)
+
     def exchange_mode(self):
         """None (no communicator) | 'variant' (M-step sharded on variants, posteriors all-gathered) | 'reduce_scatter' |
         'allreduce' (exchanges of the per-rank sums); include/demux_hip.h: dmx_get_exchange_mode."""

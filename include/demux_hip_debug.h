@@ -150,6 +150,14 @@ int dmx_set_mstep_wide_addresses(dmx_ctx *ctx, int wide);
  * rank of an nranks-GPU run whose wire behaves as modelled (scripts/emulated_scaling.py). */
 int dmx_comm_init_emulated(dmx_ctx *ctx, int rank, int nranks, double link_gbytes_per_s, double latency_us, int reduce_dtype);
 
+/* Variant-sharded M-step, G <= 64: the all-gather of the singlet posteriors is COMPACT - a barcode with one live posterior is described
+ * by its 8-byte code, which travels anyway, and its row is rebuilt by the receivers; only the rows of the barcodes with several live
+ * posteriors travel, in a list of at most capacity_rows per rank (rows_pad / 4; DEMUXALOT_AMD_EXCHANGE_COMPACT=<rows> sets it, =0
+ * switches the compact form off).  Every rank reads every rank's count behind the all-gather - the exchange's one host
+ * synchronisation - and all fall back to the all-gather of the whole table when a list overflowed.  The additions keep their bits
+ * (a posterior that is not live contributes exactly +0).  E-steps exchanged compactly / that fell back, since the context was created. */
+int dmx_get_exchange_compact(dmx_ctx *ctx, int64_t *taken, int64_t *overflows, int64_t *capacity_rows);
+
 /* ------------------------------------------------------------------------- *
  * Device self-tests of the float32 building blocks (used by tests/ on the GPU box):
  * the device restatements of numpy's float32 log / exp and of scipy's row softmax.

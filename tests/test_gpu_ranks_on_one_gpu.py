@@ -519,3 +519,57 @@ def test_variant_sharded_mstep_is_bit_identical_to_the_reference(world, monkeypa
     for betas, probs in by_sums:
         assert np.allclose(betas, fx['em0_learnt_betas'], rtol=3e-7, atol=0)
         assert np.abs(probs - fx[f'em0_it{n_it - 1}_probs']).max() <= 1e-5
+
+
+@pytest.mark.parametrize('mode', ['exact', 'guarded'])
+def test_compact_exchange_of_the_posterior_rows(mode, monkeypatch):
+    """Variant-sharded M-step, G <= 64 (include/demux_hip_debug.h: dmx_get_exchange_compact): a barcode with ONE live posterior is
+    described by its 8-byte code, which travels anyway; only the rows of the others travel, in a list of bounded capacity, and the
+    receivers rebuild the table.  10 000 barcodes x 3 000 SNPs x 48 genotypes on 3 ranks, 6 iterations: with the compact form
+    (default), with a capacity of 16 rows (every list overflows: the whole table travels, decided alike on every rank) and with the
+    compact form off - the same bits every time, equal to ONE context holding everything; and the compact form did carry the
+    exchange where it could."""
+    monkeypatch.setenv('DEMUXALOT_AMD_EXCHANGE', 'variant')
+    monkeypatch.setenv('DEMUXALOT_AMD_ESTEP', mode)
+    from demuxalot_amd import distributed, synth
+    from demuxalot_amd.device import DeviceContext
+    G, world, n_it = 48, 3, 6
+    p = synth.generate(10_000, 3000, G, calls_per_barcode=400, seed=61)
+    betas = p.prior_betas()
+    pen = np.zeros(G, dtype=np.float32)
+    with DeviceContext(0) as ctx:
+        ctx.set_problem(p.n_barcodes, p.n_variants, G, p.variant_id, p.compressed_cb, p.p_base_wrong, p.v2snp)
+        ctx.set_betas(betas)
+        ctx.set_mstep_tiles('never')           # (a rank's M-step is the work-item form: the same float64 order)
+        ctx.set_mstep_incremental(False)
+        _l, want_probs, want_add = ctx.em(n_it, 0.01, pen, False, fetch_logits=False)
+    outcomes = {}
+    for setting in (None, '16', '0'):
+        if setting is None:
+            monkeypatch.delenv('DEMUXALOT_AMD_EXCHANGE_COMPACT', raising=False)
+        else:
+            monkeypatch.setenv('DEMUXALOT_AMD_EXCHANGE_COMPACT', setting)
+        shared = ThreadWorld(world)
+
+        def rank_body(plane):
+            em = distributed.ShardedEM(plane, p.n_barcodes, p.v2snp, betas, p.variant_id, p.compressed_cb, p.p_base_wrong)
+            try:
+                probs, addition = em.learn(n_it, 0.01, pen, False)
+                return em.lo, em.hi, probs, addition, em.ctx.exchange_compact()
+            finally:
+                em.ctx.close()
+
+        outcomes[setting] = shared.run(rank_body)
+    for setting, results in outcomes.items():
+        for lo, hi, probs, addition, _stats in results:
+            if mode == 'exact':
+                fio.assert_bitwise(probs, want_probs[lo:hi], f'compact={setting}: posterior rows [{lo}, {hi})')
+                fio.assert_bitwise(addition, want_add, f'compact={setting}: addition')
+            fio.assert_bitwise(probs, outcomes['0'][[r[0] for r in outcomes['0']].index(lo)][2], f'compact={setting} vs off: posterior rows')
+            fio.assert_bitwise(addition, outcomes['0'][0][3], f'compact={setting} vs off: addition')
+    taken, overflows, cap = outcomes[None][0][4]
+    assert cap >= 64 and taken >= 2 and taken + overflows == n_it - 1, outcomes[None][0][4]   # (one exchange per M-step; the first ones may overflow)
+    taken16, overflows16, cap16 = outcomes['16'][0][4]
+    assert cap16 == 16 and overflows16 == n_it - 1 and taken16 == 0, outcomes['16'][0][4]
+    assert outcomes['0'][0][4] == (0, 0, 0)
+    print(f'{mode}: compact exchanges {taken} of {n_it - 1} (capacity {cap} rows per rank); capacity 16: {overflows16} fallbacks')
