@@ -240,6 +240,8 @@ struct dmx_ctx {
     bool emu_post_filled = false;            // emulated wire: the other ranks' blocks were filled once
     // compact exchange of the posterior rows (gather_posteriors; G <= 64): per rank a block of {rows listed, 3 pad, cap x (row, G floats)}
     unsigned *d_post_compact = nullptr;      // [nranks * post_compact_words]
+    uint2 *d_post_seen = nullptr;            // [rows_total] the code every row of d_post_g was last rebuilt from (0xFF..: unknown)
+    unsigned *h_post_counts = nullptr;       // pinned, [nranks]: the lists' lengths, read behind the all-gather
     size_t post_compact_words = 0;           // words per rank block (0: the whole table travels, as until round 6)
     unsigned post_compact_cap = 0;           // rows a block can list
     long long post_compact_taken = 0, post_compact_overflows = 0;  // E-steps exchanged compactly / that fell back to the whole table

@@ -445,6 +445,9 @@ void release_problem(dmx_ctx *c)
     dev_free(c, &c->d_nz_g, (size_t)c->rows_total * ((c->G + 63) / 64));
     dev_free(c, &c->d_post_g, (size_t)c->rows_total * c->G);
     dev_free(c, &c->d_post_compact, c->post_compact_words * (size_t)std::max(1, c->nranks));
+    dev_free(c, &c->d_post_seen, (size_t)c->rows_total);
+    if (c->h_post_counts) (void)hipHostFree(c->h_post_counts);
+    c->h_post_counts = nullptr;
     c->post_compact_words = 0;
     c->post_compact_cap = 0;
     c->mshard = c->post_gathered = c->emu_post_filled = false;

@@ -167,7 +167,12 @@ hipError_t launch_post_compact_build(hipStream_t, const uint2 *, const float *, 
     block[0] = cap + 1;  // (no kernels here: "overflow", so that the host logic takes the whole-table path it can execute)
     return hipSuccess;
 }
-hipError_t launch_post_reconstruct(hipStream_t, const uint2 *, float *, const unsigned *, unsigned long long, long long, int, int, int, unsigned) { return hipSuccess; }
+hipError_t launch_post_counts(hipStream_t, const unsigned *blocks, unsigned long long block_words, int nranks, unsigned *out)
+{
+    for (int r = 0; r < nranks; r++) out[r] = blocks[(size_t)r * block_words];
+    return hipSuccess;
+}
+hipError_t launch_post_reconstruct(hipStream_t, const uint2 *, float *, const unsigned *, unsigned long long, long long, int, int, int, unsigned, uint2 *) { return hipSuccess; }
 hipError_t launch_prior_betas(hipStream_t, const float *, float *, const unsigned long long *, const int *, const int *, const int *,
                               long long, int, double, float *) { return hipSuccess; }
 hipError_t launch_rebuild_nz(hipStream_t, const float *, long long, int, int, float, unsigned long long *, uint2 *) { return hipSuccess; }

@@ -401,8 +401,9 @@ hipError_t launch_add_f32(hipStream_t st, const float *a, const float *b, float 
 hipError_t launch_delay(hipStream_t st, long long ticks);
 // compact exchange of the posterior rows (kernels.hip: k_post_compact_build / k_post_reconstruct; dmx_exchange.cpp: gather_posteriors)
 hipError_t launch_post_compact_build(hipStream_t st, const uint2 *first, const float *post, long long B, int G, unsigned cap, unsigned *block);
+hipError_t launch_post_counts(hipStream_t st, const unsigned *blocks, unsigned long long block_words, int nranks, unsigned *out_host_visible);
 hipError_t launch_post_reconstruct(hipStream_t st, const uint2 *first_g, float *post_g, const unsigned *blocks, unsigned long long block_words,
-                                   long long rows_pad, int G, int nranks, int own, unsigned cap);
+                                   long long rows_pad, int G, int nranks, int own, unsigned cap, uint2 *seen);
 hipError_t launch_f32_to_f64(hipStream_t st, const float *in, double *out, long long n);
 hipError_t launch_prior_betas(hipStream_t st, const float *betas, float *bsum, const unsigned long long *n_mol,
                               const int *v2snp, const int *snp_ptr, const int *snp_vars, long long V, int G,

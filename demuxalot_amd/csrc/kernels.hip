@@ -3378,22 +3378,37 @@ __global__ __launch_bounds__(256) void k_post_compact_build(const uint2 *__restr
 }
 
 // the other ranks' rows: a wavefront per row with at most one live posterior (from its code), then a wavefront per listed row
+// (`seen`: the code every row of post_g was last rebuilt from - a row whose code has not changed since is what it should be already:
+// 99 % of the barcodes of a converged experiment keep a posterior of exactly 1.0 for the same donor; 0xFF..: unknown.)
+// A lane per row compares; the rows that changed are rebuilt by the whole wavefront, one after the other.
 __global__ __launch_bounds__(256) void k_post_reconstruct(const uint2 *__restrict__ first_g, float *__restrict__ post_g, const unsigned *__restrict__ blocks,
-                                                          unsigned long long block_words, long long rows_pad, int G, int nranks, int own, unsigned cap)
+                                                          unsigned long long block_words, long long rows_pad, int G, int nranks, int own, unsigned cap,
+                                                          uint2 *__restrict__ seen)
 {
     const int lane = threadIdx.x & 63;
     const long long wave = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
-    const long long n_rows = rows_pad * nranks;
-    if (wave < n_rows) {
-        const long long r = wave / rows_pad;
-        if (r == own) return;
-        const uint2 code = first_g[wave];
-        const unsigned nnz = code.y & 127u;
-        if (nnz <= 1u && lane < G)
-            post_g[(size_t)wave * G + lane] = (nnz == 1u && lane == (int)((code.y >> 7) & 63u)) ? __uint_as_float(code.x) : 0.0f;
+    const long long n_rows = rows_pad * nranks, row_waves = (n_rows + 63) / 64;
+    if (wave < row_waves) {
+        const long long row = wave * 64 + lane;
+        bool rebuild = false;
+        uint2 code = make_uint2(0u, 0u);
+        if (row < n_rows && row / rows_pad != own) {
+            code = first_g[row];
+            const uint2 before = seen[row];
+            const bool single = (code.y & 127u) <= 1u;
+            rebuild = single && !(code.x == before.x && code.y == before.y);
+            if (rebuild) seen[row] = code;
+            else if (!single) seen[row] = make_uint2(0xFFFFFFFFu, 0xFFFFFFFFu);  // (a listed row: rewritten below, every time)
+        }
+        for (unsigned long long m = __ballot(rebuild); m != 0ull; m &= m - 1ull) {  // (uniform)
+            const int src = __builtin_ctzll(m);
+            const unsigned cx = (unsigned)__shfl((int)code.x, src), cy = (unsigned)__shfl((int)code.y, src);
+            if (lane < G)
+                post_g[(size_t)(wave * 64 + src) * G + lane] = ((cy & 127u) == 1u && lane == (int)((cy >> 7) & 63u)) ? __uint_as_float(cx) : 0.0f;
+        }
         return;
     }
-    const long long e_id = wave - n_rows;
+    const long long e_id = wave - row_waves;
     const long long r = e_id / cap;
     const unsigned at = (unsigned)(e_id - r * cap);
     if (r >= nranks || r == own) return;
@@ -3402,6 +3417,18 @@ __global__ __launch_bounds__(256) void k_post_reconstruct(const uint2 *__restric
     const unsigned *e = block + 4 + (size_t)at * (size_t)(1 + G);
     const long long row = (long long)e[0];
     if (row < rows_pad && lane < G) post_g[((size_t)r * rows_pad + row) * G + lane] = __uint_as_float(e[1 + lane]);
+}
+
+// the lists' lengths of all ranks into host-visible memory (one small kernel: a strided 4-byte copy per rank cost 70 us of runtime overhead)
+__global__ void k_post_counts(const unsigned *__restrict__ blocks, unsigned long long block_words, int nranks, unsigned *__restrict__ out)
+{
+    if ((int)threadIdx.x < nranks) out[threadIdx.x] = blocks[(size_t)threadIdx.x * block_words];
+}
+
+hipError_t launch_post_counts(hipStream_t st, const unsigned *blocks, unsigned long long block_words, int nranks, unsigned *out_host_visible)
+{
+    hipLaunchKernelGGL(k_post_counts, dim3(1), dim3(1024), 0, st, blocks, block_words, nranks, out_host_visible);
+    return hipGetLastError();
 }
 
 hipError_t launch_post_compact_build(hipStream_t st, const uint2 *first, const float *post, long long B, int G, unsigned cap, unsigned *block)
@@ -3413,11 +3440,11 @@ hipError_t launch_post_compact_build(hipStream_t st, const uint2 *first, const f
 }
 
 hipError_t launch_post_reconstruct(hipStream_t st, const uint2 *first_g, float *post_g, const unsigned *blocks, unsigned long long block_words,
-                                   long long rows_pad, int G, int nranks, int own, unsigned cap)
+                                   long long rows_pad, int G, int nranks, int own, unsigned cap, uint2 *seen)
 {
-    const long long waves = rows_pad * nranks + (long long)cap * nranks;
+    const long long waves = (rows_pad * nranks + 63) / 64 + (long long)cap * nranks;
     if (waves == 0) return hipSuccess;
-    hipLaunchKernelGGL(k_post_reconstruct, dim3(blocks_for(waves, 4)), dim3(256), 0, st, first_g, post_g, blocks, block_words, rows_pad, G, nranks, own, cap);
+    hipLaunchKernelGGL(k_post_reconstruct, dim3(blocks_for(waves, 4)), dim3(256), 0, st, first_g, post_g, blocks, block_words, rows_pad, G, nranks, own, cap, seen);
     return hipGetLastError();
 }
 

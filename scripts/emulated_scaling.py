@@ -88,6 +88,7 @@ def main():
                     ctx.probs_from_betas(0.01, fetch=False)
                     ctx.estep(pen, with_doublets=dp > 0, fetch_logits=False, fetch_probs=False)
                     r = region(ctx, args.steps, args.warmup)
+                    r['compact_exchange (taken, overflowed, capacity rows)'] = ctx.exchange_compact()
                 finally:
                     ctx.close()
                 total_barcodes = B if kind == 'strong' else B * n
