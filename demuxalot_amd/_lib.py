@@ -91,6 +91,7 @@ SIGNATURES = {
 DEBUG_SIGNATURES = {
     'dmx_comm_init_emulated': (c_int, [_P, c_int, c_int, c_double, c_double, c_int]),
     'dmx_get_exchange_compact': (c_int, [_P, POINTER(c_int64), POINTER(c_int64), POINTER(c_int64)]),
+    'dmx_get_exchange_compact_table': (c_int, [_P, POINTER(c_int64), POINTER(c_int64), POINTER(c_int64)]),
     'dmx_get_guard_probes': (c_int, [_P, POINTER(c_int64), POINTER(c_int64)]),
     'dmx_debug_set_pass_ms': (c_int, [_P, c_double, c_double, c_double]),
     'dmx_get_redo_count': (c_int, [_P, POINTER(c_int64)]),

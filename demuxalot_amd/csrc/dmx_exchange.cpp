@@ -431,6 +431,23 @@ int layout_exchange(dmx_ctx *c)
         HIP_TRY(hipMalloc(&c->d_recv, c->recv_bytes));
         c->bytes += (int64_t)c->recv_bytes;
         HIP_TRY(hipMemsetAsync(c->d_exch, 0, c->exch_bytes, st));  // padding rows stay zero
+        // Compact exchange of the table (run_pstep): the rows of a rank's slice that changed since it sent them, in a list of at most
+        // slice_rows / 4 (beyond that: the whole slices, as until round 6).  DEMUXALOT_AMD_EXCHANGE_COMPACT=0 switches it off, =<n>: capacity n.
+        {
+            const char *compact = std::getenv("DEMUXALOT_AMD_EXCHANGE_COMPACT");
+            const long long asked = compact ? atoll(compact) : -1;
+            c->prob_list_words = 0;
+            c->prob_list_cap = 0;
+            c->prob_prev_valid = false;
+            if (asked != 0 && n > 1 && rows > 0) {
+                c->prob_list_cap = (unsigned)(asked > 0 ? std::min<long long>(asked, rows) : std::max<long long>(64, rows / 4));
+                c->prob_list_words = 4 + (size_t)c->prob_list_cap * (size_t)(1 + G);
+                DMX_TRY(dev_alloc(c, &c->d_prob_list, c->prob_list_words * (size_t)n));
+                HIP_TRY(hipMemsetAsync(c->d_prob_list, 0, sizeof(unsigned) * c->prob_list_words * (size_t)n, st));
+                DMX_TRY(dev_alloc(c, &c->d_prob_prev, (size_t)rows * G));
+                if (!c->h_prob_counts) HIP_TRY(hipHostMalloc((void **)&c->h_prob_counts, sizeof(unsigned) * (size_t)n, hipHostMallocDefault));
+            }
+        }
         HIP_TRY(hipStreamSynchronize(st));                          // `prow` is a local
         // DEMUXALOT_AMD_EXCHANGE=reduce_scatter keeps the M-step on every rank's own barcodes and reduce-scatters the sums;
         // =variant shards the M-step on variants whatever the sizes; default: whichever moves fewer bytes per iteration
@@ -620,6 +637,15 @@ int dmx_get_exchange_compact(dmx_ctx *c, int64_t *taken, int64_t *overflows, int
     if (taken) *taken = c->post_compact_taken;
     if (overflows) *overflows = c->post_compact_overflows;
     if (capacity_rows) *capacity_rows = c->post_compact_words ? (int64_t)c->post_compact_cap : 0;
+    return 0;
+}
+
+int dmx_get_exchange_compact_table(dmx_ctx *c, int64_t *taken, int64_t *overflows, int64_t *capacity_rows)
+{
+    if (!c) return fail(DMX_ERR_INVALID, "null ctx");
+    if (taken) *taken = c->prob_compact_taken;
+    if (overflows) *overflows = c->prob_compact_overflows;
+    if (capacity_rows) *capacity_rows = c->prob_list_words ? (int64_t)c->prob_list_cap : 0;
     return 0;
 }
 

@@ -423,6 +423,13 @@ void release_problem(dmx_ctx *c)
     dev_free(c, &c->d_raw, vg);
     c->have_raw = false;
     dev_free(c, &c->d_add, vg);
+    dev_free(c, &c->d_prob_list, c->prob_list_words * (size_t)std::max(1, c->nranks));
+    dev_free(c, &c->d_prob_prev, (size_t)c->slice_rows * c->G);
+    c->prob_list_words = 0;
+    c->prob_list_cap = 0;
+    c->prob_prev_valid = false;
+    if (c->h_prob_counts) (void)hipHostFree(c->h_prob_counts);
+    c->h_prob_counts = nullptr;
     dev_free(c, &c->d_prob, (size_t)c->prob_rows * c->G);
     dev_free(c, &c->d_prob16, c->cap_prob16);
     c->cap_prob16 = 0;

@@ -173,6 +173,7 @@ int copy_prob_out(dmx_ctx *c, float *dst)
 int copy_prob_in(dmx_ctx *c, const float *src)
 {
     const int G = c->G;
+    c->prob_prev_valid = false;  // (the table is the caller's now: what the ranks hold of each other's slices is no longer what they sent)
     if (!c->sliced) {
         HIP_TRY(hipMemcpyAsync(c->d_prob, src, sizeof(float) * c->V * G, hipMemcpyHostToDevice, c->stream));
         return 0;
@@ -256,7 +257,34 @@ int run_pstep(dmx_ctx *c, float lo, float hi, bool with_addition, bool with_half
     if (c->sliced) {  // everybody gets everybody's slice of genotype_prob
         timer_begin(c, DMX_T_ALLREDUCE, &ev);
         const size_t block = (size_t)c->slice_rows * c->G;
-        const int rc = coll_all_gather(c, c->d_prob, block, "genotype_prob");
+        float *mine = c->d_prob + (size_t)c->rank * block;
+        int rc = 0;
+        bool whole = true;
+        if (c->prob_list_words != 0 && c->prob_prev_valid) {
+            // Compact form (kernels.hip: k_prob_changes_build): only the rows of this rank's slice that changed since it sent them; every
+            // rank reads every rank's count behind the all-gather of the lists - one host synchronisation - and all take the whole
+            // slices when a list overflowed.  The receivers' copies are what was sent last, so the table keeps its bits.
+            HIP_TRY(dmx::launch_prob_changes_build(c->stream, mine, c->d_prob_prev, c->slice_rows, c->G, c->prob_list_cap,
+                                                   c->d_prob_list + (size_t)c->rank * c->prob_list_words));
+            rc = coll_all_gather(c, (float *)c->d_prob_list, c->prob_list_words, "changed rows of genotype_prob");
+            if (rc == 0) {
+                HIP_TRY(dmx::launch_post_counts(c->stream, c->d_prob_list, (unsigned long long)c->prob_list_words, c->nranks, c->h_prob_counts));
+                HIP_TRY(hipStreamSynchronize(c->stream));
+                whole = false;
+                for (int r = 0; r < c->nranks; r++) whole = whole || c->h_prob_counts[r] > c->prob_list_cap;
+                if (!whole) {
+                    c->prob_compact_taken++;
+                    HIP_TRY(dmx::launch_prob_changes_apply(c->stream, c->d_prob, c->d_prob_list, (unsigned long long)c->prob_list_words, c->slice_rows, c->G,
+                                                           c->nranks, c->rank, c->prob_list_cap));
+                } else {
+                    c->prob_compact_overflows++;
+                }
+            }
+        } else if (c->prob_list_words != 0) {  // the first table of a layout (or behind a table somebody else wrote): what is sent now is what the others hold
+            HIP_TRY(hipMemcpyAsync(c->d_prob_prev, mine, sizeof(float) * block, hipMemcpyDeviceToDevice, c->stream));
+            c->prob_prev_valid = true;
+        }
+        if (rc == 0 && whole) rc = coll_all_gather(c, c->d_prob, block, "genotype_prob");
         timer_end(c, DMX_T_ALLREDUCE, ev);
         if (rc) return rc;
     }
@@ -821,6 +849,7 @@ int dmx_probs_from_betas_f64(dmx_ctx *c, const double *betas, float lo, float hi
     HIP_TRY(hipMalloc((void **)&d_b, (vg ? vg : 1) * sizeof(double)));
     hipError_t e = vg ? hipMemcpyAsync(d_b, betas, vg * sizeof(double), hipMemcpyHostToDevice, c->stream) : hipSuccess;
     if (e == hipSuccess)
+        c->prob_prev_valid = false;  // (every rank computes the whole table here)
         e = dmx::launch_probs_from_betas_f64(c->stream, d_b, c->d_v2snp, c->d_snp_ptr, c->d_snp_vars, c->V, c->S, c->G, c->d_prow, lo, hi, c->d_prob);
     int rc_copy = 0;
     if (e == hipSuccess && vg) rc_copy = copy_prob_out(c, prob_out);

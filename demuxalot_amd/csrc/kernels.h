@@ -401,6 +401,10 @@ hipError_t launch_add_f32(hipStream_t st, const float *a, const float *b, float 
 hipError_t launch_delay(hipStream_t st, long long ticks);
 // compact exchange of the posterior rows (kernels.hip: k_post_compact_build / k_post_reconstruct; dmx_exchange.cpp: gather_posteriors)
 hipError_t launch_post_compact_build(hipStream_t st, const uint2 *first, const float *post, long long B, int G, unsigned cap, unsigned *block);
+// compact exchange of the genotype table (kernels.hip: k_prob_changes_build / k_prob_changes_apply; dmx_steps.cpp: run_pstep)
+hipError_t launch_prob_changes_build(hipStream_t st, const float *slice, float *prev, long long rows, int G, unsigned cap, unsigned *block);
+hipError_t launch_prob_changes_apply(hipStream_t st, float *table, const unsigned *blocks, unsigned long long block_words, long long slice_rows, int G,
+                                     int nranks, int own, unsigned cap);
 hipError_t launch_post_counts(hipStream_t st, const unsigned *blocks, unsigned long long block_words, int nranks, unsigned *out_host_visible);
 hipError_t launch_post_reconstruct(hipStream_t st, const uint2 *first_g, float *post_g, const unsigned *blocks, unsigned long long block_words,
                                    long long rows_pad, int G, int nranks, int own, unsigned cap, uint2 *seen);

@@ -3419,6 +3419,73 @@ __global__ __launch_bounds__(256) void k_post_reconstruct(const uint2 *__restric
     if (row < rows_pad && lane < G) post_g[((size_t)r * rows_pad + row) * G + lane] = __uint_as_float(e[1 + lane]);
 }
 
+// ---- compact exchange of the genotype table (sliced P-step; dmx_steps.cpp: run_pstep) ----
+// Between two EM iterations most rows of genotype_prob keep their bits (27 % change at the second iteration of the 200k x 100k x 64
+// experiment, 6 % at the third, 1 % at the fifth).  A rank lists the rows of ITS slice that differ from what it sent last (`prev`,
+// brought up to date here) - block = {rows listed (beyond `cap`: overflow - the whole slices travel), 3 words of padding, cap entries of
+// (row in the slice, G floats)} - and the receivers, whose copies of the slice are what was sent last, write the listed rows.
+__global__ __launch_bounds__(256) void k_prob_changes_build(const float *__restrict__ slice, float *__restrict__ prev, long long rows, int G,
+                                                            unsigned cap, unsigned *__restrict__ block)
+{
+    const int lane = threadIdx.x & 63;
+    const int W = (G + 63) >> 6;
+    const long long row = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    bool differs = false;
+    for (int s = 0; s < W; s++) {
+        const int g = lane + 64 * s;
+        if (g < G) differs = differs || __float_as_uint(slice[(size_t)row * G + g]) != __float_as_uint(prev[(size_t)row * G + g]);
+    }
+    if (__ballot(differs) == 0ull) return;  // (uniform)
+    unsigned at = 0;
+    if (lane == 0) at = atomicAdd(&block[0], 1u);
+    at = (unsigned)__shfl((int)at, 0);
+    unsigned *e = at < cap ? block + 4 + (size_t)at * (size_t)(1 + G) : nullptr;
+    if (e != nullptr && lane == 0) e[0] = (unsigned)row;
+    for (int s = 0; s < W; s++) {
+        const int g = lane + 64 * s;
+        if (g < G) {
+            const float v = slice[(size_t)row * G + g];
+            prev[(size_t)row * G + g] = v;
+            if (e != nullptr) e[1 + g] = __float_as_uint(v);
+        }
+    }
+}
+
+// the other ranks' listed rows into this rank's copy of their slices (a wavefront per entry)
+__global__ __launch_bounds__(256) void k_prob_changes_apply(float *__restrict__ table, const unsigned *__restrict__ blocks, unsigned long long block_words,
+                                                            long long slice_rows, int G, int nranks, int own, unsigned cap)
+{
+    const int lane = threadIdx.x & 63;
+    const long long e_id = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const long long r = e_id / cap;
+    const unsigned at = (unsigned)(e_id - r * cap);
+    if (r >= nranks || r == own) return;
+    const unsigned *block = blocks + (size_t)r * block_words;
+    if (at >= block[0]) return;
+    const unsigned *e = block + 4 + (size_t)at * (size_t)(1 + G);
+    const long long row = (long long)e[0];
+    if (row >= slice_rows) return;
+    for (int g = lane; g < G; g += 64) table[((size_t)r * slice_rows + row) * G + g] = __uint_as_float(e[1 + g]);
+}
+
+hipError_t launch_prob_changes_build(hipStream_t st, const float *slice, float *prev, long long rows, int G, unsigned cap, unsigned *block)
+{
+    hipError_t e = hipMemsetAsync(block, 0, 4 * sizeof(unsigned), st);
+    if (e != hipSuccess || rows == 0) return e;
+    hipLaunchKernelGGL(k_prob_changes_build, dim3(blocks_for(rows, 4)), dim3(256), 0, st, slice, prev, rows, G, cap, block);
+    return hipGetLastError();
+}
+
+hipError_t launch_prob_changes_apply(hipStream_t st, float *table, const unsigned *blocks, unsigned long long block_words, long long slice_rows, int G,
+                                     int nranks, int own, unsigned cap)
+{
+    const long long waves = (long long)cap * nranks;
+    if (waves == 0) return hipSuccess;
+    hipLaunchKernelGGL(k_prob_changes_apply, dim3(blocks_for(waves, 4)), dim3(256), 0, st, table, blocks, block_words, slice_rows, G, nranks, own, cap);
+    return hipGetLastError();
+}
+
 // the lists' lengths of all ranks into host-visible memory (one small kernel: a strided 4-byte copy per rank cost 70 us of runtime overhead)
 __global__ void k_post_counts(const unsigned *__restrict__ blocks, unsigned long long block_words, int nranks, unsigned *__restrict__ out)
 {

@@ -429,6 +429,12 @@ class DeviceContext:
         check(self._lib.dmx_get_exchange_compact(self._h, ctypes.byref(taken), ctypes.byref(overflows), ctypes.byref(cap)))
         return int(taken.value), int(overflows.value), int(cap.value)
 
+    def exchange_compact_table(self):
+        """The same for the all-gather of genotype_prob behind the sliced P-step (dmx_get_exchange_compact_table)."""
+        taken, overflows, cap = ctypes.c_int64(0), ctypes.c_int64(0), ctypes.c_int64(0)
+        check(self._lib.dmx_get_exchange_compact_table(self._h, ctypes.byref(taken), ctypes.byref(overflows), ctypes.byref(cap)))
+        return int(taken.value), int(overflows.value), int(cap.value)
+
     def exchange_mode(self):
         """None (no communicator) | 'variant' (M-step sharded on variants, posteriors all-gathered) | 'reduce_scatter' |
         'allreduce' (exchanges of the per-rank sums); include/demux_hip.h: dmx_get_exchange_mode."""

@@ -555,13 +555,13 @@ def test_compact_exchange_of_the_posterior_rows(mode, monkeypatch):
             em = distributed.ShardedEM(plane, p.n_barcodes, p.v2snp, betas, p.variant_id, p.compressed_cb, p.p_base_wrong)
             try:
                 probs, addition = em.learn(n_it, 0.01, pen, False)
-                return em.lo, em.hi, probs, addition, em.ctx.exchange_compact()
+                return em.lo, em.hi, probs, addition, em.ctx.exchange_compact(), em.ctx.exchange_compact_table()
             finally:
                 em.ctx.close()
 
         outcomes[setting] = shared.run(rank_body)
     for setting, results in outcomes.items():
-        for lo, hi, probs, addition, _stats in results:
+        for lo, hi, probs, addition, _stats, _table_stats in results:
             if mode == 'exact':
                 fio.assert_bitwise(probs, want_probs[lo:hi], f'compact={setting}: posterior rows [{lo}, {hi})')
                 fio.assert_bitwise(addition, want_add, f'compact={setting}: addition')
@@ -572,4 +572,10 @@ def test_compact_exchange_of_the_posterior_rows(mode, monkeypatch):
     taken16, overflows16, cap16 = outcomes['16'][0][4]
     assert cap16 == 16 and overflows16 == n_it - 1 and taken16 == 0, outcomes['16'][0][4]
     assert outcomes['0'][0][4] == (0, 0, 0)
-    print(f'{mode}: compact exchanges {taken} of {n_it - 1} (capacity {cap} rows per rank); capacity 16: {overflows16} fallbacks')
+    # ... and so for the table behind the sliced P-step: the rows of a slice that changed since they were sent (the first table of a
+    # layout travels whole: nobody holds anything yet)
+    t_taken, t_overflows, t_cap = outcomes[None][0][5]
+    assert t_cap >= 64 and t_taken >= 2 and t_taken + t_overflows == n_it - 1, outcomes[None][0][5]
+    assert outcomes['16'][0][5][0] == 0 and outcomes['16'][0][5][1] == n_it - 1 and outcomes['0'][0][5] == (0, 0, 0), (outcomes['16'][0][5], outcomes['0'][0][5])
+    print(f'{mode}: compact exchanges of the posteriors {taken} of {n_it - 1} (capacity {cap} rows per rank), of the table {t_taken} of {n_it - 1} '
+          f'(capacity {t_cap}); capacity 16: {overflows16} / {outcomes["16"][0][5][1]} fallbacks')
