@@ -233,6 +233,10 @@ int ensure_prob16(dmx_ctx *c)
 // table; a sliced run converts behind the all-gather of the slices: run_estep)
 int run_pstep(dmx_ctx *c, float lo, float hi, bool with_addition, bool with_half)
 {
+    // A sliced run converts the whole table behind the all-gather of the slices (run_estep) - unless the slices travel as lists of
+    // changed rows: then this rank's slice is written as binary16 here, the others' changed rows where they are applied, and the table
+    // that was valid before stays so.
+    const bool half_rows = with_half && c->sliced && c->prob_list_words != 0 && c->prob_prev_valid && c->prob16_valid && c->d_prob16 != nullptr;
     with_half = with_half && !c->sliced;
     if (with_half) DMX_TRY(ensure_prob16(c));
     c->prob16_valid = false;
@@ -251,7 +255,7 @@ int run_pstep(dmx_ctx *c, float lo, float hi, bool with_addition, bool with_half
     }
     HIP_TRY(dmx::launch_probs_from_betas(c->stream, c->d_prior, with_addition ? c->d_add : nullptr, c->d_v2snp,
                                          c->d_snp_ptr, c->d_snp_vars, v0, v1 - v0, c->sliced ? -1LL : (long long)c->S, c->G, c->d_prow, lo, hi,
-                                         c->d_prob, with_half ? c->d_prob16 : nullptr));
+                                         c->d_prob, (with_half || half_rows) ? c->d_prob16 : nullptr));
     c->prob16_valid = with_half;
     timer_end(c, DMX_T_PSTEP, ev);
     if (c->sliced) {  // everybody gets everybody's slice of genotype_prob
@@ -275,7 +279,8 @@ int run_pstep(dmx_ctx *c, float lo, float hi, bool with_addition, bool with_half
                 if (!whole) {
                     c->prob_compact_taken++;
                     HIP_TRY(dmx::launch_prob_changes_apply(c->stream, c->d_prob, c->d_prob_list, (unsigned long long)c->prob_list_words, c->slice_rows, c->G,
-                                                           c->nranks, c->rank, c->prob_list_cap));
+                                                           c->nranks, c->rank, c->prob_list_cap, half_rows ? (unsigned short *)c->d_prob16 : nullptr));
+                    c->prob16_valid = half_rows;
                 } else {
                     c->prob_compact_overflows++;
                 }
@@ -512,8 +517,13 @@ int run_estep(dmx_ctx *c, int with_doublets, bool with_prior, int prior_dtype, f
             a.guard_alt_per_call = capable ? dmx::GUARD_PER_CALL_COARSE : 0.0f;
             a.guard_alt_accum = capable ? dmx::GUARD_ACCUM_F32 : 0.0f;
             if (allow_coarse) {
-                if (!c->prob16_valid)  // (the P-step of a dmx_em / dmx_run_iterations call has written it already)
-                    HIP_TRY(dmx::launch_prob_to_half(c->stream, c->d_prob, c->prob_rows, c->G, c->d_prob16, c->d_guard_count + dmx::GS_SKIP_COARSE));
+                if (!c->prob16_valid) {  // (the P-step of a dmx_em / dmx_run_iterations call has written it already)
+                    // a sliced run whose slices travel as lists of changed rows keeps the binary16 table up to date row by row from here on
+                    // (run_pstep): converted whatever level the device takes, so that the host knows it valid
+                    const bool kept = c->sliced && c->prob_list_words != 0;
+                    HIP_TRY(dmx::launch_prob_to_half(c->stream, c->d_prob, c->prob_rows, c->G, c->d_prob16, kept ? nullptr : c->d_guard_count + dmx::GS_SKIP_COARSE));
+                    c->prob16_valid = kept;
+                }
                 dmx::EstepArgs coarse = a;
                 coarse.prob16 = c->d_prob16;
                 coarse.coarse_stream = c->d_coarse_stream;

@@ -172,7 +172,7 @@ hipError_t launch_prob_changes_build(hipStream_t, const float *, float *, long l
     block[0] = cap + 1;  // (no kernels here: "overflow" - the whole slices travel, which the host logic can execute)
     return hipSuccess;
 }
-hipError_t launch_prob_changes_apply(hipStream_t, float *, const unsigned *, unsigned long long, long long, int, int, int, unsigned) { return hipSuccess; }
+hipError_t launch_prob_changes_apply(hipStream_t, float *, const unsigned *, unsigned long long, long long, int, int, int, unsigned, unsigned short *) { return hipSuccess; }
 hipError_t launch_post_counts(hipStream_t, const unsigned *blocks, unsigned long long block_words, int nranks, unsigned *out)
 {
     for (int r = 0; r < nranks; r++) out[r] = blocks[(size_t)r * block_words];

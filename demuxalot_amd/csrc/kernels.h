@@ -404,7 +404,7 @@ hipError_t launch_post_compact_build(hipStream_t st, const uint2 *first, const f
 // compact exchange of the genotype table (kernels.hip: k_prob_changes_build / k_prob_changes_apply; dmx_steps.cpp: run_pstep)
 hipError_t launch_prob_changes_build(hipStream_t st, const float *slice, float *prev, long long rows, int G, unsigned cap, unsigned *block);
 hipError_t launch_prob_changes_apply(hipStream_t st, float *table, const unsigned *blocks, unsigned long long block_words, long long slice_rows, int G,
-                                     int nranks, int own, unsigned cap);
+                                     int nranks, int own, unsigned cap, unsigned short *table16);
 hipError_t launch_post_counts(hipStream_t st, const unsigned *blocks, unsigned long long block_words, int nranks, unsigned *out_host_visible);
 hipError_t launch_post_reconstruct(hipStream_t st, const uint2 *first_g, float *post_g, const unsigned *blocks, unsigned long long block_words,
                                    long long rows_pad, int G, int nranks, int own, unsigned cap, uint2 *seen);

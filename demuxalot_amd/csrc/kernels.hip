@@ -3453,8 +3453,9 @@ __global__ __launch_bounds__(256) void k_prob_changes_build(const float *__restr
 }
 
 // the other ranks' listed rows into this rank's copy of their slices (a wavefront per entry)
+// (table16, nullable: the binary16 table of the coarse pass, kept up to date row by row instead of converted as a whole behind the exchange)
 __global__ __launch_bounds__(256) void k_prob_changes_apply(float *__restrict__ table, const unsigned *__restrict__ blocks, unsigned long long block_words,
-                                                            long long slice_rows, int G, int nranks, int own, unsigned cap)
+                                                            long long slice_rows, int G, int nranks, int own, unsigned cap, unsigned short *__restrict__ table16)
 {
     const int lane = threadIdx.x & 63;
     const long long e_id = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -3466,7 +3467,11 @@ __global__ __launch_bounds__(256) void k_prob_changes_apply(float *__restrict__ 
     const unsigned *e = block + 4 + (size_t)at * (size_t)(1 + G);
     const long long row = (long long)e[0];
     if (row >= slice_rows) return;
-    for (int g = lane; g < G; g += 64) table[((size_t)r * slice_rows + row) * G + g] = __uint_as_float(e[1 + g]);
+    for (int g = lane; g < G; g += 64) {
+        const float v = __uint_as_float(e[1 + g]);
+        table[((size_t)r * slice_rows + row) * G + g] = v;
+        if (table16 != nullptr) table16[((size_t)r * slice_rows + row) * (size_t)(2 * G) + g] = __builtin_bit_cast(unsigned short, (_Float16)v);
+    }
 }
 
 hipError_t launch_prob_changes_build(hipStream_t st, const float *slice, float *prev, long long rows, int G, unsigned cap, unsigned *block)
@@ -3478,11 +3483,11 @@ hipError_t launch_prob_changes_build(hipStream_t st, const float *slice, float *
 }
 
 hipError_t launch_prob_changes_apply(hipStream_t st, float *table, const unsigned *blocks, unsigned long long block_words, long long slice_rows, int G,
-                                     int nranks, int own, unsigned cap)
+                                     int nranks, int own, unsigned cap, unsigned short *table16)
 {
     const long long waves = (long long)cap * nranks;
     if (waves == 0) return hipSuccess;
-    hipLaunchKernelGGL(k_prob_changes_apply, dim3(blocks_for(waves, 4)), dim3(256), 0, st, table, blocks, block_words, slice_rows, G, nranks, own, cap);
+    hipLaunchKernelGGL(k_prob_changes_apply, dim3(blocks_for(waves, 4)), dim3(256), 0, st, table, blocks, block_words, slice_rows, G, nranks, own, cap, table16);
     return hipGetLastError();
 }
 
