@@ -354,6 +354,11 @@ int dmx_mstep_f64_sums(dmx_ctx *ctx, double contribution_power, double *sums_out
  *        produce); for calls in another order the n-rank sum takes a variant's calls rank after rank instead of in the
  *        given order: the same float64 terms, a float32 rounding tie at most -
  *     -> P-step (demux.py:267-274) of slice r -> all-gather of the float32 genotype_prob slices.
+ * (Round 6: both all-gathers travel COMPACTLY where they can - the posterior rows only of the barcodes with several live posteriors,
+ * the others being described by their 8-byte codes; the rows of genotype_prob only where they changed since they were sent -, as
+ * capacity-bounded lists with the whole-table all-gather as the fallback, decided alike on every rank from the gathered counts: one host
+ * synchronisation per exchange.  Same bits.  DEMUXALOT_AMD_EXCHANGE_COMPACT=0 switches that off; demux_hip_debug.h:
+ * dmx_get_exchange_compact.)
  * That exchange moves 4 G + 8 + 8 ceil(G / 64) bytes per barcode OF THE WHOLE JOB.  When that is more than 1.25 x the
  * [V, G] partial sums (many more barcodes than variants: n x 200k-barcode weak scaling), the exchange of the sums is
  * taken instead: M-step on every rank's own barcodes over all variants, reduce-scatter of the float64 / float32 partial
