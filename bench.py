@@ -1000,6 +1000,8 @@ def main():
         ctx.set_addition(None)
         ctx.probs_from_betas(0.01, fetch=False)
         ctx.estep(pen, with_doublets=dp > 0, fetch_logits=False, fetch_probs=False)
+        if args.mstep == 'auto':   # (the cold-start region installed the problem anew: announce the run length as the headline region does)
+            ctx.set_msteps_expected(args.warmup + args.steps)
         after_idle_region = timed_region(ctx, plane, args.steps, args.warmup, idle_s=0.5)
         after_idle_region['value'] = regions[kinds[-1]]['barcodes_total'] * args.steps / after_idle_region['elapsed']
 
