@@ -139,7 +139,6 @@ hipError_t launch_mstep_tiles(hipStream_t, const MstepArgs &, const MTileArgs &)
 hipError_t launch_guard_begin(hipStream_t, unsigned *, long long, int, int, int, int) { return hipSuccess; }
 hipError_t launch_prob_to_half(hipStream_t, const float *, long long, int, unsigned short *, const unsigned *) { return hipSuccess; }
 hipError_t launch_build_coarse_stream(hipStream_t, const CallPair *, const long long *, long long, unsigned, int, long long *, unsigned *, const int *, int, double *) { return hipSuccess; }
-hipError_t launch_barcode_log2_keep(hipStream_t, const CallPair *, const long long *, long long, double *) { return hipSuccess; }
 hipError_t launch_guard_stamp(hipStream_t, unsigned *, int) { return hipSuccess; }
 hipError_t launch_guard_compact(hipStream_t, unsigned *, const int *, unsigned, int *, const int *, long long) { return hipSuccess; }
 hipError_t launch_mcombine(hipStream_t, const MstepArgs &, const long long *, long long, long long, const int *, float *, double *,

@@ -308,7 +308,6 @@ constexpr int coarse_calls_per_gather(int K) { return K > 64 ? 1 : K > 32 ? 2 : 
 constexpr int coarse_batches_per_record(int cpg) { return cpg; }  // (kernels.hip: CoarseShape<CPG>::BPR)
 hipError_t launch_build_coarse_stream(hipStream_t st, const CallPair *stream, const long long *bin_ptr, long long n_bins, unsigned zero_off,
                                       int cpg, long long *coarse_bin_ptr, unsigned *out, const int *bin_rows, int R, double *log2_keep);
-hipError_t launch_barcode_log2_keep(hipStream_t st, const CallPair *pairs, const long long *pair_ptr, long long B, double *out);
 hipError_t launch_prob_to_half(hipStream_t st, const float *prob, long long rows, int G, unsigned short *out, const unsigned *skip);  // EstepArgs::prob16; *skip != 0: nothing
 hipError_t launch_softmax_rows(hipStream_t st, const EstepArgs &a);  // rows left as logits by the option-tile launches
 // dictionary form (estep_dict.hip): distinct values and codes of every row of `prob`; stat[0] = most distinct values

@@ -907,16 +907,6 @@ static __device__ __forceinline__ unsigned row_bcast(unsigned v, int n)  // lane
     return v;
 }
 
-// v_add_f32 whose first source is lane N of the caller's row of 16 lanes (written out: the vectoriser pairs the builtin's additions
-// into packed ones, which cannot take a DPP operand - two v_mov_b32_dpp and a v_mov per operand instead of none)
-template <int N>
-static __device__ __forceinline__ float add_row_bcast(unsigned w, float x)
-{
-    float r;
-    asm("v_add_f32_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "=v"(r) : "v"(w), "v"(x), "n"(N));
-    return r;
-}
-
 struct CoarseSum {
     float lo, hi;  // sums of log2 for genotypes 2 i and 2 i + 1 (i = lane % lanes per call) over the calls of this lane's block
 };
@@ -1170,23 +1160,6 @@ __global__ __launch_bounds__(256) void k_build_coarse_stream(const CallPair *__r
         const int row = bin_rows[bin * R + r];
         if (lane == 0 && row >= 0) log2_keep[row] = v;
     }
-}
-
-// sum over a barcode's calls of log2(keep), keep > 0 (one wavefront per barcode; float64)
-__global__ __launch_bounds__(256) void k_barcode_log2_keep(const CallPair *__restrict__ pairs, const long long *__restrict__ pair_ptr, long long B,
-                                                           double *__restrict__ out)
-{
-    const long long b = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (b >= B) return;
-    const int lane = threadIdx.x & 63;
-    double s = 0.0;
-    for (long long i = pair_ptr[b] + lane; i < pair_ptr[b + 1]; i += 64) {
-        const CallPair p = pairs[i];
-        if (p.keep[0] > 0.0f) s += log2((double)p.keep[0]);
-        if (p.keep[1] > 0.0f) s += log2((double)p.keep[1]);
-    }
-    for (int off = 32; off > 0; off >>= 1) s += shfl_xor_f64(s, off);
-    if (lane == 0) out[b] = s;
 }
 
 // float32 genotype table -> binary16, round to nearest even, at the float32 table's row offsets (EstepArgs::prob16)
@@ -3027,13 +3000,6 @@ hipError_t launch_build_coarse_stream(hipStream_t st, const CallPair *stream, co
         hipLaunchKernelGGL(k_build_coarse_stream<2>, dim3(blocks_for(n_bins, 4)), dim3(256), 0, st, stream, bin_ptr, coarse_bin_ptr, n_bins, zero_off, out, bin_rows, R, log2_keep);
     else
         hipLaunchKernelGGL(k_build_coarse_stream<4>, dim3(blocks_for(n_bins, 4)), dim3(256), 0, st, stream, bin_ptr, coarse_bin_ptr, n_bins, zero_off, out, bin_rows, R, log2_keep);
-    return hipGetLastError();
-}
-
-hipError_t launch_barcode_log2_keep(hipStream_t st, const CallPair *pairs, const long long *pair_ptr, long long B, double *out)
-{
-    if (B == 0) return hipSuccess;
-    hipLaunchKernelGGL(k_barcode_log2_keep, dim3(blocks_for(B, 4)), dim3(256), 0, st, pairs, pair_ptr, B, out);
     return hipGetLastError();
 }
 
