@@ -243,13 +243,15 @@ struct dmx_ctx {
     uint2 *d_post_seen = nullptr;            // [rows_total] the code every row of d_post_g was last rebuilt from (0xFF..: unknown)
     unsigned *h_post_counts = nullptr;       // pinned, [nranks]: the lists' lengths, read behind the all-gather
     size_t post_compact_words = 0;           // words per rank block (0: the whole table travels, as until round 6)
-    unsigned post_compact_cap = 0;           // rows a block can list
+    unsigned post_compact_cap = 0;           // rows a block can list at most
+    unsigned post_cap_now = 0;               // ... in the coming exchange: twice what the longest list of the last one held (every rank reads every count: the same choice everywhere)
     long long post_compact_taken = 0, post_compact_overflows = 0;  // E-steps exchanged compactly / that fell back to the whole table
     // compact exchange of the genotype table (run_pstep; sliced P-step): the rows of this rank's slice that changed since it sent them
     unsigned *d_prob_list = nullptr;         // [nranks * prob_list_words] {rows listed, 3 pad, cap x (row, G floats)} per rank
     float *d_prob_prev = nullptr;            // [slice_rows, G] this rank's slice as the other ranks hold it
     size_t prob_list_words = 0;              // (0: the whole slices travel)
     unsigned prob_list_cap = 0;
+    unsigned prob_cap_now = 0;               // (as post_cap_now)
     bool prob_prev_valid = false;            // d_prob_prev is what every rank holds of this slice
     unsigned *h_prob_counts = nullptr;       // pinned, [nranks]
     long long prob_compact_taken = 0, prob_compact_overflows = 0;

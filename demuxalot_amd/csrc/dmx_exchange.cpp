@@ -369,6 +369,7 @@ int shard_mstep_by_variant(dmx_ctx *c, bool force)
     if (G <= 64 && asked != 0 && n > 1) {
         c->post_compact_cap = (unsigned)(asked > 0 ? std::min<long long>(asked, rows_pad) : std::max<long long>(64, rows_pad / 4));
         c->post_compact_words = 4 + (size_t)c->post_compact_cap * (size_t)(1 + G);
+        c->post_cap_now = c->post_compact_cap;
         DMX_TRY(dev_alloc(c, &c->d_post_compact, c->post_compact_words * (size_t)n));
         HIP_TRY(hipMemsetAsync(c->d_post_compact, 0, sizeof(unsigned) * c->post_compact_words * (size_t)n, st));
         DMX_TRY(dev_alloc(c, &c->d_post_seen, (size_t)c->rows_total));
@@ -442,6 +443,7 @@ int layout_exchange(dmx_ctx *c)
             if (asked != 0 && n > 1 && rows > 0) {
                 c->prob_list_cap = (unsigned)(asked > 0 ? std::min<long long>(asked, rows) : std::max<long long>(64, rows / 4));
                 c->prob_list_words = 4 + (size_t)c->prob_list_cap * (size_t)(1 + G);
+                c->prob_cap_now = c->prob_list_cap;
                 DMX_TRY(dev_alloc(c, &c->d_prob_list, c->prob_list_words * (size_t)n));
                 HIP_TRY(hipMemsetAsync(c->d_prob_list, 0, sizeof(unsigned) * c->prob_list_words * (size_t)n, st));
                 DMX_TRY(dev_alloc(c, &c->d_prob_prev, (size_t)rows * G));
@@ -482,32 +484,41 @@ int gather_posteriors(dmx_ctx *c)
         c->emu_post_filled = true;
     }
     const bool compact = c->post_compact_words != 0;
+    // The lists of THIS exchange hold four times what the longest list of the last one held + 512 rows (at most rows / 4): every rank has read every
+    // count, so every rank sizes alike - at convergence a list is 2 % of the rows, not 25 %.  A list that outgrows that overflows:
+    // the whole table travels and the next lists are full-sized again.
+    const unsigned cap_now = compact ? std::max(1u, std::min(c->post_cap_now, c->post_compact_cap)) : 0u;
+    const size_t words_now = 4 + (size_t)cap_now * (size_t)(1 + G);
+    if (compact && c->emulated)  // (nobody fills the other ranks' blocks: they list nothing, wherever this exchange's block size puts their counts)
+        HIP_TRY(hipMemsetAsync(c->d_post_compact, 0, sizeof(unsigned) * words_now * (size_t)c->nranks, c->stream));
     if (compact)  // this rank's rows with several live posteriors, listed (the count may run beyond the capacity: overflow)
-        HIP_TRY(dmx::launch_post_compact_build(c->stream, c->d_first_g + c->rank * rows, c->d_post_g + c->rank * rows * G, c->B, G, c->post_compact_cap,
-                                               c->d_post_compact + (size_t)c->rank * c->post_compact_words));
+        HIP_TRY(dmx::launch_post_compact_build(c->stream, c->d_first_g + c->rank * rows, c->d_post_g + c->rank * rows * G, c->B, G, cap_now,
+                                               c->d_post_compact + (size_t)c->rank * words_now));
     coll_group_begin(c);  // one launch for the tables
     rc = coll_all_gather(c, (float *)c->d_first_g, rows * 2, "posterior codes");
     if (rc == 0) rc = coll_all_gather(c, (float *)c->d_nz_g, rows * W * 2, "posterior bitmaps");
-    if (rc == 0 && compact) rc = coll_all_gather(c, (float *)c->d_post_compact, c->post_compact_words, "listed posterior rows");
+    if (rc == 0 && compact) rc = coll_all_gather(c, (float *)c->d_post_compact, words_now, "listed posterior rows");
     if (rc == 0 && !compact) rc = coll_all_gather(c, c->d_post_g, rows * G, "singlet posteriors");
     int rc_end = coll_group_end(c);
     if (rc == 0) rc = rc_end;
     if (rc == 0 && compact) {
-        // every rank reads every rank's count: the same decision everywhere (the one host synchronisation of the exchange)
-        // (a small kernel writes the counts into pinned, device-visible host memory: a copy per rank was 8 x 8 us at 8 ranks, one strided
+        // every rank reads every rank's count: the same decision everywhere (the one host synchronisation of the exchange; a small kernel
+        // writes the counts into pinned, device-visible host memory: a copy per rank was 8 x 8 us at 8 ranks, one strided
         // hipMemcpy2DAsync 70 us of runtime overhead)
-        HIP_TRY(dmx::launch_post_counts(c->stream, c->d_post_compact, (unsigned long long)c->post_compact_words, c->nranks, c->h_post_counts));
+        HIP_TRY(dmx::launch_post_counts(c->stream, c->d_post_compact, (unsigned long long)words_now, c->nranks, c->h_post_counts));
         HIP_TRY(hipStreamSynchronize(c->stream));
-        bool overflow = false;
-        for (int r = 0; r < c->nranks; r++) overflow = overflow || c->h_post_counts[r] > c->post_compact_cap;
+        unsigned longest = 0;
+        for (int r = 0; r < c->nranks; r++) longest = std::max(longest, c->h_post_counts[r]);
+        const bool overflow = longest > cap_now;
+        c->post_cap_now = overflow ? c->post_compact_cap : (unsigned)std::min<unsigned long long>(c->post_compact_cap, 4ull * longest + 512ull);
         if (overflow) {  // (dense posteriors: the first E-steps of a run that starts from uninformative genotypes)
             c->post_compact_overflows++;
             rc = coll_all_gather(c, c->d_post_g, rows * G, "singlet posteriors (the lists overflowed)");
             HIP_TRY(hipMemsetAsync(c->d_post_seen, 0xFF, sizeof(uint2) * (size_t)c->rows_total, c->stream));  // (the rows are the senders' own now)
         } else {
             c->post_compact_taken++;
-            HIP_TRY(dmx::launch_post_reconstruct(c->stream, c->d_first_g, c->d_post_g, c->d_post_compact, (unsigned long long)c->post_compact_words,
-                                                 (long long)rows, G, c->nranks, c->rank, c->post_compact_cap, c->d_post_seen));
+            HIP_TRY(dmx::launch_post_reconstruct(c->stream, c->d_first_g, c->d_post_g, c->d_post_compact, (unsigned long long)words_now,
+                                                 (long long)rows, G, c->nranks, c->rank, cap_now, c->d_post_seen));
         }
     }
     timer_end(c, DMX_T_ALLREDUCE, ev);

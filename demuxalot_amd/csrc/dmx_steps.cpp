@@ -268,18 +268,26 @@ int run_pstep(dmx_ctx *c, float lo, float hi, bool with_addition, bool with_half
             // Compact form (kernels.hip: k_prob_changes_build): only the rows of this rank's slice that changed since it sent them; every
             // rank reads every rank's count behind the all-gather of the lists - one host synchronisation - and all take the whole
             // slices when a list overflowed.  The receivers' copies are what was sent last, so the table keeps its bits.
-            HIP_TRY(dmx::launch_prob_changes_build(c->stream, mine, c->d_prob_prev, c->slice_rows, c->G, c->prob_list_cap,
-                                                   c->d_prob_list + (size_t)c->rank * c->prob_list_words));
-            rc = coll_all_gather(c, (float *)c->d_prob_list, c->prob_list_words, "changed rows of genotype_prob");
+            // (the lists are sized from the last exchange's counts, as the posteriors' are: dmx_exchange.cpp, gather_posteriors)
+            const unsigned cap_now = std::max(1u, std::min(c->prob_cap_now, c->prob_list_cap));
+            const size_t words_now = 4 + (size_t)cap_now * (size_t)(1 + c->G);
+            if (c->emulated)  // (nobody fills the other ranks' blocks: they list nothing, wherever this exchange's block size puts their counts)
+                HIP_TRY(hipMemsetAsync(c->d_prob_list, 0, sizeof(unsigned) * words_now * (size_t)c->nranks, c->stream));
+            HIP_TRY(dmx::launch_prob_changes_build(c->stream, mine, c->d_prob_prev, c->slice_rows, c->G, cap_now,
+                                                   c->d_prob_list + (size_t)c->rank * words_now));
+            rc = coll_all_gather(c, (float *)c->d_prob_list, words_now, "changed rows of genotype_prob");
             if (rc == 0) {
-                HIP_TRY(dmx::launch_post_counts(c->stream, c->d_prob_list, (unsigned long long)c->prob_list_words, c->nranks, c->h_prob_counts));
+                HIP_TRY(dmx::launch_post_counts(c->stream, c->d_prob_list, (unsigned long long)words_now, c->nranks, c->h_prob_counts));
                 HIP_TRY(hipStreamSynchronize(c->stream));
-                whole = false;
-                for (int r = 0; r < c->nranks; r++) whole = whole || c->h_prob_counts[r] > c->prob_list_cap;
+                unsigned longest = 0;
+                for (int r = 0; r < c->nranks; r++) longest = std::max(longest, c->h_prob_counts[r]);
+                whole = longest > cap_now;
+                if (std::getenv("DEMUXALOT_AMD_EXCHANGE_TRACE")) std::fprintf(stderr, "[table lists] longest %u capacity %u of %u\n", longest, cap_now, c->prob_list_cap);
+                c->prob_cap_now = whole ? c->prob_list_cap : (unsigned)std::min<unsigned long long>(c->prob_list_cap, 4ull * longest + 512ull);
                 if (!whole) {
                     c->prob_compact_taken++;
-                    HIP_TRY(dmx::launch_prob_changes_apply(c->stream, c->d_prob, c->d_prob_list, (unsigned long long)c->prob_list_words, c->slice_rows, c->G,
-                                                           c->nranks, c->rank, c->prob_list_cap, half_rows ? (unsigned short *)c->d_prob16 : nullptr));
+                    HIP_TRY(dmx::launch_prob_changes_apply(c->stream, c->d_prob, c->d_prob_list, (unsigned long long)words_now, c->slice_rows, c->G,
+                                                           c->nranks, c->rank, cap_now, half_rows ? (unsigned short *)c->d_prob16 : nullptr));
                     c->prob16_valid = half_rows;
                 } else {
                     c->prob_compact_overflows++;

@@ -89,6 +89,7 @@ def main():
                     ctx.estep(pen, with_doublets=dp > 0, fetch_logits=False, fetch_probs=False)
                     r = region(ctx, args.steps, args.warmup)
                     r['compact_exchange (taken, overflowed, capacity rows)'] = ctx.exchange_compact()
+                    r['compact_exchange of the table (taken, overflowed, capacity rows)'] = ctx.exchange_compact_table()
                 finally:
                     ctx.close()
                 total_barcodes = B if kind == 'strong' else B * n
