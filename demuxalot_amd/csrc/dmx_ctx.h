@@ -124,6 +124,8 @@ struct dmx_ctx {
     bool mt_shift_tried = false;    // ... the tile cut for the exponents alone (plan_mstep_shifts)
     int mstep_tiles = 1;            // dmx_set_mstep_tiles: 0 never, 1 when building the records pays, 2 always
     long long msteps_done = 0;      // M-steps run on the resident problem
+    long long incr_rows = 0;        // barcode rows the incremental state was allocated for (a variant-sharded rank: those of all ranks)
+    unsigned char *d_incr_map = nullptr;  // [incr_rows] flags of the changed barcodes (variant-sharded rank: MIncrArgs::changed_map)
     bool incr_heavy = false;        // the incremental M-step keeps falling back to full passes on this problem: the tile-major records pay (run_mstep)
     int msteps_ahead = 0;           // M-steps the running dmx_em / dmx_run_iterations call still has to do (0 outside)
     long long msteps_expected = 0;  // dmx_set_msteps_expected: M-steps the caller says it will still run (counted down as they run)

@@ -372,9 +372,12 @@ void release_incremental(dmx_ctx *c)
 {
     const size_t vg = (size_t)c->V * c->G;
     dev_free(c, &c->d_acc64, vg);
-    dev_free(c, &c->d_prev_post, (size_t)c->B * c->G);
-    dev_free(c, &c->d_prev_first, (size_t)c->B);
-    dev_free(c, &c->d_incr_list, (size_t)c->B);
+    const size_t rows = (size_t)(c->incr_rows > 0 ? c->incr_rows : c->B);
+    dev_free(c, &c->d_prev_post, rows * c->G);
+    dev_free(c, &c->d_prev_first, rows);
+    dev_free(c, &c->d_incr_list, rows);
+    dev_free(c, &c->d_incr_map, rows);
+    c->incr_rows = 0;
     dev_free(c, &c->d_incr_touched, (size_t)c->V);
     dev_free(c, &c->d_incr_state, (size_t)(3 * dmx::IS_WORDS));
     c->incr_valid = false;

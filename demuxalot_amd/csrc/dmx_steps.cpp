@@ -622,6 +622,7 @@ int run_mstep(dmx_ctx *c, float power)
     a.fixed_shift_v = nullptr;
     a.fixed_acc64 = nullptr;
     a.fixed_state = nullptr;
+    a.incr_total = 0ull;
     // tile-major form (kernels.h: MTileArgs): sums in any order, so not with the exact additions; built on first use
     a.tiles_done = false;
     dmx::MTileArgs tiles{};
@@ -690,15 +691,25 @@ int run_mstep(dmx_ctx *c, float power)
         fixed_items = c->d_mt_shift_v != nullptr;
     }
     // Incremental form (kernels.h: MIncrArgs): one context with all calls of its barcodes, the tiles' per-variant exponents at hand.
-    const bool incremental = (a.tiles_done || fixed_items) && c->mstep_incremental && !dist && !c->sliced && c->d_mt_shift_v != nullptr &&
-                             a.out32 == c->d_add && c->d_call_rows != nullptr;
+    // ... or a variant-sharded rank with the tile-major records of its slice (round 6): the same sums over the barcodes of ALL ranks, the
+    // changed barcodes found in the gathered tables, the delta pass a masked walk of the slice's variant-major records (MIncrArgs::changed_map).
+    const bool sharded_incr = a.tiles_done && c->mstep_incremental == 1 && mshard && c->d_mt_shift_v != nullptr && a.out32 == c->d_add && c->G <= 64 &&
+                              c->d_item_variant != nullptr && c->rows_total > 0;
+    const bool incremental = sharded_incr || ((a.tiles_done || fixed_items) && c->mstep_incremental && !dist && !c->sliced && c->d_mt_shift_v != nullptr &&
+                                              a.out32 == c->d_add && c->d_call_rows != nullptr);
+    const long long incr_rows = sharded_incr ? c->rows_total : c->B;
     dmx::MIncrArgs incr{};
     if (incremental) {
         if (!c->d_acc64) {
+            c->incr_rows = incr_rows;
             DMX_TRY(dev_alloc(c, &c->d_acc64, (size_t)c->V * c->G));
-            DMX_TRY(dev_alloc(c, &c->d_prev_post, (size_t)c->B * c->G));
-            DMX_TRY(dev_alloc(c, &c->d_prev_first, (size_t)c->B));
-            DMX_TRY(dev_alloc(c, &c->d_incr_list, (size_t)c->B));
+            DMX_TRY(dev_alloc(c, &c->d_prev_post, (size_t)incr_rows * c->G));
+            DMX_TRY(dev_alloc(c, &c->d_prev_first, (size_t)incr_rows));
+            DMX_TRY(dev_alloc(c, &c->d_incr_list, (size_t)incr_rows));
+            if (sharded_incr) {
+                DMX_TRY(dev_alloc(c, &c->d_incr_map, (size_t)incr_rows));
+                HIP_TRY(hipMemsetAsync(c->d_incr_map, 0, (size_t)incr_rows, c->stream));
+            }
             DMX_TRY(dev_alloc(c, &c->d_incr_touched, (size_t)c->V));
             DMX_TRY(dev_alloc(c, &c->d_incr_state, (size_t)(3 * dmx::IS_WORDS)));  // two alternating sets + the counters
             HIP_TRY(hipMemsetAsync(c->d_incr_state, 0, sizeof(unsigned) * 3 * dmx::IS_WORDS, c->stream));
@@ -710,8 +721,8 @@ int run_mstep(dmx_ctx *c, float power)
             if (c->mstep_incremental == 2) {  // (measurement: the sums built from nothing by the delta pass instead of the full pass)
                 const unsigned on[2] = {1u, 1u};
                 HIP_TRY(hipMemsetAsync(c->d_acc64, 0, sizeof(unsigned long long) * (size_t)c->V * c->G, c->stream));
-                HIP_TRY(hipMemsetAsync(c->d_prev_post, 0, sizeof(float) * (size_t)c->B * c->G, c->stream));
-                HIP_TRY(hipMemsetAsync(c->d_prev_first, 0xFF, sizeof(uint2) * (size_t)c->B, c->stream));
+                HIP_TRY(hipMemsetAsync(c->d_prev_post, 0, sizeof(float) * (size_t)incr_rows * c->G, c->stream));
+                HIP_TRY(hipMemsetAsync(c->d_prev_first, 0xFF, sizeof(uint2) * (size_t)incr_rows, c->stream));
                 HIP_TRY(hipMemsetAsync(c->d_add, 0, sizeof(float) * (size_t)c->V * c->G, c->stream));
                 HIP_TRY(hipMemcpyAsync(c->d_incr_state + dmx::IS_VALID, &on[0], sizeof(unsigned), hipMemcpyHostToDevice, c->stream));
                 HIP_TRY(hipMemcpyAsync(c->d_incr_state + dmx::IS_FORCE, &on[1], sizeof(unsigned), hipMemcpyHostToDevice, c->stream));
@@ -731,12 +742,14 @@ int run_mstep(dmx_ctx *c, float power)
         incr.list = c->d_incr_list;
         incr.touched = c->d_incr_touched;
         incr.shift_v = c->d_mt_shift_v;
-        incr.pairs = c->d_call_pairs;
-        incr.call_rows = c->d_call_rows;
-        incr.pair_ptr = c->d_pair_ptr;
-        incr.B = c->B;
+        incr.pairs = sharded_incr ? nullptr : c->d_call_pairs;
+        incr.call_rows = sharded_incr ? nullptr : c->d_call_rows;
+        incr.pair_ptr = sharded_incr ? nullptr : c->d_pair_ptr;
+        incr.changed_map = sharded_incr ? c->d_incr_map : nullptr;
+        incr.B = incr_rows;
         incr.V = c->V;
         incr.floor = dmx::mincr_floor(power);
+        a.incr_total = sharded_incr ? 2ull * (unsigned long long)incr_rows : 0ull;
         tiles.acc64 = c->d_acc64;
         tiles.incr_state = incr.state;
         if (fixed_items) {
@@ -749,7 +762,8 @@ int run_mstep(dmx_ctx *c, float power)
         c->incr_valid = false;  // (another form writes the addition: the kept sums no longer describe it)
     }
     timer_begin(c, DMX_T_MSTEP, &ev);
-    if (incremental && fixed_items) HIP_TRY(dmx::launch_mstep_items_incremental(c->stream, a, incr));
+    if (sharded_incr) HIP_TRY(dmx::launch_mstep_incremental_sharded(c->stream, a, tiles, incr));
+    else if (incremental && fixed_items) HIP_TRY(dmx::launch_mstep_items_incremental(c->stream, a, incr));
     else if (incremental) HIP_TRY(dmx::launch_mstep_incremental(c->stream, a, tiles, incr));
     else if (a.tiles_done) HIP_TRY(dmx::launch_mstep_tiles(c->stream, a, tiles));
     else HIP_TRY(dmx::launch_mstep(c->stream, a));

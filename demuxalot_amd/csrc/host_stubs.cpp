@@ -135,6 +135,7 @@ hipError_t launch_estep_dict_block(hipStream_t, const EstepArgs &) { return hipS
 hipError_t launch_mstep(hipStream_t, const MstepArgs &) { return hipSuccess; }
 hipError_t launch_mstep_incremental(hipStream_t, const MstepArgs &, const MTileArgs &, const MIncrArgs &) { return hipSuccess; }
 hipError_t launch_mstep_items_incremental(hipStream_t, const MstepArgs &, const MIncrArgs &) { return hipSuccess; }
+hipError_t launch_mstep_incremental_sharded(hipStream_t, const MstepArgs &, const MTileArgs &, const MIncrArgs &) { return hipSuccess; }
 hipError_t launch_mstep_tiles(hipStream_t, const MstepArgs &, const MTileArgs &) { return hipSuccess; }
 hipError_t launch_guard_begin(hipStream_t, unsigned *, long long, int, int, int, int) { return hipSuccess; }
 hipError_t launch_prob_to_half(hipStream_t, const float *, long long, int, unsigned short *, const unsigned *) { return hipSuccess; }

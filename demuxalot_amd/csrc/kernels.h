@@ -270,6 +270,9 @@ struct MstepArgs {
     const unsigned char *fixed_shift_v;
     unsigned long long *fixed_acc64;
     const unsigned *fixed_state;
+    // incremental M-step of a variant-sharded rank (MIncrArgs::changed_map): the delta pass stands back when the changed barcodes are more
+    // than an eighth of incr_total (2 per barcode row of the job); 0: total_calls (one context with the calls of its barcodes)
+    unsigned long long incr_total;
 };
 
 // A posterior p <= 2^-80 contributes (p * keep)^2 = +0 exactly for |keep| <= 32 (|p * keep| <= 2^-75, and a
@@ -366,6 +369,12 @@ struct MIncrArgs {
     const long long *pair_ptr;
     long long B, V;
     float floor;            // mincr_floor(power)
+    // Variant-sharded rank (round 6): B = the barcode rows of ALL ranks (post / first: the gathered tables, row stride G), pair_ptr / pairs /
+    // call_rows null - a rank holds the barcode-major records of its own barcodes only.  The changed barcodes are flagged in changed_map
+    // [B] and the delta pass is a MASKED WALK of the rank's variant-major records (k_mincr_delta_masked): a record whose barcode is
+    // flagged adds the difference of its new and old integer contribution; k_mincr_finish then brings prev / prev_first of the listed
+    // barcodes up to date and clears their flags.
+    unsigned char *changed_map;
 };
 enum { IS_N = 0,        // changed barcodes of this M-step
        IS_CALLS = 2,    // (64 bit, words 2 and 3) their (padded) calls
@@ -380,6 +389,8 @@ inline float mincr_floor(float power) { return power * 126.0f > 52.0f ? exp2f(-5
 hipError_t launch_mstep_incremental(hipStream_t st, const MstepArgs &a, const MTileArgs &t, const MIncrArgs &x);
 // the same with the fixed-point work-item form as the full pass (MstepArgs::fixed_shift_v): no tile-major records needed
 hipError_t launch_mstep_items_incremental(hipStream_t st, const MstepArgs &a, const MIncrArgs &x);
+// ... of a variant-sharded rank: changes over the gathered tables -> masked walk of the slice's records | the tile-major full pass -> finish
+hipError_t launch_mstep_incremental_sharded(hipStream_t st, const MstepArgs &a, const MTileArgs &t, const MIncrArgs &x);
 constexpr int MTILE_LDS_BYTES = 64 * 1024;  // accumulators of a tile: with the 12 KB of dense-call queues, two workgroups of 1024 threads per CU
 constexpr int MTILE_MAX_VARIANTS = 128;     // 7 bits of the record
 hipError_t launch_mstep_tiles(hipStream_t st, const MstepArgs &a, const MTileArgs &t);

@@ -1920,7 +1920,7 @@ static __device__ __forceinline__ bool incr_full(const unsigned *state, const Ms
 {
     const unsigned long long calls = ((unsigned long long)state[IS_CALLS + 1] << 32) | state[IS_CALLS];
     if (state[IS_FORCE] != 0u) return dense_regime(a);
-    return state[IS_VALID] == 0u || 8ull * calls > a.total_calls || dense_regime(a);
+    return state[IS_VALID] == 0u || 8ull * calls > (a.incr_total ? a.incr_total : a.total_calls) || dense_regime(a);
 }
 
 // c in [0, 1] -> rint(c 2^shift) as an integer (k_mstep_tiles, k_mincr_delta and the fixed-point work-item form add the same
@@ -2469,7 +2469,8 @@ __global__ __launch_bounds__(256) void k_mincr_changes(MstepArgs a, MIncrArgs x)
         if (lane == 0) {
             if (changed) {
                 x.list[atomicAdd(x.state + IS_N, 1u)] = (int)bb;
-                atomicAdd((unsigned long long *)(x.state + IS_CALLS), 2ull * (unsigned long long)(x.pair_ptr[bb + 1] - x.pair_ptr[bb]));
+                atomicAdd((unsigned long long *)(x.state + IS_CALLS), x.pair_ptr ? 2ull * (unsigned long long)(x.pair_ptr[bb + 1] - x.pair_ptr[bb]) : 2ull);
+                if (x.changed_map) x.changed_map[bb] = 1;
             } else {
                 x.prev_first[bb] = a.first[bb];  // (nothing that matters changed: the next M-step need not look at its rows again)
             }
@@ -2532,6 +2533,52 @@ __global__ __launch_bounds__(256) void k_mincr_delta(MstepArgs a, MIncrArgs x)
     }
 }
 
+// Variant-sharded rank: the delta pass as a MASKED WALK of the rank's variant-major records (a wavefront per work item: one variant's
+// calls from the barcodes of all ranks).  A lane per record tests its barcode's flag; the flagged records are taken one after the other by
+// the whole wavefront, lane = genotype: new and old posterior row (the gathered table / prev), the difference of the two integer
+// contributions added to the variant's sums with device-scope atomics.  On converged iterations 1 % of the records are flagged and the
+// pass is a read of the records (8 bytes per call of the slice) and of a byte map that stays in the L2.
+template <bool SQUARE>
+__global__ __launch_bounds__(256) void k_mincr_delta_masked(MstepArgs a, MIncrArgs x)
+{
+    if (incr_full(x.state, a)) return;
+    const int lane = threadIdx.x & 63;
+    const int G = a.G;
+    auto quant = [&](float c, int shift) { return fixed_of(SQUARE ? c * c : powf(c, a.power), shift); };
+    for (long long slot = (long long)blockIdx.x * 4 + (threadIdx.x >> 6); slot < a.n_items; slot += (long long)gridDim.x * 4) {
+        const long long item = a.order[slot];
+        const int n = a.item_len[item];
+        const uint2 *__restrict__ calls = a.calls + a.item_start[item];
+        const long long v = a.item_variant[item];
+        const int shift = (int)x.shift_v[v];
+        bool touched = false;
+        for (int c0 = 0; c0 < n; c0 += 64) {
+            uint2 d = make_uint2(0u, 0u);
+            bool flagged = false;
+            if (c0 + lane < n) {
+                d = calls[c0 + lane];
+                flagged = x.changed_map[d.x] != 0;
+            }
+            for (unsigned long long m = __ballot(flagged); m != 0ull; m &= m - 1ull) {  // (uniform)
+                const int src = __builtin_ctzll(m);
+                const unsigned row = (unsigned)__shfl((int)d.x, src);
+                const float keep = __uint_as_float((unsigned)__shfl((int)d.y, src));
+                if (lane < G) {
+                    const float now = a.post[(size_t)row * a.K + lane], before = x.prev[(size_t)row * G + lane];
+                    if (mincr_differs(now, before, x.floor)) {
+                        const unsigned long long qn = quant(now * keep, shift), qo = quant(before * keep, shift);
+                        if (qn != qo) {
+                            __hip_atomic_fetch_add(&x.acc64[(size_t)v * G + lane], qn - qo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            touched = true;
+                        }
+                    }
+                }
+            }
+        }
+        if (__ballot(touched) != 0ull && lane == 0) x.touched[v] = 1;
+    }
+}
+
 // behind the delta pass: the rows of the addition whose sums changed (a thread per variant); behind a full pass: the posteriors and
 // codes it summed, for the next M-step to compare with.  Prepares the next M-step's state words.
 __global__ __launch_bounds__(256) void k_mincr_finish(MstepArgs a, MIncrArgs x)
@@ -2564,6 +2611,20 @@ __global__ __launch_bounds__(256) void k_mincr_finish(MstepArgs a, MIncrArgs x)
                 if (lane < G) a.out32[(size_t)vv * G + lane] = (float)__builtin_ldexp((double)(long long)x.acc64[(size_t)vv * G + lane], -shift);
             }
         }
+    }
+    if (!full && x.changed_map != nullptr) {  // masked walk: the listed barcodes' rows and codes become what the sums now hold
+        const unsigned n = x.state[IS_N];
+        const int lane = threadIdx.x & 63;
+        for (long long i = (tid - lane) / 64; i < (long long)n; i += stride / 64) {  // (a wavefront per listed barcode)
+            const long long b = x.list[i];
+            if (lane < G) x.prev[(size_t)b * G + lane] = a.post[(size_t)b * a.K + lane];
+            if (lane == 0) {
+                x.prev_first[b] = a.first[b];
+                x.changed_map[b] = 0;
+            }
+        }
+    } else if (full && x.changed_map != nullptr) {  // (flags set by a comparison whose delta pass stood back)
+        for (long long b = tid; b < x.B; b += stride) x.changed_map[b] = 0;
     }
     if (tid == 0) {
         x.counters[full ? 0 : 1] += 1u;
@@ -3268,6 +3329,23 @@ hipError_t launch_mstep_items_incremental(hipStream_t st, const MstepArgs &a, co
     else
         hipLaunchKernelGGL((k_mincr_delta<false>), dim3(4096), dim3(256), 0, st, a, x);
     const hipError_t e = launch_mstep(st, a);  // (stands back unless the full pass is due; + the dense regime's kernel)
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(k_mincr_finish, dim3(2048), dim3(256), 0, st, a, x);
+    return hipGetLastError();
+}
+
+hipError_t launch_mstep_incremental_sharded(hipStream_t st, const MstepArgs &a, const MTileArgs &t, const MIncrArgs &x)
+{
+    if (t.n_tiles == 0 || x.B == 0 || x.changed_map == nullptr) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(k_mincr_changes, dim3(blocks_for(x.B, 64)), dim3(256), 0, st, a, x);
+    const dim3 grid(std::min(blocks_for(a.n_items, 4), 8192u));
+    if (a.n_items) {
+        if (a.square)
+            hipLaunchKernelGGL((k_mincr_delta_masked<true>), grid, dim3(256), 0, st, a, x);
+        else
+            hipLaunchKernelGGL((k_mincr_delta_masked<false>), grid, dim3(256), 0, st, a, x);
+    }
+    const hipError_t e = launch_mstep_tiles(st, a, t);  // (stands back unless the full pass is due; + the dense regime's kernel)
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(k_mincr_finish, dim3(2048), dim3(256), 0, st, a, x);
     return hipGetLastError();

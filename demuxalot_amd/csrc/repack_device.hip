@@ -928,6 +928,7 @@ int build_mstep_tiles(dmx_ctx *c, long long v_lo, long long v_hi)
         c->mt_tv = tv;
         return 0;
     }
+    if (c->mshard) DMX_TRY(upload_variant_shifts(c, cut));  // (the incremental M-step of a variant-sharded rank: kernels.h MIncrArgs::changed_map)
     DMX_TRY(sc.get(&keys, (size_t)m));
     DMX_TRY(sc.get(&keys_out, (size_t)m));
     DMX_TRY(sc.get(&iota, (size_t)m));

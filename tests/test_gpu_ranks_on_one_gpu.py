@@ -579,3 +579,43 @@ def test_compact_exchange_of_the_posterior_rows(mode, monkeypatch):
     assert outcomes['16'][0][5][0] == 0 and outcomes['16'][0][5][1] == n_it - 1 and outcomes['0'][0][5] == (0, 0, 0), (outcomes['16'][0][5], outcomes['0'][0][5])
     print(f'{mode}: compact exchanges of the posteriors {taken} of {n_it - 1} (capacity {cap} rows per rank), of the table {t_taken} of {n_it - 1} '
           f'(capacity {t_cap}); capacity 16: {overflows16} / {outcomes["16"][0][5][1]} fallbacks')
+
+
+@pytest.mark.parametrize('world', [2, 3])
+def test_incremental_mstep_of_a_variant_sharded_rank(world, monkeypatch):
+    """A rank of a variant-sharded run sums ITS variant slice over the barcodes of all ranks.  With the tile-major records of the slice
+    its sums are integers, so they can be kept and updated (kernels.h: MIncrArgs::changed_map): the changed barcodes are found in the
+    gathered tables, the delta pass is a masked walk of the slice's variant-major records.  8 iterations on 2 and 3 ranks with it and
+    with every M-step the full tile pass: posteriors and additions bit for bit, and the delta pass did run."""
+    monkeypatch.setenv('DEMUXALOT_AMD_EXCHANGE', 'variant')
+    monkeypatch.setenv('DEMUXALOT_AMD_ESTEP', 'guarded')
+    from demuxalot_amd import distributed, synth
+    G, n_it = 40, 8
+    p = synth.generate(9_000, 2500, G, calls_per_barcode=400, seed=77)
+    betas = p.prior_betas()
+    pen = np.zeros(G, dtype=np.float32)
+    outcomes = {}
+    for incremental in (True, False):
+        shared = ThreadWorld(world)
+
+        def rank_body(plane):
+            em = distributed.ShardedEM(plane, p.n_barcodes, p.v2snp, betas, p.variant_id, p.compressed_cb, p.p_base_wrong)
+            try:
+                em.ctx.set_mstep_tiles('always')
+                em.ctx.set_mstep_incremental(incremental)
+                em.ctx.reset_timings()
+                probs, addition = em.learn(n_it, 0.01, pen, False)
+                return em.lo, em.hi, probs, addition, em.ctx.mstep_incremental(), em.ctx.mstep_form()
+            finally:
+                em.ctx.close()
+
+        outcomes[incremental] = shared.run(rank_body)
+    for got, want in zip(outcomes[True], outcomes[False]):
+        assert got[:2] == want[:2]
+        fio.assert_bitwise(got[2], want[2], f'posterior rows [{got[0]}, {got[1]}) with the incremental M-step')
+        fio.assert_bitwise(got[3], want[3], 'addition with the incremental M-step')
+        assert got[5] == 'tiles' and want[5] == 'tiles'
+        full, delta, last = got[4]
+        assert full >= 1 and delta >= 3 and full + delta == n_it - 1, got[4]
+        assert want[4] == (0, 0, 0)
+    print(f'{world} ranks: (full, delta, barcodes changed in the last M-step) per rank', [r[4] for r in outcomes[True]])
