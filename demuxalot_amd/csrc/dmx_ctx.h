@@ -49,6 +49,9 @@ struct TimerSlot {
     int64_t timed = 0;  // launches that were bracketed by events (phase timers on)
 };
 
+// the compact exchanges' lists (d_post_compact, d_prob_list) end in these words: {rows counted, workgroups done, 2 of padding} - zero between launches
+constexpr size_t LIST_TICKET_WORDS = 4;
+
 struct dmx_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
@@ -219,6 +222,7 @@ struct dmx_ctx {
     bool emulated = false;
     double emu_link_gbps = 50.0, emu_latency_us = 10.0;
     bool in_group = false, group_paid = false;  // coll_group_begin .. coll_group_end: several collectives, one launch
+    double group_ns = 0.0;                       // emulated wire: the group's modelled time, held by ONE delay at its end
     bool emu_table_filled = false;            // the other ranks' slices of genotype_prob hold the table without addition
     double emu_ticks_per_ns = 0.1;            // wall-clock ticks of the delay kernel per nanosecond
     bool attached() const { return comm != nullptr || host_coll != nullptr || emulated; }
@@ -230,6 +234,7 @@ struct dmx_ctx {
     std::vector<long long> cut;     // [nranks + 1] first variant of every slice
     std::vector<int> h_v2snp;       // host copy of v2snp (layout decisions)
     int *d_prow = nullptr;          // [V] padded row of every variant (sliced mode)
+    int *d_row_variant = nullptr;   // [prob_rows] ... and back (padding rows: variant 0; the incremental M-step of a rank that exchanges sums)
     // M-step sharded on variants (dmx_api.cpp: shard_mstep_by_variant): d_csc and the work items hold the calls of this rank's
     // variant slice from the barcodes of ALL ranks; the three tables the M-step reads of a barcode are global
     // (row = owner rank * rows_pad + barcode), filled block by block by the ranks' E-steps and all-gathered
@@ -241,21 +246,22 @@ struct dmx_ctx {
     bool post_gathered = false;              // the tables hold the last E-step of every rank
     bool emu_post_filled = false;            // emulated wire: the other ranks' blocks were filled once
     // compact exchange of the posterior rows (gather_posteriors; G <= 64): per rank a block of {rows listed, 3 pad, cap x (row, G floats)}
-    unsigned *d_post_compact = nullptr;      // [nranks * post_compact_words]
+    unsigned *d_post_compact = nullptr;      // [nranks * post_compact_words + LIST_TICKET_WORDS] (the tail: what the build kernel counts in)
     uint2 *d_post_seen = nullptr;            // [rows_total] the code every row of d_post_g was last rebuilt from (0xFF..: unknown)
-    unsigned *h_post_counts = nullptr;       // pinned, [nranks]: the lists' lengths, read behind the all-gather
+    unsigned *h_post_counts = nullptr;       // pinned, [nranks + 1]: the lists' lengths, read behind the all-gather, and the sequence number the host polls
+    unsigned list_seq = 0;                   // (k_post_counts / wait_counts)
     size_t post_compact_words = 0;           // words per rank block (0: the whole table travels, as until round 6)
     unsigned post_compact_cap = 0;           // rows a block can list at most
     unsigned post_cap_now = 0;               // ... in the coming exchange: twice what the longest list of the last one held (every rank reads every count: the same choice everywhere)
     long long post_compact_taken = 0, post_compact_overflows = 0;  // E-steps exchanged compactly / that fell back to the whole table
     // compact exchange of the genotype table (run_pstep; sliced P-step): the rows of this rank's slice that changed since it sent them
-    unsigned *d_prob_list = nullptr;         // [nranks * prob_list_words] {rows listed, 3 pad, cap x (row, G floats)} per rank
+    unsigned *d_prob_list = nullptr;         // [nranks * prob_list_words + LIST_TICKET_WORDS] {rows listed, 3 pad, cap x (row, G floats)} per rank
     float *d_prob_prev = nullptr;            // [slice_rows, G] this rank's slice as the other ranks hold it
     size_t prob_list_words = 0;              // (0: the whole slices travel)
     unsigned prob_list_cap = 0;
     unsigned prob_cap_now = 0;               // (as post_cap_now)
     bool prob_prev_valid = false;            // d_prob_prev is what every rank holds of this slice
-    unsigned *h_prob_counts = nullptr;       // pinned, [nranks]
+    unsigned *h_prob_counts = nullptr;       // pinned, [nranks + 1]
     long long prob_compact_taken = 0, prob_compact_overflows = 0;
     void *d_exch = nullptr;         // padded send buffer of the reduce-scatter (float64 or float32 partial sums)
     void *d_recv = nullptr;         // this rank's reduced slice

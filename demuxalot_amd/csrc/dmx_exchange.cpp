@@ -206,8 +206,29 @@ int emulated_wire(dmx_ctx *c, size_t block_bytes, int rounds, hipStream_t st)
     const double latency = c->in_group && c->group_paid ? 0.0 : c->emu_latency_us * 1e3;
     c->group_paid = true;
     const double ns = rounds * (latency + (double)block_bytes / c->emu_link_gbps);
+    if (c->in_group) {  // one launch: one delay, at the end of the group (coll_group_end; the group's collectives are on c->stream)
+        c->group_ns += ns;
+        return 0;
+    }
     HIP_TRY(dmx::launch_delay(st, (long long)(ns * c->emu_ticks_per_ns)));
     return 0;
+}
+
+// The host's side of k_post_counts: the counts are in pinned memory once `seq` stands behind them.  Polling that word costs the host
+// what the kernel takes to get there; hipStreamSynchronize costs an interrupt and a wake-up on top (15 us per exchange at 8 ranks), and
+// the kernels enqueued behind k_post_counts - which do not depend on what the host decides - keep the GPU busy meanwhile.
+int wait_counts(dmx_ctx *c, unsigned *counts, int n, unsigned seq)
+{
+    for (unsigned spins = 1;; spins++) {
+        if (__atomic_load_n(&counts[n], __ATOMIC_ACQUIRE) == seq) return 0;
+        if ((spins & 1023u) != 0) continue;
+        const hipError_t e = hipStreamQuery(c->stream);
+        if (e == hipErrorNotReady) continue;
+        if (e != hipSuccess) return fail(DMX_ERR_HIP, "the exchange of the lists failed: %s", hipGetErrorString(e));
+        HIP_TRY(hipStreamSynchronize(c->stream));  // (the stream has drained: the word is there, or the memory is not coherent - then it is now)
+        if (__atomic_load_n(&counts[n], __ATOMIC_ACQUIRE) == seq) return 0;
+        return fail(DMX_ERR_HIP, "the lists' lengths did not arrive");
+    }
 }
 
 // Several collectives as one launch (ncclGroupStart / ncclGroupEnd); the host-staged and emulated backends run them one
@@ -216,12 +237,15 @@ void coll_group_begin(dmx_ctx *c)
 {
     c->in_group = true;
     c->group_paid = false;
+    c->group_ns = 0.0;
     if (c->comm && g_rccl.GroupStart) (void)g_rccl.GroupStart();
 }
 
 int coll_group_end(dmx_ctx *c)
 {
     c->in_group = false;
+    if (c->emulated && c->group_ns > 0.0) HIP_TRY(dmx::launch_delay(c->stream, (long long)(c->group_ns * c->emu_ticks_per_ns)));
+    c->group_ns = 0.0;
     if (c->comm && g_rccl.GroupEnd) {
         ncclResult_t r = g_rccl.GroupEnd();
         if (r != ncclSuccess) return fail(DMX_ERR_RCCL, "ncclGroupEnd failed: %s", rccl_error(r));
@@ -370,11 +394,12 @@ int shard_mstep_by_variant(dmx_ctx *c, bool force)
         c->post_compact_cap = (unsigned)(asked > 0 ? std::min<long long>(asked, rows_pad) : std::max<long long>(64, rows_pad / 4));
         c->post_compact_words = 4 + (size_t)c->post_compact_cap * (size_t)(1 + G);
         c->post_cap_now = c->post_compact_cap;
-        DMX_TRY(dev_alloc(c, &c->d_post_compact, c->post_compact_words * (size_t)n));
-        HIP_TRY(hipMemsetAsync(c->d_post_compact, 0, sizeof(unsigned) * c->post_compact_words * (size_t)n, st));
+        DMX_TRY(dev_alloc(c, &c->d_post_compact, c->post_compact_words * (size_t)n + LIST_TICKET_WORDS));
+        HIP_TRY(hipMemsetAsync(c->d_post_compact, 0, sizeof(unsigned) * (c->post_compact_words * (size_t)n + LIST_TICKET_WORDS), st));
         DMX_TRY(dev_alloc(c, &c->d_post_seen, (size_t)c->rows_total));
         HIP_TRY(hipMemsetAsync(c->d_post_seen, 0xFF, sizeof(uint2) * (size_t)c->rows_total, st));
-        HIP_TRY(hipHostMalloc((void **)&c->h_post_counts, sizeof(unsigned) * (size_t)n, hipHostMallocDefault));
+        HIP_TRY(hipHostMalloc((void **)&c->h_post_counts, sizeof(unsigned) * (size_t)(n + 1), hipHostMallocMapped | hipHostMallocCoherent));
+        std::memset(c->h_post_counts, 0, sizeof(unsigned) * (size_t)(n + 1));
     }
     c->mshard = true;
     c->post_gathered = false;
@@ -421,6 +446,10 @@ int layout_exchange(dmx_ctx *c)
             for (long long v = c->cut[r]; v < c->cut[r + 1]; v++) prow[v] = (int)(r * rows + (v - c->cut[r]));
         DMX_TRY(dev_alloc(c, &c->d_prow, (size_t)V));
         HIP_TRY(hipMemcpyAsync(c->d_prow, prow.data(), sizeof(int) * V, hipMemcpyHostToDevice, st));
+        std::vector<int> row_variant((size_t)std::max<long long>(1, c->prob_rows), 0);
+        for (long long v = 0; v < V; v++) row_variant[(size_t)prow[v]] = (int)v;
+        DMX_TRY(dev_alloc(c, &c->d_row_variant, (size_t)c->prob_rows));
+        HIP_TRY(hipMemcpyAsync(c->d_row_variant, row_variant.data(), sizeof(int) * (size_t)c->prob_rows, hipMemcpyHostToDevice, st));
         HIP_TRY(dmx::launch_remap_row_offsets(st, c->d_call_pairs, c->n_pairs, (unsigned)G * 4u, c->d_prow, c->d_call_rows));
         if (c->d_tile_stream) HIP_TRY(dmx::launch_remap_row_offsets(st, c->d_tile_stream, c->n_pairs, (unsigned)G * 4u, c->d_prow, nullptr));
         release_coarse_stream(c);  // (its row offsets are the tile-major stream's: rebuilt at the next admissible E-step)
@@ -444,10 +473,13 @@ int layout_exchange(dmx_ctx *c)
                 c->prob_list_cap = (unsigned)(asked > 0 ? std::min<long long>(asked, rows) : std::max<long long>(64, rows / 4));
                 c->prob_list_words = 4 + (size_t)c->prob_list_cap * (size_t)(1 + G);
                 c->prob_cap_now = c->prob_list_cap;
-                DMX_TRY(dev_alloc(c, &c->d_prob_list, c->prob_list_words * (size_t)n));
-                HIP_TRY(hipMemsetAsync(c->d_prob_list, 0, sizeof(unsigned) * c->prob_list_words * (size_t)n, st));
+                DMX_TRY(dev_alloc(c, &c->d_prob_list, c->prob_list_words * (size_t)n + LIST_TICKET_WORDS));
+                HIP_TRY(hipMemsetAsync(c->d_prob_list, 0, sizeof(unsigned) * (c->prob_list_words * (size_t)n + LIST_TICKET_WORDS), st));
                 DMX_TRY(dev_alloc(c, &c->d_prob_prev, (size_t)rows * G));
-                if (!c->h_prob_counts) HIP_TRY(hipHostMalloc((void **)&c->h_prob_counts, sizeof(unsigned) * (size_t)n, hipHostMallocDefault));
+                if (!c->h_prob_counts) {
+                    HIP_TRY(hipHostMalloc((void **)&c->h_prob_counts, sizeof(unsigned) * (size_t)(n + 1), hipHostMallocMapped | hipHostMallocCoherent));
+                    std::memset(c->h_prob_counts, 0, sizeof(unsigned) * (size_t)(n + 1));
+                }
             }
         }
         HIP_TRY(hipStreamSynchronize(st));                          // `prow` is a local
@@ -489,11 +521,10 @@ int gather_posteriors(dmx_ctx *c)
     // the whole table travels and the next lists are full-sized again.
     const unsigned cap_now = compact ? std::max(1u, std::min(c->post_cap_now, c->post_compact_cap)) : 0u;
     const size_t words_now = 4 + (size_t)cap_now * (size_t)(1 + G);
-    if (compact && c->emulated)  // (nobody fills the other ranks' blocks: they list nothing, wherever this exchange's block size puts their counts)
-        HIP_TRY(hipMemsetAsync(c->d_post_compact, 0, sizeof(unsigned) * words_now * (size_t)c->nranks, c->stream));
     if (compact)  // this rank's rows with several live posteriors, listed (the count may run beyond the capacity: overflow)
         HIP_TRY(dmx::launch_post_compact_build(c->stream, c->d_first_g + c->rank * rows, c->d_post_g + c->rank * rows * G, c->B, G, cap_now,
-                                               c->d_post_compact + (size_t)c->rank * words_now));
+                                               c->d_post_compact + (size_t)c->rank * words_now, c->d_post_compact + c->post_compact_words * (size_t)c->nranks,
+                                               c->emulated ? c->d_post_compact : nullptr, (unsigned long long)words_now, c->nranks, c->rank));
     coll_group_begin(c);  // one launch for the tables
     rc = coll_all_gather(c, (float *)c->d_first_g, rows * 2, "posterior codes");
     if (rc == 0) rc = coll_all_gather(c, (float *)c->d_nz_g, rows * W * 2, "posterior bitmaps");
@@ -502,11 +533,14 @@ int gather_posteriors(dmx_ctx *c)
     int rc_end = coll_group_end(c);
     if (rc == 0) rc = rc_end;
     if (rc == 0 && compact) {
-        // every rank reads every rank's count: the same decision everywhere (the one host synchronisation of the exchange; a small kernel
-        // writes the counts into pinned, device-visible host memory: a copy per rank was 8 x 8 us at 8 ranks, one strided
-        // hipMemcpy2DAsync 70 us of runtime overhead)
-        HIP_TRY(dmx::launch_post_counts(c->stream, c->d_post_compact, (unsigned long long)words_now, c->nranks, c->h_post_counts));
-        HIP_TRY(hipStreamSynchronize(c->stream));
+        // Every rank reads every rank's count: the same decision everywhere.  A small kernel writes the counts into pinned memory (a copy per
+        // rank was 8 x 8 us at 8 ranks, one strided hipMemcpy2DAsync 70 us of runtime overhead) and the host polls for them (wait_counts) while
+        // the rows are rebuilt: that launch does not wait for the decision - should a list have overflowed, the whole table overwrites what it wrote.
+        const unsigned seq = ++c->list_seq;
+        HIP_TRY(dmx::launch_post_counts(c->stream, c->d_post_compact, (unsigned long long)words_now, c->nranks, c->h_post_counts, seq));
+        HIP_TRY(dmx::launch_post_reconstruct(c->stream, c->d_first_g, c->d_post_g, c->d_post_compact, (unsigned long long)words_now,
+                                             (long long)rows, G, c->nranks, c->rank, cap_now, c->d_post_seen));
+        DMX_TRY(wait_counts(c, c->h_post_counts, c->nranks, seq));
         unsigned longest = 0;
         for (int r = 0; r < c->nranks; r++) longest = std::max(longest, c->h_post_counts[r]);
         const bool overflow = longest > cap_now;
@@ -517,8 +551,6 @@ int gather_posteriors(dmx_ctx *c)
             HIP_TRY(hipMemsetAsync(c->d_post_seen, 0xFF, sizeof(uint2) * (size_t)c->rows_total, c->stream));  // (the rows are the senders' own now)
         } else {
             c->post_compact_taken++;
-            HIP_TRY(dmx::launch_post_reconstruct(c->stream, c->d_first_g, c->d_post_g, c->d_post_compact, (unsigned long long)words_now,
-                                                 (long long)rows, G, c->nranks, c->rank, cap_now, c->d_post_seen));
         }
     }
     timer_end(c, DMX_T_ALLREDUCE, ev);

@@ -30,6 +30,7 @@ void exchange_slices(const int *v2snp, long long V, int n, std::vector<long long
 int host_stage(dmx_ctx *c, size_t bytes);
 int host_collective(dmx_ctx *c, int op, const void *src, size_t off_in, size_t bytes_in, void *dst, size_t off_out, size_t bytes_out, size_t total_bytes, int64_t count, int dtype, const char *what, hipStream_t st);
 int emulated_wire(dmx_ctx *c, size_t block_bytes, int rounds, hipStream_t st);
+int wait_counts(dmx_ctx *c, unsigned *counts, int n, unsigned seq);
 void coll_group_begin(dmx_ctx *c);
 int coll_group_end(dmx_ctx *c);
 int coll_reduce_scatter(dmx_ctx *c, const void *send, void *recv, size_t block, bool f64, hipStream_t st);

@@ -426,7 +426,7 @@ void release_problem(dmx_ctx *c)
     dev_free(c, &c->d_raw, vg);
     c->have_raw = false;
     dev_free(c, &c->d_add, vg);
-    dev_free(c, &c->d_prob_list, c->prob_list_words * (size_t)std::max(1, c->nranks));
+    dev_free(c, &c->d_prob_list, c->prob_list_words * (size_t)std::max(1, c->nranks) + LIST_TICKET_WORDS);
     dev_free(c, &c->d_prob_prev, (size_t)c->slice_rows * c->G);
     c->prob_list_words = 0;
     c->prob_list_cap = 0;
@@ -439,6 +439,7 @@ void release_problem(dmx_ctx *c)
     c->prob16_valid = false;
     dev_free(c, &c->d_add64, vg);
     dev_free(c, &c->d_prow, (size_t)c->V);
+    dev_free(c, &c->d_row_variant, (size_t)c->prob_rows);
     if (c->d_exch) {
         (void)hipFree(c->d_exch);
         c->bytes -= (int64_t)c->exch_bytes;
@@ -454,7 +455,7 @@ void release_problem(dmx_ctx *c)
     dev_free(c, &c->d_first_g, (size_t)c->rows_total);
     dev_free(c, &c->d_nz_g, (size_t)c->rows_total * ((c->G + 63) / 64));
     dev_free(c, &c->d_post_g, (size_t)c->rows_total * c->G);
-    dev_free(c, &c->d_post_compact, c->post_compact_words * (size_t)std::max(1, c->nranks));
+    dev_free(c, &c->d_post_compact, c->post_compact_words * (size_t)std::max(1, c->nranks) + LIST_TICKET_WORDS);
     dev_free(c, &c->d_post_seen, (size_t)c->rows_total);
     if (c->h_post_counts) (void)hipHostFree(c->h_post_counts);
     c->h_post_counts = nullptr;

@@ -271,14 +271,17 @@ int run_pstep(dmx_ctx *c, float lo, float hi, bool with_addition, bool with_half
             // (the lists are sized from the last exchange's counts, as the posteriors' are: dmx_exchange.cpp, gather_posteriors)
             const unsigned cap_now = std::max(1u, std::min(c->prob_cap_now, c->prob_list_cap));
             const size_t words_now = 4 + (size_t)cap_now * (size_t)(1 + c->G);
-            if (c->emulated)  // (nobody fills the other ranks' blocks: they list nothing, wherever this exchange's block size puts their counts)
-                HIP_TRY(hipMemsetAsync(c->d_prob_list, 0, sizeof(unsigned) * words_now * (size_t)c->nranks, c->stream));
             HIP_TRY(dmx::launch_prob_changes_build(c->stream, mine, c->d_prob_prev, c->slice_rows, c->G, cap_now,
-                                                   c->d_prob_list + (size_t)c->rank * words_now));
+                                                   c->d_prob_list + (size_t)c->rank * words_now, c->d_prob_list + c->prob_list_words * (size_t)c->nranks,
+                                                   c->emulated ? c->d_prob_list : nullptr, (unsigned long long)words_now, c->nranks, c->rank));
             rc = coll_all_gather(c, (float *)c->d_prob_list, words_now, "changed rows of genotype_prob");
             if (rc == 0) {
-                HIP_TRY(dmx::launch_post_counts(c->stream, c->d_prob_list, (unsigned long long)words_now, c->nranks, c->h_prob_counts));
-                HIP_TRY(hipStreamSynchronize(c->stream));
+                // (the listed rows are written while the host polls for the counts: should a list have overflowed, the whole slices overwrite them)
+                const unsigned seq = ++c->list_seq;
+                HIP_TRY(dmx::launch_post_counts(c->stream, c->d_prob_list, (unsigned long long)words_now, c->nranks, c->h_prob_counts, seq));
+                HIP_TRY(dmx::launch_prob_changes_apply(c->stream, c->d_prob, c->d_prob_list, (unsigned long long)words_now, c->slice_rows, c->G,
+                                                       c->nranks, c->rank, cap_now, half_rows ? (unsigned short *)c->d_prob16 : nullptr));
+                DMX_TRY(wait_counts(c, c->h_prob_counts, c->nranks, seq));
                 unsigned longest = 0;
                 for (int r = 0; r < c->nranks; r++) longest = std::max(longest, c->h_prob_counts[r]);
                 whole = longest > cap_now;
@@ -286,8 +289,6 @@ int run_pstep(dmx_ctx *c, float lo, float hi, bool with_addition, bool with_half
                 c->prob_cap_now = whole ? c->prob_list_cap : (unsigned)std::min<unsigned long long>(c->prob_list_cap, 4ull * longest + 512ull);
                 if (!whole) {
                     c->prob_compact_taken++;
-                    HIP_TRY(dmx::launch_prob_changes_apply(c->stream, c->d_prob, c->d_prob_list, (unsigned long long)words_now, c->slice_rows, c->G,
-                                                           c->nranks, c->rank, cap_now, half_rows ? (unsigned short *)c->d_prob16 : nullptr));
                     c->prob16_valid = half_rows;
                 } else {
                     c->prob_compact_overflows++;
@@ -638,8 +639,12 @@ int run_mstep(dmx_ctx *c, float power)
     // 25-iteration call: M-steps 0.71 + 23 x 0.03 ms instead of 2.6 (build) + 0.33 + 23 x 0.03.
     constexpr int MSTEP_TILES_PAY = 8;
     const long long ahead = std::max<long long>(c->msteps_ahead, c->msteps_expected);
+    // (a rank that exchanges SUMS - reduce-scatter of the partial sums of its own barcodes - is one context with all calls of its barcodes
+    // too: its partial sums stay in the exchange buffer between two M-steps, the delta pass updates the rows it touched.  Not the all-reduce,
+    // which sums in place.)
+    const bool own_sums = !mshard && (!dist || c->sliced);
     const bool can_go_incremental = c->mstep_incremental && c->mstep_tiles == 1 && !c->exact_additions && c->G <= 64 && c->n_csc > 0 && power > 0.0f &&
-                                    !dist && !mshard && !c->sliced && c->d_call_rows != nullptr && c->d_item_variant != nullptr;
+                                    own_sums && c->d_call_rows != nullptr && c->d_item_variant != nullptr;
     if (can_go_incremental && !c->incr_heavy && c->n_mt == 0 && c->d_incr_state != nullptr &&
         (c->msteps_done == 4 || c->msteps_done == 16 || c->msteps_done == 64)) {
         unsigned full_passes = 0;
@@ -685,7 +690,7 @@ int run_mstep(dmx_ctx *c, float power)
     // bit and the incremental M-step builds on them: one full pass of 0.7 ms, then delta passes, instead of 0.7 ms per M-step.
     // (dmx_set_mstep_tiles(ctx, 0) or dmx_set_mstep_incremental(ctx, 0): the float64 work-item form, as before.)
     bool fixed_items = !a.tiles_done && c->mstep_tiles != 0 && c->mstep_incremental && !c->exact_additions && c->G <= 64 && c->n_csc > 0 &&
-                       power > 0.0f && !dist && !mshard && !c->sliced && a.out32 == c->d_add && c->d_call_rows != nullptr && c->d_item_variant != nullptr;
+                       power > 0.0f && own_sums && c->d_call_rows != nullptr && c->d_item_variant != nullptr;
     if (fixed_items) {
         DMX_TRY(dmx::plan_mstep_shifts(c));
         fixed_items = c->d_mt_shift_v != nullptr;
@@ -695,8 +700,8 @@ int run_mstep(dmx_ctx *c, float power)
     // changed barcodes found in the gathered tables, the delta pass a masked walk of the slice's variant-major records (MIncrArgs::changed_map).
     const bool sharded_incr = a.tiles_done && c->mstep_incremental == 1 && mshard && c->d_mt_shift_v != nullptr && a.out32 == c->d_add && c->G <= 64 &&
                               c->d_item_variant != nullptr && c->rows_total > 0;
-    const bool incremental = sharded_incr || ((a.tiles_done || fixed_items) && c->mstep_incremental && !dist && !c->sliced && c->d_mt_shift_v != nullptr &&
-                                              a.out32 == c->d_add && c->d_call_rows != nullptr);
+    const bool incremental = sharded_incr || ((a.tiles_done || fixed_items) && c->mstep_incremental && own_sums && c->d_mt_shift_v != nullptr &&
+                                              c->d_call_rows != nullptr);
     const long long incr_rows = sharded_incr ? c->rows_total : c->B;
     dmx::MIncrArgs incr{};
     if (incremental) {
@@ -718,7 +723,7 @@ int run_mstep(dmx_ctx *c, float power)
         }
         if (!c->incr_valid || c->incr_power != power) {  // (nothing to build on: zeroed state words ask for the full pass)
             HIP_TRY(hipMemsetAsync(c->d_incr_state, 0, sizeof(unsigned) * 2 * dmx::IS_WORDS, c->stream));
-            if (c->mstep_incremental == 2) {  // (measurement: the sums built from nothing by the delta pass instead of the full pass)
+            if (c->mstep_incremental == 2 && !dist) {  // (measurement: the sums built from nothing by the delta pass instead of the full pass)
                 const unsigned on[2] = {1u, 1u};
                 HIP_TRY(hipMemsetAsync(c->d_acc64, 0, sizeof(unsigned long long) * (size_t)c->V * c->G, c->stream));
                 HIP_TRY(hipMemsetAsync(c->d_prev_post, 0, sizeof(float) * (size_t)incr_rows * c->G, c->stream));
@@ -746,6 +751,7 @@ int run_mstep(dmx_ctx *c, float power)
         incr.call_rows = sharded_incr ? nullptr : c->d_call_rows;
         incr.pair_ptr = sharded_incr ? nullptr : c->d_pair_ptr;
         incr.changed_map = sharded_incr ? c->d_incr_map : nullptr;
+        incr.row_variant = !sharded_incr && c->sliced ? c->d_row_variant : nullptr;
         incr.B = incr_rows;
         incr.V = c->V;
         incr.floor = dmx::mincr_floor(power);

@@ -85,6 +85,7 @@ hipError_t hipStreamCreateWithPriority(hipStream_t *s, unsigned, int)
 }
 hipError_t hipStreamDestroy(hipStream_t) { return hipSuccess; }
 hipError_t hipStreamSynchronize(hipStream_t) { return hipSuccess; }
+hipError_t hipStreamQuery(hipStream_t) { return hipSuccess; }
 hipError_t hipStreamWaitEvent(hipStream_t, hipEvent_t, unsigned) { return hipSuccess; }
 hipError_t hipDeviceGetStreamPriorityRange(int *least, int *greatest)
 {
@@ -162,20 +163,23 @@ hipError_t launch_f64_to_f32(hipStream_t, const double *, float *, long long) { 
 hipError_t launch_add_f32(hipStream_t, const float *, const float *, float *, long long) { return hipSuccess; }
 hipError_t launch_f32_to_f64(hipStream_t, const float *, double *, long long) { return hipSuccess; }
 hipError_t launch_delay(hipStream_t, long long) { return hipSuccess; }
-hipError_t launch_post_compact_build(hipStream_t, const uint2 *, const float *, long long, int, unsigned cap, unsigned *block)
+hipError_t launch_post_compact_build(hipStream_t, const uint2 *, const float *, long long, int, unsigned cap, unsigned *block, unsigned *, unsigned *,
+                                     unsigned long long, int, int)
 {
     block[0] = cap + 1;  // (no kernels here: "overflow", so that the host logic takes the whole-table path it can execute)
     return hipSuccess;
 }
-hipError_t launch_prob_changes_build(hipStream_t, const float *, float *, long long, int, unsigned cap, unsigned *block)
+hipError_t launch_prob_changes_build(hipStream_t, const float *, float *, long long, int, unsigned cap, unsigned *block, unsigned *, unsigned *,
+                                     unsigned long long, int, int)
 {
     block[0] = cap + 1;  // (no kernels here: "overflow" - the whole slices travel, which the host logic can execute)
     return hipSuccess;
 }
 hipError_t launch_prob_changes_apply(hipStream_t, float *, const unsigned *, unsigned long long, long long, int, int, int, unsigned, unsigned short *) { return hipSuccess; }
-hipError_t launch_post_counts(hipStream_t, const unsigned *blocks, unsigned long long block_words, int nranks, unsigned *out)
+hipError_t launch_post_counts(hipStream_t, const unsigned *blocks, unsigned long long block_words, int nranks, unsigned *out, unsigned seq)
 {
     for (int r = 0; r < nranks; r++) out[r] = blocks[(size_t)r * block_words];
+    out[nranks] = seq;
     return hipSuccess;
 }
 hipError_t launch_post_reconstruct(hipStream_t, const uint2 *, float *, const unsigned *, unsigned long long, long long, int, int, int, unsigned, uint2 *) { return hipSuccess; }

@@ -375,6 +375,9 @@ struct MIncrArgs {
     // flagged adds the difference of its new and old integer contribution; k_mincr_finish then brings prev / prev_first of the listed
     // barcodes up to date and clears their flags.
     unsigned char *changed_map;
+    // A rank that exchanges sums (sliced table): the records' table rows are the PADDED rows of the exchange layout; row_variant
+    // [padded rows] brings them back to variants (acc64, shift_v, touched are per variant).  Null: table rows = variants.
+    const int *row_variant;
 };
 enum { IS_N = 0,        // changed barcodes of this M-step
        IS_CALLS = 2,    // (64 bit, words 2 and 3) their (padded) calls
@@ -410,12 +413,16 @@ hipError_t launch_add_f32(hipStream_t st, const float *a, const float *b, float 
 // one wavefront that keeps the stream busy for `ticks` of the constant-rate wall clock (emulated wire: dmx_comm_init_emulated)
 hipError_t launch_delay(hipStream_t st, long long ticks);
 // compact exchange of the posterior rows (kernels.hip: k_post_compact_build / k_post_reconstruct; dmx_exchange.cpp: gather_posteriors)
-hipError_t launch_post_compact_build(hipStream_t st, const uint2 *first, const float *post, long long B, int G, unsigned cap, unsigned *block);
+// (ticket: two zeroed words the build kernels count in and clear again; peers: emulated wire only, else nullptr - the other ranks' headers are cleared)
+hipError_t launch_post_compact_build(hipStream_t st, const uint2 *first, const float *post, long long B, int G, unsigned cap, unsigned *block,
+                                     unsigned *ticket, unsigned *peers, unsigned long long block_words, int nranks, int own);
 // compact exchange of the genotype table (kernels.hip: k_prob_changes_build / k_prob_changes_apply; dmx_steps.cpp: run_pstep)
-hipError_t launch_prob_changes_build(hipStream_t st, const float *slice, float *prev, long long rows, int G, unsigned cap, unsigned *block);
+hipError_t launch_prob_changes_build(hipStream_t st, const float *slice, float *prev, long long rows, int G, unsigned cap, unsigned *block,
+                                     unsigned *ticket, unsigned *peers, unsigned long long block_words, int nranks, int own);
 hipError_t launch_prob_changes_apply(hipStream_t st, float *table, const unsigned *blocks, unsigned long long block_words, long long slice_rows, int G,
                                      int nranks, int own, unsigned cap, unsigned short *table16);
-hipError_t launch_post_counts(hipStream_t st, const unsigned *blocks, unsigned long long block_words, int nranks, unsigned *out_host_visible);
+// out_host_visible: [nranks + 1] - the counts, then `seq` (written last, system scope: the host polls it)
+hipError_t launch_post_counts(hipStream_t st, const unsigned *blocks, unsigned long long block_words, int nranks, unsigned *out_host_visible, unsigned seq);
 hipError_t launch_post_reconstruct(hipStream_t st, const uint2 *first_g, float *post_g, const unsigned *blocks, unsigned long long block_words,
                                    long long rows_pad, int G, int nranks, int own, unsigned cap, uint2 *seen);
 hipError_t launch_f32_to_f64(hipStream_t st, const float *in, double *out, long long n);

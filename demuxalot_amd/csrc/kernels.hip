@@ -1935,13 +1935,22 @@ static __device__ __forceinline__ unsigned long long fixed_of(float c, int shift
 // Where the integer sums of work item `item` go (fixed-point work-item form, MstepArgs::fixed_shift_v): a variant of ONE item is
 // finished here - its sums into fixed_acc64, converted once into the addition, as k_mstep_tiles writes them -, the others leave
 // their integers in the item's partial row for k_mcombine.
+// (an integer sum into the output table: one conversion - float32, or float64 on the way into a float64 exchange; prow: the padded rows
+// of the multi-GPU exchange buffer)
+static __device__ __forceinline__ void mstep_out_fixed(const MstepArgs &a, long long v, int g, unsigned long long acc, int shift)
+{
+    const size_t o = (size_t)(a.prow ? (long long)a.prow[v] : v) * a.G + g;
+    const double sum = __builtin_ldexp((double)(long long)acc, -shift);
+    if (a.out32) a.out32[o] = (float)sum;
+    else a.out64[o] = sum;
+}
+
 static __device__ __forceinline__ void mstep_store_fixed(const MstepArgs &a, long long item, int g, unsigned long long acc, int shift)
 {
     const long long v = a.item_variant[item];
     if (a.item_ptr[v + 1] - a.item_ptr[v] == 1) {
-        const size_t o = (size_t)v * a.G + g;
-        a.out32[o] = (float)__builtin_ldexp((double)(long long)acc, -shift);
-        a.fixed_acc64[o] = acc;
+        mstep_out_fixed(a, v, g, acc, shift);
+        a.fixed_acc64[(size_t)v * a.G + g] = acc;
         return;
     }
     a.partial[(size_t)item * a.G + g] = __longlong_as_double((long long)acc);
@@ -2513,6 +2522,7 @@ __global__ __launch_bounds__(256) void k_mincr_delta(MstepArgs a, MIncrArgs x)
             if (mine) {
                 keep = x.pairs[p0 + (ci >> 1)].keep[ci & 1];
                 row = x.call_rows[2 * p0 + ci];
+                if (x.row_variant != nullptr) row = (unsigned)x.row_variant[row];
             }
             const int shift = mine ? (int)x.shift_v[row] : 0;
             for (unsigned long long m = mask; m != 0ull; m &= m - 1ull) {  // (uniform)
@@ -2608,7 +2618,7 @@ __global__ __launch_bounds__(256) void k_mincr_finish(MstepArgs a, MIncrArgs x)
             for (unsigned long long m = __ballot(hit); m != 0ull; m &= m - 1ull) {
                 const long long vv = v0 + __builtin_ctzll(m);
                 const int shift = (int)x.shift_v[vv];
-                if (lane < G) a.out32[(size_t)vv * G + lane] = (float)__builtin_ldexp((double)(long long)x.acc64[(size_t)vv * G + lane], -shift);
+                if (lane < G) mstep_out_fixed(a, vv, lane, x.acc64[(size_t)vv * G + lane], shift);
             }
         }
     }
@@ -2716,7 +2726,10 @@ __global__ __launch_bounds__(256) void k_mcombine(const double *__restrict__ par
         if (fixed) {  // integer partial sums: any order, one conversion (as k_mstep_tiles writes a tile's rows); a variant without calls: 0
             unsigned long long q = 0ull;
             for (long long it = it0; it < it1; it++) q += (unsigned long long)__double_as_longlong(partial[(size_t)it * G + g]);
-            add32[v * G + g] = (float)__builtin_ldexp((double)(long long)q, -(int)fixed_shift_v[v]);
+            const long long o = (prow ? (long long)prow[v] : v) * G + g;
+            const double sum = __builtin_ldexp((double)(long long)q, -(int)fixed_shift_v[v]);
+            if (add64) add64[o] = sum;
+            if (add32) add32[o] = (float)sum;
             fixed_acc64[v * G + g] = q;
             continue;
         }
@@ -3399,26 +3412,47 @@ hipError_t launch_mcombine(hipStream_t st, const MstepArgs &a, const long long *
 // exactly +0 to every sum (NZ_FLOOR_SQUARE; with another contribution_power "live" means non-zero), so the additions keep their bits.
 // Rows with several live posteriors (1 - 15 % of the barcodes) travel in a list: block = {rows listed (beyond `cap`: overflow - the
 // caller falls back to the all-gather of the whole table), 3 words of padding, cap entries of (row, G floats)}.
+// The lists' lengths are counted in ticket[0]; the workgroup that finishes last (ticket[1]) moves the count into the block's header and
+// clears both for the next exchange - no memset between two exchanges.  (peers, emulated wire only: nobody fills the other ranks'
+// blocks; they list nothing, wherever this exchange's block size puts their headers.)
+__device__ __forceinline__ void list_finish(unsigned *__restrict__ ticket, unsigned *__restrict__ block, unsigned *__restrict__ peers,
+                                            unsigned long long block_words, int nranks, int own)
+{
+    __syncthreads();
+    if (threadIdx.x != 0) return;
+    __threadfence();
+    if (atomicAdd(&ticket[1], 1u) != gridDim.x - 1u) return;
+    __threadfence();
+    block[0] = atomicExch(&ticket[0], 0u);
+    ticket[1] = 0u;
+    if (peers != nullptr)
+        for (int r = 0; r < nranks; r++)
+            if (r != own) peers[(size_t)r * block_words] = 0u;
+}
+
 __global__ __launch_bounds__(256) void k_post_compact_build(const uint2 *__restrict__ first, const float *__restrict__ post, long long B, int G,
-                                                            unsigned cap, unsigned *__restrict__ block)
+                                                            unsigned cap, unsigned *__restrict__ block, unsigned *__restrict__ ticket,
+                                                            unsigned *__restrict__ peers, unsigned long long block_words, int nranks, int own)
 {
     const int lane = threadIdx.x & 63;
     const long long b0 = ((long long)blockIdx.x * 4 + (threadIdx.x >> 6)) * 64;
     const long long b = b0 + lane;
     const bool multi = b < B && (first[b < B ? b : 0].y & 127u) != 1u;
     unsigned long long m = __ballot(multi);
-    if (!m) return;
-    unsigned base = 0;
-    if (lane == 0) base = atomicAdd(&block[0], (unsigned)__popcll(m));
-    base = (unsigned)__shfl((int)base, 0);
-    for (unsigned i = 0; m != 0ull; m &= m - 1ull, i++) {  // (uniform)
-        const long long row = b0 + __builtin_ctzll(m);
-        const unsigned at = base + i;
-        if (at >= cap) break;
-        unsigned *e = block + 4 + (size_t)at * (size_t)(1 + G);
-        if (lane == 0) e[0] = (unsigned)row;
-        if (lane < G) e[1 + lane] = __float_as_uint(post[(size_t)row * G + lane]);
+    if (m) {  // (uniform)
+        unsigned base = 0;
+        if (lane == 0) base = atomicAdd(&ticket[0], (unsigned)__popcll(m));
+        base = (unsigned)__shfl((int)base, 0);
+        for (unsigned i = 0; m != 0ull; m &= m - 1ull, i++) {
+            const long long row = b0 + __builtin_ctzll(m);
+            const unsigned at = base + i;
+            if (at >= cap) break;
+            unsigned *e = block + 4 + (size_t)at * (size_t)(1 + G);
+            if (lane == 0) e[0] = (unsigned)row;
+            if (lane < G) e[1 + lane] = __float_as_uint(post[(size_t)row * G + lane]);
+        }
     }
+    list_finish(ticket, block, peers, block_words, nranks, own);
 }
 
 // the other ranks' rows: a wavefront per row with at most one live posterior (from its code), then a wavefront per listed row
@@ -3469,31 +3503,34 @@ __global__ __launch_bounds__(256) void k_post_reconstruct(const uint2 *__restric
 // brought up to date here) - block = {rows listed (beyond `cap`: overflow - the whole slices travel), 3 words of padding, cap entries of
 // (row in the slice, G floats)} - and the receivers, whose copies of the slice are what was sent last, write the listed rows.
 __global__ __launch_bounds__(256) void k_prob_changes_build(const float *__restrict__ slice, float *__restrict__ prev, long long rows, int G,
-                                                            unsigned cap, unsigned *__restrict__ block)
+                                                            unsigned cap, unsigned *__restrict__ block, unsigned *__restrict__ ticket,
+                                                            unsigned *__restrict__ peers, unsigned long long block_words, int nranks, int own)
 {
     const int lane = threadIdx.x & 63;
     const int W = (G + 63) >> 6;
-    const long long row = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (row >= rows) return;
-    bool differs = false;
-    for (int s = 0; s < W; s++) {
-        const int g = lane + 64 * s;
-        if (g < G) differs = differs || __float_as_uint(slice[(size_t)row * G + g]) != __float_as_uint(prev[(size_t)row * G + g]);
-    }
-    if (__ballot(differs) == 0ull) return;  // (uniform)
-    unsigned at = 0;
-    if (lane == 0) at = atomicAdd(&block[0], 1u);
-    at = (unsigned)__shfl((int)at, 0);
-    unsigned *e = at < cap ? block + 4 + (size_t)at * (size_t)(1 + G) : nullptr;
-    if (e != nullptr && lane == 0) e[0] = (unsigned)row;
-    for (int s = 0; s < W; s++) {
-        const int g = lane + 64 * s;
-        if (g < G) {
-            const float v = slice[(size_t)row * G + g];
-            prev[(size_t)row * G + g] = v;
-            if (e != nullptr) e[1 + g] = __float_as_uint(v);
+    // (a few hundred workgroups walk the rows: list_finish is one same-address atomic per workgroup - 3 125 of them were 115 us)
+    for (long long row = (long long)blockIdx.x * 4 + (threadIdx.x >> 6); row < rows; row += (long long)gridDim.x * 4) {
+        bool differs = false;
+        for (int s = 0; s < W; s++) {
+            const int g = lane + 64 * s;
+            if (g < G) differs = differs || __float_as_uint(slice[(size_t)row * G + g]) != __float_as_uint(prev[(size_t)row * G + g]);
+        }
+        if (__ballot(differs) == 0ull) continue;  // (uniform)
+        unsigned at = 0;
+        if (lane == 0) at = atomicAdd(&ticket[0], 1u);
+        at = (unsigned)__shfl((int)at, 0);
+        unsigned *e = at < cap ? block + 4 + (size_t)at * (size_t)(1 + G) : nullptr;
+        if (e != nullptr && lane == 0) e[0] = (unsigned)row;
+        for (int s = 0; s < W; s++) {
+            const int g = lane + 64 * s;
+            if (g < G) {
+                const float v = slice[(size_t)row * G + g];
+                prev[(size_t)row * G + g] = v;
+                if (e != nullptr) e[1 + g] = __float_as_uint(v);
+            }
         }
     }
+    list_finish(ticket, block, peers, block_words, nranks, own);
 }
 
 // the other ranks' listed rows into this rank's copy of their slices (a wavefront per entry)
@@ -3518,11 +3555,12 @@ __global__ __launch_bounds__(256) void k_prob_changes_apply(float *__restrict__ 
     }
 }
 
-hipError_t launch_prob_changes_build(hipStream_t st, const float *slice, float *prev, long long rows, int G, unsigned cap, unsigned *block)
+hipError_t launch_prob_changes_build(hipStream_t st, const float *slice, float *prev, long long rows, int G, unsigned cap, unsigned *block,
+                                     unsigned *ticket, unsigned *peers, unsigned long long block_words, int nranks, int own)
 {
-    hipError_t e = hipMemsetAsync(block, 0, 4 * sizeof(unsigned), st);
-    if (e != hipSuccess || rows == 0) return e;
-    hipLaunchKernelGGL(k_prob_changes_build, dim3(blocks_for(rows, 4)), dim3(256), 0, st, slice, prev, rows, G, cap, block);
+    // (no rows: one workgroup, which writes the header)
+    hipLaunchKernelGGL(k_prob_changes_build, dim3(std::min(512u, blocks_for(rows > 0 ? rows : 1, 4))), dim3(256), 0, st, slice, prev, rows, G, cap, block, ticket, peers,
+                       block_words, nranks, own);
     return hipGetLastError();
 }
 
@@ -3535,23 +3573,28 @@ hipError_t launch_prob_changes_apply(hipStream_t st, float *table, const unsigne
     return hipGetLastError();
 }
 
-// the lists' lengths of all ranks into host-visible memory (one small kernel: a strided 4-byte copy per rank cost 70 us of runtime overhead)
-__global__ void k_post_counts(const unsigned *__restrict__ blocks, unsigned long long block_words, int nranks, unsigned *__restrict__ out)
+// the lists' lengths of all ranks into host-visible memory (one small kernel: a strided 4-byte copy per rank cost 70 us of runtime overhead),
+// then `seq` behind them (system-scope release): the host polls that word instead of synchronising with the stream (dmx_exchange.cpp: wait_counts)
+__global__ void k_post_counts(const unsigned *__restrict__ blocks, unsigned long long block_words, int nranks, unsigned *__restrict__ out, unsigned seq)
 {
     if ((int)threadIdx.x < nranks) out[threadIdx.x] = blocks[(size_t)threadIdx.x * block_words];
+    __threadfence_system();
+    __syncthreads();
+    if (threadIdx.x == 0) __hip_atomic_store(out + nranks, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
-hipError_t launch_post_counts(hipStream_t st, const unsigned *blocks, unsigned long long block_words, int nranks, unsigned *out_host_visible)
+hipError_t launch_post_counts(hipStream_t st, const unsigned *blocks, unsigned long long block_words, int nranks, unsigned *out_host_visible, unsigned seq)
 {
-    hipLaunchKernelGGL(k_post_counts, dim3(1), dim3(1024), 0, st, blocks, block_words, nranks, out_host_visible);
+    if (nranks > 1024) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(k_post_counts, dim3(1), dim3(nranks <= 64 ? 64 : 1024), 0, st, blocks, block_words, nranks, out_host_visible, seq);
     return hipGetLastError();
 }
 
-hipError_t launch_post_compact_build(hipStream_t st, const uint2 *first, const float *post, long long B, int G, unsigned cap, unsigned *block)
+hipError_t launch_post_compact_build(hipStream_t st, const uint2 *first, const float *post, long long B, int G, unsigned cap, unsigned *block,
+                                     unsigned *ticket, unsigned *peers, unsigned long long block_words, int nranks, int own)
 {
-    hipError_t e = hipMemsetAsync(block, 0, 4 * sizeof(unsigned), st);
-    if (e != hipSuccess || B == 0) return e;
-    hipLaunchKernelGGL(k_post_compact_build, dim3(blocks_for(B, 256)), dim3(256), 0, st, first, post, B, G, cap, block);
+    hipLaunchKernelGGL(k_post_compact_build, dim3(blocks_for(B > 0 ? B : 1, 256)), dim3(256), 0, st, first, post, B, G, cap, block, ticket, peers,
+                       block_words, nranks, own);
     return hipGetLastError();
 }
 

@@ -862,7 +862,7 @@ int plan_mstep_shifts(dmx_ctx *c)
 {
     if (c->d_mt_shift_v != nullptr || c->mt_shift_tried) return 0;
     c->mt_shift_tried = true;
-    if (c->mshard || c->sliced) return 0;
+    if (c->mshard) return 0;  // (a variant-sharded rank: the cut of its slice comes with the records, build_mstep_tiles)
     TileCut t;
     if (!cut_mstep_tiles(c, 0, c->V, t)) return 0;
     return upload_variant_shifts(c, t);
@@ -928,7 +928,8 @@ int build_mstep_tiles(dmx_ctx *c, long long v_lo, long long v_hi)
         c->mt_tv = tv;
         return 0;
     }
-    if (c->mshard) DMX_TRY(upload_variant_shifts(c, cut));  // (the incremental M-step of a variant-sharded rank: kernels.h MIncrArgs::changed_map)
+    // (the incremental M-step of a variant-sharded rank - kernels.h MIncrArgs::changed_map - or of a rank that exchanges sums: row_variant)
+    DMX_TRY(upload_variant_shifts(c, cut));
     DMX_TRY(sc.get(&keys, (size_t)m));
     DMX_TRY(sc.get(&keys_out, (size_t)m));
     DMX_TRY(sc.get(&iota, (size_t)m));

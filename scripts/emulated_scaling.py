@@ -28,15 +28,23 @@ from demuxalot_amd.distributed import partition_barcodes  # noqa: E402
 
 
 def region(ctx, steps, warmup):
+    """ms per iteration from a region WITHOUT phase timers (their events are barrier packets on the queue: 4 - 5 phase boundaries of
+    3 - 5 us each weigh on a 0.3 ms iteration), the per-phase breakdown from a second region with them."""
     ctx.run_iterations(warmup, 0.01)
     ctx.synchronize()
-    ctx.set_phase_timers(True); ctx.reset_timings()
+    ctx.set_phase_timers(False)
     t0 = time.perf_counter()
     ctx.run_iterations(steps, 0.01)
     ctx.synchronize()
     elapsed = time.perf_counter() - t0
+    ctx.set_phase_timers(True); ctx.reset_timings()
+    t0 = time.perf_counter()
+    ctx.run_iterations(steps, 0.01)
+    ctx.synchronize()
+    elapsed_timed = time.perf_counter() - t0
     timers = ctx.timings()
-    return {'ms_per_step': 1e3 * elapsed / steps,
+    ctx.set_phase_timers(False)
+    return {'ms_per_step': 1e3 * elapsed / steps, 'ms_per_step_with_phase_timers': 1e3 * elapsed_timed / steps,
             'kernel_ms': {k: round(v['ms'] / max(1, steps), 4) for k, v in timers.items()}}
 
 

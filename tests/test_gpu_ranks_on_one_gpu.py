@@ -619,3 +619,46 @@ def test_incremental_mstep_of_a_variant_sharded_rank(world, monkeypatch):
         assert full >= 1 and delta >= 3 and full + delta == n_it - 1, got[4]
         assert want[4] == (0, 0, 0)
     print(f'{world} ranks: (full, delta, barcodes changed in the last M-step) per rank', [r[4] for r in outcomes[True]])
+
+
+@pytest.mark.parametrize('wire', ['f32', 'f64'])
+def test_incremental_mstep_of_a_rank_that_exchanges_sums(wire, monkeypatch):
+    """A rank of a run that reduce-scatters the SUMS (many more barcodes than variants: n x 200k-barcode weak scaling) holds all calls of
+    its barcodes, like one context: its partial sums are the integers of the tile-major / fixed-point work-item form and stay in the padded
+    exchange buffer between two M-steps, so the incremental M-step applies - the delta pass rewrites the rows it touched (float32 or
+    float64, as the wire; the records' padded table rows brought back to variants: MIncrArgs::row_variant), the reduce-scatter reads the
+    buffer as before.  8 iterations on 2 ranks: the full tile pass per M-step against the incremental M-step on the tile-major records
+    and on the work items (no records) - posteriors and additions bit for bit, and the delta pass did run."""
+    monkeypatch.setenv('DEMUXALOT_AMD_EXCHANGE', 'reduce_scatter')
+    monkeypatch.setenv('DEMUXALOT_AMD_ESTEP', 'guarded')
+    from demuxalot_amd import distributed, synth
+    G, n_it, world = 40, 8, 2
+    p = synth.generate(9_000, 2500, G, calls_per_barcode=400, seed=78)
+    betas = p.prior_betas()
+    pen = np.zeros(G, dtype=np.float32)
+    outcomes = {}
+    for tiles, incremental in (('always', False), ('always', True), ('auto', True)):
+        shared = ThreadWorld(world)
+
+        def rank_body(plane):
+            em = distributed.ShardedEM(plane, p.n_barcodes, p.v2snp, betas, p.variant_id, p.compressed_cb, p.p_base_wrong, reduce_dtype=wire)
+            try:
+                assert em.ctx.exchange_mode() == 'reduce_scatter'
+                em.ctx.set_mstep_tiles(tiles)
+                em.ctx.set_mstep_incremental(incremental)
+                em.ctx.reset_timings()
+                probs, addition = em.learn(n_it, 0.01, pen, False)
+                return em.lo, em.hi, probs, addition, em.ctx.mstep_incremental(), em.ctx.mstep_form()
+            finally:
+                em.ctx.close()
+
+        outcomes[tiles, incremental] = shared.run(rank_body)
+    for key, form in ((('always', True), 'tiles'), (('auto', True), 'items_fixed')):
+        for got, want in zip(outcomes[key], outcomes['always', False]):
+            assert got[:2] == want[:2]
+            fio.assert_bitwise(got[2], want[2], f'posterior rows [{got[0]}, {got[1]}) with the incremental M-step, {key}')
+            fio.assert_bitwise(got[3], want[3], f'addition with the incremental M-step, {key}')
+            full, delta, last = got[4]
+            assert full >= 1 and delta >= 3 and full + delta == n_it - 1, got[4]
+            assert got[5] == form and want[5] == 'tiles' and want[4] == (0, 0, 0), (got[5], want[5], want[4])
+        print(f'{key} / {wire}: (full, delta, changed) per rank', [r[4] for r in outcomes[key]])
