@@ -49,9 +49,6 @@ struct TimerSlot {
     int64_t timed = 0;  // launches that were bracketed by events (phase timers on)
 };
 
-// the compact exchanges' lists (d_post_compact, d_prob_list) end in these words: {rows counted, workgroups done, 2 of padding} - zero between launches
-constexpr size_t LIST_TICKET_WORDS = 4;
-
 struct dmx_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
@@ -129,6 +126,12 @@ struct dmx_ctx {
     long long msteps_done = 0;      // M-steps run on the resident problem
     long long incr_rows = 0;        // barcode rows the incremental state was allocated for (a variant-sharded rank: those of all ranks)
     unsigned char *d_incr_map = nullptr;  // [incr_rows] flags of the changed barcodes (variant-sharded rank: MIncrArgs::changed_map)
+    // variant-sharded rank, incremental M-step: the slice's records once more, BARCODE-major over the rows of all ranks ({variant, bits(1-e)},
+    // a row's calls by variant; build_slice_row_index at the first incremental M-step) - the delta pass reads the changed barcodes' calls only
+    uint2 *d_slice_rec = nullptr;         // [n_slice_rec]
+    long long *d_slice_ptr = nullptr;     // [incr_rows + 1]
+    long long n_slice_rec = 0;
+    bool slice_index_tried = false;
     bool incr_heavy = false;        // the incremental M-step keeps falling back to full passes on this problem: the tile-major records pay (run_mstep)
     int msteps_ahead = 0;           // M-steps the running dmx_em / dmx_run_iterations call still has to do (0 outside)
     long long msteps_expected = 0;  // dmx_set_msteps_expected: M-steps the caller says it will still run (counted down as they run)
@@ -246,8 +249,10 @@ struct dmx_ctx {
     bool post_gathered = false;              // the tables hold the last E-step of every rank
     bool emu_post_filled = false;            // emulated wire: the other ranks' blocks were filled once
     // compact exchange of the posterior rows (gather_posteriors; G <= 64): per rank a block of {rows listed, 3 pad, cap x (row, G floats)}
-    unsigned *d_post_compact = nullptr;      // [nranks * post_compact_words + LIST_TICKET_WORDS] (the tail: what the build kernel counts in)
+    unsigned *d_post_compact = nullptr;      // [nranks * post_compact_words]
     uint2 *d_post_seen = nullptr;            // [rows_total] the code every row of d_post_g was last rebuilt from (0xFF..: unknown)
+    float *d_post_sent = nullptr;            // [B, G] this rank's rows with several live posteriors as the other ranks hold them ...
+    unsigned char *d_post_sent_multi = nullptr;  // [B] ... where they do (0: the row was rebuilt from its code since, or never listed)
     unsigned *h_post_counts = nullptr;       // pinned, [nranks + 1]: the lists' lengths, read behind the all-gather, and the sequence number the host polls
     unsigned list_seq = 0;                   // (k_post_counts / wait_counts)
     size_t post_compact_words = 0;           // words per rank block (0: the whole table travels, as until round 6)
@@ -255,7 +260,7 @@ struct dmx_ctx {
     unsigned post_cap_now = 0;               // ... in the coming exchange: twice what the longest list of the last one held (every rank reads every count: the same choice everywhere)
     long long post_compact_taken = 0, post_compact_overflows = 0;  // E-steps exchanged compactly / that fell back to the whole table
     // compact exchange of the genotype table (run_pstep; sliced P-step): the rows of this rank's slice that changed since it sent them
-    unsigned *d_prob_list = nullptr;         // [nranks * prob_list_words + LIST_TICKET_WORDS] {rows listed, 3 pad, cap x (row, G floats)} per rank
+    unsigned *d_prob_list = nullptr;         // [nranks * prob_list_words] {rows listed, 3 pad, cap x (row, G floats)} per rank
     float *d_prob_prev = nullptr;            // [slice_rows, G] this rank's slice as the other ranks hold it
     size_t prob_list_words = 0;              // (0: the whole slices travel)
     unsigned prob_list_cap = 0;
@@ -342,6 +347,7 @@ int install_mstep_records(dmx_ctx *c, const uint4 *d_rec, long long n, long long
 // tile-major M-step records of variants [v_lo, v_hi) (the ctx's M-step records must cover exactly those); leaves n_mt == 0
 // when the problem does not fit the form
 int build_mstep_tiles(dmx_ctx *c, long long v_lo, long long v_hi);
+int build_slice_row_index(dmx_ctx *c);  // d_slice_rec / d_slice_ptr of a variant-sharded rank (left null where it does not apply)
 int plan_mstep_shifts(dmx_ctx *c);  // the tiles' fixed-point exponents per variant without the tile-major records (fixed-point work-item M-step)
 void release_mstep_tiles(dmx_ctx *c);
 int build_snp_groups(dmx_ctx *c, const unsigned long long *vb_keys, const unsigned *src_idx, const float *src_p, long long m);

@@ -394,10 +394,13 @@ int shard_mstep_by_variant(dmx_ctx *c, bool force)
         c->post_compact_cap = (unsigned)(asked > 0 ? std::min<long long>(asked, rows_pad) : std::max<long long>(64, rows_pad / 4));
         c->post_compact_words = 4 + (size_t)c->post_compact_cap * (size_t)(1 + G);
         c->post_cap_now = c->post_compact_cap;
-        DMX_TRY(dev_alloc(c, &c->d_post_compact, c->post_compact_words * (size_t)n + LIST_TICKET_WORDS));
-        HIP_TRY(hipMemsetAsync(c->d_post_compact, 0, sizeof(unsigned) * (c->post_compact_words * (size_t)n + LIST_TICKET_WORDS), st));
+        DMX_TRY(dev_alloc(c, &c->d_post_compact, c->post_compact_words * (size_t)n));
+        HIP_TRY(hipMemsetAsync(c->d_post_compact, 0, sizeof(unsigned) * (c->post_compact_words * (size_t)n), st));
         DMX_TRY(dev_alloc(c, &c->d_post_seen, (size_t)c->rows_total));
         HIP_TRY(hipMemsetAsync(c->d_post_seen, 0xFF, sizeof(uint2) * (size_t)c->rows_total, st));
+        DMX_TRY(dev_alloc(c, &c->d_post_sent, (size_t)std::max<long long>(1, c->B) * G));
+        DMX_TRY(dev_alloc(c, &c->d_post_sent_multi, (size_t)std::max<long long>(1, c->B)));
+        HIP_TRY(hipMemsetAsync(c->d_post_sent_multi, 0, (size_t)std::max<long long>(1, c->B), st));  // (nothing sent yet: every such row is listed)
         HIP_TRY(hipHostMalloc((void **)&c->h_post_counts, sizeof(unsigned) * (size_t)(n + 1), hipHostMallocMapped | hipHostMallocCoherent));
         std::memset(c->h_post_counts, 0, sizeof(unsigned) * (size_t)(n + 1));
     }
@@ -473,8 +476,8 @@ int layout_exchange(dmx_ctx *c)
                 c->prob_list_cap = (unsigned)(asked > 0 ? std::min<long long>(asked, rows) : std::max<long long>(64, rows / 4));
                 c->prob_list_words = 4 + (size_t)c->prob_list_cap * (size_t)(1 + G);
                 c->prob_cap_now = c->prob_list_cap;
-                DMX_TRY(dev_alloc(c, &c->d_prob_list, c->prob_list_words * (size_t)n + LIST_TICKET_WORDS));
-                HIP_TRY(hipMemsetAsync(c->d_prob_list, 0, sizeof(unsigned) * (c->prob_list_words * (size_t)n + LIST_TICKET_WORDS), st));
+                DMX_TRY(dev_alloc(c, &c->d_prob_list, c->prob_list_words * (size_t)n));
+                HIP_TRY(hipMemsetAsync(c->d_prob_list, 0, sizeof(unsigned) * (c->prob_list_words * (size_t)n), st));
                 DMX_TRY(dev_alloc(c, &c->d_prob_prev, (size_t)rows * G));
                 if (!c->h_prob_counts) {
                     HIP_TRY(hipHostMalloc((void **)&c->h_prob_counts, sizeof(unsigned) * (size_t)(n + 1), hipHostMallocMapped | hipHostMallocCoherent));
@@ -523,7 +526,7 @@ int gather_posteriors(dmx_ctx *c)
     const size_t words_now = 4 + (size_t)cap_now * (size_t)(1 + G);
     if (compact)  // this rank's rows with several live posteriors, listed (the count may run beyond the capacity: overflow)
         HIP_TRY(dmx::launch_post_compact_build(c->stream, c->d_first_g + c->rank * rows, c->d_post_g + c->rank * rows * G, c->B, G, cap_now,
-                                               c->d_post_compact + (size_t)c->rank * words_now, c->d_post_compact + c->post_compact_words * (size_t)c->nranks,
+                                               c->d_post_compact + (size_t)c->rank * words_now, c->d_post_sent, c->d_post_sent_multi,
                                                c->emulated ? c->d_post_compact : nullptr, (unsigned long long)words_now, c->nranks, c->rank));
     coll_group_begin(c);  // one launch for the tables
     rc = coll_all_gather(c, (float *)c->d_first_g, rows * 2, "posterior codes");
@@ -544,11 +547,16 @@ int gather_posteriors(dmx_ctx *c)
         unsigned longest = 0;
         for (int r = 0; r < c->nranks; r++) longest = std::max(longest, c->h_post_counts[r]);
         const bool overflow = longest > cap_now;
+        if (std::getenv("DEMUXALOT_AMD_EXCHANGE_TRACE")) std::fprintf(stderr, "[posterior lists] longest %u capacity %u of %u\n", longest, cap_now, c->post_compact_cap);
         c->post_cap_now = overflow ? c->post_compact_cap : (unsigned)std::min<unsigned long long>(c->post_compact_cap, 4ull * longest + 512ull);
         if (overflow) {  // (dense posteriors: the first E-steps of a run that starts from uninformative genotypes)
             c->post_compact_overflows++;
             rc = coll_all_gather(c, c->d_post_g, rows * G, "singlet posteriors (the lists overflowed)");
             HIP_TRY(hipMemsetAsync(c->d_post_seen, 0xFF, sizeof(uint2) * (size_t)c->rows_total, c->stream));  // (the rows are the senders' own now)
+            if (c->B > 0) {  // ... and what everybody holds of this rank's rows is what they are
+                HIP_TRY(hipMemcpyAsync(c->d_post_sent, c->d_post_g + c->rank * rows * G, sizeof(float) * (size_t)c->B * G, hipMemcpyDeviceToDevice, c->stream));
+                HIP_TRY(hipMemsetAsync(c->d_post_sent_multi, 1, (size_t)c->B, c->stream));
+            }
         } else {
             c->post_compact_taken++;
         }

@@ -377,6 +377,10 @@ void release_incremental(dmx_ctx *c)
     dev_free(c, &c->d_prev_first, rows);
     dev_free(c, &c->d_incr_list, rows);
     dev_free(c, &c->d_incr_map, rows);
+    dev_free(c, &c->d_slice_rec, (size_t)c->n_slice_rec);
+    dev_free(c, &c->d_slice_ptr, rows + 1);
+    c->n_slice_rec = 0;
+    c->slice_index_tried = false;
     c->incr_rows = 0;
     dev_free(c, &c->d_incr_touched, (size_t)c->V);
     dev_free(c, &c->d_incr_state, (size_t)(3 * dmx::IS_WORDS));
@@ -426,7 +430,7 @@ void release_problem(dmx_ctx *c)
     dev_free(c, &c->d_raw, vg);
     c->have_raw = false;
     dev_free(c, &c->d_add, vg);
-    dev_free(c, &c->d_prob_list, c->prob_list_words * (size_t)std::max(1, c->nranks) + LIST_TICKET_WORDS);
+    dev_free(c, &c->d_prob_list, c->prob_list_words * (size_t)std::max(1, c->nranks));
     dev_free(c, &c->d_prob_prev, (size_t)c->slice_rows * c->G);
     c->prob_list_words = 0;
     c->prob_list_cap = 0;
@@ -455,8 +459,10 @@ void release_problem(dmx_ctx *c)
     dev_free(c, &c->d_first_g, (size_t)c->rows_total);
     dev_free(c, &c->d_nz_g, (size_t)c->rows_total * ((c->G + 63) / 64));
     dev_free(c, &c->d_post_g, (size_t)c->rows_total * c->G);
-    dev_free(c, &c->d_post_compact, c->post_compact_words * (size_t)std::max(1, c->nranks) + LIST_TICKET_WORDS);
+    dev_free(c, &c->d_post_compact, c->post_compact_words * (size_t)std::max(1, c->nranks));
     dev_free(c, &c->d_post_seen, (size_t)c->rows_total);
+    dev_free(c, &c->d_post_sent, (size_t)std::max<long long>(1, c->B) * c->G);
+    dev_free(c, &c->d_post_sent_multi, (size_t)std::max<long long>(1, c->B));
     if (c->h_post_counts) (void)hipHostFree(c->h_post_counts);
     c->h_post_counts = nullptr;
     c->post_compact_words = 0;

@@ -272,7 +272,7 @@ int run_pstep(dmx_ctx *c, float lo, float hi, bool with_addition, bool with_half
             const unsigned cap_now = std::max(1u, std::min(c->prob_cap_now, c->prob_list_cap));
             const size_t words_now = 4 + (size_t)cap_now * (size_t)(1 + c->G);
             HIP_TRY(dmx::launch_prob_changes_build(c->stream, mine, c->d_prob_prev, c->slice_rows, c->G, cap_now,
-                                                   c->d_prob_list + (size_t)c->rank * words_now, c->d_prob_list + c->prob_list_words * (size_t)c->nranks,
+                                                   c->d_prob_list + (size_t)c->rank * words_now,
                                                    c->emulated ? c->d_prob_list : nullptr, (unsigned long long)words_now, c->nranks, c->rank));
             rc = coll_all_gather(c, (float *)c->d_prob_list, words_now, "changed rows of genotype_prob");
             if (rc == 0) {
@@ -712,8 +712,11 @@ int run_mstep(dmx_ctx *c, float power)
             DMX_TRY(dev_alloc(c, &c->d_prev_first, (size_t)incr_rows));
             DMX_TRY(dev_alloc(c, &c->d_incr_list, (size_t)incr_rows));
             if (sharded_incr) {
-                DMX_TRY(dev_alloc(c, &c->d_incr_map, (size_t)incr_rows));
-                HIP_TRY(hipMemsetAsync(c->d_incr_map, 0, (size_t)incr_rows, c->stream));
+                DMX_TRY(dmx::build_slice_row_index(c));  // (the slice's records by barcode row; without it: the masked walk and its byte map)
+                if (c->d_slice_rec == nullptr) {
+                    DMX_TRY(dev_alloc(c, &c->d_incr_map, (size_t)incr_rows));
+                    HIP_TRY(hipMemsetAsync(c->d_incr_map, 0, (size_t)incr_rows, c->stream));
+                }
             }
             DMX_TRY(dev_alloc(c, &c->d_incr_touched, (size_t)c->V));
             DMX_TRY(dev_alloc(c, &c->d_incr_state, (size_t)(3 * dmx::IS_WORDS)));  // two alternating sets + the counters
@@ -750,12 +753,14 @@ int run_mstep(dmx_ctx *c, float power)
         incr.pairs = sharded_incr ? nullptr : c->d_call_pairs;
         incr.call_rows = sharded_incr ? nullptr : c->d_call_rows;
         incr.pair_ptr = sharded_incr ? nullptr : c->d_pair_ptr;
-        incr.changed_map = sharded_incr ? c->d_incr_map : nullptr;
+        incr.changed_map = sharded_incr ? c->d_incr_map : nullptr;  // (null with the row index)
+        incr.rec = sharded_incr ? c->d_slice_rec : nullptr;
+        incr.rec_ptr = sharded_incr && c->d_slice_rec != nullptr ? c->d_slice_ptr : nullptr;
         incr.row_variant = !sharded_incr && c->sliced ? c->d_row_variant : nullptr;
         incr.B = incr_rows;
         incr.V = c->V;
         incr.floor = dmx::mincr_floor(power);
-        a.incr_total = sharded_incr ? 2ull * (unsigned long long)incr_rows : 0ull;
+        a.incr_total = !sharded_incr ? 0ull : incr.rec_ptr != nullptr ? (unsigned long long)c->n_csc : 2ull * (unsigned long long)incr_rows;
         tiles.acc64 = c->d_acc64;
         tiles.incr_state = incr.state;
         if (fixed_items) {

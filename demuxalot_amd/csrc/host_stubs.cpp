@@ -163,13 +163,13 @@ hipError_t launch_f64_to_f32(hipStream_t, const double *, float *, long long) { 
 hipError_t launch_add_f32(hipStream_t, const float *, const float *, float *, long long) { return hipSuccess; }
 hipError_t launch_f32_to_f64(hipStream_t, const float *, double *, long long) { return hipSuccess; }
 hipError_t launch_delay(hipStream_t, long long) { return hipSuccess; }
-hipError_t launch_post_compact_build(hipStream_t, const uint2 *, const float *, long long, int, unsigned cap, unsigned *block, unsigned *, unsigned *,
-                                     unsigned long long, int, int)
+hipError_t launch_post_compact_build(hipStream_t, const uint2 *, const float *, long long, int, unsigned cap, unsigned *block, float *, unsigned char *,
+                                     unsigned *, unsigned long long, int, int)
 {
     block[0] = cap + 1;  // (no kernels here: "overflow", so that the host logic takes the whole-table path it can execute)
     return hipSuccess;
 }
-hipError_t launch_prob_changes_build(hipStream_t, const float *, float *, long long, int, unsigned cap, unsigned *block, unsigned *, unsigned *,
+hipError_t launch_prob_changes_build(hipStream_t, const float *, float *, long long, int, unsigned cap, unsigned *block, unsigned *,
                                      unsigned long long, int, int)
 {
     block[0] = cap + 1;  // (no kernels here: "overflow" - the whole slices travel, which the host logic can execute)
@@ -305,6 +305,11 @@ int wire_records_of(dmx_ctx *c, long long row_base, uint4 *out, long long capaci
 int build_mstep_tiles(dmx_ctx *c, long long, long long)
 {
     c->mt_tried = true;
+    return 0;
+}
+int build_slice_row_index(dmx_ctx *c)
+{
+    c->slice_index_tried = true;
     return 0;
 }
 int plan_mstep_shifts(dmx_ctx *c)

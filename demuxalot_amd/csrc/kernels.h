@@ -378,6 +378,11 @@ struct MIncrArgs {
     // A rank that exchanges sums (sliced table): the records' table rows are the PADDED rows of the exchange layout; row_variant
     // [padded rows] brings them back to variants (acc64, shift_v, touched are per variant).  Null: table rows = variants.
     const int *row_variant;
+    // ... or, with the slice's records sorted by barcode row too (dmx_ctx::d_slice_rec, build_slice_row_index): rec_ptr [B + 1], rec
+    // {variant, bits(1 - e)} - the delta pass of one context (k_mincr_delta: a workgroup per changed barcode) on the rows of all ranks;
+    // changed_map is then null, IS_CALLS counts the changed barcodes' real calls against MstepArgs::incr_total = the slice's calls.
+    const uint2 *rec;
+    const long long *rec_ptr;
 };
 enum { IS_N = 0,        // changed barcodes of this M-step
        IS_CALLS = 2,    // (64 bit, words 2 and 3) their (padded) calls
@@ -413,12 +418,13 @@ hipError_t launch_add_f32(hipStream_t st, const float *a, const float *b, float 
 // one wavefront that keeps the stream busy for `ticks` of the constant-rate wall clock (emulated wire: dmx_comm_init_emulated)
 hipError_t launch_delay(hipStream_t st, long long ticks);
 // compact exchange of the posterior rows (kernels.hip: k_post_compact_build / k_post_reconstruct; dmx_exchange.cpp: gather_posteriors)
-// (ticket: two zeroed words the build kernels count in and clear again; peers: emulated wire only, else nullptr - the other ranks' headers are cleared)
+// (peers: emulated wire only, else nullptr - the other ranks' headers are cleared)
+// (sent [B, G] / sent_multi [B]: what the receivers hold of this rank's rows with several live posteriors - only rows that differ are listed)
 hipError_t launch_post_compact_build(hipStream_t st, const uint2 *first, const float *post, long long B, int G, unsigned cap, unsigned *block,
-                                     unsigned *ticket, unsigned *peers, unsigned long long block_words, int nranks, int own);
+                                     float *sent, unsigned char *sent_multi, unsigned *peers, unsigned long long block_words, int nranks, int own);
 // compact exchange of the genotype table (kernels.hip: k_prob_changes_build / k_prob_changes_apply; dmx_steps.cpp: run_pstep)
 hipError_t launch_prob_changes_build(hipStream_t st, const float *slice, float *prev, long long rows, int G, unsigned cap, unsigned *block,
-                                     unsigned *ticket, unsigned *peers, unsigned long long block_words, int nranks, int own);
+                                     unsigned *peers, unsigned long long block_words, int nranks, int own);
 hipError_t launch_prob_changes_apply(hipStream_t st, float *table, const unsigned *blocks, unsigned long long block_words, long long slice_rows, int G,
                                      int nranks, int own, unsigned cap, unsigned short *table16);
 // out_host_visible: [nranks + 1] - the counts, then `seq` (written last, system scope: the host polls it)

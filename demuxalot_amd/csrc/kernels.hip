@@ -2462,7 +2462,8 @@ static __device__ __forceinline__ bool mincr_differs(float now, float before, fl
 __global__ __launch_bounds__(256) void k_mincr_changes(MstepArgs a, MIncrArgs x)
 {
     if (x.state[IS_VALID] == 0u || dense_regime(a)) return;  // the full pass is coming
-    // (16 barcodes per wavefront: the row comparisons of a wavefront are one after the other, so more wavefronts = more of them in flight)
+    // (16 barcodes per wavefront: the row comparisons of a wavefront are one after the other, so more wavefronts = more of them in flight;
+    // 64 per wavefront where the last M-step found next to nothing changed was tried: 5 us slower at 200 000 barcodes, not faster)
     const int lane = threadIdx.x & 63;
     const long long b = ((long long)blockIdx.x * 4 + (threadIdx.x >> 6)) * 16 + lane;
     bool look = false;
@@ -2478,7 +2479,9 @@ __global__ __launch_bounds__(256) void k_mincr_changes(MstepArgs a, MIncrArgs x)
         if (lane == 0) {
             if (changed) {
                 x.list[atomicAdd(x.state + IS_N, 1u)] = (int)bb;
-                atomicAdd((unsigned long long *)(x.state + IS_CALLS), x.pair_ptr ? 2ull * (unsigned long long)(x.pair_ptr[bb + 1] - x.pair_ptr[bb]) : 2ull);
+                atomicAdd((unsigned long long *)(x.state + IS_CALLS), x.pair_ptr  ? 2ull * (unsigned long long)(x.pair_ptr[bb + 1] - x.pair_ptr[bb])
+                                                                    : x.rec_ptr ? (unsigned long long)(x.rec_ptr[bb + 1] - x.rec_ptr[bb])
+                                                                                : 2ull);
                 if (x.changed_map) x.changed_map[bb] = 1;
             } else {
                 x.prev_first[bb] = a.first[bb];  // (nothing that matters changed: the next M-step need not look at its rows again)
@@ -2512,14 +2515,19 @@ __global__ __launch_bounds__(256) void k_mincr_delta(MstepArgs a, MIncrArgs x)
             before = x.prev[(size_t)b * G + lane];
         }
         const unsigned long long mask = __ballot(lane < G && mincr_differs(now, before, x.floor));
-        const long long p0 = x.pair_ptr[b];
-        const int n_calls = 2 * (int)(x.pair_ptr[b + 1] - p0);
+        const bool indexed = x.rec_ptr != nullptr;  // (uniform) a variant-sharded rank: the slice's calls of global barcode row b
+        const long long p0 = indexed ? x.rec_ptr[b] : x.pair_ptr[b];
+        const int n_calls = indexed ? (int)(x.rec_ptr[b + 1] - p0) : 2 * (int)(x.pair_ptr[b + 1] - p0);
         for (int c0 = 64 * wave; c0 < n_calls; c0 += 256) {
             const int ci = c0 + lane;
             const bool mine = ci < n_calls;
             float keep = 0.0f;
             unsigned row = 0u;
-            if (mine) {
+            if (mine && indexed) {
+                const uint2 d = x.rec[p0 + ci];
+                row = d.x;
+                keep = __uint_as_float(d.y);
+            } else if (mine) {
                 keep = x.pairs[p0 + (ci >> 1)].keep[ci & 1];
                 row = x.call_rows[2 * p0 + ci];
                 if (x.row_variant != nullptr) row = (unsigned)x.row_variant[row];
@@ -3349,10 +3357,15 @@ hipError_t launch_mstep_items_incremental(hipStream_t st, const MstepArgs &a, co
 
 hipError_t launch_mstep_incremental_sharded(hipStream_t st, const MstepArgs &a, const MTileArgs &t, const MIncrArgs &x)
 {
-    if (t.n_tiles == 0 || x.B == 0 || x.changed_map == nullptr) return hipErrorInvalidValue;
+    if (t.n_tiles == 0 || x.B == 0 || (x.changed_map == nullptr && x.rec_ptr == nullptr)) return hipErrorInvalidValue;
     hipLaunchKernelGGL(k_mincr_changes, dim3(blocks_for(x.B, 64)), dim3(256), 0, st, a, x);
     const dim3 grid(std::min(blocks_for(a.n_items, 4), 8192u));
-    if (a.n_items) {
+    if (x.rec_ptr != nullptr) {  // the slice's records by barcode row: the changed barcodes' calls only
+        if (a.square)
+            hipLaunchKernelGGL((k_mincr_delta<true>), dim3(4096), dim3(256), 0, st, a, x);
+        else
+            hipLaunchKernelGGL((k_mincr_delta<false>), dim3(4096), dim3(256), 0, st, a, x);
+    } else if (a.n_items) {
         if (a.square)
             hipLaunchKernelGGL((k_mincr_delta_masked<true>), grid, dim3(256), 0, st, a, x);
         else
@@ -3412,47 +3425,65 @@ hipError_t launch_mcombine(hipStream_t st, const MstepArgs &a, const long long *
 // exactly +0 to every sum (NZ_FLOOR_SQUARE; with another contribution_power "live" means non-zero), so the additions keep their bits.
 // Rows with several live posteriors (1 - 15 % of the barcodes) travel in a list: block = {rows listed (beyond `cap`: overflow - the
 // caller falls back to the all-gather of the whole table), 3 words of padding, cap entries of (row, G floats)}.
-// The lists' lengths are counted in ticket[0]; the workgroup that finishes last (ticket[1]) moves the count into the block's header and
-// clears both for the next exchange - no memset between two exchanges.  (peers, emulated wire only: nobody fills the other ranks'
-// blocks; they list nothing, wherever this exchange's block size puts their headers.)
-__device__ __forceinline__ void list_finish(unsigned *__restrict__ ticket, unsigned *__restrict__ block, unsigned *__restrict__ peers,
-                                            unsigned long long block_words, int nranks, int own)
+// (peers, emulated wire only: nobody fills the other ranks' blocks; they list nothing, wherever this exchange's block size puts their
+// headers.  A "last workgroup moves the count into the header" scheme instead of the header's memset was tried: one same-address
+// device-scope atomic per workgroup, 25 - 35 ns each when they arrive together - 115 us for the 3 125 workgroups of a table slice.)
+__device__ __forceinline__ void clear_peer_headers(unsigned *__restrict__ peers, unsigned long long block_words, int nranks, int own)
 {
-    __syncthreads();
-    if (threadIdx.x != 0) return;
-    __threadfence();
-    if (atomicAdd(&ticket[1], 1u) != gridDim.x - 1u) return;
-    __threadfence();
-    block[0] = atomicExch(&ticket[0], 0u);
-    ticket[1] = 0u;
-    if (peers != nullptr)
-        for (int r = 0; r < nranks; r++)
-            if (r != own) peers[(size_t)r * block_words] = 0u;
+    if (peers == nullptr || blockIdx.x != 0 || threadIdx.x != 0) return;
+    for (int r = 0; r < nranks; r++)
+        if (r != own) peers[(size_t)r * block_words] = 0u;
 }
 
+// sent / sent_multi: what the receivers hold of this rank's rows with several live posteriors - a row is listed only when it differs from
+// that (17.8 % of the barcodes of the converged 200k x 100k x 64 experiment have several live posteriors, and next to none of them moves);
+// a row the receivers rebuild from its code is no longer described by what was sent.  16 rows per wavefront: the row comparisons of a
+// wavefront are one after the other.
 __global__ __launch_bounds__(256) void k_post_compact_build(const uint2 *__restrict__ first, const float *__restrict__ post, long long B, int G,
-                                                            unsigned cap, unsigned *__restrict__ block, unsigned *__restrict__ ticket,
-                                                            unsigned *__restrict__ peers, unsigned long long block_words, int nranks, int own)
+                                                            unsigned cap, unsigned *__restrict__ block, float *__restrict__ sent,
+                                                            unsigned char *__restrict__ sent_multi, unsigned *__restrict__ peers,
+                                                            unsigned long long block_words, int nranks, int own)
 {
+    clear_peer_headers(peers, block_words, nranks, own);
     const int lane = threadIdx.x & 63;
-    const long long b0 = ((long long)blockIdx.x * 4 + (threadIdx.x >> 6)) * 64;
+    const long long b0 = ((long long)blockIdx.x * 4 + (threadIdx.x >> 6)) * 16;
     const long long b = b0 + lane;
-    const bool multi = b < B && (first[b < B ? b : 0].y & 127u) != 1u;
-    unsigned long long m = __ballot(multi);
-    if (m) {  // (uniform)
-        unsigned base = 0;
-        if (lane == 0) base = atomicAdd(&ticket[0], (unsigned)__popcll(m));
-        base = (unsigned)__shfl((int)base, 0);
-        for (unsigned i = 0; m != 0ull; m &= m - 1ull, i++) {
-            const long long row = b0 + __builtin_ctzll(m);
-            const unsigned at = base + i;
-            if (at >= cap) break;
-            unsigned *e = block + 4 + (size_t)at * (size_t)(1 + G);
-            if (lane == 0) e[0] = (unsigned)row;
-            if (lane < G) e[1 + lane] = __float_as_uint(post[(size_t)row * G + lane]);
+    const bool in = lane < 16 && b < B;
+    const bool multi = in && (first[in ? b : 0].y & 127u) != 1u;
+    const bool was = in && sent_multi[in ? b : 0] != 0;
+    if (in && !multi && was) sent_multi[b] = 0;
+    const unsigned long long m = __ballot(multi), was_m = __ballot(multi && was);
+    if (!m) return;
+    unsigned long long dm = 0ull;  // the rows to list (uniform)
+    for (unsigned long long mm = m; mm != 0ull; mm &= mm - 1ull) {
+        const int src = __builtin_ctzll(mm);
+        bool same = false;
+        if ((was_m >> src) & 1ull) {
+            const size_t o = (size_t)(b0 + src) * G + lane;
+            const bool differs = lane < G && __float_as_uint(post[lane < G ? o : 0]) != __float_as_uint(sent[lane < G ? o : 0]);
+            same = __ballot(differs) == 0ull;
+        }
+        if (!same) dm |= 1ull << src;
+    }
+    if (!dm) return;
+    unsigned base = 0;
+    if (lane == 0) base = atomicAdd(&block[0], (unsigned)__popcll(dm));
+    base = (unsigned)__shfl((int)base, 0);
+    for (unsigned i = 0; dm != 0ull; dm &= dm - 1ull, i++) {  // (uniform)
+        const long long row = b0 + __builtin_ctzll(dm);
+        const unsigned at = base + i;
+        if (at >= cap) break;  // (overflow: the whole table travels, and `sent` becomes a copy of it)
+        unsigned *e = block + 4 + (size_t)at * (size_t)(1 + G);
+        if (lane == 0) {
+            e[0] = (unsigned)row;
+            sent_multi[row] = 1;
+        }
+        if (lane < G) {
+            const float v = post[(size_t)row * G + lane];
+            e[1 + lane] = __float_as_uint(v);
+            sent[(size_t)row * G + lane] = v;
         }
     }
-    list_finish(ticket, block, peers, block_words, nranks, own);
 }
 
 // the other ranks' rows: a wavefront per row with at most one live posterior (from its code), then a wavefront per listed row
@@ -3503,34 +3534,33 @@ __global__ __launch_bounds__(256) void k_post_reconstruct(const uint2 *__restric
 // brought up to date here) - block = {rows listed (beyond `cap`: overflow - the whole slices travel), 3 words of padding, cap entries of
 // (row in the slice, G floats)} - and the receivers, whose copies of the slice are what was sent last, write the listed rows.
 __global__ __launch_bounds__(256) void k_prob_changes_build(const float *__restrict__ slice, float *__restrict__ prev, long long rows, int G,
-                                                            unsigned cap, unsigned *__restrict__ block, unsigned *__restrict__ ticket,
-                                                            unsigned *__restrict__ peers, unsigned long long block_words, int nranks, int own)
+                                                            unsigned cap, unsigned *__restrict__ block, unsigned *__restrict__ peers,
+                                                            unsigned long long block_words, int nranks, int own)
 {
+    clear_peer_headers(peers, block_words, nranks, own);
     const int lane = threadIdx.x & 63;
     const int W = (G + 63) >> 6;
-    // (a few hundred workgroups walk the rows: list_finish is one same-address atomic per workgroup - 3 125 of them were 115 us)
-    for (long long row = (long long)blockIdx.x * 4 + (threadIdx.x >> 6); row < rows; row += (long long)gridDim.x * 4) {
-        bool differs = false;
-        for (int s = 0; s < W; s++) {
-            const int g = lane + 64 * s;
-            if (g < G) differs = differs || __float_as_uint(slice[(size_t)row * G + g]) != __float_as_uint(prev[(size_t)row * G + g]);
-        }
-        if (__ballot(differs) == 0ull) continue;  // (uniform)
-        unsigned at = 0;
-        if (lane == 0) at = atomicAdd(&ticket[0], 1u);
-        at = (unsigned)__shfl((int)at, 0);
-        unsigned *e = at < cap ? block + 4 + (size_t)at * (size_t)(1 + G) : nullptr;
-        if (e != nullptr && lane == 0) e[0] = (unsigned)row;
-        for (int s = 0; s < W; s++) {
-            const int g = lane + 64 * s;
-            if (g < G) {
-                const float v = slice[(size_t)row * G + g];
-                prev[(size_t)row * G + g] = v;
-                if (e != nullptr) e[1 + g] = __float_as_uint(v);
-            }
+    const long long row = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    bool differs = false;
+    for (int s = 0; s < W; s++) {
+        const int g = lane + 64 * s;
+        if (g < G) differs = differs || __float_as_uint(slice[(size_t)row * G + g]) != __float_as_uint(prev[(size_t)row * G + g]);
+    }
+    if (__ballot(differs) == 0ull) return;  // (uniform)
+    unsigned at = 0;
+    if (lane == 0) at = atomicAdd(&block[0], 1u);
+    at = (unsigned)__shfl((int)at, 0);
+    unsigned *e = at < cap ? block + 4 + (size_t)at * (size_t)(1 + G) : nullptr;
+    if (e != nullptr && lane == 0) e[0] = (unsigned)row;
+    for (int s = 0; s < W; s++) {
+        const int g = lane + 64 * s;
+        if (g < G) {
+            const float v = slice[(size_t)row * G + g];
+            prev[(size_t)row * G + g] = v;
+            if (e != nullptr) e[1 + g] = __float_as_uint(v);
         }
     }
-    list_finish(ticket, block, peers, block_words, nranks, own);
 }
 
 // the other ranks' listed rows into this rank's copy of their slices (a wavefront per entry)
@@ -3556,11 +3586,12 @@ __global__ __launch_bounds__(256) void k_prob_changes_apply(float *__restrict__ 
 }
 
 hipError_t launch_prob_changes_build(hipStream_t st, const float *slice, float *prev, long long rows, int G, unsigned cap, unsigned *block,
-                                     unsigned *ticket, unsigned *peers, unsigned long long block_words, int nranks, int own)
+                                     unsigned *peers, unsigned long long block_words, int nranks, int own)
 {
-    // (no rows: one workgroup, which writes the header)
-    hipLaunchKernelGGL(k_prob_changes_build, dim3(std::min(512u, blocks_for(rows > 0 ? rows : 1, 4))), dim3(256), 0, st, slice, prev, rows, G, cap, block, ticket, peers,
-                       block_words, nranks, own);
+    hipError_t e = hipMemsetAsync(block, 0, 4 * sizeof(unsigned), st);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(k_prob_changes_build, dim3(blocks_for(rows > 0 ? rows : 1, 4)), dim3(256), 0, st, slice, prev, rows, G, cap, block, peers, block_words,
+                       nranks, own);
     return hipGetLastError();
 }
 
@@ -3591,9 +3622,11 @@ hipError_t launch_post_counts(hipStream_t st, const unsigned *blocks, unsigned l
 }
 
 hipError_t launch_post_compact_build(hipStream_t st, const uint2 *first, const float *post, long long B, int G, unsigned cap, unsigned *block,
-                                     unsigned *ticket, unsigned *peers, unsigned long long block_words, int nranks, int own)
+                                     float *sent, unsigned char *sent_multi, unsigned *peers, unsigned long long block_words, int nranks, int own)
 {
-    hipLaunchKernelGGL(k_post_compact_build, dim3(blocks_for(B > 0 ? B : 1, 256)), dim3(256), 0, st, first, post, B, G, cap, block, ticket, peers,
+    hipError_t e = hipMemsetAsync(block, 0, 4 * sizeof(unsigned), st);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(k_post_compact_build, dim3(blocks_for(B > 0 ? B : 1, 64)), dim3(256), 0, st, first, post, B, G, cap, block, sent, sent_multi, peers,
                        block_words, nranks, own);
     return hipGetLastError();
 }

@@ -855,6 +855,56 @@ int upload_variant_shifts(dmx_ctx *c, const TileCut &t)
 }
 }  // namespace
 
+namespace {
+// one wavefront per work item: its records as (barcode row, {variant, bits(1 - e)})
+__global__ __launch_bounds__(256) void k_slice_rows(const uint2 *__restrict__ csc, const long long *__restrict__ item_start, const int *__restrict__ item_len,
+                                                    const int *__restrict__ item_variant, long long n_items, unsigned *__restrict__ keys,
+                                                    unsigned long long *__restrict__ vals)
+{
+    const long long item = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (item >= n_items) return;
+    const long long s0 = item_start[item];
+    const unsigned long long v = (unsigned long long)(unsigned)item_variant[item];
+    for (int i = threadIdx.x & 63; i < item_len[item]; i += 64) {
+        const uint2 d = csc[s0 + i];
+        keys[s0 + i] = d.x;
+        vals[s0 + i] = v | ((unsigned long long)d.y << 32);
+    }
+}
+}  // namespace
+
+// Variant-sharded rank, incremental M-step (kernels.h: MIncrArgs::rec): the delta pass adds the differences of the CHANGED barcodes' calls;
+// a rank holds its slice's records variant-major only, and a masked walk of all of them (k_mincr_delta_masked) is a read of 8 bytes per
+// call of the slice whatever changed - 32 us of an 8-rank iteration of 0.32 ms, 0.1 ms of a 2-rank one.  So the slice's records are
+// sorted once more, by barcode row (stable: a row's calls stay in variant order), with a pointer per row of the whole job.
+// Leaves d_slice_rec null where it does not apply (the caller stays with the masked walk).
+int build_slice_row_index(dmx_ctx *c)
+{
+    if (c->d_slice_rec != nullptr || c->slice_index_tried) return 0;
+    c->slice_index_tried = true;
+    const char *env = std::getenv("DEMUXALOT_AMD_SLICE_INDEX");  // =0: the masked walk (tests; a rank short of memory)
+    if (env && atoi(env) == 0) return 0;
+    const long long m = c->n_csc, rows = c->rows_total;
+    if (!c->mshard || m == 0 || rows == 0 || m >= (1LL << 32) || c->d_item_variant == nullptr) return 0;
+    hipStream_t st = c->stream;
+    Scratch sc(c);
+    unsigned *keys = nullptr, *keys_out = nullptr;
+    unsigned long long *vals = nullptr;
+    DMX_TRY(sc.get(&keys, (size_t)m));
+    DMX_TRY(sc.get(&keys_out, (size_t)m));
+    DMX_TRY(sc.get(&vals, (size_t)m));
+    hipLaunchKernelGGL(k_slice_rows, dim3((unsigned)((c->n_items + 3) / 4)), dim3(256), 0, st, c->d_csc, c->d_item_start, c->d_item_len,
+                       c->d_item_variant, c->n_items, keys, vals);
+    DMX_TRY(dev_alloc(c, &c->d_slice_rec, (size_t)m));
+    c->n_slice_rec = m;
+    DMX_TRY(sort_pairs64(sc, keys, keys_out, vals, (unsigned long long *)c->d_slice_rec, (size_t)m, bits_for((unsigned long long)(rows - 1)), st));
+    DMX_TRY(dev_alloc(c, &c->d_slice_ptr, (size_t)rows + 1));
+    hipLaunchKernelGGL(k_tile_ptr, dim3(grid_for(rows + 1)), dim3(256), 0, st, keys_out, m, rows, c->d_slice_ptr);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipStreamSynchronize(st));  // (scratch)
+    return 0;
+}
+
 // The exponents alone, without the tile-major records (their sort): what the fixed-point WORK-ITEM form adds with (MstepArgs::
 // fixed_shift_v) - the same cut, so the same exponents the tile-major form uses should the records be built later.  Leaves
 // d_mt_shift_v null when the problem does not take the tile cut (the caller then stays with the float64 item form).

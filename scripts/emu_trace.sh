@@ -1,6 +1,6 @@
 cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
 rm -rf gpurun_out/emu_trace; mkdir -p gpurun_out/emu_trace
-rocprofv3 --kernel-trace --memory-copy-trace --output-format csv -d gpurun_out/emu_trace -o run -- python3 scripts/emulated_scaling.py --kinds strong --ranks 8 --steps 6 --warmup 3 > /dev/null 2> gpurun_out/emu_trace/err.txt
+rocprofv3 --kernel-trace --memory-copy-trace --output-format csv -d gpurun_out/emu_trace -o run -- python3 scripts/emulated_scaling.py --kinds strong --ranks 8 --steps 12 --warmup 8 > /dev/null 2> gpurun_out/emu_trace/err.txt
 python3 - <<'PY'
 import csv
 rows = list(csv.DictReader(open('gpurun_out/emu_trace/run_kernel_trace.csv')))

@@ -581,13 +581,16 @@ def test_compact_exchange_of_the_posterior_rows(mode, monkeypatch):
           f'(capacity {t_cap}); capacity 16: {overflows16} / {outcomes["16"][0][5][1]} fallbacks')
 
 
+@pytest.mark.parametrize('row_index', [True, False])
 @pytest.mark.parametrize('world', [2, 3])
-def test_incremental_mstep_of_a_variant_sharded_rank(world, monkeypatch):
+def test_incremental_mstep_of_a_variant_sharded_rank(world, row_index, monkeypatch):
     """A rank of a variant-sharded run sums ITS variant slice over the barcodes of all ranks.  With the tile-major records of the slice
     its sums are integers, so they can be kept and updated (kernels.h: MIncrArgs::changed_map): the changed barcodes are found in the
-    gathered tables, the delta pass is a masked walk of the slice's variant-major records.  8 iterations on 2 and 3 ranks with it and
-    with every M-step the full tile pass: posteriors and additions bit for bit, and the delta pass did run."""
+    gathered tables, the delta pass visits the changed barcodes' calls through the slice's records sorted by barcode row (row_index;
+    build_slice_row_index) or is a masked walk of the slice's variant-major records (DEMUXALOT_AMD_SLICE_INDEX=0).  8 iterations on 2 and 3
+    ranks with it and with every M-step the full tile pass: posteriors and additions bit for bit, and the delta pass did run."""
     monkeypatch.setenv('DEMUXALOT_AMD_EXCHANGE', 'variant')
+    monkeypatch.setenv('DEMUXALOT_AMD_SLICE_INDEX', '1' if row_index else '0')
     monkeypatch.setenv('DEMUXALOT_AMD_ESTEP', 'guarded')
     from demuxalot_amd import distributed, synth
     G, n_it = 40, 8
