@@ -382,9 +382,9 @@ int shard_mstep_by_variant(dmx_ctx *c, bool force)
     HIP_TRY(hipMemsetAsync(c->d_first_g, 0, sizeof(uint2) * (size_t)c->rows_total, st));
     HIP_TRY(hipMemsetAsync(c->d_nz_g, 0, sizeof(unsigned long long) * (size_t)c->rows_total * W, st));
     HIP_TRY(hipMemsetAsync(c->d_post_g, 0, sizeof(float) * (size_t)c->rows_total * G, st));
-    // Compact exchange of the posterior rows (gather_posteriors): a barcode with ONE live posterior - 85 % of them after the first
-    // E-step of a separable experiment, 99 % once it has converged - is described by its 8-byte code; only the rows of the others
-    // travel, in a list of at most rows_pad / 4 per rank (beyond that: the whole table, as until round 6).  G <= 64 (the codes exist).
+    // Compact exchange of the posterior rows (gather_posteriors): a barcode with ONE live posterior - 82 % of them on the converged 200k x 100k x 64
+    // experiment - is described by its 8-byte code; only the rows of the others - and of those only the ones that differ from what
+    // was sent last (d_post_sent) - travel, in a list of at most rows_pad / 4 per rank (beyond that: the whole table, as until round 6).  G <= 64 (the codes exist).
     // DEMUXALOT_AMD_EXCHANGE_COMPACT=0 switches it off, =<n> sets the capacity to n rows (tests: the overflow path).
     c->post_compact_words = 0;
     c->post_compact_cap = 0;
