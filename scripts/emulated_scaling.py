@@ -60,6 +60,7 @@ def main():
     ap.add_argument('--exchange', default='', help="DEMUXALOT_AMD_EXCHANGE: '' (default: variant-sharded M-step) | reduce_scatter | allreduce")
     ap.add_argument('--workload', default='em_200k_100k_64', help='a workload of bench.py; with --kinds weak the whole workload is one rank\'s '
                     'share (em_130k_650k_128_doublets = one rank of BASELINE.json configs[4] on 8 GPUs)')
+    ap.add_argument('--incremental', type=int, default=1, help="0: every M-step a full pass, as bench.py's headline regions run it (the library's default is 1)")
     args = ap.parse_args()
     import bench
     B, S, G, dp, seed = bench.WORKLOADS[args.workload]
@@ -68,7 +69,7 @@ def main():
     pen = Demultiplexer._doublet_penalties(G, dp)
     counts = np.bincount(whole.compressed_cb, minlength=B)
     out = {'workload': args.workload, 'link_gbytes_per_s': args.link_gbps, 'latency_us': args.latency_us, 'steps': args.steps,
-           'exchange': args.exchange or 'variant-sharded M-step (default)', 'runs': []}
+           'exchange': args.exchange or 'variant-sharded M-step (default)', 'incremental_mstep': bool(args.incremental), 'runs': []}
     if args.exchange:
         os.environ['DEMUXALOT_AMD_EXCHANGE'] = args.exchange
     base = {}
@@ -88,6 +89,7 @@ def main():
                     ctx.set_estep_mode(mode)
                     ctx.set_exact_additions(mode == 'exact')
                     ctx.set_mstep_tiles('always')  # as bench.py: the tile-major records are built during the warm-up
+                    ctx.set_mstep_incremental(bool(args.incremental))
                     if n > 1:
                         ctx.comm_init_emulated(0, n, args.link_gbps, args.latency_us, reduce_dtype=wire)
                     ctx.set_problem(problem.n_barcodes, problem.n_variants, G, problem.variant_id, problem.compressed_cb, problem.p_base_wrong, problem.v2snp)
