@@ -78,6 +78,7 @@ SIGNATURES = {
     'dmx_reset_timings': (c_int, [_P]),
     'dmx_set_phase_timers': (c_int, [_P, c_int]),
     'dmx_set_logits_needed': (c_int, [_P, c_int]),
+    'dmx_set_lean_memory': (c_int, [_P, c_int]),
     'dmx_device_bytes': (c_int, [_P, POINTER(c_int64)]),
     'dmx_trim_cache': (c_int, [_P, POINTER(c_int64)]),
     'dmx_release_problem': (c_int, [_P]),

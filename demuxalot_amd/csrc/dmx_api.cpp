@@ -295,6 +295,13 @@ int dmx_set_coarse_pass(dmx_ctx *c, int coarse)
     return 0;
 }
 
+int dmx_set_lean_memory(dmx_ctx *c, int lean)
+{
+    if (!c) return fail(DMX_ERR_INVALID, "null context");
+    c->lean_memory = lean != 0;
+    return 0;
+}
+
 int dmx_set_guard_adaptive(dmx_ctx *c, int adaptive)
 {
     if (!c) return fail(DMX_ERR_INVALID, "null context");

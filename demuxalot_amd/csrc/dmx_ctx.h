@@ -87,6 +87,7 @@ struct dmx_ctx {
     bool coarse_ready = false;
     bool prob16_valid = false;           // ... and it holds the current d_prob
     int coarse_pass = 1;                 // dmx_set_coarse_pass
+    int lean_memory = 0;                 // dmx_set_lean_memory: the tile-major E-step stream goes once the coarse pass's records are built from it
     bool logits_needed = true;           // dmx_set_logits_needed: the last E-step of a dmx_em / dmx_run_iterations call keeps its logits readable
     bool logits_readable = true;         // the last E-step's logits are the fine pass's / the exact kernel's (dmx_get_logits, dmx_get_block)
     float p_clip_lo = 0.0f;              // lower clip of the P-step that produced d_prob (0: a caller's table, dmx_set_probs)

@@ -210,8 +210,9 @@ int ensure_full_addition(dmx_ctx *c)
 // again, of the table it finds.
 bool coarse_capable(const dmx_ctx *c, int with_doublets, float lo)
 {
+    // (its records are there, or can be built from the tile-major stream: dmx_set_lean_memory releases that one behind the build)
     return c->coarse_pass && c->estep_mode == DMX_ESTEP_GUARDED && !with_doublets && c->K > 16 && c->K <= 128 && c->tiled_estep && c->n_bins > 0 &&
-           lo >= 6.2e-5f && ((unsigned long long)c->prob_rows + 1ull) * (unsigned long long)c->G * 4ull < (1ull << 32);
+           (c->coarse_ready || c->d_tile_stream != nullptr) && lo >= 6.2e-5f && ((unsigned long long)c->prob_rows + 1ull) * (unsigned long long)c->G * 4ull < (1ull << 32);
 }
 
 // the table as binary16 + the all-zero row the padding calls gather (EstepArgs::prob16)
@@ -320,6 +321,7 @@ int prepare_dictionary(dmx_ctx *c, bool pairs, dmx::EstepArgs &a, int *form)
     const int G = c->G;
     const long long K = c->K, rows = c->prob_rows;
     const bool block_form = pairs && K > dmx::DICT_LANE_K;  // wide doublet tables: workgroup per barcode
+    if (a.call_rows == nullptr) return 0;  // (dmx_set_lean_memory: the form's row array was released)
     if (!block_form && (K > dmx::DICT_LANE_K || rows >= (1 << 24) || a.pairs_bytes == 0)) return 0;  // singlet tables beyond 256: the direct forms; 24-bit row x pitch; 32-bit record offsets
     if (block_form && (size_t)G * 72 + 9 * 1024 > 160 * 1024) return 0;  // the code rows of a chunk must fit the LDS
     if (G > 1024) return 0;  // widest k_build_dict instantiation (ensure_options refuses such runs anyway)
@@ -452,6 +454,11 @@ int run_estep(dmx_ctx *c, int with_doublets, bool with_prior, int prior_dtype, f
     a.dtab_pitch = 0;
     a.dict = nullptr;
     a.codes = nullptr;
+    if (c->lean_memory && with_doublets && c->d_tile_stream != nullptr && !c->coarse_ready) {
+        // (dmx_set_lean_memory: the tile-major schedule is the singlet runs'; a run with doublets never reads its stream - 6.4 GB of configs[4])
+        dev_free(c, &c->d_tile_stream, (size_t)c->n_pairs);
+        a.tile_stream = nullptr;
+    }
     TimerSpan ev{nullptr, nullptr};
     SpanGuard ev_guard{c, &ev};
     timer_begin(c, DMX_T_ESTEP, &ev);
@@ -517,6 +524,15 @@ int run_estep(dmx_ctx *c, int with_doublets, bool with_prior, int prior_dtype, f
                 HIP_TRY(dmx::launch_build_coarse_stream(c->stream, c->d_tile_stream, c->d_bin_ptr, c->n_bins, a.prob_bytes, cpg, c->d_coarse_bin_ptr, c->d_coarse_stream,
                                                         c->d_bin_rows, c->bin_rows_cap, c->d_log2_keep));
                 c->coarse_ready = true;
+                // dmx_set_lean_memory: the tile-major stream has done its last job (the block returns to the context's cache behind the build,
+                // stream-ordered); the fine level is the barcode-major tolerance kernel from here on (below)
+                if (c->lean_memory) {
+                    dev_free(c, &c->d_tile_stream, (size_t)c->n_pairs);
+                    // ... and the compact row array of the dictionary form with it (4 bytes per call): an E-step that keeps its logits on the
+                    // prior table then runs the tolerance kernel too, the incremental M-step reads the rows from the records
+                    dev_free(c, &c->d_call_rows, ((size_t)c->n_pairs + dmx::CALL_PAD_PAIRS) * 2);
+                    a.call_rows = nullptr;
+                }
             }
             if (allow_coarse) DMX_TRY(ensure_prob16(c));
             HIP_TRY(dmx::launch_guard_begin(c->stream, c->d_guard_count, c->B, c->K, c->guard_adaptive, capable, allow_coarse));
@@ -547,6 +563,8 @@ int run_estep(dmx_ctx *c, int with_doublets, bool with_prior, int prior_dtype, f
                 HIP_TRY(dmx::launch_estep(c->stream, coarse, false));
             }
             a.direct = c->d_guard_count + dmx::GS_SKIP_FINE;
+            if (c->d_tile_stream == nullptr) a.n_bins = 0;  // (released: the fine level walks the barcode-major records, a barcode per wavefront)
+            a.tile_stream = c->d_tile_stream;
             HIP_TRY(dmx::launch_estep(c->stream, a, with_doublets != 0));
             HIP_TRY(dmx::launch_guard_compact(c->stream, c->d_guard_count, c->d_guard_sub, c->guard_sub_cap, c->d_guard_list, c->d_bc_order, c->B));
             dmx::EstepArgs redo = a;
@@ -560,6 +578,7 @@ int run_estep(dmx_ctx *c, int with_doublets, bool with_prior, int prior_dtype, f
             c->guard_rows_total += c->B;
             c->guard_ran = true;
         } else {
+            if (c->d_tile_stream == nullptr) a.n_bins = 0;
             HIP_TRY(dmx::launch_estep(c->stream, a, with_doublets != 0));
         }
     }
@@ -644,7 +663,7 @@ int run_mstep(dmx_ctx *c, float power)
     // which sums in place.)
     const bool own_sums = !mshard && (!dist || c->sliced);
     const bool can_go_incremental = c->mstep_incremental && c->mstep_tiles == 1 && !c->exact_additions && c->G <= 64 && c->n_csc > 0 && power > 0.0f &&
-                                    own_sums && c->d_call_rows != nullptr && c->d_item_variant != nullptr;
+                                    own_sums && c->d_call_pairs != nullptr && c->d_item_variant != nullptr;
     if (can_go_incremental && !c->incr_heavy && c->n_mt == 0 && c->d_incr_state != nullptr &&
         (c->msteps_done == 4 || c->msteps_done == 16 || c->msteps_done == 64)) {
         unsigned full_passes = 0;
@@ -690,7 +709,7 @@ int run_mstep(dmx_ctx *c, float power)
     // bit and the incremental M-step builds on them: one full pass of 0.7 ms, then delta passes, instead of 0.7 ms per M-step.
     // (dmx_set_mstep_tiles(ctx, 0) or dmx_set_mstep_incremental(ctx, 0): the float64 work-item form, as before.)
     bool fixed_items = !a.tiles_done && c->mstep_tiles != 0 && c->mstep_incremental && !c->exact_additions && c->G <= 64 && c->n_csc > 0 &&
-                       power > 0.0f && own_sums && c->d_call_rows != nullptr && c->d_item_variant != nullptr;
+                       power > 0.0f && own_sums && c->d_call_pairs != nullptr && c->d_item_variant != nullptr;
     if (fixed_items) {
         DMX_TRY(dmx::plan_mstep_shifts(c));
         fixed_items = c->d_mt_shift_v != nullptr;
@@ -701,7 +720,7 @@ int run_mstep(dmx_ctx *c, float power)
     const bool sharded_incr = a.tiles_done && c->mstep_incremental == 1 && mshard && c->d_mt_shift_v != nullptr && a.out32 == c->d_add && c->G <= 64 &&
                               c->d_item_variant != nullptr && c->rows_total > 0;
     const bool incremental = sharded_incr || ((a.tiles_done || fixed_items) && c->mstep_incremental && own_sums && c->d_mt_shift_v != nullptr &&
-                                              c->d_call_rows != nullptr);
+                                              c->d_call_pairs != nullptr);
     const long long incr_rows = sharded_incr ? c->rows_total : c->B;
     dmx::MIncrArgs incr{};
     if (incremental) {

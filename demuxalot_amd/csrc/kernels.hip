@@ -2529,7 +2529,8 @@ __global__ __launch_bounds__(256) void k_mincr_delta(MstepArgs a, MIncrArgs x)
                 keep = __uint_as_float(d.y);
             } else if (mine) {
                 keep = x.pairs[p0 + (ci >> 1)].keep[ci & 1];
-                row = x.call_rows[2 * p0 + ci];
+                // (the compact row array, or - dmx_set_lean_memory has released it - the record's byte offset into the table)
+                row = x.call_rows != nullptr ? x.call_rows[2 * p0 + ci] : x.pairs[p0 + (ci >> 1)].row_off[ci & 1] / (4u * (unsigned)G);
                 if (x.row_variant != nullptr) row = (unsigned)x.row_variant[row];
             }
             const int shift = mine ? (int)x.shift_v[row] : 0;

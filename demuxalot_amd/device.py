@@ -39,7 +39,8 @@ class DeviceContext:
         (dmx_set_estep_schedule); DEMUXALOT_AMD_ESTEP_DICT = never | auto | always (dmx_set_estep_dictionary);
         DEMUXALOT_AMD_ESTEP_PACKED = never | auto | always (dmx_set_estep_packing); DEMUXALOT_AMD_COARSE_PASS = 1 | 0: the guarded
         mode's binary16 pass for E-steps whose logits nobody reads (dmx_set_coarse_pass; default on); DEMUXALOT_AMD_MSTEP_INCREMENTAL
-        = 1 | 0: the tile-major M-step keeps its integer sums and adds differences (dmx_set_mstep_incremental; default on)."""
+        = 1 | 0: the tile-major M-step keeps its integer sums and adds differences (dmx_set_mstep_incremental; default on);
+        DEMUXALOT_AMD_LEAN = 0 | 1: release the fine pass's copy of the E-step records once the coarse pass's are built (dmx_set_lean_memory)."""
         mode = os.environ.get('DEMUXALOT_AMD_ESTEP', '') or DEFAULT_ESTEP_MODE
         assert mode in ('exact', 'fast', 'guarded'), f'DEMUXALOT_AMD_ESTEP={mode!r}: exact, fast or guarded'
         self.set_estep_mode(mode)
@@ -52,6 +53,7 @@ class DeviceContext:
         self.set_estep_packing(os.environ.get('DEMUXALOT_AMD_ESTEP_PACKED', 'auto'))
         self.set_coarse_pass(os.environ.get('DEMUXALOT_AMD_COARSE_PASS', '1') != '0')
         self.set_mstep_incremental(os.environ.get('DEMUXALOT_AMD_MSTEP_INCREMENTAL', '1') != '0')
+        self.set_lean_memory(os.environ.get('DEMUXALOT_AMD_LEAN', '0') not in ('', '0'))
         self.set_phase_timers(False)
         self.set_logits_needed(True)
 
@@ -464,6 +466,11 @@ class DeviceContext:
         """Guarded mode: E-steps whose logits nobody reads may take the coarse pass (binary16 genotype table; default on;
         'always': every E-step, single ones included - their logits then carry the coarse bound; include/demux_hip.h: dmx_set_coarse_pass)."""
         check(self._lib.dmx_set_coarse_pass(self._h, 2 if coarse == 'always' else int(bool(coarse))))
+
+    def set_lean_memory(self, lean):
+        """Memory before speed for the E-steps whose logits are kept: the tile-major copy of the E-step records (16 of 67 bytes per call) is
+        released once the coarse pass's records are built from it (include/demux_hip.h: dmx_set_lean_memory; default off)."""
+        check(self._lib.dmx_set_lean_memory(self._h, int(bool(lean))))
 
     def set_mstep_incremental(self, incremental):
         """Default mode, tile-major M-step: update the kept integer sums for the barcodes whose posteriors changed instead of summing every

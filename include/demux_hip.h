@@ -213,6 +213,15 @@ int dmx_get_guard_stats(dmx_ctx *ctx, int64_t *redone_last, int64_t *redone_tota
  * dmx_get_logits / dmx_get_block(DMX_LOGITS) fail (DMX_ERR_INVALID) until an E-step has kept its logits again (dmx_estep, or a call
  * with needed = 1); posteriors, assignments and the reductions are available as ever.  Default 1. */
 int dmx_set_logits_needed(dmx_ctx *ctx, int needed);
+/* Memory before speed for the E-steps whose logits ARE kept (default 0).  A problem large enough for the tile-major E-step schedule holds its
+ * E-step records three times: barcode-major (16 bytes per call), in the order the bins consume them for the fine pass (16) and as the
+ * coarse pass's records (8), built from the second at the first E-step that may take the coarse pass.  With lean = 1 the second copy is
+ * released as soon as the third exists (dmx_get_device_bytes: 67 -> 51 bytes per call at 200k x 100k x 64): the coarse pass is untouched, the
+ * E-steps that keep their logits - the last one of a dmx_em call by default, dmx_estep - run the tolerance kernel on the barcode-major
+ * records (1.5 instead of 1.3 ms at that size), the guard and its exact redo as ever.  Applies to problems installed afterwards and to the
+ * resident one if its coarse records are not built yet; a communicator attached AFTER the release re-bases the table rows and leaves such a
+ * problem without the tile-major schedule altogether (install it again). */
+int dmx_set_lean_memory(dmx_ctx *ctx, int lean);
 /* Inside the guarded mode the library chooses per E-step, on the device, between the coarse pass (genotype table as binary16, for
  * E-steps whose logits nobody reads), the fine pass and the exact kernel on every barcode, and per M-step between the full and the
  * incremental pass; the switches that pin those choices, the controller's read-outs, the emulated wire and the device self-tests

@@ -63,6 +63,52 @@ def test_em_call_takes_the_coarse_pass_for_all_but_its_last_estep(separable):
         print(f'{name}: posteriors within {dev:.3g}, logits within {d_logit:.3g} of the exact call; levels {out[name][3]}; guard {out[name][4]}')
 
 
+def test_lean_memory_releases_the_fine_pass_records(separable):
+    """dmx_set_lean_memory(1): the tile-major copy of the E-step records - 16 bytes per (padded) call, what the fine pass reads - and the
+    dictionary form's row array (4) are released once the coarse pass's records are built.  The coarse E-steps are untouched; the E-steps that keep their logits (the last one of
+    the call, a dmx_estep behind it) run the tolerance kernel on the barcode-major records: same contract against the exact mode, and the
+    context holds that much less."""
+    from demuxalot_amd.device import DeviceContext
+    p = separable
+    pen = np.zeros(p.n_genotypes, dtype=np.float32)
+    out = {}
+    for name, mode, lean in (('exact', 'exact', False), ('default', 'guarded', False), ('lean', 'guarded', True)):
+        ctx = DeviceContext(0)
+        try:
+            ctx.set_estep_mode(mode)
+            ctx.set_exact_additions(mode == 'exact')
+            ctx.set_lean_memory(lean)
+            _install(ctx, p)
+            installed = ctx.device_bytes()
+            ctx.reset_timings()
+            logits, probs, addition = ctx.em(6, 0.01, pen, with_doublets=False)
+            levels = ctx.guard_levels()
+            logits_1, probs_1 = ctx.estep(pen, with_doublets=False)   # (the resident problem again: an E-step that keeps its logits)
+            out[name] = (logits, probs, addition, levels, installed, ctx.device_bytes(), logits_1, probs_1, ctx.guard_levels())
+        finally:
+            ctx.close()
+    assert out['default'][4] == out['lean'][4]  # (the installs are the same size: the release comes with the first coarse E-step)
+    saved = out['default'][5] - out['lean'][5]   # the tile-major stream (16 bytes per padded call) + the dictionary form's row array (4)
+    assert 20 * len(p.variant_id) <= saved <= 20 * (len(p.variant_id) + 8 * p.n_barcodes) + 8192, (saved, len(p.variant_id))
+    # the call's M-steps follow coarse E-steps in both runs - the incremental M-step's delta passes read the table rows from the records
+    # where the row array is gone: the same additions, bit for bit
+    from tests import fixture_io as fio
+    fio.assert_bitwise(out['lean'][2], out['default'][2], 'additions of the lean run')
+    lv = out['lean'][3]
+    assert lv['coarse_steps'] == 5 and lv['level'] in (1, 2), lv      # E-steps 0 .. 4 coarse as ever; the last one: the fine level or direct
+    assert out['lean'][8]['level'] in (1, 2), out['lean'][8]
+    n_calls_v = np.bincount(p.variant_id, minlength=p.n_variants).astype(np.float64)[:, None]
+    for name in ('default', 'lean'):
+        dev = check_contract(out[name][1], out['exact'][1], f'{name} vs exact after 6 iterations')
+        dev_1 = check_contract(out[name][7], out['exact'][7], f'{name} vs exact, the E-step behind the call')
+        d_add = np.abs(out[name][2].astype(np.float64) - out['exact'][2])
+        assert (d_add <= n_calls_v * 2.00001e-5 + 2.0 ** -22 * out['exact'][2]).all()
+        d_logit = max(np.abs(out[name][0] - out['exact'][0]).max(), np.abs(out[name][6] - out['exact'][6]).max())
+        assert d_logit <= 2e-3, (name, d_logit)
+        print(f'{name}: posteriors within {dev:.3g} / {dev_1:.3g}, logits within {d_logit:.3g}; device bytes {out[name][4]} -> {out[name][5]}; levels {out[name][3]}')
+    print(f'released: {saved} bytes = {saved / len(p.variant_id):.2f} per call')
+
+
 def test_coarse_pass_gives_way_where_it_proves_too_little(siblings):
     """Sibling donors, 50 calls per barcode: the coarse guard (D ~ 0.03) flags most barcodes, the fine one a fifth.  The first
     admissible E-step takes the coarse pass and finds that out; the device then prices  C + f_coarse E  against  F + f_fine E  and E
