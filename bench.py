@@ -649,6 +649,7 @@ def compact_line(full, details_path=None):
         'cold_start_5it_ms_per_iteration': (full.get('cold_start_5it') or {}).get('ms_per_step'),
         'predict_barcodes_per_s': full.get('predict_barcodes_per_s'),
         'device_bytes_per_call': (full.get('device_bytes') or {}).get('per_call_without_the_results'),
+        'lean_memory': ({k: full['lean_memory'].get(k) for k in ('device_bytes_per_call', 'ms_per_step')} if full.get('lean_memory') else None),
         'parity_timed': full.get('parity_timed'),
         'parity_on_sample': full.get('parity_on_sample'),
     }
@@ -1038,6 +1039,27 @@ def main():
         predict['note'] = ('P-step + E-step on the table without beta addition (predict_posteriors, EM iteration 0); estep_ms includes '
                            'building the dictionary; where the dictionary form runs the pass is bit-identical to the reference in every mode but `fast`')
 
+    # dmx_set_lean_memory (default off): the fine pass's copy of the E-step records and the dictionary form's row array released - the
+    # footprint and the same timed region on what is left.  The last region on this problem: the release is for good.
+    lean_region = None
+    if world == 1 and not args.timed_only and default_mode == 'guarded' and dp == 0:
+        phase('lean memory: timed region')
+        ctx.set_addition(None)
+        ctx.probs_from_betas(0.01, fetch=False)
+        ctx.estep(pen, with_doublets=False, fetch_logits=False, fetch_probs=False)
+        if args.mstep == 'auto':
+            ctx.set_msteps_expected(args.warmup + args.steps)
+        bytes_before = ctx.device_bytes()
+        ctx.set_lean_memory(True)
+        lean = timed_region(ctx, plane, args.steps, args.warmup)
+        lean_bytes = ctx.device_bytes()
+        ctx.set_lean_memory(False)
+        if lean_bytes < bytes_before:  # (a shape without the coarse pass has nothing to release)
+            lean_region = {'ms_per_step': lean['ms_per_step'], 'estep_passes': lean.get('estep_passes'),
+                           'device_bytes_per_call': (lean_bytes - 8 * B * K) / max(1, N), 'device_bytes': lean_bytes,
+                           'note': 'dmx_set_lean_memory(1) / DEMUXALOT_AMD_LEAN=1: the same timed region after the tile-major E-step stream and the dictionary form\'s row '
+                                   'array were released (E-steps that keep their logits then run the tolerance kernel on the barcode-major records)'}
+
     hard = None
     if world == 1 and not args.no_hard_workload and not args.flat_genotypes and N <= 200_000_000:
         phase('hard workloads')
@@ -1121,6 +1143,8 @@ def main():
                                           + clock_warmup.__doc__.split('\n\n')[0].replace('\n    ', ' ') + '  NOT the headline: `value` is W warm-up iterations + K timed ones, nothing else')
         if cold_region:
             out['cold_start_5it'] = cold_region
+        if lean_region:
+            out['lean_memory'] = lean_region
         if after_idle_region:
             out['after_idle'] = {k: after_idle_region[k] for k in ('value', 'ms_per_step', 'em_iterations_per_s', 'ms_per_step_with_phase_timers', 'kernel_ms')}
             out['after_idle']['note'] = ('the same timed region - W warm-up iterations, K timed ones - begun 0.5 s after the device was last busy, without the clock warm-up: what the first '

@@ -297,8 +297,12 @@ int dmx_set_coarse_pass(dmx_ctx *c, int coarse)
 
 int dmx_set_lean_memory(dmx_ctx *c, int lean)
 {
-    if (!c) return fail(DMX_ERR_INVALID, "null context");
+    DMX_TRY(bind(c));
     c->lean_memory = lean != 0;
+    if (c->lean_memory && c->coarse_ready) {  // the resident problem's coarse records exist: what run_estep would have released behind their build
+        dev_free(c, &c->d_tile_stream, (size_t)c->n_pairs);
+        dev_free(c, &c->d_call_rows, ((size_t)c->n_pairs + dmx::CALL_PAD_PAIRS) * 2);
+    }
     return 0;
 }
 

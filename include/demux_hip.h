@@ -218,9 +218,10 @@ int dmx_set_logits_needed(dmx_ctx *ctx, int needed);
  * coarse pass's records (8), built from the second at the first E-step that may take the coarse pass.  With lean = 1 the second copy is
  * released as soon as the third exists (dmx_get_device_bytes: 67 -> 51 bytes per call at 200k x 100k x 64): the coarse pass is untouched, the
  * E-steps that keep their logits - the last one of a dmx_em call by default, dmx_estep - run the tolerance kernel on the barcode-major
- * records (1.5 instead of 1.3 ms at that size), the guard and its exact redo as ever.  Applies to problems installed afterwards and to the
- * resident one if its coarse records are not built yet; a communicator attached AFTER the release re-bases the table rows and leaves such a
- * problem without the tile-major schedule altogether (install it again). */
+ * records (1.5 instead of 1.3 ms at that size), the guard and its exact redo as ever; the dictionary form's row array (4 bytes per call) goes
+ * with it: an E-step on the prior table that keeps its logits runs that kernel too.  Applies to the resident problem (at once if its coarse
+ * records exist, else behind their build) and to those installed afterwards; lean = 0 keeps what is still there.  A communicator attached
+ * AFTER the release re-bases the table rows and leaves such a problem without the tile-major schedule altogether (install it again). */
 int dmx_set_lean_memory(dmx_ctx *ctx, int lean);
 /* Inside the guarded mode the library chooses per E-step, on the device, between the coarse pass (genotype table as binary16, for
  * E-steps whose logits nobody reads), the fine pass and the exact kernel on every barcode, and per M-step between the full and the
