@@ -466,6 +466,9 @@ int run_estep(dmx_ctx *c, int with_doublets, bool with_prior, int prior_dtype, f
     // The dictionary form is exact and faster than the fine pass, but not than the COARSE pass (200k x 100k x 64: 1.1 ms with its
     // dictionary build against 0.75): an E-step whose logits nobody reads - the first of a dmx_em call of several iterations - takes
     // the coarse pass like the ones behind it (its records are built here instead of one E-step later).
+    // dmx_set_lean_memory has released the tile-major stream: the tolerance kernels of this E-step walk the coarse pass's records where they
+    // exist (k_estep_tiled_fine8: the float32 table, float64 sums), else the barcode-major ones (n_bins = 0 where they launch)
+    const bool fine8 = c->d_tile_stream == nullptr && c->coarse_ready && !with_doublets && a.n_bins > 0 && c->K > 16 && c->K <= 128;
     const bool coarse_first = c->estep_mode == DMX_ESTEP_GUARDED && !logits_kept && c->guard_adaptive && coarse_capable(c, with_doublets, c->p_clip_lo) &&
                               a.n_bins > 0 && c->dict_mode == 1;
     if (!coarse_first) DMX_TRY(prepare_dictionary(c, with_doublets != 0, a, &form));  // part of the E-step's time
@@ -537,6 +540,7 @@ int run_estep(dmx_ctx *c, int with_doublets, bool with_prior, int prior_dtype, f
             if (allow_coarse) DMX_TRY(ensure_prob16(c));
             HIP_TRY(dmx::launch_guard_begin(c->stream, c->d_guard_count, c->B, c->K, c->guard_adaptive, capable, allow_coarse));
             a.guard = 1;
+            if (fine8) a.guard_per_call = dmx::guard_per_call_fine8(dmx::coarse_calls_per_gather((int)c->K));  // (the coarse guard's estimate of the fine level reads it too)
             a.order_direct = c->d_bc_order;
             a.guard_main_coarse = 0;
             a.guard_alt_per_call = capable ? dmx::GUARD_PER_CALL_COARSE : 0.0f;
@@ -563,9 +567,20 @@ int run_estep(dmx_ctx *c, int with_doublets, bool with_prior, int prior_dtype, f
                 HIP_TRY(dmx::launch_estep(c->stream, coarse, false));
             }
             a.direct = c->d_guard_count + dmx::GS_SKIP_FINE;
-            if (c->d_tile_stream == nullptr) a.n_bins = 0;  // (released: the fine level walks the barcode-major records, a barcode per wavefront)
             a.tile_stream = c->d_tile_stream;
+            if (c->d_tile_stream == nullptr) {  // (released: the fine level walks the coarse pass's records, or a barcode per wavefront the barcode-major ones)
+                if (c->coarse_ready && !with_doublets && a.n_bins > 0 && c->K > 16 && c->K <= 128) {
+                    a.coarse_stream = c->d_coarse_stream;
+                    a.coarse_bin_ptr = c->d_coarse_bin_ptr;
+                    a.log2_keep = c->d_log2_keep;
+                    a.prob16 = nullptr;
+                    a.guard_per_call = dmx::guard_per_call_fine8(dmx::coarse_calls_per_gather((int)c->K));  // (also where the release came with this E-step)
+                } else {
+                    a.n_bins = 0;
+                }
+            }
             HIP_TRY(dmx::launch_estep(c->stream, a, with_doublets != 0));
+            a.coarse_stream = nullptr;  // (the redo below is the exact kernel's)
             HIP_TRY(dmx::launch_guard_compact(c->stream, c->d_guard_count, c->d_guard_sub, c->guard_sub_cap, c->d_guard_list, c->d_bc_order, c->B));
             dmx::EstepArgs redo = a;
             redo.direct = c->d_guard_count + dmx::GS_DIRECT;
@@ -578,7 +593,15 @@ int run_estep(dmx_ctx *c, int with_doublets, bool with_prior, int prior_dtype, f
             c->guard_rows_total += c->B;
             c->guard_ran = true;
         } else {
-            if (c->d_tile_stream == nullptr) a.n_bins = 0;
+            if (c->d_tile_stream == nullptr) {
+                if (fine8 && a.fast) {  // (the tolerance mode without the guard)
+                    a.coarse_stream = c->d_coarse_stream;
+                    a.coarse_bin_ptr = c->d_coarse_bin_ptr;
+                    a.log2_keep = c->d_log2_keep;
+                } else {
+                    a.n_bins = 0;
+                }
+            }
             HIP_TRY(dmx::launch_estep(c->stream, a, with_doublets != 0));
         }
     }

@@ -190,6 +190,12 @@ constexpr unsigned GS_UNKNOWN = 0xFFFFFFFFu;
 // so its error cancels in the posteriors and in every difference of two logits; in a logit served by a coarse E-step (dmx_set_coarse_pass(2)) it
 // is one more v_log_f32 error per call, 1.06e-5.  4.934e-4 + 1.06e-5 = 5.04e-4, rounded up (round 5: 4.94e-4, 0.1 % of headroom).
 constexpr float GUARD_PER_CALL_COARSE = 5.1e-4f;
+// The fine pass on the coarse pass's records (kernels.hip: k_estep_tiled_fine8; the tile-major stream released: dmx_set_lean_memory): float32 table,
+// float64 sums, a term keep (p + r): 4 x 2^-24 relative against the reference's float32 term (r's division, the sum's rounding, the
+// reference's two), the slot tag in one r of a block's 8 / cpg per batch (2^-19 of r <= 1.91e-6 of the term), the product's roundings and
+// the mantissa's log as GUARD_PER_CALL prices them.  Every block of a barcode's batch carries exactly one tagged r and the guard counts
+// padded calls, so the tag is charged to one call in 8 / cpg.
+inline float guard_per_call_fine8(int cpg) { return 1.91e-6f / (float)(8 / cpg) + 4.0f * 6.0e-8f + 7.0e-8f; }
 constexpr float GUARD_ACCUM_F32 = 6.0e-8f;  // 2^-24, rounded up: per float32 addition of the running sum (estep_epilogue.h)
 constexpr int GUARD_SLOTS = 256;   // hashed counters behind the state words: barcodes flagged by a guard whose pass does not run (a direct
                                    // E-step: both; a fine one: the coarse guard's; a coarse one: the fine guard's) - a set per guard

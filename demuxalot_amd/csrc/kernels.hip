@@ -941,9 +941,15 @@ struct CoarseShape {
 // dword per lane for BPR batches, and every field reaches the arithmetic as a DPP row broadcast.  The slot tag of a batch sits in the
 // low 4 bits of its r0 (2^-19 of r: priced).  Padding calls - and calls with keep = 0 - gather the all-zero row behind the table with
 // r = floor: p + r = floor exactly.  Every bin starts at a record (coarse_bin_ptr).
-template <int CPG, typename OnGroup>
+// F32 (k_estep_tiled_fine8): the same walk on the float32 table - a gather is 8 bytes per lane, the sums p + r are plain additions, and a
+// batch's product goes into a float64 sum through its mantissa and exponent (FineSum), as the fine pass on the tile-major stream does.
+struct FineSum {
+    double lo, hi;   // sums of log2 of the products' mantissas
+    int elo, ehi;    // ... and of their exponents (exact)
+};
+template <int CPG, bool F32, typename Sum, typename OnGroup>
 static __device__ __forceinline__ void coarse_walk(const unsigned *__restrict__ stream, int n_batches, __amdgpu_buffer_rsrc_t rsrc,
-                                                   unsigned lane_off, int lane, CoarseSum &lacc, OnGroup on_group)
+                                                   unsigned lane_off, int lane, Sum &lacc, OnGroup on_group)
 {
     using S = CoarseShape<CPG>;
     constexpr int GPB = S::GPB, BPR = S::BPR, DD = S::DD, T = S::T, GA = S::GA, DG = S::DG;
@@ -955,12 +961,15 @@ static __device__ __forceinline__ void coarse_walk(const unsigned *__restrict__ 
         return __builtin_nontemporal_load(&words[(size_t)dc * (CPG * 16)]);
     };
     struct Gathers {
-        unsigned h[GPB];  // gather q: binary16 probabilities of genotypes 2 i, 2 i + 1 of this block's call of gather q
+        std::conditional_t<F32, u32x2_t, unsigned> h[GPB];  // gather q: probabilities of genotypes 2 i, 2 i + 1 of this block's call of gather q (binary16 / float32)
     };
     auto issue = [&](unsigned w, auto sel, Gathers &g) {
         constexpr int B0 = decltype(sel)::value * 2 * GPB;
 #pragma unroll
-        for (int q = 0; q < GPB; q++) g.h[q] = __builtin_amdgcn_raw_buffer_load_b32(rsrc, (int)(row_bcast(w, B0 + q) + lane_off), 0, 0);
+        for (int q = 0; q < GPB; q++) {
+            if constexpr (F32) g.h[q] = __builtin_amdgcn_raw_buffer_load_b64(rsrc, (int)(row_bcast(w, B0 + q) + lane_off), 0, 0);
+            else g.h[q] = __builtin_amdgcn_raw_buffer_load_b32(rsrc, (int)(row_bcast(w, B0 + q) + lane_off), 0, 0);
+        }
     };
     auto consume = [&](int k, unsigned w, auto sel, const Gathers &g) {
         constexpr int R0 = decltype(sel)::value * 2 * GPB + GPB;
@@ -971,9 +980,14 @@ static __device__ __forceinline__ void coarse_walk(const unsigned *__restrict__ 
         auto sums = [&](auto q, float &s_lo, float &s_hi) {
             constexpr int Q = decltype(q)::value;
             const float r = __uint_as_float(row_bcast(w, R0 + Q));
-            const unsigned h = g.h[Q];  // (named here: an asm operand does not capture for the lambda)
-            asm("v_fma_mix_f32 %0, %1, 1.0, %2 op_sel_hi:[1,0,0]" : "=v"(s_lo) : "v"(h), "v"(r));
-            asm("v_fma_mix_f32 %0, %1, 1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(s_hi) : "v"(h), "v"(r));
+            if constexpr (F32) {
+                s_lo = __uint_as_float(g.h[Q].x) + r;
+                s_hi = __uint_as_float(g.h[Q].y) + r;
+            } else {
+                const unsigned h = g.h[Q];  // (named here: an asm operand does not capture for the lambda)
+                asm("v_fma_mix_f32 %0, %1, 1.0, %2 op_sel_hi:[1,0,0]" : "=v"(s_lo) : "v"(h), "v"(r));
+                asm("v_fma_mix_f32 %0, %1, 1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(s_hi) : "v"(h), "v"(r));
+            }
         };
         float prod_lo, prod_hi;
         sums(std::integral_constant<int, 0>{}, prod_lo, prod_hi);
@@ -983,8 +997,15 @@ static __device__ __forceinline__ void coarse_walk(const unsigned *__restrict__ 
             prod_lo = prod_lo * s_lo;
             prod_hi = prod_hi * s_hi;
         });
-        lacc.lo += __builtin_amdgcn_logf(prod_lo);  // v_log_f32 = log2 of a product of GPB sums p + r
-        lacc.hi += __builtin_amdgcn_logf(prod_hi);
+        if constexpr (F32) {  // (k_estep_tiled: the mantissa's log2 is within 2 ulp of a value in [-1, 0), the exponent is exact)
+            lacc.elo += __builtin_amdgcn_frexp_expf(prod_lo);
+            lacc.ehi += __builtin_amdgcn_frexp_expf(prod_hi);
+            lacc.lo += (double)__builtin_amdgcn_logf(__builtin_amdgcn_frexp_mantf(prod_lo));
+            lacc.hi += (double)__builtin_amdgcn_logf(__builtin_amdgcn_frexp_mantf(prod_hi));
+        } else {
+            lacc.lo += __builtin_amdgcn_logf(prod_lo);  // v_log_f32 = log2 of a product of GPB sums p + r
+            lacc.hi += __builtin_amdgcn_logf(prod_hi);
+        }
     };
     unsigned w[DD];
     Gathers g[DG];
@@ -1048,7 +1069,7 @@ __global__ __launch_bounds__(256) void k_estep_tiled_coarse(EstepArgs a)
     int cur = 0;  // slot whose sums are in registers, and where it parks them (kept as an address: one v_lshl_add per change of slot, not two)
     CoarseSum *cur_at = &sh_acc[wave][0][lane];
     // genotypes 2 i, 2 i + 1 of the lane's call: one dword of the binary16 row (a pair past G reads into the unused half of the row)
-    coarse_walk<CPG>(stream, n_batches, rsrc, (unsigned)(lane & (CoarseShape<CPG>::LPC - 1)) * 4u, lane, lacc, [&](int, int tag) {
+    coarse_walk<CPG, false>(stream, n_batches, rsrc, (unsigned)(lane & (CoarseShape<CPG>::LPC - 1)) * 4u, lane, lacc, [&](int, int tag) {
         if (tag == cur) return;  // (wave-uniform)
         *cur_at = lacc;
         cur_at = &sh_acc[wave][tag][lane];
@@ -1075,6 +1096,76 @@ __global__ __launch_bounds__(256) void k_estep_tiled_coarse(EstepArgs a)
         // (the float32 partial sums are those of log2(p + r) <= -log2 keep + 1.5e-4: up to 3 |log2_keep| beyond the total's magnitude)
         estep_epilogue<64, A, true>(a, (long long)row, true, out, kk, valid, lane, lane, 0, 2 * (int)(a.pair_ptr[row + 1] - a.pair_ptr[row]),
                                     3.0f * 0.6931472f * fabsf((float)lk) * 1.000001f);
+    }
+}
+
+// ------------------------------------------------------------------------------------
+// E-step, FINE pass on the coarse pass's records (dmx_set_lean_memory: the tile-major stream of k_estep_tiled is gone).  The same walk
+// of the same 8-byte records, the float32 table, float64 sums: a term is keep (p + r) with r = fl(floor / keep) and the slot tag in the
+// low 4 bits of one r in GPB - against the reference's float32 term (two roundings) the sum p + r is off by at most 2^-24 (r) + 2^-24
+// (its own rounding) + 2 x 2^-24 relative, one term in GPB by 2^-19 more (the tag), then the product's roundings and the mantissa's
+// log as in k_estep_tiled (estep_epilogue.h: GUARD_PER_CALL): guard_per_call_fine8.  The sum of log2 keep (EstepArgs::log2_keep, v_log_f32
+// results summed in float64) is the same for every option: it cancels in the posteriors the guard proves; a logit this pass serves
+// carries its error, at most 2 ulp of |log2 keep| per call (8e-8 for keep in [0.5, 1]).
+// ------------------------------------------------------------------------------------
+struct FinePark {
+    double lo, hi;
+};
+template <int CPG>
+__global__ __launch_bounds__(256) void k_estep_tiled_fine8(EstepArgs a)
+{
+    __shared__ FinePark sh_acc[4][TILE_R_MAX][64];
+    const int lane = threadIdx.x & 63;
+    const int K = a.K;
+    const int R = a.bin_rows_cap;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const long long slot_id = (long long)blockIdx.x * 4 + wave;
+    if (guard_stand_back(a)) return;  // another level runs (EstepArgs::direct)
+    if (slot_id >= a.n_bins) return;
+    const long long bin = a.bin_order[slot_id];
+    constexpr int A = CPG == 1 ? 2 : 1;
+    int kk[A];
+    bool valid[A];
+#pragma unroll
+    for (int s = 0; s < A; s++) {
+        valid[s] = lane + 64 * s < K;
+        kk[s] = valid[s] ? lane + 64 * s : K - 1;
+    }
+    for (int r = 0; r < R; r++) sh_acc[wave][r][lane] = FinePark{0.0, 0.0};
+    // (the padding calls' offset is one row behind the table: beyond num_records, a buffer load returns 0 - p + r = r)
+    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void *)a.prob, 0, (int)a.prob_bytes, 0x00020000);
+    const int n_batches = (int)(a.bin_ptr[bin + 1] - a.bin_ptr[bin]);
+    const unsigned *__restrict__ stream = a.coarse_stream + a.coarse_bin_ptr[bin] * (CPG * 16);
+    FineSum lacc{0.0, 0.0, 0, 0};
+    int cur = 0;
+    FinePark *cur_at = &sh_acc[wave][0][lane];
+    auto park = [&]() { *cur_at = FinePark{lacc.lo + (double)lacc.elo, lacc.hi + (double)lacc.ehi}; };
+    coarse_walk<CPG, true>(stream, n_batches, rsrc, (unsigned)(lane & (CoarseShape<CPG>::LPC - 1)) * 8u, lane, lacc, [&](int, int tag) {
+        if (tag == cur) return;  // (wave-uniform)
+        park();
+        cur_at = &sh_acc[wave][tag][lane];
+        const FinePark v = *cur_at;
+        lacc = FineSum{v.lo, v.hi, 0, 0};
+        cur = tag;
+    });
+    park();
+    for (int r = 0; r < R; r++) {
+        const int row = a.bin_rows[bin * R + r];
+        if (row < 0) continue;
+        FinePark v = sh_acc[wave][r][lane];
+#pragma unroll
+        for (int off = 32; off >= CoarseShape<CPG>::LPC; off >>= 1) {  // the blocks' shares of the barcode's calls
+            v.lo += shfl_xor_f64(v.lo, off);
+            v.hi += shfl_xor_f64(v.hi, off);
+        }
+        double out[A];
+        const double lk = a.log2_keep[row];
+#pragma unroll
+        for (int s = 0; s < A; s++) {  // option k = lane + 64 s: genotype k of lane k / 2
+            const double lo = __shfl(v.lo, (lane >> 1) + 32 * s), hi = __shfl(v.hi, (lane >> 1) + 32 * s);
+            out[s] = (((lane & 1) ? hi : lo) + lk) * 0.693147180559945309417232121458176568;
+        }
+        estep_epilogue<64, A, true>(a, (long long)row, true, out, kk, valid, lane, lane, 0, 2 * (int)(a.pair_ptr[row + 1] - a.pair_ptr[row]));
     }
 }
 
@@ -3151,6 +3242,15 @@ template <int A>
 static void launch_tiled(hipStream_t st, const EstepArgs &a)
 {
     const dim3 grid(blocks_for(a.n_bins, 4)), block(256);
+    if (a.fast && a.prob16 == nullptr && a.coarse_stream != nullptr) {  // the fine pass on the coarse pass's records (the tile-major stream was released)
+        if constexpr (A == 2)
+            hipLaunchKernelGGL(k_estep_tiled_fine8<1>, grid, block, 0, st, a);
+        else if (a.K > 32)
+            hipLaunchKernelGGL(k_estep_tiled_fine8<2>, grid, block, 0, st, a);
+        else
+            hipLaunchKernelGGL(k_estep_tiled_fine8<4>, grid, block, 0, st, a);
+        return;
+    }
     if constexpr (A == 1) {
         if (a.fast && a.prob16 != nullptr) {  // the coarse pass (guarded mode only: dmx_api.cpp: run_estep)
             if (a.K > 32)

@@ -213,15 +213,16 @@ int dmx_get_guard_stats(dmx_ctx *ctx, int64_t *redone_last, int64_t *redone_tota
  * dmx_get_logits / dmx_get_block(DMX_LOGITS) fail (DMX_ERR_INVALID) until an E-step has kept its logits again (dmx_estep, or a call
  * with needed = 1); posteriors, assignments and the reductions are available as ever.  Default 1. */
 int dmx_set_logits_needed(dmx_ctx *ctx, int needed);
-/* Memory before speed for the E-steps whose logits ARE kept (default 0).  A problem large enough for the tile-major E-step schedule holds its
- * E-step records three times: barcode-major (16 bytes per call), in the order the bins consume them for the fine pass (16) and as the
- * coarse pass's records (8), built from the second at the first E-step that may take the coarse pass.  With lean = 1 the second copy is
- * released as soon as the third exists (dmx_get_device_bytes: 67 -> 51 bytes per call at 200k x 100k x 64): the coarse pass is untouched, the
- * E-steps that keep their logits - the last one of a dmx_em call by default, dmx_estep - run the tolerance kernel on the barcode-major
- * records (1.5 instead of 1.3 ms at that size), the guard and its exact redo as ever; the dictionary form's row array (4 bytes per call) goes
- * with it: an E-step on the prior table that keeps its logits runs that kernel too.  Applies to the resident problem (at once if its coarse
- * records exist, else behind their build) and to those installed afterwards; lean = 0 keeps what is still there.  A communicator attached
- * AFTER the release re-bases the table rows and leaves such a problem without the tile-major schedule altogether (install it again). */
+/* Memory first (default 0).  A problem large enough for the tile-major E-step schedule holds its E-step records three times: barcode-major
+ * (16 bytes per call), in the order the bins consume them for the fine pass (16) and as the coarse pass's records (8), built from the second at
+ * the first E-step that may take the coarse pass.  With lean = 1 the second copy is released as soon as the third exists, and the dictionary
+ * form's row array (4 bytes per call) with it (dmx_get_device_bytes: 67 -> 46.7 bytes per call at 200k x 100k x 64).  The coarse pass is
+ * untouched; the E-steps that keep their logits - the last one of a dmx_em call by default, dmx_estep - run the fine pass on the COARSE pass's
+ * records (float32 table, float64 sums; the guard prices r = floor / keep and the slot tag in it: 7.8e-7 per call instead of 7e-8), in the time
+ * of the fine pass they replace (1.48 ms at that size), the guard and its exact redo as ever; an E-step on the prior table that keeps its
+ * logits runs that pass too instead of the dictionary form.  Applies to the resident problem (at once if its coarse records exist, else behind
+ * their build) and to those installed afterwards; lean = 0 keeps what is still there.  A communicator attached AFTER the release re-bases the
+ * table rows and leaves such a problem without the tile-major schedule altogether (install it again). */
 int dmx_set_lean_memory(dmx_ctx *ctx, int lean);
 /* Inside the guarded mode the library chooses per E-step, on the device, between the coarse pass (genotype table as binary16, for
  * E-steps whose logits nobody reads), the fine pass and the exact kernel on every barcode, and per M-step between the full and the

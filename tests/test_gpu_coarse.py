@@ -236,6 +236,50 @@ def test_coarse_pass_shapes_on_one_table(G):
     print(f'G={G}: {redone} of {p.n_barcodes} barcodes redone, posteriors within {dev:.3g}, logits at most {worst:.3f} of their bound')
 
 
+@pytest.mark.parametrize('G', [17, 32, 33, 64, 65, 100, 128])
+def test_fine_pass_on_the_coarse_records_shapes(G):
+    """dmx_set_lean_memory: once the tile-major stream is released the guard's fine level walks the coarse pass's 8-byte records with the
+    float32 table and float64 sums (k_estep_tiled_fine8), every shape of them: an E-step that keeps its logits against the exact mode -
+    every posterior within 1e-5, every arg-max identical, every logit within the bound the guard prices the pass with
+    (kernels.h: guard_per_call_fine8) plus the common term's (the sum of log2 keep: v_log_f32 results)."""
+    from demuxalot_amd import synth
+    from demuxalot_amd.device import DeviceContext
+    S = max(30_000, (9 << 20) // (8 * G) + 1000)
+    p = synth.generate(66_000, S, G, calls_per_barcode=240, seed=4300 + G)
+    pen = np.zeros(G, dtype=np.float32)
+    ctx = DeviceContext(0)
+    try:
+        ctx.set_estep_mode('exact')
+        ctx.set_problem(p.n_barcodes, p.n_variants, G, p.variant_id, p.compressed_cb, p.p_base_wrong, p.v2snp)
+        ctx.set_betas(p.prior_betas())
+        ctx.em(2, 0.01, pen, with_doublets=False, fetch_logits=False, fetch_probs=False, fetch_addition=False)
+        ctx.mstep(2., fetch=False)
+        ctx.probs_from_betas(0.01, fetch=False)
+        logits_e, probs_e = ctx.estep(pen, with_doublets=False)
+        ctx.set_estep_mode('guarded')
+        ctx.set_lean_memory(True)
+        ctx.set_coarse_pass('always')
+        held = ctx.device_bytes()
+        ctx.estep(pen, with_doublets=False, fetch_logits=False, fetch_probs=False)   # the coarse pass: its records are built, the stream goes
+        assert ctx.guard_levels()['level'] == 0 and ctx.device_bytes() < held + 9 * len(p.variant_id)   # (+ 8 bytes of records - 16 of stream - 4 of rows per call)
+        ctx.set_coarse_pass(True)
+        ctx.set_guard_adaptive(False)   # (the fast pass + redo whatever the device's timings say: the level under test)
+        logits_f, probs_f = ctx.estep(pen, with_doublets=False)
+        levels, redone = ctx.guard_levels(), ctx.guard_stats()[0]
+    finally:
+        ctx.close()
+    assert levels['level'] == 1 and levels['flagged_fine'] == redone, levels
+    dev = check_contract(probs_f, probs_e, f'fine pass on the coarse records, {G} genotypes')
+    n = 8 * ((np.bincount(p.compressed_cb, minlength=p.n_barcodes) + 7) // 8).astype(np.float64)[:, None]
+    mag = np.abs(logits_e.astype(np.float64))
+    cpg = 1 if G > 64 else 2 if G > 32 else 4
+    per_call = 1.91e-6 / (8 // cpg) + 4 * 6.0e-8 + 7.0e-8
+    bound = per_call * (n + 8) + 2.0e-7 * n + 3.0e-7 * (mag + 2.1e-4 * n) + 2.4e-7 * mag
+    worst = float((np.abs(logits_f.astype(np.float64) - logits_e) / bound).max())
+    assert worst <= 1.0, worst
+    print(f'G={G}: {redone} of {p.n_barcodes} barcodes redone, posteriors within {dev:.3g}, logits at most {worst:.3f} of their bound')
+
+
 def test_a_stale_time_of_a_pass_that_does_not_run_is_taken_again(separable):
     """The device times a pass only when it runs.  A coarse pass timed once at 10 ms (planted here; in the field: the first E-step on
     a device that had idled) loses against the fine pass - and would lose for ever, since it never runs again to be timed.  After 64
